@@ -1,0 +1,190 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ from the REFERENCE itself.
+
+Runnable only where /root/reference exists (the build container).  It imports
+the reference's pytorch_models / loss / utils unmodified, builds tiny models,
+applies utils.xavier_init exactly like main.py:375-377, and records
+
+  w/<name>            state_dict after xavier_init
+  b<k>/<slot>, y<k>   batches (the 7-slot list of data_fast.py:101-109)
+  eval<k>             model.eval() outputs
+  neg_*               a negatives-shaped [B, 6, ...] batch and its eval output
+  se<k>               train-mode (dropout=0) per-example squared error BEFORE step k+1
+  g0/<name>           gradients of mean(SE) on batch 0 at the initial weights
+  w1/.., w3/..        weights after 1 and 3 torch.optim.Adam steps (main.py:94-96)
+  m3/.., v3/..        Adam moments after 3 steps
+
+Only DATA is written (npz); no reference source travels.  Usage:
+    cd /tmp && python /root/repo/tests/golden/make_golden.py
+"""
+import os
+import pickle
+import sys
+import tempfile
+
+sys.dont_write_bytecode = True
+REF = '/root/reference'
+sys.path.insert(0, REF)
+
+import numpy as np
+import torch
+
+torch.set_num_threads(1)
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+
+def base_hp(model_type, **kw):
+    hp = {
+        'dataset': 'Tiny', 'k_core': 5, 'percent_reviews_to_keep': 100,
+        'weight_decay': 1e-6, 'lr': 0.002, 'epochs': 1, 'batch_size': 8,
+        'latent_size': 10, 'word_embed_size': 20, 'input_length': 37,
+        'dropout': 0.0, 'model_type': model_type,
+        'narre_num_reviews': 10, 'narre_num_words': 12,
+        'total_users': 30, 'total_items': 20,
+    }
+    hp.update(kw)
+    return hp
+
+
+def make_batch(rng, hp, B, V, negs=False):
+    mt = hp['model_type']
+    U, I = hp['total_users'], hp['total_items']
+    lead = (B, 6) if negs else (B,)
+    T = hp['input_length']
+    uid = rng.integers(0, U, size=lead)
+    iid = rng.integers(0, I, size=lead)
+    if B > 2 and not negs:                       # duplicate ids inside one batch
+        uid[1] = uid[0]
+        iid[2] = iid[0]
+    if mt == 'NARRE':
+        R, W = hp['narre_num_reviews'], hp['narre_num_words']
+        ur = rng.integers(0, V, size=lead + (R, W))
+        ir = rng.integers(0, V, size=lead + (R, W))
+        ur[..., -1, :] = 0                       # a padded (all-zero) review
+        ir[..., W // 2:] = np.where(rng.random(lead + (R, W - W // 2)) < 0.5, 0, ir[..., W // 2:])
+    else:
+        ur = rng.integers(0, V, size=lead + (T,))
+        ir = rng.integers(0, V, size=lead + (T,))
+        fill = rng.integers(1, T + 1, size=lead)
+        pos = np.arange(T)
+        ur = np.where(pos < fill[..., None], ur, 0)  # zero padded tails like data.py:198-199
+        if not negs:
+            ur[0] = 0                            # an all-padding document
+            ir[-1] = ir[0]                       # duplicate rows
+    this = rng.integers(0, V, size=lead + (T,))
+    who = rng.integers(0, U + 2, size=lead + (10,))   # includes the +1 sentinel (data.py:275)
+    rev = rng.integers(0, I + 2, size=lead + (10,))
+    y = rng.integers(1, 6, size=lead).astype(np.float32)
+    data = [this, who, rev, ur, ir, uid, iid]
+    return [np.ascontiguousarray(d.astype(np.int64)) for d in data], y
+
+
+def to_t(data, y):
+    return [torch.from_numpy(d) for d in data], torch.from_numpy(y)
+
+
+def build(hp, V, seed):
+    mt = hp['model_type']
+    tmp = tempfile.mkdtemp(prefix='r4r_golden_')
+    hp = dict(hp, data_dir=tmp + '/')
+    rng = np.random.default_rng(seed)
+    wv = rng.random((V, hp['word_embed_size'])).astype(np.float32).tolist()
+    with open(tmp + '/word2vec.pkl', 'wb') as f:
+        pickle.dump(wv, f, 2)
+    if mt in ('deepconn', 'deepconn++'):
+        from pytorch_models.DeepCoNN import DeepCoNN as Model
+    elif mt in ('transnet', 'transnet++'):
+        from pytorch_models.TransNet import TransNet as Model
+    elif mt == 'NARRE':
+        from pytorch_models.NARRE import NARRE as Model
+    else:
+        from pytorch_models.MF import MF as Model
+    from utils import xavier_init
+    torch.manual_seed(seed)
+    model = Model(hp)
+    xavier_init(model)                           # main.py:377
+    return model, hp
+
+
+def run_case(name, hp, V, B, seed, steps=3):
+    from loss import MSELoss
+    rng = np.random.default_rng(1000 + seed)
+    model, hp = build(hp, V, seed)
+    mt = hp['model_type']
+    is_tn = mt in ('transnet', 'transnet++')
+    out = {}
+    for k, v in model.state_dict().items():
+        out['w/' + k] = v.detach().numpy().copy()
+    batches = [make_batch(rng, hp, B, V), make_batch(rng, hp, max(1, B - 3), V)]  # ragged second batch
+    crit = MSELoss(hp)
+
+    model.eval()
+    with torch.no_grad():
+        for k, (d, y) in enumerate(batches):
+            for s, arr in enumerate(d):
+                out['b%d/%d' % (k, s)] = arr
+            out['y%d' % k] = y
+            o = model(to_t(d, y)[0])
+            if is_tn:
+                out['eval%d/src' % k] = o[0].numpy().copy()
+                out['eval%d/tgt' % k] = o[1].numpy().copy()
+                out['eval%d/transform' % k] = o[2].numpy().copy()
+            else:
+                out['eval%d' % k] = o.numpy().copy()
+        nd, ny = make_batch(rng, hp, 3, V, negs=True)
+        for s, arr in enumerate(nd):
+            out['neg/%d' % s] = arr
+        o = model(to_t(nd, ny)[0])
+        out['neg_eval'] = (o[0] if is_tn else o).numpy().copy()
+
+    if not is_tn:                                # TransNet's reference step crashes on torch>=1.5
+        model.train()
+        opt = torch.optim.Adam(model.parameters(), lr=hp['lr'], weight_decay=hp['weight_decay'])
+        for step in range(steps):
+            d, y = to_t(*batches[step % 2])
+            model.zero_grad()
+            opt.zero_grad()
+            o = model(d)
+            se = crit(o, y, return_mean=False)
+            out['se%d' % step] = se.detach().numpy().copy()
+            torch.mean(se).backward()
+            if step == 0:
+                for k, p in model.named_parameters():
+                    if p.grad is not None:
+                        out['g0/' + k] = p.grad.numpy().copy()
+            opt.step()
+            if step in (0, steps - 1):
+                for k, v in model.state_dict().items():
+                    out['w%d/%s' % (step + 1, k)] = v.detach().numpy().copy()
+        names = {id(p): k for k, p in model.named_parameters()}
+        for p, st in opt.state.items():
+            out['m%d/%s' % (steps, names[id(p)])] = st['exp_avg'].numpy().copy()
+            out['v%d/%s' % (steps, names[id(p)])] = st['exp_avg_sq'].numpy().copy()
+
+    keep = ('model_type', 'latent_size', 'word_embed_size', 'input_length', 'dropout', 'lr',
+            'weight_decay', 'total_users', 'total_items', 'narre_num_reviews', 'narre_num_words',
+            'batch_size')
+    out['hp_keys'] = np.array(keep)
+    out['hp_vals'] = np.array([str(hp[k]) for k in keep])
+    out['vocab'] = np.array(V)
+    path = os.path.join(OUT, name + '.npz')
+    np.savez_compressed(path, **out)
+    print('%-22s %7.1f KB  %d arrays' % (name, os.path.getsize(path) / 1024, len(out)))
+
+
+def main():
+    os.chdir(tempfile.mkdtemp(prefix='r4r_cwd_'))
+    run_case('mf_bias_only', base_hp('bias_only'), V=4, B=13, seed=1)
+    run_case('mf_dot', base_hp('MF_dot', latent_size=8), V=4, B=13, seed=2)
+    run_case('mf_full', base_hp('MF', latent_size=6), V=4, B=13, seed=3)
+    run_case('deepconn_e20', base_hp('deepconn'), V=120, B=5, seed=4)
+    run_case('deepconn_e64', base_hp('deepconn', word_embed_size=64, input_length=50, latent_size=7),
+             V=90, B=4, seed=5)
+    run_case('deepconnpp_e20', base_hp('deepconn++'), V=120, B=5, seed=6)
+    run_case('narre_e16', base_hp('NARRE', word_embed_size=16), V=80, B=4, seed=7)
+    run_case('transnet_e16', base_hp('transnet', word_embed_size=16, input_length=21), V=80, B=4, seed=8)
+    run_case('transnetpp_e16', base_hp('transnet++', word_embed_size=16, input_length=21), V=80, B=4, seed=9)
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,74 @@
+"""Shared test helpers: golden-fixture loading and synthetic batches."""
+import os
+
+import numpy as np
+import torch
+
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+
+GOLDEN_CASES = ['mf_bias_only', 'mf_dot', 'mf_full', 'deepconn_e20', 'deepconn_e64',
+                'deepconnpp_e20', 'narre_e16', 'transnet_e16', 'transnetpp_e16']
+TRAINABLE_CASES = [c for c in GOLDEN_CASES if not c.startswith('transnet')]
+
+_INT_KEYS = ('latent_size', 'word_embed_size', 'input_length', 'total_users', 'total_items',
+             'narre_num_reviews', 'narre_num_words', 'batch_size')
+_FLOAT_KEYS = ('dropout', 'lr', 'weight_decay')
+
+
+class Golden:
+    """One npz fixture written by tests/golden/make_golden.py."""
+
+    def __init__(self, name):
+        self.name = name
+        z = np.load(os.path.join(GOLDEN_DIR, name + '.npz'))
+        self.z = {k: z[k] for k in z.files}
+        hp = dict(zip(self.z['hp_keys'].tolist(), self.z['hp_vals'].tolist()))
+        for k in _INT_KEYS:
+            hp[k] = int(hp[k])
+        for k in _FLOAT_KEYS:
+            hp[k] = float(hp[k])
+        self.hp = hp
+        self.vocab = int(self.z['vocab'])
+
+    def group(self, prefix, device='cpu'):
+        pre = prefix + '/'
+        return {k[len(pre):]: torch.from_numpy(v.copy()).to(device)
+                for k, v in self.z.items() if k.startswith(pre)}
+
+    def params(self, tag='w', device='cpu'):
+        return self.group(tag, device)
+
+    def batch(self, k, device='cpu'):
+        d = self.group('b%d' % k, device)
+        data = [d[str(s)] for s in range(7)]
+        return data, torch.from_numpy(self.z['y%d' % k].copy()).to(device)
+
+    def neg_batch(self, device='cpu'):
+        d = self.group('neg', device)
+        return [d[str(s)] for s in range(7)]
+
+    def arr(self, key):
+        return torch.from_numpy(self.z[key].copy())
+
+    def has(self, key):
+        return key in self.z
+
+
+def synthetic_review_batch(B, T, V, U, I, seed=0, R=None, W=None, device='cpu'):
+    """Amazon-shaped random batch in the 7-slot layout of data_fast.py:101-109."""
+    rng = np.random.default_rng(seed)
+
+    def docs(shape):
+        tok = rng.integers(1, V, size=shape)
+        fill = rng.integers(1, shape[-1] + 1, size=shape[:-1])
+        return np.where(np.arange(shape[-1]) < fill[..., None], tok, 0)
+
+    if R is None:
+        ur, ir = docs((B, T)), docs((B, T))
+    else:
+        ur, ir = docs((B, R, W)), docs((B, R, W))
+    data = [docs((B, T)), rng.integers(0, U + 2, size=(B, 10)), rng.integers(0, I + 2, size=(B, 10)),
+            ur, ir, rng.integers(0, U, size=(B,)), rng.integers(0, I, size=(B,))]
+    y = rng.integers(1, 6, size=(B,)).astype(np.float32)
+    return [torch.from_numpy(np.ascontiguousarray(d.astype(np.int64))).to(device) for d in data], \
+        torch.from_numpy(y).to(device)
