@@ -1,0 +1,199 @@
+/* r4r.h -- C ABI of libr4r_hip.so, the MI355X (gfx950) rating-prediction hot path.
+ *
+ * The reference (noveens/reviews4rec) has no FFI: its hot path is the list of
+ * ATen ops that pytorch_models/{common_pytorch_models,MF,DeepCoNN,NARRE,TransNet}.py
+ * and torch.optim.Adam dispatch per training step.  Each entry point below
+ * replaces one of those call sites (cited as file:line under the reference
+ * root) and is what a binding written against the reference would bind.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer owned by the caller (torch owns all
+ *     memory); sizes are element counts unless a name ends in _bytes
+ *   - fp32 data, int64 indices (the reference's LongTensor batches,
+ *     data_fast.py:101-108), int32 argmax
+ *   - `stream` is a hipStream_t; nothing synchronises internally, nothing
+ *     allocates, every call is asynchronous and graph-capturable
+ *   - return 0 on success, <0 on error; r4r_last_error() describes the last
+ *     failure on the calling thread; nothing throws or aborts
+ *   - thread-compatible: no hidden global state besides the error string
+ */
+#ifndef R4R_H
+#define R4R_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define R4R_OK 0
+#define R4R_ERR_ARG (-1)      /* bad shape / null pointer / unsupported size */
+#define R4R_ERR_LAUNCH (-2)   /* HIP runtime refused the launch */
+#define R4R_ERR_WORKSPACE (-3)/* workspace too small */
+
+int r4r_version(void);
+const char *r4r_last_error(void);
+
+/* ------------------------------------------------------------------------
+ * TextCNN tower: word gather -> conv(3 x E, pad 2) -> relu -> global max-pool
+ * Replaces  nn.Embedding lookup      DeepCoNN.py:53-54, NARRE.py:95-96, TransNet.py:100-102
+ *           Conv2d + relu + max_pool common_pytorch_models.py:29-31
+ * The [N,T,E] gathered activations and the [N,F,T+2] conv output are never
+ * written to HBM.
+ *   table  [V, E]   frozen word vectors (E % 4 == 0)
+ *   idx    [N, T]   token ids in [0, V)
+ *   conv_w [F, 3, E] (= Conv2d weight [F,1,3,E]),  conv_b [F],  F <= 112
+ *   pooled [N, F]   max_p relu(conv)          argmax [N, F]  position p in [0,T+2) of the
+ *                                              max, or -1 where pooled == 0 (no gradient)
+ * ---------------------------------------------------------------------- */
+size_t r4r_textcnn_ws_bytes(int64_t N, int T, int E, int F);
+int r4r_textcnn_fwd(const float *table, int64_t V, const int64_t *idx,
+                    const float *conv_w, const float *conv_b,
+                    float *pooled, int32_t *argmax,
+                    void *ws, size_t ws_bytes,
+                    int64_t N, int T, int E, int F, void *stream);
+
+/* Backward of the tower w.r.t. conv weight and bias (the word table is frozen:
+ * Embedding.from_pretrained, DeepCoNN.py:15 -- no dgrad exists).
+ * Replaces  convolution_backward / max_pool2d_with_indices_backward /
+ *           threshold_backward behind common_pytorch_models.py:29-31.
+ * Only the argmax window of each (n, f) carries gradient:
+ *   d_conv_w[f, j, :] = sum_n g_pooled[n, f] * table[idx[n, argmax[n,f] - 2 + j], :]
+ *   d_conv_b[f]       = sum_n g_pooled[n, f]            (terms with argmax < 0 dropped)
+ * Outputs are overwritten, not accumulated. */
+int r4r_textcnn_wgrad(const float *table, int64_t V, const int64_t *idx,
+                      const float *g_pooled, const int32_t *argmax,
+                      float *d_conv_w, float *d_conv_b,
+                      void *ws, size_t ws_bytes,
+                      int64_t N, int T, int E, int F, void *stream);
+
+/* ------------------------------------------------------------------------
+ * Small dense layers (nn.Linear with in/out <= 256), optional fused ReLU.
+ * Replaces  TextCNN.fc                 common_pytorch_models.py:37
+ *           DeepCoNN.final             DeepCoNN.py:21-26,69
+ *           MF.projection              MF.py:26-31,62
+ *           NARRE.final                NARRE.py:38-43,123
+ *           Source.project             TransNet.py:17-21,33
+ *   x [N, n_in], w [n_out, n_in], b [n_out], y [N, n_out]
+ * bwd: g_x may be NULL; g_w / g_b are overwritten.  With relu != 0, `y` is the
+ * post-activation output saved by fwd. */
+int r4r_linear_fwd(const float *x, const float *w, const float *b, float *y,
+                   int64_t N, int n_in, int n_out, int relu, void *stream);
+int r4r_linear_bwd(const float *x, const float *w, const float *y, const float *g_y,
+                   float *g_x, float *g_w, float *g_b,
+                   int64_t N, int n_in, int n_out, int relu, void *stream);
+
+/* ------------------------------------------------------------------------
+ * Dropout (nn.Dropout in train mode).  Replaces common_pytorch_models.py:37,
+ * DeepCoNN.py:24, MF.py:52-53, NARRE.py:27,34,39,115-116, TransNet.py:34,58,108-109.
+ * mult[i] is 0 or 1/(1-p) drawn from Philox4x32-10(seed, offset + i/4); the
+ * multiplier tensor is kept for backward (g_x = g_y * mult) and so a test can
+ * inject the same mask into the CPU oracle.  The reference draws from torch's
+ * unseeded global RNG, so streams are not comparable. */
+int r4r_dropout_fwd(const float *x, float *y, float *mult, int64_t n, float p,
+                    uint64_t seed, uint64_t offset, void *stream);
+int r4r_mul(const float *a, const float *b, float *out, int64_t n, void *stream);
+int r4r_add(const float *a, const float *b, float *out, int64_t n, void *stream);
+
+/* ------------------------------------------------------------------------
+ * Factorisation machine head (no global bias).
+ * Replaces  TorchFM.forward            common_pytorch_models.py:49-57
+ *   out[b] = 0.5 * (sum_k (x V)_k^2 - sum_k (x^2 V^2)_k) + lin_w . x + lin_b
+ *   x [N, n], V [n, k], lin_w [n], lin_b [1], out [N]     (n <= 64, k <= 64)
+ * bwd overwrites g_x [N,n], g_V [n,k], g_lin_w [n], g_lin_b [1]. */
+int r4r_fm_fwd(const float *x, const float *V, const float *lin_w, const float *lin_b,
+               float *out, int64_t N, int n, int k, void *stream);
+int r4r_fm_bwd(const float *x, const float *V, const float *lin_w, const float *g_out,
+               float *g_x, float *g_V, float *g_lin_w, float *g_lin_b,
+               int64_t N, int n, int k, void *stream);
+
+/* ------------------------------------------------------------------------
+ * ID-embedding / bias-vector gathers and their dense gradients.
+ * Replaces  nn.Embedding(user/item)    MF.py:52-53, NARRE.py:110,112,115-116, TransNet.py:108-109
+ *           Parameter.gather           MF.py:45-46, DeepCoNN.py:70-71, NARRE.py:87-88
+ *           embedding_dense_backward / scatter_add behind them
+ *   table [R, D] (D = 1 for a bias vector), idx [n], out [n, D]
+ * scatter_add zero-fills g_table [R, D] and adds every g_out row into it (the
+ * reference's gradients for these tables are DENSE). */
+int r4r_embed_gather(const float *table, const int64_t *idx, float *out,
+                     int64_t R, int D, int64_t n, void *stream);
+int r4r_embed_scatter_add(const float *g_out, const int64_t *idx, float *g_table,
+                          int64_t R, int D, int64_t n, void *stream);
+
+/* ------------------------------------------------------------------------
+ * Rating head pieces.
+ * rowdot: out[b] = sum_d a[b,d] * c[b,d]          torch.sum(user*item,-1), MF.py:57
+ * bias_head: out[b] = (r ? r[b] : 0) + user_bias[uid[b]] + item_bias[iid[b]] + global_bias[0]
+ *           MF.py:45-49,58,68; DeepCoNN.py:70-72; NARRE.py:87-88,124
+ *           user_bias == NULL (then item_bias/uid/iid are ignored): out[b] = r[b] + global_bias[0],
+ *           the 'deepconn' head  self.global_bias + fm(cat)[:, 0]  (DeepCoNN.py:65)
+ * bias_head_bwd overwrites the DENSE g_user_bias [RU], g_item_bias [RI] (skipped when
+ * g_user_bias == NULL) and g_global [1]  (g_r == g_out, the caller aliases it). */
+int r4r_rowdot_fwd(const float *a, const float *c, float *out, int64_t N, int D, void *stream);
+int r4r_rowdot_bwd(const float *a, const float *c, const float *g_out, float *g_a, float *g_c,
+                   int64_t N, int D, void *stream);
+int r4r_bias_head_fwd(const float *r, const float *user_bias, const float *item_bias,
+                      const float *global_bias, const int64_t *uid, const int64_t *iid,
+                      float *out, int64_t N, void *stream);
+int r4r_bias_head_bwd(const float *g_out, const int64_t *uid, const int64_t *iid,
+                      float *g_user_bias, float *g_item_bias, float *g_global,
+                      int64_t RU, int64_t RI, int64_t N, void *stream);
+
+/* ------------------------------------------------------------------------
+ * NARRE review-level attention.  Replaces NARRE.attention, NARRE.py:53-64 with
+ * scorer = Linear(2L->L), ReLU, Dropout, Linear(L->1) (NARRE.py:24-36):
+ *   h      = relu(W0 [x ; other] + b0) * mult          (mult NULL in eval / p = 0)
+ *   a      = softmax_R(w3 . h + b3)                    (padded reviews NOT masked)
+ *   out[n] = sum_r a[n,r] * x[n,r,:]
+ *   x, other [N, R, L]; W0 [L, 2L]; b0 [L]; w3 [L]; b3 [1]; out [N, L]
+ * fwd saves h [N,R,L] (post relu, post dropout) and a [N,R] for backward.
+ * bwd overwrites g_x, g_other [N,R,L], g_W0, g_b0, g_w3, g_b3; ws holds the
+ * per-row scorer gradients it reduces over.   L <= 32, R <= 32. */
+size_t r4r_narre_attn_ws_bytes(int64_t N, int R, int L);
+int r4r_narre_attn_fwd(const float *x, const float *other, const float *W0, const float *b0,
+                       const float *w3, const float *b3, const float *mult,
+                       float *out, float *h_save, float *a_save,
+                       int64_t N, int R, int L, void *stream);
+int r4r_narre_attn_bwd(const float *x, const float *other, const float *W0, const float *w3,
+                       const float *mult, const float *h_save, const float *a_save,
+                       const float *g_out,
+                       float *g_x, float *g_other, float *g_W0, float *g_b0, float *g_w3, float *g_b3,
+                       void *ws, size_t ws_bytes,
+                       int64_t N, int R, int L, void *stream);
+
+/* ------------------------------------------------------------------------
+ * Per-example squared error + its gradient for mean(SE) over `denom` examples.
+ * Replaces  MSELoss.forward + torch.mean   loss.py:7-11, main.py:56-58
+ *   se[b] = (out[b]-y[b])^2 ; g_out[b] = 2 (out[b]-y[b]) / denom   (g_out may be NULL) */
+int r4r_mse_fwd_bwd(const float *out, const float *y, float *se, float *g_out,
+                    int64_t N, float denom, void *stream);
+
+/* TransNet transform loss  mean_n sum_l (a[n,l] - b[n,l])^2  (a = source.ir, b = target.ir).
+ * Replaces  torch.mean(torch.sum(torch.pow(.., 2), -1))   TransNet.py:121
+ *   a, b [N, L]; out [1]; bwd: g_out [1] -> g_a, g_b [N, L] */
+int r4r_sqdist_mean_fwd(const float *a, const float *b, float *out, int64_t N, int L, void *stream);
+int r4r_sqdist_mean_bwd(const float *a, const float *b, const float *g_out, float *g_a, float *g_b,
+                        int64_t N, int L, void *stream);
+
+/* ------------------------------------------------------------------------
+ * Dense fused Adam over many tensors in one launch.
+ * Replaces  torch.optim.Adam(lr, weight_decay).step()   main.py:94-96,60
+ * (defaults betas (0.9, 0.999), eps 1e-8, L2 decay added to the gradient,
+ * bias correction; every element of every listed tensor moves each step,
+ * SURVEY.md fact 4).
+ *   p/g/m/v : HOST arrays of `ntensor` DEVICE pointers, numel : HOST int64[ntensor] (the one
+ *   exception to "every pointer is a device pointer": the tensor list is passed by value in
+ *   the kernel arguments, 16 tensors per launch, so no descriptor table lives in HBM and no
+ *   H2D copy happens per step).  One workgroup per r4r_adam_chunk_elems()-element chunk.
+ *   g[i] == 0 means "gradient is zero" (weight decay still applies).
+ *   step = 1-based step count shared by all listed tensors. */
+int r4r_adam_chunk_elems(void);
+int r4r_adam_multi(int ntensor, const uint64_t *p, const uint64_t *g, const uint64_t *m, const uint64_t *v,
+                   const int64_t *numel, float lr, float beta1, float beta2, float eps,
+                   float weight_decay, int64_t step, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* R4R_H */

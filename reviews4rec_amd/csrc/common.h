@@ -1,0 +1,42 @@
+// Internal helpers shared by the gfx950 kernels of libr4r_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/r4r.h"
+
+namespace r4r {
+
+void set_error(const char *fmt, ...);
+
+inline int check_launch(const char *what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_error("%s: %s", what, hipGetErrorString(e));
+        return R4R_ERR_LAUNCH;
+    }
+    return R4R_OK;
+}
+
+#define R4R_REQUIRE(cond, ...)            \
+    do {                                  \
+        if (!(cond)) {                    \
+            r4r::set_error(__VA_ARGS__);  \
+            return R4R_ERR_ARG;           \
+        }                                 \
+    } while (0)
+
+inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
+
+constexpr int WAVE = 64;
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
+
+inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+}  // namespace r4r

@@ -1,0 +1,469 @@
+// Small fp32 ops of the rating heads for gfx950: tiny linear layers, dropout,
+// factorisation machine, ID-embedding gathers / dense scatter-add, dot + bias
+// heads, squared error.  All of them are launch-latency / HBM-bound, so the
+// rules that matter are coalescing and one pass over the data; none of this is
+// reshaped into MFMA work.
+//
+// Reference behaviour restated (file:line under the reference root) is cited
+// per entry point in include/r4r.h.
+#include "common.h"
+
+namespace r4r {
+
+// ------------------------------------------------------------------ linear
+// y[n][o] = act(b[o] + sum_i x[n][i] * w[o][i]);  one thread per output.
+__global__ void linear_fwd_kernel(const float *__restrict__ x, const float *__restrict__ w,
+                                  const float *__restrict__ b, float *__restrict__ y,
+                                  int64_t N, int n_in, int n_out, int relu) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N * n_out) return;
+    const int64_t n = i / n_out;
+    const int o = (int)(i - n * n_out);
+    const float *xr = x + n * n_in, *wr = w + (size_t)o * n_in;
+    float s = 0.f;
+    for (int k = 0; k < n_in; ++k) s = fmaf(xr[k], wr[k], s);
+    s += b[o];
+    y[i] = (relu && s < 0.f) ? 0.f : s;
+}
+
+// g_x[n][i] = sum_o geff[n][o] * w[o][i],  geff = relu ? g_y * (y > 0) : g_y
+__global__ void linear_bwd_x_kernel(const float *__restrict__ w, const float *__restrict__ y,
+                                    const float *__restrict__ gy, float *__restrict__ gx,
+                                    int64_t N, int n_in, int n_out, int relu) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N * n_in) return;
+    const int64_t n = i / n_in;
+    const int k = (int)(i - n * n_in);
+    float s = 0.f;
+    for (int o = 0; o < n_out; ++o) {
+        float g = gy[n * n_out + o];
+        if (relu && !(y[n * n_out + o] > 0.f)) g = 0.f;
+        s = fmaf(g, w[(size_t)o * n_in + k], s);
+    }
+    gx[i] = s;
+}
+
+// g_w[o][i] = sum_n geff[n][o] * x[n][i]; g_b[o] = sum_n geff[n][o].
+// One workgroup per output row o; thread k < n_in owns column k, thread n_in owns
+// the bias.  The document loop is strided over blockDim.y-style "lanes" of 4 row
+// groups and combined through LDS in a fixed order (deterministic).
+constexpr int LB_ROWS = 4;
+__global__ void linear_bwd_w_kernel(const float *__restrict__ x, const float *__restrict__ y,
+                                    const float *__restrict__ gy, float *__restrict__ gw,
+                                    float *__restrict__ gb, int64_t N, int n_in, int n_out, int relu) {
+    extern __shared__ float red[];   // [LB_ROWS][n_in + 1]
+    const int o = blockIdx.x;
+    const int k = threadIdx.x, rg = threadIdx.y;
+    float s = 0.f;
+    if (k <= n_in) {
+        for (int64_t n = rg; n < N; n += LB_ROWS) {
+            float g = gy[n * n_out + o];
+            if (relu && !(y[n * n_out + o] > 0.f)) g = 0.f;
+            s = (k < n_in) ? fmaf(g, x[n * n_in + k], s) : s + g;
+        }
+        red[rg * (n_in + 1) + k] = s;
+    }
+    __syncthreads();
+    if (rg == 0 && k <= n_in) {
+        float t = red[k];
+        for (int r = 1; r < LB_ROWS; ++r) t += red[r * (n_in + 1) + k];
+        if (k < n_in) gw[(size_t)o * n_in + k] = t;
+        else gb[o] = t;
+    }
+}
+
+// ----------------------------------------------------------------- dropout
+// Philox4x32-10, one 128-bit draw per 4 consecutive elements.
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                              uint32_t k0, uint32_t k1, uint32_t out[4]) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+        const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        const uint32_t n1 = (uint32_t)p1;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        const uint32_t n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+__global__ void dropout_fwd_kernel(const float *__restrict__ x, float *__restrict__ y,
+                                   float *__restrict__ mult, int64_t n, float p, float scale,
+                                   uint64_t seed, uint64_t offset) {
+    const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // group of 4 elements
+    const int64_t i0 = g * 4;
+    if (i0 >= n) return;
+    const uint64_t ctr = offset + (uint64_t)g;
+    uint32_t r[4];
+    philox4x32_10((uint32_t)ctr, (uint32_t)(ctr >> 32), 0u, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), r);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int64_t i = i0 + j;
+        if (i < n) {
+            const float u = (float)(r[j] >> 8) * (1.0f / 16777216.0f);   // [0, 1)
+            const float m = (u >= p) ? scale : 0.f;
+            mult[i] = m;
+            y[i] = x[i] * m;
+        }
+    }
+}
+
+__global__ void mul_kernel(const float *__restrict__ a, const float *__restrict__ b,
+                           float *__restrict__ out, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = a[i] * b[i];
+}
+
+__global__ void add_kernel(const float *__restrict__ a, const float *__restrict__ b,
+                           float *__restrict__ out, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = a[i] + b[i];
+}
+
+// ---------------------------------------------------------------------- FM
+// One wave per example: lane i < n holds x_i; s_k = sum_i x_i V_ik by a wave
+// reduction (K12 of the survey: "wavefront reductions for the FM second-order
+// term").  n, k <= 64.
+__global__ void fm_fwd_kernel(const float *__restrict__ x, const float *__restrict__ V,
+                              const float *__restrict__ lw, const float *__restrict__ lb,
+                              float *__restrict__ out, int64_t N, int n, int k) {
+    const int lane = threadIdx.x & 63;
+    const int64_t b = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (b >= N) return;
+    const float xi = (lane < n) ? x[b * n + lane] : 0.f;
+    float inter = 0.f;
+    for (int kk = 0; kk < k; ++kk) {
+        const float v = (lane < n) ? V[lane * k + kk] : 0.f;
+        const float s = wave_sum(xi * v);
+        const float s2 = wave_sum(xi * xi * v * v);
+        inter += s * s - s2;
+    }
+    const float lin = wave_sum((lane < n) ? xi * lw[lane] : 0.f);
+    if (lane == 0) out[b] = 0.5f * inter + lin + lb[0];
+}
+
+// g_x[b][i] = g_b * (sum_k (s_k V_ik - x_i V_ik^2) + w_i); also writes s[b][k] to ws.
+__global__ void fm_bwd_x_kernel(const float *__restrict__ x, const float *__restrict__ V,
+                                const float *__restrict__ lw, const float *__restrict__ gout,
+                                float *__restrict__ gx, int64_t N, int n, int k) {
+    const int lane = threadIdx.x & 63;
+    const int64_t b = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (b >= N) return;
+    const float xi = (lane < n) ? x[b * n + lane] : 0.f;
+    float acc = 0.f;
+    for (int kk = 0; kk < k; ++kk) {
+        const float v = (lane < n) ? V[lane * k + kk] : 0.f;
+        const float s = wave_sum(xi * v);
+        acc += s * v - xi * v * v;
+    }
+    if (lane < n) gx[b * n + lane] = gout[b] * (acc + lw[lane]);
+}
+
+// g_V[i][kk] = sum_b g_b (s_bk x_bi - x_bi^2 V_ik); g_lw[i] = sum_b g_b x_bi; g_lb = sum_b g_b.
+// One workgroup of 64 x 4 threads per (kk) column plus one for the linear part;
+// s_bk is recomputed per example by a wave reduction; rows of 4 example groups are
+// combined through LDS in a fixed order.
+__global__ void fm_bwd_p_kernel(const float *__restrict__ x, const float *__restrict__ V,
+                                const float *__restrict__ gout, float *__restrict__ gV,
+                                float *__restrict__ glw, float *__restrict__ glb,
+                                int64_t N, int n, int k) {
+    __shared__ float red[4][65];
+    const int lane = threadIdx.x, rg = threadIdx.y;   // blockDim = (64, 4)
+    const int kk = blockIdx.x;                        // kk == k -> linear part
+    float acc = 0.f, accb = 0.f;
+    const float v = (kk < k && lane < n) ? V[lane * k + kk] : 0.f;
+    for (int64_t b = rg; b < N; b += 4) {
+        const float xi = (lane < n) ? x[b * n + lane] : 0.f;
+        const float g = gout[b];
+        if (kk < k) {
+            const float s = wave_sum(xi * v);
+            acc += g * (s * xi - xi * xi * v);
+        } else {
+            acc += g * xi;
+            accb += g;
+        }
+    }
+    red[rg][lane] = acc;
+    if (lane == 0) red[rg][64] = accb;
+    __syncthreads();
+    if (rg == 0) {
+        const float t = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
+        if (kk < k) { if (lane < n) gV[lane * k + kk] = t; }
+        else {
+            if (lane < n) glw[lane] = t;
+            if (lane == 0) glb[0] = red[0][64] + red[1][64] + red[2][64] + red[3][64];
+        }
+    }
+}
+
+// ------------------------------------------------------------ embed gather
+__global__ void embed_gather_kernel(const float *__restrict__ table, const int64_t *__restrict__ idx,
+                                    float *__restrict__ out, int D, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n * D) return;
+    const int64_t r = i / D;
+    const int d = (int)(i - r * D);
+    out[i] = table[idx[r] * D + d];
+}
+
+__global__ void fill_zero_kernel(float *__restrict__ p, int64_t n) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) p[i] = 0.f;
+}
+
+__global__ void embed_scatter_add_kernel(const float *__restrict__ gout, const int64_t *__restrict__ idx,
+                                         float *__restrict__ gtable, int D, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n * D) return;
+    const int64_t r = i / D;
+    const int d = (int)(i - r * D);
+    atomicAdd(gtable + idx[r] * D + d, gout[i]);
+}
+
+// -------------------------------------------------------------- rating head
+__global__ void rowdot_fwd_kernel(const float *__restrict__ a, const float *__restrict__ c,
+                                  float *__restrict__ out, int64_t N, int D) {
+    const int lane = threadIdx.x & 63;
+    const int64_t b = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (b >= N) return;
+    float s = 0.f;
+    for (int d = lane; d < D; d += 64) s = fmaf(a[b * D + d], c[b * D + d], s);
+    s = wave_sum(s);
+    if (lane == 0) out[b] = s;
+}
+
+__global__ void rowdot_bwd_kernel(const float *__restrict__ a, const float *__restrict__ c,
+                                  const float *__restrict__ gout, float *__restrict__ ga,
+                                  float *__restrict__ gc, int64_t N, int D) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N * D) return;
+    const float g = gout[i / D];
+    ga[i] = g * c[i];
+    gc[i] = g * a[i];
+}
+
+__global__ void bias_head_fwd_kernel(const float *__restrict__ r, const float *__restrict__ ub,
+                                     const float *__restrict__ ib, const float *__restrict__ gb,
+                                     const int64_t *__restrict__ uid, const int64_t *__restrict__ iid,
+                                     float *__restrict__ out, int64_t N) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    // same association order as the reference: ((rating + user_bias) + item_bias) + global_bias;
+    // without ID biases (DeepCoNN 'deepconn' mode, DeepCoNN.py:65): rating + global_bias.
+    float s;
+    if (!ub) s = r[i];
+    else if (r) s = (r[i] + ub[uid[i]]) + ib[iid[i]];
+    else s = ub[uid[i]] + ib[iid[i]];
+    out[i] = s + gb[0];
+}
+
+// g_global = sum_b g_out[b], single workgroup, fixed order.
+__global__ void sum_kernel(const float *__restrict__ g, float *__restrict__ out, int64_t N) {
+    __shared__ float red[256];
+    float s = 0.f;
+    for (int64_t i = threadIdx.x; i < N; i += 256) s += g[i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = red[0];
+}
+
+__global__ void mse_kernel(const float *__restrict__ out, const float *__restrict__ y,
+                           float *__restrict__ se, float *__restrict__ gout, int64_t N, float inv_denom) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    const float d = out[i] - y[i];
+    se[i] = d * d;
+    if (gout) gout[i] = 2.f * d * inv_denom;
+}
+
+// out[0] = (1/N) sum_{n,l} (a-b)^2, single workgroup, fixed order.
+__global__ void sqdist_mean_fwd_kernel(const float *__restrict__ a, const float *__restrict__ b,
+                                       float *__restrict__ out, int64_t total, float inv_n) {
+    __shared__ float red[256];
+    float s = 0.f;
+    for (int64_t i = threadIdx.x; i < total; i += 256) { const float d = a[i] - b[i]; s = fmaf(d, d, s); }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = red[0] * inv_n;
+}
+
+__global__ void sqdist_mean_bwd_kernel(const float *__restrict__ a, const float *__restrict__ b,
+                                       const float *__restrict__ gout, float *__restrict__ ga,
+                                       float *__restrict__ gb, int64_t total, float inv_n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const float g = gout[0] * 2.f * inv_n * (a[i] - b[i]);
+    ga[i] = g;
+    gb[i] = -g;
+}
+
+static inline unsigned blocks_for(int64_t n, int per = 256) { return (unsigned)((n + per - 1) / per); }
+
+}  // namespace r4r
+
+using namespace r4r;
+
+extern "C" int r4r_linear_fwd(const float *x, const float *w, const float *b, float *y,
+                              int64_t N, int n_in, int n_out, int relu, void *stream) {
+    R4R_REQUIRE(x && w && b && y, "linear_fwd: null pointer");
+    R4R_REQUIRE(N >= 0 && n_in > 0 && n_out > 0, "linear_fwd: bad sizes");
+    if (N == 0) return R4R_OK;
+    linear_fwd_kernel<<<blocks_for(N * n_out), 256, 0, as_stream(stream)>>>(x, w, b, y, N, n_in, n_out, relu);
+    return check_launch("linear_fwd");
+}
+
+extern "C" int r4r_linear_bwd(const float *x, const float *w, const float *y, const float *g_y,
+                              float *g_x, float *g_w, float *g_b,
+                              int64_t N, int n_in, int n_out, int relu, void *stream) {
+    R4R_REQUIRE(x && w && g_y && g_w && g_b, "linear_bwd: null pointer");
+    R4R_REQUIRE(!relu || y, "linear_bwd: relu needs the saved output");
+    R4R_REQUIRE(N >= 0 && n_in > 0 && n_in <= 255 && n_out > 0, "linear_bwd: n_in %d out of range (1..255)", n_in);
+    hipStream_t st = as_stream(stream);
+    if (g_x && N > 0)
+        linear_bwd_x_kernel<<<blocks_for(N * n_in), 256, 0, st>>>(w, y, g_y, g_x, N, n_in, n_out, relu);
+    const int tx = ((n_in + 1 + 63) / 64) * 64;
+    linear_bwd_w_kernel<<<n_out, dim3(tx, LB_ROWS), LB_ROWS * (n_in + 1) * sizeof(float), st>>>(
+        x, y, g_y, g_w, g_b, N, n_in, n_out, relu);
+    return check_launch("linear_bwd");
+}
+
+extern "C" int r4r_dropout_fwd(const float *x, float *y, float *mult, int64_t n, float p,
+                               uint64_t seed, uint64_t offset, void *stream) {
+    R4R_REQUIRE(x && y && mult, "dropout_fwd: null pointer");
+    R4R_REQUIRE(p >= 0.f && p < 1.f, "dropout_fwd: p=%f outside [0,1)", (double)p);
+    if (n <= 0) return R4R_OK;
+    dropout_fwd_kernel<<<blocks_for((n + 3) / 4), 256, 0, as_stream(stream)>>>(x, y, mult, n, p, 1.f / (1.f - p),
+                                                                               seed, offset);
+    return check_launch("dropout_fwd");
+}
+
+extern "C" int r4r_mul(const float *a, const float *b, float *out, int64_t n, void *stream) {
+    R4R_REQUIRE(a && b && out, "mul: null pointer");
+    if (n <= 0) return R4R_OK;
+    mul_kernel<<<blocks_for(n), 256, 0, as_stream(stream)>>>(a, b, out, n);
+    return check_launch("mul");
+}
+
+extern "C" int r4r_add(const float *a, const float *b, float *out, int64_t n, void *stream) {
+    R4R_REQUIRE(a && b && out, "add: null pointer");
+    if (n <= 0) return R4R_OK;
+    add_kernel<<<blocks_for(n), 256, 0, as_stream(stream)>>>(a, b, out, n);
+    return check_launch("add");
+}
+
+extern "C" int r4r_fm_fwd(const float *x, const float *V, const float *lin_w, const float *lin_b,
+                          float *out, int64_t N, int n, int k, void *stream) {
+    R4R_REQUIRE(x && V && lin_w && lin_b && out, "fm_fwd: null pointer");
+    R4R_REQUIRE(n > 0 && n <= 64 && k > 0 && k <= 64, "fm_fwd: n=%d k=%d outside 1..64", n, k);
+    if (N <= 0) return R4R_OK;
+    fm_fwd_kernel<<<blocks_for(N * 64), 256, 0, as_stream(stream)>>>(x, V, lin_w, lin_b, out, N, n, k);
+    return check_launch("fm_fwd");
+}
+
+extern "C" int r4r_fm_bwd(const float *x, const float *V, const float *lin_w, const float *g_out,
+                          float *g_x, float *g_V, float *g_lin_w, float *g_lin_b,
+                          int64_t N, int n, int k, void *stream) {
+    R4R_REQUIRE(x && V && lin_w && g_out && g_x && g_V && g_lin_w && g_lin_b, "fm_bwd: null pointer");
+    R4R_REQUIRE(n > 0 && n <= 64 && k > 0 && k <= 64, "fm_bwd: n=%d k=%d outside 1..64", n, k);
+    hipStream_t st = as_stream(stream);
+    if (N > 0) fm_bwd_x_kernel<<<blocks_for(N * 64), 256, 0, st>>>(x, V, lin_w, g_out, g_x, N, n, k);
+    fm_bwd_p_kernel<<<k + 1, dim3(64, 4), 0, st>>>(x, V, g_out, g_V, g_lin_w, g_lin_b, N, n, k);
+    return check_launch("fm_bwd");
+}
+
+extern "C" int r4r_embed_gather(const float *table, const int64_t *idx, float *out,
+                                int64_t R, int D, int64_t n, void *stream) {
+    R4R_REQUIRE(table && idx && out, "embed_gather: null pointer");
+    R4R_REQUIRE(R > 0 && D > 0, "embed_gather: bad sizes");
+    if (n <= 0) return R4R_OK;
+    embed_gather_kernel<<<blocks_for(n * D), 256, 0, as_stream(stream)>>>(table, idx, out, D, n);
+    return check_launch("embed_gather");
+}
+
+extern "C" int r4r_embed_scatter_add(const float *g_out, const int64_t *idx, float *g_table,
+                                     int64_t R, int D, int64_t n, void *stream) {
+    R4R_REQUIRE(g_out && idx && g_table, "embed_scatter_add: null pointer");
+    R4R_REQUIRE(R > 0 && D > 0, "embed_scatter_add: bad sizes");
+    hipStream_t st = as_stream(stream);
+    const int64_t tot = R * D;
+    unsigned zb = blocks_for(tot);
+    if (zb > 4096) zb = 4096;
+    fill_zero_kernel<<<zb, 256, 0, st>>>(g_table, tot);
+    if (n > 0) embed_scatter_add_kernel<<<blocks_for(n * D), 256, 0, st>>>(g_out, idx, g_table, D, n);
+    return check_launch("embed_scatter_add");
+}
+
+extern "C" int r4r_rowdot_fwd(const float *a, const float *c, float *out, int64_t N, int D, void *stream) {
+    R4R_REQUIRE(a && c && out && D > 0, "rowdot_fwd: bad arguments");
+    if (N <= 0) return R4R_OK;
+    rowdot_fwd_kernel<<<blocks_for(N * 64), 256, 0, as_stream(stream)>>>(a, c, out, N, D);
+    return check_launch("rowdot_fwd");
+}
+
+extern "C" int r4r_rowdot_bwd(const float *a, const float *c, const float *g_out, float *g_a, float *g_c,
+                              int64_t N, int D, void *stream) {
+    R4R_REQUIRE(a && c && g_out && g_a && g_c && D > 0, "rowdot_bwd: bad arguments");
+    if (N <= 0) return R4R_OK;
+    rowdot_bwd_kernel<<<blocks_for(N * D), 256, 0, as_stream(stream)>>>(a, c, g_out, g_a, g_c, N, D);
+    return check_launch("rowdot_bwd");
+}
+
+extern "C" int r4r_bias_head_fwd(const float *r, const float *user_bias, const float *item_bias,
+                                 const float *global_bias, const int64_t *uid, const int64_t *iid,
+                                 float *out, int64_t N, void *stream) {
+    R4R_REQUIRE(global_bias && out, "bias_head_fwd: null pointer");
+    R4R_REQUIRE(user_bias ? (item_bias && uid && iid) : (r != nullptr),
+                "bias_head_fwd: need (user_bias, item_bias, uid, iid) or, without ID biases, r");
+    if (N <= 0) return R4R_OK;
+    bias_head_fwd_kernel<<<blocks_for(N), 256, 0, as_stream(stream)>>>(r, user_bias, item_bias, global_bias,
+                                                                      uid, iid, out, N);
+    return check_launch("bias_head_fwd");
+}
+
+extern "C" int r4r_bias_head_bwd(const float *g_out, const int64_t *uid, const int64_t *iid,
+                                 float *g_user_bias, float *g_item_bias, float *g_global,
+                                 int64_t RU, int64_t RI, int64_t N, void *stream) {
+    R4R_REQUIRE(g_out && g_global, "bias_head_bwd: null pointer");
+    hipStream_t st = as_stream(stream);
+    if (g_user_bias) {
+        R4R_REQUIRE(uid && iid && g_item_bias, "bias_head_bwd: null pointer");
+        if (int rc = r4r_embed_scatter_add(g_out, uid, g_user_bias, RU, 1, N, stream)) return rc;
+        if (int rc = r4r_embed_scatter_add(g_out, iid, g_item_bias, RI, 1, N, stream)) return rc;
+    }
+    sum_kernel<<<1, 256, 0, st>>>(g_out, g_global, N);
+    return check_launch("bias_head_bwd");
+}
+
+extern "C" int r4r_mse_fwd_bwd(const float *out, const float *y, float *se, float *g_out,
+                               int64_t N, float denom, void *stream) {
+    R4R_REQUIRE(out && y && se, "mse_fwd_bwd: null pointer");
+    R4R_REQUIRE(denom > 0.f, "mse_fwd_bwd: denom must be positive");
+    if (N <= 0) return R4R_OK;
+    mse_kernel<<<blocks_for(N), 256, 0, as_stream(stream)>>>(out, y, se, g_out, N, 1.f / denom);
+    return check_launch("mse_fwd_bwd");
+}
+
+extern "C" int r4r_sqdist_mean_fwd(const float *a, const float *b, float *out, int64_t N, int L, void *stream) {
+    R4R_REQUIRE(a && b && out && N > 0 && L > 0, "sqdist_mean_fwd: bad arguments");
+    sqdist_mean_fwd_kernel<<<1, 256, 0, as_stream(stream)>>>(a, b, out, N * L, 1.f / (float)N);
+    return check_launch("sqdist_mean_fwd");
+}
+
+extern "C" int r4r_sqdist_mean_bwd(const float *a, const float *b, const float *g_out, float *g_a, float *g_b,
+                                   int64_t N, int L, void *stream) {
+    R4R_REQUIRE(a && b && g_out && g_a && g_b && N > 0 && L > 0, "sqdist_mean_bwd: bad arguments");
+    sqdist_mean_bwd_kernel<<<blocks_for(N * L), 256, 0, as_stream(stream)>>>(a, b, g_out, g_a, g_b, N * L,
+                                                                            1.f / (float)N);
+    return check_launch("sqdist_mean_bwd");
+}

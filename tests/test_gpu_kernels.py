@@ -1,0 +1,314 @@
+"""Kernel-level parity: every C-ABI entry point vs the CPU oracle / a plain fp32
+restatement on the same seeded inputs.  Runs on a real MI355X only (-m gpu)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import oracle
+from oracle.models import textcnn_forward
+
+pytestmark = pytest.mark.gpu
+
+DEV = 'cuda'
+
+
+def _ops():
+    from reviews4rec_amd import ops
+    return ops
+
+
+def conv_pool_reference(idx, table, w, b):
+    """Plain ATen restatement of gather -> conv -> relu -> max-pool, with indices."""
+    x = F.embedding(idx, table).unsqueeze(1)
+    y = F.relu(F.conv2d(x, w, b, padding=(2, 0))).squeeze(-1)          # [N, F, P]
+    pooled, arg = F.max_pool1d(y, y.size(2), return_indices=True)
+    return pooled.squeeze(-1), arg.squeeze(-1), y
+
+
+TOWER_SHAPES = [
+    # N, T, E, V
+    (3, 37, 20, 50),       # E not a multiple of 16 (k padding), single tile
+    (2, 300, 64, 200),     # several tiles, default embed size
+    (5, 1, 4, 7),          # minimum document: P = 3
+    (2, 126, 300, 90),     # P == 128 exactly one full tile, E = 300 (10 chunks, ragged last)
+    (2, 127, 32, 90),      # P == 129: second tile holds one position
+    (1, 1000, 300, 500),   # the BASELINE document shape
+    (4, 100, 16, 60),      # NARRE review shape
+]
+
+
+@pytest.mark.parametrize('N,T,E,V', TOWER_SHAPES)
+def test_textcnn_forward_matches_aten(N, T, E, V):
+    ops = _ops()
+    g = torch.Generator().manual_seed(N * 1000 + T)
+    table = (torch.rand((V, E), generator=g) - 0.5) * 0.2
+    w = (torch.rand((100, 1, 3, E), generator=g) - 0.5) * (2 * math.sqrt(6.0 / (3 * E + 300 * E)))
+    b = (torch.rand(100, generator=g) - 0.5) * 0.1
+    idx = torch.randint(0, V, (N, T), generator=g)
+    idx[0, T // 2:] = 0                                     # zero-padded tail
+    ref_pooled, ref_arg, y = conv_pool_reference(idx, table, w, b)
+    pooled, arg = ops.textcnn_fwd_raw(idx.to(DEV), table.to(DEV), w.to(DEV), b.to(DEV))
+    pooled, arg = pooled.cpu(), arg.cpu().long()
+    torch.testing.assert_close(pooled, ref_pooled, rtol=1e-5, atol=1e-6)
+    # argmax: -1 exactly where the pooled value is 0; otherwise it must point at a position
+    # whose conv output equals the max (ties between distinct windows are measure-zero)
+    assert ((arg < 0) == (ref_pooled <= 0)).all()
+    pos = arg >= 0
+    picked = torch.gather(y, 2, arg.clamp(min=0).unsqueeze(-1)).squeeze(-1)
+    torch.testing.assert_close(picked[pos], ref_pooled[pos], rtol=1e-5, atol=1e-6)
+    assert (arg[pos] == ref_arg[pos]).float().mean() > 0.999
+
+
+def test_textcnn_all_negative_gives_zero_and_no_gradient():
+    ops = _ops()
+    V, E, T = 10, 8, 20
+    table = torch.rand((V, E)) * 0.1
+    w = -torch.rand((100, 1, 3, E))                         # every window negative
+    b = -torch.ones(100)
+    idx = torch.randint(0, V, (2, T))
+    pooled, arg = ops.textcnn_fwd_raw(idx.to(DEV), table.to(DEV), w.to(DEV), b.to(DEV))
+    assert (pooled == 0).all() and (arg == -1).all()
+    d_w, d_b = ops.textcnn_wgrad_raw(idx.to(DEV), table.to(DEV), torch.ones((2, 100), device=DEV), arg, w.shape)
+    assert (d_w == 0).all() and (d_b == 0).all()
+
+
+def test_textcnn_first_index_on_ties():
+    """Constant document: every interior window has the same value -> lowest index wins
+    (PyTorch's max_pool picks the first maximum)."""
+    ops = _ops()
+    V, E, T = 4, 8, 300
+    table = torch.rand((V, E)) + 0.5
+    w = torch.rand((100, 1, 3, E)) * 0.1
+    b = torch.zeros(100)
+    idx = torch.full((1, T), 2, dtype=torch.int64)
+    ref_pooled, ref_arg, _ = conv_pool_reference(idx, table, w, b)
+    pooled, arg = ops.textcnn_fwd_raw(idx.to(DEV), table.to(DEV), w.to(DEV), b.to(DEV))
+    torch.testing.assert_close(pooled.cpu(), ref_pooled, rtol=1e-5, atol=1e-6)
+    assert (arg.cpu() == 2).all()                           # first full window is at p = 2
+
+
+@pytest.mark.parametrize('N,T,E,V', TOWER_SHAPES[:5] + [(17, 60, 64, 40)])
+def test_textcnn_wgrad_matches_autograd(N, T, E, V):
+    ops = _ops()
+    g = torch.Generator().manual_seed(7 + N + T)
+    table = (torch.rand((V, E), generator=g) - 0.5) * 0.2
+    w = ((torch.rand((100, 1, 3, E), generator=g) - 0.5) * 0.2).requires_grad_(True)
+    b = ((torch.rand(100, generator=g) - 0.5) * 0.1).requires_grad_(True)
+    idx = torch.randint(0, V, (N, T), generator=g)
+    gp = torch.randn((N, 100), generator=g)
+    ref_pooled, _, _ = conv_pool_reference(idx, table, w, b)
+    ref_pooled.backward(gp)
+    pooled, arg = ops.textcnn_fwd_raw(idx.to(DEV), table.to(DEV), w.detach().to(DEV), b.detach().to(DEV))
+    d_w, d_b = ops.textcnn_wgrad_raw(idx.to(DEV), table.to(DEV), gp.to(DEV), arg, w.shape)
+    torch.testing.assert_close(d_w.cpu(), w.grad, rtol=1e-4, atol=1e-6)
+    torch.testing.assert_close(d_b.cpu(), b.grad, rtol=1e-4, atol=1e-6)
+
+
+def test_textcnn_rejects_bad_arguments():
+    ops = _ops()
+    table = torch.rand((5, 6), device=DEV)                  # E = 6 is not a multiple of 4
+    idx = torch.zeros((1, 4), dtype=torch.int64, device=DEV)
+    with pytest.raises(RuntimeError, match='multiple of 4'):
+        ops.textcnn_fwd_raw(idx, table, torch.rand((100, 1, 3, 6), device=DEV), torch.rand(100, device=DEV))
+    with pytest.raises(RuntimeError, match='ROCm device'):
+        ops.textcnn_fwd_raw(idx.cpu(), table, torch.rand((100, 1, 3, 6), device=DEV), torch.rand(100, device=DEV))
+
+
+@pytest.mark.parametrize('N,n_in,n_out,relu', [(7, 100, 10, False), (33, 20, 10, True), (1, 10, 1, False),
+                                                (1280, 100, 10, False), (5, 255, 3, True)])
+def test_linear_fwd_bwd(N, n_in, n_out, relu):
+    ops = _ops()
+    g = torch.Generator().manual_seed(N + n_in)
+    x = torch.randn((N, n_in), generator=g).requires_grad_(True)
+    w = (torch.randn((n_out, n_in), generator=g) * 0.1).requires_grad_(True)
+    b = torch.randn(n_out, generator=g).requires_grad_(True)
+    gy = torch.randn((N, n_out), generator=g)
+    ref = F.linear(x, w, b)
+    if relu:
+        ref = F.relu(ref)
+    ref.backward(gy)
+    xd, wd, bd = (t.detach().to(DEV).requires_grad_(True) for t in (x, w, b))
+    y = ops.linear(xd, wd, bd, relu)
+    y.backward(gy.to(DEV))
+    torch.testing.assert_close(y.detach().cpu(), ref.detach(), rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(xd.grad.cpu(), x.grad, rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(wd.grad.cpu(), w.grad, rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(bd.grad.cpu(), b.grad, rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize('N,n,k', [(9, 20, 8), (128, 10, 8), (3, 64, 64), (1, 12, 6)])
+def test_fm_fwd_bwd(N, n, k):
+    ops = _ops()
+    g = torch.Generator().manual_seed(N + n + k)
+    P = {'fm.V': (torch.randn((n, k), generator=g) * 0.3).requires_grad_(True),
+         'fm.lin.weight': (torch.randn((1, n), generator=g) * 0.3).requires_grad_(True),
+         'fm.lin.bias': torch.randn(1, generator=g).requires_grad_(True)}
+    x = torch.randn((N, n), generator=g).requires_grad_(True)
+    go = torch.randn(N, generator=g)
+    ref = oracle.fm_forward(P, 'fm', x)
+    ref.backward(go)
+    xd = x.detach().to(DEV).requires_grad_(True)
+    Pd = {k2: v.detach().to(DEV).requires_grad_(True) for k2, v in P.items()}
+    out = ops.fm(xd, Pd['fm.V'], Pd['fm.lin.weight'], Pd['fm.lin.bias'])
+    out.backward(go.to(DEV))
+    torch.testing.assert_close(out.detach().cpu(), ref.detach(), rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(xd.grad.cpu(), x.grad, rtol=1e-4, atol=1e-5)
+    for k2 in P:
+        torch.testing.assert_close(Pd[k2].grad.cpu(), P[k2].grad, rtol=1e-4, atol=1e-4, msg=lambda m: k2 + ': ' + m)
+
+
+def test_embed_gather_and_dense_scatter_with_duplicates():
+    ops = _ops()
+    R, D = 50, 12
+    table = torch.randn((R, D)).requires_grad_(True)
+    idx = torch.tensor([[3, 3, 7], [49, 0, 3]])
+    g = torch.randn((2, 3, D))
+    ref = F.embedding(idx, table)
+    ref.backward(g)
+    td = table.detach().to(DEV).requires_grad_(True)
+    out = ops.embed(td, idx.to(DEV))
+    out.backward(g.to(DEV))
+    assert torch.equal(out.detach().cpu(), ref.detach())
+    torch.testing.assert_close(td.grad.cpu(), table.grad, rtol=1e-6, atol=1e-6)
+    assert (td.grad.cpu()[[1, 2, 4]] == 0).all()            # untouched rows: exact zeros (dense grad)
+
+
+def test_rowdot_and_bias_head():
+    ops = _ops()
+    N, D, U, I = 37, 64, 20, 11
+    g = torch.Generator().manual_seed(5)
+    a = torch.randn((N, D), generator=g).requires_grad_(True)
+    c = torch.randn((N, D), generator=g).requires_grad_(True)
+    ub = torch.randn(U, generator=g).requires_grad_(True)
+    ib = torch.randn(I, generator=g).requires_grad_(True)
+    gb = torch.randn(1, generator=g).requires_grad_(True)
+    uid = torch.randint(0, U, (N,), generator=g)
+    iid = torch.randint(0, I, (N,), generator=g)
+    go = torch.randn(N, generator=g)
+    ref = (a * c).sum(-1) + ub[uid] + ib[iid] + gb
+    ref.backward(go)
+    ad, cd, ubd, ibd, gbd = (t.detach().to(DEV).requires_grad_(True) for t in (a, c, ub, ib, gb))
+    out = ops.bias_head(ops.rowdot(ad, cd), ubd, ibd, gbd, uid.to(DEV), iid.to(DEV))
+    out.backward(go.to(DEV))
+    torch.testing.assert_close(out.detach().cpu(), ref.detach(), rtol=1e-5, atol=1e-5)
+    for mine, theirs in ((ad, a), (cd, c), (ubd, ub), (ibd, ib), (gbd, gb)):
+        torch.testing.assert_close(mine.grad.cpu(), theirs.grad, rtol=1e-5, atol=1e-5)
+    # no-ID-bias form (DeepCoNN 'deepconn' head)
+    r = torch.randn(N, device=DEV, requires_grad=True)
+    out2 = ops.bias_head(r, None, None, gbd, None, None)
+    torch.testing.assert_close(out2.detach().cpu(), r.detach().cpu() + gb.detach(), rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize('N,R,L', [(4, 10, 10), (1, 3, 5), (65, 10, 10), (3, 32, 32)])
+def test_narre_attention_fwd_bwd(N, R, L):
+    ops = _ops()
+    from oracle.models import _narre_attention
+    g = torch.Generator().manual_seed(N + R)
+    P = {'s.0.weight': (torch.randn((L, 2 * L), generator=g) * 0.4).requires_grad_(True),
+         's.0.bias': (torch.randn(L, generator=g) * 0.1).requires_grad_(True),
+         's.3.weight': (torch.randn((1, L), generator=g) * 0.4).requires_grad_(True),
+         's.3.bias': torch.randn(1, generator=g).requires_grad_(True)}
+    x = torch.randn((N, R, L), generator=g).requires_grad_(True)
+    o = torch.randn((N, R, L), generator=g).requires_grad_(True)
+    go = torch.randn((N, L), generator=g)
+    ref = _narre_attention(P, 's', x, o, 0.0, False, None)
+    ref.backward(go)
+    xd, od = (t.detach().to(DEV).requires_grad_(True) for t in (x, o))
+    Pd = {k: v.detach().to(DEV).requires_grad_(True) for k, v in P.items()}
+    out = ops.narre_attention(xd, od, Pd['s.0.weight'], Pd['s.0.bias'], Pd['s.3.weight'], Pd['s.3.bias'])
+    out.backward(go.to(DEV))
+    torch.testing.assert_close(out.detach().cpu(), ref.detach(), rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(xd.grad.cpu(), x.grad, rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(od.grad.cpu(), o.grad, rtol=1e-4, atol=1e-5)
+    for k in ('s.0.weight', 's.0.bias', 's.3.weight'):
+        torch.testing.assert_close(Pd[k].grad.cpu(), P[k].grad, rtol=1e-4, atol=1e-4, msg=lambda m: k + ': ' + m)
+    assert Pd['s.3.bias'].grad.abs().max() < 1e-5           # softmax shift invariance: true gradient is 0
+
+
+def test_dropout_kernel_statistics_and_backward():
+    ops = _ops()
+    ops.DropoutState.manual_seed(123)
+    x = torch.ones((1000, 257), device=DEV, requires_grad=True)
+    ops.DropoutState.record = {}
+    y = ops.dropout(x, 0.6, True, 'site')
+    mult = ops.DropoutState.record['site']
+    ops.DropoutState.record = None
+    vals = torch.unique(mult.cpu())
+    assert set(np.round(vals.numpy(), 5).tolist()) == {0.0, 2.5}
+    keep = (mult > 0).float().mean().item()
+    assert abs(keep - 0.4) < 0.005
+    assert torch.equal(y.detach(), x.detach() * mult)
+    y.sum().backward()
+    assert torch.equal(x.grad, mult)
+    # a different offset gives a different mask; the same (seed, offset) reproduces it
+    ops.DropoutState.manual_seed(123)
+    ops.DropoutState.record = {}
+    ops.dropout(x.detach(), 0.6, True, 'site')
+    again = ops.DropoutState.record['site']
+    ops.dropout(x.detach(), 0.6, True, 'site')
+    other = ops.DropoutState.record['site']
+    ops.DropoutState.record = None
+    assert torch.equal(again, mult) and not torch.equal(other, mult)
+    assert ops.dropout(x, 0.6, False) is x and ops.dropout(x, 0.0, True) is x
+
+
+def test_mse_and_transform_loss():
+    ops = _ops()
+    out, y = torch.randn(77), torch.randn(77)
+    se, g = ops.mse_fwd_bwd(out.to(DEV), y.to(DEV), denom=77)
+    torch.testing.assert_close(se.cpu(), (out - y) ** 2, rtol=1e-6, atol=1e-6)
+    torch.testing.assert_close(g.cpu(), 2 * (out - y) / 77, rtol=1e-6, atol=1e-7)
+    a = torch.randn((9, 10)).requires_grad_(True)
+    b = torch.randn((9, 10)).requires_grad_(True)
+    ref = (a - b).pow(2).sum(-1).mean()
+    ref.backward()
+    ad, bd = (t.detach().to(DEV).requires_grad_(True) for t in (a, b))
+    t = ops.transform_loss(ad, bd)
+    t.backward()
+    torch.testing.assert_close(t.detach().cpu(), ref.detach(), rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(ad.grad.cpu(), a.grad, rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(bd.grad.cpu(), b.grad, rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize('sizes', [[1], [7, 8193, 3], [16384, 5, 100000], list(range(1, 20))])
+def test_fused_adam_matches_oracle(sizes):
+    from reviews4rec_amd.optim import Adam
+    g = torch.Generator().manual_seed(sum(sizes))
+    P = {str(i): torch.randn(n, generator=g) for i, n in enumerate(sizes)}
+    dev = [torch.nn.Parameter(v.clone().to(DEV)) for v in P.values()]
+    opt = Adam(dev, lr=0.002, weight_decay=1e-6)
+    state = oracle.AdamState()
+    for step in range(3):
+        grads = {k: torch.randn(v.shape, generator=g) for k, v in P.items()}
+        if step == 1:
+            grads['0'] = None                               # a skipped parameter keeps its own step count
+        oracle.adam_step(P, grads, state, 0.002, 1e-6)
+        for p, gr in zip(dev, grads.values()):
+            p.grad = None if gr is None else gr.to(DEV)
+        opt.step()
+    for p, ref in zip(dev, P.values()):
+        torch.testing.assert_close(p.detach().cpu(), ref, rtol=1e-5, atol=1e-6)
+    for i, p in enumerate(dev):
+        torch.testing.assert_close(opt.state[id(p)]['exp_avg'].cpu(), state.m[str(i)], rtol=1e-5, atol=1e-7)
+        torch.testing.assert_close(opt.state[id(p)]['exp_avg_sq'].cpu(), state.v[str(i)], rtol=1e-5, atol=1e-9)
+
+
+def test_fused_adam_unaligned_views_and_untouched_rows():
+    """Weight decay moves rows that received a zero gradient."""
+    from reviews4rec_amd.optim import Adam
+    base = torch.randn(1000 + 3, device=DEV)
+    p = torch.nn.Parameter(base[3:])                        # 12-byte offset: the scalar path
+    assert p.data_ptr() % 16 != 0
+    ref = {'p': p.detach().cpu().clone()}
+    opt = Adam([p], lr=0.002, weight_decay=1e-6)
+    grad = torch.zeros(1000)
+    grad[:10] = 1.0
+    p.grad = grad.to(DEV)
+    opt.step()
+    st = oracle.AdamState()
+    oracle.adam_step(ref, {'p': grad}, st, 0.002, 1e-6)
+    torch.testing.assert_close(p.detach().cpu(), ref['p'], rtol=1e-5, atol=1e-6)
+    assert (p.detach().cpu()[10:] != base[3:].cpu()[10:]).all()
