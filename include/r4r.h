@@ -190,7 +190,7 @@ int r4r_sqdist_mean_bwd(const float *a, const float *b, const float *g_out, floa
  *   step = 1-based step count shared by all listed tensors. */
 int r4r_adam_chunk_elems(void);
 int r4r_adam_multi(int ntensor, const uint64_t *p, const uint64_t *g, const uint64_t *m, const uint64_t *v,
-                   const int64_t *numel, float lr, float beta1, float beta2, float eps,
+                   const int64_t *numel, float lr, double beta1, double beta2, float eps,
                    float weight_decay, int64_t step, void *stream);
 
 #ifdef __cplusplus

@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(CSRC_DIR, 'libr4r_hip.so')
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), 'include', 'r4r.h')
 
 _SCALARS = {
-    'int': ctypes.c_int, 'float': ctypes.c_float, 'int64_t': ctypes.c_int64,
+    'int': ctypes.c_int, 'float': ctypes.c_float, 'double': ctypes.c_double, 'int64_t': ctypes.c_int64,
     'uint64_t': ctypes.c_uint64, 'size_t': ctypes.c_size_t, 'int32_t': ctypes.c_int32,
 }
 

@@ -19,12 +19,13 @@ struct AdamScalars {
     float lr_over_bc1;      // lr / (1 - beta1^t)
     float inv_sqrt_bc2;     // 1 / sqrt(1 - beta2^t)
     float beta1, beta2, eps, wd;
+    float omb1, omb2;       // 1 - beta, rounded from double like torch's `value=1 - beta2`
 };
 
 __device__ __forceinline__ void adam_elem(float &p, float g, float &m, float &v, const AdamScalars &s) {
     g = fmaf(s.wd, p, g);
-    m = fmaf(s.beta1, m, (1.f - s.beta1) * g);
-    v = fmaf(s.beta2, v, (1.f - s.beta2) * g * g);
+    m = fmaf(s.beta1, m, s.omb1 * g);
+    v = fmaf(s.beta2, v, s.omb2 * g * g);
     const float denom = sqrtf(v) * s.inv_sqrt_bc2 + s.eps;
     p -= s.lr_over_bc1 * (m / denom);
 }
@@ -93,16 +94,17 @@ extern "C" int r4r_adam_chunk_elems(void) { return ADAM_CHUNK; }
 
 extern "C" int r4r_adam_multi(int ntensor, const uint64_t *p, const uint64_t *g, const uint64_t *m,
                               const uint64_t *v, const int64_t *numel,
-                              float lr, float beta1, float beta2, float eps,
+                              float lr, double beta1, double beta2, float eps,
                               float weight_decay, int64_t step, void *stream) {
     R4R_REQUIRE(ntensor >= 0 && (ntensor == 0 || (p && g && m && v && numel)), "adam_multi: null pointer");
     R4R_REQUIRE(step >= 1, "adam_multi: step must be >= 1");
     AdamScalars s;
-    const double bc1 = 1.0 - pow((double)beta1, (double)step);
-    const double bc2 = 1.0 - pow((double)beta2, (double)step);
+    const double bc1 = 1.0 - pow(beta1, (double)step);
+    const double bc2 = 1.0 - pow(beta2, (double)step);
     s.lr_over_bc1 = (float)((double)lr / bc1);
     s.inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
-    s.beta1 = beta1; s.beta2 = beta2; s.eps = eps; s.wd = weight_decay;
+    s.beta1 = (float)beta1; s.beta2 = (float)beta2; s.eps = eps; s.wd = weight_decay;
+    s.omb1 = (float)(1.0 - beta1); s.omb2 = (float)(1.0 - beta2);
     for (int base = 0; base < ntensor; base += ADAM_BATCH) {
         AdamBatch tb;
         tb.ntensor = ntensor - base < ADAM_BATCH ? ntensor - base : ADAM_BATCH;

@@ -53,10 +53,11 @@ def load_word_vectors(hyper_params):
     ``word2vec.npy`` next to it, or an in-memory ``hyper_params['word_vectors']``
     (namespaced extra for synthetic runs), is accepted too."""
     if hyper_params.get('word_vectors') is not None:
-        return torch.as_tensor(np.asarray(hyper_params['word_vectors']), dtype=torch.float32)
+        # always a private copy: xavier_init later overwrites the table in place (SURVEY fact 2)
+        return torch.tensor(np.asarray(hyper_params['word_vectors']), dtype=torch.float32)
     base = hyper_params['data_dir'] + '/word2vec'
     if os.path.exists(base + '.npy'):
-        return torch.from_numpy(np.load(base + '.npy').astype(np.float32))
+        return torch.tensor(np.load(base + '.npy'), dtype=torch.float32)
     return torch.tensor(np.asarray(load_obj(base), dtype=np.float32))
 
 

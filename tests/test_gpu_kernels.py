@@ -300,6 +300,7 @@ def test_fused_adam_unaligned_views_and_untouched_rows():
     """Weight decay moves rows that received a zero gradient."""
     from reviews4rec_amd.optim import Adam
     base = torch.randn(1000 + 3, device=DEV)
+    before = base[3:].cpu().clone()
     p = torch.nn.Parameter(base[3:])                        # 12-byte offset: the scalar path
     assert p.data_ptr() % 16 != 0
     ref = {'p': p.detach().cpu().clone()}
@@ -311,4 +312,4 @@ def test_fused_adam_unaligned_views_and_untouched_rows():
     st = oracle.AdamState()
     oracle.adam_step(ref, {'p': grad}, st, 0.002, 1e-6)
     torch.testing.assert_close(p.detach().cpu(), ref['p'], rtol=1e-5, atol=1e-6)
-    assert (p.detach().cpu()[10:] != base[3:].cpu()[10:]).all()
+    assert (p.detach().cpu()[10:] != before[10:]).all()

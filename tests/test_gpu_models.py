@@ -182,9 +182,18 @@ def test_deepconn_one_step_at_baseline_shape_against_oracle():
             assert k not in got
             continue
         torch.testing.assert_close(got[k], v, rtol=2e-4, atol=1e-6, msg=lambda m: k + ': ' + m)
+    # Adam's first step is lr * g / (|g| + eps): where |g| ~ eps = 1e-8 a 1e-9 difference in g
+    # moves the weight by a visible fraction of lr, so weights are compared where the gradient
+    # is well above eps (the gradients themselves were compared above).
     sd = model.state_dict()
     for k, v in ref_P.items():
-        torch.testing.assert_close(sd[k].cpu(), v, rtol=1e-5, atol=5e-6, msg=lambda m: k + ': ' + m)
+        mine = sd[k].cpu()
+        if k in grads and grads[k] is not None:
+            solid = grads[k].abs() > 1e-6
+            torch.testing.assert_close(mine[solid], v[solid], rtol=1e-5, atol=5e-6, msg=lambda m: k + ': ' + m)
+            assert (mine - v).abs().max() < 2.5e-3          # never more than ~one lr step apart
+        else:
+            torch.testing.assert_close(mine, v, rtol=0, atol=0, msg=lambda m: k + ': ' + m)
 
 
 def test_no_silent_cpu_fallback():
