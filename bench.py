@@ -1,0 +1,192 @@
+#!/usr/bin/env python3
+"""Headline benchmark: train ratings/s, DeepCoNN (word2vec-300, 100 conv filters) on
+Amazon-Electronics-shaped synthetic interactions (BASELINE.json configs[2]).
+
+    python bench.py --gpus N --steps K --warmup W
+
+For N > 1 the driver launches this file under torch.distributed.run, one rank per
+GPU (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the env); ranks run
+data-parallel with one RCCL all-reduce of the dense gradients per step.
+
+A "step" is one full training step -- zero_grad, forward (word gather + TextCNN x2
++ FC + dropout + FM), per-example SE, mean, backward, fused Adam -- over one batch
+of `--batch-per-gpu` ratings per GPU whose index tensors are already resident in
+HBM.  Rank 0 prints ONE JSON line.  `roofline` describes the dominant kernel
+(textcnn_fwd_kernel, fp32 MFMA): algorithmic flops per launch / its mean duration,
+measured with HIP events on the launch stream over the timed region.
+`cpu_baseline` times the plain-PyTorch CPU oracle (same graph as the reference) on a
+bounded sample of the same workload, on rank 0 at N=1 only.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+PEAK_FP32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, dense
+WORKLOAD = 'cfg3_deepconn_electronics_e300'
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=50)
+    ap.add_argument('--warmup', type=int, default=10)
+    ap.add_argument('--batch-per-gpu', type=int, default=128, help='hyper_params batch_size per rank')
+    ap.add_argument('--workload', default=WORKLOAD)
+    ap.add_argument('--dropout', type=float, default=0.6, help='reference default (hyper_params.py:66)')
+    ap.add_argument('--pool', type=int, default=8, help='distinct resident batches cycled through')
+    ap.add_argument('--cpu-seconds', type=float, default=15.0, help='budget of the cpu_baseline leg')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    return ap.parse_args()
+
+
+def tower_flops_per_doc(hp):
+    """Algorithmic forward flops of ONE TextCNN tower on one document:
+    P positions x F filters x 3E window x 2."""
+    P = hp['input_length'] + 2
+    return P * 100 * 3 * hp['word_embed_size'] * 2
+
+
+def cpu_baseline(hp, table, batches_np, budget_s):
+    """The CPU oracle (stock ATen ops, same graph as the reference) on the host cores."""
+    import oracle
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    P = oracle.init_params(hp, vocab_size=None if table is None else table.shape[0], seed=0)
+    key = 'target.word2vec.weight' if hp['model_type'].startswith('transnet') else 'word2vec.weight'
+    if key in P:
+        P[key] = torch.from_numpy(table.copy())
+    state = oracle.AdamState()
+    batches = [([torch.from_numpy(d) for d in data], torch.from_numpy(y)) for data, y in batches_np]
+    oracle.train_step(P, *batches[0], hp, state)             # warm-up (allocations, MKLDNN primitives)
+    n, t0 = 0, time.perf_counter()
+    while True:
+        data, y = batches[n % len(batches)]
+        oracle.train_step(P, data, y, hp, state)
+        n += 1
+        el = time.perf_counter() - t0
+        if el >= budget_s or n >= 200:
+            break
+    B = batches[0][1].shape[0]
+    return {'value': round(n * B / el, 2), 'unit': 'ratings/s', 'cores': cores, 'kind': 'port',
+            'sample': '%d full training steps of batch %d on the same synthetic %s batches '
+                      '(plain-PyTorch CPU oracle, dropout %.1f)' % (n, B, hp['dataset'], hp['dropout'])}
+
+
+def main():
+    args = parse()
+    from reviews4rec_amd import _lib, dist as r4dist, synthetic
+    import reviews4rec_amd
+    from reviews4rec_amd.loss import MSELoss
+    from reviews4rec_amd.optim import Adam
+    from reviews4rec_amd.ops import DropoutState
+    from reviews4rec_amd.utils import xavier_init
+
+    rank, world, local = r4dist.init_from_env()
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs a GPU: the HIP path has no CPU fallback')
+    if world != args.gpus:
+        raise SystemExit('launched with WORLD_SIZE=%d but --gpus %d' % (world, args.gpus))
+    dev = torch.device('cuda', local)
+    lib = _lib.lib()
+
+    B = args.batch_per_gpu
+    hp = synthetic.hyper_params_for(args.workload, batch_size=B, dropout=args.dropout)
+    table = synthetic.word_table(hp['vocab'], hp['word_embed_size']) if hp.get('vocab') else None
+    if table is not None:
+        hp['word_vectors'] = table
+
+    torch.manual_seed(1234)                                  # same init on every rank
+    model = reviews4rec_amd.get_model_class(hp['model_type'])(hp)
+    xavier_init(model)                                       # main.py:377
+    model = model.to(dev)
+    model.train()
+    dp = r4dist.DataParallel(model)
+    dp.broadcast_parameters()
+    DropoutState.manual_seed(4321, rank)
+    criterion = MSELoss(hp)
+    optimizer = Adam(model.parameters(), lr=hp['lr'], weight_decay=hp['weight_decay'])
+
+    gen = synthetic.Generator(hp, seed=synthetic.SEED + rank)   # each rank owns its shard of the stream
+    batches_np = [gen.batch(B) for _ in range(args.pool)]
+    pool = [([torch.from_numpy(d).to(dev) for d in data], torch.from_numpy(y).to(dev)) for data, y in batches_np]
+    metric_sum = torch.zeros((), device=dev)                 # sum of SE stays on the device (no per-step sync)
+    B_global = B * world
+
+    def step(i):
+        data, y = pool[i % len(pool)]
+        model.zero_grad()
+        optimizer.zero_grad()
+        out = model(data)
+        se = criterion(out, y, return_mean=False)
+        metric_sum.add_(se.detach().sum())
+        (se.sum() * dp.loss_scale(B, B_global)).backward()
+        dp.allreduce_grads()
+        optimizer.step()
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    fence()
+    lib.r4r_timing_enable(1)
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i)
+    fence()
+    elapsed = time.perf_counter() - t0
+    lib.r4r_timing_enable(0)
+    tot, cnt = ctypes.c_double(), ctypes.c_int64()
+    lib.r4r_timing_read(0, ctypes.byref(tot), ctypes.byref(cnt), 1)
+
+    el = torch.tensor([elapsed], device=dev)
+    if world > 1:
+        torch.distributed.all_reduce(el, op=torch.distributed.ReduceOp.MAX)
+    elapsed = float(el.item())
+
+    if rank == 0:
+        value = args.steps * B_global / elapsed
+        result = {
+            'metric': 'train ratings/sec', 'value': round(value, 1), 'unit': 'ratings/s',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': round(1000.0 * elapsed / args.steps, 4),
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': args.workload, 'model_type': hp['model_type'],
+                       'word_embed_size': hp['word_embed_size'], 'input_length': hp['input_length'],
+                       'conv_filters': 100, 'latent_size': hp['latent_size'], 'vocab': hp.get('vocab', 0),
+                       'dropout': hp['dropout'], 'batch_per_gpu': B, 'global_batch': B_global,
+                       'parallelism': 'dp%d' % world, 'engine': 'module'},
+        }
+        if cnt.value and hp.get('vocab'):
+            flops = B * tower_flops_per_doc(hp)              # one launch = one tower over the local batch
+            avg_s = tot.value / cnt.value / 1000.0
+            ach = flops / avg_s / 1e12
+            result['roofline'] = {'kernel': 'textcnn_fwd_kernel', 'bound': 'mfma', 'achieved': round(ach, 2),
+                                  'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                                  'frac': round(ach / PEAK_FP32_MFMA_TFLOPS, 4), 'traffic': None,
+                                  'launches': cnt.value, 'avg_launch_ms': round(1000 * avg_s, 4),
+                                  'flops_per_launch': flops}
+        if world == 1 and not args.no_cpu_baseline:
+            cpu_hp = {k: v for k, v in hp.items() if k != 'word_vectors'}
+            result['cpu_baseline'] = cpu_baseline(cpu_hp, table, batches_np[:4], args.cpu_seconds)
+        result['train_mse_running'] = round(float(metric_sum.item()) / ((args.steps + args.warmup) * B), 4)
+        print(json.dumps(result))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

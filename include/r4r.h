@@ -193,6 +193,19 @@ int r4r_adam_multi(int ntensor, const uint64_t *p, const uint64_t *g, const uint
                    const int64_t *numel, float lr, double beta1, double beta2, float eps,
                    float weight_decay, int64_t step, void *stream);
 
+/* ------------------------------------------------------------------------
+ * Live kernel timing for bench.py's roofline leg (no reference counterpart: the
+ * reference has no profiler hooks).  When enabled, each
+ * instrumented entry point brackets its dominant kernel -- only that kernel --
+ * with hipEvents on the launch stream; read() synchronises and accumulates.
+ * `total_ms` and `count` are HOST pointers. */
+#define R4R_TIMING_TEXTCNN_FWD 0    /* textcnn_fwd_kernel (the MFMA conv tile kernel) */
+#define R4R_TIMING_TEXTCNN_WGRAD 1  /* textcnn_wgrad_kernel */
+#define R4R_TIMING_ADAM 2           /* adam_multi_kernel */
+#define R4R_TIMING_SLOTS 8
+int r4r_timing_enable(int on);
+int r4r_timing_read(int slot, double *total_ms, int64_t *count, int reset);
+
 #ifdef __cplusplus
 }
 #endif

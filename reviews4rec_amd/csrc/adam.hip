@@ -124,6 +124,7 @@ extern "C" int r4r_adam_multi(int ntensor, const uint64_t *p, const uint64_t *g,
         }
         tb.chunk_begin[ADAM_BATCH] = (int)chunks;
         if (chunks == 0) continue;
+        ScopedTiming tm(R4R_TIMING_ADAM, as_stream(stream));
         adam_multi_kernel<<<(unsigned)chunks, ADAM_THREADS, 0, as_stream(stream)>>>(tb, s);
     }
     return check_launch("adam_multi");

@@ -1,6 +1,10 @@
 // Error reporting and version for libr4r_hip.so (see include/r4r.h).
+#include <hip/hip_runtime.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <string.h>
+
+#include <vector>
 
 #include "../../include/r4r.h"
 
@@ -17,3 +21,64 @@ void set_error(const char *fmt, ...) {
 
 extern "C" int r4r_version(void) { return 1; }
 extern "C" const char *r4r_last_error(void) { return r4r::g_err; }
+
+// ---------------------------------------------------------------------------
+// Optional live kernel timing (bench.py's roofline leg): when enabled, the
+// instrumented launch sites bracket their DOMINANT kernel with hipEvents on the
+// launch stream.  r4r_timing_read() synchronises those events and accumulates.
+// Off by default: zero overhead on the normal path.
+// ---------------------------------------------------------------------------
+namespace r4r {
+struct TimedSpan { int id; hipEvent_t a, b; };
+static bool g_timing = false;
+static std::vector<TimedSpan> g_spans;
+static double g_total_ms[R4R_TIMING_SLOTS];
+static long long g_count[R4R_TIMING_SLOTS];
+
+bool timing_on() { return g_timing; }
+
+void timing_begin(int id, hipStream_t st, void **token) {
+    TimedSpan s;
+    s.id = id;
+    (void)hipEventCreate(&s.a);
+    (void)hipEventCreate(&s.b);
+    (void)hipEventRecord(s.a, st);
+    g_spans.push_back(s);
+    *token = reinterpret_cast<void *>(g_spans.size());
+}
+
+void timing_end(void *token, hipStream_t st) {
+    const size_t i = reinterpret_cast<size_t>(token) - 1;
+    (void)hipEventRecord(g_spans[i].b, st);
+}
+}  // namespace r4r
+
+extern "C" int r4r_timing_enable(int on) {
+    r4r::g_timing = on != 0;
+    return R4R_OK;
+}
+
+extern "C" int r4r_timing_read(int slot, double *total_ms, int64_t *count, int reset) {
+    if (slot < 0 || slot >= R4R_TIMING_SLOTS || !total_ms || !count) {
+        r4r::set_error("timing_read: bad arguments");
+        return R4R_ERR_ARG;
+    }
+    for (auto &s : r4r::g_spans) {
+        (void)hipEventSynchronize(s.b);
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, s.a, s.b) == hipSuccess) {
+            r4r::g_total_ms[s.id] += ms;
+            r4r::g_count[s.id] += 1;
+        }
+        (void)hipEventDestroy(s.a);
+        (void)hipEventDestroy(s.b);
+    }
+    r4r::g_spans.clear();
+    *total_ms = r4r::g_total_ms[slot];
+    *count = r4r::g_count[slot];
+    if (reset) {
+        memset(r4r::g_total_ms, 0, sizeof(r4r::g_total_ms));
+        memset(r4r::g_count, 0, sizeof(r4r::g_count));
+    }
+    return R4R_OK;
+}

@@ -10,6 +10,18 @@ namespace r4r {
 
 void set_error(const char *fmt, ...);
 
+// live kernel timing (capi.cpp); slots are the R4R_TIMING_* ids of include/r4r.h
+bool timing_on();
+void timing_begin(int id, hipStream_t st, void **token);
+void timing_end(void *token, hipStream_t st);
+
+struct ScopedTiming {
+    void *tok = nullptr;
+    hipStream_t st;
+    ScopedTiming(int id, hipStream_t s) : st(s) { if (timing_on()) timing_begin(id, s, &tok); }
+    ~ScopedTiming() { if (tok) timing_end(tok, st); }
+};
+
 inline int check_launch(const char *what) {
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {

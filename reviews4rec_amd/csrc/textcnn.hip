@@ -315,8 +315,11 @@ extern "C" int r4r_textcnn_fwd(const float *table, int64_t V, const int64_t *idx
                             hipFuncAttributeMaxDynamicSharedMemorySize, FWD_LDS_BYTES);
         attr_set = true;
     }
-    textcnn_fwd_kernel<<<(unsigned)(N * tiles), FWD_THREADS, FWD_LDS_BYTES, st>>>(
-        table, idx, wp, conv_b, pmax, parg, T, E, F, tiles, nchunk);
+    {
+        ScopedTiming tm(R4R_TIMING_TEXTCNN_FWD, st);
+        textcnn_fwd_kernel<<<(unsigned)(N * tiles), FWD_THREADS, FWD_LDS_BYTES, st>>>(
+            table, idx, wp, conv_b, pmax, parg, T, E, F, tiles, nchunk);
+    }
     textcnn_pool_finish_kernel<<<(unsigned)cdiv(N * F, 256), 256, 0, st>>>(pmax, parg, pooled, argmax, N, F, tiles);
     return check_launch("textcnn_fwd");
 }
@@ -339,8 +342,11 @@ extern "C" int r4r_textcnn_wgrad(const float *table, int64_t V, const int64_t *i
     float *part_w = reinterpret_cast<float *>(base);
     base += align256((size_t)ns * F * 3 * E * 4);
     float *part_b = reinterpret_cast<float *>(base);
-    textcnn_wgrad_kernel<<<dim3(F, ns), WG_THREADS, 0, st>>>(table, idx, g_pooled, argmax, part_w, part_b,
-                                                            N, T, E, F, per_split);
+    {
+        ScopedTiming tm(R4R_TIMING_TEXTCNN_WGRAD, st);
+        textcnn_wgrad_kernel<<<dim3(F, ns), WG_THREADS, 0, st>>>(table, idx, g_pooled, argmax, part_w, part_b,
+                                                                N, T, E, F, per_split);
+    }
     const int tot = F * 3 * E + F;
     textcnn_wgrad_reduce_kernel<<<(tot + 255) / 256, 256, 0, st>>>(part_w, part_b, d_conv_w, d_conv_b, E, F, ns);
     return check_launch("textcnn_wgrad");

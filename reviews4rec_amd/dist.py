@@ -1,0 +1,125 @@
+"""Data parallelism, one process per GPU, over RCCL (torch.distributed 'nccl' on
+ROCm) -- new work: the reference is single-process, single-device
+(main.py:407).
+
+Every example's forward/backward is independent given the weights and the loss
+is a mean over the batch (main.py:58), so a global batch is split contiguously
+across ranks and the only exchange is the gradient sum:
+
+  C1  ONE all-reduce per step over ONE flat fp32 bucket holding every gradient
+      that exists (DeepCoNN @E=300: 182,402 floats = 0.73 MB).  On the xGMI full
+      mesh a sub-MB payload is latency-bound, so a single bucket -- not
+      per-tensor calls, not ring-sized buckets -- is the right shape.
+  Parameters with no gradient (DeepCoNN's unused `final` MLP and biases in
+  'deepconn' mode) are left out of the bucket; the active set
+  is agreed once across ranks (a rank whose shard is empty contributes zeros).
+
+Weights are replicated; after an identical all-reduced gradient every rank runs
+the identical dense Adam sweep, so replicas stay bit-identical without any
+parameter traffic.  The loss must be scaled by 1/B_global (``loss_scale``), not
+1/B_local, so ragged shards weigh correctly.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend=None):
+    """Join the job torchrun / torch.distributed.run started (RANK, WORLD_SIZE, LOCAL_RANK,
+    MASTER_ADDR, MASTER_PORT).  Returns (rank, world, local_rank); a no-op at WORLD_SIZE=1."""
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    if world > 1 and not dist.is_initialized():
+        if backend is None:
+            backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+        if backend == 'nccl':
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    elif torch.cuda.is_available():
+        torch.cuda.set_device(local)
+    return rank, world, local
+
+
+def shard_bounds(n, rank, world):
+    """Contiguous split of n rows: the first n % world ranks get one extra row."""
+    base, extra = divmod(n, world)
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+def shard_batch(data, y, rank, world):
+    """This rank's contiguous slice of a global batch (the 7-slot list + ratings)."""
+    lo, hi = shard_bounds(y.shape[0], rank, world)
+    return [None if d is None else d[lo:hi] for d in data], y[lo:hi]
+
+
+class DataParallel:
+    def __init__(self, model, group=None):
+        self.model = model
+        self.group = group
+        self.on = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+        self.world = dist.get_world_size(group) if self.on else 1
+        self.rank = dist.get_rank(group) if self.on else 0
+        self.params = [p for p in model.parameters() if p.requires_grad]
+        self._active = None          # indices into self.params that carry gradients
+        self._bucket = None
+
+    def broadcast_parameters(self, src=0):
+        """Make every replica start from rank `src`'s weights (buffers included)."""
+        if not self.on:
+            return
+        for t in list(self.model.parameters()) + list(self.model.buffers()):
+            dist.broadcast(t.data, src=src, group=self.group)
+
+    def loss_scale(self, n_local, n_global):
+        """Factor turning sum-of-local-SE into this rank's share of mean(SE) over the GLOBAL batch."""
+        return 1.0 / float(n_global)
+
+    def global_count(self, n_local, device):
+        if not self.on:
+            return int(n_local)
+        t = torch.tensor([float(n_local)], device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        return int(t.item())
+
+    def _agree_active_set(self, device):
+        have = torch.tensor([1.0 if p.grad is not None else 0.0 for p in self.params], device=device)
+        if self.on:
+            dist.all_reduce(have, op=dist.ReduceOp.MAX, group=self.group)
+        self._active = [i for i, h in enumerate(have.tolist()) if h > 0]
+        total = sum(self.params[i].numel() for i in self._active)
+        self._bucket = torch.zeros(total, dtype=torch.float32, device=device)
+
+    @torch.no_grad()
+    def allreduce_grads(self):
+        """Sum gradients across ranks through one flat bucket; afterwards every active
+        parameter's .grad is a view into the reduced bucket."""
+        if not self.on:
+            return
+        device = self.params[0].device
+        if self._active is None:
+            self._agree_active_set(device)
+        bucket = self._bucket
+        off = 0
+        views = []
+        for i in self._active:
+            p = self.params[i]
+            n = p.numel()
+            v = bucket[off:off + n].view_as(p)
+            if p.grad is None:
+                v.zero_()                                   # empty shard on this rank
+            elif p.grad.data_ptr() != v.data_ptr():
+                v.copy_(p.grad)
+            views.append((p, v))
+            off += n
+        dist.all_reduce(bucket, op=dist.ReduceOp.SUM, group=self.group)
+        for p, v in views:
+            p.grad = v
+
+    @torch.no_grad()
+    def sum_scalar(self, t):
+        if self.on:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        return t
