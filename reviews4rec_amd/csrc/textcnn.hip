@@ -20,6 +20,8 @@
 // LDS image (floats): X [130][40] + W [112][104]; both row strides are
 // == 8 (mod 16) so the ds_read_b128 fragment reads (16 rows x 4 k-quads per
 // wave) are bank-conflict free (MI355X_MICROARCH.md, LDS table).
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace r4r {
@@ -176,6 +178,351 @@ __global__ __launch_bounds__(FWD_THREADS, 2) void textcnn_fwd_kernel(
     }
 }
 
+
+// ---------------------------------------------------------------------------
+// Forward tile kernel v2: same tiling, plus a register prefetch of the NEXT
+// E-chunk (issue the global loads early, write them to LDS late): the gather
+// and weight-image loads of chunk c+1 are in flight while chunk c's 336 MFMAs
+// per wave run, so the only exposed staging cost per chunk is the ds_write pass
+// and its two barriers -- which the co-resident second workgroup covers.
+// ---------------------------------------------------------------------------
+constexpr int W_VEC = NP * WS / 4;                       // 2912 float4 per weight chunk
+constexpr int W_PER_THREAD = (W_VEC + FWD_THREADS - 1) / FWD_THREADS;   // 12
+
+struct EpilogueOut { float *pmax; int *parg; };
+
+__device__ __forceinline__ void tile_compute(const float *Xs, const float *Wl, f32x4 (&acc)[2][NT],
+                                             int wave, int lrow, int q, int nblk) {
+    for (int j = 0; j < 3; ++j) {
+        for (int g = 0; g < nblk; ++g) {
+            f32x4 a[2], b[NT];
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+                a[mi] = *reinterpret_cast<const f32x4 *>(Xs + (wave * 32 + mi * 16 + lrow + j) * XS + g * 16 + q * 4);
+#pragma unroll
+            for (int ni = 0; ni < NT; ++ni)
+                b[ni] = *reinterpret_cast<const f32x4 *>(Wl + (ni * 16 + lrow) * WS + j * EC + g * 16 + q * 4);
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < NT; ++ni)
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mi][kk], b[ni][kk], acc[mi][ni], 0, 0, 0);
+        }
+    }
+}
+
+__device__ __forceinline__ void tile_epilogue(float *Xs, const f32x4 (&acc)[2][NT], const float *bias,
+                                              float *pmax, int *parg, int p0, int P, int F,
+                                              int tid, int wave, int lrow, int q) {
+    float *redv = Xs;                                   // [4 waves][NP]
+    int *redp = reinterpret_cast<int *>(Xs + 4 * NP);   // [4 waves][NP]
+#pragma unroll
+    for (int ni = 0; ni < NT; ++ni) {
+        const int col = ni * 16 + lrow;
+        const float bc = (col < F) ? bias[col] : 0.f;
+        float best = -INFINITY;
+        int bp = 0x7fffffff;
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int p = p0 + wave * 32 + mi * 16 + q * 4 + r;
+                const float v = acc[mi][ni][r] + bc;
+                if (p < P && v > best) { best = v; bp = p; }
+            }
+#pragma unroll
+        for (int off = 16; off <= 32; off <<= 1) {
+            const float ov = __shfl_xor(best, off);
+            const int op = __shfl_xor(bp, off);
+            if (ov > best || (ov == best && op < bp)) { best = ov; bp = op; }
+        }
+        if (q == 0) { redv[wave * NP + col] = best; redp[wave * NP + col] = bp; }
+    }
+    __syncthreads();
+    if (tid < NP) {
+        float best = redv[tid];
+        int bp = redp[tid];
+#pragma unroll
+        for (int w = 1; w < 4; ++w) {
+            const float ov = redv[w * NP + tid];
+            const int op = redp[w * NP + tid];
+            if (ov > best || (ov == best && op < bp)) { best = ov; bp = op; }
+        }
+        pmax[(size_t)blockIdx.x * NP + tid] = best;
+        parg[(size_t)blockIdx.x * NP + tid] = bp;
+    }
+}
+
+__global__ __launch_bounds__(FWD_THREADS, 2) void textcnn_fwd_kernel_v2(
+    const float *__restrict__ table, const int64_t *__restrict__ idx,
+    const float *__restrict__ wp, const float *__restrict__ bias,
+    float *__restrict__ pmax, int *__restrict__ parg,
+    int T, int E, int F, int tiles, int nchunk) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float *Xs = reinterpret_cast<float *>(smem);       // [XR][XS]
+    float *Wl = Xs + XR * XS;                          // [NP][WS]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int doc = blockIdx.x / tiles, tile = blockIdx.x - doc * tiles;
+    const int p0 = tile * MT;
+    const int P = T + 2;
+    const int lrow = lane & 15, q = lane >> 4;
+    const int e16 = (E + 15) & ~15;
+
+    // This thread stages float4 column c4 of rows (tid>>3) + 32k, k = 0..3, and -- for
+    // tid < 16 -- of the two halo rows 128, 129.  Row offsets into the table (in floats),
+    // -1 for rows outside the document (zero rows).
+    const int c4 = tid & 7;
+    long xoff[5];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+        const int r = (k < 4) ? (tid >> 3) + 32 * k : 128 + (tid >> 3);
+        const int t = p0 - 2 + r;
+        const bool live = (k < 4 || tid < 16) && t >= 0 && t < T;
+        xoff[k] = live ? (long)idx[(size_t)doc * T + t] * E : -1;
+    }
+
+    f32x4 xr[5], wr[W_PER_THREAD];
+    auto issue_loads = [&](int c) {
+        const int e = c * EC + c4 * 4;
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+            xr[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (xoff[k] >= 0 && e < E) xr[k] = *reinterpret_cast<const f32x4 *>(table + xoff[k] + e);
+        }
+        const f32x4 *wsrc = reinterpret_cast<const f32x4 *>(wp + (size_t)c * NP * WS);
+#pragma unroll
+        for (int k = 0; k < W_PER_THREAD; ++k) {
+            const int i = tid + k * FWD_THREADS;
+            if (i < W_VEC) wr[k] = wsrc[i];
+        }
+    };
+    auto write_lds = [&]() {
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+            const int r = (k < 4) ? (tid >> 3) + 32 * k : 128 + (tid >> 3);
+            if (k < 4 || tid < 16) *reinterpret_cast<f32x4 *>(Xs + r * XS + c4 * 4) = xr[k];
+        }
+#pragma unroll
+        for (int k = 0; k < W_PER_THREAD; ++k) {
+            const int i = tid + k * FWD_THREADS;
+            if (i < W_VEC) reinterpret_cast<f32x4 *>(Wl)[i] = wr[k];
+        }
+    };
+
+    f32x4 acc[2][NT];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NT; ++ni) acc[mi][ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    issue_loads(0);
+    write_lds();
+    __syncthreads();
+    for (int c = 0; c < nchunk; ++c) {
+        if (c + 1 < nchunk) issue_loads(c + 1);          // in flight during the MFMAs below
+        const int nblk = min(EC / 16, (e16 - c * EC) / 16);
+        tile_compute(Xs, Wl, acc, wave, lrow, q, nblk);
+        __syncthreads();                                 // every wave is done reading chunk c
+        if (c + 1 < nchunk) {
+            write_lds();
+            __syncthreads();
+        }
+    }
+    tile_epilogue(Xs, acc, bias, pmax, parg, p0, P, F, tid, wave, lrow, q);
+}
+
+
+// ---------------------------------------------------------------------------
+// Forward tile kernel v3: LDS double buffering.  PMC on v2 showed the matrix pipe
+// 75 % busy: the two co-resident workgroups run in phase and both sit in the
+// "barrier -> ds_write -> barrier" bubble at the same time.  Here the E-chunk is 16
+// columns so TWO (X, W) images fit: chunk c+1 is written into the other buffer at
+// the START of chunk c's compute (the ds_writes drain under the MFMAs), chunk c+2's
+// global loads are issued right after, and there is ONE barrier per chunk and no
+// exposed staging at all.
+//   NW = 8: 256 positions / workgroup, 1 workgroup per CU (2 waves per SIMD),
+//           weight image staged once per 256 rows
+//   NW = 4: 128 positions / workgroup, 2 workgroups per CU (NARRE's short reviews)
+// LDS per buffer (floats): X [32 NW + 2][24] + W [112][56]; strides == 8 (mod 16).
+// ---------------------------------------------------------------------------
+constexpr int EC3 = 16;
+constexpr int XS3 = EC3 + 8;            // 24
+constexpr int WS3 = 3 * EC3 + 8;        // 56
+constexpr int W3_VEC = NP * WS3 / 4;    // 1568 float4 per weight chunk
+
+template <int NW>
+struct V3 {
+    static constexpr int THREADS = 64 * NW;
+    static constexpr int MTILE = 32 * NW;
+    static constexpr int XROWS = MTILE + 2;
+    static constexpr int BUF_FLOATS = XROWS * XS3 + NP * WS3;
+    static constexpr int LDS_BYTES = 2 * BUF_FLOATS * 4;
+    static constexpr int XK = MTILE * 4 / THREADS;                    // = 2 float4 of X per thread (+ halo)
+    static constexpr int WK = (W3_VEC + THREADS - 1) / THREADS;       // 4 (NW=8) or 7 (NW=4)
+};
+
+__global__ void textcnn_pack_w3_kernel(const float *__restrict__ w, float *__restrict__ wp,
+                                       int E, int F, int nchunk) {
+    const int total = nchunk * NP * WS3;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int col = i % WS3;
+        const int n = (i / WS3) % NP;
+        const int c = i / (WS3 * NP);
+        float v = 0.f;
+        if (col < 3 * EC3 && n < F) {
+            const int j = col / EC3, e = c * EC3 + col % EC3;
+            if (e < E) v = w[((size_t)n * 3 + j) * E + e];
+        }
+        wp[i] = v;
+    }
+}
+
+// ABL (timing-only ablations, results are WRONG when ABL != 0; used by scratch/bench_conv.py):
+//   1 = no staging inside the loop, 2 = also no barrier, 3 = also no LDS fragment reads
+template <int NW, int ABL = 0>
+__global__ __launch_bounds__(64 * NW, 2) void textcnn_fwd_kernel_v3(
+    const float *__restrict__ table, const int64_t *__restrict__ idx,
+    const float *__restrict__ wp, const float *__restrict__ bias,
+    float *__restrict__ pmax, int *__restrict__ parg,
+    int T, int E, int F, int tiles, int nchunk) {
+    using C = V3<NW>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float *lds = reinterpret_cast<float *>(smem);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int doc = blockIdx.x / tiles, tile = blockIdx.x - doc * tiles;
+    const int p0 = tile * C::MTILE;
+    const int P = T + 2;
+    const int lrow = lane & 15, q = lane >> 4;
+
+    // staging role of this thread: float4 column c4 (of 4) of rows (tid>>2) + (THREADS/4) k,
+    // k < XK, plus -- for tid < 8 -- of the two halo rows MTILE, MTILE+1
+    const int c4 = tid & 3;
+    long xoff[C::XK + 1];
+#pragma unroll
+    for (int k = 0; k <= C::XK; ++k) {
+        const int r = (k < C::XK) ? (tid >> 2) + (C::THREADS / 4) * k : C::MTILE + (tid >> 2);
+        const int t = p0 - 2 + r;
+        const bool live = (k < C::XK || tid < 8) && t >= 0 && t < T;
+        xoff[k] = live ? (long)idx[(size_t)doc * T + t] * E : -1;
+    }
+
+    f32x4 xr[C::XK + 1], wr[C::WK];
+    auto issue_loads = [&](int c) {
+        const int e = c * EC3 + c4 * 4;
+#pragma unroll
+        for (int k = 0; k <= C::XK; ++k) {
+            xr[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (xoff[k] >= 0 && e < E) xr[k] = *reinterpret_cast<const f32x4 *>(table + xoff[k] + e);
+        }
+        const f32x4 *wsrc = reinterpret_cast<const f32x4 *>(wp + (size_t)c * NP * WS3);
+#pragma unroll
+        for (int k = 0; k < C::WK; ++k) {
+            const int i = tid + k * C::THREADS;
+            if (i < W3_VEC) wr[k] = wsrc[i];
+        }
+    };
+    auto write_lds = [&](float *buf) {
+        float *Xs = buf, *Wl = buf + C::XROWS * XS3;
+#pragma unroll
+        for (int k = 0; k <= C::XK; ++k) {
+            const int r = (k < C::XK) ? (tid >> 2) + (C::THREADS / 4) * k : C::MTILE + (tid >> 2);
+            if (k < C::XK || tid < 8) *reinterpret_cast<f32x4 *>(Xs + r * XS3 + c4 * 4) = xr[k];
+        }
+#pragma unroll
+        for (int k = 0; k < C::WK; ++k) {
+            const int i = tid + k * C::THREADS;
+            if (i < W3_VEC) reinterpret_cast<f32x4 *>(Wl)[i] = wr[k];
+        }
+    };
+
+    f32x4 acc[2][NT];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NT; ++ni) acc[mi][ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    issue_loads(0);
+    write_lds(lds);
+    if (nchunk > 1) issue_loads(1);
+    __syncthreads();
+    for (int c = 0; c < nchunk; ++c) {
+        float *cur = lds + ((ABL ? 0 : c) & 1) * C::BUF_FLOATS;
+        if (ABL == 0 && c + 1 < nchunk) {
+            write_lds(lds + ((c + 1) & 1) * C::BUF_FLOATS);   // chunk c+1 -> the other buffer
+            if (c + 2 < nchunk) issue_loads(c + 2);            // in flight for a whole chunk
+        }
+        const float *Xs = cur, *Wl = cur + C::XROWS * XS3;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            f32x4 a[2], b[NT];
+            if (ABL == 3 && (c > 0 || j > 0)) {
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi) { a[mi] = acc[mi][0]; asm volatile("" : "+v"(a[mi])); }
+#pragma unroll
+                for (int ni = 0; ni < NT; ++ni) { b[ni] = acc[0][ni]; asm volatile("" : "+v"(b[ni])); }
+            } else {
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+                a[mi] = *reinterpret_cast<const f32x4 *>(Xs + (wave * 32 + mi * 16 + lrow + j) * XS3 + q * 4);
+#pragma unroll
+            for (int ni = 0; ni < NT; ++ni)
+                b[ni] = *reinterpret_cast<const f32x4 *>(Wl + (ni * 16 + lrow) * WS3 + j * EC3 + q * 4);
+            }
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < NT; ++ni)
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mi][kk], b[ni][kk], acc[mi][ni], 0, 0, 0);
+        }
+        if (ABL < 2) __syncthreads();
+    }
+
+    // ---- epilogue (NW waves)
+    float *redv = lds;                                    // [NW][NP]
+    int *redp = reinterpret_cast<int *>(lds + NW * NP);   // [NW][NP]
+#pragma unroll
+    for (int ni = 0; ni < NT; ++ni) {
+        const int col = ni * 16 + lrow;
+        const float bc = (col < F) ? bias[col] : 0.f;
+        float best = -INFINITY;
+        int bp = 0x7fffffff;
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int p = p0 + wave * 32 + mi * 16 + q * 4 + r;
+                const float v = acc[mi][ni][r] + bc;
+                if (p < P && v > best) { best = v; bp = p; }
+            }
+#pragma unroll
+        for (int off = 16; off <= 32; off <<= 1) {
+            const float ov = __shfl_xor(best, off);
+            const int op = __shfl_xor(bp, off);
+            if (ov > best || (ov == best && op < bp)) { best = ov; bp = op; }
+        }
+        if (q == 0) { redv[wave * NP + col] = best; redp[wave * NP + col] = bp; }
+    }
+    __syncthreads();
+    if (tid < NP) {
+        float best = redv[tid];
+        int bp = redp[tid];
+#pragma unroll
+        for (int w = 1; w < NW; ++w) {
+            const float ov = redv[w * NP + tid];
+            const int op = redp[w * NP + tid];
+            if (ov > best || (ov == best && op < bp)) { best = ov; bp = op; }
+        }
+        pmax[(size_t)blockIdx.x * NP + tid] = best;
+        parg[(size_t)blockIdx.x * NP + tid] = bp;
+    }
+}
+
 // Combine the per-tile partials of one document, apply relu:
 //   pooled = max(0, max_p conv), argmax = first p of the max, -1 if pooled == 0.
 __global__ void textcnn_pool_finish_kernel(const float *__restrict__ pmax, const int *__restrict__ parg,
@@ -261,6 +608,19 @@ static inline int wgrad_splits(int64_t N) {
     return s;
 }
 
+// Kernel generation used by r4r_textcnn_fwd.  R4R_TEXTCNN_FWD=<n> pins one for A/B runs:
+//   1 = v1 (no prefetch), 2 = v2 (register prefetch), 3 = v3<8> (double-buffered, 256-row
+//   tiles), 4 = v3<4> (double-buffered, 128-row tiles)
+static int fwd_variant(int T) {
+    static int v = -1;
+    if (v < 0) {
+        const char *e = getenv("R4R_TEXTCNN_FWD");
+        v = e ? atoi(e) : 0;
+    }
+    if (v >= 1 && v <= 7) return v;        // 5..7: timing-only ablations of v3<4> (wrong results)
+    return (T + 2 > 160) ? 3 : 4;          // long documents: 256-row tiles; short reviews: 128
+}
+
 static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 }  // namespace r4r
@@ -269,8 +629,9 @@ using namespace r4r;
 
 extern "C" size_t r4r_textcnn_ws_bytes(int64_t N, int T, int E, int F) {
     if (N < 0 || T <= 0 || E <= 0 || F <= 0) return 0;
-    const size_t fwd = align256((size_t)n_chunks(E) * NP * WS * 4) +
-                       2 * align256((size_t)N * tiles_per_doc(T) * NP * 4);
+    const size_t img_v2 = (size_t)n_chunks(E) * NP * WS, img_v3 = (size_t)((E + EC3 - 1) / EC3) * NP * WS3;
+    const size_t fwd = align256((img_v2 > img_v3 ? img_v2 : img_v3) * 4) +
+                       2 * align256((size_t)N * tiles_per_doc(T) * NP * 4);   // tiles of the smallest MT
     const int ns = wgrad_splits(N);
     const size_t bwd = align256((size_t)ns * F * 3 * E * 4) + align256((size_t)ns * F * 4);
     return fwd > bwd ? fwd : bwd;
@@ -299,26 +660,65 @@ extern "C" int r4r_textcnn_fwd(const float *table, int64_t V, const int64_t *idx
     }
     if (N == 0) return R4R_OK;
     hipStream_t st = as_stream(stream);
-    const int nchunk = n_chunks(E), tiles = tiles_per_doc(T);
+    const int variant = fwd_variant(T);
+    const bool v3 = variant >= 3;
+    const int mtile = (variant == 3) ? 256 : 128;
+    const int nchunk = v3 ? (E + EC3 - 1) / EC3 : n_chunks(E);
+    const int tiles = (T + 2 + mtile - 1) / mtile;
+    const size_t img = (size_t)nchunk * NP * (v3 ? WS3 : WS);
     char *base = static_cast<char *>(ws);
     float *wp = reinterpret_cast<float *>(base);
-    base += align256((size_t)nchunk * NP * WS * 4);
+    base += align256(img * 4);
     float *pmax = reinterpret_cast<float *>(base);
     base += align256((size_t)N * tiles * NP * 4);
     int *parg = reinterpret_cast<int *>(base);
 
-    const int total = nchunk * NP * WS;
-    textcnn_pack_w_kernel<<<(total + 255) / 256, 256, 0, st>>>(conv_w, wp, E, F, nchunk);
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(textcnn_fwd_kernel),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, FWD_LDS_BYTES);
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, FWD_LDS_BYTES);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(textcnn_fwd_kernel_v2),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, FWD_LDS_BYTES);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(textcnn_fwd_kernel_v3<8>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, V3<8>::LDS_BYTES);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(textcnn_fwd_kernel_v3<4>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, V3<4>::LDS_BYTES);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(textcnn_fwd_kernel_v3<4, 1>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, V3<4>::LDS_BYTES);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(textcnn_fwd_kernel_v3<4, 2>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, V3<4>::LDS_BYTES);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(textcnn_fwd_kernel_v3<4, 3>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, V3<4>::LDS_BYTES);
         attr_set = true;
     }
+    if (v3)
+        textcnn_pack_w3_kernel<<<(unsigned)((img + 255) / 256), 256, 0, st>>>(conv_w, wp, E, F, nchunk);
+    else
+        textcnn_pack_w_kernel<<<(unsigned)((img + 255) / 256), 256, 0, st>>>(conv_w, wp, E, F, nchunk);
     {
         ScopedTiming tm(R4R_TIMING_TEXTCNN_FWD, st);
-        textcnn_fwd_kernel<<<(unsigned)(N * tiles), FWD_THREADS, FWD_LDS_BYTES, st>>>(
-            table, idx, wp, conv_b, pmax, parg, T, E, F, tiles, nchunk);
+        const unsigned grid = (unsigned)(N * tiles);
+        if (variant == 1)
+            textcnn_fwd_kernel<<<grid, FWD_THREADS, FWD_LDS_BYTES, st>>>(
+                table, idx, wp, conv_b, pmax, parg, T, E, F, tiles, nchunk);
+        else if (variant == 2)
+            textcnn_fwd_kernel_v2<<<grid, FWD_THREADS, FWD_LDS_BYTES, st>>>(
+                table, idx, wp, conv_b, pmax, parg, T, E, F, tiles, nchunk);
+        else if (variant == 3)
+            textcnn_fwd_kernel_v3<8><<<grid, V3<8>::THREADS, V3<8>::LDS_BYTES, st>>>(
+                table, idx, wp, conv_b, pmax, parg, T, E, F, tiles, nchunk);
+        else if (variant == 4)
+            textcnn_fwd_kernel_v3<4><<<grid, V3<4>::THREADS, V3<4>::LDS_BYTES, st>>>(
+                table, idx, wp, conv_b, pmax, parg, T, E, F, tiles, nchunk);
+        else if (variant == 5)
+            textcnn_fwd_kernel_v3<4, 1><<<grid, V3<4>::THREADS, V3<4>::LDS_BYTES, st>>>(
+                table, idx, wp, conv_b, pmax, parg, T, E, F, tiles, nchunk);
+        else if (variant == 6)
+            textcnn_fwd_kernel_v3<4, 2><<<grid, V3<4>::THREADS, V3<4>::LDS_BYTES, st>>>(
+                table, idx, wp, conv_b, pmax, parg, T, E, F, tiles, nchunk);
+        else
+            textcnn_fwd_kernel_v3<4, 3><<<grid, V3<4>::THREADS, V3<4>::LDS_BYTES, st>>>(
+                table, idx, wp, conv_b, pmax, parg, T, E, F, tiles, nchunk);
     }
     textcnn_pool_finish_kernel<<<(unsigned)cdiv(N * F, 256), 256, 0, st>>>(pmax, parg, pooled, argmax, N, F, tiles);
     return check_launch("textcnn_fwd");
