@@ -45,6 +45,8 @@ def parse():
     ap.add_argument('--pool', type=int, default=8, help='distinct resident batches cycled through')
     ap.add_argument('--cpu-seconds', type=float, default=15.0, help='budget of the cpu_baseline leg')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--engine', choices=['native', 'module'], default='native',
+                    help="native: fused r4r_deepconn_step (6 launches/step); module: op-by-op autograd path")
     return ap.parse_args()
 
 
@@ -121,8 +123,16 @@ def main():
     metric_sum = torch.zeros((), device=dev)                 # sum of SE stays on the device (no per-step sync)
     B_global = B * world
 
+    engine = None
+    if args.engine == 'native' and hp['model_type'] == 'deepconn':
+        from reviews4rec_amd.engine import DeepCoNNEngine
+        engine = DeepCoNNEngine(model, lr=hp['lr'], weight_decay=hp['weight_decay'], dp=dp, seed=4321, rank=rank)
+
     def step(i):
         data, y = pool[i % len(pool)]
+        if engine is not None:
+            engine.train_step(data, y, n_global=B_global)   # forward + loss + backward + all-reduce + Adam
+            return
         model.zero_grad()
         optimizer.zero_grad()
         out = model(data)
@@ -168,10 +178,11 @@ def main():
                        'word_embed_size': hp['word_embed_size'], 'input_length': hp['input_length'],
                        'conv_filters': 100, 'latent_size': hp['latent_size'], 'vocab': hp.get('vocab', 0),
                        'dropout': hp['dropout'], 'batch_per_gpu': B, 'global_batch': B_global,
-                       'parallelism': 'dp%d' % world, 'engine': 'module'},
+                       'parallelism': 'dp%d' % world, 'engine': 'native' if engine is not None else 'module'},
         }
         if cnt.value and hp.get('vocab'):
-            flops = B * tower_flops_per_doc(hp)              # one launch = one tower over the local batch
+            towers = 2 if engine is not None else 1          # the native step runs both towers in one launch
+            flops = towers * B * tower_flops_per_doc(hp)
             avg_s = tot.value / cnt.value / 1000.0
             ach = flops / avg_s / 1e12
             result['roofline'] = {'kernel': 'textcnn_fwd_kernel', 'bound': 'mfma', 'achieved': round(ach, 2),
@@ -182,7 +193,8 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             cpu_hp = {k: v for k, v in hp.items() if k != 'word_vectors'}
             result['cpu_baseline'] = cpu_baseline(cpu_hp, table, batches_np[:4], args.cpu_seconds)
-        result['train_mse_running'] = round(float(metric_sum.item()) / ((args.steps + args.warmup) * B), 4)
+        run_sse = float(engine.sse.item()) if engine is not None else float(metric_sum.item())
+        result['train_mse_running'] = round(run_sse / ((args.steps + args.warmup) * B), 4)
         print(json.dumps(result))
     if world > 1:
         torch.distributed.destroy_process_group()

@@ -194,6 +194,38 @@ int r4r_adam_multi(int ntensor, const uint64_t *p, const uint64_t *g, const uint
                    float weight_decay, int64_t step, void *stream);
 
 /* ------------------------------------------------------------------------
+ * Fused DeepCoNN step ('deepconn' mode): the whole of DeepCoNN.forward
+ * (DeepCoNN.py:37-66) + MSELoss/mean (loss.py:7-11, main.py:56-58) + backward in
+ * ONE call that enqueues 6 kernels (both towers share the conv launch).
+ * Replaces, per training step, every ATen op main.py:32,56-59 dispatches.
+ *
+ * The trainable parameters of this mode live in ONE flat fp32 buffer; slot i of
+ * r4r_deepconn_layout() (HOST out-arrays of r4r_deepconn_nparam() entries, offsets
+ * in floats, 16-byte aligned) is, in order:
+ *   user_conv.convs.0.weight, user_conv.convs.0.bias, user_conv.fc.weight,
+ *   user_conv.fc.bias, item_conv.(same four), fm.V, fm.lin.weight, fm.lin.bias,
+ *   global_bias            (`final`, user_bias, item_bias are unused in this mode,
+ *                           DeepCoNN.py:64-66, and are not part of the buffer)
+ * flat_g has the same layout and is OVERWRITTEN with d mean(SE)/d param, where the
+ * mean is over 1/inv_denom examples (pass 1/B_global under data parallelism).
+ *   flat_g == NULL : forward only (eval, or y == NULL for pure prediction)
+ *   training != 0  : dropout(p) on the FC outputs, Philox4x32-10(seed, offset + b*2L + i)
+ *   pred [B], se [B] (se required when y != NULL); sse_accum (nullable device scalar)
+ *   is incremented by sum_b se[b] -- the host's running metric (main.py:57) without a
+ *   per-step device->host sync. */
+int r4r_deepconn_nparam(void);
+int r4r_deepconn_layout(int E, int L, int64_t *offsets, int64_t *sizes, int64_t *total);
+size_t r4r_deepconn_ws_bytes(int64_t B, int T, int E, int L);
+size_t r4r_deepconn_ws_mult_offset(int64_t B, int T, int E, int L);   /* [B,2L] dropout multipliers (tests) */
+int r4r_deepconn_step(const float *table, int64_t V, const int64_t *user_idx, const int64_t *item_idx,
+                      const float *y, const float *flat_p, float *flat_g,
+                      float *pred, float *se, float *sse_accum,
+                      void *ws, size_t ws_bytes,
+                      int64_t B, int T, int E, int L,
+                      float dropout_p, int training, uint64_t seed, uint64_t offset,
+                      float inv_denom, void *stream);
+
+/* ------------------------------------------------------------------------
  * Live kernel timing for bench.py's roofline leg (no reference counterpart: the
  * reference has no profiler hooks).  When enabled, each
  * instrumented entry point brackets its dominant kernel -- only that kernel --

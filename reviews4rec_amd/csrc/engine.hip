@@ -1,0 +1,408 @@
+// Fused DeepCoNN training / inference step for gfx950 ('deepconn' mode: two TextCNN
+// towers -> FC -> dropout -> concat -> FM + global bias -> squared error).
+//
+// One C call enqueues the whole step -- 6 launches instead of the ~45 of the
+// op-by-op autograd path:
+//   1 pack both conv weight images            (textcnn.hip)
+//   2 conv + relu + max-pool, BOTH towers in one grid   (textcnn.hip, fp32 MFMA)
+//   3 head: pool-finish + FC + dropout + FM + SE, and the head's backward down to
+//     g_pooled, one wave per rating            (here)
+//   4 head parameter gradients, reduced over the batch in a fixed order (here)
+//   5 argmax-sparse conv wgrad, both towers    (textcnn.hip)
+//   6 wgrad partial reduce -> flat gradient buffer
+// All trainable parameters live in ONE flat fp32 buffer (layout below) and so do the
+// gradients: data parallelism is a single RCCL all-reduce over `flat_g`, and Adam is
+// a single r4r_adam_multi sweep over one "tensor".
+//
+// Reference behaviour restated (file:line under the reference root):
+//   DeepCoNN.forward                     DeepCoNN.py:37-66
+//   TextCNN.forward (fc + dropout)       common_pytorch_models.py:33-37
+//   TorchFM.forward                      common_pytorch_models.py:49-57
+//   MSELoss + mean + backward            loss.py:7-11, main.py:56-59
+// 'deepconn' mode never touches `final`, `user_bias`, `item_bias` (DeepCoNN.py:64-66,
+// SURVEY.md fact 7), so they are not in the flat buffer and Adam never sees them.
+#include "textcnn.h"
+
+namespace r4r {
+
+constexpr int F_CONV = 100;     // common_pytorch_models.py:11
+constexpr int FM_K = 8;         // DeepCoNN.py:32
+constexpr int MAX_L = 32;
+
+enum { P_UCW = 0, P_UCB, P_UFW, P_UFB, P_ICW, P_ICB, P_IFW, P_IFB, P_FMV, P_FMLW, P_FMLB, P_GB, P_COUNT };
+
+struct Layout {
+    int64_t off[P_COUNT], size[P_COUNT], total;
+};
+
+static Layout make_layout(int E, int L) {
+    Layout lay;
+    const int64_t sz[P_COUNT] = {(int64_t)F_CONV * 3 * E, F_CONV, (int64_t)L * F_CONV, L,
+                                 (int64_t)F_CONV * 3 * E, F_CONV, (int64_t)L * F_CONV, L,
+                                 (int64_t)2 * L * FM_K, 2 * L, 1, 1};
+    int64_t o = 0;
+    for (int i = 0; i < P_COUNT; ++i) {
+        lay.off[i] = o;
+        lay.size[i] = sz[i];
+        o += (sz[i] + 3) & ~(int64_t)3;          // 16-byte aligned slots; pad floats stay 0 forever
+    }
+    lay.total = o;
+    return lay;
+}
+
+struct HeadArgs {
+    // inputs
+    const float *pmax[2]; const int *parg[2];     // conv partials per tower [B, tiles, NP]
+    const float *fc_w[2]; const float *fc_b[2];   // [L,100], [L]
+    const float *V, *lin_w, *lin_b, *gbias;       // [2L,8], [2L], [1], [1]
+    const float *y;                               // [B] or NULL
+    // outputs
+    float *pooled[2]; int *argmax[2];             // [B,100]
+    float *g_pooled[2];                           // [B,100]   (training only)
+    float *mult;                                  // [B, 2L] dropout multipliers
+    float *x, *s, *g, *gz;                        // [B,2L], [B,8], [B], [B,2L]
+    float *pred, *se;                             // [B]
+    int64_t B;
+    int L, tiles, training, want_grad;
+    float p_drop, inv_denom;
+    uint64_t seed, offset;
+};
+
+__device__ __forceinline__ uint32_t philox_first_word(uint64_t ctr, uint64_t seed) {
+    uint32_t c0 = (uint32_t)ctr, c1 = (uint32_t)(ctr >> 32), c2 = 0u, c3 = 0u;
+    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+        const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        const uint32_t n1 = (uint32_t)p1;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        const uint32_t n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    return c0;
+}
+
+// One wave per rating; 4 ratings per 256-thread workgroup.
+__global__ __launch_bounds__(256) void deepconn_head_kernel(HeadArgs a) {
+    __shared__ float sp[4][2][F_CONV + 4];     // pooled, per wave
+    __shared__ float sz[4][2 * MAX_L];         // gz, per wave
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int64_t b_raw = (int64_t)blockIdx.x * 4 + w;
+    const bool live = b_raw < a.B;             // a dead wave shadows the last rating and stores nothing
+    const int64_t b = live ? b_raw : a.B - 1;
+    const int L = a.L, n = 2 * L;
+
+    // ---- pool finish: max over tiles, relu, first argmax
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+        for (int f = lane; f < F_CONV; f += 64) {
+            float best = -INFINITY;
+            int bp = -1;
+            for (int k = 0; k < a.tiles; ++k) {
+                const size_t o = ((size_t)b * a.tiles + k) * NP + f;
+                const float v = a.pmax[t][o];
+                if (v > best) { best = v; bp = a.parg[t][o]; }
+            }
+            if (!(best > 0.f)) { best = 0.f; bp = -1; }
+            sp[w][t][f] = best;
+            if (live) {
+                a.pooled[t][b * F_CONV + f] = best;
+                a.argmax[t][b * F_CONV + f] = bp;
+            }
+        }
+    __syncthreads();
+
+    // ---- FC: z[t][l] = b[l] + sum_f pooled[t][f] W[t][l][f]; lane i < 2L ends up owning x_i
+    float xi = 0.f;
+    for (int i = 0; i < n; ++i) {
+        const int t = i / L, l = i - t * L;
+        float part = 0.f;
+        for (int f = lane; f < F_CONV; f += 64) part = fmaf(sp[w][t][f], a.fc_w[t][l * F_CONV + f], part);
+        part = wave_sum(part);
+        if (lane == i) xi = part + a.fc_b[t][l];
+    }
+    // ---- dropout on the FC output (common_pytorch_models.py:37)
+    float mult = 1.f;
+    if (a.training && a.p_drop > 0.f && lane < n) {
+        const uint32_t r = philox_first_word(a.offset + (uint64_t)(b * n + lane), a.seed);
+        const float u = (float)(r >> 8) * (1.0f / 16777216.0f);
+        mult = (u >= a.p_drop) ? 1.f / (1.f - a.p_drop) : 0.f;
+    }
+    xi *= mult;
+    if (lane >= n) xi = 0.f;
+
+    // ---- FM (common_pytorch_models.py:49-57) + global bias
+    float inter = 0.f, gacc = 0.f;
+    float sk_keep[FM_K];
+#pragma unroll
+    for (int k = 0; k < FM_K; ++k) {
+        const float v = (lane < n) ? a.V[lane * FM_K + k] : 0.f;
+        const float s = wave_sum(xi * v);
+        const float s2 = wave_sum(xi * xi * v * v);
+        inter += s * s - s2;
+        gacc += s * v - xi * v * v;
+        sk_keep[k] = s;
+    }
+    const float lw = (lane < n) ? a.lin_w[lane] : 0.f;
+    const float lin = wave_sum(xi * lw);
+    const float pred = (0.5f * inter + lin + a.lin_b[0]) + a.gbias[0];
+    if (lane == 0 && live) a.pred[b] = pred;
+    if (!a.y) return;                                      // uniform across the grid
+    const float d = pred - a.y[b];
+    if (lane == 0 && live) a.se[b] = d * d;
+    if (!a.want_grad) return;                              // uniform across the grid
+
+    // ---- backward of the head down to g_pooled
+    const float g = 2.f * d * a.inv_denom;                 // d mean(SE) / d pred
+    const float gx = g * (gacc + lw);                      // d / d x_i
+    const float gz = gx * mult;                            // through dropout
+    if (lane < n) {
+        sz[w][lane] = gz;
+        if (live) {
+            a.x[b * n + lane] = xi;
+            a.gz[b * n + lane] = gz;
+            a.mult[b * n + lane] = mult;
+        }
+    }
+    if (lane < FM_K && live) {
+        float sv = 0.f;
+#pragma unroll
+        for (int k = 0; k < FM_K; ++k) if (lane == k) sv = sk_keep[k];
+        a.s[b * FM_K + lane] = sv;
+    }
+    if (lane == 0 && live) a.g[b] = g;
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+        for (int f = lane; f < F_CONV; f += 64) {
+            float acc = 0.f;
+            for (int l = 0; l < L; ++l) acc = fmaf(sz[w][t * L + l], a.fc_w[t][l * F_CONV + f], acc);
+            if (live) a.g_pooled[t][b * F_CONV + f] = acc;
+        }
+}
+
+struct HeadGradArgs {
+    const float *pooled[2];      // [B,100]
+    const float *x, *s, *g, *gz; // [B,2L], [B,8], [B], [B,2L]
+    const float *V;              // [2L,8]
+    const float *se;             // [B]
+    float *g_fc_w[2], *g_fc_b[2], *g_V, *g_lin_w, *g_lin_b, *g_gb;
+    float *sse_accum;            // nullable: += sum_b se[b]
+    int64_t B;
+    int L;
+};
+
+// Output element o of the concatenated head-gradient vector, reduced over the batch by
+// 4 row groups of one workgroup column (fixed order -> deterministic).
+__global__ __launch_bounds__(256) void deepconn_head_grad_kernel(HeadGradArgs a) {
+    __shared__ float red[4][64];
+    const int ox = threadIdx.x, rg = threadIdx.y;          // blockDim = (64, 4)
+    const int L = a.L, n = 2 * L;
+    const int n_fcw = L * F_CONV;
+    const int seg[9] = {n_fcw, L, n_fcw, L, n * FM_K, n, 1, 1, 1};   // last: sse accumulator
+    int o = blockIdx.x * 64 + ox;
+    int which = -1, local = 0, acc_o = o;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+        if (which < 0) {
+            if (acc_o < seg[k]) { which = k; local = acc_o; }
+            else acc_o -= seg[k];
+        }
+    }
+    float s = 0.f;
+    if (which >= 0) {
+        for (int64_t b = rg; b < a.B; b += 4) {
+            float term;
+            switch (which) {
+                case 0: case 2: {
+                    const int t = which >> 1, l = local / F_CONV, f = local - l * F_CONV;
+                    term = a.gz[b * n + t * L + l] * a.pooled[t][b * F_CONV + f];
+                } break;
+                case 1: case 3: term = a.gz[b * n + (which >> 1) * L + local]; break;
+                case 4: {
+                    const int i = local / FM_K, k = local - i * FM_K;
+                    const float xi = a.x[b * n + i];
+                    term = a.g[b] * (a.s[b * FM_K + k] * xi - xi * xi * a.V[local]);
+                } break;
+                case 5: term = a.g[b] * a.x[b * n + local]; break;
+                case 6: case 7: term = a.g[b]; break;
+                default: term = a.se[b]; break;
+            }
+            s += term;
+        }
+    }
+    red[rg][ox] = s;
+    __syncthreads();
+    if (rg == 0 && which >= 0) {
+        const float t = red[0][ox] + red[1][ox] + red[2][ox] + red[3][ox];
+        switch (which) {
+            case 0: a.g_fc_w[0][local] = t; break;
+            case 1: a.g_fc_b[0][local] = t; break;
+            case 2: a.g_fc_w[1][local] = t; break;
+            case 3: a.g_fc_b[1][local] = t; break;
+            case 4: a.g_V[local] = t; break;
+            case 5: a.g_lin_w[local] = t; break;
+            case 6: a.g_lin_b[0] = t; break;
+            case 7: a.g_gb[0] = t; break;
+            default: if (a.sse_accum) a.sse_accum[0] += t; break;
+        }
+    }
+}
+
+__global__ void sse_only_kernel(const float *__restrict__ se, float *__restrict__ accum, int64_t B) {
+    __shared__ float red[256];
+    float s = 0.f;
+    for (int64_t i = threadIdx.x; i < B; i += 256) s += se[i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) accum[0] += red[0];
+}
+
+struct StepWs {
+    float *wp[2], *pmax[2]; int *parg[2];
+    float *pooled[2]; int *argmax[2]; float *g_pooled[2];
+    float *mult, *x, *s, *g, *gz;
+    float *part_w[2], *part_b[2];
+    size_t bytes;
+};
+
+static StepWs carve(void *ws, int64_t B, int T, int E, int L) {
+    StepWs w;
+    char *p = static_cast<char *>(ws);
+    auto take = [&](size_t nbytes) { char *r = p; p += align256(nbytes); return r; };
+    const size_t tiles128 = (size_t)(T + 2 + 127) / 128;
+    const int ns = textcnn_wgrad_splits(B);
+    for (int t = 0; t < 2; ++t) {
+        w.wp[t] = reinterpret_cast<float *>(take(textcnn_wp_floats(E) * 4));
+        w.pmax[t] = reinterpret_cast<float *>(take((size_t)B * tiles128 * NP * 4));
+        w.parg[t] = reinterpret_cast<int *>(take((size_t)B * tiles128 * NP * 4));
+        w.pooled[t] = reinterpret_cast<float *>(take((size_t)B * F_CONV * 4));
+        w.argmax[t] = reinterpret_cast<int *>(take((size_t)B * F_CONV * 4));
+        w.g_pooled[t] = reinterpret_cast<float *>(take((size_t)B * F_CONV * 4));
+        w.part_w[t] = reinterpret_cast<float *>(take((size_t)ns * F_CONV * 3 * E * 4));
+        w.part_b[t] = reinterpret_cast<float *>(take((size_t)ns * F_CONV * 4));
+    }
+    w.mult = reinterpret_cast<float *>(take((size_t)B * 2 * L * 4));
+    w.x = reinterpret_cast<float *>(take((size_t)B * 2 * L * 4));
+    w.gz = reinterpret_cast<float *>(take((size_t)B * 2 * L * 4));
+    w.s = reinterpret_cast<float *>(take((size_t)B * FM_K * 4));
+    w.g = reinterpret_cast<float *>(take((size_t)B * 4));
+    w.bytes = (size_t)(p - static_cast<char *>(ws));
+    return w;
+}
+
+}  // namespace r4r
+
+using namespace r4r;
+
+extern "C" int r4r_deepconn_nparam(void) { return P_COUNT; }
+
+extern "C" int r4r_deepconn_layout(int E, int L, int64_t *offsets, int64_t *sizes, int64_t *total) {
+    R4R_REQUIRE(E > 0 && L > 0 && L <= MAX_L && offsets && sizes && total, "deepconn_layout: bad arguments");
+    const Layout lay = make_layout(E, L);
+    for (int i = 0; i < P_COUNT; ++i) { offsets[i] = lay.off[i]; sizes[i] = lay.size[i]; }
+    *total = lay.total;
+    return R4R_OK;
+}
+
+extern "C" size_t r4r_deepconn_ws_bytes(int64_t B, int T, int E, int L) {
+    if (B < 0 || T <= 0 || E <= 0 || L <= 0) return 0;
+    return carve(nullptr, B, T, E, L).bytes;
+}
+
+// Byte offset of the [B, 2L] dropout-multiplier block inside the workspace (so a test can
+// inject the very masks the device drew into the CPU oracle).
+extern "C" size_t r4r_deepconn_ws_mult_offset(int64_t B, int T, int E, int L) {
+    char base[1];
+    const StepWs w = carve(base, B, T, E, L);
+    return (size_t)(reinterpret_cast<char *>(w.mult) - base);
+}
+
+extern "C" int r4r_deepconn_step(const float *table, int64_t V, const int64_t *user_idx, const int64_t *item_idx,
+                                 const float *y, const float *flat_p, float *flat_g,
+                                 float *pred, float *se, float *sse_accum,
+                                 void *ws, size_t ws_bytes,
+                                 int64_t B, int T, int E, int L,
+                                 float dropout_p, int training, uint64_t seed, uint64_t offset,
+                                 float inv_denom, void *stream) {
+    R4R_REQUIRE(table && user_idx && item_idx && flat_p && pred && ws, "deepconn_step: null pointer");
+    R4R_REQUIRE(V > 0 && B >= 0 && T > 0, "deepconn_step: bad sizes");
+    R4R_REQUIRE(E > 0 && E % 4 == 0, "deepconn_step: word_embed_size %d must be a positive multiple of 4", E);
+    R4R_REQUIRE(L > 0 && L <= MAX_L, "deepconn_step: latent_size %d outside 1..%d", L, MAX_L);
+    R4R_REQUIRE(!flat_g || (y && se), "deepconn_step: gradients need ratings y and the se buffer");
+    R4R_REQUIRE(!y || se, "deepconn_step: se buffer required when y is given");
+    R4R_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, "deepconn_step: dropout %f outside [0,1)", (double)dropout_p);
+    R4R_REQUIRE(B * (int64_t)((T + 2 + 127) / 128) < (1ll << 31), "deepconn_step: grid too large");
+    if (ws_bytes < r4r_deepconn_ws_bytes(B, T, E, L)) {
+        set_error("deepconn_step: workspace %zu < %zu bytes", ws_bytes, r4r_deepconn_ws_bytes(B, T, E, L));
+        return R4R_ERR_WORKSPACE;
+    }
+    if (B == 0) return R4R_OK;
+    hipStream_t st = as_stream(stream);
+    const Layout lay = make_layout(E, L);
+    const StepWs w = carve(ws, B, T, E, L);
+    const float *P[P_COUNT];
+    float *G[P_COUNT];
+    for (int i = 0; i < P_COUNT; ++i) {
+        P[i] = flat_p + lay.off[i];
+        G[i] = flat_g ? flat_g + lay.off[i] : nullptr;
+    }
+
+    // 1+2: both towers, one grid
+    FwdTower ft[2];
+    const int64_t *idx[2] = {user_idx, item_idx};
+    for (int t = 0; t < 2; ++t) {
+        ft[t].idx = idx[t];
+        ft[t].conv_w = P[t ? P_ICW : P_UCW];
+        ft[t].conv_b = P[t ? P_ICB : P_UCB];
+        ft[t].wp = w.wp[t]; ft[t].pmax = w.pmax[t]; ft[t].parg = w.parg[t];
+    }
+    if (int rc = textcnn_fwd_launch(table, ft, 2, B, T, E, F_CONV, st)) return rc;
+
+    // 3: head forward (+ its backward)
+    HeadArgs h;
+    for (int t = 0; t < 2; ++t) {
+        h.pmax[t] = w.pmax[t]; h.parg[t] = w.parg[t];
+        h.fc_w[t] = P[t ? P_IFW : P_UFW]; h.fc_b[t] = P[t ? P_IFB : P_UFB];
+        h.pooled[t] = w.pooled[t]; h.argmax[t] = w.argmax[t]; h.g_pooled[t] = w.g_pooled[t];
+    }
+    h.V = P[P_FMV]; h.lin_w = P[P_FMLW]; h.lin_b = P[P_FMLB]; h.gbias = P[P_GB];
+    h.y = y; h.mult = w.mult; h.x = w.x; h.s = w.s; h.g = w.g; h.gz = w.gz;
+    h.pred = pred; h.se = se;
+    h.B = B; h.L = L; h.tiles = textcnn_tiles(T); h.training = training; h.want_grad = flat_g != nullptr;
+    h.p_drop = dropout_p; h.inv_denom = inv_denom; h.seed = seed; h.offset = offset;
+    deepconn_head_kernel<<<(unsigned)cdiv(B, 4), 256, 0, st>>>(h);
+
+    if (!flat_g) {
+        if (y && sse_accum) sse_only_kernel<<<1, 256, 0, st>>>(se, sse_accum, B);
+        return check_launch("deepconn_step(forward)");
+    }
+
+    // 4: head parameter gradients (+ running sum of SE)
+    HeadGradArgs hg;
+    for (int t = 0; t < 2; ++t) {
+        hg.pooled[t] = w.pooled[t];
+        hg.g_fc_w[t] = G[t ? P_IFW : P_UFW]; hg.g_fc_b[t] = G[t ? P_IFB : P_UFB];
+    }
+    hg.x = w.x; hg.s = w.s; hg.g = w.g; hg.gz = w.gz; hg.V = P[P_FMV]; hg.se = se;
+    hg.g_V = G[P_FMV]; hg.g_lin_w = G[P_FMLW]; hg.g_lin_b = G[P_FMLB]; hg.g_gb = G[P_GB];
+    hg.sse_accum = sse_accum; hg.B = B; hg.L = L;
+    const int nout = 2 * (L * F_CONV + L) + 2 * L * FM_K + 2 * L + 3;
+    deepconn_head_grad_kernel<<<(nout + 63) / 64, dim3(64, 4), 0, st>>>(hg);
+
+    // 5+6: conv weight gradients of both towers, straight into the flat buffer
+    WgradTower wt[2];
+    for (int t = 0; t < 2; ++t) {
+        wt[t].idx = idx[t]; wt[t].g_pooled = w.g_pooled[t]; wt[t].argmax = w.argmax[t];
+        wt[t].part_w = w.part_w[t]; wt[t].part_b = w.part_b[t];
+        wt[t].d_w = G[t ? P_ICW : P_UCW]; wt[t].d_b = G[t ? P_ICB : P_UCB];
+    }
+    return textcnn_wgrad_launch(table, wt, 2, B, T, E, F_CONV, st);
+}

@@ -1,0 +1,46 @@
+// Internal launch interface of the TextCNN tower kernels (textcnn.hip), shared with
+// the fused model steps (engine.hip).  Up to 4 towers run in ONE grid (blockIdx.y).
+#pragma once
+#include "common.h"
+
+namespace r4r {
+
+constexpr int NP = 112;          // filters padded to 7 MFMA column tiles of 16
+constexpr int MAX_TOWERS = 4;
+
+struct FwdTower {
+    const int64_t *idx;          // [N, T] token ids
+    const float *conv_w;         // [F, 3, E]
+    const float *conv_b;         // [F]
+    float *wp;                   // packed weight image, textcnn_wp_floats(E) floats
+    float *pmax;                 // [N, tiles, NP] per-tile running max (pre-relu)
+    int *parg;                   // [N, tiles, NP] per-tile first argmax
+};
+
+struct WgradTower {
+    const int64_t *idx;          // [N, T]
+    const float *g_pooled;       // [N, F]
+    const int *argmax;           // [N, F]
+    float *part_w;               // [nsplit, F, 3E]
+    float *part_b;               // [nsplit, F]
+    float *d_w;                  // [F, 3, E]   (overwritten)
+    float *d_b;                  // [F]
+};
+
+size_t textcnn_wp_floats(int E);
+int textcnn_tile_rows(int T);                  // conv positions per workgroup tile chosen for T
+int textcnn_tiles(int T);                      // tiles per document
+int textcnn_wgrad_splits(int64_t N);
+
+// pack the weight images, then the MFMA tile kernel over all towers; partials land in pmax/parg
+int textcnn_fwd_launch(const float *table, const FwdTower *tw, int ntower,
+                       int64_t N, int T, int E, int F, hipStream_t st);
+// pooled = max(0, max over tiles), argmax = first position or -1
+int textcnn_pool_finish_launch(const float *pmax, const int *parg, float *pooled, int *argmax,
+                               int64_t N, int T, int F, hipStream_t st);
+int textcnn_wgrad_launch(const float *table, const WgradTower *tw, int ntower,
+                         int64_t N, int T, int E, int F, hipStream_t st);
+
+static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+}  // namespace r4r

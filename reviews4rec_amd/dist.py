@@ -119,6 +119,12 @@ class DataParallel:
             p.grad = v
 
     @torch.no_grad()
+    def allreduce_flat(self, flat):
+        """The fused engine's gradients already live in one flat buffer: one all-reduce, no copies."""
+        if self.on:
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+
+    @torch.no_grad()
     def sum_scalar(self, t):
         if self.on:
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)

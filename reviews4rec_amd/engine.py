@@ -1,0 +1,150 @@
+"""Native fused training engine for DeepCoNN ('deepconn' mode).
+
+``DeepCoNNEngine(model, ...)`` takes the drop-in ``DeepCoNN`` module, moves its
+trainable parameters into ONE flat device buffer (the module's Parameters become
+views of it, so ``model(data)``, ``state_dict()`` and checkpoints keep working) and
+runs a whole training step -- forward, loss, backward, gradient all-reduce, Adam --
+as two C calls: ``r4r_deepconn_step`` (6 kernels) and ``r4r_adam_multi`` (1 kernel).
+
+Host-loop contract restated from main.py:26-60: zero_grad -> forward -> per-example SE
+(summed into the running train metric) -> mean -> backward -> optimizer.step().  The
+running metric lives on the device (``sse``) and is read once per epoch, which gives
+the same number as the reference's per-batch ``float(torch.sum(loss))`` without a
+device->host sync per step.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import ptr
+
+
+class DeepCoNNEngine:
+    def __init__(self, model, lr=0.002, weight_decay=1e-6, betas=(0.9, 0.999), eps=1e-8, dp=None,
+                 seed=0x5EED5EED, rank=0):
+        hp = model.hyper_params
+        if hp['model_type'] != 'deepconn':
+            raise ValueError("DeepCoNNEngine implements model_type 'deepconn' (FM head); use the module path "
+                             "+ reviews4rec_amd.optim.Adam for %r" % (hp['model_type'],))
+        self.model, self.hp, self.dp = model, hp, dp
+        self.lr, self.wd, self.betas, self.eps = float(lr), float(weight_decay), tuple(betas), float(eps)
+        self.table = model.word2vec.weight
+        if not self.table.is_cuda:
+            raise RuntimeError('DeepCoNNEngine: move the model to a ROCm device first; the HIP path has no '
+                               'CPU fallback')
+        self.dev = self.table.device
+        self.V, self.E = self.table.shape
+        self.L = hp['latent_size']
+        lib = _lib.lib()
+        n = lib.r4r_deepconn_nparam()
+        off, size, total = (ctypes.c_int64 * n)(), (ctypes.c_int64 * n)(), ctypes.c_int64()
+        _lib.check(lib.r4r_deepconn_layout(self.E, self.L, off, size, ctypes.byref(total)), 'r4r_deepconn_layout')
+        m = model
+        self.slots = [m.user_conv.convs[0].weight, m.user_conv.convs[0].bias, m.user_conv.fc.weight,
+                      m.user_conv.fc.bias, m.item_conv.convs[0].weight, m.item_conv.convs[0].bias,
+                      m.item_conv.fc.weight, m.item_conv.fc.bias, m.fm.V, m.fm.lin.weight, m.fm.lin.bias,
+                      m.global_bias]
+        self.offsets, self.sizes, self.total = list(off), list(size), int(total.value)
+        self.flat_p = torch.zeros(self.total, dtype=torch.float32, device=self.dev)
+        for p, o, s in zip(self.slots, self.offsets, self.sizes):
+            assert p.numel() == s, (tuple(p.shape), s)
+            view = self.flat_p[o:o + s].view(p.shape)
+            view.copy_(p.data)
+            p.data = view                       # the Parameter now aliases the flat buffer
+        self.flat_g = torch.zeros_like(self.flat_p)
+        self.flat_m = torch.zeros_like(self.flat_p)
+        self.flat_v = torch.zeros_like(self.flat_p)
+        self.sse = torch.zeros(1, dtype=torch.float32, device=self.dev)     # running sum of SE
+        self.step_count = 0
+        self.seed = (int(seed) * 0x9E3779B97F4A7C15 + int(rank) * 0xD1B54A32D192ED03) & 0xFFFFFFFFFFFFFFFF
+        self.offset = 0
+        self._ws = None
+        self._ws_key = None
+        self._out = {}
+
+    # ------------------------------------------------------------------ buffers
+    def _workspace(self, B, T):
+        key = (B, T)
+        if self._ws_key != key:
+            nb = _lib.lib().r4r_deepconn_ws_bytes(B, T, self.E, self.L)
+            self._ws = torch.empty(max(nb, 256), dtype=torch.uint8, device=self.dev)
+            self._ws_key = key
+        return self._ws
+
+    def _outputs(self, B):
+        if B not in self._out:
+            self._out[B] = (torch.empty(B, dtype=torch.float32, device=self.dev),
+                            torch.empty(B, dtype=torch.float32, device=self.dev))
+        return self._out[B]
+
+    def dropout_multipliers(self, B, T):
+        """[B, 2L] multipliers the last training step drew (columns: user tower L, item tower L)."""
+        off = _lib.lib().r4r_deepconn_ws_mult_offset(B, T, self.E, self.L)
+        raw = self._workspace(B, T)[off:off + B * 2 * self.L * 4]
+        return raw.view(torch.float32).view(B, 2 * self.L).clone()
+
+    # -------------------------------------------------------------------- steps
+    def _launch(self, data, y, grad, training, inv_denom):
+        user_idx, item_idx = data[3], data[4]
+        n = data[5].numel()
+        user_idx = user_idx.reshape(n, -1)
+        item_idx = item_idx.reshape(n, -1)
+        if not (user_idx.is_cuda and user_idx.dtype == torch.int64):
+            raise RuntimeError('DeepCoNNEngine: batches must be int64 tensors on the ROCm device')
+        user_idx, item_idx = user_idx.contiguous(), item_idx.contiguous()
+        T = user_idx.shape[1]
+        pred, se = self._outputs(n)
+        ws = self._workspace(n, T)
+        p_drop = float(self.hp['dropout'])
+        rc = _lib.lib().r4r_deepconn_step(
+            ptr(self.table), self.V, ptr(user_idx), ptr(item_idx), ptr(y), ptr(self.flat_p),
+            ptr(self.flat_g) if grad else None, ptr(pred), ptr(se), ptr(self.sse) if y is not None else None,
+            ptr(ws), ws.numel(), n, T, self.E, self.L, p_drop, int(training), self.seed, self.offset,
+            float(inv_denom), _lib.current_stream())
+        _lib.check(rc, 'r4r_deepconn_step')
+        if training and p_drop > 0.0:
+            self.offset += n * 2 * self.L
+        return pred, se
+
+    def train_step(self, data, y, n_global=None):
+        """One optimisation step on this rank's shard.  Returns the per-example SE tensor
+        (device); the running sum is in ``self.sse``."""
+        n = data[5].numel()
+        y = y.reshape(-1).contiguous()
+        denom = float(n_global if n_global is not None else n * (self.dp.world if self.dp else 1))
+        _, se = self._launch(data, y, grad=True, training=self.model.training, inv_denom=1.0 / denom)
+        if self.dp is not None and self.dp.on:
+            self.dp.allreduce_flat(self.flat_g)
+        self.step_count += 1
+        one = ctypes.c_uint64 * 1
+        rc = _lib.lib().r4r_adam_multi(1, one(self.flat_p.data_ptr()), one(self.flat_g.data_ptr()),
+                                       one(self.flat_m.data_ptr()), one(self.flat_v.data_ptr()),
+                                       (ctypes.c_int64 * 1)(self.total), self.lr, self.betas[0], self.betas[1],
+                                       self.eps, self.wd, self.step_count, _lib.current_stream())
+        _lib.check(rc, 'r4r_adam_multi')
+        return se
+
+    @torch.no_grad()
+    def predict(self, data, y=None):
+        """Eval-mode forward (no dropout, no gradients).  Returns (pred, se or None)."""
+        if y is not None:
+            y = y.reshape(-1).contiguous()
+        pred, se = self._launch(data, y, grad=False, training=False, inv_denom=1.0)
+        shape = tuple(data[5].shape)
+        return pred.view(shape), (se.view(shape) if y is not None else None)
+
+    def grads(self):
+        """Named views of the flat gradient buffer (reference parameter names)."""
+        names = ['user_conv.convs.0.weight', 'user_conv.convs.0.bias', 'user_conv.fc.weight', 'user_conv.fc.bias',
+                 'item_conv.convs.0.weight', 'item_conv.convs.0.bias', 'item_conv.fc.weight', 'item_conv.fc.bias',
+                 'fm.V', 'fm.lin.weight', 'fm.lin.bias', 'global_bias']
+        return {k: self.flat_g[o:o + s].view(p.shape) for k, p, o, s in
+                zip(names, self.slots, self.offsets, self.sizes)}
+
+    def moments(self):
+        names = list(self.grads())
+        return ({k: self.flat_m[o:o + s].view(p.shape) for k, p, o, s in
+                 zip(names, self.slots, self.offsets, self.sizes)},
+                {k: self.flat_v[o:o + s].view(p.shape) for k, p, o, s in
+                 zip(names, self.slots, self.offsets, self.sizes)})
