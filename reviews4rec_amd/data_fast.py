@@ -1,0 +1,89 @@
+"""Fast batcher (counterpart of the reference's data_fast.py).
+
+Same contract as ``data_fast.DataLoader`` (data_fast.py:14-123): the whole split is
+resident in host RAM as 8 arrays ``a..h`` (this_reviews, users_who_reviewed,
+reviewed_items, user_reviews, item_reviews, user, item, rating -- the datasets
+make_quick_data.py:23-32 writes), ``len(loader)`` is the number of batches, and
+``iter()`` yields contiguous slices of ``batch_size`` rows -- no shuffling, ragged
+last batch -- as ``([7 int64 device tensors], float32 device tensor)``.
+
+On-disk format: the reference uses gzip HDF5 through h5py, which does not exist in
+this image; the same 8 datasets are stored as one ``.npz`` per split
+(``train.npz`` / ``val.npz`` / ``test.npz`` under ``quick_data_*/<data_dir>``), i8 / f8
+like the HDF5 writer.  ``from_arrays`` builds a loader from in-memory arrays
+(synthetic data).
+
+Host->device: the reference builds 8 tensors per batch from pageable numpy slices
+(3 MB of int64 per DeepCoNN batch, synchronous).  Here the arrays are pinned once and
+every batch is copied with non_blocking=True on the current stream.
+"""
+import os
+
+import numpy as np
+import torch
+
+from .utils import load_obj
+
+KEYS = 'abcdefgh'
+
+
+class DataLoader():
+    def __init__(self, hyper_params, file_name=None, arrays=None, device=None):
+        self.hyper_params = hyper_params
+        self.bsz = int(hyper_params['batch_size'])
+        self.file_name = file_name
+        self.device = device if device is not None else (
+            torch.device('cuda') if torch.cuda.is_available() else torch.device('cpu'))
+        if arrays is None:
+            init_path = '/'.join(hyper_params['data_dir'].split('/')[1:])
+            root = 'quick_data_narre/' if hyper_params['model_type'] in ['NARRE'] else 'quick_data_deepconn/'
+            path = root + init_path + file_name
+            if not os.path.exists(path) and path.endswith('.hdf5'):
+                path = path[:-5] + '.npz'
+            with np.load(path) as z:
+                arrays = {k: z[k] for k in KEYS}
+        self.total = len(arrays['a'])
+        pin = torch.cuda.is_available()
+        self._t = {}
+        for k in KEYS:
+            dt = np.float32 if k == 'h' else np.int64
+            t = torch.from_numpy(np.ascontiguousarray(arrays[k]).astype(dt, copy=False))
+            self._t[k] = t.pin_memory() if pin else t
+
+    @classmethod
+    def from_arrays(cls, hyper_params, data, y, device=None):
+        arrays = dict(zip(KEYS[:7], data))
+        arrays['h'] = y
+        return cls(hyper_params, arrays=arrays, device=device)
+
+    def __len__(self):
+        return int(self.total // self.bsz) + int(self.total % self.bsz > 0)
+
+    def iter(self, eval=False, torch=True):
+        for index in range(0, self.total, self.bsz):
+            sl = slice(index, index + self.bsz)
+            if torch:
+                yield [self._t[k][sl].to(self.device, non_blocking=True) for k in KEYS[:7]], \
+                    self._t['h'][sl].to(self.device, non_blocking=True)
+            else:
+                yield [self._t[k][sl].numpy() for k in KEYS[:7]], self._t['h'][sl].numpy()
+
+
+def save_split(path, data, y):
+    """Write one split in the on-disk format above (i8 ids, f8 ratings)."""
+    os.makedirs(os.path.dirname(path) or '.', exist_ok=True)
+    arrays = {k: np.asarray(d, dtype=np.int64) for k, d in zip(KEYS[:7], data)}
+    arrays['h'] = np.asarray(y, dtype=np.float64)
+    np.savez(path, **arrays)
+
+
+def load_data_fast(hyper_params):
+    print('Loading data...')
+    num_users, num_items, num_words = load_obj(hyper_params['data_dir'] + 'num_users_items')
+    hyper_params['total_users'] = num_users
+    hyper_params['total_items'] = num_items
+    hyper_params['total_words'] = num_words
+    train_loader = DataLoader(hyper_params, 'train.hdf5')
+    test_loader = DataLoader(hyper_params, 'test.hdf5')
+    val_loader = DataLoader(hyper_params, 'val.hdf5')
+    return train_loader, test_loader, val_loader, hyper_params

@@ -1,0 +1,181 @@
+"""Training loop (counterpart of the reference's main.py train / train_complete /
+main_pytorch).  The per-batch sequence is the reference's (main.py:26-60):
+
+    zero_grad -> forward -> per-example SE -> metrics += sum(SE) -> mean -> backward -> step
+
+and ``metrics['MSE'] = round(sum SE / N, 4)`` (main.py:66).  Two deliberate host-side
+differences, both numerically neutral: the running sum of SE stays on the device and
+is read once per epoch (the reference syncs with ``float(torch.sum(..))`` every
+batch, main.py:57), and ``optimizer`` is this package's fused Adam (same surface).
+With ``hyper_params['engine'] == 'native'`` and a model that has a fused step
+(DeepCoNN 'deepconn'), the whole sequence runs as one native call per batch.
+
+TransNet's three-optimiser step (main.py:35-53) raises on torch >= 1.5 in the
+reference; ``train`` restates its torch-0.4 behaviour: the three
+backward passes run against one retained graph of pre-step activations while each
+optimiser writes through ``.data`` (no autograd version bump).
+"""
+import datetime as dt
+import time
+
+import torch
+
+from .eval import evaluate, eval_ranking
+from .loss import MSELoss
+from .utils import file_write, init_transnet_optim, is_cuda_available, log_end_epoch, xavier_init
+
+INF = 10000.0
+
+
+def _is_transnet(hyper_params):
+    return hyper_params['model_type'] in ['transnet', 'transnet++']
+
+
+def train(model, criterion, optimizer, reader, hyper_params, engine=None, dp=None):
+    model.train()
+    tn = _is_transnet(hyper_params)
+    metrics = {'MSE': 0.0}
+    if tn:
+        metrics['MSE_target'], metrics['MSE_transform'] = 0.0, 0.0
+    total_x, total_batches = 0.0, 0.0
+    device_sum = None
+    if engine is not None:
+        engine.sse.zero_()
+
+    for data, y in reader.iter():
+        n_local = int(y.shape[0])
+        n_global = dp.global_count(n_local, y.device) if (dp is not None and dp.on) else n_local
+        if engine is not None:
+            engine.train_step(data, y, n_global=n_global)
+            total_x += float(n_local)
+            total_batches += 1
+            continue
+
+        model.zero_grad()
+        if tn:
+            for o in optimizer:
+                o.zero_grad()
+        else:
+            optimizer.zero_grad()
+        all_output = model(data)
+
+        if tn:
+            optimizer_source, optimizer_source_fm, optimizer_target, optimizer_all = optimizer
+            loss_target = criterion(all_output[1], y)
+            loss_target.backward(retain_graph=True)
+            optimizer_target.step()
+            loss_transform = all_output[2]
+            loss_transform.backward(retain_graph=True)
+            optimizer_source.step()
+            loss_source = criterion(all_output[0], y, return_mean=False)
+            se_sum = torch.sum(loss_source.detach())
+            torch.mean(loss_source).backward()
+            optimizer_source_fm.step()
+            metrics['MSE_target'] += float(loss_target.detach())
+            metrics['MSE_transform'] += float(loss_transform.detach())
+        else:
+            loss = criterion(all_output, y, return_mean=False)
+            se_sum = torch.sum(loss.detach())
+            (torch.sum(loss) / float(n_global)).backward()       # == torch.mean(loss) on one rank
+            if dp is not None:
+                dp.allreduce_grads()
+            optimizer.step()
+        device_sum = se_sum if device_sum is None else device_sum + se_sum
+        total_x += float(n_local)
+        total_batches += 1
+
+    sse = float(engine.sse.item()) if engine is not None else (float(device_sum) if device_sum is not None else 0.0)
+    if dp is not None and dp.on:
+        t = torch.tensor([sse, total_x], dtype=torch.float64, device=next(model.parameters()).device)
+        dp.sum_scalar(t)
+        sse, total_x = float(t[0]), float(t[1])
+    metrics['MSE'] = round(sse / float(total_x), 4)
+    if tn:
+        metrics['MSE_target'] = round(metrics['MSE_target'] / float(total_batches), 4)
+        metrics['MSE_transform'] = round(metrics['MSE_transform'] / float(total_batches), 4)
+    return metrics
+
+
+def make_optimizer(hyper_params, model):
+    from .optim import Adam
+    if _is_transnet(hyper_params):
+        return init_transnet_optim(hyper_params, model)
+    return Adam(model.parameters(), lr=hyper_params['lr'], weight_decay=hyper_params['weight_decay'])
+
+
+def make_engine(hyper_params, model, dp=None, rank=0):
+    """The fused native step, where the model has one and the config asks for it."""
+    if hyper_params.get('engine', 'native') != 'native' or hyper_params['model_type'] != 'deepconn':
+        return None
+    from .engine import DeepCoNNEngine
+    return DeepCoNNEngine(model, lr=hyper_params['lr'], weight_decay=hyper_params['weight_decay'], dp=dp,
+                          seed=hyper_params.get('seed', 0x5EED5EED), rank=rank)
+
+
+def train_complete(hyper_params, Model, train_reader, val_reader, user_count, item_count, model, review=True,
+                   dp=None):
+    file_write(hyper_params['log_file'], '\n\nSimulation run on: ' + str(dt.datetime.now()) + '\n\n')
+    file_write(hyper_params['log_file'], 'Data reading complete!')
+    file_write(hyper_params['log_file'], 'Number of train batches: {:4d}'.format(len(train_reader)))
+    file_write(hyper_params['log_file'], 'Number of validation batches: {:4d}'.format(len(val_reader)))
+
+    criterion = MSELoss(hyper_params)
+    rank = dp.rank if dp is not None else 0
+    engine = make_engine(hyper_params, model, dp=dp, rank=rank)
+    optimizer = None if engine is not None else make_optimizer(hyper_params, model)
+
+    file_write(hyper_params['log_file'], str(model))
+    file_write(hyper_params['log_file'], '\nModel Built!\nStarting Training...\n')
+    try:
+        best_MSE = float(INF)
+        for epoch in range(1, hyper_params['epochs'] + 1):
+            epoch_start_time = time.time()
+            metrics = train(model, criterion, optimizer, train_reader, hyper_params, engine=engine, dp=dp)
+            metrics['dataset'] = hyper_params['dataset']
+            metrics, _, _ = evaluate(model, criterion, val_reader, hyper_params, user_count, item_count,
+                                     review=review, engine=engine)
+            metrics['dataset'] = hyper_params['dataset']
+            log_end_epoch(hyper_params, metrics, epoch, time.time() - epoch_start_time, metrics_on='(VAL)')
+            if metrics['MSE'] < best_MSE:
+                if rank == 0:
+                    print('Saving model...')
+                    torch.save(model.state_dict(), hyper_params['model_path'])
+                best_MSE = metrics['MSE']
+    except KeyboardInterrupt:
+        print('Exiting from training early')
+
+    # reload the best-on-validation checkpoint into a fresh model (main.py:131-134)
+    model = Model(hyper_params)
+    if is_cuda_available:
+        model = model.cuda()
+    model.load_state_dict(torch.load(hyper_params['model_path']))
+    model.eval()
+    return model
+
+
+def main_pytorch(hyper_params, readers, user_count=None, item_count=None, review_based_model=True, dp=None,
+                 ranking_reader=None):
+    """Counterpart of main.main_pytorch (main.py:342-399) over already-built readers
+    ``(train, test, val)`` -- the pickle-based slow loader of the reference is out of scope."""
+    import reviews4rec_amd
+    Model = reviews4rec_amd.get_model_class(hyper_params['model_type'])
+    train_reader, test_reader, val_reader = readers
+    user_count = {} if user_count is None else user_count
+    item_count = {} if item_count is None else item_count
+    model = Model(hyper_params)
+    if is_cuda_available:
+        model = model.cuda()
+    xavier_init(model)                                    # main.py:377
+    if dp is not None:
+        dp.model, dp.params = model, [p for p in model.parameters() if p.requires_grad]
+        dp.broadcast_parameters()
+    start_time = time.time()
+    model = train_complete(hyper_params, Model, train_reader, val_reader, user_count, item_count, model,
+                           review=review_based_model, dp=dp)
+    criterion = MSELoss(hyper_params)
+    metrics, user_count_mse_map, item_count_mse_map = evaluate(
+        model, criterion, test_reader, hyper_params, user_count, item_count, review=review_based_model)
+    if ranking_reader is not None:
+        metrics.update(eval_ranking(model, ranking_reader, hyper_params, review=review_based_model))
+    log_end_epoch(hyper_params, metrics, 'final', time.time() - start_time, metrics_on='(TEST)')
+    return metrics, user_count_mse_map, item_count_mse_map

@@ -172,8 +172,21 @@ def run_case(name, hp, V, B, seed, steps=3):
     print('%-22s %7.1f KB  %d arrays' % (name, os.path.getsize(path) / 1024, len(out)))
 
 
+def common_paths():
+    """get_common_path strings for the shipped defaults (hyper_params.py:3-48), as data."""
+    import json
+    from hyper_params import get_common_path, hyper_params as ref_hp     # creates saved_* in the scratch cwd
+    out = {}
+    for mt in ('bias_only', 'MF', 'MF_dot', 'deepconn', 'deepconn++', 'NARRE', 'transnet', 'transnet++'):
+        hp = dict(ref_hp, model_type=mt, only_reviews=False)          # the key the reference forgets (fact 10)
+        out[mt] = get_common_path(hp)
+    json.dump(out, open(os.path.join(OUT, 'common_paths.json'), 'w'), indent=1)
+    print('common_paths.json', len(out), 'entries')
+
+
 def main():
     os.chdir(tempfile.mkdtemp(prefix='r4r_cwd_'))
+    common_paths()
     run_case('mf_bias_only', base_hp('bias_only'), V=4, B=13, seed=1)
     run_case('mf_dot', base_hp('MF_dot', latent_size=8), V=4, B=13, seed=2)
     run_case('mf_full', base_hp('MF', latent_size=6), V=4, B=13, seed=3)

@@ -72,3 +72,25 @@ def synthetic_review_batch(B, T, V, U, I, seed=0, R=None, W=None, device='cpu'):
     y = rng.integers(1, 6, size=(B,)).astype(np.float32)
     return [torch.from_numpy(np.ascontiguousarray(d.astype(np.int64))).to(device) for d in data], \
         torch.from_numpy(y).to(device)
+
+
+class OracleModule(torch.nn.Module):
+    """CPU stand-in with the drop-in models' duck type (Model(hp) -> forward(data)),
+    computing with the oracle.  Lets the host loop / batcher / data-parallel logic be
+    tested where no GPU exists.  TEST ONLY."""
+
+    def __init__(self, hyper_params, params=None, vocab=50, seed=0):
+        super().__init__()
+        import oracle
+        self.hyper_params = hyper_params
+        P = params if params is not None else oracle.init_params(hyper_params, vocab_size=vocab, seed=seed)
+        self.names = list(P)
+        self.plist = torch.nn.ParameterList([
+            torch.nn.Parameter(v.clone(), requires_grad=not k.endswith('word2vec.weight')) for k, v in P.items()])
+
+    def as_dict(self):
+        return dict(zip(self.names, self.plist))
+
+    def forward(self, data):
+        import oracle
+        return oracle.model_forward(self.as_dict(), data, self.hyper_params, train=self.training)
