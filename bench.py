@@ -31,6 +31,7 @@ import numpy as np
 import torch
 
 PEAK_FP32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, dense
+PEAK_HBM_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E spec peak (6.3 TB/s measured achievable)
 WORKLOAD = 'cfg3_deepconn_electronics_e300'
 
 
@@ -46,6 +47,9 @@ def parse():
     ap.add_argument('--cpu-seconds', type=float, default=12.0,
                     help='budget of each half (thread calibration, measurement) of the cpu_baseline leg')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--conv-algo', choices=['auto', 'direct', 'project'], default='auto',
+                    help='native engine: direct gather-fused MFMA conv, or projection GEMM over the distinct '
+                         'tokens + gather-add-max (include/r4r.h R4R_CONV_*)')
     ap.add_argument('--engine', choices=['native', 'module'], default='native',
                     help="native: fused r4r_deepconn_step (6 launches/step); module: op-by-op autograd path")
     return ap.parse_args()
@@ -148,7 +152,8 @@ def main():
     engine = None
     if args.engine == 'native' and hp['model_type'] == 'deepconn':
         from reviews4rec_amd.engine import DeepCoNNEngine
-        engine = DeepCoNNEngine(model, lr=hp['lr'], weight_decay=hp['weight_decay'], dp=dp, seed=4321, rank=rank)
+        engine = DeepCoNNEngine(model, lr=hp['lr'], weight_decay=hp['weight_decay'], dp=dp, seed=4321, rank=rank,
+                                conv_algo={'auto': 0, 'direct': 1, 'project': 2}[args.conv_algo])
 
     def step(i):
         data, y = pool[i % len(pool)]
@@ -180,8 +185,15 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     lib.r4r_timing_enable(0)
-    tot, cnt = ctypes.c_double(), ctypes.c_int64()
-    lib.r4r_timing_read(0, ctypes.byref(tot), ctypes.byref(cnt), 1)
+    slots = {'textcnn_fwd_kernel': 0, 'textcnn_wgrad_kernel': 1, 'adam_multi_kernel': 2,
+             'proj_gemm_kernel': 3, 'proj_gather_max_kernel': 4}
+    timed = {}
+    for name, slot in slots.items():
+        tot, cnt = ctypes.c_double(), ctypes.c_int64()
+        lib.r4r_timing_read(slot, ctypes.byref(tot), ctypes.byref(cnt), 0)
+        if cnt.value:
+            timed[name] = (tot.value / cnt.value, cnt.value)          # (avg ms per launch, launches)
+    lib.r4r_timing_read(0, ctypes.byref(ctypes.c_double()), ctypes.byref(ctypes.c_int64()), 1)
 
     el = torch.tensor([elapsed], device=dev)
     if world > 1:
@@ -200,17 +212,35 @@ def main():
                        'word_embed_size': hp['word_embed_size'], 'input_length': hp['input_length'],
                        'conv_filters': 100, 'latent_size': hp['latent_size'], 'vocab': hp.get('vocab', 0),
                        'dropout': hp['dropout'], 'batch_per_gpu': B, 'global_batch': B_global,
-                       'parallelism': 'dp%d' % world, 'engine': 'native' if engine is not None else 'module'},
+                       'parallelism': 'dp%d' % world, 'engine': 'native' if engine is not None else 'module',
+                       'conv_algo': args.conv_algo},
         }
-        if cnt.value and hp.get('vocab'):
-            towers = 2 if engine is not None else 1          # the native step runs both towers in one launch
+        result['kernel_ms'] = {k: round(v[0], 4) for k, v in timed.items()}
+        towers = 2 if engine is not None else 1              # the native step runs both towers per launch
+        positions = towers * B * (hp['input_length'] + 2)
+        if 'proj_gather_max_kernel' in timed:
+            # project-then-gather: the gather-add-max kernel is HBM/L2-bound.  Algorithmic bytes per
+            # launch: every position reads its three 400-B tap rows + an 8-B token id.
+            avg_s = timed['proj_gather_max_kernel'][0] / 1000.0
+            nbytes = towers * B * hp['input_length'] * (8 + 1200)
+            ach = nbytes / avg_s / 1e9
+            result['roofline'] = {'kernel': 'proj_gather_max_kernel', 'bound': 'hbm', 'achieved': round(ach, 1),
+                                  'peak': PEAK_HBM_GBS, 'unit': 'GB/s', 'frac': round(ach / PEAK_HBM_GBS, 4),
+                                  'traffic': None, 'launches': timed['proj_gather_max_kernel'][1],
+                                  'avg_launch_ms': round(1000 * avg_s, 4), 'bytes_per_launch': nbytes}
+            g_s = timed['proj_gemm_kernel'][0] / 1000.0
+            result['roofline_conv_equivalent'] = {
+                'note': 'flops of the direct conv this pair of kernels replaces / (gemm + gather time)',
+                'equivalent_TFLOPs': round(towers * B * tower_flops_per_doc(hp) / (avg_s + g_s) / 1e12, 1),
+                'peak_fp32_mfma': PEAK_FP32_MFMA_TFLOPS}
+        elif 'textcnn_fwd_kernel' in timed and hp.get('vocab'):
             flops = towers * B * tower_flops_per_doc(hp)
-            avg_s = tot.value / cnt.value / 1000.0
+            avg_s = timed['textcnn_fwd_kernel'][0] / 1000.0
             ach = flops / avg_s / 1e12
             result['roofline'] = {'kernel': 'textcnn_fwd_kernel', 'bound': 'mfma', 'achieved': round(ach, 2),
                                   'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                                   'frac': round(ach / PEAK_FP32_MFMA_TFLOPS, 4), 'traffic': None,
-                                  'launches': cnt.value, 'avg_launch_ms': round(1000 * avg_s, 4),
+                                  'launches': timed['textcnn_fwd_kernel'][1], 'avg_launch_ms': round(1000 * avg_s, 4),
                                   'flops_per_launch': flops}
         if world == 1 and not args.no_cpu_baseline:
             cpu_hp = {k: v for k, v in hp.items() if k != 'word_vectors'}

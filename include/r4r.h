@@ -210,20 +210,26 @@ int r4r_adam_multi(int ntensor, const uint64_t *p, const uint64_t *g, const uint
  * mean is over 1/inv_denom examples (pass 1/B_global under data parallelism).
  *   flat_g == NULL : forward only (eval, or y == NULL for pure prediction)
  *   training != 0  : dropout(p) on the FC outputs, Philox4x32-10(seed, offset + b*2L + i)
+ *   conv_algo      : R4R_CONV_AUTO | R4R_CONV_DIRECT (gather-fused MFMA conv over every position)
+ *                    | R4R_CONV_PROJECT (projection GEMM over the batch's distinct tokens, then a
+ *                    gather-add-max over positions; same function, different summation order)
  *   pred [B], se [B] (se required when y != NULL); sse_accum (nullable device scalar)
  *   is incremented by sum_b se[b] -- the host's running metric (main.py:57) without a
  *   per-step device->host sync. */
+#define R4R_CONV_AUTO 0
+#define R4R_CONV_DIRECT 1
+#define R4R_CONV_PROJECT 2
 int r4r_deepconn_nparam(void);
 int r4r_deepconn_layout(int E, int L, int64_t *offsets, int64_t *sizes, int64_t *total);
-size_t r4r_deepconn_ws_bytes(int64_t B, int T, int E, int L);
-size_t r4r_deepconn_ws_mult_offset(int64_t B, int T, int E, int L);   /* [B,2L] dropout multipliers (tests) */
+size_t r4r_deepconn_ws_bytes(int64_t B, int T, int E, int L, int64_t V);
+size_t r4r_deepconn_ws_mult_offset(int64_t B, int T, int E, int L, int64_t V);   /* [B,2L] dropout multipliers (tests) */
 int r4r_deepconn_step(const float *table, int64_t V, const int64_t *user_idx, const int64_t *item_idx,
                       const float *y, const float *flat_p, float *flat_g,
                       float *pred, float *se, float *sse_accum,
                       void *ws, size_t ws_bytes,
                       int64_t B, int T, int E, int L,
                       float dropout_p, int training, uint64_t seed, uint64_t offset,
-                      float inv_denom, void *stream);
+                      float inv_denom, int conv_algo, void *stream);
 
 /* ------------------------------------------------------------------------
  * Live kernel timing for bench.py's roofline leg (no reference counterpart: the
@@ -234,6 +240,8 @@ int r4r_deepconn_step(const float *table, int64_t V, const int64_t *user_idx, co
 #define R4R_TIMING_TEXTCNN_FWD 0    /* textcnn_fwd_kernel (the MFMA conv tile kernel) */
 #define R4R_TIMING_TEXTCNN_WGRAD 1  /* textcnn_wgrad_kernel */
 #define R4R_TIMING_ADAM 2           /* adam_multi_kernel */
+#define R4R_TIMING_PROJ_GEMM 3      /* proj_gemm_kernel (projection of the batch's distinct tokens) */
+#define R4R_TIMING_PROJ_GATHER 4    /* proj_gather_max_kernel (gather-add-max over positions) */
 #define R4R_TIMING_SLOTS 8
 int r4r_timing_enable(int on);
 int r4r_timing_read(int slot, double *total_ms, int64_t *count, int reset);

@@ -21,6 +21,8 @@
 //   MSELoss + mean + backward            loss.py:7-11, main.py:56-59
 // 'deepconn' mode never touches `final`, `user_bias`, `item_bias` (DeepCoNN.py:64-66,
 // SURVEY.md fact 7), so they are not in the flat buffer and Adam never sees them.
+#include <stdlib.h>
+
 #include "textcnn.h"
 
 namespace r4r {
@@ -267,13 +269,14 @@ __global__ void sse_only_kernel(const float *__restrict__ se, float *__restrict_
 
 struct StepWs {
     float *wp[2], *pmax[2]; int *parg[2];
+    int *flags[2], *slot[2], *list[2], *count[2]; float *wimg[2], *ptab[2];   // project-then-gather
     float *pooled[2]; int *argmax[2]; float *g_pooled[2];
     float *mult, *x, *s, *g, *gz;
     float *part_w[2], *part_b[2];
     size_t bytes;
 };
 
-static StepWs carve(void *ws, int64_t B, int T, int E, int L) {
+static StepWs carve(void *ws, int64_t B, int T, int E, int L, int64_t V) {
     StepWs w;
     char *p = static_cast<char *>(ws);
     auto take = [&](size_t nbytes) { char *r = p; p += align256(nbytes); return r; };
@@ -288,6 +291,12 @@ static StepWs carve(void *ws, int64_t B, int T, int E, int L) {
         w.g_pooled[t] = reinterpret_cast<float *>(take((size_t)B * F_CONV * 4));
         w.part_w[t] = reinterpret_cast<float *>(take((size_t)ns * F_CONV * 3 * E * 4));
         w.part_b[t] = reinterpret_cast<float *>(take((size_t)ns * F_CONV * 4));
+        w.flags[t] = reinterpret_cast<int *>(take((size_t)V * 4));
+        w.slot[t] = reinterpret_cast<int *>(take((size_t)V * 4));
+        w.list[t] = reinterpret_cast<int *>(take((size_t)proj_row_capacity(B, T, V) * 4));
+        w.count[t] = reinterpret_cast<int *>(take(256));
+        w.wimg[t] = reinterpret_cast<float *>(take(proj_wimg_floats(E) * 4));
+        w.ptab[t] = reinterpret_cast<float *>(take(proj_ptab_floats(B, T, V) * 4));
     }
     w.mult = reinterpret_cast<float *>(take((size_t)B * 2 * L * 4));
     w.x = reinterpret_cast<float *>(take((size_t)B * 2 * L * 4));
@@ -312,16 +321,29 @@ extern "C" int r4r_deepconn_layout(int E, int L, int64_t *offsets, int64_t *size
     return R4R_OK;
 }
 
-extern "C" size_t r4r_deepconn_ws_bytes(int64_t B, int T, int E, int L) {
-    if (B < 0 || T <= 0 || E <= 0 || L <= 0) return 0;
-    return carve(nullptr, B, T, E, L).bytes;
+extern "C" size_t r4r_deepconn_ws_bytes(int64_t B, int T, int E, int L, int64_t V) {
+    if (B < 0 || T <= 0 || E <= 0 || L <= 0 || V <= 0) return 0;
+    return carve(nullptr, B, T, E, L, V).bytes;
+}
+
+// R4R_CONV_ALGO=direct|project pins the algorithm for A/B runs; AUTO picks the
+// projection when the window is wide enough that the MFMA work dominates (E >= 128).
+static int pick_conv_algo(int requested, int E) {
+    static int pin = -1;
+    if (pin < 0) {
+        const char *e = getenv("R4R_CONV_ALGO");
+        pin = !e ? 0 : (e[0] == 'd' ? R4R_CONV_DIRECT : (e[0] == 'p' ? R4R_CONV_PROJECT : 0));
+    }
+    if (pin) return pin;
+    if (requested == R4R_CONV_DIRECT || requested == R4R_CONV_PROJECT) return requested;
+    return E >= 128 ? R4R_CONV_PROJECT : R4R_CONV_DIRECT;
 }
 
 // Byte offset of the [B, 2L] dropout-multiplier block inside the workspace (so a test can
 // inject the very masks the device drew into the CPU oracle).
-extern "C" size_t r4r_deepconn_ws_mult_offset(int64_t B, int T, int E, int L) {
+extern "C" size_t r4r_deepconn_ws_mult_offset(int64_t B, int T, int E, int L, int64_t V) {
     char base[1];
-    const StepWs w = carve(base, B, T, E, L);
+    const StepWs w = carve(base, B, T, E, L, V);
     return (size_t)(reinterpret_cast<char *>(w.mult) - base);
 }
 
@@ -331,7 +353,7 @@ extern "C" int r4r_deepconn_step(const float *table, int64_t V, const int64_t *u
                                  void *ws, size_t ws_bytes,
                                  int64_t B, int T, int E, int L,
                                  float dropout_p, int training, uint64_t seed, uint64_t offset,
-                                 float inv_denom, void *stream) {
+                                 float inv_denom, int conv_algo, void *stream) {
     R4R_REQUIRE(table && user_idx && item_idx && flat_p && pred && ws, "deepconn_step: null pointer");
     R4R_REQUIRE(V > 0 && B >= 0 && T > 0, "deepconn_step: bad sizes");
     R4R_REQUIRE(E > 0 && E % 4 == 0, "deepconn_step: word_embed_size %d must be a positive multiple of 4", E);
@@ -340,14 +362,14 @@ extern "C" int r4r_deepconn_step(const float *table, int64_t V, const int64_t *u
     R4R_REQUIRE(!y || se, "deepconn_step: se buffer required when y is given");
     R4R_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, "deepconn_step: dropout %f outside [0,1)", (double)dropout_p);
     R4R_REQUIRE(B * (int64_t)((T + 2 + 127) / 128) < (1ll << 31), "deepconn_step: grid too large");
-    if (ws_bytes < r4r_deepconn_ws_bytes(B, T, E, L)) {
-        set_error("deepconn_step: workspace %zu < %zu bytes", ws_bytes, r4r_deepconn_ws_bytes(B, T, E, L));
+    if (ws_bytes < r4r_deepconn_ws_bytes(B, T, E, L, V)) {
+        set_error("deepconn_step: workspace %zu < %zu bytes", ws_bytes, r4r_deepconn_ws_bytes(B, T, E, L, V));
         return R4R_ERR_WORKSPACE;
     }
     if (B == 0) return R4R_OK;
     hipStream_t st = as_stream(stream);
     const Layout lay = make_layout(E, L);
-    const StepWs w = carve(ws, B, T, E, L);
+    const StepWs w = carve(ws, B, T, E, L, V);
     const float *P[P_COUNT];
     float *G[P_COUNT];
     for (int i = 0; i < P_COUNT; ++i) {
@@ -355,16 +377,32 @@ extern "C" int r4r_deepconn_step(const float *table, int64_t V, const int64_t *u
         G[i] = flat_g ? flat_g + lay.off[i] : nullptr;
     }
 
-    // 1+2: both towers, one grid
-    FwdTower ft[2];
+    // 1+2: both towers, one grid -- either the direct gather-fused conv or project-then-gather
     const int64_t *idx[2] = {user_idx, item_idx};
-    for (int t = 0; t < 2; ++t) {
-        ft[t].idx = idx[t];
-        ft[t].conv_w = P[t ? P_ICW : P_UCW];
-        ft[t].conv_b = P[t ? P_ICB : P_UCB];
-        ft[t].wp = w.wp[t]; ft[t].pmax = w.pmax[t]; ft[t].parg = w.parg[t];
+    const int algo = pick_conv_algo(conv_algo, E);
+    int tiles;
+    if (algo == R4R_CONV_PROJECT) {
+        ProjTower pt[2];
+        for (int t = 0; t < 2; ++t) {
+            pt[t].idx = idx[t];
+            pt[t].conv_w = P[t ? P_ICW : P_UCW];
+            pt[t].conv_b = P[t ? P_ICB : P_UCB];
+            pt[t].flags = w.flags[t]; pt[t].slot = w.slot[t]; pt[t].list = w.list[t]; pt[t].count = w.count[t];
+            pt[t].wimg = w.wimg[t]; pt[t].ptab = w.ptab[t]; pt[t].pmax = w.pmax[t]; pt[t].parg = w.parg[t];
+        }
+        if (int rc = textcnn_proj_fwd_launch(table, V, pt, 2, B, T, E, F_CONV, st)) return rc;
+        tiles = proj_tiles(T);
+    } else {
+        FwdTower ft[2];
+        for (int t = 0; t < 2; ++t) {
+            ft[t].idx = idx[t];
+            ft[t].conv_w = P[t ? P_ICW : P_UCW];
+            ft[t].conv_b = P[t ? P_ICB : P_UCB];
+            ft[t].wp = w.wp[t]; ft[t].pmax = w.pmax[t]; ft[t].parg = w.parg[t];
+        }
+        if (int rc = textcnn_fwd_launch(table, ft, 2, B, T, E, F_CONV, st)) return rc;
+        tiles = textcnn_tiles(T);
     }
-    if (int rc = textcnn_fwd_launch(table, ft, 2, B, T, E, F_CONV, st)) return rc;
 
     // 3: head forward (+ its backward)
     HeadArgs h;
@@ -376,7 +414,7 @@ extern "C" int r4r_deepconn_step(const float *table, int64_t V, const int64_t *u
     h.V = P[P_FMV]; h.lin_w = P[P_FMLW]; h.lin_b = P[P_FMLB]; h.gbias = P[P_GB];
     h.y = y; h.mult = w.mult; h.x = w.x; h.s = w.s; h.g = w.g; h.gz = w.gz;
     h.pred = pred; h.se = se;
-    h.B = B; h.L = L; h.tiles = textcnn_tiles(T); h.training = training; h.want_grad = flat_g != nullptr;
+    h.B = B; h.L = L; h.tiles = tiles; h.training = training; h.want_grad = flat_g != nullptr;
     h.p_drop = dropout_p; h.inv_denom = inv_denom; h.seed = seed; h.offset = offset;
     deepconn_head_kernel<<<(unsigned)cdiv(B, 4), 256, 0, st>>>(h);
 

@@ -27,6 +27,27 @@ struct WgradTower {
     float *d_b;                  // [F]
 };
 
+// project-then-gather path (project.hip)
+struct ProjTower {
+    const int64_t *idx;          // [N, T]
+    const float *conv_w;         // [F, 3, E]
+    const float *conv_b;         // [F]
+    int *flags;                  // [V]   token-used marks (zeroed by the launcher)
+    int *slot;                   // [V]   token -> dense row of ptab, -1 if unused
+    int *list;                   // [cap] dense row -> token
+    int *count;                  // [1]   number of distinct tokens
+    float *wimg;                 // proj_wimg_floats(E)
+    float *ptab;                 // [cap, 300] projected rows: 3 taps x 100 filters
+    float *pmax;                 // [N, proj_tiles(T), NP]
+    int *parg;
+};
+int proj_tiles(int T);
+size_t proj_wimg_floats(int E);
+int64_t proj_row_capacity(int64_t N, int T, int64_t V);
+size_t proj_ptab_floats(int64_t N, int T, int64_t V);
+int textcnn_proj_fwd_launch(const float *table, int64_t V, const ProjTower *tw, int ntower,
+                            int64_t N, int T, int E, int F, hipStream_t st);
+
 size_t textcnn_wp_floats(int E);
 int textcnn_tile_rows(int T);                  // conv positions per workgroup tile chosen for T
 int textcnn_tiles(int T);                      // tiles per document

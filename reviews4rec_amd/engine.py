@@ -22,12 +22,13 @@ from ._lib import ptr
 
 class DeepCoNNEngine:
     def __init__(self, model, lr=0.002, weight_decay=1e-6, betas=(0.9, 0.999), eps=1e-8, dp=None,
-                 seed=0x5EED5EED, rank=0):
+                 seed=0x5EED5EED, rank=0, conv_algo=0):
         hp = model.hyper_params
         if hp['model_type'] != 'deepconn':
             raise ValueError("DeepCoNNEngine implements model_type 'deepconn' (FM head); use the module path "
                              "+ reviews4rec_amd.optim.Adam for %r" % (hp['model_type'],))
         self.model, self.hp, self.dp = model, hp, dp
+        self.conv_algo = int(conv_algo)          # 0 auto, 1 direct conv, 2 project-then-gather (include/r4r.h)
         self.lr, self.wd, self.betas, self.eps = float(lr), float(weight_decay), tuple(betas), float(eps)
         self.table = model.word2vec.weight
         if not self.table.is_cuda:
@@ -67,7 +68,7 @@ class DeepCoNNEngine:
     def _workspace(self, B, T):
         key = (B, T)
         if self._ws_key != key:
-            nb = _lib.lib().r4r_deepconn_ws_bytes(B, T, self.E, self.L)
+            nb = _lib.lib().r4r_deepconn_ws_bytes(B, T, self.E, self.L, self.V)
             self._ws = torch.empty(max(nb, 256), dtype=torch.uint8, device=self.dev)
             self._ws_key = key
         return self._ws
@@ -80,7 +81,7 @@ class DeepCoNNEngine:
 
     def dropout_multipliers(self, B, T):
         """[B, 2L] multipliers the last training step drew (columns: user tower L, item tower L)."""
-        off = _lib.lib().r4r_deepconn_ws_mult_offset(B, T, self.E, self.L)
+        off = _lib.lib().r4r_deepconn_ws_mult_offset(B, T, self.E, self.L, self.V)
         raw = self._workspace(B, T)[off:off + B * 2 * self.L * 4]
         return raw.view(torch.float32).view(B, 2 * self.L).clone()
 
@@ -101,7 +102,7 @@ class DeepCoNNEngine:
             ptr(self.table), self.V, ptr(user_idx), ptr(item_idx), ptr(y), ptr(self.flat_p),
             ptr(self.flat_g) if grad else None, ptr(pred), ptr(se), ptr(self.sse) if y is not None else None,
             ptr(ws), ws.numel(), n, T, self.E, self.L, p_drop, int(training), self.seed, self.offset,
-            float(inv_denom), _lib.current_stream())
+            float(inv_denom), self.conv_algo, _lib.current_stream())
         _lib.check(rc, 'r4r_deepconn_step')
         if training and p_drop > 0.0:
             self.offset += n * 2 * self.L

@@ -20,10 +20,14 @@ def make_engine(g, dropout=None, **kw):
     return DeepCoNNEngine(model, lr=hp['lr'], weight_decay=hp['weight_decay'], **kw), model, hp
 
 
+ALGOS = [1, 2]      # R4R_CONV_DIRECT, R4R_CONV_PROJECT (include/r4r.h)
+
+
+@pytest.mark.parametrize('algo', ALGOS)
 @pytest.mark.parametrize('case', ['deepconn_e20', 'deepconn_e64'])
-def test_engine_eval_matches_reference_golden(case):
+def test_engine_eval_matches_reference_golden(case, algo):
     g = Golden(case)
-    eng, model, _ = make_engine(g)
+    eng, model, _ = make_engine(g, conv_algo=algo)
     model.eval()
     for k in (0, 1):
         data, y = g.batch(k, DEV)
@@ -39,10 +43,11 @@ def test_engine_eval_matches_reference_golden(case):
         torch.testing.assert_close(model(g.batch(0, DEV)[0]).cpu(), g.arr('eval0'), rtol=1e-5, atol=1e-5)
 
 
+@pytest.mark.parametrize('algo', ALGOS)
 @pytest.mark.parametrize('case', ['deepconn_e20', 'deepconn_e64'])
-def test_engine_training_trajectory_matches_reference_golden(case):
+def test_engine_training_trajectory_matches_reference_golden(case, algo):
     g = Golden(case)
-    eng, model, hp = make_engine(g)
+    eng, model, hp = make_engine(g, conv_algo=algo)
     model.train()
     total = 0.0
     for step in range(3):
@@ -96,7 +101,8 @@ def test_engine_dropout_masks_injected_into_oracle():
     assert not torch.equal(eng.dropout_multipliers(B, T).cpu(), mult)
 
 
-def test_engine_matches_module_path_at_baseline_shape():
+@pytest.mark.parametrize('algo', ALGOS)
+def test_engine_matches_module_path_at_baseline_shape(algo):
     """B=32 rows of the config-3 shape (T=1000, E=300): fused step == op-by-op autograd path."""
     import reviews4rec_amd
     from reviews4rec_amd.engine import DeepCoNNEngine
@@ -116,7 +122,7 @@ def test_engine_matches_module_path_at_baseline_shape():
     ref = fresh()
     opt = Adam(ref.parameters(), lr=hp['lr'], weight_decay=hp['weight_decay'])
     eng_model = fresh()
-    eng = DeepCoNNEngine(eng_model, lr=hp['lr'], weight_decay=hp['weight_decay'])
+    eng = DeepCoNNEngine(eng_model, lr=hp['lr'], weight_decay=hp['weight_decay'], conv_algo=algo)
     for _ in range(2):
         ref.zero_grad()
         se_ref = MSELoss(hp)(ref(data), y, return_mean=False)
@@ -137,12 +143,40 @@ def test_engine_matches_module_path_at_baseline_shape():
             assert (b[k] - a[k]).abs().max() < 1e-3
 
 
-def test_engine_ragged_and_single_row_batches():
+@pytest.mark.parametrize('algo', ALGOS)
+def test_engine_ragged_and_single_row_batches(algo):
     g = Golden('deepconn_e20')
-    eng, model, _ = make_engine(g)
+    eng, model, _ = make_engine(g, conv_algo=algo)
     model.eval()
     data, y = g.batch(0, DEV)
     full, _ = eng.predict(data, y)
     for n in (1, 3):
         part, _ = eng.predict([d[:n] for d in data], y[:n])
         assert torch.equal(part, full[:n])
+
+
+def test_projection_and_direct_conv_agree_on_argmax_and_pooled():
+    """Full config-3 batch (B=128, T=1000, E=300, Zipf tokens, zero-padded tails): the two
+    conv algorithms must give the same predictions to rounding and the same gradients."""
+    import reviews4rec_amd
+    from reviews4rec_amd import synthetic
+    from reviews4rec_amd.engine import DeepCoNNEngine
+    hp = synthetic.hyper_params_for('cfg3_deepconn_electronics_e300', dropout=0.0, vocab=20000)
+    hp['word_vectors'] = synthetic.word_table(hp['vocab'], hp['word_embed_size'])
+    gen = synthetic.Generator(hp, seed=5)
+    data, y = gen.batch(128)
+    data = [torch.from_numpy(d).to(DEV) for d in data]
+    y = torch.from_numpy(y).to(DEV)
+    outs = {}
+    for algo in ALGOS:
+        torch.manual_seed(0)
+        m = reviews4rec_amd.get_model_class('deepconn')(hp)
+        from reviews4rec_amd.utils import xavier_init
+        xavier_init(m)
+        m = m.to(DEV).train()
+        eng = DeepCoNNEngine(m, conv_algo=algo)
+        se = eng.train_step(data, y).clone()
+        outs[algo] = (se, {k: v.clone() for k, v in eng.grads().items()})
+    torch.testing.assert_close(outs[1][0], outs[2][0], rtol=1e-5, atol=1e-6)
+    for k in outs[1][1]:
+        torch.testing.assert_close(outs[1][1][k], outs[2][1][k], rtol=1e-4, atol=1e-7, msg=lambda mm: k + ': ' + mm)
