@@ -87,15 +87,31 @@ __device__ __forceinline__ uint32_t philox_first_word(uint64_t ctr, uint64_t see
     return c0;
 }
 
-// One wave per rating; 4 ratings per 256-thread workgroup.
+// One wave per rating, 4 ratings per 256-thread workgroup.  Everything a rating needs
+// besides its own partials -- both FC matrices, FM V / lin -- is staged in LDS once per
+// workgroup with independent coalesced loads, and the tile loop of the pool-finish is
+// unrolled, so the kernel is a handful of memory round trips instead of a chain of ~40.
+constexpr int HEAD_MAX_TILES = 8;
+
 __global__ __launch_bounds__(256) void deepconn_head_kernel(HeadArgs a) {
-    __shared__ float sp[4][2][F_CONV + 4];     // pooled, per wave
-    __shared__ float sz[4][2 * MAX_L];         // gz, per wave
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    __shared__ float sw[2][MAX_L][F_CONV + 1];   // FC weights, +1 pad: lane i reads row i
+    __shared__ float sfb[2][MAX_L];
+    __shared__ float sV[2 * MAX_L][FM_K];
+    __shared__ float slw[2 * MAX_L];
+    __shared__ float sp[4][2][F_CONV + 4];       // pooled, per wave
+    __shared__ float sz[4][2 * MAX_L];           // gz, per wave
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int64_t b_raw = (int64_t)blockIdx.x * 4 + w;
     const bool live = b_raw < a.B;             // a dead wave shadows the last rating and stores nothing
     const int64_t b = live ? b_raw : a.B - 1;
     const int L = a.L, n = 2 * L;
+
+    for (int i = tid; i < 2 * L * F_CONV; i += 256) {
+        const int t = i / (L * F_CONV), r = i - t * L * F_CONV;
+        sw[t][r / F_CONV][r % F_CONV] = a.fc_w[t][r];
+    }
+    if (tid < n) { sfb[tid / L][tid % L] = a.fc_b[tid / L][tid % L]; slw[tid] = a.lin_w[tid]; }
+    for (int i = tid; i < n * FM_K; i += 256) sV[i / FM_K][i % FM_K] = a.V[i];
 
     // ---- pool finish: max over tiles, relu, first argmax
 #pragma unroll
@@ -103,10 +119,19 @@ __global__ __launch_bounds__(256) void deepconn_head_kernel(HeadArgs a) {
         for (int f = lane; f < F_CONV; f += 64) {
             float best = -INFINITY;
             int bp = -1;
-            for (int k = 0; k < a.tiles; ++k) {
-                const size_t o = ((size_t)b * a.tiles + k) * NP + f;
-                const float v = a.pmax[t][o];
-                if (v > best) { best = v; bp = a.parg[t][o]; }
+            for (int k0 = 0; k0 < a.tiles; k0 += HEAD_MAX_TILES) {
+                float v[HEAD_MAX_TILES];
+                int pp[HEAD_MAX_TILES];
+#pragma unroll
+                for (int k = 0; k < HEAD_MAX_TILES; ++k) {
+                    const bool in = k0 + k < a.tiles;
+                    const size_t o = ((size_t)b * a.tiles + (in ? k0 + k : 0)) * NP + f;
+                    v[k] = in ? a.pmax[t][o] : -INFINITY;
+                    pp[k] = a.parg[t][o];
+                }
+#pragma unroll
+                for (int k = 0; k < HEAD_MAX_TILES; ++k)
+                    if (v[k] > best) { best = v[k]; bp = pp[k]; }
             }
             if (!(best > 0.f)) { best = 0.f; bp = -1; }
             sp[w][t][f] = best;
@@ -117,14 +142,14 @@ __global__ __launch_bounds__(256) void deepconn_head_kernel(HeadArgs a) {
         }
     __syncthreads();
 
-    // ---- FC: z[t][l] = b[l] + sum_f pooled[t][f] W[t][l][f]; lane i < 2L ends up owning x_i
+    // ---- FC: lane i < 2L computes z[t][l] = b[l] + sum_f pooled[t][f] W[t][l][f]
     float xi = 0.f;
-    for (int i = 0; i < n; ++i) {
-        const int t = i / L, l = i - t * L;
-        float part = 0.f;
-        for (int f = lane; f < F_CONV; f += 64) part = fmaf(sp[w][t][f], a.fc_w[t][l * F_CONV + f], part);
-        part = wave_sum(part);
-        if (lane == i) xi = part + a.fc_b[t][l];
+    if (lane < n) {
+        const int t = lane / L, l = lane - t * L;
+        float acc = 0.f;
+#pragma unroll 4
+        for (int f = 0; f < F_CONV; ++f) acc = fmaf(sp[w][t][f], sw[t][l][f], acc);
+        xi = acc + sfb[t][l];
     }
     // ---- dropout on the FC output (common_pytorch_models.py:37)
     float mult = 1.f;
@@ -134,21 +159,20 @@ __global__ __launch_bounds__(256) void deepconn_head_kernel(HeadArgs a) {
         mult = (u >= a.p_drop) ? 1.f / (1.f - a.p_drop) : 0.f;
     }
     xi *= mult;
-    if (lane >= n) xi = 0.f;
 
     // ---- FM (common_pytorch_models.py:49-57) + global bias
     float inter = 0.f, gacc = 0.f;
     float sk_keep[FM_K];
 #pragma unroll
     for (int k = 0; k < FM_K; ++k) {
-        const float v = (lane < n) ? a.V[lane * FM_K + k] : 0.f;
+        const float v = (lane < n) ? sV[lane][k] : 0.f;
         const float s = wave_sum(xi * v);
         const float s2 = wave_sum(xi * xi * v * v);
         inter += s * s - s2;
         gacc += s * v - xi * v * v;
         sk_keep[k] = s;
     }
-    const float lw = (lane < n) ? a.lin_w[lane] : 0.f;
+    const float lw = (lane < n) ? slw[lane] : 0.f;
     const float lin = wave_sum(xi * lw);
     const float pred = (0.5f * inter + lin + a.lin_b[0]) + a.gbias[0];
     if (lane == 0 && live) a.pred[b] = pred;
@@ -181,7 +205,7 @@ __global__ __launch_bounds__(256) void deepconn_head_kernel(HeadArgs a) {
     for (int t = 0; t < 2; ++t)
         for (int f = lane; f < F_CONV; f += 64) {
             float acc = 0.f;
-            for (int l = 0; l < L; ++l) acc = fmaf(sz[w][t * L + l], a.fc_w[t][l * F_CONV + f], acc);
+            for (int l = 0; l < L; ++l) acc = fmaf(sz[w][t * L + l], sw[t][l][f], acc);
             if (live) a.g_pooled[t][b * F_CONV + f] = acc;
         }
 }
@@ -198,10 +222,11 @@ struct HeadGradArgs {
 };
 
 // Output element o of the concatenated head-gradient vector, reduced over the batch by
-// 4 row groups of one workgroup column (fixed order -> deterministic).
-__global__ __launch_bounds__(256) void deepconn_head_grad_kernel(HeadGradArgs a) {
-    __shared__ float red[4][64];
-    const int ox = threadIdx.x, rg = threadIdx.y;          // blockDim = (64, 4)
+// HG_ROWS row groups of one workgroup column (fixed order -> deterministic).
+constexpr int HG_ROWS = 16;
+__global__ __launch_bounds__(64 * HG_ROWS) void deepconn_head_grad_kernel(HeadGradArgs a) {
+    __shared__ float red[HG_ROWS][64];
+    const int ox = threadIdx.x, rg = threadIdx.y;          // blockDim = (64, HG_ROWS)
     const int L = a.L, n = 2 * L;
     const int n_fcw = L * F_CONV;
     const int seg[9] = {n_fcw, L, n_fcw, L, n * FM_K, n, 1, 1, 1};   // last: sse accumulator
@@ -216,7 +241,7 @@ __global__ __launch_bounds__(256) void deepconn_head_grad_kernel(HeadGradArgs a)
     }
     float s = 0.f;
     if (which >= 0) {
-        for (int64_t b = rg; b < a.B; b += 4) {
+        for (int64_t b = rg; b < a.B; b += HG_ROWS) {
             float term;
             switch (which) {
                 case 0: case 2: {
@@ -239,7 +264,9 @@ __global__ __launch_bounds__(256) void deepconn_head_grad_kernel(HeadGradArgs a)
     red[rg][ox] = s;
     __syncthreads();
     if (rg == 0 && which >= 0) {
-        const float t = red[0][ox] + red[1][ox] + red[2][ox] + red[3][ox];
+        float t = 0.f;
+#pragma unroll
+        for (int r = 0; r < HG_ROWS; ++r) t += red[r][ox];
         switch (which) {
             case 0: a.g_fc_w[0][local] = t; break;
             case 1: a.g_fc_b[0][local] = t; break;
@@ -269,7 +296,8 @@ __global__ void sse_only_kernel(const float *__restrict__ se, float *__restrict_
 
 struct StepWs {
     float *wp[2], *pmax[2]; int *parg[2];
-    int *flags[2], *slot[2], *list[2], *count[2]; float *wimg[2], *ptab[2];   // project-then-gather
+    int *flags[2], *slot[2], *list[2], *count[2]; float *ptab[2];   // project-then-gather
+    size_t flags_off[2];
     float *pooled[2]; int *argmax[2]; float *g_pooled[2];
     float *mult, *x, *s, *g, *gz;
     float *part_w[2], *part_b[2];
@@ -291,11 +319,11 @@ static StepWs carve(void *ws, int64_t B, int T, int E, int L, int64_t V) {
         w.g_pooled[t] = reinterpret_cast<float *>(take((size_t)B * F_CONV * 4));
         w.part_w[t] = reinterpret_cast<float *>(take((size_t)ns * F_CONV * 3 * E * 4));
         w.part_b[t] = reinterpret_cast<float *>(take((size_t)ns * F_CONV * 4));
-        w.flags[t] = reinterpret_cast<int *>(take((size_t)V * 4));
-        w.slot[t] = reinterpret_cast<int *>(take((size_t)V * 4));
+        w.flags[t] = reinterpret_cast<int *>(take((size_t)(V + 4) * 4));
+        w.flags_off[t] = (size_t)(reinterpret_cast<char *>(w.flags[t]) - static_cast<char *>(ws));
+        w.slot[t] = reinterpret_cast<int *>(take((size_t)(V + 4) * 4));
         w.list[t] = reinterpret_cast<int *>(take((size_t)proj_row_capacity(B, T, V) * 4));
         w.count[t] = reinterpret_cast<int *>(take(256));
-        w.wimg[t] = reinterpret_cast<float *>(take(proj_wimg_floats(E) * 4));
         w.ptab[t] = reinterpret_cast<float *>(take(proj_ptab_floats(B, T, V) * 4));
     }
     w.mult = reinterpret_cast<float *>(take((size_t)B * 2 * L * 4));
@@ -388,7 +416,7 @@ extern "C" int r4r_deepconn_step(const float *table, int64_t V, const int64_t *u
             pt[t].conv_w = P[t ? P_ICW : P_UCW];
             pt[t].conv_b = P[t ? P_ICB : P_UCB];
             pt[t].flags = w.flags[t]; pt[t].slot = w.slot[t]; pt[t].list = w.list[t]; pt[t].count = w.count[t];
-            pt[t].wimg = w.wimg[t]; pt[t].ptab = w.ptab[t]; pt[t].pmax = w.pmax[t]; pt[t].parg = w.parg[t];
+            pt[t].ptab = w.ptab[t]; pt[t].pmax = w.pmax[t]; pt[t].parg = w.parg[t];
         }
         if (int rc = textcnn_proj_fwd_launch(table, V, pt, 2, B, T, E, F_CONV, st)) return rc;
         tiles = proj_tiles(T);
@@ -433,7 +461,7 @@ extern "C" int r4r_deepconn_step(const float *table, int64_t V, const int64_t *u
     hg.g_V = G[P_FMV]; hg.g_lin_w = G[P_FMLW]; hg.g_lin_b = G[P_FMLB]; hg.g_gb = G[P_GB];
     hg.sse_accum = sse_accum; hg.B = B; hg.L = L;
     const int nout = 2 * (L * F_CONV + L) + 2 * L * FM_K + 2 * L + 3;
-    deepconn_head_grad_kernel<<<(nout + 63) / 64, dim3(64, 4), 0, st>>>(hg);
+    deepconn_head_grad_kernel<<<(nout + 63) / 64, dim3(64, HG_ROWS), 0, st>>>(hg);
 
     // 5+6: conv weight gradients of both towers, straight into the flat buffer
     WgradTower wt[2];

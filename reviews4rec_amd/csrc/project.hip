@@ -18,6 +18,8 @@
 // pool-finish / head / wgrad kernels are shared.  Only the summation ORDER differs
 // from the direct kernel (per-tap dot products first, then 3 adds): fp32 rounding
 // level, covered by the same parity tests.
+#include <stdlib.h>
+
 #include "textcnn.h"
 
 namespace r4r {
@@ -30,12 +32,15 @@ constexpr int PN = 304;            // GEMM N: 300 padded to 19 tiles of 16
 constexpr int PNT = PN / 16;       // 19
 constexpr int PEC = 16;            // K chunk
 constexpr int PS = PEC + 8;        // LDS row stride (floats), == 8 mod 16: conflict-free b128 reads
-constexpr int PM = 128;            // GEMM rows per workgroup (8 waves x 16)
-constexpr int GEMM_THREADS = 512;
-constexpr int GEMM_BUF = (PM + PN) * PS;               // floats per LDS buffer
-constexpr int GEMM_LDS_BYTES = 2 * GEMM_BUF * 4;       // 82,944 B
-constexpr int PB_VEC = PN * PS / 4;                    // 1824 float4 per weight chunk
-constexpr int PB_PER_THREAD = (PB_VEC + GEMM_THREADS - 1) / GEMM_THREADS;   // 4
+constexpr int PM = 128;            // GEMM rows per workgroup (4 waves x 2 row tiles of 16)
+constexpr int GEMM_THREADS = 256;
+constexpr int GM = 2;              // 16-row tiles per wave
+constexpr int PNH = 10;                                // column tiles of the wider half (10 + 9 = 19)
+constexpr int PNH_COLS = PNH * 16;                     // 160
+constexpr int GEMM_BUF = (PM + PNH_COLS) * PS;         // floats per LDS buffer
+constexpr int GEMM_LDS_BYTES = 2 * GEMM_BUF * 4;       // 55,296 B -> 2 workgroups per CU
+constexpr int PA_ROWS = 2;                             // A rows staged per thread: (tid >> 2) + 64 k
+constexpr int PB_ROWS = 3;                             // B rows staged per thread: (tid >> 2) + 64 k
 constexpr int SEG = 128;           // positions per partial (matches the direct kernel's NW=4 tile)
 
 struct ProjArgs {
@@ -43,6 +48,7 @@ struct ProjArgs {
     const float *table;
     int64_t N, V;
     int T, E, F, nchunk, tiles, cap;
+    int dbg;                       // timing experiments only (R4R_PROJ_DBG): 1 no A loads, 2 no B loads, 4 no MFMA
 };
 
 // ---- 1a. mark the tokens each tower's documents use
@@ -54,57 +60,67 @@ __global__ void proj_mark_kernel(ProjArgs a) {
 }
 
 // ---- 1b. compact: slot[v] = dense row id of token v (or -1), list[row] = v, count.
-// One workgroup per tower; thread t owns tokens t, t+1024, ... (coalesced); any
-// bijection token <-> row works, so no sort is needed.
+// grid = (ceil(V / 4096), ntower): a workgroup owns 4096 consecutive tokens (one int4 of
+// flags per thread), scans its flags in LDS and reserves a contiguous row range with ONE
+// atomicAdd on the tower's counter.  The order in which workgroups reserve ranges varies
+// from run to run, but any token <-> row bijection gives bit-identical results downstream
+// (a projected row depends only on its own token), so no global scan or sort is needed.
+// Flags are cleared as they are consumed; `count` is reset by the gather kernel: both
+// are all-zero between calls (the caller provides the workspace zeroed once).
 __global__ __launch_bounds__(1024) void proj_compact_kernel(ProjArgs a) {
-    __shared__ int part[1024];
-    const ProjTower &tw = a.t[blockIdx.x];
-    const int tid = threadIdx.x;
-    int cnt = 0;
-    for (int64_t v = tid; v < a.V; v += 1024) cnt += tw.flags[v];
-    part[tid] = cnt;
-    __syncthreads();
-    for (int off = 1; off < 1024; off <<= 1) {             // inclusive Hillis-Steele scan
-        const int add = (tid >= off) ? part[tid - off] : 0;
-        __syncthreads();
-        part[tid] += add;
-        __syncthreads();
-    }
-    int at = part[tid] - cnt;                               // exclusive prefix
-    for (int64_t v = tid; v < a.V; v += 1024) {
-        if (tw.flags[v]) { tw.slot[v] = at; tw.list[at] = (int)v; ++at; }
-        else tw.slot[v] = -1;
-    }
-    if (tid == 1023) tw.count[0] = part[1023];
-}
-
-// ---- 2a. weight image for the projection GEMM: [chunk][304][24],
-//      img[c][j*100+f][k] = W[f][j][c*16+k]   (0 for n >= 300, e >= E, pad cols)
-__global__ void proj_pack_w_kernel(ProjArgs a) {
+    __shared__ int wsum[16];
+    __shared__ int base_row;
     const ProjTower &tw = a.t[blockIdx.y];
-    const int total = a.nchunk * PN * PS;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
-        const int k = i % PS;
-        const int n = (i / PS) % PN;
-        const int c = i / (PS * PN);
-        float v = 0.f;
-        if (k < PEC && n < 3 * a.F) {
-            const int j = n / a.F, f = n - j * a.F, e = c * PEC + k;
-            if (e < a.E) v = tw.conv_w[((size_t)f * 3 + j) * a.E + e];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t gi = (int64_t)blockIdx.x * 1024 + tid;    // int4 group: tokens 4 gi .. 4 gi + 3
+    const int64_t ngroups = (a.V + 3) / 4;                  // flags / slot buffers are padded to 4
+    int4 f = make_int4(0, 0, 0, 0);
+    if (gi < ngroups) f = reinterpret_cast<int4 *>(tw.flags)[gi];
+    const int fl[4] = {f.x, f.y, f.z, f.w};
+    const int cnt = f.x + f.y + f.z + f.w;
+    // exclusive prefix of cnt inside the workgroup: wave scan + 16-entry LDS scan
+    int incl = cnt;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int up = __shfl_up(incl, off);
+        if (lane >= off) incl += up;
+    }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    if (tid == 0) {
+        int run = 0;
+        for (int w = 0; w < 16; ++w) { const int c = wsum[w]; wsum[w] = run; run += c; }
+        base_row = run ? atomicAdd(tw.count, run) : 0;
+    }
+    __syncthreads();
+    int at = base_row + wsum[wave] + incl - cnt;
+    if (gi < ngroups) {
+        int sl[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            sl[k] = -1;
+            if (fl[k]) { sl[k] = at; tw.list[at] = (int)(gi * 4 + k); ++at; }
         }
-        tw.wimg[i] = v;
+        *reinterpret_cast<int4 *>(tw.slot + gi * 4) = make_int4(sl[0], sl[1], sl[2], sl[3]);
+        if (cnt) reinterpret_cast<int4 *>(tw.flags)[gi] = make_int4(0, 0, 0, 0);
     }
 }
 
-// ---- 2b. projection GEMM: Q[row, 0..299] = table[list[row], :] . Wimg.
-// grid = (cap/128 tiles, ntower); 8 waves, wave w owns rows [16w, 16w+16) x 304 cols
-// (19 accumulators of 16x16).  LDS double-buffered exactly like the direct kernel.
-__global__ __launch_bounds__(GEMM_THREADS, 2) void proj_gemm_kernel(ProjArgs a) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    float *lds = reinterpret_cast<float *>(smem);
+// ---- 2. projection GEMM: Q[row, j*100+f] = table[list[row], :] . W[f, j, :].
+// The B operand is staged straight from the conv weight [F][3][E]: LDS row n = j*100+f takes
+// the 16 contiguous floats W[f][j][c*16 .. c*16+15] (four float4 per row, rows 300..303 zero).
+// grid = (cap/128 row tiles x 2 column halves, ntower); 4 waves, wave w owns rows
+// [32w, 32w+32) x one half of the 304 columns (2 x (10 or 9) accumulators of 16x16): ~2x the
+// workgroups of a full-width tile, 2 co-resident per CU, so a batch whose distinct-token
+// count lands just above a multiple of 256 x 128 rows does not cost a whole extra round.
+// LDS double-buffered exactly like the direct kernel.
+template <int NTILE>
+__device__ __forceinline__ void proj_gemm_body(const ProjArgs &a, float *lds) {
     const ProjTower &tw = a.t[blockIdx.y];
     const int count = tw.count[0];
-    const int row0 = blockIdx.x * PM;
+    const int row0 = (blockIdx.x >> 1) * PM;
+    const int half = blockIdx.x & 1;
+    const int col0 = half * PNH_COLS;                       // first column of this half
     if (row0 >= count) return;                              // over-provisioned grid: uniform exit
     const float *__restrict__ table = a.table;
     const int E = a.E, nchunk = a.nchunk;
@@ -112,163 +128,210 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void proj_gemm_kernel(ProjArgs a) 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lrow = lane & 15, q = lane >> 4;
 
-    // staging role: A float4 column c4 of row (tid >> 2); B float4 tid + 512 k
-    const int c4 = tid & 3, arow = tid >> 2;
-    const long aoff = (row0 + arow < count) ? (long)tw.list[row0 + arow] * E : -1;
+    // staging role: float4 column c4 of A rows (tid >> 2) + 64 k (k < 2) and of B rows
+    // (tid >> 2) + 64 k (k < 3; rows 0..191 cover the 160 B rows of this half)
+    const int c4 = tid & 3, srow = tid >> 2;
+    long aoff[PA_ROWS], boff[PB_ROWS];
+#pragma unroll
+    for (int k = 0; k < PA_ROWS; ++k) {
+        const int r = row0 + srow + 64 * k;
+        aoff[k] = (r < count) ? (long)tw.list[r] * E : -1;
+    }
+#pragma unroll
+    for (int k = 0; k < PB_ROWS; ++k) {
+        const int nl = srow + 64 * k, n = col0 + nl;        // n = j * 100 + f
+        const int j = n / PF, f = n - j * PF;
+        boff[k] = (nl < PNH_COLS && n < PROW) ? ((long)f * 3 + j) * E : -1;
+    }
 
-    f32x4 ar, br[PB_PER_THREAD];
+    f32x4 ar[PA_ROWS], br[PB_ROWS];
     auto issue_loads = [&](int c) {
         const int e = c * PEC + c4 * 4;
-        ar = (f32x4){0.f, 0.f, 0.f, 0.f};
-        if (aoff >= 0 && e < E) ar = *reinterpret_cast<const f32x4 *>(table + aoff + e);
-        const f32x4 *wsrc = reinterpret_cast<const f32x4 *>(tw.wimg + (size_t)c * PN * PS);
 #pragma unroll
-        for (int k = 0; k < PB_PER_THREAD; ++k) {
-            const int i = tid + k * GEMM_THREADS;
-            if (i < PB_VEC) br[k] = wsrc[i];
+        for (int k = 0; k < PA_ROWS; ++k) {
+            ar[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (aoff[k] >= 0 && e < E && !(a.dbg & 1)) ar[k] = *reinterpret_cast<const f32x4 *>(table + aoff[k] + e);
+        }
+#pragma unroll
+        for (int k = 0; k < PB_ROWS; ++k) {
+            br[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (boff[k] >= 0 && e < E && !(a.dbg & 2)) br[k] = *reinterpret_cast<const f32x4 *>(tw.conv_w + boff[k] + e);
         }
     };
     auto write_lds = [&](float *buf) {
-        *reinterpret_cast<f32x4 *>(buf + arow * PS + c4 * 4) = ar;
+#pragma unroll
+        for (int k = 0; k < PA_ROWS; ++k)
+            *reinterpret_cast<f32x4 *>(buf + (srow + 64 * k) * PS + c4 * 4) = ar[k];
         float *Bl = buf + PM * PS;
 #pragma unroll
-        for (int k = 0; k < PB_PER_THREAD; ++k) {
-            const int i = tid + k * GEMM_THREADS;
-            if (i < PB_VEC) reinterpret_cast<f32x4 *>(Bl)[i] = br[k];
+        for (int k = 0; k < PB_ROWS; ++k) {
+            const int nl = srow + 64 * k;
+            if (nl < PNH_COLS) *reinterpret_cast<f32x4 *>(Bl + nl * PS + c4 * 4) = br[k];
         }
     };
 
-    f32x4 acc[PNT];
+    f32x4 acc[GM][NTILE];
 #pragma unroll
-    for (int ni = 0; ni < PNT; ++ni) acc[ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int mi = 0; mi < GM; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NTILE; ++ni) acc[mi][ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    auto compute = [&](const float *cur) {
+        const float *Bl = cur + PM * PS;
+        f32x4 av[GM], b[NTILE];
+#pragma unroll
+        for (int mi = 0; mi < GM; ++mi)
+            av[mi] = *reinterpret_cast<const f32x4 *>(cur + (wave * 32 + mi * 16 + lrow) * PS + q * 4);
+#pragma unroll
+        for (int ni = 0; ni < NTILE; ++ni)
+            b[ni] = *reinterpret_cast<const f32x4 *>(Bl + (ni * 16 + lrow) * PS + q * 4);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+            for (int mi = 0; mi < GM; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < NTILE; ++ni)
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mi][kk], b[ni][kk], acc[mi][ni], 0, 0, 0);
+    };
 
     issue_loads(0);
     write_lds(lds);
     if (nchunk > 1) issue_loads(1);
     __syncthreads();
     for (int c = 0; c < nchunk; ++c) {
-        const float *cur = lds + (c & 1) * GEMM_BUF;
         if (c + 1 < nchunk) {
-            write_lds(lds + ((c + 1) & 1) * GEMM_BUF);
-            if (c + 2 < nchunk) issue_loads(c + 2);
+            write_lds(lds + ((c + 1) & 1) * GEMM_BUF);      // chunk c+1 -> the other buffer
+            if (c + 2 < nchunk) issue_loads(c + 2);         // in flight for a whole chunk
         }
-        const float *Bl = cur + PM * PS;
-        const f32x4 av = *reinterpret_cast<const f32x4 *>(cur + (wave * 16 + lrow) * PS + q * 4);
-        f32x4 b[PNT];
-#pragma unroll
-        for (int ni = 0; ni < PNT; ++ni)
-            b[ni] = *reinterpret_cast<const f32x4 *>(Bl + (ni * 16 + lrow) * PS + q * 4);
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk)
-#pragma unroll
-            for (int ni = 0; ni < PNT; ++ni)
-                acc[ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[kk], b[ni][kk], acc[ni], 0, 0, 0);
+        if (!(a.dbg & 4)) compute(lds + (c & 1) * GEMM_BUF);
         __syncthreads();
     }
 
     // C layout: col = lane & 15, row = (lane >> 4) * 4 + reg
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int row = row0 + wave * 16 + q * 4 + r;
-        if (row < count) {
-            float *dst = tw.ptab + (size_t)row * PROW;
+    for (int mi = 0; mi < GM; ++mi)
 #pragma unroll
-            for (int ni = 0; ni < PNT; ++ni) {
-                const int col = ni * 16 + lrow;
-                if (col < PROW) dst[col] = acc[ni][r];
+        for (int r = 0; r < 4; ++r) {
+            const int row = row0 + wave * 32 + mi * 16 + q * 4 + r;
+            if (row < count) {
+                float *dst = tw.ptab + (size_t)row * PROW;
+#pragma unroll
+                for (int ni = 0; ni < NTILE; ++ni) {
+                    const int col = col0 + ni * 16 + lrow;
+                    if (col < PROW) dst[col] = acc[mi][ni][r];
+                }
             }
         }
-    }
 }
 
-// ---- 3. gather-add-max.  grid = (N, ntower), 256 threads = 8 workers of 32 lanes; lane
-// wl < 25 owns filters 4wl..4wl+3 (one float4 of each 400-byte tap row).  A worker walks
-// one 128-position segment: token t completes position p = t (its tap-2 row), feeds tap 1
-// of p = t+1 and tap 0 of p = t+2.  Slots of the segment's 130 tokens are staged in LDS
-// first so the row loads are independent of each other and can be issued 4 tokens deep.
+__global__ __launch_bounds__(GEMM_THREADS, 2) void proj_gemm_kernel(ProjArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float *lds = reinterpret_cast<float *>(smem);
+    if (blockIdx.x & 1) proj_gemm_body<PNT - PNH>(a, lds);   // columns 160..303: 9 tiles
+    else proj_gemm_body<PNH>(a, lds);                        // columns 0..159: 10 tiles
+}
+
+// ---- 3. gather-add-max.  One workgroup = TWO 128-position segments of one document
+// (grid = (N * ceil(tiles / 2), ntower)); its 8 workers of 32 lanes each walk a
+// 32-position slice, so a worker's dependent chain is 34 tokens / 8 in flight = 5 memory
+// round trips (it was 130 / 4 = 33: at batch 128 the kernel was pure latency).  Lane
+// wl < 25 owns filters 4wl..4wl+3 (one float4 of each 400-byte tap row).  Token t completes
+// position p = t (its tap-2 row), feeds tap 1 of p = t+1 and tap 0 of p = t+2.  The four
+// slices of a segment are merged through LDS in position order (strict >, so the first
+// maximum wins like PyTorch's max-pool).
+constexpr int SLICE = 32;                 // positions per worker
+constexpr int GDEPTH = 8;                 // tokens in flight per lane
+
 __global__ __launch_bounds__(256) void proj_gather_max_kernel(ProjArgs a) {
-    __shared__ int sl[8][SEG + 8];
+    __shared__ int sl[8][SLICE + 2];
+    __shared__ float sbest[8][PF];
+    __shared__ int sbp[8][PF];
     const ProjTower &tw = a.t[blockIdx.y];
-    const int64_t doc = blockIdx.x;
+    const int pairs = (a.tiles + 1) / 2;
+    const int64_t doc = blockIdx.x / pairs;
+    const int seg_base = (blockIdx.x - doc * pairs) * 2;
     const int worker = threadIdx.x >> 5, wl = threadIdx.x & 31;
     const int T = a.T, P = T + 2;
     const bool act = wl < PF / 4;
     const f32x4 zero = (f32x4){0.f, 0.f, 0.f, 0.f};
-    f32x4 bias = zero;
-    if (act) bias = *reinterpret_cast<const f32x4 *>(tw.conv_b + wl * 4);
+    if (blockIdx.x == 0 && threadIdx.x == 0) tw.count[0] = 0;   // consumed by the GEMM launch before this one
 
-    for (int seg0 = 0; seg0 < a.tiles; seg0 += 8) {
-        const int seg = seg0 + worker;
-        const int p_lo = seg * SEG, p_hi = min(P, p_lo + SEG);
-        const int t_lo = p_lo - 2;
-        const int ntok = (seg < a.tiles) ? p_hi - t_lo : 0;        // tokens t_lo .. p_hi-1
-        for (int k = wl; k < ntok; k += 32) {
-            const int t = t_lo + k;
-            sl[worker][k] = (t >= 0 && t < T) ? tw.slot[tw.idx[doc * T + t]] : -1;
-        }
-        __syncthreads();
-        if (seg < a.tiles && act) {
-            f32x4 s_a = zero, s_b = zero;                  // partial sums of positions t and t+1
-            float best[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
-            int bp[4] = {0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff};
-            const float *base = tw.ptab + wl * 4;
-            int k = 0;
-            for (; k + 4 <= ntok; k += 4) {
-                f32x4 r0[4], r1[4], r2[4];
+    const int seg = seg_base + (worker >> 2);               // workers 0-3: first segment, 4-7: second
+    const int p_lo = seg * SEG + (worker & 3) * SLICE;
+    const int p_hi = min(P, p_lo + SLICE);
+    const int t_lo = p_lo - 2;
+    const int ntok = (seg < a.tiles && p_hi > p_lo) ? p_hi - t_lo : 0;     // tokens t_lo .. p_hi-1
+    for (int k = wl; k < ntok; k += 32) {
+        const int t = t_lo + k;
+        sl[worker][k] = (t >= 0 && t < T) ? tw.slot[tw.idx[doc * T + t]] : -1;
+    }
+    __syncthreads();
+
+    float best[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    int bp[4] = {0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff};
+    if (ntok > 0 && act) {
+        const f32x4 bias = *reinterpret_cast<const f32x4 *>(tw.conv_b + wl * 4);
+        const float *base = tw.ptab + wl * 4;
+        f32x4 s_a = zero, s_b = zero;                        // partial sums of positions t and t+1
+        // halo: tokens t_lo and t_lo+1 only seed the sliding sums (tap 0 of t_lo, taps 1 and 0 of
+        // t_lo+1): three loads issued together with the first group, not a round of their own
+        auto load_row = [&](int s, int tap) {
+            const float *row = base + (size_t)(s < 0 ? 0 : s) * PROW + tap * PF;   // clamped: no branch
+            const f32x4 v = *reinterpret_cast<const f32x4 *>(row);
+            return s < 0 ? zero : v;
+        };
+        const int s0 = sl[worker][0], s1 = sl[worker][1];
+        const f32x4 h00 = load_row(s0, 0), h11 = load_row(s1, 1), h10 = load_row(s1, 0);
+        const int npos = ntok - 2;                           // positions p_lo .. p_hi-1 <-> tokens 2 .. ntok-1
+        bool seeded = false;
+        for (int k = 0; k < npos; k += GDEPTH) {
+            f32x4 r0[GDEPTH], r1[GDEPTH], r2[GDEPTH];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int s = sl[worker][k + u];
-                    r0[u] = r1[u] = r2[u] = zero;
-                    if (s >= 0) {
-                        const float *row = base + (size_t)s * PROW;
-                        r0[u] = *reinterpret_cast<const f32x4 *>(row);
-                        r1[u] = *reinterpret_cast<const f32x4 *>(row + PF);
-                        r2[u] = *reinterpret_cast<const f32x4 *>(row + 2 * PF);
-                    }
-                }
+            for (int u = 0; u < GDEPTH; ++u) {
+                const int s = (k + u < npos) ? sl[worker][2 + k + u] : -1;
+                r0[u] = load_row(s, 0);
+                r1[u] = load_row(s, 1);
+                r2[u] = load_row(s, 2);
+            }
+            if (!seeded) { s_a = h00 + h11; s_b = h10; seeded = true; }
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int p = t_lo + k + u;
+            for (int u = 0; u < GDEPTH; ++u) {
+                if (k + u < npos) {
+                    const int p = p_lo + k + u;
                     const f32x4 y = (s_a + r2[u]) + bias;
-                    if (p >= p_lo) {
 #pragma unroll
-                        for (int c = 0; c < 4; ++c)
-                            if (y[c] > best[c]) { best[c] = y[c]; bp[c] = p; }
-                    }
+                    for (int c = 0; c < 4; ++c)
+                        if (y[c] > best[c]) { best[c] = y[c]; bp[c] = p; }
                     s_a = s_b + r1[u];
                     s_b = r0[u];
                 }
             }
-            for (; k < ntok; ++k) {
-                const int s = sl[worker][k];
-                f32x4 r0 = zero, r1 = zero, r2 = zero;
-                if (s >= 0) {
-                    const float *row = base + (size_t)s * PROW;
-                    r0 = *reinterpret_cast<const f32x4 *>(row);
-                    r1 = *reinterpret_cast<const f32x4 *>(row + PF);
-                    r2 = *reinterpret_cast<const f32x4 *>(row + 2 * PF);
-                }
-                const int p = t_lo + k;
-                const f32x4 y = (s_a + r2) + bias;
-                if (p >= p_lo) {
-#pragma unroll
-                    for (int c = 0; c < 4; ++c)
-                        if (y[c] > best[c]) { best[c] = y[c]; bp[c] = p; }
-                }
-                s_a = s_b + r1;
-                s_b = r0;
-            }
-            const size_t o = ((size_t)doc * a.tiles + seg) * NP + wl * 4;
-            *reinterpret_cast<f32x4 *>(tw.pmax + o) = (f32x4){best[0], best[1], best[2], best[3]};
-            *reinterpret_cast<int4 *>(tw.parg + o) = make_int4(bp[0], bp[1], bp[2], bp[3]);
         }
-        __syncthreads();
+    }
+    if (act) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { sbest[worker][wl * 4 + c] = best[c]; sbp[worker][wl * 4 + c] = bp[c]; }
+    }
+    __syncthreads();
+    // merge the 4 slices of each segment in position order; thread f (< 100) of each half
+    const int half = threadIdx.x >> 7, f = threadIdx.x & 127;
+    const int oseg = seg_base + half;
+    if (f < PF && oseg < a.tiles) {
+        float mb = sbest[half * 4][f];
+        int mp = sbp[half * 4][f];
+#pragma unroll
+        for (int w = 1; w < 4; ++w) {
+            const float v = sbest[half * 4 + w][f];
+            if (v > mb) { mb = v; mp = sbp[half * 4 + w][f]; }
+        }
+        const size_t o = ((size_t)doc * a.tiles + oseg) * NP + f;
+        tw.pmax[o] = mb;
+        tw.parg[o] = mp;
     }
 }
 
 // ----------------------------------------------------------------- launchers
 int proj_tiles(int T) { return (T + 2 + SEG - 1) / SEG; }
-size_t proj_wimg_floats(int E) { return (size_t)((E + PEC - 1) / PEC) * PN * PS; }
 int64_t proj_row_capacity(int64_t N, int T, int64_t V) { return (N * T < V) ? N * T : V; }
 size_t proj_ptab_floats(int64_t N, int T, int64_t V) { return (size_t)proj_row_capacity(N, T, V) * PROW; }
 
@@ -290,21 +353,21 @@ int textcnn_proj_fwd_launch(const float *table, int64_t V, const ProjTower *tw, 
     a.nchunk = (E + PEC - 1) / PEC;
     a.tiles = proj_tiles(T);
     a.cap = (int)proj_row_capacity(N, T, V);
-    for (int k = 0; k < ntower; ++k) (void)hipMemsetAsync(tw[k].flags, 0, (size_t)V * sizeof(int), st);
+    { const char *e = getenv("R4R_PROJ_DBG"); a.dbg = e ? atoi(e) : 0; }
     int mark_blocks = (int)cdiv(N * T, 256 * 8);
     if (mark_blocks > 2048) mark_blocks = 2048;
     if (mark_blocks < 1) mark_blocks = 1;
     proj_mark_kernel<<<dim3(mark_blocks, ntower), 256, 0, st>>>(a);
-    proj_compact_kernel<<<ntower, 1024, 0, st>>>(a);
-    const int img = a.nchunk * PN * PS;
-    proj_pack_w_kernel<<<dim3((img + 255) / 256, ntower), 256, 0, st>>>(a);
+    proj_compact_kernel<<<dim3((unsigned)cdiv((V + 3) / 4, 1024), ntower), 1024, 0, st>>>(a);
     {
         ScopedTiming tm(R4R_TIMING_PROJ_GEMM, st);
-        proj_gemm_kernel<<<dim3((a.cap + PM - 1) / PM, ntower), GEMM_THREADS, GEMM_LDS_BYTES, st>>>(a);
+        int rows = a.cap;
+        if (const char *e = getenv("R4R_PROJ_ROWS")) rows = atoi(e);   // experiment: tighter grid
+        proj_gemm_kernel<<<dim3(2 * ((rows + PM - 1) / PM), ntower), GEMM_THREADS, GEMM_LDS_BYTES, st>>>(a);
     }
     {
         ScopedTiming tm(R4R_TIMING_PROJ_GATHER, st);
-        proj_gather_max_kernel<<<dim3((unsigned)N, ntower), 256, 0, st>>>(a);
+        proj_gather_max_kernel<<<dim3((unsigned)(N * ((a.tiles + 1) / 2)), ntower), 256, 0, st>>>(a);
     }
     return check_launch("textcnn_proj_fwd");
 }

@@ -32,17 +32,15 @@ struct ProjTower {
     const int64_t *idx;          // [N, T]
     const float *conv_w;         // [F, 3, E]
     const float *conv_b;         // [F]
-    int *flags;                  // [V]   token-used marks (zeroed by the launcher)
+    int *flags;                  // [V rounded up to 4] token-used marks; all-zero on entry, left all-zero
     int *slot;                   // [V]   token -> dense row of ptab, -1 if unused
     int *list;                   // [cap] dense row -> token
     int *count;                  // [1]   number of distinct tokens
-    float *wimg;                 // proj_wimg_floats(E)
     float *ptab;                 // [cap, 300] projected rows: 3 taps x 100 filters
     float *pmax;                 // [N, proj_tiles(T), NP]
     int *parg;
 };
 int proj_tiles(int T);
-size_t proj_wimg_floats(int E);
 int64_t proj_row_capacity(int64_t N, int T, int64_t V);
 size_t proj_ptab_floats(int64_t N, int T, int64_t V);
 int textcnn_proj_fwd_launch(const float *table, int64_t V, const ProjTower *tw, int ntower,

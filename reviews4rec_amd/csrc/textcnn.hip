@@ -272,7 +272,15 @@ struct WgradArgs {
     int T, E, F, per_split, nsplit;
 };
 
+constexpr int WG_CHUNK = 16;       // documents resolved per phase-1 round
+
 __global__ __launch_bounds__(WG_THREADS) void textcnn_wgrad_kernel(WgradArgs a) {
+    // Phase 1 resolves, for a chunk of documents at once, the dependent chain
+    // argmax -> position -> token id -> table row offset (one lane per (document, tap), so
+    // the chain's latency is paid once per chunk, not once per document); phase 2 streams
+    // the resolved rows with independent float4 loads.
+    __shared__ long s_off[WG_CHUNK][3];     // table row offset in floats, -1 = no contribution
+    __shared__ float s_g[WG_CHUNK];
     const WgradTower &tw = a.t[blockIdx.z];
     const float *__restrict__ table = a.table;
     const int64_t *__restrict__ idx = tw.idx;
@@ -283,28 +291,50 @@ __global__ __launch_bounds__(WG_THREADS) void textcnn_wgrad_kernel(WgradArgs a) 
     const int64_t n0 = (int64_t)s * a.per_split;
     const int64_t n1 = min(a.N, n0 + (int64_t)a.per_split);
     const int nvec = 3 * E / 4;
-    for (int v = threadIdx.x; v < nvec; v += WG_THREADS) {
-        const int j = (v * 4) / E;
-        const int e = v * 4 - j * E;
-        f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
-        for (int64_t n = n0; n < n1; ++n) {
+    const int tid = threadIdx.x;
+    // each thread owns up to 2 float4 columns of the [3][E] window (3E/4 <= 512)
+    f32x4 acc[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
+    int vj[2], ve[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int v = tid + k * WG_THREADS;
+        vj[k] = (v * 4) / E;
+        ve[k] = v * 4 - vj[k] * E;
+    }
+    float sb = 0.f;
+    for (int64_t c0 = n0; c0 < n1; c0 += WG_CHUNK) {
+        const int nd = (int)min((int64_t)WG_CHUNK, n1 - c0);
+        __syncthreads();
+        if (tid < nd * 3) {
+            const int d = tid / 3, j = tid - d * 3;
+            const int64_t n = c0 + d;
             const int p = argmax[n * F + f];
-            if (p < 0) continue;
             const int t = p - 2 + j;
-            if (t < 0 || t >= T) continue;
-            const float g = gp[n * F + f];
-            const int64_t tk = idx[n * T + t];
-            const f32x4 x = *reinterpret_cast<const f32x4 *>(table + (size_t)tk * E + e);
-            acc += g * x;
+            long off = -1;
+            if (p >= 0 && t >= 0 && t < T) off = (long)idx[n * T + t] * E;
+            s_off[d][j] = off;
+            if (j == 0) s_g[d] = (p >= 0) ? gp[n * F + f] : 0.f;
         }
-        *reinterpret_cast<f32x4 *>(tw.part_w + ((size_t)s * F + f) * 3 * E + v * 4) = acc;
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            if (tid + k * WG_THREADS < nvec) {
+#pragma unroll 4
+                for (int d = 0; d < nd; ++d) {
+                    const long off = s_off[d][vj[k]];
+                    if (off >= 0) acc[k] += s_g[d] * *reinterpret_cast<const f32x4 *>(table + off + ve[k]);
+                }
+            }
+        }
+        if (tid == 0)
+            for (int d = 0; d < nd; ++d) sb += s_g[d];
     }
-    if (threadIdx.x == 0) {
-        float sb = 0.f;
-        for (int64_t n = n0; n < n1; ++n)
-            if (argmax[n * F + f] >= 0) sb += gp[n * F + f];
-        tw.part_b[(size_t)s * F + f] = sb;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int v = tid + k * WG_THREADS;
+        if (v < nvec) *reinterpret_cast<f32x4 *>(tw.part_w + ((size_t)s * F + f) * 3 * E + v * 4) = acc[k];
     }
+    if (tid == 0) tw.part_b[(size_t)s * F + f] = sb;
 }
 
 __global__ void textcnn_wgrad_reduce_kernel(WgradArgs a) {
@@ -431,6 +461,7 @@ static int check_tower_args(const void *table, int64_t V, const void *idx, int64
     R4R_REQUIRE(E > 0 && E % 4 == 0, "textcnn: word_embed_size %d must be a positive multiple of 4 "
                                      "(pad the frozen table on the host otherwise)", E);
     R4R_REQUIRE(F > 0 && F <= NP, "textcnn: %d filters > %d supported", F, NP);
+    R4R_REQUIRE(3 * E / 4 <= 512, "textcnn: word_embed_size %d > 680 not supported by the wgrad kernel", E);
     R4R_REQUIRE(N * (int64_t)((T + 2 + 127) / 128) < (1ll << 31), "textcnn: grid too large");
     return R4R_OK;
 }

@@ -69,7 +69,8 @@ class DeepCoNNEngine:
         key = (B, T)
         if self._ws_key != key:
             nb = _lib.lib().r4r_deepconn_ws_bytes(B, T, self.E, self.L, self.V)
-            self._ws = torch.empty(max(nb, 256), dtype=torch.uint8, device=self.dev)
+            # zero-filled: the token-flag region must be all-zero on first use (kept zero by the kernels)
+            self._ws = torch.zeros(max(nb, 256), dtype=torch.uint8, device=self.dev)
             self._ws_key = key
         return self._ws
 
