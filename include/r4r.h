@@ -185,7 +185,8 @@ int r4r_sqdist_mean_bwd(const float *a, const float *b, const float *g_out, floa
  *   p/g/m/v : HOST arrays of `ntensor` DEVICE pointers, numel : HOST int64[ntensor] (the one
  *   exception to "every pointer is a device pointer": the tensor list is passed by value in
  *   the kernel arguments, 16 tensors per launch, so no descriptor table lives in HBM and no
- *   H2D copy happens per step).  One workgroup per r4r_adam_chunk_elems()-element chunk.
+ *   H2D copy happens per step).  One workgroup per r4r_adam_chunk_elems()-element chunk (1024
+ *   when the whole list is under 4 M elements: latency-bound, more and shorter workgroups).
  *   g[i] == 0 means "gradient is zero" (weight decay still applies).
  *   step = 1-based step count shared by all listed tensors. */
 int r4r_adam_chunk_elems(void);

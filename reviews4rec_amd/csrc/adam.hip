@@ -12,7 +12,8 @@
 
 namespace r4r {
 
-constexpr int ADAM_CHUNK = 8192;
+constexpr int ADAM_CHUNK = 8192;      // elements per workgroup for large tensor lists
+constexpr int ADAM_CHUNK_SMALL = 1024; // ... when the whole list is small (latency-bound): more, shorter workgroups
 constexpr int ADAM_THREADS = 256;
 
 struct AdamScalars {
@@ -40,6 +41,7 @@ struct AdamBatch {
     int64_t numel[ADAM_BATCH];
     int chunk_begin[ADAM_BATCH + 1];   // prefix sum of per-tensor chunk counts
     int ntensor;
+    int chunk;                         // elements per workgroup
 };
 
 __global__ __launch_bounds__(ADAM_THREADS) void adam_multi_kernel(AdamBatch tb, AdamScalars s) {
@@ -47,14 +49,14 @@ __global__ __launch_bounds__(ADAM_THREADS) void adam_multi_kernel(AdamBatch tb, 
 #pragma unroll
     for (int k = 1; k < ADAM_BATCH; ++k)
         if (k < tb.ntensor && (int)blockIdx.x >= tb.chunk_begin[k]) t = k;
-    const int64_t start = (int64_t)((int)blockIdx.x - tb.chunk_begin[t]) * ADAM_CHUNK;
+    const int64_t start = (int64_t)((int)blockIdx.x - tb.chunk_begin[t]) * tb.chunk;
     float *p = tb.p[t] + start;
     const float *g = tb.g[t] ? tb.g[t] + start : nullptr;
     float *m = tb.m[t] + start;
     float *v = tb.v[t] + start;
     const int64_t *numel = tb.numel;
     int64_t cnt = numel[t] - start;
-    if (cnt > ADAM_CHUNK) cnt = ADAM_CHUNK;
+    if (cnt > tb.chunk) cnt = tb.chunk;
     const bool aligned = ((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(m) |
                            reinterpret_cast<uintptr_t>(v) | reinterpret_cast<uintptr_t>(g)) & 15) == 0;
     if (aligned) {
@@ -105,8 +107,12 @@ extern "C" int r4r_adam_multi(int ntensor, const uint64_t *p, const uint64_t *g,
     s.inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
     s.beta1 = (float)beta1; s.beta2 = (float)beta2; s.eps = eps; s.wd = weight_decay;
     s.omb1 = (float)(1.0 - beta1); s.omb2 = (float)(1.0 - beta2);
+    int64_t total = 0;
+    for (int k = 0; k < ntensor; ++k) total += numel[k];
+    const int chunk = total >= (4ll << 20) ? ADAM_CHUNK : ADAM_CHUNK_SMALL;
     for (int base = 0; base < ntensor; base += ADAM_BATCH) {
         AdamBatch tb;
+        tb.chunk = chunk;
         tb.ntensor = ntensor - base < ADAM_BATCH ? ntensor - base : ADAM_BATCH;
         int64_t chunks = 0;
         for (int k = 0; k < ADAM_BATCH; ++k) {
@@ -119,7 +125,7 @@ extern "C" int r4r_adam_multi(int ntensor, const uint64_t *p, const uint64_t *g,
             R4R_REQUIRE(!live || (tb.p[k] && tb.m[k] && tb.v[k] && tb.numel[k] >= 0), "adam_multi: tensor %d: null "
                         "p/m/v or negative size", base + k);
             tb.chunk_begin[k] = (int)chunks;
-            chunks += cdiv(tb.numel[k], ADAM_CHUNK);
+            chunks += cdiv(tb.numel[k], chunk);
             R4R_REQUIRE(chunks < (1ll << 31), "adam_multi: too many chunks");
         }
         tb.chunk_begin[ADAM_BATCH] = (int)chunks;

@@ -24,6 +24,7 @@
 #include <stdlib.h>
 
 #include "textcnn.h"
+#include "wgrad_device.h"
 
 namespace r4r {
 
@@ -222,15 +223,17 @@ struct HeadGradArgs {
 };
 
 // Output element o of the concatenated head-gradient vector, reduced over the batch by
-// HG_ROWS row groups of one workgroup column (fixed order -> deterministic).
-constexpr int HG_ROWS = 16;
-__global__ __launch_bounds__(64 * HG_ROWS) void deepconn_head_grad_kernel(HeadGradArgs a) {
-    __shared__ float red[HG_ROWS][64];
-    const int ox = threadIdx.x, rg = threadIdx.y;          // blockDim = (64, HG_ROWS)
+// HG_ROWS row groups of one 256-thread workgroup (fixed order -> deterministic).  `blk`
+// selects the HG_COLS outputs this workgroup owns: few outputs x many row groups keeps each
+// thread's serial chain short (B / 16 terms).
+constexpr int HG_ROWS = 16, HG_COLS = 16;
+__device__ __forceinline__ void head_grad_block(const HeadGradArgs &a, int blk) {
+    __shared__ float red[HG_ROWS][HG_COLS];
+    const int ox = threadIdx.x & (HG_COLS - 1), rg = threadIdx.x / HG_COLS;
     const int L = a.L, n = 2 * L;
     const int n_fcw = L * F_CONV;
     const int seg[9] = {n_fcw, L, n_fcw, L, n * FM_K, n, 1, 1, 1};   // last: sse accumulator
-    int o = blockIdx.x * 64 + ox;
+    int o = blk * HG_COLS + ox;
     int which = -1, local = 0, acc_o = o;
 #pragma unroll
     for (int k = 0; k < 9; ++k) {
@@ -241,6 +244,7 @@ __global__ __launch_bounds__(64 * HG_ROWS) void deepconn_head_grad_kernel(HeadGr
     }
     float s = 0.f;
     if (which >= 0) {
+#pragma unroll 4
         for (int64_t b = rg; b < a.B; b += HG_ROWS) {
             float term;
             switch (which) {
@@ -277,6 +281,21 @@ __global__ __launch_bounds__(64 * HG_ROWS) void deepconn_head_grad_kernel(HeadGr
             case 6: a.g_lin_b[0] = t; break;
             case 7: a.g_gb[0] = t; break;
             default: if (a.sse_accum) a.sse_accum[0] += t; break;
+        }
+    }
+}
+
+// The backward's two independent halves in ONE launch ("horizontal fusion"): z < 2 -> the
+// argmax-sparse conv wgrad of tower z; z == 2 -> the head parameter gradients (strided
+// over the first workgroups of that slice; the rest exit).  Neither depends on the other, both
+// are latency-bound, so they overlap instead of running back to back.
+__global__ __launch_bounds__(WG_THREADS) void deepconn_backward_kernel(WgradArgs w, HeadGradArgs h, int hg_blocks) {
+    if (blockIdx.z < 2) {
+        wgrad_block(w, blockIdx.x, blockIdx.y, blockIdx.z);
+    } else {
+        for (int blk = blockIdx.y * gridDim.x + blockIdx.x; blk < hg_blocks; blk += gridDim.x * gridDim.y) {
+            head_grad_block(h, blk);
+            __syncthreads();
         }
     }
 }
@@ -461,14 +480,24 @@ extern "C" int r4r_deepconn_step(const float *table, int64_t V, const int64_t *u
     hg.g_V = G[P_FMV]; hg.g_lin_w = G[P_FMLW]; hg.g_lin_b = G[P_FMLB]; hg.g_gb = G[P_GB];
     hg.sse_accum = sse_accum; hg.B = B; hg.L = L;
     const int nout = 2 * (L * F_CONV + L) + 2 * L * FM_K + 2 * L + 3;
-    deepconn_head_grad_kernel<<<(nout + 63) / 64, dim3(64, HG_ROWS), 0, st>>>(hg);
+    const int hg_blocks = (nout + HG_COLS - 1) / HG_COLS;
 
-    // 5+6: conv weight gradients of both towers, straight into the flat buffer
+    // 5: conv weight gradients of both towers + the head gradients, one launch
     WgradTower wt[2];
+    WgradArgs wa;
     for (int t = 0; t < 2; ++t) {
         wt[t].idx = idx[t]; wt[t].g_pooled = w.g_pooled[t]; wt[t].argmax = w.argmax[t];
         wt[t].part_w = w.part_w[t]; wt[t].part_b = w.part_b[t];
         wt[t].d_w = G[t ? P_ICW : P_UCW]; wt[t].d_b = G[t ? P_ICB : P_UCB];
     }
-    return textcnn_wgrad_launch(table, wt, 2, B, T, E, F_CONV, st);
+    for (int k = 0; k < MAX_TOWERS; ++k) wa.t[k] = wt[k < 2 ? k : 0];
+    wa.table = table; wa.N = B; wa.T = T; wa.E = E; wa.F = F_CONV;
+    wa.nsplit = textcnn_wgrad_splits(B);
+    wa.per_split = (int)cdiv(B, wa.nsplit);
+    {
+        ScopedTiming tm(R4R_TIMING_TEXTCNN_WGRAD, st);
+        deepconn_backward_kernel<<<dim3(F_CONV, wa.nsplit, 3), WG_THREADS, 0, st>>>(wa, hg, hg_blocks);
+    }
+    // 6: wgrad partial reduce -> flat gradient buffer
+    return textcnn_wgrad_reduce_launch(wt, 2, B, E, F_CONV, st);
 }

@@ -32,14 +32,14 @@ constexpr int PN = 304;            // GEMM N: 300 padded to 19 tiles of 16
 constexpr int PNT = PN / 16;       // 19
 constexpr int PEC = 16;            // K chunk
 constexpr int PS = PEC + 8;        // LDS row stride (floats), == 8 mod 16: conflict-free b128 reads
-constexpr int PM = 128;            // GEMM rows per workgroup (4 waves x 2 row tiles of 16)
-constexpr int GEMM_THREADS = 256;
 constexpr int GM = 2;              // 16-row tiles per wave
+constexpr int PM = 64 * GM;        // GEMM rows per workgroup (4 waves x GM row tiles of 16)
+constexpr int GEMM_THREADS = 256;
 constexpr int PNH = 10;                                // column tiles of the wider half (10 + 9 = 19)
 constexpr int PNH_COLS = PNH * 16;                     // 160
 constexpr int GEMM_BUF = (PM + PNH_COLS) * PS;         // floats per LDS buffer
 constexpr int GEMM_LDS_BYTES = 2 * GEMM_BUF * 4;       // 55,296 B -> 2 workgroups per CU
-constexpr int PA_ROWS = 2;                             // A rows staged per thread: (tid >> 2) + 64 k
+constexpr int PA_ROWS = GM;                            // A rows staged per thread: (tid >> 2) + 64 k
 constexpr int PB_ROWS = 3;                             // B rows staged per thread: (tid >> 2) + 64 k
 constexpr int SEG = 128;           // positions per partial (matches the direct kernel's NW=4 tile)
 
@@ -48,7 +48,6 @@ struct ProjArgs {
     const float *table;
     int64_t N, V;
     int T, E, F, nchunk, tiles, cap;
-    int dbg;                       // timing experiments only (R4R_PROJ_DBG): 1 no A loads, 2 no B loads, 4 no MFMA
 };
 
 // ---- 1a. mark the tokens each tower's documents use
@@ -150,12 +149,12 @@ __device__ __forceinline__ void proj_gemm_body(const ProjArgs &a, float *lds) {
 #pragma unroll
         for (int k = 0; k < PA_ROWS; ++k) {
             ar[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            if (aoff[k] >= 0 && e < E && !(a.dbg & 1)) ar[k] = *reinterpret_cast<const f32x4 *>(table + aoff[k] + e);
+            if (aoff[k] >= 0 && e < E) ar[k] = *reinterpret_cast<const f32x4 *>(table + aoff[k] + e);
         }
 #pragma unroll
         for (int k = 0; k < PB_ROWS; ++k) {
             br[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            if (boff[k] >= 0 && e < E && !(a.dbg & 2)) br[k] = *reinterpret_cast<const f32x4 *>(tw.conv_w + boff[k] + e);
+            if (boff[k] >= 0 && e < E) br[k] = *reinterpret_cast<const f32x4 *>(tw.conv_w + boff[k] + e);
         }
     };
     auto write_lds = [&](float *buf) {
@@ -181,7 +180,7 @@ __device__ __forceinline__ void proj_gemm_body(const ProjArgs &a, float *lds) {
         f32x4 av[GM], b[NTILE];
 #pragma unroll
         for (int mi = 0; mi < GM; ++mi)
-            av[mi] = *reinterpret_cast<const f32x4 *>(cur + (wave * 32 + mi * 16 + lrow) * PS + q * 4);
+            av[mi] = *reinterpret_cast<const f32x4 *>(cur + (wave * 16 * GM + mi * 16 + lrow) * PS + q * 4);
 #pragma unroll
         for (int ni = 0; ni < NTILE; ++ni)
             b[ni] = *reinterpret_cast<const f32x4 *>(Bl + (ni * 16 + lrow) * PS + q * 4);
@@ -203,25 +202,32 @@ __device__ __forceinline__ void proj_gemm_body(const ProjArgs &a, float *lds) {
             write_lds(lds + ((c + 1) & 1) * GEMM_BUF);      // chunk c+1 -> the other buffer
             if (c + 2 < nchunk) issue_loads(c + 2);         // in flight for a whole chunk
         }
-        if (!(a.dbg & 4)) compute(lds + (c & 1) * GEMM_BUF);
+        compute(lds + (c & 1) * GEMM_BUF);
         __syncthreads();
     }
 
-    // C layout: col = lane & 15, row = (lane >> 4) * 4 + reg
+    // Epilogue.  C layout of the MFMA: col = lane & 15, row = (lane >> 4) * 4 + reg -- storing
+    // that directly is 80 scattered 4-byte stores per lane.  Instead each wave transposes one
+    // 16-row tile at a time through its own LDS slab and writes whole row segments as float4
+    // (an LDS queue is in-order per wave, so no barrier is needed inside a wave).
+    constexpr int TS = NTILE * 16 + 4;                       // slab row stride (floats)
+    float *slab = lds + wave * (16 * (PNH_COLS + 4));        // LDS is free after the last barrier
+    constexpr int NV = NTILE * 4;                            // float4 per row segment
 #pragma unroll
-    for (int mi = 0; mi < GM; ++mi)
+    for (int mi = 0; mi < GM; ++mi) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int row = row0 + wave * 32 + mi * 16 + q * 4 + r;
-            if (row < count) {
-                float *dst = tw.ptab + (size_t)row * PROW;
+        for (int ni = 0; ni < NTILE; ++ni)
 #pragma unroll
-                for (int ni = 0; ni < NTILE; ++ni) {
-                    const int col = col0 + ni * 16 + lrow;
-                    if (col < PROW) dst[col] = acc[mi][ni][r];
-                }
-            }
+            for (int r = 0; r < 4; ++r) slab[(q * 4 + r) * TS + ni * 16 + lrow] = acc[mi][ni][r];
+        for (int i = lane; i < 16 * NV; i += 64) {
+            const int rr = i / NV, cv = i - rr * NV;
+            const int row = row0 + wave * 16 * GM + mi * 16 + rr;
+            const int col = col0 + cv * 4;
+            if (row < count && col < PROW)
+                *reinterpret_cast<f32x4 *>(tw.ptab + (size_t)row * PROW + col) =
+                    *reinterpret_cast<const f32x4 *>(slab + rr * TS + cv * 4);
         }
+    }
 }
 
 __global__ __launch_bounds__(GEMM_THREADS, 2) void proj_gemm_kernel(ProjArgs a) {
@@ -353,7 +359,6 @@ int textcnn_proj_fwd_launch(const float *table, int64_t V, const ProjTower *tw, 
     a.nchunk = (E + PEC - 1) / PEC;
     a.tiles = proj_tiles(T);
     a.cap = (int)proj_row_capacity(N, T, V);
-    { const char *e = getenv("R4R_PROJ_DBG"); a.dbg = e ? atoi(e) : 0; }
     int mark_blocks = (int)cdiv(N * T, 256 * 8);
     if (mark_blocks > 2048) mark_blocks = 2048;
     if (mark_blocks < 1) mark_blocks = 1;
@@ -361,9 +366,7 @@ int textcnn_proj_fwd_launch(const float *table, int64_t V, const ProjTower *tw, 
     proj_compact_kernel<<<dim3((unsigned)cdiv((V + 3) / 4, 1024), ntower), 1024, 0, st>>>(a);
     {
         ScopedTiming tm(R4R_TIMING_PROJ_GEMM, st);
-        int rows = a.cap;
-        if (const char *e = getenv("R4R_PROJ_ROWS")) rows = atoi(e);   // experiment: tighter grid
-        proj_gemm_kernel<<<dim3(2 * ((rows + PM - 1) / PM), ntower), GEMM_THREADS, GEMM_LDS_BYTES, st>>>(a);
+        proj_gemm_kernel<<<dim3(2 * ((a.cap + PM - 1) / PM), ntower), GEMM_THREADS, GEMM_LDS_BYTES, st>>>(a);
     }
     {
         ScopedTiming tm(R4R_TIMING_PROJ_GATHER, st);

@@ -60,6 +60,9 @@ int textcnn_pool_finish_launch(const float *pmax, const int *parg, float *pooled
 int textcnn_wgrad_launch(const float *table, const WgradTower *tw, int ntower,
                          int64_t N, int T, int E, int F, hipStream_t st);
 
+// second stage of the wgrad: add the nsplit partials of every tower in a fixed order
+int textcnn_wgrad_reduce_launch(const WgradTower *tw, int ntower, int64_t N, int E, int F, hipStream_t st);
+
 static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 }  // namespace r4r

@@ -34,6 +34,7 @@
 #include <stdlib.h>
 
 #include "textcnn.h"
+#include "wgrad_device.h"
 
 namespace r4r {
 
@@ -263,78 +264,10 @@ __global__ void textcnn_pool_finish_kernel(const float *__restrict__ pmax, const
 // slice of documents; a second kernel adds the nsplit partials in a fixed order
 // (deterministic, no atomics).
 // ---------------------------------------------------------------------------
-constexpr int WG_THREADS = 256;
-
-struct WgradArgs {
-    WgradTower t[MAX_TOWERS];
-    const float *table;
-    int64_t N;
-    int T, E, F, per_split, nsplit;
-};
-
-constexpr int WG_CHUNK = 16;       // documents resolved per phase-1 round
+// (WgradArgs and the per-workgroup body live in wgrad_device.h, shared with engine.hip)
 
 __global__ __launch_bounds__(WG_THREADS) void textcnn_wgrad_kernel(WgradArgs a) {
-    // Phase 1 resolves, for a chunk of documents at once, the dependent chain
-    // argmax -> position -> token id -> table row offset (one lane per (document, tap), so
-    // the chain's latency is paid once per chunk, not once per document); phase 2 streams
-    // the resolved rows with independent float4 loads.
-    __shared__ long s_off[WG_CHUNK][3];     // table row offset in floats, -1 = no contribution
-    __shared__ float s_g[WG_CHUNK];
-    const WgradTower &tw = a.t[blockIdx.z];
-    const float *__restrict__ table = a.table;
-    const int64_t *__restrict__ idx = tw.idx;
-    const float *__restrict__ gp = tw.g_pooled;
-    const int *__restrict__ argmax = tw.argmax;
-    const int T = a.T, E = a.E, F = a.F;
-    const int f = blockIdx.x, s = blockIdx.y;
-    const int64_t n0 = (int64_t)s * a.per_split;
-    const int64_t n1 = min(a.N, n0 + (int64_t)a.per_split);
-    const int nvec = 3 * E / 4;
-    const int tid = threadIdx.x;
-    // each thread owns up to 2 float4 columns of the [3][E] window (3E/4 <= 512)
-    f32x4 acc[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
-    int vj[2], ve[2];
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-        const int v = tid + k * WG_THREADS;
-        vj[k] = (v * 4) / E;
-        ve[k] = v * 4 - vj[k] * E;
-    }
-    float sb = 0.f;
-    for (int64_t c0 = n0; c0 < n1; c0 += WG_CHUNK) {
-        const int nd = (int)min((int64_t)WG_CHUNK, n1 - c0);
-        __syncthreads();
-        if (tid < nd * 3) {
-            const int d = tid / 3, j = tid - d * 3;
-            const int64_t n = c0 + d;
-            const int p = argmax[n * F + f];
-            const int t = p - 2 + j;
-            long off = -1;
-            if (p >= 0 && t >= 0 && t < T) off = (long)idx[n * T + t] * E;
-            s_off[d][j] = off;
-            if (j == 0) s_g[d] = (p >= 0) ? gp[n * F + f] : 0.f;
-        }
-        __syncthreads();
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            if (tid + k * WG_THREADS < nvec) {
-#pragma unroll 4
-                for (int d = 0; d < nd; ++d) {
-                    const long off = s_off[d][vj[k]];
-                    if (off >= 0) acc[k] += s_g[d] * *reinterpret_cast<const f32x4 *>(table + off + ve[k]);
-                }
-            }
-        }
-        if (tid == 0)
-            for (int d = 0; d < nd; ++d) sb += s_g[d];
-    }
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-        const int v = tid + k * WG_THREADS;
-        if (v < nvec) *reinterpret_cast<f32x4 *>(tw.part_w + ((size_t)s * F + f) * 3 * E + v * 4) = acc[k];
-    }
-    if (tid == 0) tw.part_b[(size_t)s * F + f] = sb;
+    wgrad_block(a, blockIdx.x, blockIdx.y, blockIdx.z);
 }
 
 __global__ void textcnn_wgrad_reduce_kernel(WgradArgs a) {
@@ -435,6 +368,15 @@ int textcnn_wgrad_launch(const float *table, const WgradTower *tw, int ntower,
         ScopedTiming tm(R4R_TIMING_TEXTCNN_WGRAD, st);
         textcnn_wgrad_kernel<<<dim3(F, a.nsplit, ntower), WG_THREADS, 0, st>>>(a);
     }
+    return textcnn_wgrad_reduce_launch(tw, ntower, N, E, F, st);
+}
+
+int textcnn_wgrad_reduce_launch(const WgradTower *tw, int ntower, int64_t N, int E, int F, hipStream_t st) {
+    WgradArgs a;
+    for (int k = 0; k < MAX_TOWERS; ++k) a.t[k] = tw[k < ntower ? k : 0];
+    a.table = nullptr; a.N = N; a.T = 0; a.E = E; a.F = F;
+    a.nsplit = textcnn_wgrad_splits(N);
+    a.per_split = (int)cdiv(N > 0 ? N : 1, a.nsplit);
     const int tot = F * 3 * E + F;
     textcnn_wgrad_reduce_kernel<<<dim3((tot + 255) / 256, ntower), 256, 0, st>>>(a);
     return check_launch("textcnn_wgrad");
