@@ -35,6 +35,18 @@ PEAK_HBM_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E spec peak (6.3 TB
 WORKLOAD = 'cfg3_deepconn_electronics_e300'
 
 
+def measured_traffic(kernel, args):
+    """HBM-side bytes per launch of `kernel` from the committed rocprofv3 --pmc summary
+    (profiles/, separate counter passes of this same command) -- only for the configuration
+    that summary was collected on; None otherwise."""
+    path = os.path.join(ROOT, 'profiles', 'r01d_bench_pmc_summary.json')
+    if not (os.path.exists(path) and args.workload == WORKLOAD and args.batch_per_gpu == 128
+            and args.engine == 'native' and args.conv_algo in ('auto', 'project')):
+        return None
+    k = json.load(open(path))['kernels'].get('r4r::' + kernel, {})
+    return k.get('hbm_bytes_per_launch')
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -219,19 +231,35 @@ def main():
         towers = 2 if engine is not None else 1              # the native step runs both towers per launch
         positions = towers * B * (hp['input_length'] + 2)
         if 'proj_gather_max_kernel' in timed:
-            # project-then-gather: the gather-add-max kernel is HBM/L2-bound.  Algorithmic bytes per
-            # launch: every position reads its three 400-B tap rows + an 8-B token id.
+            # project-then-gather.  Dominant kernel: the projection GEMM over the
+            # batch's DISTINCT tokens (fp32 MFMA).  Its useful flops are data dependent, so they are
+            # counted on the host from the very batches that were run: rows x E x 300 x 2 per tower.
+            rows = np.mean([len(np.unique(d[3])) + len(np.unique(d[4])) for d, _ in batches_np])
+            g_s = timed['proj_gemm_kernel'][0] / 1000.0
+            gflops = rows * hp['word_embed_size'] * 300 * 2
+            ach = gflops / g_s / 1e12
+            result['roofline'] = {'kernel': 'proj_gemm_kernel', 'bound': 'mfma', 'achieved': round(ach, 2),
+                                  'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                                  'frac': round(ach / PEAK_FP32_MFMA_TFLOPS, 4),
+                                  'traffic': measured_traffic('proj_gemm_kernel', args),
+                                  'launches': timed['proj_gemm_kernel'][1], 'avg_launch_ms': round(1000 * g_s, 4),
+                                  'flops_per_launch': int(gflops), 'distinct_token_rows_per_launch': int(rows)}
+            # second leg: the gather-add-max kernel is HBM/L2-bound.  Algorithmic bytes per launch
+            # (SURVEY 8d): every position reads its three 400-B tap rows + an 8-B token id.
             avg_s = timed['proj_gather_max_kernel'][0] / 1000.0
             nbytes = towers * B * hp['input_length'] * (8 + 1200)
-            ach = nbytes / avg_s / 1e9
-            result['roofline'] = {'kernel': 'proj_gather_max_kernel', 'bound': 'hbm', 'achieved': round(ach, 1),
-                                  'peak': PEAK_HBM_GBS, 'unit': 'GB/s', 'frac': round(ach / PEAK_HBM_GBS, 4),
-                                  'traffic': None, 'launches': timed['proj_gather_max_kernel'][1],
-                                  'avg_launch_ms': round(1000 * avg_s, 4), 'bytes_per_launch': nbytes}
-            g_s = timed['proj_gemm_kernel'][0] / 1000.0
-            result['roofline_conv_equivalent'] = {
-                'note': 'flops of the direct conv this pair of kernels replaces / (gemm + gather time)',
-                'equivalent_TFLOPs': round(towers * B * tower_flops_per_doc(hp) / (avg_s + g_s) / 1e12, 1),
+            ach_b = nbytes / avg_s / 1e9
+            result['roofline_gather'] = {'kernel': 'proj_gather_max_kernel', 'bound': 'hbm',
+                                         'achieved': round(ach_b, 1), 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
+                                         'frac': round(ach_b / PEAK_HBM_GBS, 4),
+                                         'traffic': measured_traffic('proj_gather_max_kernel', args),
+                                         'avg_launch_ms': round(1000 * avg_s, 4), 'bytes_per_launch': nbytes,
+                                         'note': 'algorithmic bytes; the projected rows are L2/MALL resident, so '
+                                                 'this can exceed what HBM itself delivers'}
+            result['conv_equivalent'] = {
+                'note': 'SURVEY 8d algorithmic conv flops (2 towers x P x 100 x 3E x 2 per rating) / (gemm + gather '
+                        'time): what a direct conv would have to sustain to match',
+                'TFLOPs': round(towers * B * tower_flops_per_doc(hp) / (avg_s + g_s) / 1e12, 1),
                 'peak_fp32_mfma': PEAK_FP32_MFMA_TFLOPS}
         elif 'textcnn_fwd_kernel' in timed and hp.get('vocab'):
             flops = towers * B * tower_flops_per_doc(hp)
