@@ -31,14 +31,15 @@ def init_from_env(backend=None):
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
+    if torch.cuda.is_available():
+        # R4R_DIST_BACKEND=gloo lets several ranks share one GPU (test rigs with a single device):
+        # the rank -> device map wraps around instead of failing
+        local = local % torch.cuda.device_count()
+        torch.cuda.set_device(local)
     if world > 1 and not dist.is_initialized():
         if backend is None:
-            backend = 'nccl' if torch.cuda.is_available() else 'gloo'
-        if backend == 'nccl':
-            torch.cuda.set_device(local)
+            backend = os.environ.get('R4R_DIST_BACKEND') or ('nccl' if torch.cuda.is_available() else 'gloo')
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
-    elif torch.cuda.is_available():
-        torch.cuda.set_device(local)
     return rank, world, local
 
 
