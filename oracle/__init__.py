@@ -25,4 +25,4 @@ from .models import (  # noqa: F401
     init_params,
     trainable_names,
 )
-from .optim import adam_step, AdamState, train_step  # noqa: F401
+from .optim import adam_step, AdamState, train_step, transnet_train_step  # noqa: F401

@@ -66,3 +66,46 @@ def train_step(params, data, y, hyper_params, state, masks=None):
     grads = {k: leaves[k].grad for k in names}
     adam_step(params, grads, state, hyper_params['lr'], hyper_params['weight_decay'])
     return float(se.detach().sum()), grads
+
+
+def transnet_train_step(params, data, y, hyper_params, states):
+    """TransNet's three-optimiser step (main.py:26-53 with utils.init_transnet_optim,
+    utils.py:70-92) with the torch-0.4 semantics the reference was written for: ONE forward,
+    three backward passes over the retained graph, and an optimiser step between them that
+    writes through ``.data`` (no autograd version bump), so later backward passes see
+    post-step weights wherever a weight is a saved tensor and pre-step activations everywhere.
+    Gradients accumulate across the three passes (zeroed once per batch).
+
+    ``states`` = dict(source=AdamState(), source_fm=AdamState(), target=AdamState()).
+    Mutates ``params`` and ``states``; returns (per-example source SE, loss_target, loss_transform).
+    """
+    mt = hyper_params['model_type']
+    names = trainable_names(params)
+    leaves = {k: params[k].detach().clone().requires_grad_(True) for k in names}
+    full = dict(params)
+    full.update(leaves)
+    src_pred, tgt_pred, transform = model_forward(full, data, hyper_params, train=True)
+
+    groups = {
+        'target': [k for k in names if k.startswith('target.')],
+        'source': [k for k in names if k.startswith('source.')],
+        'source_fm': [k for k in names if k.startswith('source_fm.')] +
+                     (['user_embedding.weight', 'item_embedding.weight'] if mt == 'transnet++' else []),
+    }
+
+    def step(group):
+        data_view = {k: leaves[k].data for k in groups[group]}          # write-through, no version bump
+        grads = {k: (None if leaves[k].grad is None else leaves[k].grad.detach().clone()) for k in groups[group]}
+        adam_step(data_view, grads, states[group], hyper_params['lr'], hyper_params['weight_decay'])
+
+    loss_target = mse_loss(tgt_pred, y)
+    loss_target.backward(retain_graph=True)
+    step('target')
+    transform.backward(retain_graph=True)
+    step('source')
+    se = mse_loss(src_pred, y, return_mean=False)
+    se.mean().backward()
+    step('source_fm')
+    for k in names:
+        params[k] = leaves[k].detach()
+    return se.detach(), float(loss_target.detach()), float(transform.detach())

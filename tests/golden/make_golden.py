@@ -13,6 +13,8 @@ applies utils.xavier_init exactly like main.py:375-377, and records
   g0/<name>           gradients of mean(SE) on batch 0 at the initial weights
   w1/.., w3/..        weights after 1 and 3 torch.optim.Adam steps (main.py:94-96)
   m3/.., v3/..        Adam moments after 3 steps
+  tn_se<k>, tn_aux<k>, tn_w1/.., tn_w3/..   TransNet only: the 3-optimiser step of main.py:35-53
+                      run with write-through (torch-0.4 style) optimisers, see DataAdam
 
 Only DATA is written (npz); no reference source travels.  Usage:
     cd /tmp && python /root/repo/tests/golden/make_golden.py
@@ -172,6 +174,83 @@ def run_case(name, hp, V, B, seed, steps=3):
     print('%-22s %7.1f KB  %d arrays' % (name, os.path.getsize(path) / 1024, len(out)))
 
 
+class DataAdam:
+    """Adam with torch.optim.Adam's arithmetic (betas .9/.999, eps 1e-8, L2 decay on the grad,
+    bias-corrected) that writes through ``p.data`` -- what every optimiser did on torch 0.4, the
+    version the reference targets (README.md:20).  Writing through .data does not bump autograd's
+    version counter, so the reference's three backward passes over one retained graph
+    (main.py:38-50) run instead of raising.  Generator-side helper, not
+    reference code; its arithmetic is the one the other fixtures pin against torch.optim.Adam."""
+
+    def __init__(self, params, lr, weight_decay):
+        self.params = list(params)
+        self.lr, self.wd = lr, weight_decay
+        self.state = {}
+
+    def zero_grad(self):
+        for p in self.params:
+            p.grad = None
+
+    def step(self):
+        import math
+        for p in self.params:
+            if p.grad is None:
+                continue
+            st = self.state.setdefault(id(p), {'t': 0, 'm': torch.zeros_like(p.data), 'v': torch.zeros_like(p.data)})
+            st['t'] += 1
+            g = p.grad.data + self.wd * p.data
+            st['m'].mul_(0.9).add_(g, alpha=0.1)
+            st['v'].mul_(0.999).addcmul_(g, g, value=1 - 0.999)
+            bc1, bc2 = 1 - 0.9 ** st['t'], 1 - 0.999 ** st['t']
+            p.data.addcdiv_(st['m'], st['v'].sqrt() / math.sqrt(bc2) + 1e-8, value=-self.lr / bc1)
+
+
+def run_transnet_training(name, hp, V, B, seed, steps=3):
+    """The reference's TransNet step (main.py:26-53) with write-through optimisers grouped like
+    utils.init_transnet_optim (utils.py:70-92); appends the trajectory to <name>.npz."""
+    from loss import MSELoss
+    rng = np.random.default_rng(1000 + seed)
+    model, hp = build(hp, V, seed)
+    batches = [make_batch(rng, hp, B, V), make_batch(rng, hp, max(1, B - 3), V)]
+    path = os.path.join(OUT, name + '.npz')
+    out = dict(np.load(path))
+    crit = MSELoss(hp)
+    kw = dict(lr=hp['lr'], weight_decay=hp['weight_decay'])
+    fm_params = list(model.source_fm.parameters())
+    if hp['model_type'] == 'transnet++':
+        fm_params += [model.user_embedding.weight, model.item_embedding.weight]
+    optimizer = [DataAdam(model.source.parameters(), **kw), DataAdam(fm_params, **kw),
+                 DataAdam(model.target.parameters(), **kw), DataAdam(model.parameters(), **kw)]
+    model.train()
+    for step in range(steps):
+        d, y = to_t(*batches[step % 2])
+        model.zero_grad()
+        for o in optimizer:
+            o.zero_grad()
+        all_output = model(d)
+        optimizer_source, optimizer_source_fm, optimizer_target, optimizer_all = optimizer
+        loss_target = crit(all_output[1], y)
+        loss_target.backward(retain_graph=True)
+        optimizer_target.step()
+        loss_transform = all_output[2]
+        loss_transform.backward(retain_graph=True)
+        optimizer_source.step()
+        loss_source = crit(all_output[0], y, return_mean=False)
+        out['tn_se%d' % step] = loss_source.detach().numpy().copy()
+        out['tn_aux%d' % step] = np.array([float(loss_target.detach()), float(loss_transform.detach())], np.float32)
+        torch.mean(loss_source).backward()
+        optimizer_source_fm.step()
+        if step in (0, steps - 1):
+            for k, v in model.state_dict().items():
+                out['tn_w%d/%s' % (step + 1, k)] = v.detach().numpy().copy()
+    # the training batches are the same b0 / b1 stored by run_case (same rng stream): assert it
+    for k, (dd, yy) in enumerate(batches):
+        for s_, arr in enumerate(dd):
+            assert np.array_equal(out['b%d/%d' % (k, s_)], arr)
+    np.savez_compressed(path, **out)
+    print('%-22s + TransNet training trajectory, %7.1f KB' % (name, os.path.getsize(path) / 1024))
+
+
 def common_paths():
     """get_common_path strings for the shipped defaults (hyper_params.py:3-48), as data."""
     import json
@@ -197,6 +276,9 @@ def main():
     run_case('narre_e16', base_hp('NARRE', word_embed_size=16), V=80, B=4, seed=7)
     run_case('transnet_e16', base_hp('transnet', word_embed_size=16, input_length=21), V=80, B=4, seed=8)
     run_case('transnetpp_e16', base_hp('transnet++', word_embed_size=16, input_length=21), V=80, B=4, seed=9)
+    run_transnet_training('transnet_e16', base_hp('transnet', word_embed_size=16, input_length=21), V=80, B=4, seed=8)
+    run_transnet_training('transnetpp_e16', base_hp('transnet++', word_embed_size=16, input_length=21), V=80, B=4,
+                          seed=9)
 
 
 if __name__ == '__main__':

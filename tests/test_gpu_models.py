@@ -126,6 +126,33 @@ def test_train_mode_dropout_with_injected_masks(case):
         torch.testing.assert_close(out.detach().cpu(), ref, rtol=1e-5, atol=1e-5)
 
 
+@pytest.mark.parametrize('case', ['transnet_e16', 'transnetpp_e16'])
+def test_transnet_three_optimiser_step_matches_reference_golden(case):
+    """SURVEY 8 row a-12 on the HIP path: reviews4rec_amd.main.train drives the 3 backward passes /
+    3 fused-Adam steps of main.py:35-53; the fused Adam writes through raw pointers, which is the
+    torch-0.4 write-through behaviour the fixture was generated with."""
+    from reviews4rec_amd import main as M
+    from reviews4rec_amd.loss import MSELoss
+    g = Golden(case)
+    model, hp = build_model(g)
+    optimizer = M.make_optimizer(hp, model)
+    sse = 0.0
+    for step in range(3):
+        class OneBatch:
+            def iter(self, eval=False):
+                yield g.batch(step % 2, DEV)
+        metrics = M.train(model, MSELoss(hp), optimizer, OneBatch(), hp)
+        ref_se = g.arr('tn_se%d' % step)
+        assert metrics['MSE'] == pytest.approx(round(float(ref_se.mean()), 4), abs=2e-4)
+        aux = g.arr('tn_aux%d' % step)
+        assert metrics['MSE_target'] == pytest.approx(float(aux[0]), abs=2e-4)
+        assert metrics['MSE_transform'] == pytest.approx(float(aux[1]), abs=2e-4)
+        if step in (0, 2):
+            sd = model.state_dict()
+            for k, v in g.params('tn_w%d' % (step + 1)).items():
+                torch.testing.assert_close(sd[k].cpu(), v, rtol=1e-5, atol=1e-5, msg=lambda m: k + ': ' + m)
+
+
 def test_deepconn_full_size_batch_against_oracle_and_properties():
     """BASELINE config 3 shape: B=128, T=1000, E=300, 100 filters.  The oracle checks a
     sample of rows (seconds on CPU); the whole batch is checked through
