@@ -80,8 +80,9 @@ int r4r_textcnn_wgrad(const float *table, int64_t V, const int64_t *idx,
  * post-activation output saved by fwd. */
 int r4r_linear_fwd(const float *x, const float *w, const float *b, float *y,
                    int64_t N, int n_in, int n_out, int relu, void *stream);
+size_t r4r_linear_bwd_ws_bytes(int64_t N, int n_in, int n_out);   /* 0 for small N (ws may be NULL) */
 int r4r_linear_bwd(const float *x, const float *w, const float *y, const float *g_y,
-                   float *g_x, float *g_w, float *g_b,
+                   float *g_x, float *g_w, float *g_b, void *ws, size_t ws_bytes,
                    int64_t N, int n_in, int n_out, int relu, void *stream);
 
 /* ------------------------------------------------------------------------

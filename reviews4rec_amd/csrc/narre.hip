@@ -97,21 +97,22 @@ __global__ void narre_attn_bwd_kernel(const float *__restrict__ x, const float *
 }
 
 // Parameter gradients, reduced over all N*R rows in a fixed order.
-// grid = L + 1: block l < L -> row l of g_W0 (2L columns) and g_b0[l];
-//               block L     -> g_w3 (L columns) and g_b3.
-// blockDim = (128, 4): threadIdx.x = column, threadIdx.y = one of 4 row groups.
+// grid = (L + 1, nsplit): block l < L -> row l of g_W0 (2L columns) and g_b0[l]; block L ->
+// g_w3 (L columns) and g_b3; workgroup (., s) reduces its slice of rows, a finish kernel adds
+// the nsplit partials (deterministic, no atomics).  blockDim = (128, 4): threadIdx.x = column,
+// threadIdx.y = one of 4 row groups.
 __global__ void narre_attn_bwd_p_kernel(const float *__restrict__ x, const float *__restrict__ other,
                                         const float *__restrict__ h_save, const float *__restrict__ g_pre,
-                                        const float *__restrict__ g_sc,
-                                        float *__restrict__ g_W0, float *__restrict__ g_b0,
-                                        float *__restrict__ g_w3, float *__restrict__ g_b3,
-                                        int64_t rows, int L) {
+                                        const float *__restrict__ g_sc, float *__restrict__ part,
+                                        int64_t rows, int L, int per_split) {
     __shared__ float red[4][128];
     const int c = threadIdx.x, rg = threadIdx.y;
-    const int blk = blockIdx.x;
+    const int blk = blockIdx.x, sp = blockIdx.y;
+    const int64_t r0 = (int64_t)sp * per_split, r1 = min(rows, r0 + (int64_t)per_split);
     float acc = 0.f;
     if (blk < L) {
-        for (int64_t i = rg; i < rows; i += 4) {
+#pragma unroll 4
+        for (int64_t i = r0 + rg; i < r1; i += 4) {
             const float g = g_pre[i * L + blk];
             float val = 0.f;
             if (c < L) val = x[i * L + c];
@@ -120,7 +121,8 @@ __global__ void narre_attn_bwd_p_kernel(const float *__restrict__ x, const float
             acc = fmaf(g, val, acc);
         }
     } else {
-        for (int64_t i = rg; i < rows; i += 4) {
+#pragma unroll 4
+        for (int64_t i = r0 + rg; i < r1; i += 4) {
             const float g = g_sc[i];
             float val = 0.f;
             if (c < L) val = h_save[i * L + c];
@@ -130,16 +132,29 @@ __global__ void narre_attn_bwd_p_kernel(const float *__restrict__ x, const float
     }
     red[rg][c] = acc;
     __syncthreads();
-    if (rg == 0) {
-        const float t = red[0][c] + red[1][c] + red[2][c] + red[3][c];
-        if (blk < L) {
-            if (c < 2 * L) g_W0[(size_t)blk * 2 * L + c] = t;
-            else if (c == 2 * L) g_b0[blk] = t;
-        } else {
-            if (c < L) g_w3[c] = t;
-            else if (c == L) g_b3[0] = t;
-        }
+    if (rg == 0) part[((size_t)sp * (L + 1) + blk) * 128 + c] = red[0][c] + red[1][c] + red[2][c] + red[3][c];
+}
+
+__global__ void narre_attn_bwd_p_finish_kernel(const float *__restrict__ part, float *__restrict__ g_W0,
+                                               float *__restrict__ g_b0, float *__restrict__ g_w3,
+                                               float *__restrict__ g_b3, int L, int nsplit) {
+    const int blk = blockIdx.x, c = threadIdx.x;            // blockDim = 128
+    float t = 0.f;
+    for (int s = 0; s < nsplit; ++s) t += part[((size_t)s * (L + 1) + blk) * 128 + c];
+    if (blk < L) {
+        if (c < 2 * L) g_W0[(size_t)blk * 2 * L + c] = t;
+        else if (c == 2 * L) g_b0[blk] = t;
+    } else {
+        if (c < L) g_w3[c] = t;
+        else if (c == L) g_b3[0] = t;
     }
+}
+
+static inline int attn_splits(int64_t rows) {
+    int s = (int)(rows / 128);
+    if (s > 64) s = 64;
+    if (s < 1) s = 1;
+    return s;
 }
 
 }  // namespace r4r
@@ -147,7 +162,7 @@ __global__ void narre_attn_bwd_p_kernel(const float *__restrict__ x, const float
 using namespace r4r;
 
 extern "C" size_t r4r_narre_attn_ws_bytes(int64_t N, int R, int L) {
-    return (size_t)(N * R * L + N * R) * sizeof(float);
+    return (size_t)(N * R * L + N * R + (int64_t)attn_splits(N * R) * (L + 1) * 128) * sizeof(float);
 }
 
 extern "C" int r4r_narre_attn_fwd(const float *x, const float *other, const float *W0, const float *b0,
@@ -181,7 +196,11 @@ extern "C" int r4r_narre_attn_bwd(const float *x, const float *other, const floa
     if (N > 0)
         narre_attn_bwd_kernel<<<(unsigned)N, dim3(L, R), 0, st>>>(x, W0, w3, mult, h_save, a_save, g_out,
                                                                   g_x, g_other, g_pre, g_sc, R, L);
-    narre_attn_bwd_p_kernel<<<L + 1, dim3(128, 4), 0, st>>>(x, other, h_save, g_pre, g_sc, g_W0, g_b0, g_w3, g_b3,
-                                                           N * R, L);
+    float *part = g_sc + N * R;
+    const int ns = attn_splits(N * R);
+    const int per_split = (int)cdiv(N * R > 0 ? N * R : 1, ns);
+    narre_attn_bwd_p_kernel<<<dim3(L + 1, ns), dim3(128, 4), 0, st>>>(x, other, h_save, g_pre, g_sc, part,
+                                                                     N * R, L, per_split);
+    narre_attn_bwd_p_finish_kernel<<<L + 1, 128, 0, st>>>(part, g_W0, g_b0, g_w3, g_b3, L, ns);
     return check_launch("narre_attn_bwd");
 }

@@ -44,19 +44,23 @@ __global__ void linear_bwd_x_kernel(const float *__restrict__ w, const float *__
 }
 
 // g_w[o][i] = sum_n geff[n][o] * x[n][i]; g_b[o] = sum_n geff[n][o].
-// One workgroup per output row o; thread k < n_in owns column k, thread n_in owns
-// the bias.  The document loop is strided over blockDim.y-style "lanes" of 4 row
-// groups and combined through LDS in a fixed order (deterministic).
+// grid = (n_out, nsplit): workgroup (o, s) reduces its slice of rows with LB_ROWS row groups
+// (thread k < n_in owns column k, thread n_in the bias), combined through LDS in a fixed
+// order; a second tiny kernel adds the nsplit partials in a fixed order (deterministic, no
+// atomics).  With nsplit == 1 the first kernel writes the result directly.
 constexpr int LB_ROWS = 4;
 __global__ void linear_bwd_w_kernel(const float *__restrict__ x, const float *__restrict__ y,
                                     const float *__restrict__ gy, float *__restrict__ gw,
-                                    float *__restrict__ gb, int64_t N, int n_in, int n_out, int relu) {
+                                    float *__restrict__ gb, float *__restrict__ part,
+                                    int64_t N, int n_in, int n_out, int relu, int per_split) {
     extern __shared__ float red[];   // [LB_ROWS][n_in + 1]
-    const int o = blockIdx.x;
+    const int o = blockIdx.x, sp = blockIdx.y;
     const int k = threadIdx.x, rg = threadIdx.y;
+    const int64_t r0 = (int64_t)sp * per_split, r1 = min(N, r0 + (int64_t)per_split);
     float s = 0.f;
     if (k <= n_in) {
-        for (int64_t n = rg; n < N; n += LB_ROWS) {
+#pragma unroll 4
+        for (int64_t n = r0 + rg; n < r1; n += LB_ROWS) {
             float g = gy[n * n_out + o];
             if (relu && !(y[n * n_out + o] > 0.f)) g = 0.f;
             s = (k < n_in) ? fmaf(g, x[n * n_in + k], s) : s + g;
@@ -67,9 +71,22 @@ __global__ void linear_bwd_w_kernel(const float *__restrict__ x, const float *__
     if (rg == 0 && k <= n_in) {
         float t = red[k];
         for (int r = 1; r < LB_ROWS; ++r) t += red[r * (n_in + 1) + k];
-        if (k < n_in) gw[(size_t)o * n_in + k] = t;
+        if (part) part[((size_t)sp * n_out + o) * (n_in + 1) + k] = t;
+        else if (k < n_in) gw[(size_t)o * n_in + k] = t;
         else gb[o] = t;
     }
+}
+
+__global__ void linear_bwd_w_finish_kernel(const float *__restrict__ part, float *__restrict__ gw,
+                                           float *__restrict__ gb, int n_in, int n_out, int nsplit) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int per = n_out * (n_in + 1);
+    if (i >= per) return;
+    float t = 0.f;
+    for (int s = 0; s < nsplit; ++s) t += part[(size_t)s * per + i];
+    const int o = i / (n_in + 1), k = i - o * (n_in + 1);
+    if (k < n_in) gw[(size_t)o * n_in + k] = t;
+    else gb[o] = t;
 }
 
 // ----------------------------------------------------------------- dropout
@@ -323,18 +340,41 @@ extern "C" int r4r_linear_fwd(const float *x, const float *w, const float *b, fl
     return check_launch("linear_fwd");
 }
 
+static inline int linear_bwd_splits(int64_t N) {
+    int s = (int)(N / 64);                 // >= 64 rows per workgroup
+    if (s > 32) s = 32;
+    if (s < 1) s = 1;
+    return s;
+}
+
+extern "C" size_t r4r_linear_bwd_ws_bytes(int64_t N, int n_in, int n_out) {
+    const int ns = linear_bwd_splits(N);
+    return ns > 1 ? (size_t)ns * n_out * (n_in + 1) * sizeof(float) : 0;
+}
+
 extern "C" int r4r_linear_bwd(const float *x, const float *w, const float *y, const float *g_y,
-                              float *g_x, float *g_w, float *g_b,
+                              float *g_x, float *g_w, float *g_b, void *ws, size_t ws_bytes,
                               int64_t N, int n_in, int n_out, int relu, void *stream) {
     R4R_REQUIRE(x && w && g_y && g_w && g_b, "linear_bwd: null pointer");
     R4R_REQUIRE(!relu || y, "linear_bwd: relu needs the saved output");
     R4R_REQUIRE(N >= 0 && n_in > 0 && n_in <= 255 && n_out > 0, "linear_bwd: n_in %d out of range (1..255)", n_in);
+    if (ws_bytes < r4r_linear_bwd_ws_bytes(N, n_in, n_out) || (r4r_linear_bwd_ws_bytes(N, n_in, n_out) && !ws)) {
+        set_error("linear_bwd: workspace %zu < %zu bytes", ws_bytes, r4r_linear_bwd_ws_bytes(N, n_in, n_out));
+        return R4R_ERR_WORKSPACE;
+    }
     hipStream_t st = as_stream(stream);
     if (g_x && N > 0)
         linear_bwd_x_kernel<<<blocks_for(N * n_in), 256, 0, st>>>(w, y, g_y, g_x, N, n_in, n_out, relu);
     const int tx = ((n_in + 1 + 63) / 64) * 64;
-    linear_bwd_w_kernel<<<n_out, dim3(tx, LB_ROWS), LB_ROWS * (n_in + 1) * sizeof(float), st>>>(
-        x, y, g_y, g_w, g_b, N, n_in, n_out, relu);
+    const int ns = linear_bwd_splits(N);
+    const int per_split = (int)cdiv(N > 0 ? N : 1, ns);
+    float *part = ns > 1 ? static_cast<float *>(ws) : nullptr;
+    linear_bwd_w_kernel<<<dim3(n_out, ns), dim3(tx, LB_ROWS), LB_ROWS * (n_in + 1) * sizeof(float), st>>>(
+        x, y, g_y, g_w, g_b, part, N, n_in, n_out, relu, per_split);
+    if (ns > 1) {
+        const int per = n_out * (n_in + 1);
+        linear_bwd_w_finish_kernel<<<(per + 255) / 256, 256, 0, st>>>(part, g_w, g_b, n_in, n_out, ns);
+    }
     return check_launch("linear_bwd");
 }
 

@@ -108,8 +108,10 @@ class Linear(Function):
         g_x = torch.empty_like(x2) if ctx.need_gx else None
         g_w = torch.empty_like(w)
         g_b = torch.empty((n_out,), dtype=torch.float32, device=w.device)
+        nb = _lib.lib().r4r_linear_bwd_ws_bytes(x2.shape[0], n_in, n_out)
+        ws = _workspace(nb, w.device) if nb else None
         call('r4r_linear_bwd', ptr(x2), ptr(w), ptr(y), ptr(g_y), ptr(g_x), ptr(g_w), ptr(g_b),
-             x2.shape[0], n_in, n_out, int(ctx.relu))
+             ptr(ws), nb, x2.shape[0], n_in, n_out, int(ctx.relu))
         return (g_x.view(*ctx.lead, n_in) if g_x is not None else None), g_w, g_b, None
 
 
