@@ -62,8 +62,9 @@ def parse():
     ap.add_argument('--conv-algo', choices=['auto', 'direct', 'project'], default='auto',
                     help='native engine: direct gather-fused MFMA conv, or projection GEMM over the distinct '
                          'tokens + gather-add-max (include/r4r.h R4R_CONV_*)')
-    ap.add_argument('--engine', choices=['native', 'module'], default='native',
-                    help="native: fused r4r_deepconn_step (6 launches/step); module: op-by-op autograd path")
+    ap.add_argument('--engine', choices=['native', 'module', 'graph'], default='native',
+                    help="native: fused r4r_deepconn_step where the model has one (else module); module: op-by-op "
+                         "autograd path; graph: the module path captured into one hipGraph per step")
     return ap.parse_args()
 
 
@@ -167,8 +168,18 @@ def main():
         engine = DeepCoNNEngine(model, lr=hp['lr'], weight_decay=hp['weight_decay'], dp=dp, seed=4321, rank=rank,
                                 conv_algo={'auto': 0, 'direct': 1, 'project': 2}[args.conv_algo])
 
+    graphed = None
+    if args.engine == 'graph':
+        if world > 1:
+            raise SystemExit('--engine graph is single-GPU for now (the all-reduce is not captured)')
+        from reviews4rec_amd.graph import GraphedStep
+        graphed = GraphedStep(model, criterion, optimizer, *pool[0])
+
     def step(i):
         data, y = pool[i % len(pool)]
+        if graphed is not None:
+            graphed(data, y)
+            return
         if engine is not None:
             engine.train_step(data, y, n_global=B_global)   # forward + loss + backward + all-reduce + Adam
             return
@@ -224,7 +235,8 @@ def main():
                        'word_embed_size': hp['word_embed_size'], 'input_length': hp['input_length'],
                        'conv_filters': 100, 'latent_size': hp['latent_size'], 'vocab': hp.get('vocab', 0),
                        'dropout': hp['dropout'], 'batch_per_gpu': B, 'global_batch': B_global,
-                       'parallelism': 'dp%d' % world, 'engine': 'native' if engine is not None else 'module',
+                       'parallelism': 'dp%d' % world,
+                       'engine': 'native' if engine is not None else ('graph' if graphed is not None else 'module'),
                        'conv_algo': args.conv_algo},
         }
         result['kernel_ms'] = {k: round(v[0], 4) for k, v in timed.items()}
@@ -273,7 +285,8 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             cpu_hp = {k: v for k, v in hp.items() if k != 'word_vectors'}
             result['cpu_baseline'] = cpu_baseline(cpu_hp, table, batches_np[:4], args.cpu_seconds)
-        run_sse = float(engine.sse.item()) if engine is not None else float(metric_sum.item())
+        run_sse = float(engine.sse.item()) if engine is not None else (
+            float(graphed.sse.item()) if graphed is not None else float(metric_sum.item()))
         result['train_mse_running'] = round(run_sse / ((args.steps + args.warmup) * B), 4)
         print(json.dumps(result))
     if world > 1:

@@ -93,7 +93,11 @@ int r4r_linear_bwd(const float *x, const float *w, const float *y, const float *
  * inject the same mask into the CPU oracle.  The reference draws from torch's
  * unseeded global RNG, so streams are not comparable. */
 int r4r_dropout_fwd(const float *x, float *y, float *mult, int64_t n, float p,
-                    uint64_t seed, uint64_t offset, void *stream);
+                    uint64_t seed, uint64_t offset, uint64_t *offset_dev, void *stream);
+/* offset_dev (nullable, DEVICE): the stream position lives in device memory: the kernel uses
+ * offset + *offset_dev and *offset_dev is advanced by ceil(n/4) afterwards on the same stream,
+ * so a captured hipGraph draws fresh masks on every replay. */
+int r4r_counter_add(uint64_t *counter, uint64_t delta, void *stream);
 int r4r_mul(const float *a, const float *b, float *out, int64_t n, void *stream);
 int r4r_add(const float *a, const float *b, float *out, int64_t n, void *stream);
 
@@ -189,11 +193,14 @@ int r4r_sqdist_mean_bwd(const float *a, const float *b, const float *g_out, floa
  *   H2D copy happens per step).  One workgroup per r4r_adam_chunk_elems()-element chunk (1024
  *   when the whole list is under 4 M elements: latency-bound, more and shorter workgroups).
  *   g[i] == 0 means "gradient is zero" (weight decay still applies).
- *   step = 1-based step count shared by all listed tensors. */
+ *   step = 1-based step count shared by all listed tensors; or step_dev (nullable, DEVICE):
+ *   a counter of COMPLETED steps in device memory -- the kernel then uses t = *step_dev + 1 and
+ *   derives the bias corrections itself (for hipGraph replay; the caller advances the counter
+ *   with r4r_counter_add after the launch). */
 int r4r_adam_chunk_elems(void);
 int r4r_adam_multi(int ntensor, const uint64_t *p, const uint64_t *g, const uint64_t *m, const uint64_t *v,
                    const int64_t *numel, float lr, double beta1, double beta2, float eps,
-                   float weight_decay, int64_t step, void *stream);
+                   float weight_decay, int64_t step, const int64_t *step_dev, void *stream);
 
 /* ------------------------------------------------------------------------
  * Fused DeepCoNN step ('deepconn' mode): the whole of DeepCoNN.forward

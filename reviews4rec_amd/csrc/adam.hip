@@ -19,6 +19,9 @@ constexpr int ADAM_THREADS = 256;
 struct AdamScalars {
     float lr_over_bc1;      // lr / (1 - beta1^t)
     float inv_sqrt_bc2;     // 1 / sqrt(1 - beta2^t)
+    float lr;
+    double b1d, b2d;        // betas in double, for the device-side bias correction
+    const int64_t *step_dev;   // optional: completed-step counter in device memory (graph replay)
     float beta1, beta2, eps, wd;
     float omb1, omb2;       // 1 - beta, rounded from double like torch's `value=1 - beta2`
 };
@@ -45,6 +48,13 @@ struct AdamBatch {
 };
 
 __global__ __launch_bounds__(ADAM_THREADS) void adam_multi_kernel(AdamBatch tb, AdamScalars s) {
+    if (s.step_dev) {
+        // t = completed steps + 1, bias corrections computed here so that a captured graph
+        // replays with the right step (kernel arguments are frozen at capture time)
+        const double t_ = (double)(s.step_dev[0] + 1);
+        s.lr_over_bc1 = (float)((double)s.lr / (1.0 - pow(s.b1d, t_)));
+        s.inv_sqrt_bc2 = (float)(1.0 / sqrt(1.0 - pow(s.b2d, t_)));
+    }
     int t = 0;
 #pragma unroll
     for (int k = 1; k < ADAM_BATCH; ++k)
@@ -97,9 +107,10 @@ extern "C" int r4r_adam_chunk_elems(void) { return ADAM_CHUNK; }
 extern "C" int r4r_adam_multi(int ntensor, const uint64_t *p, const uint64_t *g, const uint64_t *m,
                               const uint64_t *v, const int64_t *numel,
                               float lr, double beta1, double beta2, float eps,
-                              float weight_decay, int64_t step, void *stream) {
+                              float weight_decay, int64_t step, const int64_t *step_dev, void *stream) {
     R4R_REQUIRE(ntensor >= 0 && (ntensor == 0 || (p && g && m && v && numel)), "adam_multi: null pointer");
-    R4R_REQUIRE(step >= 1, "adam_multi: step must be >= 1");
+    R4R_REQUIRE(step_dev || step >= 1, "adam_multi: step must be >= 1");
+    if (step_dev) step = 1;            // placeholder: the kernel derives the corrections from *step_dev
     AdamScalars s;
     const double bc1 = 1.0 - pow(beta1, (double)step);
     const double bc2 = 1.0 - pow(beta2, (double)step);
@@ -107,6 +118,7 @@ extern "C" int r4r_adam_multi(int ntensor, const uint64_t *p, const uint64_t *g,
     s.inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
     s.beta1 = (float)beta1; s.beta2 = (float)beta2; s.eps = eps; s.wd = weight_decay;
     s.omb1 = (float)(1.0 - beta1); s.omb2 = (float)(1.0 - beta2);
+    s.lr = lr; s.b1d = beta1; s.b2d = beta2; s.step_dev = step_dev;
     int64_t total = 0;
     for (int k = 0; k < ntensor; ++k) total += numel[k];
     const int chunk = total >= (4ll << 20) ? ADAM_CHUNK : ADAM_CHUNK_SMALL;

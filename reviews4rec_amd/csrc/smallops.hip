@@ -109,11 +109,11 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
 
 __global__ void dropout_fwd_kernel(const float *__restrict__ x, float *__restrict__ y,
                                    float *__restrict__ mult, int64_t n, float p, float scale,
-                                   uint64_t seed, uint64_t offset) {
+                                   uint64_t seed, uint64_t offset, const uint64_t *__restrict__ offset_dev) {
     const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // group of 4 elements
     const int64_t i0 = g * 4;
     if (i0 >= n) return;
-    const uint64_t ctr = offset + (uint64_t)g;
+    const uint64_t ctr = offset + (offset_dev ? offset_dev[0] : 0) + (uint64_t)g;
     uint32_t r[4];
     philox4x32_10((uint32_t)ctr, (uint32_t)(ctr >> 32), 0u, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), r);
 #pragma unroll
@@ -126,6 +126,12 @@ __global__ void dropout_fwd_kernel(const float *__restrict__ x, float *__restric
             y[i] = x[i] * m;
         }
     }
+}
+
+// counter[0] += delta: advances a device-resident Philox offset / step count AFTER the kernels
+// that read it (same stream), so a captured hipGraph replays with fresh values.
+__global__ void counter_add_kernel(uint64_t *__restrict__ ctr, uint64_t delta) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) ctr[0] += delta;
 }
 
 __global__ void mul_kernel(const float *__restrict__ a, const float *__restrict__ b,
@@ -379,13 +385,21 @@ extern "C" int r4r_linear_bwd(const float *x, const float *w, const float *y, co
 }
 
 extern "C" int r4r_dropout_fwd(const float *x, float *y, float *mult, int64_t n, float p,
-                               uint64_t seed, uint64_t offset, void *stream) {
+                               uint64_t seed, uint64_t offset, uint64_t *offset_dev, void *stream) {
     R4R_REQUIRE(x && y && mult, "dropout_fwd: null pointer");
     R4R_REQUIRE(p >= 0.f && p < 1.f, "dropout_fwd: p=%f outside [0,1)", (double)p);
     if (n <= 0) return R4R_OK;
-    dropout_fwd_kernel<<<blocks_for((n + 3) / 4), 256, 0, as_stream(stream)>>>(x, y, mult, n, p, 1.f / (1.f - p),
-                                                                               seed, offset);
+    hipStream_t st = as_stream(stream);
+    dropout_fwd_kernel<<<blocks_for((n + 3) / 4), 256, 0, st>>>(x, y, mult, n, p, 1.f / (1.f - p), seed, offset,
+                                                                offset_dev);
+    if (offset_dev) counter_add_kernel<<<1, 64, 0, st>>>(offset_dev, (uint64_t)((n + 3) / 4));
     return check_launch("dropout_fwd");
+}
+
+extern "C" int r4r_counter_add(uint64_t *counter, uint64_t delta, void *stream) {
+    R4R_REQUIRE(counter, "counter_add: null pointer");
+    counter_add_kernel<<<1, 64, 0, as_stream(stream)>>>(counter, delta);
+    return check_launch("counter_add");
 }
 
 extern "C" int r4r_mul(const float *a, const float *b, float *out, int64_t n, void *stream) {

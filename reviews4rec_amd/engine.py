@@ -123,7 +123,7 @@ class DeepCoNNEngine:
         rc = _lib.lib().r4r_adam_multi(1, one(self.flat_p.data_ptr()), one(self.flat_g.data_ptr()),
                                        one(self.flat_m.data_ptr()), one(self.flat_v.data_ptr()),
                                        (ctypes.c_int64 * 1)(self.total), self.lr, self.betas[0], self.betas[1],
-                                       self.eps, self.wd, self.step_count, _lib.current_stream())
+                                       self.eps, self.wd, self.step_count, None, _lib.current_stream())
         _lib.check(rc, 'r4r_adam_multi')
         return se
 

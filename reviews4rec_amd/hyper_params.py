@@ -7,7 +7,8 @@ and importing this module has no filesystem side effects -- directories are
 created by ``finalize()``.
 
 Namespaced extras understood by this package (all default to reference behaviour):
-  engine         'native' (fused HIP step where one exists) | 'module' (op-by-op autograd)
+  engine         'native' (fused HIP step where one exists, else module) | 'module' (op-by-op
+                 autograd) | 'graph' (the module step captured into one hipGraph per batch shape)
   word_vectors   in-memory V x E table instead of data_dir/word2vec.pkl (synthetic runs)
   seed           dropout Philox seed
 """

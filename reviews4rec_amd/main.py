@@ -31,7 +31,14 @@ def _is_transnet(hyper_params):
     return hyper_params['model_type'] in ['transnet', 'transnet++']
 
 
-def train(model, criterion, optimizer, reader, hyper_params, engine=None, dp=None):
+class _GraphHolder:
+    """Lazily captured hipGraph of the module-engine step (hyper_params['engine'] == 'graph')."""
+
+    def __init__(self):
+        self.step = None
+
+
+def train(model, criterion, optimizer, reader, hyper_params, engine=None, dp=None, graph=None):
     model.train()
     tn = _is_transnet(hyper_params)
     metrics = {'MSE': 0.0}
@@ -47,6 +54,15 @@ def train(model, criterion, optimizer, reader, hyper_params, engine=None, dp=Non
         n_global = dp.global_count(n_local, y.device) if (dp is not None and dp.on) else n_local
         if engine is not None:
             engine.train_step(data, y, n_global=n_global)
+            total_x += float(n_local)
+            total_batches += 1
+            continue
+        if graph is not None and not tn and not (dp is not None and dp.on):
+            if graph.step is None:
+                from .graph import GraphedStep
+                graph.step = GraphedStep(model, criterion, optimizer, data, y)
+                graph.step.sse.zero_()
+            se = graph.step(data, y)
             total_x += float(n_local)
             total_batches += 1
             continue
@@ -85,6 +101,9 @@ def train(model, criterion, optimizer, reader, hyper_params, engine=None, dp=Non
         total_batches += 1
 
     sse = float(engine.sse.item()) if engine is not None else (float(device_sum) if device_sum is not None else 0.0)
+    if graph is not None and graph.step is not None and engine is None:
+        sse += float(graph.step.sse.item())
+        graph.step.sse.zero_()
     if dp is not None and dp.on:
         t = torch.tensor([sse, total_x], dtype=torch.float64, device=next(model.parameters()).device)
         dp.sum_scalar(t)
@@ -123,6 +142,7 @@ def train_complete(hyper_params, Model, train_reader, val_reader, user_count, it
     rank = dp.rank if dp is not None else 0
     engine = make_engine(hyper_params, model, dp=dp, rank=rank)
     optimizer = None if engine is not None else make_optimizer(hyper_params, model)
+    graph = _GraphHolder() if (engine is None and hyper_params.get('engine') == 'graph') else None
 
     file_write(hyper_params['log_file'], str(model))
     file_write(hyper_params['log_file'], '\nModel Built!\nStarting Training...\n')
@@ -130,7 +150,8 @@ def train_complete(hyper_params, Model, train_reader, val_reader, user_count, it
         best_MSE = float(INF)
         for epoch in range(1, hyper_params['epochs'] + 1):
             epoch_start_time = time.time()
-            metrics = train(model, criterion, optimizer, train_reader, hyper_params, engine=engine, dp=dp)
+            metrics = train(model, criterion, optimizer, train_reader, hyper_params, engine=engine, dp=dp,
+                            graph=graph)
             metrics['dataset'] = hyper_params['dataset']
             metrics, _, _ = evaluate(model, criterion, val_reader, hyper_params, user_count, item_count,
                                      review=review, engine=engine)

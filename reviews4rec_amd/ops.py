@@ -121,15 +121,32 @@ def linear(x, weight, bias, relu=False):
 
 # ------------------------------------------------------------------ dropout
 class DropoutState:
-    """Philox stream position for the dropout kernels (per process / per rank)."""
+    """Philox stream position for the dropout kernels (per process / per rank).
+
+    Eager mode keeps the position on the host (``offset``).  For hipGraph capture
+    (``device_counter`` set, see graph.py) it lives in a device int64 tensor that the dropout
+    launch itself advances, so every replay of a captured step draws fresh masks."""
     seed = 0x5EED5EED
     offset = 0
     record = None          # dict: site -> multiplier tensor, when a test wants the masks
+    device_counter = None  # torch int64 [1] on the device, or None
 
     @classmethod
     def manual_seed(cls, seed, rank=0):
         cls.seed = (int(seed) * 0x9E3779B97F4A7C15 + int(rank) * 0xD1B54A32D192ED03) & 0xFFFFFFFFFFFFFFFF
         cls.offset = 0
+        if cls.device_counter is not None:
+            cls.device_counter.zero_()
+
+    @classmethod
+    def draw(cls, x, y, mult, p):
+        """Launch the dropout kernel on x -> (y, mult) and advance the stream position."""
+        n = x.numel()
+        if cls.device_counter is not None:
+            call('r4r_dropout_fwd', ptr(x), ptr(y), ptr(mult), n, float(p), cls.seed, 0, ptr(cls.device_counter))
+        else:
+            call('r4r_dropout_fwd', ptr(x), ptr(y), ptr(mult), n, float(p), cls.seed, cls.offset, None)
+            cls.offset += (n + 3) // 4
 
 
 class Dropout(Function):
@@ -138,9 +155,7 @@ class Dropout(Function):
         x = _f32(x, 'x')
         y = torch.empty_like(x)
         mult = torch.empty_like(x)
-        n = x.numel()
-        call('r4r_dropout_fwd', ptr(x), ptr(y), ptr(mult), n, float(p), DropoutState.seed, DropoutState.offset)
-        DropoutState.offset += (n + 3) // 4
+        DropoutState.draw(x, y, mult, p)
         if DropoutState.record is not None and site is not None:
             DropoutState.record[site] = mult
         ctx.save_for_backward(mult)
@@ -340,9 +355,7 @@ class NarreAttention(Function):
             ones = torch.ones((N, R, L), dtype=torch.float32, device=x.device)
             mult = torch.empty_like(ones)
             scratch = torch.empty_like(ones)
-            call('r4r_dropout_fwd', ptr(ones), ptr(scratch), ptr(mult), ones.numel(), float(p),
-                 DropoutState.seed, DropoutState.offset)
-            DropoutState.offset += (ones.numel() + 3) // 4
+            DropoutState.draw(ones, scratch, mult, p)
             if DropoutState.record is not None and site is not None:
                 DropoutState.record[site] = mult
         out = torch.empty((N, L), dtype=torch.float32, device=x.device)

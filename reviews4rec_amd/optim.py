@@ -19,6 +19,7 @@ class Adam:
         self.params = [p for p in params if p.requires_grad]
         self.lr, self.betas, self.eps, self.weight_decay = float(lr), tuple(betas), float(eps), float(weight_decay)
         self.state = {}                       # id(param) -> dict(step, exp_avg, exp_avg_sq)
+        self.step_dev = None                  # device int64 [1]: completed steps (hipGraph mode, graph.py)
         self.param_groups = [dict(params=self.params, lr=self.lr, betas=self.betas, eps=self.eps,
                                   weight_decay=self.weight_decay)]
 
@@ -67,8 +68,22 @@ class Adam:
             V = arr(*[st['exp_avg_sq'].data_ptr() for _, _, st in items])
             numel = (ctypes.c_int64 * n)(*[p.numel() for p, _, _ in items])
             rc = lib.r4r_adam_multi(n, P, G, M, V, numel, lr, self.betas[0], self.betas[1], self.eps,
-                                    self.weight_decay, step, stream)
+                                    self.weight_decay, step, _lib.ptr(self.step_dev), stream)
             _lib.check(rc, 'r4r_adam_multi')
+        if self.step_dev is not None:
+            if len(by_step) > 1:
+                raise RuntimeError('Adam(graph mode): every parameter must share one step count')
+            _lib.check(lib.r4r_counter_add(_lib.ptr(self.step_dev), 1, stream), 'r4r_counter_add')
+
+    def enable_device_step(self):
+        """Keep the step count in device memory (needed before capturing step() in a hipGraph).
+        Every parameter must already have optimizer state (run one eager step first) so the
+        counter can be initialised from the common step count."""
+        steps = {st['step'] for st in self.state.values()}
+        if len(steps) > 1:
+            raise RuntimeError('Adam(graph mode): parameters are at different step counts %r' % (steps,))
+        dev = self.params[0].device
+        self.step_dev = torch.tensor([steps.pop() if steps else 0], dtype=torch.int64, device=dev)
 
     def state_dict(self):
         return {'state': {i: {k: (v.clone() if torch.is_tensor(v) else v) for k, v in self.state[id(p)].items()}

@@ -53,7 +53,7 @@ def test_argument_validation_needs_no_gpu(lib):
     assert lib.r4r_textcnn_ws_bytes(128, 1000, 300, 100) > 0
     rc = lib.r4r_fm_fwd(1, 1, 1, 1, 1, 4, 65, 8, None)
     assert rc == -1
-    rc = lib.r4r_dropout_fwd(1, 1, 1, 4, ctypes.c_float(1.5), 0, 0, None)
+    rc = lib.r4r_dropout_fwd(1, 1, 1, 4, ctypes.c_float(1.5), 0, 0, None, None)
     assert rc == -1
 
 
