@@ -244,7 +244,9 @@ int r4r_deepconn_step(const float *table, int64_t V, const int64_t *user_idx, co
  * Live kernel timing for bench.py's roofline leg (no reference counterpart: the
  * reference has no profiler hooks).  When enabled, each
  * instrumented entry point brackets its dominant kernel -- only that kernel --
- * with hipEvents on the launch stream; read() synchronises and accumulates.
+ * with hipEvents (recycled from a pool) on the launch stream; read() synchronises and
+ * accumulates.  Each instrumented launch costs two event records, so bench.py instruments only
+ * the kernels its roofline needs.
  * `total_ms` and `count` are HOST pointers. */
 #define R4R_TIMING_TEXTCNN_FWD 0    /* textcnn_fwd_kernel (the MFMA conv tile kernel) */
 #define R4R_TIMING_TEXTCNN_WGRAD 1  /* textcnn_wgrad_kernel */
@@ -252,7 +254,7 @@ int r4r_deepconn_step(const float *table, int64_t V, const int64_t *user_idx, co
 #define R4R_TIMING_PROJ_GEMM 3      /* proj_gemm_kernel (projection of the batch's distinct tokens) */
 #define R4R_TIMING_PROJ_GATHER 4    /* proj_gather_max_kernel (gather-add-max over positions) */
 #define R4R_TIMING_SLOTS 8
-int r4r_timing_enable(int on);
+int r4r_timing_enable(int slot_mask);   /* bit i instruments slot i; 0 switches timing off */
 int r4r_timing_read(int slot, double *total_ms, int64_t *count, int reset);
 
 #ifdef __cplusplus

@@ -30,18 +30,28 @@ extern "C" const char *r4r_last_error(void) { return r4r::g_err; }
 // ---------------------------------------------------------------------------
 namespace r4r {
 struct TimedSpan { int id; hipEvent_t a, b; };
-static bool g_timing = false;
-static std::vector<TimedSpan> g_spans;
+static unsigned g_timing_mask = 0;             // bit i set -> slot i is instrumented
+static std::vector<TimedSpan> g_spans;         // spans recorded since the last read
+static std::vector<hipEvent_t> g_pool;         // recycled events: no create/destroy per launch
 static double g_total_ms[R4R_TIMING_SLOTS];
 static long long g_count[R4R_TIMING_SLOTS];
 
-bool timing_on() { return g_timing; }
+bool timing_on() { return g_timing_mask != 0; }
+
+static hipEvent_t take_event() {
+    if (!g_pool.empty()) { hipEvent_t e = g_pool.back(); g_pool.pop_back(); return e; }
+    hipEvent_t e;
+    (void)hipEventCreate(&e);
+    return e;
+}
 
 void timing_begin(int id, hipStream_t st, void **token) {
+    *token = nullptr;
+    if (!(g_timing_mask & (1u << id))) return;
     TimedSpan s;
     s.id = id;
-    (void)hipEventCreate(&s.a);
-    (void)hipEventCreate(&s.b);
+    s.a = take_event();
+    s.b = take_event();
     (void)hipEventRecord(s.a, st);
     g_spans.push_back(s);
     *token = reinterpret_cast<void *>(g_spans.size());
@@ -53,8 +63,8 @@ void timing_end(void *token, hipStream_t st) {
 }
 }  // namespace r4r
 
-extern "C" int r4r_timing_enable(int on) {
-    r4r::g_timing = on != 0;
+extern "C" int r4r_timing_enable(int mask) {
+    r4r::g_timing_mask = (unsigned)mask;
     return R4R_OK;
 }
 
@@ -70,8 +80,8 @@ extern "C" int r4r_timing_read(int slot, double *total_ms, int64_t *count, int r
             r4r::g_total_ms[s.id] += ms;
             r4r::g_count[s.id] += 1;
         }
-        (void)hipEventDestroy(s.a);
-        (void)hipEventDestroy(s.b);
+        r4r::g_pool.push_back(s.a);
+        r4r::g_pool.push_back(s.b);
     }
     r4r::g_spans.clear();
     *total_ms = r4r::g_total_ms[slot];
