@@ -56,6 +56,7 @@ def parse():
     ap.add_argument('--workload', default=WORKLOAD)
     ap.add_argument('--dropout', type=float, default=0.6, help='reference default (hyper_params.py:66)')
     ap.add_argument('--pool', type=int, default=8, help='distinct resident batches cycled through')
+    ap.add_argument('--embed', type=int, default=None, help='override word_embed_size (crossover experiments)')
     ap.add_argument('--cpu-seconds', type=float, default=12.0,
                     help='budget of each half (thread calibration, measurement) of the cpu_baseline leg')
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -143,6 +144,8 @@ def main():
 
     B = args.batch_per_gpu
     hp = synthetic.hyper_params_for(args.workload, batch_size=B, dropout=args.dropout)
+    if args.embed:
+        hp['word_embed_size'] = args.embed
     table = synthetic.word_table(hp['vocab'], hp['word_embed_size']) if hp.get('vocab') else None
     if table is not None:
         hp['word_vectors'] = table

@@ -40,14 +40,17 @@ const char *r4r_last_error(void);
  * Replaces  nn.Embedding lookup      DeepCoNN.py:53-54, NARRE.py:95-96, TransNet.py:100-102
  *           Conv2d + relu + max_pool common_pytorch_models.py:29-31
  * The [N,T,E] gathered activations and the [N,F,T+2] conv output are never
- * written to HBM.
+ * written to HBM.  Two algorithms compute the same function (selection: R4R_CONV_AUTO rule in
+ * DESIGN.md 4.1b; env R4R_CONV_ALGO=direct|project pins one): the direct gather-fused MFMA conv
+ * over every position, or project-then-gather (projection GEMM over the batch's distinct tokens
+ * + gather-add-max over positions).
  *   table  [V, E]   frozen word vectors (E % 4 == 0)
  *   idx    [N, T]   token ids in [0, V)
  *   conv_w [F, 3, E] (= Conv2d weight [F,1,3,E]),  conv_b [F],  F <= 112
  *   pooled [N, F]   max_p relu(conv)          argmax [N, F]  position p in [0,T+2) of the
  *                                              max, or -1 where pooled == 0 (no gradient)
  * ---------------------------------------------------------------------- */
-size_t r4r_textcnn_ws_bytes(int64_t N, int T, int E, int F);
+size_t r4r_textcnn_ws_bytes(int64_t N, int T, int E, int F, int64_t V);
 int r4r_textcnn_fwd(const float *table, int64_t V, const int64_t *idx,
                     const float *conv_w, const float *conv_b,
                     float *pooled, int32_t *argmax,

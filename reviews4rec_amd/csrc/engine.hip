@@ -373,19 +373,6 @@ extern "C" size_t r4r_deepconn_ws_bytes(int64_t B, int T, int E, int L, int64_t 
     return carve(nullptr, B, T, E, L, V).bytes;
 }
 
-// R4R_CONV_ALGO=direct|project pins the algorithm for A/B runs; AUTO picks the
-// projection when the window is wide enough that the MFMA work dominates (E >= 128).
-static int pick_conv_algo(int requested, int E) {
-    static int pin = -1;
-    if (pin < 0) {
-        const char *e = getenv("R4R_CONV_ALGO");
-        pin = !e ? 0 : (e[0] == 'd' ? R4R_CONV_DIRECT : (e[0] == 'p' ? R4R_CONV_PROJECT : 0));
-    }
-    if (pin) return pin;
-    if (requested == R4R_CONV_DIRECT || requested == R4R_CONV_PROJECT) return requested;
-    return E >= 128 ? R4R_CONV_PROJECT : R4R_CONV_DIRECT;
-}
-
 // Byte offset of the [B, 2L] dropout-multiplier block inside the workspace (so a test can
 // inject the very masks the device drew into the CPU oracle).
 extern "C" size_t r4r_deepconn_ws_mult_offset(int64_t B, int T, int E, int L, int64_t V) {
@@ -426,7 +413,7 @@ extern "C" int r4r_deepconn_step(const float *table, int64_t V, const int64_t *u
 
     // 1+2: both towers, one grid -- either the direct gather-fused conv or project-then-gather
     const int64_t *idx[2] = {user_idx, item_idx};
-    const int algo = pick_conv_algo(conv_algo, E);
+    const int algo = textcnn_pick_algo(conv_algo, B, T, E, F_CONV);
     int tiles;
     if (algo == R4R_CONV_PROJECT) {
         ProjTower pt[2];
@@ -437,7 +424,7 @@ extern "C" int r4r_deepconn_step(const float *table, int64_t V, const int64_t *u
             pt[t].flags = w.flags[t]; pt[t].slot = w.slot[t]; pt[t].list = w.list[t]; pt[t].count = w.count[t];
             pt[t].ptab = w.ptab[t]; pt[t].pmax = w.pmax[t]; pt[t].parg = w.parg[t];
         }
-        if (int rc = textcnn_proj_fwd_launch(table, V, pt, 2, B, T, E, F_CONV, st)) return rc;
+        if (int rc = textcnn_proj_fwd_launch(table, V, pt, 2, B, T, E, F_CONV, /*zero_state=*/false, st)) return rc;
         tiles = proj_tiles(T);
     } else {
         FwdTower ft[2];

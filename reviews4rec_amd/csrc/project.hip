@@ -50,6 +50,16 @@ struct ProjArgs {
     int T, E, F, nchunk, tiles, cap;
 };
 
+// ---- 0. zero the token-state (callers whose workspace is not persistently zeroed).  A kernel
+// rather than hipMemsetAsync: memset nodes misbehaved under hipGraph replay (memory fault).
+__global__ void proj_zero_kernel(ProjArgs a) {
+    const ProjTower &tw = a.t[blockIdx.y];
+    const int64_t n = ((a.V + 3) / 4) * 4;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        tw.flags[i] = 0;
+    if (blockIdx.x == 0 && threadIdx.x == 0) tw.count[0] = 0;
+}
+
 // ---- 1a. mark the tokens each tower's documents use
 __global__ void proj_mark_kernel(ProjArgs a) {
     const ProjTower &tw = a.t[blockIdx.y];
@@ -342,7 +352,7 @@ int64_t proj_row_capacity(int64_t N, int T, int64_t V) { return (N * T < V) ? N 
 size_t proj_ptab_floats(int64_t N, int T, int64_t V) { return (size_t)proj_row_capacity(N, T, V) * PROW; }
 
 int textcnn_proj_fwd_launch(const float *table, int64_t V, const ProjTower *tw, int ntower,
-                            int64_t N, int T, int E, int F, hipStream_t st) {
+                            int64_t N, int T, int E, int F, bool zero_state, hipStream_t st) {
     if (F != PF) {
         set_error("project-then-gather path is built for %d filters, got %d", PF, F);
         return R4R_ERR_ARG;
@@ -359,6 +369,11 @@ int textcnn_proj_fwd_launch(const float *table, int64_t V, const ProjTower *tw, 
     a.nchunk = (E + PEC - 1) / PEC;
     a.tiles = proj_tiles(T);
     a.cap = (int)proj_row_capacity(N, T, V);
+    if (zero_state) {
+        int zb = (int)cdiv(V, 256 * 4);
+        if (zb > 1024) zb = 1024;
+        proj_zero_kernel<<<dim3(zb < 1 ? 1 : zb, ntower), 256, 0, st>>>(a);
+    }
     int mark_blocks = (int)cdiv(N * T, 256 * 8);
     if (mark_blocks > 2048) mark_blocks = 2048;
     if (mark_blocks < 1) mark_blocks = 1;

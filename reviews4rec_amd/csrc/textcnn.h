@@ -43,8 +43,11 @@ struct ProjTower {
 int proj_tiles(int T);
 int64_t proj_row_capacity(int64_t N, int T, int64_t V);
 size_t proj_ptab_floats(int64_t N, int T, int64_t V);
+// zero_state: memset flags + count first (callers whose workspace is not persistently zeroed)
 int textcnn_proj_fwd_launch(const float *table, int64_t V, const ProjTower *tw, int ntower,
-                            int64_t N, int T, int E, int F, hipStream_t st);
+                            int64_t N, int T, int E, int F, bool zero_state, hipStream_t st);
+// R4R_CONV_AUTO / _DIRECT / _PROJECT (include/r4r.h) -> the algorithm to run; honours R4R_CONV_ALGO
+int textcnn_pick_algo(int requested, int64_t N, int T, int E, int F);
 
 size_t textcnn_wp_floats(int E);
 int textcnn_tile_rows(int T);                  // conv positions per workgroup tile chosen for T
@@ -56,7 +59,7 @@ int textcnn_fwd_launch(const float *table, const FwdTower *tw, int ntower,
                        int64_t N, int T, int E, int F, hipStream_t st);
 // pooled = max(0, max over tiles), argmax = first position or -1
 int textcnn_pool_finish_launch(const float *pmax, const int *parg, float *pooled, int *argmax,
-                               int64_t N, int T, int F, hipStream_t st);
+                               int64_t N, int tiles, int F, hipStream_t st);
 int textcnn_wgrad_launch(const float *table, const WgradTower *tw, int ntower,
                          int64_t N, int T, int E, int F, hipStream_t st);
 

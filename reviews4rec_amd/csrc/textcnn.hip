@@ -305,6 +305,23 @@ int textcnn_tiles(int T) {
     return (T + 2 + m - 1) / m;
 }
 
+// Which conv algorithm to run.  R4R_CONV_ALGO=direct|project pins it (A/B runs, tests).
+// AUTO (measured crossover): project-then-gather wins at every batch size for
+// wide windows (E >= 128: 0.080 vs 0.135 ms/step at B=2, E=300) and from ~64 k positions up
+// for narrow ones (E=64: 0.092 vs 0.154 ms at B=128; 0.069 vs 0.063 ms at B=32).
+int textcnn_pick_algo(int requested, int64_t N, int T, int E, int F) {
+    static int pin = -1;
+    if (pin < 0) {
+        const char *e = getenv("R4R_CONV_ALGO");
+        pin = !e ? 0 : (e[0] == 'd' ? R4R_CONV_DIRECT : (e[0] == 'p' ? R4R_CONV_PROJECT : 0));
+    }
+    int algo = pin ? pin : requested;
+    if (algo != R4R_CONV_DIRECT && algo != R4R_CONV_PROJECT)
+        algo = (E >= 128 || N * (int64_t)(T + 2) >= 65536) ? R4R_CONV_PROJECT : R4R_CONV_DIRECT;
+    if (F != 100) algo = R4R_CONV_DIRECT;                   // the projection kernels are built for 100 filters
+    return algo;
+}
+
 int textcnn_wgrad_splits(int64_t N) {
     // >= 1024 workgroups when the batch allows it, at least 8 documents per split
     int s = (int)cdiv(N, 8);
@@ -351,9 +368,8 @@ int textcnn_fwd_launch(const float *table, const FwdTower *tw, int ntower,
 }
 
 int textcnn_pool_finish_launch(const float *pmax, const int *parg, float *pooled, int *argmax,
-                               int64_t N, int T, int F, hipStream_t st) {
-    textcnn_pool_finish_kernel<<<(unsigned)cdiv(N * F, 256), 256, 0, st>>>(pmax, parg, pooled, argmax, N, F,
-                                                                          textcnn_tiles(T));
+                               int64_t N, int tiles, int F, hipStream_t st) {
+    textcnn_pool_finish_kernel<<<(unsigned)cdiv(N * F, 256), 256, 0, st>>>(pmax, parg, pooled, argmax, N, F, tiles);
     return check_launch("textcnn_pool_finish");
 }
 
@@ -388,13 +404,17 @@ using namespace r4r;
 
 // Workspace: [weight image][pmax][parg] for the forward, [part_w][part_b] for the
 // backward; sized for the smaller (128-row) tile so either tile height fits.
-extern "C" size_t r4r_textcnn_ws_bytes(int64_t N, int T, int E, int F) {
-    if (N < 0 || T <= 0 || E <= 0 || F <= 0) return 0;
+extern "C" size_t r4r_textcnn_ws_bytes(int64_t N, int T, int E, int F, int64_t V) {
+    if (N < 0 || T <= 0 || E <= 0 || F <= 0 || V <= 0) return 0;
     const size_t tiles128 = (size_t)(T + 2 + 127) / 128;
-    const size_t fwd = align256(textcnn_wp_floats(E) * 4) + 2 * align256((size_t)N * tiles128 * NP * 4);
+    const size_t partials = 2 * align256((size_t)N * tiles128 * NP * 4);
+    const size_t fwd = align256(textcnn_wp_floats(E) * 4) + partials;
+    const size_t proj = partials + 2 * align256((size_t)(V + 4) * 4) + align256((size_t)proj_row_capacity(N, T, V) * 4) +
+                        align256(256) + align256(proj_ptab_floats(N, T, V) * 4);
     const int ns = textcnn_wgrad_splits(N);
     const size_t bwd = align256((size_t)ns * F * 3 * E * 4) + align256((size_t)ns * F * 4);
-    return fwd > bwd ? fwd : bwd;
+    size_t m = fwd > bwd ? fwd : bwd;
+    return m > proj ? m : proj;
 }
 
 static int check_tower_args(const void *table, int64_t V, const void *idx, int64_t N, int T, int E, int F) {
@@ -415,23 +435,33 @@ extern "C" int r4r_textcnn_fwd(const float *table, int64_t V, const int64_t *idx
                                int64_t N, int T, int E, int F, void *stream) {
     if (int rc = check_tower_args(table, V, idx, N, T, E, F)) return rc;
     R4R_REQUIRE(conv_w && conv_b && pooled && argmax && ws, "textcnn_fwd: null pointer");
-    if (ws_bytes < r4r_textcnn_ws_bytes(N, T, E, F)) {
-        set_error("textcnn_fwd: workspace %zu < %zu bytes", ws_bytes, r4r_textcnn_ws_bytes(N, T, E, F));
+    if (ws_bytes < r4r_textcnn_ws_bytes(N, T, E, F, V)) {
+        set_error("textcnn_fwd: workspace %zu < %zu bytes", ws_bytes, r4r_textcnn_ws_bytes(N, T, E, F, V));
         return R4R_ERR_WORKSPACE;
     }
     if (N == 0) return R4R_OK;
     hipStream_t st = as_stream(stream);
-    const int tiles = textcnn_tiles(T);
     char *base = static_cast<char *>(ws);
+    auto take = [&](size_t nbytes) { char *r = base; base += align256(nbytes); return r; };
+    const size_t tiles128 = (size_t)(T + 2 + 127) / 128;
+    float *pmax = reinterpret_cast<float *>(take((size_t)N * tiles128 * NP * 4));
+    int *parg = reinterpret_cast<int *>(take((size_t)N * tiles128 * NP * 4));
+    if (textcnn_pick_algo(R4R_CONV_AUTO, N, T, E, F) == R4R_CONV_PROJECT) {
+        ProjTower pt;
+        pt.idx = idx; pt.conv_w = conv_w; pt.conv_b = conv_b; pt.pmax = pmax; pt.parg = parg;
+        pt.flags = reinterpret_cast<int *>(take((size_t)(V + 4) * 4));
+        pt.slot = reinterpret_cast<int *>(take((size_t)(V + 4) * 4));
+        pt.list = reinterpret_cast<int *>(take((size_t)proj_row_capacity(N, T, V) * 4));
+        pt.count = reinterpret_cast<int *>(take(256));
+        pt.ptab = reinterpret_cast<float *>(take(proj_ptab_floats(N, T, V) * 4));
+        if (int rc = textcnn_proj_fwd_launch(table, V, &pt, 1, N, T, E, F, /*zero_state=*/true, st)) return rc;
+        return textcnn_pool_finish_launch(pmax, parg, pooled, argmax, N, proj_tiles(T), F, st);
+    }
     FwdTower tw;
-    tw.idx = idx; tw.conv_w = conv_w; tw.conv_b = conv_b;
-    tw.wp = reinterpret_cast<float *>(base);
-    base += align256(textcnn_wp_floats(E) * 4);
-    tw.pmax = reinterpret_cast<float *>(base);
-    base += align256((size_t)N * tiles * NP * 4);
-    tw.parg = reinterpret_cast<int *>(base);
+    tw.idx = idx; tw.conv_w = conv_w; tw.conv_b = conv_b; tw.pmax = pmax; tw.parg = parg;
+    tw.wp = reinterpret_cast<float *>(take(textcnn_wp_floats(E) * 4));
     if (int rc = textcnn_fwd_launch(table, &tw, 1, N, T, E, F, st)) return rc;
-    return textcnn_pool_finish_launch(tw.pmax, tw.parg, pooled, argmax, N, T, F, st);
+    return textcnn_pool_finish_launch(pmax, parg, pooled, argmax, N, textcnn_tiles(T), F, st);
 }
 
 extern "C" int r4r_textcnn_wgrad(const float *table, int64_t V, const int64_t *idx,
@@ -441,8 +471,8 @@ extern "C" int r4r_textcnn_wgrad(const float *table, int64_t V, const int64_t *i
                                  int64_t N, int T, int E, int F, void *stream) {
     if (int rc = check_tower_args(table, V, idx, N, T, E, F)) return rc;
     R4R_REQUIRE(g_pooled && argmax && d_conv_w && d_conv_b && ws, "textcnn_wgrad: null pointer");
-    if (ws_bytes < r4r_textcnn_ws_bytes(N, T, E, F)) {
-        set_error("textcnn_wgrad: workspace %zu < %zu bytes", ws_bytes, r4r_textcnn_ws_bytes(N, T, E, F));
+    if (ws_bytes < r4r_textcnn_ws_bytes(N, T, E, F, V)) {
+        set_error("textcnn_wgrad: workspace %zu < %zu bytes", ws_bytes, r4r_textcnn_ws_bytes(N, T, E, F, V));
         return R4R_ERR_WORKSPACE;
     }
     const int ns = textcnn_wgrad_splits(N);

@@ -46,7 +46,7 @@ def textcnn_fwd_raw(idx, table, conv_w, conv_b):
     F = conv_b.numel()
     pooled = torch.empty((N, F), dtype=torch.float32, device=idx.device)
     argmax = torch.empty((N, F), dtype=torch.int32, device=idx.device)
-    nb = _lib.lib().r4r_textcnn_ws_bytes(N, T, E, F)
+    nb = _lib.lib().r4r_textcnn_ws_bytes(N, T, E, F, V)
     ws = _workspace(nb, idx.device)
     call('r4r_textcnn_fwd', ptr(table), V, ptr(idx), ptr(conv_w), ptr(conv_b), ptr(pooled), ptr(argmax),
          ptr(ws), ws.numel(), N, T, E, F)
@@ -60,7 +60,7 @@ def textcnn_wgrad_raw(idx, table, g_pooled, argmax, conv_w_shape):
     F = g_pooled.shape[1]
     d_w = torch.empty(conv_w_shape, dtype=torch.float32, device=idx.device)
     d_b = torch.empty((F,), dtype=torch.float32, device=idx.device)
-    nb = _lib.lib().r4r_textcnn_ws_bytes(N, T, E, F)
+    nb = _lib.lib().r4r_textcnn_ws_bytes(N, T, E, F, V)
     ws = _workspace(nb, idx.device)
     call('r4r_textcnn_wgrad', ptr(table), V, ptr(idx), ptr(g_pooled), ptr(argmax), ptr(d_w), ptr(d_b),
          ptr(ws), ws.numel(), N, T, E, F)

@@ -62,6 +62,31 @@ def test_textcnn_forward_matches_aten(N, T, E, V):
     assert (arg[pos] == ref_arg[pos]).float().mean() > 0.999
 
 
+@pytest.mark.parametrize('N,T,E,V', [(70, 1000, 64, 3000), (700, 100, 64, 2000), (36, 1000, 300, 1500)])
+def test_textcnn_forward_auto_algorithm_at_scale(N, T, E, V):
+    """>= 65536 positions (or E >= 128): R4R_CONV_AUTO runs project-then-gather inside
+    r4r_textcnn_fwd (the small narrow shapes above run the direct conv); both must match ATen.  The whole suite is additionally run
+    with R4R_CONV_ALGO=project / =direct pinned."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(N + T + E)
+    table = (torch.rand((V, E), generator=g) - 0.5) * 0.2
+    w = (torch.rand((100, 1, 3, E), generator=g) - 0.5) * (2 * math.sqrt(6.0 / (3 * E + 300 * E)))
+    b = (torch.rand(100, generator=g) - 0.5) * 0.1
+    zipf = torch.distributions.Categorical(probs=1.0 / torch.arange(1, V + 1).float())
+    idx = zipf.sample((N, T))
+    fill = torch.randint(1, T + 1, (N, 1), generator=g)
+    idx = torch.where(torch.arange(T)[None, :] < fill, idx, torch.zeros_like(idx))     # zero-padded tails
+    ref_pooled, ref_arg, y = conv_pool_reference(idx, table, w, b)
+    pooled, arg = ops.textcnn_fwd_raw(idx.to(DEV), table.to(DEV), w.to(DEV), b.to(DEV))
+    pooled, arg = pooled.cpu(), arg.cpu().long()
+    torch.testing.assert_close(pooled, ref_pooled, rtol=1e-5, atol=1e-6)
+    assert ((arg < 0) == (ref_pooled <= 0)).all()
+    pos = arg >= 0
+    picked = torch.gather(y, 2, arg.clamp(min=0).unsqueeze(-1)).squeeze(-1)
+    torch.testing.assert_close(picked[pos], ref_pooled[pos], rtol=1e-5, atol=1e-6)
+    assert (arg[pos] == ref_arg[pos]).float().mean() > 0.99
+
+
 def test_textcnn_all_negative_gives_zero_and_no_gradient():
     ops = _ops()
     V, E, T = 10, 8, 20
