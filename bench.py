@@ -56,6 +56,9 @@ def parse():
     ap.add_argument('--workload', default=WORKLOAD)
     ap.add_argument('--dropout', type=float, default=0.6, help='reference default (hyper_params.py:66)')
     ap.add_argument('--pool', type=int, default=8, help='distinct resident batches cycled through')
+    ap.add_argument('--from-host', action='store_true',
+                    help='feed the steps from pinned HOST arrays through data_fast.DataLoader (double-buffered H2D on a '
+                         'copy stream) instead of HBM-resident batches: the PCIe-inclusive rate, for DESIGN.md only')
     ap.add_argument('--embed', type=int, default=None, help='override word_embed_size (crossover experiments)')
     ap.add_argument('--cpu-seconds', type=float, default=12.0,
                     help='budget of each half (thread calibration, measurement) of the cpu_baseline leg')
@@ -197,6 +200,23 @@ def main():
         dp.allreduce_grads()
         optimizer.step()
 
+    if args.from_host:
+        from reviews4rec_amd import data_fast
+        cat = [np.concatenate([b[0][k] for b in batches_np]) for k in range(7)]
+        ycat = np.concatenate([b[1] for b in batches_np])
+        loader = data_fast.DataLoader.from_arrays(dict(hp, batch_size=B), cat, ycat, device=dev)
+
+        def host_batches():
+            while True:
+                for item in loader.iter():
+                    yield item
+        feed = host_batches()
+        resident_step = step
+
+        def step(i):                                         # noqa: F811  (same step, batches arrive over PCIe)
+            pool[0] = next(feed)
+            resident_step(0)
+
     def fence():
         torch.cuda.synchronize()
         if world > 1:
@@ -240,14 +260,16 @@ def main():
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(1000.0 * elapsed / args.steps, 4),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': args.workload, 'model_type': hp['model_type'],
-                       'word_embed_size': hp['word_embed_size'], 'input_length': hp['input_length'],
-                       'conv_filters': 100, 'latent_size': hp['latent_size'], 'vocab': hp.get('vocab', 0),
-                       'dropout': hp['dropout'], 'batch_per_gpu': B, 'global_batch': B_global,
+            'dtype': 'f32', 'data': 'synthetic' + (' (streamed from pinned host memory)' if args.from_host else ''),
+            'config': {'workload': args.workload, 'ratings_per_step': B_global, 'batch_per_gpu': B,
                        'parallelism': 'dp%d' % world,
                        'engine': 'native' if engine is not None else ('graph' if graphed is not None else 'module'),
-                       'conv_algo': args.conv_algo},
+                       'conv_algo': args.conv_algo,
+                       'shape': {'recommender': hp['model_type'], 'word_embed_size': hp['word_embed_size'],
+                                 'input_length': hp['input_length'], 'conv_filters': 100,
+                                 'latent_size': hp['latent_size'], 'vocab': hp.get('vocab', 0),
+                                 'users': hp['total_users'], 'items': hp['total_items'],
+                                 'dropout': hp['dropout']}},
         }
         result['kernel_ms'] = {k: round(v[0], 4) for k, v in timed.items()}
         towers = 2 if engine is not None else 1              # the native step runs both towers per launch

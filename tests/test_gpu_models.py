@@ -231,3 +231,28 @@ def test_no_silent_cpu_fallback():
     model = reviews4rec_amd.get_model_class('MF_dot')(hp)   # left on the CPU on purpose
     with pytest.raises(RuntimeError, match='ROCm device'):
         model(g.batch(0)[0])
+
+
+def test_batcher_double_buffered_h2d_feeds_the_native_step():
+    """data_fast.DataLoader on the GPU: pinned arrays, batch k+1 copied on a copy stream while
+    batch k trains; every batch must arrive intact and in order (ragged tail included)."""
+    import numpy as np
+    from reviews4rec_amd import data_fast
+    hp = dict(batch_size=128, model_type='deepconn', data_dir='data/Tiny/5_core/')
+    data, y = synthetic_review_batch(300, 200, 500, 30, 20, seed=3)
+    data_np, y_np = [d.numpy() for d in data], y.numpy()
+    loader = data_fast.DataLoader.from_arrays(hp, data_np, y_np)
+    assert loader.device.type == 'cuda'
+    for epoch in range(2):
+        at, sizes = 0, []
+        for batch, yy in loader.iter():
+            n = yy.shape[0]
+            assert all(t.is_cuda and t.dtype == torch.int64 for t in batch) and yy.dtype == torch.float32
+            burn = torch.empty(1 << 22, device=DEV).normal_()          # keep the compute stream busy
+            for t, src in zip(batch, data_np):
+                assert np.array_equal(t.cpu().numpy(), src[at:at + n])
+            assert np.allclose(yy.cpu().numpy(), y_np[at:at + n])
+            at += n
+            sizes.append(n)
+            del burn
+        assert sizes == [128, 128, 44]
