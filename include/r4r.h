@@ -128,6 +128,12 @@ int r4r_embed_gather(const float *table, const int64_t *idx, float *out,
                      int64_t R, int D, int64_t n, void *stream);
 int r4r_embed_scatter_add(const float *g_out, const int64_t *idx, float *g_table,
                           int64_t R, int D, int64_t n, void *stream);
+/* Same result, fixed summation order (the first occurrence of a row adds its later duplicates in
+ * ascending entry order; no atomics): bit-identical on every run and every rank.  Used to rebuild
+ * the dense gradient from the all-gathered compact (row-id, grad-row) lists under data parallelism
+ * (no reference counterpart: the reference is single-process). */
+int r4r_embed_scatter_add_ordered(const float *g_out, const int64_t *idx, float *g_table,
+                                  int64_t R, int D, int64_t n, void *stream);
 
 /* ------------------------------------------------------------------------
  * Rating head pieces.

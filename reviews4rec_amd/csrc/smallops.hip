@@ -246,6 +246,29 @@ __global__ void embed_scatter_add_kernel(const float *__restrict__ gout, const i
     atomicAdd(gtable + idx[r] * D + d, gout[i]);
 }
 
+// Deterministic variant: one wave per entry; the FIRST occurrence of a row (the "leader") adds
+// the gradient rows of all its later duplicates in ascending entry order and owns the store --
+// no atomics, the same bits on every run and on every rank.  O(n^2) index compares, meant for the
+// compact (row-id, grad-row) lists of a batch (n = global batch size), not for bulk scatters.
+__global__ void embed_scatter_add_ordered_kernel(const float *__restrict__ gout, const int64_t *__restrict__ idx,
+                                                 float *__restrict__ gtable, int D, int64_t n) {
+    const int lane = threadIdx.x & 63;
+    const int64_t e = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (e >= n) return;
+    const int64_t row = idx[e];
+    if (row < 0) return;                                     // padding entry of an all-gathered list
+    bool dup = false;
+    for (int64_t k = lane; k < e; k += 64) dup |= (idx[k] == row);
+    if (__any(dup)) return;                                  // an earlier entry leads this row
+    for (int d0 = 0; d0 < D; d0 += 64) {
+        const int d = d0 + lane;
+        float acc = (d < D) ? gout[e * D + d] : 0.f;
+        for (int64_t k = e + 1; k < n; ++k)
+            if (idx[k] == row && d < D) acc += gout[k * D + d];
+        if (d < D) gtable[row * D + d] = acc;
+    }
+}
+
 // -------------------------------------------------------------- rating head
 __global__ void rowdot_fwd_kernel(const float *__restrict__ a, const float *__restrict__ c,
                                   float *__restrict__ out, int64_t N, int D) {
@@ -456,6 +479,19 @@ extern "C" int r4r_embed_scatter_add(const float *g_out, const int64_t *idx, flo
     fill_zero_kernel<<<zb, 256, 0, st>>>(g_table, tot);
     if (n > 0) embed_scatter_add_kernel<<<blocks_for(n * D), 256, 0, st>>>(g_out, idx, g_table, D, n);
     return check_launch("embed_scatter_add");
+}
+
+extern "C" int r4r_embed_scatter_add_ordered(const float *g_out, const int64_t *idx, float *g_table,
+                                             int64_t R, int D, int64_t n, void *stream) {
+    R4R_REQUIRE(g_out && idx && g_table, "embed_scatter_add_ordered: null pointer");
+    R4R_REQUIRE(R > 0 && D > 0 && n >= 0 && n <= (1 << 20), "embed_scatter_add_ordered: bad sizes");
+    hipStream_t st = as_stream(stream);
+    const int64_t tot = R * D;
+    unsigned zb = blocks_for(tot);
+    if (zb > 4096) zb = 4096;
+    fill_zero_kernel<<<zb, 256, 0, st>>>(g_table, tot);
+    if (n > 0) embed_scatter_add_ordered_kernel<<<blocks_for(n * 64), 256, 0, st>>>(g_out, idx, g_table, D, n);
+    return check_launch("embed_scatter_add_ordered");
 }
 
 extern "C" int r4r_rowdot_fwd(const float *a, const float *c, float *out, int64_t N, int D, void *stream) {

@@ -6,10 +6,17 @@ Every example's forward/backward is independent given the weights and the loss
 is a mean over the batch (main.py:58), so a global batch is split contiguously
 across ranks and the only exchange is the gradient sum:
 
-  C1  ONE all-reduce per step over ONE flat fp32 bucket holding every gradient
-      that exists (DeepCoNN @E=300: 182,402 floats = 0.73 MB).  On the xGMI full
-      mesh a sub-MB payload is latency-bound, so a single bucket -- not
+  C1  ONE all-reduce per step over ONE flat fp32 bucket holding every DENSE-layer
+      gradient that exists (DeepCoNN @E=300: 182,402 floats = 0.73 MB).  On the
+      xGMI full mesh a sub-MB payload is latency-bound, so a single bucket -- not
       per-tensor calls, not ring-sized buckets -- is the right shape.
+  C2  ID-embedding tables and bias vectors (MF_dot on Electronics: 16.6 M floats =
+      66 MB if reduced densely) never cross xGMI as dense gradients.  Their backward
+      records compact (row-id, gradient-row) lists (ops.SparseGradCapture); each rank
+      pads its list to the step's common length, ONE all_gather per table moves
+      B_global x (D + 2) floats, and every rank rebuilds the identical dense gradient
+      with a fixed summation order (r4r_embed_scatter_add_ordered), then runs the
+      same dense Adam (untouched rows still move by weight decay: SURVEY.md fact 4).
   Parameters with no gradient (DeepCoNN's unused `final` MLP and biases in
   'deepconn' mode) are left out of the bucket; the active set
   is agreed once across ranks (a rank whose shard is empty contributes zeros).
@@ -57,7 +64,10 @@ def shard_batch(data, y, rank, world):
 
 
 class DataParallel:
-    def __init__(self, model, group=None):
+    def __init__(self, model, group=None, sparse_tables=True, rebuild_fn=None):
+        """sparse_tables: exchange ID-table / bias gradients as compact lists (C2) instead of
+        putting them into the dense bucket.  rebuild_fn(idx, g, R, D, out) -> dense [R, D]
+        gradient (default: the HIP ordered scatter; tests on the CPU inject their own)."""
         self.model = model
         self.group = group
         self.on = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
@@ -66,6 +76,14 @@ class DataParallel:
         self.params = [p for p in model.parameters() if p.requires_grad]
         self._active = None          # indices into self.params that carry gradients
         self._bucket = None
+        self.sparse = bool(sparse_tables) and self.on
+        self._rebuild = rebuild_fn
+        self._sparse_set = None      # indices into self.params exchanged as compact lists
+        self._dense_grads = {}
+        if self.sparse:
+            from . import ops
+            ops.SparseGradCapture.active = True
+            ops.SparseGradCapture.clear()
 
     def broadcast_parameters(self, src=0):
         """Make every replica start from rank `src`'s weights (buffers included)."""
@@ -85,13 +103,55 @@ class DataParallel:
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
         return int(t.item())
 
-    def _agree_active_set(self, device):
+    def _agree_active_set(self, device, contributions):
         have = torch.tensor([1.0 if p.grad is not None else 0.0 for p in self.params], device=device)
+        sp = torch.tensor([1.0 if p.data_ptr() in contributions else 0.0 for p in self.params], device=device)
         if self.on:
             dist.all_reduce(have, op=dist.ReduceOp.MAX, group=self.group)
-        self._active = [i for i, h in enumerate(have.tolist()) if h > 0]
+            dist.all_reduce(sp, op=dist.ReduceOp.MAX, group=self.group)
+        self._sparse_set = [i for i, h in enumerate(sp.tolist()) if h > 0]
+        self._active = [i for i, h in enumerate(have.tolist()) if h > 0 and i not in set(self._sparse_set)]
         total = sum(self.params[i].numel() for i in self._active)
         self._bucket = torch.zeros(total, dtype=torch.float32, device=device)
+
+    @torch.no_grad()
+    def _exchange_sparse(self, device, contributions):
+        """C2: all_gather the compact (row-id, grad-row) lists and rebuild dense gradients."""
+        if not self._sparse_set:
+            return
+        rebuild = self._rebuild
+        if rebuild is None:
+            from . import ops
+            rebuild = ops.rebuild_dense
+        locals_ = []
+        for i in self._sparse_set:
+            p = self.params[i]
+            D = 1 if p.dim() == 1 else p.shape[1]
+            parts = contributions.get(p.data_ptr(), [])
+            if parts:
+                idx = torch.cat([a.reshape(-1) for a, _ in parts])
+                g = torch.cat([b.reshape(-1, D) for _, b in parts])
+            else:
+                idx = torch.empty(0, dtype=torch.int64, device=device)
+                g = torch.empty((0, D), dtype=torch.float32, device=device)
+            locals_.append((p, D, idx, g))
+        counts = torch.tensor([float(idx.numel()) for _, _, idx, _ in locals_], device=device)
+        dist.all_reduce(counts, op=dist.ReduceOp.MAX, group=self.group)       # common padded length per table
+        for (p, D, idx, g), nmax in zip(locals_, counts.tolist()):
+            nmax = int(nmax)
+            pad_idx = torch.full((nmax,), -1, dtype=torch.int64, device=device)
+            pad_g = torch.zeros((nmax, D), dtype=torch.float32, device=device)
+            pad_idx[:idx.numel()] = idx
+            pad_g[:idx.numel()] = g
+            all_idx = torch.empty((self.world * nmax,), dtype=torch.int64, device=device)
+            all_g = torch.empty((self.world * nmax, D), dtype=torch.float32, device=device)
+            dist.all_gather_into_tensor(all_idx, pad_idx, group=self.group)
+            dist.all_gather_into_tensor(all_g, pad_g, group=self.group)
+            R = p.shape[0]
+            out = self._dense_grads.get(id(p))
+            if out is None:
+                out = self._dense_grads[id(p)] = torch.empty((R, D), dtype=torch.float32, device=device)
+            p.grad = rebuild(all_idx, all_g, R, D, out).view_as(p)
 
     @torch.no_grad()
     def allreduce_grads(self):
@@ -100,8 +160,15 @@ class DataParallel:
         if not self.on:
             return
         device = self.params[0].device
+        contributions = {}
+        if self.sparse:
+            from . import ops
+            contributions = ops.SparseGradCapture.contributions
         if self._active is None:
-            self._agree_active_set(device)
+            self._agree_active_set(device, contributions)
+        if self.sparse:
+            self._exchange_sparse(device, contributions)
+            ops.SparseGradCapture.clear()
         bucket = self._bucket
         off = 0
         views = []

@@ -250,6 +250,35 @@ def fm(x, V, lin_w, lin_b):
 
 
 # ------------------------------------------------------- embeddings / biases
+class SparseGradCapture:
+    """Data-parallel mode for ID tables / bias vectors (dist.DataParallel turns it on).
+
+    When ``active`` the backward of an embedding / bias gather does NOT build the dense table
+    gradient; it records the compact contribution ``(row ids, gradient rows)`` under the table's
+    storage address and hands autograd an uninitialised placeholder.  DataParallel all-gathers the
+    compact lists and rebuilds the identical dense gradient on every rank
+    (``rebuild_dense``), so a dense table gradient never crosses xGMI."""
+    active = False
+    contributions = {}          # table.data_ptr() -> list[(idx [n] int64, g [n, D] fp32)]
+
+    @classmethod
+    def record(cls, table_ptr, idx, g):
+        cls.contributions.setdefault(table_ptr, []).append((idx, g))
+
+    @classmethod
+    def clear(cls):
+        cls.contributions = {}
+
+
+def rebuild_dense(idx, g, R, D, out=None):
+    """Dense [R, D] gradient from a compact list, deterministic summation order."""
+    idx, g = _i64(idx, 'idx').reshape(-1), _f32(g, 'g').reshape(-1, D)
+    if out is None:
+        out = torch.empty((R, D), dtype=torch.float32, device=g.device)
+    call('r4r_embed_scatter_add_ordered', ptr(g), ptr(idx), ptr(out), R, D, idx.numel())
+    return out
+
+
 class EmbedGather(Function):
     """rows = table[idx]; backward is the reference's DENSE table gradient."""
 
@@ -262,6 +291,7 @@ class EmbedGather(Function):
         call('r4r_embed_gather', ptr(table), ptr(flat), ptr(out), R, D, flat.numel())
         ctx.save_for_backward(flat)
         ctx.shape = (R, D)
+        ctx.table_ptr = table.data_ptr()
         return out.view(*idx.shape, D)
 
     @staticmethod
@@ -270,6 +300,9 @@ class EmbedGather(Function):
         R, D = ctx.shape
         g = _f32(g, 'g').reshape(-1, D)
         g_table = torch.empty((R, D), dtype=torch.float32, device=g.device)
+        if SparseGradCapture.active:
+            SparseGradCapture.record(ctx.table_ptr, flat, g)   # dense gradient rebuilt after the exchange
+            return g_table, None
         call('r4r_embed_scatter_add', ptr(g), ptr(flat), ptr(g_table), R, D, flat.numel())
         return g_table, None
 
@@ -314,6 +347,7 @@ class BiasHead(Function):
             N = uid.numel()
             ctx.save_for_backward(uid, iid)
             ctx.sizes = (user_bias.numel(), item_bias.numel())
+            ctx.ptrs = (user_bias.data_ptr(), item_bias.data_ptr())
         if r is not None:
             r = _f32(r, 'r')
             N = r.numel()
@@ -334,6 +368,11 @@ class BiasHead(Function):
             RU, RI = ctx.sizes
             g_ub = torch.empty((RU,), dtype=torch.float32, device=g.device)
             g_ib = torch.empty((RI,), dtype=torch.float32, device=g.device)
+            if SparseGradCapture.active:
+                SparseGradCapture.record(ctx.ptrs[0], uid, g.reshape(-1, 1))
+                SparseGradCapture.record(ctx.ptrs[1], iid, g.reshape(-1, 1))
+                call('r4r_bias_head_bwd', ptr(g), None, None, None, None, ptr(g_gb), 0, 0, g.numel())
+                return (g if ctx.has_r else None), g_ub, g_ib, g_gb, None, None
         call('r4r_bias_head_bwd', ptr(g), ptr(uid), ptr(iid), ptr(g_ub), ptr(g_ib), ptr(g_gb), RU, RI, g.numel())
         return (g if ctx.has_r else None), g_ub, g_ib, g_gb, None, None
 

@@ -102,3 +102,64 @@ def test_shard_bounds_cover_the_batch():
             assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
             sizes = [hi - lo for lo, hi in spans]
             assert max(sizes) - min(sizes) <= 1
+
+
+def _sparse_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    torch.set_num_threads(1)
+    from reviews4rec_amd import dist as r4dist, ops
+    r4dist.init_from_env(backend='gloo')
+
+    class Tiny(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.table = torch.nn.Parameter(torch.zeros(11, 3))
+            self.bias = torch.nn.Parameter(torch.zeros(11))
+            self.dense = torch.nn.Parameter(torch.zeros(4))
+
+    def rebuild(idx, g, R, D, out):                        # CPU stand-in for r4r_embed_scatter_add_ordered
+        out.zero_()
+        keep = idx >= 0
+        out.index_add_(0, idx[keep], g[keep])
+        return out
+
+    model = Tiny()
+    dp = r4dist.DataParallel(model, rebuild_fn=rebuild)
+    gen = torch.Generator().manual_seed(100 + rank)
+    n = 5 if rank == 0 else 3                               # ragged shards -> padded exchange
+    for step in range(2):
+        idx = torch.randint(0, 11, (n,), generator=gen)
+        g = torch.randn((n, 3), generator=gen)
+        gb = torch.randn((n, 1), generator=gen)
+        # what ops.EmbedGather / BiasHead backward record in capture mode
+        ops.SparseGradCapture.record(model.table.data_ptr(), idx, g)
+        ops.SparseGradCapture.record(model.bias.data_ptr(), idx, gb)
+        model.table.grad = torch.empty_like(model.table)     # the uninitialised placeholders
+        model.bias.grad = torch.empty_like(model.bias)
+        model.dense.grad = torch.full((4,), float(rank + 1))
+        dp.allreduce_grads()
+        torch.save(dict(table=model.table.grad.clone(), bias=model.bias.grad.clone(), dense=model.dense.grad.clone(),
+                        idx=idx, g=g, gb=gb), os.path.join(out_dir, 's%d_r%d.pt' % (step, rank)))
+    assert not ops.SparseGradCapture.contributions          # consumed
+    ops.SparseGradCapture.active = False
+    dist.destroy_process_group()
+
+
+def test_sparse_table_gradients_are_exchanged_as_compact_lists(tmp_path):
+    """ID-table / bias gradients travel as all-gathered (row-id, grad-row) lists; every
+    rank rebuilds the same dense gradient = sum of all ranks' contributions; dense-layer gradients
+    still go through the flat all-reduce bucket."""
+    port = _free_port()
+    mp.spawn(_sparse_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    for step in range(2):
+        r0 = torch.load(os.path.join(tmp_path, 's%d_r0.pt' % step))
+        r1 = torch.load(os.path.join(tmp_path, 's%d_r1.pt' % step))
+        want_t = torch.zeros(11, 3).index_add_(0, torch.cat([r0['idx'], r1['idx']]), torch.cat([r0['g'], r1['g']]))
+        want_b = torch.zeros(11, 1).index_add_(0, torch.cat([r0['idx'], r1['idx']]), torch.cat([r0['gb'], r1['gb']]))
+        for r in (r0, r1):
+            torch.testing.assert_close(r['table'], want_t)
+            torch.testing.assert_close(r['bias'], want_b.view(-1))
+            assert torch.equal(r['dense'], torch.full((4,), 3.0))
+        assert torch.equal(r0['table'], r1['table']) and torch.equal(r0['bias'], r1['bias'])

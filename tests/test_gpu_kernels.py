@@ -201,6 +201,56 @@ def test_embed_gather_and_dense_scatter_with_duplicates():
     assert (td.grad.cpu()[[1, 2, 4]] == 0).all()            # untouched rows: exact zeros (dense grad)
 
 
+def test_ordered_scatter_is_deterministic_and_skips_padding():
+    """r4r_embed_scatter_add_ordered (the dense rebuild of the all-gathered compact lists): equals
+    index_add, ignores -1 padding entries, and is bit-identical run to run with many duplicates."""
+    ops = _ops()
+    R, D, n = 40, 10, 600
+    g = torch.Generator().manual_seed(1)
+    idx = torch.randint(0, 7, (n,), generator=g)            # heavy duplication
+    idx[::9] = -1                                           # padding entries
+    rows = torch.randn((n, D), generator=g)
+    keep = idx >= 0
+    want = torch.zeros((R, D), dtype=torch.float64).index_add_(0, idx[keep], rows[keep].double()).float()
+    a = ops.rebuild_dense(idx.to(DEV), rows.to(DEV), R, D)
+    b = ops.rebuild_dense(idx.to(DEV), rows.to(DEV), R, D)
+    torch.testing.assert_close(a.cpu(), want, rtol=1e-5, atol=1e-5)
+    assert torch.equal(a, b)
+    assert (a.cpu()[7:] == 0).all()
+
+
+def test_sparse_capture_mode_matches_dense_backward():
+    """With ops.SparseGradCapture on, the embedding / bias backward records compact contributions;
+    rebuilding them gives the same dense gradients the default backward produces."""
+    ops = _ops()
+    U, I, D, N = 30, 20, 8, 50
+    g = torch.Generator().manual_seed(2)
+    ue, ub, ib, gb = torch.randn((U, D), generator=g), torch.randn(U, generator=g), torch.randn(I, generator=g), torch.randn(1)
+    uid, iid = torch.randint(0, U, (N,), generator=g).to(DEV), torch.randint(0, I, (N,), generator=g).to(DEV)
+    go = torch.randn(N, generator=g).to(DEV)
+
+    def run():
+        P = [t.clone().to(DEV).requires_grad_(True) for t in (ue, ub, ib, gb)]
+        out = ops.bias_head(ops.embed(P[0], uid).sum(-1), P[1], P[2], P[3], uid, iid)
+        out.backward(go)
+        return P
+
+    ref = run()
+    ops.SparseGradCapture.active = True
+    ops.SparseGradCapture.clear()
+    try:
+        P = run()
+        c = ops.SparseGradCapture.contributions
+        for p, r, (R, Dp) in zip(P[:3], ref[:3], ((U, D), (U, 1), (I, 1))):
+            (idx, rows), = c[p.data_ptr()]
+            dense = ops.rebuild_dense(idx, rows, R, Dp).view_as(r.grad)
+            torch.testing.assert_close(dense, r.grad, rtol=1e-5, atol=1e-6)
+        torch.testing.assert_close(P[3].grad, ref[3].grad)
+    finally:
+        ops.SparseGradCapture.active = False
+        ops.SparseGradCapture.clear()
+
+
 def test_rowdot_and_bias_head():
     ops = _ops()
     N, D, U, I = 37, 64, 20, 11
