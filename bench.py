@@ -162,7 +162,12 @@ def main():
     dp.broadcast_parameters()
     DropoutState.manual_seed(4321, rank)
     criterion = MSELoss(hp)
-    optimizer = Adam(model.parameters(), lr=hp['lr'], weight_decay=hp['weight_decay'])
+    is_tn = hp['model_type'] in ('transnet', 'transnet++')
+    if is_tn:
+        from reviews4rec_amd.utils import init_transnet_optim
+        optimizer = init_transnet_optim(hp, model)           # utils.py:70-92: [source, source_fm, target, all]
+    else:
+        optimizer = Adam(model.parameters(), lr=hp['lr'], weight_decay=hp['weight_decay'])
 
     gen = synthetic.Generator(hp, seed=synthetic.SEED + rank)   # each rank owns its shard of the stream
     batches_np = [gen.batch(B) for _ in range(args.pool)]
@@ -181,7 +186,7 @@ def main():
         if world > 1:
             raise SystemExit('--engine graph is single-GPU for now (the all-reduce is not captured)')
         from reviews4rec_amd.graph import GraphedStep
-        graphed = GraphedStep(model, criterion, optimizer, *pool[0])
+        graphed = GraphedStep(model, criterion, optimizer, *pool[0])   # TransNet: the optimiser list
 
     def step(i):
         data, y = pool[i % len(pool)]
@@ -192,6 +197,19 @@ def main():
             engine.train_step(data, y, n_global=B_global)   # forward + loss + backward + all-reduce + Adam
             return
         model.zero_grad()
+        if is_tn:                                            # the 3-optimiser step of main.py:35-53
+            for o in optimizer:
+                o.zero_grad()
+            out = model(data)
+            criterion(out[1], y).backward(retain_graph=True)
+            optimizer[2].step()
+            out[2].backward(retain_graph=True)
+            optimizer[0].step()
+            se = criterion(out[0], y, return_mean=False)
+            metric_sum.add_(se.detach().sum())
+            torch.mean(se).backward()
+            optimizer[1].step()
+            return
         optimizer.zero_grad()
         out = model(data)
         se = criterion(out, y, return_mean=False)

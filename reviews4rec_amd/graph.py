@@ -24,7 +24,12 @@ from . import ops
 
 class GraphedStep:
     def __init__(self, model, criterion, optimizer, example_data, example_y, warmup=2):
+        """optimizer: one fused Adam, or TransNet's list [source, source_fm, target, all]
+        (utils.init_transnet_optim) -- then the captured body is the 3-optimiser step of
+        main.py:35-53."""
         self.model, self.criterion, self.optimizer = model, criterion, optimizer
+        self.tn = isinstance(optimizer, (list, tuple))
+        self.optimizers = list(optimizer[:3]) if self.tn else [optimizer]
         dev = example_y.device
         self.static_data = [None if d is None else d.clone() for d in example_data]
         self.static_y = example_y.clone()
@@ -37,8 +42,8 @@ class GraphedStep:
         # the dropout stream position are snapshotted and restored around them.
         params = [p for p in model.parameters()]
         snap_p = [p.detach().clone() for p in params]
-        snap_s = {k: {n: (v.clone() if torch.is_tensor(v) else v) for n, v in st.items()}
-                  for k, st in optimizer.state.items()}
+        snap_s = [{k: {n: (v.clone() if torch.is_tensor(v) else v) for n, v in st.items()}
+                   for k, st in o.state.items()} for o in self.optimizers]
         snap_off = (ops.DropoutState.offset, ops.DropoutState.device_counter.clone())
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
@@ -49,33 +54,51 @@ class GraphedStep:
         with torch.no_grad():
             for p, sp in zip(params, snap_p):
                 p.copy_(sp)
-            for k, st in optimizer.state.items():
-                old = snap_s.get(k)
-                for n in ('exp_avg', 'exp_avg_sq'):
-                    st[n].copy_(old[n]) if old is not None else st[n].zero_()
-                st['step'] = old['step'] if old is not None else 0
+            for o, snap in zip(self.optimizers, snap_s):
+                for k, st in o.state.items():
+                    old = snap.get(k)
+                    for n in ('exp_avg', 'exp_avg_sq'):
+                        st[n].copy_(old[n]) if old is not None else st[n].zero_()
+                    st['step'] = old['step'] if old is not None else 0
         ops.DropoutState.offset = snap_off[0]
         ops.DropoutState.device_counter.copy_(snap_off[1])
-        optimizer.enable_device_step()
+        for o in self.optimizers:
+            o.enable_device_step()
         self.graph = torch.cuda.CUDAGraph()
-        optimizer.zero_grad(set_to_none=True)
+        self._zero_grads(set_to_none=True)
         with torch.cuda.graph(self.graph):
             self._body(self.static_data, self.static_y, count=True)
         self.graph_se = self.last_se                         # static output of the captured step
         self.warmup_steps = warmup
 
+    def _zero_grads(self, set_to_none=True):
+        self.model.zero_grad(set_to_none=set_to_none)
+        for o in (self.optimizer if self.tn else [self.optimizer]):
+            o.zero_grad(set_to_none=set_to_none)
+
     def _body(self, data, y, count):
         out = self.model(data)
-        se = self.criterion(out, y, return_mean=False)
-        if count:
-            self.sse.add_(se.detach().sum())
-        torch.mean(se).backward()
-        self.optimizer.step()
+        if self.tn:
+            opt_source, opt_source_fm, opt_target = self.optimizers
+            self.criterion(out[1], y).backward(retain_graph=True)
+            opt_target.step()
+            out[2].backward(retain_graph=True)
+            opt_source.step()
+            se = self.criterion(out[0], y, return_mean=False)
+            if count:
+                self.sse.add_(se.detach().sum())
+            torch.mean(se).backward()
+            opt_source_fm.step()
+        else:
+            se = self.criterion(out, y, return_mean=False)
+            if count:
+                self.sse.add_(se.detach().sum())
+            torch.mean(se).backward()
+            self.optimizer.step()
         self.last_se = se
 
     def _eager(self, data, y, count=True):
-        self.model.zero_grad()
-        self.optimizer.zero_grad()
+        self._zero_grads()
         self._body(data, y, count)
 
     def __call__(self, data, y):

@@ -81,3 +81,27 @@ def test_host_loop_with_graph_engine_matches_reference_metric():
     expected = round(float(g.arr('se0').sum() + g.arr('se1').sum()) / n, 4)
     assert holder.step is not None and metrics['MSE'] == pytest.approx(expected, abs=2e-4)
     ops.DropoutState.device_counter = None
+
+
+@pytest.mark.parametrize('case', ['transnet_e16', 'transnetpp_e16'])
+def test_graphed_transnet_three_optimiser_step(case):
+    """The 3-optimiser TransNet step captured in one hipGraph reproduces the reference-generated
+    trajectory (steps 0 and 2 replay the graph, step 1 is the ragged batch -> eager)."""
+    from reviews4rec_amd import main as M, ops
+    from reviews4rec_amd.graph import GraphedStep
+    from reviews4rec_amd.loss import MSELoss
+    ops.DropoutState.device_counter = None
+    g = Golden(case)
+    model, hp = build_model(g)
+    model.train()
+    d0, y0 = g.batch(0, DEV)
+    step = GraphedStep(model, MSELoss(hp), M.make_optimizer(hp, model), d0, y0)
+    for k in range(3):
+        data, y = g.batch(k % 2, DEV)
+        se = step(data, y)
+        torch.testing.assert_close(se.detach().cpu(), g.arr('tn_se%d' % k), rtol=1e-4, atol=1e-5)
+        if k in (0, 2):
+            sd = model.state_dict()
+            for name, v in g.params('tn_w%d' % (k + 1)).items():
+                torch.testing.assert_close(sd[name].cpu(), v, rtol=1e-5, atol=1e-5, msg=lambda m: name + ': ' + m)
+    ops.DropoutState.device_counter = None
