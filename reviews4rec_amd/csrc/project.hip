@@ -277,11 +277,27 @@ __global__ __launch_bounds__(256) void proj_gather_max_kernel(ProjArgs a) {
     const int p_hi = min(P, p_lo + SLICE);
     const int t_lo = p_lo - 2;
     const int ntok = (seg < a.tiles && p_hi > p_lo) ? p_hi - t_lo : 0;     // tokens t_lo .. p_hi-1
+    // stage the slice's slots; at the same time find out whether all its tokens are the SAME row
+    // (typically the zero-padded tail of a document, data.py:198-199): then every position of the
+    // slice has the same window sum and its first position decides the slice (first-max wins).
+    bool same = true;
     for (int k = wl; k < ntok; k += 32) {
         const int t = t_lo + k;
-        sl[worker][k] = (t >= 0 && t < T) ? tw.slot[tw.idx[doc * T + t]] : -1;
+        const int sv = (t >= 0 && t < T) ? tw.slot[tw.idx[doc * T + t]] : -1;
+        sl[worker][k] = sv;
     }
     __syncthreads();
+    if (ntok > 0) {
+        const int s_first = sl[worker][0];
+        for (int k = wl; k < ntok; k += 32) same &= (sl[worker][k] == s_first);
+    }
+    // all 32 lanes of the worker (one half-wave) must agree
+    {
+        const unsigned long long m = __ballot(same);
+        const unsigned long long mine = (worker & 1) ? (m >> 32) : (m & 0xffffffffull);
+        same = (mine == 0xffffffffull);
+    }
+    const int npos_eff = same ? min(1, ntok - 2) : ntok - 2;   // positions actually walked
 
     float best[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
     int bp[4] = {0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff};
@@ -298,7 +314,7 @@ __global__ __launch_bounds__(256) void proj_gather_max_kernel(ProjArgs a) {
         };
         const int s0 = sl[worker][0], s1 = sl[worker][1];
         const f32x4 h00 = load_row(s0, 0), h11 = load_row(s1, 1), h10 = load_row(s1, 0);
-        const int npos = ntok - 2;                           // positions p_lo .. p_hi-1 <-> tokens 2 .. ntok-1
+        const int npos = npos_eff;                           // positions p_lo .. <-> tokens 2 ..; 1 if the slice is uniform
         bool seeded = false;
         for (int k = 0; k < npos; k += GDEPTH) {
             f32x4 r0[GDEPTH], r1[GDEPTH], r2[GDEPTH];

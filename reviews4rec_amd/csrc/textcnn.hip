@@ -323,8 +323,16 @@ int textcnn_pick_algo(int requested, int64_t N, int T, int E, int F) {
 }
 
 int textcnn_wgrad_splits(int64_t N) {
-    // >= 1024 workgroups when the batch allows it, at least 8 documents per split
-    int s = (int)cdiv(N, 8);
+    // Documents per split: 16 = one phase-1 round of the wgrad workgroup.  Measured at B=128 (backward +
+    // reduce kernels): 8 docs 14.0 + 8.3 us, 16 docs 11.0 + 5.1, 32 docs 14.6 + 4.9, 64 docs 25.2 + 4.4.
+    // R4R_WGRAD_DOCS pins another value for A/B runs.
+    static int docs = -1;
+    if (docs < 0) {
+        const char *e = getenv("R4R_WGRAD_DOCS");
+        docs = e ? atoi(e) : 16;
+        if (docs < 1) docs = 16;
+    }
+    int s = (int)cdiv(N, docs);
     if (s > 16) s = 16;
     if (s < 1) s = 1;
     return s;
