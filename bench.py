@@ -68,6 +68,9 @@ def parse():
     ap.add_argument('--conv-algo', choices=['auto', 'direct', 'project'], default='auto',
                     help='native engine: direct gather-fused MFMA conv, or projection GEMM over the distinct '
                          'tokens + gather-add-max (include/r4r.h R4R_CONV_*)')
+    ap.add_argument('--token-prefetch', type=int, default=0,
+                    help='native engine: compact batch k+1\'s tokens on a side stream during step k '
+                         '(measured 2 %% slower than inline at cfg3 B=128: DESIGN.md section 7)')
     ap.add_argument('--engine', choices=['native', 'module', 'graph'], default='native',
                     help="native: fused r4r_deepconn_step where the model has one (else module); module: op-by-op "
                          "autograd path; graph: the module path captured into one hipGraph per step")
@@ -194,7 +197,8 @@ def main():
             graphed(data, y)
             return
         if engine is not None:
-            engine.train_step(data, y, n_global=B_global)   # forward + loss + backward + all-reduce + Adam
+            # forward + loss + backward + all-reduce + Adam; the next batch's token compaction overlaps it
+            engine.train_step(data, y, n_global=B_global, next_data=pool[(i + 1) % len(pool)][0] if args.token_prefetch else None)
             return
         model.zero_grad()
         if is_tn:                                            # the 3-optimiser step of main.py:35-53

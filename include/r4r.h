@@ -247,7 +247,15 @@ int r4r_deepconn_step(const float *table, int64_t V, const int64_t *user_idx, co
                       void *ws, size_t ws_bytes,
                       int64_t B, int T, int E, int L,
                       float dropout_p, int training, uint64_t seed, uint64_t offset,
-                      float inv_denom, int conv_algo, void *stream);
+                      float inv_denom, int conv_algo, int token_buffer, int tokens_ready, void *stream);
+/* Token compaction of a batch (distinct tokens -> dense rows) into token-state buffer 0 or 1 of the
+ * workspace.  It depends only on the indices, so the caller may run it for batch k+1 on another
+ * stream while step k computes, and then pass token_buffer / tokens_ready = 1 to step k+1
+ * (otherwise the step does it itself).  The workspace must be zero-filled when created; the
+ * kernels keep the flag / count words zero between calls. */
+int r4r_deepconn_tokens(const int64_t *user_idx, const int64_t *item_idx, void *ws, size_t ws_bytes,
+                        int64_t B, int T, int E, int L, int64_t V, int conv_algo, int token_buffer,
+                        int discard, void *stream);   /* discard != 0: reset a prepared but unused buffer */
 
 /* ------------------------------------------------------------------------
  * Live kernel timing for bench.py's roofline leg (no reference counterpart: the

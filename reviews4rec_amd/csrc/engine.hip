@@ -315,8 +315,9 @@ __global__ void sse_only_kernel(const float *__restrict__ se, float *__restrict_
 
 struct StepWs {
     float *wp[2], *pmax[2]; int *parg[2];
-    int *flags[2], *slot[2], *list[2], *count[2]; float *ptab[2];   // project-then-gather
-    size_t flags_off[2];
+    // project-then-gather: token state is double buffered ([buffer][tower]) so batch k+1's
+    // compaction can run while step k computes; the projected rows are per tower
+    int *flags[2][2], *slot[2][2], *list[2][2], *count[2][2]; float *ptab[2];
     float *pooled[2]; int *argmax[2]; float *g_pooled[2];
     float *mult, *x, *s, *g, *gz;
     float *part_w[2], *part_b[2];
@@ -338,11 +339,12 @@ static StepWs carve(void *ws, int64_t B, int T, int E, int L, int64_t V) {
         w.g_pooled[t] = reinterpret_cast<float *>(take((size_t)B * F_CONV * 4));
         w.part_w[t] = reinterpret_cast<float *>(take((size_t)ns * F_CONV * 3 * E * 4));
         w.part_b[t] = reinterpret_cast<float *>(take((size_t)ns * F_CONV * 4));
-        w.flags[t] = reinterpret_cast<int *>(take((size_t)(V + 4) * 4));
-        w.flags_off[t] = (size_t)(reinterpret_cast<char *>(w.flags[t]) - static_cast<char *>(ws));
-        w.slot[t] = reinterpret_cast<int *>(take((size_t)(V + 4) * 4));
-        w.list[t] = reinterpret_cast<int *>(take((size_t)proj_row_capacity(B, T, V) * 4));
-        w.count[t] = reinterpret_cast<int *>(take(256));
+        for (int bf = 0; bf < 2; ++bf) {
+            w.flags[bf][t] = reinterpret_cast<int *>(take((size_t)(V + 4) * 4));
+            w.slot[bf][t] = reinterpret_cast<int *>(take((size_t)(V + 4) * 4));
+            w.list[bf][t] = reinterpret_cast<int *>(take((size_t)proj_row_capacity(B, T, V) * 4));
+            w.count[bf][t] = reinterpret_cast<int *>(take(256));
+        }
         w.ptab[t] = reinterpret_cast<float *>(take(proj_ptab_floats(B, T, V) * 4));
     }
     w.mult = reinterpret_cast<float *>(take((size_t)B * 2 * L * 4));
@@ -381,13 +383,43 @@ extern "C" size_t r4r_deepconn_ws_mult_offset(int64_t B, int T, int E, int L, in
     return (size_t)(reinterpret_cast<char *>(w.mult) - base);
 }
 
+// Token compaction of a batch into token-state buffer `token_buffer` (project-then-gather only;
+// a no-op for configurations that run the direct conv).  Depends only on the indices: run it for
+// batch k+1 on a side stream while step k computes, then pass tokens_ready = 1 to that step.
+extern "C" int r4r_deepconn_tokens(const int64_t *user_idx, const int64_t *item_idx, void *ws, size_t ws_bytes,
+                                   int64_t B, int T, int E, int L, int64_t V, int conv_algo, int token_buffer,
+                                   int discard, void *stream) {
+    R4R_REQUIRE(user_idx && item_idx && ws, "deepconn_tokens: null pointer");
+    R4R_REQUIRE(token_buffer == 0 || token_buffer == 1, "deepconn_tokens: token_buffer must be 0 or 1");
+    if (ws_bytes < r4r_deepconn_ws_bytes(B, T, E, L, V)) {
+        set_error("deepconn_tokens: workspace %zu < %zu bytes", ws_bytes, r4r_deepconn_ws_bytes(B, T, E, L, V));
+        return R4R_ERR_WORKSPACE;
+    }
+    if (B == 0 || textcnn_pick_algo(conv_algo, B, T, E, F_CONV) != R4R_CONV_PROJECT) return R4R_OK;
+    const StepWs w = carve(ws, B, T, E, L, V);
+    if (discard) {                                          // drop a prepared-but-unused token state
+        for (int t = 0; t < 2; ++t) (void)hipMemsetAsync(w.count[token_buffer][t], 0, sizeof(int), as_stream(stream));
+        return check_launch("deepconn_tokens(discard)");
+    }
+    ProjTower pt[2];
+    const int64_t *idx[2] = {user_idx, item_idx};
+    for (int t = 0; t < 2; ++t) {
+        pt[t] = ProjTower{};
+        pt[t].idx = idx[t];
+        pt[t].flags = w.flags[token_buffer][t]; pt[t].slot = w.slot[token_buffer][t];
+        pt[t].list = w.list[token_buffer][t]; pt[t].count = w.count[token_buffer][t];
+    }
+    return textcnn_proj_tokens_launch(V, pt, 2, B, T, /*zero_state=*/false, as_stream(stream));
+}
+
 extern "C" int r4r_deepconn_step(const float *table, int64_t V, const int64_t *user_idx, const int64_t *item_idx,
                                  const float *y, const float *flat_p, float *flat_g,
                                  float *pred, float *se, float *sse_accum,
                                  void *ws, size_t ws_bytes,
                                  int64_t B, int T, int E, int L,
                                  float dropout_p, int training, uint64_t seed, uint64_t offset,
-                                 float inv_denom, int conv_algo, void *stream) {
+                                 float inv_denom, int conv_algo, int token_buffer, int tokens_ready,
+                                 void *stream) {
     R4R_REQUIRE(table && user_idx && item_idx && flat_p && pred && ws, "deepconn_step: null pointer");
     R4R_REQUIRE(V > 0 && B >= 0 && T > 0, "deepconn_step: bad sizes");
     R4R_REQUIRE(E > 0 && E % 4 == 0, "deepconn_step: word_embed_size %d must be a positive multiple of 4", E);
@@ -396,6 +428,7 @@ extern "C" int r4r_deepconn_step(const float *table, int64_t V, const int64_t *u
     R4R_REQUIRE(!y || se, "deepconn_step: se buffer required when y is given");
     R4R_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, "deepconn_step: dropout %f outside [0,1)", (double)dropout_p);
     R4R_REQUIRE(B * (int64_t)((T + 2 + 127) / 128) < (1ll << 31), "deepconn_step: grid too large");
+    R4R_REQUIRE(token_buffer == 0 || token_buffer == 1, "deepconn_step: token_buffer must be 0 or 1");
     if (ws_bytes < r4r_deepconn_ws_bytes(B, T, E, L, V)) {
         set_error("deepconn_step: workspace %zu < %zu bytes", ws_bytes, r4r_deepconn_ws_bytes(B, T, E, L, V));
         return R4R_ERR_WORKSPACE;
@@ -421,10 +454,13 @@ extern "C" int r4r_deepconn_step(const float *table, int64_t V, const int64_t *u
             pt[t].idx = idx[t];
             pt[t].conv_w = P[t ? P_ICW : P_UCW];
             pt[t].conv_b = P[t ? P_ICB : P_UCB];
-            pt[t].flags = w.flags[t]; pt[t].slot = w.slot[t]; pt[t].list = w.list[t]; pt[t].count = w.count[t];
+            pt[t].flags = w.flags[token_buffer][t]; pt[t].slot = w.slot[token_buffer][t];
+            pt[t].list = w.list[token_buffer][t]; pt[t].count = w.count[token_buffer][t];
             pt[t].ptab = w.ptab[t]; pt[t].pmax = w.pmax[t]; pt[t].parg = w.parg[t];
         }
-        if (int rc = textcnn_proj_fwd_launch(table, V, pt, 2, B, T, E, F_CONV, /*zero_state=*/false, st)) return rc;
+        if (!tokens_ready)
+            if (int rc = textcnn_proj_tokens_launch(V, pt, 2, B, T, /*zero_state=*/false, st)) return rc;
+        if (int rc = textcnn_proj_compute_launch(table, V, pt, 2, B, T, E, F_CONV, st)) return rc;
         tiles = proj_tiles(T);
     } else {
         FwdTower ft[2];

@@ -367,24 +367,22 @@ int proj_tiles(int T) { return (T + 2 + SEG - 1) / SEG; }
 int64_t proj_row_capacity(int64_t N, int T, int64_t V) { return (N * T < V) ? N * T : V; }
 size_t proj_ptab_floats(int64_t N, int T, int64_t V) { return (size_t)proj_row_capacity(N, T, V) * PROW; }
 
-int textcnn_proj_fwd_launch(const float *table, int64_t V, const ProjTower *tw, int ntower,
-                            int64_t N, int T, int E, int F, bool zero_state, hipStream_t st) {
-    if (F != PF) {
-        set_error("project-then-gather path is built for %d filters, got %d", PF, F);
-        return R4R_ERR_ARG;
-    }
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(proj_gemm_kernel),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES);
-        attr_set = true;
-    }
+static ProjArgs make_args(const float *table, int64_t V, const ProjTower *tw, int ntower,
+                          int64_t N, int T, int E, int F) {
     ProjArgs a;
     for (int k = 0; k < MAX_TOWERS; ++k) a.t[k] = tw[k < ntower ? k : 0];
     a.table = table; a.N = N; a.V = V; a.T = T; a.E = E; a.F = F;
     a.nchunk = (E + PEC - 1) / PEC;
     a.tiles = proj_tiles(T);
     a.cap = (int)proj_row_capacity(N, T, V);
+    return a;
+}
+
+// Phase A: token state of a batch (flags -> slot / list / count).  Depends only on the indices,
+// so a caller may run it for batch k+1 on another stream while step k computes.
+int textcnn_proj_tokens_launch(int64_t V, const ProjTower *tw, int ntower, int64_t N, int T,
+                               bool zero_state, hipStream_t st) {
+    const ProjArgs a = make_args(nullptr, V, tw, ntower, N, T, PEC, PF);
     if (zero_state) {
         int zb = (int)cdiv(V, 256 * 4);
         if (zb > 1024) zb = 1024;
@@ -395,6 +393,23 @@ int textcnn_proj_fwd_launch(const float *table, int64_t V, const ProjTower *tw, 
     if (mark_blocks < 1) mark_blocks = 1;
     proj_mark_kernel<<<dim3(mark_blocks, ntower), 256, 0, st>>>(a);
     proj_compact_kernel<<<dim3((unsigned)cdiv((V + 3) / 4, 1024), ntower), 1024, 0, st>>>(a);
+    return check_launch("textcnn_proj_tokens");
+}
+
+// Phase B: projection GEMM + gather-add-max, given the token state.
+int textcnn_proj_compute_launch(const float *table, int64_t V, const ProjTower *tw, int ntower,
+                                int64_t N, int T, int E, int F, hipStream_t st) {
+    if (F != PF) {
+        set_error("project-then-gather path is built for %d filters, got %d", PF, F);
+        return R4R_ERR_ARG;
+    }
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(proj_gemm_kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES);
+        attr_set = true;
+    }
+    const ProjArgs a = make_args(table, V, tw, ntower, N, T, E, F);
     {
         ScopedTiming tm(R4R_TIMING_PROJ_GEMM, st);
         proj_gemm_kernel<<<dim3(2 * ((a.cap + PM - 1) / PM), ntower), GEMM_THREADS, GEMM_LDS_BYTES, st>>>(a);
@@ -404,6 +419,12 @@ int textcnn_proj_fwd_launch(const float *table, int64_t V, const ProjTower *tw, 
         proj_gather_max_kernel<<<dim3((unsigned)(N * ((a.tiles + 1) / 2)), ntower), 256, 0, st>>>(a);
     }
     return check_launch("textcnn_proj_fwd");
+}
+
+int textcnn_proj_fwd_launch(const float *table, int64_t V, const ProjTower *tw, int ntower,
+                            int64_t N, int T, int E, int F, bool zero_state, hipStream_t st) {
+    if (int rc = textcnn_proj_tokens_launch(V, tw, ntower, N, T, zero_state, st)) return rc;
+    return textcnn_proj_compute_launch(table, V, tw, ntower, N, T, E, F, st);
 }
 
 }  // namespace r4r

@@ -46,6 +46,10 @@ size_t proj_ptab_floats(int64_t N, int T, int64_t V);
 // zero_state: memset flags + count first (callers whose workspace is not persistently zeroed)
 int textcnn_proj_fwd_launch(const float *table, int64_t V, const ProjTower *tw, int ntower,
                             int64_t N, int T, int E, int F, bool zero_state, hipStream_t st);
+int textcnn_proj_tokens_launch(int64_t V, const ProjTower *tw, int ntower, int64_t N, int T,
+                               bool zero_state, hipStream_t st);
+int textcnn_proj_compute_launch(const float *table, int64_t V, const ProjTower *tw, int ntower,
+                                int64_t N, int T, int E, int F, hipStream_t st);
 // R4R_CONV_AUTO / _DIRECT / _PROJECT (include/r4r.h) -> the algorithm to run; honours R4R_CONV_ALGO
 int textcnn_pick_algo(int requested, int64_t N, int T, int E, int F);
 

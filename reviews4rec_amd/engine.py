@@ -63,6 +63,11 @@ class DeepCoNNEngine:
         self._ws = None
         self._ws_key = None
         self._out = {}
+        # token-state double buffering (project-then-gather): see prefetch_tokens()
+        self._side = None
+        self._prepared = None           # (key, buffer, event) of a batch whose tokens are already compacted
+        self._last_buf = 1
+        self._step_done = [None, None]  # per buffer: event after the last step that read it
 
     # ------------------------------------------------------------------ buffers
     def _workspace(self, B, T):
@@ -72,6 +77,8 @@ class DeepCoNNEngine:
             # zero-filled: the token-flag region must be all-zero on first use (kept zero by the kernels)
             self._ws = torch.zeros(max(nb, 256), dtype=torch.uint8, device=self.dev)
             self._ws_key = key
+            self._prepared = None       # token state lived in the old workspace
+            self._step_done = [None, None]
         return self._ws
 
     def _outputs(self, B):
@@ -87,35 +94,96 @@ class DeepCoNNEngine:
         return raw.view(torch.float32).view(B, 2 * self.L).clone()
 
     # -------------------------------------------------------------------- steps
-    def _launch(self, data, y, grad, training, inv_denom):
+    def _indices(self, data):
         user_idx, item_idx = data[3], data[4]
         n = data[5].numel()
         user_idx = user_idx.reshape(n, -1)
         item_idx = item_idx.reshape(n, -1)
         if not (user_idx.is_cuda and user_idx.dtype == torch.int64):
             raise RuntimeError('DeepCoNNEngine: batches must be int64 tensors on the ROCm device')
-        user_idx, item_idx = user_idx.contiguous(), item_idx.contiguous()
+        return user_idx.contiguous(), item_idx.contiguous(), n
+
+    @staticmethod
+    def _key(user_idx, item_idx, n):
+        return (user_idx.data_ptr(), item_idx.data_ptr(), n, user_idx.shape[1])
+
+    def prefetch_tokens(self, next_data):
+        """Compact the distinct tokens of the NEXT batch on a side stream, concurrently with the
+        step that is running now (the compaction depends only on the indices; the running step's
+        projection GEMM is MFMA-bound and leaves the memory system idle).  The next train_step /
+        predict on that very batch then skips its own mark + compact launches."""
+        user_idx, item_idx, n = self._indices(next_data)
+        T = user_idx.shape[1]
+        if self._ws_key != (n, T):
+            return                                           # different shape: that step will build its own
+        lib = _lib.lib()
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=self.dev)
+        main = torch.cuda.current_stream(self.dev)
+        if self._prepared is not None:                       # an unused prepared state: drop it
+            _, pbuf, pev, _keep = self._prepared
+            main.wait_event(pev)
+            _lib.check(lib.r4r_deepconn_tokens(ptr(user_idx), ptr(item_idx), ptr(self._ws), self._ws.numel(), n, T,
+                                               self.E, self.L, self.V, self.conv_algo, pbuf, 1, main.cuda_stream),
+                       'r4r_deepconn_tokens(discard)')
+            dropped = torch.cuda.Event()
+            dropped.record(main)
+            self._step_done[pbuf] = dropped                  # the side stream must see the reset
+            self._last_buf = pbuf ^ 1
+            self._prepared = None
+        buf = self._last_buf ^ 1                             # the buffer the running step does NOT use
+        if self._step_done[buf] is not None:
+            self._side.wait_event(self._step_done[buf])      # its last reader has finished
+        else:
+            self._side.wait_stream(main)                     # first use: order after everything issued so far
+        rc = lib.r4r_deepconn_tokens(ptr(user_idx), ptr(item_idx), ptr(self._ws), self._ws.numel(), n, T,
+                                     self.E, self.L, self.V, self.conv_algo, buf, 0, self._side.cuda_stream)
+        _lib.check(rc, 'r4r_deepconn_tokens')
+        ev = torch.cuda.Event()
+        ev.record(self._side)
+        # keep the index tensors alive until the side stream is done with them
+        self._prepared = (self._key(user_idx, item_idx, n), buf, ev, (user_idx, item_idx))
+
+    def _launch(self, data, y, grad, training, inv_denom):
+        user_idx, item_idx, n = self._indices(data)
         T = user_idx.shape[1]
         pred, se = self._outputs(n)
         ws = self._workspace(n, T)
         p_drop = float(self.hp['dropout'])
+        main = torch.cuda.current_stream(self.dev)
+        ready = 0
+        if self._prepared is not None and self._prepared[0] == self._key(user_idx, item_idx, n):
+            buf, ev = self._prepared[1], self._prepared[2]
+            main.wait_event(ev)
+            self._prepared = None
+            ready = 1
+        else:
+            buf = (self._prepared[1] ^ 1) if self._prepared is not None else self._last_buf ^ 1
         rc = _lib.lib().r4r_deepconn_step(
             ptr(self.table), self.V, ptr(user_idx), ptr(item_idx), ptr(y), ptr(self.flat_p),
             ptr(self.flat_g) if grad else None, ptr(pred), ptr(se), ptr(self.sse) if y is not None else None,
             ptr(ws), ws.numel(), n, T, self.E, self.L, p_drop, int(training), self.seed, self.offset,
-            float(inv_denom), self.conv_algo, _lib.current_stream())
+            float(inv_denom), self.conv_algo, buf, ready, main.cuda_stream)
         _lib.check(rc, 'r4r_deepconn_step')
+        self._last_buf = buf
+        if self._side is not None:                           # only pay for the event when prefetching is in use
+            done = torch.cuda.Event()
+            done.record(main)
+            self._step_done[buf] = done
         if training and p_drop > 0.0:
             self.offset += n * 2 * self.L
         return pred, se
 
-    def train_step(self, data, y, n_global=None):
+    def train_step(self, data, y, n_global=None, next_data=None):
         """One optimisation step on this rank's shard.  Returns the per-example SE tensor
-        (device); the running sum is in ``self.sse``."""
+        (device); the running sum is in ``self.sse``.  ``next_data``: the batch that will be
+        trained on next, if known -- its token compaction is overlapped with this step."""
         n = data[5].numel()
         y = y.reshape(-1).contiguous()
         denom = float(n_global if n_global is not None else n * (self.dp.world if self.dp else 1))
         _, se = self._launch(data, y, grad=True, training=self.model.training, inv_denom=1.0 / denom)
+        if next_data is not None:
+            self.prefetch_tokens(next_data)
         if self.dp is not None and self.dp.on:
             self.dp.allreduce_flat(self.flat_g)
         self.step_count += 1

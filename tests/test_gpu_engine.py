@@ -180,3 +180,42 @@ def test_projection_and_direct_conv_agree_on_argmax_and_pooled():
     torch.testing.assert_close(outs[1][0], outs[2][0], rtol=1e-5, atol=1e-6)
     for k in outs[1][1]:
         torch.testing.assert_close(outs[1][1][k], outs[2][1][k], rtol=1e-4, atol=1e-7, msg=lambda mm: k + ': ' + mm)
+
+
+def test_token_prefetch_is_bit_identical_and_survives_mispredicted_batches():
+    """Token compaction of batch k+1 overlapped with step k (side stream, double-buffered token
+    state) must not change a single bit; a prepared batch that is never trained on (wrong
+    guess, an eval in between) is discarded cleanly."""
+    import reviews4rec_amd
+    from reviews4rec_amd.engine import DeepCoNNEngine
+    B, T, E, V, U, I = 64, 400, 128, 3000, 100, 50
+    hp = dict(model_type='deepconn', latent_size=10, word_embed_size=E, input_length=T, dropout=0.0,
+              total_users=U, total_items=I, lr=0.002, weight_decay=1e-6)
+    P = oracle.init_params(hp, vocab_size=V, seed=4)
+    batches = [synthetic_review_batch(B, T, V, U, I, seed=30 + i, device=DEV) for i in range(5)]
+
+    def fresh():
+        m = reviews4rec_amd.get_model_class('deepconn')(dict(hp, word_vectors=P['word2vec.weight'].numpy()))
+        m.load_state_dict(P)
+        return DeepCoNNEngine(m.to(DEV).train(), lr=hp['lr'], weight_decay=hp['weight_decay'], conv_algo=2)
+
+    plain, pre = fresh(), fresh()
+    order = [0, 1, 2, 3, 4, 0, 1, 2, 3, 4, 2, 2]
+    for k, b in enumerate(order):
+        data, y = batches[b]
+        se_a = plain.train_step(data, y).clone()
+        if k == 4:          # wrong guess: batch 3 is announced, batch 0 comes next
+            nxt = batches[3][0]
+        elif k + 1 < len(order):
+            nxt = batches[order[k + 1]][0]
+        else:
+            nxt = None
+        se_b = pre.train_step(data, y, next_data=nxt).clone()
+        assert torch.equal(se_a, se_b), k
+        if k == 7:          # an evaluation on another batch while a prepared state is pending
+            pa, _ = plain.predict(batches[4][0], batches[4][1])
+            pb, _ = pre.predict(batches[4][0], batches[4][1])
+            assert torch.equal(pa, pb)
+    torch.cuda.synchronize()
+    assert torch.equal(plain.flat_p, pre.flat_p)
+    assert torch.equal(plain.flat_m, pre.flat_m) and torch.equal(plain.flat_v, pre.flat_v)
