@@ -12,7 +12,7 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC_DIR = os.path.join(_HERE, 'csrc')
-LIB_PATH = os.path.join(CSRC_DIR, 'libr4r_hip.so')
+LIB_PATH = os.environ.get('R4R_LIBRARY') or os.path.join(CSRC_DIR, 'libr4r_hip.so')   # override: instrumented builds
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), 'include', 'r4r.h')
 
 _SCALARS = {

@@ -37,10 +37,10 @@ constexpr int PM = 64 * GM;        // GEMM rows per workgroup (4 waves x GM row 
 constexpr int GEMM_THREADS = 256;
 constexpr int PNH = 10;                                // column tiles of the wider half (10 + 9 = 19)
 constexpr int PNH_COLS = PNH * 16;                     // 160
-constexpr int GEMM_BUF = (PM + PNH_COLS) * PS;         // floats per LDS buffer
-constexpr int GEMM_LDS_BYTES = 2 * GEMM_BUF * 4;       // 55,296 B -> 2 workgroups per CU
 constexpr int PA_ROWS = GM;                            // A rows staged per thread: (tid >> 2) + 64 k
 constexpr int PB_ROWS = 3;                             // B rows staged per thread: (tid >> 2) + 64 k
+constexpr int GEMM_BUF = (PM + 64 * PB_ROWS) * PS;     // floats per LDS buffer (B rows staged unguarded: 192)
+constexpr int GEMM_LDS_BYTES = 2 * GEMM_BUF * 4;       // 61,440 B -> 2 workgroups per CU
 constexpr int SEG = 128;           // positions per partial (matches the direct kernel's NW=4 tile)
 
 struct ProjArgs {
@@ -49,6 +49,20 @@ struct ProjArgs {
     int64_t N, V;
     int T, E, F, nchunk, tiles, cap;
 };
+
+#ifdef R4R_TRACE
+// Timeline instrumentation (make trace): 8 words per workgroup of the projection GEMM --
+// start, operands-staged, loop-done, end (s_memrealtime, 100 MHz), HW_ID, XCC_ID, active flag.
+__device__ unsigned long long *g_trace = nullptr;
+extern "C" int r4r_debug_trace(void *buf) {
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_trace), &buf, sizeof(buf)) == hipSuccess ? 0 : -1;
+}
+#define TRACE_STAMP(k)                                                                                  \
+    if (g_trace && threadIdx.x == 0)                                                                    \
+        g_trace[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 + (k)] = wall_clock64();
+#else
+#define TRACE_STAMP(k)
+#endif
 
 // ---- 0. zero the token-state (callers whose workspace is not persistently zeroed).  A kernel
 // rather than hipMemsetAsync: memset nodes misbehaved under hipGraph replay (memory fault).
@@ -117,12 +131,12 @@ __global__ __launch_bounds__(1024) void proj_compact_kernel(ProjArgs a) {
 
 // ---- 2. projection GEMM: Q[row, j*100+f] = table[list[row], :] . W[f, j, :].
 // The B operand is staged straight from the conv weight [F][3][E]: LDS row n = j*100+f takes
-// the 16 contiguous floats W[f][j][c*16 .. c*16+15] (four float4 per row, rows 300..303 zero).
+// the 16 contiguous floats W[f][j][c*16 .. c*16+15] (four float4 per row).
 // grid = (cap/128 row tiles x 2 column halves, ntower); 4 waves, wave w owns rows
 // [32w, 32w+32) x one half of the 304 columns (2 x (10 or 9) accumulators of 16x16): ~2x the
 // workgroups of a full-width tile, 2 co-resident per CU, so a batch whose distinct-token
 // count lands just above a multiple of 256 x 128 rows does not cost a whole extra round.
-// LDS double-buffered exactly like the direct kernel.
+// K runs in chunks of 16 floats through two LDS buffers and two operand register sets.
 template <int NTILE>
 __device__ __forceinline__ void proj_gemm_body(const ProjArgs &a, float *lds) {
     const ProjTower &tw = a.t[blockIdx.y];
@@ -130,6 +144,15 @@ __device__ __forceinline__ void proj_gemm_body(const ProjArgs &a, float *lds) {
     const int row0 = (blockIdx.x >> 1) * PM;
     const int half = blockIdx.x & 1;
     const int col0 = half * PNH_COLS;                       // first column of this half
+    TRACE_STAMP(0)
+#ifdef R4R_TRACE
+    if (g_trace && threadIdx.x == 0) {
+        unsigned long long *tr = g_trace + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8;
+        tr[4] = __builtin_amdgcn_s_getreg((31 << 11) | 4);      // HW_REG_HW_ID
+        tr[5] = __builtin_amdgcn_s_getreg((31 << 11) | 20);     // HW_REG_XCC_ID
+        tr[6] = row0 < count;
+    }
+#endif
     if (row0 >= count) return;                              // over-provisioned grid: uniform exit
     const float *__restrict__ table = a.table;
     const int E = a.E, nchunk = a.nchunk;
@@ -138,45 +161,43 @@ __device__ __forceinline__ void proj_gemm_body(const ProjArgs &a, float *lds) {
     const int lrow = lane & 15, q = lane >> 4;
 
     // staging role: float4 column c4 of A rows (tid >> 2) + 64 k (k < 2) and of B rows
-    // (tid >> 2) + 64 k (k < 3; rows 0..191 cover the 160 B rows of this half)
+    // (tid >> 2) + 64 k (k < 3; rows 0..191 cover the 160 B rows of this half).  Every load
+    // is unconditional (hipcc turns a predicated load into a branch and a full counter wait):
+    // rows past `count` re-read the last valid row and padding columns re-read W[0][0] -- their
+    // results are never stored -- and the K tail (E % 16) re-reads the last float4 of the row,
+    // with the B side zeroed before it reaches LDS so the products vanish.
     const int c4 = tid & 3, srow = tid >> 2;
-    long aoff[PA_ROWS], boff[PB_ROWS];
+    const float *aptr[PA_ROWS], *bptr[PB_ROWS];
 #pragma unroll
     for (int k = 0; k < PA_ROWS; ++k) {
-        const int r = row0 + srow + 64 * k;
-        aoff[k] = (r < count) ? (long)tw.list[r] * E : -1;
+        const int r = min(row0 + srow + 64 * k, count - 1);
+        aptr[k] = table + (long)tw.list[r] * E;
     }
+    const float *__restrict__ conv_w = tw.conv_w;
 #pragma unroll
     for (int k = 0; k < PB_ROWS; ++k) {
         const int nl = srow + 64 * k, n = col0 + nl;        // n = j * 100 + f
         const int j = n / PF, f = n - j * PF;
-        boff[k] = (nl < PNH_COLS && n < PROW) ? ((long)f * 3 + j) * E : -1;
+        bptr[k] = conv_w + ((nl < PNH_COLS && n < PROW) ? ((long)f * 3 + j) * E : 0);
     }
 
     f32x4 ar[PA_ROWS], br[PB_ROWS];
-    auto issue_loads = [&](int c) {
-        const int e = c * PEC + c4 * 4;
+    auto issue_loads = [&](int c) {                          // any c: past the end it re-reads the tail
+        const int e = min(c * PEC + c4 * 4, E - 4);
 #pragma unroll
-        for (int k = 0; k < PA_ROWS; ++k) {
-            ar[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            if (aoff[k] >= 0 && e < E) ar[k] = *reinterpret_cast<const f32x4 *>(table + aoff[k] + e);
-        }
+        for (int k = 0; k < PA_ROWS; ++k) ar[k] = *reinterpret_cast<const f32x4 *>(aptr[k] + e);
 #pragma unroll
-        for (int k = 0; k < PB_ROWS; ++k) {
-            br[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            if (boff[k] >= 0 && e < E) br[k] = *reinterpret_cast<const f32x4 *>(tw.conv_w + boff[k] + e);
-        }
+        for (int k = 0; k < PB_ROWS; ++k) br[k] = *reinterpret_cast<const f32x4 *>(bptr[k] + e);
     };
-    auto write_lds = [&](float *buf) {
+    auto write_lds = [&](float *buf, int c) {
+        const float keep = (c * PEC + c4 * 4 < E) ? 1.f : 0.f;  // zero the K tail of B (branch-free)
 #pragma unroll
         for (int k = 0; k < PA_ROWS; ++k)
             *reinterpret_cast<f32x4 *>(buf + (srow + 64 * k) * PS + c4 * 4) = ar[k];
         float *Bl = buf + PM * PS;
 #pragma unroll
-        for (int k = 0; k < PB_ROWS; ++k) {
-            const int nl = srow + 64 * k;
-            if (nl < PNH_COLS) *reinterpret_cast<f32x4 *>(Bl + nl * PS + c4 * 4) = br[k];
-        }
+        for (int k = 0; k < PB_ROWS; ++k)
+            *reinterpret_cast<f32x4 *>(Bl + (srow + 64 * k) * PS + c4 * 4) = br[k] * keep;
     };
 
     f32x4 acc[GM][NTILE];
@@ -185,43 +206,81 @@ __device__ __forceinline__ void proj_gemm_body(const ProjArgs &a, float *lds) {
 #pragma unroll
         for (int ni = 0; ni < NTILE; ++ni) acc[mi][ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    auto compute = [&](const float *cur) {
-        const float *Bl = cur + PM * PS;
-        f32x4 av[GM], b[NTILE];
+    // Operand registers are double-buffered too: the staging of chunk c+2 (registers -> LDS),
+    // the global loads of chunk c+3 and the ds_reads of chunk c+1 are all issued among the
+    // MFMAs of chunk c, so between two chunks the matrix pipe only waits for the barrier.
+    // The body is branch-free (one scheduling region): past the last chunk it stages and reads
+    // data nobody consumes.  A 16x16x4 fp32 MFMA occupies the pipe for 32 cycles, which leaves
+    // room for one memory instruction behind every few of them; left to itself hipcc emits
+    // the reads, the stores and the loads as three bursts during which the pipe idles.
+    const int aoffl = (wave * 16 * GM + lrow) * PS + q * 4, boffl = PM * PS + lrow * PS + q * 4;
+    auto read_ops = [&](const float *buf, f32x4 (&av)[GM], f32x4 (&b)[NTILE]) {
+#pragma unroll
+        for (int mi = 0; mi < GM; ++mi) av[mi] = *reinterpret_cast<const f32x4 *>(buf + aoffl + mi * 16 * PS);
+#pragma unroll
+        for (int ni = 0; ni < NTILE; ++ni) b[ni] = *reinterpret_cast<const f32x4 *>(buf + boffl + ni * 16 * PS);
+    };
+    auto mfma = [&](const f32x4 (&av)[GM], const f32x4 (&b)[NTILE], int kk) {
 #pragma unroll
         for (int mi = 0; mi < GM; ++mi)
-            av[mi] = *reinterpret_cast<const f32x4 *>(cur + (wave * 16 * GM + mi * 16 + lrow) * PS + q * 4);
 #pragma unroll
-        for (int ni = 0; ni < NTILE; ++ni)
-            b[ni] = *reinterpret_cast<const f32x4 *>(Bl + (ni * 16 + lrow) * PS + q * 4);
+            for (int ni = 0; ni < NTILE; ++ni)
+                acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mi][kk], b[ni][kk], acc[mi][ni], 0, 0, 0);
+    };
+    // chunk c: operands `cur` are in registers; LDS buffer (c+1)&1 holds chunk c+1 once the
+    // barrier is passed; the staging registers hold chunk c+2 (loaded a whole chunk ago).
+    auto step = [&](int c, const f32x4 (&cav)[GM], const f32x4 (&cb)[NTILE], f32x4 (&nav)[GM], f32x4 (&nb)[NTILE]) {
+        __syncthreads();                                    // chunk c+1 visible; buffer c&1 fully read
+        write_lds(lds + (c & 1) * GEMM_BUF, c + 2);
+        issue_loads(c + 3);
+        mfma(cav, cb, 0);
+        mfma(cav, cb, 1);
+        read_ops(lds + ((c + 1) & 1) * GEMM_BUF, nav, nb);
+        mfma(cav, cb, 2);
+        mfma(cav, cb, 3);
+        // schedule: (1 LDS write, 3 MFMA) x 5 | (1 load, 3 MFMA) x 5 | (1 LDS read, 3 MFMA) x 12, rest
+        constexpr int NREAD = GM + NTILE, NSTG = PA_ROWS + PB_ROWS, NM = 4 * GM * NTILE;
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk)
+        for (int i = 0; i < NSTG; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+            __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+        }
 #pragma unroll
-            for (int mi = 0; mi < GM; ++mi)
+        for (int i = 0; i < NSTG; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+        }
 #pragma unroll
-                for (int ni = 0; ni < NTILE; ++ni)
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mi][kk], b[ni][kk], acc[mi][ni], 0, 0, 0);
+        for (int i = 0; i < NREAD; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, NM - 3 * (NREAD + 2 * NSTG), 0);
     };
 
+    f32x4 av0[GM], b0[NTILE], av1[GM], b1[NTILE];
     issue_loads(0);
-    write_lds(lds);
-    if (nchunk > 1) issue_loads(1);
+    write_lds(lds, 0);
+    issue_loads(1);
     __syncthreads();
-    for (int c = 0; c < nchunk; ++c) {
-        if (c + 1 < nchunk) {
-            write_lds(lds + ((c + 1) & 1) * GEMM_BUF);      // chunk c+1 -> the other buffer
-            if (c + 2 < nchunk) issue_loads(c + 2);         // in flight for a whole chunk
-        }
-        compute(lds + (c & 1) * GEMM_BUF);
-        __syncthreads();
+    read_ops(lds, av0, b0);
+    write_lds(lds + GEMM_BUF, 1);
+    issue_loads(2);
+    TRACE_STAMP(1)
+    for (int c = 0; c < nchunk; c += 2) {
+        step(c, av0, b0, av1, b1);
+        if (c + 1 < nchunk) step(c + 1, av1, b1, av0, b0);
     }
-
+    __syncthreads();                                        // all operand reads done: LDS is free
+    TRACE_STAMP(2)
     // Epilogue.  C layout of the MFMA: col = lane & 15, row = (lane >> 4) * 4 + reg -- storing
     // that directly is 80 scattered 4-byte stores per lane.  Instead each wave transposes one
     // 16-row tile at a time through its own LDS slab and writes whole row segments as float4
     // (an LDS queue is in-order per wave, so no barrier is needed inside a wave).
     constexpr int TS = NTILE * 16 + 4;                       // slab row stride (floats)
-    float *slab = lds + wave * (16 * (PNH_COLS + 4));        // LDS is free after the last barrier
+    float *slab = lds + wave * (16 * (PNH_COLS + 4));
     constexpr int NV = NTILE * 4;                            // float4 per row segment
 #pragma unroll
     for (int mi = 0; mi < GM; ++mi) {
@@ -238,6 +297,7 @@ __device__ __forceinline__ void proj_gemm_body(const ProjArgs &a, float *lds) {
                     *reinterpret_cast<const f32x4 *>(slab + rr * TS + cv * 4);
         }
     }
+    TRACE_STAMP(3)
 }
 
 __global__ __launch_bounds__(GEMM_THREADS, 2) void proj_gemm_kernel(ProjArgs a) {
