@@ -50,8 +50,8 @@ def measured_traffic(kernel, args):
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=50)
-    ap.add_argument('--warmup', type=int, default=10)
+    ap.add_argument('--steps', type=int, default=200)
+    ap.add_argument('--warmup', type=int, default=20)
     ap.add_argument('--batch-per-gpu', type=int, default=128, help='hyper_params batch_size per rank')
     ap.add_argument('--workload', default=WORKLOAD)
     ap.add_argument('--dropout', type=float, default=0.6, help='reference default (hyper_params.py:66)')
@@ -68,9 +68,9 @@ def parse():
     ap.add_argument('--conv-algo', choices=['auto', 'direct', 'project'], default='auto',
                     help='native engine: direct gather-fused MFMA conv, or projection GEMM over the distinct '
                          'tokens + gather-add-max (include/r4r.h R4R_CONV_*)')
-    ap.add_argument('--token-prefetch', type=int, default=0,
-                    help='native engine: compact batch k+1\'s tokens on a side stream during step k '
-                         '(measured 2 %% slower than inline at cfg3 B=128: DESIGN.md section 7)')
+    ap.add_argument('--token-prefetch', choices=['fused', 'side-stream', 'off'], default='fused',
+                    help='native engine: token marks / compaction of batch k+1 prepared during step k -- on step '
+                         'k\'s backward and gradient-reduce launches (fused), on a side stream, or not at all')
     ap.add_argument('--engine', choices=['native', 'module', 'graph'], default='native',
                     help="native: fused r4r_deepconn_step where the model has one (else module); module: op-by-op "
                          "autograd path; graph: the module path captured into one hipGraph per step")
@@ -198,7 +198,10 @@ def main():
             return
         if engine is not None:
             # forward + loss + backward + all-reduce + Adam; the next batch's token compaction overlaps it
-            engine.train_step(data, y, n_global=B_global, next_data=pool[(i + 1) % len(pool)][0] if args.token_prefetch else None)
+            nxt = pool[(i + 1) % len(pool)][0]
+            engine.train_step(data, y, n_global=B_global, next_data=nxt if args.token_prefetch == 'fused' else None)
+            if args.token_prefetch == 'side-stream':
+                engine.prefetch_tokens(nxt)
             return
         model.zero_grad()
         if is_tn:                                            # the 3-optimiser step of main.py:35-53
@@ -249,13 +252,13 @@ def main():
         step(i)
     fence()
     # Kernel timing for the roofline legs happens INSIDE the timed region but is sampled: only every
-    # 5th step is instrumented, and only the kernels the legs need (direct conv: slot 0; projection
+    # 10th step is instrumented, and only the kernels the legs need (direct conv: slot 0; projection
     # GEMM + gather: slots 3, 4).  A HIP event record serialises the queue for ~3 us; instrumenting
     # every launch of every step cost 20 % of a 0.13 ms step, sampling costs ~1 %.
     mask = 0 if args.no_kernel_timing else (1 << 0) | (1 << 3) | (1 << 4)
     t0 = time.perf_counter()
     for i in range(args.steps):
-        lib.r4r_timing_enable(mask if i % 5 == 0 else 0)
+        lib.r4r_timing_enable(mask if i % 10 == 5 else 0)
         step(args.warmup + i)
     fence()
     elapsed = time.perf_counter() - t0

@@ -231,6 +231,13 @@ int r4r_adam_multi(int ntensor, const uint64_t *p, const uint64_t *g, const uint
  *   conv_algo      : R4R_CONV_AUTO | R4R_CONV_DIRECT (gather-fused MFMA conv over every position)
  *                    | R4R_CONV_PROJECT (projection GEMM over the batch's distinct tokens, then a
  *                    gather-add-max over positions; same function, different summation order)
+ *   token_buffer   : which of the two token-state buffers of the workspace this step uses (0/1)
+ *   tokens_ready   : != 0 when that buffer already holds this batch's compacted tokens
+ *                    (prepared by r4r_deepconn_tokens or by the previous step, below)
+ *   next_user_idx / next_item_idx (both or neither; training steps only): the NEXT batch of the
+ *                    same B and T.  Its token marks ride on this step's backward launch and their
+ *                    compaction on the gradient-reduce launch, into buffer token_buffer ^ 1; call
+ *                    the next step with that buffer and tokens_ready = 1.
  *   pred [B], se [B] (se required when y != NULL); sse_accum (nullable device scalar)
  *   is incremented by sum_b se[b] -- the host's running metric (main.py:57) without a
  *   per-step device->host sync. */
@@ -247,7 +254,8 @@ int r4r_deepconn_step(const float *table, int64_t V, const int64_t *user_idx, co
                       void *ws, size_t ws_bytes,
                       int64_t B, int T, int E, int L,
                       float dropout_p, int training, uint64_t seed, uint64_t offset,
-                      float inv_denom, int conv_algo, int token_buffer, int tokens_ready, void *stream);
+                      float inv_denom, int conv_algo, int token_buffer, int tokens_ready,
+                      const int64_t *next_user_idx, const int64_t *next_item_idx, void *stream);
 /* Token compaction of a batch (distinct tokens -> dense rows) into token-state buffer 0 or 1 of the
  * workspace.  It depends only on the indices, so the caller may run it for batch k+1 on another
  * stream while step k computes, and then pass token_buffer / tokens_ready = 1 to step k+1

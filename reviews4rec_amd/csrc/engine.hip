@@ -25,6 +25,7 @@
 
 #include "textcnn.h"
 #include "wgrad_device.h"
+#include "tokens_device.h"
 
 namespace r4r {
 
@@ -106,6 +107,8 @@ __global__ __launch_bounds__(256) void deepconn_head_kernel(HeadArgs a) {
     const bool live = b_raw < a.B;             // a dead wave shadows the last rating and stores nothing
     const int64_t b = live ? b_raw : a.B - 1;
     const int L = a.L, n = 2 * L;
+    // scalars the tail needs: issued now, so they ride along with the first memory round trip
+    const float lin_b0 = a.lin_b[0], gbias0 = a.gbias[0], yb = a.y ? a.y[b] : 0.f;
 
     for (int i = tid; i < 2 * L * F_CONV; i += 256) {
         const int t = i / (L * F_CONV), r = i - t * L * F_CONV;
@@ -114,7 +117,45 @@ __global__ __launch_bounds__(256) void deepconn_head_kernel(HeadArgs a) {
     if (tid < n) { sfb[tid / L][tid % L] = a.fc_b[tid / L][tid % L]; slw[tid] = a.lin_w[tid]; }
     for (int i = tid; i < n * FM_K; i += 256) sV[i / FM_K][i % FM_K] = a.V[i];
 
-    // ---- pool finish: max over tiles, relu, first argmax
+    // ---- pool finish: max over tiles, relu, first argmax.  The common case (<= 8 tiles, i.e.
+    // T <= 1022) loads everything a lane needs -- 2 towers x 2 filters x 8 tiles of (max, arg) --
+    // before the first compare: one memory round trip instead of four dependent ones (the
+    // partials were just written by another XCD, so a round trip is a MALL/HBM access).
+    if (a.tiles <= HEAD_MAX_TILES) {
+        float v[2][2][HEAD_MAX_TILES];
+        int pp[2][2][HEAD_MAX_TILES];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int f = min(lane + 64 * h, F_CONV - 1);
+#pragma unroll
+                for (int k = 0; k < HEAD_MAX_TILES; ++k) {
+                    const size_t o = ((size_t)b * a.tiles + min(k, a.tiles - 1)) * NP + f;
+                    v[t][h][k] = a.pmax[t][o];
+                    pp[t][h][k] = a.parg[t][o];
+                }
+            }
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int f = lane + 64 * h;
+                float best = -INFINITY;
+                int bp = -1;
+#pragma unroll
+                for (int k = 0; k < HEAD_MAX_TILES; ++k)       // a clamped duplicate never wins (strict >)
+                    if (v[t][h][k] > best) { best = v[t][h][k]; bp = pp[t][h][k]; }
+                if (!(best > 0.f)) { best = 0.f; bp = -1; }
+                if (f < F_CONV) {
+                    sp[w][t][f] = best;
+                    if (live) {
+                        a.pooled[t][b * F_CONV + f] = best;
+                        a.argmax[t][b * F_CONV + f] = bp;
+                    }
+                }
+            }
+    } else {
 #pragma unroll
     for (int t = 0; t < 2; ++t)
         for (int f = lane; f < F_CONV; f += 64) {
@@ -141,6 +182,7 @@ __global__ __launch_bounds__(256) void deepconn_head_kernel(HeadArgs a) {
                 a.argmax[t][b * F_CONV + f] = bp;
             }
         }
+    }
     __syncthreads();
 
     // ---- FC: lane i < 2L computes z[t][l] = b[l] + sum_f pooled[t][f] W[t][l][f]
@@ -175,10 +217,10 @@ __global__ __launch_bounds__(256) void deepconn_head_kernel(HeadArgs a) {
     }
     const float lw = (lane < n) ? slw[lane] : 0.f;
     const float lin = wave_sum(xi * lw);
-    const float pred = (0.5f * inter + lin + a.lin_b[0]) + a.gbias[0];
+    const float pred = (0.5f * inter + lin + lin_b0) + gbias0;
     if (lane == 0 && live) a.pred[b] = pred;
     if (!a.y) return;                                      // uniform across the grid
-    const float d = pred - a.y[b];
+    const float d = pred - yb;
     if (lane == 0 && live) a.se[b] = d * d;
     if (!a.want_grad) return;                              // uniform across the grid
 
@@ -289,15 +331,29 @@ __device__ __forceinline__ void head_grad_block(const HeadGradArgs &a, int blk) 
 // argmax-sparse conv wgrad of tower z; z == 2 -> the head parameter gradients (strided
 // over the first workgroups of that slice; the rest exit).  Neither depends on the other, both
 // are latency-bound, so they overlap instead of running back to back.
-__global__ __launch_bounds__(WG_THREADS) void deepconn_backward_kernel(WgradArgs w, HeadGradArgs h, int hg_blocks) {
+// With a 4th z-slice the launch also marks the tokens of the NEXT batch (`nx`): that work depends
+// only on the next batch's indices, the slice's workgroups fill CUs the latency-bound wgrad
+// leaves idle, and the next step then starts at its GEMM.
+__global__ __launch_bounds__(WG_THREADS) void deepconn_backward_kernel(WgradArgs w, HeadGradArgs h, int hg_blocks,
+                                                                       TokenArgs nx) {
     if (blockIdx.z < 2) {
         wgrad_block(w, blockIdx.x, blockIdx.y, blockIdx.z);
-    } else {
+    } else if (blockIdx.z == 2) {
         for (int blk = blockIdx.y * gridDim.x + blockIdx.x; blk < hg_blocks; blk += gridDim.x * gridDim.y) {
             head_grad_block(h, blk);
             __syncthreads();
         }
+    } else {
+        token_mark_block(nx, blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y, WG_THREADS);
     }
+}
+
+// Second stage of the wgrad (fixed-order sum of the partials) and, in the extra workgroups, the
+// compaction of the next batch's token marks.
+constexpr int RED_THREADS = 256;
+__global__ __launch_bounds__(RED_THREADS) void deepconn_reduce_kernel(WgradArgs w, int red_blocks, TokenArgs nx) {
+    if ((int)blockIdx.x < red_blocks) wgrad_reduce_block(w, blockIdx.y, blockIdx.x);
+    else token_compact_block<RED_THREADS / 64>(nx.t[blockIdx.y], nx.V, blockIdx.x - red_blocks);
 }
 
 __global__ void sse_only_kernel(const float *__restrict__ se, float *__restrict__ accum, int64_t B) {
@@ -419,8 +475,12 @@ extern "C" int r4r_deepconn_step(const float *table, int64_t V, const int64_t *u
                                  int64_t B, int T, int E, int L,
                                  float dropout_p, int training, uint64_t seed, uint64_t offset,
                                  float inv_denom, int conv_algo, int token_buffer, int tokens_ready,
+                                 const int64_t *next_user_idx, const int64_t *next_item_idx,
                                  void *stream) {
     R4R_REQUIRE(table && user_idx && item_idx && flat_p && pred && ws, "deepconn_step: null pointer");
+    R4R_REQUIRE(!next_user_idx == !next_item_idx, "deepconn_step: next_user_idx and next_item_idx go together");
+    R4R_REQUIRE(!next_user_idx || flat_g, "deepconn_step: the next batch's tokens ride on the backward launches "
+                                          "(training steps only)");
     R4R_REQUIRE(V > 0 && B >= 0 && T > 0, "deepconn_step: bad sizes");
     R4R_REQUIRE(E > 0 && E % 4 == 0, "deepconn_step: word_embed_size %d must be a positive multiple of 4", E);
     R4R_REQUIRE(L > 0 && L <= MAX_L, "deepconn_step: latent_size %d outside 1..%d", L, MAX_L);
@@ -517,10 +577,29 @@ extern "C" int r4r_deepconn_step(const float *table, int64_t V, const int64_t *u
     wa.table = table; wa.N = B; wa.T = T; wa.E = E; wa.F = F_CONV;
     wa.nsplit = textcnn_wgrad_splits(B);
     wa.per_split = (int)cdiv(B, wa.nsplit);
+    // token state of the next batch (same B, T) into the OTHER token buffer, if asked for and
+    // if that batch will run project-then-gather
+    const bool prefetch = next_user_idx && algo == R4R_CONV_PROJECT;
+    TokenArgs nx{};
+    if (prefetch) {
+        ProjTower nt[2];
+        const int64_t *nidx[2] = {next_user_idx, next_item_idx};
+        const int ob = token_buffer ^ 1;
+        for (int t = 0; t < 2; ++t) {
+            nt[t] = ProjTower{};
+            nt[t].idx = nidx[t];
+            nt[t].flags = w.flags[ob][t]; nt[t].slot = w.slot[ob][t];
+            nt[t].list = w.list[ob][t]; nt[t].count = w.count[ob][t];
+        }
+        nx = make_token_args(V, nt, 2, B, T);
+    }
     {
         ScopedTiming tm(R4R_TIMING_TEXTCNN_WGRAD, st);
-        deepconn_backward_kernel<<<dim3(F_CONV, wa.nsplit, 3), WG_THREADS, 0, st>>>(wa, hg, hg_blocks);
+        deepconn_backward_kernel<<<dim3(F_CONV, wa.nsplit, prefetch ? 4 : 3), WG_THREADS, 0, st>>>(wa, hg, hg_blocks, nx);
     }
-    // 6: wgrad partial reduce -> flat gradient buffer
-    return textcnn_wgrad_reduce_launch(wt, 2, B, E, F_CONV, st);
+    // 6: wgrad partial reduce -> flat gradient buffer (+ compaction of the next batch's tokens)
+    const int red_blocks = (F_CONV * 3 * E + F_CONV + RED_THREADS - 1) / RED_THREADS;
+    const int comp_blocks = prefetch ? (int)cdiv((V + 3) / 4, RED_THREADS) : 0;
+    deepconn_reduce_kernel<<<dim3(red_blocks + comp_blocks, 2), RED_THREADS, 0, st>>>(wa, red_blocks, nx);
+    return check_launch("deepconn_step");
 }

@@ -21,6 +21,7 @@
 #include <stdlib.h>
 
 #include "textcnn.h"
+#include "tokens_device.h"
 
 namespace r4r {
 
@@ -74,59 +75,13 @@ __global__ void proj_zero_kernel(ProjArgs a) {
     if (blockIdx.x == 0 && threadIdx.x == 0) tw.count[0] = 0;
 }
 
-// ---- 1a. mark the tokens each tower's documents use
-__global__ void proj_mark_kernel(ProjArgs a) {
-    const ProjTower &tw = a.t[blockIdx.y];
-    const int64_t total = a.N * a.T;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x)
-        tw.flags[tw.idx[i]] = 1;
-}
+// ---- 1a. mark the tokens each tower's documents use (body: tokens_device.h)
+__global__ void proj_mark_kernel(TokenArgs a) { token_mark_block(a, blockIdx.x, gridDim.x, blockDim.x); }
 
-// ---- 1b. compact: slot[v] = dense row id of token v (or -1), list[row] = v, count.
-// grid = (ceil(V / 4096), ntower): a workgroup owns 4096 consecutive tokens (one int4 of
-// flags per thread), scans its flags in LDS and reserves a contiguous row range with ONE
-// atomicAdd on the tower's counter.  The order in which workgroups reserve ranges varies
-// from run to run, but any token <-> row bijection gives bit-identical results downstream
-// (a projected row depends only on its own token), so no global scan or sort is needed.
-// Flags are cleared as they are consumed; `count` is reset by the gather kernel: both
-// are all-zero between calls (the caller provides the workspace zeroed once).
-__global__ __launch_bounds__(1024) void proj_compact_kernel(ProjArgs a) {
-    __shared__ int wsum[16];
-    __shared__ int base_row;
-    const ProjTower &tw = a.t[blockIdx.y];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int64_t gi = (int64_t)blockIdx.x * 1024 + tid;    // int4 group: tokens 4 gi .. 4 gi + 3
-    const int64_t ngroups = (a.V + 3) / 4;                  // flags / slot buffers are padded to 4
-    int4 f = make_int4(0, 0, 0, 0);
-    if (gi < ngroups) f = reinterpret_cast<int4 *>(tw.flags)[gi];
-    const int fl[4] = {f.x, f.y, f.z, f.w};
-    const int cnt = f.x + f.y + f.z + f.w;
-    // exclusive prefix of cnt inside the workgroup: wave scan + 16-entry LDS scan
-    int incl = cnt;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const int up = __shfl_up(incl, off);
-        if (lane >= off) incl += up;
-    }
-    if (lane == 63) wsum[wave] = incl;
-    __syncthreads();
-    if (tid == 0) {
-        int run = 0;
-        for (int w = 0; w < 16; ++w) { const int c = wsum[w]; wsum[w] = run; run += c; }
-        base_row = run ? atomicAdd(tw.count, run) : 0;
-    }
-    __syncthreads();
-    int at = base_row + wsum[wave] + incl - cnt;
-    if (gi < ngroups) {
-        int sl[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            sl[k] = -1;
-            if (fl[k]) { sl[k] = at; tw.list[at] = (int)(gi * 4 + k); ++at; }
-        }
-        *reinterpret_cast<int4 *>(tw.slot + gi * 4) = make_int4(sl[0], sl[1], sl[2], sl[3]);
-        if (cnt) reinterpret_cast<int4 *>(tw.flags)[gi] = make_int4(0, 0, 0, 0);
-    }
+// ---- 1b. compact: slot[v] = dense row id of token v (or -1), list[row] = v, count
+// (body: tokens_device.h).  grid = (ceil(V / 4096), ntower).
+__global__ __launch_bounds__(1024) void proj_compact_kernel(TokenArgs a) {
+    token_compact_block<16>(a.t[blockIdx.y], a.V, blockIdx.x);
 }
 
 // ---- 2. projection GEMM: Q[row, j*100+f] = table[list[row], :] . W[f, j, :].
@@ -448,11 +403,12 @@ int textcnn_proj_tokens_launch(int64_t V, const ProjTower *tw, int ntower, int64
         if (zb > 1024) zb = 1024;
         proj_zero_kernel<<<dim3(zb < 1 ? 1 : zb, ntower), 256, 0, st>>>(a);
     }
-    int mark_blocks = (int)cdiv(N * T, 256 * 8);
-    if (mark_blocks > 2048) mark_blocks = 2048;
+    const TokenArgs ta = make_token_args(V, tw, ntower, N, T);
+    int mark_blocks = (int)cdiv(N * T * ntower, 256 * 8);
+    if (mark_blocks > 4096) mark_blocks = 4096;
     if (mark_blocks < 1) mark_blocks = 1;
-    proj_mark_kernel<<<dim3(mark_blocks, ntower), 256, 0, st>>>(a);
-    proj_compact_kernel<<<dim3((unsigned)cdiv((V + 3) / 4, 1024), ntower), 1024, 0, st>>>(a);
+    proj_mark_kernel<<<mark_blocks, 256, 0, st>>>(ta);
+    proj_compact_kernel<<<dim3((unsigned)cdiv((V + 3) / 4, 1024), ntower), 1024, 0, st>>>(ta);
     return check_launch("textcnn_proj_tokens");
 }
 

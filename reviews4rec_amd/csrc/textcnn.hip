@@ -270,21 +270,7 @@ __global__ __launch_bounds__(WG_THREADS) void textcnn_wgrad_kernel(WgradArgs a) 
     wgrad_block(a, blockIdx.x, blockIdx.y, blockIdx.z);
 }
 
-__global__ void textcnn_wgrad_reduce_kernel(WgradArgs a) {
-    const WgradTower &tw = a.t[blockIdx.y];
-    const int nw = a.F * 3 * a.E;
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < nw) {
-        float s = 0.f;
-        for (int k = 0; k < a.nsplit; ++k) s += tw.part_w[(size_t)k * nw + i];
-        tw.d_w[i] = s;
-    } else if (i < nw + a.F) {
-        const int f = i - nw;
-        float s = 0.f;
-        for (int k = 0; k < a.nsplit; ++k) s += tw.part_b[(size_t)k * a.F + f];
-        tw.d_b[f] = s;
-    }
-}
+__global__ void textcnn_wgrad_reduce_kernel(WgradArgs a) { wgrad_reduce_block(a, blockIdx.y, blockIdx.x); }
 
 // ----------------------------------------------------------------- launchers
 size_t textcnn_wp_floats(int E) { return (size_t)n_chunks(E) * NP * WS; }

@@ -1,0 +1,87 @@
+// Token state of the project-then-gather conv (project.hip): mark the tokens a batch uses,
+// compact them into dense rows.  Per-workgroup bodies, shared by the stand-alone kernels
+// (project.hip) and by the fused DeepCoNN step (engine.hip), which runs them for the NEXT
+// batch inside the backward / reduce launches of the current one.
+#pragma once
+#include "textcnn.h"
+
+namespace r4r {
+
+struct TokenTower {
+    const int64_t *idx;          // [N, T]
+    int *flags, *slot, *list, *count;   // as in ProjTower
+};
+struct TokenArgs {
+    TokenTower t[MAX_TOWERS];
+    int64_t N, V;
+    int T, ntower;
+};
+
+// ---- mark: block `blk` of `nblk` blocks of `nthreads` threads, all towers
+__device__ __forceinline__ void token_mark_block(const TokenArgs &a, int blk, int nblk, int nthreads) {
+    const int64_t total = a.N * a.T;
+    for (int t = 0; t < a.ntower; ++t) {
+        const int64_t *__restrict__ idx = a.t[t].idx;
+        int *__restrict__ flags = a.t[t].flags;
+        for (int64_t i = (int64_t)blk * nthreads + threadIdx.x; i < total; i += (int64_t)nblk * nthreads)
+            flags[idx[i]] = 1;
+    }
+}
+
+// ---- compact: slot[v] = dense row id of token v (or -1), list[row] = v, count.
+// A workgroup of NW waves owns 256 NW consecutive tokens (one int4 of flags per thread),
+// scans its flags in LDS and reserves a contiguous row range with ONE atomicAdd on the
+// tower's counter.  The order in which workgroups reserve ranges varies from run to run, but
+// any token <-> row bijection gives bit-identical results downstream (a projected row depends
+// only on its own token), so no global scan or sort is needed.  Flags are cleared as they are
+// consumed; `count` is reset by the gather kernel: both are all-zero between uses.
+template <int NW>
+__device__ __forceinline__ void token_compact_block(const TokenTower &tw, int64_t V, int blk) {
+    __shared__ int wsum[NW];
+    __shared__ int base_row;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t gi = (int64_t)blk * (64 * NW) + tid;      // int4 group: tokens 4 gi .. 4 gi + 3
+    const int64_t ngroups = (V + 3) / 4;                    // flags / slot buffers are padded to 4
+    int4 f = make_int4(0, 0, 0, 0);
+    if (gi < ngroups) f = reinterpret_cast<int4 *>(tw.flags)[gi];
+    const int fl[4] = {f.x, f.y, f.z, f.w};
+    const int cnt = f.x + f.y + f.z + f.w;
+    // exclusive prefix of cnt inside the workgroup: wave scan + NW-entry LDS scan
+    int incl = cnt;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int up = __shfl_up(incl, off);
+        if (lane >= off) incl += up;
+    }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    if (tid == 0) {
+        int run = 0;
+        for (int w = 0; w < NW; ++w) { const int c = wsum[w]; wsum[w] = run; run += c; }
+        base_row = run ? atomicAdd(tw.count, run) : 0;
+    }
+    __syncthreads();
+    int at = base_row + wsum[wave] + incl - cnt;
+    if (gi < ngroups) {
+        int sl[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            sl[k] = -1;
+            if (fl[k]) { sl[k] = at; tw.list[at] = (int)(gi * 4 + k); ++at; }
+        }
+        *reinterpret_cast<int4 *>(tw.slot + gi * 4) = make_int4(sl[0], sl[1], sl[2], sl[3]);
+        if (cnt) reinterpret_cast<int4 *>(tw.flags)[gi] = make_int4(0, 0, 0, 0);
+    }
+}
+
+static inline TokenArgs make_token_args(int64_t V, const ProjTower *tw, int ntower, int64_t N, int T) {
+    TokenArgs a;
+    for (int k = 0; k < MAX_TOWERS; ++k) {
+        const ProjTower &s = tw[k < ntower ? k : 0];
+        a.t[k].idx = s.idx; a.t[k].flags = s.flags; a.t[k].slot = s.slot; a.t[k].list = s.list; a.t[k].count = s.count;
+    }
+    a.N = N; a.V = V; a.T = T; a.ntower = ntower;
+    return a;
+}
+
+}  // namespace r4r

@@ -81,4 +81,22 @@ __device__ __forceinline__ void wgrad_block(const WgradArgs &a, int f, int s, in
 }
 
 
+// Second stage: element i of tower `tw`'s [F*3E weight | F bias] gradient = sum of the nsplit
+// partials in a fixed order (deterministic).
+__device__ __forceinline__ void wgrad_reduce_block(const WgradArgs &a, int tower, int blk) {
+    const WgradTower &tw = a.t[tower];
+    const int nw = a.F * 3 * a.E;
+    const int i = blk * blockDim.x + threadIdx.x;
+    if (i < nw) {
+        float s = 0.f;
+        for (int k = 0; k < a.nsplit; ++k) s += tw.part_w[(size_t)k * nw + i];
+        tw.d_w[i] = s;
+    } else if (i < nw + a.F) {
+        const int f = i - nw;
+        float s = 0.f;
+        for (int k = 0; k < a.nsplit; ++k) s += tw.part_b[(size_t)k * a.F + f];
+        tw.d_b[f] = s;
+    }
+}
+
 }  // namespace r4r

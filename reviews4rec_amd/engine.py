@@ -121,16 +121,7 @@ class DeepCoNNEngine:
             self._side = torch.cuda.Stream(device=self.dev)
         main = torch.cuda.current_stream(self.dev)
         if self._prepared is not None:                       # an unused prepared state: drop it
-            _, pbuf, pev, _keep = self._prepared
-            main.wait_event(pev)
-            _lib.check(lib.r4r_deepconn_tokens(ptr(user_idx), ptr(item_idx), ptr(self._ws), self._ws.numel(), n, T,
-                                               self.E, self.L, self.V, self.conv_algo, pbuf, 1, main.cuda_stream),
-                       'r4r_deepconn_tokens(discard)')
-            dropped = torch.cuda.Event()
-            dropped.record(main)
-            self._step_done[pbuf] = dropped                  # the side stream must see the reset
-            self._last_buf = pbuf ^ 1
-            self._prepared = None
+            self._discard_prepared(main)
         buf = self._last_buf ^ 1                             # the buffer the running step does NOT use
         if self._step_done[buf] is not None:
             self._side.wait_event(self._step_done[buf])      # its last reader has finished
@@ -144,27 +135,54 @@ class DeepCoNNEngine:
         # keep the index tensors alive until the side stream is done with them
         self._prepared = (self._key(user_idx, item_idx, n), buf, ev, (user_idx, item_idx))
 
-    def _launch(self, data, y, grad, training, inv_denom):
+    def _discard_prepared(self, main):
+        """Drop a prepared token state nobody consumed (a wrong guess, an eval in between)."""
+        key, pbuf, pev, keep = self._prepared
+        if pev is not None:
+            main.wait_event(pev)
+        u, i = keep
+        _lib.check(_lib.lib().r4r_deepconn_tokens(ptr(u), ptr(i), ptr(self._ws), self._ws.numel(), key[2], key[3],
+                                                  self.E, self.L, self.V, self.conv_algo, pbuf, 1, main.cuda_stream),
+                   'r4r_deepconn_tokens(discard)')
+        if self._side is not None:
+            dropped = torch.cuda.Event()
+            dropped.record(main)
+            self._step_done[pbuf] = dropped                  # the side stream must see the reset
+        self._last_buf = pbuf ^ 1
+        self._prepared = None
+
+    def _launch(self, data, y, grad, training, inv_denom, next_data=None):
         user_idx, item_idx, n = self._indices(data)
         T = user_idx.shape[1]
         pred, se = self._outputs(n)
         ws = self._workspace(n, T)
         p_drop = float(self.hp['dropout'])
         main = torch.cuda.current_stream(self.dev)
+        nxt = None
+        if next_data is not None and grad:
+            nu, ni, nn = self._indices(next_data)
+            if (nn, nu.shape[1]) == (n, T):                  # same shape: same workspace layout
+                nxt = (nu, ni)
         ready = 0
         if self._prepared is not None and self._prepared[0] == self._key(user_idx, item_idx, n):
             buf, ev = self._prepared[1], self._prepared[2]
-            main.wait_event(ev)
+            if ev is not None:
+                main.wait_event(ev)
             self._prepared = None
             ready = 1
         else:
+            if self._prepared is not None and nxt is not None:
+                self._discard_prepared(main)                 # its buffer is needed for the new guess
             buf = (self._prepared[1] ^ 1) if self._prepared is not None else self._last_buf ^ 1
         rc = _lib.lib().r4r_deepconn_step(
             ptr(self.table), self.V, ptr(user_idx), ptr(item_idx), ptr(y), ptr(self.flat_p),
             ptr(self.flat_g) if grad else None, ptr(pred), ptr(se), ptr(self.sse) if y is not None else None,
             ptr(ws), ws.numel(), n, T, self.E, self.L, p_drop, int(training), self.seed, self.offset,
-            float(inv_denom), self.conv_algo, buf, ready, main.cuda_stream)
+            float(inv_denom), self.conv_algo, buf, ready,
+            ptr(nxt[0]) if nxt else None, ptr(nxt[1]) if nxt else None, main.cuda_stream)
         _lib.check(rc, 'r4r_deepconn_step')
+        if nxt is not None:      # (a step that runs the direct conv ignores token state altogether)
+            self._prepared = (self._key(nxt[0], nxt[1], n), buf ^ 1, None, nxt)
         self._last_buf = buf
         if self._side is not None:                           # only pay for the event when prefetching is in use
             done = torch.cuda.Event()
@@ -177,13 +195,13 @@ class DeepCoNNEngine:
     def train_step(self, data, y, n_global=None, next_data=None):
         """One optimisation step on this rank's shard.  Returns the per-example SE tensor
         (device); the running sum is in ``self.sse``.  ``next_data``: the batch that will be
-        trained on next, if known -- its token compaction is overlapped with this step."""
+        trained on next, if known -- its token marks / compaction ride on this step's backward /
+        gradient-reduce launches, and that step then starts at its projection GEMM."""
         n = data[5].numel()
         y = y.reshape(-1).contiguous()
         denom = float(n_global if n_global is not None else n * (self.dp.world if self.dp else 1))
-        _, se = self._launch(data, y, grad=True, training=self.model.training, inv_denom=1.0 / denom)
-        if next_data is not None:
-            self.prefetch_tokens(next_data)
+        _, se = self._launch(data, y, grad=True, training=self.model.training, inv_denom=1.0 / denom,
+                             next_data=next_data)
         if self.dp is not None and self.dp.on:
             self.dp.allreduce_flat(self.flat_g)
         self.step_count += 1

@@ -182,10 +182,11 @@ def test_projection_and_direct_conv_agree_on_argmax_and_pooled():
         torch.testing.assert_close(outs[1][1][k], outs[2][1][k], rtol=1e-4, atol=1e-7, msg=lambda mm: k + ': ' + mm)
 
 
-def test_token_prefetch_is_bit_identical_and_survives_mispredicted_batches():
-    """Token compaction of batch k+1 overlapped with step k (side stream, double-buffered token
-    state) must not change a single bit; a prepared batch that is never trained on (wrong
-    guess, an eval in between) is discarded cleanly."""
+@pytest.mark.parametrize('how', ['fused', 'side_stream'])
+def test_token_prefetch_is_bit_identical_and_survives_mispredicted_batches(how):
+    """Token compaction of batch k+1 prepared during step k -- riding on step k's backward /
+    reduce launches ('fused') or on a side stream -- must not change a single bit; a prepared
+    batch that is never trained on (wrong guess, an eval in between) is discarded cleanly."""
     import reviews4rec_amd
     from reviews4rec_amd.engine import DeepCoNNEngine
     B, T, E, V, U, I = 64, 400, 128, 3000, 100, 50
@@ -210,7 +211,12 @@ def test_token_prefetch_is_bit_identical_and_survives_mispredicted_batches():
             nxt = batches[order[k + 1]][0]
         else:
             nxt = None
-        se_b = pre.train_step(data, y, next_data=nxt).clone()
+        if how == 'fused':
+            se_b = pre.train_step(data, y, next_data=nxt).clone()
+        else:
+            se_b = pre.train_step(data, y).clone()
+            if nxt is not None:
+                pre.prefetch_tokens(nxt)
         assert torch.equal(se_a, se_b), k
         if k == 7:          # an evaluation on another batch while a prepared state is pending
             pa, _ = plain.predict(batches[4][0], batches[4][1])
