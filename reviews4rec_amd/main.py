@@ -38,6 +38,20 @@ class _GraphHolder:
         self.step = None
 
 
+def _with_next(batches):
+    """(batch, next batch or None) pairs: the native engine prepares the next batch's token state
+    while it trains on the current one (DeepCoNNEngine.train_step, next_data=)."""
+    it = iter(batches)
+    try:
+        cur = next(it)
+    except StopIteration:
+        return
+    for nxt in it:
+        yield cur, nxt
+        cur = nxt
+    yield cur, None
+
+
 def train(model, criterion, optimizer, reader, hyper_params, engine=None, dp=None, graph=None):
     model.train()
     tn = _is_transnet(hyper_params)
@@ -49,11 +63,12 @@ def train(model, criterion, optimizer, reader, hyper_params, engine=None, dp=Non
     if engine is not None:
         engine.sse.zero_()
 
-    for data, y in reader.iter():
+    batches = _with_next(reader.iter()) if engine is not None else ((b, None) for b in reader.iter())
+    for (data, y), upcoming in batches:
         n_local = int(y.shape[0])
         n_global = dp.global_count(n_local, y.device) if (dp is not None and dp.on) else n_local
         if engine is not None:
-            engine.train_step(data, y, n_global=n_global)
+            engine.train_step(data, y, n_global=n_global, next_data=upcoming[0] if upcoming is not None else None)
             total_x += float(n_local)
             total_batches += 1
             continue

@@ -225,3 +225,41 @@ def test_token_prefetch_is_bit_identical_and_survives_mispredicted_batches(how):
     torch.cuda.synchronize()
     assert torch.equal(plain.flat_p, pre.flat_p)
     assert torch.equal(plain.flat_m, pre.flat_m) and torch.equal(plain.flat_v, pre.flat_v)
+
+
+def test_host_loop_with_native_engine_and_lookahead_matches_reference_metric():
+    """main.train driving the native engine with the one-batch lookahead (the upcoming batch's
+    tokens are prepared during the current step; the ragged last batch is not): the epoch metric
+    round(sum SE / N, 4) (main.py:66) equals the reference's over the golden batches."""
+    from reviews4rec_amd import main as M
+    from reviews4rec_amd.loss import MSELoss
+    g = Golden('deepconn_e20')
+    eng, model, hp = make_engine(g, conv_algo=2)
+    model.train()
+
+    class Reader:
+        def iter(self, eval=False):
+            for k in (0, 1):
+                yield g.batch(k, DEV)
+
+    metrics = M.train(model, MSELoss(hp), None, Reader(), hp, engine=eng)
+    n = g.arr('y0').shape[0] + g.arr('y1').shape[0]
+    expected = round(float(g.arr('se0').sum() + g.arr('se1').sum()) / n, 4)
+    assert metrics['MSE'] == pytest.approx(expected, abs=2e-4)
+    # a second epoch over batches of equal shape exercises the prepared-token path end to end
+    data, y = g.batch(0, DEV)
+
+    class Same:
+        def iter(self, eval=False):
+            for _ in range(3):
+                yield [d.clone() for d in data], y
+
+    ref, _, _ = make_engine(g, conv_algo=2)
+    ref.model.train()
+    M.train(model, MSELoss(hp), None, Same(), hp, engine=eng)
+    for k in (0, 1):
+        ref.train_step(*g.batch(k, DEV))
+    for _ in range(3):
+        ref.train_step(data, y)
+    torch.cuda.synchronize()
+    assert torch.equal(ref.flat_p, eng.flat_p)
