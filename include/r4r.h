@@ -238,6 +238,11 @@ int r4r_adam_multi(int ntensor, const uint64_t *p, const uint64_t *g, const uint
  *                    same B and T.  Its token marks ride on this step's backward launch and their
  *                    compaction on the gradient-reduce launch, into buffer token_buffer ^ 1; call
  *                    the next step with that buffer and tokens_ready = 1.
+ *   flat_m / flat_v (both or neither; layout of flat_p): when given, the step is also the
+ *                    optimiser -- torch.optim.Adam(lr, betas, eps, weight_decay) update number
+ *                    adam_step (1-based) of flat_p in place (main.py:94-96,60), done by the launch
+ *                    that finishes the gradients; flat_g still receives the gradients.  Leave NULL
+ *                    under data parallelism (all-reduce flat_g, then r4r_adam_multi).
  *   pred [B], se [B] (se required when y != NULL); sse_accum (nullable device scalar)
  *   is incremented by sum_b se[b] -- the host's running metric (main.py:57) without a
  *   per-step device->host sync. */
@@ -249,13 +254,15 @@ int r4r_deepconn_layout(int E, int L, int64_t *offsets, int64_t *sizes, int64_t 
 size_t r4r_deepconn_ws_bytes(int64_t B, int T, int E, int L, int64_t V);
 size_t r4r_deepconn_ws_mult_offset(int64_t B, int T, int E, int L, int64_t V);   /* [B,2L] dropout multipliers (tests) */
 int r4r_deepconn_step(const float *table, int64_t V, const int64_t *user_idx, const int64_t *item_idx,
-                      const float *y, const float *flat_p, float *flat_g,
+                      const float *y, float *flat_p, float *flat_g,
                       float *pred, float *se, float *sse_accum,
                       void *ws, size_t ws_bytes,
                       int64_t B, int T, int E, int L,
                       float dropout_p, int training, uint64_t seed, uint64_t offset,
                       float inv_denom, int conv_algo, int token_buffer, int tokens_ready,
-                      const int64_t *next_user_idx, const int64_t *next_item_idx, void *stream);
+                      const int64_t *next_user_idx, const int64_t *next_item_idx,
+                      float *flat_m, float *flat_v, float lr, double beta1, double beta2, float eps,
+                      float weight_decay, int64_t adam_step, void *stream);
 /* Token compaction of a batch (distinct tokens -> dense rows) into token-state buffer 0 or 1 of the
  * workspace.  It depends only on the indices, so the caller may run it for batch k+1 on another
  * stream while step k computes, and then pass token_buffer / tokens_ready = 1 to step k+1

@@ -8,31 +8,13 @@
 // used at main.py:94-96,60 -- betas (0.9, 0.999), eps 1e-8, L2 weight decay
 // added to the gradient, bias-corrected, NOT amsgrad.  Every element moves
 // every step, including embedding rows no example touched.
-#include "common.h"
+#include "adam_device.h"
 
 namespace r4r {
 
 constexpr int ADAM_CHUNK = 8192;      // elements per workgroup for large tensor lists
 constexpr int ADAM_CHUNK_SMALL = 1024; // ... when the whole list is small (latency-bound): more, shorter workgroups
 constexpr int ADAM_THREADS = 256;
-
-struct AdamScalars {
-    float lr_over_bc1;      // lr / (1 - beta1^t)
-    float inv_sqrt_bc2;     // 1 / sqrt(1 - beta2^t)
-    float lr;
-    double b1d, b2d;        // betas in double, for the device-side bias correction
-    const int64_t *step_dev;   // optional: completed-step counter in device memory (graph replay)
-    float beta1, beta2, eps, wd;
-    float omb1, omb2;       // 1 - beta, rounded from double like torch's `value=1 - beta2`
-};
-
-__device__ __forceinline__ void adam_elem(float &p, float g, float &m, float &v, const AdamScalars &s) {
-    g = fmaf(s.wd, p, g);
-    m = fmaf(s.beta1, m, s.omb1 * g);
-    v = fmaf(s.beta2, v, s.omb2 * g * g);
-    const float denom = sqrtf(v) * s.inv_sqrt_bc2 + s.eps;
-    p -= s.lr_over_bc1 * (m / denom);
-}
 
 constexpr int ADAM_BATCH = 16;     // tensors described by value in one launch's kernel arguments
 
@@ -111,14 +93,7 @@ extern "C" int r4r_adam_multi(int ntensor, const uint64_t *p, const uint64_t *g,
     R4R_REQUIRE(ntensor >= 0 && (ntensor == 0 || (p && g && m && v && numel)), "adam_multi: null pointer");
     R4R_REQUIRE(step_dev || step >= 1, "adam_multi: step must be >= 1");
     if (step_dev) step = 1;            // placeholder: the kernel derives the corrections from *step_dev
-    AdamScalars s;
-    const double bc1 = 1.0 - pow(beta1, (double)step);
-    const double bc2 = 1.0 - pow(beta2, (double)step);
-    s.lr_over_bc1 = (float)((double)lr / bc1);
-    s.inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
-    s.beta1 = (float)beta1; s.beta2 = (float)beta2; s.eps = eps; s.wd = weight_decay;
-    s.omb1 = (float)(1.0 - beta1); s.omb2 = (float)(1.0 - beta2);
-    s.lr = lr; s.b1d = beta1; s.b2d = beta2; s.step_dev = step_dev;
+    const AdamScalars s = adam_make_scalars(lr, beta1, beta2, eps, weight_decay, step, step_dev);
     int64_t total = 0;
     for (int k = 0; k < ntensor; ++k) total += numel[k];
     const int chunk = total >= (4ll << 20) ? ADAM_CHUNK : ADAM_CHUNK_SMALL;

@@ -26,6 +26,7 @@
 #include "textcnn.h"
 #include "wgrad_device.h"
 #include "tokens_device.h"
+#include "adam_device.h"
 
 namespace r4r {
 
@@ -350,10 +351,45 @@ __global__ __launch_bounds__(WG_THREADS) void deepconn_backward_kernel(WgradArgs
 
 // Second stage of the wgrad (fixed-order sum of the partials) and, in the extra workgroups, the
 // compaction of the next batch's token marks.
+// With `opt.on` the launch is also the optimiser: a conv-gradient element is updated as soon as
+// it is summed, and a third group of workgroups updates the head parameters (their gradients
+// were finished by the backward launch) -- one launch less per step, same Adam arithmetic as
+// adam.hip.  Not under data parallelism: the all-reduce sits between gradient and update there.
 constexpr int RED_THREADS = 256;
-__global__ __launch_bounds__(RED_THREADS) void deepconn_reduce_kernel(WgradArgs w, int red_blocks, TokenArgs nx) {
-    if ((int)blockIdx.x < red_blocks) wgrad_reduce_block(w, blockIdx.y, blockIdx.x);
-    else token_compact_block<RED_THREADS / 64>(nx.t[blockIdx.y], nx.V, blockIdx.x - red_blocks);
+struct FusedAdam {
+    float *p, *m, *v;            // flat parameter / moment buffers (layout of flat_g)
+    const float *g;              // flat_g
+    int64_t lo[2], hi[2];        // the two runs of non-conv parameters in the flat layout
+    AdamScalars s;
+    int on;
+};
+__global__ __launch_bounds__(RED_THREADS) void deepconn_reduce_kernel(WgradArgs w, int red_blocks, int comp_blocks,
+                                                                      TokenArgs nx, FusedAdam opt) {
+    const int bx = blockIdx.x;
+    if (bx < red_blocks) {
+        wgrad_reduce_block(w, blockIdx.y, bx);
+        if (opt.on) {                                       // this thread's element, just written
+            const WgradTower &tw = w.t[blockIdx.y];
+            const int nw = w.F * 3 * w.E;
+            const int i = bx * RED_THREADS + threadIdx.x;
+            const float *gp = i < nw ? tw.d_w + i : (i < nw + w.F ? tw.d_b + (i - nw) : nullptr);
+            if (gp) {
+                const int64_t o = gp - opt.g;
+                float P = opt.p[o], M = opt.m[o], V = opt.v[o];
+                adam_elem(P, *gp, M, V, opt.s);
+                opt.p[o] = P; opt.m[o] = M; opt.v[o] = V;
+            }
+        }
+    } else if (bx < red_blocks + comp_blocks) {
+        token_compact_block<RED_THREADS / 64>(nx.t[blockIdx.y], nx.V, bx - red_blocks);
+    } else {
+        const int64_t o = opt.lo[blockIdx.y] + (int64_t)(bx - red_blocks - comp_blocks) * RED_THREADS + threadIdx.x;
+        if (o < opt.hi[blockIdx.y]) {
+            float P = opt.p[o], M = opt.m[o], V = opt.v[o];
+            adam_elem(P, opt.g[o], M, V, opt.s);
+            opt.p[o] = P; opt.m[o] = M; opt.v[o] = V;
+        }
+    }
 }
 
 __global__ void sse_only_kernel(const float *__restrict__ se, float *__restrict__ accum, int64_t B) {
@@ -469,15 +505,20 @@ extern "C" int r4r_deepconn_tokens(const int64_t *user_idx, const int64_t *item_
 }
 
 extern "C" int r4r_deepconn_step(const float *table, int64_t V, const int64_t *user_idx, const int64_t *item_idx,
-                                 const float *y, const float *flat_p, float *flat_g,
+                                 const float *y, float *flat_p, float *flat_g,
                                  float *pred, float *se, float *sse_accum,
                                  void *ws, size_t ws_bytes,
                                  int64_t B, int T, int E, int L,
                                  float dropout_p, int training, uint64_t seed, uint64_t offset,
                                  float inv_denom, int conv_algo, int token_buffer, int tokens_ready,
                                  const int64_t *next_user_idx, const int64_t *next_item_idx,
+                                 float *flat_m, float *flat_v, float lr, double beta1, double beta2, float eps,
+                                 float weight_decay, int64_t adam_step,
                                  void *stream) {
     R4R_REQUIRE(table && user_idx && item_idx && flat_p && pred && ws, "deepconn_step: null pointer");
+    R4R_REQUIRE(!flat_m == !flat_v, "deepconn_step: flat_m and flat_v go together");
+    R4R_REQUIRE(!flat_m || (flat_g && adam_step >= 1), "deepconn_step: the fused optimiser needs gradients and "
+                                                       "adam_step >= 1");
     R4R_REQUIRE(!next_user_idx == !next_item_idx, "deepconn_step: next_user_idx and next_item_idx go together");
     R4R_REQUIRE(!next_user_idx || flat_g, "deepconn_step: the next batch's tokens ride on the backward launches "
                                           "(training steps only)");
@@ -600,6 +641,18 @@ extern "C" int r4r_deepconn_step(const float *table, int64_t V, const int64_t *u
     // 6: wgrad partial reduce -> flat gradient buffer (+ compaction of the next batch's tokens)
     const int red_blocks = (F_CONV * 3 * E + F_CONV + RED_THREADS - 1) / RED_THREADS;
     const int comp_blocks = prefetch ? (int)cdiv((V + 3) / 4, RED_THREADS) : 0;
-    deepconn_reduce_kernel<<<dim3(red_blocks + comp_blocks, 2), RED_THREADS, 0, st>>>(wa, red_blocks, nx);
+    FusedAdam opt{};
+    int opt_blocks = 0;
+    if (flat_m) {
+        opt.on = 1;
+        opt.p = flat_p; opt.m = flat_m; opt.v = flat_v; opt.g = flat_g;
+        opt.lo[0] = lay.off[P_UFW]; opt.hi[0] = lay.off[P_ICW];      // user fc weight + bias
+        opt.lo[1] = lay.off[P_IFW]; opt.hi[1] = lay.total;           // item fc, FM, global bias
+        opt.s = adam_make_scalars(lr, beta1, beta2, eps, weight_decay, adam_step, nullptr);
+        const int64_t longest = opt.hi[0] - opt.lo[0] > opt.hi[1] - opt.lo[1] ? opt.hi[0] - opt.lo[0] : opt.hi[1] - opt.lo[1];
+        opt_blocks = (int)cdiv(longest, RED_THREADS);
+    }
+    deepconn_reduce_kernel<<<dim3(red_blocks + comp_blocks + opt_blocks, 2), RED_THREADS, 0, st>>>(
+        wa, red_blocks, comp_blocks, nx, opt);
     return check_launch("deepconn_step");
 }

@@ -151,7 +151,7 @@ class DeepCoNNEngine:
         self._last_buf = pbuf ^ 1
         self._prepared = None
 
-    def _launch(self, data, y, grad, training, inv_denom, next_data=None):
+    def _launch(self, data, y, grad, training, inv_denom, next_data=None, adam_step=0):
         user_idx, item_idx, n = self._indices(data)
         T = user_idx.shape[1]
         pred, se = self._outputs(n)
@@ -179,7 +179,9 @@ class DeepCoNNEngine:
             ptr(self.flat_g) if grad else None, ptr(pred), ptr(se), ptr(self.sse) if y is not None else None,
             ptr(ws), ws.numel(), n, T, self.E, self.L, p_drop, int(training), self.seed, self.offset,
             float(inv_denom), self.conv_algo, buf, ready,
-            ptr(nxt[0]) if nxt else None, ptr(nxt[1]) if nxt else None, main.cuda_stream)
+            ptr(nxt[0]) if nxt else None, ptr(nxt[1]) if nxt else None,
+            ptr(self.flat_m) if adam_step else None, ptr(self.flat_v) if adam_step else None,
+            self.lr, self.betas[0], self.betas[1], self.eps, self.wd, int(adam_step), main.cuda_stream)
         _lib.check(rc, 'r4r_deepconn_step')
         if nxt is not None:      # (a step that runs the direct conv ignores token state altogether)
             self._prepared = (self._key(nxt[0], nxt[1], n), buf ^ 1, None, nxt)
@@ -200,11 +202,15 @@ class DeepCoNNEngine:
         n = data[5].numel()
         y = y.reshape(-1).contiguous()
         denom = float(n_global if n_global is not None else n * (self.dp.world if self.dp else 1))
+        self.step_count += 1
+        if not (self.dp is not None and self.dp.on):
+            # single process: the launch that finishes the gradients is also the Adam update
+            _, se = self._launch(data, y, grad=True, training=self.model.training, inv_denom=1.0 / denom,
+                                 next_data=next_data, adam_step=self.step_count)
+            return se
         _, se = self._launch(data, y, grad=True, training=self.model.training, inv_denom=1.0 / denom,
                              next_data=next_data)
-        if self.dp is not None and self.dp.on:
-            self.dp.allreduce_flat(self.flat_g)
-        self.step_count += 1
+        self.dp.allreduce_flat(self.flat_g)
         one = ctypes.c_uint64 * 1
         rc = _lib.lib().r4r_adam_multi(1, one(self.flat_p.data_ptr()), one(self.flat_g.data_ptr()),
                                        one(self.flat_m.data_ptr()), one(self.flat_v.data_ptr()),
