@@ -39,7 +39,7 @@ def measured_traffic(kernel, args):
     """HBM-side bytes per launch of `kernel` from the committed rocprofv3 --pmc summary
     (profiles/, separate counter passes of this same command) -- only for the configuration
     that summary was collected on; None otherwise."""
-    path = os.path.join(ROOT, 'profiles', 'r01d_bench_pmc_summary.json')
+    path = os.path.join(ROOT, 'profiles', 'r01f_bench_pmc_summary.json')
     if not (os.path.exists(path) and args.workload == WORKLOAD and args.batch_per_gpu == 128
             and args.engine == 'native' and args.conv_algo in ('auto', 'project')):
         return None
@@ -238,9 +238,11 @@ def main():
         feed = host_batches()
         resident_step = step
 
+        pool[:] = [next(feed), next(feed)]                   # [current, upcoming]: the host loop's lookahead
+
         def step(i):                                         # noqa: F811  (same step, batches arrive over PCIe)
-            pool[0] = next(feed)
-            resident_step(0)
+            resident_step(0)                                 # trains pool[0], prepares the tokens of pool[1]
+            pool[0], pool[1] = pool[1], next(feed)
 
     def fence():
         torch.cuda.synchronize()
