@@ -69,3 +69,50 @@ def test_dp2_hip_step_equals_reference_step_on_whole_batch(tmp_path, case):
         assert torch.equal(r0[k], r1[k]), k                       # replicas stay bit-identical
         if not ill_conditioned(k):
             torch.testing.assert_close(r0[k], v, rtol=1e-5, atol=5e-6, msg=lambda m: k + ': ' + m)
+
+
+def _engine_worker(rank, world, port, case, out_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, TESTS)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank), R4R_DIST_BACKEND='gloo')
+    from helpers import Golden
+    from test_gpu_models import build_model
+    from reviews4rec_amd import dist as r4dist
+    from reviews4rec_amd.engine import DeepCoNNEngine
+    r4dist.init_from_env()
+    g = Golden(case)
+    model, hp = build_model(g)
+    model.train()
+    dp = r4dist.DataParallel(model)
+    dp.broadcast_parameters()
+    eng = DeepCoNNEngine(model, lr=hp['lr'], weight_decay=hp['weight_decay'], dp=dp, rank=rank, conv_algo=2)
+    shards = [r4dist.shard_batch(*g.batch(k, 'cuda'), rank, world) for k in (0, 1)]
+    ses = []
+    for step in range(3):
+        sd, sy = shards[step % 2]
+        nxt = shards[(step + 1) % 2][0] if step < 2 else None      # shapes differ: the guess is declined
+        n_global = dp.global_count(sy.shape[0], sy.device)
+        ses.append(eng.train_step(sd, sy, n_global=n_global, next_data=nxt).cpu().clone())
+    torch.save({'w': {k: v.detach().cpu() for k, v in model.state_dict().items()}, 'se': ses},
+               os.path.join(out_dir, 'e%d.pt' % rank))
+    torch.distributed.destroy_process_group()
+
+
+def test_dp2_native_engine_follows_the_reference_trajectory(tmp_path):
+    """The fused DeepCoNN step under data parallelism (flat-gradient all-reduce between the step
+    and a separate Adam launch): 2 ranks x half batches == the reference's 3 single-process steps."""
+    sys.path.insert(0, TESTS)
+    from helpers import Golden
+    case = 'deepconn_e20'
+    port = _free_port()
+    mp.spawn(_engine_worker, args=(2, port, case, str(tmp_path)), nprocs=2, join=True)
+    g = Golden(case)
+    r0 = torch.load(os.path.join(tmp_path, 'e0.pt'))
+    r1 = torch.load(os.path.join(tmp_path, 'e1.pt'))
+    for step in range(3):
+        se = torch.cat([r0['se'][step], r1['se'][step]])
+        torch.testing.assert_close(se, g.arr('se%d' % step), rtol=1e-4, atol=1e-5)
+    for k, v in g.params('w3').items():
+        assert torch.equal(r0['w'][k], r1['w'][k]), k               # replicas stay bit-identical
+        torch.testing.assert_close(r0['w'][k], v, rtol=1e-5, atol=5e-6, msg=lambda m: k + ': ' + m)
