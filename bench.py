@@ -183,6 +183,9 @@ def main():
         from reviews4rec_amd.engine import DeepCoNNEngine
         engine = DeepCoNNEngine(model, lr=hp['lr'], weight_decay=hp['weight_decay'], dp=dp, seed=4321, rank=rank,
                                 conv_algo={'auto': 0, 'direct': 1, 'project': 2}[args.conv_algo])
+    # N > 1: measure the two gradient-exchange forms on this node's fabric once, before any timed
+    # step, and keep the faster (R4R_DP_EXCHANGE=allreduce|gather pins one)
+    exchange_ms = engine.autotune_exchange() if (engine is not None and world > 1) else {}
 
     graphed = None
     if args.engine == 'graph':
@@ -292,6 +295,8 @@ def main():
                        'parallelism': 'dp%d' % world,
                        'engine': 'native' if engine is not None else ('graph' if graphed is not None else 'module'),
                        'conv_algo': args.conv_algo,
+                       **({'dp_exchange': engine.exchange,
+                           'dp_exchange_ms': {k: round(v, 4) for k, v in exchange_ms.items()}} if exchange_ms else {}),
                        'shape': {'recommender': hp['model_type'], 'word_embed_size': hp['word_embed_size'],
                                  'input_length': hp['input_length'], 'conv_filters': 100,
                                  'latent_size': hp['latent_size'], 'vocab': hp.get('vocab', 0),

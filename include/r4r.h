@@ -210,6 +210,14 @@ int r4r_adam_chunk_elems(void);
 int r4r_adam_multi(int ntensor, const uint64_t *p, const uint64_t *g, const uint64_t *m, const uint64_t *v,
                    const int64_t *numel, float lr, double beta1, double beta2, float eps,
                    float weight_decay, int64_t step, const int64_t *step_dev, void *stream);
+/* Data-parallel Adam on one flat buffer: gradient = sum over the `world` per-rank buffers of an
+ * all_gather (`gathered` [world][numel], added in rank order: identical bits on every rank),
+ * update as above in the same pass; g_sum (nullable) receives the summed gradient.  numel % 4 == 0,
+ * 16-byte aligned buffers (the flat buffers of r4r_deepconn_layout are). */
+int r4r_adam_gathered(float *p, const float *gathered, int world, float *g_sum, float *m, float *v,
+                      int64_t numel, float lr, double beta1, double beta2, float eps,
+                      float weight_decay, int64_t step, void *stream);
+
 
 /* ------------------------------------------------------------------------
  * Fused DeepCoNN step ('deepconn' mode): the whole of DeepCoNN.forward

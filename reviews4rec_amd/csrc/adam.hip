@@ -80,9 +80,56 @@ __global__ __launch_bounds__(ADAM_THREADS) void adam_multi_kernel(AdamBatch tb, 
     }
 }
 
+// Data-parallel form: the gradient is the sum of `world` per-rank buffers that an all_gather
+// laid out back to back; they are added in rank order (every rank gets the same bits) and the
+// element is updated at once -- the exchange needs one collective phase instead of the
+// reduce-scatter + all-gather of an all-reduce, and no separate summation launch.
+__global__ __launch_bounds__(ADAM_THREADS) void adam_gathered_kernel(float *__restrict__ p, const float *__restrict__ gathered,
+                                                                     int world, float *__restrict__ g_sum,
+                                                                     float *__restrict__ m, float *__restrict__ v,
+                                                                     int64_t numel, AdamScalars s) {
+    const int64_t nvec = numel >> 2;
+    const int64_t i = (int64_t)blockIdx.x * ADAM_THREADS + threadIdx.x;
+    if (i < nvec) {
+        float4 G = reinterpret_cast<const float4 *>(gathered)[i];
+        for (int w = 1; w < world; ++w) {
+            const float4 t = reinterpret_cast<const float4 *>(gathered + (size_t)w * numel)[i];
+            G.x += t.x; G.y += t.y; G.z += t.z; G.w += t.w;
+        }
+        float4 P = reinterpret_cast<float4 *>(p)[i];
+        float4 M = reinterpret_cast<float4 *>(m)[i];
+        float4 V = reinterpret_cast<float4 *>(v)[i];
+        adam_elem(P.x, G.x, M.x, V.x, s);
+        adam_elem(P.y, G.y, M.y, V.y, s);
+        adam_elem(P.z, G.z, M.z, V.z, s);
+        adam_elem(P.w, G.w, M.w, V.w, s);
+        reinterpret_cast<float4 *>(p)[i] = P;
+        reinterpret_cast<float4 *>(m)[i] = M;
+        reinterpret_cast<float4 *>(v)[i] = V;
+        if (g_sum) reinterpret_cast<float4 *>(g_sum)[i] = G;
+    }
+}
+
 }  // namespace r4r
 
 using namespace r4r;
+
+extern "C" int r4r_adam_gathered(float *p, const float *gathered, int world, float *g_sum, float *m, float *v,
+                                 int64_t numel, float lr, double beta1, double beta2, float eps,
+                                 float weight_decay, int64_t step, void *stream) {
+    R4R_REQUIRE(p && gathered && m && v, "adam_gathered: null pointer");
+    R4R_REQUIRE(world >= 1 && numel >= 0 && step >= 1, "adam_gathered: bad world / numel / step");
+    R4R_REQUIRE(numel % 4 == 0, "adam_gathered: numel %lld must be a multiple of 4 (flat buffers are)", (long long)numel);
+    R4R_REQUIRE(((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(gathered) | reinterpret_cast<uintptr_t>(m) |
+                  reinterpret_cast<uintptr_t>(v) | reinterpret_cast<uintptr_t>(g_sum)) & 15) == 0,
+                "adam_gathered: buffers must be 16-byte aligned");
+    if (numel == 0) return R4R_OK;
+    const AdamScalars s = adam_make_scalars(lr, beta1, beta2, eps, weight_decay, step, nullptr);
+    ScopedTiming tm(R4R_TIMING_ADAM, as_stream(stream));
+    adam_gathered_kernel<<<(unsigned)cdiv(numel / 4, ADAM_THREADS), ADAM_THREADS, 0, as_stream(stream)>>>(
+        p, gathered, world, g_sum, m, v, numel, s);
+    return check_launch("adam_gathered");
+}
 
 extern "C" int r4r_adam_chunk_elems(void) { return ADAM_CHUNK; }
 

@@ -192,6 +192,15 @@ class DataParallel:
         if self.on:
             dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
 
+    def gather_flat(self, flat, out):
+        """All ranks' flat gradient buffers back to back in `out` [world * n] (rank order): the
+        one-phase alternative to the all-reduce; the sum happens in the optimiser kernel
+        (r4r_adam_gathered), in rank order, so every rank computes the same bits."""
+        if self.on:
+            dist.all_gather_into_tensor(out, flat, group=self.group)
+        else:
+            out[:flat.numel()].copy_(flat)
+
     @torch.no_grad()
     def sum_scalar(self, t):
         if self.on:

@@ -13,6 +13,7 @@ the same number as the reference's per-batch ``float(torch.sum(loss))`` without 
 device->host sync per step.
 """
 import ctypes
+import os
 
 import torch
 
@@ -60,6 +61,12 @@ class DeepCoNNEngine:
         self.step_count = 0
         self.seed = (int(seed) * 0x9E3779B97F4A7C15 + int(rank) * 0xD1B54A32D192ED03) & 0xFFFFFFFFFFFFFFFF
         self.offset = 0
+        # data-parallel gradient exchange: 'allreduce' (all-reduce flat_g, then r4r_adam_multi) or
+        # 'gather' (all_gather the flat buffers, sum + Adam in one launch); see autotune_exchange()
+        self.exchange = os.environ.get('R4R_DP_EXCHANGE', 'allreduce')
+        if self.exchange not in ('allreduce', 'gather'):
+            raise ValueError("R4R_DP_EXCHANGE must be 'allreduce' or 'gather', got %r" % (self.exchange,))
+        self._gathered = None
         self._ws = None
         self._ws_key = None
         self._out = {}
@@ -210,14 +217,53 @@ class DeepCoNNEngine:
             return se
         _, se = self._launch(data, y, grad=True, training=self.model.training, inv_denom=1.0 / denom,
                              next_data=next_data)
-        self.dp.allreduce_flat(self.flat_g)
-        one = ctypes.c_uint64 * 1
-        rc = _lib.lib().r4r_adam_multi(1, one(self.flat_p.data_ptr()), one(self.flat_g.data_ptr()),
-                                       one(self.flat_m.data_ptr()), one(self.flat_v.data_ptr()),
-                                       (ctypes.c_int64 * 1)(self.total), self.lr, self.betas[0], self.betas[1],
-                                       self.eps, self.wd, self.step_count, None, _lib.current_stream())
-        _lib.check(rc, 'r4r_adam_multi')
+        self._exchange_and_update(self.flat_p, self.flat_g, self.flat_m, self.flat_v, self.step_count)
         return se
+
+    def _exchange_and_update(self, p, g, m, v, step):
+        """Sum the ranks' gradients and apply Adam update number `step` to (p, m, v)."""
+        if self.exchange == 'gather':
+            if self._gathered is None:
+                self._gathered = torch.empty(self.dp.world * self.total, dtype=torch.float32, device=self.dev)
+            self.dp.gather_flat(g, self._gathered)
+            rc = _lib.lib().r4r_adam_gathered(ptr(p), ptr(self._gathered), self.dp.world, ptr(g), ptr(m), ptr(v),
+                                              self.total, self.lr, self.betas[0], self.betas[1], self.eps, self.wd,
+                                              int(step), _lib.current_stream())
+            _lib.check(rc, 'r4r_adam_gathered')
+            return
+        self.dp.allreduce_flat(g)
+        one = ctypes.c_uint64 * 1
+        rc = _lib.lib().r4r_adam_multi(1, one(p.data_ptr()), one(g.data_ptr()), one(m.data_ptr()), one(v.data_ptr()),
+                                       (ctypes.c_int64 * 1)(self.total), self.lr, self.betas[0], self.betas[1],
+                                       self.eps, self.wd, int(step), None, _lib.current_stream())
+        _lib.check(rc, 'r4r_adam_multi')
+
+    def autotune_exchange(self, trials=20):
+        """Time both gradient-exchange forms on the job's own fabric (scratch buffers: the model is
+        not touched) and keep the faster one; every rank takes the same decision (the slowest
+        rank's time counts).  Call it once, outside any timed region.  -> {'allreduce': ms, 'gather': ms}"""
+        if not (self.dp is not None and self.dp.on):
+            return {}
+        scratch = [torch.zeros_like(self.flat_p) for _ in range(4)]
+        keep, res = self.exchange, {}
+        for how in ('allreduce', 'gather'):
+            self.exchange = how
+            for _ in range(3):
+                self._exchange_and_update(*scratch, 1)
+            torch.cuda.synchronize(self.dev)
+            torch.distributed.barrier(group=self.dp.group)
+            t0 = torch.cuda.Event(enable_timing=True)
+            t1 = torch.cuda.Event(enable_timing=True)
+            t0.record()
+            for _ in range(trials):
+                self._exchange_and_update(*scratch, 1)
+            t1.record()
+            torch.cuda.synchronize(self.dev)
+            t = torch.tensor([t0.elapsed_time(t1) / trials], dtype=torch.float64, device=self.dev)
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX, group=self.dp.group)
+            res[how] = float(t.item())
+        self.exchange = keep if os.environ.get('R4R_DP_EXCHANGE') else min(res, key=res.get)
+        return res
 
     @torch.no_grad()
     def predict(self, data, y=None):

@@ -71,11 +71,13 @@ def test_dp2_hip_step_equals_reference_step_on_whole_batch(tmp_path, case):
             torch.testing.assert_close(r0[k], v, rtol=1e-5, atol=5e-6, msg=lambda m: k + ': ' + m)
 
 
-def _engine_worker(rank, world, port, case, out_dir):
+def _engine_worker(rank, world, port, case, out_dir, exchange):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, TESTS)
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       LOCAL_RANK=str(rank), R4R_DIST_BACKEND='gloo')
+    if exchange != 'autotune':
+        os.environ['R4R_DP_EXCHANGE'] = exchange
     from helpers import Golden
     from test_gpu_models import build_model
     from reviews4rec_amd import dist as r4dist
@@ -87,6 +89,13 @@ def _engine_worker(rank, world, port, case, out_dir):
     dp = r4dist.DataParallel(model)
     dp.broadcast_parameters()
     eng = DeepCoNNEngine(model, lr=hp['lr'], weight_decay=hp['weight_decay'], dp=dp, rank=rank, conv_algo=2)
+    if exchange == 'autotune':
+        before = eng.flat_p.clone()
+        times = eng.autotune_exchange(trials=3)
+        assert set(times) == {'allreduce', 'gather'} and eng.exchange in times
+        assert torch.equal(before, eng.flat_p)                     # tuning runs on scratch buffers
+    else:
+        assert eng.exchange == exchange
     shards = [r4dist.shard_batch(*g.batch(k, 'cuda'), rank, world) for k in (0, 1)]
     ses = []
     for step in range(3):
@@ -99,14 +108,17 @@ def _engine_worker(rank, world, port, case, out_dir):
     torch.distributed.destroy_process_group()
 
 
-def test_dp2_native_engine_follows_the_reference_trajectory(tmp_path):
-    """The fused DeepCoNN step under data parallelism (flat-gradient all-reduce between the step
-    and a separate Adam launch): 2 ranks x half batches == the reference's 3 single-process steps."""
+@pytest.mark.parametrize('exchange', ['allreduce', 'gather', 'autotune'])
+def test_dp2_native_engine_follows_the_reference_trajectory(tmp_path, exchange):
+    """The fused DeepCoNN step under data parallelism -- gradients summed by one all-reduce and a
+    separate Adam launch, or all_gathered and summed in rank order inside the Adam launch, or
+    whichever of the two the engine measures to be faster: 2 ranks x half batches == the
+    reference's 3 single-process steps."""
     sys.path.insert(0, TESTS)
     from helpers import Golden
     case = 'deepconn_e20'
     port = _free_port()
-    mp.spawn(_engine_worker, args=(2, port, case, str(tmp_path)), nprocs=2, join=True)
+    mp.spawn(_engine_worker, args=(2, port, case, str(tmp_path), exchange), nprocs=2, join=True)
     g = Golden(case)
     r0 = torch.load(os.path.join(tmp_path, 'e0.pt'))
     r1 = torch.load(os.path.join(tmp_path, 'e1.pt'))
