@@ -274,6 +274,24 @@ class DeepCoNNEngine:
         shape = tuple(data[5].shape)
         return pred.view(shape), (se.view(shape) if y is not None else None)
 
+    def state_dict(self):
+        """Optimiser-side state of the fused step (the weights themselves live in the model's
+        state_dict): Adam moments and step count, the dropout stream position."""
+        return {'exp_avg': self.flat_m.clone(), 'exp_avg_sq': self.flat_v.clone(), 'step': self.step_count,
+                'dropout_offset': self.offset, 'lr': self.lr, 'weight_decay': self.wd, 'betas': self.betas,
+                'eps': self.eps}
+
+    def load_state_dict(self, sd):
+        if sd['exp_avg'].numel() != self.total:
+            raise ValueError('DeepCoNNEngine.load_state_dict: %d moment elements for a %d-element layout'
+                             % (sd['exp_avg'].numel(), self.total))
+        self.flat_m.copy_(sd['exp_avg'].to(self.dev))
+        self.flat_v.copy_(sd['exp_avg_sq'].to(self.dev))
+        self.step_count = int(sd['step'])
+        self.offset = int(sd['dropout_offset'])
+        self.lr, self.wd = float(sd['lr']), float(sd['weight_decay'])
+        self.betas, self.eps = tuple(sd['betas']), float(sd['eps'])
+
     def grads(self):
         """Named views of the flat gradient buffer (reference parameter names)."""
         names = ['user_conv.convs.0.weight', 'user_conv.convs.0.bias', 'user_conv.fc.weight', 'user_conv.fc.bias',

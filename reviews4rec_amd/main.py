@@ -16,6 +16,7 @@ backward passes run against one retained graph of pre-step activations while eac
 optimiser writes through ``.data`` (no autograd version bump).
 """
 import datetime as dt
+import os
 import time
 
 import torch
@@ -161,9 +162,28 @@ def train_complete(hyper_params, Model, train_reader, val_reader, user_count, it
 
     file_write(hyper_params['log_file'], str(model))
     file_write(hyper_params['log_file'], '\nModel Built!\nStarting Training...\n')
+    # Epoch-level resume (absent upstream): hyper_params['checkpoint_path'] names a file
+    # rewritten after every epoch with the weights, the optimiser state (Adam moments, step counts,
+    # dropout stream position) and the loop state; if it exists when training starts, training
+    # continues after the epoch it records and lands on the same weights as an uninterrupted run.
+    ckpt_path = hyper_params.get('checkpoint_path')
+    first_epoch, best_MSE = 1, float(INF)
+    if ckpt_path and os.path.exists(ckpt_path):
+        ck = torch.load(ckpt_path, map_location='cpu')
+        model.load_state_dict(ck['model'])
+        if engine is not None:
+            engine.load_state_dict(ck['optimizer'])
+        elif isinstance(optimizer, (list, tuple)):
+            for o, sd in zip(optimizer, ck['optimizer']):
+                o.load_state_dict(sd)
+        else:
+            optimizer.load_state_dict(ck['optimizer'])
+        from . import ops
+        ops.DropoutState.offset = int(ck.get('dropout_offset', 0))    # module path's Philox stream position
+        first_epoch, best_MSE = int(ck['epoch']) + 1, float(ck['best_MSE'])
+        file_write(hyper_params['log_file'], 'Resuming after epoch {:d} from {}'.format(int(ck['epoch']), ckpt_path))
     try:
-        best_MSE = float(INF)
-        for epoch in range(1, hyper_params['epochs'] + 1):
+        for epoch in range(first_epoch, hyper_params['epochs'] + 1):
             epoch_start_time = time.time()
             metrics = train(model, criterion, optimizer, train_reader, hyper_params, engine=engine, dp=dp,
                             graph=graph)
@@ -177,6 +197,18 @@ def train_complete(hyper_params, Model, train_reader, val_reader, user_count, it
                     print('Saving model...')
                     torch.save(model.state_dict(), hyper_params['model_path'])
                 best_MSE = metrics['MSE']
+            if ckpt_path and rank == 0:
+                if engine is not None:
+                    opt_sd = engine.state_dict()
+                elif isinstance(optimizer, (list, tuple)):
+                    opt_sd = [o.state_dict() for o in optimizer]
+                else:
+                    opt_sd = optimizer.state_dict()
+                tmp = ckpt_path + '.tmp'
+                from . import ops
+                torch.save({'epoch': epoch, 'best_MSE': best_MSE, 'model': model.state_dict(),
+                            'optimizer': opt_sd, 'dropout_offset': ops.DropoutState.offset}, tmp)
+                os.replace(tmp, ckpt_path)                  # a crash mid-write leaves the previous one intact
     except KeyboardInterrupt:
         print('Exiting from training early')
 
