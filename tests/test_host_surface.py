@@ -122,6 +122,20 @@ def test_evaluate_metrics_and_count_maps():
     assert sum(len(v) for v in ucm.values()) == se.numel() == sum(len(v) for v in icm.values())
     assert 3 in ucm and 0 in icm                              # train-frequency keys (eval.py:45-53)
     assert sorted(x for v in icm.values() for x in v) == pytest.approx(sorted(se.tolist()), abs=1e-5)
+    # against the reference's per-example loop restated (eval.py:42-53): same keys, same lists in
+    # the same order, same side effect on the count dictionaries
+    users = torch.cat([d0[5], d1[5]]).tolist()
+    items = torch.cat([d0[6], d1[6]]).tolist()
+    ref_uc, ref_ic, ref_ucm, ref_icm = {int(d0[5][0]): 3}, {}, {}, {}
+    model.eval()
+    with torch.no_grad():
+        mine = torch.cat([(model(d0) - y0) ** 2, (model(d1) - y1) ** 2]).tolist()
+    for u, i, e in zip(users, items, mine):
+        ref_uc.setdefault(u, 0)
+        ref_ic.setdefault(i, 0)
+        ref_ucm.setdefault(ref_uc[u], []).append(e)
+        ref_icm.setdefault(ref_ic[i], []).append(e)
+    assert ucm == ref_ucm and icm == ref_icm and user_count == ref_uc
 
 
 def test_eval_ranking_hr_at_1():
