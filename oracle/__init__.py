@@ -17,6 +17,8 @@ from .models import (  # noqa: F401
     textcnn_forward,
     fm_forward,
     mf_forward,
+    neumf_forward,
+    neumf_init,
     deepconn_forward,
     narre_forward,
     transnet_forward,

@@ -17,6 +17,8 @@ Reference map (file:line under /root/reference):
   textcnn_forward   pytorch_models/common_pytorch_models.py:22-39
   fm_forward        pytorch_models/common_pytorch_models.py:49-57
   mf_forward        pytorch_models/MF.py:39-68
+  neumf_forward     pytorch_models/NeuMF.py:25-38 (GMF), 60-74 (MLP), 120-143 (NeuMF)
+  neumf_init        pytorch_models/NeuMF.py:100-118 (NeuMF.init from pre-trained GMF / MLP)
   deepconn_forward  pytorch_models/DeepCoNN.py:37-72
   narre_forward     pytorch_models/NARRE.py:53-124
   transnet_forward  pytorch_models/TransNet.py:25-37,55-61,83-122
@@ -106,6 +108,54 @@ def mf_forward(params, data, model_type, p=0.0, train=False, masks=None):
     return (base + fm_forward(params, 'final', x)).view(shape)
 
 
+def neumf_forward(params, data, stage, p=0.0, train=False, masks=None):
+    """stage 'GMF' / 'MLP' (the two pre-training models) or 'NeuMF' (their fusion)."""
+    user_id, item_id = data[5], data[6]
+    shape = user_id.shape
+    u, i = user_id.reshape(-1), item_id.reshape(-1)
+    base = params['user_bias'][u] + params['item_bias'][i] + params['global_bias']
+
+    def emb(name, site):
+        idx = u if 'user' in name else i
+        return _dropout(params[name + '.weight'][idx], site, p, train, masks)
+
+    def project(x):
+        h = _dropout(x, 'project.0', p, train, masks)
+        h = F.relu(_linear(params, 'project.1', h))
+        return _linear(params, 'project.3', h)
+
+    if stage == 'GMF':
+        joint = emb('user_embedding', 'dropout.user') * emb('item_embedding', 'dropout.item')
+    elif stage == 'MLP':
+        joint = project(torch.cat([emb('user_embedding', 'dropout.user'), emb('item_embedding', 'dropout.item')], -1))
+    elif stage == 'NeuMF':
+        gmf = emb('gmf_user_embedding', 'dropout.gmf_user') * emb('gmf_item_embedding', 'dropout.gmf_item')
+        mlp = project(torch.cat([emb('mlp_user_embedding', 'dropout.mlp_user'),
+                                 emb('mlp_item_embedding', 'dropout.mlp_item')], -1))
+        joint = torch.cat([gmf, mlp], -1)
+    else:
+        raise ValueError('unknown NeuMF stage %r' % (stage,))
+    rating = _linear(params, 'final', joint)[:, 0]
+    return (base + rating).view(shape)
+
+
+def neumf_init(neumf, gmf, mlp):
+    """NeuMF.init: returns the NeuMF parameter dict initialised from pre-trained GMF / MLP dicts
+    (`neumf` supplies the entries init leaves alone: global_bias)."""
+    P = dict(neumf)
+    P['gmf_user_embedding.weight'] = gmf['user_embedding.weight'].clone()
+    P['gmf_item_embedding.weight'] = gmf['item_embedding.weight'].clone()
+    P['mlp_user_embedding.weight'] = mlp['user_embedding.weight'].clone()
+    P['mlp_item_embedding.weight'] = mlp['item_embedding.weight'].clone()
+    for k in ('project.1.weight', 'project.1.bias', 'project.3.weight', 'project.3.bias'):
+        P[k] = mlp[k].clone()
+    P['final.weight'] = torch.cat([gmf['final.weight'], mlp['final.weight']], -1)
+    P['final.bias'] = 0.5 * (gmf['final.bias'] + mlp['final.bias'])
+    P['user_bias'] = 0.5 * (gmf['user_bias'] + mlp['user_bias'])
+    P['item_bias'] = 0.5 * (gmf['item_bias'] + mlp['item_bias'])
+    return P
+
+
 def deepconn_forward(params, data, model_type, p=0.0, train=False, masks=None):
     user_reviews, item_reviews, user_id, item_id = data[3], data[4], data[5], data[6]
     shape, n = _flatten_negs(user_id)
@@ -190,6 +240,8 @@ def model_forward(params, data, hyper_params, train=False, masks=None):
     p = float(hyper_params.get('dropout', 0.0))
     if mt in ('bias_only', 'MF_dot', 'MF'):
         return mf_forward(params, data, mt, p, train, masks)
+    if mt == 'NeuMF':
+        return neumf_forward(params, data, hyper_params.get('neumf_stage', 'NeuMF'), p, train, masks)
     if mt in ('deepconn', 'deepconn++'):
         return deepconn_forward(params, data, mt, p, train, masks)
     if mt == 'NARRE':
@@ -262,6 +314,20 @@ def init_params(hyper_params, vocab_size=None, seed=0):
             _linear_params(P, 'projection.1', 2 * L, L, gen)
             _linear_params(P, 'projection.3', L, L, gen)
             _fm_params(P, 'final', 2 * L, L, gen)
+        return P
+    if mt == 'NeuMF':
+        stage = hyper_params.get('neumf_stage', 'NeuMF')
+        P['user_bias'] = torch.full((U + 1,), 0.1)
+        P['item_bias'] = torch.full((I + 1,), 0.1)
+        P['global_bias'] = torch.full((1,), 4.0)
+        tables = ['user_embedding', 'item_embedding'] if stage != 'NeuMF' else \
+            ['gmf_user_embedding', 'gmf_item_embedding', 'mlp_user_embedding', 'mlp_item_embedding']
+        for t in tables:
+            P[t + '.weight'] = _xavier(((U if 'user' in t else I) + 1, L), gen)
+        if stage != 'GMF':
+            _linear_params(P, 'project.1', 2 * L, L, gen)
+            _linear_params(P, 'project.3', L, L, gen)
+        _linear_params(P, 'final', 2 * L if stage == 'NeuMF' else L, 1, gen)
         return P
     V = vocab_size
     if mt in ('deepconn', 'deepconn++'):

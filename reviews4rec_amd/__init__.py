@@ -23,6 +23,8 @@ def get_model_class(model_type):
         from .pytorch_models.NARRE import NARRE as Model
     elif model_type in ('bias_only', 'MF', 'MF_dot'):
         from .pytorch_models.MF import MF as Model
+    elif model_type == 'NeuMF':                      # GMF / MLP / NeuMF by hyper_params['neumf_stage']
+        from .pytorch_models.NeuMF import build as Model
     else:
         raise ValueError('model_type %r is not on the accelerated path' % (model_type,))
     return Model

@@ -221,6 +221,41 @@ def train_complete(hyper_params, Model, train_reader, val_reader, user_count, it
     return model
 
 
+def main_NeuMF(hyper_params, readers, user_count=None, item_count=None, dp=None, ranking_reader=None):
+    """Counterpart of main.main_NeuMF (main.py:289-340) over already-built readers: pre-train GMF,
+    pre-train MLP (each with its own checkpoint path), initialise NeuMF from both, train it,
+    evaluate MSE (+ HR@1 when a negatives reader is given)."""
+    from .pytorch_models.NeuMF import GMF, MLP, NeuMF
+    train_reader, test_reader, val_reader = readers
+    user_count = {} if user_count is None else user_count
+    item_count = {} if item_count is None else item_count
+    start_time = time.time()
+    initial_path = hyper_params['model_path']
+    stage_models = {}
+    for tag, cls in (('_gmf', GMF), ('_mlp', MLP)):
+        hyper_params['model_path'] = initial_path + tag
+        model = cls(hyper_params)
+        if is_cuda_available:
+            model = model.cuda()
+        xavier_init(model)                                # main.py:300,309
+        stage_models[tag] = train_complete(hyper_params, cls, train_reader, val_reader, user_count, item_count,
+                                           model, review=False, dp=dp)
+    hyper_params['model_path'] = initial_path
+    model = NeuMF(hyper_params)
+    if is_cuda_available:
+        model = model.cuda()
+    model.init(stage_models['_gmf'], stage_models['_mlp'])    # main.py:326 (no xavier_init here)
+    model = train_complete(hyper_params, NeuMF, train_reader, val_reader, user_count, item_count, model,
+                           review=False, dp=dp)
+    criterion = MSELoss(hyper_params)
+    metrics, user_count_mse_map, item_count_mse_map = evaluate(
+        model, criterion, test_reader, hyper_params, user_count, item_count, review=False)
+    if ranking_reader is not None:
+        metrics.update(eval_ranking(model, ranking_reader, hyper_params, review=False))
+    log_end_epoch(hyper_params, metrics, 'final', time.time() - start_time, metrics_on='(TEST)')
+    return metrics, user_count_mse_map, item_count_mse_map
+
+
 def main_pytorch(hyper_params, readers, user_count=None, item_count=None, review_based_model=True, dp=None,
                  ranking_reader=None):
     """Counterpart of main.main_pytorch (main.py:342-399) over already-built readers

@@ -15,6 +15,8 @@ applies utils.xavier_init exactly like main.py:375-377, and records
   m3/.., v3/..        Adam moments after 3 steps
   tn_se<k>, tn_aux<k>, tn_w1/.., tn_w3/..   TransNet only: the 3-optimiser step of main.py:35-53
                       run with write-through (torch-0.4 style) optimisers, see DataAdam
+  init_gmf/.., init_mlp/..   neumf_full only: the GMF / MLP weights NeuMF.init (NeuMF.py:100-118)
+                      was fed with; w/.. is its result
 
 Only DATA is written (npz); no reference source travels.  Usage:
     cd /tmp && python /root/repo/tests/golden/make_golden.py
@@ -85,8 +87,41 @@ def to_t(data, y):
     return [torch.from_numpy(d) for d in data], torch.from_numpy(y)
 
 
+def build_neumf(hp, seed):
+    """GMF / MLP: Model(hp) + xavier_init (main.py:299-301,308-310); NeuMF: NeuMF(hp).init(gmf, mlp)
+    from freshly built GMF / MLP models, NO xavier_init (main.py:324-326).  Returns (model, extras)
+    where extras holds the GMF / MLP weights NeuMF.init was fed with."""
+    from pytorch_models.NeuMF import GMF, MLP, NeuMF
+    from utils import xavier_init
+    stage = hp['neumf_stage']
+    torch.manual_seed(seed)
+    if stage in ('GMF', 'MLP'):
+        model = (GMF if stage == 'GMF' else MLP)(hp)
+        xavier_init(model)
+        return model, {}
+    gmf, mlp = GMF(hp), MLP(hp)
+    xavier_init(gmf)
+    xavier_init(mlp)
+    with torch.no_grad():                        # pre-training stand-in: biases away from their constants
+        for m in (gmf, mlp):
+            m.user_bias.add_(torch.randn_like(m.user_bias) * 0.05)
+            m.item_bias.add_(torch.randn_like(m.item_bias) * 0.05)
+    extras = {}
+    for tag, m in (('init_gmf', gmf), ('init_mlp', mlp)):
+        for k, v in m.state_dict().items():
+            extras['%s/%s' % (tag, k)] = v.detach().numpy().copy()
+    model = NeuMF(hp)
+    model.init(gmf, mlp)
+    return model, extras
+
+
 def build(hp, V, seed):
     mt = hp['model_type']
+    if mt == 'NeuMF':
+        model, extras = build_neumf(hp, seed)
+        build.extras = extras
+        return model, hp
+    build.extras = {}
     tmp = tempfile.mkdtemp(prefix='r4r_golden_')
     hp = dict(hp, data_dir=tmp + '/')
     rng = np.random.default_rng(seed)
@@ -117,6 +152,7 @@ def run_case(name, hp, V, B, seed, steps=3):
     out = {}
     for k, v in model.state_dict().items():
         out['w/' + k] = v.detach().numpy().copy()
+    out.update(build.extras)
     batches = [make_batch(rng, hp, B, V), make_batch(rng, hp, max(1, B - 3), V)]  # ragged second batch
     crit = MSELoss(hp)
 
@@ -165,7 +201,7 @@ def run_case(name, hp, V, B, seed, steps=3):
 
     keep = ('model_type', 'latent_size', 'word_embed_size', 'input_length', 'dropout', 'lr',
             'weight_decay', 'total_users', 'total_items', 'narre_num_reviews', 'narre_num_words',
-            'batch_size')
+            'batch_size') + (('neumf_stage',) if mt == 'NeuMF' else ())
     out['hp_keys'] = np.array(keep)
     out['hp_vals'] = np.array([str(hp[k]) for k in keep])
     out['vocab'] = np.array(V)
@@ -265,6 +301,11 @@ def common_paths():
 
 def main():
     os.chdir(tempfile.mkdtemp(prefix='r4r_cwd_'))
+    if len(sys.argv) > 1 and sys.argv[1] == 'neumf':       # only the NeuMF family (added later)
+        run_case('neumf_gmf', base_hp('NeuMF', latent_size=8, neumf_stage='GMF'), V=4, B=13, seed=10)
+        run_case('neumf_mlp', base_hp('NeuMF', latent_size=8, neumf_stage='MLP'), V=4, B=13, seed=11)
+        run_case('neumf_full', base_hp('NeuMF', latent_size=8, neumf_stage='NeuMF'), V=4, B=13, seed=12)
+        return
     common_paths()
     run_case('mf_bias_only', base_hp('bias_only'), V=4, B=13, seed=1)
     run_case('mf_dot', base_hp('MF_dot', latent_size=8), V=4, B=13, seed=2)
@@ -279,6 +320,9 @@ def main():
     run_transnet_training('transnet_e16', base_hp('transnet', word_embed_size=16, input_length=21), V=80, B=4, seed=8)
     run_transnet_training('transnetpp_e16', base_hp('transnet++', word_embed_size=16, input_length=21), V=80, B=4,
                           seed=9)
+    run_case('neumf_gmf', base_hp('NeuMF', latent_size=8, neumf_stage='GMF'), V=4, B=13, seed=10)
+    run_case('neumf_mlp', base_hp('NeuMF', latent_size=8, neumf_stage='MLP'), V=4, B=13, seed=11)
+    run_case('neumf_full', base_hp('NeuMF', latent_size=8, neumf_stage='NeuMF'), V=4, B=13, seed=12)
 
 
 if __name__ == '__main__':

@@ -7,7 +7,8 @@ import torch
 GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
 
 GOLDEN_CASES = ['mf_bias_only', 'mf_dot', 'mf_full', 'deepconn_e20', 'deepconn_e64',
-                'deepconnpp_e20', 'narre_e16', 'transnet_e16', 'transnetpp_e16']
+                'deepconnpp_e20', 'narre_e16', 'transnet_e16', 'transnetpp_e16',
+                'neumf_gmf', 'neumf_mlp', 'neumf_full']
 TRAINABLE_CASES = [c for c in GOLDEN_CASES if not c.startswith('transnet')]
 
 _INT_KEYS = ('latent_size', 'word_embed_size', 'input_length', 'total_users', 'total_items',

@@ -102,7 +102,7 @@ def test_training_trajectory_matches_reference_golden(case):
                                        atol=1e-9, msg=lambda m: k + ': ' + m)
 
 
-@pytest.mark.parametrize('case', ['mf_full', 'deepconnpp_e20', 'narre_e16', 'transnetpp_e16'])
+@pytest.mark.parametrize('case', ['mf_full', 'deepconnpp_e20', 'narre_e16', 'transnetpp_e16', 'neumf_mlp', 'neumf_full'])
 def test_train_mode_dropout_with_injected_masks(case):
     """The device draws the masks (Philox); the same multipliers injected into the CPU
     oracle must reproduce the train-mode outputs (streams themselves are
@@ -256,3 +256,34 @@ def test_batcher_double_buffered_h2d_feeds_the_native_step():
             sizes.append(n)
             del burn
         assert sizes == [128, 128, 44]
+
+
+def test_neumf_init_and_three_stage_schedule(tmp_path):
+    """NeuMF.init on the device == the reference's (fixture), and main.main_NeuMF runs its
+    GMF -> MLP -> NeuMF schedule end to end on the HIP path (main.py:289-340)."""
+    from reviews4rec_amd import main as M
+    from reviews4rec_amd.pytorch_models.NeuMF import GMF, MLP, NeuMF
+    g = Golden('neumf_full')
+    hp = dict(g.hp)
+    gmf, mlp, full = GMF(hp).to(DEV), MLP(hp).to(DEV), NeuMF(hp).to(DEV)
+    gmf.load_state_dict(g.group('init_gmf'), strict=True)
+    mlp.load_state_dict(g.group('init_mlp'), strict=True)
+    full.init(gmf, mlp)
+    for k, v in g.params().items():
+        assert torch.equal(full.state_dict()[k].cpu(), v), k
+
+    class Reader:
+        def __len__(self):
+            return 2
+
+        def iter(self, eval=False):
+            for k in (0, 1):
+                yield g.batch(k, DEV)
+
+    hp.update(epochs=2, dataset='golden', log_file=str(tmp_path / 'neumf.log'), model_path=str(tmp_path / 'neumf.pt'))
+    metrics, ucm, icm = M.main_NeuMF(hp, (Reader(), Reader(), Reader()))
+    assert 0.0 < metrics['MSE'] < 25.0 and sum(len(v) for v in ucm.values()) == 13 + 10
+    for tag in ('_gmf', '_mlp', ''):                          # one best-on-validation checkpoint per stage
+        assert (tmp_path / ('neumf.pt' + tag)).exists()
+    log = open(tmp_path / 'neumf.log').read()
+    assert log.count('end of epoch 2') == 3
