@@ -179,13 +179,17 @@ def main():
     B_global = B * world
 
     engine = None
+    if args.engine == 'native' and hp['model_type'] in ('MF_dot', 'bias_only') and world == 1 and B <= 1024:
+        from reviews4rec_amd.engine import MFEngine
+        engine = MFEngine(model, lr=hp['lr'], weight_decay=hp['weight_decay'], seed=4321, rank=rank)
     if args.engine == 'native' and hp['model_type'] == 'deepconn':
         from reviews4rec_amd.engine import DeepCoNNEngine
         engine = DeepCoNNEngine(model, lr=hp['lr'], weight_decay=hp['weight_decay'], dp=dp, seed=4321, rank=rank,
                                 conv_algo={'auto': 0, 'direct': 1, 'project': 2}[args.conv_algo])
     # N > 1: measure the two gradient-exchange forms on this node's fabric once, before any timed
     # step, and keep the faster (R4R_DP_EXCHANGE=allreduce|gather pins one)
-    exchange_ms = engine.autotune_exchange() if (engine is not None and world > 1) else {}
+    exchange_ms = engine.autotune_exchange() if (engine is not None and world > 1
+                                                 and hasattr(engine, 'autotune_exchange')) else {}
 
     graphed = None
     if args.engine == 'graph':
@@ -260,7 +264,8 @@ def main():
     # 10th step is instrumented, and only the kernels the legs need (direct conv: slot 0; projection
     # GEMM + gather: slots 3, 4).  A HIP event record serialises the queue for ~3 us; instrumenting
     # every launch of every step cost 20 % of a 0.13 ms step, sampling costs ~1 %.
-    mask = 0 if args.no_kernel_timing else (1 << 0) | (1 << 3) | (1 << 4)
+    mask = 0 if args.no_kernel_timing else (1 << 0) | (1 << 3) | (1 << 4) | \
+        ((1 << 2) if hp['model_type'] in ('MF_dot', 'bias_only') else 0)       # MF: the Adam sweep is the leg
     t0 = time.perf_counter()
     for i in range(args.steps):
         lib.r4r_timing_enable(mask if i % 10 == 5 else 0)
@@ -346,6 +351,18 @@ def main():
                                   'frac': round(ach / PEAK_FP32_MFMA_TFLOPS, 4), 'traffic': None,
                                   'launches': timed['textcnn_fwd_kernel'][1], 'avg_launch_ms': round(1000 * avg_s, 4),
                                   'flops_per_launch': flops}
+        elif hp['model_type'] in ('MF_dot', 'bias_only') and 'adam_multi_kernel' in timed:
+            # ID-only models: the dense Adam sweep is the step (24 B per parameter when no
+            # dense gradient is materialised -- the native step -- 28 B when it is -- the module path)
+            nparam = sum(p.numel() for p in model.parameters())
+            per = 24 if engine is not None else 28
+            avg_s = timed['adam_multi_kernel'][0] / 1000.0
+            ach_b = nparam * per / avg_s / 1e9
+            result['roofline'] = {'kernel': 'mf_adam_kernel' if engine is not None else 'adam_multi_kernel',
+                                  'bound': 'hbm', 'achieved': round(ach_b, 1), 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
+                                  'frac': round(ach_b / PEAK_HBM_GBS, 4), 'traffic': None,
+                                  'launches': timed['adam_multi_kernel'][1], 'avg_launch_ms': round(1000 * avg_s, 4),
+                                  'bytes_per_launch': int(nparam * per), 'parameters': int(nparam)}
         if world == 1 and not args.no_cpu_baseline:
             cpu_hp = {k: v for k, v in hp.items() if k != 'word_vectors'}
             result['cpu_baseline'] = cpu_baseline(cpu_hp, table, batches_np[:4], args.cpu_seconds)

@@ -292,7 +292,35 @@ int r4r_deepconn_tokens(const int64_t *user_idx, const int64_t *item_idx, void *
 #define R4R_TIMING_TEXTCNN_WGRAD 1  /* textcnn_wgrad_kernel */
 #define R4R_TIMING_ADAM 2           /* adam_multi_kernel */
 #define R4R_TIMING_PROJ_GEMM 3      /* proj_gemm_kernel (projection of the batch's distinct tokens) */
-#define R4R_TIMING_PROJ_GATHER 4    /* proj_gather_max_kernel (gather-add-max over positions) */
+#define R4R_TIMING_PROJ_GATHER 4    /* ---- fused native step for the ID-only recommenders: model_type 'MF_dot' and 'bias_only'
+ * Replaces, per training step, MF.forward (MF.py:39-58: user/item bias gathers, the two
+ * ID-embedding gathers + dropout, the row dot product), MSELoss (loss.py:7-11), loss.backward()
+ * and torch.optim.Adam.step() (main.py:56-60,94-96) by TWO launches.  The dense gradient of an
+ * ID table is never materialised: gradient rows stay compact ([B, D]) and the Adam sweep treats a
+ * row no rating touched as gradient zero (24 B/element instead of 28 + a zero fill); rows touched
+ * more than once sum their entries in ascending batch order (deterministic).
+ *   p / m / v : HOST arrays of 5 DEVICE pointers -- user_embedding.weight [n_users, D],
+ *               item_embedding.weight [n_items, D], user_bias [n_users], item_bias [n_items],
+ *               global_bias [1] (n_users = total_users + 1, n_items = total_items + 1, MF.py:14-24);
+ *               the two table entries are ignored when D == 0 ('bias_only').
+ *               m == v == NULL: forward only (pred, and se when y is given).
+ *   dropout   : Philox4x32-10(seed, offset + b*2D + d) for the user row, + D for the item row
+ *   adam_step : 1-based update count; also tags the rows this step touched (workspace)
+ *   ws        : r4r_mf_ws_bytes; its first bytes (the row tags) must be ZERO on first use and
+ *               are kept consistent by the kernels -- allocate once, zero once.
+ *   B <= 1024 for training steps.  sse_accum (nullable) += sum_b se[b] on training steps. */
+size_t r4r_mf_ws_bytes(int64_t B, int D, int64_t n_users, int64_t n_items);
+size_t r4r_mf_ws_mult_offset(int64_t B, int D, int64_t n_users, int64_t n_items);   /* [B,2D] dropout multipliers (tests) */
+size_t r4r_mf_ws_grad_offset(int64_t B, int D, int64_t n_users, int64_t n_items, int which);   /* 0: user rows [B,D], 1: item rows, 2: d loss/d pred [B] (tests) */
+int r4r_mf_step(const int64_t *uid, const int64_t *iid, const float *y,
+                const uint64_t *p, const uint64_t *m, const uint64_t *v,
+                int64_t n_users, int64_t n_items, int D,
+                float *pred, float *se, float *sse_accum, void *ws, size_t ws_bytes, int64_t B,
+                float dropout_p, int training, uint64_t seed, uint64_t offset, float inv_denom,
+                float lr, double beta1, double beta2, float eps, float weight_decay, int64_t adam_step,
+                void *stream);
+
+/* proj_gather_max_kernel (gather-add-max over positions) */
 #define R4R_TIMING_SLOTS 8
 int r4r_timing_enable(int slot_mask);   /* bit i instruments slot i; 0 switches timing off */
 int r4r_timing_read(int slot, double *total_ms, int64_t *count, int reset);

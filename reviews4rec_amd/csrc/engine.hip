@@ -73,22 +73,6 @@ struct HeadArgs {
     uint64_t seed, offset;
 };
 
-__device__ __forceinline__ uint32_t philox_first_word(uint64_t ctr, uint64_t seed) {
-    uint32_t c0 = (uint32_t)ctr, c1 = (uint32_t)(ctr >> 32), c2 = 0u, c3 = 0u;
-    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
-#pragma unroll
-    for (int r = 0; r < 10; ++r) {
-        const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
-        const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
-        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
-        const uint32_t n1 = (uint32_t)p1;
-        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
-        const uint32_t n3 = (uint32_t)p0;
-        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
-        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
-    }
-    return c0;
-}
 
 // One wave per rating, 4 ratings per 256-thread workgroup.  Everything a rating needs
 // besides its own partials -- both FC matrices, FM V / lin -- is staged in LDS once per

@@ -306,3 +306,144 @@ class DeepCoNNEngine:
                  zip(names, self.slots, self.offsets, self.sizes)},
                 {k: self.flat_v[o:o + s].view(p.shape) for k, p, o, s in
                  zip(names, self.slots, self.offsets, self.sizes)})
+
+
+class MFEngine:
+    """Native step for model_type 'MF_dot' / 'bias_only' (csrc/mf_engine.hip, r4r_mf_step): forward,
+    loss, backward and the dense Adam update of MF.py / main.py:56-60,94-96 in two launches; the
+    dense gradient of an ID table is never materialised.  Same calling surface as DeepCoNNEngine
+    (train_step / predict / sse / state_dict).  Single process only: under data parallelism the
+    module path + the compact-list exchange of dist.py run instead."""
+    MAX_TRAIN_BATCH = 1024
+
+    def __init__(self, model, lr=0.002, weight_decay=1e-6, betas=(0.9, 0.999), eps=1e-8, seed=0x5EED5EED, rank=0):
+        hp = model.hyper_params
+        if hp['model_type'] not in ('MF_dot', 'bias_only'):
+            raise ValueError("MFEngine implements model_type 'MF_dot' and 'bias_only', got %r" % (hp['model_type'],))
+        self.model, self.hp = model, hp
+        self.lr, self.wd, self.betas, self.eps = float(lr), float(weight_decay), tuple(betas), float(eps)
+        self.has_tables = hp['model_type'] == 'MF_dot'
+        self.D = int(hp['latent_size']) if self.has_tables else 0
+        self.params = ([model.user_embedding.weight, model.item_embedding.weight] if self.has_tables else [None, None]) \
+            + [model.user_bias, model.item_bias, model.global_bias]
+        live = [p for p in self.params if p is not None]
+        if not all(p.is_cuda and p.dtype == torch.float32 and p.is_contiguous() for p in live):
+            raise RuntimeError('MFEngine: move the model to a ROCm device first (fp32, contiguous); the HIP '
+                               'path has no CPU fallback')
+        self.dev = live[0].device
+        self.n_users, self.n_items = model.user_bias.numel(), model.item_bias.numel()
+        self.m = [None if p is None else torch.zeros_like(p) for p in self.params]
+        self.v = [None if p is None else torch.zeros_like(p) for p in self.params]
+        self.sse = torch.zeros(1, dtype=torch.float32, device=self.dev)
+        self.step_count = 0
+        self.seed = (int(seed) * 0x9E3779B97F4A7C15 + int(rank) * 0xD1B54A32D192ED03) & 0xFFFFFFFFFFFFFFFF
+        self.offset = 0
+        self._ws, self._ws_B, self._out = None, None, {}
+
+    def _ptrs(self, tensors):
+        return (ctypes.c_uint64 * 5)(*[0 if t is None else t.data_ptr() for t in tensors])
+
+    def _workspace(self, B):
+        """One workspace per batch size (the ragged last batch alternates with the full ones); the
+        row tags at the head of the buffer are shared state, so they move with the switch."""
+        if self._ws_B != B:
+            cache = self.__dict__.setdefault('_ws_cache', {})
+            nxt = cache.get(B)
+            if nxt is None:
+                nb = _lib.lib().r4r_mf_ws_bytes(B, self.D, self.n_users, self.n_items)
+                nxt = cache[B] = torch.zeros(max(nb, 256), dtype=torch.uint8, device=self.dev)   # tags start at zero
+            if self._ws is not None:
+                keep = 256 * (-(-self.n_users * 4 // 256) + -(-self.n_items * 4 // 256))
+                nxt[:keep].copy_(self._ws[:keep])
+            self._ws, self._ws_B = nxt, B
+        return self._ws
+
+    def _launch(self, data, y, train_mode, inv_denom, adam_step):
+        uid, iid = data[5].reshape(-1), data[6].reshape(-1)
+        if not (uid.is_cuda and uid.dtype == torch.int64):
+            raise RuntimeError('MFEngine: batches must be int64 tensors on the ROCm device')
+        uid, iid = uid.contiguous(), iid.contiguous()
+        n = uid.numel()
+        if n not in self._out:
+            self._out[n] = (torch.empty(n, dtype=torch.float32, device=self.dev),
+                            torch.empty(n, dtype=torch.float32, device=self.dev))
+        pred, se = self._out[n]
+        ws = self._workspace(n)
+        rc = _lib.lib().r4r_mf_step(
+            ptr(uid), ptr(iid), ptr(y), self._ptrs(self.params),
+            self._ptrs(self.m) if adam_step else None, self._ptrs(self.v) if adam_step else None,
+            self.n_users, self.n_items, self.D, ptr(pred), ptr(se), ptr(self.sse) if adam_step else None,
+            ptr(ws), ws.numel(), n, float(self.hp['dropout']), int(train_mode), self.seed, self.offset,
+            float(inv_denom), self.lr, self.betas[0], self.betas[1], self.eps, self.wd, int(adam_step),
+            _lib.current_stream())
+        _lib.check(rc, 'r4r_mf_step')
+        if train_mode and float(self.hp['dropout']) > 0.0:
+            self.offset += n * 2 * self.D
+        return pred, se
+
+    @torch.no_grad()
+    def train_step(self, data, y, n_global=None, next_data=None):
+        """One optimisation step.  Returns the per-example SE tensor (device); the running sum is
+        in ``self.sse``.  (``next_data`` is accepted for loop compatibility; nothing to prepare.)"""
+        n = data[5].numel()
+        y = y.reshape(-1).contiguous()
+        self.step_count += 1
+        _, se = self._launch(data, y, self.model.training, 1.0 / float(n_global if n_global is not None else n),
+                             self.step_count)
+        return se
+
+    @torch.no_grad()
+    def predict(self, data, y=None):
+        """Eval-mode forward (no dropout, no gradients).  Returns (pred, se or None)."""
+        if y is not None:
+            y = y.reshape(-1).contiguous()
+        pred, se = self._launch(data, y, False, 1.0, 0)
+        shape = tuple(data[5].shape)
+        return pred.view(shape), (se.view(shape) if y is not None else None)
+
+    def dropout_multipliers(self, B):
+        """[B, 2D] multipliers the last training step drew (user row D, item row D)."""
+        off = _lib.lib().r4r_mf_ws_mult_offset(B, self.D, self.n_users, self.n_items)
+        return self._workspace(B)[off:off + B * 2 * self.D * 4].view(torch.float32).view(B, 2 * self.D).clone()
+
+    def dense_grads(self, data):
+        """Dense gradients of the LAST training step, rebuilt from its compact rows (introspection
+        for tests; the step itself never builds them).  `data`: the batch of that step."""
+        uid, iid = data[5].reshape(-1), data[6].reshape(-1)
+        B = uid.numel()
+        lib, ws = _lib.lib(), self._workspace(B)
+
+        def view(which, cols):
+            off = lib.r4r_mf_ws_grad_offset(B, self.D, self.n_users, self.n_items, which)
+            return ws[off:off + B * cols * 4].view(torch.float32).view(B, cols) if cols else None
+        g = view(2, 1)[:, 0]
+        out = {'user_bias': torch.zeros_like(self.params[2]).index_add_(0, uid, g),
+               'item_bias': torch.zeros_like(self.params[3]).index_add_(0, iid, g),
+               'global_bias': g.sum().reshape(1)}
+        if self.has_tables:
+            out['user_embedding.weight'] = torch.zeros_like(self.params[0]).index_add_(0, uid, view(0, self.D))
+            out['item_embedding.weight'] = torch.zeros_like(self.params[1]).index_add_(0, iid, view(1, self.D))
+        return out
+
+    def moments(self):
+        names = ['user_embedding.weight', 'item_embedding.weight', 'user_bias', 'item_bias', 'global_bias']
+        return ({k: t for k, t in zip(names, self.m) if t is not None},
+                {k: t for k, t in zip(names, self.v) if t is not None})
+
+    def state_dict(self):
+        m, v = self.moments()
+        return {'exp_avg': {k: t.clone() for k, t in m.items()}, 'exp_avg_sq': {k: t.clone() for k, t in v.items()},
+                'step': self.step_count, 'dropout_offset': self.offset, 'lr': self.lr, 'weight_decay': self.wd,
+                'betas': self.betas, 'eps': self.eps}
+
+    def load_state_dict(self, sd):
+        m, v = self.moments()
+        for k in m:
+            m[k].copy_(sd['exp_avg'][k].to(self.dev))
+            v[k].copy_(sd['exp_avg_sq'][k].to(self.dev))
+        self.step_count, self.offset = int(sd['step']), int(sd['dropout_offset'])
+        self.lr, self.wd = float(sd['lr']), float(sd['weight_decay'])
+        self.betas, self.eps = tuple(sd['betas']), float(sd['eps'])
+        # row tags written by earlier steps of THIS process must not collide with resumed step numbers
+        for ws in self.__dict__.get('_ws_cache', {}).values():
+            ws.zero_()

@@ -140,7 +140,15 @@ def make_optimizer(hyper_params, model):
 
 def make_engine(hyper_params, model, dp=None, rank=0):
     """The fused native step, where the model has one and the config asks for it."""
-    if hyper_params.get('engine', 'native') != 'native' or hyper_params['model_type'] != 'deepconn':
+    if hyper_params.get('engine', 'native') != 'native':
+        return None
+    if hyper_params['model_type'] in ('MF_dot', 'bias_only'):
+        if (dp is not None and dp.on) or int(hyper_params.get('batch_size', 128)) > 1024:
+            return None                                   # DP / very large batches: module path (dist.py C2)
+        from .engine import MFEngine
+        return MFEngine(model, lr=hyper_params['lr'], weight_decay=hyper_params['weight_decay'],
+                        seed=hyper_params.get('seed', 0x5EED5EED), rank=rank)
+    if hyper_params['model_type'] != 'deepconn':
         return None
     from .engine import DeepCoNNEngine
     return DeepCoNNEngine(model, lr=hyper_params['lr'], weight_decay=hyper_params['weight_decay'], dp=dp,
