@@ -265,14 +265,15 @@ def test_host_loop_with_native_engine_and_lookahead_matches_reference_metric():
     assert torch.equal(ref.flat_p, eng.flat_p)
 
 
+@pytest.mark.parametrize('case', ['deepconn_e20', 'mf_dot'])
 @pytest.mark.parametrize('engine_kind', ['native', 'module'])
-def test_train_complete_resumes_exactly_from_its_epoch_checkpoint(tmp_path, engine_kind):
+def test_train_complete_resumes_exactly_from_its_epoch_checkpoint(tmp_path, engine_kind, case):
     """main.train_complete with hyper_params['checkpoint_path']: a run stopped after epoch 2 and
     started again lands on the very weights of an uninterrupted 4-epoch run -- Adam moments, step
     counts and the dropout stream position travel with the checkpoint (dropout 0.5 here)."""
     import reviews4rec_amd
     from reviews4rec_amd import main as M, ops
-    g = Golden('deepconn_e20')
+    g = Golden(case)
 
     class Reader:
         def __len__(self):
@@ -290,7 +291,10 @@ def test_train_complete_resumes_exactly_from_its_epoch_checkpoint(tmp_path, engi
         if ckpt:
             hp['checkpoint_path'] = str(tmp_path / 'resume.ckpt')
         Model = reviews4rec_amd.get_model_class(hp['model_type'])
-        M.train_complete(hp, Model, Reader(), Reader(), {}, {}, model, review=True)
+        if engine_kind == 'native':                           # the fused step of this model family is in use
+            from reviews4rec_amd.engine import DeepCoNNEngine, MFEngine
+            assert isinstance(M.make_engine(hp, model), MFEngine if case == 'mf_dot' else DeepCoNNEngine)
+        M.train_complete(hp, Model, Reader(), Reader(), {}, {}, model, review=case != 'mf_dot')
         return {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
 
     whole = run('whole', 4, ckpt=False)
