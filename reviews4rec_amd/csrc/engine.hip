@@ -95,12 +95,40 @@ __global__ __launch_bounds__(256) void deepconn_head_kernel(HeadArgs a) {
     // scalars the tail needs: issued now, so they ride along with the first memory round trip
     const float lin_b0 = a.lin_b[0], gbias0 = a.gbias[0], yb = a.y ? a.y[b] : 0.f;
 
-    for (int i = tid; i < 2 * L * F_CONV; i += 256) {
-        const int t = i / (L * F_CONV), r = i - t * L * F_CONV;
-        sw[t][r / F_CONV][r % F_CONV] = a.fc_w[t][r];
+    // Stage the head's weights in LDS.  All the loads of this prologue -- these and the pooling
+    // partials below -- are issued before anything waits (a load -> LDS-store loop over the FC
+    // matrix alone was 8 dependent L2 round trips: 6 us of a 12 us kernel).
+    constexpr int WREGS = (2 * MAX_L * F_CONV + 255) / 256;
+    float wreg[WREGS];
+    const int wtot = 2 * L * F_CONV;
+#pragma unroll
+    for (int k = 0; k < WREGS; ++k) {
+        const int i = min(tid + 256 * k, wtot - 1);
+        const int t = i / (L * F_CONV);
+        wreg[k] = a.fc_w[t][i - t * L * F_CONV];
     }
-    if (tid < n) { sfb[tid / L][tid % L] = a.fc_b[tid / L][tid % L]; slw[tid] = a.lin_w[tid]; }
-    for (int i = tid; i < n * FM_K; i += 256) sV[i / FM_K][i % FM_K] = a.V[i];
+    const float fbreg = (tid < n) ? a.fc_b[tid / L][tid % L] : 0.f;
+    const float lwreg = (tid < n) ? a.lin_w[tid] : 0.f;
+    constexpr int VREGS = (2 * MAX_L * FM_K + 255) / 256;
+    float vreg[VREGS];
+#pragma unroll
+    for (int k = 0; k < VREGS; ++k) vreg[k] = a.V[min(tid + 256 * k, n * FM_K - 1)];
+    auto stage_weights = [&]() {
+#pragma unroll
+        for (int k = 0; k < WREGS; ++k) {
+            const int i = tid + 256 * k;
+            if (i < wtot) {
+                const int t = i / (L * F_CONV), r = i - t * L * F_CONV;
+                sw[t][r / F_CONV][r % F_CONV] = wreg[k];
+            }
+        }
+        if (tid < n) { sfb[tid / L][tid % L] = fbreg; slw[tid] = lwreg; }
+#pragma unroll
+        for (int k = 0; k < VREGS; ++k) {
+            const int i = tid + 256 * k;
+            if (i < n * FM_K) sV[i / FM_K][i % FM_K] = vreg[k];
+        }
+    };
 
     // ---- pool finish: max over tiles, relu, first argmax.  The common case (<= 8 tiles, i.e.
     // T <= 1022) loads everything a lane needs -- 2 towers x 2 filters x 8 tiles of (max, arg) --
@@ -168,6 +196,7 @@ __global__ __launch_bounds__(256) void deepconn_head_kernel(HeadArgs a) {
             }
         }
     }
+    stage_weights();
     __syncthreads();
 
     // ---- FC: lane i < 2L computes z[t][l] = b[l] + sum_f pooled[t][f] W[t][l][f]
