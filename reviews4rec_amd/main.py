@@ -7,8 +7,9 @@ and ``metrics['MSE'] = round(sum SE / N, 4)`` (main.py:66).  Two deliberate host
 differences, both numerically neutral: the running sum of SE stays on the device and
 is read once per epoch (the reference syncs with ``float(torch.sum(..))`` every
 batch, main.py:57), and ``optimizer`` is this package's fused Adam (same surface).
-With ``hyper_params['engine'] == 'native'`` and a model that has a fused step
-(DeepCoNN 'deepconn'), the whole sequence runs as one native call per batch.
+``hyper_params['engine']`` (default 'auto'): models with a fused native step (DeepCoNN 'deepconn',
+MF_dot, bias_only) run the whole sequence as one native call per batch; the others run the
+op-by-op step captured once into a hipGraph and replayed ('module' forces plain eager).
 
 TransNet's three-optimiser step (main.py:35-53) raises on torch >= 1.5 in the
 reference; ``train`` restates its torch-0.4 behaviour: the three
@@ -140,7 +141,7 @@ def make_optimizer(hyper_params, model):
 
 def make_engine(hyper_params, model, dp=None, rank=0):
     """The fused native step, where the model has one and the config asks for it."""
-    if hyper_params.get('engine', 'native') != 'native':
+    if hyper_params.get('engine', 'auto') not in ('auto', 'native'):
         return None
     if hyper_params['model_type'] in ('MF_dot', 'bias_only'):
         if (dp is not None and dp.on) or int(hyper_params.get('batch_size', 128)) > 1024:
@@ -166,7 +167,9 @@ def train_complete(hyper_params, Model, train_reader, val_reader, user_count, it
     rank = dp.rank if dp is not None else 0
     engine = make_engine(hyper_params, model, dp=dp, rank=rank)
     optimizer = None if engine is not None else make_optimizer(hyper_params, model)
-    graph = _GraphHolder() if (engine is None and hyper_params.get('engine') == 'graph') else None
+    # no fused step for this model: capture the op-by-op step in a hipGraph (TransNet's three-optimiser
+    # step and data-parallel runs stay eager inside train())
+    graph = _GraphHolder() if (engine is None and hyper_params.get('engine', 'auto') in ('auto', 'graph')) else None
 
     file_write(hyper_params['log_file'], str(model))
     file_write(hyper_params['log_file'], '\nModel Built!\nStarting Training...\n')
@@ -188,6 +191,8 @@ def train_complete(hyper_params, Model, train_reader, val_reader, user_count, it
             optimizer.load_state_dict(ck['optimizer'])
         from . import ops
         ops.DropoutState.offset = int(ck.get('dropout_offset', 0))    # module path's Philox stream position
+        if ops.DropoutState.device_counter is not None:               # ... which a captured step keeps on the device
+            ops.DropoutState.device_counter.fill_(ops.DropoutState.offset)
         first_epoch, best_MSE = int(ck['epoch']) + 1, float(ck['best_MSE'])
         file_write(hyper_params['log_file'], 'Resuming after epoch {:d} from {}'.format(int(ck['epoch']), ckpt_path))
     try:
@@ -214,8 +219,10 @@ def train_complete(hyper_params, Model, train_reader, val_reader, user_count, it
                     opt_sd = optimizer.state_dict()
                 tmp = ckpt_path + '.tmp'
                 from . import ops
+                drop_at = ops.DropoutState.offset if ops.DropoutState.device_counter is None else \
+                    int(ops.DropoutState.device_counter.item())
                 torch.save({'epoch': epoch, 'best_MSE': best_MSE, 'model': model.state_dict(),
-                            'optimizer': opt_sd, 'dropout_offset': ops.DropoutState.offset}, tmp)
+                            'optimizer': opt_sd, 'dropout_offset': drop_at}, tmp)
                 os.replace(tmp, ckpt_path)                  # a crash mid-write leaves the previous one intact
     except KeyboardInterrupt:
         print('Exiting from training early')

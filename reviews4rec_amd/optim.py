@@ -86,6 +86,10 @@ class Adam:
         self.step_dev = torch.tensor([steps.pop() if steps else 0], dtype=torch.int64, device=dev)
 
     def state_dict(self):
+        if self.step_dev is not None:                     # graph mode: the device counter is the truth
+            done = int(self.step_dev.item())
+            for st in self.state.values():
+                st['step'] = done
         return {'state': {i: {k: (v.clone() if torch.is_tensor(v) else v) for k, v in self.state[id(p)].items()}
                           for i, p in enumerate(self.params) if id(p) in self.state},
                 'param_groups': [{k: v for k, v in self.param_groups[0].items() if k != 'params'}]}
@@ -97,3 +101,6 @@ class Adam:
         for k, v in sd['param_groups'][0].items():
             self.param_groups[0][k] = v
         self.lr = float(self.param_groups[0]['lr'])
+        if self.step_dev is not None:
+            steps = {st['step'] for st in self.state.values()}
+            self.step_dev.fill_(steps.pop() if len(steps) == 1 else 0)

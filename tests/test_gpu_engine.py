@@ -265,8 +265,9 @@ def test_host_loop_with_native_engine_and_lookahead_matches_reference_metric():
     assert torch.equal(ref.flat_p, eng.flat_p)
 
 
-@pytest.mark.parametrize('case', ['deepconn_e20', 'mf_dot'])
-@pytest.mark.parametrize('engine_kind', ['native', 'module'])
+@pytest.mark.parametrize('case,engine_kind', [('deepconn_e20', 'native'), ('deepconn_e20', 'module'),
+                                              ('mf_dot', 'native'), ('mf_dot', 'module'),
+                                              ('narre_e16', 'auto'), ('deepconnpp_e20', 'graph')])
 def test_train_complete_resumes_exactly_from_its_epoch_checkpoint(tmp_path, engine_kind, case):
     """main.train_complete with hyper_params['checkpoint_path']: a run stopped after epoch 2 and
     started again lands on the very weights of an uninterrupted 4-epoch run -- Adam moments, step
@@ -284,6 +285,7 @@ def test_train_complete_resumes_exactly_from_its_epoch_checkpoint(tmp_path, engi
                 yield g.batch(k, DEV)
 
     def run(tag, epochs, ckpt):
+        ops.DropoutState.device_counter = None          # a fresh process would start without one
         ops.DropoutState.manual_seed(1234)
         model, hp = build_model(g, dropout=0.5)
         hp.update(engine=engine_kind, epochs=epochs, dataset='golden', log_file=str(tmp_path / (tag + '.log')),
@@ -295,6 +297,7 @@ def test_train_complete_resumes_exactly_from_its_epoch_checkpoint(tmp_path, engi
             from reviews4rec_amd.engine import DeepCoNNEngine, MFEngine
             assert isinstance(M.make_engine(hp, model), MFEngine if case == 'mf_dot' else DeepCoNNEngine)
         M.train_complete(hp, Model, Reader(), Reader(), {}, {}, model, review=case != 'mf_dot')
+        ops.DropoutState.device_counter = None
         return {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
 
     whole = run('whole', 4, ckpt=False)
