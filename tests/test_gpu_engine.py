@@ -270,8 +270,9 @@ def test_host_loop_with_native_engine_and_lookahead_matches_reference_metric():
                                               ('narre_e16', 'auto'), ('deepconnpp_e20', 'graph')])
 def test_train_complete_resumes_exactly_from_its_epoch_checkpoint(tmp_path, engine_kind, case):
     """main.train_complete with hyper_params['checkpoint_path']: a run stopped after epoch 2 and
-    started again lands on the very weights of an uninterrupted 4-epoch run -- Adam moments, step
-    counts and the dropout stream position travel with the checkpoint (dropout 0.5 here)."""
+    started again lands on the weights of an uninterrupted 4-epoch run -- Adam moments, step
+    counts and the dropout stream position travel with the checkpoint (dropout 0.5 here: a lost
+    stream position would show up as a gross difference, not a rounding one)."""
     import reviews4rec_amd
     from reviews4rec_amd import main as M, ops
     g = Golden(case)
@@ -307,7 +308,11 @@ def test_train_complete_resumes_exactly_from_its_epoch_checkpoint(tmp_path, engi
     assert 'Resuming after epoch 2' in log2 and 'end of epoch 3' in log2 and 'end of epoch 1' not in log2
     assert 'Resuming' not in open(tmp_path / 'whole.log').read()
     for k in whole:
-        assert torch.equal(whole[k], resumed[k]), k
+        if engine_kind == 'native':                      # the fused steps sum in a fixed order: bit-identical
+            assert torch.equal(whole[k], resumed[k]), k
+        else:                                            # the op-by-op path's dense ID-table gradient is an
+            torch.testing.assert_close(resumed[k], whole[k], rtol=1e-5, atol=1e-6,   # atomic scatter-add
+                                       msg=lambda m: k + ': ' + m)
 
 
 # ------------------------------------------------------------------------ MF_dot / bias_only native step
