@@ -320,6 +320,47 @@ int r4r_mf_step(const int64_t *uid, const int64_t *iid, const float *y,
                 float lr, double beta1, double beta2, float eps, float weight_decay, int64_t adam_step,
                 void *stream);
 
+/* ---- fused native step for NARRE (pytorch_models/NARRE.py:10-124)
+ * Replaces, per training step: the word gathers + TextCNN over the B*R review documents of each
+ * side, TextCNN's FC + dropout, both attention scorers + softmax (NARRE.py:53-64), the four
+ * ID-embedding gathers, the interaction, `final`, the bias head, MSELoss (loss.py:7-11),
+ * loss.backward() and torch.optim.Adam.step() (main.py:56-60,94-96) -- six launches.
+ *   user_reviews / item_reviews [B, R, T] token ids; reviewed_items / users_who_reviewed [B, R]
+ *   (R = narre_num_reviews = the neighbour count of data.py:274-279); uid / iid [B].
+ *   flat_p / flat_g / flat_m / flat_v : the DENSE parameters in the layout of r4r_narre_layout
+ *     (21 slots, 16-byte aligned): user_conv.convs.0.weight, .bias, user_conv.fc.weight, .bias,
+ *     item_conv.(same four), attention_scorer_user.0.weight, .0.bias, .3.weight, .3.bias,
+ *     attention_scorer_item.(same four), final.1.weight, .1.bias, .3.weight, .3.bias, global_bias.
+ *     flat_g == NULL: forward only.
+ *   rows_p / rows_m / rows_v : HOST arrays of 4 DEVICE pointers -- user_embedding.weight
+ *     [n_users, L], item_embedding.weight [n_items, L], user_bias [n_users], item_bias [n_items]
+ *     (n_users = total_users + 2, n_items = total_items + 2: NARRE.py:17-18,44-45).  Their dense
+ *     gradients are never materialised (compact rows + a tagged Adam sweep, as r4r_mf_step).
+ *   dropout: Philox4x32-10(seed, offset + b*(4RL+3L) + k), k = site-major: user_conv.dropout [R,L],
+ *     item_conv.dropout, attention_scorer_user.2, attention_scorer_item.2, dropout.user [L],
+ *     dropout.item, final.0.
+ *   token_buffer / tokens_ready / next_*_reviews / conv_algo: as r4r_deepconn_step.
+ *   ws: r4r_narre_ws_bytes, ZERO on first use (row tags, token flags, gradient-row padding). */
+int r4r_narre_nparam(void);
+int r4r_narre_layout(int E, int L, int64_t *offsets, int64_t *sizes, int64_t *total);
+size_t r4r_narre_ws_bytes(int64_t B, int R, int T, int E, int L, int64_t V, int64_t n_users, int64_t n_items);
+size_t r4r_narre_ws_offset(int64_t B, int R, int T, int E, int L, int64_t V, int64_t n_users, int64_t n_items,
+                           int which);   /* tests: 0 dropout multipliers, 1/2 compact rows user/item, 3/4 their ids, 5 d loss/d pred */
+int r4r_narre_step(const float *table, int64_t V,
+                   const int64_t *user_reviews, const int64_t *item_reviews,
+                   const int64_t *reviewed_items, const int64_t *users_who_reviewed,
+                   const int64_t *uid, const int64_t *iid, const float *y,
+                   float *flat_p, float *flat_g, float *flat_m, float *flat_v,
+                   const uint64_t *rows_p, const uint64_t *rows_m, const uint64_t *rows_v,
+                   int64_t n_users, int64_t n_items,
+                   float *pred, float *se, float *sse_accum, void *ws, size_t ws_bytes,
+                   int64_t B, int R, int T, int E, int L,
+                   float dropout_p, int training, uint64_t seed, uint64_t offset, float inv_denom,
+                   int conv_algo, int token_buffer, int tokens_ready,
+                   const int64_t *next_user_reviews, const int64_t *next_item_reviews,
+                   float lr, double beta1, double beta2, float eps, float weight_decay, int64_t adam_step,
+                   void *stream);
+
 /* proj_gather_max_kernel (gather-add-max over positions) */
 #define R4R_TIMING_SLOTS 8
 int r4r_timing_enable(int slot_mask);   /* bit i instruments slot i; 0 switches timing off */

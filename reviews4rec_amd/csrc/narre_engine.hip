@@ -1,0 +1,773 @@
+// Fused native training step for NARRE (pytorch_models/NARRE.py:10-124): per rating, R reviews
+// of W words on the user side and on the item side.  One C call = forward, loss (loss.py:7-11),
+// backward and the dense Adam update (main.py:56-60,94-96) in six launches:
+//
+//   1+2  token compaction (rides on the previous step when the loop announces the next batch),
+//        projection GEMM + gather-add-max over the 2 x B*R review documents (project.hip), or the
+//        direct gather-fused conv for small launches (textcnn.hip)
+//   3    narre_head_kernel   one workgroup per rating: pool finish, TextCNN's FC + dropout per
+//                            review, both attention scorers + softmax (NARRE.py:53-64), the ID
+//                            vectors, the interaction, `final`, the bias head, SE -- and the whole
+//                            backward of that down to d/d pooled, with the rating's contribution
+//                            to every head parameter gradient written as ONE row of a [B, NHP]
+//                            matrix and its ID-table gradient rows kept compact
+//   4    backward launch     argmax-sparse conv wgrad of both towers (wgrad_device.h), the column
+//                            sums of the [B, NHP] matrix in fixed order, next batch's token marks
+//   5    reduce launch       wgrad partials -> gradient, Adam on every dense parameter, next
+//                            batch's token compaction
+//   6    narre_rows_kernel   Adam sweep over the two ID tables and the two bias vectors: rows no
+//                            rating touched have gradient zero (never materialised), touched rows
+//                            sum their compact entries in ascending order (deterministic)
+//
+// The op-by-op path issues ~130 launches for the same step.
+#include <stdlib.h>
+
+#include "adam_device.h"
+#include "textcnn.h"
+#include "tokens_device.h"
+#include "wgrad_device.h"
+
+namespace r4r {
+
+constexpr int NF = 100;                // conv filters (common_pytorch_models.py:11)
+constexpr int NR_MAX_L = 32, NR_MAX_R = 32;
+
+// flat dense-parameter layout (21 slots); slots 0,1 / 4,5 are the conv weight + bias of the towers
+enum { NP_UCW = 0, NP_UCB, NP_UFW, NP_UFB, NP_ICW, NP_ICB, NP_IFW, NP_IFB,
+       NP_AUW0, NP_AUB0, NP_AUW3, NP_AUB3, NP_AIW0, NP_AIB0, NP_AIW3, NP_AIB3,
+       NP_F1W, NP_F1B, NP_F3W, NP_F3B, NP_GB, NP_COUNT };
+
+struct NLayout { int64_t off[NP_COUNT], size[NP_COUNT], total; };
+
+static NLayout narre_layout(int E, int L) {
+    NLayout lay;
+    const int64_t sz[NP_COUNT] = {(int64_t)NF * 3 * E, NF, (int64_t)L * NF, L, (int64_t)NF * 3 * E, NF, (int64_t)L * NF, L,
+                                  (int64_t)L * 2 * L, L, L, 1, (int64_t)L * 2 * L, L, L, 1,
+                                  (int64_t)L * L, L, L, 1, 1};
+    int64_t o = 0;
+    for (int i = 0; i < NP_COUNT; ++i) {
+        lay.off[i] = o;
+        lay.size[i] = sz[i];
+        o += (sz[i] + 3) & ~(int64_t)3;          // 16-byte aligned slots; pad floats stay 0 forever
+    }
+    lay.total = o;
+    return lay;
+}
+
+// Per-rating head-gradient row: the non-conv dense parameters in flat-layout order, i.e. flat
+// offsets [off[UFW], off[ICW]) followed by [off[IFW], total).  `hp_index` maps a flat offset of a
+// head parameter to its column.
+struct HeadCols { int64_t lo0, hi0, lo1, hi1; int n; };
+static HeadCols head_cols(const NLayout &lay) {
+    HeadCols h;
+    h.lo0 = lay.off[NP_UFW]; h.hi0 = lay.off[NP_ICW]; h.lo1 = lay.off[NP_IFW]; h.hi1 = lay.total;
+    h.n = (int)((h.hi0 - h.lo0) + (h.hi1 - h.lo1));
+    return h;
+}
+
+struct NarreHead {
+    const float *pmax[2]; const int *parg[2];       // conv partials [N, tiles, NP], N = B*R
+    const float *flat_p;                            // dense parameters (layout above)
+    int off[NP_COUNT];                              // flat offsets (fit int: < 2^31 floats)
+    int col0_lo, col0_n, col1_lo;                   // head-column mapping: off in [lo0, lo0+n0) -> off-lo0, else n0 + off - lo1
+    const float *emb[2], *bias[2];                  // user / item embedding tables [rows, L], bias vectors
+    const int64_t *self_id[2];                      // uid, iid [B]
+    const int64_t *other_id[2];                     // side 0 (user tower): reviewed_items [B,R] -> ITEM table
+                                                    // side 1 (item tower): users_who_reviewed [B,R] -> USER table
+    const float *y;
+    float *pooled[2]; int *argmax[2]; float *g_pooled[2];   // [N, 100]
+    float *part;                                    // [B, NHP]
+    float *grow[2]; int64_t *gid[2];                // compact rows / ids of table t: [B(1+R), L], [B(1+R)]
+    float *g;                                       // [B] d mean(SE) / d pred
+    int *tag[2];                                    // row tags of the user / item side
+    float *mult;                                    // [B, 4RL + 3L] dropout multipliers
+    float *pred, *se;
+    int64_t B;
+    int R, L, tiles, nhp, training, want_grad, now;
+    float p_drop, inv_denom;
+    uint64_t seed, offset;
+};
+
+__device__ __forceinline__ int head_col(const NarreHead &a, int flat_off) {
+    return flat_off < a.col0_lo + a.col0_n ? flat_off - a.col0_lo : a.col0_n + flat_off - a.col1_lo;
+}
+
+// One workgroup per rating.  Dynamic LDS, carved for the actual R and L.
+__global__ __launch_bounds__(256) void narre_head_kernel(NarreHead a) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int R = a.R, L = a.L, RL = R * L, L2 = 2 * L;
+    const int tid = threadIdx.x;
+    const int64_t b = blockIdx.x;
+    // ---- LDS carve
+    float *P = sm;                          // [2][R][100]   pooled conv features
+    float *fcw = P + 2 * R * NF;            // [2][L][101]
+    float *W0 = fcw + 2 * L * (NF + 1);     // [2][L][2L+1]
+    float *F1 = W0 + 2 * L * (L2 + 1);      // [L][L+1]
+    float *x = F1 + L * (L + 1);            // [2][R][L]     TextCNN outputs after dropout
+    float *xm = x + 2 * RL;                 // [2][R][L]     their dropout multipliers
+    float *o = xm + 2 * RL;                 // [2][R][L]     the other side's ID vectors
+    float *h = o + 2 * RL;                  // [2][R][L]     scorer hidden (after relu, before dropout)
+    float *hm = h + 2 * RL;                 // [2][R][L]     scorer dropout multipliers
+    float *dz = hm + 2 * RL;                // [2][R][L]     scratch: dhpre, then dz
+    float *sc = dz + 2 * RL;                // [2][R]        scores -> attention weights
+    float *da = sc + 2 * R;                 // [2][R]        d attention -> d score
+    float *sv = da + 2 * R;                 // small vectors, 12 x [2][L] slots below
+    float *fcb = sv, *b0 = sv + L2, *w3 = sv + 2 * L2, *ev = sv + 3 * L2, *evm = sv + 4 * L2, *v = sv + 5 * L2,
+          *dv = sv + 6 * L2, *cdv = sv + 7 * L2 /* cd [L], cm [L] */, *fv = sv + 8 * L2 /* f1b [L], F3 [L] */,
+          *fh = sv + 9 * L2 /* fh [L], dfpre [L] */, *misc = sv + 10 * L2;   // misc: b3[2], f3b, gb, ub, ib, g, dot[2]
+    const float *fp = a.flat_p;
+    const float keep = 1.f / (1.f - a.p_drop);
+    const bool drop = a.training && a.p_drop > 0.f;
+    const int ND = 4 * RL + 3 * L;                          // dropout draws per rating
+    auto draw = [&](int k) -> float {                       // multiplier of draw k of this rating
+        if (!drop) return 1.f;
+        const uint32_t r = philox_first_word(a.offset + (uint64_t)(b * ND + k), a.seed);
+        const float m = ((float)(r >> 8) * (1.0f / 16777216.0f) >= a.p_drop) ? keep : 0.f;
+        if (a.mult) a.mult[b * ND + k] = m;
+        return m;
+    };
+    if (!drop && a.mult) for (int k = tid; k < ND; k += 256) a.mult[b * ND + k] = 1.f;
+
+    // ---- S0: weights -> LDS, pool finish, ID vectors
+    for (int i = tid; i < 2 * L * NF; i += 256) {
+        const int s = i / (L * NF), r = i - s * L * NF;
+        fcw[(s * L + r / NF) * (NF + 1) + r % NF] = fp[a.off[s ? NP_IFW : NP_UFW] + r];
+    }
+    for (int i = tid; i < 2 * L * L2; i += 256) {
+        const int s = i / (L * L2), r = i - s * L * L2;
+        W0[(s * L + r / L2) * (L2 + 1) + r % L2] = fp[a.off[s ? NP_AIW0 : NP_AUW0] + r];
+    }
+    for (int i = tid; i < L * L; i += 256) F1[(i / L) * (L + 1) + i % L] = fp[a.off[NP_F1W] + i];
+    for (int i = tid; i < L2; i += 256) {
+        const int s = i / L, l = i - s * L;
+        fcb[i] = fp[a.off[s ? NP_IFB : NP_UFB] + l];
+        b0[i] = fp[a.off[s ? NP_AIB0 : NP_AUB0] + l];
+        w3[i] = fp[a.off[s ? NP_AIW3 : NP_AUW3] + l];
+        ev[i] = a.emb[s][a.self_id[s][b] * L + l];
+        evm[i] = draw(4 * RL + s * L + l);
+    }
+    for (int i = tid; i < L; i += 256) { fv[i] = fp[a.off[NP_F1B] + i]; fv[L + i] = fp[a.off[NP_F3W] + i]; }
+    if (tid == 0) {
+        misc[0] = fp[a.off[NP_AUB3]]; misc[1] = fp[a.off[NP_AIB3]]; misc[2] = fp[a.off[NP_F3B]]; misc[3] = fp[a.off[NP_GB]];
+        misc[4] = a.bias[0][a.self_id[0][b]]; misc[5] = a.bias[1][a.self_id[1][b]];
+    }
+    for (int i = tid; i < 2 * RL; i += 256) {               // other side's ID vectors: side s reads table 1-s
+        const int s = i / RL, r = (i - s * RL) / L, l = i % L;
+        o[i] = a.emb[1 - s][a.other_id[s][b * R + r] * L + l];
+    }
+    for (int i = tid; i < 2 * R * NF; i += 256) {           // pool finish: max over tiles, relu, first argmax
+        const int s = i / (R * NF), rr = (i - s * R * NF) / NF, f = i % NF;
+        const int64_t n = b * R + rr;
+        float best = -INFINITY;
+        int bp = -1;
+        for (int k = 0; k < a.tiles; ++k) {
+            const size_t q = ((size_t)n * a.tiles + k) * NP + f;
+            const float val = a.pmax[s][q];
+            if (val > best) { best = val; bp = a.parg[s][q]; }
+        }
+        if (!(best > 0.f)) { best = 0.f; bp = -1; }
+        P[i] = best;
+        a.pooled[s][n * NF + f] = best;
+        a.argmax[s][n * NF + f] = bp;
+    }
+    __syncthreads();
+    // ---- S1: TextCNN FC + dropout per review (common_pytorch_models.py:35-37)
+    for (int i = tid; i < 2 * RL; i += 256) {
+        const int s = i / RL, r = (i - s * RL) / L, l = i % L;
+        const float *pr = P + (s * R + r) * NF, *wr = fcw + (s * L + l) * (NF + 1);
+        float acc = 0.f;
+        for (int f = 0; f < NF; ++f) acc = fmaf(pr[f], wr[f], acc);
+        const float m = draw(s * RL + r * L + l);
+        xm[i] = m;
+        x[i] = (acc + fcb[s * L + l]) * m;
+    }
+    __syncthreads();
+    // ---- S2: scorer hidden layer on [x ; other] (NARRE.py:55-58)
+    for (int i = tid; i < 2 * RL; i += 256) {
+        const int s = i / RL, r = (i - s * RL) / L, k = i % L;
+        const float *wr = W0 + (s * L + k) * (L2 + 1), *xr = x + (s * R + r) * L, *orow = o + (s * R + r) * L;
+        float acc = 0.f;
+        for (int j = 0; j < L; ++j) acc = fmaf(xr[j], wr[j], acc);
+        for (int j = 0; j < L; ++j) acc = fmaf(orow[j], wr[L + j], acc);
+        acc += b0[s * L + k];
+        h[i] = acc > 0.f ? acc : 0.f;
+        hm[i] = draw(2 * RL + s * RL + r * L + k);
+    }
+    __syncthreads();
+    // ---- S3: scores
+    for (int i = tid; i < 2 * R; i += 256) {
+        const int s = i / R;
+        float acc = 0.f;
+        for (int k = 0; k < L; ++k) acc = fmaf(h[i * L + k] * hm[i * L + k], w3[s * L + k], acc);
+        sc[i] = acc + misc[s];
+    }
+    __syncthreads();
+    // ---- S4: softmax over the R reviews of a side (pads are not masked, like the reference)
+    if (tid < 2) {
+        float mx = -INFINITY, den = 0.f;
+        for (int r = 0; r < R; ++r) mx = fmaxf(mx, sc[tid * R + r]);
+        for (int r = 0; r < R; ++r) { const float e = expf(sc[tid * R + r] - mx); sc[tid * R + r] = e; den += e; }
+        for (int r = 0; r < R; ++r) sc[tid * R + r] /= den;
+    }
+    __syncthreads();
+    // ---- S5: attended review vector + the ID vector (NARRE.py:110-111)
+    for (int i = tid; i < L2; i += 256) {
+        const int s = i / L, l = i - s * L;
+        float acc = 0.f;
+        for (int r = 0; r < R; ++r) acc = fmaf(sc[s * R + r], x[(s * R + r) * L + l], acc);
+        v[i] = acc + ev[i] * evm[i];
+    }
+    __syncthreads();
+    // ---- S6: interaction + dropout (final.0)
+    for (int i = tid; i < L; i += 256) {
+        const float m = draw(4 * RL + 2 * L + i);
+        cdv[L + i] = m;
+        cdv[i] = v[i] * v[L + i] * m;
+    }
+    __syncthreads();
+    // ---- S7: final.1 + relu
+    for (int k = tid; k < L; k += 256) {
+        float acc = 0.f;
+        for (int l = 0; l < L; ++l) acc = fmaf(cdv[l], F1[k * (L + 1) + l], acc);
+        acc += fv[k];
+        fh[k] = acc > 0.f ? acc : 0.f;
+    }
+    __syncthreads();
+    // ---- S8: final.3, bias head, SE
+    if (tid == 0) {
+        float acc = 0.f;
+        for (int k = 0; k < L; ++k) acc = fmaf(fh[k], fv[L + k], acc);
+        const float rating = acc + misc[2];
+        const float pred = ((rating + misc[4]) + misc[5]) + misc[3];
+        a.pred[b] = pred;
+        float g = 0.f;
+        if (a.y) {
+            const float d = pred - a.y[b];
+            a.se[b] = d * d;
+            g = 2.f * d * a.inv_denom;
+        }
+        misc[6] = g;
+        if (a.want_grad) a.g[b] = g;
+    }
+    if (!a.want_grad) return;                               // uniform
+    __syncthreads();
+    const float g = misc[6];
+    float *prow = a.part + (size_t)b * a.nhp;
+    const int64_t nself = a.B;                              // entries [0, B): self rows, then B*R others
+    // ---- B1: final.3 / final.1 bias, d fpre
+    for (int k = tid; k < L; k += 256) {
+        prow[head_col(a, a.off[NP_F3W] + k)] = g * fh[k];
+        const float d = fh[k] > 0.f ? g * fv[L + k] : 0.f;
+        fh[L + k] = d;
+        prow[head_col(a, a.off[NP_F1B] + k)] = d;
+    }
+    if (tid == 0) {
+        prow[head_col(a, a.off[NP_F3B])] = g;
+        prow[head_col(a, a.off[NP_GB])] = g;
+        // ids + tags of the self rows: user table entry b <- uid, item table entry b <- iid
+        for (int s = 0; s < 2; ++s) {
+            const int64_t id = a.self_id[s][b];
+            a.gid[s][b] = id;
+            a.tag[s][id] = a.now;
+        }
+    }
+    for (int i = tid; i < 2 * R; i += 256) {                // others: side s's ids index table 1-s
+        const int s = i / R, r = i - s * R;
+        const int64_t id = a.other_id[s][b * R + r];
+        a.gid[1 - s][nself + b * R + r] = id;
+        a.tag[1 - s][id] = a.now;
+    }
+    __syncthreads();
+    // ---- B2: final.1 weight, d interaction -> d v
+    for (int i = tid; i < L * L; i += 256) prow[head_col(a, a.off[NP_F1W] + i)] = fh[L + i / L] * cdv[i % L];
+    for (int l = tid; l < L; l += 256) {
+        float acc = 0.f;
+        for (int k = 0; k < L; ++k) acc = fmaf(fh[L + k], F1[k * (L + 1) + l], acc);
+        const float dcat = acc * cdv[L + l];
+        dv[l] = dcat * v[L + l];
+        dv[L + l] = dcat * v[l];
+    }
+    __syncthreads();
+    // ---- B3: self ID rows (compact), d attention weights
+    for (int i = tid; i < L2; i += 256) {
+        const int s = i / L, l = i - s * L;
+        a.grow[s][(size_t)b * L + l] = dv[i] * evm[i];
+    }
+    for (int i = tid; i < 2 * R; i += 256) {
+        const int s = i / R;
+        float acc = 0.f;
+        for (int l = 0; l < L; ++l) acc = fmaf(dv[s * L + l], x[i * L + l], acc);
+        da[i] = acc;
+    }
+    __syncthreads();
+    // ---- B4: softmax backward
+    if (tid < 2) {
+        float dot = 0.f;
+        for (int r = 0; r < R; ++r) dot = fmaf(sc[tid * R + r], da[tid * R + r], dot);
+        misc[7 + tid] = dot;
+    }
+    __syncthreads();
+    for (int i = tid; i < 2 * R; i += 256) da[i] = sc[i] * (da[i] - misc[7 + i / R]);   // d score
+    __syncthreads();
+    // ---- B5: scorer output layer, d hidden
+    if (tid < 2) {
+        float acc = 0.f;
+        for (int r = 0; r < R; ++r) acc += da[tid * R + r];
+        prow[head_col(a, a.off[tid ? NP_AIB3 : NP_AUB3])] = acc;
+    }
+    for (int i = tid; i < L2; i += 256) {
+        const int s = i / L, k = i - s * L;
+        float acc = 0.f;
+        for (int r = 0; r < R; ++r) acc = fmaf(da[s * R + r], h[(s * R + r) * L + k] * hm[(s * R + r) * L + k], acc);
+        prow[head_col(a, a.off[s ? NP_AIW3 : NP_AUW3] + k)] = acc;
+    }
+    for (int i = tid; i < 2 * RL; i += 256) {
+        const int s = i / RL, r = (i - s * RL) / L, k = i % L;
+        dz[i] = h[i] > 0.f ? da[s * R + r] * w3[s * L + k] * hm[i] : 0.f;     // d hpre
+    }
+    __syncthreads();
+    // ---- B6: scorer hidden layer gradients, d x (-> d z), d other (compact rows)
+    for (int i = tid; i < L2; i += 256) {
+        const int s = i / L, k = i - s * L;
+        float acc = 0.f;
+        for (int r = 0; r < R; ++r) acc += dz[(s * R + r) * L + k];
+        prow[head_col(a, a.off[s ? NP_AIB0 : NP_AUB0] + k)] = acc;
+    }
+    for (int i = tid; i < 2 * L * L2; i += 256) {
+        const int s = i / (L * L2), k = (i - s * L * L2) / L2, j = i % L2;
+        float acc = 0.f;
+        for (int r = 0; r < R; ++r) {
+            const float c = j < L ? x[(s * R + r) * L + j] : o[(s * R + r) * L + j - L];
+            acc = fmaf(dz[(s * R + r) * L + k], c, acc);
+        }
+        prow[head_col(a, a.off[s ? NP_AIW0 : NP_AUW0] + k * L2 + j)] = acc;
+    }
+    float dzv[(2 * NR_MAX_R * NR_MAX_L + 255) / 256];        // d z of this thread's elements (kept over the barrier)
+#pragma unroll
+    for (int it = 0; it < (2 * NR_MAX_R * NR_MAX_L + 255) / 256; ++it) {
+        const int i = tid + 256 * it;
+        dzv[it] = 0.f;
+        if (i < 2 * RL) {
+            const int s = i / RL, r = (i - s * RL) / L, j = i % L;
+            float ax = sc[s * R + r] * dv[s * L + j], ao = 0.f;
+            for (int k = 0; k < L; ++k) {
+                const float d = dz[(s * R + r) * L + k];
+                ax = fmaf(d, W0[(s * L + k) * (L2 + 1) + j], ax);
+                ao = fmaf(d, W0[(s * L + k) * (L2 + 1) + L + j], ao);
+            }
+            dzv[it] = ax * xm[i];
+            a.grow[1 - s][(size_t)(nself + b * R + r) * L + j] = ao;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < (2 * NR_MAX_R * NR_MAX_L + 255) / 256; ++it) {
+        const int i = tid + 256 * it;
+        if (i < 2 * RL) dz[i] = dzv[it];
+    }
+    __syncthreads();
+    // ---- B7: TextCNN FC gradients, d pooled
+    for (int i = tid; i < L2; i += 256) {
+        const int s = i / L, l = i - s * L;
+        float acc = 0.f;
+        for (int r = 0; r < R; ++r) acc += dz[(s * R + r) * L + l];
+        prow[head_col(a, a.off[s ? NP_IFB : NP_UFB] + l)] = acc;
+    }
+    for (int i = tid; i < 2 * L * NF; i += 256) {
+        const int s = i / (L * NF), l = (i - s * L * NF) / NF, f = i % NF;
+        float acc = 0.f;
+        for (int r = 0; r < R; ++r) acc = fmaf(dz[(s * R + r) * L + l], P[(s * R + r) * NF + f], acc);
+        prow[head_col(a, a.off[s ? NP_IFW : NP_UFW] + l * NF + f)] = acc;
+    }
+    for (int i = tid; i < 2 * R * NF; i += 256) {
+        const int s = i / (R * NF), r = (i - s * R * NF) / NF, f = i % NF;
+        float acc = 0.f;
+        for (int l = 0; l < L; ++l) acc = fmaf(dz[(s * R + r) * L + l], fcw[(s * L + l) * (NF + 1) + f], acc);
+        a.g_pooled[s][(b * R + r) * NF + f] = acc;
+    }
+}
+
+static size_t narre_head_lds_bytes(int R, int L) {
+    const size_t fl = (size_t)2 * R * NF + 2 * L * (NF + 1) + 2 * L * (2 * L + 1) + L * (L + 1) + 6 * 2 * R * L + 2 * 2 * R +
+                      11 * 2 * L + 16;
+    return fl * 4;
+}
+
+// ---- 4: column sums of the [B, NHP] matrix (fixed order) -> flat gradient; + running SE
+struct ColSum {
+    const float *part, *se;
+    float *flat_g, *sse_accum;
+    int64_t B;
+    int nhp, col0_lo, col0_n, col1_lo;
+};
+constexpr int CS_ROWS = 16, CS_COLS = 16;
+__device__ __forceinline__ void colsum_block(const ColSum &c, int blk) {
+    __shared__ float red[CS_ROWS][CS_COLS];
+    const int ox = threadIdx.x & (CS_COLS - 1), rg = threadIdx.x / CS_COLS;
+    const int col = blk * CS_COLS + ox;                     // column nhp = the SE accumulator
+    float s = 0.f;
+    if (col < c.nhp) for (int64_t b = rg; b < c.B; b += CS_ROWS) s += c.part[(size_t)b * c.nhp + col];
+    else if (col == c.nhp) for (int64_t b = rg; b < c.B; b += CS_ROWS) s += c.se[b];
+    red[rg][ox] = s;
+    __syncthreads();
+    if (rg == 0 && col <= c.nhp) {
+        float t = 0.f;
+#pragma unroll
+        for (int r = 0; r < CS_ROWS; ++r) t += red[r][ox];
+        if (col == c.nhp) { if (c.sse_accum) c.sse_accum[0] += t; }
+        else c.flat_g[col < c.col0_n ? c.col0_lo + col : c.col1_lo + (col - c.col0_n)] = t;
+    }
+}
+
+__global__ __launch_bounds__(WG_THREADS) void narre_backward_kernel(WgradArgs w, ColSum c, int cs_blocks, TokenArgs nx) {
+    if (blockIdx.z < 2) {
+        wgrad_block(w, blockIdx.x, blockIdx.y, blockIdx.z);
+    } else if (blockIdx.z == 2) {
+        for (int blk = blockIdx.y * gridDim.x + blockIdx.x; blk < cs_blocks; blk += gridDim.x * gridDim.y) {
+            colsum_block(c, blk);
+            __syncthreads();
+        }
+    } else {
+        token_mark_block(nx, blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y, WG_THREADS);
+    }
+}
+
+// ---- 5: wgrad partial reduce + Adam on the dense parameters + next batch's compaction
+constexpr int NRED_THREADS = 256;
+struct DenseAdam {
+    float *p, *m, *v;
+    const float *g;
+    int64_t lo0, hi0, lo1, hi1;
+    AdamScalars s;
+    int on;
+};
+__global__ __launch_bounds__(NRED_THREADS) void narre_reduce_kernel(WgradArgs w, int red_blocks, int comp_blocks,
+                                                                    TokenArgs nx, DenseAdam opt) {
+    const int bx = blockIdx.x;
+    if (bx < red_blocks) {
+        wgrad_reduce_block(w, blockIdx.y, bx);
+        if (opt.on) {
+            const WgradTower &tw = w.t[blockIdx.y];
+            const int nw = w.F * 3 * w.E;
+            const int i = bx * NRED_THREADS + threadIdx.x;
+            const float *gp = i < nw ? tw.d_w + i : (i < nw + w.F ? tw.d_b + (i - nw) : nullptr);
+            if (gp) {
+                const int64_t o = gp - opt.g;
+                float P = opt.p[o], M = opt.m[o], V = opt.v[o];
+                adam_elem(P, *gp, M, V, opt.s);
+                opt.p[o] = P; opt.m[o] = M; opt.v[o] = V;
+            }
+        }
+    } else if (bx < red_blocks + comp_blocks) {
+        token_compact_block<NRED_THREADS / 64>(nx.t[blockIdx.y], nx.V, bx - red_blocks);
+    } else {
+        const int64_t base = blockIdx.y ? opt.lo1 : opt.lo0, end = blockIdx.y ? opt.hi1 : opt.hi0;
+        const int64_t o = base + (int64_t)(bx - red_blocks - comp_blocks) * NRED_THREADS + threadIdx.x;
+        if (o < end) {
+            float P = opt.p[o], M = opt.m[o], V = opt.v[o];
+            adam_elem(P, opt.g[o], M, V, opt.s);
+            opt.p[o] = P; opt.m[o] = M; opt.v[o] = V;
+        }
+    }
+}
+
+// ---- 6: Adam sweep over the ID tables and bias vectors (scalar kernel arguments only: an
+// argument array indexed by the workgroup's slot is copied to scratch by hipcc, mf_engine.hip)
+constexpr int NROW_CHUNK = 2048, NROW_THREADS = 256;
+struct RowSweep {
+    float *p0, *p1, *p2, *p3, *m0, *m1, *m2, *m3, *v0, *v1, *v2, *v3;   // user table, item table, user bias, item bias
+    int64_t n0, n1, n2, n3;
+    int cb1, cb2, cb3;
+    const int64_t *gid0, *gid1;        // entry ids of the user / item table
+    const float *grow0, *grow1;        // entry rows [entries, L]
+    const float *g;                    // [B]: bias entries are the first B table entries (the self rows)
+    const int *tag0, *tag1;
+    int64_t entries, B;
+    int L, now;
+    AdamScalars s;
+};
+__global__ __launch_bounds__(NROW_THREADS) void narre_rows_kernel(RowSweep w) {
+    const int bx = (int)blockIdx.x;
+    const int t = (bx >= w.cb1) + (bx >= w.cb2) + (bx >= w.cb3);
+    float *bp = w.p0, *bm = w.m0, *bv = w.v0;
+    int64_t numel = w.n0;
+    int cb = 0;
+    if (t == 1) { bp = w.p1; bm = w.m1; bv = w.v1; numel = w.n1; cb = w.cb1; }
+    else if (t == 2) { bp = w.p2; bm = w.m2; bv = w.v2; numel = w.n2; cb = w.cb2; }
+    else if (t == 3) { bp = w.p3; bm = w.m3; bv = w.v3; numel = w.n3; cb = w.cb3; }
+    const bool user_side = (t == 0 || t == 2), table = t < 2;
+    const int W = table ? w.L : 1;
+    const int *tag = user_side ? w.tag0 : w.tag1;
+    const int64_t *ids = user_side ? w.gid0 : w.gid1;
+    const float *rows = user_side ? w.grow0 : w.grow1;
+    const int64_t nent = table ? w.entries : w.B;
+    const int64_t start = (int64_t)(bx - cb) * NROW_CHUNK;
+    int64_t cnt = numel - start;
+    if (cnt > NROW_CHUNK) cnt = NROW_CHUNK;
+    // every element's loads are issued before its tag is looked at; (row, col) by 32-bit division
+    for (int64_t i = threadIdx.x; i < cnt; i += NROW_THREADS) {
+        const int64_t e = start + i;
+        float P = bp[e], M = bm[e], V = bv[e];
+        const int64_t row = e / W;
+        const int col = (int)(e - row * W);
+        float G = 0.f;
+        if (tag[row] == w.now)
+            for (int64_t k = 0; k < nent; ++k)              // ascending entry order: deterministic
+                if (ids[k] == row) G += table ? rows[k * w.L + col] : w.g[k];
+        adam_elem(P, G, M, V, w.s);
+        bp[e] = P; bm[e] = M; bv[e] = V;
+    }
+}
+
+struct NarreWs {
+    float *wp[2], *pmax[2]; int *parg[2];
+    int *flags[2][2], *slot[2][2], *list[2][2], *count[2][2]; float *ptab[2];
+    float *pooled[2]; int *argmax[2]; float *g_pooled[2];
+    float *part_w[2], *part_b[2];
+    int *tag[2];
+    float *part, *grow[2], *g, *mult; int64_t *gid[2];
+    size_t bytes;
+};
+
+static NarreWs narre_carve(void *ws, int64_t B, int R, int T, int E, int L, int64_t V, int64_t n_users, int64_t n_items) {
+    NarreWs w;
+    char *p = static_cast<char *>(ws);
+    size_t o = 0;
+    auto take = [&](size_t nbytes) { char *r = p ? p + o : nullptr; o += align256(nbytes); return r; };
+    const int64_t N = B * R;
+    const size_t tiles128 = (size_t)(T + 2 + 127) / 128;
+    const int ns = textcnn_wgrad_splits(N);
+    w.tag[0] = reinterpret_cast<int *>(take((size_t)n_users * 4));          // tags first: persistent, zeroed once
+    w.tag[1] = reinterpret_cast<int *>(take((size_t)n_items * 4));
+    for (int t = 0; t < 2; ++t)
+        for (int bf = 0; bf < 2; ++bf) {                                    // token state: persistent too
+            w.flags[bf][t] = reinterpret_cast<int *>(take((size_t)(V + 4) * 4));
+            w.count[bf][t] = reinterpret_cast<int *>(take(256));
+        }
+    for (int t = 0; t < 2; ++t) {
+        for (int bf = 0; bf < 2; ++bf) {
+            w.slot[bf][t] = reinterpret_cast<int *>(take((size_t)(V + 4) * 4));
+            w.list[bf][t] = reinterpret_cast<int *>(take((size_t)proj_row_capacity(N, T, V) * 4));
+        }
+        w.wp[t] = reinterpret_cast<float *>(take(textcnn_wp_floats(E) * 4));
+        w.pmax[t] = reinterpret_cast<float *>(take((size_t)N * tiles128 * NP * 4));
+        w.parg[t] = reinterpret_cast<int *>(take((size_t)N * tiles128 * NP * 4));
+        w.pooled[t] = reinterpret_cast<float *>(take((size_t)N * NF * 4));
+        w.argmax[t] = reinterpret_cast<int *>(take((size_t)N * NF * 4));
+        w.g_pooled[t] = reinterpret_cast<float *>(take((size_t)N * NF * 4));
+        w.part_w[t] = reinterpret_cast<float *>(take((size_t)ns * NF * 3 * E * 4));
+        w.part_b[t] = reinterpret_cast<float *>(take((size_t)ns * NF * 4));
+        w.ptab[t] = reinterpret_cast<float *>(take(proj_ptab_floats(N, T, V) * 4));
+        w.grow[t] = reinterpret_cast<float *>(take((size_t)B * (1 + R) * L * 4));
+        w.gid[t] = reinterpret_cast<int64_t *>(take((size_t)B * (1 + R) * 8));
+    }
+    const NLayout lay = narre_layout(E, L);
+    w.part = reinterpret_cast<float *>(take((size_t)B * head_cols(lay).n * 4));
+    w.g = reinterpret_cast<float *>(take((size_t)B * 4));
+    w.mult = reinterpret_cast<float *>(take((size_t)B * (4 * R * L + 3 * L) * 4));
+    w.bytes = o;
+    return w;
+}
+
+}  // namespace r4r
+
+using namespace r4r;
+
+extern "C" int r4r_narre_nparam(void) { return NP_COUNT; }
+
+extern "C" int r4r_narre_layout(int E, int L, int64_t *offsets, int64_t *sizes, int64_t *total) {
+    R4R_REQUIRE(offsets && sizes && total, "narre_layout: null pointer");
+    R4R_REQUIRE(E > 0 && L > 0, "narre_layout: bad sizes");
+    const NLayout lay = narre_layout(E, L);
+    for (int i = 0; i < NP_COUNT; ++i) { offsets[i] = lay.off[i]; sizes[i] = lay.size[i]; }
+    *total = lay.total;
+    return R4R_OK;
+}
+
+extern "C" size_t r4r_narre_ws_bytes(int64_t B, int R, int T, int E, int L, int64_t V, int64_t n_users, int64_t n_items) {
+    if (B < 0 || R <= 0 || T <= 0 || E <= 0 || L <= 0 || V <= 0 || n_users <= 0 || n_items <= 0) return 0;
+    return narre_carve(nullptr, B, R, T, E, L, V, n_users, n_items).bytes;
+}
+
+// which: 0 dropout multipliers [B, 4RL+3L]; 1 / 2 compact rows of the user / item table [B(1+R), L];
+// 3 / 4 their ids (int64); 5 d loss / d pred [B]
+extern "C" size_t r4r_narre_ws_offset(int64_t B, int R, int T, int E, int L, int64_t V, int64_t n_users, int64_t n_items,
+                                      int which) {
+    const NarreWs w = narre_carve(reinterpret_cast<void *>(256), B, R, T, E, L, V, n_users, n_items);
+    const char *q = which == 0 ? reinterpret_cast<char *>(w.mult) : which == 1 ? reinterpret_cast<char *>(w.grow[0])
+                  : which == 2 ? reinterpret_cast<char *>(w.grow[1]) : which == 3 ? reinterpret_cast<char *>(w.gid[0])
+                  : which == 4 ? reinterpret_cast<char *>(w.gid[1]) : reinterpret_cast<char *>(w.g);
+    return (size_t)(q - reinterpret_cast<char *>(256));
+}
+
+extern "C" int r4r_narre_step(const float *table, int64_t V,
+                              const int64_t *user_reviews, const int64_t *item_reviews,
+                              const int64_t *reviewed_items, const int64_t *users_who_reviewed,
+                              const int64_t *uid, const int64_t *iid, const float *y,
+                              float *flat_p, float *flat_g, float *flat_m, float *flat_v,
+                              const uint64_t *rows_p, const uint64_t *rows_m, const uint64_t *rows_v,
+                              int64_t n_users, int64_t n_items,
+                              float *pred, float *se, float *sse_accum, void *ws, size_t ws_bytes,
+                              int64_t B, int R, int T, int E, int L,
+                              float dropout_p, int training, uint64_t seed, uint64_t offset, float inv_denom,
+                              int conv_algo, int token_buffer, int tokens_ready,
+                              const int64_t *next_user_reviews, const int64_t *next_item_reviews,
+                              float lr, double beta1, double beta2, float eps, float weight_decay, int64_t adam_step,
+                              void *stream) {
+    R4R_REQUIRE(table && user_reviews && item_reviews && reviewed_items && users_who_reviewed && uid && iid && flat_p &&
+                rows_p && pred && ws, "narre_step: null pointer");
+    R4R_REQUIRE(V > 0 && B >= 0 && T > 0 && n_users > 0 && n_items > 0, "narre_step: bad sizes");
+    R4R_REQUIRE(R > 0 && R <= NR_MAX_R, "narre_step: narre_num_reviews %d outside 1..%d", R, NR_MAX_R);
+    R4R_REQUIRE(L > 0 && L <= NR_MAX_L, "narre_step: latent_size %d outside 1..%d", L, NR_MAX_L);
+    R4R_REQUIRE(E > 0 && E % 4 == 0, "narre_step: word_embed_size %d must be a positive multiple of 4", E);
+    const bool train_step = flat_g != nullptr;
+    R4R_REQUIRE(!train_step || (y && se && flat_m && flat_v && rows_m && rows_v && adam_step >= 1),
+                "narre_step: a training step needs ratings, se, gradient / moment buffers and adam_step >= 1");
+    R4R_REQUIRE(!y || se, "narre_step: se buffer required when y is given");
+    R4R_REQUIRE(!next_user_reviews == !next_item_reviews, "narre_step: next_user_reviews and next_item_reviews go together");
+    R4R_REQUIRE(!next_user_reviews || train_step, "narre_step: the next batch's tokens ride on the backward launches");
+    R4R_REQUIRE(token_buffer == 0 || token_buffer == 1, "narre_step: token_buffer must be 0 or 1");
+    R4R_REQUIRE(adam_step < (1ll << 31), "narre_step: step tag overflow");
+    R4R_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, "narre_step: dropout %f outside [0,1)", (double)dropout_p);
+    const int64_t N = B * R;
+    R4R_REQUIRE(N * (int64_t)((T + 2 + 127) / 128) < (1ll << 31), "narre_step: grid too large");
+    if (ws_bytes < r4r_narre_ws_bytes(B, R, T, E, L, V, n_users, n_items)) {
+        set_error("narre_step: workspace %zu < %zu bytes", ws_bytes, r4r_narre_ws_bytes(B, R, T, E, L, V, n_users, n_items));
+        return R4R_ERR_WORKSPACE;
+    }
+    if (B == 0) return R4R_OK;
+    hipStream_t st = as_stream(stream);
+    const NLayout lay = narre_layout(E, L);
+    R4R_REQUIRE(lay.total < (1ll << 31), "narre_step: dense parameter buffer too large");
+    const HeadCols hc = head_cols(lay);
+    const NarreWs w = narre_carve(ws, B, R, T, E, L, V, n_users, n_items);
+    const float *P[NP_COUNT];
+    float *G[NP_COUNT];
+    for (int i = 0; i < NP_COUNT; ++i) { P[i] = flat_p + lay.off[i]; G[i] = flat_g ? flat_g + lay.off[i] : nullptr; }
+
+    // 1+2: both towers' review documents, one grid
+    const int64_t *idx[2] = {user_reviews, item_reviews};
+    const int algo = textcnn_pick_algo(conv_algo, N, T, E, NF);
+    int tiles;
+    if (algo == R4R_CONV_PROJECT) {
+        ProjTower pt[2];
+        for (int t = 0; t < 2; ++t) {
+            pt[t].idx = idx[t];
+            pt[t].conv_w = P[t ? NP_ICW : NP_UCW]; pt[t].conv_b = P[t ? NP_ICB : NP_UCB];
+            pt[t].flags = w.flags[token_buffer][t]; pt[t].slot = w.slot[token_buffer][t];
+            pt[t].list = w.list[token_buffer][t]; pt[t].count = w.count[token_buffer][t];
+            pt[t].ptab = w.ptab[t]; pt[t].pmax = w.pmax[t]; pt[t].parg = w.parg[t];
+        }
+        if (!tokens_ready)
+            if (int rc = textcnn_proj_tokens_launch(V, pt, 2, N, T, /*zero_state=*/false, st)) return rc;
+        if (int rc = textcnn_proj_compute_launch(table, V, pt, 2, N, T, E, NF, st)) return rc;
+        tiles = proj_tiles(T);
+    } else {
+        FwdTower ft[2];
+        for (int t = 0; t < 2; ++t) {
+            ft[t].idx = idx[t];
+            ft[t].conv_w = P[t ? NP_ICW : NP_UCW]; ft[t].conv_b = P[t ? NP_ICB : NP_UCB];
+            ft[t].wp = w.wp[t]; ft[t].pmax = w.pmax[t]; ft[t].parg = w.parg[t];
+        }
+        if (int rc = textcnn_fwd_launch(table, ft, 2, N, T, E, NF, st)) return rc;
+        tiles = textcnn_tiles(T);
+    }
+
+    // 3: head
+    NarreHead h;
+    for (int t = 0; t < 2; ++t) {
+        h.pmax[t] = w.pmax[t]; h.parg[t] = w.parg[t];
+        h.pooled[t] = w.pooled[t]; h.argmax[t] = w.argmax[t]; h.g_pooled[t] = w.g_pooled[t];
+        h.emb[t] = reinterpret_cast<const float *>(rows_p[t]);
+        h.bias[t] = reinterpret_cast<const float *>(rows_p[2 + t]);
+        h.grow[t] = w.grow[t]; h.gid[t] = w.gid[t]; h.tag[t] = w.tag[t];
+        R4R_REQUIRE(h.emb[t] && h.bias[t], "narre_step: null table / bias pointer");
+    }
+    h.self_id[0] = uid; h.self_id[1] = iid;
+    h.other_id[0] = reviewed_items; h.other_id[1] = users_who_reviewed;
+    h.flat_p = flat_p;
+    for (int i = 0; i < NP_COUNT; ++i) h.off[i] = (int)lay.off[i];
+    h.col0_lo = (int)hc.lo0; h.col0_n = (int)(hc.hi0 - hc.lo0); h.col1_lo = (int)hc.lo1;
+    h.y = y; h.part = w.part; h.g = w.g; h.mult = w.mult; h.pred = pred; h.se = se;
+    h.B = B; h.R = R; h.L = L; h.tiles = tiles; h.nhp = hc.n; h.training = training; h.want_grad = train_step;
+    h.now = (int)adam_step; h.p_drop = dropout_p; h.inv_denom = inv_denom; h.seed = seed; h.offset = offset;
+    const size_t lds = narre_head_lds_bytes(R, L);
+    R4R_REQUIRE(lds <= 160 * 1024, "narre_step: R = %d, L = %d need %zu bytes of LDS", R, L, lds);
+    static size_t lds_set = 0;
+    if (lds > lds_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(narre_head_kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        lds_set = lds;
+    }
+    narre_head_kernel<<<(unsigned)B, 256, lds, st>>>(h);
+    if (!train_step) return check_launch("narre_step(forward)");
+
+    // 4: conv weight gradients + head-parameter column sums (+ next batch's token marks)
+    WgradTower wt[2];
+    WgradArgs wa;
+    for (int t = 0; t < 2; ++t) {
+        wt[t].idx = idx[t]; wt[t].g_pooled = w.g_pooled[t]; wt[t].argmax = w.argmax[t];
+        wt[t].part_w = w.part_w[t]; wt[t].part_b = w.part_b[t];
+        wt[t].d_w = G[t ? NP_ICW : NP_UCW]; wt[t].d_b = G[t ? NP_ICB : NP_UCB];
+    }
+    for (int k = 0; k < MAX_TOWERS; ++k) wa.t[k] = wt[k < 2 ? k : 0];
+    wa.table = table; wa.N = N; wa.T = T; wa.E = E; wa.F = NF;
+    wa.nsplit = textcnn_wgrad_splits(N);
+    wa.per_split = (int)cdiv(N, wa.nsplit);
+    ColSum cs;
+    cs.part = w.part; cs.se = se; cs.flat_g = flat_g; cs.sse_accum = sse_accum; cs.B = B; cs.nhp = hc.n;
+    cs.col0_lo = (int)hc.lo0; cs.col0_n = (int)(hc.hi0 - hc.lo0); cs.col1_lo = (int)hc.lo1;
+    const int cs_blocks = (hc.n + 1 + CS_COLS - 1) / CS_COLS;
+    const bool prefetch = next_user_reviews && algo == R4R_CONV_PROJECT;
+    TokenArgs nx{};
+    if (prefetch) {
+        ProjTower nt[2];
+        const int64_t *nidx[2] = {next_user_reviews, next_item_reviews};
+        const int ob = token_buffer ^ 1;
+        for (int t = 0; t < 2; ++t) {
+            nt[t] = ProjTower{};
+            nt[t].idx = nidx[t];
+            nt[t].flags = w.flags[ob][t]; nt[t].slot = w.slot[ob][t]; nt[t].list = w.list[ob][t]; nt[t].count = w.count[ob][t];
+        }
+        nx = make_token_args(V, nt, 2, N, T);
+    }
+    narre_backward_kernel<<<dim3(NF, wa.nsplit, prefetch ? 4 : 3), WG_THREADS, 0, st>>>(wa, cs, cs_blocks, nx);
+
+    // 5: wgrad reduce + Adam on the dense parameters (+ next batch's compaction)
+    const int red_blocks = (NF * 3 * E + NF + NRED_THREADS - 1) / NRED_THREADS;
+    const int comp_blocks = prefetch ? (int)cdiv((V + 3) / 4, NRED_THREADS) : 0;
+    DenseAdam opt;
+    opt.on = 1; opt.p = flat_p; opt.m = flat_m; opt.v = flat_v; opt.g = flat_g;
+    opt.lo0 = hc.lo0; opt.hi0 = hc.hi0; opt.lo1 = hc.lo1; opt.hi1 = hc.hi1;
+    opt.s = adam_make_scalars(lr, beta1, beta2, eps, weight_decay, adam_step, nullptr);
+    const int64_t longest = hc.hi0 - hc.lo0 > hc.hi1 - hc.lo1 ? hc.hi0 - hc.lo0 : hc.hi1 - hc.lo1;
+    const int opt_blocks = (int)cdiv(longest, NRED_THREADS);
+    narre_reduce_kernel<<<dim3(red_blocks + comp_blocks + opt_blocks, 2), NRED_THREADS, 0, st>>>(wa, red_blocks, comp_blocks,
+                                                                                                nx, opt);
+
+    // 6: ID tables + bias vectors
+    RowSweep rs;
+    float *rp[4], *rm[4], *rv[4];
+    for (int k = 0; k < 4; ++k) {
+        rp[k] = reinterpret_cast<float *>(rows_p[k]); rm[k] = reinterpret_cast<float *>(rows_m[k]);
+        rv[k] = reinterpret_cast<float *>(rows_v[k]);
+        R4R_REQUIRE(rp[k] && rm[k] && rv[k], "narre_step: row tensor %d: null parameter / moment pointer", k);
+    }
+    rs.p0 = rp[0]; rs.p1 = rp[1]; rs.p2 = rp[2]; rs.p3 = rp[3];
+    rs.m0 = rm[0]; rs.m1 = rm[1]; rs.m2 = rm[2]; rs.m3 = rm[3];
+    rs.v0 = rv[0]; rs.v1 = rv[1]; rs.v2 = rv[2]; rs.v3 = rv[3];
+    const int64_t numel[4] = {n_users * L, n_items * L, n_users, n_items};
+    int64_t begin[5], chunks = 0;
+    for (int k = 0; k < 4; ++k) { begin[k] = chunks; chunks += cdiv(numel[k], NROW_CHUNK); }
+    R4R_REQUIRE(chunks < (1ll << 31), "narre_step: too many chunks");
+    rs.n0 = numel[0]; rs.n1 = numel[1]; rs.n2 = numel[2]; rs.n3 = numel[3];
+    rs.cb1 = (int)begin[1]; rs.cb2 = (int)begin[2]; rs.cb3 = (int)begin[3];
+    rs.gid0 = w.gid[0]; rs.gid1 = w.gid[1]; rs.grow0 = w.grow[0]; rs.grow1 = w.grow[1]; rs.g = w.g;
+    rs.tag0 = w.tag[0]; rs.tag1 = w.tag[1]; rs.entries = B * (1 + R); rs.B = B; rs.L = L; rs.now = (int)adam_step;
+    rs.s = opt.s;
+    {
+        ScopedTiming tm(R4R_TIMING_ADAM, st);
+        narre_rows_kernel<<<(unsigned)chunks, NROW_THREADS, 0, st>>>(rs);
+    }
+    return check_launch("narre_step");
+}

@@ -447,3 +447,210 @@ class MFEngine:
         # row tags written by earlier steps of THIS process must not collide with resumed step numbers
         for ws in self.__dict__.get('_ws_cache', {}).values():
             ws.zero_()
+
+
+class NarreEngine:
+    """Native step for NARRE (csrc/narre_engine.hip, r4r_narre_step): TextCNN over the B*R review
+    documents of each side, both attention scorers, the ID vectors, `final`, the bias head, SE,
+    the backward and the dense Adam update in six launches (the op-by-op path needs ~130).
+    Dense parameters live in one flat buffer (the module's Parameters alias it), the ID tables
+    and bias vectors stay where they are and are updated by a tagged sweep that never builds
+    their dense gradient.  Same surface as DeepCoNNEngine; single process only."""
+
+    NAMES = ['user_conv.convs.0.weight', 'user_conv.convs.0.bias', 'user_conv.fc.weight', 'user_conv.fc.bias',
+             'item_conv.convs.0.weight', 'item_conv.convs.0.bias', 'item_conv.fc.weight', 'item_conv.fc.bias',
+             'attention_scorer_user.0.weight', 'attention_scorer_user.0.bias', 'attention_scorer_user.3.weight',
+             'attention_scorer_user.3.bias', 'attention_scorer_item.0.weight', 'attention_scorer_item.0.bias',
+             'attention_scorer_item.3.weight', 'attention_scorer_item.3.bias', 'final.1.weight', 'final.1.bias',
+             'final.3.weight', 'final.3.bias', 'global_bias']
+    ROW_NAMES = ['user_embedding.weight', 'item_embedding.weight', 'user_bias', 'item_bias']
+
+    def __init__(self, model, lr=0.002, weight_decay=1e-6, betas=(0.9, 0.999), eps=1e-8, seed=0x5EED5EED, rank=0,
+                 conv_algo=0):
+        hp = model.hyper_params
+        if hp['model_type'] != 'NARRE':
+            raise ValueError("NarreEngine implements model_type 'NARRE', got %r" % (hp['model_type'],))
+        self.model, self.hp = model, hp
+        self.conv_algo = int(conv_algo)
+        self.lr, self.wd, self.betas, self.eps = float(lr), float(weight_decay), tuple(betas), float(eps)
+        self.table = model.word2vec.weight
+        if not self.table.is_cuda:
+            raise RuntimeError('NarreEngine: move the model to a ROCm device first; the HIP path has no CPU fallback')
+        self.dev = self.table.device
+        self.V, self.E = self.table.shape
+        self.L = int(hp['latent_size'])
+        lib = _lib.lib()
+        n = lib.r4r_narre_nparam()
+        off, size, total = (ctypes.c_int64 * n)(), (ctypes.c_int64 * n)(), ctypes.c_int64()
+        _lib.check(lib.r4r_narre_layout(self.E, self.L, off, size, ctypes.byref(total)), 'r4r_narre_layout')
+        params = dict(model.named_parameters())
+        self.slots = [params[k] for k in self.NAMES]
+        self.offsets, self.sizes, self.total = list(off), list(size), int(total.value)
+        self.flat_p = torch.zeros(self.total, dtype=torch.float32, device=self.dev)
+        for p, o, s in zip(self.slots, self.offsets, self.sizes):
+            assert p.numel() == s, (tuple(p.shape), s)
+            view = self.flat_p[o:o + s].view(p.shape)
+            view.copy_(p.data)
+            p.data = view                       # the Parameter now aliases the flat buffer
+        self.flat_g = torch.zeros_like(self.flat_p)
+        self.flat_m = torch.zeros_like(self.flat_p)
+        self.flat_v = torch.zeros_like(self.flat_p)
+        self.rows = [params[k] for k in self.ROW_NAMES]
+        if not all(p.is_contiguous() and p.dtype == torch.float32 for p in self.rows):
+            raise RuntimeError('NarreEngine: fp32 contiguous ID tables / bias vectors only')
+        self.rows_m = [torch.zeros_like(p) for p in self.rows]
+        self.rows_v = [torch.zeros_like(p) for p in self.rows]
+        self.n_users, self.n_items = self.rows[2].numel(), self.rows[3].numel()
+        self.sse = torch.zeros(1, dtype=torch.float32, device=self.dev)
+        self.step_count = 0
+        self.seed = (int(seed) * 0x9E3779B97F4A7C15 + int(rank) * 0xD1B54A32D192ED03) & 0xFFFFFFFFFFFFFFFF
+        self.offset = 0
+        self._ws, self._ws_key, self._out = None, None, {}
+        self._prepared, self._last_buf = None, 1
+
+    @staticmethod
+    def _p4(tensors):
+        return (ctypes.c_uint64 * 4)(*[t.data_ptr() for t in tensors])
+
+    def _fields(self, data):
+        n = data[5].numel()
+        ur, ir = data[3], data[4]
+        R, T = ur.shape[-2], ur.shape[-1]
+        if tuple(ir.shape[-2:]) != (R, T):
+            raise RuntimeError('NarreEngine: user and item reviews must share [num_reviews, num_words]')
+        who, rev = data[1].reshape(n, -1), data[2].reshape(n, -1)
+        if who.shape[1] != R or rev.shape[1] != R:
+            raise RuntimeError('NarreEngine: %d neighbour ids for %d reviews (NARRE.py concatenates them)'
+                               % (who.shape[1], R))
+        f = [ur.reshape(n, R, T), ir.reshape(n, R, T), rev, who, data[5].reshape(-1), data[6].reshape(-1)]
+        if not all(t.is_cuda and t.dtype == torch.int64 for t in f):
+            raise RuntimeError('NarreEngine: batches must be int64 tensors on the ROCm device')
+        return [t.contiguous() for t in f], n, R, T
+
+    def _workspace(self, B, R, T):
+        key = (B, R, T)
+        if self._ws_key != key:
+            cache = self.__dict__.setdefault('_ws_cache', {})
+            nxt = cache.get(key)
+            if nxt is None:
+                nb = _lib.lib().r4r_narre_ws_bytes(B, R, T, self.E, self.L, self.V, self.n_users, self.n_items)
+                nxt = cache[key] = torch.zeros(max(nb, 256), dtype=torch.uint8, device=self.dev)
+            if self._ws is not None:                         # the row tags head the buffer: shared state
+                keep = 256 * (-(-self.n_users * 4 // 256) + -(-self.n_items * 4 // 256))
+                nxt[:keep].copy_(self._ws[:keep])
+            self._ws, self._ws_key = nxt, key
+            self._prepared = None                            # token state lived in the other workspace
+        return self._ws
+
+    def _launch(self, data, y, train_mode, inv_denom, adam_step, next_data=None):
+        f, n, R, T = self._fields(data)
+        if n not in self._out:
+            self._out[n] = (torch.empty(n, dtype=torch.float32, device=self.dev),
+                            torch.empty(n, dtype=torch.float32, device=self.dev))
+        pred, se = self._out[n]
+        ws = self._workspace(n, R, T)
+        nxt = None
+        if next_data is not None and adam_step:
+            nf, nn, nR, nT = self._fields(next_data)
+            if (nn, nR, nT) == (n, R, T):
+                nxt = nf
+        key = (f[0].data_ptr(), f[1].data_ptr(), n, R, T)
+        ready = 0
+        if self._prepared is not None and self._prepared[0] == key:
+            buf, ready = self._prepared[1], 1
+            self._prepared = None
+        else:
+            if self._prepared is not None:                   # a wrong guess: drop its token state
+                pb = self._prepared[1]
+                off = 256 * (-(-self.n_users * 4 // 256) + -(-self.n_items * 4 // 256))
+                vb = 256 * (-(-(self.V + 4) * 4 // 256))
+                for t in range(2):                           # the compaction counters of that buffer
+                    at = off + (t * 2 + pb) * (vb + 256) + vb
+                    ws[at:at + 4].zero_()
+                self._prepared = None
+                self._last_buf = pb ^ 1
+            buf = self._last_buf ^ 1
+        rc = _lib.lib().r4r_narre_step(
+            ptr(self.table), self.V, ptr(f[0]), ptr(f[1]), ptr(f[2]), ptr(f[3]), ptr(f[4]), ptr(f[5]), ptr(y),
+            ptr(self.flat_p), ptr(self.flat_g) if adam_step else None, ptr(self.flat_m) if adam_step else None,
+            ptr(self.flat_v) if adam_step else None, self._p4(self.rows),
+            self._p4(self.rows_m) if adam_step else None, self._p4(self.rows_v) if adam_step else None,
+            self.n_users, self.n_items, ptr(pred), ptr(se), ptr(self.sse) if adam_step else None,
+            ptr(ws), ws.numel(), n, R, T, self.E, self.L, float(self.hp['dropout']), int(train_mode), self.seed,
+            self.offset, float(inv_denom), self.conv_algo, buf, ready,
+            ptr(nxt[0]) if nxt else None, ptr(nxt[1]) if nxt else None,
+            self.lr, self.betas[0], self.betas[1], self.eps, self.wd, int(adam_step), _lib.current_stream())
+        _lib.check(rc, 'r4r_narre_step')
+        self._last_buf = buf
+        if nxt is not None:
+            self._prepared = ((nxt[0].data_ptr(), nxt[1].data_ptr(), n, R, T), buf ^ 1, nxt)
+        if train_mode and float(self.hp['dropout']) > 0.0:
+            self.offset += n * (4 * R * self.L + 3 * self.L)
+        return pred, se
+
+    @torch.no_grad()
+    def train_step(self, data, y, n_global=None, next_data=None):
+        n = data[5].numel()
+        y = y.reshape(-1).contiguous()
+        self.step_count += 1
+        _, se = self._launch(data, y, self.model.training, 1.0 / float(n_global if n_global is not None else n),
+                             self.step_count, next_data)
+        return se
+
+    @torch.no_grad()
+    def predict(self, data, y=None):
+        if y is not None:
+            y = y.reshape(-1).contiguous()
+        pred, se = self._launch(data, y, False, 1.0, 0)
+        shape = tuple(data[5].shape)
+        return pred.view(shape), (se.view(shape) if y is not None else None)
+
+    def _ws_view(self, data, which, cols, dtype=torch.float32):
+        f, n, R, T = self._fields(data)
+        off = _lib.lib().r4r_narre_ws_offset(n, R, T, self.E, self.L, self.V, self.n_users, self.n_items, which)
+        rows = n if which in (0, 5) else n * (1 + R)
+        item = 8 if dtype == torch.int64 else 4
+        return self._workspace(n, R, T)[off:off + rows * cols * item].view(dtype).view(rows, cols)
+
+    def dropout_multipliers(self, data):
+        """[B, 4RL + 3L] multipliers the last training step drew (site-major, include/r4r.h)."""
+        R = data[3].shape[-2]
+        return self._ws_view(data, 0, 4 * R * self.L + 3 * self.L).clone()
+
+    def grads(self, data):
+        """Gradients of the LAST training step by reference parameter name; the ID-table / bias
+        gradients are rebuilt from their compact rows (introspection for tests)."""
+        out = {k: self.flat_g[o:o + s].view(p.shape) for k, p, o, s in
+               zip(self.NAMES, self.slots, self.offsets, self.sizes)}
+        B = data[5].numel()
+        g = self._ws_view(data, 5, 1)[:, 0]
+        for t, name in enumerate(self.ROW_NAMES[:2]):
+            ids = self._ws_view(data, 3 + t, 1, torch.int64)[:, 0]
+            out[name] = torch.zeros_like(self.rows[t]).index_add_(0, ids, self._ws_view(data, 1 + t, self.L))
+            out[self.ROW_NAMES[2 + t]] = torch.zeros_like(self.rows[2 + t]).index_add_(0, ids[:B], g)
+        return out
+
+    def moments(self):
+        m = {k: self.flat_m[o:o + s].view(p.shape) for k, p, o, s in zip(self.NAMES, self.slots, self.offsets, self.sizes)}
+        v = {k: self.flat_v[o:o + s].view(p.shape) for k, p, o, s in zip(self.NAMES, self.slots, self.offsets, self.sizes)}
+        m.update(zip(self.ROW_NAMES, self.rows_m))
+        v.update(zip(self.ROW_NAMES, self.rows_v))
+        return m, v
+
+    def state_dict(self):
+        m, v = self.moments()
+        return {'exp_avg': {k: t.clone() for k, t in m.items()}, 'exp_avg_sq': {k: t.clone() for k, t in v.items()},
+                'step': self.step_count, 'dropout_offset': self.offset, 'lr': self.lr, 'weight_decay': self.wd,
+                'betas': self.betas, 'eps': self.eps}
+
+    def load_state_dict(self, sd):
+        m, v = self.moments()
+        for k in m:
+            m[k].copy_(sd['exp_avg'][k].to(self.dev))
+            v[k].copy_(sd['exp_avg_sq'][k].to(self.dev))
+        self.step_count, self.offset = int(sd['step']), int(sd['dropout_offset'])
+        self.lr, self.wd = float(sd['lr']), float(sd['weight_decay'])
+        self.betas, self.eps = tuple(sd['betas']), float(sd['eps'])
+        for ws in self.__dict__.get('_ws_cache', {}).values():
+            ws.zero_()
+        self._prepared = None

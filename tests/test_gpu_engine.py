@@ -388,3 +388,93 @@ def test_mf_engine_equals_module_path_with_duplicates_and_dropout():
     sd = model.state_dict()
     for k, v in P.items():
         torch.testing.assert_close(sd[k].cpu(), v, rtol=1e-5, atol=5e-6, msg=lambda m: k + ': ' + m)
+
+
+# --------------------------------------------------------------------------------- NARRE native step
+def test_narre_engine_eval_matches_reference_golden():
+    from reviews4rec_amd.engine import NarreEngine
+    g = Golden('narre_e16')
+    model, hp = build_model(g)
+    eng = NarreEngine(model.eval())
+    for k in (0, 1):
+        data, y = g.batch(k, DEV)
+        pred, se = eng.predict(data, y)
+        torch.testing.assert_close(pred.cpu(), g.arr('eval%d' % k), rtol=1e-5, atol=1e-5)
+    pred, _ = eng.predict(g.neg_batch(DEV))
+    torch.testing.assert_close(pred.cpu(), g.arr('neg_eval'), rtol=1e-5, atol=1e-5)
+
+
+def test_narre_engine_training_trajectory_matches_reference_golden():
+    """r4r_narre_step along the reference-generated 3-step trajectory: per-example SE, every
+    gradient of step 0 (ID tables / biases rebuilt from their compact rows), weights after 1 and
+    3 steps, Adam moments, the running SE."""
+    from test_oracle_golden import ill_conditioned
+    from reviews4rec_amd.engine import NarreEngine
+    g = Golden('narre_e16')
+    model, hp = build_model(g)
+    model.train()
+    eng = NarreEngine(model, lr=hp['lr'], weight_decay=hp['weight_decay'])
+    total = 0.0
+    for step in range(3):
+        data, y = g.batch(step % 2, DEV)
+        nxt = g.batch((step + 1) % 2, DEV)[0]                # shapes differ (ragged batch): the guess is declined
+        se = eng.train_step(data, y, next_data=nxt).clone()
+        torch.testing.assert_close(se.cpu(), g.arr('se%d' % step), rtol=1e-4, atol=1e-5)
+        total += float(g.arr('se%d' % step).sum())
+        if step == 0:
+            got, ref_g = eng.grads(data), g.group('g0')
+            assert set(got) == set(ref_g)
+            for k, v in ref_g.items():
+                torch.testing.assert_close(got[k].cpu(), v, rtol=1e-4, atol=1e-7, msg=lambda m: k + ': ' + m)
+        if step in (0, 2):
+            sd = model.state_dict()
+            for k, v in g.params('w%d' % (step + 1)).items():
+                if ill_conditioned(k):
+                    continue
+                torch.testing.assert_close(sd[k].cpu(), v, rtol=1e-5, atol=5e-6, msg=lambda m: k + ': ' + m)
+    m, v = eng.moments()
+    for k, ref in g.group('m3').items():
+        torch.testing.assert_close(m[k].cpu(), ref, rtol=1e-4, atol=1e-7, msg=lambda mm: k + ': ' + mm)
+    for k, ref in g.group('v3').items():
+        if not ill_conditioned(k):
+            torch.testing.assert_close(v[k].cpu(), ref, rtol=1e-4, atol=1e-10, msg=lambda mm: k + ': ' + mm)
+    torch.testing.assert_close(eng.sse.cpu()[0], torch.tensor(total), rtol=1e-5, atol=1e-4)
+
+
+def test_narre_engine_dropout_masks_injected_into_oracle():
+    """Dropout 0.5 on all seven sites: the multipliers the device drew, injected into the CPU
+    oracle, reproduce the step's SE and its updated weights."""
+    from reviews4rec_amd.engine import NarreEngine
+    g = Golden('narre_e16')
+    model, hp = build_model(g, dropout=0.5)
+    model.train()
+    eng = NarreEngine(model, lr=hp['lr'], weight_decay=hp['weight_decay'])
+    P = {k: v.clone() for k, v in g.params().items()}
+    state = oracle.AdamState()
+    L = hp['latent_size']
+    for step in range(2):
+        data, y = g.batch(0, DEV)
+        se = eng.train_step(data, y).cpu().clone()
+        B, R = data[5].numel(), data[3].shape[-2]
+        mult = eng.dropout_multipliers(data).cpu()
+        assert 0.3 < float((mult == 0).float().mean()) < 0.7
+        RL = R * L
+        masks = {'user_conv.dropout': mult[:, 0:RL].reshape(B * R, L),
+                 'item_conv.dropout': mult[:, RL:2 * RL].reshape(B * R, L),
+                 'attention_scorer_user.2': mult[:, 2 * RL:3 * RL].reshape(B, R, L),
+                 'attention_scorer_item.2': mult[:, 3 * RL:4 * RL].reshape(B, R, L),
+                 'dropout.user': mult[:, 4 * RL:4 * RL + L], 'dropout.item': mult[:, 4 * RL + L:4 * RL + 2 * L],
+                 'final.0': mult[:, 4 * RL + 2 * L:]}
+        cpu_data, cpu_y = g.batch(0)
+        sse, _ = oracle.train_step(P, cpu_data, cpu_y, dict(hp), state, masks=masks)
+        torch.testing.assert_close(se.sum(), torch.tensor(sse), rtol=1e-4, atol=1e-4)
+    sd = model.state_dict()
+    from test_oracle_golden import ill_conditioned
+    for k, v in P.items():
+        if not ill_conditioned(k):
+            # two Adam steps turn 1e-9-level gradient differences on near-zero gradients into
+            # 1e-5-level weight differences (lr * m / sqrt(v)): rounding-level agreement on all but a
+            # handful of elements, and nothing beyond a fraction of one lr-sized step anywhere
+            diff = (sd[k].cpu() - v).abs()
+            assert float((diff > 2e-5 + 1e-4 * v.abs()).float().mean()) < 2e-3, k
+            assert float(diff.max()) < 5e-4, k
