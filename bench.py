@@ -182,6 +182,10 @@ def main():
     if args.engine == 'native' and hp['model_type'] in ('MF_dot', 'bias_only') and world == 1 and B <= 1024:
         from reviews4rec_amd.engine import MFEngine
         engine = MFEngine(model, lr=hp['lr'], weight_decay=hp['weight_decay'], seed=4321, rank=rank)
+    if args.engine == 'native' and hp['model_type'] == 'NARRE' and world == 1:
+        from reviews4rec_amd.engine import NarreEngine
+        engine = NarreEngine(model, lr=hp['lr'], weight_decay=hp['weight_decay'], seed=4321, rank=rank,
+                             conv_algo={'auto': 0, 'direct': 1, 'project': 2}[args.conv_algo])
     if args.engine == 'native' and hp['model_type'] == 'deepconn':
         from reviews4rec_amd.engine import DeepCoNNEngine
         engine = DeepCoNNEngine(model, lr=hp['lr'], weight_decay=hp['weight_decay'], dp=dp, seed=4321, rank=rank,

@@ -471,13 +471,21 @@ __global__ __launch_bounds__(NRED_THREADS) void narre_reduce_kernel(WgradArgs w,
     }
 }
 
-// ---- 6: Adam sweep over the ID tables and bias vectors (scalar kernel arguments only: an
-// argument array indexed by the workgroup's slot is copied to scratch by hipcc, mf_engine.hip)
+// ---- 6: Adam over the ID tables and bias vectors, two kinds of workgroup in one launch
+//   sweep workgroups  stream every element; a row NO rating touched (tag != this step) gets the
+//                     gradient-zero update, a touched row is left alone
+//   entry waves       one wave per compact entry k.  It scans the entry ids once (64 lanes wide);
+//                     if k is the first entry of its row it sums that row's entries in ascending
+//                     order (deterministic) and applies the update to the table row (all
+//                     entries) and to the row's bias element (the self entries, the first B)
+// (scalar kernel arguments only: an argument array indexed by the workgroup's slot is copied to
+// scratch by hipcc, mf_engine.hip)
 constexpr int NROW_CHUNK = 2048, NROW_THREADS = 256;
+constexpr int NROW_MAX_ENTRIES = 4096;   // B (1 + R): an entry wave keeps every entry id in registers
 struct RowSweep {
     float *p0, *p1, *p2, *p3, *m0, *m1, *m2, *m3, *v0, *v1, *v2, *v3;   // user table, item table, user bias, item bias
     int64_t n0, n1, n2, n3;
-    int cb1, cb2, cb3;
+    int cb1, cb2, cb3, cb_entries;
     const int64_t *gid0, *gid1;        // entry ids of the user / item table
     const float *grow0, *grow1;        // entry rows [entries, L]
     const float *g;                    // [B]: bias entries are the first B table entries (the self rows)
@@ -488,6 +496,93 @@ struct RowSweep {
 };
 __global__ __launch_bounds__(NROW_THREADS) void narre_rows_kernel(RowSweep w) {
     const int bx = (int)blockIdx.x;
+    if (bx >= w.cb_entries) {
+        // ---- entry waves: 4 per workgroup, all of one table (user table's groups first)
+        __shared__ int sid[NROW_MAX_ENTRIES];
+        const int lane = threadIdx.x & 63;
+        const int groups = (int)((w.entries + 3) / 4);
+        int gi = bx - w.cb_entries;
+        const int t = gi >= groups;
+        if (t) gi -= groups;
+        const int64_t *ids = t ? w.gid1 : w.gid0;
+        const float *rows = t ? w.grow1 : w.grow0;
+        for (int64_t j = threadIdx.x; j < w.entries; j += NROW_THREADS) sid[j] = (int)ids[j];   // one round trip
+        __syncthreads();
+        const int64_t k = (int64_t)gi * 4 + (threadIdx.x >> 6);
+        if (k >= w.entries) return;                         // whole wave
+        const int row = sid[k];
+        const int L = w.L;
+        const int nch = (int)((w.entries + 63) / 64);
+        // phase 1: is k the first entry of its row?  (scan of the ids in LDS, 64 at a time)
+        bool first = true;
+        for (int c = 0; c < nch && first; ++c) {
+            const int j = c * 64 + lane;
+            const unsigned long long mask = __ballot(j < w.entries && sid[j] == row);
+            if (mask && (int64_t)c * 64 + (__ffsll((long long)mask) - 1) < k) first = false;
+            if (mask && (int64_t)c * 64 + 63 >= k) break;   // reached k's own chunk: nothing earlier matched
+        }
+        if (!first) return;                                 // an earlier entry owns this row (uniform)
+        // phase 2 (one wave per DISTINCT row): every lane adds up the rows of ITS hits, chunk by
+        // chunk in ascending order, then one fixed butterfly per column combines the 64 lanes -- a
+        // fixed order, so the result is deterministic (a butterfly per chunk made a row with
+        // hundreds of entries a 70 us chain of cross-lane permutes)
+        float rv[NR_MAX_L];
+#pragma unroll
+        for (int col = 0; col < NR_MAX_L; ++col) rv[col] = 0.f;
+        float gv = 0.f;
+        unsigned long long mine = 0;                        // bit c: entry c*64 + lane is a hit (nch <= 64)
+        for (int c = (int)(k / 64); c < nch; ++c) {         // (no hit before k's chunk: k is the first)
+            const int64_t j = (int64_t)c * 64 + lane;
+            if (j < w.entries && sid[j] == row) mine |= 1ull << c;
+        }
+        while (__ballot(mine != 0)) {                       // four of a lane's hits per round, their loads together
+            int cs[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                cs[u] = mine ? __ffsll((long long)mine) - 1 : -1;
+                if (mine) mine &= mine - 1;
+            }
+            float tmp[4][NR_MAX_L], tg[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int64_t j = (int64_t)(cs[u] < 0 ? 0 : cs[u]) * 64 + lane;
+#pragma unroll
+                for (int col = 0; col < NR_MAX_L; ++col)
+                    tmp[u][col] = (cs[u] >= 0 && col < L) ? rows[j * L + col] : 0.f;
+                tg[u] = (cs[u] >= 0 && j < w.B) ? w.g[j] : 0.f;         // only the self entries carry a bias gradient
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {                   // ascending entry order within the lane
+#pragma unroll
+                for (int col = 0; col < NR_MAX_L; ++col) rv[col] += tmp[u][col];
+                gv += tg[u];
+            }
+        }
+        float acc = 0.f;                                    // lane < L: column `lane` of the table row
+#pragma unroll
+        for (int col = 0; col < NR_MAX_L; ++col) {
+            if (col < L) {                                  // uniform
+                const float sum = wave_sum(rv[col]);
+                if (lane == col) acc = sum;
+            }
+        }
+        const float accb = wave_sum(gv);
+        if (lane < L) {
+            float *p = (t ? w.p1 : w.p0) + (int64_t)row * L + lane, *m = (t ? w.m1 : w.m0) + (int64_t)row * L + lane,
+                  *v = (t ? w.v1 : w.v0) + (int64_t)row * L + lane;
+            float P = *p, M = *m, V = *v;
+            adam_elem(P, acc, M, V, w.s);
+            *p = P; *m = M; *v = V;
+        }
+        if (lane == 0) {                                    // the row's bias element (gradient zero if no self entry)
+            float *p = (t ? w.p3 : w.p2) + row, *m = (t ? w.m3 : w.m2) + row, *v = (t ? w.v3 : w.v2) + row;
+            float P = *p, M = *m, V = *v;
+            adam_elem(P, accb, M, V, w.s);
+            *p = P; *m = M; *v = V;
+        }
+        return;
+    }
+    // ---- sweep workgroups
     const int t = (bx >= w.cb1) + (bx >= w.cb2) + (bx >= w.cb3);
     float *bp = w.p0, *bm = w.m0, *bv = w.v0;
     int64_t numel = w.n0;
@@ -495,27 +590,31 @@ __global__ __launch_bounds__(NROW_THREADS) void narre_rows_kernel(RowSweep w) {
     if (t == 1) { bp = w.p1; bm = w.m1; bv = w.v1; numel = w.n1; cb = w.cb1; }
     else if (t == 2) { bp = w.p2; bm = w.m2; bv = w.v2; numel = w.n2; cb = w.cb2; }
     else if (t == 3) { bp = w.p3; bm = w.m3; bv = w.v3; numel = w.n3; cb = w.cb3; }
-    const bool user_side = (t == 0 || t == 2), table = t < 2;
-    const int W = table ? w.L : 1;
-    const int *tag = user_side ? w.tag0 : w.tag1;
-    const int64_t *ids = user_side ? w.gid0 : w.gid1;
-    const float *rows = user_side ? w.grow0 : w.grow1;
-    const int64_t nent = table ? w.entries : w.B;
+    const unsigned W = t < 2 ? (unsigned)w.L : 1u;
+    const int *tag = (t == 0 || t == 2) ? w.tag0 : w.tag1;
     const int64_t start = (int64_t)(bx - cb) * NROW_CHUNK;
     int64_t cnt = numel - start;
     if (cnt > NROW_CHUNK) cnt = NROW_CHUNK;
-    // every element's loads are issued before its tag is looked at; (row, col) by 32-bit division
-    for (int64_t i = threadIdx.x; i < cnt; i += NROW_THREADS) {
-        const int64_t e = start + i;
-        float P = bp[e], M = bm[e], V = bv[e];
-        const int64_t row = e / W;
-        const int col = (int)(e - row * W);
-        float G = 0.f;
-        if (tag[row] == w.now)
-            for (int64_t k = 0; k < nent; ++k)              // ascending entry order: deterministic
-                if (ids[k] == row) G += table ? rows[k * w.L + col] : w.g[k];
-        adam_elem(P, G, M, V, w.s);
-        bp[e] = P; bm[e] = M; bv[e] = V;
+    const int64_t row0 = start / W;                         // one 64-bit division per workgroup
+    const unsigned col0 = (unsigned)(start - row0 * W);
+    constexpr int PER = NROW_CHUNK / NROW_THREADS;
+    float P[PER], M[PER], V[PER];
+    int T[PER];
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {                         // all loads of the thread before any use
+        const int64_t i = threadIdx.x + (int64_t)u * NROW_THREADS;
+        const int64_t ii = i < cnt ? i : 0;
+        const int64_t row = row0 + (col0 + (unsigned)ii) / W;
+        P[u] = bp[start + ii]; M[u] = bm[start + ii]; V[u] = bv[start + ii];
+        T[u] = tag[row];
+    }
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+        const int64_t i = threadIdx.x + (int64_t)u * NROW_THREADS;
+        if (i < cnt && T[u] != w.now) {
+            adam_elem(P[u], 0.f, M[u], V[u], w.s);
+            bp[start + i] = P[u]; bm[start + i] = M[u]; bv[start + i] = V[u];
+        }
     }
 }
 
@@ -628,6 +727,8 @@ extern "C" int r4r_narre_step(const float *table, int64_t V,
     R4R_REQUIRE(!next_user_reviews || train_step, "narre_step: the next batch's tokens ride on the backward launches");
     R4R_REQUIRE(token_buffer == 0 || token_buffer == 1, "narre_step: token_buffer must be 0 or 1");
     R4R_REQUIRE(adam_step < (1ll << 31), "narre_step: step tag overflow");
+    R4R_REQUIRE(!train_step || B * (1 + R) <= NROW_MAX_ENTRIES, "narre_step: %lld ID entries per table > %d (use the "
+                "module path for larger batches)", (long long)(B * (1 + R)), NROW_MAX_ENTRIES);
     R4R_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, "narre_step: dropout %f outside [0,1)", (double)dropout_p);
     const int64_t N = B * R;
     R4R_REQUIRE(N * (int64_t)((T + 2 + 127) / 128) < (1ll << 31), "narre_step: grid too large");
@@ -761,7 +862,8 @@ extern "C" int r4r_narre_step(const float *table, int64_t V,
     for (int k = 0; k < 4; ++k) { begin[k] = chunks; chunks += cdiv(numel[k], NROW_CHUNK); }
     R4R_REQUIRE(chunks < (1ll << 31), "narre_step: too many chunks");
     rs.n0 = numel[0]; rs.n1 = numel[1]; rs.n2 = numel[2]; rs.n3 = numel[3];
-    rs.cb1 = (int)begin[1]; rs.cb2 = (int)begin[2]; rs.cb3 = (int)begin[3];
+    rs.cb1 = (int)begin[1]; rs.cb2 = (int)begin[2]; rs.cb3 = (int)begin[3]; rs.cb_entries = (int)chunks;
+    chunks += 2 * cdiv(B * (1 + R), 4);                     // the entry waves, 4 per workgroup, per table
     rs.gid0 = w.gid[0]; rs.gid1 = w.gid[1]; rs.grow0 = w.grow[0]; rs.grow1 = w.grow[1]; rs.g = w.g;
     rs.tag0 = w.tag[0]; rs.tag1 = w.tag[1]; rs.entries = B * (1 + R); rs.B = B; rs.L = L; rs.now = (int)adam_step;
     rs.s = opt.s;

@@ -8,7 +8,7 @@ differences, both numerically neutral: the running sum of SE stays on the device
 is read once per epoch (the reference syncs with ``float(torch.sum(..))`` every
 batch, main.py:57), and ``optimizer`` is this package's fused Adam (same surface).
 ``hyper_params['engine']`` (default 'auto'): models with a fused native step (DeepCoNN 'deepconn',
-MF_dot, bias_only) run the whole sequence as one native call per batch; the others run the
+NARRE, MF_dot, bias_only) run the whole sequence as one native call per batch; the others run the
 op-by-op step captured once into a hipGraph and replayed ('module' forces plain eager).
 
 TransNet's three-optimiser step (main.py:35-53) raises on torch >= 1.5 in the
@@ -149,6 +149,12 @@ def make_engine(hyper_params, model, dp=None, rank=0):
         from .engine import MFEngine
         return MFEngine(model, lr=hyper_params['lr'], weight_decay=hyper_params['weight_decay'],
                         seed=hyper_params.get('seed', 0x5EED5EED), rank=rank)
+    if hyper_params['model_type'] == 'NARRE':
+        if dp is not None and dp.on:
+            return None                                   # DP: module path (dist.py C1 + C2)
+        from .engine import NarreEngine
+        return NarreEngine(model, lr=hyper_params['lr'], weight_decay=hyper_params['weight_decay'],
+                           seed=hyper_params.get('seed', 0x5EED5EED), rank=rank)
     if hyper_params['model_type'] != 'deepconn':
         return None
     from .engine import DeepCoNNEngine
