@@ -128,14 +128,58 @@ __global__ __launch_bounds__(256) void narre_head_kernel(NarreHead a) {
     };
     if (!drop && a.mult) for (int k = tid; k < ND; k += 256) a.mult[b * ND + k] = 1.f;
 
-    // ---- S0: weights -> LDS, pool finish, ID vectors
-    for (int i = tid; i < 2 * L * NF; i += 256) {
-        const int s = i / (L * NF), r = i - s * L * NF;
-        fcw[(s * L + r / NF) * (NF + 1) + r % NF] = fp[a.off[s ? NP_IFW : NP_UFW] + r];
+    // ---- S0: weights -> LDS, pool finish, ID vectors.  The three big reads -- the pooling
+    // partials, the FC matrices, the scorer matrices -- are issued into registers before anything
+    // waits (a load -> LDS-store loop is one memory round trip per iteration: 8 + 8 + 2 of them)
+    constexpr int PREG = (2 * NR_MAX_R * NF + 255) / 256, WREG = (2 * NR_MAX_L * NF + 255) / 256,
+                  AREG = (2 * NR_MAX_L * 2 * NR_MAX_L + 255) / 256;
+    float pv[PREG], wv[WREG], av[AREG];
+    int pa[PREG];
+    const bool one_tile = a.tiles == 1;
+#pragma unroll
+    for (int u = 0; u < PREG; ++u) {
+        pv[u] = 0.f; pa[u] = 0;
+        if (one_tile && 256 * u < 2 * R * NF) {             // uniform: rounds past the end cost nothing
+            const int i = min(tid + 256 * u, 2 * R * NF - 1);
+            const int s = i / (R * NF), rr = (i - s * R * NF) / NF, f = i % NF;
+            const size_t q = ((size_t)(b * R + rr) * a.tiles) * NP + f;
+            pv[u] = a.pmax[s][q];
+            pa[u] = a.parg[s][q];
+        }
     }
-    for (int i = tid; i < 2 * L * L2; i += 256) {
-        const int s = i / (L * L2), r = i - s * L * L2;
-        W0[(s * L + r / L2) * (L2 + 1) + r % L2] = fp[a.off[s ? NP_AIW0 : NP_AUW0] + r];
+#pragma unroll
+    for (int u = 0; u < WREG; ++u) {
+        wv[u] = 0.f;
+        if (256 * u < 2 * L * NF) {
+            const int i = min(tid + 256 * u, 2 * L * NF - 1);
+            const int s = i / (L * NF);
+            wv[u] = fp[a.off[s ? NP_IFW : NP_UFW] + i - s * L * NF];
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < AREG; ++u) {
+        av[u] = 0.f;
+        if (256 * u < 2 * L * L2) {
+            const int i = min(tid + 256 * u, 2 * L * L2 - 1);
+            const int s = i / (L * L2);
+            av[u] = fp[a.off[s ? NP_AIW0 : NP_AUW0] + i - s * L * L2];
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < WREG; ++u) {
+        const int i = tid + 256 * u;
+        if (i < 2 * L * NF) {
+            const int s = i / (L * NF), r = i - s * L * NF;
+            fcw[(s * L + r / NF) * (NF + 1) + r % NF] = wv[u];
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < AREG; ++u) {
+        const int i = tid + 256 * u;
+        if (i < 2 * L * L2) {
+            const int s = i / (L * L2), r = i - s * L * L2;
+            W0[(s * L + r / L2) * (L2 + 1) + r % L2] = av[u];
+        }
     }
     for (int i = tid; i < L * L; i += 256) F1[(i / L) * (L + 1) + i % L] = fp[a.off[NP_F1W] + i];
     for (int i = tid; i < L2; i += 256) {
@@ -155,20 +199,37 @@ __global__ __launch_bounds__(256) void narre_head_kernel(NarreHead a) {
         const int s = i / RL, r = (i - s * RL) / L, l = i % L;
         o[i] = a.emb[1 - s][a.other_id[s][b * R + r] * L + l];
     }
-    for (int i = tid; i < 2 * R * NF; i += 256) {           // pool finish: max over tiles, relu, first argmax
-        const int s = i / (R * NF), rr = (i - s * R * NF) / NF, f = i % NF;
-        const int64_t n = b * R + rr;
-        float best = -INFINITY;
-        int bp = -1;
-        for (int k = 0; k < a.tiles; ++k) {
-            const size_t q = ((size_t)n * a.tiles + k) * NP + f;
-            const float val = a.pmax[s][q];
-            if (val > best) { best = val; bp = a.parg[s][q]; }
+    if (one_tile) {                                         // pool finish of a one-tile document: relu + argmax
+#pragma unroll
+        for (int u = 0; u < PREG; ++u) {
+            const int i = tid + 256 * u;
+            if (i < 2 * R * NF) {
+                const int s = i / (R * NF), rr = (i - s * R * NF) / NF, f = i % NF;
+                const int64_t n = b * R + rr;
+                float best = pv[u];
+                int bp = pa[u];
+                if (!(best > 0.f)) { best = 0.f; bp = -1; }
+                P[i] = best;
+                a.pooled[s][n * NF + f] = best;
+                a.argmax[s][n * NF + f] = bp;
+            }
         }
-        if (!(best > 0.f)) { best = 0.f; bp = -1; }
-        P[i] = best;
-        a.pooled[s][n * NF + f] = best;
-        a.argmax[s][n * NF + f] = bp;
+    } else {
+        for (int i = tid; i < 2 * R * NF; i += 256) {       // pool finish: max over tiles, relu, first argmax
+            const int s = i / (R * NF), rr = (i - s * R * NF) / NF, f = i % NF;
+            const int64_t n = b * R + rr;
+            float best = -INFINITY;
+            int bp = -1;
+            for (int k = 0; k < a.tiles; ++k) {
+                const size_t q = ((size_t)n * a.tiles + k) * NP + f;
+                const float val = a.pmax[s][q];
+                if (val > best) { best = val; bp = a.parg[s][q]; }
+            }
+            if (!(best > 0.f)) { best = 0.f; bp = -1; }
+            P[i] = best;
+            a.pooled[s][n * NF + f] = best;
+            a.argmax[s][n * NF + f] = bp;
+        }
     }
     __syncthreads();
     // ---- S1: TextCNN FC + dropout per review (common_pytorch_models.py:35-37)
@@ -419,9 +480,11 @@ __device__ __forceinline__ void colsum_block(const ColSum &c, int blk) {
     }
 }
 
-__global__ __launch_bounds__(WG_THREADS) void narre_backward_kernel(WgradArgs w, ColSum c, int cs_blocks, TokenArgs nx) {
+__global__ __launch_bounds__(WG_THREADS) void narre_backward_kernel(WgradArgs w, ColSum c, int cs_blocks, TokenArgs nx,
+                                                                    int packed) {
     if (blockIdx.z < 2) {
-        wgrad_block(w, blockIdx.x, blockIdx.y, blockIdx.z);
+        if (packed) wgrad_block_packed(w, blockIdx.x, blockIdx.y, blockIdx.z);   // grid.x = ceil(F / 4)
+        else wgrad_block(w, blockIdx.x, blockIdx.y, blockIdx.z);
     } else if (blockIdx.z == 2) {
         for (int blk = blockIdx.y * gridDim.x + blockIdx.x; blk < cs_blocks; blk += gridDim.x * gridDim.y) {
             colsum_block(c, blk);
@@ -832,7 +895,9 @@ extern "C" int r4r_narre_step(const float *table, int64_t V,
         }
         nx = make_token_args(V, nt, 2, N, T);
     }
-    narre_backward_kernel<<<dim3(NF, wa.nsplit, prefetch ? 4 : 3), WG_THREADS, 0, st>>>(wa, cs, cs_blocks, nx);
+    const int packed = 3 * E / 4 <= 64;                     // narrow windows: one wave per filter
+    narre_backward_kernel<<<dim3(packed ? (NF + 3) / 4 : NF, wa.nsplit, prefetch ? 4 : 3), WG_THREADS, 0, st>>>(
+        wa, cs, cs_blocks, nx, packed);
 
     // 5: wgrad reduce + Adam on the dense parameters (+ next batch's compaction)
     const int red_blocks = (NF * 3 * E + NF + NRED_THREADS - 1) / NRED_THREADS;

@@ -81,6 +81,56 @@ __device__ __forceinline__ void wgrad_block(const WgradArgs &a, int f, int s, in
 }
 
 
+// Narrow windows (3E/4 <= 64 float4, i.e. E <= 85: the reference's default word_embed_size 64):
+// one WAVE per filter, four filters per workgroup -- `wgrad_block` would leave three waves of
+// four idle in its streaming phase.  Same per-(filter, split) summation order, so the same bits.
+// grid.x = ceil(F / 4) for this form.
+__device__ __forceinline__ void wgrad_block_packed(const WgradArgs &a, int fgroup, int s, int tower) {
+    __shared__ long p_off[4][WG_CHUNK][3];
+    __shared__ float p_g[4][WG_CHUNK];
+    const WgradTower &tw = a.t[tower];
+    const float *__restrict__ table = a.table;
+    const int64_t *__restrict__ idx = tw.idx;
+    const float *__restrict__ gp = tw.g_pooled;
+    const int *__restrict__ argmax = tw.argmax;
+    const int T = a.T, E = a.E, F = a.F;
+    const int64_t n0 = (int64_t)s * a.per_split;
+    const int64_t n1 = min(a.N, n0 + (int64_t)a.per_split);
+    const int nvec = 3 * E / 4;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int f = fgroup * 4 + wave;
+    const bool live = f < F;
+    wg_f32x4 acc = (wg_f32x4){0.f, 0.f, 0.f, 0.f};
+    const int vj = (lane * 4) / E, ve = lane * 4 - vj * E;
+    float sb = 0.f;
+    for (int64_t c0 = n0; c0 < n1; c0 += WG_CHUNK) {
+        const int nd = (int)min((int64_t)WG_CHUNK, n1 - c0);
+        __syncthreads();
+        if (live && lane < nd * 3) {
+            const int d = lane / 3, j = lane - d * 3;
+            const int64_t n = c0 + d;
+            const int p = argmax[n * F + f];
+            const int t = p - 2 + j;
+            long off = -1;
+            if (p >= 0 && t >= 0 && t < T) off = (long)idx[n * T + t] * E;
+            p_off[wave][d][j] = off;
+            if (j == 0) p_g[wave][d] = (p >= 0) ? gp[n * F + f] : 0.f;
+        }
+        __syncthreads();
+        if (live && lane < nvec) {
+#pragma unroll 4
+            for (int d = 0; d < nd; ++d) {
+                const long off = p_off[wave][d][vj];
+                if (off >= 0) acc += p_g[wave][d] * *reinterpret_cast<const wg_f32x4 *>(table + off + ve);
+            }
+        }
+        if (live && lane == 0)
+            for (int d = 0; d < nd; ++d) sb += p_g[wave][d];
+    }
+    if (live && lane < nvec) *reinterpret_cast<wg_f32x4 *>(tw.part_w + ((size_t)s * F + f) * 3 * E + lane * 4) = acc;
+    if (live && lane == 0) tw.part_b[(size_t)s * F + f] = sb;
+}
+
 // Second stage: element i of tower `tw`'s [F*3E weight | F bias] gradient = sum of the nsplit
 // partials in a fixed order (deterministic).
 __device__ __forceinline__ void wgrad_reduce_block(const WgradArgs &a, int tower, int blk) {
