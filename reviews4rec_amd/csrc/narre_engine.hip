@@ -30,7 +30,7 @@
 namespace r4r {
 
 constexpr int NF = 100;                // conv filters (common_pytorch_models.py:11)
-constexpr int NR_MAX_L = 32, NR_MAX_R = 32;
+constexpr int NR_MAX_L = 32, NR_MAX_R = 32;        // hard limits; the kernels are instantiated for <= 16 and <= 32
 
 // flat dense-parameter layout (21 slots); slots 0,1 / 4,5 are the conv weight + bias of the towers
 enum { NP_UCW = 0, NP_UCB, NP_UFW, NP_UFB, NP_ICW, NP_ICB, NP_IFW, NP_IFB,
@@ -93,6 +93,9 @@ __device__ __forceinline__ int head_col(const NarreHead &a, int flat_off) {
 }
 
 // One workgroup per rating.  Dynamic LDS, carved for the actual R and L.
+// MR / ML: compile-time caps of R / L (register arrays and unrolled loops are sized by them:
+// the <= 16 instantiation is 10 % faster on the default shape than the <= 32 one)
+template <int MR, int ML>
 __global__ __launch_bounds__(256) void narre_head_kernel(NarreHead a) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int R = a.R, L = a.L, RL = R * L, L2 = 2 * L;
@@ -116,6 +119,11 @@ __global__ __launch_bounds__(256) void narre_head_kernel(NarreHead a) {
           *dv = sv + 6 * L2, *cdv = sv + 7 * L2 /* cd [L], cm [L] */, *fv = sv + 8 * L2 /* f1b [L], F3 [L] */,
           *fh = sv + 9 * L2 /* fh [L], dfpre [L] */, *misc = sv + 10 * L2;   // misc: b3[2], f3b, gb, ub, ib, g, dot[2]
     const float *fp = a.flat_p;
+    // Index decompositions without integer division by a runtime value (~40 instructions each, and
+    // the kernel does hundreds per thread): a side is a compare (there are two), NF is a compile-time
+    // constant, and x / d for x <= 6400 is exact as (int)((x + 0.5f) * (1.f / d)).
+    const float invL = 1.f / (float)L, invL2 = 1.f / (float)L2;
+    auto qd = [](int x, float inv) { return (int)(((float)x + 0.5f) * inv); };
     const float keep = 1.f / (1.f - a.p_drop);
     const bool drop = a.training && a.p_drop > 0.f;
     const int ND = 4 * RL + 3 * L;                          // dropout draws per rating
@@ -131,8 +139,8 @@ __global__ __launch_bounds__(256) void narre_head_kernel(NarreHead a) {
     // ---- S0: weights -> LDS, pool finish, ID vectors.  The three big reads -- the pooling
     // partials, the FC matrices, the scorer matrices -- are issued into registers before anything
     // waits (a load -> LDS-store loop is one memory round trip per iteration: 8 + 8 + 2 of them)
-    constexpr int PREG = (2 * NR_MAX_R * NF + 255) / 256, WREG = (2 * NR_MAX_L * NF + 255) / 256,
-                  AREG = (2 * NR_MAX_L * 2 * NR_MAX_L + 255) / 256;
+    constexpr int PREG = (2 * MR * NF + 255) / 256, WREG = (2 * ML * NF + 255) / 256,
+                  AREG = (2 * ML * 2 * ML + 255) / 256;
     float pv[PREG], wv[WREG], av[AREG];
     int pa[PREG];
     const bool one_tile = a.tiles == 1;
@@ -141,7 +149,7 @@ __global__ __launch_bounds__(256) void narre_head_kernel(NarreHead a) {
         pv[u] = 0.f; pa[u] = 0;
         if (one_tile && 256 * u < 2 * R * NF) {             // uniform: rounds past the end cost nothing
             const int i = min(tid + 256 * u, 2 * R * NF - 1);
-            const int s = i / (R * NF), rr = (i - s * R * NF) / NF, f = i % NF;
+            const int s = i >= R * NF, rem = i - s * R * NF, rr = rem / NF, f = rem - rr * NF;
             const size_t q = ((size_t)(b * R + rr) * a.tiles) * NP + f;
             pv[u] = a.pmax[s][q];
             pa[u] = a.parg[s][q];
@@ -152,7 +160,7 @@ __global__ __launch_bounds__(256) void narre_head_kernel(NarreHead a) {
         wv[u] = 0.f;
         if (256 * u < 2 * L * NF) {
             const int i = min(tid + 256 * u, 2 * L * NF - 1);
-            const int s = i / (L * NF);
+            const int s = i >= L * NF;
             wv[u] = fp[a.off[s ? NP_IFW : NP_UFW] + i - s * L * NF];
         }
     }
@@ -161,50 +169,82 @@ __global__ __launch_bounds__(256) void narre_head_kernel(NarreHead a) {
         av[u] = 0.f;
         if (256 * u < 2 * L * L2) {
             const int i = min(tid + 256 * u, 2 * L * L2 - 1);
-            const int s = i / (L * L2);
+            const int s = i >= L * L2;
             av[u] = fp[a.off[s ? NP_AIW0 : NP_AUW0] + i - s * L * L2];
         }
     }
+    // the small reads ride in the same round trip; the ID vectors need their ids first (round 2)
+    constexpr int FREG = (ML * ML + 255) / 256, OREG = (2 * MR * ML + 255) / 256;
+    float f1v[FREG], ov[OREG];
+    int64_t oid[OREG];
+#pragma unroll
+    for (int u = 0; u < FREG; ++u) f1v[u] = (256 * u < L * L) ? fp[a.off[NP_F1W] + min(tid + 256 * u, L * L - 1)] : 0.f;
+#pragma unroll
+    for (int u = 0; u < OREG; ++u) {
+        oid[u] = 0;
+        if (256 * u < 2 * RL) {
+            const int i = min(tid + 256 * u, 2 * RL - 1);
+            const int s = i >= RL, rem = i - s * RL, r = qd(rem, invL);
+            oid[u] = a.other_id[s][b * R + r];
+        }
+    }
+    const int ti = min(tid, L2 - 1), ts = ti >= L, tl = ti - ts * L;          // this thread's (side, l) for the [2][L] vectors
+    const float fcb_r = fp[a.off[ts ? NP_IFB : NP_UFB] + tl], b0_r = fp[a.off[ts ? NP_AIB0 : NP_AUB0] + tl],
+                w3_r = fp[a.off[ts ? NP_AIW3 : NP_AUW3] + tl];
+    const int64_t sid_r = a.self_id[ts][b];
+    const float f1b_r = fp[a.off[NP_F1B] + min(tid, L - 1)], f3w_r = fp[a.off[NP_F3W] + min(tid, L - 1)];
+    const float m0 = fp[a.off[NP_AUB3]], m1 = fp[a.off[NP_AIB3]], m2 = fp[a.off[NP_F3B]], m3 = fp[a.off[NP_GB]];
+    const int64_t sid0 = a.self_id[0][b], sid1 = a.self_id[1][b];
+    // round 2: the reads that depend on ids
+#pragma unroll
+    for (int u = 0; u < OREG; ++u) {
+        ov[u] = 0.f;
+        if (256 * u < 2 * RL) {
+            const int i = min(tid + 256 * u, 2 * RL - 1);
+            const int s = i >= RL, rem = i - s * RL, r = qd(rem, invL), l = rem - r * L;
+            ov[u] = a.emb[1 - s][oid[u] * L + l];
+        }
+    }
+    const float ev_r = a.emb[ts][sid_r * L + tl];
+    const float ub_r = a.bias[0][sid0], ib_r = a.bias[1][sid1];
 #pragma unroll
     for (int u = 0; u < WREG; ++u) {
         const int i = tid + 256 * u;
         if (i < 2 * L * NF) {
-            const int s = i / (L * NF), r = i - s * L * NF;
-            fcw[(s * L + r / NF) * (NF + 1) + r % NF] = wv[u];
+            const int s = i >= L * NF, r = i - s * L * NF, l = r / NF;
+            fcw[(s * L + l) * (NF + 1) + r - l * NF] = wv[u];
         }
     }
 #pragma unroll
     for (int u = 0; u < AREG; ++u) {
         const int i = tid + 256 * u;
         if (i < 2 * L * L2) {
-            const int s = i / (L * L2), r = i - s * L * L2;
-            W0[(s * L + r / L2) * (L2 + 1) + r % L2] = av[u];
+            const int s = i >= L * L2, r = i - s * L * L2, k = qd(r, invL2);
+            W0[(s * L + k) * (L2 + 1) + r - k * L2] = av[u];
         }
     }
-    for (int i = tid; i < L * L; i += 256) F1[(i / L) * (L + 1) + i % L] = fp[a.off[NP_F1W] + i];
-    for (int i = tid; i < L2; i += 256) {
-        const int s = i / L, l = i - s * L;
-        fcb[i] = fp[a.off[s ? NP_IFB : NP_UFB] + l];
-        b0[i] = fp[a.off[s ? NP_AIB0 : NP_AUB0] + l];
-        w3[i] = fp[a.off[s ? NP_AIW3 : NP_AUW3] + l];
-        ev[i] = a.emb[s][a.self_id[s][b] * L + l];
-        evm[i] = draw(4 * RL + s * L + l);
+#pragma unroll
+    for (int u = 0; u < FREG; ++u) {
+        const int i = tid + 256 * u;
+        if (i < L * L) { const int k = qd(i, invL); F1[k * (L + 1) + i - k * L] = f1v[u]; }
     }
-    for (int i = tid; i < L; i += 256) { fv[i] = fp[a.off[NP_F1B] + i]; fv[L + i] = fp[a.off[NP_F3W] + i]; }
-    if (tid == 0) {
-        misc[0] = fp[a.off[NP_AUB3]]; misc[1] = fp[a.off[NP_AIB3]]; misc[2] = fp[a.off[NP_F3B]]; misc[3] = fp[a.off[NP_GB]];
-        misc[4] = a.bias[0][a.self_id[0][b]]; misc[5] = a.bias[1][a.self_id[1][b]];
+    if (tid < L2) {
+        fcb[tid] = fcb_r; b0[tid] = b0_r; w3[tid] = w3_r; ev[tid] = ev_r;
+        evm[tid] = draw(4 * RL + ts * L + tl);
     }
-    for (int i = tid; i < 2 * RL; i += 256) {               // other side's ID vectors: side s reads table 1-s
-        const int s = i / RL, r = (i - s * RL) / L, l = i % L;
-        o[i] = a.emb[1 - s][a.other_id[s][b * R + r] * L + l];
+    if (tid < L) { fv[tid] = f1b_r; fv[L + tid] = f3w_r; }
+    if (tid == 0) { misc[0] = m0; misc[1] = m1; misc[2] = m2; misc[3] = m3; misc[4] = ub_r; misc[5] = ib_r; }
+#pragma unroll
+    for (int u = 0; u < OREG; ++u) {                        // other side's ID vectors: side s reads table 1-s
+        const int i = tid + 256 * u;
+        if (i < 2 * RL) o[i] = ov[u];
     }
     if (one_tile) {                                         // pool finish of a one-tile document: relu + argmax
 #pragma unroll
         for (int u = 0; u < PREG; ++u) {
             const int i = tid + 256 * u;
             if (i < 2 * R * NF) {
-                const int s = i / (R * NF), rr = (i - s * R * NF) / NF, f = i % NF;
+                const int s = i >= R * NF, rem = i - s * R * NF, rr = rem / NF, f = rem - rr * NF;
                 const int64_t n = b * R + rr;
                 float best = pv[u];
                 int bp = pa[u];
@@ -216,7 +256,7 @@ __global__ __launch_bounds__(256) void narre_head_kernel(NarreHead a) {
         }
     } else {
         for (int i = tid; i < 2 * R * NF; i += 256) {       // pool finish: max over tiles, relu, first argmax
-            const int s = i / (R * NF), rr = (i - s * R * NF) / NF, f = i % NF;
+            const int s = i >= R * NF, rem = i - s * R * NF, rr = rem / NF, f = rem - rr * NF;
             const int64_t n = b * R + rr;
             float best = -INFINITY;
             int bp = -1;
@@ -234,7 +274,7 @@ __global__ __launch_bounds__(256) void narre_head_kernel(NarreHead a) {
     __syncthreads();
     // ---- S1: TextCNN FC + dropout per review (common_pytorch_models.py:35-37)
     for (int i = tid; i < 2 * RL; i += 256) {
-        const int s = i / RL, r = (i - s * RL) / L, l = i % L;
+        const int s = i >= RL, rem = i - s * RL, r = qd(rem, invL), l = rem - r * L;
         const float *pr = P + (s * R + r) * NF, *wr = fcw + (s * L + l) * (NF + 1);
         float acc = 0.f;
         for (int f = 0; f < NF; ++f) acc = fmaf(pr[f], wr[f], acc);
@@ -245,7 +285,7 @@ __global__ __launch_bounds__(256) void narre_head_kernel(NarreHead a) {
     __syncthreads();
     // ---- S2: scorer hidden layer on [x ; other] (NARRE.py:55-58)
     for (int i = tid; i < 2 * RL; i += 256) {
-        const int s = i / RL, r = (i - s * RL) / L, k = i % L;
+        const int s = i >= RL, rem = i - s * RL, r = qd(rem, invL), k = rem - r * L;
         const float *wr = W0 + (s * L + k) * (L2 + 1), *xr = x + (s * R + r) * L, *orow = o + (s * R + r) * L;
         float acc = 0.f;
         for (int j = 0; j < L; ++j) acc = fmaf(xr[j], wr[j], acc);
@@ -257,7 +297,7 @@ __global__ __launch_bounds__(256) void narre_head_kernel(NarreHead a) {
     __syncthreads();
     // ---- S3: scores
     for (int i = tid; i < 2 * R; i += 256) {
-        const int s = i / R;
+        const int s = i >= R;
         float acc = 0.f;
         for (int k = 0; k < L; ++k) acc = fmaf(h[i * L + k] * hm[i * L + k], w3[s * L + k], acc);
         sc[i] = acc + misc[s];
@@ -273,7 +313,7 @@ __global__ __launch_bounds__(256) void narre_head_kernel(NarreHead a) {
     __syncthreads();
     // ---- S5: attended review vector + the ID vector (NARRE.py:110-111)
     for (int i = tid; i < L2; i += 256) {
-        const int s = i / L, l = i - s * L;
+        const int s = i >= L, l = i - s * L;
         float acc = 0.f;
         for (int r = 0; r < R; ++r) acc = fmaf(sc[s * R + r], x[(s * R + r) * L + l], acc);
         v[i] = acc + ev[i] * evm[i];
@@ -333,14 +373,14 @@ __global__ __launch_bounds__(256) void narre_head_kernel(NarreHead a) {
         }
     }
     for (int i = tid; i < 2 * R; i += 256) {                // others: side s's ids index table 1-s
-        const int s = i / R, r = i - s * R;
+        const int s = i >= R, r = i - s * R;
         const int64_t id = a.other_id[s][b * R + r];
         a.gid[1 - s][nself + b * R + r] = id;
         a.tag[1 - s][id] = a.now;
     }
     __syncthreads();
     // ---- B2: final.1 weight, d interaction -> d v
-    for (int i = tid; i < L * L; i += 256) prow[head_col(a, a.off[NP_F1W] + i)] = fh[L + i / L] * cdv[i % L];
+    for (int i = tid; i < L * L; i += 256) { const int k = qd(i, invL); prow[head_col(a, a.off[NP_F1W] + i)] = fh[L + k] * cdv[i - k * L]; }
     for (int l = tid; l < L; l += 256) {
         float acc = 0.f;
         for (int k = 0; k < L; ++k) acc = fmaf(fh[L + k], F1[k * (L + 1) + l], acc);
@@ -351,11 +391,11 @@ __global__ __launch_bounds__(256) void narre_head_kernel(NarreHead a) {
     __syncthreads();
     // ---- B3: self ID rows (compact), d attention weights
     for (int i = tid; i < L2; i += 256) {
-        const int s = i / L, l = i - s * L;
+        const int s = i >= L, l = i - s * L;
         a.grow[s][(size_t)b * L + l] = dv[i] * evm[i];
     }
     for (int i = tid; i < 2 * R; i += 256) {
-        const int s = i / R;
+        const int s = i >= R;
         float acc = 0.f;
         for (int l = 0; l < L; ++l) acc = fmaf(dv[s * L + l], x[i * L + l], acc);
         da[i] = acc;
@@ -368,7 +408,7 @@ __global__ __launch_bounds__(256) void narre_head_kernel(NarreHead a) {
         misc[7 + tid] = dot;
     }
     __syncthreads();
-    for (int i = tid; i < 2 * R; i += 256) da[i] = sc[i] * (da[i] - misc[7 + i / R]);   // d score
+    for (int i = tid; i < 2 * R; i += 256) da[i] = sc[i] * (da[i] - misc[7 + (i >= R)]);   // d score
     __syncthreads();
     // ---- B5: scorer output layer, d hidden
     if (tid < 2) {
@@ -377,25 +417,25 @@ __global__ __launch_bounds__(256) void narre_head_kernel(NarreHead a) {
         prow[head_col(a, a.off[tid ? NP_AIB3 : NP_AUB3])] = acc;
     }
     for (int i = tid; i < L2; i += 256) {
-        const int s = i / L, k = i - s * L;
+        const int s = i >= L, k = i - s * L;
         float acc = 0.f;
         for (int r = 0; r < R; ++r) acc = fmaf(da[s * R + r], h[(s * R + r) * L + k] * hm[(s * R + r) * L + k], acc);
         prow[head_col(a, a.off[s ? NP_AIW3 : NP_AUW3] + k)] = acc;
     }
     for (int i = tid; i < 2 * RL; i += 256) {
-        const int s = i / RL, r = (i - s * RL) / L, k = i % L;
+        const int s = i >= RL, rem = i - s * RL, r = qd(rem, invL), k = rem - r * L;
         dz[i] = h[i] > 0.f ? da[s * R + r] * w3[s * L + k] * hm[i] : 0.f;     // d hpre
     }
     __syncthreads();
     // ---- B6: scorer hidden layer gradients, d x (-> d z), d other (compact rows)
     for (int i = tid; i < L2; i += 256) {
-        const int s = i / L, k = i - s * L;
+        const int s = i >= L, k = i - s * L;
         float acc = 0.f;
         for (int r = 0; r < R; ++r) acc += dz[(s * R + r) * L + k];
         prow[head_col(a, a.off[s ? NP_AIB0 : NP_AUB0] + k)] = acc;
     }
     for (int i = tid; i < 2 * L * L2; i += 256) {
-        const int s = i / (L * L2), k = (i - s * L * L2) / L2, j = i % L2;
+        const int s = i >= L * L2, rem = i - s * L * L2, k = qd(rem, invL2), j = rem - k * L2;
         float acc = 0.f;
         for (int r = 0; r < R; ++r) {
             const float c = j < L ? x[(s * R + r) * L + j] : o[(s * R + r) * L + j - L];
@@ -403,13 +443,13 @@ __global__ __launch_bounds__(256) void narre_head_kernel(NarreHead a) {
         }
         prow[head_col(a, a.off[s ? NP_AIW0 : NP_AUW0] + k * L2 + j)] = acc;
     }
-    float dzv[(2 * NR_MAX_R * NR_MAX_L + 255) / 256];        // d z of this thread's elements (kept over the barrier)
+    float dzv[(2 * MR * ML + 255) / 256];        // d z of this thread's elements (kept over the barrier)
 #pragma unroll
-    for (int it = 0; it < (2 * NR_MAX_R * NR_MAX_L + 255) / 256; ++it) {
+    for (int it = 0; it < (2 * MR * ML + 255) / 256; ++it) {
         const int i = tid + 256 * it;
         dzv[it] = 0.f;
         if (i < 2 * RL) {
-            const int s = i / RL, r = (i - s * RL) / L, j = i % L;
+            const int s = i >= RL, rem = i - s * RL, r = qd(rem, invL), j = rem - r * L;
             float ax = sc[s * R + r] * dv[s * L + j], ao = 0.f;
             for (int k = 0; k < L; ++k) {
                 const float d = dz[(s * R + r) * L + k];
@@ -422,26 +462,26 @@ __global__ __launch_bounds__(256) void narre_head_kernel(NarreHead a) {
     }
     __syncthreads();
 #pragma unroll
-    for (int it = 0; it < (2 * NR_MAX_R * NR_MAX_L + 255) / 256; ++it) {
+    for (int it = 0; it < (2 * MR * ML + 255) / 256; ++it) {
         const int i = tid + 256 * it;
         if (i < 2 * RL) dz[i] = dzv[it];
     }
     __syncthreads();
     // ---- B7: TextCNN FC gradients, d pooled
     for (int i = tid; i < L2; i += 256) {
-        const int s = i / L, l = i - s * L;
+        const int s = i >= L, l = i - s * L;
         float acc = 0.f;
         for (int r = 0; r < R; ++r) acc += dz[(s * R + r) * L + l];
         prow[head_col(a, a.off[s ? NP_IFB : NP_UFB] + l)] = acc;
     }
     for (int i = tid; i < 2 * L * NF; i += 256) {
-        const int s = i / (L * NF), l = (i - s * L * NF) / NF, f = i % NF;
+        const int s = i >= L * NF, rem = i - s * L * NF, l = rem / NF, f = rem - l * NF;
         float acc = 0.f;
         for (int r = 0; r < R; ++r) acc = fmaf(dz[(s * R + r) * L + l], P[(s * R + r) * NF + f], acc);
         prow[head_col(a, a.off[s ? NP_IFW : NP_UFW] + l * NF + f)] = acc;
     }
     for (int i = tid; i < 2 * R * NF; i += 256) {
-        const int s = i / (R * NF), r = (i - s * R * NF) / NF, f = i % NF;
+        const int s = i >= R * NF, rem = i - s * R * NF, r = rem / NF, f = rem - r * NF;
         float acc = 0.f;
         for (int l = 0; l < L; ++l) acc = fmaf(dz[(s * R + r) * L + l], fcw[(s * L + l) * (NF + 1) + f], acc);
         a.g_pooled[s][(b * R + r) * NF + f] = acc;
@@ -557,6 +597,7 @@ struct RowSweep {
     int L, now;
     AdamScalars s;
 };
+template <int ML>
 __global__ __launch_bounds__(NROW_THREADS) void narre_rows_kernel(RowSweep w) {
     const int bx = (int)blockIdx.x;
     if (bx >= w.cb_entries) {
@@ -589,9 +630,9 @@ __global__ __launch_bounds__(NROW_THREADS) void narre_rows_kernel(RowSweep w) {
         // chunk in ascending order, then one fixed butterfly per column combines the 64 lanes -- a
         // fixed order, so the result is deterministic (a butterfly per chunk made a row with
         // hundreds of entries a 70 us chain of cross-lane permutes)
-        float rv[NR_MAX_L];
+        float rv[ML];
 #pragma unroll
-        for (int col = 0; col < NR_MAX_L; ++col) rv[col] = 0.f;
+        for (int col = 0; col < ML; ++col) rv[col] = 0.f;
         float gv = 0.f;
         unsigned long long mine = 0;                        // bit c: entry c*64 + lane is a hit (nch <= 64)
         for (int c = (int)(k / 64); c < nch; ++c) {         // (no hit before k's chunk: k is the first)
@@ -605,25 +646,25 @@ __global__ __launch_bounds__(NROW_THREADS) void narre_rows_kernel(RowSweep w) {
                 cs[u] = mine ? __ffsll((long long)mine) - 1 : -1;
                 if (mine) mine &= mine - 1;
             }
-            float tmp[4][NR_MAX_L], tg[4];
+            float tmp[4][ML], tg[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int64_t j = (int64_t)(cs[u] < 0 ? 0 : cs[u]) * 64 + lane;
 #pragma unroll
-                for (int col = 0; col < NR_MAX_L; ++col)
+                for (int col = 0; col < ML; ++col)
                     tmp[u][col] = (cs[u] >= 0 && col < L) ? rows[j * L + col] : 0.f;
                 tg[u] = (cs[u] >= 0 && j < w.B) ? w.g[j] : 0.f;         // only the self entries carry a bias gradient
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {                   // ascending entry order within the lane
 #pragma unroll
-                for (int col = 0; col < NR_MAX_L; ++col) rv[col] += tmp[u][col];
+                for (int col = 0; col < ML; ++col) rv[col] += tmp[u][col];
                 gv += tg[u];
             }
         }
         float acc = 0.f;                                    // lane < L: column `lane` of the table row
 #pragma unroll
-        for (int col = 0; col < NR_MAX_L; ++col) {
+        for (int col = 0; col < ML; ++col) {
             if (col < L) {                                  // uniform
                 const float sum = wave_sum(rv[col]);
                 if (lane == col) acc = sum;
@@ -857,13 +898,16 @@ extern "C" int r4r_narre_step(const float *table, int64_t V,
     h.now = (int)adam_step; h.p_drop = dropout_p; h.inv_denom = inv_denom; h.seed = seed; h.offset = offset;
     const size_t lds = narre_head_lds_bytes(R, L);
     R4R_REQUIRE(lds <= 160 * 1024, "narre_step: R = %d, L = %d need %zu bytes of LDS", R, L, lds);
-    static size_t lds_set = 0;
-    if (lds > lds_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(narre_head_kernel),
+    const bool small = R <= 16 && L <= 16;
+    static size_t lds_set[2] = {0, 0};
+    if (lds > lds_set[small]) {
+        (void)hipFuncSetAttribute(small ? reinterpret_cast<const void *>(narre_head_kernel<16, 16>)
+                                        : reinterpret_cast<const void *>(narre_head_kernel<32, 32>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        lds_set = lds;
+        lds_set[small] = lds;
     }
-    narre_head_kernel<<<(unsigned)B, 256, lds, st>>>(h);
+    if (small) narre_head_kernel<16, 16><<<(unsigned)B, 256, lds, st>>>(h);
+    else narre_head_kernel<32, 32><<<(unsigned)B, 256, lds, st>>>(h);
     if (!train_step) return check_launch("narre_step(forward)");
 
     // 4: conv weight gradients + head-parameter column sums (+ next batch's token marks)
@@ -934,7 +978,8 @@ extern "C" int r4r_narre_step(const float *table, int64_t V,
     rs.s = opt.s;
     {
         ScopedTiming tm(R4R_TIMING_ADAM, st);
-        narre_rows_kernel<<<(unsigned)chunks, NROW_THREADS, 0, st>>>(rs);
+        if (L <= 16) narre_rows_kernel<16><<<(unsigned)chunks, NROW_THREADS, 0, st>>>(rs);
+        else narre_rows_kernel<32><<<(unsigned)chunks, NROW_THREADS, 0, st>>>(rs);
     }
     return check_launch("narre_step");
 }

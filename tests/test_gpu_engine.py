@@ -478,3 +478,32 @@ def test_narre_engine_dropout_masks_injected_into_oracle():
             diff = (sd[k].cpu() - v).abs()
             assert float((diff > 2e-5 + 1e-4 * v.abs()).float().mean()) < 2e-3, k
             assert float(diff.max()) < 5e-4, k
+
+
+def test_narre_engine_wide_latent_uses_the_general_instantiation():
+    """latent_size 24 / 20 reviews (> 16: the <= 32 kernels) against the CPU oracle: two steps,
+    SE and updated weights."""
+    import reviews4rec_amd
+    from reviews4rec_amd.engine import NarreEngine
+    from test_oracle_golden import ill_conditioned
+    B, R, W, E, V, U, I, L = 6, 20, 14, 32, 300, 50, 40, 24
+    hp = dict(model_type='NARRE', latent_size=L, word_embed_size=E, dropout=0.0, total_users=U, total_items=I,
+              lr=0.002, weight_decay=1e-6, narre_num_reviews=R, narre_num_words=W)
+    P = oracle.init_params(hp, vocab_size=V, seed=8)
+    model = reviews4rec_amd.get_model_class('NARRE')(dict(hp, word_vectors=P['word2vec.weight'].numpy()))
+    model.load_state_dict(P)
+    model = model.to(DEV).train()
+    eng = NarreEngine(model, lr=hp['lr'], weight_decay=hp['weight_decay'])
+    state = oracle.AdamState()
+    data, y = synthetic_review_batch(B, W, V, U, I, seed=2, R=R, W=W)
+    data[1] = torch.randint(0, U + 2, (B, R))
+    data[2] = torch.randint(0, I + 2, (B, R))
+    for step in range(2):
+        se = eng.train_step([d.to(DEV) for d in data], y.to(DEV)).cpu().clone()
+        sse, _ = oracle.train_step(P, data, y, hp, state)
+        torch.testing.assert_close(se.sum(), torch.tensor(sse), rtol=1e-4, atol=1e-4)
+    sd = model.state_dict()
+    for k, v in P.items():
+        if not ill_conditioned(k):
+            diff = (sd[k].cpu() - v).abs()
+            assert float((diff > 2e-5 + 1e-4 * v.abs()).float().mean()) < 2e-3 and float(diff.max()) < 5e-4, k
