@@ -103,9 +103,12 @@ __global__ __launch_bounds__(256) void deepconn_head_kernel(HeadArgs a) {
     const int wtot = 2 * L * F_CONV;
 #pragma unroll
     for (int k = 0; k < WREGS; ++k) {
-        const int i = min(tid + 256 * k, wtot - 1);
-        const int t = i / (L * F_CONV);
-        wreg[k] = a.fc_w[t][i - t * L * F_CONV];
+        wreg[k] = 0.f;
+        if (256 * k < wtot) {                               // uniform: rounds past the end cost nothing
+            const int i = min(tid + 256 * k, wtot - 1);
+            const int t = i >= L * F_CONV;
+            wreg[k] = a.fc_w[t][i - t * L * F_CONV];
+        }
     }
     const float fbreg = (tid < n) ? a.fc_b[tid / L][tid % L] : 0.f;
     const float lwreg = (tid < n) ? a.lin_w[tid] : 0.f;
@@ -118,8 +121,8 @@ __global__ __launch_bounds__(256) void deepconn_head_kernel(HeadArgs a) {
         for (int k = 0; k < WREGS; ++k) {
             const int i = tid + 256 * k;
             if (i < wtot) {
-                const int t = i / (L * F_CONV), r = i - t * L * F_CONV;
-                sw[t][r / F_CONV][r % F_CONV] = wreg[k];
+                const int t = i >= L * F_CONV, r = i - t * L * F_CONV, l = r / F_CONV;
+                sw[t][l][r - l * F_CONV] = wreg[k];
             }
         }
         if (tid < n) { sfb[tid / L][tid % L] = fbreg; slw[tid] = lwreg; }
