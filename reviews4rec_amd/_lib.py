@@ -68,6 +68,10 @@ def lib():
         raise RuntimeError(
             'reviews4rec_amd: %s is missing. The HIP hot path has no fallback; build it with '
             '`python -c "import __graft_entry__ as g; g.build()"` (or `make -C reviews4rec_amd/csrc`).' % LIB_PATH)
+    # PyTorch-ROCm ships its own libamdhip64.  Load it first: if this library pulled the system
+    # runtime in before torch brought its own, the process would hold two HIP runtimes and the
+    # second one finds no device ("no ROCm-capable device is detected").
+    import torch  # noqa: F401
     l = ctypes.CDLL(LIB_PATH)
     _decls = parse_header()
     for name, (restype, argtypes, _) in _decls.items():
