@@ -297,8 +297,9 @@ int r4r_deepconn_tokens(const int64_t *user_idx, const int64_t *item_idx, void *
  * ID-embedding gathers + dropout, the row dot product), MSELoss (loss.py:7-11), loss.backward()
  * and torch.optim.Adam.step() (main.py:56-60,94-96) by TWO launches.  The dense gradient of an
  * ID table is never materialised: gradient rows stay compact ([B, D]) and the Adam sweep treats a
- * row no rating touched as gradient zero (24 B/element instead of 28 + a zero fill); rows touched
- * more than once sum their entries in ascending batch order (deterministic).
+ * row no rating touched as gradient zero (24 B/element instead of 28 + a zero fill); a touched row
+ * is updated by the wave of its first rating, which sums the row's entries in a fixed order
+ * (deterministic, no atomics).
  *   p / m / v : HOST arrays of 5 DEVICE pointers -- user_embedding.weight [n_users, D],
  *               item_embedding.weight [n_items, D], user_bias [n_users], item_bias [n_items],
  *               global_bias [1] (n_users = total_users + 1, n_items = total_items + 1, MF.py:14-24);
@@ -308,7 +309,7 @@ int r4r_deepconn_tokens(const int64_t *user_idx, const int64_t *item_idx, void *
  *   adam_step : 1-based update count; also tags the rows this step touched (workspace)
  *   ws        : r4r_mf_ws_bytes; its first bytes (the row tags) must be ZERO on first use and
  *               are kept consistent by the kernels -- allocate once, zero once.
- *   B <= 1024 for training steps.  sse_accum (nullable) += sum_b se[b] on training steps. */
+ *   B <= 16384 for training steps.  sse_accum (nullable) += sum_b se[b] on training steps. */
 size_t r4r_mf_ws_bytes(int64_t B, int D, int64_t n_users, int64_t n_items);
 size_t r4r_mf_ws_mult_offset(int64_t B, int D, int64_t n_users, int64_t n_items);   /* [B,2D] dropout multipliers (tests) */
 size_t r4r_mf_ws_grad_offset(int64_t B, int D, int64_t n_users, int64_t n_items, int which);   /* 0: user rows [B,D], 1: item rows, 2: d loss/d pred [B] (tests) */

@@ -6,11 +6,15 @@
 //   1. mf_fwd_bwd_kernel   one wave per rating: gathers, Philox dropout, dot, prediction, SE,
 //                          and the rating's gradient rows kept COMPACT ([B, D] per table + the
 //                          scalar d loss / d pred); marks the rows it touched with the step's tag
-//   2. mf_adam_kernel      one streaming pass over every parameter (every row moves every step:
-//                          L2 weight decay).  The dense table gradient is never
-//                          materialised: a row whose tag is not this step's has gradient zero
-//                          (24 B/element: read p, m, v, write p, m, v), a tagged row sums its
-//                          compact entries in ascending batch order (deterministic, no atomics).
+//   2. mf_adam_kernel      every parameter moves every step (L2 weight decay), but
+//                          the dense table gradient is never materialised.  Two kinds of workgroup:
+//                          SWEEP workgroups stream every element (24 B: read p, m, v, write p, m, v)
+//                          and give the rows no rating touched (tag != this step) the gradient-zero
+//                          update; ENTRY waves, one per rating and side, scan the batch's ids (LDS),
+//                          and the first entry of a row sums that row's gradient rows -- four
+//                          interleaved accumulators of entries taken in ascending order, combined in
+//                          a fixed order: deterministic, no atomics -- and updates the table row and
+//                          its bias element.
 //
 // The op-by-op module path needs ~25 launches and a zero-filled dense gradient per table for the
 // same step (28 B/element + the fill); on Amazon-Electronics-sized tables (16.6 M parameters)
@@ -22,7 +26,7 @@ namespace r4r {
 
 constexpr int MF_MAX_D = 256;          // latent size: <= 4 elements per lane of the rating's wave
 constexpr int MF_SLOTS = 5;            // user table, item table, user bias, item bias, global bias
-constexpr int MF_MAX_B = 1024;         // a tagged row scans the batch for its entries
+constexpr int MF_MAX_B = 16384;        // the entry waves keep a side's ids in LDS (4 B each)
 
 struct MfStep {
     const int64_t *uid, *iid;          // [B]
@@ -96,7 +100,7 @@ __global__ __launch_bounds__(256) void mf_fwd_bwd_kernel(MfStep a) {
 
 constexpr int MF_CHUNK = 8192, MF_THREADS = 256;
 
-constexpr int MF_CHUNK_BIAS = 1024;    // bias vectors: one float4 per thread, so their workgroups are not the tail
+constexpr int MF_CHUNK_BIAS = 1024;    // bias vectors: short workgroups, so they are not the tail
 
 // Scalar fields only: an array member indexed by the workgroup's slot number (even through a
 // chain of constant-index selects, which LLVM turns back into an indexed access) is copied to
@@ -105,8 +109,8 @@ struct MfSweep {
     float *p0, *p1, *p2, *p3, *p4;
     float *m0, *m1, *m2, *m3, *m4;
     float *v0, *v1, *v2, *v3, *v4;
-    int64_t n0, n1, n2, n3, n4;        // elements per slot
-    int cb1, cb2, cb3, cb4;            // first workgroup of slots 1..4 (slot 0 starts at 0)
+    int64_t n0, n1, n2, n3;            // elements of the tables and bias vectors
+    int cb1, cb2, cb3, cb_global, cb_entries;   // first workgroup of slots 1..3, of the global-bias group, of the entry waves
     const int64_t *uid, *iid;
     const float *gu, *gi, *g, *se;
     float *sse_accum;
@@ -118,88 +122,156 @@ struct MfSweep {
 
 __host__ __device__ inline int mf_chunk(int t) { return t < 2 ? MF_CHUNK : MF_CHUNK_BIAS; }
 
-// What one workgroup of the sweep needs, picked out of the kernel arguments with unrolled
-// compares and passed BY VALUE: indexing the argument struct with a runtime slot number (or
-// handing helpers a reference to it) makes hipcc copy the whole struct to scratch, and a kernel
-// that owns scratch streamed at 3.7 instead of 5+ TB/s.
-struct MfSlot {
-    float *p, *m, *v;                  // this workgroup's chunk
-    const int *tag;                    // row tags of the slot's side (NULL: global bias)
-    const int64_t *ids;                // uid / iid
-    const float *grow;                 // compact gradient rows [B, D] (tables) or NULL (bias vectors: g)
-    const float *g;                    // [B]
-    int64_t B;
-    int D, now;
-};
-
-// gradient of element (row, col): zero unless the row carries this step's tag
-__device__ __forceinline__ float mf_grad(const MfSlot s, int64_t row, int col) {
-    float acc = 0.f;
-    if (!s.tag) {                                           // global bias: every rating contributes
-        for (int64_t b = 0; b < s.B; ++b) acc += s.g[b];
-        return acc;
-    }
-    if (s.tag[row] != s.now) return 0.f;
-    for (int64_t b = 0; b < s.B; ++b)                       // ascending batch order: deterministic
-        if (s.ids[b] == row) acc += s.grow ? s.grow[b * s.D + col] : s.g[b];
-    return acc;
-}
-
-// four consecutive columns of a tagged table row, one scan of the batch
-__device__ __forceinline__ float4 mf_grad4(const MfSlot s, int64_t row, int col) {
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int64_t b = 0; b < s.B; ++b)
-        if (s.ids[b] == row) {
-            const float4 r = *reinterpret_cast<const float4 *>(s.grow + b * s.D + col);
-            acc.x += r.x; acc.y += r.y; acc.z += r.z; acc.w += r.w;
-        }
-    return acc;
-}
-
 __global__ __launch_bounds__(MF_THREADS) void mf_adam_kernel(MfSweep w) {
-    const int bx = (int)blockIdx.x;
-    // the workgroup's slot: 0 user table, 1 item table, 2 user bias, 3 item bias, 4 global bias
-    const int t = (bx >= w.cb1) + (bx >= w.cb2) + (bx >= w.cb3) + (bx >= w.cb4);
+    extern __shared__ int sid[];                            // entry waves: the side's ids
+    __shared__ float red[MF_THREADS];
+    const int bx = (int)blockIdx.x, tid = threadIdx.x;
+    if (bx >= w.cb_entries) {
+        // ---- entry waves: 4 per workgroup, all of one side (user side's groups first)
+        const int lane = tid & 63;
+        const int groups = (int)((w.B + 3) / 4);
+        int gi = bx - w.cb_entries;
+        const int t = gi >= groups;
+        if (t) gi -= groups;
+        const int64_t *ids = t ? w.iid : w.uid;
+        for (int64_t j = tid; j < w.B; j += MF_THREADS) sid[j] = (int)ids[j];
+        __syncthreads();
+        const int64_t k = (int64_t)gi * 4 + (tid >> 6);
+        if (k >= w.B) return;                               // whole wave
+        const int row = sid[k];
+        const int nch = (int)((w.B + 63) / 64), kc = (int)(k / 64);
+        // is k the first entry of its row?  (chunks up to k's own)
+        for (int c = 0; c <= kc; ++c) {
+            const int j = c * 64 + lane;
+            const unsigned long long mask = __ballot(j < w.B && sid[j] == row);
+            if (mask && (int64_t)c * 64 + (__ffsll((long long)mask) - 1) < k) return;   // an earlier entry owns the row
+        }
+        // owner: the row's entries in ascending order, dealt round-robin to four accumulators whose
+        // loads are in flight together; lanes are columns (lane, lane + 64, ...)
+        const int D = w.D;
+        const float *rows = t ? w.gi : w.gu;
+        float acc[4][MF_MAX_D / 64], gsum[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int x = 0; x < MF_MAX_D / 64; ++x) acc[q][x] = 0.f;
+        // (entries are popped four at a time into named slots: a runtime-indexed pending list
+        // would live in scratch, and a kernel that owns scratch streams slower -- see MfSweep)
+        int carry0 = -1, carry1 = -1, carry2 = -1;          // < 4 entries left over from the previous chunk
+        auto add4 = [&](int e0, int e1, int e2, int e3) {   // e_q < 0: slot q unused
+            float tmp[4][MF_MAX_D / 64], tg[4];
+            const int es[4] = {e0, e1, e2, e3};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int e = es[q] < 0 ? 0 : es[q];
+#pragma unroll
+                for (int x = 0; x < MF_MAX_D / 64; ++x)
+                    tmp[q][x] = (es[q] >= 0 && lane + 64 * x < D) ? rows[(int64_t)e * D + lane + 64 * x] : 0.f;
+                tg[q] = es[q] >= 0 ? w.g[e] : 0.f;
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+#pragma unroll
+                for (int x = 0; x < MF_MAX_D / 64; ++x) acc[q][x] += tmp[q][x];
+                gsum[q] += tg[q];
+            }
+        };
+        auto pop = [](unsigned long long &mask, int base) {
+            if (!mask) return -1;
+            const int e = base + (__ffsll((long long)mask) - 1);
+            mask &= mask - 1;
+            return e;
+        };
+        for (int c = kc; c < nch; ++c) {
+            const int j = c * 64 + lane;
+            unsigned long long mask = __ballot(j < w.B && sid[j] == row);
+            // complete the carried group first (keeps every entry's accumulator = its rank mod 4)
+            if (carry0 >= 0 && mask) {
+                const int n = carry2 >= 0 ? 3 : (carry1 >= 0 ? 2 : 1);
+                const int a1 = n >= 2 ? carry1 : pop(mask, c * 64), a2 = n >= 3 ? carry2 : pop(mask, c * 64);
+                const int a3 = pop(mask, c * 64);
+                if (a3 >= 0) { add4(carry0, a1, a2, a3); carry0 = carry1 = carry2 = -1; }
+                else { carry1 = a1; carry2 = a2; }          // still short of four
+            }
+            while (carry0 < 0 && mask) {
+                const int e0 = pop(mask, c * 64), e1 = pop(mask, c * 64), e2 = pop(mask, c * 64), e3 = pop(mask, c * 64);
+                if (e3 >= 0) add4(e0, e1, e2, e3);
+                else { carry0 = e0; carry1 = e1; carry2 = e2; }
+            }
+        }
+        if (carry0 >= 0) add4(carry0, carry1, carry2, -1);
+        const float gb = (gsum[0] + gsum[1]) + (gsum[2] + gsum[3]);
+        if (D > 0) {
+            float *bp = t ? w.p1 : w.p0, *bm = t ? w.m1 : w.m0, *bv = t ? w.v1 : w.v0;
+#pragma unroll
+            for (int x = 0; x < MF_MAX_D / 64; ++x) {
+                const int col = lane + 64 * x;
+                if (col < D) {
+                    const int64_t o = (int64_t)row * D + col;
+                    const float G = (acc[0][x] + acc[1][x]) + (acc[2][x] + acc[3][x]);
+                    float P = bp[o], M = bm[o], V = bv[o];
+                    adam_elem(P, G, M, V, w.s);
+                    bp[o] = P; bm[o] = M; bv[o] = V;
+                }
+            }
+        }
+        if (lane == 0) {                                    // the row's bias element
+            float *bp = t ? w.p3 : w.p2, *bm = t ? w.m3 : w.m2, *bv = t ? w.v3 : w.v2;
+            float P = bp[row], M = bm[row], V = bv[row];
+            adam_elem(P, gb, M, V, w.s);
+            bp[row] = P; bm[row] = M; bv[row] = V;
+        }
+        return;
+    }
+    if (bx >= w.cb_global) {
+        // ---- global bias (gradient = sum of d loss / d pred over the batch) + the running SE:
+        // strided per-thread sums, then a fixed tree -- deterministic
+        float a = 0.f, e = 0.f;
+        for (int64_t b = tid; b < w.B; b += MF_THREADS) { a += w.g[b]; e += w.se[b]; }
+        red[tid] = a;
+        __syncthreads();
+        for (int off = MF_THREADS / 2; off > 0; off >>= 1) { if (tid < off) red[tid] += red[tid + off]; __syncthreads(); }
+        const float gsum = red[0];
+        __syncthreads();
+        red[tid] = e;
+        __syncthreads();
+        for (int off = MF_THREADS / 2; off > 0; off >>= 1) { if (tid < off) red[tid] += red[tid + off]; __syncthreads(); }
+        if (tid == 0) {
+            float P = w.p4[0], M = w.m4[0], V = w.v4[0];
+            adam_elem(P, gsum, M, V, w.s);
+            w.p4[0] = P; w.m4[0] = M; w.v4[0] = V;
+            if (w.sse_accum) w.sse_accum[0] += red[0];
+        }
+        return;
+    }
+    // ---- sweep workgroups: slot 0 user table, 1 item table, 2 user bias, 3 item bias
+    const int t = (bx >= w.cb1) + (bx >= w.cb2) + (bx >= w.cb3);
     float *bp = w.p0, *bm = w.m0, *bv = w.v0;
     int64_t numel = w.n0;
     int cb = 0;
     if (t == 1) { bp = w.p1; bm = w.m1; bv = w.v1; numel = w.n1; cb = w.cb1; }
     else if (t == 2) { bp = w.p2; bm = w.m2; bv = w.v2; numel = w.n2; cb = w.cb2; }
     else if (t == 3) { bp = w.p3; bm = w.m3; bv = w.v3; numel = w.n3; cb = w.cb3; }
-    else if (t == 4) { bp = w.p4; bm = w.m4; bv = w.v4; numel = w.n4; cb = w.cb4; }
     const int W = t < 2 ? w.D : 1;
     const int64_t start = (int64_t)(bx - cb) * mf_chunk(t);
     int64_t cnt = numel - start;
     if (cnt > mf_chunk(t)) cnt = mf_chunk(t);
     float *p = bp + start, *m = bm + start, *v = bv + start;
-    const bool user_side = (t == 0 || t == 2);
-    MfSlot a;
-    a.p = p; a.m = m; a.v = v;
-    a.tag = t == 4 ? nullptr : (user_side ? w.tag_u : w.tag_i);
-    a.ids = user_side ? w.uid : w.iid;
-    a.grow = t == 0 ? w.gu : (t == 1 ? w.gi : nullptr);
-    a.g = w.g; a.B = w.B; a.D = w.D; a.now = w.now;
-    if (t == 4 && threadIdx.x == 0 && w.sse_accum) {        // the running metric (main.py:57), same launch
-        float s = 0.f;
-        for (int64_t b = 0; b < w.B; ++b) s += w.se[b];
-        w.sse_accum[0] += s;
-    }
-    const bool vec = (W % 4 == 0) && (((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(m) |
-                                        reinterpret_cast<uintptr_t>(v)) & 15) == 0);
+    const int *tag = (t == 0 || t == 2) ? w.tag_u : w.tag_i;
+    const bool aligned = (((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(m) | reinterpret_cast<uintptr_t>(v)) & 15) == 0);
     // (row, column) of a thread's element advance incrementally: a 64-bit division per element
     // would cost more than the 24 bytes the element moves
     const int64_t row_start = start / W;
     const int col_start = (int)(start - row_start * W);
-    if (vec) {                                              // a float4 never straddles a row
+    if (W % 4 == 0 && aligned) {                            // table rows: a float4 never straddles a row
         const int64_t nvec = cnt >> 2;
-        const int *tag = a.tag;
-        const unsigned first = col_start + threadIdx.x * 4u;
+        const unsigned first = col_start + tid * 4u;
         int64_t row = row_start + first / (unsigned)W;
         int col = (int)(first % (unsigned)W);
         const int step_row = (MF_THREADS * 4) / W, step_col = (MF_THREADS * 4) % W;
         // two float4 per round, every load of the round (p, m, v and the row tags) issued before
         // the first use: one memory round trip per round, eight requests in flight per lane
-        int64_t i = threadIdx.x;
+        int64_t i = tid;
         for (; i + MF_THREADS < nvec; i += 2 * MF_THREADS) {
             int64_t row1 = row + step_row;
             int col1 = col + step_col;
@@ -209,16 +281,18 @@ __global__ __launch_bounds__(MF_THREADS) void mf_adam_kernel(MfSweep w) {
             float4 M0 = reinterpret_cast<float4 *>(m)[i], M1 = reinterpret_cast<float4 *>(m)[j];
             float4 V0 = reinterpret_cast<float4 *>(v)[i], V1 = reinterpret_cast<float4 *>(v)[j];
             const int t0 = tag[row], t1 = tag[row1];
-            float4 G0 = make_float4(0.f, 0.f, 0.f, 0.f), G1 = G0;
-            if (t0 == a.now) G0 = mf_grad4(a, row, col);
-            if (t1 == a.now) G1 = mf_grad4(a, row1, col1);
-            adam_elem(P0.x, G0.x, M0.x, V0.x, w.s); adam_elem(P0.y, G0.y, M0.y, V0.y, w.s);
-            adam_elem(P0.z, G0.z, M0.z, V0.z, w.s); adam_elem(P0.w, G0.w, M0.w, V0.w, w.s);
-            adam_elem(P1.x, G1.x, M1.x, V1.x, w.s); adam_elem(P1.y, G1.y, M1.y, V1.y, w.s);
-            adam_elem(P1.z, G1.z, M1.z, V1.z, w.s); adam_elem(P1.w, G1.w, M1.w, V1.w, w.s);
-            reinterpret_cast<float4 *>(p)[i] = P0; reinterpret_cast<float4 *>(p)[j] = P1;
-            reinterpret_cast<float4 *>(m)[i] = M0; reinterpret_cast<float4 *>(m)[j] = M1;
-            reinterpret_cast<float4 *>(v)[i] = V0; reinterpret_cast<float4 *>(v)[j] = V1;
+            if (t0 != w.now) {                              // touched rows belong to their entry wave
+                adam_elem(P0.x, 0.f, M0.x, V0.x, w.s); adam_elem(P0.y, 0.f, M0.y, V0.y, w.s);
+                adam_elem(P0.z, 0.f, M0.z, V0.z, w.s); adam_elem(P0.w, 0.f, M0.w, V0.w, w.s);
+                reinterpret_cast<float4 *>(p)[i] = P0; reinterpret_cast<float4 *>(m)[i] = M0;
+                reinterpret_cast<float4 *>(v)[i] = V0;
+            }
+            if (t1 != w.now) {
+                adam_elem(P1.x, 0.f, M1.x, V1.x, w.s); adam_elem(P1.y, 0.f, M1.y, V1.y, w.s);
+                adam_elem(P1.z, 0.f, M1.z, V1.z, w.s); adam_elem(P1.w, 0.f, M1.w, V1.w, w.s);
+                reinterpret_cast<float4 *>(p)[j] = P1; reinterpret_cast<float4 *>(m)[j] = M1;
+                reinterpret_cast<float4 *>(v)[j] = V1;
+            }
             row = row1 + step_row;
             col = col1 + step_col;
             if (col >= W) { col -= W; ++row; }
@@ -227,64 +301,27 @@ __global__ __launch_bounds__(MF_THREADS) void mf_adam_kernel(MfSweep w) {
             float4 P = reinterpret_cast<float4 *>(p)[i];
             float4 M = reinterpret_cast<float4 *>(m)[i];
             float4 V = reinterpret_cast<float4 *>(v)[i];
-            float4 G = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (tag[row] == a.now) G = mf_grad4(a, row, col);
-            adam_elem(P.x, G.x, M.x, V.x, w.s);
-            adam_elem(P.y, G.y, M.y, V.y, w.s);
-            adam_elem(P.z, G.z, M.z, V.z, w.s);
-            adam_elem(P.w, G.w, M.w, V.w, w.s);
-            reinterpret_cast<float4 *>(p)[i] = P;
-            reinterpret_cast<float4 *>(m)[i] = M;
-            reinterpret_cast<float4 *>(v)[i] = V;
+            if (tag[row] != w.now) {
+                adam_elem(P.x, 0.f, M.x, V.x, w.s); adam_elem(P.y, 0.f, M.y, V.y, w.s);
+                adam_elem(P.z, 0.f, M.z, V.z, w.s); adam_elem(P.w, 0.f, M.w, V.w, w.s);
+                reinterpret_cast<float4 *>(p)[i] = P; reinterpret_cast<float4 *>(m)[i] = M;
+                reinterpret_cast<float4 *>(v)[i] = V;
+            }
             row += step_row;
             col += step_col;
             if (col >= W) { col -= W; ++row; }
         }
-    } else if (W == 1 && (((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(m) |
-                             reinterpret_cast<uintptr_t>(v)) & 15) == 0) && t < 4) {
-        // bias vectors: four rows per float4, their four tags in one int4 (tags are 256-B aligned,
-        // start is a multiple of 4)
-        const int *tag = a.tag;
-        const int64_t *ids = a.ids;
-        const int64_t nvec = cnt >> 2;
-        for (int64_t i = threadIdx.x; i < nvec; i += MF_THREADS) {
-            const int64_t r0 = start + i * 4;
-            float4 P = reinterpret_cast<float4 *>(p)[i];
-            float4 M = reinterpret_cast<float4 *>(m)[i];
-            float4 V = reinterpret_cast<float4 *>(v)[i];
-            const int4 T = *reinterpret_cast<const int4 *>(tag + r0);
-            float G0 = 0.f, G1 = 0.f, G2 = 0.f, G3 = 0.f;     // (no runtime-indexed array: that would be scratch)
-            if (T.x == a.now || T.y == a.now || T.z == a.now || T.w == a.now)
-                for (int64_t b = 0; b < a.B; ++b) {           // ascending batch order: deterministic
-                    const int64_t d = ids[b] - r0;
-                    const float gb = a.g[b];
-                    if (d == 0) G0 += gb;
-                    if (d == 1) G1 += gb;
-                    if (d == 2) G2 += gb;
-                    if (d == 3) G3 += gb;
-                }
-            adam_elem(P.x, G0, M.x, V.x, w.s);
-            adam_elem(P.y, G1, M.y, V.y, w.s);
-            adam_elem(P.z, G2, M.z, V.z, w.s);
-            adam_elem(P.w, G3, M.w, V.w, w.s);
-            reinterpret_cast<float4 *>(p)[i] = P;
-            reinterpret_cast<float4 *>(m)[i] = M;
-            reinterpret_cast<float4 *>(v)[i] = V;
-        }
-        for (int64_t i = (nvec << 2) + threadIdx.x; i < cnt; i += MF_THREADS) {      // < 4 leftover rows
-            float P = p[i], M = m[i], V = v[i];
-            adam_elem(P, mf_grad(a, start + i, 0), M, V, w.s);
-            p[i] = P; m[i] = M; v[i] = V;
-        }
-    } else {
-        const unsigned first = col_start + threadIdx.x;
+    } else {                                                // bias vectors (W = 1) and unaligned tables
+        const unsigned first = col_start + tid;
         int64_t row = row_start + first / (unsigned)W;
         int col = (int)(first % (unsigned)W);
         const int step_row = MF_THREADS / W, step_col = MF_THREADS % W;
-        for (int64_t i = threadIdx.x; i < cnt; i += MF_THREADS) {
+        for (int64_t i = tid; i < cnt; i += MF_THREADS) {
             float P = p[i], M = m[i], V = v[i];
-            adam_elem(P, mf_grad(a, row, col), M, V, w.s);
-            p[i] = P; m[i] = M; v[i] = V;
+            if (tag[row] != w.now) {
+                adam_elem(P, 0.f, M, V, w.s);
+                p[i] = P; m[i] = M; v[i] = V;
+            }
             row += step_row;
             col += step_col;
             if (col >= W) { col -= W; ++row; }
@@ -350,8 +387,8 @@ extern "C" int r4r_mf_step(const int64_t *uid, const int64_t *iid, const float *
     R4R_REQUIRE(!m || (y && se && adam_step >= 1), "mf_step: a training step needs ratings, the se buffer and "
                                                    "adam_step >= 1");
     R4R_REQUIRE(!y || se, "mf_step: se buffer required when y is given");
-    R4R_REQUIRE(!m || B <= MF_MAX_B, "mf_step: batch %lld > %d (a touched row scans the batch for its entries; use "
-                                     "the module path for larger batches)", (long long)B, MF_MAX_B);
+    R4R_REQUIRE(!m || B <= MF_MAX_B, "mf_step: batch %lld > %d (the entry waves keep a side's ids in LDS; use the "
+                                     "module path for larger batches)", (long long)B, MF_MAX_B);
     R4R_REQUIRE(adam_step < (1ll << 31), "mf_step: step tag overflow");
     R4R_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, "mf_step: dropout %f outside [0,1)", (double)dropout_p);
     if (ws_bytes < r4r_mf_ws_bytes(B, D, n_users, n_items)) {
@@ -384,21 +421,25 @@ extern "C" int r4r_mf_step(const int64_t *uid, const int64_t *iid, const float *
     sw.p0 = a.p[0]; sw.p1 = a.p[1]; sw.p2 = a.p[2]; sw.p3 = a.p[3]; sw.p4 = a.p[4];
     sw.m0 = a.m[0]; sw.m1 = a.m[1]; sw.m2 = a.m[2]; sw.m3 = a.m[3]; sw.m4 = a.m[4];
     sw.v0 = a.v[0]; sw.v1 = a.v[1]; sw.v2 = a.v[2]; sw.v3 = a.v[3]; sw.v4 = a.v[4];
-    int64_t numel[MF_SLOTS], begin[MF_SLOTS + 1], chunks = 0;
-    for (int k = 0; k < MF_SLOTS; ++k) {
+    int64_t numel[4], begin[4], chunks = 0;
+    for (int k = 0; k < 4; ++k) {                           // sweep workgroups: tables, bias vectors
         numel[k] = rows[k] * width[k];
         begin[k] = chunks;
         chunks += cdiv(numel[k], mf_chunk(k));
-        R4R_REQUIRE(chunks < (1ll << 31), "mf_step: too many chunks");
     }
-    sw.n0 = numel[0]; sw.n1 = numel[1]; sw.n2 = numel[2]; sw.n3 = numel[3]; sw.n4 = numel[4];
-    sw.cb1 = (int)begin[1]; sw.cb2 = (int)begin[2]; sw.cb3 = (int)begin[3]; sw.cb4 = (int)begin[4];
+    sw.n0 = numel[0]; sw.n1 = numel[1]; sw.n2 = numel[2]; sw.n3 = numel[3];
+    sw.cb1 = (int)begin[1]; sw.cb2 = (int)begin[2]; sw.cb3 = (int)begin[3];
+    sw.cb_global = (int)chunks;                             // one workgroup: global bias + running SE
+    chunks += 1;
+    sw.cb_entries = (int)chunks;                            // entry waves: 4 per workgroup, per side
+    chunks += 2 * cdiv(B, 4);
+    R4R_REQUIRE(chunks < (1ll << 31), "mf_step: too many workgroups");
     sw.uid = uid; sw.iid = iid; sw.gu = w.gu; sw.gi = w.gi; sw.g = w.g; sw.se = se; sw.sse_accum = sse_accum;
     sw.tag_u = w.tag_u; sw.tag_i = w.tag_i; sw.B = B; sw.D = D; sw.now = (int)adam_step;
     sw.s = adam_make_scalars(lr, beta1, beta2, eps, weight_decay, adam_step, nullptr);
     {
         ScopedTiming tm(R4R_TIMING_ADAM, st);
-        mf_adam_kernel<<<(unsigned)chunks, MF_THREADS, 0, st>>>(sw);
+        mf_adam_kernel<<<(unsigned)chunks, MF_THREADS, (size_t)B * sizeof(int), st>>>(sw);
     }
     return check_launch("mf_step");
 }

@@ -314,7 +314,8 @@ class MFEngine:
     dense gradient of an ID table is never materialised.  Same calling surface as DeepCoNNEngine
     (train_step / predict / sse / state_dict).  Single process only: under data parallelism the
     module path + the compact-list exchange of dist.py run instead."""
-    MAX_TRAIN_BATCH = 1024
+    MAX_TRAIN_BATCH = 16384      # accepted; a row with hundreds of entries is summed by ONE wave, so the host
+                                 # loop prefers the captured module path above batch 1024 (main.make_engine)
 
     def __init__(self, model, lr=0.002, weight_decay=1e-6, betas=(0.9, 0.999), eps=1e-8, seed=0x5EED5EED, rank=0):
         hp = model.hyper_params
