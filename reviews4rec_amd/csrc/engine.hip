@@ -80,13 +80,16 @@ struct HeadArgs {
 // unrolled, so the kernel is a handful of memory round trips instead of a chain of ~40.
 constexpr int HEAD_MAX_TILES = 8;
 
+// ML: compile-time cap of the latent size (LDS arrays, register arrays and unrolled staging loops
+// are sized by it; instantiated for <= 16 and <= 32)
+template <int ML>
 __global__ __launch_bounds__(256) void deepconn_head_kernel(HeadArgs a) {
-    __shared__ float sw[2][MAX_L][F_CONV + 1];   // FC weights, +1 pad: lane i reads row i
-    __shared__ float sfb[2][MAX_L];
-    __shared__ float sV[2 * MAX_L][FM_K];
-    __shared__ float slw[2 * MAX_L];
+    __shared__ float sw[2][ML][F_CONV + 1];   // FC weights, +1 pad: lane i reads row i
+    __shared__ float sfb[2][ML];
+    __shared__ float sV[2 * ML][FM_K];
+    __shared__ float slw[2 * ML];
     __shared__ float sp[4][2][F_CONV + 4];       // pooled, per wave
-    __shared__ float sz[4][2 * MAX_L];           // gz, per wave
+    __shared__ float sz[4][2 * ML];           // gz, per wave
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int64_t b_raw = (int64_t)blockIdx.x * 4 + w;
     const bool live = b_raw < a.B;             // a dead wave shadows the last rating and stores nothing
@@ -98,7 +101,7 @@ __global__ __launch_bounds__(256) void deepconn_head_kernel(HeadArgs a) {
     // Stage the head's weights in LDS.  All the loads of this prologue -- these and the pooling
     // partials below -- are issued before anything waits (a load -> LDS-store loop over the FC
     // matrix alone was 8 dependent L2 round trips: 6 us of a 12 us kernel).
-    constexpr int WREGS = (2 * MAX_L * F_CONV + 255) / 256;
+    constexpr int WREGS = (2 * ML * F_CONV + 255) / 256;
     float wreg[WREGS];
     const int wtot = 2 * L * F_CONV;
 #pragma unroll
@@ -112,7 +115,7 @@ __global__ __launch_bounds__(256) void deepconn_head_kernel(HeadArgs a) {
     }
     const float fbreg = (tid < n) ? a.fc_b[tid / L][tid % L] : 0.f;
     const float lwreg = (tid < n) ? a.lin_w[tid] : 0.f;
-    constexpr int VREGS = (2 * MAX_L * FM_K + 255) / 256;
+    constexpr int VREGS = (2 * ML * FM_K + 255) / 256;
     float vreg[VREGS];
 #pragma unroll
     for (int k = 0; k < VREGS; ++k) vreg[k] = a.V[min(tid + 256 * k, n * FM_K - 1)];
@@ -603,7 +606,8 @@ extern "C" int r4r_deepconn_step(const float *table, int64_t V, const int64_t *u
     h.pred = pred; h.se = se;
     h.B = B; h.L = L; h.tiles = tiles; h.training = training; h.want_grad = flat_g != nullptr;
     h.p_drop = dropout_p; h.inv_denom = inv_denom; h.seed = seed; h.offset = offset;
-    deepconn_head_kernel<<<(unsigned)cdiv(B, 4), 256, 0, st>>>(h);
+    if (L <= 16) deepconn_head_kernel<16><<<(unsigned)cdiv(B, 4), 256, 0, st>>>(h);
+    else deepconn_head_kernel<32><<<(unsigned)cdiv(B, 4), 256, 0, st>>>(h);
 
     if (!flat_g) {
         if (y && sse_accum) sse_only_kernel<<<1, 256, 0, st>>>(se, sse_accum, B);
