@@ -30,6 +30,10 @@
 namespace r4r {
 
 constexpr int NF = 100;                // conv filters (common_pytorch_models.py:11)
+#ifndef R4R_NHEAD_THREADS
+#define R4R_NHEAD_THREADS 512
+#endif
+constexpr int NHEAD_THREADS = R4R_NHEAD_THREADS;   // threads of the per-rating head workgroup
 constexpr int NR_MAX_L = 32, NR_MAX_R = 32;        // hard limits; the kernels are instantiated for <= 16 and <= 32
 
 // flat dense-parameter layout (21 slots); slots 0,1 / 4,5 are the conv weight + bias of the towers
@@ -94,9 +98,12 @@ __device__ __forceinline__ int head_col(const NarreHead &a, int flat_off) {
 
 // One workgroup per rating.  Dynamic LDS, carved for the actual R and L.
 // MR / ML: compile-time caps of R / L (register arrays and unrolled loops are sized by them:
-// the <= 16 instantiation is 10 % faster on the default shape than the <= 32 one)
-template <int MR, int ML>
-__global__ __launch_bounds__(256) void narre_head_kernel(NarreHead a) {
+// the <= 16 instantiation is 10 % faster on the default shape than the <= 32 one); NT: threads.
+// The kernel is bound by vector-ALU issue (index arithmetic around ~2000-element loops), with one
+// workgroup per CU on half the CUs -- so more waves per rating, not fewer instructions per
+// memory access, is what shortens it.
+template <int MR, int ML, int NT>
+__global__ __launch_bounds__(NT) void narre_head_kernel(NarreHead a) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int R = a.R, L = a.L, RL = R * L, L2 = 2 * L;
     const int tid = threadIdx.x;
@@ -134,21 +141,21 @@ __global__ __launch_bounds__(256) void narre_head_kernel(NarreHead a) {
         if (a.mult) a.mult[b * ND + k] = m;
         return m;
     };
-    if (!drop && a.mult) for (int k = tid; k < ND; k += 256) a.mult[b * ND + k] = 1.f;
+    if (!drop && a.mult) for (int k = tid; k < ND; k += NT) a.mult[b * ND + k] = 1.f;
 
     // ---- S0: weights -> LDS, pool finish, ID vectors.  The three big reads -- the pooling
     // partials, the FC matrices, the scorer matrices -- are issued into registers before anything
     // waits (a load -> LDS-store loop is one memory round trip per iteration: 8 + 8 + 2 of them)
-    constexpr int PREG = (2 * MR * NF + 255) / 256, WREG = (2 * ML * NF + 255) / 256,
-                  AREG = (2 * ML * 2 * ML + 255) / 256;
+    constexpr int PREG = (2 * MR * NF + NT - 1) / NT, WREG = (2 * ML * NF + NT - 1) / NT,
+                  AREG = (2 * ML * 2 * ML + NT - 1) / NT;
     float pv[PREG], wv[WREG], av[AREG];
     int pa[PREG];
     const bool one_tile = a.tiles == 1;
 #pragma unroll
     for (int u = 0; u < PREG; ++u) {
         pv[u] = 0.f; pa[u] = 0;
-        if (one_tile && 256 * u < 2 * R * NF) {             // uniform: rounds past the end cost nothing
-            const int i = min(tid + 256 * u, 2 * R * NF - 1);
+        if (one_tile && NT * u < 2 * R * NF) {             // uniform: rounds past the end cost nothing
+            const int i = min(tid + NT * u, 2 * R * NF - 1);
             const int s = i >= R * NF, rem = i - s * R * NF, rr = rem / NF, f = rem - rr * NF;
             const size_t q = ((size_t)(b * R + rr) * a.tiles) * NP + f;
             pv[u] = a.pmax[s][q];
@@ -158,8 +165,8 @@ __global__ __launch_bounds__(256) void narre_head_kernel(NarreHead a) {
 #pragma unroll
     for (int u = 0; u < WREG; ++u) {
         wv[u] = 0.f;
-        if (256 * u < 2 * L * NF) {
-            const int i = min(tid + 256 * u, 2 * L * NF - 1);
+        if (NT * u < 2 * L * NF) {
+            const int i = min(tid + NT * u, 2 * L * NF - 1);
             const int s = i >= L * NF;
             wv[u] = fp[a.off[s ? NP_IFW : NP_UFW] + i - s * L * NF];
         }
@@ -167,23 +174,23 @@ __global__ __launch_bounds__(256) void narre_head_kernel(NarreHead a) {
 #pragma unroll
     for (int u = 0; u < AREG; ++u) {
         av[u] = 0.f;
-        if (256 * u < 2 * L * L2) {
-            const int i = min(tid + 256 * u, 2 * L * L2 - 1);
+        if (NT * u < 2 * L * L2) {
+            const int i = min(tid + NT * u, 2 * L * L2 - 1);
             const int s = i >= L * L2;
             av[u] = fp[a.off[s ? NP_AIW0 : NP_AUW0] + i - s * L * L2];
         }
     }
     // the small reads ride in the same round trip; the ID vectors need their ids first (round 2)
-    constexpr int FREG = (ML * ML + 255) / 256, OREG = (2 * MR * ML + 255) / 256;
+    constexpr int FREG = (ML * ML + NT - 1) / NT, OREG = (2 * MR * ML + NT - 1) / NT;
     float f1v[FREG], ov[OREG];
     int64_t oid[OREG];
 #pragma unroll
-    for (int u = 0; u < FREG; ++u) f1v[u] = (256 * u < L * L) ? fp[a.off[NP_F1W] + min(tid + 256 * u, L * L - 1)] : 0.f;
+    for (int u = 0; u < FREG; ++u) f1v[u] = (NT * u < L * L) ? fp[a.off[NP_F1W] + min(tid + NT * u, L * L - 1)] : 0.f;
 #pragma unroll
     for (int u = 0; u < OREG; ++u) {
         oid[u] = 0;
-        if (256 * u < 2 * RL) {
-            const int i = min(tid + 256 * u, 2 * RL - 1);
+        if (NT * u < 2 * RL) {
+            const int i = min(tid + NT * u, 2 * RL - 1);
             const int s = i >= RL, rem = i - s * RL, r = qd(rem, invL);
             oid[u] = a.other_id[s][b * R + r];
         }
@@ -199,8 +206,8 @@ __global__ __launch_bounds__(256) void narre_head_kernel(NarreHead a) {
 #pragma unroll
     for (int u = 0; u < OREG; ++u) {
         ov[u] = 0.f;
-        if (256 * u < 2 * RL) {
-            const int i = min(tid + 256 * u, 2 * RL - 1);
+        if (NT * u < 2 * RL) {
+            const int i = min(tid + NT * u, 2 * RL - 1);
             const int s = i >= RL, rem = i - s * RL, r = qd(rem, invL), l = rem - r * L;
             ov[u] = a.emb[1 - s][oid[u] * L + l];
         }
@@ -209,7 +216,7 @@ __global__ __launch_bounds__(256) void narre_head_kernel(NarreHead a) {
     const float ub_r = a.bias[0][sid0], ib_r = a.bias[1][sid1];
 #pragma unroll
     for (int u = 0; u < WREG; ++u) {
-        const int i = tid + 256 * u;
+        const int i = tid + NT * u;
         if (i < 2 * L * NF) {
             const int s = i >= L * NF, r = i - s * L * NF, l = r / NF;
             fcw[(s * L + l) * (NF + 1) + r - l * NF] = wv[u];
@@ -217,7 +224,7 @@ __global__ __launch_bounds__(256) void narre_head_kernel(NarreHead a) {
     }
 #pragma unroll
     for (int u = 0; u < AREG; ++u) {
-        const int i = tid + 256 * u;
+        const int i = tid + NT * u;
         if (i < 2 * L * L2) {
             const int s = i >= L * L2, r = i - s * L * L2, k = qd(r, invL2);
             W0[(s * L + k) * (L2 + 1) + r - k * L2] = av[u];
@@ -225,7 +232,7 @@ __global__ __launch_bounds__(256) void narre_head_kernel(NarreHead a) {
     }
 #pragma unroll
     for (int u = 0; u < FREG; ++u) {
-        const int i = tid + 256 * u;
+        const int i = tid + NT * u;
         if (i < L * L) { const int k = qd(i, invL); F1[k * (L + 1) + i - k * L] = f1v[u]; }
     }
     if (tid < L2) {
@@ -236,13 +243,13 @@ __global__ __launch_bounds__(256) void narre_head_kernel(NarreHead a) {
     if (tid == 0) { misc[0] = m0; misc[1] = m1; misc[2] = m2; misc[3] = m3; misc[4] = ub_r; misc[5] = ib_r; }
 #pragma unroll
     for (int u = 0; u < OREG; ++u) {                        // other side's ID vectors: side s reads table 1-s
-        const int i = tid + 256 * u;
+        const int i = tid + NT * u;
         if (i < 2 * RL) o[i] = ov[u];
     }
     if (one_tile) {                                         // pool finish of a one-tile document: relu + argmax
 #pragma unroll
         for (int u = 0; u < PREG; ++u) {
-            const int i = tid + 256 * u;
+            const int i = tid + NT * u;
             if (i < 2 * R * NF) {
                 const int s = i >= R * NF, rem = i - s * R * NF, rr = rem / NF, f = rem - rr * NF;
                 const int64_t n = b * R + rr;
@@ -255,7 +262,7 @@ __global__ __launch_bounds__(256) void narre_head_kernel(NarreHead a) {
             }
         }
     } else {
-        for (int i = tid; i < 2 * R * NF; i += 256) {       // pool finish: max over tiles, relu, first argmax
+        for (int i = tid; i < 2 * R * NF; i += NT) {       // pool finish: max over tiles, relu, first argmax
             const int s = i >= R * NF, rem = i - s * R * NF, rr = rem / NF, f = rem - rr * NF;
             const int64_t n = b * R + rr;
             float best = -INFINITY;
@@ -273,7 +280,7 @@ __global__ __launch_bounds__(256) void narre_head_kernel(NarreHead a) {
     }
     __syncthreads();
     // ---- S1: TextCNN FC + dropout per review (common_pytorch_models.py:35-37)
-    for (int i = tid; i < 2 * RL; i += 256) {
+    for (int i = tid; i < 2 * RL; i += NT) {
         const int s = i >= RL, rem = i - s * RL, r = qd(rem, invL), l = rem - r * L;
         const float *pr = P + (s * R + r) * NF, *wr = fcw + (s * L + l) * (NF + 1);
         float acc = 0.f;
@@ -284,7 +291,7 @@ __global__ __launch_bounds__(256) void narre_head_kernel(NarreHead a) {
     }
     __syncthreads();
     // ---- S2: scorer hidden layer on [x ; other] (NARRE.py:55-58)
-    for (int i = tid; i < 2 * RL; i += 256) {
+    for (int i = tid; i < 2 * RL; i += NT) {
         const int s = i >= RL, rem = i - s * RL, r = qd(rem, invL), k = rem - r * L;
         const float *wr = W0 + (s * L + k) * (L2 + 1), *xr = x + (s * R + r) * L, *orow = o + (s * R + r) * L;
         float acc = 0.f;
@@ -296,7 +303,7 @@ __global__ __launch_bounds__(256) void narre_head_kernel(NarreHead a) {
     }
     __syncthreads();
     // ---- S3: scores
-    for (int i = tid; i < 2 * R; i += 256) {
+    for (int i = tid; i < 2 * R; i += NT) {
         const int s = i >= R;
         float acc = 0.f;
         for (int k = 0; k < L; ++k) acc = fmaf(h[i * L + k] * hm[i * L + k], w3[s * L + k], acc);
@@ -312,7 +319,7 @@ __global__ __launch_bounds__(256) void narre_head_kernel(NarreHead a) {
     }
     __syncthreads();
     // ---- S5: attended review vector + the ID vector (NARRE.py:110-111)
-    for (int i = tid; i < L2; i += 256) {
+    for (int i = tid; i < L2; i += NT) {
         const int s = i >= L, l = i - s * L;
         float acc = 0.f;
         for (int r = 0; r < R; ++r) acc = fmaf(sc[s * R + r], x[(s * R + r) * L + l], acc);
@@ -320,14 +327,14 @@ __global__ __launch_bounds__(256) void narre_head_kernel(NarreHead a) {
     }
     __syncthreads();
     // ---- S6: interaction + dropout (final.0)
-    for (int i = tid; i < L; i += 256) {
+    for (int i = tid; i < L; i += NT) {
         const float m = draw(4 * RL + 2 * L + i);
         cdv[L + i] = m;
         cdv[i] = v[i] * v[L + i] * m;
     }
     __syncthreads();
     // ---- S7: final.1 + relu
-    for (int k = tid; k < L; k += 256) {
+    for (int k = tid; k < L; k += NT) {
         float acc = 0.f;
         for (int l = 0; l < L; ++l) acc = fmaf(cdv[l], F1[k * (L + 1) + l], acc);
         acc += fv[k];
@@ -356,7 +363,7 @@ __global__ __launch_bounds__(256) void narre_head_kernel(NarreHead a) {
     float *prow = a.part + (size_t)b * a.nhp;
     const int64_t nself = a.B;                              // entries [0, B): self rows, then B*R others
     // ---- B1: final.3 / final.1 bias, d fpre
-    for (int k = tid; k < L; k += 256) {
+    for (int k = tid; k < L; k += NT) {
         prow[head_col(a, a.off[NP_F3W] + k)] = g * fh[k];
         const float d = fh[k] > 0.f ? g * fv[L + k] : 0.f;
         fh[L + k] = d;
@@ -372,7 +379,7 @@ __global__ __launch_bounds__(256) void narre_head_kernel(NarreHead a) {
             a.tag[s][id] = a.now;
         }
     }
-    for (int i = tid; i < 2 * R; i += 256) {                // others: side s's ids index table 1-s
+    for (int i = tid; i < 2 * R; i += NT) {                // others: side s's ids index table 1-s
         const int s = i >= R, r = i - s * R;
         const int64_t id = a.other_id[s][b * R + r];
         a.gid[1 - s][nself + b * R + r] = id;
@@ -380,8 +387,8 @@ __global__ __launch_bounds__(256) void narre_head_kernel(NarreHead a) {
     }
     __syncthreads();
     // ---- B2: final.1 weight, d interaction -> d v
-    for (int i = tid; i < L * L; i += 256) { const int k = qd(i, invL); prow[head_col(a, a.off[NP_F1W] + i)] = fh[L + k] * cdv[i - k * L]; }
-    for (int l = tid; l < L; l += 256) {
+    for (int i = tid; i < L * L; i += NT) { const int k = qd(i, invL); prow[head_col(a, a.off[NP_F1W] + i)] = fh[L + k] * cdv[i - k * L]; }
+    for (int l = tid; l < L; l += NT) {
         float acc = 0.f;
         for (int k = 0; k < L; ++k) acc = fmaf(fh[L + k], F1[k * (L + 1) + l], acc);
         const float dcat = acc * cdv[L + l];
@@ -390,11 +397,11 @@ __global__ __launch_bounds__(256) void narre_head_kernel(NarreHead a) {
     }
     __syncthreads();
     // ---- B3: self ID rows (compact), d attention weights
-    for (int i = tid; i < L2; i += 256) {
+    for (int i = tid; i < L2; i += NT) {
         const int s = i >= L, l = i - s * L;
         a.grow[s][(size_t)b * L + l] = dv[i] * evm[i];
     }
-    for (int i = tid; i < 2 * R; i += 256) {
+    for (int i = tid; i < 2 * R; i += NT) {
         const int s = i >= R;
         float acc = 0.f;
         for (int l = 0; l < L; ++l) acc = fmaf(dv[s * L + l], x[i * L + l], acc);
@@ -408,7 +415,7 @@ __global__ __launch_bounds__(256) void narre_head_kernel(NarreHead a) {
         misc[7 + tid] = dot;
     }
     __syncthreads();
-    for (int i = tid; i < 2 * R; i += 256) da[i] = sc[i] * (da[i] - misc[7 + (i >= R)]);   // d score
+    for (int i = tid; i < 2 * R; i += NT) da[i] = sc[i] * (da[i] - misc[7 + (i >= R)]);   // d score
     __syncthreads();
     // ---- B5: scorer output layer, d hidden
     if (tid < 2) {
@@ -416,25 +423,25 @@ __global__ __launch_bounds__(256) void narre_head_kernel(NarreHead a) {
         for (int r = 0; r < R; ++r) acc += da[tid * R + r];
         prow[head_col(a, a.off[tid ? NP_AIB3 : NP_AUB3])] = acc;
     }
-    for (int i = tid; i < L2; i += 256) {
+    for (int i = tid; i < L2; i += NT) {
         const int s = i >= L, k = i - s * L;
         float acc = 0.f;
         for (int r = 0; r < R; ++r) acc = fmaf(da[s * R + r], h[(s * R + r) * L + k] * hm[(s * R + r) * L + k], acc);
         prow[head_col(a, a.off[s ? NP_AIW3 : NP_AUW3] + k)] = acc;
     }
-    for (int i = tid; i < 2 * RL; i += 256) {
+    for (int i = tid; i < 2 * RL; i += NT) {
         const int s = i >= RL, rem = i - s * RL, r = qd(rem, invL), k = rem - r * L;
         dz[i] = h[i] > 0.f ? da[s * R + r] * w3[s * L + k] * hm[i] : 0.f;     // d hpre
     }
     __syncthreads();
     // ---- B6: scorer hidden layer gradients, d x (-> d z), d other (compact rows)
-    for (int i = tid; i < L2; i += 256) {
+    for (int i = tid; i < L2; i += NT) {
         const int s = i >= L, k = i - s * L;
         float acc = 0.f;
         for (int r = 0; r < R; ++r) acc += dz[(s * R + r) * L + k];
         prow[head_col(a, a.off[s ? NP_AIB0 : NP_AUB0] + k)] = acc;
     }
-    for (int i = tid; i < 2 * L * L2; i += 256) {
+    for (int i = tid; i < 2 * L * L2; i += NT) {
         const int s = i >= L * L2, rem = i - s * L * L2, k = qd(rem, invL2), j = rem - k * L2;
         float acc = 0.f;
         for (int r = 0; r < R; ++r) {
@@ -443,10 +450,10 @@ __global__ __launch_bounds__(256) void narre_head_kernel(NarreHead a) {
         }
         prow[head_col(a, a.off[s ? NP_AIW0 : NP_AUW0] + k * L2 + j)] = acc;
     }
-    float dzv[(2 * MR * ML + 255) / 256];        // d z of this thread's elements (kept over the barrier)
+    float dzv[(2 * MR * ML + NT - 1) / NT];        // d z of this thread's elements (kept over the barrier)
 #pragma unroll
-    for (int it = 0; it < (2 * MR * ML + 255) / 256; ++it) {
-        const int i = tid + 256 * it;
+    for (int it = 0; it < (2 * MR * ML + NT - 1) / NT; ++it) {
+        const int i = tid + NT * it;
         dzv[it] = 0.f;
         if (i < 2 * RL) {
             const int s = i >= RL, rem = i - s * RL, r = qd(rem, invL), j = rem - r * L;
@@ -462,25 +469,25 @@ __global__ __launch_bounds__(256) void narre_head_kernel(NarreHead a) {
     }
     __syncthreads();
 #pragma unroll
-    for (int it = 0; it < (2 * MR * ML + 255) / 256; ++it) {
-        const int i = tid + 256 * it;
+    for (int it = 0; it < (2 * MR * ML + NT - 1) / NT; ++it) {
+        const int i = tid + NT * it;
         if (i < 2 * RL) dz[i] = dzv[it];
     }
     __syncthreads();
     // ---- B7: TextCNN FC gradients, d pooled
-    for (int i = tid; i < L2; i += 256) {
+    for (int i = tid; i < L2; i += NT) {
         const int s = i >= L, l = i - s * L;
         float acc = 0.f;
         for (int r = 0; r < R; ++r) acc += dz[(s * R + r) * L + l];
         prow[head_col(a, a.off[s ? NP_IFB : NP_UFB] + l)] = acc;
     }
-    for (int i = tid; i < 2 * L * NF; i += 256) {
+    for (int i = tid; i < 2 * L * NF; i += NT) {
         const int s = i >= L * NF, rem = i - s * L * NF, l = rem / NF, f = rem - l * NF;
         float acc = 0.f;
         for (int r = 0; r < R; ++r) acc = fmaf(dz[(s * R + r) * L + l], P[(s * R + r) * NF + f], acc);
         prow[head_col(a, a.off[s ? NP_IFW : NP_UFW] + l * NF + f)] = acc;
     }
-    for (int i = tid; i < 2 * R * NF; i += 256) {
+    for (int i = tid; i < 2 * R * NF; i += NT) {
         const int s = i >= R * NF, rem = i - s * R * NF, r = rem / NF, f = rem - r * NF;
         float acc = 0.f;
         for (int l = 0; l < L; ++l) acc = fmaf(dz[(s * R + r) * L + l], fcw[(s * L + l) * (NF + 1) + f], acc);
@@ -901,13 +908,13 @@ extern "C" int r4r_narre_step(const float *table, int64_t V,
     const bool small = R <= 16 && L <= 16;
     static size_t lds_set[2] = {0, 0};
     if (lds > lds_set[small]) {
-        (void)hipFuncSetAttribute(small ? reinterpret_cast<const void *>(narre_head_kernel<16, 16>)
-                                        : reinterpret_cast<const void *>(narre_head_kernel<32, 32>),
+        (void)hipFuncSetAttribute(small ? reinterpret_cast<const void *>(narre_head_kernel<16, 16, NHEAD_THREADS>)
+                                        : reinterpret_cast<const void *>(narre_head_kernel<32, 32, NHEAD_THREADS>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         lds_set[small] = lds;
     }
-    if (small) narre_head_kernel<16, 16><<<(unsigned)B, 256, lds, st>>>(h);
-    else narre_head_kernel<32, 32><<<(unsigned)B, 256, lds, st>>>(h);
+    if (small) narre_head_kernel<16, 16, NHEAD_THREADS><<<(unsigned)B, NHEAD_THREADS, lds, st>>>(h);
+    else narre_head_kernel<32, 32, NHEAD_THREADS><<<(unsigned)B, NHEAD_THREADS, lds, st>>>(h);
     if (!train_step) return check_launch("narre_step(forward)");
 
     // 4: conv weight gradients + head-parameter column sums (+ next batch's token marks)
