@@ -346,7 +346,9 @@ int r4r_narre_nparam(void);
 int r4r_narre_layout(int E, int L, int64_t *offsets, int64_t *sizes, int64_t *total);
 size_t r4r_narre_ws_bytes(int64_t B, int R, int T, int E, int L, int64_t V, int64_t n_users, int64_t n_items);
 size_t r4r_narre_ws_offset(int64_t B, int R, int T, int E, int L, int64_t V, int64_t n_users, int64_t n_items,
-                           int which);   /* tests: 0 dropout multipliers, 1/2 compact rows user/item, 3/4 their ids, 5 d loss/d pred */
+                           int which);   /* 0 dropout multipliers, 1/2 compact rows user/item, 3/4 their ids, 5 d loss/d pred (tests);
+                                         6 + 2*tower + buffer: compaction counter of a token buffer (zero the int to discard
+                                         a prepared-but-unused token state) */
 int r4r_narre_step(const float *table, int64_t V,
                    const int64_t *user_reviews, const int64_t *item_reviews,
                    const int64_t *reviewed_items, const int64_t *users_who_reviewed,

@@ -800,10 +800,13 @@ extern "C" size_t r4r_narre_ws_bytes(int64_t B, int R, int T, int E, int L, int6
 }
 
 // which: 0 dropout multipliers [B, 4RL+3L]; 1 / 2 compact rows of the user / item table [B(1+R), L];
-// 3 / 4 their ids (int64); 5 d loss / d pred [B]
+// 3 / 4 their ids (int64); 5 d loss / d pred [B]; 6 + 2 * tower + buffer: that token buffer's
+// compaction counter (one int: zero it to discard a prepared-but-unused token state)
 extern "C" size_t r4r_narre_ws_offset(int64_t B, int R, int T, int E, int L, int64_t V, int64_t n_users, int64_t n_items,
                                       int which) {
     const NarreWs w = narre_carve(reinterpret_cast<void *>(256), B, R, T, E, L, V, n_users, n_items);
+    if (which >= 6 && which < 10)
+        return (size_t)(reinterpret_cast<char *>(w.count[(which - 6) & 1][(which - 6) >> 1]) - reinterpret_cast<char *>(256));
     const char *q = which == 0 ? reinterpret_cast<char *>(w.mult) : which == 1 ? reinterpret_cast<char *>(w.grow[0])
                   : which == 2 ? reinterpret_cast<char *>(w.grow[1]) : which == 3 ? reinterpret_cast<char *>(w.gid[0])
                   : which == 4 ? reinterpret_cast<char *>(w.gid[1]) : reinterpret_cast<char *>(w.g);

@@ -563,10 +563,9 @@ class NarreEngine:
         else:
             if self._prepared is not None:                   # a wrong guess: drop its token state
                 pb = self._prepared[1]
-                off = 256 * (-(-self.n_users * 4 // 256) + -(-self.n_items * 4 // 256))
-                vb = 256 * (-(-(self.V + 4) * 4 // 256))
                 for t in range(2):                           # the compaction counters of that buffer
-                    at = off + (t * 2 + pb) * (vb + 256) + vb
+                    at = _lib.lib().r4r_narre_ws_offset(n, R, T, self.E, self.L, self.V, self.n_users, self.n_items,
+                                                        6 + 2 * t + pb)
                     ws[at:at + 4].zero_()
                 self._prepared = None
                 self._last_buf = pb ^ 1

@@ -507,3 +507,43 @@ def test_narre_engine_wide_latent_uses_the_general_instantiation():
         if not ill_conditioned(k):
             diff = (sd[k].cpu() - v).abs()
             assert float((diff > 2e-5 + 1e-4 * v.abs()).float().mean()) < 2e-3 and float(diff.max()) < 5e-4, k
+
+
+def test_narre_engine_token_prefetch_is_bit_identical_with_wrong_guesses():
+    """NARRE: the next batch's token state prepared on the current step's launches (project path)
+    changes no bit; a wrong guess and an eval in between are handled."""
+    import reviews4rec_amd
+    from reviews4rec_amd.engine import NarreEngine
+    B, R, W, E, V, U, I, L = 16, 10, 60, 32, 900, 60, 40, 10
+    hp = dict(model_type='NARRE', latent_size=L, word_embed_size=E, dropout=0.0, total_users=U, total_items=I,
+              lr=0.002, weight_decay=1e-6, narre_num_reviews=R, narre_num_words=W)
+    P = oracle.init_params(hp, vocab_size=V, seed=6)
+
+    def batch(seed):
+        data, y = synthetic_review_batch(B, W, V, U, I, seed=seed, R=R, W=W, device=DEV)
+        g = torch.Generator().manual_seed(seed)
+        data[1] = torch.randint(0, U + 2, (B, R), generator=g).to(DEV)
+        data[2] = torch.randint(0, I + 2, (B, R), generator=g).to(DEV)
+        return data, y
+    batches = [batch(40 + k) for k in range(4)]
+
+    def fresh():
+        m = reviews4rec_amd.get_model_class('NARRE')(dict(hp, word_vectors=P['word2vec.weight'].numpy()))
+        m.load_state_dict(P)
+        return NarreEngine(m.to(DEV).train(), lr=hp['lr'], weight_decay=hp['weight_decay'], conv_algo=2)
+    plain, pre = fresh(), fresh()
+    order = [0, 1, 2, 3, 0, 1, 2, 3, 1, 1]
+    for k, b in enumerate(order):
+        data, y = batches[b]
+        se_a = plain.train_step(data, y).clone()
+        nxt = batches[2][0] if k == 3 else (batches[order[k + 1]][0] if k + 1 < len(order) else None)   # k == 3: wrong
+        se_b = pre.train_step(data, y, next_data=nxt).clone()
+        assert torch.equal(se_a, se_b), k
+        if k == 6:
+            pa, _ = plain.predict(*batches[0])
+            pb, _ = pre.predict(*batches[0])
+            assert torch.equal(pa, pb)
+    torch.cuda.synchronize()
+    assert torch.equal(plain.flat_p, pre.flat_p)
+    for a, c in zip(plain.rows, pre.rows):
+        assert torch.equal(a, c)
