@@ -59,6 +59,8 @@ def parse():
     ap.add_argument('--from-host', action='store_true',
                     help='feed the steps from pinned HOST arrays through data_fast.DataLoader (double-buffered H2D on a '
                          'copy stream) instead of HBM-resident batches: the PCIe-inclusive rate, for DESIGN.md only')
+    ap.add_argument('--model-type', default=None, help="override the workload's recommender (e.g. deepconn++ on the "
+                    "cfg3 shapes)")
     ap.add_argument('--embed', type=int, default=None, help='override word_embed_size (crossover experiments)')
     ap.add_argument('--cpu-seconds', type=float, default=12.0,
                     help='budget of each half (thread calibration, measurement) of the cpu_baseline leg')
@@ -150,6 +152,8 @@ def main():
 
     B = args.batch_per_gpu
     hp = synthetic.hyper_params_for(args.workload, batch_size=B, dropout=args.dropout)
+    if args.model_type:
+        hp['model_type'] = args.model_type
     if args.embed:
         hp['word_embed_size'] = args.embed
     table = synthetic.word_table(hp['vocab'], hp['word_embed_size']) if hp.get('vocab') else None
@@ -186,6 +190,10 @@ def main():
         from reviews4rec_amd.engine import NarreEngine
         engine = NarreEngine(model, lr=hp['lr'], weight_decay=hp['weight_decay'], seed=4321, rank=rank,
                              conv_algo={'auto': 0, 'direct': 1, 'project': 2}[args.conv_algo])
+    if args.engine == 'native' and hp['model_type'] == 'deepconn++' and world == 1:
+        from reviews4rec_amd.engine import DeepCoNNPPEngine
+        engine = DeepCoNNPPEngine(model, lr=hp['lr'], weight_decay=hp['weight_decay'], seed=4321, rank=rank,
+                                  conv_algo={'auto': 0, 'direct': 1, 'project': 2}[args.conv_algo])
     if args.engine == 'native' and hp['model_type'] == 'deepconn':
         from reviews4rec_amd.engine import DeepCoNNEngine
         engine = DeepCoNNEngine(model, lr=hp['lr'], weight_decay=hp['weight_decay'], dp=dp, seed=4321, rank=rank,

@@ -364,6 +364,33 @@ int r4r_narre_step(const float *table, int64_t V,
                    float lr, double beta1, double beta2, float eps, float weight_decay, int64_t adam_step,
                    void *stream);
 
+/* ---- fused native step for DeepCoNN++ (DeepCoNN.py:37-72, model_type 'deepconn++'): the two
+ * TextCNN towers, `final` = Linear(2L, L) -> ReLU -> Dropout -> Linear(L, 1), user / item / global
+ * bias.  Same structure and arguments as r4r_narre_step; user_idx / item_idx [B, T] as in
+ * r4r_deepconn_step.  Flat layout (13 slots, r4r_deepconnpp_layout): user_conv.convs.0.weight, .bias,
+ * user_conv.fc.weight, .bias, item_conv.(same four), final.0.weight, final.0.bias, final.3.weight,
+ * final.3.bias, global_bias.  rows_p / rows_m / rows_v: HOST arrays of 2 DEVICE pointers -- user_bias
+ * [n_users], item_bias [n_items] (n = total + 2).  Dropout draws per rating: user_conv.dropout [L],
+ * item_conv.dropout [L], final.2 [L] at Philox counter offset + b*3L + k.  (The `fm` module the
+ * reference also constructs is unused in this mode and never trained.) */
+int r4r_deepconnpp_nparam(void);
+int r4r_deepconnpp_layout(int E, int L, int64_t *offsets, int64_t *sizes, int64_t *total);
+size_t r4r_deepconnpp_ws_bytes(int64_t B, int T, int E, int L, int64_t V, int64_t n_users, int64_t n_items);
+size_t r4r_deepconnpp_ws_offset(int64_t B, int T, int E, int L, int64_t V, int64_t n_users, int64_t n_items,
+                                int which);   /* 0 dropout multipliers [B,3L], 5 d loss/d pred, 6 + 2*tower + buffer: token counter */
+int r4r_deepconnpp_step(const float *table, int64_t V, const int64_t *user_idx, const int64_t *item_idx,
+                        const int64_t *uid, const int64_t *iid, const float *y,
+                        float *flat_p, float *flat_g, float *flat_m, float *flat_v,
+                        const uint64_t *rows_p, const uint64_t *rows_m, const uint64_t *rows_v,
+                        int64_t n_users, int64_t n_items,
+                        float *pred, float *se, float *sse_accum, void *ws, size_t ws_bytes,
+                        int64_t B, int T, int E, int L,
+                        float dropout_p, int training, uint64_t seed, uint64_t offset, float inv_denom,
+                        int conv_algo, int token_buffer, int tokens_ready,
+                        const int64_t *next_user_idx, const int64_t *next_item_idx,
+                        float lr, double beta1, double beta2, float eps, float weight_decay, int64_t adam_step,
+                        void *stream);
+
 /* proj_gather_max_kernel (gather-add-max over positions) */
 #define R4R_TIMING_SLOTS 8
 int r4r_timing_enable(int slot_mask);   /* bit i instruments slot i; 0 switches timing off */

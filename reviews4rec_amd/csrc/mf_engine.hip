@@ -237,9 +237,11 @@ __global__ __launch_bounds__(MF_THREADS) void mf_adam_kernel(MfSweep w) {
         __syncthreads();
         for (int off = MF_THREADS / 2; off > 0; off >>= 1) { if (tid < off) red[tid] += red[tid + off]; __syncthreads(); }
         if (tid == 0) {
-            float P = w.p4[0], M = w.m4[0], V = w.v4[0];
-            adam_elem(P, gsum, M, V, w.s);
-            w.p4[0] = P; w.m4[0] = M; w.v4[0] = V;
+            if (w.p4) {                                     // (absent when the caller keeps its global bias elsewhere)
+                float P = w.p4[0], M = w.m4[0], V = w.v4[0];
+                adam_elem(P, gsum, M, V, w.s);
+                w.p4[0] = P; w.m4[0] = M; w.v4[0] = V;
+            }
             if (w.sse_accum) w.sse_accum[0] += red[0];
         }
         return;
@@ -350,6 +352,34 @@ static MfWs mf_carve(void *ws, int64_t B, int D, int64_t n_users, int64_t n_item
     w.mult = reinterpret_cast<float *>(take((size_t)B * 2 * D * 4));
     w.bytes = o;
     return w;
+}
+
+// Adam on two ID bias vectors whose gradient is d loss / d pred of the ratings that name the id
+// (DeepCoNN++'s user_bias / item_bias, DeepCoNN.py:69-71): the D = 0 form of the sweep above --
+// untouched elements take the gradient-zero update, a touched element the fixed-order sum of its
+// ratings.  `tag_*`: per-element step tags the caller's forward kernel set to `now`.
+int mf_bias_rows_launch(float *ub, float *ub_m, float *ub_v, float *ib, float *ib_m, float *ib_v,
+                        int64_t n_users, int64_t n_items, const int64_t *uid, const int64_t *iid, const float *g,
+                        const int *tag_u, const int *tag_i, int64_t B, int now, const AdamScalars &sc, hipStream_t st) {
+    if (B > MF_MAX_B) {
+        set_error("bias rows: batch %lld > %d", (long long)B, MF_MAX_B);
+        return R4R_ERR_ARG;
+    }
+    MfSweep sw{};
+    sw.p2 = ub; sw.m2 = ub_m; sw.v2 = ub_v; sw.p3 = ib; sw.m3 = ib_m; sw.v3 = ib_v;
+    sw.n0 = sw.n1 = 0; sw.n2 = n_users; sw.n3 = n_items;
+    int64_t chunks = 0;
+    sw.cb1 = sw.cb2 = 0;                                    // no tables: slots 0, 1 are empty
+    chunks += cdiv(n_users, mf_chunk(2));
+    sw.cb3 = (int)chunks;
+    chunks += cdiv(n_items, mf_chunk(3));
+    sw.cb_global = (int)chunks;                             // no global-bias workgroup either
+    sw.cb_entries = (int)chunks;
+    chunks += 2 * cdiv(B, 4);
+    sw.uid = uid; sw.iid = iid; sw.g = g; sw.se = nullptr; sw.sse_accum = nullptr;
+    sw.tag_u = tag_u; sw.tag_i = tag_i; sw.B = B; sw.D = 0; sw.now = now; sw.s = sc;
+    mf_adam_kernel<<<(unsigned)chunks, MF_THREADS, (size_t)B * sizeof(int), st>>>(sw);
+    return check_launch("bias rows");
 }
 
 }  // namespace r4r

@@ -465,12 +465,14 @@ class NarreEngine:
              'attention_scorer_item.3.weight', 'attention_scorer_item.3.bias', 'final.1.weight', 'final.1.bias',
              'final.3.weight', 'final.3.bias', 'global_bias']
     ROW_NAMES = ['user_embedding.weight', 'item_embedding.weight', 'user_bias', 'item_bias']
+    MODEL_TYPE = 'NARRE'
+    C = 'narre'                  # prefix of the C entry points
 
     def __init__(self, model, lr=0.002, weight_decay=1e-6, betas=(0.9, 0.999), eps=1e-8, seed=0x5EED5EED, rank=0,
                  conv_algo=0):
         hp = model.hyper_params
-        if hp['model_type'] != 'NARRE':
-            raise ValueError("NarreEngine implements model_type 'NARRE', got %r" % (hp['model_type'],))
+        if hp['model_type'] != self.MODEL_TYPE:
+            raise ValueError('%s implements model_type %r, got %r' % (type(self).__name__, self.MODEL_TYPE, hp['model_type']))
         self.model, self.hp = model, hp
         self.conv_algo = int(conv_algo)
         self.lr, self.wd, self.betas, self.eps = float(lr), float(weight_decay), tuple(betas), float(eps)
@@ -481,9 +483,9 @@ class NarreEngine:
         self.V, self.E = self.table.shape
         self.L = int(hp['latent_size'])
         lib = _lib.lib()
-        n = lib.r4r_narre_nparam()
+        n = getattr(lib, 'r4r_%s_nparam' % self.C)()
         off, size, total = (ctypes.c_int64 * n)(), (ctypes.c_int64 * n)(), ctypes.c_int64()
-        _lib.check(lib.r4r_narre_layout(self.E, self.L, off, size, ctypes.byref(total)), 'r4r_narre_layout')
+        _lib.check(getattr(lib, 'r4r_%s_layout' % self.C)(self.E, self.L, off, size, ctypes.byref(total)), 'layout')
         params = dict(model.named_parameters())
         self.slots = [params[k] for k in self.NAMES]
         self.offsets, self.sizes, self.total = list(off), list(size), int(total.value)
@@ -501,7 +503,7 @@ class NarreEngine:
             raise RuntimeError('NarreEngine: fp32 contiguous ID tables / bias vectors only')
         self.rows_m = [torch.zeros_like(p) for p in self.rows]
         self.rows_v = [torch.zeros_like(p) for p in self.rows]
-        self.n_users, self.n_items = self.rows[2].numel(), self.rows[3].numel()
+        self.n_users, self.n_items = self.rows[-2].numel(), self.rows[-1].numel()
         self.sse = torch.zeros(1, dtype=torch.float32, device=self.dev)
         self.step_count = 0
         self.seed = (int(seed) * 0x9E3779B97F4A7C15 + int(rank) * 0xD1B54A32D192ED03) & 0xFFFFFFFFFFFFFFFF
@@ -534,7 +536,7 @@ class NarreEngine:
             cache = self.__dict__.setdefault('_ws_cache', {})
             nxt = cache.get(key)
             if nxt is None:
-                nb = _lib.lib().r4r_narre_ws_bytes(B, R, T, self.E, self.L, self.V, self.n_users, self.n_items)
+                nb = self._ws_bytes(B, R, T)
                 nxt = cache[key] = torch.zeros(max(nb, 256), dtype=torch.uint8, device=self.dev)
             if self._ws is not None:                         # the row tags head the buffer: shared state
                 keep = 256 * (-(-self.n_users * 4 // 256) + -(-self.n_items * 4 // 256))
@@ -542,6 +544,27 @@ class NarreEngine:
             self._ws, self._ws_key = nxt, key
             self._prepared = None                            # token state lived in the other workspace
         return self._ws
+
+    def _ws_bytes(self, B, R, T):
+        return _lib.lib().r4r_narre_ws_bytes(B, R, T, self.E, self.L, self.V, self.n_users, self.n_items)
+
+    def _ws_offset(self, B, R, T, which):
+        return _lib.lib().r4r_narre_ws_offset(B, R, T, self.E, self.L, self.V, self.n_users, self.n_items, which)
+
+    def _draws(self, R):
+        return 4 * R * self.L + 3 * self.L                   # dropout draws per rating
+
+    def _step(self, f, y, pred, se, ws, n, R, T, train_mode, inv_denom, adam_step, buf, ready, nxt):
+        return _lib.lib().r4r_narre_step(
+            ptr(self.table), self.V, ptr(f[0]), ptr(f[1]), ptr(f[2]), ptr(f[3]), ptr(f[4]), ptr(f[5]), ptr(y),
+            ptr(self.flat_p), ptr(self.flat_g) if adam_step else None, ptr(self.flat_m) if adam_step else None,
+            ptr(self.flat_v) if adam_step else None, self._p4(self.rows),
+            self._p4(self.rows_m) if adam_step else None, self._p4(self.rows_v) if adam_step else None,
+            self.n_users, self.n_items, ptr(pred), ptr(se), ptr(self.sse) if adam_step else None,
+            ptr(ws), ws.numel(), n, R, T, self.E, self.L, float(self.hp['dropout']), int(train_mode), self.seed,
+            self.offset, float(inv_denom), self.conv_algo, buf, ready,
+            ptr(nxt[0]) if nxt else None, ptr(nxt[1]) if nxt else None,
+            self.lr, self.betas[0], self.betas[1], self.eps, self.wd, int(adam_step), _lib.current_stream())
 
     def _launch(self, data, y, train_mode, inv_denom, adam_step, next_data=None):
         f, n, R, T = self._fields(data)
@@ -564,28 +587,18 @@ class NarreEngine:
             if self._prepared is not None:                   # a wrong guess: drop its token state
                 pb = self._prepared[1]
                 for t in range(2):                           # the compaction counters of that buffer
-                    at = _lib.lib().r4r_narre_ws_offset(n, R, T, self.E, self.L, self.V, self.n_users, self.n_items,
-                                                        6 + 2 * t + pb)
+                    at = self._ws_offset(n, R, T, 6 + 2 * t + pb)
                     ws[at:at + 4].zero_()
                 self._prepared = None
                 self._last_buf = pb ^ 1
             buf = self._last_buf ^ 1
-        rc = _lib.lib().r4r_narre_step(
-            ptr(self.table), self.V, ptr(f[0]), ptr(f[1]), ptr(f[2]), ptr(f[3]), ptr(f[4]), ptr(f[5]), ptr(y),
-            ptr(self.flat_p), ptr(self.flat_g) if adam_step else None, ptr(self.flat_m) if adam_step else None,
-            ptr(self.flat_v) if adam_step else None, self._p4(self.rows),
-            self._p4(self.rows_m) if adam_step else None, self._p4(self.rows_v) if adam_step else None,
-            self.n_users, self.n_items, ptr(pred), ptr(se), ptr(self.sse) if adam_step else None,
-            ptr(ws), ws.numel(), n, R, T, self.E, self.L, float(self.hp['dropout']), int(train_mode), self.seed,
-            self.offset, float(inv_denom), self.conv_algo, buf, ready,
-            ptr(nxt[0]) if nxt else None, ptr(nxt[1]) if nxt else None,
-            self.lr, self.betas[0], self.betas[1], self.eps, self.wd, int(adam_step), _lib.current_stream())
-        _lib.check(rc, 'r4r_narre_step')
+        rc = self._step(f, y, pred, se, ws, n, R, T, train_mode, inv_denom, adam_step, buf, ready, nxt)
+        _lib.check(rc, 'r4r_%s_step' % self.C)
         self._last_buf = buf
         if nxt is not None:
             self._prepared = ((nxt[0].data_ptr(), nxt[1].data_ptr(), n, R, T), buf ^ 1, nxt)
         if train_mode and float(self.hp['dropout']) > 0.0:
-            self.offset += n * (4 * R * self.L + 3 * self.L)
+            self.offset += n * self._draws(R)
         return pred, se
 
     @torch.no_grad()
@@ -607,15 +620,15 @@ class NarreEngine:
 
     def _ws_view(self, data, which, cols, dtype=torch.float32):
         f, n, R, T = self._fields(data)
-        off = _lib.lib().r4r_narre_ws_offset(n, R, T, self.E, self.L, self.V, self.n_users, self.n_items, which)
+        off = self._ws_offset(n, R, T, which)
         rows = n if which in (0, 5) else n * (1 + R)
         item = 8 if dtype == torch.int64 else 4
         return self._workspace(n, R, T)[off:off + rows * cols * item].view(dtype).view(rows, cols)
 
     def dropout_multipliers(self, data):
         """[B, 4RL + 3L] multipliers the last training step drew (site-major, include/r4r.h)."""
-        R = data[3].shape[-2]
-        return self._ws_view(data, 0, 4 * R * self.L + 3 * self.L).clone()
+        f, n, R, T = self._fields(data)
+        return self._ws_view(data, 0, self._draws(R)).clone()
 
     def grads(self, data):
         """Gradients of the LAST training step by reference parameter name; the ID-table / bias
@@ -654,3 +667,58 @@ class NarreEngine:
         for ws in self.__dict__.get('_ws_cache', {}).values():
             ws.zero_()
         self._prepared = None
+
+
+class DeepCoNNPPEngine(NarreEngine):
+    """Native step for DeepCoNN++ (model_type 'deepconn++': TextCNN towers + `final` MLP + ID
+    biases; csrc/narre_engine.hip, r4r_deepconnpp_step).  Shares NarreEngine's machinery: flat
+    dense buffer aliased by the module's Parameters, the two ID bias vectors updated by a tagged
+    sweep, token double-buffering.  The reference's `fm` module is constructed but unused in this
+    mode (DeepCoNN.py:64-72) and is left alone."""
+    NAMES = ['user_conv.convs.0.weight', 'user_conv.convs.0.bias', 'user_conv.fc.weight', 'user_conv.fc.bias',
+             'item_conv.convs.0.weight', 'item_conv.convs.0.bias', 'item_conv.fc.weight', 'item_conv.fc.bias',
+             'final.0.weight', 'final.0.bias', 'final.3.weight', 'final.3.bias', 'global_bias']
+    ROW_NAMES = ['user_bias', 'item_bias']
+    MODEL_TYPE = 'deepconn++'
+    C = 'deepconnpp'
+
+    def _fields(self, data):
+        n = data[5].numel()
+        f = [data[3].reshape(n, -1), data[4].reshape(n, -1), data[5].reshape(-1), data[6].reshape(-1)]
+        if f[0].shape != f[1].shape:
+            raise RuntimeError('DeepCoNNPPEngine: user and item documents must share input_length')
+        if not all(t.is_cuda and t.dtype == torch.int64 for t in f):
+            raise RuntimeError('DeepCoNNPPEngine: batches must be int64 tensors on the ROCm device')
+        return [t.contiguous() for t in f], n, 1, f[0].shape[1]
+
+    def _ws_bytes(self, B, R, T):
+        return _lib.lib().r4r_deepconnpp_ws_bytes(B, T, self.E, self.L, self.V, self.n_users, self.n_items)
+
+    def _ws_offset(self, B, R, T, which):
+        return _lib.lib().r4r_deepconnpp_ws_offset(B, T, self.E, self.L, self.V, self.n_users, self.n_items, which)
+
+    def _draws(self, R):
+        return 3 * self.L
+
+    def _step(self, f, y, pred, se, ws, n, R, T, train_mode, inv_denom, adam_step, buf, ready, nxt):
+        p2 = lambda ts: (ctypes.c_uint64 * 2)(*[t.data_ptr() for t in ts])   # noqa: E731
+        return _lib.lib().r4r_deepconnpp_step(
+            ptr(self.table), self.V, ptr(f[0]), ptr(f[1]), ptr(f[2]), ptr(f[3]), ptr(y),
+            ptr(self.flat_p), ptr(self.flat_g) if adam_step else None, ptr(self.flat_m) if adam_step else None,
+            ptr(self.flat_v) if adam_step else None, p2(self.rows),
+            p2(self.rows_m) if adam_step else None, p2(self.rows_v) if adam_step else None,
+            self.n_users, self.n_items, ptr(pred), ptr(se), ptr(self.sse) if adam_step else None,
+            ptr(ws), ws.numel(), n, T, self.E, self.L, float(self.hp['dropout']), int(train_mode), self.seed,
+            self.offset, float(inv_denom), self.conv_algo, buf, ready,
+            ptr(nxt[0]) if nxt else None, ptr(nxt[1]) if nxt else None,
+            self.lr, self.betas[0], self.betas[1], self.eps, self.wd, int(adam_step), _lib.current_stream())
+
+    def grads(self, data):
+        out = {k: self.flat_g[o:o + s].view(p.shape) for k, p, o, s in
+               zip(self.NAMES, self.slots, self.offsets, self.sizes)}
+        f, n, R, T = self._fields(data)
+        off = self._ws_offset(n, R, T, 5)
+        g = self._workspace(n, R, T)[off:off + n * 4].view(torch.float32)
+        out['user_bias'] = torch.zeros_like(self.rows[0]).index_add_(0, f[2], g)
+        out['item_bias'] = torch.zeros_like(self.rows[1]).index_add_(0, f[3], g)
+        return out

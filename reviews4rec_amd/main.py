@@ -7,8 +7,8 @@ and ``metrics['MSE'] = round(sum SE / N, 4)`` (main.py:66).  Two deliberate host
 differences, both numerically neutral: the running sum of SE stays on the device and
 is read once per epoch (the reference syncs with ``float(torch.sum(..))`` every
 batch, main.py:57), and ``optimizer`` is this package's fused Adam (same surface).
-``hyper_params['engine']`` (default 'auto'): models with a fused native step (DeepCoNN 'deepconn',
-NARRE, MF_dot, bias_only) run the whole sequence as one native call per batch; the others run the
+``hyper_params['engine']`` (default 'auto'): models with a fused native step (DeepCoNN 'deepconn' and
+'deepconn++', NARRE, MF_dot, bias_only) run the whole sequence as one native call per batch; the others run the
 op-by-op step captured once into a hipGraph and replayed ('module' forces plain eager).
 
 TransNet's three-optimiser step (main.py:35-53) raises on torch >= 1.5 in the
@@ -155,6 +155,12 @@ def make_engine(hyper_params, model, dp=None, rank=0):
         from .engine import NarreEngine
         return NarreEngine(model, lr=hyper_params['lr'], weight_decay=hyper_params['weight_decay'],
                            seed=hyper_params.get('seed', 0x5EED5EED), rank=rank)
+    if hyper_params['model_type'] == 'deepconn++':
+        if (dp is not None and dp.on) or int(hyper_params.get('batch_size', 128)) > 16384:
+            return None
+        from .engine import DeepCoNNPPEngine
+        return DeepCoNNPPEngine(model, lr=hyper_params['lr'], weight_decay=hyper_params['weight_decay'],
+                                seed=hyper_params.get('seed', 0x5EED5EED), rank=rank)
     if hyper_params['model_type'] != 'deepconn':
         return None
     from .engine import DeepCoNNEngine

@@ -609,3 +609,68 @@ def test_native_engines_long_run_stays_consistent_and_learns(kind):
     sa, sb = plain.model.state_dict(), told.model.state_dict()
     for k_ in sa:
         assert torch.equal(sa[k_], sb[k_]), k_
+
+
+# ------------------------------------------------------------------------------ DeepCoNN++ native step
+def test_deepconnpp_engine_matches_reference_golden():
+    """r4r_deepconnpp_step: eval outputs, then the reference-generated 3-step trajectory (SE, every
+    gradient of step 0, weights after 1 and 3 steps, Adam moments); `fm`, unused in this mode, never moves."""
+    from reviews4rec_amd.engine import DeepCoNNPPEngine
+    g = Golden('deepconnpp_e20')
+    model, hp = build_model(g)
+    eng = DeepCoNNPPEngine(model.eval())
+    for k in (0, 1):
+        data, y = g.batch(k, DEV)
+        pred, _ = eng.predict(data, y)
+        torch.testing.assert_close(pred.cpu(), g.arr('eval%d' % k), rtol=1e-5, atol=1e-5)
+    pred, _ = eng.predict(g.neg_batch(DEV))
+    torch.testing.assert_close(pred.cpu(), g.arr('neg_eval'), rtol=1e-5, atol=1e-5)
+    for algo in ALGOS:
+        model, hp = build_model(g)
+        model.train()
+        eng = DeepCoNNPPEngine(model, lr=hp['lr'], weight_decay=hp['weight_decay'], conv_algo=algo)
+        total = 0.0
+        for step in range(3):
+            data, y = g.batch(step % 2, DEV)
+            se = eng.train_step(data, y, next_data=g.batch((step + 1) % 2, DEV)[0]).clone()
+            torch.testing.assert_close(se.cpu(), g.arr('se%d' % step), rtol=1e-4, atol=1e-5)
+            total += float(g.arr('se%d' % step).sum())
+            if step == 0:
+                got, ref_g = eng.grads(data), g.group('g0')
+                assert set(got) == set(ref_g)
+                for k, v in ref_g.items():
+                    torch.testing.assert_close(got[k].cpu(), v, rtol=1e-4, atol=1e-7, msg=lambda m: k + ': ' + m)
+            if step in (0, 2):
+                sd = model.state_dict()
+                for k, v in g.params('w%d' % (step + 1)).items():
+                    torch.testing.assert_close(sd[k].cpu(), v, rtol=1e-5, atol=5e-6, msg=lambda m: k + ': ' + m)
+        m, v = eng.moments()
+        for k, ref in g.group('m3').items():
+            torch.testing.assert_close(m[k].cpu(), ref, rtol=1e-4, atol=1e-7, msg=lambda mm: k + ': ' + mm)
+        for k, ref in g.group('v3').items():
+            torch.testing.assert_close(v[k].cpu(), ref, rtol=1e-4, atol=1e-10, msg=lambda mm: k + ': ' + mm)
+        torch.testing.assert_close(eng.sse.cpu()[0], torch.tensor(total), rtol=1e-5, atol=1e-4)
+
+
+def test_deepconnpp_engine_dropout_masks_injected_into_oracle():
+    from reviews4rec_amd.engine import DeepCoNNPPEngine
+    g = Golden('deepconnpp_e20')
+    model, hp = build_model(g, dropout=0.5)
+    model.train()
+    eng = DeepCoNNPPEngine(model, lr=hp['lr'], weight_decay=hp['weight_decay'])
+    P = {k: v.clone() for k, v in g.params().items()}
+    state = oracle.AdamState()
+    L = hp['latent_size']
+    for step in range(2):
+        data, y = g.batch(0, DEV)
+        se = eng.train_step(data, y).cpu().clone()
+        mult = eng.dropout_multipliers(data).cpu()
+        assert 0.25 < float((mult == 0).float().mean()) < 0.75
+        masks = {'user_conv.dropout': mult[:, :L], 'item_conv.dropout': mult[:, L:2 * L], 'final.2': mult[:, 2 * L:]}
+        cpu_data, cpu_y = g.batch(0)
+        sse, _ = oracle.train_step(P, cpu_data, cpu_y, dict(hp), state, masks=masks)
+        torch.testing.assert_close(se.sum(), torch.tensor(sse), rtol=1e-4, atol=1e-4)
+    sd = model.state_dict()
+    for k, v in P.items():
+        diff = (sd[k].cpu() - v).abs()
+        assert float((diff > 2e-5 + 1e-4 * v.abs()).float().mean()) < 2e-3 and float(diff.max()) < 5e-4, k
