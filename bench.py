@@ -183,7 +183,7 @@ def main():
     B_global = B * world
 
     engine = None
-    if args.engine == 'native' and hp['model_type'] in ('MF_dot', 'bias_only') and world == 1 and B <= 1024:
+    if args.engine == 'native' and hp['model_type'] in ('MF_dot', 'bias_only') and world == 1 and B <= 16384:
         from reviews4rec_amd.engine import MFEngine
         engine = MFEngine(model, lr=hp['lr'], weight_decay=hp['weight_decay'], seed=4321, rank=rank)
     if args.engine == 'native' and hp['model_type'] == 'NARRE' and world == 1:

@@ -307,10 +307,13 @@ int r4r_deepconn_tokens(const int64_t *user_idx, const int64_t *item_idx, void *
  *               m == v == NULL: forward only (pred, and se when y is given).
  *   dropout   : Philox4x32-10(seed, offset + b*2D + d) for the user row, + D for the item row
  *   adam_step : 1-based update count; also tags the rows this step touched (workspace)
- *   ws        : r4r_mf_ws_bytes; its first bytes (the row tags) must be ZERO on first use and
- *               are kept consistent by the kernels -- allocate once, zero once.
+ *   ws        : r4r_mf_ws_bytes; its first r4r_mf_ws_persist_bytes (per-row step tags and the
+ *               owner-election slots) must be ZERO on first use and are kept consistent by the
+ *               kernels as long as adam_step only grows -- allocate once, zero once; a caller
+ *               that switches buffers (another B) carries that head over.
  *   B <= 16384 for training steps.  sse_accum (nullable) += sum_b se[b] on training steps. */
 size_t r4r_mf_ws_bytes(int64_t B, int D, int64_t n_users, int64_t n_items);
+size_t r4r_mf_ws_persist_bytes(int64_t B, int D, int64_t n_users, int64_t n_items);
 size_t r4r_mf_ws_mult_offset(int64_t B, int D, int64_t n_users, int64_t n_items);   /* [B,2D] dropout multipliers (tests) */
 size_t r4r_mf_ws_grad_offset(int64_t B, int D, int64_t n_users, int64_t n_items, int which);   /* 0: user rows [B,D], 1: item rows, 2: d loss/d pred [B] (tests) */
 int r4r_mf_step(const int64_t *uid, const int64_t *iid, const float *y,

@@ -6,15 +6,20 @@
 //   1. mf_fwd_bwd_kernel   one wave per rating: gathers, Philox dropout, dot, prediction, SE,
 //                          and the rating's gradient rows kept COMPACT ([B, D] per table + the
 //                          scalar d loss / d pred); marks the rows it touched with the step's tag
+//                          and elects, per touched row, its first and last rating (atomicMax on
+//                          (step, ~rating) / (step, rating): the result does not depend on order)
 //   2. mf_adam_kernel      every parameter moves every step (L2 weight decay), but
 //                          the dense table gradient is never materialised.  Two kinds of workgroup:
 //                          SWEEP workgroups stream every element (24 B: read p, m, v, write p, m, v)
 //                          and give the rows no rating touched (tag != this step) the gradient-zero
-//                          update; ENTRY waves, one per rating and side, scan the batch's ids (LDS),
-//                          and the first entry of a row sums that row's gradient rows -- four
-//                          interleaved accumulators of entries taken in ascending order, combined in
-//                          a fixed order: deterministic, no atomics -- and updates the table row and
-//                          its bias element.
+//                          update; ENTRY waves take the ratings: the FIRST rating of a row owns it
+//                          and applies the sum of the row's gradient rows -- a row named once
+//                          directly (a lane group of D / 4 lanes per rating, four ratings per wave
+//                          at D = 64), a row named several times by scanning the batch's ids
+//                          between its first and last rating and accumulating the matches in
+//                          ascending order into fixed accumulators, combined in a fixed order:
+//                          deterministic, no float atomics -- and updates the table row and its
+//                          bias element.
 //
 // The op-by-op module path needs ~25 launches and a zero-filled dense gradient per table for the
 // same step (28 B/element + the fill); on Amazon-Electronics-sized tables (16.6 M parameters)
@@ -28,6 +33,12 @@ constexpr int MF_MAX_D = 256;          // latent size: <= 4 elements per lane of
 constexpr int MF_SLOTS = 5;            // user table, item table, user bias, item bias, global bias
 constexpr int MF_MAX_B = 16384;        // the entry waves keep a side's ids in LDS (4 B each)
 
+// Owner election: every rating atomicMax-es (step, ~rating number) into its rows' slots; the slot
+// then names the row's FIRST rating of this step (any order of arrival gives the same result).
+__host__ __device__ inline unsigned long long mf_first_pack(int step, int64_t k) {
+    return ((unsigned long long)(unsigned)step << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)k);
+}
+
 struct MfStep {
     const int64_t *uid, *iid;          // [B]
     const float *y;                    // [B] or NULL
@@ -39,6 +50,9 @@ struct MfStep {
     float *g;                          // [B] d mean(SE) / d pred
     float *mult;                       // [B, 2D] dropout multipliers
     int *tag_u, *tag_i;                // [U+1], [I+1]: step tag of the last step that touched the row
+    unsigned long long *first_u, *first_i;   // [U+1], [I+1]: mf_first_pack of the row's first rating
+    unsigned long long *last_u, *last_i;     // [U+1], [I+1]: (step << 32 | the row's last rating)
+    int *uid32, *iid32;                      // [B] compact copies of the ids
     float *pred, *se, *sse_accum;
     int64_t B;
     int D, training, want_grad, tag;
@@ -87,6 +101,13 @@ __global__ __launch_bounds__(256) void mf_fwd_bwd_kernel(MfStep a) {
         a.g[b] = g;
         a.tag_u[u] = a.tag;
         a.tag_i[i] = a.tag;
+        atomicMax(a.first_u + u, mf_first_pack(a.tag, b));
+        atomicMax(a.first_i + i, mf_first_pack(a.tag, b));
+        const unsigned long long lastv = ((unsigned long long)(unsigned)a.tag << 32) | (unsigned long long)b;
+        atomicMax(a.last_u + u, lastv);
+        atomicMax(a.last_i + i, lastv);
+        a.uid32[b] = (int)u;
+        a.iid32[b] = (int)i;
     }
 #pragma unroll
     for (int k = 0; k < MF_MAX_D / 64; ++k) {
@@ -111,6 +132,10 @@ struct MfSweep {
     float *v0, *v1, *v2, *v3, *v4;
     int64_t n0, n1, n2, n3;            // elements of the tables and bias vectors
     int cb1, cb2, cb3, cb_global, cb_entries;   // first workgroup of slots 1..3, of the global-bias group, of the entry waves
+    int n_entry_wgs, epw;              // entry workgroups (both sides); entries per wave
+    const unsigned long long *first_u, *first_i;   // per row: (step << 32 | ~first rating), or NULL (entry waves scan LDS ids)
+    const unsigned long long *last_u, *last_i;     // per row: (step << 32 | last rating)
+    const int *uid32, *iid32;                      // the batch's ids, compact (with first_*)
     const int64_t *uid, *iid;
     const float *gu, *gi, *g, *se;
     float *sse_accum;
@@ -120,87 +145,183 @@ struct MfSweep {
     AdamScalars s;
 };
 
+// entries per wave: one up to batch 1024, then enough that a side has <= 256 workgroups (each stages
+// the side's B ids in LDS once)
+static int mf_epw(int64_t B) { return (int)(B <= 1024 ? 1 : (B + 1023) / 1024); }
+
 __host__ __device__ inline int mf_chunk(int t) { return t < 2 ? MF_CHUNK : MF_CHUNK_BIAS; }
 
-__global__ __launch_bounds__(MF_THREADS) void mf_adam_kernel(MfSweep w) {
-    extern __shared__ int sid[];                            // entry waves: the side's ids
-    __shared__ float red[MF_THREADS];
-    const int bx = (int)blockIdx.x, tid = threadIdx.x;
-    if (bx >= w.cb_entries) {
-        // ---- entry waves: 4 per workgroup, all of one side (user side's groups first)
-        const int lane = tid & 63;
-        const int groups = (int)((w.B + 3) / 4);
-        int gi = bx - w.cb_entries;
-        const int t = gi >= groups;
-        if (t) gi -= groups;
-        const int64_t *ids = t ? w.iid : w.uid;
-        for (int64_t j = tid; j < w.B; j += MF_THREADS) sid[j] = (int)ids[j];
-        __syncthreads();
-        const int64_t k = (int64_t)gi * 4 + (tid >> 6);
-        if (k >= w.B) return;                               // whole wave
-        const int row = sid[k];
-        const int nch = (int)((w.B + 63) / 64), kc = (int)(k / 64);
-        // is k the first entry of its row?  (chunks up to k's own)
-        for (int c = 0; c <= kc; ++c) {
+// the wide form of the entry waves applies (see mf_entry)
+__host__ __device__ inline bool mf_wide(int D, const float *p, const float *m, const float *v) {
+    const int lpr = D >> 2;
+    return D >= 4 && (D & 3) == 0 && lpr <= 64 && (lpr & (lpr - 1)) == 0 &&
+           (((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(m) | reinterpret_cast<uintptr_t>(v)) & 15) == 0);
+}
+
+// One entry of the batch (rating k's id on side t), run by one wave: nothing to do unless k is the
+// FIRST entry of its row; the first entry owns the row and applies the sum of the row's entries.
+//
+// Ownership and the scan range come from the forward kernel's election slots when the caller has
+// them (`first` / `last`: a row named once needs no scan at all, one named twice is scanned
+// between its two ratings) -- ids are then read from the compact int32 copy in global memory,
+// eight 64-id chunks per round trip; otherwise (`sid`: the side's ids staged in LDS) by scanning.
+//
+// The row's entries, in ascending order, are appended to a per-wave pending list (LDS) chunk by
+// chunk and consumed `cap` at a time, so entry number r of the row always lands in the same lane
+// group and accumulator; accumulators, then lane groups, are combined in a fixed order:
+// deterministic, no atomics.
+//   wide form (D % 4 == 0, D / 4 a power of two): D / 4 lanes read one gradient row as float4, so
+//     the wave reads epl = 256 / D entries per load instruction, eight instructions in flight (a
+//     popular item in a batch of thousands has > 1000 entries: not one dependent load each);
+//   generic form: lanes are columns (lane, lane + 64, ...), four entries in flight.
+template <int NACC>
+__device__ __forceinline__ void mf_entry(const MfSweep &w, const int *sid, int *pl, int t, int64_t k, int lane) {
+    const unsigned long long *first = t ? w.first_i : w.first_u;
+    const int *gid = t ? w.iid32 : w.uid32;
+    const int kc = (int)(k / 64);
+    int row, c_end = (int)((w.B + 63) / 64);                // chunks [kc, c_end) hold the row's entries
+    bool single = false;
+    if (first) {
+        row = gid[k];
+        if (first[row] != mf_first_pack(w.now, k)) return;
+        const unsigned last_k = (unsigned)(t ? w.last_i : w.last_u)[row];   // low word: the row's last rating
+        single = last_k == (unsigned)k;
+        c_end = (int)(last_k / 64u) + 1;
+    } else {
+        row = sid[k];
+        for (int c = 0; c <= kc; ++c) {                     // chunks up to k's own
             const int j = c * 64 + lane;
             const unsigned long long mask = __ballot(j < w.B && sid[j] == row);
             if (mask && (int64_t)c * 64 + (__ffsll((long long)mask) - 1) < k) return;   // an earlier entry owns the row
         }
-        // owner: the row's entries in ascending order, dealt round-robin to four accumulators whose
-        // loads are in flight together; lanes are columns (lane, lane + 64, ...)
-        const int D = w.D;
-        const float *rows = t ? w.gi : w.gu;
+    }
+    const int D = w.D;
+    const float *rows = t ? w.gi : w.gu;
+    const int last_j = (int)w.B - 1;
+
+    // scan chunks [kc, c_end), appending matches to pl and handing `cap` of them at a time to flush(base, n)
+    auto scan = [&](auto &&flush, int cap) {
+        if (single) {                                       // the row's only rating: nothing to look for
+            if (lane == 0) pl[0] = (int)k;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            flush(0, 1);
+            return;
+        }
+        int np = 0;
+        for (int c = kc; c < c_end; c += NACC) {
+            int idv[NACC];
+#pragma unroll
+            for (int q = 0; q < NACC; ++q) {                // clamped addresses: the loads stay unconditional
+                const int j = (c + q) * 64 + lane;
+                const int jj = j < last_j ? j : last_j;
+                idv[q] = first ? gid[jj] : sid[jj];
+            }
+#pragma unroll
+            for (int q = 0; q < NACC; ++q) {
+                const int j = (c + q) * 64 + lane;
+                const bool match = c + q < c_end && j <= last_j && idv[q] == row;
+                const unsigned long long mask = __ballot(match);
+                if (!mask) continue;
+                const int below = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32),
+                                                                 __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+                if (match) pl[np + below] = j;
+                np += __popcll(mask);
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                if (np >= cap) {
+                    int head = 0;
+                    for (; np - head >= cap; head += cap) flush(head, cap);
+                    const int left = np - head;             // < cap <= 64
+                    const int keep = lane < left ? pl[head + lane] : 0;
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    if (lane < left) pl[lane] = keep;
+                    np = left;
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                }
+            }
+        }
+        if (np) flush(0, np);
+    };
+
+    float gb;                                               // the bias element's gradient
+    const int lpr = D >> 2;                                 // lanes per gradient row, a float4 each
+    if (mf_wide(D, t ? w.p1 : w.p0, t ? w.m1 : w.m0, t ? w.v1 : w.v0)) {
+        const int sh = __ffs(lpr) - 1, epl = 64 >> sh;
+        const int grp = lane >> sh, sub = lane & (lpr - 1);
+        const int nacc = epl * NACC > 64 ? (64 / epl) : NACC, cap = nacc * epl;   // cap <= 64
+        float4 acc[NACC];
+        float gs[NACC];
+#pragma unroll
+        for (int q = 0; q < NACC; ++q) { acc[q] = make_float4(0.f, 0.f, 0.f, 0.f); gs[q] = 0.f; }
+        scan([&](int base, int n) {
+            float4 tmp[NACC];
+            float tg[NACC];
+#pragma unroll
+            for (int q = 0; q < NACC; ++q) {
+                const int idx = q * epl + grp;
+                const int e = pl[base + ((q < nacc && idx < n) ? idx : 0)];
+                tmp[q] = reinterpret_cast<const float4 *>(rows + (int64_t)e * D)[sub];
+                tg[q] = w.g[e];
+            }
+#pragma unroll
+            for (int q = 0; q < NACC; ++q) {
+                const bool on = q < nacc && q * epl + grp < n;
+                acc[q].x += on ? tmp[q].x : 0.f; acc[q].y += on ? tmp[q].y : 0.f;
+                acc[q].z += on ? tmp[q].z : 0.f; acc[q].w += on ? tmp[q].w : 0.f;
+                gs[q] += on ? tg[q] : 0.f;
+            }
+        }, cap);
+#pragma unroll
+        for (int h = NACC / 2; h > 0; h >>= 1)              // fixed tree over the accumulators
+#pragma unroll
+            for (int q = 0; q < h; ++q) {
+                acc[q].x += acc[q + h].x; acc[q].y += acc[q + h].y; acc[q].z += acc[q + h].z; acc[q].w += acc[q + h].w;
+                gs[q] += gs[q + h];
+            }
+        float4 G = acc[0];
+        gb = gs[0];
+        for (int off = lpr; off < 64; off <<= 1) {          // lane groups (a + b == b + a: every lane ends with the same bits)
+            G.x += __shfl_xor(G.x, off); G.y += __shfl_xor(G.y, off);
+            G.z += __shfl_xor(G.z, off); G.w += __shfl_xor(G.w, off);
+            gb += __shfl_xor(gb, off);
+        }
+        if (grp == 0) {
+            float *bp = t ? w.p1 : w.p0, *bm = t ? w.m1 : w.m0, *bv = t ? w.v1 : w.v0;
+            const int64_t o = ((int64_t)row * D >> 2) + sub;
+            float4 P = reinterpret_cast<float4 *>(bp)[o], M = reinterpret_cast<float4 *>(bm)[o];
+            float4 V = reinterpret_cast<float4 *>(bv)[o];
+            adam_elem(P.x, G.x, M.x, V.x, w.s); adam_elem(P.y, G.y, M.y, V.y, w.s);
+            adam_elem(P.z, G.z, M.z, V.z, w.s); adam_elem(P.w, G.w, M.w, V.w, w.s);
+            reinterpret_cast<float4 *>(bp)[o] = P; reinterpret_cast<float4 *>(bm)[o] = M;
+            reinterpret_cast<float4 *>(bv)[o] = V;
+        }
+    } else {
         float acc[4][MF_MAX_D / 64], gsum[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int q = 0; q < 4; ++q)
 #pragma unroll
             for (int x = 0; x < MF_MAX_D / 64; ++x) acc[q][x] = 0.f;
-        // (entries are popped four at a time into named slots: a runtime-indexed pending list
-        // would live in scratch, and a kernel that owns scratch streams slower -- see MfSweep)
-        int carry0 = -1, carry1 = -1, carry2 = -1;          // < 4 entries left over from the previous chunk
-        auto add4 = [&](int e0, int e1, int e2, int e3) {   // e_q < 0: slot q unused
+        scan([&](int base, int n) {
             float tmp[4][MF_MAX_D / 64], tg[4];
-            const int es[4] = {e0, e1, e2, e3};
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const int e = es[q] < 0 ? 0 : es[q];
+                const int e = pl[base + (q < n ? q : 0)];
 #pragma unroll
                 for (int x = 0; x < MF_MAX_D / 64; ++x)
-                    tmp[q][x] = (es[q] >= 0 && lane + 64 * x < D) ? rows[(int64_t)e * D + lane + 64 * x] : 0.f;
-                tg[q] = es[q] >= 0 ? w.g[e] : 0.f;
+                    tmp[q][x] = (lane + 64 * x < D) ? rows[(int64_t)e * D + lane + 64 * x] : 0.f;
+                tg[q] = w.g[e];
             }
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
 #pragma unroll
-                for (int x = 0; x < MF_MAX_D / 64; ++x) acc[q][x] += tmp[q][x];
-                gsum[q] += tg[q];
+                for (int x = 0; x < MF_MAX_D / 64; ++x) acc[q][x] += q < n ? tmp[q][x] : 0.f;
+                gsum[q] += q < n ? tg[q] : 0.f;
             }
-        };
-        auto pop = [](unsigned long long &mask, int base) {
-            if (!mask) return -1;
-            const int e = base + (__ffsll((long long)mask) - 1);
-            mask &= mask - 1;
-            return e;
-        };
-        for (int c = kc; c < nch; ++c) {
-            const int j = c * 64 + lane;
-            unsigned long long mask = __ballot(j < w.B && sid[j] == row);
-            // complete the carried group first (keeps every entry's accumulator = its rank mod 4)
-            if (carry0 >= 0 && mask) {
-                const int n = carry2 >= 0 ? 3 : (carry1 >= 0 ? 2 : 1);
-                const int a1 = n >= 2 ? carry1 : pop(mask, c * 64), a2 = n >= 3 ? carry2 : pop(mask, c * 64);
-                const int a3 = pop(mask, c * 64);
-                if (a3 >= 0) { add4(carry0, a1, a2, a3); carry0 = carry1 = carry2 = -1; }
-                else { carry1 = a1; carry2 = a2; }          // still short of four
-            }
-            while (carry0 < 0 && mask) {
-                const int e0 = pop(mask, c * 64), e1 = pop(mask, c * 64), e2 = pop(mask, c * 64), e3 = pop(mask, c * 64);
-                if (e3 >= 0) add4(e0, e1, e2, e3);
-                else { carry0 = e0; carry1 = e1; carry2 = e2; }
-            }
-        }
-        if (carry0 >= 0) add4(carry0, carry1, carry2, -1);
-        const float gb = (gsum[0] + gsum[1]) + (gsum[2] + gsum[3]);
+        }, 4);
+        gb = (gsum[0] + gsum[1]) + (gsum[2] + gsum[3]);
         if (D > 0) {
             float *bp = t ? w.p1 : w.p0, *bm = t ? w.m1 : w.m0, *bv = t ? w.v1 : w.v0;
 #pragma unroll
@@ -215,11 +336,86 @@ __global__ __launch_bounds__(MF_THREADS) void mf_adam_kernel(MfSweep w) {
                 }
             }
         }
-        if (lane == 0) {                                    // the row's bias element
-            float *bp = t ? w.p3 : w.p2, *bm = t ? w.m3 : w.m2, *bv = t ? w.v3 : w.v2;
-            float P = bp[row], M = bm[row], V = bv[row];
-            adam_elem(P, gb, M, V, w.s);
-            bp[row] = P; bm[row] = M; bv[row] = V;
+    }
+    if (lane == 0) {                                        // the row's bias element
+        float *bp = t ? w.p3 : w.p2, *bm = t ? w.m3 : w.m2, *bv = t ? w.v3 : w.v2;
+        float P = bp[row], M = bm[row], V = bv[row];
+        adam_elem(P, gb, M, V, w.s);
+        bp[row] = P; bm[row] = M; bv[row] = V;
+    }
+}
+
+template <int NACC>
+__global__ __launch_bounds__(MF_THREADS) void mf_adam_kernel(MfSweep w) {
+    extern __shared__ int sid[];                            // entry waves: the side's ids
+    __shared__ float red[MF_THREADS];
+    __shared__ int pend[MF_THREADS / 64][128];              // entry waves, wide form: the row's pending entries
+    const int tid = threadIdx.x;
+    // Entry workgroups are dispatched FIRST (the owner of a popular row is the launch's longest
+    // workgroup; interleaving them with the sweep workgroups measured slower), but keep the highest
+    // slot numbers.
+    const int bx = (int)blockIdx.x < w.n_entry_wgs ? w.cb_entries + (int)blockIdx.x : (int)blockIdx.x - w.n_entry_wgs;
+    if (bx >= w.cb_entries) {
+        // ---- entry waves: 4 per workgroup, all of one side (user side's groups first)
+        const int lane = tid & 63;
+        const int groups = w.n_entry_wgs >> 1;
+        int gi = bx - w.cb_entries;
+        const int t = gi >= groups;
+        if (t) gi -= groups;
+        if (w.first_u) {
+            // election slots: a wave takes `epw` ratings.  In the wide form a lane group
+            // (D / 4 lanes, a float4 each) handles one of them on its own when it is its row's only
+            // rating -- no scan, three round trips; rows with more ratings then get the whole wave,
+            // one after the other.
+            // (ratings wv, wv + nw, wv + 2 nw, ...: a row's FIRST rating is its owner, and popular rows
+            // first appear early in the batch -- consecutive ratings would put them in the same wave)
+            const int64_t base = (int64_t)gi * 4 + (tid >> 6), nw = (int64_t)(w.n_entry_wgs >> 1) * 4;
+            if (base >= w.B) return;
+            unsigned long long multi = 0;
+            if (w.epw > 1) {
+                const int D = w.D, lpr = D >> 2, sh = __ffs(lpr) - 1;
+                const int grp = lane >> sh, sub = lane & (lpr - 1);
+                const int64_t k = base + grp * nw;
+                const bool valid = k < w.B;
+                const int row = (t ? w.iid32 : w.uid32)[valid ? k : base];
+                const unsigned long long f = (t ? w.first_i : w.first_u)[row], l = (t ? w.last_i : w.last_u)[row];
+                const bool owner = valid && f == mf_first_pack(w.now, k);
+                const bool single = owner && (unsigned)l == (unsigned)k;
+                multi = __ballot(owner && !single && sub == 0);
+                if (single) {
+                    const float4 G = reinterpret_cast<const float4 *>((t ? w.gi : w.gu) + k * D)[sub];
+                    float *bp = t ? w.p1 : w.p0, *bm = t ? w.m1 : w.m0, *bv = t ? w.v1 : w.v0;
+                    const int64_t o = ((int64_t)row * D >> 2) + sub;
+                    float4 P = reinterpret_cast<float4 *>(bp)[o], M = reinterpret_cast<float4 *>(bm)[o];
+                    float4 V = reinterpret_cast<float4 *>(bv)[o];
+                    adam_elem(P.x, G.x, M.x, V.x, w.s); adam_elem(P.y, G.y, M.y, V.y, w.s);
+                    adam_elem(P.z, G.z, M.z, V.z, w.s); adam_elem(P.w, G.w, M.w, V.w, w.s);
+                    reinterpret_cast<float4 *>(bp)[o] = P; reinterpret_cast<float4 *>(bm)[o] = M;
+                    reinterpret_cast<float4 *>(bv)[o] = V;
+                    if (sub == 0) {                         // the row's bias element
+                        float *cp = t ? w.p3 : w.p2, *cm = t ? w.m3 : w.m2, *cv = t ? w.v3 : w.v2;
+                        float Pb = cp[row], Mb = cm[row], Vb = cv[row];
+                        adam_elem(Pb, w.g[k], Mb, Vb, w.s);
+                        cp[row] = Pb; cm[row] = Mb; cv[row] = Vb;
+                    }
+                }
+                while (multi) {
+                    const int q = (__ffsll((long long)multi) - 1) >> sh;
+                    multi &= multi - 1;
+                    mf_entry<NACC>(w, sid, pend[tid >> 6], t, base + q * nw, lane);
+                }
+            } else {
+                mf_entry<NACC>(w, sid, pend[tid >> 6], t, base, lane);
+            }
+            return;
+        }
+        const int64_t *ids = t ? w.iid : w.uid;             // no election slots: stage the side's ids
+        for (int64_t j = tid; j < w.B; j += MF_THREADS) sid[j] = (int)ids[j];
+        __syncthreads();
+        for (int it = 0; it < w.epw; ++it) {                // entries of this wave: interleaved with its neighbours
+            const int64_t k = ((int64_t)gi * w.epw + it) * 4 + (tid >> 6);
+            if (k >= w.B) break;
+            mf_entry<NACC>(w, sid, pend[tid >> 6], t, k, lane);
         }
         return;
     }
@@ -334,7 +530,9 @@ __global__ __launch_bounds__(MF_THREADS) void mf_adam_kernel(MfSweep w) {
 struct MfWs {
     float *gu, *gi, *g, *mult;
     int *tag_u, *tag_i;
-    size_t bytes;
+    unsigned long long *first_u, *first_i, *last_u, *last_i;
+    int *uid32, *iid32;
+    size_t bytes, persist;             // persist: the head of the buffer that carries state across steps
 };
 
 static size_t a256(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -346,6 +544,13 @@ static MfWs mf_carve(void *ws, int64_t B, int D, int64_t n_users, int64_t n_item
     MfWs w;
     w.tag_u = reinterpret_cast<int *>(take((size_t)n_users * 4));   // tags first: they must persist (zeroed once)
     w.tag_i = reinterpret_cast<int *>(take((size_t)n_items * 4));
+    w.first_u = reinterpret_cast<unsigned long long *>(take((size_t)n_users * 8));
+    w.first_i = reinterpret_cast<unsigned long long *>(take((size_t)n_items * 8));
+    w.last_u = reinterpret_cast<unsigned long long *>(take((size_t)n_users * 8));
+    w.last_i = reinterpret_cast<unsigned long long *>(take((size_t)n_items * 8));
+    w.persist = o;
+    w.uid32 = reinterpret_cast<int *>(take((size_t)B * 4));
+    w.iid32 = reinterpret_cast<int *>(take((size_t)B * 4));
     w.gu = reinterpret_cast<float *>(take((size_t)B * D * 4));
     w.gi = reinterpret_cast<float *>(take((size_t)B * D * 4));
     w.g = reinterpret_cast<float *>(take((size_t)B * 4));
@@ -375,10 +580,14 @@ int mf_bias_rows_launch(float *ub, float *ub_m, float *ub_v, float *ib, float *i
     chunks += cdiv(n_items, mf_chunk(3));
     sw.cb_global = (int)chunks;                             // no global-bias workgroup either
     sw.cb_entries = (int)chunks;
-    chunks += 2 * cdiv(B, 4);
+    sw.epw = mf_epw(B);
+    sw.n_entry_wgs = (int)(2 * cdiv(B, 4 * sw.epw));
+    chunks += sw.n_entry_wgs;
+    sw.first_u = sw.first_i = sw.last_u = sw.last_i = nullptr;
+    sw.uid32 = sw.iid32 = nullptr;
     sw.uid = uid; sw.iid = iid; sw.g = g; sw.se = nullptr; sw.sse_accum = nullptr;
     sw.tag_u = tag_u; sw.tag_i = tag_i; sw.B = B; sw.D = 0; sw.now = now; sw.s = sc;
-    mf_adam_kernel<<<(unsigned)chunks, MF_THREADS, (size_t)B * sizeof(int), st>>>(sw);
+    mf_adam_kernel<4><<<(unsigned)chunks, MF_THREADS, (size_t)B * sizeof(int), st>>>(sw);
     return check_launch("bias rows");
 }
 
@@ -389,6 +598,11 @@ using namespace r4r;
 extern "C" size_t r4r_mf_ws_bytes(int64_t B, int D, int64_t n_users, int64_t n_items) {
     if (B < 0 || D < 0 || n_users <= 0 || n_items <= 0) return 0;
     return mf_carve(nullptr, B, D, n_users, n_items).bytes;
+}
+
+extern "C" size_t r4r_mf_ws_persist_bytes(int64_t B, int D, int64_t n_users, int64_t n_items) {
+    if (B < 0 || D < 0 || n_users <= 0 || n_items <= 0) return 0;
+    return mf_carve(nullptr, B, D, n_users, n_items).persist;
 }
 
 extern "C" size_t r4r_mf_ws_mult_offset(int64_t B, int D, int64_t n_users, int64_t n_items) {
@@ -442,6 +656,10 @@ extern "C" int r4r_mf_step(const int64_t *uid, const int64_t *iid, const float *
         a.rows[k] = rows[k]; a.width[k] = width[k];
     }
     a.gu = w.gu; a.gi = w.gi; a.g = w.g; a.mult = w.mult; a.tag_u = w.tag_u; a.tag_i = w.tag_i;
+    a.first_u = w.first_u; a.first_i = w.first_i; a.last_u = w.last_u; a.last_i = w.last_i;
+    a.uid32 = w.uid32; a.iid32 = w.iid32;
+    a.first_u = w.first_u; a.first_i = w.first_i; a.last_u = w.last_u; a.last_i = w.last_i;
+    a.uid32 = w.uid32; a.iid32 = w.iid32;
     a.pred = pred; a.se = se; a.sse_accum = sse_accum;
     a.B = B; a.D = D; a.training = training; a.want_grad = m != nullptr; a.tag = (int)adam_step;
     a.p_drop = dropout_p; a.inv_denom = inv_denom; a.seed = seed; a.offset = offset;
@@ -462,14 +680,22 @@ extern "C" int r4r_mf_step(const int64_t *uid, const int64_t *iid, const float *
     sw.cb_global = (int)chunks;                             // one workgroup: global bias + running SE
     chunks += 1;
     sw.cb_entries = (int)chunks;                            // entry waves: 4 per workgroup, per side
-    chunks += 2 * cdiv(B, 4);
+    // election slots (no LDS staging to amortise): a wave takes 256 / D ratings in the wide form, else one
+    sw.epw = (D > 0 && mf_wide(D, sw.p0, sw.m0, sw.v0) && mf_wide(D, sw.p1, sw.m1, sw.v1)) ? 256 / D : 1;
+    sw.n_entry_wgs = (int)(2 * cdiv(B, 4 * sw.epw));
+    chunks += sw.n_entry_wgs;
+    sw.first_u = w.first_u; sw.first_i = w.first_i; sw.last_u = w.last_u; sw.last_i = w.last_i;
+    sw.uid32 = w.uid32; sw.iid32 = w.iid32;
     R4R_REQUIRE(chunks < (1ll << 31), "mf_step: too many workgroups");
     sw.uid = uid; sw.iid = iid; sw.gu = w.gu; sw.gi = w.gi; sw.g = w.g; sw.se = se; sw.sse_accum = sse_accum;
     sw.tag_u = w.tag_u; sw.tag_i = w.tag_i; sw.B = B; sw.D = D; sw.now = (int)adam_step;
     sw.s = adam_make_scalars(lr, beta1, beta2, eps, weight_decay, adam_step, nullptr);
     {
         ScopedTiming tm(R4R_TIMING_ADAM, st);
-        mf_adam_kernel<<<(unsigned)chunks, MF_THREADS, (size_t)B * sizeof(int), st>>>(sw);
+        // more loads in flight per entry wave (and fewer waves per SIMD: 156 vs 116 VGPRs) once rows can
+        // have hundreds of ratings
+        if (B > 2048) mf_adam_kernel<8><<<(unsigned)chunks, MF_THREADS, 0, st>>>(sw);
+        else mf_adam_kernel<4><<<(unsigned)chunks, MF_THREADS, 0, st>>>(sw);
     }
     return check_launch("mf_step");
 }

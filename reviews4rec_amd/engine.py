@@ -314,8 +314,7 @@ class MFEngine:
     dense gradient of an ID table is never materialised.  Same calling surface as DeepCoNNEngine
     (train_step / predict / sse / state_dict).  Single process only: under data parallelism the
     module path + the compact-list exchange of dist.py run instead."""
-    MAX_TRAIN_BATCH = 16384      # accepted; a row with hundreds of entries is summed by ONE wave, so the host
-                                 # loop prefers the captured module path above batch 1024 (main.make_engine)
+    MAX_TRAIN_BATCH = 16384      # r4r_mf_step's limit; larger batches take the module path (main.make_engine)
 
     def __init__(self, model, lr=0.002, weight_decay=1e-6, betas=(0.9, 0.999), eps=1e-8, seed=0x5EED5EED, rank=0):
         hp = model.hyper_params
@@ -354,7 +353,7 @@ class MFEngine:
                 nb = _lib.lib().r4r_mf_ws_bytes(B, self.D, self.n_users, self.n_items)
                 nxt = cache[B] = torch.zeros(max(nb, 256), dtype=torch.uint8, device=self.dev)   # tags start at zero
             if self._ws is not None:
-                keep = 256 * (-(-self.n_users * 4 // 256) + -(-self.n_items * 4 // 256))
+                keep = _lib.lib().r4r_mf_ws_persist_bytes(B, self.D, self.n_users, self.n_items)
                 nxt[:keep].copy_(self._ws[:keep])
             self._ws, self._ws_B = nxt, B
         return self._ws

@@ -144,7 +144,7 @@ def make_engine(hyper_params, model, dp=None, rank=0):
     if hyper_params.get('engine', 'auto') not in ('auto', 'native'):
         return None
     if hyper_params['model_type'] in ('MF_dot', 'bias_only'):
-        if (dp is not None and dp.on) or int(hyper_params.get('batch_size', 128)) > 1024:
+        if (dp is not None and dp.on) or int(hyper_params.get('batch_size', 128)) > 16384:
             return None                                   # DP / very large batches: module path (dist.py C2)
         from .engine import MFEngine
         return MFEngine(model, lr=hyper_params['lr'], weight_decay=hyper_params['weight_decay'],

@@ -390,6 +390,54 @@ def test_mf_engine_equals_module_path_with_duplicates_and_dropout():
         torch.testing.assert_close(sd[k].cpu(), v, rtol=1e-5, atol=5e-6, msg=lambda m: k + ': ' + m)
 
 
+@pytest.mark.parametrize('D,B', [(64, 5000), (32, 3000), (10, 2500), (64, 16384)])
+def test_mf_engine_large_batch_with_popular_rows(D, B):
+    """Batches of thousands (SURVEY 8d quotes MF at B = 8,192): an item named by ~14 % of the
+    ratings, a user by ~5 %, rows named once, twice, and ids whose first / last rating sit at the
+    ends of the batch.  Wide (D = 64, 32) and generic (D = 10) forms of the entry waves against
+    the CPU oracle for two steps, dropout masks injected; and the step is deterministic."""
+    import reviews4rec_amd
+    from reviews4rec_amd.engine import MFEngine
+    U, I = 30000, 9000
+    hp = dict(model_type='MF_dot', latent_size=D, dropout=0.5, total_users=U, total_items=I, lr=0.002,
+              weight_decay=1e-6)
+    P0 = oracle.init_params(hp, seed=11)
+    rng = torch.Generator().manual_seed(17)
+    batches = []
+    for step in range(2):
+        uid = torch.randint(0, U, (B,), generator=rng)
+        iid = torch.randint(0, I, (B,), generator=rng)
+        iid[torch.rand(B, generator=rng) < 0.14] = 7
+        uid[torch.rand(B, generator=rng) < 0.05] = 123
+        uid[0] = uid[B - 1] = 4242                                        # first and last rating of the batch
+        iid[1] = iid[B - 2] = 4243
+        y = torch.randint(1, 6, (B,), generator=rng).float()
+        batches.append((uid, iid, y))
+
+    def run():
+        model = reviews4rec_amd.get_model_class('MF_dot')(hp)
+        model.load_state_dict(P0)
+        model = model.to(DEV).train()
+        eng = MFEngine(model, lr=hp['lr'], weight_decay=hp['weight_decay'])
+        out = []
+        for uid, iid, y in batches:
+            se = eng.train_step([None] * 5 + [uid.to(DEV), iid.to(DEV)], y.to(DEV)).cpu().clone()
+            out.append((se, eng.dropout_multipliers(B).cpu()))
+        return {k: v.cpu().clone() for k, v in model.state_dict().items()}, out
+
+    sd, out = run()
+    P, state = {k: v.clone() for k, v in P0.items()}, oracle.AdamState()
+    for (uid, iid, y), (se, mult) in zip(batches, out):
+        masks = {'dropout.user': mult[:, :D], 'dropout.item': mult[:, D:]}
+        sse, _ = oracle.train_step(P, [None] * 5 + [uid, iid], y, hp, state, masks=masks)
+        torch.testing.assert_close(se.sum(), torch.tensor(sse), rtol=1e-4, atol=1e-3)
+    for k, v in P.items():
+        torch.testing.assert_close(sd[k], v, rtol=1e-5, atol=5e-6, msg=lambda m: k + ': ' + m)
+    sd2, _ = run()
+    for k in sd:
+        assert torch.equal(sd[k], sd2[k]), k
+
+
 # --------------------------------------------------------------------------------- NARRE native step
 def test_narre_engine_eval_matches_reference_golden():
     from reviews4rec_amd.engine import NarreEngine
