@@ -39,7 +39,7 @@ def measured_traffic(kernel, args):
     """HBM-side bytes per launch of `kernel` from the committed rocprofv3 --pmc summary
     (profiles/, separate counter passes of this same command) -- only for the configuration
     that summary was collected on; None otherwise."""
-    path = os.path.join(ROOT, 'profiles', 'r01i_bench_pmc_summary.json')
+    path = os.path.join(ROOT, 'profiles', 'r01l_bench_pmc_summary.json')
     if not (os.path.exists(path) and args.workload == WORKLOAD and args.batch_per_gpu == 128
             and args.engine == 'native' and args.conv_algo in ('auto', 'project')):
         return None

@@ -35,13 +35,8 @@ constexpr int PEC = 16;            // K chunk
 constexpr int PS = PEC + 8;        // LDS row stride (floats), == 8 mod 16: conflict-free b128 reads
 constexpr int GM = 2;              // 16-row tiles per wave
 constexpr int PM = 64 * GM;        // GEMM rows per workgroup (4 waves x GM row tiles of 16)
-constexpr int GEMM_THREADS = 256;
 constexpr int PNH = 10;                                // column tiles of the wider half (10 + 9 = 19)
 constexpr int PNH_COLS = PNH * 16;                     // 160
-constexpr int PA_ROWS = GM;                            // A rows staged per thread: (tid >> 2) + 64 k
-constexpr int PB_ROWS = 3;                             // B rows staged per thread: (tid >> 2) + 64 k
-constexpr int GEMM_BUF = (PM + 64 * PB_ROWS) * PS;     // floats per LDS buffer (B rows staged unguarded: 192)
-constexpr int GEMM_LDS_BYTES = 2 * GEMM_BUF * 4;       // 61,440 B -> 2 workgroups per CU
 constexpr int SEG = 128;           // positions per partial (matches the direct kernel's NW=4 tile)
 
 struct ProjArgs {
@@ -87,88 +82,85 @@ __global__ __launch_bounds__(1024) void proj_compact_kernel(TokenArgs a) {
 // ---- 2. projection GEMM: Q[row, j*100+f] = table[list[row], :] . W[f, j, :].
 // The B operand is staged straight from the conv weight [F][3][E]: LDS row n = j*100+f takes
 // the 16 contiguous floats W[f][j][c*16 .. c*16+15] (four float4 per row).
-// grid = (cap/128 row tiles x 2 column halves, ntower); 4 waves, wave w owns rows
-// [32w, 32w+32) x one half of the 304 columns (2 x (10 or 9) accumulators of 16x16): ~2x the
-// workgroups of a full-width tile, 2 co-resident per CU, so a batch whose distinct-token
-// count lands just above a multiple of 256 x 128 rows does not cost a whole extra round.
-// K runs in chunks of 16 floats through two LDS buffers and two operand register sets.
-template <int NTILE>
+// grid = (cap/128 row tiles, ntower); ONE workgroup of 8 waves per 128-row tile: wave w owns rows
+// [32 (w & 3), +32) x column half (w >> 2) of the 304 columns (2 x (10 or 9) accumulators of
+// 16x16), so the A tile is staged once for both halves and a CU holds one workgroup whose two
+// waves per SIMD cover each other's stalls.  K runs in chunks of 16 floats through two LDS
+// buffers, two operand register sets and two staging register sets.
+//
+// What bounds it (tools/gemm_trace.py, tools/microbench/): under this load the
+// shader clock sits at ~2.1-2.2 GHz, not the 2.4 GHz behind the 157 TFLOP/s figure; every memory
+// instruction a wave issues costs its MFMA stream ~20 cycles (12 ds_read_b128 per 80 MFMAs take
+// 9-11 % off the pure MFMA rate in isolation); prologue + epilogue are ~5 us of a ~54 us launch
+// and all workgroups run them in phase.  Two other decompositions were built and measured
+// slower: two 4-wave workgroups per row tile (one per column half: the A tile staged twice,
+// 61.9 us vs 57.5), and a B-stationary form (an 80-column slice of W resident in LDS, A straight
+// from global memory into registers in the MFMA layout, no barrier in the loop: 9 instead of 20
+// memory instructions per 80 MFMAs, but four times the A traffic and waves that finish out of
+// step -- a wave storing its tile while its SIMD neighbour streams MFMAs crawls: 64.3 us).
+constexpr int GEMM_THREADS = 512;
+constexpr int WB_ROWS = 320;                              // B rows staged: 304 padded to 5 x 64
+constexpr int GEMM_BUF = (PM + WB_ROWS) * PS;               // floats per LDS buffer
+constexpr int GEMM_LDS_BYTES = 2 * GEMM_BUF * 4;              // 86,016 B
+
+template <int NTILE, int NB>
 __device__ __forceinline__ void proj_gemm_body(const ProjArgs &a, float *lds) {
     const ProjTower &tw = a.t[blockIdx.y];
     const int count = tw.count[0];
-    const int row0 = (blockIdx.x >> 1) * PM;
-    const int half = blockIdx.x & 1;
-    const int col0 = half * PNH_COLS;                       // first column of this half
+    const int row0 = blockIdx.x * PM;
     TRACE_STAMP(0)
 #ifdef R4R_TRACE
     if (g_trace && threadIdx.x == 0) {
         unsigned long long *tr = g_trace + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8;
-        tr[4] = __builtin_amdgcn_s_getreg((31 << 11) | 4);      // HW_REG_HW_ID
-        tr[5] = __builtin_amdgcn_s_getreg((31 << 11) | 20);     // HW_REG_XCC_ID
-        tr[6] = row0 < count;
+        tr[4] = __builtin_amdgcn_s_getreg((31 << 11) | 4);
+        tr[5] = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+        tr[6] = 1;
     }
 #endif
-    if (row0 >= count) return;                              // over-provisioned grid: uniform exit
     const float *__restrict__ table = a.table;
     const int E = a.E, nchunk = a.nchunk;
-
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lrow = lane & 15, q = lane >> 4;
+    const int half = wave >> 2, col0 = half * PNH_COLS;
 
-    // staging role: float4 column c4 of A rows (tid >> 2) + 64 k (k < 2) and of B rows
-    // (tid >> 2) + 64 k (k < 3; rows 0..191 cover the 160 B rows of this half).  Every load
-    // is unconditional (hipcc turns a predicated load into a branch and a full counter wait):
-    // rows past `count` re-read the last valid row and padding columns re-read W[0][0] -- their
-    // results are never stored -- and the K tail (E % 16) re-reads the last float4 of the row,
-    // with the B side zeroed before it reaches LDS so the products vanish.
+    // staging role: float4 column c4 of A row (tid >> 2) and of B rows (tid >> 2) + 128 k
+    // (k < NB: waves 0..3 stage three, rows 0..319; waves 4..7 two).
     const int c4 = tid & 3, srow = tid >> 2;
-    const float *aptr[PA_ROWS], *bptr[PB_ROWS];
-#pragma unroll
-    for (int k = 0; k < PA_ROWS; ++k) {
-        const int r = min(row0 + srow + 64 * k, count - 1);
-        aptr[k] = table + (long)tw.list[r] * E;
-    }
+    const float *aptr = table + (long)tw.list[min(row0 + srow, count - 1)] * E;
+    const float *bptr[NB];
     const float *__restrict__ conv_w = tw.conv_w;
 #pragma unroll
-    for (int k = 0; k < PB_ROWS; ++k) {
-        const int nl = srow + 64 * k, n = col0 + nl;        // n = j * 100 + f
+    for (int k = 0; k < NB; ++k) {
+        const int n = srow + 128 * k;                       // n = j * 100 + f
         const int j = n / PF, f = n - j * PF;
-        bptr[k] = conv_w + ((nl < PNH_COLS && n < PROW) ? ((long)f * 3 + j) * E : 0);
+        bptr[k] = conv_w + (n < PROW ? ((long)f * 3 + j) * E : 0);
     }
-
-    f32x4 ar[PA_ROWS], br[PB_ROWS];
+    // Every load is unconditional (hipcc turns a predicated load into a branch and a full counter
+    // wait): rows past `count` re-read the last valid row and padding columns re-read W[0][0] --
+    // their results are never stored -- and the K tail (E % 16) re-reads the last float4 of the
+    // row, with the B side zeroed before it reaches LDS so the products vanish.  (A second set of
+    // staging registers, giving the loads two chunks to arrive, measured 1 % slower.)
+    f32x4 ar, br[NB];
     auto issue_loads = [&](int c) {                          // any c: past the end it re-reads the tail
         const int e = min(c * PEC + c4 * 4, E - 4);
+        ar = *reinterpret_cast<const f32x4 *>(aptr + e);
 #pragma unroll
-        for (int k = 0; k < PA_ROWS; ++k) ar[k] = *reinterpret_cast<const f32x4 *>(aptr[k] + e);
-#pragma unroll
-        for (int k = 0; k < PB_ROWS; ++k) br[k] = *reinterpret_cast<const f32x4 *>(bptr[k] + e);
+        for (int k = 0; k < NB; ++k) br[k] = *reinterpret_cast<const f32x4 *>(bptr[k] + e);
     };
     auto write_lds = [&](float *buf, int c) {
         const float keep = (c * PEC + c4 * 4 < E) ? 1.f : 0.f;  // zero the K tail of B (branch-free)
-#pragma unroll
-        for (int k = 0; k < PA_ROWS; ++k)
-            *reinterpret_cast<f32x4 *>(buf + (srow + 64 * k) * PS + c4 * 4) = ar[k];
+        *reinterpret_cast<f32x4 *>(buf + srow * PS + c4 * 4) = ar;
         float *Bl = buf + PM * PS;
 #pragma unroll
-        for (int k = 0; k < PB_ROWS; ++k)
-            *reinterpret_cast<f32x4 *>(Bl + (srow + 64 * k) * PS + c4 * 4) = br[k] * keep;
+        for (int k = 0; k < NB; ++k)
+            *reinterpret_cast<f32x4 *>(Bl + (srow + 128 * k) * PS + c4 * 4) = br[k] * keep;
     };
-
     f32x4 acc[GM][NTILE];
 #pragma unroll
     for (int mi = 0; mi < GM; ++mi)
 #pragma unroll
         for (int ni = 0; ni < NTILE; ++ni) acc[mi][ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-    // Operand registers are double-buffered too: the staging of chunk c+2 (registers -> LDS),
-    // the global loads of chunk c+3 and the ds_reads of chunk c+1 are all issued among the
-    // MFMAs of chunk c, so between two chunks the matrix pipe only waits for the barrier.
-    // The body is branch-free (one scheduling region): past the last chunk it stages and reads
-    // data nobody consumes.  A 16x16x4 fp32 MFMA occupies the pipe for 32 cycles, which leaves
-    // room for one memory instruction behind every few of them; left to itself hipcc emits
-    // the reads, the stores and the loads as three bursts during which the pipe idles.
-    const int aoffl = (wave * 16 * GM + lrow) * PS + q * 4, boffl = PM * PS + lrow * PS + q * 4;
+    const int aoffl = ((wave & 3) * 16 * GM + lrow) * PS + q * 4, boffl = (PM + col0 + lrow) * PS + q * 4;
     auto read_ops = [&](const float *buf, f32x4 (&av)[GM], f32x4 (&b)[NTILE]) {
 #pragma unroll
         for (int mi = 0; mi < GM; ++mi) av[mi] = *reinterpret_cast<const f32x4 *>(buf + aoffl + mi * 16 * PS);
@@ -182,6 +174,13 @@ __device__ __forceinline__ void proj_gemm_body(const ProjArgs &a, float *lds) {
             for (int ni = 0; ni < NTILE; ++ni)
                 acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mi][kk], b[ni][kk], acc[mi][ni], 0, 0, 0);
     };
+    // Operand registers are double-buffered too: the staging of chunk c+2 (registers -> LDS),
+    // the global loads of chunk c+3 and the ds_reads of chunk c+1 are all issued among the
+    // MFMAs of chunk c, so between two chunks the matrix pipe only waits for the barrier.
+    // The body is branch-free (one scheduling region): past the last chunk it stages and reads
+    // data nobody consumes.  A 16x16x4 fp32 MFMA occupies the pipe for 32 cycles, which leaves
+    // room for one memory instruction behind every few of them; left to itself hipcc emits
+    // the reads, the stores and the loads as three bursts during which the pipe idles.
     // chunk c: operands `cur` are in registers; LDS buffer (c+1)&1 holds chunk c+1 once the
     // barrier is passed; the staging registers hold chunk c+2 (loaded a whole chunk ago).
     auto step = [&](int c, const f32x4 (&cav)[GM], const f32x4 (&cb)[NTILE], f32x4 (&nav)[GM], f32x4 (&nb)[NTILE]) {
@@ -193,8 +192,8 @@ __device__ __forceinline__ void proj_gemm_body(const ProjArgs &a, float *lds) {
         read_ops(lds + ((c + 1) & 1) * GEMM_BUF, nav, nb);
         mfma(cav, cb, 2);
         mfma(cav, cb, 3);
-        // schedule: (1 LDS write, 3 MFMA) x 5 | (1 load, 3 MFMA) x 5 | (1 LDS read, 3 MFMA) x 12, rest
-        constexpr int NREAD = GM + NTILE, NSTG = PA_ROWS + PB_ROWS, NM = 4 * GM * NTILE;
+        // schedule: (1 LDS write, 3 MFMA) x NSTG | (1 load, 3 MFMA) x NSTG | (1 LDS read, 3 MFMA) x NREAD, rest
+        constexpr int NREAD = GM + NTILE, NSTG = 1 + NB, NM = 4 * GM * NTILE;
 #pragma unroll
         for (int i = 0; i < NSTG; ++i) {
             __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
@@ -214,7 +213,6 @@ __device__ __forceinline__ void proj_gemm_body(const ProjArgs &a, float *lds) {
         }
         __builtin_amdgcn_sched_group_barrier(0x008, NM - 3 * (NREAD + 2 * NSTG), 0);
     };
-
     f32x4 av0[GM], b0[NTILE], av1[GM], b1[NTILE];
     issue_loads(0);
     write_lds(lds, 0);
@@ -224,19 +222,30 @@ __device__ __forceinline__ void proj_gemm_body(const ProjArgs &a, float *lds) {
     write_lds(lds + GEMM_BUF, 1);
     issue_loads(2);
     TRACE_STAMP(1)
-    for (int c = 0; c < nchunk; c += 2) {
+#ifdef R4R_TRACE
+    const unsigned long long clk0 = __builtin_readcyclecounter();
+#endif
+    // (the odd last chunk is peeled: with an exit in the middle of the loop body hipcc's counter
+    // analysis falls back to vmcnt(0) at the loop head)
+    int c = 0;
+    for (; c + 1 < nchunk; c += 2) {
         step(c, av0, b0, av1, b1);
-        if (c + 1 < nchunk) step(c + 1, av1, b1, av0, b0);
+        step(c + 1, av1, b1, av0, b0);
     }
+    if (c < nchunk) step(c, av0, b0, av1, b1);
+#ifdef R4R_TRACE
+    if (g_trace && threadIdx.x == 0)                        // shader cycles of the loop (vs the 100 MHz stamps: the clock)
+        g_trace[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 + 7] = __builtin_readcyclecounter() - clk0;
+#endif
     __syncthreads();                                        // all operand reads done: LDS is free
     TRACE_STAMP(2)
     // Epilogue.  C layout of the MFMA: col = lane & 15, row = (lane >> 4) * 4 + reg -- storing
     // that directly is 80 scattered 4-byte stores per lane.  Instead each wave transposes one
     // 16-row tile at a time through its own LDS slab and writes whole row segments as float4
     // (an LDS queue is in-order per wave, so no barrier is needed inside a wave).
-    constexpr int TS = NTILE * 16 + 4;                       // slab row stride (floats)
+    constexpr int TS = NTILE * 16 + 4;
     float *slab = lds + wave * (16 * (PNH_COLS + 4));
-    constexpr int NV = NTILE * 4;                            // float4 per row segment
+    constexpr int NV = NTILE * 4;
 #pragma unroll
     for (int mi = 0; mi < GM; ++mi) {
 #pragma unroll
@@ -245,7 +254,7 @@ __device__ __forceinline__ void proj_gemm_body(const ProjArgs &a, float *lds) {
             for (int r = 0; r < 4; ++r) slab[(q * 4 + r) * TS + ni * 16 + lrow] = acc[mi][ni][r];
         for (int i = lane; i < 16 * NV; i += 64) {
             const int rr = i / NV, cv = i - rr * NV;
-            const int row = row0 + wave * 16 * GM + mi * 16 + rr;
+            const int row = row0 + (wave & 3) * 16 * GM + mi * 16 + rr;
             const int col = col0 + cv * 4;
             if (row < count && col < PROW)
                 *reinterpret_cast<f32x4 *>(tw.ptab + (size_t)row * PROW + col) =
@@ -255,11 +264,12 @@ __device__ __forceinline__ void proj_gemm_body(const ProjArgs &a, float *lds) {
     TRACE_STAMP(3)
 }
 
-__global__ __launch_bounds__(GEMM_THREADS, 2) void proj_gemm_kernel(ProjArgs a) {
+__global__ __launch_bounds__(GEMM_THREADS) void proj_gemm_kernel(ProjArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float *lds = reinterpret_cast<float *>(smem);
-    if (blockIdx.x & 1) proj_gemm_body<PNT - PNH>(a, lds);   // columns 160..303: 9 tiles
-    else proj_gemm_body<PNH>(a, lds);                        // columns 0..159: 10 tiles
+    if ((int)blockIdx.x * PM >= a.t[blockIdx.y].count[0]) return;   // over-provisioned grid: uniform exit
+    if (threadIdx.x >> 8) proj_gemm_body<PNT - PNH, 2>(a, lds);   // waves 4..7: columns 160..303
+    else proj_gemm_body<PNH, 3>(a, lds);                          // waves 0..3: columns 0..159
 }
 
 // ---- 3. gather-add-max.  One workgroup = TWO 128-position segments of one document
@@ -428,7 +438,7 @@ int textcnn_proj_compute_launch(const float *table, int64_t V, const ProjTower *
     const ProjArgs a = make_args(table, V, tw, ntower, N, T, E, F);
     {
         ScopedTiming tm(R4R_TIMING_PROJ_GEMM, st);
-        proj_gemm_kernel<<<dim3(2 * ((a.cap + PM - 1) / PM), ntower), GEMM_THREADS, GEMM_LDS_BYTES, st>>>(a);
+        proj_gemm_kernel<<<dim3((a.cap + PM - 1) / PM, ntower), GEMM_THREADS, GEMM_LDS_BYTES, st>>>(a);
     }
     {
         ScopedTiming tm(R4R_TIMING_PROJ_GATHER, st);

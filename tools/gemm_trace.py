@@ -55,14 +55,16 @@ print('epilogue: med %.2f max %.2f' % (np.median(end - loop), (end - loop).max()
 print('active end: min %.2f med %.2f max %.2f' % (end.min(), np.median(end), end.max()))
 w7 = a[:, 7]
 if w7.any():
-    vm = ((w7 >> 40) & 0xfffff) * 16; bar = ((w7 >> 20) & 0xfffff) * 16; iss = (w7 & 0xfffff) * 16
-    print('loader cycles per WG (median): vmcnt-wait %d  barrier-wait %d  dma-issue %d   (loop total ~%d cycles at 2.4 GHz)' % (np.median(vm), np.median(bar), np.median(iss), np.median(loop - staged) * 2400))
+    mhz = w7 / (loop - staged)
+    print('shader clock over the loop: med %.0f MHz (min %.0f, max %.0f); cycles med %d' % (np.median(mhz), mhz.min(), mhz.max(), np.median(w7)))
 hw = a[:, 4]; xcc = a[:, 5] & 0xf
 cu = (hw >> 8) & 0xf; sh = (hw >> 12) & 1; se = (hw >> 13) & 0x7
 cuid = xcc * 1000 + se * 100 + sh * 10 + cu
 ids, cnt = np.unique(cuid, return_counts=True)
 print('distinct CUs used by active WGs: %d; WGs per CU histogram:' % len(ids), np.bincount(cnt))
 print('per XCC active WGs:', np.bincount(xcc.astype(int), minlength=8))
+print('per XCC end (med / max):', ' '.join('%.1f/%.1f' % (np.median(end[xcc == x]), end[xcc == x].max()) for x in range(8) if (xcc == x).any()))
+print('per XCC loop (med):', ' '.join('%.1f' % np.median((loop - staged)[xcc == x]) for x in range(8) if (xcc == x).any()))
 # concurrency per CU over time: how many active WGs share a CU at each WG's midpoint
 order = np.argsort(st)
 for k in list(range(0, len(order), max(1, len(order) // 24))):
