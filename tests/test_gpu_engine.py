@@ -390,7 +390,8 @@ def test_mf_engine_equals_module_path_with_duplicates_and_dropout():
         torch.testing.assert_close(sd[k].cpu(), v, rtol=1e-5, atol=5e-6, msg=lambda m: k + ': ' + m)
 
 
-@pytest.mark.parametrize('D,B', [(64, 5000), (32, 3000), (10, 2500), (64, 16384)])
+@pytest.mark.parametrize('D,B', [(64, 5000), (32, 3000), (10, 2500), (64, 16384), (4, 2100), (8, 1000), (128, 1500),
+                                 (256, 2100), (100, 3000)])
 def test_mf_engine_large_batch_with_popular_rows(D, B):
     """Batches of thousands (SURVEY 8d quotes MF at B = 8,192): an item named by ~14 % of the
     ratings, a user by ~5 %, rows named once, twice, and ids whose first / last rating sit at the
