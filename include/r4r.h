@@ -328,7 +328,7 @@ int r4r_mf_step(const int64_t *uid, const int64_t *iid, const float *y,
  * Replaces, per training step: the word gathers + TextCNN over the B*R review documents of each
  * side, TextCNN's FC + dropout, both attention scorers + softmax (NARRE.py:53-64), the four
  * ID-embedding gathers, the interaction, `final`, the bias head, MSELoss (loss.py:7-11),
- * loss.backward() and torch.optim.Adam.step() (main.py:56-60,94-96) -- six launches.
+ * loss.backward() and torch.optim.Adam.step() (main.py:56-60,94-96) -- five launches.
  *   user_reviews / item_reviews [B, R, T] token ids; reviewed_items / users_who_reviewed [B, R]
  *   (R = narre_num_reviews = the neighbour count of data.py:274-279); uid / iid [B].
  *   flat_p / flat_g / flat_m / flat_v : the DENSE parameters in the layout of r4r_narre_layout

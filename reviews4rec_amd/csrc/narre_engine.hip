@@ -1,6 +1,6 @@
 // Fused native training step for NARRE (pytorch_models/NARRE.py:10-124): per rating, R reviews
 // of W words on the user side and on the item side.  One C call = forward, loss (loss.py:7-11),
-// backward and the dense Adam update (main.py:56-60,94-96) in six launches:
+// backward and the dense Adam update (main.py:56-60,94-96) in five launches:
 //
 //   1+2  token compaction (rides on the previous step when the loop announces the next batch),
 //        projection GEMM + gather-add-max over the 2 x B*R review documents (project.hip), or the
@@ -12,12 +12,13 @@
 //                            to every head parameter gradient written as ONE row of a [B, NHP]
 //                            matrix and its ID-table gradient rows kept compact
 //   4    backward launch     argmax-sparse conv wgrad of both towers (wgrad_device.h), the column
-//                            sums of the [B, NHP] matrix in fixed order, next batch's token marks
+//                            sums of the [B, NHP] matrix in fixed order, next batch's token marks,
+//                            and the Adam sweep over the two ID tables and the two bias vectors
+//                            (narre_rows_block): rows no rating touched have gradient zero (never
+//                            materialised), touched rows sum their compact entries in ascending
+//                            order (deterministic)
 //   5    reduce launch       wgrad partials -> gradient, Adam on every dense parameter, next
 //                            batch's token compaction
-//   6    narre_rows_kernel   Adam sweep over the two ID tables and the two bias vectors: rows no
-//                            rating touched have gradient zero (never materialised), touched rows
-//                            sum their compact entries in ascending order (deterministic)
 //
 // The op-by-op path issues ~130 launches for the same step.
 #include <stdlib.h>
@@ -528,61 +529,9 @@ __device__ __forceinline__ void colsum_block(const ColSum &c, int blk) {
     }
 }
 
-__global__ __launch_bounds__(WG_THREADS) void narre_backward_kernel(WgradArgs w, ColSum c, int cs_blocks, TokenArgs nx,
-                                                                    int packed) {
-    if (blockIdx.z < 2) {
-        if (packed) wgrad_block_packed(w, blockIdx.x, blockIdx.y, blockIdx.z);   // grid.x = ceil(F / 4)
-        else wgrad_block(w, blockIdx.x, blockIdx.y, blockIdx.z);
-    } else if (blockIdx.z == 2) {
-        for (int blk = blockIdx.y * gridDim.x + blockIdx.x; blk < cs_blocks; blk += gridDim.x * gridDim.y) {
-            colsum_block(c, blk);
-            __syncthreads();
-        }
-    } else {
-        token_mark_block(nx, blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y, WG_THREADS);
-    }
-}
-
-// ---- 5: wgrad partial reduce + Adam on the dense parameters + next batch's compaction
-constexpr int NRED_THREADS = 256;
-struct DenseAdam {
-    float *p, *m, *v;
-    const float *g;
-    int64_t lo0, hi0, lo1, hi1;
-    AdamScalars s;
-    int on;
-};
-__global__ __launch_bounds__(NRED_THREADS) void narre_reduce_kernel(WgradArgs w, int red_blocks, int comp_blocks,
-                                                                    TokenArgs nx, DenseAdam opt) {
-    const int bx = blockIdx.x;
-    if (bx < red_blocks) {
-        wgrad_reduce_block(w, blockIdx.y, bx);
-        if (opt.on) {
-            const WgradTower &tw = w.t[blockIdx.y];
-            const int nw = w.F * 3 * w.E;
-            const int i = bx * NRED_THREADS + threadIdx.x;
-            const float *gp = i < nw ? tw.d_w + i : (i < nw + w.F ? tw.d_b + (i - nw) : nullptr);
-            if (gp) {
-                const int64_t o = gp - opt.g;
-                float P = opt.p[o], M = opt.m[o], V = opt.v[o];
-                adam_elem(P, *gp, M, V, opt.s);
-                opt.p[o] = P; opt.m[o] = M; opt.v[o] = V;
-            }
-        }
-    } else if (bx < red_blocks + comp_blocks) {
-        token_compact_block<NRED_THREADS / 64>(nx.t[blockIdx.y], nx.V, bx - red_blocks);
-    } else {
-        const int64_t base = blockIdx.y ? opt.lo1 : opt.lo0, end = blockIdx.y ? opt.hi1 : opt.hi0;
-        const int64_t o = base + (int64_t)(bx - red_blocks - comp_blocks) * NRED_THREADS + threadIdx.x;
-        if (o < end) {
-            float P = opt.p[o], M = opt.m[o], V = opt.v[o];
-            adam_elem(P, opt.g[o], M, V, opt.s);
-            opt.p[o] = P; opt.m[o] = M; opt.v[o] = V;
-        }
-    }
-}
-
-// ---- 6: Adam over the ID tables and bias vectors, two kinds of workgroup in one launch
+// ---- Adam over the ID tables and bias vectors (a role of the backward launch: it depends only on
+// the head kernel, and its ~18 us of latency-bound work hides behind the weight gradient), two
+// kinds of workgroup
 //   sweep workgroups  stream every element; a row NO rating touched (tag != this step) gets the
 //                     gradient-zero update, a touched row is left alone
 //   entry waves       one wave per compact entry k.  It scans the entry ids once (64 lanes wide);
@@ -606,8 +555,7 @@ struct RowSweep {
     AdamScalars s;
 };
 template <int ML>
-__global__ __launch_bounds__(NROW_THREADS) void narre_rows_kernel(RowSweep w) {
-    const int bx = (int)blockIdx.x;
+__device__ __forceinline__ void narre_rows_block(const RowSweep &w, int bx) {
     if (bx >= w.cb_entries) {
         // ---- entry waves: 4 per workgroup, all of one table (user table's groups first)
         __shared__ int sid[NROW_MAX_ENTRIES];
@@ -729,6 +677,78 @@ __global__ __launch_bounds__(NROW_THREADS) void narre_rows_kernel(RowSweep w) {
         }
     }
 }
+
+// ML: 0 = no ID-table role (DeepCoNN++), else the rows role's template argument.  z-slices: the ID
+// tables (ML > 0), the two towers' weight gradients, the head-parameter column sums, the next
+// batch's token marks (if announced).
+template <int ML>
+__global__ __launch_bounds__(WG_THREADS) void narre_backward_kernel(WgradArgs w, ColSum c, int cs_blocks, TokenArgs nx,
+                                                                    int packed, RowSweep rows, int row_blocks) {
+    const int blk0 = blockIdx.y * gridDim.x + blockIdx.x, nblk = gridDim.x * gridDim.y;
+    // the ID-table role is dispatched FIRST (slice 0 when present): its owners' dependent chains are
+    // the longest thing in the launch, the weight-gradient workgroups fill in around them
+    const int z = (int)blockIdx.z - (ML > 0 ? 1 : 0);
+    if (z < 0) {
+        if constexpr (ML > 0) {
+            // entry workgroups first (the owner of a popular row is the longest), then the sweep
+            for (int blk = blk0; blk < row_blocks; blk += nblk) {
+                const int ne = row_blocks - rows.cb_entries;
+                narre_rows_block<ML>(rows, blk < ne ? rows.cb_entries + blk : blk - ne);
+                __syncthreads();
+            }
+        }
+    } else if (z < 2) {
+        if (packed) wgrad_block_packed(w, blockIdx.x, blockIdx.y, z);   // grid.x = ceil(F / 4)
+        else wgrad_block(w, blockIdx.x, blockIdx.y, z);
+    } else if (z == 2) {
+        for (int blk = blk0; blk < cs_blocks; blk += nblk) {
+            colsum_block(c, blk);
+            __syncthreads();
+        }
+    } else {
+        token_mark_block(nx, blk0, nblk, WG_THREADS);
+    }
+}
+
+// ---- 5: wgrad partial reduce + Adam on the dense parameters + next batch's compaction
+constexpr int NRED_THREADS = 256;
+struct DenseAdam {
+    float *p, *m, *v;
+    const float *g;
+    int64_t lo0, hi0, lo1, hi1;
+    AdamScalars s;
+    int on;
+};
+__global__ __launch_bounds__(NRED_THREADS) void narre_reduce_kernel(WgradArgs w, int red_blocks, int comp_blocks,
+                                                                    TokenArgs nx, DenseAdam opt) {
+    const int bx = blockIdx.x;
+    if (bx < red_blocks) {
+        wgrad_reduce_block(w, blockIdx.y, bx);
+        if (opt.on) {
+            const WgradTower &tw = w.t[blockIdx.y];
+            const int nw = w.F * 3 * w.E;
+            const int i = bx * NRED_THREADS + threadIdx.x;
+            const float *gp = i < nw ? tw.d_w + i : (i < nw + w.F ? tw.d_b + (i - nw) : nullptr);
+            if (gp) {
+                const int64_t o = gp - opt.g;
+                float P = opt.p[o], M = opt.m[o], V = opt.v[o];
+                adam_elem(P, *gp, M, V, opt.s);
+                opt.p[o] = P; opt.m[o] = M; opt.v[o] = V;
+            }
+        }
+    } else if (bx < red_blocks + comp_blocks) {
+        token_compact_block<NRED_THREADS / 64>(nx.t[blockIdx.y], nx.V, bx - red_blocks);
+    } else {
+        const int64_t base = blockIdx.y ? opt.lo1 : opt.lo0, end = blockIdx.y ? opt.hi1 : opt.hi0;
+        const int64_t o = base + (int64_t)(bx - red_blocks - comp_blocks) * NRED_THREADS + threadIdx.x;
+        if (o < end) {
+            float P = opt.p[o], M = opt.m[o], V = opt.v[o];
+            adam_elem(P, opt.g[o], M, V, opt.s);
+            opt.p[o] = P; opt.m[o] = M; opt.v[o] = V;
+        }
+    }
+}
+
 
 struct NarreWs {
     float *wp[2], *pmax[2]; int *parg[2];
@@ -1168,23 +1188,7 @@ extern "C" int r4r_narre_step(const float *table, int64_t V,
         }
         nx = make_token_args(V, nt, 2, N, T);
     }
-    const int packed = 3 * E / 4 <= 64;                     // narrow windows: one wave per filter
-    narre_backward_kernel<<<dim3(packed ? (NF + 3) / 4 : NF, wa.nsplit, prefetch ? 4 : 3), WG_THREADS, 0, st>>>(
-        wa, cs, cs_blocks, nx, packed);
-
-    // 5: wgrad reduce + Adam on the dense parameters (+ next batch's compaction)
-    const int red_blocks = (NF * 3 * E + NF + NRED_THREADS - 1) / NRED_THREADS;
-    const int comp_blocks = prefetch ? (int)cdiv((V + 3) / 4, NRED_THREADS) : 0;
-    DenseAdam opt;
-    opt.on = 1; opt.p = flat_p; opt.m = flat_m; opt.v = flat_v; opt.g = flat_g;
-    opt.lo0 = hc.lo0; opt.hi0 = hc.hi0; opt.lo1 = hc.lo1; opt.hi1 = hc.hi1;
-    opt.s = adam_make_scalars(lr, beta1, beta2, eps, weight_decay, adam_step, nullptr);
-    const int64_t longest = hc.hi0 - hc.lo0 > hc.hi1 - hc.lo1 ? hc.hi0 - hc.lo0 : hc.hi1 - hc.lo1;
-    const int opt_blocks = (int)cdiv(longest, NRED_THREADS);
-    narre_reduce_kernel<<<dim3(red_blocks + comp_blocks + opt_blocks, 2), NRED_THREADS, 0, st>>>(wa, red_blocks, comp_blocks,
-                                                                                                nx, opt);
-
-    // 6: ID tables + bias vectors
+    // ID tables + bias vectors: a role of the backward launch
     RowSweep rs;
     float *rp[4], *rm[4], *rv[4];
     for (int k = 0; k < 4; ++k) {
@@ -1198,18 +1202,31 @@ extern "C" int r4r_narre_step(const float *table, int64_t V,
     const int64_t numel[4] = {n_users * L, n_items * L, n_users, n_items};
     int64_t begin[5], chunks = 0;
     for (int k = 0; k < 4; ++k) { begin[k] = chunks; chunks += cdiv(numel[k], NROW_CHUNK); }
-    R4R_REQUIRE(chunks < (1ll << 31), "narre_step: too many chunks");
     rs.n0 = numel[0]; rs.n1 = numel[1]; rs.n2 = numel[2]; rs.n3 = numel[3];
     rs.cb1 = (int)begin[1]; rs.cb2 = (int)begin[2]; rs.cb3 = (int)begin[3]; rs.cb_entries = (int)chunks;
     chunks += 2 * cdiv(B * (1 + R), 4);                     // the entry waves, 4 per workgroup, per table
+    R4R_REQUIRE(chunks < (1ll << 31), "narre_step: too many chunks");
     rs.gid0 = w.gid[0]; rs.gid1 = w.gid[1]; rs.grow0 = w.grow[0]; rs.grow1 = w.grow[1]; rs.g = w.g;
     rs.tag0 = w.tag[0]; rs.tag1 = w.tag[1]; rs.entries = B * (1 + R); rs.B = B; rs.L = L; rs.now = (int)adam_step;
-    rs.s = opt.s;
-    {
-        ScopedTiming tm(R4R_TIMING_ADAM, st);
-        if (L <= 16) narre_rows_kernel<16><<<(unsigned)chunks, NROW_THREADS, 0, st>>>(rs);
-        else narre_rows_kernel<32><<<(unsigned)chunks, NROW_THREADS, 0, st>>>(rs);
-    }
+    rs.s = adam_make_scalars(lr, beta1, beta2, eps, weight_decay, adam_step, nullptr);
+
+    const int packed = 3 * E / 4 <= 64;                     // narrow windows: one wave per filter
+    const dim3 bgrid(packed ? (NF + 3) / 4 : NF, wa.nsplit, prefetch ? 5 : 4);
+    if (L <= 16) narre_backward_kernel<16><<<bgrid, WG_THREADS, 0, st>>>(wa, cs, cs_blocks, nx, packed, rs, (int)chunks);
+    else narre_backward_kernel<32><<<bgrid, WG_THREADS, 0, st>>>(wa, cs, cs_blocks, nx, packed, rs, (int)chunks);
+
+    // 5: wgrad reduce + Adam on the dense parameters (+ next batch's compaction)
+    const int red_blocks = (NF * 3 * E + NF + NRED_THREADS - 1) / NRED_THREADS;
+    const int comp_blocks = prefetch ? (int)cdiv((V + 3) / 4, NRED_THREADS) : 0;
+    DenseAdam opt;
+    opt.on = 1; opt.p = flat_p; opt.m = flat_m; opt.v = flat_v; opt.g = flat_g;
+    opt.lo0 = hc.lo0; opt.hi0 = hc.hi0; opt.lo1 = hc.lo1; opt.hi1 = hc.hi1;
+    opt.s = adam_make_scalars(lr, beta1, beta2, eps, weight_decay, adam_step, nullptr);
+    const int64_t longest = hc.hi0 - hc.lo0 > hc.hi1 - hc.lo1 ? hc.hi0 - hc.lo0 : hc.hi1 - hc.lo1;
+    const int opt_blocks = (int)cdiv(longest, NRED_THREADS);
+    narre_reduce_kernel<<<dim3(red_blocks + comp_blocks + opt_blocks, 2), NRED_THREADS, 0, st>>>(wa, red_blocks, comp_blocks,
+                                                                                                nx, opt);
+
     return check_launch("narre_step");
 }
 
@@ -1355,8 +1372,8 @@ extern "C" int r4r_deepconnpp_step(const float *table, int64_t V, const int64_t 
         nx = make_token_args(V, nt, 2, B, T);
     }
     const int packed = 3 * E / 4 <= 64;
-    narre_backward_kernel<<<dim3(packed ? (NF + 3) / 4 : NF, wa.nsplit, prefetch ? 4 : 3), WG_THREADS, 0, st>>>(
-        wa, cs, cs_blocks, nx, packed);
+    narre_backward_kernel<0><<<dim3(packed ? (NF + 3) / 4 : NF, wa.nsplit, prefetch ? 4 : 3), WG_THREADS, 0, st>>>(
+        wa, cs, cs_blocks, nx, packed, RowSweep{}, 0);
 
     const int red_blocks = (NF * 3 * E + NF + NRED_THREADS - 1) / NRED_THREADS;
     const int comp_blocks = prefetch ? (int)cdiv((V + 3) / 4, NRED_THREADS) : 0;

@@ -452,7 +452,7 @@ class MFEngine:
 class NarreEngine:
     """Native step for NARRE (csrc/narre_engine.hip, r4r_narre_step): TextCNN over the B*R review
     documents of each side, both attention scorers, the ID vectors, `final`, the bias head, SE,
-    the backward and the dense Adam update in six launches (the op-by-op path needs ~130).
+    the backward and the dense Adam update in five launches (the op-by-op path needs ~130).
     Dense parameters live in one flat buffer (the module's Parameters alias it), the ID tables
     and bias vectors stay where they are and are updated by a tagged sweep that never builds
     their dense gradient.  Same surface as DeepCoNNEngine; single process only."""
