@@ -194,6 +194,10 @@ def main():
         from reviews4rec_amd.engine import DeepCoNNPPEngine
         engine = DeepCoNNPPEngine(model, lr=hp['lr'], weight_decay=hp['weight_decay'], seed=4321, rank=rank,
                                   conv_algo={'auto': 0, 'direct': 1, 'project': 2}[args.conv_algo])
+    if args.engine == 'native' and is_tn and world == 1:
+        from reviews4rec_amd.engine import TransNetEngine
+        engine = TransNetEngine(model, lr=hp['lr'], weight_decay=hp['weight_decay'], seed=4321, rank=rank,
+                                conv_algo={'auto': 0, 'direct': 1, 'project': 2}[args.conv_algo])
     if args.engine == 'native' and hp['model_type'] == 'deepconn':
         from reviews4rec_amd.engine import DeepCoNNEngine
         engine = DeepCoNNEngine(model, lr=hp['lr'], weight_decay=hp['weight_decay'], dp=dp, seed=4321, rank=rank,
@@ -269,6 +273,12 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
+    # The synthetic generators hold millions of Python objects; a generation-2 collection in the
+    # middle of the timed loop is a 30-60 ms host pause, longer than the launch queue is deep
+    # (seen as one idle GPU gap on the slow-step workloads).  Collect now and freeze the survivors.
+    import gc
+    gc.collect()
+    gc.freeze()
     for i in range(args.warmup):
         step(i)
     fence()
@@ -279,9 +289,30 @@ def main():
     mask = 0 if args.no_kernel_timing else (1 << 0) | (1 << 3) | (1 << 4) | \
         ((1 << 2) if hp['model_type'] in ('MF_dot', 'bias_only') else 0)       # MF: the Adam sweep is the leg
     t0 = time.perf_counter()
+    dbg = [] if os.environ.get('R4R_BENCH_TRACE') else None
+    gev = []
+    if dbg is not None:
+        gev.append(torch.cuda.Event(enable_timing=True))
+        gev[-1].record()
+    depth = int(os.environ.get('R4R_BENCH_DEPTH', '0'))
+    marks = []
     for i in range(args.steps):
         lib.r4r_timing_enable(mask if i % 10 == 5 else 0)
         step(args.warmup + i)
+        if depth and i % 4 == 3:
+            ev = torch.cuda.Event()
+            ev.record()
+            marks.append(ev)
+            if len(marks) > depth // 4:
+                marks.pop(0).synchronize()
+        if dbg is not None and i % 20 == 19:
+            dbg.append(time.perf_counter() - t0)
+            gev.append(torch.cuda.Event(enable_timing=True))
+            gev[-1].record()
+    if dbg is not None:
+        print('enqueue wall at every 20th step (ms):', ' '.join('%.1f' % (1e3 * d) for d in dbg), file=sys.stderr)
+        torch.cuda.synchronize()
+        print('GPU ms per 20 steps:', ' '.join('%.1f' % gev[k].elapsed_time(gev[k + 1]) for k in range(len(gev) - 1)), file=sys.stderr)
     fence()
     elapsed = time.perf_counter() - t0
     lib.r4r_timing_enable(0)
@@ -378,7 +409,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             cpu_hp = {k: v for k, v in hp.items() if k != 'word_vectors'}
             result['cpu_baseline'] = cpu_baseline(cpu_hp, table, batches_np[:4], args.cpu_seconds)
-        run_sse = float(engine.sse.item()) if engine is not None else (
+        run_sse = float(engine.sse[0].item()) if engine is not None else (
             float(graphed.sse.item()) if graphed is not None else float(metric_sum.item()))
         result['train_mse_running'] = round(run_sse / ((args.steps + args.warmup) * B), 4)
         print(json.dumps(result))

@@ -394,6 +394,46 @@ int r4r_deepconnpp_step(const float *table, int64_t V, const int64_t *user_idx, 
                         float lr, double beta1, double beta2, float eps, float weight_decay, int64_t adam_step,
                         void *stream);
 
+/* ---- fused native step for TransNet / TransNet++ (TransNet.py:9-122; the three-optimiser step of
+ * main.py:26-53 with utils.init_transnet_optim, utils.py:70-92).  Three TextCNN towers (user
+ * documents, item documents, the review being rated: user_idx / item_idx / this_idx [B, T]) and
+ * three losses from one forward -- target MSE -> target.*, transform loss mean ||s_ir - t_ir||^2 ->
+ * source.*, source MSE -> source_fm.* and (TransNet++, plus = 1) the ID vectors.  The gradient each
+ * of the reference's three optimisers consumes is that of its own loss on its own parameter group
+ * at the pre-step weights, so the step is one backward with three disjoint groups and -- the three
+ * Adams sharing lr, weight decay and step count -- one flat Adam (csrc/narre_engine.hip has the
+ * argument; the reference-generated trajectories pin it).
+ * Flat layout (22 slots, r4r_transnet_layout): source.user_conv.convs.0.weight, .bias,
+ * source.item_conv.convs.0.(same), target.conv.convs.0.(same), source.user_conv.fc.weight, .bias,
+ * source.item_conv.fc.(same), target.conv.fc.(same), source.project.0.weight, .bias,
+ * source.project.2.weight, .bias, source_fm.V, source_fm.lin.weight, .bias, target.fm.V,
+ * target.fm.lin.weight, .bias.  rows_p / rows_m / rows_v: HOST arrays of 2 DEVICE pointers --
+ * user_embedding.weight [n_users, 5], item_embedding.weight [n_items, 5] (TransNet++; NULL otherwise).
+ * pred / se: the SOURCE prediction and its squared error (what main.py:57 sums); sse_accum (3 floats,
+ * nullable) += [sum of se, this batch's mean target SE, this batch's transform loss]; the workspace
+ * holds per rating (r4r_transnet_ws_offset which = 3) the target prediction, its squared error and
+ * ||s_ir - t_ir||^2.  Dropout draws per rating at Philox counter offset + b*(5L+10) + k:
+ * source.user_conv.dropout [L], source.item_conv.dropout [L], target.conv.dropout [L],
+ * source.dropout [L], target.dropout [L], dropout.user [5], dropout.item [5]. */
+int r4r_transnet_nparam(void);
+int r4r_transnet_layout(int E, int L, int plus, int64_t *offsets, int64_t *sizes, int64_t *total);
+size_t r4r_transnet_ws_bytes(int64_t B, int T, int E, int L, int plus, int64_t V, int64_t n_users, int64_t n_items);
+size_t r4r_transnet_ws_offset(int64_t B, int T, int E, int L, int plus, int64_t V, int64_t n_users, int64_t n_items,
+                              int which);   /* 0 dropout multipliers, 1 / 2 ID-vector gradient rows [B,5], 3 aux [B,3], 6 + 2*tower + buffer: token counter */
+int r4r_transnet_step(const float *table, int64_t V,
+                      const int64_t *user_idx, const int64_t *item_idx, const int64_t *this_idx,
+                      const int64_t *uid, const int64_t *iid, const float *y,
+                      float *flat_p, float *flat_g, float *flat_m, float *flat_v,
+                      const uint64_t *rows_p, const uint64_t *rows_m, const uint64_t *rows_v,
+                      int64_t n_users, int64_t n_items,
+                      float *pred, float *se, float *sse_accum, void *ws, size_t ws_bytes,
+                      int64_t B, int T, int E, int L, int plus,
+                      float dropout_p, int training, uint64_t seed, uint64_t offset, float inv_denom,
+                      int conv_algo, int token_buffer, int tokens_ready,
+                      const int64_t *next_user_idx, const int64_t *next_item_idx, const int64_t *next_this_idx,
+                      float lr, double beta1, double beta2, float eps, float weight_decay, int64_t adam_step,
+                      void *stream);
+
 /* proj_gather_max_kernel (gather-add-max over positions) */
 #define R4R_TIMING_SLOTS 8
 int r4r_timing_enable(int slot_mask);   /* bit i instruments slot i; 0 switches timing off */

@@ -68,7 +68,7 @@ def train_step(params, data, y, hyper_params, state, masks=None):
     return float(se.detach().sum()), grads
 
 
-def transnet_train_step(params, data, y, hyper_params, states):
+def transnet_train_step(params, data, y, hyper_params, states, masks=None):
     """TransNet's three-optimiser step (main.py:26-53 with utils.init_transnet_optim,
     utils.py:70-92) with the torch-0.4 semantics the reference was written for: ONE forward,
     three backward passes over the retained graph, and an optimiser step between them that
@@ -78,13 +78,14 @@ def transnet_train_step(params, data, y, hyper_params, states):
 
     ``states`` = dict(source=AdamState(), source_fm=AdamState(), target=AdamState()).
     Mutates ``params`` and ``states``; returns (per-example source SE, loss_target, loss_transform).
+    ``masks``: dropout multipliers by site name (tests inject the device-drawn ones).
     """
     mt = hyper_params['model_type']
     names = trainable_names(params)
     leaves = {k: params[k].detach().clone().requires_grad_(True) for k in names}
     full = dict(params)
     full.update(leaves)
-    src_pred, tgt_pred, transform = model_forward(full, data, hyper_params, train=True)
+    src_pred, tgt_pred, transform = model_forward(full, data, hyper_params, train=True, masks=masks)
 
     groups = {
         'target': [k for k in names if k.startswith('target.')],

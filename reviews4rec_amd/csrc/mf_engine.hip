@@ -264,7 +264,7 @@ __device__ __forceinline__ void mf_entry(const MfSweep &w, const int *sid, int *
                 const int idx = q * epl + grp;
                 const int e = pl[base + ((q < nacc && idx < n) ? idx : 0)];
                 tmp[q] = reinterpret_cast<const float4 *>(rows + (int64_t)e * D)[sub];
-                tg[q] = w.g[e];
+                tg[q] = w.g ? w.g[e] : 0.f;
             }
 #pragma unroll
             for (int q = 0; q < NACC; ++q) {
@@ -312,7 +312,7 @@ __device__ __forceinline__ void mf_entry(const MfSweep &w, const int *sid, int *
 #pragma unroll
                 for (int x = 0; x < MF_MAX_D / 64; ++x)
                     tmp[q][x] = (lane + 64 * x < D) ? rows[(int64_t)e * D + lane + 64 * x] : 0.f;
-                tg[q] = w.g[e];
+                tg[q] = w.g ? w.g[e] : 0.f;
             }
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
@@ -337,7 +337,7 @@ __device__ __forceinline__ void mf_entry(const MfSweep &w, const int *sid, int *
             }
         }
     }
-    if (lane == 0) {                                        // the row's bias element
+    if (lane == 0 && (t ? w.p3 : w.p2)) {                   // the row's bias element (a caller may have none)
         float *bp = t ? w.p3 : w.p2, *bm = t ? w.m3 : w.m2, *bv = t ? w.v3 : w.v2;
         float P = bp[row], M = bm[row], V = bv[row];
         adam_elem(P, gb, M, V, w.s);
@@ -509,6 +509,65 @@ __global__ __launch_bounds__(MF_THREADS) void mf_adam_kernel(MfSweep w) {
             col += step_col;
             if (col >= W) { col -= W; ++row; }
         }
+    } else if (W >= 4 && aligned) {
+        // table rows whose width is not a multiple of four (TransNet++'s 5-wide ID vectors): a float4
+        // covers at most two rows.  Elements of a touched row are neither updated nor STORED (their
+        // entry wave is writing them).
+        const int64_t nvec = cnt >> 2;
+        const unsigned first = col_start + tid * 4u;
+        int64_t row = row_start + first / (unsigned)W;
+        int col = (int)(first % (unsigned)W);
+        const int step_row = (MF_THREADS * 4) / W, step_col = (MF_THREADS * 4) % W;
+        auto finish = [&](int64_t i, float4 P, float4 M, float4 V, int col_i, int t_lo, int t_hi) {
+            const bool f0 = t_lo != w.now, f1 = (col_i + 1 >= W ? t_hi : t_lo) != w.now,
+                       f2 = (col_i + 2 >= W ? t_hi : t_lo) != w.now, f3 = (col_i + 3 >= W ? t_hi : t_lo) != w.now;
+            if (f0) adam_elem(P.x, 0.f, M.x, V.x, w.s);
+            if (f1) adam_elem(P.y, 0.f, M.y, V.y, w.s);
+            if (f2) adam_elem(P.z, 0.f, M.z, V.z, w.s);
+            if (f3) adam_elem(P.w, 0.f, M.w, V.w, w.s);
+            if (f0 && f1 && f2 && f3) {
+                reinterpret_cast<float4 *>(p)[i] = P; reinterpret_cast<float4 *>(m)[i] = M;
+                reinterpret_cast<float4 *>(v)[i] = V;
+            } else {
+                if (f0) { p[4 * i] = P.x; m[4 * i] = M.x; v[4 * i] = V.x; }
+                if (f1) { p[4 * i + 1] = P.y; m[4 * i + 1] = M.y; v[4 * i + 1] = V.y; }
+                if (f2) { p[4 * i + 2] = P.z; m[4 * i + 2] = M.z; v[4 * i + 2] = V.z; }
+                if (f3) { p[4 * i + 3] = P.w; m[4 * i + 3] = M.w; v[4 * i + 3] = V.w; }
+            }
+        };
+        int64_t i = tid;
+        for (; i + MF_THREADS < nvec; i += 2 * MF_THREADS) {
+            int64_t row1 = row + step_row;
+            int col1 = col + step_col;
+            if (col1 >= W) { col1 -= W; ++row1; }
+            const int64_t j = i + MF_THREADS;
+            const float4 P0 = reinterpret_cast<float4 *>(p)[i], P1 = reinterpret_cast<float4 *>(p)[j];
+            const float4 M0 = reinterpret_cast<float4 *>(m)[i], M1 = reinterpret_cast<float4 *>(m)[j];
+            const float4 V0 = reinterpret_cast<float4 *>(v)[i], V1 = reinterpret_cast<float4 *>(v)[j];
+            const int a0 = tag[row], a1 = tag[row + (col + 3 >= W)], b0 = tag[row1], b1 = tag[row1 + (col1 + 3 >= W)];
+            finish(i, P0, M0, V0, col, a0, a1);
+            finish(j, P1, M1, V1, col1, b0, b1);
+            row = row1 + step_row;
+            col = col1 + step_col;
+            if (col >= W) { col -= W; ++row; }
+        }
+        for (; i < nvec; i += MF_THREADS) {
+            const float4 P = reinterpret_cast<float4 *>(p)[i], M = reinterpret_cast<float4 *>(m)[i];
+            const float4 V = reinterpret_cast<float4 *>(v)[i];
+            finish(i, P, M, V, col, tag[row], tag[row + (col + 3 >= W)]);
+            row += step_row;
+            col += step_col;
+            if (col >= W) { col -= W; ++row; }
+        }
+        const int64_t k = (nvec << 2) + tid;                // the chunk's last cnt % 4 elements
+        if (k < cnt) {
+            const int64_t r = (start + k) / W;
+            float P = p[k], M = m[k], V = v[k];
+            if (tag[r] != w.now) {
+                adam_elem(P, 0.f, M, V, w.s);
+                p[k] = P; m[k] = M; v[k] = V;
+            }
+        }
     } else {                                                // bias vectors (W = 1) and unaligned tables
         const unsigned first = col_start + tid;
         int64_t row = row_start + first / (unsigned)W;
@@ -589,6 +648,37 @@ int mf_bias_rows_launch(float *ub, float *ub_m, float *ub_v, float *ib, float *i
     sw.tag_u = tag_u; sw.tag_i = tag_i; sw.B = B; sw.D = 0; sw.now = now; sw.s = sc;
     mf_adam_kernel<4><<<(unsigned)chunks, MF_THREADS, (size_t)B * sizeof(int), st>>>(sw);
     return check_launch("bias rows");
+}
+
+// Adam on two ID tables of width D whose gradient rows are compact ([B, D] per table, one row per
+// rating; TransNet++'s user / item vectors, TransNet.py:75-76): the sweep + entry waves above
+// without bias vectors.  `tag_*`: per-row step tags the caller's forward kernel set to `now`.
+int mf_table_rows_launch(float *ut, float *ut_m, float *ut_v, float *it, float *it_m, float *it_v,
+                         int64_t n_users, int64_t n_items, int D, const int64_t *uid, const int64_t *iid,
+                         const float *gu, const float *gi, const int *tag_u, const int *tag_i, int64_t B, int now,
+                         const AdamScalars &sc, hipStream_t st) {
+    if (B > MF_MAX_B || D < 1 || D > MF_MAX_D) {
+        set_error("table rows: batch %lld > %d or width %d outside 1..%d", (long long)B, MF_MAX_B, D, MF_MAX_D);
+        return R4R_ERR_ARG;
+    }
+    MfSweep sw{};
+    sw.p0 = ut; sw.m0 = ut_m; sw.v0 = ut_v; sw.p1 = it; sw.m1 = it_m; sw.v1 = it_v;
+    sw.n0 = n_users * D; sw.n1 = n_items * D; sw.n2 = sw.n3 = 0;
+    int64_t chunks = cdiv(sw.n0, mf_chunk(0));
+    sw.cb1 = (int)chunks;
+    chunks += cdiv(sw.n1, mf_chunk(1));
+    sw.cb2 = sw.cb3 = sw.cb_global = sw.cb_entries = (int)chunks;   // no bias vectors, no global-bias workgroup
+    sw.epw = mf_epw(B);
+    sw.n_entry_wgs = (int)(2 * cdiv(B, 4 * sw.epw));
+    chunks += sw.n_entry_wgs;
+    if (chunks >= (1ll << 31)) {
+        set_error("table rows: too many workgroups");
+        return R4R_ERR_ARG;
+    }
+    sw.uid = uid; sw.iid = iid; sw.gu = gu; sw.gi = gi; sw.g = nullptr; sw.se = nullptr; sw.sse_accum = nullptr;
+    sw.tag_u = tag_u; sw.tag_i = tag_i; sw.B = B; sw.D = D; sw.now = now; sw.s = sc;
+    mf_adam_kernel<4><<<(unsigned)chunks, MF_THREADS, (size_t)B * sizeof(int), st>>>(sw);
+    return check_launch("table rows");
 }
 
 }  // namespace r4r

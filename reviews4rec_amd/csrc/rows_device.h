@@ -8,4 +8,9 @@ int mf_bias_rows_launch(float *ub, float *ub_m, float *ub_v, float *ib, float *i
                         int64_t n_users, int64_t n_items, const int64_t *uid, const int64_t *iid, const float *g,
                         const int *tag_u, const int *tag_i, int64_t B, int now, const AdamScalars &sc, hipStream_t st);
 
+int mf_table_rows_launch(float *ut, float *ut_m, float *ut_v, float *it, float *it_m, float *it_v,
+                         int64_t n_users, int64_t n_items, int D, const int64_t *uid, const int64_t *iid,
+                         const float *gu, const float *gi, const int *tag_u, const int *tag_i, int64_t B, int now,
+                         const AdamScalars &sc, hipStream_t st);
+
 }  // namespace r4r

@@ -466,16 +466,17 @@ class NarreEngine:
     ROW_NAMES = ['user_embedding.weight', 'item_embedding.weight', 'user_bias', 'item_bias']
     MODEL_TYPE = 'NARRE'
     C = 'narre'                  # prefix of the C entry points
+    NTOWER = 2                   # TextCNN towers (token states per buffer)
 
     def __init__(self, model, lr=0.002, weight_decay=1e-6, betas=(0.9, 0.999), eps=1e-8, seed=0x5EED5EED, rank=0,
                  conv_algo=0):
         hp = model.hyper_params
-        if hp['model_type'] != self.MODEL_TYPE:
+        if hp['model_type'] not in (self.MODEL_TYPE if isinstance(self.MODEL_TYPE, tuple) else (self.MODEL_TYPE,)):
             raise ValueError('%s implements model_type %r, got %r' % (type(self).__name__, self.MODEL_TYPE, hp['model_type']))
         self.model, self.hp = model, hp
         self.conv_algo = int(conv_algo)
         self.lr, self.wd, self.betas, self.eps = float(lr), float(weight_decay), tuple(betas), float(eps)
-        self.table = model.word2vec.weight
+        self.table = self._word_table(model)
         if not self.table.is_cuda:
             raise RuntimeError('NarreEngine: move the model to a ROCm device first; the HIP path has no CPU fallback')
         self.dev = self.table.device
@@ -484,7 +485,8 @@ class NarreEngine:
         lib = _lib.lib()
         n = getattr(lib, 'r4r_%s_nparam' % self.C)()
         off, size, total = (ctypes.c_int64 * n)(), (ctypes.c_int64 * n)(), ctypes.c_int64()
-        _lib.check(getattr(lib, 'r4r_%s_layout' % self.C)(self.E, self.L, off, size, ctypes.byref(total)), 'layout')
+        _lib.check(getattr(lib, 'r4r_%s_layout' % self.C)(self.E, self.L, *self._layout_extra(), off, size,
+                                                          ctypes.byref(total)), 'layout')
         params = dict(model.named_parameters())
         self.slots = [params[k] for k in self.NAMES]
         self.offsets, self.sizes, self.total = list(off), list(size), int(total.value)
@@ -502,13 +504,25 @@ class NarreEngine:
             raise RuntimeError('NarreEngine: fp32 contiguous ID tables / bias vectors only')
         self.rows_m = [torch.zeros_like(p) for p in self.rows]
         self.rows_v = [torch.zeros_like(p) for p in self.rows]
-        self.n_users, self.n_items = self.rows[-2].numel(), self.rows[-1].numel()
-        self.sse = torch.zeros(1, dtype=torch.float32, device=self.dev)
+        self.n_users, self.n_items = self._cardinalities()
+        self.sse = torch.zeros(self.SSE_SLOTS, dtype=torch.float32, device=self.dev)
         self.step_count = 0
         self.seed = (int(seed) * 0x9E3779B97F4A7C15 + int(rank) * 0xD1B54A32D192ED03) & 0xFFFFFFFFFFFFFFFF
         self.offset = 0
         self._ws, self._ws_key, self._out = None, None, {}
         self._prepared, self._last_buf = None, 1
+
+    SSE_SLOTS = 1
+
+    @staticmethod
+    def _word_table(model):
+        return model.word2vec.weight
+
+    def _layout_extra(self):
+        return ()
+
+    def _cardinalities(self):
+        return self.rows[-2].numel(), self.rows[-1].numel()
 
     @staticmethod
     def _p4(tensors):
@@ -577,7 +591,7 @@ class NarreEngine:
             nf, nn, nR, nT = self._fields(next_data)
             if (nn, nR, nT) == (n, R, T):
                 nxt = nf
-        key = (f[0].data_ptr(), f[1].data_ptr(), n, R, T)
+        key = tuple(t.data_ptr() for t in f[:self.NTOWER]) + (n, R, T)
         ready = 0
         if self._prepared is not None and self._prepared[0] == key:
             buf, ready = self._prepared[1], 1
@@ -585,7 +599,7 @@ class NarreEngine:
         else:
             if self._prepared is not None:                   # a wrong guess: drop its token state
                 pb = self._prepared[1]
-                for t in range(2):                           # the compaction counters of that buffer
+                for t in range(self.NTOWER):                 # the compaction counters of that buffer
                     at = self._ws_offset(n, R, T, 6 + 2 * t + pb)
                     ws[at:at + 4].zero_()
                 self._prepared = None
@@ -595,7 +609,7 @@ class NarreEngine:
         _lib.check(rc, 'r4r_%s_step' % self.C)
         self._last_buf = buf
         if nxt is not None:
-            self._prepared = ((nxt[0].data_ptr(), nxt[1].data_ptr(), n, R, T), buf ^ 1, nxt)
+            self._prepared = (tuple(t.data_ptr() for t in nxt[:self.NTOWER]) + (n, R, T), buf ^ 1, nxt)
         if train_mode and float(self.hp['dropout']) > 0.0:
             self.offset += n * self._draws(R)
         return pred, se
@@ -720,4 +734,97 @@ class DeepCoNNPPEngine(NarreEngine):
         g = self._workspace(n, R, T)[off:off + n * 4].view(torch.float32)
         out['user_bias'] = torch.zeros_like(self.rows[0]).index_add_(0, f[2], g)
         out['item_bias'] = torch.zeros_like(self.rows[1]).index_add_(0, f[3], g)
+        return out
+
+
+class TransNetEngine(NarreEngine):
+    """Native step for TransNet / TransNet++ (csrc/narre_engine.hip, r4r_transnet_step): three
+    TextCNN towers, the source MLP, both factorisation machines, the three losses of main.py:35-53
+    and their three disjoint parameter groups in ONE backward and one flat Adam (the three
+    optimisers of utils.init_transnet_optim share lr, weight decay and step count; include/r4r.h
+    has the argument for why the reference's three-pass step consumes exactly these gradients).
+    ``sse`` holds [sum of source SE, sum of per-batch target MSE, sum of per-batch transform loss].
+    Replaces the whole optimiser list of the host loop; single process only."""
+    NAMES = ['source.user_conv.convs.0.weight', 'source.user_conv.convs.0.bias',
+             'source.item_conv.convs.0.weight', 'source.item_conv.convs.0.bias',
+             'target.conv.convs.0.weight', 'target.conv.convs.0.bias',
+             'source.user_conv.fc.weight', 'source.user_conv.fc.bias',
+             'source.item_conv.fc.weight', 'source.item_conv.fc.bias',
+             'target.conv.fc.weight', 'target.conv.fc.bias',
+             'source.project.0.weight', 'source.project.0.bias', 'source.project.2.weight', 'source.project.2.bias',
+             'source_fm.V', 'source_fm.lin.weight', 'source_fm.lin.bias',
+             'target.fm.V', 'target.fm.lin.weight', 'target.fm.lin.bias']
+    MODEL_TYPE = ('transnet', 'transnet++')
+    C = 'transnet'
+    NTOWER = 3
+    SSE_SLOTS = 3
+
+    def __init__(self, model, **kw):
+        self.plus = int(model.hyper_params['model_type'] == 'transnet++')
+        self.ROW_NAMES = ['user_embedding.weight', 'item_embedding.weight'] if self.plus else []
+        self._hp_counts = (int(model.hyper_params['total_users']) + 2, int(model.hyper_params['total_items']) + 2)
+        super().__init__(model, **kw)
+
+    @staticmethod
+    def _word_table(model):
+        return model.target.word2vec.weight
+
+    def _layout_extra(self):
+        return (self.plus,)
+
+    def _cardinalities(self):
+        return (self.rows[0].shape[0], self.rows[1].shape[0]) if self.plus else self._hp_counts
+
+    def _fields(self, data):
+        n = data[5].numel()
+        f = [data[3].reshape(n, -1), data[4].reshape(n, -1), data[0].reshape(n, -1), data[5].reshape(-1), data[6].reshape(-1)]
+        if not (f[0].shape == f[1].shape == f[2].shape):
+            raise RuntimeError('TransNetEngine: the three documents of a rating must share input_length')
+        if not all(t.is_cuda and t.dtype == torch.int64 for t in f):
+            raise RuntimeError('TransNetEngine: batches must be int64 tensors on the ROCm device')
+        return [t.contiguous() for t in f], n, 1, f[0].shape[1]
+
+    def _ws_bytes(self, B, R, T):
+        return _lib.lib().r4r_transnet_ws_bytes(B, T, self.E, self.L, self.plus, self.V, self.n_users, self.n_items)
+
+    def _ws_offset(self, B, R, T, which):
+        return _lib.lib().r4r_transnet_ws_offset(B, T, self.E, self.L, self.plus, self.V, self.n_users, self.n_items, which)
+
+    def _draws(self, R):
+        return 5 * self.L + 10
+
+    def _step(self, f, y, pred, se, ws, n, R, T, train_mode, inv_denom, adam_step, buf, ready, nxt):
+        p2 = lambda ts: (ctypes.c_uint64 * 2)(*[t.data_ptr() for t in ts]) if ts else None   # noqa: E731
+        return _lib.lib().r4r_transnet_step(
+            ptr(self.table), self.V, ptr(f[0]), ptr(f[1]), ptr(f[2]), ptr(f[3]), ptr(f[4]), ptr(y),
+            ptr(self.flat_p), ptr(self.flat_g) if adam_step else None, ptr(self.flat_m) if adam_step else None,
+            ptr(self.flat_v) if adam_step else None, p2(self.rows),
+            p2(self.rows_m) if adam_step else None, p2(self.rows_v) if adam_step else None,
+            self.n_users, self.n_items, ptr(pred), ptr(se), ptr(self.sse) if adam_step else None,
+            ptr(ws), ws.numel(), n, T, self.E, self.L, self.plus, float(self.hp['dropout']), int(train_mode), self.seed,
+            self.offset, float(inv_denom), self.conv_algo, buf, ready,
+            ptr(nxt[0]) if nxt else None, ptr(nxt[1]) if nxt else None, ptr(nxt[2]) if nxt else None,
+            self.lr, self.betas[0], self.betas[1], self.eps, self.wd, int(adam_step), _lib.current_stream())
+
+    def aux(self, data):
+        """[B, 3] of the LAST step on `data`: target prediction, its squared error, ||s_ir - t_ir||^2."""
+        f, n, R, T = self._fields(data)
+        off = self._ws_offset(n, R, T, 3)
+        return self._workspace(n, R, T)[off:off + n * 12].view(torch.float32).view(n, 3).clone()
+
+    @torch.no_grad()
+    def predict(self, data, y=None):
+        """Eval-mode forward: (source prediction, its SE or None) -- what eval.py scores; `aux` has the rest."""
+        return super().predict(data, y)
+
+    def grads(self, data):
+        out = {k: self.flat_g[o:o + s].view(p.shape) for k, p, o, s in
+               zip(self.NAMES, self.slots, self.offsets, self.sizes)}
+        if self.plus:
+            f, n, R, T = self._fields(data)
+            ws = self._workspace(n, R, T)
+            for t, name in enumerate(self.ROW_NAMES):
+                off = self._ws_offset(n, R, T, 1 + t)
+                rows = ws[off:off + n * 5 * 4].view(torch.float32).view(n, 5)
+                out[name] = torch.zeros_like(self.rows[t]).index_add_(0, f[3 + t], rows)
         return out

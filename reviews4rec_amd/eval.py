@@ -40,6 +40,11 @@ def evaluate(model, criterion, reader, hyper_params, user_count, item_count, rev
             if engine is not None:
                 output, mse = engine.predict(data, y)
                 mse = mse.clone()                            # the engine reuses its output buffer
+                if is_tn:                                    # TransNetEngine: per rating (target pred, its SE, transform)
+                    aux = engine.aux(data)
+                    r, c = aux[:, 1].mean(), aux[:, 2].mean()
+                    mse_right = r if mse_right is None else mse_right + r
+                    conv_loss = c if conv_loss is None else conv_loss + c
             else:
                 output = model(data)
                 if is_tn:

@@ -117,7 +117,9 @@ def train(model, criterion, optimizer, reader, hyper_params, engine=None, dp=Non
         total_x += float(n_local)
         total_batches += 1
 
-    sse = float(engine.sse.item()) if engine is not None else (float(device_sum) if device_sum is not None else 0.0)
+    sse = float(engine.sse[0].item()) if engine is not None else (float(device_sum) if device_sum is not None else 0.0)
+    if engine is not None and tn:                            # TransNetEngine: sums of the per-batch means
+        metrics['MSE_target'], metrics['MSE_transform'] = float(engine.sse[1].item()), float(engine.sse[2].item())
     if graph is not None and graph.step is not None and engine is None:
         sse += float(graph.step.sse.item())
         graph.step.sse.zero_()
@@ -161,6 +163,12 @@ def make_engine(hyper_params, model, dp=None, rank=0):
         from .engine import DeepCoNNPPEngine
         return DeepCoNNPPEngine(model, lr=hyper_params['lr'], weight_decay=hyper_params['weight_decay'],
                                 seed=hyper_params.get('seed', 0x5EED5EED), rank=rank)
+    if _is_transnet(hyper_params):
+        if (dp is not None and dp.on) or int(hyper_params.get('batch_size', 128)) > 16384:
+            return None
+        from .engine import TransNetEngine
+        return TransNetEngine(model, lr=hyper_params['lr'], weight_decay=hyper_params['weight_decay'],
+                              seed=hyper_params.get('seed', 0x5EED5EED), rank=rank)
     if hyper_params['model_type'] != 'deepconn':
         return None
     from .engine import DeepCoNNEngine
@@ -178,6 +186,11 @@ def train_complete(hyper_params, Model, train_reader, val_reader, user_count, it
     criterion = MSELoss(hyper_params)
     rank = dp.rank if dp is not None else 0
     engine = make_engine(hyper_params, model, dp=dp, rank=rank)
+    # the readers hold millions of Python objects: without this a generation-2 collection stops the
+    # host for tens of milliseconds in the middle of an epoch, longer than the launch queue is deep
+    import gc
+    gc.collect()
+    gc.freeze()
     optimizer = None if engine is not None else make_optimizer(hyper_params, model)
     # no fused step for this model: capture the op-by-op step in a hipGraph (TransNet's three-optimiser
     # step and data-parallel runs stay eager inside train())

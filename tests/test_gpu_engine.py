@@ -267,7 +267,8 @@ def test_host_loop_with_native_engine_and_lookahead_matches_reference_metric():
 
 @pytest.mark.parametrize('case,engine_kind', [('deepconn_e20', 'native'), ('deepconn_e20', 'module'),
                                               ('mf_dot', 'native'), ('mf_dot', 'module'),
-                                              ('narre_e16', 'auto'), ('deepconnpp_e20', 'graph')])
+                                              ('narre_e16', 'auto'), ('deepconnpp_e20', 'graph'),
+                                              ('transnetpp_e16', 'auto')])
 def test_train_complete_resumes_exactly_from_its_epoch_checkpoint(tmp_path, engine_kind, case):
     """main.train_complete with hyper_params['checkpoint_path']: a run stopped after epoch 2 and
     started again lands on the weights of an uninterrupted 4-epoch run -- Adam moments, step
@@ -290,7 +291,7 @@ def test_train_complete_resumes_exactly_from_its_epoch_checkpoint(tmp_path, engi
         ops.DropoutState.manual_seed(1234)
         model, hp = build_model(g, dropout=0.5)
         hp.update(engine=engine_kind, epochs=epochs, dataset='golden', log_file=str(tmp_path / (tag + '.log')),
-                  model_path=str(tmp_path / (tag + '.pt')), seed=99)
+                  model_path=str(tmp_path / (tag.rstrip('12') + '.pt')), seed=99)    # a resumed run keeps its model_path
         if ckpt:
             hp['checkpoint_path'] = str(tmp_path / 'resume.ckpt')
         Model = reviews4rec_amd.get_model_class(hp['model_type'])
@@ -723,3 +724,95 @@ def test_deepconnpp_engine_dropout_masks_injected_into_oracle():
     for k, v in P.items():
         diff = (sd[k].cpu() - v).abs()
         assert float((diff > 2e-5 + 1e-4 * v.abs()).float().mean()) < 2e-3 and float(diff.max()) < 5e-4, k
+
+
+# --------------------------------------------------------------------------------- TransNet native step
+@pytest.mark.parametrize('case', ['transnet_e16', 'transnetpp_e16'])
+@pytest.mark.parametrize('algo', ALGOS)
+def test_transnet_engine_matches_reference_three_optimiser_trajectory(case, algo):
+    """r4r_transnet_step (one backward, three disjoint parameter groups, one flat Adam) along the
+    reference-generated trajectory of the three-optimiser step (main.py:35-53 under torch-0.4
+    write-through semantics): per-example source SE, target / transform losses, weights after 1
+    and 3 steps; then eval-mode predictions."""
+    from reviews4rec_amd.engine import TransNetEngine
+    g = Golden(case)
+    model, hp = build_model(g)
+    model.train()
+    eng = TransNetEngine(model, lr=hp['lr'], weight_decay=hp['weight_decay'], conv_algo=algo)
+    for step in range(3):
+        data, y = g.batch(step % 2, DEV)
+        before = eng.sse.clone()
+        se = eng.train_step(data, y).clone()
+        torch.testing.assert_close(se.cpu(), g.arr('tn_se%d' % step), rtol=1e-4, atol=1e-5)
+        aux = g.arr('tn_aux%d' % step)
+        got = (eng.sse - before).cpu()
+        torch.testing.assert_close(got[1:], aux, rtol=1e-4, atol=1e-5)
+        torch.testing.assert_close(got[0], g.arr('tn_se%d' % step).sum(), rtol=1e-4, atol=1e-4)
+        if step in (0, 2):
+            sd = model.state_dict()
+            for k, v in g.params('tn_w%d' % (step + 1)).items():
+                torch.testing.assert_close(sd[k].cpu(), v, rtol=1e-5, atol=5e-6, msg=lambda m: k + ': ' + m)
+
+
+@pytest.mark.parametrize('case', ['transnet_e16', 'transnetpp_e16'])
+def test_transnet_engine_dropout_masks_and_eval(case):
+    """Dropout 0.5 at all seven sites: the device-drawn masks injected into the CPU oracle's
+    three-optimiser step reproduce two engine steps; eval-mode predictions equal the module's."""
+    from reviews4rec_amd.engine import TransNetEngine
+    g = Golden(case)
+    model, hp = build_model(g, dropout=0.5)
+    P = {k: v.clone() for k, v in g.params().items()}
+    model.train()
+    eng = TransNetEngine(model, lr=hp['lr'], weight_decay=hp['weight_decay'])
+    L = int(hp['latent_size'])
+    states = dict(source=oracle.AdamState(), source_fm=oracle.AdamState(), target=oracle.AdamState())
+    for step in range(2):
+        data, y = g.batch(step % 2, DEV)
+        se = eng.train_step(data, y).cpu().clone()
+        mult = eng.dropout_multipliers(data).cpu()
+        assert 0.3 < float((mult[:, :5 * L] == 0).float().mean()) < 0.7
+        masks = {'source.user_conv.dropout': mult[:, :L], 'source.item_conv.dropout': mult[:, L:2 * L],
+                 'target.conv.dropout': mult[:, 2 * L:3 * L], 'source.dropout': mult[:, 3 * L:4 * L],
+                 'target.dropout': mult[:, 4 * L:5 * L], 'dropout.user': mult[:, 5 * L:5 * L + 5],
+                 'dropout.item': mult[:, 5 * L + 5:]}
+        cdata, cy = g.batch(step % 2)
+        ref_se, lt, ltr = oracle.transnet_train_step(P, cdata, cy, hp, states, masks=masks)
+        torch.testing.assert_close(se, ref_se, rtol=1e-4, atol=1e-5)
+        aux = eng.aux(data).cpu()
+        torch.testing.assert_close(aux[:, 1].mean(), torch.tensor(lt), rtol=1e-4, atol=1e-5)
+        torch.testing.assert_close(aux[:, 2].mean(), torch.tensor(ltr), rtol=1e-4, atol=1e-5)
+    sd = model.state_dict()
+    for k, v in P.items():
+        torch.testing.assert_close(sd[k].cpu(), v, rtol=1e-5, atol=5e-6, msg=lambda m: k + ': ' + m)
+    model.eval()
+    data, y = g.batch(0, DEV)
+    pred, se = eng.predict(data, y)
+    with torch.no_grad():
+        ref = model(data)
+    torch.testing.assert_close(pred, ref[0], rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(eng.aux(data)[:, 0], ref[1].reshape(-1), rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize('case', ['transnet_e16', 'transnetpp_e16'])
+def test_transnet_engine_through_the_host_loop(case):
+    """reviews4rec_amd.main.train with the native TransNet step in place of the optimiser list:
+    the three metrics of main.py:62-66 along the reference trajectory, and make_engine picks it."""
+    from reviews4rec_amd import main as M
+    from reviews4rec_amd.engine import TransNetEngine
+    from reviews4rec_amd.loss import MSELoss
+    g = Golden(case)
+    model, hp = build_model(g)
+    eng = M.make_engine(dict(hp, engine='auto'), model)
+    assert isinstance(eng, TransNetEngine)
+    for step in range(3):
+        class OneBatch:
+            def iter(self, eval=False):
+                yield g.batch(step % 2, DEV)
+        metrics = M.train(model, MSELoss(hp), None, OneBatch(), hp, engine=eng)
+        assert metrics['MSE'] == pytest.approx(round(float(g.arr('tn_se%d' % step).mean()), 4), abs=2e-4)
+        aux = g.arr('tn_aux%d' % step)
+        assert metrics['MSE_target'] == pytest.approx(float(aux[0]), abs=2e-4)
+        assert metrics['MSE_transform'] == pytest.approx(float(aux[1]), abs=2e-4)
+    sd = model.state_dict()
+    for k, v in g.params('tn_w3').items():
+        torch.testing.assert_close(sd[k].cpu(), v, rtol=1e-5, atol=5e-6, msg=lambda m: k + ': ' + m)
