@@ -419,7 +419,7 @@ int r4r_transnet_nparam(void);
 int r4r_transnet_layout(int E, int L, int plus, int64_t *offsets, int64_t *sizes, int64_t *total);
 size_t r4r_transnet_ws_bytes(int64_t B, int T, int E, int L, int plus, int64_t V, int64_t n_users, int64_t n_items);
 size_t r4r_transnet_ws_offset(int64_t B, int T, int E, int L, int plus, int64_t V, int64_t n_users, int64_t n_items,
-                              int which);   /* 0 dropout multipliers, 1 / 2 ID-vector gradient rows [B,5], 3 aux [B,3], 6 + 2*tower + buffer: token counter */
+                              int which);   /* 0 dropout multipliers, 1 / 2 ID-vector gradient rows [B,5], 3 aux [B,3], 4 size of the persistent head, 6 + 2*tower + buffer: token counter */
 int r4r_transnet_step(const float *table, int64_t V,
                       const int64_t *user_idx, const int64_t *item_idx, const int64_t *this_idx,
                       const int64_t *uid, const int64_t *iid, const float *y,

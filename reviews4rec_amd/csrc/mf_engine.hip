@@ -26,6 +26,7 @@
 // the sweep is the whole cost, so this kernel is the HBM-bound leg of SURVEY.md 8d for MF.
 #include "adam_device.h"
 #include "common.h"
+#include "rows_device.h"
 
 namespace r4r {
 
@@ -119,7 +120,7 @@ __global__ __launch_bounds__(256) void mf_fwd_bwd_kernel(MfStep a) {
     }
 }
 
-constexpr int MF_CHUNK = 8192, MF_THREADS = 256;
+constexpr int MF_THREADS = 256;        // (MF_CHUNK, the elements per sweep workgroup of a table: rows_device.h)
 
 constexpr int MF_CHUNK_BIAS = 1024;    // bias vectors: short workgroups, so they are not the tail
 
@@ -140,6 +141,7 @@ struct MfSweep {
     const float *gu, *gi, *g, *se;
     float *sse_accum;
     const int *tag_u, *tag_i;
+    const int *ctag_u = nullptr, *ctag_i = nullptr;   // per sweep chunk of the tables: the last step that touched a row in it (optional)
     int64_t B;
     int D, now;
     AdamScalars s;
@@ -457,6 +459,38 @@ __global__ __launch_bounds__(MF_THREADS) void mf_adam_kernel(MfSweep w) {
     float *p = bp + start, *m = bm + start, *v = bv + start;
     const int *tag = (t == 0 || t == 2) ? w.tag_u : w.tag_i;
     const bool aligned = (((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(m) | reinterpret_cast<uintptr_t>(v)) & 15) == 0);
+    const int *ctag = t == 0 ? w.ctag_u : (t == 1 ? w.ctag_i : nullptr);
+    if (ctag && aligned && ctag[bx - cb] != w.now) {
+        // no rating touched a row of this chunk (all but a handful of chunks of a 10^7-row table):
+        // stream it -- no row tags, no row / column bookkeeping
+        const int64_t nvec = cnt >> 2;
+        int64_t i = tid;
+        for (; i + MF_THREADS < nvec; i += 2 * MF_THREADS) {
+            const int64_t j = i + MF_THREADS;
+            float4 P0 = reinterpret_cast<float4 *>(p)[i], P1 = reinterpret_cast<float4 *>(p)[j];
+            float4 M0 = reinterpret_cast<float4 *>(m)[i], M1 = reinterpret_cast<float4 *>(m)[j];
+            float4 V0 = reinterpret_cast<float4 *>(v)[i], V1 = reinterpret_cast<float4 *>(v)[j];
+            adam_elem(P0.x, 0.f, M0.x, V0.x, w.s); adam_elem(P0.y, 0.f, M0.y, V0.y, w.s);
+            adam_elem(P0.z, 0.f, M0.z, V0.z, w.s); adam_elem(P0.w, 0.f, M0.w, V0.w, w.s);
+            adam_elem(P1.x, 0.f, M1.x, V1.x, w.s); adam_elem(P1.y, 0.f, M1.y, V1.y, w.s);
+            adam_elem(P1.z, 0.f, M1.z, V1.z, w.s); adam_elem(P1.w, 0.f, M1.w, V1.w, w.s);
+            reinterpret_cast<float4 *>(p)[i] = P0; reinterpret_cast<float4 *>(m)[i] = M0; reinterpret_cast<float4 *>(v)[i] = V0;
+            reinterpret_cast<float4 *>(p)[j] = P1; reinterpret_cast<float4 *>(m)[j] = M1; reinterpret_cast<float4 *>(v)[j] = V1;
+        }
+        for (; i < nvec; i += MF_THREADS) {
+            float4 P = reinterpret_cast<float4 *>(p)[i], M = reinterpret_cast<float4 *>(m)[i], V = reinterpret_cast<float4 *>(v)[i];
+            adam_elem(P.x, 0.f, M.x, V.x, w.s); adam_elem(P.y, 0.f, M.y, V.y, w.s);
+            adam_elem(P.z, 0.f, M.z, V.z, w.s); adam_elem(P.w, 0.f, M.w, V.w, w.s);
+            reinterpret_cast<float4 *>(p)[i] = P; reinterpret_cast<float4 *>(m)[i] = M; reinterpret_cast<float4 *>(v)[i] = V;
+        }
+        const int64_t k = (nvec << 2) + tid;                // cnt % 4 elements at the end of a table
+        if (k < cnt) {
+            float P = p[k], M = m[k], V = v[k];
+            adam_elem(P, 0.f, M, V, w.s);
+            p[k] = P; m[k] = M; v[k] = V;
+        }
+        return;
+    }
     // (row, column) of a thread's element advance incrementally: a 64-bit division per element
     // would cost more than the 24 bytes the element moves
     const int64_t row_start = start / W;
@@ -655,7 +689,8 @@ int mf_bias_rows_launch(float *ub, float *ub_m, float *ub_v, float *ib, float *i
 // without bias vectors.  `tag_*`: per-row step tags the caller's forward kernel set to `now`.
 int mf_table_rows_launch(float *ut, float *ut_m, float *ut_v, float *it, float *it_m, float *it_v,
                          int64_t n_users, int64_t n_items, int D, const int64_t *uid, const int64_t *iid,
-                         const float *gu, const float *gi, const int *tag_u, const int *tag_i, int64_t B, int now,
+                         const float *gu, const float *gi, const int *tag_u, const int *tag_i,
+                         const int *ctag_u, const int *ctag_i, int64_t B, int now,
                          const AdamScalars &sc, hipStream_t st) {
     if (B > MF_MAX_B || D < 1 || D > MF_MAX_D) {
         set_error("table rows: batch %lld > %d or width %d outside 1..%d", (long long)B, MF_MAX_B, D, MF_MAX_D);
@@ -676,7 +711,8 @@ int mf_table_rows_launch(float *ut, float *ut_m, float *ut_v, float *it, float *
         return R4R_ERR_ARG;
     }
     sw.uid = uid; sw.iid = iid; sw.gu = gu; sw.gi = gi; sw.g = nullptr; sw.se = nullptr; sw.sse_accum = nullptr;
-    sw.tag_u = tag_u; sw.tag_i = tag_i; sw.B = B; sw.D = D; sw.now = now; sw.s = sc;
+    sw.tag_u = tag_u; sw.tag_i = tag_i; sw.ctag_u = ctag_u; sw.ctag_i = ctag_i;
+    sw.B = B; sw.D = D; sw.now = now; sw.s = sc;
     mf_adam_kernel<4><<<(unsigned)chunks, MF_THREADS, (size_t)B * sizeof(int), st>>>(sw);
     return check_launch("table rows");
 }

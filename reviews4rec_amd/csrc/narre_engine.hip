@@ -1074,7 +1074,7 @@ struct TnHead {
     float *pooled[3]; int *argmax[3]; float *g_pooled[3];   // [B, 100]
     float *part;                                    // [B, NHP]
     float *grow[2];                                 // [B, 5] compact gradient rows of the ID vectors
-    int *tag[2];
+    int *tag[2], *ctag[2];                          // row tags; sweep-chunk tags (rows_device.h)
     float *mult;                                    // [B, 5L + 10] dropout multipliers (see r4r.h)
     float *pred, *se;                               // source prediction and its SE
     float *aux;                                     // [B, 3]: target prediction, its SE, ||s_ir - t_ir||^2
@@ -1224,7 +1224,14 @@ __global__ __launch_bounds__(256) void tn_head_kernel(TnHead a) {
     }
     if (tid == 0) {
         a.pred[b] = out_s;
-        if (a.want_grad && a.plus) { a.tag[0][a.id[0][b]] = a.now; a.tag[1][a.id[1][b]] = a.now; }
+        if (a.want_grad && a.plus) {
+            for (int s = 0; s < 2; ++s) {
+                const int64_t r = a.id[s][b];
+                a.tag[s][r] = a.now;
+                a.ctag[s][r * TN_ID / MF_CHUNK] = a.now;              // (a row can straddle two chunks)
+                a.ctag[s][(r * TN_ID + TN_ID - 1) / MF_CHUNK] = a.now;
+            }
+        }
     }
     if (!a.want_grad) return;                               // uniform
     float *prow = a.part + (size_t)b * a.nhp;
@@ -1293,9 +1300,9 @@ struct TnWs {
     int *flags[2][3], *slot[2][3], *list[2][3], *count[2][3]; float *ptab[3];
     float *pooled[3]; int *argmax[3]; float *g_pooled[3];
     float *part_w[3], *part_b[3];
-    int *tag[2];
+    int *tag[2], *ctag[2];
     float *part, *grow[2], *mult, *aux;
-    size_t bytes;
+    size_t bytes, persist;
 };
 static TnWs tn_carve(void *ws, int64_t B, int T, int E, int L, int plus, int64_t V, int64_t n_users, int64_t n_items) {
     TnWs w;
@@ -1306,6 +1313,9 @@ static TnWs tn_carve(void *ws, int64_t B, int T, int E, int L, int plus, int64_t
     const int ns = textcnn_wgrad_splits(B);
     w.tag[0] = reinterpret_cast<int *>(take((size_t)n_users * 4));          // persistent state first
     w.tag[1] = reinterpret_cast<int *>(take((size_t)n_items * 4));
+    w.ctag[0] = reinterpret_cast<int *>(take((size_t)cdiv(n_users * TN_ID, MF_CHUNK) * 4));
+    w.ctag[1] = reinterpret_cast<int *>(take((size_t)cdiv(n_items * TN_ID, MF_CHUNK) * 4));
+    w.persist = o;
     for (int t = 0; t < 3; ++t)
         for (int bf = 0; bf < 2; ++bf) {
             w.flags[bf][t] = reinterpret_cast<int *>(take((size_t)(V + 4) * 4));
@@ -1731,11 +1741,13 @@ extern "C" size_t r4r_transnet_ws_bytes(int64_t B, int T, int E, int L, int plus
 }
 
 // which: 0 dropout multipliers [B, 5L + 10]; 1 / 2 compact gradient rows of the user / item ID vectors
-// [B, 5]; 3 the per-rating auxiliary outputs [B, 3]; 6 + 2 * tower + buffer: a token buffer's counter
-// (towers 0 user, 1 item, 2 this review)
+// [B, 5]; 3 the per-rating auxiliary outputs [B, 3]; 4 the SIZE of the persistent head of the workspace
+// (row and chunk tags: zero once, carry over when switching buffers); 6 + 2 * tower + buffer: a token
+// buffer's counter (towers 0 user, 1 item, 2 this review)
 extern "C" size_t r4r_transnet_ws_offset(int64_t B, int T, int E, int L, int plus, int64_t V, int64_t n_users,
                                          int64_t n_items, int which) {
     const TnWs w = tn_carve(reinterpret_cast<void *>(256), B, T, E, L, plus, V, n_users, n_items);
+    if (which == 4) return w.persist;
     if (which >= 6 && which < 12)
         return (size_t)(reinterpret_cast<char *>(w.count[(which - 6) & 1][(which - 6) >> 1]) - reinterpret_cast<char *>(256));
     const char *q = which == 0 ? reinterpret_cast<char *>(w.mult) : which == 1 ? reinterpret_cast<char *>(w.grow[0])
@@ -1831,7 +1843,7 @@ extern "C" int r4r_transnet_step(const float *table, int64_t V,
                 R4R_REQUIRE(rm[t] && rv[t], "transnet_step: ID-vector table %d: null moment pointer", t);
             }
         }
-        h.emb[t] = rp[t]; h.tag[t] = w.tag[t]; h.grow[t] = w.grow[t];
+        h.emb[t] = rp[t]; h.tag[t] = w.tag[t]; h.ctag[t] = w.ctag[t]; h.grow[t] = w.grow[t];
     }
     h.id[0] = uid; h.id[1] = iid; h.flat_p = flat_p;
     for (int i = 0; i < TN_COUNT; ++i) h.off[i] = (int)lay.off[i];
@@ -1886,5 +1898,5 @@ extern "C" int r4r_transnet_step(const float *table, int64_t V,
         wa, red_blocks, comp_blocks, nx, opt);
     if (!plus) return check_launch("transnet_step");
     return mf_table_rows_launch(rp[0], rm[0], rv[0], rp[1], rm[1], rv[1], n_users, n_items, TN_ID, uid, iid, w.grow[0], w.grow[1],
-                                w.tag[0], w.tag[1], B, (int)adam_step, opt.s, st);
+                                w.tag[0], w.tag[1], w.ctag[0], w.ctag[1], B, (int)adam_step, opt.s, st);
 }

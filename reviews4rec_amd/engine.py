@@ -552,11 +552,14 @@ class NarreEngine:
                 nb = self._ws_bytes(B, R, T)
                 nxt = cache[key] = torch.zeros(max(nb, 256), dtype=torch.uint8, device=self.dev)
             if self._ws is not None:                         # the row tags head the buffer: shared state
-                keep = 256 * (-(-self.n_users * 4 // 256) + -(-self.n_items * 4 // 256))
+                keep = self._persist_bytes(B, R, T)
                 nxt[:keep].copy_(self._ws[:keep])
             self._ws, self._ws_key = nxt, key
             self._prepared = None                            # token state lived in the other workspace
         return self._ws
+
+    def _persist_bytes(self, B, R, T):
+        return 256 * (-(-self.n_users * 4 // 256) + -(-self.n_items * 4 // 256))
 
     def _ws_bytes(self, B, R, T):
         return _lib.lib().r4r_narre_ws_bytes(B, R, T, self.E, self.L, self.V, self.n_users, self.n_items)
@@ -789,6 +792,9 @@ class TransNetEngine(NarreEngine):
 
     def _ws_offset(self, B, R, T, which):
         return _lib.lib().r4r_transnet_ws_offset(B, T, self.E, self.L, self.plus, self.V, self.n_users, self.n_items, which)
+
+    def _persist_bytes(self, B, R, T):
+        return self._ws_offset(B, R, T, 4)
 
     def _draws(self, R):
         return 5 * self.L + 10

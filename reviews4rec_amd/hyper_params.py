@@ -8,7 +8,7 @@ created by ``finalize()``.
 
 Namespaced extras understood by this package (all default to reference behaviour):
   engine         'auto' (default: fused native step where one exists -- DeepCoNN 'deepconn' and
-                 'deepconn++', NARRE, MF_dot, bias_only -- else the op-by-op step captured into one hipGraph) | 'native' (native
+                 'deepconn++', NARRE, TransNet(++), MF_dot, bias_only -- else the op-by-op step captured into one hipGraph) | 'native' (native
                  or plain eager) | 'graph' | 'module' (op-by-op autograd, eager)
   word_vectors   in-memory V x E table instead of data_dir/word2vec.pkl (synthetic runs)
   seed           dropout Philox seed

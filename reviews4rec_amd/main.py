@@ -8,7 +8,7 @@ differences, both numerically neutral: the running sum of SE stays on the device
 is read once per epoch (the reference syncs with ``float(torch.sum(..))`` every
 batch, main.py:57), and ``optimizer`` is this package's fused Adam (same surface).
 ``hyper_params['engine']`` (default 'auto'): models with a fused native step (DeepCoNN 'deepconn' and
-'deepconn++', NARRE, MF_dot, bias_only) run the whole sequence as one native call per batch; the others run the
+'deepconn++', NARRE, TransNet(++), MF_dot, bias_only) run the whole sequence as one native call per batch; the others run the
 op-by-op step captured once into a hipGraph and replayed ('module' forces plain eager).
 
 TransNet's three-optimiser step (main.py:35-53) raises on torch >= 1.5 in the
