@@ -401,7 +401,7 @@ int r4r_deepconnpp_step(const float *table, int64_t V, const int64_t *user_idx, 
  * source.*, source MSE -> source_fm.* and (TransNet++, plus = 1) the ID vectors.  The gradient each
  * of the reference's three optimisers consumes is that of its own loss on its own parameter group
  * at the pre-step weights, so the step is one backward with three disjoint groups and -- the three
- * Adams sharing lr, weight decay and step count -- one flat Adam (csrc/narre_engine.hip has the
+ * Adams sharing lr, weight decay and step count -- one flat Adam (csrc/transnet_engine.hip has the
  * argument; the reference-generated trajectories pin it).
  * Flat layout (22 slots, r4r_transnet_layout): source.user_conv.convs.0.weight, .bias,
  * source.item_conv.convs.0.(same), target.conv.convs.0.(same), source.user_conv.fc.weight, .bias,

@@ -1,0 +1,509 @@
+// Fused native training step for TransNet / TransNet++ (launch roles shared with the other review
+// models: step_device.h).
+#include "step_device.h"
+
+namespace r4r {
+
+// TransNet / TransNet++ (TransNet.py:9-122, trained by main.py:26-53 with utils.init_transnet_optim,
+// utils.py:70-92).  Three TextCNN towers -- source.user_conv, source.item_conv on the user's and the
+// item's documents, target.conv on the review being rated -- and three losses from ONE forward:
+//   target     mean (FM_t(t_ir) - y)^2               -> optimizer_target   (target.conv, target.fm)
+//   transform  mean ||s_ir - t_ir||^2                -> optimizer_source   (source.*)
+//   source     mean (FM_s([ue, ie,] s_ir) - y)^2     -> optimizer_source_fm (source_fm, ID vectors)
+// with s_ir = dropout(project(cat(xu, xi))), t_ir = dropout(xt).  The reference runs three backward
+// passes over the retained graph with an optimiser step after each, gradients accumulating; the
+// gradient each optimiser CONSUMES is that of its own loss with respect to its own (disjoint)
+// parameter group, evaluated at the pre-step weights of everything it flows through (the target
+// pass reaches nothing else; the transform pass reaches source.* before optimizer_source has
+// stepped, its contribution to target.* is zeroed unused at the next batch; the source pass
+// stops at source_fm and the ID vectors as far as consumed gradients go).  So the step is one
+// backward with three disjoint groups, and -- the three Adams sharing lr, weight decay and step
+// count -- one flat Adam.  Pinned by the reference-generated 3-step trajectories (tests).
+// Flat layout (22 slots): the three conv weight / bias pairs first, then every head parameter in
+// one contiguous range.
+enum { TN_UCW = 0, TN_UCB, TN_ICW, TN_ICB, TN_TCW, TN_TCB, TN_UFW, TN_UFB, TN_IFW, TN_IFB, TN_TFW, TN_TFB,
+       TN_P0W, TN_P0B, TN_P2W, TN_P2B, TN_SV, TN_SLW, TN_SLB, TN_TV, TN_TLW, TN_TLB, TN_COUNT };
+constexpr int TN_ID = 5;               // width of the ID vectors (TransNet.py:75-76)
+constexpr int TN_FM_K = 8;             // factors of both FMs (TransNet.py:50,77,79)
+struct TLayout { int64_t off[TN_COUNT], size[TN_COUNT], total; };
+static TLayout tn_layout(int E, int L, int plus) {
+    TLayout lay;
+    const int64_t ns = L + (plus ? 2 * TN_ID : 0);
+    const int64_t sz[TN_COUNT] = {(int64_t)NF * 3 * E, NF, (int64_t)NF * 3 * E, NF, (int64_t)NF * 3 * E, NF,
+                                  (int64_t)L * NF, L, (int64_t)L * NF, L, (int64_t)L * NF, L,
+                                  (int64_t)L * 2 * L, L, (int64_t)L * L, L,
+                                  ns * TN_FM_K, ns, 1, (int64_t)L * TN_FM_K, L, 1};
+    int64_t o = 0;
+    for (int i = 0; i < TN_COUNT; ++i) {
+        lay.off[i] = o;
+        lay.size[i] = sz[i];
+        o += (sz[i] + 3) & ~(int64_t)3;
+    }
+    lay.total = o;
+    return lay;
+}
+
+struct TnHead {
+    const float *pmax[3]; const int *parg[3];       // conv partials [B, tiles, NP]: user, item, this
+    const float *flat_p;
+    int off[TN_COUNT];
+    int lo;                                         // first head parameter (column 0 of `part`)
+    const float *emb[2];                            // user / item ID vectors [*, 5] (TransNet++) or NULL
+    const int64_t *id[2];                           // uid, iid [B]
+    const float *y;
+    float *pooled[3]; int *argmax[3]; float *g_pooled[3];   // [B, 100]
+    float *part;                                    // [B, NHP]
+    float *grow[2];                                 // [B, 5] compact gradient rows of the ID vectors
+    int *tag[2], *ctag[2];                          // row tags; sweep-chunk tags (rows_device.h)
+    float *mult;                                    // [B, 5L + 10] dropout multipliers (see r4r.h)
+    float *pred, *se;                               // source prediction and its SE
+    float *aux;                                     // [B, 3]: target prediction, its SE, ||s_ir - t_ir||^2
+    int64_t B;
+    int L, tiles, nhp, training, want_grad, now, plus;
+    float p_drop, inv_denom;
+    uint64_t seed, offset;
+};
+
+// One workgroup of 256 threads per rating.
+template <int ML>
+__global__ __launch_bounds__(256) void tn_head_kernel(TnHead a) {
+    constexpr int MS = ML + 2 * TN_ID;                      // widest source_fm input
+    __shared__ float P[3][NF];
+    __shared__ float fcw[3][ML][NF + 1];
+    __shared__ float W0[ML][2 * ML + 1], W2[ML][ML + 1];
+    __shared__ float Vs[MS][TN_FM_K], Vt[ML][TN_FM_K], lws[MS], lwt[ML];
+    __shared__ float x[3 * ML], xm[3 * ML], fcb[3 * ML], dz[3 * ML];
+    __shared__ float b0s[ML], b2s[ML], hs[ML], dhs[ML], sir[ML], sirm[ML], tir[ML], tirm[ML], dtmp[ML];
+    __shared__ float fin[MS], finm[2 * TN_ID], dfs[MS], dft[ML], sks[TN_FM_K], skt[TN_FM_K], misc[8];
+    const int L = a.L, L2 = 2 * L, L3 = 3 * L, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int ns = L + (a.plus ? 2 * TN_ID : 0), eo = a.plus ? 2 * TN_ID : 0;   // final = [ue, ie, s_ir]
+    const int64_t b = blockIdx.x;
+    const float *fp = a.flat_p;
+    const float keep = 1.f / (1.f - a.p_drop);
+    const bool drop = a.training && a.p_drop > 0.f;
+    const int ND = 5 * L + 2 * TN_ID;
+    auto draw = [&](int k) -> float {
+        float m = 1.f;
+        if (drop) {
+            const uint32_t r = philox_first_word(a.offset + (uint64_t)(b * ND + k), a.seed);
+            m = ((float)(r >> 8) * (1.0f / 16777216.0f) >= a.p_drop) ? keep : 0.f;
+        }
+        if (a.mult) a.mult[b * ND + k] = m;
+        return m;
+    };
+    const float invL2 = 1.f / (float)L2, invL = 1.f / (float)L;
+    auto qd = [](int v, float inv) { return (int)(((float)v + 0.5f) * inv); };
+    // ---- S0: weights, pool finish (max over tiles, relu, first argmax), ID vectors
+    for (int i = tid; i < 3 * L * NF; i += 256) {
+        const int s = i / (L * NF), r = i - s * L * NF, l = r / NF;
+        fcw[s][l][r - l * NF] = fp[a.off[s == 0 ? TN_UFW : (s == 1 ? TN_IFW : TN_TFW)] + r];
+    }
+    for (int i = tid; i < L * L2; i += 256) { const int k = qd(i, invL2); W0[k][i - k * L2] = fp[a.off[TN_P0W] + i]; }
+    for (int i = tid; i < L * L; i += 256) { const int k = qd(i, invL); W2[k][i - k * L] = fp[a.off[TN_P2W] + i]; }
+    for (int i = tid; i < ns * TN_FM_K; i += 256) Vs[i / TN_FM_K][i % TN_FM_K] = fp[a.off[TN_SV] + i];
+    for (int i = tid; i < L * TN_FM_K; i += 256) Vt[i / TN_FM_K][i % TN_FM_K] = fp[a.off[TN_TV] + i];
+    if (tid < ns) lws[tid] = fp[a.off[TN_SLW] + tid];
+    if (tid < L) { lwt[tid] = fp[a.off[TN_TLW] + tid]; b0s[tid] = fp[a.off[TN_P0B] + tid]; b2s[tid] = fp[a.off[TN_P2B] + tid]; }
+    if (tid < L3) {
+        const int s = tid / L;
+        fcb[tid] = fp[a.off[s == 0 ? TN_UFB : (s == 1 ? TN_IFB : TN_TFB)] + (tid - s * L)];
+    }
+    if (tid == 0) { misc[0] = fp[a.off[TN_SLB]]; misc[1] = fp[a.off[TN_TLB]]; }
+    if (a.plus && tid >= 64 && tid < 64 + 2 * TN_ID) {      // dropout.user / dropout.item on the ID vectors
+        const int k = tid - 64, s = k >= TN_ID, c = k - s * TN_ID;
+        const float m = draw(5 * L + k);
+        finm[k] = m;
+        fin[k] = a.emb[s][a.id[s][b] * TN_ID + c] * m;
+    }
+    for (int i = tid; i < 3 * NF; i += 256) {
+        const int s = i / NF, f = i - s * NF;
+        float best = -INFINITY;
+        int bp = -1;
+        for (int k = 0; k < a.tiles; ++k) {
+            const size_t q = ((size_t)b * a.tiles + k) * NP + f;
+            const float val = a.pmax[s][q];
+            if (val > best) { best = val; bp = a.parg[s][q]; }
+        }
+        if (!(best > 0.f)) { best = 0.f; bp = -1; }
+        P[s][f] = best;
+        a.pooled[s][b * NF + f] = best;
+        a.argmax[s][b * NF + f] = bp;
+    }
+    __syncthreads();
+    // ---- S1: the towers' FC + dropout (common_pytorch_models.py:35-37): xu, xi, xt
+    if (tid < L3) {
+        const int s = tid / L, l = tid - s * L;
+        float acc = 0.f;
+        for (int f = 0; f < NF; ++f) acc = fmaf(P[s][f], fcw[s][l][f], acc);
+        const float m = draw(tid);
+        xm[tid] = m;
+        x[tid] = (acc + fcb[tid]) * m;
+    }
+    __syncthreads();
+    // ---- S2: source.project.0 + relu (TransNet.py:19-22); target: t_ir = dropout(xt) (TransNet.py:58)
+    if (tid < L) {
+        float acc = 0.f;
+        for (int j = 0; j < L2; ++j) acc = fmaf(x[j], W0[tid][j], acc);
+        acc += b0s[tid];
+        hs[tid] = acc > 0.f ? acc : 0.f;
+    } else if (tid >= 64 && tid < 64 + L) {
+        const int l = tid - 64;
+        const float m = draw(4 * L + l);
+        tirm[l] = m;
+        tir[l] = x[L2 + l] * m;
+    }
+    __syncthreads();
+    // ---- S3: source.project.2 + dropout = s_ir (TransNet.py:33-36)
+    if (tid < L) {
+        float acc = 0.f;
+        for (int j = 0; j < L; ++j) acc = fmaf(hs[j], W2[tid][j], acc);
+        const float m = draw(3 * L + tid);
+        sirm[tid] = m;
+        const float v = (acc + b2s[tid]) * m;
+        sir[tid] = v;
+        fin[eo + tid] = v;
+    }
+    __syncthreads();
+    // ---- S4: the two factorisation machines (common_pytorch_models.py:49-57): wave 0 source, wave 1 target
+    if (wv < 2) {
+        const int n = wv ? L : ns;
+        const float xi = lane < n ? (wv ? tir[lane] : fin[lane]) : 0.f;
+        float inter = 0.f, gacc = 0.f;
+#pragma unroll
+        for (int k = 0; k < TN_FM_K; ++k) {
+            const float v = lane < n ? (wv ? Vt[lane][k] : Vs[lane][k]) : 0.f;
+            const float s = wave_sum(xi * v);
+            const float s2 = wave_sum(xi * xi * v * v);
+            inter += s * s - s2;
+            gacc += s * v - xi * v * v;
+            if (lane == 0) (wv ? skt : sks)[k] = s;
+        }
+        const float lw = lane < n ? (wv ? lwt[lane] : lws[lane]) : 0.f;
+        const float lin = wave_sum(xi * lw);
+        const float out = 0.5f * inter + (lin + misc[wv]);
+        if (lane < n) (wv ? dft : dfs)[lane] = gacc + lw;      // d FM / d x_i
+        if (lane == 0) misc[2 + wv] = out;
+    } else if (wv == 2) {
+        const float d = lane < L ? sir[lane] - tir[lane] : 0.f;
+        const float tr = wave_sum(d * d);
+        if (lane == 0) misc[4] = tr;
+    }
+    __syncthreads();
+    const float out_s = misc[2], out_t = misc[3];
+    float g_s = 0.f, g_t = 0.f;
+    if (a.y) {
+        const float yb = a.y[b];
+        g_s = 2.f * (out_s - yb) * a.inv_denom;
+        g_t = 2.f * (out_t - yb) * a.inv_denom;
+        if (tid == 0) {
+            a.se[b] = (out_s - yb) * (out_s - yb);
+            if (a.aux) { a.aux[b * 3] = out_t; a.aux[b * 3 + 1] = (out_t - yb) * (out_t - yb); a.aux[b * 3 + 2] = misc[4]; }
+        }
+    } else if (tid == 0 && a.aux) {
+        a.aux[b * 3] = out_t; a.aux[b * 3 + 1] = 0.f; a.aux[b * 3 + 2] = misc[4];
+    }
+    if (tid == 0) {
+        a.pred[b] = out_s;
+        if (a.want_grad && a.plus) {
+            for (int s = 0; s < 2; ++s) {
+                const int64_t r = a.id[s][b];
+                a.tag[s][r] = a.now;
+                a.ctag[s][r * TN_ID / MF_CHUNK] = a.now;              // (a row can straddle two chunks)
+                a.ctag[s][(r * TN_ID + TN_ID - 1) / MF_CHUNK] = a.now;
+            }
+        }
+    }
+    if (!a.want_grad) return;                               // uniform
+    float *prow = a.part + (size_t)b * a.nhp;
+    auto col = [&](int flat_off) { return flat_off - a.lo; };
+    // ---- B1: FM parameter gradients (d V_ik = g (x_i s_k - x_i^2 V_ik), d lin.w_i = g x_i, d lin.b = g);
+    // the ID vectors' compact gradient rows; d s_ir from the transform loss; d t_ir from the target loss
+    for (int i = tid; i < ns * TN_FM_K; i += 256) {
+        const int r = i / TN_FM_K, k = i - r * TN_FM_K;
+        prow[col(a.off[TN_SV] + i)] = g_s * (fin[r] * sks[k] - fin[r] * fin[r] * Vs[r][k]);
+    }
+    for (int i = tid; i < L * TN_FM_K; i += 256) {
+        const int r = i / TN_FM_K, k = i - r * TN_FM_K;
+        prow[col(a.off[TN_TV] + i)] = g_t * (tir[r] * skt[k] - tir[r] * tir[r] * Vt[r][k]);
+    }
+    if (tid < ns) prow[col(a.off[TN_SLW] + tid)] = g_s * fin[tid];
+    if (tid < L) prow[col(a.off[TN_TLW] + tid)] = g_t * tir[tid];
+    if (tid == 0) { prow[col(a.off[TN_SLB])] = g_s; prow[col(a.off[TN_TLB])] = g_t; }
+    if (a.plus && tid >= 64 && tid < 64 + 2 * TN_ID) {
+        const int k = tid - 64, s = k >= TN_ID, c = k - s * TN_ID;
+        a.grow[s][b * TN_ID + c] = g_s * dfs[k] * finm[k];
+    }
+    if (tid >= 128 && tid < 128 + L) {
+        const int l = tid - 128;
+        dtmp[l] = 2.f * (sir[l] - tir[l]) * a.inv_denom * sirm[l];       // d (project.2 output)
+        dz[L2 + l] = g_t * dft[l] * tirm[l] * xm[L2 + l];                // d (target FC output)
+    }
+    __syncthreads();
+    // ---- B2: source.project.2 gradients, d hidden
+    for (int i = tid; i < L * L; i += 256) { const int k = qd(i, invL); prow[col(a.off[TN_P2W] + i)] = dtmp[k] * hs[i - k * L]; }
+    if (tid < L) {
+        prow[col(a.off[TN_P2B] + tid)] = dtmp[tid];
+        float acc = 0.f;
+        for (int k = 0; k < L; ++k) acc = fmaf(dtmp[k], W2[k][tid], acc);
+        const float d = hs[tid] > 0.f ? acc : 0.f;
+        dhs[tid] = d;
+        prow[col(a.off[TN_P0B] + tid)] = d;
+    }
+    __syncthreads();
+    // ---- B3: source.project.0 weight, d cat -> d (source FC outputs)
+    for (int i = tid; i < L * L2; i += 256) { const int k = qd(i, invL2); prow[col(a.off[TN_P0W] + i)] = dhs[k] * x[i - k * L2]; }
+    if (tid < L2) {
+        float acc = 0.f;
+        for (int k = 0; k < L; ++k) acc = fmaf(dhs[k], W0[k][tid], acc);
+        dz[tid] = acc * xm[tid];
+    }
+    __syncthreads();
+    // ---- B4: the towers' FC gradients, d pooled
+    if (tid < L3) {
+        const int s = tid / L;
+        prow[col(a.off[s == 0 ? TN_UFB : (s == 1 ? TN_IFB : TN_TFB)] + (tid - s * L))] = dz[tid];
+    }
+    for (int i = tid; i < 3 * L * NF; i += 256) {
+        const int s = i / (L * NF), r = i - s * L * NF, l = r / NF, f = r - l * NF;
+        prow[col(a.off[s == 0 ? TN_UFW : (s == 1 ? TN_IFW : TN_TFW)] + r)] = dz[s * L + l] * P[s][f];
+    }
+    for (int i = tid; i < 3 * NF; i += 256) {
+        const int s = i / NF, f = i - s * NF;
+        float acc = 0.f;
+        for (int l = 0; l < L; ++l) acc = fmaf(dz[s * L + l], fcw[s][l][f], acc);
+        a.g_pooled[s][b * NF + f] = acc;
+    }
+}
+
+struct TnWs {
+    float *wp[3], *pmax[3]; int *parg[3];
+    int *flags[2][3], *slot[2][3], *list[2][3], *count[2][3]; float *ptab[3];
+    float *pooled[3]; int *argmax[3]; float *g_pooled[3];
+    float *part_w[3], *part_b[3];
+    int *tag[2], *ctag[2];
+    float *part, *grow[2], *mult, *aux;
+    size_t bytes, persist;
+};
+static TnWs tn_carve(void *ws, int64_t B, int T, int E, int L, int plus, int64_t V, int64_t n_users, int64_t n_items) {
+    TnWs w;
+    char *p = static_cast<char *>(ws);
+    size_t o = 0;
+    auto take = [&](size_t nbytes) { char *r = p ? p + o : nullptr; o += align256(nbytes); return r; };
+    const size_t tiles128 = (size_t)(T + 2 + 127) / 128;
+    const int ns = textcnn_wgrad_splits(B);
+    w.tag[0] = reinterpret_cast<int *>(take((size_t)n_users * 4));          // persistent state first
+    w.tag[1] = reinterpret_cast<int *>(take((size_t)n_items * 4));
+    w.ctag[0] = reinterpret_cast<int *>(take((size_t)cdiv(n_users * TN_ID, MF_CHUNK) * 4));
+    w.ctag[1] = reinterpret_cast<int *>(take((size_t)cdiv(n_items * TN_ID, MF_CHUNK) * 4));
+    w.persist = o;
+    for (int t = 0; t < 3; ++t)
+        for (int bf = 0; bf < 2; ++bf) {
+            w.flags[bf][t] = reinterpret_cast<int *>(take((size_t)(V + 4) * 4));
+            w.count[bf][t] = reinterpret_cast<int *>(take(256));
+        }
+    for (int t = 0; t < 3; ++t) {
+        for (int bf = 0; bf < 2; ++bf) {
+            w.slot[bf][t] = reinterpret_cast<int *>(take((size_t)(V + 4) * 4));
+            w.list[bf][t] = reinterpret_cast<int *>(take((size_t)proj_row_capacity(B, T, V) * 4));
+        }
+        w.wp[t] = reinterpret_cast<float *>(take(textcnn_wp_floats(E) * 4));
+        w.pmax[t] = reinterpret_cast<float *>(take((size_t)B * tiles128 * NP * 4));
+        w.parg[t] = reinterpret_cast<int *>(take((size_t)B * tiles128 * NP * 4));
+        w.pooled[t] = reinterpret_cast<float *>(take((size_t)B * NF * 4));
+        w.argmax[t] = reinterpret_cast<int *>(take((size_t)B * NF * 4));
+        w.g_pooled[t] = reinterpret_cast<float *>(take((size_t)B * NF * 4));
+        w.part_w[t] = reinterpret_cast<float *>(take((size_t)ns * NF * 3 * E * 4));
+        w.part_b[t] = reinterpret_cast<float *>(take((size_t)ns * NF * 4));
+        w.ptab[t] = reinterpret_cast<float *>(take(proj_ptab_floats(B, T, V) * 4));
+    }
+    const TLayout lay = tn_layout(E, L, plus);
+    w.part = reinterpret_cast<float *>(take((size_t)B * (lay.total - lay.off[TN_UFW]) * 4));
+    w.grow[0] = reinterpret_cast<float *>(take((size_t)B * TN_ID * 4));
+    w.grow[1] = reinterpret_cast<float *>(take((size_t)B * TN_ID * 4));
+    w.mult = reinterpret_cast<float *>(take((size_t)B * (5 * L + 2 * TN_ID) * 4));
+    w.aux = reinterpret_cast<float *>(take((size_t)B * 3 * 4));
+    w.bytes = o;
+    return w;
+}
+
+}  // namespace r4r
+
+using namespace r4r;
+
+// ------------------------------------------------------------------------------ TransNet(++)
+extern "C" int r4r_transnet_nparam(void) { return TN_COUNT; }
+
+extern "C" int r4r_transnet_layout(int E, int L, int plus, int64_t *offsets, int64_t *sizes, int64_t *total) {
+    R4R_REQUIRE(offsets && sizes && total, "transnet_layout: null pointer");
+    R4R_REQUIRE(E > 0 && L > 0 && L <= NR_MAX_L, "transnet_layout: bad sizes");
+    const TLayout lay = tn_layout(E, L, plus);
+    for (int i = 0; i < TN_COUNT; ++i) { offsets[i] = lay.off[i]; sizes[i] = lay.size[i]; }
+    *total = lay.total;
+    return R4R_OK;
+}
+
+extern "C" size_t r4r_transnet_ws_bytes(int64_t B, int T, int E, int L, int plus, int64_t V, int64_t n_users, int64_t n_items) {
+    if (B < 0 || T <= 0 || E <= 0 || L <= 0 || V <= 0 || n_users <= 0 || n_items <= 0) return 0;
+    return tn_carve(nullptr, B, T, E, L, plus, V, n_users, n_items).bytes;
+}
+
+// which: 0 dropout multipliers [B, 5L + 10]; 1 / 2 compact gradient rows of the user / item ID vectors
+// [B, 5]; 3 the per-rating auxiliary outputs [B, 3]; 4 the SIZE of the persistent head of the workspace
+// (row and chunk tags: zero once, carry over when switching buffers); 6 + 2 * tower + buffer: a token
+// buffer's counter (towers 0 user, 1 item, 2 this review)
+extern "C" size_t r4r_transnet_ws_offset(int64_t B, int T, int E, int L, int plus, int64_t V, int64_t n_users,
+                                         int64_t n_items, int which) {
+    const TnWs w = tn_carve(reinterpret_cast<void *>(256), B, T, E, L, plus, V, n_users, n_items);
+    if (which == 4) return w.persist;
+    if (which >= 6 && which < 12)
+        return (size_t)(reinterpret_cast<char *>(w.count[(which - 6) & 1][(which - 6) >> 1]) - reinterpret_cast<char *>(256));
+    const char *q = which == 0 ? reinterpret_cast<char *>(w.mult) : which == 1 ? reinterpret_cast<char *>(w.grow[0])
+                  : which == 2 ? reinterpret_cast<char *>(w.grow[1]) : reinterpret_cast<char *>(w.aux);
+    return (size_t)(q - reinterpret_cast<char *>(256));
+}
+
+extern "C" int r4r_transnet_step(const float *table, int64_t V,
+                                 const int64_t *user_idx, const int64_t *item_idx, const int64_t *this_idx,
+                                 const int64_t *uid, const int64_t *iid, const float *y,
+                                 float *flat_p, float *flat_g, float *flat_m, float *flat_v,
+                                 const uint64_t *rows_p, const uint64_t *rows_m, const uint64_t *rows_v,
+                                 int64_t n_users, int64_t n_items,
+                                 float *pred, float *se, float *sse_accum, void *ws, size_t ws_bytes,
+                                 int64_t B, int T, int E, int L, int plus,
+                                 float dropout_p, int training, uint64_t seed, uint64_t offset, float inv_denom,
+                                 int conv_algo, int token_buffer, int tokens_ready,
+                                 const int64_t *next_user_idx, const int64_t *next_item_idx, const int64_t *next_this_idx,
+                                 float lr, double beta1, double beta2, float eps, float weight_decay, int64_t adam_step,
+                                 void *stream) {
+    R4R_REQUIRE(table && user_idx && item_idx && this_idx && flat_p && pred && ws, "transnet_step: null pointer");
+    R4R_REQUIRE(!plus || (uid && iid && rows_p), "transnet_step: TransNet++ needs the ids and the ID-vector tables");
+    R4R_REQUIRE(V > 0 && B >= 0 && T > 0 && n_users > 0 && n_items > 0, "transnet_step: bad sizes");
+    R4R_REQUIRE(L > 0 && L <= NR_MAX_L, "transnet_step: latent_size %d outside 1..%d", L, NR_MAX_L);
+    R4R_REQUIRE(E > 0 && E % 4 == 0, "transnet_step: word_embed_size %d must be a positive multiple of 4", E);
+    const bool train_step = flat_g != nullptr;
+    R4R_REQUIRE(!train_step || (y && se && flat_m && flat_v && adam_step >= 1 && (!plus || (rows_m && rows_v))),
+                "transnet_step: a training step needs ratings, se, gradient / moment buffers and adam_step >= 1");
+    R4R_REQUIRE(!y || se, "transnet_step: se buffer required when y is given");
+    R4R_REQUIRE(!next_user_idx == !next_item_idx && !next_user_idx == !next_this_idx,
+                "transnet_step: the three next-batch index arrays go together");
+    R4R_REQUIRE(!next_user_idx || train_step, "transnet_step: the next batch's tokens ride on the backward launches");
+    R4R_REQUIRE(token_buffer == 0 || token_buffer == 1, "transnet_step: token_buffer must be 0 or 1");
+    R4R_REQUIRE(adam_step < (1ll << 31), "transnet_step: step tag overflow");
+    R4R_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, "transnet_step: dropout %f outside [0,1)", (double)dropout_p);
+    R4R_REQUIRE(B * (int64_t)((T + 2 + 127) / 128) < (1ll << 31), "transnet_step: grid too large");
+    if (ws_bytes < r4r_transnet_ws_bytes(B, T, E, L, plus, V, n_users, n_items)) {
+        set_error("transnet_step: workspace %zu < %zu bytes", ws_bytes,
+                  r4r_transnet_ws_bytes(B, T, E, L, plus, V, n_users, n_items));
+        return R4R_ERR_WORKSPACE;
+    }
+    if (B == 0) return R4R_OK;
+    hipStream_t st = as_stream(stream);
+    const TLayout lay = tn_layout(E, L, plus);
+    R4R_REQUIRE(lay.total < (1ll << 31), "transnet_step: dense parameter buffer too large");
+    const int64_t lo = lay.off[TN_UFW], hi = lay.total;
+    const int nhp = (int)(hi - lo);
+    const TnWs w = tn_carve(ws, B, T, E, L, plus, V, n_users, n_items);
+    const float *P[TN_COUNT];
+    float *G[TN_COUNT];
+    for (int i = 0; i < TN_COUNT; ++i) { P[i] = flat_p + lay.off[i]; G[i] = flat_g ? flat_g + lay.off[i] : nullptr; }
+    const int cw[3] = {TN_UCW, TN_ICW, TN_TCW}, cb[3] = {TN_UCB, TN_ICB, TN_TCB};
+
+    const int64_t *idx[3] = {user_idx, item_idx, this_idx};
+    const int algo = textcnn_pick_algo(conv_algo, B, T, E, NF);
+    int tiles;
+    if (algo == R4R_CONV_PROJECT) {
+        ProjTower pt[3];
+        for (int t = 0; t < 3; ++t) {
+            pt[t].idx = idx[t];
+            pt[t].conv_w = P[cw[t]]; pt[t].conv_b = P[cb[t]];
+            pt[t].flags = w.flags[token_buffer][t]; pt[t].slot = w.slot[token_buffer][t];
+            pt[t].list = w.list[token_buffer][t]; pt[t].count = w.count[token_buffer][t];
+            pt[t].ptab = w.ptab[t]; pt[t].pmax = w.pmax[t]; pt[t].parg = w.parg[t];
+        }
+        if (!tokens_ready)
+            if (int rc = textcnn_proj_tokens_launch(V, pt, 3, B, T, /*zero_state=*/false, st)) return rc;
+        if (int rc = textcnn_proj_compute_launch(table, V, pt, 3, B, T, E, NF, st)) return rc;
+        tiles = proj_tiles(T);
+    } else {
+        FwdTower ft[3];
+        for (int t = 0; t < 3; ++t) {
+            ft[t].idx = idx[t];
+            ft[t].conv_w = P[cw[t]]; ft[t].conv_b = P[cb[t]];
+            ft[t].wp = w.wp[t]; ft[t].pmax = w.pmax[t]; ft[t].parg = w.parg[t];
+        }
+        if (int rc = textcnn_fwd_launch(table, ft, 3, B, T, E, NF, st)) return rc;
+        tiles = textcnn_tiles(T);
+    }
+
+    TnHead h;
+    for (int t = 0; t < 3; ++t) {
+        h.pmax[t] = w.pmax[t]; h.parg[t] = w.parg[t];
+        h.pooled[t] = w.pooled[t]; h.argmax[t] = w.argmax[t]; h.g_pooled[t] = w.g_pooled[t];
+    }
+    float *rp[2] = {nullptr, nullptr}, *rm[2] = {nullptr, nullptr}, *rv[2] = {nullptr, nullptr};
+    for (int t = 0; t < 2; ++t) {
+        if (plus) {
+            rp[t] = reinterpret_cast<float *>(rows_p[t]);
+            R4R_REQUIRE(rp[t], "transnet_step: null ID-vector table");
+            if (train_step) {
+                rm[t] = reinterpret_cast<float *>(rows_m[t]); rv[t] = reinterpret_cast<float *>(rows_v[t]);
+                R4R_REQUIRE(rm[t] && rv[t], "transnet_step: ID-vector table %d: null moment pointer", t);
+            }
+        }
+        h.emb[t] = rp[t]; h.tag[t] = w.tag[t]; h.ctag[t] = w.ctag[t]; h.grow[t] = w.grow[t];
+    }
+    h.id[0] = uid; h.id[1] = iid; h.flat_p = flat_p;
+    for (int i = 0; i < TN_COUNT; ++i) h.off[i] = (int)lay.off[i];
+    h.lo = (int)lo;
+    h.y = y; h.part = w.part; h.mult = w.mult; h.pred = pred; h.se = se; h.aux = w.aux;
+    h.B = B; h.L = L; h.tiles = tiles; h.nhp = nhp; h.training = training; h.want_grad = train_step;
+    h.now = (int)adam_step; h.plus = plus; h.p_drop = dropout_p; h.inv_denom = inv_denom; h.seed = seed; h.offset = offset;
+    if (L <= 16) tn_head_kernel<16><<<(unsigned)B, 256, 0, st>>>(h);
+    else tn_head_kernel<32><<<(unsigned)B, 256, 0, st>>>(h);
+    if (!train_step) return check_launch("transnet_step(forward)");
+
+    WgradTower wt[3];
+    WgradArgs wa;
+    for (int t = 0; t < 3; ++t) {
+        wt[t].idx = idx[t]; wt[t].g_pooled = w.g_pooled[t]; wt[t].argmax = w.argmax[t];
+        wt[t].part_w = w.part_w[t]; wt[t].part_b = w.part_b[t];
+        wt[t].d_w = G[cw[t]]; wt[t].d_b = G[cb[t]];
+    }
+    for (int k = 0; k < MAX_TOWERS; ++k) wa.t[k] = wt[k < 3 ? k : 0];
+    wa.table = table; wa.N = B; wa.T = T; wa.E = E; wa.F = NF;
+    wa.nsplit = textcnn_wgrad_splits(B);
+    wa.per_split = (int)cdiv(B, wa.nsplit);
+    ColSum cs;
+    cs.part = w.part; cs.se = se; cs.flat_g = flat_g; cs.sse_accum = sse_accum; cs.B = B; cs.nhp = nhp;
+    cs.col0_lo = (int)lo; cs.col0_n = nhp; cs.col1_lo = (int)hi;
+    cs.aux = w.aux; cs.inv_denom = inv_denom;                // sse_accum: [sum source SE, sum of batch-mean target SE, sum of batch-mean transform loss]
+    const int cs_blocks = (nhp + 3 + CS_COLS - 1) / CS_COLS;
+    const bool prefetch = next_user_idx && algo == R4R_CONV_PROJECT;
+    TokenArgs nx{};
+    if (prefetch) {
+        ProjTower nt[3];
+        const int64_t *nidx[3] = {next_user_idx, next_item_idx, next_this_idx};
+        const int ob = token_buffer ^ 1;
+        for (int t = 0; t < 3; ++t) {
+            nt[t] = ProjTower{};
+            nt[t].idx = nidx[t];
+            nt[t].flags = w.flags[ob][t]; nt[t].slot = w.slot[ob][t]; nt[t].list = w.list[ob][t]; nt[t].count = w.count[ob][t];
+        }
+        nx = make_token_args(V, nt, 3, B, T);
+    }
+    const int packed = 3 * E / 4 <= 64;
+    narre_backward_kernel<0><<<dim3(packed ? (NF + 3) / 4 : NF, wa.nsplit, prefetch ? 5 : 4), WG_THREADS, 0, st>>>(
+        wa, cs, cs_blocks, nx, packed, RowSweep{}, 0, 3);
+
+    const int red_blocks = (NF * 3 * E + NF + NRED_THREADS - 1) / NRED_THREADS;
+    const int comp_blocks = prefetch ? (int)cdiv((V + 3) / 4, NRED_THREADS) : 0;
+    DenseAdam opt;
+    opt.on = 1; opt.p = flat_p; opt.m = flat_m; opt.v = flat_v; opt.g = flat_g;
+    opt.lo0 = lo; opt.hi0 = hi; opt.lo1 = hi; opt.hi1 = hi;       // every head parameter in one range (tower 0's slice)
+    opt.s = adam_make_scalars(lr, beta1, beta2, eps, weight_decay, adam_step, nullptr);
+    narre_reduce_kernel<<<dim3(red_blocks + comp_blocks + (int)cdiv(hi - lo, NRED_THREADS), 3), NRED_THREADS, 0, st>>>(
+        wa, red_blocks, comp_blocks, nx, opt);
+    if (!plus) return check_launch("transnet_step");
+    return mf_table_rows_launch(rp[0], rm[0], rv[0], rp[1], rm[1], rv[1], n_users, n_items, TN_ID, uid, iid, w.grow[0], w.grow[1],
+                                w.tag[0], w.tag[1], w.ctag[0], w.ctag[1], B, (int)adam_step, opt.s, st);
+}

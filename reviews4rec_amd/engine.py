@@ -687,7 +687,7 @@ class NarreEngine:
 
 class DeepCoNNPPEngine(NarreEngine):
     """Native step for DeepCoNN++ (model_type 'deepconn++': TextCNN towers + `final` MLP + ID
-    biases; csrc/narre_engine.hip, r4r_deepconnpp_step).  Shares NarreEngine's machinery: flat
+    biases; csrc/deepconnpp_engine.hip, r4r_deepconnpp_step).  Shares NarreEngine's machinery: flat
     dense buffer aliased by the module's Parameters, the two ID bias vectors updated by a tagged
     sweep, token double-buffering.  The reference's `fm` module is constructed but unused in this
     mode (DeepCoNN.py:64-72) and is left alone."""
@@ -741,7 +741,7 @@ class DeepCoNNPPEngine(NarreEngine):
 
 
 class TransNetEngine(NarreEngine):
-    """Native step for TransNet / TransNet++ (csrc/narre_engine.hip, r4r_transnet_step): three
+    """Native step for TransNet / TransNet++ (csrc/transnet_engine.hip, r4r_transnet_step): three
     TextCNN towers, the source MLP, both factorisation machines, the three losses of main.py:35-53
     and their three disjoint parameter groups in ONE backward and one flat Adam (the three
     optimisers of utils.init_transnet_optim share lr, weight decay and step count; include/r4r.h
