@@ -816,3 +816,67 @@ def test_transnet_engine_through_the_host_loop(case):
     sd = model.state_dict()
     for k, v in g.params('tn_w3').items():
         torch.testing.assert_close(sd[k].cpu(), v, rtol=1e-5, atol=5e-6, msg=lambda m: k + ': ' + m)
+
+
+@pytest.mark.parametrize('mt', ['transnet', 'transnet++'])
+def test_transnet_engine_wide_latent_and_larger_shapes(mt):
+    """latent_size 24 (> 16: the <= 32 head instantiation), E = 64, T = 200 (project-then-gather by
+    choice), duplicated ids, against the CPU oracle's literal three-optimiser step: two steps."""
+    import reviews4rec_amd
+    from reviews4rec_amd.engine import TransNetEngine
+    from test_oracle_golden import ill_conditioned
+    B, T, E, V, U, I, L = 12, 200, 64, 400, 30, 20, 24
+    hp = dict(model_type=mt, latent_size=L, word_embed_size=E, input_length=T, dropout=0.0, total_users=U, total_items=I,
+              lr=0.002, weight_decay=1e-6)
+    P = oracle.init_params(hp, vocab_size=V, seed=4)
+    model = reviews4rec_amd.get_model_class(mt)(dict(hp, word_vectors=P['target.word2vec.weight'].numpy()))
+    model.load_state_dict(P)
+    model = model.to(DEV).train()
+    eng = TransNetEngine(model, lr=hp['lr'], weight_decay=hp['weight_decay'], conv_algo=2)
+    states = dict(source=oracle.AdamState(), source_fm=oracle.AdamState(), target=oracle.AdamState())
+    data, y = synthetic_review_batch(B, T, V, U, I, seed=3)
+    data[5][:4] = data[5][0]                                 # the same user four times, the same item three times
+    data[6][5:8] = data[6][5]
+    for step in range(2):
+        se = eng.train_step([d.to(DEV) for d in data], y.to(DEV)).cpu().clone()
+        ref_se, lt, ltr = oracle.transnet_train_step(P, data, y, hp, states)
+        torch.testing.assert_close(se, ref_se, rtol=1e-4, atol=1e-4)
+        aux = eng.aux([d.to(DEV) for d in data]).cpu()
+        torch.testing.assert_close(aux[:, 1].mean(), torch.tensor(lt), rtol=1e-4, atol=1e-4)
+        torch.testing.assert_close(aux[:, 2].mean(), torch.tensor(ltr), rtol=1e-4, atol=1e-4)
+    sd = model.state_dict()
+    for k, v in P.items():
+        if not ill_conditioned(k):
+            diff = (sd[k].cpu() - v).abs()
+            assert float((diff > 2e-5 + 1e-4 * v.abs()).float().mean()) < 2e-3 and float(diff.max()) < 5e-4, k
+
+
+def test_transnet_engine_token_prefetch_is_bit_identical_with_wrong_guesses():
+    """TransNet++: the next batch's token state (three towers) prepared on the current step's
+    launches changes no bit; a wrong guess and an eval in between are handled."""
+    import reviews4rec_amd
+    from reviews4rec_amd.engine import TransNetEngine
+    B, T, E, V, U, I, L = 16, 300, 32, 900, 60, 40, 10
+    hp = dict(model_type='transnet++', latent_size=L, word_embed_size=E, input_length=T, dropout=0.5, total_users=U,
+              total_items=I, lr=0.002, weight_decay=1e-6)
+    P = oracle.init_params(hp, vocab_size=V, seed=6)
+    batches = [synthetic_review_batch(B, T, V, U, I, seed=50 + k, device=DEV) for k in range(4)]
+
+    def run(prefetch):
+        model = reviews4rec_amd.get_model_class('transnet++')(dict(hp, word_vectors=P['target.word2vec.weight'].numpy()))
+        model.load_state_dict(P)
+        eng = TransNetEngine(model.to(DEV).train(), lr=hp['lr'], weight_decay=hp['weight_decay'], conv_algo=2, seed=7)
+        order = [0, 1, 2, 3, 0, 2]
+        for n, k in enumerate(order):
+            data, y = batches[k]
+            guess = batches[order[n + 1] if n + 1 < len(order) and n != 2 else 1][0]    # step 2 announces the wrong batch
+            eng.train_step(data, y, next_data=guess if prefetch else None)
+            if n == 3:
+                model.eval()
+                eng.predict(batches[1][0], batches[1][1])
+                model.train()
+        return {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+
+    a, b = run(False), run(True)
+    for k in a:
+        assert torch.equal(a[k], b[k]), k
