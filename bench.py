@@ -287,7 +287,7 @@ def main():
     # GEMM + gather: slots 3, 4).  A HIP event record serialises the queue for ~3 us; instrumenting
     # every launch of every step cost 20 % of a 0.13 ms step, sampling costs ~1 %.
     mask = 0 if args.no_kernel_timing else (1 << 0) | (1 << 3) | (1 << 4) | \
-        ((1 << 2) if hp['model_type'] in ('MF_dot', 'bias_only') else 0)       # MF: the Adam sweep is the leg
+        ((1 << 2) if hp['model_type'] in ('MF_dot', 'bias_only', 'transnet++') else 0)   # the Adam sweep is the leg
     t0 = time.perf_counter()
     dbg = [] if os.environ.get('R4R_BENCH_TRACE') else None
     gev = []
@@ -352,13 +352,14 @@ def main():
                                  'dropout': hp['dropout']}},
         }
         result['kernel_ms'] = {k: round(v[0], 4) for k, v in timed.items()}
-        towers = 2 if engine is not None else 1              # the native step runs both towers per launch
+        towers = (3 if is_tn else 2) if engine is not None else 1    # the native step runs all towers per launch
         positions = towers * B * (hp['input_length'] + 2)
         if 'proj_gather_max_kernel' in timed:
             # project-then-gather.  Dominant kernel: the projection GEMM over the
             # batch's DISTINCT tokens (fp32 MFMA).  Its useful flops are data dependent, so they are
             # counted on the host from the very batches that were run: rows x E x 300 x 2 per tower.
-            rows = np.mean([len(np.unique(d[3])) + len(np.unique(d[4])) for d, _ in batches_np])
+            rows = np.mean([len(np.unique(d[3])) + len(np.unique(d[4])) + (len(np.unique(d[0])) if is_tn else 0)
+                            for d, _ in batches_np])
             g_s = timed['proj_gemm_kernel'][0] / 1000.0
             gflops = rows * hp['word_embed_size'] * 300 * 2
             ach = gflops / g_s / 1e12
@@ -385,6 +386,18 @@ def main():
                         'time): what a direct conv would have to sustain to match',
                 'TFLOPs': round(towers * B * tower_flops_per_doc(hp) / (avg_s + g_s) / 1e12, 1),
                 'peak_fp32_mfma': PEAK_FP32_MFMA_TFLOPS}
+            if hp['model_type'] == 'transnet++' and engine is not None and 'adam_multi_kernel' in timed:
+                # TransNet++: the dominant kernel is the Adam sweep over the two ID-vector tables (24 B per
+                # parameter), HBM-bound; the GEMM leg moves aside
+                result['roofline_gemm'] = result['roofline']
+                nparam = model.user_embedding.weight.numel() + model.item_embedding.weight.numel()
+                avg_s = timed['adam_multi_kernel'][0] / 1000.0
+                ach_b = nparam * 24 / avg_s / 1e9
+                result['roofline'] = {'kernel': 'mf_adam_kernel', 'bound': 'hbm', 'achieved': round(ach_b, 1),
+                                      'peak': PEAK_HBM_GBS, 'unit': 'GB/s', 'frac': round(ach_b / PEAK_HBM_GBS, 4),
+                                      'traffic': None, 'launches': timed['adam_multi_kernel'][1],
+                                      'avg_launch_ms': round(1000 * avg_s, 4), 'bytes_per_launch': int(nparam * 24),
+                                      'parameters': int(nparam)}
         elif 'textcnn_fwd_kernel' in timed and hp.get('vocab'):
             flops = towers * B * tower_flops_per_doc(hp)
             avg_s = timed['textcnn_fwd_kernel'][0] / 1000.0

@@ -713,7 +713,10 @@ int mf_table_rows_launch(float *ut, float *ut_m, float *ut_v, float *it, float *
     sw.uid = uid; sw.iid = iid; sw.gu = gu; sw.gi = gi; sw.g = nullptr; sw.se = nullptr; sw.sse_accum = nullptr;
     sw.tag_u = tag_u; sw.tag_i = tag_i; sw.ctag_u = ctag_u; sw.ctag_i = ctag_i;
     sw.B = B; sw.D = D; sw.now = now; sw.s = sc;
-    mf_adam_kernel<4><<<(unsigned)chunks, MF_THREADS, (size_t)B * sizeof(int), st>>>(sw);
+    {
+        ScopedTiming tm(R4R_TIMING_ADAM, st);
+        mf_adam_kernel<4><<<(unsigned)chunks, MF_THREADS, (size_t)B * sizeof(int), st>>>(sw);
+    }
     return check_launch("table rows");
 }
 
