@@ -289,22 +289,14 @@ def main():
     mask = 0 if args.no_kernel_timing else (1 << 0) | (1 << 3) | (1 << 4) | \
         ((1 << 2) if hp['model_type'] in ('MF_dot', 'bias_only', 'transnet++') else 0)   # the Adam sweep is the leg
     t0 = time.perf_counter()
-    dbg = [] if os.environ.get('R4R_BENCH_TRACE') else None
+    dbg = [] if os.environ.get('R4R_BENCH_TRACE') else None   # host / GPU progress per 20 steps on stderr (how the GC pause was found)
     gev = []
     if dbg is not None:
         gev.append(torch.cuda.Event(enable_timing=True))
         gev[-1].record()
-    depth = int(os.environ.get('R4R_BENCH_DEPTH', '0'))
-    marks = []
     for i in range(args.steps):
         lib.r4r_timing_enable(mask if i % 10 == 5 else 0)
         step(args.warmup + i)
-        if depth and i % 4 == 3:
-            ev = torch.cuda.Event()
-            ev.record()
-            marks.append(ev)
-            if len(marks) > depth // 4:
-                marks.pop(0).synchronize()
         if dbg is not None and i % 20 == 19:
             dbg.append(time.perf_counter() - t0)
             gev.append(torch.cuda.Event(enable_timing=True))
