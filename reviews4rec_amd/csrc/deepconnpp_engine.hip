@@ -278,6 +278,8 @@ extern "C" int r4r_deepconnpp_step(const float *table, int64_t V, const int64_t 
     R4R_REQUIRE(adam_step < (1ll << 31), "deepconnpp_step: step tag overflow");
     R4R_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, "deepconnpp_step: dropout %f outside [0,1)", (double)dropout_p);
     R4R_REQUIRE(B * (int64_t)((T + 2 + 127) / 128) < (1ll << 31), "deepconnpp_step: grid too large");
+    R4R_REQUIRE(!train_step || B <= 16384, "deepconnpp_step: batch %lld > 16384 (the bias sweep keeps a side's ids in LDS; "
+                "use the module path for larger batches)", (long long)B);
     if (ws_bytes < r4r_deepconnpp_ws_bytes(B, T, E, L, V, n_users, n_items)) {
         set_error("deepconnpp_step: workspace %zu < %zu bytes", ws_bytes, r4r_deepconnpp_ws_bytes(B, T, E, L, V, n_users, n_items));
         return R4R_ERR_WORKSPACE;

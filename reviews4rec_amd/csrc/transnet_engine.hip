@@ -391,6 +391,8 @@ extern "C" int r4r_transnet_step(const float *table, int64_t V,
     R4R_REQUIRE(adam_step < (1ll << 31), "transnet_step: step tag overflow");
     R4R_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, "transnet_step: dropout %f outside [0,1)", (double)dropout_p);
     R4R_REQUIRE(B * (int64_t)((T + 2 + 127) / 128) < (1ll << 31), "transnet_step: grid too large");
+    R4R_REQUIRE(!(plus && train_step) || B <= 16384, "transnet_step: batch %lld > 16384 (the ID-vector sweep keeps a side's ids "
+                "in LDS; use the module path for larger batches)", (long long)B);
     if (ws_bytes < r4r_transnet_ws_bytes(B, T, E, L, plus, V, n_users, n_items)) {
         set_error("transnet_step: workspace %zu < %zu bytes", ws_bytes,
                   r4r_transnet_ws_bytes(B, T, E, L, plus, V, n_users, n_items));
