@@ -183,9 +183,9 @@ def main():
     B_global = B * world
 
     engine = None
-    if args.engine == 'native' and hp['model_type'] in ('MF_dot', 'bias_only') and world == 1 and B <= 16384:
+    if args.engine == 'native' and hp['model_type'] in ('MF_dot', 'bias_only') and B * world <= 16384:
         from reviews4rec_amd.engine import MFEngine
-        engine = MFEngine(model, lr=hp['lr'], weight_decay=hp['weight_decay'], seed=4321, rank=rank)
+        engine = MFEngine(model, lr=hp['lr'], weight_decay=hp['weight_decay'], seed=4321, rank=rank, dp=dp)
     if args.engine == 'native' and hp['model_type'] == 'NARRE' and world == 1:
         from reviews4rec_amd.engine import NarreEngine
         engine = NarreEngine(model, lr=hp['lr'], weight_decay=hp['weight_decay'], seed=4321, rank=rank,

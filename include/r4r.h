@@ -324,6 +324,25 @@ int r4r_mf_step(const int64_t *uid, const int64_t *iid, const float *y,
                 float lr, double beta1, double beta2, float eps, float weight_decay, int64_t adam_step,
                 void *stream);
 
+/* ---- MF under data parallelism: one process per GPU, replicated tables.
+ * r4r_mf_grad: this rank's forward + compact gradient rows into one packed `block`
+ *   (r4r_mf_dp_block_bytes(B_pad, D) bytes: uid32 [B_pad] | iid32 | g | gu [B_pad, D] | gi; entries
+ *   past this rank's B carry id -1: ragged shards).  inv_denom = 1 / B_global.
+ * The caller all_gathers the blocks (rank order), then every rank calls
+ * r4r_mf_apply(blocks [world], ...): row tags + owner election over the gathered entries, then the
+ *   same tagged sweep as r4r_mf_step -- identical bits on every rank, and identical to the
+ *   single-process step on the concatenated batch.  ws: r4r_mf_ws_bytes(world * B_pad, ...), zeroed
+ *   once; world * B_pad <= 16384. */
+size_t r4r_mf_dp_block_bytes(int64_t B_pad, int D);
+int r4r_mf_grad(const int64_t *uid, const int64_t *iid, const float *y, const uint64_t *p,
+                int64_t n_users, int64_t n_items, int D, float *pred, float *se, void *block, float *mult,
+                int64_t B, int64_t B_pad, float dropout_p, int training, uint64_t seed, uint64_t offset,
+                float inv_denom, void *stream);
+int r4r_mf_apply(const void *blocks, int world, int64_t B_pad, const uint64_t *p, const uint64_t *m,
+                 const uint64_t *v, int64_t n_users, int64_t n_items, int D, void *ws, size_t ws_bytes,
+                 float lr, double beta1, double beta2, float eps, float weight_decay, int64_t adam_step,
+                 void *stream);
+
 /* ---- fused native step for NARRE (pytorch_models/NARRE.py:10-124)
  * Replaces, per training step: the word gathers + TextCNN over the B*R review documents of each
  * side, TextCNN's FC + dropout, both attention scorers + softmax (NARRE.py:53-64), the four

@@ -56,6 +56,8 @@ struct MfStep {
     int *uid32, *iid32;                      // [B] compact copies of the ids
     float *pred, *se, *sse_accum;
     int64_t B;
+    int64_t B_pad = 0;                 // data parallel: rows [B, B_pad) of the entry arrays are filled as padding (id -1)
+    int register_rows = 1;             // 0: no row tags / owner election here (data parallel: done over the gathered entries)
     int D, training, want_grad, tag;
     float p_drop, inv_denom;
     uint64_t seed, offset;
@@ -64,7 +66,10 @@ struct MfStep {
 __global__ __launch_bounds__(256) void mf_fwd_bwd_kernel(MfStep a) {
     const int lane = threadIdx.x & 63;
     const int64_t b = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (b >= a.B) return;                                   // whole wave
+    if (b >= a.B) {                                         // whole wave
+        if (b < a.B_pad && lane == 0) { a.uid32[b] = -1; a.iid32[b] = -1; a.g[b] = 0.f; }
+        return;
+    }
     const int D = a.D;
     const int64_t u = a.uid[b], i = a.iid[b];
     const float base = (a.p[2][u] + a.p[3][i]) + a.p[4][0];
@@ -100,13 +105,15 @@ __global__ __launch_bounds__(256) void mf_fwd_bwd_kernel(MfStep a) {
     const float g = 2.f * d * a.inv_denom;
     if (lane == 0) {
         a.g[b] = g;
-        a.tag_u[u] = a.tag;
-        a.tag_i[i] = a.tag;
-        atomicMax(a.first_u + u, mf_first_pack(a.tag, b));
-        atomicMax(a.first_i + i, mf_first_pack(a.tag, b));
-        const unsigned long long lastv = ((unsigned long long)(unsigned)a.tag << 32) | (unsigned long long)b;
-        atomicMax(a.last_u + u, lastv);
-        atomicMax(a.last_i + i, lastv);
+        if (a.register_rows) {
+            a.tag_u[u] = a.tag;
+            a.tag_i[i] = a.tag;
+            atomicMax(a.first_u + u, mf_first_pack(a.tag, b));
+            atomicMax(a.first_i + i, mf_first_pack(a.tag, b));
+            const unsigned long long lastv = ((unsigned long long)(unsigned)a.tag << 32) | (unsigned long long)b;
+            atomicMax(a.last_u + u, lastv);
+            atomicMax(a.last_i + i, lastv);
+        }
         a.uid32[b] = (int)u;
         a.iid32[b] = (int)i;
     }
@@ -185,6 +192,7 @@ __device__ __forceinline__ void mf_entry(const MfSweep &w, const int *sid, int *
     bool single = false;
     if (first) {
         row = gid[k];
+        if (row < 0) return;                                // a padded entry (data-parallel gather of ragged shards)
         if (first[row] != mf_first_pack(w.now, k)) return;
         const unsigned last_k = (unsigned)(t ? w.last_i : w.last_u)[row];   // low word: the row's last rating
         single = last_k == (unsigned)k;
@@ -378,8 +386,9 @@ __global__ __launch_bounds__(MF_THREADS) void mf_adam_kernel(MfSweep w) {
                 const int D = w.D, lpr = D >> 2, sh = __ffs(lpr) - 1;
                 const int grp = lane >> sh, sub = lane & (lpr - 1);
                 const int64_t k = base + grp * nw;
-                const bool valid = k < w.B;
-                const int row = (t ? w.iid32 : w.uid32)[valid ? k : base];
+                const int row_raw = (t ? w.iid32 : w.uid32)[k < w.B ? k : base];
+                const bool valid = k < w.B && row_raw >= 0;  // (-1: a padded entry of a gathered ragged shard)
+                const int row = valid ? row_raw : 0;
                 const unsigned long long f = (t ? w.first_i : w.first_u)[row], l = (t ? w.last_i : w.last_u)[row];
                 const bool owner = valid && f == mf_first_pack(w.now, k);
                 const bool single = owner && (unsigned)l == (unsigned)k;
@@ -425,7 +434,7 @@ __global__ __launch_bounds__(MF_THREADS) void mf_adam_kernel(MfSweep w) {
         // ---- global bias (gradient = sum of d loss / d pred over the batch) + the running SE:
         // strided per-thread sums, then a fixed tree -- deterministic
         float a = 0.f, e = 0.f;
-        for (int64_t b = tid; b < w.B; b += MF_THREADS) { a += w.g[b]; e += w.se[b]; }
+        for (int64_t b = tid; b < w.B; b += MF_THREADS) { a += w.g[b]; e += w.se ? w.se[b] : 0.f; }
         red[tid] = a;
         __syncthreads();
         for (int off = MF_THREADS / 2; off > 0; off >>= 1) { if (tid < off) red[tid] += red[tid + off]; __syncthreads(); }
@@ -827,4 +836,154 @@ extern "C" int r4r_mf_step(const int64_t *uid, const int64_t *iid, const float *
         else mf_adam_kernel<4><<<(unsigned)chunks, MF_THREADS, 0, st>>>(sw);
     }
     return check_launch("mf_step");
+}
+
+// ------------------------------------------------------------------ data parallel
+// One process per GPU, replicated tables.  Each rank computes the compact gradient rows of ITS
+// ratings (r4r_mf_grad) into a packed block; one all_gather moves the blocks; every rank then
+// applies the same update from all blocks in rank order (r4r_mf_apply): replicas stay bit-identical,
+// and the result equals the single-process step on the concatenated batch (same entries, same
+// order).  Block layout (bytes): uid32 [B_pad] | iid32 [B_pad] | g [B_pad] | gu [B_pad, D] | gi [B_pad, D];
+// entries past a rank's own count carry id -1 (ragged shards).
+namespace r4r {
+
+struct MfBlock { size_t uid, iid, g, gu, gi, bytes; };
+static MfBlock mf_block(int64_t B_pad, int D) {
+    MfBlock k;
+    size_t o = 0;
+    auto take = [&](size_t n) { size_t r = o; o += a256(n); return r; };
+    k.uid = take((size_t)B_pad * 4); k.iid = take((size_t)B_pad * 4); k.g = take((size_t)B_pad * 4);
+    k.gu = take((size_t)B_pad * D * 4); k.gi = take((size_t)B_pad * D * 4);
+    k.bytes = o;
+    return k;
+}
+
+struct MfRegister {
+    const char *blocks;                // [world] packed blocks
+    MfBlock k;
+    int world, D, now;
+    int64_t B_pad;
+    int *tag_u, *tag_i, *uid32, *iid32;
+    unsigned long long *first_u, *first_i, *last_u, *last_i;
+    float *g, *gu, *gi;                // contiguous [world * B_pad] entry arrays for the update kernel
+};
+
+// one wave per gathered entry: ids, d loss / d pred and the two gradient rows into the contiguous
+// entry arrays; row tags and owner election for the real entries
+__global__ __launch_bounds__(256) void mf_register_kernel(MfRegister a) {
+    const int lane = threadIdx.x & 63;
+    const int64_t e = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (e >= (int64_t)a.world * a.B_pad) return;
+    const int64_t r = e / a.B_pad, b = e - r * a.B_pad;
+    const char *blk = a.blocks + (size_t)r * a.k.bytes;
+    const int u = reinterpret_cast<const int *>(blk + a.k.uid)[b], i = reinterpret_cast<const int *>(blk + a.k.iid)[b];
+    if (lane == 0) {
+        a.uid32[e] = u; a.iid32[e] = i;
+        a.g[e] = reinterpret_cast<const float *>(blk + a.k.g)[b];
+        if (u >= 0) {
+            a.tag_u[u] = a.now; a.tag_i[i] = a.now;
+            atomicMax(a.first_u + u, mf_first_pack(a.now, e));
+            atomicMax(a.first_i + i, mf_first_pack(a.now, e));
+            const unsigned long long lastv = ((unsigned long long)(unsigned)a.now << 32) | (unsigned long long)e;
+            atomicMax(a.last_u + u, lastv);
+            atomicMax(a.last_i + i, lastv);
+        }
+    }
+    if (u >= 0)
+        for (int d = lane; d < a.D; d += 64) {
+            a.gu[e * a.D + d] = reinterpret_cast<const float *>(blk + a.k.gu)[b * a.D + d];
+            a.gi[e * a.D + d] = reinterpret_cast<const float *>(blk + a.k.gi)[b * a.D + d];
+        }
+}
+
+}  // namespace r4r
+
+extern "C" size_t r4r_mf_dp_block_bytes(int64_t B_pad, int D) {
+    if (B_pad < 0 || D < 0) return 0;
+    return mf_block(B_pad, D).bytes;
+}
+
+extern "C" int r4r_mf_grad(const int64_t *uid, const int64_t *iid, const float *y, const uint64_t *p,
+                           int64_t n_users, int64_t n_items, int D, float *pred, float *se, void *block, float *mult,
+                           int64_t B, int64_t B_pad, float dropout_p, int training, uint64_t seed, uint64_t offset,
+                           float inv_denom, void *stream) {
+    R4R_REQUIRE(p && pred && se && block && y, "mf_grad: null pointer");
+    R4R_REQUIRE(B == 0 || (uid && iid), "mf_grad: null ids");
+    R4R_REQUIRE(n_users > 0 && n_items > 0 && B >= 0 && B_pad >= B, "mf_grad: bad sizes");
+    R4R_REQUIRE(D >= 0 && D <= MF_MAX_D, "mf_grad: latent_size %d outside 0..%d", D, MF_MAX_D);
+    R4R_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, "mf_grad: dropout %f outside [0,1)", (double)dropout_p);
+    if (B_pad == 0) return R4R_OK;
+    const MfBlock k = mf_block(B_pad, D);
+    char *blk = static_cast<char *>(block);
+    MfStep a{};
+    a.uid = uid; a.iid = iid; a.y = y;
+    for (int s = 0; s < MF_SLOTS; ++s) a.p[s] = reinterpret_cast<float *>(p[s]);
+    for (int s = (D > 0 ? 0 : 2); s < MF_SLOTS; ++s) R4R_REQUIRE(a.p[s], "mf_grad: slot %d: null parameter pointer", s);
+    a.uid32 = reinterpret_cast<int *>(blk + k.uid); a.iid32 = reinterpret_cast<int *>(blk + k.iid);
+    a.g = reinterpret_cast<float *>(blk + k.g); a.gu = reinterpret_cast<float *>(blk + k.gu);
+    a.gi = reinterpret_cast<float *>(blk + k.gi); a.mult = mult;
+    a.pred = pred; a.se = se; a.B = B; a.B_pad = B_pad; a.register_rows = 0; a.D = D; a.training = training;
+    a.want_grad = 1; a.tag = 0; a.p_drop = dropout_p; a.inv_denom = inv_denom; a.seed = seed; a.offset = offset;
+    mf_fwd_bwd_kernel<<<(unsigned)cdiv(B_pad, 4), 256, 0, as_stream(stream)>>>(a);
+    return check_launch("mf_grad");
+}
+
+extern "C" int r4r_mf_apply(const void *blocks, int world, int64_t B_pad, const uint64_t *p, const uint64_t *m,
+                            const uint64_t *v, int64_t n_users, int64_t n_items, int D, void *ws, size_t ws_bytes,
+                            float lr, double beta1, double beta2, float eps, float weight_decay, int64_t adam_step,
+                            void *stream) {
+    R4R_REQUIRE(blocks && p && m && v && ws, "mf_apply: null pointer");
+    R4R_REQUIRE(world >= 1 && B_pad >= 0 && n_users > 0 && n_items > 0, "mf_apply: bad sizes");
+    const int64_t B = (int64_t)world * B_pad;
+    R4R_REQUIRE(B <= MF_MAX_B, "mf_apply: %lld gathered entries > %d", (long long)B, MF_MAX_B);
+    R4R_REQUIRE(D >= 0 && D <= MF_MAX_D, "mf_apply: latent_size %d outside 0..%d", D, MF_MAX_D);
+    R4R_REQUIRE(adam_step >= 1 && adam_step < (1ll << 31), "mf_apply: bad adam_step");
+    if (ws_bytes < r4r_mf_ws_bytes(B, D, n_users, n_items)) {
+        set_error("mf_apply: workspace %zu < %zu bytes", ws_bytes, r4r_mf_ws_bytes(B, D, n_users, n_items));
+        return R4R_ERR_WORKSPACE;
+    }
+    if (B == 0) return R4R_OK;
+    hipStream_t st = as_stream(stream);
+    const MfWs w = mf_carve(ws, B, D, n_users, n_items);
+    MfRegister rg;
+    rg.blocks = static_cast<const char *>(blocks); rg.k = mf_block(B_pad, D); rg.world = world; rg.D = D;
+    rg.now = (int)adam_step; rg.B_pad = B_pad;
+    rg.tag_u = w.tag_u; rg.tag_i = w.tag_i; rg.uid32 = w.uid32; rg.iid32 = w.iid32;
+    rg.first_u = w.first_u; rg.first_i = w.first_i; rg.last_u = w.last_u; rg.last_i = w.last_i;
+    rg.g = w.g; rg.gu = w.gu; rg.gi = w.gi;
+    mf_register_kernel<<<(unsigned)cdiv(B, 4), 256, 0, st>>>(rg);
+    float *P[MF_SLOTS], *M[MF_SLOTS], *V[MF_SLOTS];
+    for (int k = 0; k < MF_SLOTS; ++k) {
+        P[k] = reinterpret_cast<float *>(p[k]); M[k] = reinterpret_cast<float *>(m[k]); V[k] = reinterpret_cast<float *>(v[k]);
+        R4R_REQUIRE(k < (D > 0 ? 0 : 2) || (P[k] && M[k] && V[k]), "mf_apply: slot %d: null parameter / moment pointer", k);
+    }
+    MfSweep sw{};
+    sw.p0 = P[0]; sw.p1 = P[1]; sw.p2 = P[2]; sw.p3 = P[3]; sw.p4 = P[4];
+    sw.m0 = M[0]; sw.m1 = M[1]; sw.m2 = M[2]; sw.m3 = M[3]; sw.m4 = M[4];
+    sw.v0 = V[0]; sw.v1 = V[1]; sw.v2 = V[2]; sw.v3 = V[3]; sw.v4 = V[4];
+    const int64_t rows[4] = {n_users, n_items, n_users, n_items};
+    const int width[4] = {D, D, 1, 1};
+    int64_t numel[4], begin[4], chunks = 0;
+    for (int k = 0; k < 4; ++k) {
+        numel[k] = rows[k] * width[k];
+        begin[k] = chunks;
+        chunks += cdiv(numel[k], mf_chunk(k));
+    }
+    sw.n0 = numel[0]; sw.n1 = numel[1]; sw.n2 = numel[2]; sw.n3 = numel[3];
+    sw.cb1 = (int)begin[1]; sw.cb2 = (int)begin[2]; sw.cb3 = (int)begin[3];
+    sw.cb_global = (int)chunks;
+    chunks += 1;
+    sw.cb_entries = (int)chunks;
+    sw.epw = (D > 0 && mf_wide(D, sw.p0, sw.m0, sw.v0) && mf_wide(D, sw.p1, sw.m1, sw.v1)) ? 256 / D : 1;
+    sw.n_entry_wgs = (int)(2 * cdiv(B, 4 * sw.epw));
+    chunks += sw.n_entry_wgs;
+    R4R_REQUIRE(chunks < (1ll << 31), "mf_apply: too many workgroups");
+    sw.first_u = w.first_u; sw.first_i = w.first_i; sw.last_u = w.last_u; sw.last_i = w.last_i;
+    sw.uid32 = w.uid32; sw.iid32 = w.iid32;
+    sw.uid = nullptr; sw.iid = nullptr; sw.gu = w.gu; sw.gi = w.gi; sw.g = w.g; sw.se = nullptr; sw.sse_accum = nullptr;
+    sw.tag_u = w.tag_u; sw.tag_i = w.tag_i; sw.B = B; sw.D = D; sw.now = (int)adam_step;
+    sw.s = adam_make_scalars(lr, beta1, beta2, eps, weight_decay, adam_step, nullptr);
+    if (B > 2048) mf_adam_kernel<8><<<(unsigned)chunks, MF_THREADS, 0, st>>>(sw);
+    else mf_adam_kernel<4><<<(unsigned)chunks, MF_THREADS, 0, st>>>(sw);
+    return check_launch("mf_apply");
 }

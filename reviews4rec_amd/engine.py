@@ -312,11 +312,13 @@ class MFEngine:
     """Native step for model_type 'MF_dot' / 'bias_only' (csrc/mf_engine.hip, r4r_mf_step): forward,
     loss, backward and the dense Adam update of MF.py / main.py:56-60,94-96 in two launches; the
     dense gradient of an ID table is never materialised.  Same calling surface as DeepCoNNEngine
-    (train_step / predict / sse / state_dict).  Single process only: under data parallelism the
-    module path + the compact-list exchange of dist.py run instead."""
+    (train_step / predict / sse / state_dict).  Under data parallelism (``dp``) the step splits into
+    r4r_mf_grad -> one all_gather of the ranks' compact rows -> r4r_mf_apply."""
     MAX_TRAIN_BATCH = 16384      # r4r_mf_step's limit; larger batches take the module path (main.make_engine)
 
-    def __init__(self, model, lr=0.002, weight_decay=1e-6, betas=(0.9, 0.999), eps=1e-8, seed=0x5EED5EED, rank=0):
+    def __init__(self, model, lr=0.002, weight_decay=1e-6, betas=(0.9, 0.999), eps=1e-8, seed=0x5EED5EED, rank=0,
+                 dp=None):
+        self.dp = dp if (dp is not None and dp.on) else None
         hp = model.hyper_params
         if hp['model_type'] not in ('MF_dot', 'bias_only'):
             raise ValueError("MFEngine implements model_type 'MF_dot' and 'bias_only', got %r" % (hp['model_type'],))
@@ -381,6 +383,42 @@ class MFEngine:
             self.offset += n * 2 * self.D
         return pred, se
 
+    def _train_step_dp(self, data, y, n_global):
+        """Data parallel: this rank's compact gradient rows into a packed block, ONE
+        all_gather of the blocks, then the same tagged sweep over all ranks' entries in rank order
+        on every rank (r4r_mf_grad / r4r_mf_apply): replicas stay bit-identical."""
+        lib, dist = _lib.lib(), torch.distributed
+        uid, iid = data[5].reshape(-1).contiguous(), data[6].reshape(-1).contiguous()
+        n, world = uid.numel(), self.dp.world
+        sizes = torch.tensor([n], dtype=torch.int64, device=self.dev)
+        all_sizes = torch.empty(world, dtype=torch.int64, device=self.dev)
+        dist.all_gather_into_tensor(all_sizes, sizes, group=self.dp.group)    # ragged shards: pad to the longest
+        B_pad = int(all_sizes.max().item())
+        if n_global is None:
+            n_global = int(all_sizes.sum().item())
+        key = ('dp', B_pad)
+        if key not in self._out:
+            nb = lib.r4r_mf_dp_block_bytes(B_pad, self.D)
+            self._out[key] = (torch.empty(max(B_pad, 1), dtype=torch.float32, device=self.dev),
+                              torch.empty(max(B_pad, 1), dtype=torch.float32, device=self.dev),
+                              torch.zeros(nb, dtype=torch.uint8, device=self.dev),
+                              torch.zeros(world * nb, dtype=torch.uint8, device=self.dev))
+        pred, se, block, blocks = self._out[key]
+        _lib.check(lib.r4r_mf_grad(ptr(uid), ptr(iid), ptr(y), self._ptrs(self.params), self.n_users, self.n_items, self.D,
+                                   ptr(pred), ptr(se), ptr(block), None, n, B_pad, float(self.hp['dropout']),
+                                   int(self.model.training), self.seed, self.offset, 1.0 / float(n_global),
+                                   _lib.current_stream()), 'r4r_mf_grad')
+        dist.all_gather_into_tensor(blocks, block, group=self.dp.group)
+        ws = self._workspace(world * B_pad)
+        _lib.check(lib.r4r_mf_apply(ptr(blocks), world, B_pad, self._ptrs(self.params), self._ptrs(self.m),
+                                    self._ptrs(self.v), self.n_users, self.n_items, self.D, ptr(ws), ws.numel(),
+                                    self.lr, self.betas[0], self.betas[1], self.eps, self.wd, int(self.step_count),
+                                    _lib.current_stream()), 'r4r_mf_apply')
+        if self.model.training and float(self.hp['dropout']) > 0.0:
+            self.offset += n * 2 * self.D
+        self.sse += se[:n].sum()                             # this rank's share; the host loop sums the ranks
+        return se[:n]
+
     @torch.no_grad()
     def train_step(self, data, y, n_global=None, next_data=None):
         """One optimisation step.  Returns the per-example SE tensor (device); the running sum is
@@ -388,6 +426,8 @@ class MFEngine:
         n = data[5].numel()
         y = y.reshape(-1).contiguous()
         self.step_count += 1
+        if self.dp is not None:
+            return self._train_step_dp(data, y, n_global)
         _, se = self._launch(data, y, self.model.training, 1.0 / float(n_global if n_global is not None else n),
                              self.step_count)
         return se

@@ -146,11 +146,12 @@ def make_engine(hyper_params, model, dp=None, rank=0):
     if hyper_params.get('engine', 'auto') not in ('auto', 'native'):
         return None
     if hyper_params['model_type'] in ('MF_dot', 'bias_only'):
-        if (dp is not None and dp.on) or int(hyper_params.get('batch_size', 128)) > 16384:
-            return None                                   # DP / very large batches: module path (dist.py C2)
+        world = dp.world if (dp is not None and dp.on) else 1
+        if int(hyper_params.get('batch_size', 128)) * world > 16384:
+            return None                                   # very large (global) batches: module path (dist.py C2)
         from .engine import MFEngine
         return MFEngine(model, lr=hyper_params['lr'], weight_decay=hyper_params['weight_decay'],
-                        seed=hyper_params.get('seed', 0x5EED5EED), rank=rank)
+                        seed=hyper_params.get('seed', 0x5EED5EED), rank=rank, dp=dp)
     if hyper_params['model_type'] == 'NARRE':
         if dp is not None and dp.on:
             return None                                   # DP: module path (dist.py C1 + C2)

@@ -128,3 +128,60 @@ def test_dp2_native_engine_follows_the_reference_trajectory(tmp_path, exchange):
     for k, v in g.params('w3').items():
         assert torch.equal(r0['w'][k], r1['w'][k]), k               # replicas stay bit-identical
         torch.testing.assert_close(r0['w'][k], v, rtol=1e-5, atol=5e-6, msg=lambda m: k + ': ' + m)
+
+
+def _mf_worker(rank, world, port, case, out_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, TESTS)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank), R4R_DIST_BACKEND='gloo')
+    from helpers import Golden
+    from test_gpu_models import build_model
+    from reviews4rec_amd import dist as r4dist, main as M
+    from reviews4rec_amd.engine import MFEngine
+    r4dist.init_from_env()
+    g = Golden(case)
+    model, hp = build_model(g)
+    model.train()
+    dp = r4dist.DataParallel(model)
+    dp.broadcast_parameters()
+    eng = M.make_engine(dict(hp, engine='auto', batch_size=64), model, dp=dp, rank=rank)
+    assert isinstance(eng, MFEngine) and eng.dp is not None
+    ses = []
+    for step in range(3):
+        data, y = g.batch(step % 2, 'cuda')
+        sd, sy = r4dist.shard_batch(data, y, rank, world)            # ragged: the ranks' shards differ in length
+        ses.append(eng.train_step(sd, sy).cpu().clone())
+    torch.save({'w': {k: v.detach().cpu() for k, v in model.state_dict().items()}, 'se': ses},
+               os.path.join(out_dir, 'm%d.pt' % rank))
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.parametrize('case', ['mf_dot', 'mf_bias_only'])
+def test_dp2_native_mf_step_equals_the_single_process_step(tmp_path, case):
+    """MF under data parallelism on the native step (r4r_mf_grad -> all_gather of the packed compact
+    rows -> r4r_mf_apply): 2 ranks x ragged shards reproduce the reference's 3 single-process steps,
+    replicas bit-identical -- and identical, bit for bit, to the single-process native step on the
+    whole batch (same entries in the same order)."""
+    sys.path.insert(0, TESTS)
+    from helpers import Golden
+    from test_gpu_models import build_model
+    from reviews4rec_amd.engine import MFEngine
+    port = _free_port()
+    mp.spawn(_mf_worker, args=(2, port, case, str(tmp_path)), nprocs=2, join=True)
+    g = Golden(case)
+    r0 = torch.load(os.path.join(tmp_path, 'm0.pt'))
+    r1 = torch.load(os.path.join(tmp_path, 'm1.pt'))
+    model, hp = build_model(g)
+    model.train()
+    eng = MFEngine(model, lr=hp['lr'], weight_decay=hp['weight_decay'])
+    for step in range(3):
+        data, y = g.batch(step % 2, 'cuda')
+        eng.train_step(data, y)
+        se = torch.cat([r0['se'][step], r1['se'][step]])
+        torch.testing.assert_close(se, g.arr('se%d' % step), rtol=1e-4, atol=1e-5)
+    single = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    for k, v in g.params('w3').items():
+        assert torch.equal(r0['w'][k], r1['w'][k]), k               # replicas stay bit-identical
+        assert torch.equal(r0['w'][k], single[k]), k                # == the single-process native step
+        torch.testing.assert_close(r0['w'][k], v, rtol=1e-5, atol=5e-6, msg=lambda m: k + ': ' + m)
