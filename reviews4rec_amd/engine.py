@@ -390,11 +390,12 @@ class MFEngine:
         lib, dist = _lib.lib(), torch.distributed
         uid, iid = data[5].reshape(-1).contiguous(), data[6].reshape(-1).contiguous()
         n, world = uid.numel(), self.dp.world
-        sizes = torch.tensor([n], dtype=torch.int64, device=self.dev)
-        all_sizes = torch.empty(world, dtype=torch.int64, device=self.dev)
-        dist.all_gather_into_tensor(all_sizes, sizes, group=self.dp.group)    # ragged shards: pad to the longest
-        B_pad = int(all_sizes.max().item())
-        if n_global is None:
+        B_pad = int(self.hp.get('batch_size', 0))            # every rank's shard fits the configured batch: pad to it
+        if n_global is None or n > B_pad:                    # (otherwise agree on the sizes first: one more collective + a sync)
+            sizes = torch.tensor([n], dtype=torch.int64, device=self.dev)
+            all_sizes = torch.empty(world, dtype=torch.int64, device=self.dev)
+            dist.all_gather_into_tensor(all_sizes, sizes, group=self.dp.group)
+            B_pad = int(all_sizes.max().item())
             n_global = int(all_sizes.sum().item())
         key = ('dp', B_pad)
         if key not in self._out:

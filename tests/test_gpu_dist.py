@@ -151,7 +151,9 @@ def _mf_worker(rank, world, port, case, out_dir):
     for step in range(3):
         data, y = g.batch(step % 2, 'cuda')
         sd, sy = r4dist.shard_batch(data, y, rank, world)            # ragged: the ranks' shards differ in length
-        ses.append(eng.train_step(sd, sy).cpu().clone())
+        # (with the global count known the shards are padded to hyper_params['batch_size'] and no sizes are
+        # exchanged; without it the ranks agree on the sizes first: both forms)
+        ses.append(eng.train_step(sd, sy, n_global=int(y.shape[0]) if step != 1 else None).cpu().clone())
     torch.save({'w': {k: v.detach().cpu() for k, v in model.state_dict().items()}, 'se': ses},
                os.path.join(out_dir, 'm%d.pt' % rank))
     torch.distributed.destroy_process_group()
