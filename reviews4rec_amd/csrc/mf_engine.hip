@@ -907,8 +907,8 @@ extern "C" int r4r_mf_grad(const int64_t *uid, const int64_t *iid, const float *
                            int64_t n_users, int64_t n_items, int D, float *pred, float *se, void *block, float *mult,
                            int64_t B, int64_t B_pad, float dropout_p, int training, uint64_t seed, uint64_t offset,
                            float inv_denom, void *stream) {
-    R4R_REQUIRE(p && pred && se && block && y, "mf_grad: null pointer");
-    R4R_REQUIRE(B == 0 || (uid && iid), "mf_grad: null ids");
+    R4R_REQUIRE(p && pred && se && block, "mf_grad: null pointer");
+    R4R_REQUIRE(B == 0 || (uid && iid && y), "mf_grad: null ids / ratings");   // (an empty shard has none)
     R4R_REQUIRE(n_users > 0 && n_items > 0 && B >= 0 && B_pad >= B, "mf_grad: bad sizes");
     R4R_REQUIRE(D >= 0 && D <= MF_MAX_D, "mf_grad: latent_size %d outside 0..%d", D, MF_MAX_D);
     R4R_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, "mf_grad: dropout %f outside [0,1)", (double)dropout_p);

@@ -208,9 +208,16 @@ class DeepCoNNEngine:
         gradient-reduce launches, and that step then starts at its projection GEMM."""
         n = data[5].numel()
         y = y.reshape(-1).contiguous()
+        dp_on = self.dp is not None and self.dp.on
+        if n == 0 and not dp_on:                             # nothing to train on: no step, no state change
+            return torch.empty(0, dtype=torch.float32, device=self.dev)
         denom = float(n_global if n_global is not None else n * (self.dp.world if self.dp else 1))
         self.step_count += 1
-        if not (self.dp is not None and self.dp.on):
+        if dp_on and n == 0:                                 # an empty shard contributes a zero gradient
+            self.flat_g.zero_()
+            self._exchange_and_update(self.flat_p, self.flat_g, self.flat_m, self.flat_v, self.step_count)
+            return torch.empty(0, dtype=torch.float32, device=self.dev)
+        if not dp_on:
             # single process: the launch that finishes the gradients is also the Adam update
             _, se = self._launch(data, y, grad=True, training=self.model.training, inv_denom=1.0 / denom,
                                  next_data=next_data, adam_step=self.step_count)
@@ -268,6 +275,9 @@ class DeepCoNNEngine:
     @torch.no_grad()
     def predict(self, data, y=None):
         """Eval-mode forward (no dropout, no gradients).  Returns (pred, se or None)."""
+        if data[5].numel() == 0:                             # an empty batch: nothing to launch
+            e = torch.empty(tuple(data[5].shape), dtype=torch.float32, device=self.dev)
+            return e, (e.clone() if y is not None else None)
         if y is not None:
             y = y.reshape(-1).contiguous()
         pred, se = self._launch(data, y, grad=False, training=False, inv_denom=1.0)
@@ -426,6 +436,8 @@ class MFEngine:
         in ``self.sse``.  (``next_data`` is accepted for loop compatibility; nothing to prepare.)"""
         n = data[5].numel()
         y = y.reshape(-1).contiguous()
+        if n == 0 and self.dp is None:                       # nothing to train on: no step, no state change
+            return torch.empty(0, dtype=torch.float32, device=self.dev)
         self.step_count += 1
         if self.dp is not None:
             return self._train_step_dp(data, y, n_global)
@@ -436,6 +448,9 @@ class MFEngine:
     @torch.no_grad()
     def predict(self, data, y=None):
         """Eval-mode forward (no dropout, no gradients).  Returns (pred, se or None)."""
+        if data[5].numel() == 0:                             # an empty batch: nothing to launch
+            e = torch.empty(tuple(data[5].shape), dtype=torch.float32, device=self.dev)
+            return e, (e.clone() if y is not None else None)
         if y is not None:
             y = y.reshape(-1).contiguous()
         pred, se = self._launch(data, y, False, 1.0, 0)
@@ -662,6 +677,8 @@ class NarreEngine:
     def train_step(self, data, y, n_global=None, next_data=None):
         n = data[5].numel()
         y = y.reshape(-1).contiguous()
+        if n == 0:                                           # nothing to train on: no step, no state change
+            return torch.empty(0, dtype=torch.float32, device=self.dev)
         self.step_count += 1
         _, se = self._launch(data, y, self.model.training, 1.0 / float(n_global if n_global is not None else n),
                              self.step_count, next_data)
@@ -669,6 +686,9 @@ class NarreEngine:
 
     @torch.no_grad()
     def predict(self, data, y=None):
+        if data[5].numel() == 0:                             # an empty batch: nothing to launch
+            e = torch.empty(tuple(data[5].shape), dtype=torch.float32, device=self.dev)
+            return e, (e.clone() if y is not None else None)
         if y is not None:
             y = y.reshape(-1).contiguous()
         pred, se = self._launch(data, y, False, 1.0, 0)

@@ -187,3 +187,54 @@ def test_dp2_native_mf_step_equals_the_single_process_step(tmp_path, case):
         assert torch.equal(r0['w'][k], r1['w'][k]), k               # replicas stay bit-identical
         assert torch.equal(r0['w'][k], single[k]), k                # == the single-process native step
         torch.testing.assert_close(r0['w'][k], v, rtol=1e-5, atol=5e-6, msg=lambda m: k + ': ' + m)
+
+
+def _empty_shard_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, TESTS)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank), R4R_DIST_BACKEND='gloo', R4R_DP_EXCHANGE='allreduce')
+    from helpers import Golden
+    from test_gpu_models import build_model
+    from reviews4rec_amd import dist as r4dist
+    from reviews4rec_amd.engine import DeepCoNNEngine, MFEngine
+    r4dist.init_from_env()
+    out = {}
+    for case, Eng, kw in (('deepconn_e20', DeepCoNNEngine, dict(conv_algo=2)), ('mf_dot', MFEngine, {})):
+        g = Golden(case)
+        model, hp = build_model(g)
+        model.train()
+        dp = r4dist.DataParallel(model)
+        dp.broadcast_parameters()
+        eng = Eng(model, lr=hp['lr'], weight_decay=hp['weight_decay'], dp=dp, rank=rank, **kw)
+        data, y = g.batch(0, 'cuda')
+        one = [None if d is None else d[:1] for d in data]           # a global batch of ONE rating: rank 1's shard is empty
+        sd, sy = r4dist.shard_batch(one, y[:1], rank, world)
+        se = eng.train_step(sd, sy, n_global=1)
+        assert se.numel() == (1 if rank == 0 else 0)
+        out[case] = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    torch.save(out, os.path.join(out_dir, 'z%d.pt' % rank))
+    torch.distributed.destroy_process_group()
+
+
+def test_dp2_native_steps_with_an_empty_shard(tmp_path):
+    """A global batch of one rating over two ranks: the rank without rows contributes a zero
+    gradient / no entries, both ranks end on the weights of the single-process step on that rating."""
+    sys.path.insert(0, TESTS)
+    from helpers import Golden
+    from test_gpu_models import build_model
+    from reviews4rec_amd.engine import DeepCoNNEngine, MFEngine
+    port = _free_port()
+    mp.spawn(_empty_shard_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0 = torch.load(os.path.join(tmp_path, 'z0.pt'))
+    r1 = torch.load(os.path.join(tmp_path, 'z1.pt'))
+    for case, Eng, kw in (('deepconn_e20', DeepCoNNEngine, dict(conv_algo=2)), ('mf_dot', MFEngine, {})):
+        g = Golden(case)
+        model, hp = build_model(g)
+        model.train()
+        eng = Eng(model, lr=hp['lr'], weight_decay=hp['weight_decay'], **kw)
+        data, y = g.batch(0, 'cuda')
+        eng.train_step([None if d is None else d[:1] for d in data], y[:1])
+        for k, v in model.state_dict().items():
+            assert torch.equal(r0[case][k], r1[case][k]), (case, k)
+            torch.testing.assert_close(r0[case][k], v.cpu(), rtol=1e-6, atol=1e-7, msg=lambda m: case + ' ' + k + ': ' + m)

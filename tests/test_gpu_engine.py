@@ -880,3 +880,30 @@ def test_transnet_engine_token_prefetch_is_bit_identical_with_wrong_guesses():
     a, b = run(False), run(True)
     for k in a:
         assert torch.equal(a[k], b[k]), k
+
+
+@pytest.mark.parametrize('case', ['deepconn_e20', 'mf_dot', 'narre_e16', 'deepconnpp_e20', 'transnetpp_e16'])
+def test_native_engines_accept_an_empty_and_a_one_row_batch(case):
+    """Edge sizes through every native step: a batch of zero ratings (a rank's empty shard, an
+    exhausted reader) is a no-op that changes no weight, a batch of one rating trains."""
+    from reviews4rec_amd import main as M
+    g = Golden(case)
+    model, hp = build_model(g)
+    model.train()
+    eng = M.make_engine(dict(hp, engine='native'), model)
+    assert eng is not None
+    data, y = g.batch(0, DEV)
+    before = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    empty = [None if d is None else d[:0] for d in data]
+    se = eng.train_step(empty, y[:0])
+    assert se.numel() == 0
+    pred, _ = eng.predict(empty, y[:0])
+    assert pred.numel() == 0
+    torch.cuda.synchronize()
+    for k, v in model.state_dict().items():
+        assert torch.equal(v, before[k]), k
+    one = [None if d is None else d[:1] for d in data]
+    se = eng.train_step(one, y[:1])
+    assert se.shape == (1,) and bool(torch.isfinite(se).all())
+    changed = [k for k, v in model.state_dict().items() if not torch.equal(v, before[k])]
+    assert changed, 'a one-rating step must move the weights'
