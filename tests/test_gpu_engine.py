@@ -907,3 +907,32 @@ def test_native_engines_accept_an_empty_and_a_one_row_batch(case):
     assert se.shape == (1,) and bool(torch.isfinite(se).all())
     changed = [k for k, v in model.state_dict().items() if not torch.equal(v, before[k])]
     assert changed, 'a one-rating step must move the weights'
+
+
+@pytest.mark.parametrize('mt,L', [('deepconn', 24), ('deepconn', 32), ('deepconn++', 24), ('deepconn++', 32)])
+def test_deepconn_engines_wide_latent_use_the_general_instantiation(mt, L):
+    """latent_size 24 and 32 (> 16: the <= 32 head instantiations; 32 is the hard limit) with tall
+    documents (T = 1100: nine 128-position segments, past the head's one-round-trip pool-finish)
+    against the CPU oracle: two steps, SE and updated weights."""
+    from reviews4rec_amd import main as M
+    from test_oracle_golden import ill_conditioned
+    B, T, E, V, U, I = 10, 1100, 32, 500, 30, 20
+    hp = dict(model_type=mt, latent_size=L, word_embed_size=E, input_length=T, dropout=0.0, total_users=U, total_items=I,
+              lr=0.002, weight_decay=1e-6)
+    P = oracle.init_params(hp, vocab_size=V, seed=9)
+    import reviews4rec_amd
+    model = reviews4rec_amd.get_model_class(mt)(dict(hp, word_vectors=P['word2vec.weight'].numpy()))
+    model.load_state_dict(P)
+    model = model.to(DEV).train()
+    eng = M.make_engine(dict(hp, engine='native'), model)
+    state = oracle.AdamState()
+    data, y = synthetic_review_batch(B, T, V, U, I, seed=12)
+    for step in range(2):
+        se = eng.train_step([d.to(DEV) for d in data], y.to(DEV)).cpu().clone()
+        sse, _ = oracle.train_step(P, data, y, hp, state)
+        torch.testing.assert_close(se.sum(), torch.tensor(sse), rtol=1e-4, atol=1e-4)
+    sd = model.state_dict()
+    for k, v in P.items():
+        if not ill_conditioned(k):
+            diff = (sd[k].cpu() - v).abs()
+            assert float((diff > 2e-5 + 1e-4 * v.abs()).float().mean()) < 2e-3 and float(diff.max()) < 5e-4, k
