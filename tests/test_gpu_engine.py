@@ -936,3 +936,27 @@ def test_deepconn_engines_wide_latent_use_the_general_instantiation(mt, L):
         if not ill_conditioned(k):
             diff = (sd[k].cpu() - v).abs()
             assert float((diff > 2e-5 + 1e-4 * v.abs()).float().mean()) < 2e-3 and float(diff.max()) < 5e-4, k
+
+
+@pytest.mark.parametrize('case', ['deepconnpp_e20', 'transnet_e16', 'transnetpp_e16'])
+def test_native_engines_eval_incl_negatives_shaped_batches(case):
+    """predict() of the DeepCoNN++ / TransNet engines on the golden batches and on the negatives-shaped
+    [B, 6, ...] batch of eval.py:64-92 (the engine folds the extra dim into the batch)."""
+    from reviews4rec_amd import main as M
+    g = Golden(case)
+    model, hp = build_model(g)
+    model.eval()
+    eng = M.make_engine(dict(hp, engine='native'), model)
+    tn = case.startswith('transnet')
+    for k in (0, 1):
+        data, y = g.batch(k, DEV)
+        pred, se = eng.predict(data, y)
+        torch.testing.assert_close(pred.cpu(), g.arr('eval%d/src' % k if tn else 'eval%d' % k), rtol=1e-5, atol=1e-5)
+        if tn:                                               # target prediction and transform loss: the aux outputs
+            aux = eng.aux(data).cpu()
+            torch.testing.assert_close(aux[:, 0], g.arr('eval%d/tgt' % k).reshape(-1), rtol=1e-5, atol=1e-5)
+            torch.testing.assert_close(aux[:, 2].mean(), g.arr('eval%d/transform' % k).reshape(()), rtol=1e-5, atol=1e-5)
+    pred, _ = eng.predict(g.neg_batch(DEV))
+    ref = g.arr('neg_eval')
+    assert tuple(pred.shape) == tuple(ref.shape) == (3, 6)
+    torch.testing.assert_close(pred.cpu(), ref, rtol=1e-5, atol=1e-5)
