@@ -960,3 +960,32 @@ def test_native_engines_eval_incl_negatives_shaped_batches(case):
     ref = g.arr('neg_eval')
     assert tuple(pred.shape) == tuple(ref.shape) == (3, 6)
     torch.testing.assert_close(pred.cpu(), ref, rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize('B', [700, 5000])
+def test_mf_engine_bias_only_large_batch(B):
+    """bias_only (no tables: D = 0) at batches of hundreds / thousands with a popular item and user:
+    the entry waves' bias-only form against the CPU oracle, two steps."""
+    import reviews4rec_amd
+    from reviews4rec_amd.engine import MFEngine
+    U, I = 3000, 900
+    hp = dict(model_type='bias_only', latent_size=8, dropout=0.0, total_users=U, total_items=I, lr=0.002, weight_decay=1e-6)
+    P = oracle.init_params(hp, seed=13)
+    model = reviews4rec_amd.get_model_class('bias_only')(hp)
+    model.load_state_dict(P)
+    model = model.to(DEV).train()
+    eng = MFEngine(model, lr=hp['lr'], weight_decay=hp['weight_decay'])
+    state = oracle.AdamState()
+    rng = torch.Generator().manual_seed(19)
+    for step in range(2):
+        uid = torch.randint(0, U, (B,), generator=rng)
+        iid = torch.randint(0, I, (B,), generator=rng)
+        iid[torch.rand(B, generator=rng) < 0.2] = 5
+        uid[torch.rand(B, generator=rng) < 0.1] = 77
+        y = torch.randint(1, 6, (B,), generator=rng).float()
+        se = eng.train_step([None] * 5 + [uid.to(DEV), iid.to(DEV)], y.to(DEV)).cpu().clone()
+        sse, _ = oracle.train_step(P, [None] * 5 + [uid, iid], y, hp, state)
+        torch.testing.assert_close(se.sum(), torch.tensor(sse), rtol=1e-4, atol=1e-3)
+    sd = model.state_dict()
+    for k, v in P.items():
+        torch.testing.assert_close(sd[k].cpu(), v, rtol=1e-5, atol=5e-6, msg=lambda m: k + ': ' + m)
