@@ -35,16 +35,25 @@ PEAK_HBM_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E spec peak (6.3 TB
 WORKLOAD = 'cfg3_deepconn_electronics_e300'
 
 
+PMC_SUMMARIES = {WORKLOAD: 'r01l_bench_pmc_summary.json',
+                 'cfg2_mfdot_electronics': 'r01k_bench_cfg2_pmc_summary.json',
+                 'cfg5_transnetpp_synthetic': 'r01m_bench_cfg5_pmc_summary.json'}
+
+
 def measured_traffic(kernel, args):
     """HBM-side bytes per launch of `kernel` from the committed rocprofv3 --pmc summary
-    (profiles/, separate counter passes of this same command) -- only for the configuration
-    that summary was collected on; None otherwise."""
-    path = os.path.join(ROOT, 'profiles', 'r01l_bench_pmc_summary.json')
-    if not (os.path.exists(path) and args.workload == WORKLOAD and args.batch_per_gpu == 128
-            and args.engine == 'native' and args.conv_algo in ('auto', 'project')):
+    (profiles/, separate counter passes of this same command) -- only for the configurations
+    those summaries were collected on; None otherwise."""
+    name = PMC_SUMMARIES.get(args.workload)
+    path = os.path.join(ROOT, 'profiles', name) if name else None
+    if not (path and os.path.exists(path) and args.batch_per_gpu == 128 and args.engine == 'native'
+            and args.conv_algo in ('auto', 'project') and not args.model_type and not args.embed):
         return None
-    k = json.load(open(path))['kernels'].get('r4r::' + kernel, {})
-    return k.get('hbm_bytes_per_launch')
+    kernels = json.load(open(path))['kernels']
+    for k, v in kernels.items():
+        if k.startswith('r4r::' + kernel):                   # (template instantiations carry a <..> suffix)
+            return v.get('hbm_bytes_per_launch')
+    return None
 
 
 def parse():
@@ -387,7 +396,8 @@ def main():
                 ach_b = nparam * 24 / avg_s / 1e9
                 result['roofline'] = {'kernel': 'mf_adam_kernel', 'bound': 'hbm', 'achieved': round(ach_b, 1),
                                       'peak': PEAK_HBM_GBS, 'unit': 'GB/s', 'frac': round(ach_b / PEAK_HBM_GBS, 4),
-                                      'traffic': None, 'launches': timed['adam_multi_kernel'][1],
+                                      'traffic': measured_traffic('mf_adam_kernel', args),
+                                      'launches': timed['adam_multi_kernel'][1],
                                       'avg_launch_ms': round(1000 * avg_s, 4), 'bytes_per_launch': int(nparam * 24),
                                       'parameters': int(nparam)}
         elif 'textcnn_fwd_kernel' in timed and hp.get('vocab'):
@@ -408,7 +418,8 @@ def main():
             ach_b = nparam * per / avg_s / 1e9
             result['roofline'] = {'kernel': 'mf_adam_kernel' if engine is not None else 'adam_multi_kernel',
                                   'bound': 'hbm', 'achieved': round(ach_b, 1), 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
-                                  'frac': round(ach_b / PEAK_HBM_GBS, 4), 'traffic': None,
+                                  'frac': round(ach_b / PEAK_HBM_GBS, 4),
+                                  'traffic': measured_traffic('mf_adam_kernel', args) if engine is not None else None,
                                   'launches': timed['adam_multi_kernel'][1], 'avg_launch_ms': round(1000 * avg_s, 4),
                                   'bytes_per_launch': int(nparam * per), 'parameters': int(nparam)}
         if world == 1 and not args.no_cpu_baseline:

@@ -5,7 +5,7 @@ cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/prof_$1
 mkdir -p $OUT
-CMD="python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline"
+CMD="python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline $BENCH_ARGS"   # BENCH_ARGS: e.g. "--workload cfg5_transnetpp_synthetic"
 rocprofv3 --kernel-trace --stats -d $OUT/kt -- $CMD > $OUT/bench.log 2>&1
 tail -1 $OUT/bench.log | cut -c1-160
 DB=$(find $OUT/kt -name "*.db" | head -1)
@@ -14,6 +14,6 @@ rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_AC
 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_INSTS_VALU --output-format csv -d $OUT/p2 -- $CMD > $OUT/p2.log 2>&1
 rocprofv3 --pmc FETCH_SIZE TCC_HIT_sum --output-format csv -d $OUT/p3 -- $CMD > $OUT/p3.log 2>&1
 rocprofv3 --pmc WRITE_SIZE TCC_MISS_sum TCC_REQ_sum --output-format csv -d $OUT/p4 -- $CMD > $OUT/p4.log 2>&1
-python3 $R/tools/pmc_summary.py $OUT $OUT/pmc_summary.json "bench.py --steps 20 --warmup 5, cfg3 B=128, native engine"
+python3 $R/tools/pmc_summary.py $OUT $OUT/pmc_summary.json "bench.py --steps 20 --warmup 5 $BENCH_ARGS, native engine"
 cat $OUT/kernel_stats.csv
 rm -rf $OUT/p1 $OUT/p2 $OUT/p3 $OUT/p4 $OUT/kt
