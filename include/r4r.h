@@ -453,6 +453,18 @@ int r4r_transnet_step(const float *table, int64_t V,
                       float lr, double beta1, double beta2, float eps, float weight_decay, int64_t adam_step,
                       void *stream);
 
+/* Data parallel: call r4r_transnet_step with flat_m == NULL (gradients only: flat_g and, TransNet++,
+ * the compact ID-vector rows at r4r_transnet_ws_offset 1 / 2), exchange -- all-reduce flat_g and apply
+ * r4r_adam_multi; all_gather the ranks' (uid, iid, gradient rows), ids -1 padding ragged shards --
+ * then update the ID-vector tables from ALL ranks' rows (same `ws` and shape arguments as the step:
+ * the row tags live there).  B_all <= 16384. */
+int r4r_transnet_rows_apply(const int64_t *uid_all, const int64_t *iid_all, const float *gu_all, const float *gi_all,
+                            int64_t B_all, const uint64_t *rows_p, const uint64_t *rows_m, const uint64_t *rows_v,
+                            int64_t n_users, int64_t n_items, void *ws, size_t ws_bytes,
+                            int64_t B, int T, int E, int L, int64_t V,
+                            float lr, double beta1, double beta2, float eps, float weight_decay, int64_t adam_step,
+                            void *stream);
+
 /* proj_gather_max_kernel (gather-add-max over positions) */
 #define R4R_TIMING_SLOTS 8
 int r4r_timing_enable(int slot_mask);   /* bit i instruments slot i; 0 switches timing off */

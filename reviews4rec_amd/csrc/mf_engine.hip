@@ -199,6 +199,7 @@ __device__ __forceinline__ void mf_entry(const MfSweep &w, const int *sid, int *
         c_end = (int)(last_k / 64u) + 1;
     } else {
         row = sid[k];
+        if (row < 0) return;                                // a padded entry (gathered ragged shards)
         for (int c = 0; c <= kc; ++c) {                     // chunks up to k's own
             const int j = c * 64 + lane;
             const unsigned long long mask = __ballot(j < w.B && sid[j] == row);

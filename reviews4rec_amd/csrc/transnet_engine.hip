@@ -381,8 +381,11 @@ extern "C" int r4r_transnet_step(const float *table, int64_t V,
     R4R_REQUIRE(L > 0 && L <= NR_MAX_L, "transnet_step: latent_size %d outside 1..%d", L, NR_MAX_L);
     R4R_REQUIRE(E > 0 && E % 4 == 0, "transnet_step: word_embed_size %d must be a positive multiple of 4", E);
     const bool train_step = flat_g != nullptr;
-    R4R_REQUIRE(!train_step || (y && se && flat_m && flat_v && adam_step >= 1 && (!plus || (rows_m && rows_v))),
-                "transnet_step: a training step needs ratings, se, gradient / moment buffers and adam_step >= 1");
+    // flat_m == NULL on a training step: gradients only (flat_g, the compact ID-vector rows) -- the data-parallel
+    // form, where the exchange sits between gradient and update (r4r_adam_multi + r4r_transnet_rows_apply)
+    const bool apply = flat_m != nullptr;
+    R4R_REQUIRE(!train_step || (y && se && adam_step >= 1 && (!apply || (flat_v && (!plus || (rows_m && rows_v))))),
+                "transnet_step: a training step needs ratings, se, gradient buffers and adam_step >= 1 (+ moments to update)");
     R4R_REQUIRE(!y || se, "transnet_step: se buffer required when y is given");
     R4R_REQUIRE(!next_user_idx == !next_item_idx && !next_user_idx == !next_this_idx,
                 "transnet_step: the three next-batch index arrays go together");
@@ -447,7 +450,7 @@ extern "C" int r4r_transnet_step(const float *table, int64_t V,
         if (plus) {
             rp[t] = reinterpret_cast<float *>(rows_p[t]);
             R4R_REQUIRE(rp[t], "transnet_step: null ID-vector table");
-            if (train_step) {
+            if (train_step && apply) {
                 rm[t] = reinterpret_cast<float *>(rows_m[t]); rv[t] = reinterpret_cast<float *>(rows_v[t]);
                 R4R_REQUIRE(rm[t] && rv[t], "transnet_step: ID-vector table %d: null moment pointer", t);
             }
@@ -500,12 +503,59 @@ extern "C" int r4r_transnet_step(const float *table, int64_t V,
     const int red_blocks = (NF * 3 * E + NF + NRED_THREADS - 1) / NRED_THREADS;
     const int comp_blocks = prefetch ? (int)cdiv((V + 3) / 4, NRED_THREADS) : 0;
     DenseAdam opt;
-    opt.on = 1; opt.p = flat_p; opt.m = flat_m; opt.v = flat_v; opt.g = flat_g;
+    opt.on = apply ? 1 : 0; opt.p = flat_p; opt.m = flat_m; opt.v = flat_v; opt.g = flat_g;
     opt.lo0 = lo; opt.hi0 = hi; opt.lo1 = hi; opt.hi1 = hi;       // every head parameter in one range (tower 0's slice)
     opt.s = adam_make_scalars(lr, beta1, beta2, eps, weight_decay, adam_step, nullptr);
-    narre_reduce_kernel<<<dim3(red_blocks + comp_blocks + (int)cdiv(hi - lo, NRED_THREADS), 3), NRED_THREADS, 0, st>>>(
+    const int opt_blocks = apply ? (int)cdiv(hi - lo, NRED_THREADS) : 0;
+    narre_reduce_kernel<<<dim3(red_blocks + comp_blocks + opt_blocks, 3), NRED_THREADS, 0, st>>>(
         wa, red_blocks, comp_blocks, nx, opt);
-    if (!plus) return check_launch("transnet_step");
+    if (!plus || !apply) return check_launch("transnet_step");
     return mf_table_rows_launch(rp[0], rm[0], rv[0], rp[1], rm[1], rv[1], n_users, n_items, TN_ID, uid, iid, w.grow[0], w.grow[1],
                                 w.tag[0], w.tag[1], w.ctag[0], w.ctag[1], B, (int)adam_step, opt.s, st);
+}
+
+// Data parallel, TransNet++: the ID-vector update from ALL ranks' compact rows (gathered by the
+// caller in rank order; ids -1 pad ragged shards), after a gradients-only r4r_transnet_step
+// (flat_m == NULL).  `ws` and the shape arguments are the step's: the row / chunk tags live there.
+namespace r4r {
+__global__ void tn_tag_rows_kernel(const int64_t *uid, const int64_t *iid, int64_t n, int *tag_u, int *tag_i, int *ctag_u,
+                                   int *ctag_i, int now) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n) return;
+    const int64_t u = uid[e], i = iid[e];
+    if (u < 0) return;
+    tag_u[u] = now; tag_i[i] = now;
+    ctag_u[u * TN_ID / MF_CHUNK] = now; ctag_u[(u * TN_ID + TN_ID - 1) / MF_CHUNK] = now;
+    ctag_i[i * TN_ID / MF_CHUNK] = now; ctag_i[(i * TN_ID + TN_ID - 1) / MF_CHUNK] = now;
+}
+}  // namespace r4r
+
+extern "C" int r4r_transnet_rows_apply(const int64_t *uid_all, const int64_t *iid_all, const float *gu_all,
+                                       const float *gi_all, int64_t B_all,
+                                       const uint64_t *rows_p, const uint64_t *rows_m, const uint64_t *rows_v,
+                                       int64_t n_users, int64_t n_items, void *ws, size_t ws_bytes,
+                                       int64_t B, int T, int E, int L, int64_t V,
+                                       float lr, double beta1, double beta2, float eps, float weight_decay, int64_t adam_step,
+                                       void *stream) {
+    R4R_REQUIRE(uid_all && iid_all && gu_all && gi_all && rows_p && rows_m && rows_v && ws, "transnet_rows_apply: null pointer");
+    R4R_REQUIRE(B_all >= 0 && B_all <= 16384, "transnet_rows_apply: %lld gathered ratings outside 0..16384", (long long)B_all);
+    R4R_REQUIRE(adam_step >= 1 && adam_step < (1ll << 31), "transnet_rows_apply: bad adam_step");
+    if (ws_bytes < r4r_transnet_ws_bytes(B, T, E, L, 1, V, n_users, n_items)) {
+        set_error("transnet_rows_apply: workspace %zu < %zu bytes", ws_bytes, r4r_transnet_ws_bytes(B, T, E, L, 1, V, n_users, n_items));
+        return R4R_ERR_WORKSPACE;
+    }
+    if (B_all == 0) return R4R_OK;
+    hipStream_t st = as_stream(stream);
+    const TnWs w = tn_carve(ws, B, T, E, L, 1, V, n_users, n_items);
+    float *rp[2], *rm[2], *rv[2];
+    for (int t = 0; t < 2; ++t) {
+        rp[t] = reinterpret_cast<float *>(rows_p[t]); rm[t] = reinterpret_cast<float *>(rows_m[t]);
+        rv[t] = reinterpret_cast<float *>(rows_v[t]);
+        R4R_REQUIRE(rp[t] && rm[t] && rv[t], "transnet_rows_apply: ID-vector table %d: null pointer", t);
+    }
+    tn_tag_rows_kernel<<<(unsigned)cdiv(B_all, 256), 256, 0, st>>>(uid_all, iid_all, B_all, w.tag[0], w.tag[1], w.ctag[0],
+                                                                 w.ctag[1], (int)adam_step);
+    const AdamScalars sc = adam_make_scalars(lr, beta1, beta2, eps, weight_decay, adam_step, nullptr);
+    return mf_table_rows_launch(rp[0], rm[0], rv[0], rp[1], rm[1], rv[1], n_users, n_items, TN_ID, uid_all, iid_all, gu_all,
+                                gi_all, w.tag[0], w.tag[1], w.ctag[0], w.ctag[1], B_all, (int)adam_step, sc, st);
 }

@@ -119,7 +119,10 @@ def train(model, criterion, optimizer, reader, hyper_params, engine=None, dp=Non
 
     sse = float(engine.sse[0].item()) if engine is not None else (float(device_sum) if device_sum is not None else 0.0)
     if engine is not None and tn:                            # TransNetEngine: sums of the per-batch means
-        metrics['MSE_target'], metrics['MSE_transform'] = float(engine.sse[1].item()), float(engine.sse[2].item())
+        aux = engine.sse[1:3].clone()
+        if dp is not None and dp.on:                         # (each rank holds its shard's share of every batch mean)
+            dp.sum_scalar(aux)
+        metrics['MSE_target'], metrics['MSE_transform'] = float(aux[0].item()), float(aux[1].item())
     if graph is not None and graph.step is not None and engine is None:
         sse += float(graph.step.sse.item())
         graph.step.sse.zero_()
@@ -165,11 +168,12 @@ def make_engine(hyper_params, model, dp=None, rank=0):
         return DeepCoNNPPEngine(model, lr=hyper_params['lr'], weight_decay=hyper_params['weight_decay'],
                                 seed=hyper_params.get('seed', 0x5EED5EED), rank=rank)
     if _is_transnet(hyper_params):
-        if (dp is not None and dp.on) or int(hyper_params.get('batch_size', 128)) > 16384:
+        world = dp.world if (dp is not None and dp.on) else 1
+        if int(hyper_params.get('batch_size', 128)) * world > 16384:
             return None
         from .engine import TransNetEngine
         return TransNetEngine(model, lr=hyper_params['lr'], weight_decay=hyper_params['weight_decay'],
-                              seed=hyper_params.get('seed', 0x5EED5EED), rank=rank)
+                              seed=hyper_params.get('seed', 0x5EED5EED), rank=rank, dp=dp)
     if hyper_params['model_type'] != 'deepconn':
         return None
     from .engine import DeepCoNNEngine

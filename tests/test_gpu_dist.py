@@ -238,3 +238,54 @@ def test_dp2_native_steps_with_an_empty_shard(tmp_path):
         for k, v in model.state_dict().items():
             assert torch.equal(r0[case][k], r1[case][k]), (case, k)
             torch.testing.assert_close(r0[case][k], v.cpu(), rtol=1e-6, atol=1e-7, msg=lambda m: case + ' ' + k + ': ' + m)
+
+
+def _transnet_worker(rank, world, port, case, out_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, TESTS)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank), R4R_DIST_BACKEND='gloo')
+    from helpers import Golden
+    from test_gpu_models import build_model
+    from reviews4rec_amd import dist as r4dist, main as M
+    from reviews4rec_amd.engine import TransNetEngine
+    r4dist.init_from_env()
+    g = Golden(case)
+    model, hp = build_model(g)
+    model.train()
+    dp = r4dist.DataParallel(model)
+    dp.broadcast_parameters()
+    eng = M.make_engine(dict(hp, engine='auto', batch_size=64), model, dp=dp, rank=rank)
+    assert isinstance(eng, TransNetEngine) and eng.dp is not None
+    ses, aux = [], []
+    for step in range(3):
+        data, y = g.batch(step % 2, 'cuda')
+        sd, sy = r4dist.shard_batch(data, y, rank, world)
+        before = eng.sse.clone()
+        ses.append(eng.train_step(sd, sy, n_global=int(y.shape[0]) if step != 1 else None).cpu().clone())
+        aux.append((eng.sse - before)[1:].cpu().clone())
+    torch.save({'w': {k: v.detach().cpu() for k, v in model.state_dict().items()}, 'se': ses, 'aux': aux},
+               os.path.join(out_dir, 't%d.pt' % rank))
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.parametrize('case', ['transnet_e16', 'transnetpp_e16'])
+def test_dp2_native_transnet_step_follows_the_reference_trajectory(tmp_path, case):
+    """TransNet(++) under data parallelism on the native step: gradients only per rank, one all-reduce
+    of the flat dense gradient + the flat Adam, and (TransNet++) the ranks' compact ID-vector rows
+    gathered into the same tagged sweep: 2 ranks x ragged shards == the reference's three
+    single-process three-optimiser steps; replicas bit-identical."""
+    sys.path.insert(0, TESTS)
+    from helpers import Golden
+    port = _free_port()
+    mp.spawn(_transnet_worker, args=(2, port, case, str(tmp_path)), nprocs=2, join=True)
+    g = Golden(case)
+    r0 = torch.load(os.path.join(tmp_path, 't0.pt'))
+    r1 = torch.load(os.path.join(tmp_path, 't1.pt'))
+    for step in range(3):
+        se = torch.cat([r0['se'][step], r1['se'][step]])
+        torch.testing.assert_close(se, g.arr('tn_se%d' % step), rtol=1e-4, atol=1e-5)
+        torch.testing.assert_close(r0['aux'][step] + r1['aux'][step], g.arr('tn_aux%d' % step), rtol=1e-4, atol=1e-5)
+    for k, v in g.params('tn_w3').items():
+        assert torch.equal(r0['w'][k], r1['w'][k]), k               # replicas stay bit-identical
+        torch.testing.assert_close(r0['w'][k], v, rtol=1e-5, atol=5e-6, msg=lambda m: k + ': ' + m)
