@@ -199,9 +199,9 @@ def main():
         from reviews4rec_amd.engine import NarreEngine
         engine = NarreEngine(model, lr=hp['lr'], weight_decay=hp['weight_decay'], seed=4321, rank=rank,
                              conv_algo={'auto': 0, 'direct': 1, 'project': 2}[args.conv_algo])
-    if args.engine == 'native' and hp['model_type'] == 'deepconn++' and world == 1:
+    if args.engine == 'native' and hp['model_type'] == 'deepconn++' and B * world <= 16384:
         from reviews4rec_amd.engine import DeepCoNNPPEngine
-        engine = DeepCoNNPPEngine(model, lr=hp['lr'], weight_decay=hp['weight_decay'], seed=4321, rank=rank,
+        engine = DeepCoNNPPEngine(model, lr=hp['lr'], weight_decay=hp['weight_decay'], seed=4321, rank=rank, dp=dp,
                                   conv_algo={'auto': 0, 'direct': 1, 'project': 2}[args.conv_algo])
     if args.engine == 'native' and is_tn and B * world <= 16384:
         from reviews4rec_amd.engine import TransNetEngine

@@ -413,6 +413,17 @@ int r4r_deepconnpp_step(const float *table, int64_t V, const int64_t *user_idx, 
                         float lr, double beta1, double beta2, float eps, float weight_decay, int64_t adam_step,
                         void *stream);
 
+/* Data parallel: r4r_deepconnpp_step with flat_m == NULL computes gradients only (flat_g; d loss / d pred
+ * at r4r_deepconnpp_ws_offset 5); after the exchange -- all-reduce flat_g + r4r_adam_multi, all_gather of
+ * the ranks' (uid, iid, d loss / d pred), ids -1 padding ragged shards -- this updates the two ID bias
+ * vectors from ALL ranks' ratings (same `ws` and shape arguments as the step).  B_all <= 16384. */
+int r4r_deepconnpp_rows_apply(const int64_t *uid_all, const int64_t *iid_all, const float *g_all, int64_t B_all,
+                              const uint64_t *rows_p, const uint64_t *rows_m, const uint64_t *rows_v,
+                              int64_t n_users, int64_t n_items, void *ws, size_t ws_bytes,
+                              int64_t B, int T, int E, int L, int64_t V,
+                              float lr, double beta1, double beta2, float eps, float weight_decay, int64_t adam_step,
+                              void *stream);
+
 /* ---- fused native step for TransNet / TransNet++ (TransNet.py:9-122; the three-optimiser step of
  * main.py:26-53 with utils.init_transnet_optim, utils.py:70-92).  Three TextCNN towers (user
  * documents, item documents, the review being rated: user_idx / item_idx / this_idx [B, T]) and

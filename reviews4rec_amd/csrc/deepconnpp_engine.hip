@@ -269,8 +269,11 @@ extern "C" int r4r_deepconnpp_step(const float *table, int64_t V, const int64_t 
     R4R_REQUIRE(L > 0 && L <= NR_MAX_L, "deepconnpp_step: latent_size %d outside 1..%d", L, NR_MAX_L);
     R4R_REQUIRE(E > 0 && E % 4 == 0, "deepconnpp_step: word_embed_size %d must be a positive multiple of 4", E);
     const bool train_step = flat_g != nullptr;
-    R4R_REQUIRE(!train_step || (y && se && flat_m && flat_v && rows_m && rows_v && adam_step >= 1),
-                "deepconnpp_step: a training step needs ratings, se, gradient / moment buffers and adam_step >= 1");
+    // flat_m == NULL on a training step: gradients only (flat_g, d loss / d pred in the workspace) -- the
+    // data-parallel form (r4r_adam_multi + r4r_deepconnpp_rows_apply after the exchange)
+    const bool apply = flat_m != nullptr;
+    R4R_REQUIRE(!train_step || (y && se && adam_step >= 1 && (!apply || (flat_v && rows_m && rows_v))),
+                "deepconnpp_step: a training step needs ratings, se, gradient buffers and adam_step >= 1 (+ moments to update)");
     R4R_REQUIRE(!y || se, "deepconnpp_step: se buffer required when y is given");
     R4R_REQUIRE(!next_user_idx == !next_item_idx, "deepconnpp_step: next_user_idx and next_item_idx go together");
     R4R_REQUIRE(!next_user_idx || train_step, "deepconnpp_step: the next batch's tokens ride on the backward launches");
@@ -375,12 +378,13 @@ extern "C" int r4r_deepconnpp_step(const float *table, int64_t V, const int64_t 
     const int red_blocks = (NF * 3 * E + NF + NRED_THREADS - 1) / NRED_THREADS;
     const int comp_blocks = prefetch ? (int)cdiv((V + 3) / 4, NRED_THREADS) : 0;
     DenseAdam opt;
-    opt.on = 1; opt.p = flat_p; opt.m = flat_m; opt.v = flat_v; opt.g = flat_g;
+    opt.on = apply ? 1 : 0; opt.p = flat_p; opt.m = flat_m; opt.v = flat_v; opt.g = flat_g;
     opt.lo0 = lo0; opt.hi0 = hi0; opt.lo1 = lo1; opt.hi1 = hi1;
     opt.s = adam_make_scalars(lr, beta1, beta2, eps, weight_decay, adam_step, nullptr);
     const int64_t longest = hi0 - lo0 > hi1 - lo1 ? hi0 - lo0 : hi1 - lo1;
-    narre_reduce_kernel<<<dim3(red_blocks + comp_blocks + (int)cdiv(longest, NRED_THREADS), 2), NRED_THREADS, 0, st>>>(
-        wa, red_blocks, comp_blocks, nx, opt);
+    narre_reduce_kernel<<<dim3(red_blocks + comp_blocks + (apply ? (int)cdiv(longest, NRED_THREADS) : 0), 2), NRED_THREADS, 0,
+                          st>>>(wa, red_blocks, comp_blocks, nx, opt);
+    if (!apply) return check_launch("deepconnpp_step");
 
     float *rp[2], *rm[2], *rv[2];
     for (int k = 0; k < 2; ++k) {
@@ -390,4 +394,44 @@ extern "C" int r4r_deepconnpp_step(const float *table, int64_t V, const int64_t 
     }
     return mf_bias_rows_launch(rp[0], rm[0], rv[0], rp[1], rm[1], rv[1], n_users, n_items, uid, iid, w.g, w.tag[0], w.tag[1], B,
                                (int)adam_step, opt.s, st);
+}
+
+// Data parallel: the ID bias update from ALL ranks' (uid, iid, d loss / d pred), gathered by the
+// caller in rank order (ids -1 pad ragged shards), after a gradients-only r4r_deepconnpp_step
+// (flat_m == NULL).  `ws` and the shape arguments are the step's: the row tags live there.
+namespace r4r {
+__global__ void dcpp_tag_rows_kernel(const int64_t *uid, const int64_t *iid, int64_t n, int *tag_u, int *tag_i, int now) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n || uid[e] < 0) return;
+    tag_u[uid[e]] = now;
+    tag_i[iid[e]] = now;
+}
+}  // namespace r4r
+
+extern "C" int r4r_deepconnpp_rows_apply(const int64_t *uid_all, const int64_t *iid_all, const float *g_all, int64_t B_all,
+                                         const uint64_t *rows_p, const uint64_t *rows_m, const uint64_t *rows_v,
+                                         int64_t n_users, int64_t n_items, void *ws, size_t ws_bytes,
+                                         int64_t B, int T, int E, int L, int64_t V,
+                                         float lr, double beta1, double beta2, float eps, float weight_decay,
+                                         int64_t adam_step, void *stream) {
+    R4R_REQUIRE(uid_all && iid_all && g_all && rows_p && rows_m && rows_v && ws, "deepconnpp_rows_apply: null pointer");
+    R4R_REQUIRE(B_all >= 0 && B_all <= 16384, "deepconnpp_rows_apply: %lld gathered ratings outside 0..16384", (long long)B_all);
+    R4R_REQUIRE(adam_step >= 1 && adam_step < (1ll << 31), "deepconnpp_rows_apply: bad adam_step");
+    if (ws_bytes < r4r_deepconnpp_ws_bytes(B, T, E, L, V, n_users, n_items)) {
+        set_error("deepconnpp_rows_apply: workspace %zu < %zu bytes", ws_bytes, r4r_deepconnpp_ws_bytes(B, T, E, L, V, n_users, n_items));
+        return R4R_ERR_WORKSPACE;
+    }
+    if (B_all == 0) return R4R_OK;
+    hipStream_t st = as_stream(stream);
+    const DcppWs w = dcpp_carve(ws, B, T, E, L, V, n_users, n_items);
+    float *rp[2], *rm[2], *rv[2];
+    for (int k = 0; k < 2; ++k) {
+        rp[k] = reinterpret_cast<float *>(rows_p[k]); rm[k] = reinterpret_cast<float *>(rows_m[k]);
+        rv[k] = reinterpret_cast<float *>(rows_v[k]);
+        R4R_REQUIRE(rp[k] && rm[k] && rv[k], "deepconnpp_rows_apply: bias vector %d: null pointer", k);
+    }
+    dcpp_tag_rows_kernel<<<(unsigned)cdiv(B_all, 256), 256, 0, st>>>(uid_all, iid_all, B_all, w.tag[0], w.tag[1], (int)adam_step);
+    const AdamScalars sc = adam_make_scalars(lr, beta1, beta2, eps, weight_decay, adam_step, nullptr);
+    return mf_bias_rows_launch(rp[0], rm[0], rv[0], rp[1], rm[1], rv[1], n_users, n_items, uid_all, iid_all, g_all, w.tag[0],
+                               w.tag[1], B_all, (int)adam_step, sc, st);
 }

@@ -673,8 +673,65 @@ class NarreEngine:
             self.offset += n * self._draws(R)
         return pred, se
 
+    # ---- data parallel: gradients only on this rank (the C step with flat_m = NULL), C1 -- one
+    # all-reduce of the flat dense gradient + the flat Adam -- and C2: the ranks' compact ID rows gathered
+    # (ids -1 pad ragged shards) into the same tagged sweep on every rank.  Subclasses with ID rows give
+    # _dp_payload / _dp_apply.
+    dp = None
+
+    def _dp_payload(self, f, n, R, T, ids, vals):
+        raise NotImplementedError
+
+    def _dp_apply(self, uid_all, iid_all, all_vals, B_all, ws, nb, T):
+        raise NotImplementedError
+
+    DP_COLS = 0                  # floats per rating in the gathered payload (0: no ID rows to exchange)
+
+    @torch.no_grad()
+    def _train_step_dp(self, data, y, n_global, next_data):
+        lib, dist = _lib.lib(), torch.distributed
+        n, world = data[5].numel(), self.dp.world
+        B_pad = int(self.hp.get('batch_size', 0))
+        if n_global is None or n > B_pad:
+            sizes = torch.tensor([n], dtype=torch.int64, device=self.dev)
+            all_sizes = torch.empty(world, dtype=torch.int64, device=self.dev)
+            dist.all_gather_into_tensor(all_sizes, sizes, group=self.dp.group)
+            B_pad, n_global = int(all_sizes.max().item()), int(all_sizes.sum().item())
+        y = y.reshape(-1).contiguous()
+        self.step_count += 1
+        se = torch.empty(0, dtype=torch.float32, device=self.dev)
+        if n > 0:
+            _, se = self._launch(data, y, self.model.training, 1.0 / float(n_global), self.step_count, next_data)
+        else:
+            self.flat_g.zero_()                              # an empty shard contributes a zero gradient
+        self.dp.allreduce_flat(self.flat_g)
+        one = ctypes.c_uint64 * 1
+        _lib.check(lib.r4r_adam_multi(1, one(self.flat_p.data_ptr()), one(self.flat_g.data_ptr()),
+                                      one(self.flat_m.data_ptr()), one(self.flat_v.data_ptr()),
+                                      (ctypes.c_int64 * 1)(self.total), self.lr, self.betas[0], self.betas[1], self.eps,
+                                      self.wd, int(self.step_count), None, _lib.current_stream()), 'r4r_adam_multi')
+        if not self.DP_COLS:
+            return se
+        ids = torch.full((B_pad, 2), -1, dtype=torch.int64, device=self.dev)
+        vals = torch.zeros((B_pad, self.DP_COLS), dtype=torch.float32, device=self.dev)
+        T = int(self.hp['input_length'])
+        if n > 0:
+            f, _, R, T = self._fields(data)
+            self._dp_payload(f, n, R, T, ids, vals)
+        all_ids = torch.empty((world, B_pad, 2), dtype=torch.int64, device=self.dev)
+        all_vals = torch.empty((world, B_pad, self.DP_COLS), dtype=torch.float32, device=self.dev)
+        dist.all_gather_into_tensor(all_ids.view(-1), ids.view(-1), group=self.dp.group)
+        dist.all_gather_into_tensor(all_vals.view(-1), vals.view(-1), group=self.dp.group)
+        uid_all, iid_all = all_ids[:, :, 0].reshape(-1).contiguous(), all_ids[:, :, 1].reshape(-1).contiguous()
+        nb = max(n, 1)                                       # (the workspace of this rank's own shape holds the row tags)
+        self._dp_apply(uid_all, iid_all, all_vals.view(world * B_pad, self.DP_COLS), world * B_pad,
+                       self._workspace(nb, 1, T), nb, T)
+        return se
+
     @torch.no_grad()
     def train_step(self, data, y, n_global=None, next_data=None):
+        if self.dp is not None:
+            return self._train_step_dp(data, y, n_global, next_data)
         n = data[5].numel()
         y = y.reshape(-1).contiguous()
         if n == 0:                                           # nothing to train on: no step, no state change
@@ -758,6 +815,24 @@ class DeepCoNNPPEngine(NarreEngine):
     ROW_NAMES = ['user_bias', 'item_bias']
     MODEL_TYPE = 'deepconn++'
     C = 'deepconnpp'
+    DP_COLS = 1
+
+    def __init__(self, model, dp=None, **kw):
+        self.dp = dp if (dp is not None and dp.on) else None
+        super().__init__(model, **kw)
+
+    def _dp_payload(self, f, n, R, T, ids, vals):
+        off = self._ws_offset(n, R, T, 5)
+        ids[:n, 0], ids[:n, 1] = f[2], f[3]
+        vals[:n, 0] = self._workspace(n, R, T)[off:off + n * 4].view(torch.float32)
+
+    def _dp_apply(self, uid_all, iid_all, all_vals, B_all, ws, nb, T):
+        g_all = all_vals[:, 0].contiguous()
+        p2 = lambda ts: (ctypes.c_uint64 * 2)(*[t.data_ptr() for t in ts])   # noqa: E731
+        _lib.check(_lib.lib().r4r_deepconnpp_rows_apply(
+            ptr(uid_all), ptr(iid_all), ptr(g_all), B_all, p2(self.rows), p2(self.rows_m), p2(self.rows_v),
+            self.n_users, self.n_items, ptr(ws), ws.numel(), nb, T, self.E, self.L, self.V, self.lr, self.betas[0],
+            self.betas[1], self.eps, self.wd, int(self.step_count), _lib.current_stream()), 'r4r_deepconnpp_rows_apply')
 
     def _fields(self, data):
         n = data[5].numel()
@@ -781,9 +856,11 @@ class DeepCoNNPPEngine(NarreEngine):
         p2 = lambda ts: (ctypes.c_uint64 * 2)(*[t.data_ptr() for t in ts])   # noqa: E731
         return _lib.lib().r4r_deepconnpp_step(
             ptr(self.table), self.V, ptr(f[0]), ptr(f[1]), ptr(f[2]), ptr(f[3]), ptr(y),
-            ptr(self.flat_p), ptr(self.flat_g) if adam_step else None, ptr(self.flat_m) if adam_step else None,
-            ptr(self.flat_v) if adam_step else None, p2(self.rows),
-            p2(self.rows_m) if adam_step else None, p2(self.rows_v) if adam_step else None,
+            ptr(self.flat_p), ptr(self.flat_g) if adam_step else None,
+            ptr(self.flat_m) if (adam_step and self.dp is None) else None,     # data parallel: gradients only
+            ptr(self.flat_v) if (adam_step and self.dp is None) else None, p2(self.rows),
+            p2(self.rows_m) if (adam_step and self.dp is None) else None,
+            p2(self.rows_v) if (adam_step and self.dp is None) else None,
             self.n_users, self.n_items, ptr(pred), ptr(se), ptr(self.sse) if adam_step else None,
             ptr(ws), ws.numel(), n, T, self.E, self.L, float(self.hp['dropout']), int(train_mode), self.seed,
             self.offset, float(inv_denom), self.conv_algo, buf, ready,
@@ -825,8 +902,9 @@ class TransNetEngine(NarreEngine):
 
     def __init__(self, model, dp=None, **kw):
         self.dp = dp if (dp is not None and dp.on) else None
-        self._gathered = None
         self.plus = int(model.hyper_params['model_type'] == 'transnet++')
+        if not self.plus:
+            self.DP_COLS = 0                                 # plain TransNet: no ID rows to exchange
         self.ROW_NAMES = ['user_embedding.weight', 'item_embedding.weight'] if self.plus else []
         self._hp_counts = (int(model.hyper_params['total_users']) + 2, int(model.hyper_params['total_items']) + 2)
         super().__init__(model, **kw)
@@ -877,62 +955,22 @@ class TransNetEngine(NarreEngine):
             ptr(nxt[0]) if nxt else None, ptr(nxt[1]) if nxt else None, ptr(nxt[2]) if nxt else None,
             self.lr, self.betas[0], self.betas[1], self.eps, self.wd, int(adam_step), _lib.current_stream())
 
-    @torch.no_grad()
-    def train_step(self, data, y, n_global=None, next_data=None):
-        if self.dp is None:
-            return super().train_step(data, y, n_global, next_data)
-        # Data parallel: gradients only on this rank (r4r_transnet_step with flat_m = NULL), then C1 -- one
-        # all-reduce of the flat dense gradient + the flat Adam -- and, TransNet++, C2: the ranks' compact
-        # ID-vector rows gathered (ids -1 pad ragged shards) into the same tagged sweep on every rank.
-        lib, dist = _lib.lib(), torch.distributed
-        n, world = data[5].numel(), self.dp.world
-        B_pad = int(self.hp.get('batch_size', 0))
-        if n_global is None or n > B_pad:
-            sizes = torch.tensor([n], dtype=torch.int64, device=self.dev)
-            all_sizes = torch.empty(world, dtype=torch.int64, device=self.dev)
-            dist.all_gather_into_tensor(all_sizes, sizes, group=self.dp.group)
-            B_pad, n_global = int(all_sizes.max().item()), int(all_sizes.sum().item())
-        y = y.reshape(-1).contiguous()
-        self.step_count += 1
-        se = torch.empty(0, dtype=torch.float32, device=self.dev)
-        if n > 0:
-            _, se = self._launch(data, y, self.model.training, 1.0 / float(n_global), self.step_count, next_data)
-        else:
-            self.flat_g.zero_()                              # an empty shard contributes a zero gradient
-        self.dp.allreduce_flat(self.flat_g)
-        one = ctypes.c_uint64 * 1
-        _lib.check(lib.r4r_adam_multi(1, one(self.flat_p.data_ptr()), one(self.flat_g.data_ptr()),
-                                      one(self.flat_m.data_ptr()), one(self.flat_v.data_ptr()),
-                                      (ctypes.c_int64 * 1)(self.total), self.lr, self.betas[0], self.betas[1], self.eps,
-                                      self.wd, int(self.step_count), None, _lib.current_stream()), 'r4r_adam_multi')
-        if not self.plus:
-            return se
-        ids = torch.full((B_pad, 2), -1, dtype=torch.int64, device=self.dev)
-        rows = torch.zeros((B_pad, 10), dtype=torch.float32, device=self.dev)
-        T = data[3].reshape(max(n, 1), -1).shape[1] if n > 0 else int(self.hp['input_length'])
-        if n > 0:
-            f, _, R, T = self._fields(data)
-            ws = self._workspace(n, R, T)
-            ids[:n, 0], ids[:n, 1] = f[3], f[4]
-            for t in range(2):
-                off = self._ws_offset(n, R, T, 1 + t)
-                rows[:n, 5 * t:5 * t + 5] = ws[off:off + n * 20].view(torch.float32).view(n, 5)
-        all_ids = torch.empty((world, B_pad, 2), dtype=torch.int64, device=self.dev)
-        all_rows = torch.empty((world, B_pad, 10), dtype=torch.float32, device=self.dev)
-        dist.all_gather_into_tensor(all_ids.view(-1), ids.view(-1), group=self.dp.group)
-        dist.all_gather_into_tensor(all_rows.view(-1), rows.view(-1), group=self.dp.group)
-        uid_all, iid_all = all_ids[:, :, 0].reshape(-1).contiguous(), all_ids[:, :, 1].reshape(-1).contiguous()
-        gu_all = all_rows[:, :, :5].reshape(-1, 5).contiguous()
-        gi_all = all_rows[:, :, 5:].reshape(-1, 5).contiguous()
-        nb = max(n, 1)                                       # (the workspace of this rank's own shape holds the row tags)
-        ws = self._workspace(nb, 1, T)
+    DP_COLS = 10
+
+    def _dp_payload(self, f, n, R, T, ids, vals):
+        ws = self._workspace(n, R, T)
+        ids[:n, 0], ids[:n, 1] = f[3], f[4]
+        for t in range(2):
+            off = self._ws_offset(n, R, T, 1 + t)
+            vals[:n, 5 * t:5 * t + 5] = ws[off:off + n * 20].view(torch.float32).view(n, 5)
+
+    def _dp_apply(self, uid_all, iid_all, all_vals, B_all, ws, nb, T):
+        gu_all, gi_all = all_vals[:, :5].contiguous(), all_vals[:, 5:].contiguous()
         p2 = lambda ts: (ctypes.c_uint64 * 2)(*[t.data_ptr() for t in ts])   # noqa: E731
-        _lib.check(lib.r4r_transnet_rows_apply(ptr(uid_all), ptr(iid_all), ptr(gu_all), ptr(gi_all), world * B_pad,
-                                               p2(self.rows), p2(self.rows_m), p2(self.rows_v), self.n_users,
-                                               self.n_items, ptr(ws), ws.numel(), nb, T, self.E, self.L, self.V, self.lr,
-                                               self.betas[0], self.betas[1], self.eps, self.wd, int(self.step_count),
-                                               _lib.current_stream()), 'r4r_transnet_rows_apply')
-        return se
+        _lib.check(_lib.lib().r4r_transnet_rows_apply(
+            ptr(uid_all), ptr(iid_all), ptr(gu_all), ptr(gi_all), B_all, p2(self.rows), p2(self.rows_m), p2(self.rows_v),
+            self.n_users, self.n_items, ptr(ws), ws.numel(), nb, T, self.E, self.L, self.V, self.lr, self.betas[0],
+            self.betas[1], self.eps, self.wd, int(self.step_count), _lib.current_stream()), 'r4r_transnet_rows_apply')
 
     def aux(self, data):
         """[B, 3] of the LAST step on `data`: target prediction, its squared error, ||s_ir - t_ir||^2."""

@@ -162,11 +162,12 @@ def make_engine(hyper_params, model, dp=None, rank=0):
         return NarreEngine(model, lr=hyper_params['lr'], weight_decay=hyper_params['weight_decay'],
                            seed=hyper_params.get('seed', 0x5EED5EED), rank=rank)
     if hyper_params['model_type'] == 'deepconn++':
-        if (dp is not None and dp.on) or int(hyper_params.get('batch_size', 128)) > 16384:
+        world = dp.world if (dp is not None and dp.on) else 1
+        if int(hyper_params.get('batch_size', 128)) * world > 16384:
             return None
         from .engine import DeepCoNNPPEngine
         return DeepCoNNPPEngine(model, lr=hyper_params['lr'], weight_decay=hyper_params['weight_decay'],
-                                seed=hyper_params.get('seed', 0x5EED5EED), rank=rank)
+                                seed=hyper_params.get('seed', 0x5EED5EED), rank=rank, dp=dp)
     if _is_transnet(hyper_params):
         world = dp.world if (dp is not None and dp.on) else 1
         if int(hyper_params.get('batch_size', 128)) * world > 16384:
