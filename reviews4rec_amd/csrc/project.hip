@@ -281,7 +281,11 @@ __global__ __launch_bounds__(GEMM_THREADS) void proj_gemm_kernel(ProjArgs a) {
 // slices of a segment are merged through LDS in position order (strict >, so the first
 // maximum wins like PyTorch's max-pool).
 constexpr int SLICE = 32;                 // positions per worker
-constexpr int GDEPTH = 8;                 // tokens in flight per lane
+#ifndef R4R_GDEPTH
+#define R4R_GDEPTH 7
+#endif
+constexpr int GDEPTH = R4R_GDEPTH;        // tokens in flight per lane (7: 124 VGPRs, four waves per SIMD -- every workgroup of the
+                                          // cfg3 launch resident at once; 8: 136 VGPRs, three, 1 us slower; 4..6 within 0.5 us of 7)
 
 __global__ __launch_bounds__(256) void proj_gather_max_kernel(ProjArgs a) {
     __shared__ int sl[8][SLICE + 2];
