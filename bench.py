@@ -195,9 +195,9 @@ def main():
     if args.engine == 'native' and hp['model_type'] in ('MF_dot', 'bias_only') and B * world <= 16384:
         from reviews4rec_amd.engine import MFEngine
         engine = MFEngine(model, lr=hp['lr'], weight_decay=hp['weight_decay'], seed=4321, rank=rank, dp=dp)
-    if args.engine == 'native' and hp['model_type'] == 'NARRE' and world == 1:
+    if args.engine == 'native' and hp['model_type'] == 'NARRE' and B * 11 <= 4096 and B * 11 * world <= 16384:
         from reviews4rec_amd.engine import NarreEngine
-        engine = NarreEngine(model, lr=hp['lr'], weight_decay=hp['weight_decay'], seed=4321, rank=rank,
+        engine = NarreEngine(model, lr=hp['lr'], weight_decay=hp['weight_decay'], seed=4321, rank=rank, dp=dp,
                              conv_algo={'auto': 0, 'direct': 1, 'project': 2}[args.conv_algo])
     if args.engine == 'native' and hp['model_type'] == 'deepconn++' and B * world <= 16384:
         from reviews4rec_amd.engine import DeepCoNNPPEngine

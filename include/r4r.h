@@ -386,6 +386,19 @@ int r4r_narre_step(const float *table, int64_t V,
                    float lr, double beta1, double beta2, float eps, float weight_decay, int64_t adam_step,
                    void *stream);
 
+/* Data parallel: r4r_narre_step with flat_m == NULL computes gradients only (flat_g; the compact ID entries
+ * at r4r_narre_ws_offset 1..5); after the exchange -- all-reduce flat_g + r4r_adam_multi, all_gather of the
+ * ranks' entries -- this updates the two ID tables and bias vectors from ALL ranks' entries in the order
+ * given (ids -1 pad ragged shards).  g_entry: an entry's bias gradient (d loss / d pred for a rating's own
+ * user / item entry, 0 for a neighbour entry).  Same `ws` and shape arguments as the step.  entries <= 16384. */
+int r4r_narre_rows_apply(const int64_t *gid0, const int64_t *gid1, const float *grow0, const float *grow1,
+                         const float *g_entry, int64_t entries,
+                         const uint64_t *rows_p, const uint64_t *rows_m, const uint64_t *rows_v,
+                         int64_t n_users, int64_t n_items, void *ws, size_t ws_bytes,
+                         int64_t B, int R, int T, int E, int L, int64_t V,
+                         float lr, double beta1, double beta2, float eps, float weight_decay, int64_t adam_step,
+                         void *stream);
+
 /* ---- fused native step for DeepCoNN++ (DeepCoNN.py:37-72, model_type 'deepconn++'): the two
  * TextCNN towers, `final` = Linear(2L, L) -> ReLU -> Dropout -> Linear(L, 1), user / item / global
  * bias.  Same structure and arguments as r4r_narre_step; user_idx / item_idx [B, T] as in

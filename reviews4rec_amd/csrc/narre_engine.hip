@@ -600,8 +600,11 @@ extern "C" int r4r_narre_step(const float *table, int64_t V,
     R4R_REQUIRE(L > 0 && L <= NR_MAX_L, "narre_step: latent_size %d outside 1..%d", L, NR_MAX_L);
     R4R_REQUIRE(E > 0 && E % 4 == 0, "narre_step: word_embed_size %d must be a positive multiple of 4", E);
     const bool train_step = flat_g != nullptr;
-    R4R_REQUIRE(!train_step || (y && se && flat_m && flat_v && rows_m && rows_v && adam_step >= 1),
-                "narre_step: a training step needs ratings, se, gradient / moment buffers and adam_step >= 1");
+    // flat_m == NULL on a training step: gradients only (flat_g and the compact ID rows in the workspace) -- the
+    // data-parallel form (r4r_adam_multi + r4r_narre_rows_apply after the exchange)
+    const bool apply = flat_m != nullptr;
+    R4R_REQUIRE(!train_step || (y && se && adam_step >= 1 && (!apply || (flat_v && rows_m && rows_v))),
+                "narre_step: a training step needs ratings, se, gradient buffers and adam_step >= 1 (+ moments to update)");
     R4R_REQUIRE(!y || se, "narre_step: se buffer required when y is given");
     R4R_REQUIRE(!next_user_reviews == !next_item_reviews, "narre_step: next_user_reviews and next_item_reviews go together");
     R4R_REQUIRE(!next_user_reviews || train_step, "narre_step: the next batch's tokens ride on the backward launches");
@@ -719,9 +722,10 @@ extern "C" int r4r_narre_step(const float *table, int64_t V,
     RowSweep rs;
     float *rp[4], *rm[4], *rv[4];
     for (int k = 0; k < 4; ++k) {
-        rp[k] = reinterpret_cast<float *>(rows_p[k]); rm[k] = reinterpret_cast<float *>(rows_m[k]);
-        rv[k] = reinterpret_cast<float *>(rows_v[k]);
-        R4R_REQUIRE(rp[k] && rm[k] && rv[k], "narre_step: row tensor %d: null parameter / moment pointer", k);
+        rp[k] = reinterpret_cast<float *>(rows_p[k]);
+        rm[k] = apply ? reinterpret_cast<float *>(rows_m[k]) : nullptr;
+        rv[k] = apply ? reinterpret_cast<float *>(rows_v[k]) : nullptr;
+        R4R_REQUIRE(rp[k] && (!apply || (rm[k] && rv[k])), "narre_step: row tensor %d: null parameter / moment pointer", k);
     }
     rs.p0 = rp[0]; rs.p1 = rp[1]; rs.p2 = rp[2]; rs.p3 = rp[3];
     rs.m0 = rm[0]; rs.m1 = rm[1]; rs.m2 = rm[2]; rs.m3 = rm[3];
@@ -739,20 +743,90 @@ extern "C" int r4r_narre_step(const float *table, int64_t V,
 
     const int packed = 3 * E / 4 <= 64;                     // narrow windows: one wave per filter
     const dim3 bgrid(packed ? (NF + 3) / 4 : NF, wa.nsplit, prefetch ? 5 : 4);
-    if (L <= 16) narre_backward_kernel<16><<<bgrid, WG_THREADS, 0, st>>>(wa, cs, cs_blocks, nx, packed, rs, (int)chunks, 2);
+    if (!apply)                                             // gradients only: no ID-table role in this launch
+        narre_backward_kernel<0><<<dim3(bgrid.x, bgrid.y, bgrid.z - 1), WG_THREADS, 0, st>>>(wa, cs, cs_blocks, nx, packed,
+                                                                                             RowSweep{}, 0, 2);
+    else if (L <= 16) narre_backward_kernel<16><<<bgrid, WG_THREADS, 0, st>>>(wa, cs, cs_blocks, nx, packed, rs, (int)chunks, 2);
     else narre_backward_kernel<32><<<bgrid, WG_THREADS, 0, st>>>(wa, cs, cs_blocks, nx, packed, rs, (int)chunks, 2);
 
     // 5: wgrad reduce + Adam on the dense parameters (+ next batch's compaction)
     const int red_blocks = (NF * 3 * E + NF + NRED_THREADS - 1) / NRED_THREADS;
     const int comp_blocks = prefetch ? (int)cdiv((V + 3) / 4, NRED_THREADS) : 0;
     DenseAdam opt;
-    opt.on = 1; opt.p = flat_p; opt.m = flat_m; opt.v = flat_v; opt.g = flat_g;
+    opt.on = apply ? 1 : 0; opt.p = flat_p; opt.m = flat_m; opt.v = flat_v; opt.g = flat_g;
     opt.lo0 = hc.lo0; opt.hi0 = hc.hi0; opt.lo1 = hc.lo1; opt.hi1 = hc.hi1;
     opt.s = adam_make_scalars(lr, beta1, beta2, eps, weight_decay, adam_step, nullptr);
     const int64_t longest = hc.hi0 - hc.lo0 > hc.hi1 - hc.lo1 ? hc.hi0 - hc.lo0 : hc.hi1 - hc.lo1;
-    const int opt_blocks = (int)cdiv(longest, NRED_THREADS);
+    const int opt_blocks = apply ? (int)cdiv(longest, NRED_THREADS) : 0;
     narre_reduce_kernel<<<dim3(red_blocks + comp_blocks + opt_blocks, 2), NRED_THREADS, 0, st>>>(wa, red_blocks, comp_blocks,
                                                                                                 nx, opt);
 
     return check_launch("narre_step");
+}
+
+// Data parallel: the ID tables + bias vectors from ALL ranks' compact entries (gathered by the caller
+// in one fixed order; ids -1 pad ragged shards), after a gradients-only r4r_narre_step (flat_m ==
+// NULL).  gid0 / gid1 [entries]: entry ids of the user / item table; grow0 / grow1 [entries, L]: their
+// gradient rows; g_entry [entries]: an entry's bias gradient (d loss / d pred for a rating's own
+// user / item entry, 0 for a neighbour entry).  `ws` and the shape arguments are the step's: the
+// row tags live there.  entries <= 16384.
+namespace r4r {
+__global__ void narre_tag_rows_kernel(const int64_t *gid0, const int64_t *gid1, int64_t n, int *tag0, int *tag1, int now) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n) return;
+    if (gid0[e] >= 0) tag0[gid0[e]] = now;
+    if (gid1[e] >= 0) tag1[gid1[e]] = now;
+}
+}  // namespace r4r
+
+extern "C" int r4r_narre_rows_apply(const int64_t *gid0, const int64_t *gid1, const float *grow0, const float *grow1,
+                                    const float *g_entry, int64_t entries,
+                                    const uint64_t *rows_p, const uint64_t *rows_m, const uint64_t *rows_v,
+                                    int64_t n_users, int64_t n_items, void *ws, size_t ws_bytes,
+                                    int64_t B, int R, int T, int E, int L, int64_t V,
+                                    float lr, double beta1, double beta2, float eps, float weight_decay, int64_t adam_step,
+                                    void *stream) {
+    R4R_REQUIRE(gid0 && gid1 && grow0 && grow1 && g_entry && rows_p && rows_m && rows_v && ws, "narre_rows_apply: null pointer");
+    R4R_REQUIRE(entries >= 0 && entries <= NROW_DP_MAX_ENTRIES, "narre_rows_apply: %lld entries outside 0..%d",
+                (long long)entries, NROW_DP_MAX_ENTRIES);
+    R4R_REQUIRE(L > 0 && L <= NR_MAX_L, "narre_rows_apply: latent_size %d outside 1..%d", L, NR_MAX_L);
+    R4R_REQUIRE(adam_step >= 1 && adam_step < (1ll << 31), "narre_rows_apply: bad adam_step");
+    if (ws_bytes < r4r_narre_ws_bytes(B, R, T, E, L, V, n_users, n_items)) {
+        set_error("narre_rows_apply: workspace %zu < %zu bytes", ws_bytes, r4r_narre_ws_bytes(B, R, T, E, L, V, n_users, n_items));
+        return R4R_ERR_WORKSPACE;
+    }
+    if (entries == 0) return R4R_OK;
+    hipStream_t st = as_stream(stream);
+    const NarreWs w = narre_carve(ws, B, R, T, E, L, V, n_users, n_items);
+    RowSweep rs;
+    float *rp[4], *rm[4], *rv[4];
+    for (int k = 0; k < 4; ++k) {
+        rp[k] = reinterpret_cast<float *>(rows_p[k]); rm[k] = reinterpret_cast<float *>(rows_m[k]);
+        rv[k] = reinterpret_cast<float *>(rows_v[k]);
+        R4R_REQUIRE(rp[k] && rm[k] && rv[k], "narre_rows_apply: row tensor %d: null parameter / moment pointer", k);
+    }
+    rs.p0 = rp[0]; rs.p1 = rp[1]; rs.p2 = rp[2]; rs.p3 = rp[3];
+    rs.m0 = rm[0]; rs.m1 = rm[1]; rs.m2 = rm[2]; rs.m3 = rm[3];
+    rs.v0 = rv[0]; rs.v1 = rv[1]; rs.v2 = rv[2]; rs.v3 = rv[3];
+    const int64_t numel[4] = {n_users * L, n_items * L, n_users, n_items};
+    int64_t begin[5], chunks = 0;
+    for (int k = 0; k < 4; ++k) { begin[k] = chunks; chunks += cdiv(numel[k], NROW_CHUNK); }
+    rs.n0 = numel[0]; rs.n1 = numel[1]; rs.n2 = numel[2]; rs.n3 = numel[3];
+    rs.cb1 = (int)begin[1]; rs.cb2 = (int)begin[2]; rs.cb3 = (int)begin[3]; rs.cb_entries = (int)chunks;
+    chunks += 2 * cdiv(entries, 4);
+    R4R_REQUIRE(chunks < (1ll << 31), "narre_rows_apply: too many chunks");
+    rs.gid0 = gid0; rs.gid1 = gid1; rs.grow0 = grow0; rs.grow1 = grow1; rs.g = g_entry;
+    rs.tag0 = w.tag[0]; rs.tag1 = w.tag[1]; rs.entries = entries; rs.B = entries; rs.L = L; rs.now = (int)adam_step;
+    rs.s = adam_make_scalars(lr, beta1, beta2, eps, weight_decay, adam_step, nullptr);
+    narre_tag_rows_kernel<<<(unsigned)cdiv(entries, 256), 256, 0, st>>>(gid0, gid1, entries, w.tag[0], w.tag[1], (int)adam_step);
+    const size_t lds = (size_t)entries * sizeof(int);
+    static size_t attr16 = 0, attr32 = 0;
+    if (L <= 16) {
+        if (attr16 < lds) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(narre_rows_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr16 = lds; }
+        narre_rows_kernel<16><<<(unsigned)chunks, NROW_THREADS, lds, st>>>(rs);
+    } else {
+        if (attr32 < lds) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(narre_rows_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr32 = lds; }
+        narre_rows_kernel<32><<<(unsigned)chunks, NROW_THREADS, lds, st>>>(rs);
+    }
+    return check_launch("narre_rows_apply");
 }

@@ -73,11 +73,12 @@ struct RowSweep {
     int L, now;
     AdamScalars s;
 };
-template <int ML>
-__device__ __forceinline__ void narre_rows_block(const RowSweep &w, int bx) {
+// MW: 64-bit words of a lane's hit mask (entries <= 4096 MW: 1 in the fused single-process launch,
+// 4 in the stand-alone data-parallel launch); `sid`: LDS for the entry ids (entries ints).
+template <int ML, int MW>
+__device__ __forceinline__ void narre_rows_block(const RowSweep &w, int bx, int *sid) {
     if (bx >= w.cb_entries) {
         // ---- entry waves: 4 per workgroup, all of one table (user table's groups first)
-        __shared__ int sid[NROW_MAX_ENTRIES];
         const int lane = threadIdx.x & 63;
         const int groups = (int)((w.entries + 3) / 4);
         int gi = bx - w.cb_entries;
@@ -90,6 +91,7 @@ __device__ __forceinline__ void narre_rows_block(const RowSweep &w, int bx) {
         const int64_t k = (int64_t)gi * 4 + (threadIdx.x >> 6);
         if (k >= w.entries) return;                         // whole wave
         const int row = sid[k];
+        if (row < 0) return;                                // a padded entry (gathered ragged shards): whole wave
         const int L = w.L;
         const int nch = (int)((w.entries + 63) / 64);
         // phase 1: is k the first entry of its row?  (scan of the ids in LDS, 64 at a time)
@@ -109,18 +111,31 @@ __device__ __forceinline__ void narre_rows_block(const RowSweep &w, int bx) {
 #pragma unroll
         for (int col = 0; col < ML; ++col) rv[col] = 0.f;
         float gv = 0.f;
-        unsigned long long mine = 0;                        // bit c: entry c*64 + lane is a hit (nch <= 64)
+        unsigned long long mine[MW];                        // bit c of word c / 64: entry c*64 + lane is a hit (nch <= 64 MW)
+#pragma unroll
+        for (int q = 0; q < MW; ++q) mine[q] = 0;
         for (int c = (int)(k / 64); c < nch; ++c) {         // (no hit before k's chunk: k is the first)
             const int64_t j = (int64_t)c * 64 + lane;
-            if (j < w.entries && sid[j] == row) mine |= 1ull << c;
+            if (j < w.entries && sid[j] == row) {
+#pragma unroll
+                for (int q = 0; q < MW; ++q)
+                    if ((c >> 6) == q) mine[q] |= 1ull << (c & 63);
+            }
         }
-        while (__ballot(mine != 0)) {                       // four of a lane's hits per round, their loads together
+        auto any = [&]() { unsigned long long o = 0;
+#pragma unroll
+            for (int q = 0; q < MW; ++q) o |= mine[q];
+            return o != 0; };
+        auto pop = [&]() -> int {                           // the lane's lowest remaining hit (ascending order), -1 if none
+#pragma unroll
+            for (int q = 0; q < MW; ++q)
+                if (mine[q]) { const int c = __ffsll((long long)mine[q]) - 1; mine[q] &= mine[q] - 1; return q * 64 + c; }
+            return -1;
+        };
+        while (__ballot(any())) {                           // four of a lane's hits per round, their loads together
             int cs[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                cs[u] = mine ? __ffsll((long long)mine) - 1 : -1;
-                if (mine) mine &= mine - 1;
-            }
+            for (int u = 0; u < 4; ++u) cs[u] = pop();
             float tmp[4][ML], tg[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
@@ -209,10 +224,11 @@ __global__ __launch_bounds__(WG_THREADS) void narre_backward_kernel(WgradArgs w,
     const int z = (int)blockIdx.z - (ML > 0 ? 1 : 0);
     if (z < 0) {
         if constexpr (ML > 0) {
+            __shared__ int rows_sid[NROW_MAX_ENTRIES];
             // entry workgroups first (the owner of a popular row is the longest), then the sweep
             for (int blk = blk0; blk < row_blocks; blk += nblk) {
                 const int ne = row_blocks - rows.cb_entries;
-                narre_rows_block<ML>(rows, blk < ne ? rows.cb_entries + blk : blk - ne);
+                narre_rows_block<ML, 1>(rows, blk < ne ? rows.cb_entries + blk : blk - ne, rows_sid);
                 __syncthreads();
             }
         }
@@ -227,6 +243,15 @@ __global__ __launch_bounds__(WG_THREADS) void narre_backward_kernel(WgradArgs w,
     } else {
         token_mark_block(nx, blk0, nblk, WG_THREADS);
     }
+}
+
+// The ID-table role as a launch of its own (data parallel: the entries of ALL ranks, gathered): up to
+// 16,384 entries per table, their ids in dynamic LDS.
+constexpr int NROW_DP_WORDS = 4, NROW_DP_MAX_ENTRIES = 64 * 64 * NROW_DP_WORDS;
+template <int ML>
+static __global__ __launch_bounds__(NROW_THREADS) void narre_rows_kernel(RowSweep w) {
+    extern __shared__ int rows_sid_dyn[];
+    narre_rows_block<ML, NROW_DP_WORDS>(w, (int)blockIdx.x, rows_sid_dyn);
 }
 
 // ---- 5: wgrad partial reduce + Adam on the dense parameters + next batch's compaction

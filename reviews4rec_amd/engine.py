@@ -525,7 +525,9 @@ class NarreEngine:
     NTOWER = 2                   # TextCNN towers (token states per buffer)
 
     def __init__(self, model, lr=0.002, weight_decay=1e-6, betas=(0.9, 0.999), eps=1e-8, seed=0x5EED5EED, rank=0,
-                 conv_algo=0):
+                 conv_algo=0, dp=None):
+        if dp is not None and dp.on:
+            self.dp = dp
         hp = model.hyper_params
         if hp['model_type'] not in (self.MODEL_TYPE if isinstance(self.MODEL_TYPE, tuple) else (self.MODEL_TYPE,)):
             raise ValueError('%s implements model_type %r, got %r' % (type(self).__name__, self.MODEL_TYPE, hp['model_type']))
@@ -629,9 +631,11 @@ class NarreEngine:
     def _step(self, f, y, pred, se, ws, n, R, T, train_mode, inv_denom, adam_step, buf, ready, nxt):
         return _lib.lib().r4r_narre_step(
             ptr(self.table), self.V, ptr(f[0]), ptr(f[1]), ptr(f[2]), ptr(f[3]), ptr(f[4]), ptr(f[5]), ptr(y),
-            ptr(self.flat_p), ptr(self.flat_g) if adam_step else None, ptr(self.flat_m) if adam_step else None,
-            ptr(self.flat_v) if adam_step else None, self._p4(self.rows),
-            self._p4(self.rows_m) if adam_step else None, self._p4(self.rows_v) if adam_step else None,
+            ptr(self.flat_p), ptr(self.flat_g) if adam_step else None,
+            ptr(self.flat_m) if (adam_step and self.dp is None) else None,     # data parallel: gradients only
+            ptr(self.flat_v) if (adam_step and self.dp is None) else None, self._p4(self.rows),
+            self._p4(self.rows_m) if (adam_step and self.dp is None) else None,
+            self._p4(self.rows_v) if (adam_step and self.dp is None) else None,
             self.n_users, self.n_items, ptr(pred), ptr(se), ptr(self.sse) if adam_step else None,
             ptr(ws), ws.numel(), n, R, T, self.E, self.L, float(self.hp['dropout']), int(train_mode), self.seed,
             self.offset, float(inv_denom), self.conv_algo, buf, ready,
@@ -679,13 +683,46 @@ class NarreEngine:
     # _dp_payload / _dp_apply.
     dp = None
 
+    DP_COLS = 1                  # nonzero: the family has ID rows to exchange (subclasses without: 0)
+
+    def _dp_doc_shape(self, data):
+        """(reviews per rating, words per document) of this engine's batches, also for an empty shard."""
+        return int(data[3].shape[-2]), int(data[3].shape[-1])  # (a shard's slice keeps these dims when empty)
+
+    def _dp_cols(self, R):
+        """(int64 ids, floats) per rating in the gathered payload."""
+        return 2 + 2 * R, 1 + 2 * (1 + R) * self.L
+
     def _dp_payload(self, f, n, R, T, ids, vals):
-        raise NotImplementedError
+        # per rating: [uid, iid, R neighbour ids of the user table, R of the item table] and
+        # [d loss/d pred, (1 + R) x L gradient rows of the user table, then of the item table]
+        ws, L = self._workspace(n, R, T), self.L
+        view = lambda which, cols, dt: ws[self._ws_offset(n, R, T, which):][:n * (1 + R) * cols * (8 if dt == torch.int64 else 4)] \
+            .view(dt).view(n * (1 + R), cols)                # noqa: E731
+        off = self._ws_offset(n, R, T, 5)
+        vals[:n, 0] = ws[off:off + n * 4].view(torch.float32)
+        for t in range(2):
+            gid, grow = view(3 + t, 1, torch.int64)[:, 0], view(1 + t, L, torch.float32)
+            ids[:n, t] = gid[:n]
+            ids[:n, 2 + t * R:2 + (t + 1) * R] = gid[n:].view(n, R)
+            base = 1 + t * (1 + R) * L
+            vals[:n, base:base + L] = grow[:n]
+            vals[:n, base + L:base + (1 + R) * L] = grow[n:].reshape(n, R * L)
 
-    def _dp_apply(self, uid_all, iid_all, all_vals, B_all, ws, nb, T):
-        raise NotImplementedError
-
-    DP_COLS = 0                  # floats per rating in the gathered payload (0: no ID rows to exchange)
+    def _dp_apply(self, all_ids, all_vals, B_all, ws, nb, R, T):
+        L = self.L
+        gids, grows = [], []
+        for t in range(2):                                   # entries in (rank, rating, [self, neighbours]) order
+            gids.append(torch.cat([all_ids[:, t:t + 1], all_ids[:, 2 + t * R:2 + (t + 1) * R]], dim=1).reshape(-1).contiguous())
+            base = 1 + t * (1 + R) * L
+            grows.append(all_vals[:, base:base + (1 + R) * L].reshape(-1, L).contiguous())
+        g_entry = torch.zeros((B_all, 1 + R), dtype=torch.float32, device=self.dev)
+        g_entry[:, 0] = all_vals[:, 0]
+        _lib.check(_lib.lib().r4r_narre_rows_apply(
+            ptr(gids[0]), ptr(gids[1]), ptr(grows[0]), ptr(grows[1]), ptr(g_entry), B_all * (1 + R),
+            self._p4(self.rows), self._p4(self.rows_m), self._p4(self.rows_v), self.n_users, self.n_items,
+            ptr(ws), ws.numel(), nb, R, T, self.E, L, self.V, self.lr, self.betas[0], self.betas[1], self.eps, self.wd,
+            int(self.step_count), _lib.current_stream()), 'r4r_narre_rows_apply')
 
     @torch.no_grad()
     def _train_step_dp(self, data, y, n_global, next_data):
@@ -712,20 +749,20 @@ class NarreEngine:
                                       self.wd, int(self.step_count), None, _lib.current_stream()), 'r4r_adam_multi')
         if not self.DP_COLS:
             return se
-        ids = torch.full((B_pad, 2), -1, dtype=torch.int64, device=self.dev)
-        vals = torch.zeros((B_pad, self.DP_COLS), dtype=torch.float32, device=self.dev)
-        T = int(self.hp['input_length'])
+        R, T = self._dp_doc_shape(data)
+        id_cols, val_cols = self._dp_cols(R)
+        ids = torch.full((B_pad, id_cols), -1, dtype=torch.int64, device=self.dev)
+        vals = torch.zeros((B_pad, val_cols), dtype=torch.float32, device=self.dev)
         if n > 0:
             f, _, R, T = self._fields(data)
             self._dp_payload(f, n, R, T, ids, vals)
-        all_ids = torch.empty((world, B_pad, 2), dtype=torch.int64, device=self.dev)
-        all_vals = torch.empty((world, B_pad, self.DP_COLS), dtype=torch.float32, device=self.dev)
+        all_ids = torch.empty((world, B_pad, id_cols), dtype=torch.int64, device=self.dev)
+        all_vals = torch.empty((world, B_pad, val_cols), dtype=torch.float32, device=self.dev)
         dist.all_gather_into_tensor(all_ids.view(-1), ids.view(-1), group=self.dp.group)
         dist.all_gather_into_tensor(all_vals.view(-1), vals.view(-1), group=self.dp.group)
-        uid_all, iid_all = all_ids[:, :, 0].reshape(-1).contiguous(), all_ids[:, :, 1].reshape(-1).contiguous()
         nb = max(n, 1)                                       # (the workspace of this rank's own shape holds the row tags)
-        self._dp_apply(uid_all, iid_all, all_vals.view(world * B_pad, self.DP_COLS), world * B_pad,
-                       self._workspace(nb, 1, T), nb, T)
+        self._dp_apply(all_ids.view(world * B_pad, id_cols), all_vals.view(world * B_pad, val_cols), world * B_pad,
+                       self._workspace(nb, R, T), nb, R, T)
         return se
 
     @torch.no_grad()
@@ -818,15 +855,21 @@ class DeepCoNNPPEngine(NarreEngine):
     DP_COLS = 1
 
     def __init__(self, model, dp=None, **kw):
-        self.dp = dp if (dp is not None and dp.on) else None
-        super().__init__(model, **kw)
+        super().__init__(model, dp=dp, **kw)
+
+    def _dp_doc_shape(self, data):
+        return 1, int(data[3].shape[-1])
+
+    def _dp_cols(self, R):
+        return 2, 1
 
     def _dp_payload(self, f, n, R, T, ids, vals):
         off = self._ws_offset(n, R, T, 5)
         ids[:n, 0], ids[:n, 1] = f[2], f[3]
         vals[:n, 0] = self._workspace(n, R, T)[off:off + n * 4].view(torch.float32)
 
-    def _dp_apply(self, uid_all, iid_all, all_vals, B_all, ws, nb, T):
+    def _dp_apply(self, all_ids, all_vals, B_all, ws, nb, R, T):
+        uid_all, iid_all = all_ids[:, 0].contiguous(), all_ids[:, 1].contiguous()
         g_all = all_vals[:, 0].contiguous()
         p2 = lambda ts: (ctypes.c_uint64 * 2)(*[t.data_ptr() for t in ts])   # noqa: E731
         _lib.check(_lib.lib().r4r_deepconnpp_rows_apply(
@@ -901,13 +944,14 @@ class TransNetEngine(NarreEngine):
     SSE_SLOTS = 3
 
     def __init__(self, model, dp=None, **kw):
-        self.dp = dp if (dp is not None and dp.on) else None
+        if dp is not None and dp.on:
+            self.dp = dp
         self.plus = int(model.hyper_params['model_type'] == 'transnet++')
         if not self.plus:
             self.DP_COLS = 0                                 # plain TransNet: no ID rows to exchange
         self.ROW_NAMES = ['user_embedding.weight', 'item_embedding.weight'] if self.plus else []
         self._hp_counts = (int(model.hyper_params['total_users']) + 2, int(model.hyper_params['total_items']) + 2)
-        super().__init__(model, **kw)
+        super().__init__(model, dp=dp, **kw)
 
     @staticmethod
     def _word_table(model):
@@ -964,7 +1008,14 @@ class TransNetEngine(NarreEngine):
             off = self._ws_offset(n, R, T, 1 + t)
             vals[:n, 5 * t:5 * t + 5] = ws[off:off + n * 20].view(torch.float32).view(n, 5)
 
-    def _dp_apply(self, uid_all, iid_all, all_vals, B_all, ws, nb, T):
+    def _dp_doc_shape(self, data):
+        return 1, int(data[3].shape[-1])
+
+    def _dp_cols(self, R):
+        return 2, 10
+
+    def _dp_apply(self, all_ids, all_vals, B_all, ws, nb, R, T):
+        uid_all, iid_all = all_ids[:, 0].contiguous(), all_ids[:, 1].contiguous()
         gu_all, gi_all = all_vals[:, :5].contiguous(), all_vals[:, 5:].contiguous()
         p2 = lambda ts: (ctypes.c_uint64 * 2)(*[t.data_ptr() for t in ts])   # noqa: E731
         _lib.check(_lib.lib().r4r_transnet_rows_apply(

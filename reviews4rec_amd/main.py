@@ -156,11 +156,13 @@ def make_engine(hyper_params, model, dp=None, rank=0):
         return MFEngine(model, lr=hyper_params['lr'], weight_decay=hyper_params['weight_decay'],
                         seed=hyper_params.get('seed', 0x5EED5EED), rank=rank, dp=dp)
     if hyper_params['model_type'] == 'NARRE':
-        if dp is not None and dp.on:
-            return None                                   # DP: module path (dist.py C1 + C2)
+        world = dp.world if (dp is not None and dp.on) else 1
+        entries = int(hyper_params.get('batch_size', 128)) * (1 + int(hyper_params.get('narre_num_reviews', 10)))
+        if entries > 4096 or (world > 1 and entries * world > 16384):
+            return None                                   # more ID entries than the rows role holds: module path
         from .engine import NarreEngine
         return NarreEngine(model, lr=hyper_params['lr'], weight_decay=hyper_params['weight_decay'],
-                           seed=hyper_params.get('seed', 0x5EED5EED), rank=rank)
+                           seed=hyper_params.get('seed', 0x5EED5EED), rank=rank, dp=dp)
     if hyper_params['model_type'] == 'deepconn++':
         world = dp.world if (dp is not None and dp.on) else 1
         if int(hyper_params.get('batch_size', 128)) * world > 16384:

@@ -989,3 +989,50 @@ def test_mf_engine_bias_only_large_batch(B):
     sd = model.state_dict()
     for k, v in P.items():
         torch.testing.assert_close(sd[k].cpu(), v, rtol=1e-5, atol=5e-6, msg=lambda m: k + ': ' + m)
+
+
+def test_narre_rows_apply_thousands_of_gathered_entries():
+    """r4r_narre_rows_apply on its own (the data-parallel ID-table update): 6,000 gathered entries per table
+    (past the 4,096 the fused single-process role holds: the multi-word hit masks), popular rows, padding
+    entries (-1), against a dense Adam step in plain torch; two steps."""
+    import ctypes
+    from reviews4rec_amd import _lib
+    from reviews4rec_amd._lib import ptr
+    lib = _lib.lib()
+    U, I, L, n = 3000, 2000, 10, 6000
+    B, R, T, E, V = 8, 4, 30, 16, 100                       # (only sizes the workspace that holds the row tags)
+    gen = torch.Generator().manual_seed(23)
+    tabs = [torch.randn(U, L, generator=gen), torch.randn(I, L, generator=gen), torch.randn(U, generator=gen),
+            torch.randn(I, generator=gen)]
+    P = [t.clone().to(DEV) for t in tabs]
+    M = [torch.zeros_like(t) for t in P]
+    Vv = [torch.zeros_like(t) for t in P]
+    ws = torch.zeros(lib.r4r_narre_ws_bytes(B, R, T, E, L, V, U, I), dtype=torch.uint8, device=DEV)
+    refP = [t.clone() for t in tabs]
+    state = oracle.AdamState()
+    lr, wd = 0.002, 1e-6
+    p4 = lambda ts: (ctypes.c_uint64 * 4)(*[t.data_ptr() for t in ts])   # noqa: E731
+    for step in (1, 2):
+        gid = [torch.randint(0, U, (n,), generator=gen), torch.randint(0, I, (n,), generator=gen)]
+        gid[0][torch.rand(n, generator=gen) < 0.1] = 17          # ~600 entries on one row
+        gid[1][torch.rand(n, generator=gen) < 0.05] = 3
+        pad = torch.rand(n, generator=gen) < 0.03
+        gid[0][pad] = -1
+        gid[1][pad] = -1
+        grow = [torch.randn(n, L, generator=gen) * 0.1, torch.randn(n, L, generator=gen) * 0.1]
+        g_entry = torch.where(torch.rand(n, generator=gen) < 0.2, torch.randn(n, generator=gen), torch.zeros(n))
+        d = [x.to(DEV) for x in gid + grow + [g_entry]]
+        rc = lib.r4r_narre_rows_apply(ptr(d[0]), ptr(d[1]), ptr(d[2]), ptr(d[3]), ptr(d[4]), n, p4(P), p4(M), p4(Vv), U, I,
+                                      ptr(ws), ws.numel(), B, R, T, E, L, V, lr, 0.9, 0.999, 1e-8, wd, step,
+                                      _lib.current_stream())
+        _lib.check(rc, 'r4r_narre_rows_apply')
+        ok = ~pad
+        grads = {'0': torch.zeros(U, L).index_add_(0, gid[0][ok], grow[0][ok]),
+                 '1': torch.zeros(I, L).index_add_(0, gid[1][ok], grow[1][ok]),
+                 '2': torch.zeros(U).index_add_(0, gid[0][ok], g_entry[ok]),
+                 '3': torch.zeros(I).index_add_(0, gid[1][ok], g_entry[ok])}
+        params = {str(k): refP[k] for k in range(4)}
+        oracle.adam_step(params, grads, state, lr, wd)
+        refP = [params[str(k)] for k in range(4)]
+    for k in range(4):
+        torch.testing.assert_close(P[k].cpu(), refP[k], rtol=1e-5, atol=5e-6, msg=lambda m: 'table %d: %s' % (k, m))
