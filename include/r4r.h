@@ -292,7 +292,13 @@ int r4r_deepconn_tokens(const int64_t *user_idx, const int64_t *item_idx, void *
 #define R4R_TIMING_TEXTCNN_WGRAD 1  /* textcnn_wgrad_kernel */
 #define R4R_TIMING_ADAM 2           /* adam_multi_kernel */
 #define R4R_TIMING_PROJ_GEMM 3      /* proj_gemm_kernel (projection of the batch's distinct tokens) */
-#define R4R_TIMING_PROJ_GATHER 4    /* ---- fused native step for the ID-only recommenders: model_type 'MF_dot' and 'bias_only'
+#define R4R_TIMING_PROJ_GATHER 4    /* proj_gather_max_kernel (gather-add-max over positions) */
+#define R4R_TIMING_SLOTS 8
+int r4r_timing_enable(int slot_mask);   /* bit i instruments slot i; 0 switches timing off */
+int r4r_timing_read(int slot, double *total_ms, int64_t *count, int reset);
+
+/* ------------------------------------------------------------------------
+ * Fused native step for the ID-only recommenders: model_type 'MF_dot' and 'bias_only'
  * Replaces, per training step, MF.forward (MF.py:39-58: user/item bias gathers, the two
  * ID-embedding gathers + dropout, the row dot product), MSELoss (loss.py:7-11), loss.backward()
  * and torch.optim.Adam.step() (main.py:56-60,94-96) by TWO launches.  The dense gradient of an
@@ -489,10 +495,29 @@ int r4r_transnet_rows_apply(const int64_t *uid_all, const int64_t *iid_all, cons
                             float lr, double beta1, double beta2, float eps, float weight_decay, int64_t adam_step,
                             void *stream);
 
-/* proj_gather_max_kernel (gather-add-max over positions) */
-#define R4R_TIMING_SLOTS 8
-int r4r_timing_enable(int slot_mask);   /* bit i instruments slot i; 0 switches timing off */
-int r4r_timing_read(int slot, double *total_ms, int64_t *count, int reset);
+/* ------------------------------------------------------------------------
+ * Device-side batch construction (the loader side of the path).
+ * Replaces  data.DataLoader.remove_overlap / pad_and_join / pad_only and the 10-wide neighbour
+ *           padding                                   data.py:144-236, 273-279, 375-447
+ *           the per-batch LongTensor constructions    data.py:293-301, data_fast.py:101-109
+ * The reviews of a dataset live in HBM as token pools (one per side; reviews4rec_amd/data.py):
+ *   tok [tokens] int32, rev_off [reviews + 1] token range of a review, first [owners + 1] review
+ *   range of a user / item, nb [reviews] the item / user a review is about (u_to_i_map / i_to_u_map)
+ *   held_tok / held_off: the held-out reviews (test_reviews) as a pool of single reviews
+ * For n ratings -- u, i: ids; nb_item: the item whose reviewer list is reported (== i except in
+ * iter_negs, data.py:398); ku / ki: index of the rating's own review among the user's / item's
+ * reviews, or -1 (nothing removed); held: index into the held pool or -1 ([0], data.py:245); train:
+ * 1 = the own review is the user's review ku (data.py:221) -- ONE launch writes, as one int64 block,
+ *   [n, doc] own review | [n, 10] users who reviewed the item (pad_user) | [n, 10] items the user
+ *   reviewed (pad_item) | [n, doc] user document | [n, doc] item document
+ * with doc = T (documents: reviews concatenated, cut / zero padded, R == 0) or R * W (NARRE: R
+ * reviews of W words). */
+int r4r_batch_build(const int32_t *user_tok, const int64_t *user_rev_off, const int64_t *user_first,
+                    const int64_t *user_nb, const int32_t *item_tok, const int64_t *item_rev_off,
+                    const int64_t *item_first, const int64_t *item_nb, const int32_t *held_tok,
+                    const int64_t *held_off, const int64_t *u, const int64_t *i, const int64_t *nb_item,
+                    const int64_t *ku, const int64_t *ki, const int64_t *held, int train, int64_t *out,
+                    int64_t n, int T, int R, int W, int64_t pad_user, int64_t pad_item, void *stream);
 
 #ifdef __cplusplus
 }

@@ -89,6 +89,10 @@ class DataLoader():
     def __len__(self):
         return int(self.total // self.bsz) + int(self.total % self.bsz > 0)
 
+    def batch_sizes(self):
+        """Rows of every batch iter() will yield (data parallelism sums them across ranks once per epoch)."""
+        return [min(self.bsz, self.total - i) for i in range(0, self.total, self.bsz)]
+
     def _stage(self, grp, stream):
         """Enqueue the single H2D copy of batch group `grp` on `stream`; returns the per-batch
         device views + the event + the device block."""

@@ -85,6 +85,57 @@ class DataParallel:
             ops.SparseGradCapture.active = True
             ops.SparseGradCapture.clear()
 
+    def rebind(self, model):
+        """Point the exchange at `model` (a new training stage, a freshly built model): its parameters
+        become the exchanged set, every cached decision about the previous model -- which parameters
+        carry gradients, the flat bucket, the compact-list tables, their dense buffers -- is dropped,
+        stale compact-gradient records are cleared, and rank 0's weights are broadcast so the replicas
+        start identical (each rank ran its own xavier_init)."""
+        self.model = model
+        self.params = [p for p in model.parameters() if p.requires_grad]
+        self._active = self._bucket = self._sparse_set = None
+        self._dense_grads = {}
+        if self.sparse:
+            from . import ops
+            ops.SparseGradCapture.clear()
+        self.broadcast_parameters()
+
+    def barrier(self):
+        if self.on:
+            dist.barrier(group=self.group)
+
+    def gather_ints(self, values):
+        """[[rank 0's values], [rank 1's], ...] of a short list of host integers."""
+        if not self.on:
+            return [list(values)]
+        dev = self.params[0].device if self.params else torch.device('cpu')
+        mine = torch.tensor(list(values), dtype=torch.int64, device=dev)
+        out = torch.empty(self.world * mine.numel(), dtype=torch.int64, device=dev)
+        dist.all_gather_into_tensor(out, mine, group=self.group)
+        return out.view(self.world, -1).tolist()
+
+    def epoch_counts(self, reader):
+        """Global size of every batch of the coming epoch, from the ranks' own batch sizes: one
+        collective per epoch.  None when the reader cannot tell its batch sizes up front.  Ranks must
+        hold the same NUMBER of batches (possibly empty ones) -- anything else would hang the first
+        collective of the shorter rank's missing step, so it is an error here."""
+        if not self.on:
+            return None
+        sizes = reader.batch_sizes() if hasattr(reader, 'batch_sizes') else None
+        dev = self.params[0].device if self.params else torch.device('cpu')
+        n = torch.tensor([-1 if sizes is None else len(sizes)], dtype=torch.int64, device=dev)
+        lo, hi = n.clone(), n.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=self.group)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=self.group)
+        if int(lo) < 0:
+            return None
+        if int(lo) != int(hi):
+            raise RuntimeError('data parallel: ranks hold %d..%d batches this epoch; shard every global batch '
+                               '(dist.shard_batch) so that all ranks step together' % (int(lo), int(hi)))
+        t = torch.tensor(sizes, dtype=torch.int64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        return t.tolist()
+
     def broadcast_parameters(self, src=0):
         """Make every replica start from rank `src`'s weights (buffers included)."""
         if not self.on:

@@ -75,16 +75,25 @@ def evaluate(model, criterion, reader, hyper_params, user_count, item_count, rev
     return metrics, _count_maps(users, ses, user_count), _count_maps(items, ses, item_count)
 
 
-def eval_ranking(model, reader, hyper_params, review=False):
-    """HR@1: % of rows whose positive (column 0 of the [B, 6] scores) ranks first."""
-    hits, total = 0.0, 0.0
+def eval_ranking(model, reader, hyper_params, review=False, engine=None):
+    """HR@1 (eval.py:64-92): % of ranking rows whose positive -- column 0 of the [B, 6] scores -- is what
+    ``torch.topk(scores[row], k=1)`` returns.  The scores of the whole split stay on the device and are
+    copied ONCE; the top-1 is then taken on the host by the same ATen routine the reference calls per
+    row (batched here), so exact score ties resolve the way they do there (a device-side topk may order
+    ties differently).  ``engine``: a native engine of `model` -- its fused eval forward scores the batches."""
+    parts = []
     is_tn = hyper_params['model_type'] in ['transnet', 'transnet++']
     with torch.no_grad():
         for data, y in reader.iter_negs(review):
-            output = model(data)
-            if is_tn:
-                output = output[0]
-            top = torch.topk(output, k=1, dim=-1, sorted=True).indices[:, 0]
-            hits += float((top == 0).sum())
-            total += float(top.numel())
-    return {'HR@1': round(100.0 * hits / total, 2)}
+            if engine is not None:
+                output = engine.predict(data, None)[0].clone()   # the engine reuses its output buffer
+            else:
+                output = model(data)
+                if is_tn:
+                    output = output[0]
+            parts.append(output.reshape(-1, output.shape[-1]))
+    scores = torch.cat(parts).float().cpu() if parts else torch.zeros(0, 6)
+    # batched host topk == the reference's per-row call, ties included (probed: 10k rows of 3-valued scores)
+    top = torch.topk(scores, k=1, dim=-1, sorted=True).indices[:, 0]
+    hits, total = float((top == 0).sum()), float(scores.shape[0])
+    return {'HR@1': round(100.0 * hits / total, 2)}        # no ranking rows: ZeroDivisionError, like eval.py:90

@@ -65,10 +65,25 @@ def train(model, criterion, optimizer, reader, hyper_params, engine=None, dp=Non
     if engine is not None:
         engine.sse.zero_()
 
+    dp_on = dp is not None and dp.on
+    if tn and dp_on and engine is None:
+        # the op-by-op three-optimiser step has no gradient exchange between its three backward passes:
+        # replicas would diverge silently (and the sparse-capture placeholders would reach Adam)
+        raise RuntimeError("TransNet under data parallelism needs the native step (hyper_params['engine'] = "
+                           "'auto' or 'native', batch_size * world <= 16384); the op-by-op three-optimiser "
+                           "step is single-process only")
+    # global batch sizes for the loss scale 1/B_global: ONE collective per epoch from the readers' batch
+    # sizes (a per-step all-reduce + .item() would serialise the launch queue behind every batch)
+    counts = dp.epoch_counts(reader) if dp_on else None
     batches = _with_next(reader.iter()) if engine is not None else ((b, None) for b in reader.iter())
-    for (data, y), upcoming in batches:
+    for step_no, ((data, y), upcoming) in enumerate(batches):
         n_local = int(y.shape[0])
-        n_global = dp.global_count(n_local, y.device) if (dp is not None and dp.on) else n_local
+        if not dp_on:
+            n_global = n_local
+        elif counts is not None:
+            n_global = counts[step_no]
+        else:                                                 # a reader that cannot say its batch sizes up front
+            n_global = dp.global_count(n_local, y.device)
         if engine is not None:
             engine.train_step(data, y, n_global=n_global, next_data=upcoming[0] if upcoming is not None else None)
             total_x += float(n_local)
@@ -144,44 +159,99 @@ def make_optimizer(hyper_params, model):
     return Adam(model.parameters(), lr=hyper_params['lr'], weight_decay=hyper_params['weight_decay'])
 
 
+def native_step_limits(hyper_params, world=1):
+    """None when the model's fused native step can run this configuration, else the reason it cannot
+    (the limits are those the C entry points enforce: include/r4r.h, csrc/step_device.h)."""
+    mt = hyper_params['model_type']
+    B = int(hyper_params.get('batch_size', 128))
+    L = int(hyper_params.get('latent_size', 10))
+    E = int(hyper_params.get('word_embed_size', 64))
+    R = int(hyper_params.get('narre_num_reviews', 10))
+    if mt in ('MF_dot', 'bias_only'):
+        if mt == 'MF_dot' and L > 256:
+            return 'latent_size %d > 256' % L
+        if B * world > 16384:
+            return 'global batch %d > 16384' % (B * world)
+        return None
+    if mt not in ('deepconn', 'deepconn++', 'NARRE', 'transnet', 'transnet++'):
+        return 'no fused native step for model_type %r' % (mt,)
+    if L > 32:
+        return 'latent_size %d > 32' % L
+    if E % 4 != 0:
+        return 'word_embed_size %d is not a multiple of 4' % E
+    if 3 * E // 4 > 512:
+        return 'word_embed_size %d > 680' % E
+    if mt == 'NARRE':
+        if R > 32:
+            return 'narre_num_reviews %d > 32' % R
+        if B * (1 + R) > 4096:
+            return '%d ID entries per table and step > 4096' % (B * (1 + R))
+        if world > 1 and B * (1 + R) * world > 16384:
+            return '%d gathered ID entries per table and step > 16384' % (B * (1 + R) * world)
+        return None
+    if mt != 'deepconn' and B * world > 16384:
+        return 'global batch %d > 16384' % (B * world)
+    return None
+
+
+def module_path_limits(hyper_params):
+    """Same question for the op-by-op HIP path (csrc/smallops.hip: FM input width and rank <= 64, a
+    dense layer's input width <= 255, TextCNN rows 16-byte aligned)."""
+    mt = hyper_params['model_type']
+    L = int(hyper_params.get('latent_size', 10))
+    E = int(hyper_params.get('word_embed_size', 64))
+    if mt in ('deepconn', 'deepconn++', 'NARRE', 'transnet', 'transnet++'):
+        if E % 4 != 0:
+            return 'word_embed_size %d is not a multiple of 4' % E
+        if 3 * E // 4 > 512:
+            return 'word_embed_size %d > 680' % E
+    fm_in = {'MF': 2 * L, 'deepconn': 2 * L, 'transnet': L, 'transnet++': L + 10}.get(mt)
+    if fm_in is not None and fm_in > 64:
+        return 'factorization machine over %d inputs > 64 (latent_size %d)' % (fm_in, L)
+    if mt == 'MF' and L > 64:
+        return 'factorization machine of rank %d > 64' % L
+    if mt in ('MF', 'NeuMF', 'NARRE', 'deepconn++') and 2 * L > 255:
+        return 'dense layer over %d inputs > 255' % (2 * L)
+    if mt == 'NARRE' and (int(hyper_params.get('narre_num_reviews', 10)) > 32 or L > 32):
+        return 'NARRE attention over more than 32 reviews / 32 latent dimensions'
+    return None
+
+
 def make_engine(hyper_params, model, dp=None, rank=0):
-    """The fused native step, where the model has one and the config asks for it."""
-    if hyper_params.get('engine', 'auto') not in ('auto', 'native'):
+    """The fused native step, where the model has one and the configuration fits it.  'auto' falls
+    back to the op-by-op HIP path (with the reason logged) when it does not; 'native' raises; a
+    configuration NEITHER path can run raises one clear error here, before any training."""
+    want = hyper_params.get('engine', 'auto')
+    world = dp.world if (dp is not None and dp.on) else 1
+    why_not = native_step_limits(hyper_params, world)
+    if want not in ('auto', 'native') or why_not is not None:
+        if want == 'native':
+            raise RuntimeError("hyper_params['engine'] = 'native': " + why_not)
+        blocked = module_path_limits(hyper_params)
+        if blocked is not None:
+            raise RuntimeError('reviews4rec_amd cannot run this configuration on the HIP path: ' + blocked +
+                               ((' (and the fused native step: ' + why_not + ')') if why_not else ''))
+        if want == 'auto' and why_not is not None:          # loud: this path is several times slower
+            import warnings
+            msg = "engine 'auto': the fused native step cannot run this configuration (" + why_not + \
+                "); using the op-by-op HIP path"
+            warnings.warn(msg, RuntimeWarning, stacklevel=2)
+            if hyper_params.get('log_file'):
+                file_write(hyper_params['log_file'], msg, dont_print=True)
         return None
-    if hyper_params['model_type'] in ('MF_dot', 'bias_only'):
-        world = dp.world if (dp is not None and dp.on) else 1
-        if int(hyper_params.get('batch_size', 128)) * world > 16384:
-            return None                                   # very large (global) batches: module path (dist.py C2)
-        from .engine import MFEngine
-        return MFEngine(model, lr=hyper_params['lr'], weight_decay=hyper_params['weight_decay'],
-                        seed=hyper_params.get('seed', 0x5EED5EED), rank=rank, dp=dp)
-    if hyper_params['model_type'] == 'NARRE':
-        world = dp.world if (dp is not None and dp.on) else 1
-        entries = int(hyper_params.get('batch_size', 128)) * (1 + int(hyper_params.get('narre_num_reviews', 10)))
-        if entries > 4096 or (world > 1 and entries * world > 16384):
-            return None                                   # more ID entries than the rows role holds: module path
-        from .engine import NarreEngine
-        return NarreEngine(model, lr=hyper_params['lr'], weight_decay=hyper_params['weight_decay'],
-                           seed=hyper_params.get('seed', 0x5EED5EED), rank=rank, dp=dp)
-    if hyper_params['model_type'] == 'deepconn++':
-        world = dp.world if (dp is not None and dp.on) else 1
-        if int(hyper_params.get('batch_size', 128)) * world > 16384:
-            return None
-        from .engine import DeepCoNNPPEngine
-        return DeepCoNNPPEngine(model, lr=hyper_params['lr'], weight_decay=hyper_params['weight_decay'],
-                                seed=hyper_params.get('seed', 0x5EED5EED), rank=rank, dp=dp)
+    from . import engine as E
+    kw = dict(lr=hyper_params['lr'], weight_decay=hyper_params['weight_decay'],
+              seed=hyper_params.get('seed', 0x5EED5EED), rank=rank, dp=dp)
+    mt = hyper_params['model_type']
+    if mt in ('MF_dot', 'bias_only'):
+        return E.MFEngine(model, **kw)
+    if mt == 'NARRE':
+        return E.NarreEngine(model, **kw)
+    if mt == 'deepconn++':
+        return E.DeepCoNNPPEngine(model, **kw)
     if _is_transnet(hyper_params):
-        world = dp.world if (dp is not None and dp.on) else 1
-        if int(hyper_params.get('batch_size', 128)) * world > 16384:
-            return None
-        from .engine import TransNetEngine
-        return TransNetEngine(model, lr=hyper_params['lr'], weight_decay=hyper_params['weight_decay'],
-                              seed=hyper_params.get('seed', 0x5EED5EED), rank=rank, dp=dp)
-    if hyper_params['model_type'] != 'deepconn':
-        return None
-    from .engine import DeepCoNNEngine
-    return DeepCoNNEngine(model, lr=hyper_params['lr'], weight_decay=hyper_params['weight_decay'], dp=dp,
-                          seed=hyper_params.get('seed', 0x5EED5EED), rank=rank)
+        return E.TransNetEngine(model, **kw)
+    return E.DeepCoNNEngine(model, **kw)
 
 
 def train_complete(hyper_params, Model, train_reader, val_reader, user_count, item_count, model, review=True,
@@ -193,6 +263,8 @@ def train_complete(hyper_params, Model, train_reader, val_reader, user_count, it
 
     criterion = MSELoss(hyper_params)
     rank = dp.rank if dp is not None else 0
+    if dp is not None:
+        dp.rebind(model)        # THIS model's parameters are what gets exchanged; replicas start from rank 0's
     engine = make_engine(hyper_params, model, dp=dp, rank=rank)
     # the readers hold millions of Python objects: without this a generation-2 collection stops the
     # host for tens of milliseconds in the middle of an epoch, longer than the launch queue is deep
@@ -224,6 +296,11 @@ def train_complete(hyper_params, Model, train_reader, val_reader, user_count, it
             optimizer.load_state_dict(ck['optimizer'])
         from . import ops
         ops.DropoutState.offset = int(ck.get('dropout_offset', 0))    # module path's Philox stream position
+        per_rank = ck.get('rank_offsets')                             # ragged shards: every rank has its own
+        if per_rank is not None and len(per_rank) > rank:
+            ops.DropoutState.offset = int(per_rank[rank][1])
+            if engine is not None:
+                engine.offset = int(per_rank[rank][0])
         if ops.DropoutState.device_counter is not None:               # ... which a captured step keeps on the device
             ops.DropoutState.device_counter.fill_(ops.DropoutState.offset)
         first_epoch, best_MSE = int(ck['epoch']) + 1, float(ck['best_MSE'])
@@ -241,8 +318,16 @@ def train_complete(hyper_params, Model, train_reader, val_reader, user_count, it
             if metrics['MSE'] < best_MSE:
                 if rank == 0:
                     print('Saving model...')
-                    torch.save(model.state_dict(), hyper_params['model_path'])
+                    tmp = hyper_params['model_path'] + '.tmp'
+                    torch.save(model.state_dict(), tmp)
+                    os.replace(tmp, hyper_params['model_path'])     # never a partial file under the final name
                 best_MSE = metrics['MSE']
+            if ckpt_path:
+                from . import ops
+                drop_at = ops.DropoutState.offset if ops.DropoutState.device_counter is None else \
+                    int(ops.DropoutState.device_counter.item())
+                mine = [int(getattr(engine, 'offset', 0)) if engine is not None else 0, int(drop_at)]
+                rank_offsets = dp.gather_ints(mine) if (dp is not None and dp.on) else [mine]
             if ckpt_path and rank == 0:
                 if engine is not None:
                     opt_sd = engine.state_dict()
@@ -251,16 +336,16 @@ def train_complete(hyper_params, Model, train_reader, val_reader, user_count, it
                 else:
                     opt_sd = optimizer.state_dict()
                 tmp = ckpt_path + '.tmp'
-                from . import ops
-                drop_at = ops.DropoutState.offset if ops.DropoutState.device_counter is None else \
-                    int(ops.DropoutState.device_counter.item())
                 torch.save({'epoch': epoch, 'best_MSE': best_MSE, 'model': model.state_dict(),
-                            'optimizer': opt_sd, 'dropout_offset': drop_at}, tmp)
+                            'optimizer': opt_sd, 'dropout_offset': drop_at, 'rank_offsets': rank_offsets}, tmp)
                 os.replace(tmp, ckpt_path)                  # a crash mid-write leaves the previous one intact
     except KeyboardInterrupt:
         print('Exiting from training early')
 
-    # reload the best-on-validation checkpoint into a fresh model (main.py:131-134)
+    # reload the best-on-validation checkpoint into a fresh model (main.py:131-134); under data
+    # parallelism only rank 0 wrote it: nobody reads before the writer is done
+    if dp is not None and dp.on:
+        dp.barrier()
     model = Model(hyper_params)
     if is_cuda_available:
         model = model.cuda()
@@ -269,12 +354,41 @@ def train_complete(hyper_params, Model, train_reader, val_reader, user_count, it
     return model
 
 
-def main_NeuMF(hyper_params, readers, user_count=None, item_count=None, dp=None, ranking_reader=None):
-    """Counterpart of main.main_NeuMF (main.py:289-340) over already-built readers: pre-train GMF,
-    pre-train MLP (each with its own checkpoint path), initialise NeuMF from both, train it,
-    evaluate MSE (+ HR@1 when a negatives reader is given)."""
+def _load_readers(hyper_params, review_based_model):
+    """The readers main.py:357-372 builds.  The reference prefers its preprocessed-epoch loader
+    (data_fast.py) for review models because its pickle loader rebuilds batches in Python; here the
+    pickle loader builds batches on the device from HBM-resident token pools (data.py), so it is the
+    default.  hyper_params['loader'] = 'fast' asks for the preprocessed files (quick_data_*)."""
+    from .data import load_data
+    if review_based_model and hyper_params.get('loader', 'pools') == 'fast':
+        from .data_fast import load_data_fast
+        train_reader, test_reader, val_reader, hyper_params = load_data_fast(hyper_params)
+        _, ranking_reader, _, _ = load_data(hyper_params)               # main.py:394: needs the pickle reader
+        return train_reader, test_reader, val_reader, ranking_reader, hyper_params
+    train_reader, test_reader, val_reader, hyper_params = load_data(hyper_params)
+    return train_reader, test_reader, val_reader, test_reader, hyper_params
+
+
+def _final_engine(hyper_params, model):
+    """A native engine around the reloaded best model, for the test-set passes (eval only)."""
+    if not is_cuda_available:
+        return None
+    return make_engine(dict(hyper_params, log_file=None), model)
+
+
+def main_NeuMF(hyper_params, readers=None, user_count=None, item_count=None, dp=None, ranking_reader=None,
+               gpu_id=None):
+    """Counterpart of main.main_NeuMF (main.py:289-340): pre-train GMF, pre-train MLP (each with its own
+    checkpoint path), initialise NeuMF from both, train it, evaluate MSE + HR@1.  ``readers`` =
+    (train, test, val) skips the loading (synthetic data); without it the dataset directory is read
+    like the reference does."""
     from .pytorch_models.NeuMF import GMF, MLP, NeuMF
-    train_reader, test_reader, val_reader = readers
+    from .utils import load_user_item_counts
+    if readers is None:
+        user_count, item_count = load_user_item_counts(hyper_params)
+        train_reader, test_reader, val_reader, ranking_reader, hyper_params = _load_readers(hyper_params, False)
+    else:
+        train_reader, test_reader, val_reader = readers
     user_count = {} if user_count is None else user_count
     item_count = {} if item_count is None else item_count
     start_time = time.time()
@@ -304,29 +418,50 @@ def main_NeuMF(hyper_params, readers, user_count=None, item_count=None, dp=None,
     return metrics, user_count_mse_map, item_count_mse_map
 
 
-def main_pytorch(hyper_params, readers, user_count=None, item_count=None, review_based_model=True, dp=None,
-                 ranking_reader=None):
-    """Counterpart of main.main_pytorch (main.py:342-399) over already-built readers
-    ``(train, test, val)`` -- the pickle-based slow loader of the reference is out of scope."""
+def main_pytorch(hyper_params, readers=None, user_count=None, item_count=None, review_based_model=None, dp=None,
+                 ranking_reader=None, gpu_id=None):
+    """Counterpart of main.main_pytorch (main.py:342-399).  ``readers`` = (train, test, val) skips the
+    loading (synthetic data); without it the dataset directory is read like the reference does:
+    train-set counts, the three loaders, and the negatives reader for HR@1."""
     import reviews4rec_amd
+    from .utils import load_user_item_counts
     Model = reviews4rec_amd.get_model_class(hyper_params['model_type'])
-    train_reader, test_reader, val_reader = readers
+    if review_based_model is None:
+        review_based_model = hyper_params['model_type'] not in ['bias_only', 'MF', 'MF_dot', 'NeuMF']
+    if readers is None:
+        user_count, item_count = load_user_item_counts(hyper_params)
+        train_reader, test_reader, val_reader, ranking_reader, hyper_params = \
+            _load_readers(hyper_params, review_based_model)
+    else:
+        train_reader, test_reader, val_reader = readers
     user_count = {} if user_count is None else user_count
     item_count = {} if item_count is None else item_count
     model = Model(hyper_params)
     if is_cuda_available:
         model = model.cuda()
     xavier_init(model)                                    # main.py:377
-    if dp is not None:
-        dp.model, dp.params = model, [p for p in model.parameters() if p.requires_grad]
-        dp.broadcast_parameters()
     start_time = time.time()
     model = train_complete(hyper_params, Model, train_reader, val_reader, user_count, item_count, model,
                            review=review_based_model, dp=dp)
     criterion = MSELoss(hyper_params)
+    engine = _final_engine(hyper_params, model)           # the fused eval forward scores the test passes
     metrics, user_count_mse_map, item_count_mse_map = evaluate(
-        model, criterion, test_reader, hyper_params, user_count, item_count, review=review_based_model)
+        model, criterion, test_reader, hyper_params, user_count, item_count, review=review_based_model,
+        engine=engine)
     if ranking_reader is not None:
-        metrics.update(eval_ranking(model, ranking_reader, hyper_params, review=review_based_model))
+        metrics.update(eval_ranking(model, ranking_reader, hyper_params, review=review_based_model, engine=engine))
     log_end_epoch(hyper_params, metrics, 'final', time.time() - start_time, metrics_on='(TEST)')
     return metrics, user_count_mse_map, item_count_mse_map
+
+
+def main(hyper_params, gpu_id=None):
+    """main.main (main.py:400-430) for the model families on the accelerated path; returns the metrics."""
+    if gpu_id is not None:
+        torch.cuda.set_device(int(gpu_id))
+    mt = hyper_params['model_type']
+    if mt in ['SVD', 'kNN', 'NMF', 'SVD++', 'baseline', 'HFT', 'MPCN']:
+        raise ValueError('model_type %r (Surprise / HFT / MPCN) is outside the accelerated path; run it with the '
+                         'reference' % (mt,))
+    method = main_NeuMF if mt == 'NeuMF' else main_pytorch
+    metrics, user_count_mse_map, item_count_mse_map = method(hyper_params, gpu_id=gpu_id)
+    return metrics

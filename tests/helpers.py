@@ -95,3 +95,44 @@ class OracleModule(torch.nn.Module):
     def forward(self, data):
         import oracle
         return oracle.model_forward(self.as_dict(), data, self.hyper_params, train=self.training)
+
+
+TINY_DIR = os.path.join(GOLDEN_DIR, 'tiny')
+TINY_FILES = ('train', 'test', 'val', 'user_reviews', 'item_reviews', 'test_reviews', 'this_index_user_item',
+              'num_users_items', 'word2vec', 'user_count', 'item_count', 'negs')
+
+
+def materialise_tiny(root):
+    """Write tests/golden/tiny/dataset.json back into the .pkl files of a reference dataset directory
+    (preprocess_random_split.py:296-316, make_negative_sets.py:83) -> the data_dir string."""
+    import json
+    import pickle
+    ds = json.load(open(os.path.join(TINY_DIR, 'dataset.json')))
+
+    def ints(d, depth):
+        if depth == 0 or not isinstance(d, dict):
+            return d
+        return {int(k): ints(v, depth - 1) for k, v in d.items()}
+
+    ds['user_reviews'], ds['item_reviews'] = ints(ds['user_reviews'], 1), ints(ds['item_reviews'], 1)
+    ds['test_reviews'], ds['this_index_user_item'] = ints(ds['test_reviews'], 2), ints(ds['this_index_user_item'], 2)
+    ds['user_count'], ds['item_count'] = ints(ds['user_count'], 1), ints(ds['item_count'], 1)
+    ds['negs'] = ints(ds['negs'], 1)
+    root = os.path.join(str(root), 'data', 'Tiny', '5_core')
+    os.makedirs(root, exist_ok=True)
+    for name in TINY_FILES:
+        with open(os.path.join(root, name + '.pkl'), 'wb') as f:
+            pickle.dump(ds[name], f, 2)
+    return root + '/'
+
+
+def tiny_hp(model_type, data_dir, **kw):
+    """hyper_params of a tests/golden/tiny fixture (the generator's tiny_hp) + the data directory."""
+    import json
+    name = {'deepconn++': 'deepconn++_e2e', 'bias_only': 'bias_only_e2e'}.get(model_type, model_type + '_eval')
+    hp = dict(json.load(open(os.path.join(TINY_DIR, name + '.json')))['hp'])
+    for k in ('total_users', 'total_items', 'total_words'):
+        hp.pop(k, None)                                   # load_data sets them (data.py:469-471)
+    hp['data_dir'] = data_dir
+    hp.update(kw)
+    return hp

@@ -93,3 +93,57 @@ def test_product_package_never_imports_the_oracle():
                 src = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r'^\s*(from|import)\s+oracle\b', src, re.M), os.path.join(dirpath, f)
                 assert 'oracle/' not in src and 'oracle.' not in src.replace('the CPU oracle.', ''), f
+
+
+def test_header_is_plain_c(tmp_path):
+    """include/r4r.h is the boundary a C / cgo / JNI host would include: it must compile as C99, not
+    only as C++ (the library itself includes it from .hip / .cpp files)."""
+    import shutil
+    import subprocess
+    if shutil.which('gcc') is None:
+        pytest.skip('no gcc')
+    src = tmp_path / 'use_r4r.c'
+    src.write_text('#include "r4r.h"\n'
+                   'int main(void) {\n'
+                   '    size_t (*ws)(int64_t, int, int, int, int64_t) = r4r_textcnn_ws_bytes;\n'
+                   '    const char *(*err)(void) = r4r_last_error;\n'
+                   '    return (ws != 0 && err != 0 && R4R_OK == 0 && R4R_TIMING_SLOTS > 0) ? r4r_version() : 1;\n'
+                   '}\n')
+    inc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'include')
+    out = subprocess.run(['gcc', '-std=c99', '-Wall', '-Wextra', '-pedantic', '-Werror', '-fsyntax-only',
+                          '-I', inc, str(src)], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+
+
+def test_integration_stub_matches_the_header():
+    """The reference-side ctypes stub printed in INTEGRATION.md, executed verbatim against the built
+    library: every argtypes / restype it declares must be what include/r4r.h declares."""
+    import ctypes
+    import re
+    from reviews4rec_amd import _lib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, 'INTEGRATION.md')).read()
+    blocks = [b for b in re.findall(r'```python\n(.*?)```', text, flags=re.S) if 'r4r_binding.py' in b]
+    assert len(blocks) == 1
+    code = blocks[0].replace("ctypes.CDLL('libr4r_hip.so')", 'ctypes.CDLL(%r)' % _lib.LIB_PATH)
+    ns = {}
+    exec(compile(code, 'INTEGRATION.md:r4r_binding.py', 'exec'), ns)
+    decls = _lib.parse_header()
+    stub = ns['_lib']
+    touched = set(re.findall(r'_lib\.(r4r_\w+)\.(?:argtypes|restype)', code))
+    assert {'r4r_textcnn_ws_bytes', 'r4r_textcnn_fwd', 'r4r_last_error'} <= touched
+    for name in touched:
+        restype, argtypes, _ = decls[name]
+        fn = getattr(stub, name)
+        if fn.argtypes is not None:
+            assert list(fn.argtypes) == argtypes, name
+        assert fn.restype in (restype, ctypes.c_int if restype is ctypes.c_int else restype), name
+    # and the call sites inside the stub pass as many arguments as the header declares
+    for name in ('r4r_textcnn_ws_bytes', 'r4r_textcnn_fwd'):
+        call = re.search(r'_lib\.%s\((.*?)\)\n' % name, code, flags=re.S).group(1)
+        depth, n = 0, 1
+        for ch in call:
+            depth += ch in '([' 
+            depth -= ch in ')]'
+            n += (ch == ',' and depth == 0)
+        assert n == len(decls[name][1]), (name, n)
