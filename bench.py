@@ -11,11 +11,26 @@ data-parallel with one RCCL all-reduce of the dense gradients per step.
 A "step" is one full training step -- zero_grad, forward (word gather + TextCNN x2
 + FC + dropout + FM), per-example SE, mean, backward, fused Adam -- over one batch
 of `--batch-per-gpu` ratings per GPU whose index tensors are already resident in
-HBM.  Rank 0 prints ONE JSON line.  `roofline` describes the dominant kernel
-(textcnn_fwd_kernel, fp32 MFMA): algorithmic flops per launch / its mean duration,
-measured with HIP events on the launch stream over the timed region.
+HBM.  Rank 0 prints ONE JSON line.  `roofline` describes the dominant kernel of the
+default step -- proj_gemm_kernel, the fp32-MFMA projection of the batch's distinct
+tokens (project-then-gather): useful flops of the batches actually
+run / the kernel's mean duration, measured with HIP events on the launch stream
+inside the timed region (textcnn_fwd_kernel takes its place with --conv-algo direct).
+`roofline_gather` is the second leg (proj_gather_max_kernel; its operands are L2 /
+Infinity-Cache resident, so it is reported against that, not against HBM).
 `cpu_baseline` times the plain-PyTorch CPU oracle (same graph as the reference) on a
 bounded sample of the same workload, on rank 0 at N=1 only.
+
+Scaling: the default is WEAK (`--batch-per-gpu` ratings per rank, the reference's
+batch_size 128, so N GPUs train 128 N ratings per step).  `--scaling strong
+--global-batch G` shards a fixed global batch of G ratings instead.  A weak run at
+N > 1 appends a second, separately timed STRONG measurement at G = 1024
+(`"strong": {...}`) so one SCALE sweep yields both curves, and every N > 1 run ends
+with a replica check: the ranks' parameter buffers must be bit-identical.
+
+Data dependence: project-then-gather's work follows the DISTINCT tokens of a batch.
+`--doc-fill full` (no zero padding) and `--token-dist uniform` (no Zipf head) are the
+unfriendly points; the value line always uses the SURVEY 8d defaults.
 """
 import argparse
 import ctypes
@@ -40,20 +55,27 @@ PMC_SUMMARIES = {WORKLOAD: 'r01l_bench_pmc_summary.json',
                  'cfg5_transnetpp_synthetic': 'r01m_bench_cfg5_pmc_summary.json'}
 
 
-def measured_traffic(kernel, args):
-    """HBM-side bytes per launch of `kernel` from the committed rocprofv3 --pmc summary
-    (profiles/, separate counter passes of this same command) -- only for the configurations
-    those summaries were collected on; None otherwise."""
+def measured_traffic(kernel, args, live_launch_s=None):
+    """(HBM-side bytes per launch of `kernel`, the file they come from) out of the committed rocprofv3
+    --pmc summary (profiles/: separate counter passes of this same command, corrected as
+    MI355X_MICROARCH.md prescribes) -- only for the configuration those passes ran, and only while the
+    summary still describes this build: if the kernel duration recorded with the counters is more than
+    25 % away from the one measured live in this run, the summary is stale and no traffic is reported."""
     name = PMC_SUMMARIES.get(args.workload)
     path = os.path.join(ROOT, 'profiles', name) if name else None
     if not (path and os.path.exists(path) and args.batch_per_gpu == 128 and args.engine == 'native'
-            and args.conv_algo in ('auto', 'project') and not args.model_type and not args.embed):
-        return None
+            and args.conv_algo in ('auto', 'project') and not args.model_type and not args.embed
+            and args.scaling == 'weak' and args.doc_fill == 'lognormal' and args.token_dist == 'zipf'):
+        return None, None
     kernels = json.load(open(path))['kernels']
     for k, v in kernels.items():
         if k.startswith('r4r::' + kernel):                   # (template instantiations carry a <..> suffix)
-            return v.get('hbm_bytes_per_launch')
-    return None
+            then = v.get("avg_duration_us_under_pmc")
+            if live_launch_s and then and abs(then * 1e-6 - live_launch_s) > 0.25 * live_launch_s:
+                return None, 'profiles/%s is stale for %s (%.1f us then, %.1f us now)' % (
+                    name, kernel, then, live_launch_s * 1e6)
+            return v.get('hbm_bytes_per_launch'), 'profiles/' + name
+    return None, None
 
 
 def parse():
@@ -82,6 +104,20 @@ def parse():
     ap.add_argument('--token-prefetch', choices=['fused', 'side-stream', 'off'], default='fused',
                     help='native engine: token marks / compaction of batch k+1 prepared during step k -- on step '
                          'k\'s backward and gradient-reduce launches (fused), on a side stream, or not at all')
+    ap.add_argument('--scaling', choices=['weak', 'strong'], default='weak',
+                    help='weak: --batch-per-gpu ratings per rank (default); strong: --global-batch ratings per step '
+                         'sharded over the ranks')
+    ap.add_argument('--global-batch', type=int, default=1024, help='--scaling strong: ratings per step over all ranks')
+    ap.add_argument('--strong-leg', default='1024,8192',
+                    help='weak runs at N > 1 also time strong-scaling legs at these global batch sizes '
+                         "(comma list; '' skips): the fixed global batch is sharded over the ranks")
+    ap.add_argument('--doc-fill', choices=['lognormal', 'full'], default='lognormal',
+                    help='lognormal: documents zero-padded to T (SURVEY 8d, default); full: no padding')
+    ap.add_argument('--token-dist', choices=['zipf', 'uniform'], default='zipf',
+                    help='zipf (SURVEY 8d, default) or uniform word ids (most distinct tokens per batch)')
+    ap.add_argument('--ramp', type=int, default=30,
+                    help='untimed steps before the requested warm-up when --warmup is shorter than this: clocks '
+                         'and launch queue reach steady state whatever --warmup says (reported as warmup_effective)')
     ap.add_argument('--engine', choices=['native', 'module', 'graph'], default='native',
                     help="native: fused r4r_deepconn_step where the model has one (else module); module: op-by-op "
                          "autograd path; graph: the module path captured into one hipGraph per step")
@@ -142,10 +178,36 @@ def cpu_baseline(hp, table, batches_np, budget_s):
                       % (n, B, hp['dataset'], hp['dropout'], ncpu, best)}
 
 
+def make_engine(args, hp, model, dp, rank, world, B):
+    """The fused native step of the workload's recommender (reviews4rec_amd.main.make_engine's
+    selection, with the bench's conv-algo / seed knobs); None -> the op-by-op module path."""
+    if args.engine != 'native':
+        return None
+    from reviews4rec_amd import engine as E
+    from reviews4rec_amd.main import native_step_limits
+    why_not = native_step_limits(dict(hp, batch_size=B), world)
+    if why_not is not None:
+        print('bench: no native step for this configuration (%s): module path' % why_not, file=sys.stderr)
+        return None
+    kw = dict(lr=hp['lr'], weight_decay=hp['weight_decay'], seed=4321, rank=rank, dp=dp)
+    algo = {'auto': 0, 'direct': 1, 'project': 2}[args.conv_algo]
+    mt = hp['model_type']
+    if mt in ('MF_dot', 'bias_only'):
+        return E.MFEngine(model, **kw)
+    if mt == 'NARRE':
+        return E.NarreEngine(model, conv_algo=algo, **kw)
+    if mt == 'deepconn++':
+        return E.DeepCoNNPPEngine(model, conv_algo=algo, **kw)
+    if mt in ('transnet', 'transnet++'):
+        return E.TransNetEngine(model, conv_algo=algo, **kw)
+    return E.DeepCoNNEngine(model, conv_algo=algo, **kw)
+
+
 def main():
     args = parse()
     from reviews4rec_amd import _lib, dist as r4dist, synthetic
     import reviews4rec_amd
+    from reviews4rec_amd.main import native_step_limits
     from reviews4rec_amd.loss import MSELoss
     from reviews4rec_amd.optim import Adam
     from reviews4rec_amd.ops import DropoutState
@@ -159,7 +221,13 @@ def main():
     dev = torch.device('cuda', local)
     lib = _lib.lib()
 
-    B = args.batch_per_gpu
+    strong = args.scaling == 'strong'
+    if strong:
+        if args.global_batch % world:
+            raise SystemExit('--global-batch %d is not divisible by %d ranks' % (args.global_batch, world))
+        B = args.global_batch // world
+    else:
+        B = args.batch_per_gpu
     hp = synthetic.hyper_params_for(args.workload, batch_size=B, dropout=args.dropout)
     if args.model_type:
         hp['model_type'] = args.model_type
@@ -185,32 +253,22 @@ def main():
     else:
         optimizer = Adam(model.parameters(), lr=hp['lr'], weight_decay=hp['weight_decay'])
 
-    gen = synthetic.Generator(hp, seed=synthetic.SEED + rank)   # each rank owns its shard of the stream
-    batches_np = [gen.batch(B) for _ in range(args.pool)]
-    pool = [([torch.from_numpy(d).to(dev) for d in data], torch.from_numpy(y).to(dev)) for data, y in batches_np]
+    # each rank owns its shard of the stream (a contiguous shard of every global batch: the rank's
+    # generator IS its shard -- ratings are i.i.d. draws)
+    gen = synthetic.Generator(hp, seed=synthetic.SEED + rank, doc_fill=args.doc_fill, token_dist=args.token_dist)
+
+    def make_pool(b):
+        np_batches = [gen.batch(b) for _ in range(args.pool)]
+        return np_batches, [([torch.from_numpy(d).to(dev) for d in data], torch.from_numpy(y).to(dev))
+                            for data, y in np_batches]
+
+    batches_np, pool = make_pool(B)
     metric_sum = torch.zeros((), device=dev)                 # sum of SE stays on the device (no per-step sync)
     B_global = B * world
 
-    engine = None
-    if args.engine == 'native' and hp['model_type'] in ('MF_dot', 'bias_only') and B * world <= 16384:
-        from reviews4rec_amd.engine import MFEngine
-        engine = MFEngine(model, lr=hp['lr'], weight_decay=hp['weight_decay'], seed=4321, rank=rank, dp=dp)
-    if args.engine == 'native' and hp['model_type'] == 'NARRE' and B * 11 <= 4096 and B * 11 * world <= 16384:
-        from reviews4rec_amd.engine import NarreEngine
-        engine = NarreEngine(model, lr=hp['lr'], weight_decay=hp['weight_decay'], seed=4321, rank=rank, dp=dp,
-                             conv_algo={'auto': 0, 'direct': 1, 'project': 2}[args.conv_algo])
-    if args.engine == 'native' and hp['model_type'] == 'deepconn++' and B * world <= 16384:
-        from reviews4rec_amd.engine import DeepCoNNPPEngine
-        engine = DeepCoNNPPEngine(model, lr=hp['lr'], weight_decay=hp['weight_decay'], seed=4321, rank=rank, dp=dp,
-                                  conv_algo={'auto': 0, 'direct': 1, 'project': 2}[args.conv_algo])
-    if args.engine == 'native' and is_tn and B * world <= 16384:
-        from reviews4rec_amd.engine import TransNetEngine
-        engine = TransNetEngine(model, lr=hp['lr'], weight_decay=hp['weight_decay'], seed=4321, rank=rank, dp=dp,
-                                conv_algo={'auto': 0, 'direct': 1, 'project': 2}[args.conv_algo])
-    if args.engine == 'native' and hp['model_type'] == 'deepconn':
-        from reviews4rec_amd.engine import DeepCoNNEngine
-        engine = DeepCoNNEngine(model, lr=hp['lr'], weight_decay=hp['weight_decay'], dp=dp, seed=4321, rank=rank,
-                                conv_algo={'auto': 0, 'direct': 1, 'project': 2}[args.conv_algo])
+    engine = make_engine(args, hp, model, dp, rank, world, B)
+    if engine is None and is_tn and world > 1:
+        raise SystemExit('TransNet under data parallelism needs the native step (see reviews4rec_amd.main.train)')
     # N > 1: measure the two gradient-exchange forms on this node's fabric once, before any timed
     # step, and keep the faster (R4R_DP_EXCHANGE=allreduce|gather pins one)
     exchange_ms = engine.autotune_exchange() if (engine is not None and world > 1
@@ -223,39 +281,44 @@ def main():
         from reviews4rec_amd.graph import GraphedStep
         graphed = GraphedStep(model, criterion, optimizer, *pool[0])   # TransNet: the optimiser list
 
-    def step(i):
-        data, y = pool[i % len(pool)]
-        if graphed is not None:
-            graphed(data, y)
-            return
-        if engine is not None:
-            # forward + loss + backward + all-reduce + Adam; the next batch's token compaction overlaps it
-            nxt = pool[(i + 1) % len(pool)][0]
-            engine.train_step(data, y, n_global=B_global, next_data=nxt if args.token_prefetch == 'fused' else None)
-            if args.token_prefetch == 'side-stream':
-                engine.prefetch_tokens(nxt)
-            return
-        model.zero_grad()
-        if is_tn:                                            # the 3-optimiser step of main.py:35-53
-            for o in optimizer:
-                o.zero_grad()
+    def make_step(pool, b, b_global):
+        def step(i):
+            data, y = pool[i % len(pool)]
+            if graphed is not None:
+                graphed(data, y)
+                return
+            if engine is not None:
+                # forward + loss + backward + all-reduce + Adam; the next batch's token compaction overlaps it
+                nxt = pool[(i + 1) % len(pool)][0]
+                engine.train_step(data, y, n_global=b_global,
+                                  next_data=nxt if args.token_prefetch == 'fused' else None)
+                if args.token_prefetch == 'side-stream':
+                    engine.prefetch_tokens(nxt)
+                return
+            model.zero_grad()
+            if is_tn:                                        # the 3-optimiser step of main.py:35-53
+                for o in optimizer:
+                    o.zero_grad()
+                out = model(data)
+                criterion(out[1], y).backward(retain_graph=True)
+                optimizer[2].step()
+                out[2].backward(retain_graph=True)
+                optimizer[0].step()
+                se = criterion(out[0], y, return_mean=False)
+                metric_sum.add_(se.detach().sum())
+                torch.mean(se).backward()
+                optimizer[1].step()
+                return
+            optimizer.zero_grad()
             out = model(data)
-            criterion(out[1], y).backward(retain_graph=True)
-            optimizer[2].step()
-            out[2].backward(retain_graph=True)
-            optimizer[0].step()
-            se = criterion(out[0], y, return_mean=False)
+            se = criterion(out, y, return_mean=False)
             metric_sum.add_(se.detach().sum())
-            torch.mean(se).backward()
-            optimizer[1].step()
-            return
-        optimizer.zero_grad()
-        out = model(data)
-        se = criterion(out, y, return_mean=False)
-        metric_sum.add_(se.detach().sum())
-        (se.sum() * dp.loss_scale(B, B_global)).backward()
-        dp.allreduce_grads()
-        optimizer.step()
+            (se.sum() * dp.loss_scale(b, b_global)).backward()
+            dp.allreduce_grads()
+            optimizer.step()
+        return step
+
+    step = make_step(pool, B, B_global)
 
     if args.from_host:
         from reviews4rec_amd import data_fast
@@ -282,41 +345,41 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
+    def timed_region(step_fn, steps, first, mask):
+        """EXACTLY `steps` steps between two fences; -> max-over-ranks wall seconds."""
+        fence()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            lib.r4r_timing_enable(mask if i % 10 == 5 else 0)
+            step_fn(first + i)
+        fence()
+        elapsed = time.perf_counter() - t0
+        lib.r4r_timing_enable(0)
+        el = torch.tensor([elapsed], device=dev)
+        if world > 1:
+            torch.distributed.all_reduce(el, op=torch.distributed.ReduceOp.MAX)
+        return float(el.item())
+
     # The synthetic generators hold millions of Python objects; a generation-2 collection in the
     # middle of the timed loop is a 30-60 ms host pause, longer than the launch queue is deep
     # (seen as one idle GPU gap on the slow-step workloads).  Collect now and freeze the survivors.
     import gc
     gc.collect()
     gc.freeze()
-    for i in range(args.warmup):
+    # Untimed ramp: a 20-step timed region is 2 ms of GPU time, and a GPU that was idle a moment ago
+    # has neither its clocks nor its launch queue in steady state after a 5-step warm-up (that run read
+    # 6 % low).  Whatever --warmup says, at least --ramp untimed steps precede the timed region.
+    ramp = max(0, args.ramp - args.warmup)
+    for i in range(ramp + args.warmup):
         step(i)
-    fence()
     # Kernel timing for the roofline legs happens INSIDE the timed region but is sampled: only every
     # 10th step is instrumented, and only the kernels the legs need (direct conv: slot 0; projection
     # GEMM + gather: slots 3, 4).  A HIP event record serialises the queue for ~3 us; instrumenting
     # every launch of every step cost 20 % of a 0.13 ms step, sampling costs ~1 %.
     mask = 0 if args.no_kernel_timing else (1 << 0) | (1 << 3) | (1 << 4) | \
         ((1 << 2) if hp['model_type'] in ('MF_dot', 'bias_only', 'transnet++') else 0)   # the Adam sweep is the leg
-    t0 = time.perf_counter()
-    dbg = [] if os.environ.get('R4R_BENCH_TRACE') else None   # host / GPU progress per 20 steps on stderr (how the GC pause was found)
-    gev = []
-    if dbg is not None:
-        gev.append(torch.cuda.Event(enable_timing=True))
-        gev[-1].record()
-    for i in range(args.steps):
-        lib.r4r_timing_enable(mask if i % 10 == 5 else 0)
-        step(args.warmup + i)
-        if dbg is not None and i % 20 == 19:
-            dbg.append(time.perf_counter() - t0)
-            gev.append(torch.cuda.Event(enable_timing=True))
-            gev[-1].record()
-    if dbg is not None:
-        print('enqueue wall at every 20th step (ms):', ' '.join('%.1f' % (1e3 * d) for d in dbg), file=sys.stderr)
-        torch.cuda.synchronize()
-        print('GPU ms per 20 steps:', ' '.join('%.1f' % gev[k].elapsed_time(gev[k + 1]) for k in range(len(gev) - 1)), file=sys.stderr)
-    fence()
-    elapsed = time.perf_counter() - t0
-    lib.r4r_timing_enable(0)
+    elapsed = timed_region(step, args.steps, ramp + args.warmup, mask)
+    steps_run = ramp + args.warmup + args.steps
     slots = {'textcnn_fwd_kernel': 0, 'textcnn_wgrad_kernel': 1, 'adam_multi_kernel': 2,
              'proj_gemm_kernel': 3, 'proj_gather_max_kernel': 4}
     timed = {}
@@ -325,25 +388,57 @@ def main():
         lib.r4r_timing_read(slot, ctypes.byref(tot), ctypes.byref(cnt), 0)
         if cnt.value:
             timed[name] = (tot.value / cnt.value, cnt.value)          # (avg ms per launch, launches)
-    lib.r4r_timing_read(0, ctypes.byref(ctypes.c_double()), ctypes.byref(ctypes.c_int64()), 1)
+    lib.r4r_timing_read(0, ctypes.byref(ctypes.c_double()), ctypes.byref(ctypes.c_int64()), 1)   # reset ALL slots
+    run_sse = float(engine.sse[0].item()) if engine is not None else (
+        float(graphed.sse.item()) if graphed is not None else float(metric_sum.item()))
 
-    el = torch.tensor([elapsed], device=dev)
+    # N > 1, weak: separately timed strong-scaling legs, each at a fixed global batch sharded over the ranks
+    strong_legs = []
+    if world > 1 and not strong and not args.from_host and graphed is None:
+        for G in [int(x) for x in str(args.strong_leg).split(',') if x.strip()]:
+            if G % world:
+                continue
+            bs = G // world
+            if engine is not None and native_step_limits(dict(hp, batch_size=bs), world):
+                continue
+            _, pool_s = make_pool(bs)
+            step_s = make_step(pool_s, bs, G)
+            for i in range(10):
+                step_s(i)
+            el_s = timed_region(step_s, args.steps, 10, 0)
+            strong_legs.append({'global_batch': G, 'batch_per_gpu': bs,
+                                'ratings_per_s': round(args.steps * G / el_s, 1),
+                                'ms_per_step': round(1000.0 * el_s / args.steps, 4), 'steps': args.steps})
+            del pool_s
+
+    # replica check: after identical gradient sums and the identical dense Adam every rank must hold
+    # the same bits; a broken exchange shows up here, not in a throughput number
+    replicas = None
     if world > 1:
-        torch.distributed.all_reduce(el, op=torch.distributed.ReduceOp.MAX)
-    elapsed = float(el.item())
+        flat = torch.cat([p.detach().reshape(-1).view(torch.int32).to(torch.int64) for p in model.parameters()
+                          if p.dtype == torch.float32])
+        digest = torch.stack([flat.sum(), (flat * (torch.arange(flat.numel(), device=dev) % 8191 + 1)).sum()])
+        allsum = [torch.empty_like(digest) for _ in range(world)]
+        torch.distributed.all_gather(allsum, digest)
+        replicas = all(bool((d == allsum[0]).all()) for d in allsum)
+        if not replicas:
+            raise SystemExit('bench.py: replicas diverged (parameter digests differ across ranks) -- the '
+                             'data-parallel exchange is broken; no number is reported')
 
     if rank == 0:
         value = args.steps * B_global / elapsed
         result = {
             'metric': 'train ratings/sec', 'value': round(value, 1), 'unit': 'ratings/s',
-            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'warmup_effective': ramp + args.warmup,
             'ms_per_step': round(1000.0 * elapsed / args.steps, 4),
-            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'higher_is_better': True, 'scaling': 'strong' if strong else 'weak', 'vs_baseline': None,
             'dtype': 'f32', 'data': 'synthetic' + (' (streamed from pinned host memory)' if args.from_host else ''),
             'config': {'workload': args.workload, 'ratings_per_step': B_global, 'batch_per_gpu': B,
                        'parallelism': 'dp%d' % world,
                        'engine': 'native' if engine is not None else ('graph' if graphed is not None else 'module'),
-                       'conv_algo': args.conv_algo,
+                       'conv_algo': args.conv_algo, 'doc_fill': args.doc_fill, 'token_dist': args.token_dist,
+                       **({'rccl_ranks': world, 'dist_backend': torch.distributed.get_backend(),
+                           'replicas_identical': replicas} if world > 1 else {}),
                        **({'dp_exchange': engine.exchange,
                            'dp_exchange_ms': {k: round(v, 4) for k, v in exchange_ms.items()}} if exchange_ms else {}),
                        'shape': {'recommender': hp['model_type'], 'word_embed_size': hp['word_embed_size'],
@@ -352,36 +447,50 @@ def main():
                                  'users': hp['total_users'], 'items': hp['total_items'],
                                  'dropout': hp['dropout']}},
         }
+        if strong_legs:
+            result['strong'] = strong_legs[0]                 # G = 1024 (2.70 M ratings/s at N = 1)
+            result['strong_legs'] = strong_legs
         result['kernel_ms'] = {k: round(v[0], 4) for k, v in timed.items()}
         towers = (3 if is_tn else 2) if engine is not None else 1    # the native step runs all towers per launch
-        positions = towers * B * (hp['input_length'] + 2)
         if 'proj_gather_max_kernel' in timed:
             # project-then-gather.  Dominant kernel: the projection GEMM over the
             # batch's DISTINCT tokens (fp32 MFMA).  Its useful flops are data dependent, so they are
             # counted on the host from the very batches that were run: rows x E x 300 x 2 per tower.
-            rows = np.mean([len(np.unique(d[3])) + len(np.unique(d[4])) + (len(np.unique(d[0])) if is_tn else 0)
-                            for d, _ in batches_np])
+            per_side = [np.mean([len(np.unique(d[k])) for d, _ in batches_np]) for k in ((3, 4, 0) if is_tn else (3, 4))]
+            rows = float(sum(per_side))
             g_s = timed['proj_gemm_kernel'][0] / 1000.0
             gflops = rows * hp['word_embed_size'] * 300 * 2
             ach = gflops / g_s / 1e12
+            traffic, src = measured_traffic('proj_gemm_kernel', args, g_s)
             result['roofline'] = {'kernel': 'proj_gemm_kernel', 'bound': 'mfma', 'achieved': round(ach, 2),
                                   'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                                   'frac': round(ach / PEAK_FP32_MFMA_TFLOPS, 4),
-                                  'traffic': measured_traffic('proj_gemm_kernel', args),
+                                  'traffic': traffic, 'traffic_source': src,
                                   'launches': timed['proj_gemm_kernel'][1], 'avg_launch_ms': round(1000 * g_s, 4),
-                                  'flops_per_launch': int(gflops), 'distinct_token_rows_per_launch': int(rows)}
-            # second leg: the gather-add-max kernel is HBM/L2-bound.  Algorithmic bytes per launch
-            # (SURVEY 8d): every position reads its three 400-B tap rows + an 8-B token id.
+                                  'flops_per_launch': int(gflops), 'distinct_token_rows_per_launch': int(rows),
+                                  'positions_per_launch': int(towers * B * hp['input_length'])}
+            # second leg: the gather-add-max kernel streams every position's three 400-B tap rows + an 8-B
+            # token id (1.2 KB + 8 B per position).  The projected rows it reads were written by
+            # the GEMM a moment ago and are L2 / Infinity-Cache resident (cfg3: 35 MB), so its ceiling is
+            # that cache's bandwidth, not HBM's: reported as achieved load bandwidth + the HBM-side bytes
+            # the PMC passes counted, with NO fraction of an HBM peak.  Only a vocabulary whose projected
+            # rows outgrow the 256 MB Infinity Cache (cfg5: 1 M words) makes this a true HBM gather.
             avg_s = timed['proj_gather_max_kernel'][0] / 1000.0
             nbytes = towers * B * hp['input_length'] * (8 + 1200)
             ach_b = nbytes / avg_s / 1e9
-            result['roofline_gather'] = {'kernel': 'proj_gather_max_kernel', 'bound': 'hbm',
-                                         'achieved': round(ach_b, 1), 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
-                                         'frac': round(ach_b / PEAK_HBM_GBS, 4),
-                                         'traffic': measured_traffic('proj_gather_max_kernel', args),
-                                         'avg_launch_ms': round(1000 * avg_s, 4), 'bytes_per_launch': nbytes,
-                                         'note': 'algorithmic bytes; the projected rows are L2/MALL resident, so '
-                                                 'this can exceed what HBM itself delivers'}
+            g_traffic, g_src = measured_traffic('proj_gather_max_kernel', args, avg_s)
+            ptab_bytes = rows * 1200
+            leg = {'kernel': 'proj_gather_max_kernel', 'achieved': round(ach_b, 1), 'unit': 'GB/s',
+                   'avg_launch_ms': round(1000 * avg_s, 4), 'bytes_per_launch': nbytes,
+                   'traffic': g_traffic, 'traffic_source': g_src, 'projected_rows_bytes': int(ptab_bytes)}
+            if ptab_bytes > 256e6:
+                leg.update({'bound': 'hbm', 'peak': PEAK_HBM_GBS, 'frac': round(ach_b / PEAK_HBM_GBS, 4)})
+            else:
+                leg.update({'bound': 'l2/mall', 'peak': None, 'frac': None,
+                            'hbm_side_GBs': None if g_traffic is None else round(g_traffic / avg_s / 1e9, 1),
+                            'note': 'algorithmic load bandwidth out of L2 / Infinity Cache (projected rows are '
+                                    'cache resident); hbm_side_GBs = PMC-counted HBM bytes / launch time'})
+            result['roofline_gather'] = leg
             result['conv_equivalent'] = {
                 'note': 'SURVEY 8d algorithmic conv flops (2 towers x P x 100 x 3E x 2 per rating) / (gemm + gather '
                         'time): what a direct conv would have to sustain to match',
@@ -394,9 +503,10 @@ def main():
                 nparam = model.user_embedding.weight.numel() + model.item_embedding.weight.numel()
                 avg_s = timed['adam_multi_kernel'][0] / 1000.0
                 ach_b = nparam * 24 / avg_s / 1e9
+                traffic, src = measured_traffic('mf_adam_kernel', args, avg_s)
                 result['roofline'] = {'kernel': 'mf_adam_kernel', 'bound': 'hbm', 'achieved': round(ach_b, 1),
                                       'peak': PEAK_HBM_GBS, 'unit': 'GB/s', 'frac': round(ach_b / PEAK_HBM_GBS, 4),
-                                      'traffic': measured_traffic('mf_adam_kernel', args),
+                                      'traffic': traffic, 'traffic_source': src,
                                       'launches': timed['adam_multi_kernel'][1],
                                       'avg_launch_ms': round(1000 * avg_s, 4), 'bytes_per_launch': int(nparam * 24),
                                       'parameters': int(nparam)}
@@ -416,18 +526,16 @@ def main():
             per = 24 if engine is not None else 28
             avg_s = timed['adam_multi_kernel'][0] / 1000.0
             ach_b = nparam * per / avg_s / 1e9
+            traffic, src = measured_traffic('mf_adam_kernel', args, avg_s) if engine is not None else (None, None)
             result['roofline'] = {'kernel': 'mf_adam_kernel' if engine is not None else 'adam_multi_kernel',
                                   'bound': 'hbm', 'achieved': round(ach_b, 1), 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
-                                  'frac': round(ach_b / PEAK_HBM_GBS, 4),
-                                  'traffic': measured_traffic('mf_adam_kernel', args) if engine is not None else None,
+                                  'frac': round(ach_b / PEAK_HBM_GBS, 4), 'traffic': traffic, 'traffic_source': src,
                                   'launches': timed['adam_multi_kernel'][1], 'avg_launch_ms': round(1000 * avg_s, 4),
                                   'bytes_per_launch': int(nparam * per), 'parameters': int(nparam)}
         if world == 1 and not args.no_cpu_baseline:
             cpu_hp = {k: v for k, v in hp.items() if k != 'word_vectors'}
             result['cpu_baseline'] = cpu_baseline(cpu_hp, table, batches_np[:4], args.cpu_seconds)
-        run_sse = float(engine.sse[0].item()) if engine is not None else (
-            float(graphed.sse.item()) if graphed is not None else float(metric_sum.item()))
-        result['train_mse_running'] = round(run_sse / ((args.steps + args.warmup) * B), 4)
+        result['train_mse_running'] = round(run_sse / (steps_run * B), 4)
         print(json.dumps(result))
     if world > 1:
         torch.distributed.destroy_process_group()

@@ -51,19 +51,32 @@ def word_table(V, E, rng=None):
 
 
 class Generator:
-    def __init__(self, hp, seed=SEED):
+    """doc_fill 'lognormal' (SURVEY 8d default: documents zero-padded to T) or 'full' (every document
+    fills all T positions: no pad run); token_dist 'zipf' (default) or 'uniform' (every word equally
+    likely: the most distinct tokens a batch can hold).  The non-default settings are stress points
+    for the project-then-gather convolution, whose work follows the batch's DISTINCT tokens."""
+
+    def __init__(self, hp, seed=SEED, doc_fill='lognormal', token_dist='zipf'):
         self.hp = hp
         self.rng = np.random.default_rng(seed)
         self.users = _zipf_sampler(hp['total_users'], 1.1, self.rng)
         self.items = _zipf_sampler(hp['total_items'], 1.1, self.rng)
+        if doc_fill not in ('lognormal', 'full') or token_dist not in ('zipf', 'uniform'):
+            raise ValueError('doc_fill / token_dist: %r / %r' % (doc_fill, token_dist))
+        self.doc_fill = doc_fill
         V = hp.get('vocab', 0)
         self.tokens = None
         if V:
-            tok = _zipf_sampler(V - 1, 1.0, self.rng)
-            self.tokens = lambda size: tok(size) + 1          # id 0 is the pad / UNK row
+            if token_dist == 'uniform':
+                self.tokens = lambda size: self.rng.integers(1, V, size=size)
+            else:
+                tok = _zipf_sampler(V - 1, 1.0, self.rng)
+                self.tokens = lambda size: tok(size) + 1      # id 0 is the pad / UNK row
 
     def _docs(self, lead, T):
         tok = self.tokens(lead + (T,))
+        if self.doc_fill == 'full':
+            return tok
         fill = np.minimum(T, self.rng.lognormal(math.log(0.4 * T), 1.0, size=lead)).astype(np.int64).clip(min=1)
         return np.where(np.arange(T) < fill[..., None], tok, 0)
 
