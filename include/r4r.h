@@ -57,6 +57,11 @@ int r4r_textcnn_fwd(const float *table, int64_t V, const int64_t *idx,
                     void *ws, size_t ws_bytes,
                     int64_t N, int T, int E, int F, void *stream);
 
+/* Form of the projection GEMM inside project-then-gather (A/B runs and tests; results are bit-identical):
+ * 1 = the balanced 7-row-tile form wherever its plan applies (default), 0 = always the 128-row tile form,
+ * -1 = take it from the environment again (R4R_GEMM=tile pins the tile form). */
+int r4r_gemm_form(int balanced);
+
 /* Backward of the tower w.r.t. conv weight and bias (the word table is frozen:
  * Embedding.from_pretrained, DeepCoNN.py:15 -- no dgrad exists).
  * Replaces  convolution_backward / max_pool2d_with_indices_backward /

@@ -44,6 +44,7 @@ struct ProjArgs {
     const float *table;
     int64_t N, V;
     int T, E, F, nchunk, tiles, cap;
+    int ntower, balanced;          // balanced: the GEMM may use its 7-row-tile form (R4R_GEMM=tile pins the tile form)
 };
 
 #ifdef R4R_TRACE
@@ -55,7 +56,7 @@ extern "C" int r4r_debug_trace(void *buf) {
 }
 #define TRACE_STAMP(k)                                                                                  \
     if (g_trace && threadIdx.x == 0)                                                                    \
-        g_trace[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 + (k)] = wall_clock64();
+        g_trace[((size_t)blockIdx.x) * 8 + (k)] = wall_clock64();
 #else
 #define TRACE_STAMP(k)
 #endif
@@ -82,7 +83,7 @@ __global__ __launch_bounds__(1024) void proj_compact_kernel(TokenArgs a) {
 // ---- 2. projection GEMM: Q[row, j*100+f] = table[list[row], :] . W[f, j, :].
 // The B operand is staged straight from the conv weight [F][3][E]: LDS row n = j*100+f takes
 // the 16 contiguous floats W[f][j][c*16 .. c*16+15] (four float4 per row).
-// grid = (cap/128 row tiles, ntower); ONE workgroup of 8 waves per 128-row tile: wave w owns rows
+// persistent grid (one workgroup per CU at most); ONE workgroup of 8 waves per 128-row tile: wave w owns rows
 // [32 (w & 3), +32) x column half (w >> 2) of the 304 columns (2 x (10 or 9) accumulators of
 // 16x16), so the A tile is staged once for both halves and a CU holds one workgroup whose two
 // waves per SIMD cover each other's stalls.  K runs in chunks of 16 floats through two LDS
@@ -104,14 +105,13 @@ constexpr int GEMM_BUF = (PM + WB_ROWS) * PS;               // floats per LDS bu
 constexpr int GEMM_LDS_BYTES = 2 * GEMM_BUF * 4;              // 86,016 B
 
 template <int NTILE, int NB>
-__device__ __forceinline__ void proj_gemm_body(const ProjArgs &a, float *lds) {
-    const ProjTower &tw = a.t[blockIdx.y];
+__device__ __forceinline__ void proj_gemm_body(const ProjArgs &a, float *lds, int tower, int row0) {
+    const ProjTower &tw = a.t[tower];
     const int count = tw.count[0];
-    const int row0 = blockIdx.x * PM;
     TRACE_STAMP(0)
 #ifdef R4R_TRACE
     if (g_trace && threadIdx.x == 0) {
-        unsigned long long *tr = g_trace + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8;
+        unsigned long long *tr = g_trace + ((size_t)blockIdx.x) * 8;
         tr[4] = __builtin_amdgcn_s_getreg((31 << 11) | 4);
         tr[5] = __builtin_amdgcn_s_getreg((31 << 11) | 20);
         tr[6] = 1;
@@ -235,7 +235,7 @@ __device__ __forceinline__ void proj_gemm_body(const ProjArgs &a, float *lds) {
     if (c < nchunk) step(c, av0, b0, av1, b1);
 #ifdef R4R_TRACE
     if (g_trace && threadIdx.x == 0)                        // shader cycles of the loop (vs the 100 MHz stamps: the clock)
-        g_trace[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 + 7] = __builtin_readcyclecounter() - clk0;
+        g_trace[((size_t)blockIdx.x) * 8 + 7] = __builtin_readcyclecounter() - clk0;
 #endif
     __syncthreads();                                        // all operand reads done: LDS is free
     TRACE_STAMP(2)
@@ -264,12 +264,290 @@ __device__ __forceinline__ void proj_gemm_body(const ProjArgs &a, float *lds) {
     TRACE_STAMP(3)
 }
 
+// ---- 2b. the balanced form of the projection GEMM.
+// The tile form above gives every workgroup 8 row tiles of 16 rows (128 rows x 304 columns = 152
+// MFMA tiles, 38 per SIMD) and leaves the CUs without a tile idle: at the headline batch 231 tiles on
+// 256 CUs, i.e. the launch takes the time of 8 row tiles where 7.2 per CU would do.  Row tiles cannot
+// be split, but a row tile's 19 COLUMN tiles can: here every workgroup owns 7 private row tiles and
+// the row tiles left over (total - 7 per workgroup) are each SHARED by >= 3 workgroups, which stage
+// its 16 rows next to their own 112 (the LDS image is the tile form's: 128 A rows + 320 B rows per
+// K chunk) and compute <= 7 of its column tiles each.  Inside the workgroup the 7 x 19 private tiles
+// are split by COLUMNS over the four SIMDs -- 5 / 5 / 5 / 4 column tiles, the two waves of a SIMD
+// sharing their 7 x NC block evenly -- so SIMDs 0-2 run 35 MFMA tiles per K step and SIMD 3 runs 28 +
+// the shared row tile's <= 7 (computed unconditionally, stored only where assigned: no branch in the
+// loop): 35 instead of 38 per SIMD, and every CU busy.  Same K order per output element as the tile form: identical bits.
+// The plan is a pure function of the towers' distinct-token counts (read by every workgroup); when
+// it does not apply -- fewer than 7 or more than 7 1/3 row tiles per workgroup -- the tile form runs.
+constexpr int G7_WGS = 256;        // persistent workgroups = CUs of an MI355X (one workgroup per CU by LDS)
+constexpr int G7_ROWS = 7;         // private row tiles per workgroup
+
+struct Gemm7Plan { int tower, row0, sh_row0, sh_c0, sh_n; };
+
+__device__ __forceinline__ bool gemm7_plan(const ProjArgs &a, int wg, int nwg, Gemm7Plan &p) {
+    int rt[MAX_TOWERS], g[MAX_TOWERS];
+    int U = 0;
+    for (int t = 0; t < a.ntower; ++t) { rt[t] = (a.t[t].count[0] + 15) >> 4; U += rt[t]; }
+    const int cap = nwg < G7_WGS ? nwg : G7_WGS;
+    int G = U / G7_ROWS;
+    if (G > cap) G = cap;
+    if (G < a.ntower) return false;
+    for (int t = 0; t < a.ntower; ++t) {
+        g[t] = rt[t] * G / U;                               // (products < 2^24: 32-bit arithmetic)
+        const int left = rt[t] - G7_ROWS * g[t];           // row tiles nobody owns: shared, >= 3 workgroups each
+        if (g[t] < 1 || left < 0 || 3 * left > g[t]) return false;
+    }
+    p.tower = -1;
+    int base = 0;
+    for (int t = 0; t < a.ntower; ++t) {
+        if (wg >= base && wg < base + g[t]) {
+            const int wl = wg - base, left = rt[t] - G7_ROWS * g[t];
+            p.tower = t;
+            p.row0 = wl * G7_ROWS * 16;
+            p.sh_row0 = -1; p.sh_c0 = 0; p.sh_n = 0;
+            if (left > 0) {
+                const int lt = wl * left / g[t];                                   // the shared row tile of this workgroup
+                const int w_lo = (lt * g[t] + left - 1) / left;                     // its sharers: [w_lo, w_hi)
+                const int w_hi = ((lt + 1) * g[t] + left - 1) / left;
+                const int n = w_hi - w_lo, k = wl - w_lo;
+                p.sh_row0 = (G7_ROWS * g[t] + lt) * 16;
+                p.sh_c0 = PNT * k / n;
+                p.sh_n = PNT * (k + 1) / n - p.sh_c0;                               // <= ceil(19 / 3) = 7
+            }
+        }
+        base += g[t];
+    }
+    return true;                                            // p.tower < 0: nothing to do for this workgroup
+}
+
+// One wave of the balanced form.  SIMD = wave & 3 owns NC column tiles (5, 5, 5, 4) of the 7 private row
+// tiles; its two waves split that 7 x NC block CHECKERBOARD-wise so that both carry the same load (18 / 17
+// tiles at NC = 5) -- a 4 + 3 row split leaves the lighter wave waiting at the chunk barrier while the
+// heavier one finishes alone, with nobody to fill the issue holes its memory instructions tear (measured:
+// 81 % pipe utilisation in the loop against the tile form's 92 %):
+//     HALF 0: row tiles 0..3 x the first CA columns  +  row tiles 4..6 x the rest     (CA = ceil(NC / 2))
+//     HALF 1: row tiles 0..3 x the rest              +  row tiles 4..6 x the first CA
+// EX: column tiles of the shared row tile this wave adds (SIMD 3 only).  NB: B rows this thread stages
+// per chunk (waves 0-3 stage three and are HALF 1, waves 4-7 two and are HALF 0).
+template <int NC, int HALF, int EX, int NB>
+__device__ __forceinline__ void proj_gemm7_body(const ProjArgs &a, float *lds, const Gemm7Plan &p) {
+    const ProjTower &tw = a.t[p.tower];
+    const int count = tw.count[0];
+    TRACE_STAMP(0)
+#ifdef R4R_TRACE
+    if (g_trace && threadIdx.x == 0) {
+        unsigned long long *tr = g_trace + ((size_t)blockIdx.x) * 8;
+        tr[4] = __builtin_amdgcn_s_getreg((31 << 11) | 4);
+        tr[5] = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+        tr[6] = 1;
+    }
+#endif
+    const float *__restrict__ table = a.table;
+    const int E = a.E, nchunk = a.nchunk;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lrow = lane & 15, q = lane >> 4, simd = wave & 3;
+    constexpr int NE = EX > 0 ? EX : 1;
+    constexpr int CA = (NC + 1) / 2;
+    constexpr int CT = HALF ? NC - CA : CA, CT0 = HALF ? CA : 0;      // column tiles of row tiles 0..3
+    constexpr int CB = HALF ? CA : NC - CA, CB0 = HALF ? 0 : CA;      // column tiles of row tiles 4..6
+    constexpr int RT = 4, RB = G7_ROWS - RT;
+
+    // staging role, as in the tile form: float4 column c4 of A row (tid >> 2) -- LDS rows 0..111 are the
+    // private rows, 112..127 the shared row tile -- and of B rows (tid >> 2) + 128 k
+    const int c4 = tid & 3, srow = tid >> 2;
+    int grow = srow < G7_ROWS * 16 ? p.row0 + srow : (p.sh_row0 < 0 ? 0 : p.sh_row0 + srow - G7_ROWS * 16);
+    grow = grow < count ? grow : count - 1;
+    const float *aptr = table + (long)tw.list[grow] * E;
+    const float *bptr[NB];
+    const float *__restrict__ conv_w = tw.conv_w;
+#pragma unroll
+    for (int k = 0; k < NB; ++k) {
+        const int n = srow + 128 * k;                       // n = j * 100 + f
+        const int j = n / PF, f = n - j * PF;
+        bptr[k] = conv_w + (n < PROW ? ((long)f * 3 + j) * E : 0);
+    }
+    f32x4 ar, br[NB];
+    auto issue_loads = [&](int c) {
+        const int e = min(c * PEC + c4 * 4, E - 4);
+        ar = *reinterpret_cast<const f32x4 *>(aptr + e);
+#pragma unroll
+        for (int k = 0; k < NB; ++k) br[k] = *reinterpret_cast<const f32x4 *>(bptr[k] + e);
+    };
+    auto write_lds = [&](float *buf, int c) {
+        const float keep = (c * PEC + c4 * 4 < E) ? 1.f : 0.f;
+        *reinterpret_cast<f32x4 *>(buf + srow * PS + c4 * 4) = ar;
+        float *Bl = buf + PM * PS;
+#pragma unroll
+        for (int k = 0; k < NB; ++k)
+            *reinterpret_cast<f32x4 *>(Bl + (srow + 128 * k) * PS + c4 * 4) = br[k] * keep;
+    };
+    f32x4 acct[RT][CT], accb[RB][CB], ex[NE];
+#pragma unroll
+    for (int mi = 0; mi < RT; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < CT; ++ni) acct[mi][ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int mi = 0; mi < RB; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < CB; ++ni) accb[mi][ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < NE; ++j) ex[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    constexpr int EOFF = HALF ? 4 : 0;                      // first shared-tile unit of this wave (SIMD 3 only)
+    const int cbase = simd * 5;                             // first column tile (SIMD 3: 15..18)
+    const int aoffl = lrow * PS + q * 4, boffl = (PM + cbase * 16 + lrow) * PS + q * 4;
+    const int saoffl = (G7_ROWS * 16 + lrow) * PS + q * 4;
+    int ecol[NE], eboffl[NE];
+#pragma unroll
+    for (int j = 0; j < NE; ++j) {
+        ecol[j] = min(p.sh_c0 + EOFF + j, PNT - 1);         // beyond the assignment: computed, never stored
+        eboffl[j] = (PM + ecol[j] * 16 + lrow) * PS + q * 4;
+    }
+    struct Ops { f32x4 av[G7_ROWS], b[NC], sa, eb[NE]; };
+    auto read_ops = [&](const float *buf, Ops &o) {
+#pragma unroll
+        for (int mi = 0; mi < G7_ROWS; ++mi) o.av[mi] = *reinterpret_cast<const f32x4 *>(buf + aoffl + mi * 16 * PS);
+#pragma unroll
+        for (int ni = 0; ni < NC; ++ni) o.b[ni] = *reinterpret_cast<const f32x4 *>(buf + boffl + ni * 16 * PS);
+        if (EX > 0) {
+            o.sa = *reinterpret_cast<const f32x4 *>(buf + saoffl);
+#pragma unroll
+            for (int j = 0; j < NE; ++j) o.eb[j] = *reinterpret_cast<const f32x4 *>(buf + eboffl[j]);
+        }
+    };
+    auto mfma = [&](const Ops &o, int kk) {
+#pragma unroll
+        for (int mi = 0; mi < RT; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < CT; ++ni)
+                acct[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(o.av[mi][kk], o.b[CT0 + ni][kk], acct[mi][ni], 0, 0, 0);
+#pragma unroll
+        for (int mi = 0; mi < RB; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < CB; ++ni)
+                accb[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(o.av[RT + mi][kk], o.b[CB0 + ni][kk], accb[mi][ni], 0, 0, 0);
+        if (EX > 0) {
+#pragma unroll
+            for (int j = 0; j < NE; ++j)
+                ex[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(o.sa[kk], o.eb[j][kk], ex[j], 0, 0, 0);
+        }
+    };
+    // the tile form's software pipeline (see there): LDS and operand registers double-buffered, staging
+    // registers a chunk ahead, one memory instruction behind every three MFMAs
+    auto step = [&](int c, const Ops &cur, Ops &nxt) {
+        __syncthreads();
+        write_lds(lds + (c & 1) * GEMM_BUF, c + 2);
+        issue_loads(c + 3);
+        mfma(cur, 0);
+        mfma(cur, 1);
+        read_ops(lds + ((c + 1) & 1) * GEMM_BUF, nxt);
+        mfma(cur, 2);
+        mfma(cur, 3);
+        constexpr int NREAD = G7_ROWS + NC + (EX > 0 ? 1 + EX : 0), NSTG = 1 + NB;
+        constexpr int NM = 4 * (RT * CT + RB * CB + EX);
+        constexpr int GAP = NM / (NREAD + 2 * NSTG) >= 3 ? 3 : 2;     // MFMAs between two memory instructions
+        static_assert(NM >= GAP * (NREAD + 2 * NSTG), "more memory instructions than MFMA slots");
+#pragma unroll
+        for (int i = 0; i < NSTG; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+            __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, GAP, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < NSTG; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, GAP, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < NREAD; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, GAP, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, NM - GAP * (NREAD + 2 * NSTG), 0);
+    };
+    Ops o0, o1;
+    issue_loads(0);
+    write_lds(lds, 0);
+    issue_loads(1);
+    __syncthreads();
+    read_ops(lds, o0);
+    write_lds(lds + GEMM_BUF, 1);
+    issue_loads(2);
+    TRACE_STAMP(1)
+#ifdef R4R_TRACE
+    const unsigned long long clk0 = __builtin_readcyclecounter();
+#endif
+    int c = 0;
+    for (; c + 1 < nchunk; c += 2) {
+        step(c, o0, o1);
+        step(c + 1, o1, o0);
+    }
+    if (c < nchunk) step(c, o0, o1);
+#ifdef R4R_TRACE
+    if (g_trace && threadIdx.x == 0)
+        g_trace[((size_t)blockIdx.x) * 8 + 7] = __builtin_readcyclecounter() - clk0;
+#endif
+    __syncthreads();                                        // all operand reads done: LDS is free
+    TRACE_STAMP(2)
+    // epilogue: per wave, one 16-row tile at a time through its own LDS slab, whole row segments as float4
+    constexpr int CMAX = CT > CB ? CT : CB;
+    constexpr int TS = CMAX * 16 + 4;
+    float *slab = lds + wave * (16 * (PNH_COLS + 4));
+    auto store_tile = [&](const f32x4 *row_acc, int ntile, int row_first, int col_tile0) {
+        const int nv = ntile * 4;
+        for (int ni = 0; ni < ntile; ++ni)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) slab[(q * 4 + r) * TS + ni * 16 + lrow] = row_acc[ni][r];
+        for (int i = lane; i < 16 * nv; i += 64) {
+            const int rr = i / nv, cv = i - rr * nv;
+            const int row = row_first + rr, col = col_tile0 * 16 + cv * 4;
+            if (row < count && col < PROW)
+                *reinterpret_cast<f32x4 *>(tw.ptab + (size_t)row * PROW + col) =
+                    *reinterpret_cast<const f32x4 *>(slab + rr * TS + cv * 4);
+        }
+    };
+#pragma unroll
+    for (int mi = 0; mi < RT; ++mi) store_tile(acct[mi], CT, p.row0 + mi * 16, cbase + CT0);
+#pragma unroll
+    for (int mi = 0; mi < RB; ++mi) store_tile(accb[mi], CB, p.row0 + (RT + mi) * 16, cbase + CB0);
+    if (EX > 0) {
+#pragma unroll
+        for (int j = 0; j < NE; ++j)
+            if (EOFF + j < p.sh_n && p.sh_row0 >= 0) store_tile(&ex[j], 1, p.sh_row0, ecol[j]);
+    }
+    TRACE_STAMP(3)
+}
+
 __global__ __launch_bounds__(GEMM_THREADS) void proj_gemm_kernel(ProjArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float *lds = reinterpret_cast<float *>(smem);
-    if ((int)blockIdx.x * PM >= a.t[blockIdx.y].count[0]) return;   // over-provisioned grid: uniform exit
-    if (threadIdx.x >> 8) proj_gemm_body<PNT - PNH, 2>(a, lds);   // waves 4..7: columns 160..303
-    else proj_gemm_body<PNH, 3>(a, lds);                          // waves 0..3: columns 0..159
+    if (a.balanced) {
+        Gemm7Plan p;
+        if (gemm7_plan(a, (int)blockIdx.x, (int)gridDim.x, p)) {
+            if (p.tower < 0) return;                         // uniform: this workgroup has no rows
+            const int wave = threadIdx.x >> 6;
+            if (wave < 4) {                                  // HALF 1 (17 tiles), three B rows to stage
+                if ((wave & 3) == 3) proj_gemm7_body<4, 1, 3, 3>(a, lds, p);
+                else proj_gemm7_body<5, 1, 0, 3>(a, lds, p);
+            } else {                                         // HALF 0 (18 tiles), two B rows to stage
+                if ((wave & 3) == 3) proj_gemm7_body<4, 0, 4, 2>(a, lds, p);
+                else proj_gemm7_body<5, 0, 0, 2>(a, lds, p);
+            }
+            return;
+        }
+    }
+    // tile form, persistent: the 128-row tiles of all towers form one list; workgroup w takes tiles
+    // w, w + gridDim.x, ... (a grid of one workgroup per CU: nothing is launched only to exit)
+    int first[MAX_TOWERS + 1];
+    first[0] = 0;
+    for (int t = 0; t < a.ntower; ++t) first[t + 1] = first[t] + (a.t[t].count[0] + PM - 1) / PM;
+    for (int tile = blockIdx.x; tile < first[a.ntower]; tile += gridDim.x) {
+        int t = 0;
+        while (tile >= first[t + 1]) ++t;
+        const int row0 = (tile - first[t]) * PM;
+        if (threadIdx.x >> 8) proj_gemm_body<PNT - PNH, 2>(a, lds, t, row0);   // waves 4..7: columns 160..303
+        else proj_gemm_body<PNH, 3>(a, lds, t, row0);                          // waves 0..3: columns 0..159
+        __syncthreads();                                    // the epilogue's LDS slabs are free again
+    }
 }
 
 // ---- 3. gather-add-max.  One workgroup = TWO 128-position segments of one document
@@ -299,7 +577,10 @@ __global__ __launch_bounds__(256) void proj_gather_max_kernel(ProjArgs a) {
     const int T = a.T, P = T + 2;
     const bool act = wl < PF / 4;
     const f32x4 zero = (f32x4){0.f, 0.f, 0.f, 0.f};
-    if (blockIdx.x == 0 && threadIdx.x == 0) tw.count[0] = 0;   // consumed by the GEMM launch before this one
+    if (blockIdx.x == 0 && threadIdx.x == 0) {              // consumed by the GEMM launch before this one
+        tw.count[1] = tw.count[0];                          // ... but remembered: the host's measured conv rule reads it
+        tw.count[0] = 0;
+    }
 
     const int seg = seg_base + (worker >> 2);               // workers 0-3: first segment, 4-7: second
     const int p_lo = seg * SEG + (worker & 3) * SLICE;
@@ -396,6 +677,8 @@ int proj_tiles(int T) { return (T + 2 + SEG - 1) / SEG; }
 int64_t proj_row_capacity(int64_t N, int T, int64_t V) { return (N * T < V) ? N * T : V; }
 size_t proj_ptab_floats(int64_t N, int T, int64_t V) { return (size_t)proj_row_capacity(N, T, V) * PROW; }
 
+static int g_gemm_balanced = -1;       // -1: from the environment (R4R_GEMM=tile pins the tile form) on first use
+
 static ProjArgs make_args(const float *table, int64_t V, const ProjTower *tw, int ntower,
                           int64_t N, int T, int E, int F) {
     ProjArgs a;
@@ -404,6 +687,12 @@ static ProjArgs make_args(const float *table, int64_t V, const ProjTower *tw, in
     a.nchunk = (E + PEC - 1) / PEC;
     a.tiles = proj_tiles(T);
     a.cap = (int)proj_row_capacity(N, T, V);
+    a.ntower = ntower;
+    if (g_gemm_balanced < 0) {
+        const char *e = getenv("R4R_GEMM");
+        g_gemm_balanced = (e && e[0] == 't') ? 0 : 1;
+    }
+    a.balanced = g_gemm_balanced;
     return a;
 }
 
@@ -442,7 +731,10 @@ int textcnn_proj_compute_launch(const float *table, int64_t V, const ProjTower *
     const ProjArgs a = make_args(table, V, tw, ntower, N, T, E, F);
     {
         ScopedTiming tm(R4R_TIMING_PROJ_GEMM, st);
-        proj_gemm_kernel<<<dim3((a.cap + PM - 1) / PM, ntower), GEMM_THREADS, GEMM_LDS_BYTES, st>>>(a);
+        // persistent: one workgroup per CU at most (86 KB of LDS each), fewer when the row capacity is small
+        int64_t wgs = ((int64_t)a.cap + G7_ROWS * 16 - 1) / (G7_ROWS * 16) * ntower;
+        if (wgs > G7_WGS) wgs = G7_WGS;
+        proj_gemm_kernel<<<dim3((unsigned)wgs), GEMM_THREADS, GEMM_LDS_BYTES, st>>>(a);
     }
     {
         ScopedTiming tm(R4R_TIMING_PROJ_GATHER, st);
@@ -450,6 +742,8 @@ int textcnn_proj_compute_launch(const float *table, int64_t V, const ProjTower *
     }
     return check_launch("textcnn_proj_fwd");
 }
+
+void proj_gemm_set_form(int balanced) { g_gemm_balanced = balanced; }
 
 int textcnn_proj_fwd_launch(const float *table, int64_t V, const ProjTower *tw, int ntower,
                             int64_t N, int T, int E, int F, bool zero_state, hipStream_t st) {

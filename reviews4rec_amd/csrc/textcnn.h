@@ -50,6 +50,7 @@ int textcnn_proj_tokens_launch(int64_t V, const ProjTower *tw, int ntower, int64
                                bool zero_state, hipStream_t st);
 int textcnn_proj_compute_launch(const float *table, int64_t V, const ProjTower *tw, int ntower,
                                 int64_t N, int T, int E, int F, hipStream_t st);
+void proj_gemm_set_form(int balanced);          // 1: balanced 7-row-tile form where it applies (default), 0: tile form, -1: env
 // R4R_CONV_AUTO / _DIRECT / _PROJECT (include/r4r.h) -> the algorithm to run; honours R4R_CONV_ALGO
 int textcnn_pick_algo(int requested, int64_t N, int T, int E, int F);
 

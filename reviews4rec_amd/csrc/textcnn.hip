@@ -458,6 +458,11 @@ extern "C" int r4r_textcnn_fwd(const float *table, int64_t V, const int64_t *idx
     return textcnn_pool_finish_launch(pmax, parg, pooled, argmax, N, textcnn_tiles(T), F, st);
 }
 
+extern "C" int r4r_gemm_form(int balanced) {
+    proj_gemm_set_form(balanced);
+    return R4R_OK;
+}
+
 extern "C" int r4r_textcnn_wgrad(const float *table, int64_t V, const int64_t *idx,
                                  const float *g_pooled, const int32_t *argmax,
                                  float *d_conv_w, float *d_conv_b,

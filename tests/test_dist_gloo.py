@@ -163,3 +163,115 @@ def test_sparse_table_gradients_are_exchanged_as_compact_lists(tmp_path):
             torch.testing.assert_close(r['bias'], want_b.view(-1))
             assert torch.equal(r['dense'], torch.full((4,), 3.0))
         assert torch.equal(r0['table'], r1['table']) and torch.equal(r0['bias'], r1['bias'])
+
+
+def _host_loop_worker(rank, world, port, out_dir):
+    """train_complete under data parallelism on the CPU (oracle stand-in for the model): the stage model
+    is re-bound to the exchange, global batch sizes come from ONE collective per epoch, only rank 0
+    writes the best-model file and nobody reads it early, and the three-optimiser TransNet step refuses
+    to run without its native engine."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, TESTS)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    torch.set_num_threads(1)
+    from helpers import Golden, OracleModule
+    from reviews4rec_amd import dist as r4dist, main as M
+    from reviews4rec_amd.loss import MSELoss
+    r4dist.init_from_env(backend='gloo')
+    g = Golden('mf_dot')
+    hp = dict(g.hp, epochs=2, dataset='Tiny', log_file=os.path.join(out_dir, 'log%d' % rank),
+              model_path=os.path.join(out_dir, 'best.pt'), engine='module', batch_size=4)
+    data, y = g.batch(0)                                      # 13 ratings -> global batches of 8, ragged tail
+
+    class Reader:
+        """This rank's contiguous shard of every global batch of 2 * batch_size ratings."""
+        def __init__(self):
+            self.batches = []
+            for s in range(0, y.shape[0], 8):
+                gd, gy = [None if d is None else d[s:s + 8] for d in data], y[s:s + 8]
+                self.batches.append(r4dist.shard_batch(gd, gy, rank, world))
+        def __len__(self):
+            return len(self.batches)
+        def batch_sizes(self):
+            return [int(b[1].shape[0]) for b in self.batches]
+        def iter(self, eval=False):
+            return iter(self.batches)
+
+    def rebuild(idx, gr, R, D, out):                          # CPU stand-in for r4r_embed_scatter_add_ordered
+        out.zero_()
+        keep = idx >= 0
+        out.index_add_(0, idx[keep], gr[keep])
+        return out
+
+    seen = {}
+
+    class Model(OracleModule):                                 # train_complete re-creates Model(hyper_params)
+        def __init__(self, hyper_params):
+            super().__init__(hyper_params, params=g.params())
+
+    model = Model(hp)
+    if rank == 1:
+        with torch.no_grad():
+            for p in model.parameters():
+                p.add_(0.5)                                    # rebind() must broadcast rank 0's weights
+    stale = Model(hp)
+    dp = r4dist.DataParallel(stale, rebuild_fn=rebuild, sparse_tables=False)
+    dp._active, dp._bucket = [0], torch.zeros(1)               # cached decisions about ANOTHER model
+    reader = Reader()
+    counts = dp.epoch_counts(reader)
+    assert counts == [8, 5], counts
+    assert dp.gather_ints([rank, 10 * rank]) == [[0, 0], [1, 10]]
+    # the reference's torch.optim.Adam stands in for the fused HIP Adam on this CPU rig
+    real_make = M.make_optimizer
+    M.make_optimizer = lambda hyper_params, m: torch.optim.Adam(
+        [p for p in m.parameters() if p.requires_grad], lr=hyper_params['lr'], weight_decay=hyper_params['weight_decay'])
+    M.is_cuda_available = False
+    best = M.train_complete(hp, Model, reader, reader, {}, {}, model, review=False, dp=dp)
+    M.make_optimizer = real_make
+    assert dp.model is model and dp._active is not None and len(dp.params) == len(list(model.parameters()))
+    torch.save({k: v.detach().clone() for k, v in model.as_dict().items()}, os.path.join(out_dir, 'hl%d.pt' % rank))
+    torch.save({k: v.detach().clone() for k, v in best.as_dict().items()}, os.path.join(out_dir, 'best%d.pt' % rank))
+    # ranks with different batch counts would hang the shorter rank's missing step: an error up front
+    class Short(Reader):
+        def batch_sizes(self):
+            return super().batch_sizes()[:1 + rank]
+    try:
+        dp.epoch_counts(Short())
+        raise AssertionError('unequal batch counts went unnoticed')
+    except RuntimeError as e:
+        assert 'batches this epoch' in str(e)
+    # TransNet's op-by-op three-optimiser step has no gradient exchange: refused under DP
+    try:
+        M.train(model, MSELoss(hp), [None] * 4, reader, dict(hp, model_type='transnet'), engine=None, dp=dp)
+        raise AssertionError('TransNet trained under DP without the native step')
+    except RuntimeError as e:
+        assert 'native step' in str(e)
+    dist.destroy_process_group()
+
+
+def test_host_loop_under_data_parallelism(tmp_path):
+    sys.path.insert(0, TESTS)
+    from helpers import Golden, OracleModule
+    from reviews4rec_amd.loss import MSELoss
+    port = _free_port()
+    mp.spawn(_host_loop_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    g = Golden('mf_dot')
+    data, y = g.batch(0)
+    ref = OracleModule(g.hp, params=g.params())
+    opt = torch.optim.Adam([p for p in ref.parameters() if p.requires_grad], lr=g.hp['lr'],
+                           weight_decay=g.hp['weight_decay'])
+    ref.train()
+    for epoch in range(2):
+        for s in range(0, y.shape[0], 8):
+            opt.zero_grad()
+            torch.mean(MSELoss(g.hp)(ref([None if d is None else d[s:s + 8] for d in data]), y[s:s + 8],
+                                     return_mean=False)).backward()
+            opt.step()
+    r0, r1 = torch.load(os.path.join(tmp_path, 'hl0.pt')), torch.load(os.path.join(tmp_path, 'hl1.pt'))
+    b0, b1 = torch.load(os.path.join(tmp_path, 'best0.pt')), torch.load(os.path.join(tmp_path, 'best1.pt'))
+    for k, v in ref.as_dict().items():
+        assert torch.equal(r0[k], r1[k]), k                  # replicas identical although rank 1 started elsewhere
+        assert torch.equal(b0[k], b1[k]), k                  # both ranks reloaded the same complete file
+        torch.testing.assert_close(r0[k], v.detach(), rtol=1e-5, atol=2e-6, msg=lambda m: k + ': ' + m)
+    assert not os.path.exists(os.path.join(tmp_path, 'best.pt.tmp'))

@@ -388,3 +388,35 @@ def test_fused_adam_unaligned_views_and_untouched_rows():
     oracle.adam_step(ref, {'p': grad}, st, 0.002, 1e-6)
     torch.testing.assert_close(p.detach().cpu(), ref['p'], rtol=1e-5, atol=1e-6)
     assert (p.detach().cpu()[10:] != before[10:]).all()
+
+
+@pytest.mark.parametrize('V', [336, 340, 1000, 3000, 28672, 29500, 30100, 41000])
+def test_projection_gemm_balanced_form_is_bit_identical_to_the_tile_form(V):
+    """The projection GEMM has two decompositions (csrc/project.hip): 128-row tiles, and the balanced form --
+    7 private row tiles per workgroup + a row tile shared column-wise by >= 3 workgroups -- chosen on the
+    device from the distinct-token count.  Counts on both sides of every edge of that plan (exactly 7 row
+    tiles per workgroup, a shared tile split 3 / 4 / 5 ways, the 256-workgroup cap, counts where the plan
+    does not apply): same bits either way, and equal to ATen."""
+    from reviews4rec_amd import _lib
+    ops = _ops()
+    E, T = 128, 100
+    N = -(-V // T) + 3
+    g = torch.Generator().manual_seed(V)
+    table = (torch.rand((V, E), generator=g) - 0.5) * 0.2
+    w = (torch.rand((100, 1, 3, E), generator=g) - 0.5) * (2 * math.sqrt(6.0 / (3 * E + 300 * E)))
+    b = (torch.rand(100, generator=g) - 0.5) * 0.1
+    idx = torch.cat([torch.randperm(V, generator=g), torch.randint(0, V, (N * T - V,), generator=g)]).view(N, T)
+    args = (idx.to(DEV), table.to(DEV), w.to(DEV), b.to(DEV))          # every one of the V rows is distinct-used
+    lib = _lib.lib()
+    try:
+        lib.r4r_gemm_form(0)
+        p0, a0 = ops.textcnn_fwd_raw(*args)
+        p0, a0 = p0.clone(), a0.clone()
+        lib.r4r_gemm_form(1)
+        p1, a1 = ops.textcnn_fwd_raw(*args)
+    finally:
+        lib.r4r_gemm_form(-1)
+    assert torch.equal(p0, p1) and torch.equal(a0, a1)
+    if V <= 3000:
+        ref_pooled, ref_arg, y = conv_pool_reference(idx, table, w, b)
+        torch.testing.assert_close(p1.cpu(), ref_pooled, rtol=1e-5, atol=1e-6)
