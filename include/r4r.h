@@ -57,6 +57,18 @@ int r4r_textcnn_fwd(const float *table, int64_t V, const int64_t *idx,
                     void *ws, size_t ws_bytes,
                     int64_t N, int T, int E, int F, void *stream);
 
+/* The algorithm a request resolves to: `requested` R4R_CONV_AUTO / _DIRECT / _PROJECT for N documents (per
+ * tower) of T words, embed size E, F filters -> R4R_CONV_DIRECT or R4R_CONV_PROJECT (the static
+ * R4R_CONV_AUTO rule and the R4R_CONV_ALGO environment pin applied). */
+int r4r_conv_algo(int requested, int64_t N, int T, int E, int F);
+
+/* The MEASURED rule behind the engines' automatic choice: project-then-gather's work follows the batch's
+ * DISTINCT tokens, the direct conv's its positions.  `rows`: distinct tokens of a batch summed over its
+ * towers (left by the gather kernel next to each tower's token counter: the int after it), `docs`:
+ * documents summed over the towers, V: vocabulary.  Returns R4R_CONV_PROJECT or R4R_CONV_DIRECT by a cost
+ * model fitted to MI355X measurements.  Host-side arithmetic, no device work. */
+int r4r_conv_pick(int E, int T, int64_t docs, int64_t rows, int64_t V);
+
 /* Form of the projection GEMM inside project-then-gather (A/B runs and tests; results are bit-identical):
  * 1 = the balanced 7-row-tile form wherever its plan applies (default), 0 = always the 128-row tile form,
  * -1 = take it from the environment again (R4R_GEMM=tile pins the tile form). */
@@ -266,6 +278,7 @@ int r4r_deepconn_nparam(void);
 int r4r_deepconn_layout(int E, int L, int64_t *offsets, int64_t *sizes, int64_t *total);
 size_t r4r_deepconn_ws_bytes(int64_t B, int T, int E, int L, int64_t V);
 size_t r4r_deepconn_ws_mult_offset(int64_t B, int T, int E, int L, int64_t V);   /* [B,2L] dropout multipliers (tests) */
+size_t r4r_deepconn_ws_count_offset(int64_t B, int T, int E, int L, int64_t V, int tower, int buffer);   /* token counter of (tower, token buffer): int[0] live count, int[1] the count the last gather consumed */
 int r4r_deepconn_step(const float *table, int64_t V, const int64_t *user_idx, const int64_t *item_idx,
                       const float *y, float *flat_p, float *flat_g,
                       float *pred, float *se, float *sse_accum,

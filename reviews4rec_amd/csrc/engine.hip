@@ -494,6 +494,12 @@ extern "C" size_t r4r_deepconn_ws_mult_offset(int64_t B, int T, int E, int L, in
     return (size_t)(reinterpret_cast<char *>(w.mult) - base);
 }
 
+extern "C" size_t r4r_deepconn_ws_count_offset(int64_t B, int T, int E, int L, int64_t V, int tower, int buffer) {
+    char base[1];
+    const StepWs w = carve(base, B, T, E, L, V);
+    return (size_t)(reinterpret_cast<char *>(w.count[buffer & 1][tower & 1]) - base);
+}
+
 // Token compaction of a batch into token-state buffer `token_buffer` (project-then-gather only;
 // a no-op for configurations that run the direct conv).  Depends only on the indices: run it for
 // batch k+1 on a side stream while step k computes, then pass tokens_ready = 1 to that step.

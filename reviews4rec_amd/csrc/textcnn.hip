@@ -458,6 +458,32 @@ extern "C" int r4r_textcnn_fwd(const float *table, int64_t V, const int64_t *idx
     return textcnn_pool_finish_launch(pmax, parg, pooled, argmax, N, textcnn_tiles(T), F, st);
 }
 
+// Which algorithm a request runs (the static rule above + the R4R_CONV_ALGO pin): hosts that keep
+// per-algorithm state (prepared token buffers) ask instead of restating the rule.
+extern "C" int r4r_conv_algo(int requested, int64_t N, int T, int E, int F) {
+    return textcnn_pick_algo(requested, N, T, E, F);
+}
+
+// Measured rule: given what a batch actually holds -- `rows` distinct tokens (summed over the towers)
+// in `docs` documents of T words -- is the projection (GEMM over the distinct rows + gather-add-max +
+// token compaction over V words) or the direct conv (every position) the faster forward?  Cost model
+// fitted to MI355X measurements at E = 64 and 300 (DESIGN.md 4.1c lists them, profiles/r02_conv_rule.txt):
+//   direct      0.12 + 0.0051 E ns per position, positions rounded up to 128 per document
+//   GEMM        (11 + 0.14 E) us per started wave of 256 row tiles of 128 rows
+//   gather      0.085 ns + 0.0006 ns per MB of projected rows (1200 B each), per position
+//   tokens      4 us + 0.027 us per 1000 words of vocabulary
+extern "C" int r4r_conv_pick(int E, int T, int64_t docs, int64_t rows, int64_t V) {
+    if (E <= 0 || T <= 0 || docs <= 0 || rows <= 0) return R4R_CONV_PROJECT;
+    const double P = (double)(T + 2);
+    const double padded = (double)docs * (double)(((int64_t)P + 127) / 128 * 128);
+    const double t_direct = padded * (0.12 + 0.0051 * E) * 1e-3;                            // us
+    const double waves = (double)((rows + 32767) / 32768);
+    const double t_gemm = waves * (11.0 + 0.14 * E);
+    const double t_gather = (double)docs * P * (0.085 + 0.0006 * ((double)rows * 1200.0 / 1e6)) * 1e-3;
+    const double t_tokens = 4.0 + 0.027 * ((double)V / 1000.0);
+    return (t_gemm + t_gather + t_tokens < t_direct) ? R4R_CONV_PROJECT : R4R_CONV_DIRECT;
+}
+
 extern "C" int r4r_gemm_form(int balanced) {
     proj_gemm_set_form(balanced);
     return R4R_OK;

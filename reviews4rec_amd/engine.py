@@ -21,7 +21,53 @@ from . import _lib
 from ._lib import ptr
 
 
-class DeepCoNNEngine:
+class _ConvRule:
+    """The engines' automatic choice between the two convolution algorithms (conv_algo = 0).
+
+    project-then-gather's work follows the batch's DISTINCT tokens, the direct conv's its positions, so
+    which is faster depends on the data (at cfg5's million-word vocabulary the direct
+    conv wins by 10-45 % on full-length or uniformly drawn documents, projection wins on Amazon-shaped
+    ones).  The distinct count of a batch is on the device anyway (the token compaction's counter; the
+    gather kernel leaves it next to the live counter), so the rule MEASURES: shapes the static rule sends
+    to the direct conv (narrow windows, small launches) stay there; everything else starts on projection,
+    and at training step PROBE_AT and every PROBE_EVERY steps after it the step runs projection, its
+    counters are read back (one stream sync per probe) and r4r_conv_pick's cost model decides what the
+    following steps run.  Deterministic: the probe points are fixed step numbers and the decision is a
+    pure function of the probed batch.  Both algorithms compute the same function (parity-tested against
+    each other and the reference), so a switch only changes fp32 summation order."""
+    PROBE_AT, PROBE_EVERY = 4, 1024
+
+    def _rule_reset(self):
+        self._rule_n = 0                 # training steps the rule has seen
+        self._rule_choice = None         # None until the first probe
+        self.conv_rows = None            # distinct rows (all towers) of the last probe
+
+    def _rule_request(self, docs_per_tower, T, training):
+        """-> (algorithm to request from the C step, the one that will actually run, probe this step?)"""
+        lib = _lib.lib()
+        req, probe = self.conv_algo, False
+        if req == 0 and lib.r4r_conv_algo(0, docs_per_tower, T, self.E, 100) == 2:
+            n = self._rule_n
+            probe = bool(training) and n >= self.PROBE_AT and (n - self.PROBE_AT) % self.PROBE_EVERY == 0
+            req = 2 if (probe or self._rule_choice is None) else self._rule_choice
+            if training:
+                self._rule_n += 1
+        return req, lib.r4r_conv_algo(req, docs_per_tower, T, self.E, 100), probe
+
+    def _rule_decide(self, counters, docs_total, T):
+        """`counters`: per tower the int32 [live, last] pair of the token buffer the probe step used."""
+        torch.cuda.current_stream(self.dev).synchronize()
+        self.conv_rows = int(sum(int(c.view(torch.int32)[1]) for c in counters))
+        if self.conv_rows > 0:
+            self._rule_choice = int(_lib.lib().r4r_conv_pick(self.E, T, docs_total, self.conv_rows, self.V))
+
+    @property
+    def conv_choice(self):
+        """'project' / 'direct' once measured, None before the first probe (or when conv_algo pins one)."""
+        return {None: None, 1: 'direct', 2: 'project'}[self._rule_choice]
+
+
+class DeepCoNNEngine(_ConvRule):
     def __init__(self, model, lr=0.002, weight_decay=1e-6, betas=(0.9, 0.999), eps=1e-8, dp=None,
                  seed=0x5EED5EED, rank=0, conv_algo=0):
         hp = model.hyper_params
@@ -75,6 +121,7 @@ class DeepCoNNEngine:
         self._prepared = None           # (key, buffer, event) of a batch whose tokens are already compacted
         self._last_buf = 1
         self._step_done = [None, None]  # per buffer: event after the last step that read it
+        self._rule_reset()
 
     # ------------------------------------------------------------------ buffers
     def _workspace(self, B, T):
@@ -124,6 +171,9 @@ class DeepCoNNEngine:
         if self._ws_key != (n, T):
             return                                           # different shape: that step will build its own
         lib = _lib.lib()
+        req = self.conv_algo or (self._rule_choice or 0)
+        if lib.r4r_conv_algo(req, n, T, self.E, 100) != 2:
+            return                                           # that step runs the direct conv: no token state
         if self._side is None:
             self._side = torch.cuda.Stream(device=self.dev)
         main = torch.cuda.current_stream(self.dev)
@@ -135,7 +185,7 @@ class DeepCoNNEngine:
         else:
             self._side.wait_stream(main)                     # first use: order after everything issued so far
         rc = lib.r4r_deepconn_tokens(ptr(user_idx), ptr(item_idx), ptr(self._ws), self._ws.numel(), n, T,
-                                     self.E, self.L, self.V, self.conv_algo, buf, 0, self._side.cuda_stream)
+                                     self.E, self.L, self.V, 2, buf, 0, self._side.cuda_stream)
         _lib.check(rc, 'r4r_deepconn_tokens')
         ev = torch.cuda.Event()
         ev.record(self._side)
@@ -149,7 +199,7 @@ class DeepCoNNEngine:
             main.wait_event(pev)
         u, i = keep
         _lib.check(_lib.lib().r4r_deepconn_tokens(ptr(u), ptr(i), ptr(self._ws), self._ws.numel(), key[2], key[3],
-                                                  self.E, self.L, self.V, self.conv_algo, pbuf, 1, main.cuda_stream),
+                                                  self.E, self.L, self.V, 2, pbuf, 1, main.cuda_stream),
                    'r4r_deepconn_tokens(discard)')
         if self._side is not None:
             dropped = torch.cuda.Event()
@@ -165,32 +215,34 @@ class DeepCoNNEngine:
         ws = self._workspace(n, T)
         p_drop = float(self.hp['dropout'])
         main = torch.cuda.current_stream(self.dev)
+        req, algo, probe = self._rule_request(n, T, grad)
+        projecting = algo == 2                               # only that algorithm has token state
         nxt = None
-        if next_data is not None and grad:
+        if next_data is not None and grad and projecting:
             nu, ni, nn = self._indices(next_data)
             if (nn, nu.shape[1]) == (n, T):                  # same shape: same workspace layout
                 nxt = (nu, ni)
         ready = 0
-        if self._prepared is not None and self._prepared[0] == self._key(user_idx, item_idx, n):
+        if projecting and self._prepared is not None and self._prepared[0] == self._key(user_idx, item_idx, n):
             buf, ev = self._prepared[1], self._prepared[2]
             if ev is not None:
                 main.wait_event(ev)
             self._prepared = None
             ready = 1
         else:
-            if self._prepared is not None and nxt is not None:
-                self._discard_prepared(main)                 # its buffer is needed for the new guess
+            if self._prepared is not None and (nxt is not None or not projecting):
+                self._discard_prepared(main)                 # its buffer is needed, or nobody will consume it
             buf = (self._prepared[1] ^ 1) if self._prepared is not None else self._last_buf ^ 1
         rc = _lib.lib().r4r_deepconn_step(
             ptr(self.table), self.V, ptr(user_idx), ptr(item_idx), ptr(y), ptr(self.flat_p),
             ptr(self.flat_g) if grad else None, ptr(pred), ptr(se), ptr(self.sse) if y is not None else None,
             ptr(ws), ws.numel(), n, T, self.E, self.L, p_drop, int(training), self.seed, self.offset,
-            float(inv_denom), self.conv_algo, buf, ready,
+            float(inv_denom), req, buf, ready,
             ptr(nxt[0]) if nxt else None, ptr(nxt[1]) if nxt else None,
             ptr(self.flat_m) if adam_step else None, ptr(self.flat_v) if adam_step else None,
             self.lr, self.betas[0], self.betas[1], self.eps, self.wd, int(adam_step), main.cuda_stream)
         _lib.check(rc, 'r4r_deepconn_step')
-        if nxt is not None:      # (a step that runs the direct conv ignores token state altogether)
+        if nxt is not None:
             self._prepared = (self._key(nxt[0], nxt[1], n), buf ^ 1, None, nxt)
         self._last_buf = buf
         if self._side is not None:                           # only pay for the event when prefetching is in use
@@ -199,6 +251,10 @@ class DeepCoNNEngine:
             self._step_done[buf] = done
         if training and p_drop > 0.0:
             self.offset += n * 2 * self.L
+        if probe and projecting:
+            lib = _lib.lib()
+            at = [lib.r4r_deepconn_ws_count_offset(n, T, self.E, self.L, self.V, t, buf) for t in range(2)]
+            self._rule_decide([ws[a:a + 8] for a in at], 2 * n, T)
         return pred, se
 
     def train_step(self, data, y, n_global=None, next_data=None):
@@ -505,7 +561,7 @@ class MFEngine:
             ws.zero_()
 
 
-class NarreEngine:
+class NarreEngine(_ConvRule):
     """Native step for NARRE (csrc/narre_engine.hip, r4r_narre_step): TextCNN over the B*R review
     documents of each side, both attention scorers, the ID vectors, `final`, the bias head, SE,
     the backward and the dense Adam update in five launches (the op-by-op path needs ~130).
@@ -569,6 +625,8 @@ class NarreEngine:
         self.offset = 0
         self._ws, self._ws_key, self._out = None, None, {}
         self._prepared, self._last_buf = None, 1
+        self._algo_req = self.conv_algo
+        self._rule_reset()
 
     SSE_SLOTS = 1
 
@@ -638,7 +696,7 @@ class NarreEngine:
             self._p4(self.rows_v) if (adam_step and self.dp is None) else None,
             self.n_users, self.n_items, ptr(pred), ptr(se), ptr(self.sse) if adam_step else None,
             ptr(ws), ws.numel(), n, R, T, self.E, self.L, float(self.hp['dropout']), int(train_mode), self.seed,
-            self.offset, float(inv_denom), self.conv_algo, buf, ready,
+            self.offset, float(inv_denom), self._algo_req, buf, ready,
             ptr(nxt[0]) if nxt else None, ptr(nxt[1]) if nxt else None,
             self.lr, self.betas[0], self.betas[1], self.eps, self.wd, int(adam_step), _lib.current_stream())
 
@@ -649,19 +707,21 @@ class NarreEngine:
                             torch.empty(n, dtype=torch.float32, device=self.dev))
         pred, se = self._out[n]
         ws = self._workspace(n, R, T)
+        self._algo_req, algo, probe = self._rule_request(n * R, T, bool(adam_step))
+        projecting = algo == 2                               # only that algorithm has token state
         nxt = None
-        if next_data is not None and adam_step:
+        if next_data is not None and adam_step and projecting:
             nf, nn, nR, nT = self._fields(next_data)
             if (nn, nR, nT) == (n, R, T):
                 nxt = nf
         key = tuple(t.data_ptr() for t in f[:self.NTOWER]) + (n, R, T)
         ready = 0
-        if self._prepared is not None and self._prepared[0] == key:
+        if projecting and self._prepared is not None and self._prepared[0] == key:
             buf, ready = self._prepared[1], 1
             self._prepared = None
         else:
-            if self._prepared is not None:                   # a wrong guess: drop its token state
-                pb = self._prepared[1]
+            if self._prepared is not None:                   # a wrong guess, or a step that will not consume it:
+                pb = self._prepared[1]                       # drop its token state
                 for t in range(self.NTOWER):                 # the compaction counters of that buffer
                     at = self._ws_offset(n, R, T, 6 + 2 * t + pb)
                     ws[at:at + 4].zero_()
@@ -675,6 +735,9 @@ class NarreEngine:
             self._prepared = (tuple(t.data_ptr() for t in nxt[:self.NTOWER]) + (n, R, T), buf ^ 1, nxt)
         if train_mode and float(self.hp['dropout']) > 0.0:
             self.offset += n * self._draws(R)
+        if probe and projecting:
+            at = [self._ws_offset(n, R, T, 6 + 2 * t + buf) for t in range(self.NTOWER)]
+            self._rule_decide([ws[a:a + 8] for a in at], self.NTOWER * n * R, T)
         return pred, se
 
     # ---- data parallel: gradients only on this rank (the C step with flat_m = NULL), C1 -- one
@@ -906,7 +969,7 @@ class DeepCoNNPPEngine(NarreEngine):
             p2(self.rows_v) if (adam_step and self.dp is None) else None,
             self.n_users, self.n_items, ptr(pred), ptr(se), ptr(self.sse) if adam_step else None,
             ptr(ws), ws.numel(), n, T, self.E, self.L, float(self.hp['dropout']), int(train_mode), self.seed,
-            self.offset, float(inv_denom), self.conv_algo, buf, ready,
+            self.offset, float(inv_denom), self._algo_req, buf, ready,
             ptr(nxt[0]) if nxt else None, ptr(nxt[1]) if nxt else None,
             self.lr, self.betas[0], self.betas[1], self.eps, self.wd, int(adam_step), _lib.current_stream())
 
@@ -995,7 +1058,7 @@ class TransNetEngine(NarreEngine):
             p2(self.rows_v) if (adam_step and self.dp is None) else None,
             self.n_users, self.n_items, ptr(pred), ptr(se), ptr(self.sse) if adam_step else None,
             ptr(ws), ws.numel(), n, T, self.E, self.L, self.plus, float(self.hp['dropout']), int(train_mode), self.seed,
-            self.offset, float(inv_denom), self.conv_algo, buf, ready,
+            self.offset, float(inv_denom), self._algo_req, buf, ready,
             ptr(nxt[0]) if nxt else None, ptr(nxt[1]) if nxt else None, ptr(nxt[2]) if nxt else None,
             self.lr, self.betas[0], self.betas[1], self.eps, self.wd, int(adam_step), _lib.current_stream())
 

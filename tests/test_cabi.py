@@ -147,3 +147,23 @@ def test_integration_stub_matches_the_header():
             depth -= ch in ')]'
             n += (ch == ',' and depth == 0)
         assert n == len(decls[name][1]), (name, n)
+
+
+def test_conv_pick_reproduces_the_measured_decisions():
+    """r4r_conv_pick's cost model against the twelve (configuration, data) points measured on MI355X
+    (profiles/r02_conv_rule.txt): distinct rows -> the algorithm that was faster."""
+    from reviews4rec_amd import _lib
+    lib = _lib.lib()
+    PROJECT, DIRECT = 2, 1
+    points = [   # E, T, documents (all towers), vocabulary, [(distinct rows, faster algorithm), ...]
+        (300, 1000, 256, 50002, [(29547, PROJECT), (45464, PROJECT), (71421, PROJECT), (92264, PROJECT)]),      # cfg3
+        (64, 100, 2560, 50002, [(19741, PROJECT), (31970, PROJECT), (49182, PROJECT), (75188, PROJECT)]),       # cfg4
+        (64, 1000, 384, 1000000, [(76899, PROJECT), (137449, DIRECT), (177702, DIRECT), (360391, DIRECT)]),     # cfg5
+    ]
+    for E, T, docs, V, cases in points:
+        for rows, want in cases:
+            assert lib.r4r_conv_pick(E, T, docs, rows, V) == want, (E, T, docs, V, rows)
+    # the request -> algorithm map the engines consult (static rule; F != 100 has no projection kernels)
+    assert lib.r4r_conv_algo(0, 128, 1000, 300, 100) == PROJECT and lib.r4r_conv_algo(0, 8, 100, 64, 100) == DIRECT
+    assert lib.r4r_conv_algo(1, 128, 1000, 300, 100) == DIRECT and lib.r4r_conv_algo(2, 8, 100, 64, 100) == PROJECT
+    assert lib.r4r_conv_algo(2, 128, 1000, 300, 64) == DIRECT

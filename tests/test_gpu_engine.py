@@ -2,6 +2,9 @@
 reference-generated golden trajectories, the autograd module path and the CPU
 oracle (dropout masks drawn on the device and injected into the oracle)."""
 import copy
+import os
+
+import numpy as np
 
 import pytest
 import torch
@@ -1036,3 +1039,49 @@ def test_narre_rows_apply_thousands_of_gathered_entries():
         refP = [params[str(k)] for k in range(4)]
     for k in range(4):
         torch.testing.assert_close(P[k].cpu(), refP[k], rtol=1e-5, atol=5e-6, msg=lambda m: 'table %d: %s' % (k, m))
+
+
+@pytest.mark.parametrize('dist,expect', [('uniform', 'direct'), ('zipf', 'project')])
+def test_conv_rule_measures_the_distinct_tokens_and_flips(dist, expect):
+    """conv_algo = 0: the engine probes the batch's distinct-token count (left on the device by the gather
+    kernel) at a fixed step and lets r4r_conv_pick choose.  Uniformly drawn full-length documents over a
+    300k-word vocabulary (E = 64) hold ~208k distinct rows in 256k positions: the direct conv is faster and
+    the rule must flip to it; Zipf documents with zero-padded tails stay on projection.  The count it read is
+    exactly numpy's, and training through the flip lands where a projection-only run lands."""
+    import reviews4rec_amd
+    from reviews4rec_amd.engine import DeepCoNNEngine
+    from reviews4rec_amd import synthetic
+    if os.environ.get('R4R_CONV_ALGO'):
+        pytest.skip('R4R_CONV_ALGO pins the algorithm')
+    V, E, B, T = 300000, 64, 128, 1000
+    hp = dict(model_type='deepconn', latent_size=10, word_embed_size=E, input_length=T, dropout=0.0, total_users=500,
+              total_items=300, lr=0.002, weight_decay=1e-6, vocab=V)
+    table = synthetic.word_table(V, E)
+    gen = synthetic.Generator(dict(hp), seed=11, doc_fill='full' if dist == 'uniform' else 'lognormal', token_dist=dist)
+    batches = []
+    for _ in range(3):
+        d, y = gen.batch(B)
+        batches.append(([torch.from_numpy(x).cuda() for x in d], torch.from_numpy(y).cuda(), d))
+
+    def run(conv_algo):
+        torch.manual_seed(3)
+        model = reviews4rec_amd.get_model_class('deepconn')(dict(hp, word_vectors=table))
+        from reviews4rec_amd.utils import xavier_init
+        xavier_init(model)
+        eng = DeepCoNNEngine(model.cuda().train(), lr=hp['lr'], weight_decay=hp['weight_decay'], conv_algo=conv_algo)
+        rows_seen = None
+        for k in range(DeepCoNNEngine.PROBE_AT + 4):
+            data, y, _ = batches[k % 3]
+            eng.train_step(data, y, next_data=batches[(k + 1) % 3][0])
+            if k == DeepCoNNEngine.PROBE_AT:
+                rows_seen = (eng.conv_rows, k % 3)
+        pred, _ = eng.predict(batches[0][0])
+        return eng, rows_seen, pred.clone()
+
+    auto, rows_seen, pred_auto = run(0)
+    assert auto.conv_choice == expect
+    d = batches[rows_seen[1]][2]
+    assert rows_seen[0] == len(np.unique(d[3])) + len(np.unique(d[4]))
+    pinned, _, pred_proj = run(2)
+    assert pinned.conv_choice is None
+    torch.testing.assert_close(pred_auto, pred_proj, rtol=2e-4, atol=2e-4)
