@@ -53,6 +53,8 @@ class DataLoader():
         for k in KEYS:
             dt = np.float32 if k == 'h' else np.int64
             self._t[k] = torch.from_numpy(np.ascontiguousarray(arrays[k]).astype(dt, copy=False))
+        self._tail = {k: tuple(self._t[k].shape[1:]) for k in KEYS}      # per-row shape of every field
+        arrays = None
         # Batches are fixed contiguous slices (the reference never shuffles, data_fast.py:99), so each
         # batch is packed ONCE into one contiguous pinned block [a | b | ... | g | h-as-int64-bits]:
         # one H2D copy per batch instead of eight, and the device-side fields are contiguous views.
@@ -62,23 +64,26 @@ class DataLoader():
         self.group = max(1, int(hyper_params.get('h2d_group', 8)))
         self._packed, self._layout = [], []
         if pin:
-            blocks = []
-            for index in range(0, self.total, self.bsz):
+            def block(index):
                 sl = slice(index, index + self.bsz)
                 parts = [self._t[k][sl].reshape(-1) for k in KEYS[:7]]
                 yb = self._t['h'][sl]
                 ypad = torch.zeros(yb.numel() + (yb.numel() & 1), dtype=torch.float32)
                 ypad[:yb.numel()] = yb
                 parts.append(ypad.view(torch.int64))
-                blocks.append(torch.cat(parts))
-            for g0 in range(0, len(blocks), self.group):
-                grp = blocks[g0:g0 + self.group]
+                return torch.cat(parts)
+            starts = list(range(0, self.total, self.bsz))
+            for g0 in range(0, len(starts), self.group):       # one group at a time: never a second full copy
+                grp = [block(i) for i in starts[g0:g0 + self.group]]
                 self._packed.append(torch.cat(grp).pin_memory())
                 offs, at = [], 0
                 for blk in grp:
                     offs.append((at, blk.numel()))
                     at += blk.numel()
                 self._layout.append(offs)
+            # the split now lives ONCE, in the pinned blocks (Electronics-sized DeepCoNN data is tens of GB):
+            # the unpacked arrays are dropped, host-side iteration re-slices the blocks
+            self._t = None
 
     @classmethod
     def from_arrays(cls, hyper_params, data, y, device=None):
@@ -108,24 +113,43 @@ class DataLoader():
             blk = dev[off:off + cnt_blk]
             data, at = [], 0
             for k in KEYS[:7]:
-                shape = (n,) + tuple(self._t[k].shape[1:])
+                shape = (n,) + self._tail[k]
                 cnt = int(np.prod(shape))
                 data.append(blk[at:at + cnt].view(shape))
                 at += cnt
             out.append((data, blk[at:].view(_torch.float32)[:n]))
         return out, ev, dev
 
+    def _host_batches(self):
+        """(fields, ratings) of every batch as host tensors: slices of the arrays, or -- once they were
+        packed into pinned blocks and dropped -- views of those blocks."""
+        import torch as _torch
+        if self._t is not None:
+            for index in range(0, self.total, self.bsz):
+                sl = slice(index, index + self.bsz)
+                yield [self._t[k][sl] for k in KEYS[:7]], self._t['h'][sl]
+            return
+        for grp, offs in enumerate(self._layout):
+            for j, (off, cnt_blk) in enumerate(offs):
+                n = min(self.bsz, self.total - (grp * self.group + j) * self.bsz)
+                blk = self._packed[grp][off:off + cnt_blk]
+                data, at = [], 0
+                for k in KEYS[:7]:
+                    shape = (n,) + self._tail[k]
+                    cnt = int(np.prod(shape))
+                    data.append(blk[at:at + cnt].view(shape))
+                    at += cnt
+                yield data, blk[at:].view(_torch.float32)[:n]
+
     def iter(self, eval=False, torch=True):
         import torch as _torch
         if not torch:
-            for index in range(0, self.total, self.bsz):
-                sl = slice(index, index + self.bsz)
-                yield [self._t[k][sl].numpy() for k in KEYS[:7]], self._t['h'][sl].numpy()
+            for data, y in self._host_batches():
+                yield [d.numpy() for d in data], y.numpy()
             return
         if self.device.type != 'cuda':
-            for index in range(0, self.total, self.bsz):
-                sl = slice(index, index + self.bsz)
-                yield [self._t[k][sl].to(self.device) for k in KEYS[:7]], self._t['h'][sl].to(self.device)
+            for data, y in self._host_batches():
+                yield [d.to(self.device) for d in data], y.to(self.device)
             return
         if self._copy_stream is None:
             self._copy_stream = _torch.cuda.Stream(device=self.device)
