@@ -93,6 +93,8 @@ def parse():
     ap.add_argument('--model-type', default=None, help="override the workload's recommender (e.g. deepconn++ on the "
                     "cfg3 shapes)")
     ap.add_argument('--embed', type=int, default=None, help='override word_embed_size (crossover experiments)')
+    ap.add_argument('--latent', type=int, default=None, help='override latent_size')
+    ap.add_argument('--neumf-stage', default=None, help="with --model-type NeuMF: GMF / MLP / NeuMF")
     ap.add_argument('--cpu-seconds', type=float, default=12.0,
                     help='budget of each half (thread calibration, measurement) of the cpu_baseline leg')
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -194,6 +196,8 @@ def make_engine(args, hp, model, dp, rank, world, B):
     mt = hp['model_type']
     if mt in ('MF_dot', 'bias_only'):
         return E.MFEngine(model, **kw)
+    if mt in ('MF', 'NeuMF'):
+        return E.IdNetEngine(model, **{k: v for k, v in kw.items() if k != 'dp'})
     if mt == 'NARRE':
         return E.NarreEngine(model, conv_algo=algo, **kw)
     if mt == 'deepconn++':
@@ -233,6 +237,10 @@ def main():
         hp['model_type'] = args.model_type
     if args.embed:
         hp['word_embed_size'] = args.embed
+    if args.latent:
+        hp['latent_size'] = args.latent
+    if args.neumf_stage:
+        hp['neumf_stage'] = args.neumf_stage
     table = synthetic.word_table(hp['vocab'], hp['word_embed_size']) if hp.get('vocab') else None
     if table is not None:
         hp['word_vectors'] = table

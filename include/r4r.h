@@ -514,6 +514,36 @@ int r4r_transnet_rows_apply(const int64_t *uid_all, const int64_t *iid_all, cons
                             void *stream);
 
 /* ------------------------------------------------------------------------
+ * Fused native step for the ID-only recommenders with dense layers: model_type 'MF' (MF.py:60-68) and
+ * the NeuMF family (NeuMF.py: GMF :10-36, MLP :38-72, NeuMF :74-143; main.py:289-340 trains them in
+ * three stages).  Replaces, per training step, the model's forward, MSELoss (loss.py:7-11),
+ * loss.backward() and torch.optim.Adam.step() (main.py:56-60,94-96) by 4 launches (5 for NeuMF): a head
+ * kernel per rating (forward + backward, compact ID-table gradient rows), the dense-gradient column sums
+ * + Adam, and the tagged Adam sweeps over the ID tables and bias vectors (every row moves every step;
+ * no dense table gradient is materialised).
+ *   variant    0 MF   1 GMF   2 MLP   3 NeuMF
+ *   flat_*     the dense parameters in r4r_idnet_layout order (8 slots; absent ones have size 0):
+ *              projection/project .1.weight [L,2L], .1.bias, .3.weight [L,L], .3.bias, final.V [2L,L]
+ *              (MF), final.lin.weight | final.weight [1, 2L or L], its bias, global_bias
+ *   rows_*     HOST arrays of 6 device pointers: user / item table of the first pair (MF, GMF, MLP:
+ *              user_embedding, item_embedding; NeuMF: gmf_*), of the second pair (NeuMF: mlp_*; else
+ *              unused), user_bias, item_bias -- parameters, and their Adam moments
+ *   flat_g == NULL: eval-mode forward only.  L <= 32, B <= 16384 for training steps. */
+int r4r_idnet_nparam(void);
+int r4r_idnet_layout(int variant, int L, int64_t *offsets, int64_t *sizes, int64_t *total);
+size_t r4r_idnet_ws_bytes(int variant, int64_t B, int L, int64_t n_users, int64_t n_items);
+size_t r4r_idnet_ws_offset(int variant, int64_t B, int L, int64_t n_users, int64_t n_items,
+                           int which);   /* 0 dropout multipliers [B, draws], 1 d loss/d pred [B], 2 size of the persistent head (row tags), 4 + 2*pair + side: compact gradient rows [B, L] */
+int r4r_idnet_step(int variant, const int64_t *uid, const int64_t *iid, const float *y,
+                   float *flat_p, float *flat_g, float *flat_m, float *flat_v,
+                   const uint64_t *rows_p, const uint64_t *rows_m, const uint64_t *rows_v,
+                   int64_t n_users, int64_t n_items,
+                   float *pred, float *se, float *sse_accum, void *ws, size_t ws_bytes,
+                   int64_t B, int L, float dropout_p, int training, uint64_t seed, uint64_t offset,
+                   float inv_denom, float lr, double beta1, double beta2, float eps, float weight_decay,
+                   int64_t adam_step, void *stream);
+
+/* ------------------------------------------------------------------------
  * Device-side batch construction (the loader side of the path).
  * Replaces  data.DataLoader.remove_overlap / pad_and_join / pad_only and the 10-wide neighbour
  *           padding                                   data.py:144-236, 273-279, 375-447

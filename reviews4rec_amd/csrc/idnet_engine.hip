@@ -1,0 +1,419 @@
+// Fused native training step for the ID-only recommenders with dense layers: model_type 'MF'
+// (MF.py:60-68: MLP (+) GMF -> factorisation machine) and the NeuMF family (NeuMF.py: GMF, MLP,
+// NeuMF; trained in three stages by main.py:289-340).  'MF_dot' / 'bias_only' have their own, leaner
+// step (mf_engine.hip); the pattern here is the review models' (narre_engine.hip):
+//
+//   1  idnet_head_kernel   one workgroup per rating: the ID-row gathers + Philox dropout, the elementwise
+//                          (GMF) product, the projection MLP (Dropout -> Linear(2L, L) -> ReLU ->
+//                          Linear(L, L)), the final layer (a Linear, or MF's TorchFM), the bias head,
+//                          SE -- and the backward of all of it: the rating's contribution to every dense
+//                          parameter gradient as ONE row of a [B, NP] matrix, its ID-table gradient rows
+//                          compact ([B, L] per table), row tags for the sweeps
+//   2  idnet_reduce_kernel column sums of that matrix in a fixed order = the dense gradient, Adam on
+//                          every dense parameter the moment its sum is complete, running sum of SE
+//   3+ the tagged Adam sweeps of mf_engine.hip over the ID tables (one launch per user / item table
+//      pair: NeuMF has two) and over the two bias vectors: every row moves every step (weight decay,
+//      SURVEY fact 4), the dense gradient of a table is never materialised
+//
+// 4 launches per step (5 for NeuMF) against ~40 dependent ones op by op.  Variants share one kernel:
+//   variant      rows gathered            z (input of the final layer)            final
+//   0 MF         A                         [mlp(A), uA * iA]        (MF.py:60-66)  TorchFM(2L, L)
+//   1 GMF        A                         uA * iA                  (NeuMF.py:32)  Linear(L, 1)
+//   2 MLP        A                         mlp(A)                   (NeuMF.py:67)  Linear(L, 1)
+//   3 NeuMF      A (gmf_*), B (mlp_*)      [uA * iA, mlp(B)]        (NeuMF.py:134) Linear(2L, 1)
+#include "adam_device.h"
+#include "rows_device.h"
+#include "textcnn.h"
+
+namespace r4r {
+
+enum { IDN_MF = 0, IDN_GMF, IDN_MLP, IDN_NEUMF };
+// flat dense layout: projection / project .1 and .3, final (FM: V + lin, else Linear), global bias
+enum { IP_P1W = 0, IP_P1B, IP_P3W, IP_P3B, IP_FV, IP_FW, IP_FB, IP_GB, IP_COUNT };
+constexpr int IDN_MAX_L = 32;        // LDS arrays of the head kernel are sized by it (and MF's FM reads 2L <= 64 inputs)
+
+struct ILayout { int64_t off[IP_COUNT], size[IP_COUNT], total; };
+
+__host__ __device__ inline bool idn_has_mlp(int v) { return v != IDN_GMF; }
+__host__ __device__ inline bool idn_has_gmf(int v) { return v != IDN_MLP; }
+__host__ __device__ inline int idn_zwidth(int v, int L) { return (v == IDN_MF || v == IDN_NEUMF) ? 2 * L : L; }
+__host__ __device__ inline int idn_pairs(int v) { return v == IDN_NEUMF ? 2 : 1; }
+// dropout draws per rating: the gathered rows (2L per pair), then the projection's input (2L)
+__host__ __device__ inline int idn_draws(int v, int L) { return 2 * L * idn_pairs(v) + (idn_has_mlp(v) ? 2 * L : 0); }
+
+static ILayout idn_layout(int variant, int L) {
+    ILayout lay;
+    const int nz = idn_zwidth(variant, L);
+    const bool mlp = idn_has_mlp(variant);
+    const int64_t sz[IP_COUNT] = {mlp ? (int64_t)L * 2 * L : 0, mlp ? L : 0, mlp ? (int64_t)L * L : 0, mlp ? L : 0,
+                                  variant == IDN_MF ? (int64_t)nz * L : 0, nz, 1, 1};
+    int64_t o = 0;
+    for (int i = 0; i < IP_COUNT; ++i) {
+        lay.off[i] = o;
+        lay.size[i] = sz[i];
+        o += (sz[i] + 3) & ~(int64_t)3;          // 16-byte aligned slots; pad floats stay 0 forever
+    }
+    lay.total = o;
+    return lay;
+}
+
+struct IdnHead {
+    const float *flat_p;
+    int off[IP_COUNT], size[IP_COUNT];
+    const float *tab[2][2];            // [pair][side] ID tables [rows, L]
+    const float *bias[2];
+    const int64_t *id[2];              // uid, iid [B]
+    const float *y;
+    float *part;                       // [B, np]
+    float *grow[2][2];                 // [pair][side] compact gradient rows [B, L]
+    float *g;                          // [B] d mean(SE) / d pred
+    int *tag[2];
+    float *mult;                       // [B, draws]
+    float *pred, *se;
+    int64_t B;
+    int L, np, variant, training, want_grad, now;
+    float p_drop, inv_denom;
+    uint64_t seed, offset;
+};
+
+template <int ML>
+__global__ __launch_bounds__(256) void idnet_head_kernel(IdnHead a) {
+    __shared__ float W1[ML][2 * ML + 1], W3[ML][ML + 1], FV[2 * ML][ML + 1];
+    __shared__ float row[2][2][ML], rm[2][2][ML];          // gathered rows after dropout, their multipliers
+    __shared__ float cat[2 * ML], catm[2 * ML], hid[ML], mlp[ML], z[2 * ML], dz[2 * ML], dmlp[ML], dhid[ML], dcat[2 * ML];
+    __shared__ float b1[ML], b3[ML], fw[2 * ML], sfm[ML], misc[8];
+    const int L = a.L, L2 = 2 * L, tid = threadIdx.x, v = a.variant;
+    const int64_t b = blockIdx.x;
+    const float *fp = a.flat_p;
+    const bool has_mlp = idn_has_mlp(v), has_gmf = idn_has_gmf(v), fm = v == IDN_MF;
+    const int npair = idn_pairs(v), nz = idn_zwidth(v, L), ND = idn_draws(v, L);
+    const int mp = v == IDN_NEUMF ? 1 : 0;                  // the pair the projection reads
+    const float keep = 1.f / (1.f - a.p_drop);
+    const bool drop = a.training && a.p_drop > 0.f;
+    auto draw = [&](int k) -> float {
+        float m = 1.f;
+        if (drop) {
+            const uint32_t r = philox_first_word(a.offset + (uint64_t)(b * ND + k), a.seed);
+            m = ((float)(r >> 8) * (1.0f / 16777216.0f) >= a.p_drop) ? keep : 0.f;
+        }
+        if (a.mult) a.mult[b * ND + k] = m;
+        return m;
+    };
+    // ---- S0: weights -> LDS, the ID rows (+ dropout), biases
+    const int64_t uid = a.id[0][b], iid = a.id[1][b];
+    if (has_mlp) {
+        for (int i = tid; i < L * L2; i += 256) { const int k = i / L2; W1[k][i - k * L2] = fp[a.off[IP_P1W] + i]; }
+        for (int i = tid; i < L * L; i += 256) { const int k = i / L; W3[k][i - k * L] = fp[a.off[IP_P3W] + i]; }
+        if (tid < L) { b1[tid] = fp[a.off[IP_P1B] + tid]; b3[tid] = fp[a.off[IP_P3B] + tid]; }
+    }
+    if (fm) for (int i = tid; i < nz * L; i += 256) { const int r = i / L; FV[r][i - r * L] = fp[a.off[IP_FV] + i]; }
+    if (tid < nz) fw[tid] = fp[a.off[IP_FW] + tid];
+    for (int i = tid; i < npair * L2; i += 256) {            // draw k = pair * 2L + side * L + l
+        const int pr = i / L2, r = i - pr * L2, s = r >= L, l = r - s * L;
+        const float m = draw(i);
+        rm[pr][s][l] = m;
+        row[pr][s][l] = a.tab[pr][s][(s ? iid : uid) * L + l] * m;
+    }
+    if (tid == 0) {
+        misc[0] = fp[a.off[IP_FB]]; misc[1] = fp[a.off[IP_GB]];
+        misc[2] = a.bias[0][uid]; misc[3] = a.bias[1][iid];
+    }
+    __syncthreads();
+    // ---- S1: projection input = Dropout(cat[user, item]) (MF.py:26-27,61-62; NeuMF.py:51-52,64-66)
+    if (has_mlp && tid < L2) {
+        const int s = tid >= L, l = tid - s * L;
+        const float m = draw(npair * L2 + tid);
+        catm[tid] = m;
+        cat[tid] = row[mp][s][l] * m;
+    }
+    __syncthreads();
+    // ---- S2: Linear(2L, L) + ReLU
+    if (has_mlp && tid < L) {
+        float acc = 0.f;
+        for (int j = 0; j < L2; ++j) acc = fmaf(cat[j], W1[tid][j], acc);
+        acc += b1[tid];
+        hid[tid] = acc > 0.f ? acc : 0.f;
+    }
+    __syncthreads();
+    // ---- S3: Linear(L, L); z = what the final layer reads
+    if (has_mlp && tid < L) {
+        float acc = 0.f;
+        for (int k = 0; k < L; ++k) acc = fmaf(hid[k], W3[tid][k], acc);
+        mlp[tid] = acc + b3[tid];
+    }
+    __syncthreads();
+    if (tid < nz) {
+        float val;
+        if (v == IDN_GMF) val = row[0][0][tid] * row[0][1][tid];
+        else if (v == IDN_MLP) val = mlp[tid];
+        else if (v == IDN_MF) val = tid < L ? mlp[tid] : row[0][0][tid - L] * row[0][1][tid - L];
+        else val = tid < L ? row[0][0][tid] * row[0][1][tid] : mlp[tid - L];
+        z[tid] = val;
+    }
+    __syncthreads();
+    // ---- S4: final layer.  FM (common_pytorch_models.py:49-57): 0.5 (|zV|^2 - z^2 . V^2) + lin(z)
+    if (fm && tid < L) {
+        float s = 0.f;
+        for (int i = 0; i < nz; ++i) s = fmaf(z[i], FV[i][tid], s);
+        sfm[tid] = s;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        float rating = 0.f;
+        for (int i = 0; i < nz; ++i) rating = fmaf(z[i], fw[i], rating);
+        rating += misc[0];
+        if (fm) {
+            float s1 = 0.f, s2 = 0.f;
+            for (int k = 0; k < L; ++k) s1 = fmaf(sfm[k], sfm[k], s1);
+            for (int k = 0; k < L; ++k) {
+                float t = 0.f;
+                for (int i = 0; i < nz; ++i) t = fmaf(z[i] * z[i], FV[i][k] * FV[i][k], t);
+                s2 += t;
+            }
+            rating = 0.5f * (s1 - s2) + rating;
+        }
+        const float pred = ((misc[2] + misc[3]) + misc[1]) + rating;      // user_bias + item_bias + global_bias + rating
+        a.pred[b] = pred;
+        float g = 0.f;
+        if (a.y) {
+            const float d = pred - a.y[b];
+            a.se[b] = d * d;
+            g = 2.f * d * a.inv_denom;
+        }
+        misc[4] = g;
+        if (a.want_grad) {
+            a.g[b] = g;
+            a.tag[0][uid] = a.now;
+            a.tag[1][iid] = a.now;
+        }
+    }
+    if (!a.want_grad) return;                               // uniform
+    __syncthreads();
+    const float g = misc[4];
+    float *prow = a.part + (size_t)b * a.np;
+    // ---- B1: final layer -> d z
+    if (tid < nz) {
+        prow[a.off[IP_FW] + tid] = g * z[tid];
+        float d = fw[tid];
+        if (fm) {
+            float acc = 0.f;
+            for (int k = 0; k < L; ++k) acc += sfm[k] * FV[tid][k] - z[tid] * FV[tid][k] * FV[tid][k];
+            d += acc;
+        }
+        dz[tid] = g * d;
+    }
+    if (fm) for (int i = tid; i < nz * L; i += 256) {
+        const int r = i / L, k = i - r * L;
+        prow[a.off[IP_FV] + i] = g * (z[r] * sfm[k] - z[r] * z[r] * FV[r][k]);
+    }
+    if (tid == 0) { prow[a.off[IP_FB]] = g; prow[a.off[IP_GB]] = g; }
+    if (tid < IP_COUNT) {                                   // the alignment pads between slots: columns nobody owns
+        const int end = tid + 1 < IP_COUNT ? a.off[tid + 1] : a.np;
+        for (int c = a.off[tid] + a.size[tid]; c < end; ++c) prow[c] = 0.f;
+    }
+    __syncthreads();
+    // ---- B2: split d z; Linear(L, L) backward
+    if (has_mlp && tid < L) {
+        const int at = v == IDN_NEUMF ? L + tid : tid;      // where mlp sits inside z
+        const float d = dz[at];
+        dmlp[tid] = d;
+        prow[a.off[IP_P3B] + tid] = d;
+    }
+    __syncthreads();
+    if (has_mlp) {
+        for (int i = tid; i < L * L; i += 256) { const int k = i / L; prow[a.off[IP_P3W] + i] = dmlp[k] * hid[i - k * L]; }
+        if (tid < L) {
+            float acc = 0.f;
+            for (int k = 0; k < L; ++k) acc = fmaf(dmlp[k], W3[k][tid], acc);
+            const float d = hid[tid] > 0.f ? acc : 0.f;
+            dhid[tid] = d;
+            prow[a.off[IP_P1B] + tid] = d;
+        }
+    }
+    __syncthreads();
+    // ---- B3: Linear(2L, L) backward -> d cat -> (through the projection's dropout) d rows of pair mp
+    if (has_mlp) {
+        for (int i = tid; i < L * L2; i += 256) { const int k = i / L2; prow[a.off[IP_P1W] + i] = dhid[k] * cat[i - k * L2]; }
+        if (tid < L2) {
+            float acc = 0.f;
+            for (int k = 0; k < L; ++k) acc = fmaf(dhid[k], W1[k][tid], acc);
+            dcat[tid] = acc * catm[tid];
+        }
+    }
+    __syncthreads();
+    // ---- B4: compact ID-table gradient rows (through the row dropout): GMF product + projection paths
+    for (int i = tid; i < npair * L2; i += 256) {
+        const int pr = i / L2, r = i - pr * L2, s = r >= L, l = r - s * L;
+        float d = 0.f;
+        if (has_gmf && pr == 0) {
+            const int at = v == IDN_MF ? L + l : l;         // where the product sits inside z
+            d = dz[at] * row[0][1 - s][l];
+        }
+        if (has_mlp && pr == mp) d += dcat[r];
+        a.grow[pr][s][(size_t)b * L + l] = d * rm[pr][s][l];
+    }
+}
+
+// ---- 2: dense gradient = column sums of part [B, np] (fixed order), Adam, running SE
+struct IdnReduce {
+    const float *part, *se;
+    float *flat_g, *flat_p, *flat_m, *flat_v, *sse_accum;
+    int64_t B;
+    int np, apply;
+    AdamScalars s;
+};
+constexpr int IR_ROWS = 16, IR_COLS = 16;
+__global__ __launch_bounds__(IR_ROWS * IR_COLS) void idnet_reduce_kernel(IdnReduce c) {
+    __shared__ float red[IR_ROWS][IR_COLS];
+    const int ox = threadIdx.x & (IR_COLS - 1), rg = threadIdx.x / IR_COLS;
+    const int col = blockIdx.x * IR_COLS + ox;              // column np = the SE accumulator
+    float s = 0.f;
+    if (col < c.np) for (int64_t b = rg; b < c.B; b += IR_ROWS) s += c.part[(size_t)b * c.np + col];
+    else if (col == c.np) for (int64_t b = rg; b < c.B; b += IR_ROWS) s += c.se[b];
+    red[rg][ox] = s;
+    __syncthreads();
+    if (rg == 0 && col <= c.np) {
+        float t = 0.f;
+#pragma unroll
+        for (int r = 0; r < IR_ROWS; ++r) t += red[r][ox];
+        if (col == c.np) { if (c.sse_accum) c.sse_accum[0] += t; return; }
+        c.flat_g[col] = t;
+        if (c.apply) {
+            float P = c.flat_p[col], M = c.flat_m[col], V = c.flat_v[col];
+            adam_elem(P, t, M, V, c.s);
+            c.flat_p[col] = P; c.flat_m[col] = M; c.flat_v[col] = V;
+        }
+    }
+}
+
+struct IdnWs {
+    int *tag[2];
+    float *part, *g, *mult, *grow[2][2];
+    size_t bytes, persist;
+};
+static IdnWs idn_carve(void *ws, int variant, int64_t B, int L, int64_t n_users, int64_t n_items) {
+    IdnWs w;
+    char *p = static_cast<char *>(ws);
+    size_t o = 0;
+    auto take = [&](size_t nbytes) { char *r = p ? p + o : nullptr; o += align256(nbytes); return r; };
+    w.tag[0] = reinterpret_cast<int *>(take((size_t)n_users * 4));          // persistent state first (zeroed once)
+    w.tag[1] = reinterpret_cast<int *>(take((size_t)n_items * 4));
+    w.persist = o;
+    const ILayout lay = idn_layout(variant, L);
+    w.part = reinterpret_cast<float *>(take((size_t)B * lay.total * 4));
+    w.g = reinterpret_cast<float *>(take((size_t)B * 4));
+    w.mult = reinterpret_cast<float *>(take((size_t)B * idn_draws(variant, L) * 4));
+    for (int pr = 0; pr < 2; ++pr)
+        for (int s = 0; s < 2; ++s) w.grow[pr][s] = reinterpret_cast<float *>(take((size_t)B * L * 4));
+    w.bytes = o;
+    return w;
+}
+
+}  // namespace r4r
+
+using namespace r4r;
+
+extern "C" int r4r_idnet_nparam(void) { return IP_COUNT; }
+
+extern "C" int r4r_idnet_layout(int variant, int L, int64_t *offsets, int64_t *sizes, int64_t *total) {
+    R4R_REQUIRE(offsets && sizes && total, "idnet_layout: null pointer");
+    R4R_REQUIRE(variant >= 0 && variant <= IDN_NEUMF && L > 0 && L <= IDN_MAX_L, "idnet_layout: variant %d, latent_size %d "
+                "(0..3, 1..%d)", variant, L, IDN_MAX_L);
+    const ILayout lay = idn_layout(variant, L);
+    for (int i = 0; i < IP_COUNT; ++i) { offsets[i] = lay.off[i]; sizes[i] = lay.size[i]; }
+    *total = lay.total;
+    return R4R_OK;
+}
+
+extern "C" size_t r4r_idnet_ws_bytes(int variant, int64_t B, int L, int64_t n_users, int64_t n_items) {
+    if (variant < 0 || variant > IDN_NEUMF || B < 0 || L <= 0 || L > IDN_MAX_L || n_users <= 0 || n_items <= 0) return 0;
+    return idn_carve(nullptr, variant, B, L, n_users, n_items).bytes;
+}
+
+// which: 0 dropout multipliers [B, draws]; 1 d loss / d pred [B]; 2 the persistent head's size;
+// 4 + 2 * pair + side: compact gradient rows [B, L] of that ID table
+extern "C" size_t r4r_idnet_ws_offset(int variant, int64_t B, int L, int64_t n_users, int64_t n_items, int which) {
+    const IdnWs w = idn_carve(reinterpret_cast<void *>(256), variant, B, L, n_users, n_items);
+    if (which == 2) return w.persist;
+    const char *q = which == 0 ? reinterpret_cast<char *>(w.mult)
+                               : which == 1 ? reinterpret_cast<char *>(w.g)
+                                            : reinterpret_cast<char *>(w.grow[((which - 4) >> 1) & 1][(which - 4) & 1]);
+    return (size_t)(q - reinterpret_cast<char *>(256));
+}
+
+extern "C" int r4r_idnet_step(int variant, const int64_t *uid, const int64_t *iid, const float *y,
+                              float *flat_p, float *flat_g, float *flat_m, float *flat_v,
+                              const uint64_t *rows_p, const uint64_t *rows_m, const uint64_t *rows_v,
+                              int64_t n_users, int64_t n_items,
+                              float *pred, float *se, float *sse_accum, void *ws, size_t ws_bytes,
+                              int64_t B, int L, float dropout_p, int training, uint64_t seed, uint64_t offset,
+                              float inv_denom, float lr, double beta1, double beta2, float eps, float weight_decay,
+                              int64_t adam_step, void *stream) {
+    R4R_REQUIRE(uid && iid && flat_p && rows_p && pred && ws, "idnet_step: null pointer");
+    R4R_REQUIRE(variant >= 0 && variant <= IDN_NEUMF, "idnet_step: variant %d outside 0..3", variant);
+    R4R_REQUIRE(L > 0 && L <= IDN_MAX_L, "idnet_step: latent_size %d outside 1..%d", L, IDN_MAX_L);
+    R4R_REQUIRE(n_users > 0 && n_items > 0 && B >= 0, "idnet_step: bad sizes");
+    const bool train_step = flat_g != nullptr;
+    R4R_REQUIRE(!train_step || (y && se && flat_m && flat_v && rows_m && rows_v && adam_step >= 1),
+                "idnet_step: a training step needs ratings, se, gradient + moment buffers and adam_step >= 1");
+    R4R_REQUIRE(!y || se, "idnet_step: se buffer required when y is given");
+    R4R_REQUIRE(adam_step < (1ll << 31), "idnet_step: step tag overflow");
+    R4R_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, "idnet_step: dropout %f outside [0,1)", (double)dropout_p);
+    R4R_REQUIRE(!train_step || B <= 16384, "idnet_step: batch %lld > 16384 (the table sweeps keep a side's ids in LDS; use the "
+                "module path for larger batches)", (long long)B);
+    if (ws_bytes < r4r_idnet_ws_bytes(variant, B, L, n_users, n_items)) {
+        set_error("idnet_step: workspace %zu < %zu bytes", ws_bytes, r4r_idnet_ws_bytes(variant, B, L, n_users, n_items));
+        return R4R_ERR_WORKSPACE;
+    }
+    if (B == 0) return R4R_OK;
+    hipStream_t st = as_stream(stream);
+    const ILayout lay = idn_layout(variant, L);
+    R4R_REQUIRE(lay.total < (1ll << 31) && B * lay.total < (1ll << 31), "idnet_step: head-gradient matrix too large");
+    const IdnWs w = idn_carve(ws, variant, B, L, n_users, n_items);
+    const int npair = idn_pairs(variant);
+
+    // rows_*: [pair A user table, pair A item table, pair B user table, pair B item table, user_bias, item_bias]
+    IdnHead h;
+    h.flat_p = flat_p;
+    for (int i = 0; i < IP_COUNT; ++i) { h.off[i] = (int)lay.off[i]; h.size[i] = (int)lay.size[i]; }
+    for (int pr = 0; pr < 2; ++pr)
+        for (int s = 0; s < 2; ++s) {
+            h.tab[pr][s] = reinterpret_cast<const float *>(rows_p[(pr < npair ? pr : 0) * 2 + s]);
+            h.grow[pr][s] = w.grow[pr][s];
+            R4R_REQUIRE(h.tab[pr][s], "idnet_step: null ID table");
+        }
+    for (int s = 0; s < 2; ++s) {
+        h.bias[s] = reinterpret_cast<const float *>(rows_p[4 + s]);
+        h.tag[s] = w.tag[s];
+        R4R_REQUIRE(h.bias[s], "idnet_step: null bias vector");
+    }
+    h.id[0] = uid; h.id[1] = iid; h.y = y; h.part = w.part; h.g = w.g; h.mult = w.mult; h.pred = pred; h.se = se;
+    h.B = B; h.L = L; h.np = (int)lay.total; h.variant = variant; h.training = training; h.want_grad = train_step;
+    h.now = (int)adam_step; h.p_drop = dropout_p; h.inv_denom = inv_denom; h.seed = seed; h.offset = offset;
+    if (L <= 16) idnet_head_kernel<16><<<(unsigned)B, 256, 0, st>>>(h);
+    else idnet_head_kernel<IDN_MAX_L><<<(unsigned)B, 256, 0, st>>>(h);
+    if (!train_step) {
+        if (int rc = check_launch("idnet_step(forward)")) return rc;
+        return R4R_OK;
+    }
+    const AdamScalars sc = adam_make_scalars(lr, beta1, beta2, eps, weight_decay, adam_step, nullptr);
+    IdnReduce r;
+    r.part = w.part; r.se = se; r.flat_g = flat_g; r.flat_p = flat_p; r.flat_m = flat_m; r.flat_v = flat_v;
+    r.sse_accum = sse_accum; r.B = B; r.np = (int)lay.total; r.apply = 1; r.s = sc;
+    idnet_reduce_kernel<<<(unsigned)cdiv(lay.total + 1, IR_COLS), IR_ROWS * IR_COLS, 0, st>>>(r);
+
+    float *rp[6], *rm[6], *rv[6];
+    for (int k = 0; k < 6; ++k) {
+        const bool used = k >= 4 || k < 2 * npair;
+        rp[k] = reinterpret_cast<float *>(rows_p[k]); rm[k] = reinterpret_cast<float *>(rows_m[k]);
+        rv[k] = reinterpret_cast<float *>(rows_v[k]);
+        R4R_REQUIRE(!used || (rp[k] && rm[k] && rv[k]), "idnet_step: table / bias %d: null parameter / moment pointer", k);
+    }
+    for (int pr = 0; pr < npair; ++pr)
+        if (int rc = mf_table_rows_launch(rp[2 * pr], rm[2 * pr], rv[2 * pr], rp[2 * pr + 1], rm[2 * pr + 1], rv[2 * pr + 1],
+                                          n_users, n_items, L, uid, iid, w.grow[pr][0], w.grow[pr][1], w.tag[0], w.tag[1],
+                                          nullptr, nullptr, B, (int)adam_step, sc, st))
+            return rc;
+    return mf_bias_rows_launch(rp[4], rm[4], rv[4], rp[5], rm[5], rv[5], n_users, n_items, uid, iid, w.g, w.tag[0], w.tag[1], B,
+                               (int)adam_step, sc, st);
+}

@@ -1108,3 +1108,211 @@ class TransNetEngine(NarreEngine):
                 rows = ws[off:off + n * 5 * 4].view(torch.float32).view(n, 5)
                 out[name] = torch.zeros_like(self.rows[t]).index_add_(0, f[3 + t], rows)
         return out
+
+
+class IdNetEngine:
+    """Native step for the ID-only recommenders with dense layers -- model_type 'MF' (MF.py:60-68) and the
+    NeuMF family (NeuMF.py: GMF / MLP / NeuMF) -- csrc/idnet_engine.hip, r4r_idnet_step: forward, loss,
+    backward and the dense Adam update of main.py:56-60,94-96 in 4 launches (5 for NeuMF); the dense
+    gradient of an ID table is never materialised.  Same calling surface as the other engines
+    (train_step / predict / sse / state_dict).  Single process: under data parallelism these families
+    take the op-by-op path with dist.py's exchanges."""
+    VARIANTS = {'MF': 0, 'GMF': 1, 'MLP': 2, 'NeuMF': 3}
+    # reference parameter names of the 8 flat slots (None: the variant has no such layer)
+    SLOT_NAMES = {
+        'MF': ['projection.1.weight', 'projection.1.bias', 'projection.3.weight', 'projection.3.bias', 'final.V',
+               'final.lin.weight', 'final.lin.bias', 'global_bias'],
+        'GMF': [None, None, None, None, None, 'final.weight', 'final.bias', 'global_bias'],
+        'MLP': ['project.1.weight', 'project.1.bias', 'project.3.weight', 'project.3.bias', None, 'final.weight',
+                'final.bias', 'global_bias'],
+        'NeuMF': ['project.1.weight', 'project.1.bias', 'project.3.weight', 'project.3.bias', None, 'final.weight',
+                  'final.bias', 'global_bias'],
+    }
+    TABLE_NAMES = {
+        'MF': ['user_embedding.weight', 'item_embedding.weight'],
+        'GMF': ['user_embedding.weight', 'item_embedding.weight'],
+        'MLP': ['user_embedding.weight', 'item_embedding.weight'],
+        'NeuMF': ['gmf_user_embedding.weight', 'gmf_item_embedding.weight', 'mlp_user_embedding.weight',
+                  'mlp_item_embedding.weight'],
+    }
+    MAX_L, MAX_TRAIN_BATCH = 32, 16384
+
+    @staticmethod
+    def kind_of(model):
+        mt = model.hyper_params['model_type']
+        return 'MF' if mt == 'MF' else type(model).__name__          # NeuMF.py's classes share one model_type
+
+    def __init__(self, model, lr=0.002, weight_decay=1e-6, betas=(0.9, 0.999), eps=1e-8, seed=0x5EED5EED, rank=0,
+                 dp=None):
+        if dp is not None and dp.on:
+            raise RuntimeError('IdNetEngine is single-process; under data parallelism use the op-by-op path')
+        self.kind = self.kind_of(model)
+        if self.kind not in self.VARIANTS:
+            raise ValueError('IdNetEngine implements MF / GMF / MLP / NeuMF, got %r' % (self.kind,))
+        self.variant = self.VARIANTS[self.kind]
+        hp = model.hyper_params
+        self.model, self.hp = model, hp
+        self.lr, self.wd, self.betas, self.eps = float(lr), float(weight_decay), tuple(betas), float(eps)
+        self.L = int(hp['latent_size'])
+        params = dict(model.named_parameters())
+        self.tables = [params[k] for k in self.TABLE_NAMES[self.kind]]
+        self.biases = [params['user_bias'], params['item_bias']]
+        if not all(p.is_cuda for p in self.tables):
+            raise RuntimeError('IdNetEngine: move the model to a ROCm device first; the HIP path has no CPU fallback')
+        if not all(p.is_contiguous() and p.dtype == torch.float32 for p in self.tables + self.biases):
+            raise RuntimeError('IdNetEngine: fp32 contiguous ID tables / bias vectors only')
+        self.dev = self.tables[0].device
+        self.n_users, self.n_items = int(self.tables[0].shape[0]), int(self.tables[1].shape[0])
+        lib = _lib.lib()
+        n = lib.r4r_idnet_nparam()
+        off, size, total = (ctypes.c_int64 * n)(), (ctypes.c_int64 * n)(), ctypes.c_int64()
+        _lib.check(lib.r4r_idnet_layout(self.variant, self.L, off, size, ctypes.byref(total)), 'r4r_idnet_layout')
+        self.names = self.SLOT_NAMES[self.kind]
+        self.offsets, self.sizes, self.total = list(off), list(size), int(total.value)
+        self.flat_p = torch.zeros(self.total, dtype=torch.float32, device=self.dev)
+        self.slots = []
+        for name, o, s in zip(self.names, self.offsets, self.sizes):
+            if name is None:
+                assert s == 0
+                self.slots.append(None)
+                continue
+            p = params[name]
+            assert p.numel() == s, (name, tuple(p.shape), s)
+            view = self.flat_p[o:o + s].view(p.shape)
+            view.copy_(p.data)
+            p.data = view                       # the Parameter now aliases the flat buffer
+            self.slots.append(p)
+        self.flat_g = torch.zeros_like(self.flat_p)
+        self.flat_m = torch.zeros_like(self.flat_p)
+        self.flat_v = torch.zeros_like(self.flat_p)
+        self.rows = self.tables + [None] * (4 - len(self.tables)) + self.biases
+        self.rows_m = [None if p is None else torch.zeros_like(p) for p in self.rows]
+        self.rows_v = [None if p is None else torch.zeros_like(p) for p in self.rows]
+        self.sse = torch.zeros(1, dtype=torch.float32, device=self.dev)
+        self.step_count = 0
+        self.seed = (int(seed) * 0x9E3779B97F4A7C15 + int(rank) * 0xD1B54A32D192ED03) & 0xFFFFFFFFFFFFFFFF
+        self.offset = 0
+        self._ws, self._ws_B, self._out = None, None, {}
+
+    @staticmethod
+    def _p6(tensors):
+        return (ctypes.c_uint64 * 6)(*[0 if t is None else t.data_ptr() for t in tensors])
+
+    def draws(self):
+        return 2 * self.L * (2 if self.variant == 3 else 1) + (0 if self.variant == 1 else 2 * self.L)
+
+    def _workspace(self, B):
+        if self._ws_B != B:
+            lib = _lib.lib()
+            nb = lib.r4r_idnet_ws_bytes(self.variant, B, self.L, self.n_users, self.n_items)
+            nxt = torch.zeros(max(nb, 256), dtype=torch.uint8, device=self.dev)
+            if self._ws is not None:                         # the row tags head the buffer: shared state
+                keep = lib.r4r_idnet_ws_offset(self.variant, B, self.L, self.n_users, self.n_items, 2)
+                nxt[:keep].copy_(self._ws[:keep])
+            self._ws, self._ws_B = nxt, B
+        return self._ws
+
+    def _launch(self, data, y, train_mode, inv_denom, adam_step):
+        uid, iid = data[5].reshape(-1).contiguous(), data[6].reshape(-1).contiguous()
+        if not (uid.is_cuda and uid.dtype == torch.int64 and iid.is_cuda and iid.dtype == torch.int64):
+            raise RuntimeError('IdNetEngine: batches must be int64 tensors on the ROCm device')
+        n = uid.numel()
+        if adam_step and n > self.MAX_TRAIN_BATCH:
+            raise RuntimeError('IdNetEngine: training batch %d > %d' % (n, self.MAX_TRAIN_BATCH))
+        if n not in self._out:
+            self._out[n] = (torch.empty(n, dtype=torch.float32, device=self.dev),
+                            torch.empty(n, dtype=torch.float32, device=self.dev))
+        pred, se = self._out[n]
+        ws = self._workspace(n)
+        rc = _lib.lib().r4r_idnet_step(
+            self.variant, ptr(uid), ptr(iid), ptr(y), ptr(self.flat_p), ptr(self.flat_g) if adam_step else None,
+            ptr(self.flat_m) if adam_step else None, ptr(self.flat_v) if adam_step else None,
+            self._p6(self.rows), self._p6(self.rows_m) if adam_step else None,
+            self._p6(self.rows_v) if adam_step else None, self.n_users, self.n_items, ptr(pred), ptr(se),
+            ptr(self.sse) if adam_step else None, ptr(ws), ws.numel(), n, self.L, float(self.hp['dropout']),
+            int(train_mode), self.seed, self.offset, float(inv_denom), self.lr, self.betas[0], self.betas[1], self.eps,
+            self.wd, int(adam_step), _lib.current_stream())
+        _lib.check(rc, 'r4r_idnet_step')
+        if train_mode and float(self.hp['dropout']) > 0.0:
+            self.offset += n * self.draws()
+        return pred, se
+
+    def train_step(self, data, y, n_global=None, next_data=None):
+        """One optimisation step.  Returns the per-example SE tensor (device, reused by the next call);
+        the running sum is in ``self.sse``."""
+        n = data[5].numel()
+        if n == 0:
+            return torch.empty(0, dtype=torch.float32, device=self.dev)
+        self.step_count += 1
+        _, se = self._launch(data, y.reshape(-1).contiguous(), self.model.training,
+                             1.0 / float(n_global if n_global is not None else n), self.step_count)
+        return se
+
+    @torch.no_grad()
+    def predict(self, data, y=None):
+        """Eval-mode forward (no dropout, no gradients).  Returns (pred, se or None)."""
+        if data[5].numel() == 0:
+            e = torch.empty(tuple(data[5].shape), dtype=torch.float32, device=self.dev)
+            return e, (e.clone() if y is not None else None)
+        if y is not None:
+            y = y.reshape(-1).contiguous()
+        pred, se = self._launch(data, y, False, 1.0, 0)
+        shape = tuple(data[5].shape)
+        return pred.view(shape), (se.view(shape) if y is not None else None)
+
+    # ---- introspection for the parity tests
+    def _ws_view(self, B, which, cols):
+        lib = _lib.lib()
+        at = lib.r4r_idnet_ws_offset(self.variant, B, self.L, self.n_users, self.n_items, which)
+        return self._workspace(B)[at:at + B * cols * 4].view(torch.float32).view(B, cols)
+
+    def dropout_multipliers(self, B):
+        """[B, draws] multipliers of the last training step: per table pair the user row [L] and the item
+        row [L], then (variants with a projection) its 2L inputs."""
+        return self._ws_view(B, 0, self.draws()).clone()
+
+    def grads(self, data):
+        """Reference-named gradients of the LAST training step on `data`: the dense ones are views of the
+        flat buffer, the ID tables / bias vectors are rebuilt from their compact rows."""
+        out = {k: self.flat_g[o:o + s].view(p.shape) for k, p, o, s in
+               zip(self.names, self.slots, self.offsets, self.sizes) if k is not None}
+        uid, iid = data[5].reshape(-1), data[6].reshape(-1)
+        B = uid.numel()
+        for t, name in enumerate(self.TABLE_NAMES[self.kind]):
+            rows = self._ws_view(B, 4 + t, self.L)
+            out[name] = torch.zeros_like(self.tables[t]).index_add_(0, uid if t % 2 == 0 else iid, rows)
+        g = self._ws_view(B, 1, 1)[:, 0]
+        out['user_bias'] = torch.zeros_like(self.biases[0]).index_add_(0, uid, g)
+        out['item_bias'] = torch.zeros_like(self.biases[1]).index_add_(0, iid, g)
+        return out
+
+    def moments(self):
+        m = {k: self.flat_m[o:o + s].view(p.shape) for k, p, o, s in
+             zip(self.names, self.slots, self.offsets, self.sizes) if k is not None}
+        v = {k: self.flat_v[o:o + s].view(p.shape) for k, p, o, s in
+             zip(self.names, self.slots, self.offsets, self.sizes) if k is not None}
+        for t, name in enumerate(self.TABLE_NAMES[self.kind] + ['user_bias', 'item_bias']):
+            i = t if t < len(self.tables) else 4 + t - len(self.tables)
+            m[name], v[name] = self.rows_m[i], self.rows_v[i]
+        return m, v
+
+    def state_dict(self):
+        return {'exp_avg': self.flat_m.clone(), 'exp_avg_sq': self.flat_v.clone(),
+                'rows_exp_avg': [None if t is None else t.clone() for t in self.rows_m],
+                'rows_exp_avg_sq': [None if t is None else t.clone() for t in self.rows_v],
+                'step': self.step_count, 'dropout_offset': self.offset, 'lr': self.lr, 'weight_decay': self.wd,
+                'betas': self.betas, 'eps': self.eps}
+
+    def load_state_dict(self, sd):
+        if sd['exp_avg'].numel() != self.total:
+            raise ValueError('IdNetEngine.load_state_dict: %d moment elements for a %d-element layout'
+                             % (sd['exp_avg'].numel(), self.total))
+        self.flat_m.copy_(sd['exp_avg'].to(self.dev))
+        self.flat_v.copy_(sd['exp_avg_sq'].to(self.dev))
+        for mine, theirs in zip(self.rows_m + self.rows_v, list(sd['rows_exp_avg']) + list(sd['rows_exp_avg_sq'])):
+            if mine is not None:
+                mine.copy_(theirs.to(self.dev))
+        self.step_count = int(sd['step'])
+        self.offset = int(sd['dropout_offset'])
+        self.lr, self.wd = float(sd['lr']), float(sd['weight_decay'])
+        self.betas, self.eps = tuple(sd['betas']), float(sd['eps'])

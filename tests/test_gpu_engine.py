@@ -1085,3 +1085,144 @@ def test_conv_rule_measures_the_distinct_tokens_and_flips(dist, expect):
     pinned, _, pred_proj = run(2)
     assert pinned.conv_choice is None
     torch.testing.assert_close(pred_auto, pred_proj, rtol=2e-4, atol=2e-4)
+
+
+# --------------------------------------------------------------------------------- MF / NeuMF native step
+IDNET_CASES = ['mf_full', 'neumf_gmf', 'neumf_mlp', 'neumf_full']
+
+
+@pytest.mark.parametrize('case', IDNET_CASES)
+def test_idnet_engine_matches_reference_golden(case):
+    """r4r_idnet_step (model_type 'MF' and NeuMF's GMF / MLP / NeuMF): eval outputs incl. the negatives
+    shape, then the reference-generated 3-step trajectory -- SE, every gradient of step 0 (ID tables and
+    bias vectors rebuilt from the compact rows), weights after 1 and 3 steps, Adam moments."""
+    from reviews4rec_amd.engine import IdNetEngine
+    g = Golden(case)
+    model, hp = build_model(g)
+    eng = IdNetEngine(model.eval())
+    for k in (0, 1):
+        data, y = g.batch(k, DEV)
+        pred, se = eng.predict(data, y)
+        torch.testing.assert_close(pred.cpu(), g.arr('eval%d' % k), rtol=1e-5, atol=1e-5)
+        torch.testing.assert_close(se.cpu(), (g.arr('eval%d' % k) - y.cpu()) ** 2, rtol=1e-4, atol=1e-5)
+    pred, _ = eng.predict(g.neg_batch(DEV))
+    assert tuple(pred.shape) == tuple(g.arr('neg_eval').shape)
+    torch.testing.assert_close(pred.cpu(), g.arr('neg_eval'), rtol=1e-5, atol=1e-5)
+
+    model, hp = build_model(g)
+    model.train()
+    eng = IdNetEngine(model, lr=hp['lr'], weight_decay=hp['weight_decay'])
+    total = 0.0
+    for step in range(3):
+        data, y = g.batch(step % 2, DEV)
+        se = eng.train_step(data, y).clone()
+        torch.testing.assert_close(se.cpu(), g.arr('se%d' % step), rtol=1e-4, atol=1e-5)
+        total += float(g.arr('se%d' % step).sum())
+        if step == 0:
+            got, ref_g = eng.grads(data), g.group('g0')
+            assert set(got) == set(ref_g)
+            for k, v in ref_g.items():
+                torch.testing.assert_close(got[k].cpu(), v, rtol=1e-4, atol=1e-7, msg=lambda m: k + ': ' + m)
+        if step in (0, 2):
+            sd = model.state_dict()
+            for k, v in g.params('w%d' % (step + 1)).items():
+                torch.testing.assert_close(sd[k].cpu(), v, rtol=1e-5, atol=5e-6, msg=lambda m: k + ': ' + m)
+    m, v = eng.moments()
+    for k, ref in g.group('m3').items():
+        torch.testing.assert_close(m[k].cpu(), ref, rtol=1e-4, atol=1e-7, msg=lambda mm: k + ': ' + mm)
+    for k, ref in g.group('v3').items():
+        torch.testing.assert_close(v[k].cpu(), ref, rtol=1e-4, atol=1e-10, msg=lambda mm: k + ': ' + mm)
+    torch.testing.assert_close(eng.sse.cpu()[0], torch.tensor(total), rtol=1e-5, atol=1e-4)
+
+
+@pytest.mark.parametrize('case', IDNET_CASES)
+def test_idnet_engine_dropout_masks_injected_into_oracle(case):
+    """Train-mode parity: the masks the device drew (Philox) are injected into the CPU oracle at every dropout
+    site (the gathered rows of each table pair, the projection's input)."""
+    from reviews4rec_amd.engine import IdNetEngine
+    g = Golden(case)
+    model, hp = build_model(g, dropout=0.5)
+    model.train()
+    eng = IdNetEngine(model, lr=hp['lr'], weight_decay=hp['weight_decay'])
+    P = {k: v.clone() for k, v in g.params().items()}
+    state = oracle.AdamState()
+    L = hp['latent_size']
+    for step in range(2):
+        data, y = g.batch(0, DEV)
+        B = y.numel()
+        se = eng.train_step(data, y).cpu().clone()
+        mult = eng.dropout_multipliers(B).cpu()
+        assert 0.25 < float((mult == 0).float().mean()) < 0.75
+        if eng.kind == 'NeuMF':
+            masks = {'dropout.gmf_user': mult[:, :L], 'dropout.gmf_item': mult[:, L:2 * L],
+                     'dropout.mlp_user': mult[:, 2 * L:3 * L], 'dropout.mlp_item': mult[:, 3 * L:4 * L],
+                     'project.0': mult[:, 4 * L:]}
+        else:
+            masks = {'dropout.user': mult[:, :L], 'dropout.item': mult[:, L:2 * L]}
+            if eng.kind != 'GMF':
+                masks['projection.0' if eng.kind == 'MF' else 'project.0'] = mult[:, 2 * L:]
+        cpu_data, cpu_y = g.batch(0)
+        sse, _ = oracle.train_step(P, cpu_data, cpu_y, dict(hp), state, masks=masks)
+        torch.testing.assert_close(se.sum(), torch.tensor(sse), rtol=1e-4, atol=1e-4)
+    sd = model.state_dict()
+    for k, v in P.items():
+        diff = (sd[k].cpu() - v).abs()
+        assert float((diff > 2e-5 + 1e-4 * v.abs()).float().mean()) < 2e-3 and float(diff.max()) < 5e-4, k
+
+
+@pytest.mark.parametrize('kind,L,B', [('MF', 32, 3000), ('NeuMF', 10, 2500), ('MLP', 24, 700), ('GMF', 5, 16384)])
+def test_idnet_engine_large_batches_with_popular_rows(kind, L, B):
+    """Wide / odd latent sizes and batches where one item collects 14 % of the ratings and one user 5 %: the
+    step against the oracle (dropout masks injected), run-to-run bit equality."""
+    import reviews4rec_amd
+    from reviews4rec_amd.engine import IdNetEngine
+    U, I = 4000, 900
+    hp = dict(model_type='MF' if kind == 'MF' else 'NeuMF', latent_size=L, dropout=0.3, total_users=U, total_items=I,
+              lr=0.002, weight_decay=1e-6, word_embed_size=16, input_length=10)
+    if kind != 'MF':
+        hp['neumf_stage'] = kind
+    P = oracle.init_params(hp, vocab_size=None, seed=3)
+    gen = torch.Generator().manual_seed(B + L)
+    uid = torch.randint(0, U, (B,), generator=gen)
+    iid = torch.randint(0, I, (B,), generator=gen)
+    iid[torch.rand(B, generator=gen) < 0.14] = 7
+    uid[torch.rand(B, generator=gen) < 0.05] = 11
+    uid[0], iid[-1] = U, I                                    # the last row of each table
+    y = torch.randint(1, 6, (B,), generator=gen).float()
+    data = [None, None, None, None, None, uid, iid]
+
+    def run():
+        model = reviews4rec_amd.get_model_class(hp['model_type'])(hp)
+        model.load_state_dict(P)
+        model = model.to(DEV).train()
+        eng = IdNetEngine(model, lr=hp['lr'], weight_decay=hp['weight_decay'], seed=9)
+        dev = [None] * 5 + [uid.to(DEV), iid.to(DEV)]
+        ses, mults = [], []
+        for _ in range(2):
+            ses.append(eng.train_step(dev, y.to(DEV)).clone())
+            mults.append(eng.dropout_multipliers(B).cpu())
+        return model, eng, ses, mults
+
+    model, eng, ses, mults = run()
+    model2, eng2, ses2, _ = run()
+    sd, sd2 = model.state_dict(), model2.state_dict()
+    assert all(torch.equal(sd[k], sd2[k]) for k in sd) and torch.equal(ses[1], ses2[1])      # deterministic
+    ref = {k: v.clone() for k, v in P.items()}
+    state = oracle.AdamState()
+    for step in range(2):
+        mult = mults[step]
+        if kind == 'NeuMF':
+            masks = {'dropout.gmf_user': mult[:, :L], 'dropout.gmf_item': mult[:, L:2 * L],
+                     'dropout.mlp_user': mult[:, 2 * L:3 * L], 'dropout.mlp_item': mult[:, 3 * L:4 * L],
+                     'project.0': mult[:, 4 * L:]}
+        else:
+            masks = {'dropout.user': mult[:, :L], 'dropout.item': mult[:, L:2 * L]}
+            if kind != 'GMF':
+                masks['projection.0' if kind == 'MF' else 'project.0'] = mult[:, 2 * L:]
+        sse, _ = oracle.train_step(ref, data, y, dict(hp), state, masks=masks)
+        torch.testing.assert_close(ses[step].sum().cpu(), torch.tensor(sse), rtol=2e-4, atol=1e-2)
+    for k, v in ref.items():
+        diff = (sd[k].cpu() - v).abs()
+        # Adam's first steps are lr * g / (|g| + eps): weights whose gradient is ~1e-8 amplify rounding;
+        # bound the outliers by one lr step
+        assert float((diff > 2e-5 + 1e-4 * v.abs()).float().mean()) < 5e-3 and float(diff.max()) < 2.1 * hp['lr'], k

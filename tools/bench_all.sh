@@ -19,3 +19,7 @@ run "cfg3 E=64 native" --embed 64
 run "cfg5 shapes, transnet native" --workload cfg5_transnetpp_synthetic --model-type transnet
 run "cfg5 shapes, transnet graph" --workload cfg5_transnetpp_synthetic --model-type transnet --engine graph
 run "cfg3 from host memory native" --from-host
+run "cfg2 shapes, MF (L=32) native" --workload cfg2_mfdot_electronics --model-type MF --latent 32
+run "cfg2 shapes, MF (L=32) graph" --workload cfg2_mfdot_electronics --model-type MF --latent 32 --engine graph
+run "cfg2 shapes, NeuMF (L=32) native" --workload cfg2_mfdot_electronics --model-type NeuMF --latent 32
+run "cfg2 shapes, NeuMF (L=32) graph" --workload cfg2_mfdot_electronics --model-type NeuMF --latent 32 --engine graph
