@@ -1,0 +1,86 @@
+"""Device-side batch construction (r4r_batch_build, reviews4rec_amd/data.py) on one MI355X: time per batch
+and bytes moved, Amazon-shaped synthetic reviews (log-normal review lengths, Zipf users / items / words).
+
+    python tools/bench_batcher.py [--ratings 300000] [--model-type deepconn|NARRE]
+
+Prints one JSON line: microseconds per batch of 128 ratings (HIP events over 200 batches), the int64 bytes
+a batch writes, the token bytes it reads, and the resulting GB/s -- the loader-side number DESIGN.md quotes
+next to the preprocessed-epoch loader's PCIe-bound rate."""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--ratings', type=int, default=300000)
+    ap.add_argument('--users', type=int, default=40000)
+    ap.add_argument('--items', type=int, default=15000)
+    ap.add_argument('--vocab', type=int, default=50002)
+    ap.add_argument('--batch', type=int, default=128)
+    ap.add_argument('--model-type', default='deepconn')
+    args = ap.parse_args()
+    from reviews4rec_amd import synthetic
+    from reviews4rec_amd.data import DataLoader
+    rng = np.random.default_rng(7)
+    users = synthetic._zipf_sampler(args.users, 1.1, rng)
+    items = synthetic._zipf_sampler(args.items, 1.1, rng)
+    words = synthetic._zipf_sampler(args.vocab - 1, 1.0, rng)
+    t0 = time.time()
+    seen, train = set(), []
+    u_all, i_all = users((args.ratings * 2,)), items((args.ratings * 2,))
+    for u, i in zip(u_all.tolist(), i_all.tolist()):
+        if (u, i) not in seen:
+            seen.add((u, i))
+            train.append([u, i, float(rng.integers(1, 6))])
+            if len(train) == args.ratings:
+                break
+    lens = np.minimum(400, rng.lognormal(np.log(60), 0.9, size=len(train))).astype(np.int64).clip(min=1)
+    toks = (words((int(lens.sum()),)) + 1).astype(np.int64)
+    cuts = np.concatenate([[0], np.cumsum(lens)])
+    user_reviews = {u: [] for u in range(args.users)}
+    item_reviews = {i: [] for i in range(args.items)}
+    tiui = {}
+    for n, (u, i, r) in enumerate(train):
+        rev = toks[cuts[n]:cuts[n + 1]].tolist()
+        tiui.setdefault(u, {})[i] = [len(user_reviews[u]), len(item_reviews[i])]
+        user_reviews[u].append(rev)
+        item_reviews[i].append(rev)
+    hp = dict(model_type=args.model_type, batch_size=args.batch, input_length=1000, narre_num_reviews=10,
+              narre_num_words=100, total_users=args.users, total_items=args.items)
+    t1 = time.time()
+    loader = DataLoader(hp, train, user_reviews, item_reviews, None, this_index_user_item=tiui, device='cuda')
+    t2 = time.time()
+    it = loader.iter()
+    for _ in range(20):
+        data, y = next(it)
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    n = 200
+    a.record()
+    for _ in range(n):
+        data, y = next(it)
+    b.record()
+    torch.cuda.synchronize()
+    us = a.elapsed_time(b) * 1000.0 / n
+    out_bytes = sum(d.numel() * 8 for d in data[:5])
+    tok_bytes = int(sum((d != 0).sum().item() for d in (data[0], data[3], data[4])) * 4)
+    pool_mb = (loader.store.users.tok.nbytes + loader.store.items.tok.nbytes) / 1e6
+    print(json.dumps({'kernel': 'batch_build_kernel', 'model_type': args.model_type, 'batch': args.batch,
+                      'us_per_batch': round(us, 2), 'int64_bytes_written': out_bytes, 'token_bytes_read': tok_bytes,
+                      'GBs': round((out_bytes + tok_bytes) / us / 1e3, 1), 'ratings': len(train),
+                      'token_pools_MB': round(pool_mb, 1),
+                      'padded_epoch_arrays_MB': round(len(train) * out_bytes / args.batch / 1e6, 1),
+                      'host_s': {'synthesize': round(t1 - t0, 1), 'flatten_into_pools': round(t2 - t1, 1)}}))
+
+
+if __name__ == '__main__':
+    main()
