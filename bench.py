@@ -197,7 +197,7 @@ def make_engine(args, hp, model, dp, rank, world, B):
     if mt in ('MF_dot', 'bias_only'):
         return E.MFEngine(model, **kw)
     if mt in ('MF', 'NeuMF'):
-        return E.IdNetEngine(model, **{k: v for k, v in kw.items() if k != 'dp'})
+        return E.IdNetEngine(model, **kw)
     if mt == 'NARRE':
         return E.NarreEngine(model, conv_algo=algo, **kw)
     if mt == 'deepconn++':

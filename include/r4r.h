@@ -543,6 +543,18 @@ int r4r_idnet_step(int variant, const int64_t *uid, const int64_t *iid, const fl
                    float inv_denom, float lr, double beta1, double beta2, float eps, float weight_decay,
                    int64_t adam_step, void *stream);
 
+/* Data parallel: r4r_idnet_step with flat_m == NULL computes gradients only (flat_g, and in the workspace
+ * d loss/d pred [B] and the compact rows [B, L] per table: r4r_idnet_ws_offset 1, 4..7); after the exchange --
+ * all-reduce flat_g + r4r_adam_multi; all_gather of (uid, iid, d loss/d pred, rows), ids -1 padding ragged
+ * shards -- the ID tables and bias vectors are updated from ALL ranks' rows.  gu_all / gi_all: HOST arrays of
+ * 2 device pointers ([B_all, L] rows of the first / second table pair).  `ws`, B: the step's own.  B_all <= 16384. */
+int r4r_idnet_rows_apply(int variant, const int64_t *uid_all, const int64_t *iid_all, const float *g_all,
+                         const uint64_t *gu_all, const uint64_t *gi_all, int64_t B_all,
+                         const uint64_t *rows_p, const uint64_t *rows_m, const uint64_t *rows_v,
+                         int64_t n_users, int64_t n_items, void *ws, size_t ws_bytes, int64_t B, int L,
+                         float lr, double beta1, double beta2, float eps, float weight_decay,
+                         int64_t adam_step, void *stream);
+
 /* ------------------------------------------------------------------------
  * Device-side batch construction (the loader side of the path).
  * Replaces  data.DataLoader.remove_overlap / pad_and_join / pad_only and the 10-wide neighbour

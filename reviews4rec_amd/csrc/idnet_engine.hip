@@ -354,8 +354,11 @@ extern "C" int r4r_idnet_step(int variant, const int64_t *uid, const int64_t *ii
     R4R_REQUIRE(L > 0 && L <= IDN_MAX_L, "idnet_step: latent_size %d outside 1..%d", L, IDN_MAX_L);
     R4R_REQUIRE(n_users > 0 && n_items > 0 && B >= 0, "idnet_step: bad sizes");
     const bool train_step = flat_g != nullptr;
-    R4R_REQUIRE(!train_step || (y && se && flat_m && flat_v && rows_m && rows_v && adam_step >= 1),
-                "idnet_step: a training step needs ratings, se, gradient + moment buffers and adam_step >= 1");
+    // flat_m == NULL on a training step: gradients only (flat_g, the compact rows and d loss / d pred in the
+    // workspace) -- the data-parallel form (r4r_adam_multi + r4r_idnet_rows_apply after the exchange)
+    const bool apply = flat_m != nullptr;
+    R4R_REQUIRE(!train_step || (y && se && adam_step >= 1 && (!apply || (flat_v && rows_m && rows_v))),
+                "idnet_step: a training step needs ratings, se, gradient buffers and adam_step >= 1 (+ moments to update)");
     R4R_REQUIRE(!y || se, "idnet_step: se buffer required when y is given");
     R4R_REQUIRE(adam_step < (1ll << 31), "idnet_step: step tag overflow");
     R4R_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, "idnet_step: dropout %f outside [0,1)", (double)dropout_p);
@@ -399,8 +402,9 @@ extern "C" int r4r_idnet_step(int variant, const int64_t *uid, const int64_t *ii
     const AdamScalars sc = adam_make_scalars(lr, beta1, beta2, eps, weight_decay, adam_step, nullptr);
     IdnReduce r;
     r.part = w.part; r.se = se; r.flat_g = flat_g; r.flat_p = flat_p; r.flat_m = flat_m; r.flat_v = flat_v;
-    r.sse_accum = sse_accum; r.B = B; r.np = (int)lay.total; r.apply = 1; r.s = sc;
+    r.sse_accum = sse_accum; r.B = B; r.np = (int)lay.total; r.apply = apply ? 1 : 0; r.s = sc;
     idnet_reduce_kernel<<<(unsigned)cdiv(lay.total + 1, IR_COLS), IR_ROWS * IR_COLS, 0, st>>>(r);
+    if (!apply) return check_launch("idnet_step(gradients)");
 
     float *rp[6], *rm[6], *rv[6];
     for (int k = 0; k < 6; ++k) {
@@ -416,4 +420,57 @@ extern "C" int r4r_idnet_step(int variant, const int64_t *uid, const int64_t *ii
             return rc;
     return mf_bias_rows_launch(rp[4], rm[4], rv[4], rp[5], rm[5], rv[5], n_users, n_items, uid, iid, w.g, w.tag[0], w.tag[1], B,
                                (int)adam_step, sc, st);
+}
+
+// Data parallel: the ID-table / bias updates from ALL ranks' compact rows, gathered by the caller in rank order
+// (ids -1 pad ragged shards), after a gradients-only r4r_idnet_step (flat_m == NULL) and the dense exchange
+// (all-reduce of flat_g + r4r_adam_multi).  gu_all / gi_all: [pairs] device pointers to [B_all, L] rows (HOST
+// arrays of 2 entries; the second pair only for NeuMF); g_all [B_all].  `ws` and B are the step's own: the row
+// tags live in the workspace's persistent head.
+namespace r4r {
+__global__ void idn_tag_rows_kernel(const int64_t *uid, const int64_t *iid, int64_t n, int *tag_u, int *tag_i, int now) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n || uid[e] < 0) return;
+    tag_u[uid[e]] = now;
+    tag_i[iid[e]] = now;
+}
+}  // namespace r4r
+
+extern "C" int r4r_idnet_rows_apply(int variant, const int64_t *uid_all, const int64_t *iid_all, const float *g_all,
+                                    const uint64_t *gu_all, const uint64_t *gi_all, int64_t B_all,
+                                    const uint64_t *rows_p, const uint64_t *rows_m, const uint64_t *rows_v,
+                                    int64_t n_users, int64_t n_items, void *ws, size_t ws_bytes, int64_t B, int L,
+                                    float lr, double beta1, double beta2, float eps, float weight_decay,
+                                    int64_t adam_step, void *stream) {
+    R4R_REQUIRE(uid_all && iid_all && g_all && gu_all && gi_all && rows_p && rows_m && rows_v && ws, "idnet_rows_apply: null pointer");
+    R4R_REQUIRE(variant >= 0 && variant <= IDN_NEUMF && L > 0 && L <= IDN_MAX_L, "idnet_rows_apply: bad variant / latent_size");
+    R4R_REQUIRE(B_all >= 0 && B_all <= 16384, "idnet_rows_apply: %lld gathered ratings outside 0..16384", (long long)B_all);
+    R4R_REQUIRE(adam_step >= 1 && adam_step < (1ll << 31), "idnet_rows_apply: bad adam_step");
+    if (ws_bytes < r4r_idnet_ws_bytes(variant, B, L, n_users, n_items)) {
+        set_error("idnet_rows_apply: workspace %zu < %zu bytes", ws_bytes, r4r_idnet_ws_bytes(variant, B, L, n_users, n_items));
+        return R4R_ERR_WORKSPACE;
+    }
+    if (B_all == 0) return R4R_OK;
+    hipStream_t st = as_stream(stream);
+    const IdnWs w = idn_carve(ws, variant, B, L, n_users, n_items);
+    const int npair = idn_pairs(variant);
+    float *rp[6], *rm[6], *rv[6];
+    for (int k = 0; k < 6; ++k) {
+        const bool used = k >= 4 || k < 2 * npair;
+        rp[k] = reinterpret_cast<float *>(rows_p[k]); rm[k] = reinterpret_cast<float *>(rows_m[k]);
+        rv[k] = reinterpret_cast<float *>(rows_v[k]);
+        R4R_REQUIRE(!used || (rp[k] && rm[k] && rv[k]), "idnet_rows_apply: table / bias %d: null pointer", k);
+    }
+    idn_tag_rows_kernel<<<(unsigned)cdiv(B_all, 256), 256, 0, st>>>(uid_all, iid_all, B_all, w.tag[0], w.tag[1], (int)adam_step);
+    const AdamScalars sc = adam_make_scalars(lr, beta1, beta2, eps, weight_decay, adam_step, nullptr);
+    for (int pr = 0; pr < npair; ++pr) {
+        const float *gu = reinterpret_cast<const float *>(gu_all[pr]), *gi = reinterpret_cast<const float *>(gi_all[pr]);
+        R4R_REQUIRE(gu && gi, "idnet_rows_apply: null gradient rows of pair %d", pr);
+        if (int rc = mf_table_rows_launch(rp[2 * pr], rm[2 * pr], rv[2 * pr], rp[2 * pr + 1], rm[2 * pr + 1], rv[2 * pr + 1],
+                                          n_users, n_items, L, uid_all, iid_all, gu, gi, w.tag[0], w.tag[1], nullptr, nullptr,
+                                          B_all, (int)adam_step, sc, st))
+            return rc;
+    }
+    return mf_bias_rows_launch(rp[4], rm[4], rv[4], rp[5], rm[5], rv[5], n_users, n_items, uid_all, iid_all, g_all, w.tag[0],
+                               w.tag[1], B_all, (int)adam_step, sc, st);
 }

@@ -457,7 +457,12 @@ class MFEngine:
         uid, iid = data[5].reshape(-1).contiguous(), data[6].reshape(-1).contiguous()
         n, world = uid.numel(), self.dp.world
         B_pad = int(self.hp.get('batch_size', 0))            # every rank's shard fits the configured batch: pad to it
-        if n_global is None or n > B_pad:                    # (otherwise agree on the sizes first: one more collective + a sync)
+        if n_global is not None and n > B_pad:
+            # (taking the size-agreement branch on THIS rank only would leave the others in a different
+            # collective: a hang, not an error)
+            raise RuntimeError("data parallel: this rank's shard has %d ratings but hyper_params['batch_size'] is %d; "
+                               "pass n_global=None to let the ranks agree on the sizes first" % (n, B_pad))
+        if n_global is None:                                 # (otherwise agree on the sizes first: one more collective + a sync)
             sizes = torch.tensor([n], dtype=torch.int64, device=self.dev)
             all_sizes = torch.empty(world, dtype=torch.int64, device=self.dev)
             dist.all_gather_into_tensor(all_sizes, sizes, group=self.dp.group)
@@ -792,7 +797,12 @@ class NarreEngine(_ConvRule):
         lib, dist = _lib.lib(), torch.distributed
         n, world = data[5].numel(), self.dp.world
         B_pad = int(self.hp.get('batch_size', 0))
-        if n_global is None or n > B_pad:
+        if n_global is not None and n > B_pad:
+            # (taking the size-agreement branch on THIS rank only would leave the others in a different
+            # collective: a hang, not an error)
+            raise RuntimeError("data parallel: this rank's shard has %d ratings but hyper_params['batch_size'] is %d; "
+                               "pass n_global=None to let the ranks agree on the sizes first" % (n, B_pad))
+        if n_global is None:
             sizes = torch.tensor([n], dtype=torch.int64, device=self.dev)
             all_sizes = torch.empty(world, dtype=torch.int64, device=self.dev)
             dist.all_gather_into_tensor(all_sizes, sizes, group=self.dp.group)
@@ -1115,8 +1125,9 @@ class IdNetEngine:
     NeuMF family (NeuMF.py: GMF / MLP / NeuMF) -- csrc/idnet_engine.hip, r4r_idnet_step: forward, loss,
     backward and the dense Adam update of main.py:56-60,94-96 in 4 launches (5 for NeuMF); the dense
     gradient of an ID table is never materialised.  Same calling surface as the other engines
-    (train_step / predict / sse / state_dict).  Single process: under data parallelism these families
-    take the op-by-op path with dist.py's exchanges."""
+    (train_step / predict / sse / state_dict).  Under data parallelism (``dp``) the step computes gradients
+    only, the dense gradient is all-reduced into the flat Adam and the ranks' compact ID rows are gathered
+    into the same tagged sweeps on every rank (r4r_idnet_rows_apply): replicas stay bit-identical."""
     VARIANTS = {'MF': 0, 'GMF': 1, 'MLP': 2, 'NeuMF': 3}
     # reference parameter names of the 8 flat slots (None: the variant has no such layer)
     SLOT_NAMES = {
@@ -1144,8 +1155,7 @@ class IdNetEngine:
 
     def __init__(self, model, lr=0.002, weight_decay=1e-6, betas=(0.9, 0.999), eps=1e-8, seed=0x5EED5EED, rank=0,
                  dp=None):
-        if dp is not None and dp.on:
-            raise RuntimeError('IdNetEngine is single-process; under data parallelism use the op-by-op path')
+        self.dp = dp if (dp is not None and dp.on) else None
         self.kind = self.kind_of(model)
         if self.kind not in self.VARIANTS:
             raise ValueError('IdNetEngine implements MF / GMF / MLP / NeuMF, got %r' % (self.kind,))
@@ -1224,11 +1234,12 @@ class IdNetEngine:
                             torch.empty(n, dtype=torch.float32, device=self.dev))
         pred, se = self._out[n]
         ws = self._workspace(n)
+        apply = bool(adam_step) and self.dp is None          # data parallel: gradients only
         rc = _lib.lib().r4r_idnet_step(
             self.variant, ptr(uid), ptr(iid), ptr(y), ptr(self.flat_p), ptr(self.flat_g) if adam_step else None,
-            ptr(self.flat_m) if adam_step else None, ptr(self.flat_v) if adam_step else None,
-            self._p6(self.rows), self._p6(self.rows_m) if adam_step else None,
-            self._p6(self.rows_v) if adam_step else None, self.n_users, self.n_items, ptr(pred), ptr(se),
+            ptr(self.flat_m) if apply else None, ptr(self.flat_v) if apply else None,
+            self._p6(self.rows), self._p6(self.rows_m) if apply else None,
+            self._p6(self.rows_v) if apply else None, self.n_users, self.n_items, ptr(pred), ptr(se),
             ptr(self.sse) if adam_step else None, ptr(ws), ws.numel(), n, self.L, float(self.hp['dropout']),
             int(train_mode), self.seed, self.offset, float(inv_denom), self.lr, self.betas[0], self.betas[1], self.eps,
             self.wd, int(adam_step), _lib.current_stream())
@@ -1240,12 +1251,67 @@ class IdNetEngine:
     def train_step(self, data, y, n_global=None, next_data=None):
         """One optimisation step.  Returns the per-example SE tensor (device, reused by the next call);
         the running sum is in ``self.sse``."""
+        if self.dp is not None:
+            return self._train_step_dp(data, y, n_global)
         n = data[5].numel()
         if n == 0:
             return torch.empty(0, dtype=torch.float32, device=self.dev)
         self.step_count += 1
         _, se = self._launch(data, y.reshape(-1).contiguous(), self.model.training,
                              1.0 / float(n_global if n_global is not None else n), self.step_count)
+        return se
+
+    def _train_step_dp(self, data, y, n_global):
+        lib, dist = _lib.lib(), torch.distributed
+        n, world, L = data[5].numel(), self.dp.world, self.L
+        B_pad = int(self.hp.get('batch_size', 0))
+        if n_global is not None and n > B_pad:
+            # (taking the size-agreement branch on THIS rank only would leave the others in a different
+            # collective: a hang, not an error)
+            raise RuntimeError("data parallel: this rank's shard has %d ratings but hyper_params['batch_size'] is %d; "
+                               "pass n_global=None to let the ranks agree on the sizes first" % (n, B_pad))
+        if n_global is None:                                 # agree on the sizes first: one more collective + a sync
+            sizes = torch.tensor([n], dtype=torch.int64, device=self.dev)
+            all_sizes = torch.empty(world, dtype=torch.int64, device=self.dev)
+            dist.all_gather_into_tensor(all_sizes, sizes, group=self.dp.group)
+            B_pad, n_global = int(all_sizes.max().item()), int(all_sizes.sum().item())
+        self.step_count += 1
+        se = torch.empty(0, dtype=torch.float32, device=self.dev)
+        if n > 0:
+            _, se = self._launch(data, y.reshape(-1).contiguous(), self.model.training, 1.0 / float(n_global),
+                                 self.step_count)
+        else:
+            self.flat_g.zero_()                              # an empty shard contributes a zero gradient
+        self.dp.allreduce_flat(self.flat_g)                  # C1: the dense gradient
+        one = ctypes.c_uint64 * 1
+        _lib.check(lib.r4r_adam_multi(1, one(self.flat_p.data_ptr()), one(self.flat_g.data_ptr()),
+                                      one(self.flat_m.data_ptr()), one(self.flat_v.data_ptr()),
+                                      (ctypes.c_int64 * 1)(self.total), self.lr, self.betas[0], self.betas[1], self.eps,
+                                      self.wd, int(self.step_count), None, _lib.current_stream()), 'r4r_adam_multi')
+        # C2: per rating (uid, iid) and (d loss / d pred, the compact rows of every table); -1 ids pad ragged shards
+        ntab = len(self.tables)
+        ids = torch.full((B_pad, 2), -1, dtype=torch.int64, device=self.dev)
+        vals = torch.zeros((B_pad, 1 + ntab * L), dtype=torch.float32, device=self.dev)
+        if n > 0:
+            ids[:n, 0], ids[:n, 1] = data[5].reshape(-1), data[6].reshape(-1)
+            vals[:n, 0] = self._ws_view(n, 1, 1)[:, 0]
+            for t in range(ntab):
+                vals[:n, 1 + t * L:1 + (t + 1) * L] = self._ws_view(n, 4 + t, L)
+        all_ids = torch.empty((world * B_pad, 2), dtype=torch.int64, device=self.dev)
+        all_vals = torch.empty((world * B_pad, 1 + ntab * L), dtype=torch.float32, device=self.dev)
+        dist.all_gather_into_tensor(all_ids.view(-1), ids.view(-1), group=self.dp.group)
+        dist.all_gather_into_tensor(all_vals.view(-1), vals.view(-1), group=self.dp.group)
+        uid_all, iid_all = all_ids[:, 0].contiguous(), all_ids[:, 1].contiguous()
+        g_all = all_vals[:, 0].contiguous()
+        rows = [all_vals[:, 1 + t * L:1 + (t + 1) * L].contiguous() for t in range(ntab)]
+        p2 = lambda ts: (ctypes.c_uint64 * 2)(*[t.data_ptr() for t in ts] + [0] * (2 - len(ts)))
+        nb = max(n, 1)                                       # (the workspace of this rank's own shape holds the row tags)
+        ws = self._workspace(nb)
+        _lib.check(lib.r4r_idnet_rows_apply(
+            self.variant, ptr(uid_all), ptr(iid_all), ptr(g_all), p2(rows[0::2]), p2(rows[1::2]), world * B_pad,
+            self._p6(self.rows), self._p6(self.rows_m), self._p6(self.rows_v), self.n_users, self.n_items, ptr(ws),
+            ws.numel(), nb, L, self.lr, self.betas[0], self.betas[1], self.eps, self.wd, int(self.step_count),
+            _lib.current_stream()), 'r4r_idnet_rows_apply')
         return se
 
     @torch.no_grad()

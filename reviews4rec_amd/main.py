@@ -174,12 +174,10 @@ def native_step_limits(hyper_params, world=1):
             return 'global batch %d > 16384' % (B * world)
         return None
     if mt in ('MF', 'NeuMF'):
-        if world > 1:
-            return "the fused step of model_type %r is single-process" % (mt,)
         if L > 32:
             return 'latent_size %d > 32' % L
-        if B > 16384:
-            return 'batch %d > 16384' % B
+        if B * world > 16384:
+            return 'global batch %d > 16384' % (B * world)
         return None
     if mt not in ('deepconn', 'deepconn++', 'NARRE', 'transnet', 'transnet++'):
         return 'no fused native step for model_type %r' % (mt,)
@@ -254,7 +252,7 @@ def make_engine(hyper_params, model, dp=None, rank=0):
     if mt in ('MF_dot', 'bias_only'):
         return E.MFEngine(model, **kw)
     if mt in ('MF', 'NeuMF'):
-        return E.IdNetEngine(model, **{k: v for k, v in kw.items() if k != 'dp'})
+        return E.IdNetEngine(model, **kw)
     if mt == 'NARRE':
         return E.NarreEngine(model, **kw)
     if mt == 'deepconn++':

@@ -383,3 +383,58 @@ def test_dp2_native_narre_step_follows_the_reference_trajectory(tmp_path):
         assert torch.equal(r0['w'][k], r1['w'][k]), k               # replicas stay bit-identical
         if not ill_conditioned(k):
             torch.testing.assert_close(r0['w'][k], v, rtol=1e-4, atol=2e-5, msg=lambda m: k + ': ' + m)
+
+
+def _idnet_worker(rank, world, port, case, out_dir):
+    import faulthandler
+    faulthandler.dump_traceback_later(120, exit=True)        # a protocol mismatch between the ranks must not hang the suite
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, TESTS)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank), R4R_DIST_BACKEND='gloo')
+    from helpers import Golden
+    from test_gpu_models import build_model
+    from reviews4rec_amd import dist as r4dist, main as M
+    from reviews4rec_amd.engine import IdNetEngine
+    r4dist.init_from_env()
+    g = Golden(case)
+    model, hp = build_model(g)
+    model.train()
+    dp = r4dist.DataParallel(model)
+    dp.broadcast_parameters()
+    model.hyper_params['batch_size'] = 64                    # per-rank batch: every shard below fits it
+    eng = M.make_engine(dict(hp, engine='auto', batch_size=64), model, dp=dp, rank=rank)
+    assert isinstance(eng, IdNetEngine) and eng.dp is not None
+    ses = []
+    for step in range(3):
+        data, y = g.batch(step % 2, 'cuda')
+        sd, sy = r4dist.shard_batch(data, y, rank, world)
+        if step == 2 and rank == 1:                          # an empty shard on one rank
+            sd, sy = [None if d is None else d[:0] for d in sd], sy[:0]
+        elif step == 2:
+            sd, sy = data, y
+        ses.append(eng.train_step(sd, sy, n_global=int(y.shape[0]) if step != 1 else None).cpu().clone())
+    torch.save({'w': {k: v.detach().cpu() for k, v in model.state_dict().items()}, 'se': ses},
+               os.path.join(out_dir, 'i%d.pt' % rank))
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.parametrize('case', ['mf_full', 'neumf_gmf', 'neumf_mlp', 'neumf_full'])
+def test_dp2_native_idnet_step_follows_the_reference_trajectory(tmp_path, case):
+    """MF / GMF / MLP / NeuMF under data parallelism on the native step (r4r_idnet_step gradients only, one
+    all-reduce of the flat dense gradient + the flat Adam, the ranks' compact ID rows gathered into
+    r4r_idnet_rows_apply): 2 ranks x ragged shards (one of them empty in the last step) == the reference's three
+    single-process steps; replicas bit-identical."""
+    sys.path.insert(0, TESTS)
+    from helpers import Golden
+    port = _free_port()
+    mp.spawn(_idnet_worker, args=(2, port, case, str(tmp_path)), nprocs=2, join=True)
+    g = Golden(case)
+    r0 = torch.load(os.path.join(tmp_path, 'i0.pt'))
+    r1 = torch.load(os.path.join(tmp_path, 'i1.pt'))
+    for step in range(3):
+        se = torch.cat([r0['se'][step], r1['se'][step]])
+        torch.testing.assert_close(se, g.arr('se%d' % step), rtol=1e-4, atol=1e-5)
+    for k, v in g.params('w3').items():
+        assert torch.equal(r0['w'][k], r1['w'][k]), k               # replicas stay bit-identical
+        torch.testing.assert_close(r0['w'][k], v, rtol=1e-5, atol=5e-6, msg=lambda m: k + ': ' + m)
