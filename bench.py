@@ -46,6 +46,7 @@ import numpy as np
 import torch
 
 PEAK_FP32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, dense
+PEAK_F16_MFMA_TFLOPS = 2500.0     # MI355X_MICROARCH.md: dense fp16 / bf16 MFMA (no sparsity)
 PEAK_HBM_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E spec peak (6.3 TB/s measured achievable)
 WORKLOAD = 'cfg3_deepconn_electronics_e300'
 
@@ -65,7 +66,8 @@ def measured_traffic(kernel, args, live_launch_s=None):
     path = os.path.join(ROOT, 'profiles', name) if name else None
     if not (path and os.path.exists(path) and args.batch_per_gpu == 128 and args.engine == 'native'
             and args.conv_algo in ('auto', 'project') and not args.model_type and not args.embed
-            and args.scaling == 'weak' and args.doc_fill == 'lognormal' and args.token_dist == 'zipf'):
+            and args.scaling == 'weak' and args.doc_fill == 'lognormal' and args.token_dist == 'zipf'
+            and args.gemm_math == 'f32'):
         return None, None
     kernels = json.load(open(path))['kernels']
     for k, v in kernels.items():
@@ -120,6 +122,10 @@ def parse():
     ap.add_argument('--ramp', type=int, default=30,
                     help='untimed steps before the requested warm-up when --warmup is shorter than this: clocks '
                          'and launch queue reach steady state whatever --warmup says (reported as warmup_effective)')
+    ap.add_argument('--gemm-math', choices=['f32', 'f16x2'], default='f32',
+                    help='arithmetic of the projection GEMM: f32 (default, the headline: fp32 operands on the fp32 MFMA) or '
+                         'the opt-in fp16-split form (every operand = hi + lo fp16, three f16-MFMA products per fp32 '
+                         'product, fp32 accumulation; csrc/project_f16.hip) -- reported under its own dtype')
     ap.add_argument('--engine', choices=['native', 'module', 'graph'], default='native',
                     help="native: fused r4r_deepconn_step where the model has one (else module); module: op-by-op "
                          "autograd path; graph: the module path captured into one hipGraph per step")
@@ -217,6 +223,7 @@ def main():
     from reviews4rec_amd.ops import DropoutState
     from reviews4rec_amd.utils import xavier_init
 
+    os.environ['R4R_GEMM_MATH'] = args.gemm_math             # read by the engines when they are built
     rank, world, local = r4dist.init_from_env()
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a GPU: the HIP path has no CPU fallback')
@@ -443,11 +450,14 @@ def main():
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'warmup_effective': ramp + args.warmup,
             'ms_per_step': round(1000.0 * elapsed / args.steps, 4),
             'higher_is_better': True, 'scaling': 'strong' if strong else 'weak', 'vs_baseline': None,
-            'dtype': 'f32', 'data': 'synthetic' + (' (streamed from pinned host memory)' if args.from_host else ''),
+            'dtype': 'f32' if args.gemm_math == 'f32' else 'f32 with an fp16-split projection GEMM (3 f16-MFMA products per '
+                                                            'fp32 product, fp32 accumulate; opt-in, not the headline)',
+            'data': 'synthetic' + (' (streamed from pinned host memory)' if args.from_host else ''),
             'config': {'workload': args.workload, 'ratings_per_step': B_global, 'batch_per_gpu': B,
                        'parallelism': 'dp%d' % world,
                        'engine': 'native' if engine is not None else ('graph' if graphed is not None else 'module'),
-                       'conv_algo': args.conv_algo, 'doc_fill': args.doc_fill, 'token_dist': args.token_dist,
+                       'conv_algo': args.conv_algo, 'gemm_math': args.gemm_math, 'doc_fill': args.doc_fill,
+                       'token_dist': args.token_dist,
                        **({'rccl_ranks': world, 'dist_backend': torch.distributed.get_backend(),
                            'replicas_identical': replicas} if world > 1 else {}),
                        **({'dp_exchange': engine.exchange,
@@ -473,9 +483,13 @@ def main():
             gflops = rows * hp['word_embed_size'] * 300 * 2
             ach = gflops / g_s / 1e12
             traffic, src = measured_traffic('proj_gemm_kernel', args, g_s)
-            result['roofline'] = {'kernel': 'proj_gemm_kernel', 'bound': 'mfma', 'achieved': round(ach, 2),
-                                  'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                                  'frac': round(ach / PEAK_FP32_MFMA_TFLOPS, 4),
+            f16 = args.gemm_math == 'f16x2'
+            # fp16-split form: three f16 MFMA products per useful fp32 product -> a third of the dense f16 peak
+            peak = PEAK_F16_MFMA_TFLOPS / 3.0 if f16 else PEAK_FP32_MFMA_TFLOPS
+            result['roofline'] = {'kernel': 'proj_gemm_f16_kernel (+ its weight-pack launch)' if f16 else 'proj_gemm_kernel',
+                                  'bound': 'mfma', 'achieved': round(ach, 2),
+                                  'peak': round(peak, 1), 'unit': 'TFLOP/s',
+                                  'frac': round(ach / peak, 4),
                                   'traffic': traffic, 'traffic_source': src,
                                   'launches': timed['proj_gemm_kernel'][1], 'avg_launch_ms': round(1000 * g_s, 4),
                                   'flops_per_launch': int(gflops), 'distinct_token_rows_per_launch': int(rows),

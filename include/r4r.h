@@ -69,6 +69,16 @@ int r4r_conv_algo(int requested, int64_t N, int T, int E, int F);
  * model fitted to MI355X measurements.  Host-side arithmetic, no device work. */
 int r4r_conv_pick(int E, int T, int64_t docs, int64_t rows, int64_t V);
 
+/* Arithmetic of the projection GEMM inside project-then-gather.  0 (default, the fp32 results every parity claim
+ * refers to): fp32 operands on the fp32 MFMA.  1 (opt-in experiment): every operand split exactly
+ * into two fp16 numbers (hi + lo), three f16-MFMA products per fp32 product into ONE fp32 accumulator, exact
+ * power-of-two scaling from `table_maxabs` = max |word table| (frozen: computed once by the host) and
+ * `weight_maxabs` = max |conv weights| over the towers (the host re-reads it every few steps; the scale keeps two
+ * binades of headroom): ~2^-21 relative error per product at 16 / 3 the fp32-MFMA rate.  Mode 1 applies to the fused
+ * steps (their host keeps the scales current); mode 2 also to r4r_textcnn_fwd (the caller vouches that the scales
+ * describe the table and weights it passes).  Process-wide, like r4r_gemm_form. */
+int r4r_gemm_math(int mode, float table_maxabs, float weight_maxabs);
+
 /* Form of the projection GEMM inside project-then-gather (A/B runs and tests; results are bit-identical):
  * 1 = the balanced 7-row-tile form wherever its plan applies (default), 0 = always the 128-row tile form,
  * -1 = take it from the environment again (R4R_GEMM=tile pins the tile form). */

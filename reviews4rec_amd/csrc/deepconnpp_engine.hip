@@ -308,7 +308,7 @@ extern "C" int r4r_deepconnpp_step(const float *table, int64_t V, const int64_t 
             pt[t].conv_w = P[t ? DP_ICW : DP_UCW]; pt[t].conv_b = P[t ? DP_ICB : DP_UCB];
             pt[t].flags = w.flags[token_buffer][t]; pt[t].slot = w.slot[token_buffer][t];
             pt[t].list = w.list[token_buffer][t]; pt[t].count = w.count[token_buffer][t];
-            pt[t].ptab = w.ptab[t]; pt[t].pmax = w.pmax[t]; pt[t].parg = w.parg[t];
+            pt[t].ptab = w.ptab[t]; pt[t].pmax = w.pmax[t]; pt[t].parg = w.parg[t]; pt[t].wimg = w.wp[t];
         }
         if (!tokens_ready)
             if (int rc = textcnn_proj_tokens_launch(V, pt, 2, B, T, /*zero_state=*/false, st)) return rc;

@@ -678,6 +678,12 @@ int64_t proj_row_capacity(int64_t N, int T, int64_t V) { return (N * T < V) ? N 
 size_t proj_ptab_floats(int64_t N, int T, int64_t V) { return (size_t)proj_row_capacity(N, T, V) * PROW; }
 
 static int g_gemm_balanced = -1;       // -1: from the environment (R4R_GEMM=tile pins the tile form) on first use
+static int g_gemm_math = 0;            // 0: fp32 MFMA (the default and the headline); 1: fp16-split operands (project_f16.hip)
+static float g_table_maxabs = 0.f;     // max |table|, given with mode 1 (the table is frozen: the host computes it once)
+static float g_weight_maxabs = 0.f;    // max |conv weights|, likewise (re-read by the host every few steps)
+int proj_gemm_f16_launch(const float *table, const ProjTower *tw, int ntower, int cap, int E, float table_maxabs,
+                         float weight_maxabs, hipStream_t st);
+size_t proj_gemm_f16_wimg_bytes(int E);
 
 static ProjArgs make_args(const float *table, int64_t V, const ProjTower *tw, int ntower,
                           int64_t N, int T, int E, int F) {
@@ -729,7 +735,12 @@ int textcnn_proj_compute_launch(const float *table, int64_t V, const ProjTower *
         attr_set = true;
     }
     const ProjArgs a = make_args(table, V, tw, ntower, N, T, E, F);
-    {
+    bool f16 = g_gemm_math >= 1 && proj_gemm_f16_wimg_bytes(E) <= textcnn_wp_floats(E) * 4;
+    for (int t = 0; t < ntower; ++t) f16 = f16 && tw[t].wimg != nullptr;       // (callers without the scratch: fp32)
+    if (f16) {
+        ScopedTiming tm(R4R_TIMING_PROJ_GEMM, st);           // (the opt-in arithmetic: its weight-scale launch included)
+        if (int rc = proj_gemm_f16_launch(table, tw, ntower, a.cap, E, g_table_maxabs, g_weight_maxabs, st)) return rc;
+    } else {
         ScopedTiming tm(R4R_TIMING_PROJ_GEMM, st);
         // persistent: one workgroup per CU at most (86 KB of LDS each), fewer when the row capacity is small
         int64_t wgs = ((int64_t)a.cap + G7_ROWS * 16 - 1) / (G7_ROWS * 16) * ntower;
@@ -744,6 +755,10 @@ int textcnn_proj_compute_launch(const float *table, int64_t V, const ProjTower *
 }
 
 void proj_gemm_set_form(int balanced) { g_gemm_balanced = balanced; }
+int proj_gemm_math_mode() { return g_gemm_math; }
+void proj_gemm_set_math(int mode, float table_maxabs, float weight_maxabs) {
+    g_gemm_math = mode; g_table_maxabs = table_maxabs; g_weight_maxabs = weight_maxabs;
+}
 
 int textcnn_proj_fwd_launch(const float *table, int64_t V, const ProjTower *tw, int ntower,
                             int64_t N, int T, int E, int F, bool zero_state, hipStream_t st) {

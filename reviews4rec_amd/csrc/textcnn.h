@@ -39,6 +39,8 @@ struct ProjTower {
     float *ptab;                 // [cap, 300] projected rows: 3 taps x 100 filters
     float *pmax;                 // [N, proj_tiles(T), NP]
     int *parg;
+    float *wimg = nullptr;       // optional scratch of textcnn_wp_floats(E) floats (the direct conv's weight-image region):
+                                 // the fp16-split GEMM packs its B operand there; absent -> fp32 GEMM
 };
 int proj_tiles(int T);
 int64_t proj_row_capacity(int64_t N, int T, int64_t V);
@@ -50,6 +52,8 @@ int textcnn_proj_tokens_launch(int64_t V, const ProjTower *tw, int ntower, int64
                                bool zero_state, hipStream_t st);
 int textcnn_proj_compute_launch(const float *table, int64_t V, const ProjTower *tw, int ntower,
                                 int64_t N, int T, int E, int F, hipStream_t st);
+void proj_gemm_set_math(int mode, float table_maxabs, float weight_maxabs);
+int proj_gemm_math_mode();   // 0: fp32 MFMA (default), 1: fp16-split operands, fp32 accumulate
 void proj_gemm_set_form(int balanced);          // 1: balanced 7-row-tile form where it applies (default), 0: tile form, -1: env
 // R4R_CONV_AUTO / _DIRECT / _PROJECT (include/r4r.h) -> the algorithm to run; honours R4R_CONV_ALGO
 int textcnn_pick_algo(int requested, int64_t N, int T, int E, int F);

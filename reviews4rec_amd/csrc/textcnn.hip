@@ -404,7 +404,7 @@ extern "C" size_t r4r_textcnn_ws_bytes(int64_t N, int T, int E, int F, int64_t V
     const size_t partials = 2 * align256((size_t)N * tiles128 * NP * 4);
     const size_t fwd = align256(textcnn_wp_floats(E) * 4) + partials;
     const size_t proj = partials + 2 * align256((size_t)(V + 4) * 4) + align256((size_t)proj_row_capacity(N, T, V) * 4) +
-                        align256(256) + align256(proj_ptab_floats(N, T, V) * 4);
+                        align256(256) + align256(proj_ptab_floats(N, T, V) * 4) + align256(textcnn_wp_floats(E) * 4);
     const int ns = textcnn_wgrad_splits(N);
     const size_t bwd = align256((size_t)ns * F * 3 * E * 4) + align256((size_t)ns * F * 4);
     size_t m = fwd > bwd ? fwd : bwd;
@@ -448,6 +448,10 @@ extern "C" int r4r_textcnn_fwd(const float *table, int64_t V, const int64_t *idx
         pt.list = reinterpret_cast<int *>(take((size_t)proj_row_capacity(N, T, V) * 4));
         pt.count = reinterpret_cast<int *>(take(256));
         pt.ptab = reinterpret_cast<float *>(take(proj_ptab_floats(N, T, V) * 4));
+        // scratch of the opt-in fp16-split GEMM: handed over only in mode 2 (the caller vouches that the scales given
+        // to r4r_gemm_math describe THIS table and these weights; mode 1 is for the fused steps, whose host refreshes them)
+        float *wimg = reinterpret_cast<float *>(take(textcnn_wp_floats(E) * 4));
+        pt.wimg = proj_gemm_math_mode() == 2 ? wimg : nullptr;
         if (int rc = textcnn_proj_fwd_launch(table, V, &pt, 1, N, T, E, F, /*zero_state=*/true, st)) return rc;
         return textcnn_pool_finish_launch(pmax, parg, pooled, argmax, N, proj_tiles(T), F, st);
     }
@@ -482,6 +486,14 @@ extern "C" int r4r_conv_pick(int E, int T, int64_t docs, int64_t rows, int64_t V
     const double t_gather = (double)docs * P * (0.085 + 0.0006 * ((double)rows * 1200.0 / 1e6)) * 1e-3;
     const double t_tokens = 4.0 + 0.027 * ((double)V / 1000.0);
     return (t_gemm + t_gather + t_tokens < t_direct) ? R4R_CONV_PROJECT : R4R_CONV_DIRECT;
+}
+
+extern "C" int r4r_gemm_math(int mode, float table_maxabs, float weight_maxabs) {
+    R4R_REQUIRE(mode >= 0 && mode <= 2, "gemm_math: mode %d (0 fp32, 1 f16x2 in the fused steps, 2 also in r4r_textcnn_fwd)", mode);
+    R4R_REQUIRE(mode == 0 || (table_maxabs > 0.f && table_maxabs < 3.0e38f && weight_maxabs > 0.f && weight_maxabs < 3.0e38f),
+                "gemm_math: f16x2 needs max |table| > 0 and max |conv weights| > 0");
+    proj_gemm_set_math(mode, table_maxabs, weight_maxabs);
+    return R4R_OK;
 }
 
 extern "C" int r4r_gemm_form(int balanced) {

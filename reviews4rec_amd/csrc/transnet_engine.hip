@@ -423,7 +423,7 @@ extern "C" int r4r_transnet_step(const float *table, int64_t V,
             pt[t].conv_w = P[cw[t]]; pt[t].conv_b = P[cb[t]];
             pt[t].flags = w.flags[token_buffer][t]; pt[t].slot = w.slot[token_buffer][t];
             pt[t].list = w.list[token_buffer][t]; pt[t].count = w.count[token_buffer][t];
-            pt[t].ptab = w.ptab[t]; pt[t].pmax = w.pmax[t]; pt[t].parg = w.parg[t];
+            pt[t].ptab = w.ptab[t]; pt[t].pmax = w.pmax[t]; pt[t].parg = w.parg[t]; pt[t].wimg = w.wp[t];
         }
         if (!tokens_ready)
             if (int rc = textcnn_proj_tokens_launch(V, pt, 3, B, T, /*zero_state=*/false, st)) return rc;

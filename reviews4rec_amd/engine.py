@@ -21,6 +21,27 @@ from . import _lib
 from ._lib import ptr
 
 
+GEMM_MATH_REFRESH = 32        # steps between two reads of max |conv weights| (one small D2H sync each)
+_MATH_OWNER = [None]          # the engine whose table / weights the process-wide scales currently describe
+
+
+def apply_gemm_math(table, conv_weights=()):
+    """R4R_GEMM_MATH=f16x2 switches the projection GEMM to fp16-split operands with fp32 accumulation (an
+    opt-in experiment, csrc/project_f16.hip; never the default).  Its exact power-of-two scales come from
+    here: the frozen table's maximum and the conv weights' (re-read every GEMM_MATH_REFRESH steps by the
+    engines; the device-side scale keeps two binades of headroom, Adam moves a weight by <= lr per step)."""
+    mode = os.environ.get('R4R_GEMM_MATH', 'f32')
+    if mode not in ('f32', 'f16x2'):
+        raise ValueError("R4R_GEMM_MATH must be 'f32' or 'f16x2', got %r" % (mode,))
+    lib = _lib.lib()
+    if mode == 'f16x2':
+        wmax = max([float(w.detach().abs().max().item()) for w in conv_weights] + [1e-30])
+        _lib.check(lib.r4r_gemm_math(1, float(table.detach().abs().max().item()), wmax), 'r4r_gemm_math')
+    else:
+        _lib.check(lib.r4r_gemm_math(0, 0.0, 0.0), 'r4r_gemm_math')
+    return mode
+
+
 class _ConvRule:
     """The engines' automatic choice between the two convolution algorithms (conv_algo = 0).
 
@@ -45,6 +66,11 @@ class _ConvRule:
     def _rule_request(self, docs_per_tower, T, training):
         """-> (algorithm to request from the C step, the one that will actually run, probe this step?)"""
         lib = _lib.lib()
+        if getattr(self, 'gemm_math', 'f32') == 'f16x2':
+            self._math_steps = getattr(self, '_math_steps', 0) + int(bool(training))
+            if _MATH_OWNER[0] is not self or (training and self._math_steps % GEMM_MATH_REFRESH == 0):
+                apply_gemm_math(self.table, self._conv_weights())       # (several engines in one process: re-own)
+                _MATH_OWNER[0] = self
         req, probe = self.conv_algo, False
         if req == 0 and lib.r4r_conv_algo(0, docs_per_tower, T, self.E, 100) == 2:
             n = self._rule_n
@@ -60,6 +86,10 @@ class _ConvRule:
         self.conv_rows = int(sum(int(c.view(torch.int32)[1]) for c in counters))
         if self.conv_rows > 0:
             self._rule_choice = int(_lib.lib().r4r_conv_pick(self.E, T, docs_total, self.conv_rows, self.V))
+
+    def _conv_weights(self):
+        """The towers' conv weights (what the fp16-split GEMM's weight scale is taken from)."""
+        return [p for k, p in self.model.named_parameters() if k.endswith('convs.0.weight')]
 
     @property
     def conv_choice(self):
@@ -84,6 +114,7 @@ class DeepCoNNEngine(_ConvRule):
         self.dev = self.table.device
         self.V, self.E = self.table.shape
         self.L = hp['latent_size']
+        self.gemm_math = apply_gemm_math(self.table, self._conv_weights())
         lib = _lib.lib()
         n = lib.r4r_deepconn_nparam()
         off, size, total = (ctypes.c_int64 * n)(), (ctypes.c_int64 * n)(), ctypes.c_int64()
@@ -601,6 +632,7 @@ class NarreEngine(_ConvRule):
         self.dev = self.table.device
         self.V, self.E = self.table.shape
         self.L = int(hp['latent_size'])
+        self.gemm_math = apply_gemm_math(self.table, self._conv_weights())
         lib = _lib.lib()
         n = getattr(lib, 'r4r_%s_nparam' % self.C)()
         off, size, total = (ctypes.c_int64 * n)(), (ctypes.c_int64 * n)(), ctypes.c_int64()
