@@ -23,8 +23,10 @@
 // rows.  With the matrix pipe 5x faster the kernel is bound by the L1 / TA line-request rate of its
 // staging, so gathered 128-byte row pieces for B (first version: 50 us) were the wrong shape.
 //
-// Structure = the tile form of project.hip (persistent grid, 128-row x 304-column tiles, 8 waves of
-// 32 rows x (10 | 9) column tiles, LDS double-buffered, staging registers a chunk ahead); a K chunk is
+// Structure = the tile form of project.hip (persistent grid, 128-row x 304-column tiles, LDS double-buffered,
+// staging registers a chunk ahead) with squarer wave tiles: 8 waves of 64 rows x (5 | 5 | 5 | 4) column tiles
+// read 18 instead of 24 operand pieces from LDS per 60 MFMAs -- with the matrix pipe this fast, LDS reads
+// are the next limiter; a K chunk is
 // 32 wide (one MFMA k-step) and holds both planes: a row is [32 hi | 32 lo] fp16 = 128 B + 16 B pad
 // (row stride 144 B = 16 x odd: the 16 rows a ds_read_b128 touches fall into distinct bank groups).
 #include "textcnn.h"
@@ -41,7 +43,7 @@ constexpr int HB_ROWS = 320;           // B rows staged (304 padded to 5 x 64)
 constexpr int HBUF = (HM + HB_ROWS) * HROW;        // bytes per LDS buffer (64,512)
 constexpr int H_LDS_BYTES = 2 * HBUF;               // 129,024
 constexpr int H_THREADS = 512;
-constexpr int HPF = 100, HPROW = 300, HNT = 19, HNH = 10, HNH_COLS = 160;
+constexpr int HPF = 100, HPROW = 300, HNH_COLS = 160;
 
 struct F16Tower {
     const float *conv_w;
@@ -106,7 +108,7 @@ __device__ __forceinline__ void proj_gemm_f16_body(const F16Args &a, char *lds, 
     const int E = a.E, nchunk = a.nchunk;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lrow = lane & 15, kq = lane >> 4;
-    const int half = wave >> 2, col0 = half * HNH_COLS;
+    const int rg = wave & 1, cg = wave >> 1, col0 = cg * 80;   // wave tile: rows 64 rg .. +63, column tiles 5 cg .. (+NTILE)
     // staging roles.  A: octet o (k = 8 o .. 8 o + 7) of row (tid >> 2), gathered from the table and split
     // here.  B: the packed image of a chunk is HB_ROWS * HROW = 46,080 contiguous bytes = 2,880 pieces of 16:
     // thread tid copies pieces tid + 512 i (i < 6; the last round is partial)
@@ -134,31 +136,44 @@ __device__ __forceinline__ void proj_gemm_f16_body(const F16Args &a, char *lds, 
         for (int i = 0; i < BROUNDS; ++i)
             if (tid + H_THREADS * i < BPIECES) *reinterpret_cast<h_f32x4 *>(Bl + (size_t)(tid + H_THREADS * i) * 16) = br[i];
     };
-    h_f32x4 acc[2][NTILE];
+    constexpr int MT = 4;                                   // row tiles per wave
+    h_f32x4 acc[MT][NTILE];
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
+    for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
         for (int ni = 0; ni < NTILE; ++ni) acc[mi][ni] = (h_f32x4){0.f, 0.f, 0.f, 0.f};
-    const int aoff = ((wave & 3) * 32 + lrow) * HROW + kq * 16;
+    const int aoff = (rg * 64 + lrow) * HROW + kq * 16;
     const int boff = (HM + col0 + lrow) * HROW + kq * 16;
     auto compute = [&](const char *buf) {
-        f16x8 ah[2], al[2];
+        f16x8 ah[MT], al[MT];
 #pragma unroll
-        for (int mi = 0; mi < 2; ++mi) {
+        for (int mi = 0; mi < MT; ++mi) {
             ah[mi] = *reinterpret_cast<const f16x8 *>(buf + aoff + mi * 16 * HROW);
             al[mi] = *reinterpret_cast<const f16x8 *>(buf + aoff + mi * 16 * HROW + 64);
         }
+        f16x8 bh[NTILE], bl[NTILE];
 #pragma unroll
         for (int ni = 0; ni < NTILE; ++ni) {
-            const f16x8 bh = *reinterpret_cast<const f16x8 *>(buf + boff + ni * 16 * HROW);
-            const f16x8 bl = *reinterpret_cast<const f16x8 *>(buf + boff + ni * 16 * HROW + 64);
-#pragma unroll
-            for (int mi = 0; mi < 2; ++mi) {
-                acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[mi], bh, acc[mi][ni], 0, 0, 0);   // small terms first
-                acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[mi], bl, acc[mi][ni], 0, 0, 0);
-                acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[mi], bh, acc[mi][ni], 0, 0, 0);
-            }
+            bh[ni] = *reinterpret_cast<const f16x8 *>(buf + boff + ni * 16 * HROW);
+            bl[ni] = *reinterpret_cast<const f16x8 *>(buf + boff + ni * 16 * HROW + 64);
         }
+        // term by term over all MT x NTILE accumulators: the three MFMAs of one accumulator are dependent, 20
+        // independent ones between them keep the matrix pipe issuing back to back (small terms first)
+#pragma unroll
+        for (int ni = 0; ni < NTILE; ++ni)
+#pragma unroll
+            for (int mi = 0; mi < MT; ++mi)
+                acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[mi], bh[ni], acc[mi][ni], 0, 0, 0);
+#pragma unroll
+        for (int ni = 0; ni < NTILE; ++ni)
+#pragma unroll
+            for (int mi = 0; mi < MT; ++mi)
+                acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[mi], bl[ni], acc[mi][ni], 0, 0, 0);
+#pragma unroll
+        for (int ni = 0; ni < NTILE; ++ni)
+#pragma unroll
+            for (int mi = 0; mi < MT; ++mi)
+                acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[mi], bh[ni], acc[mi][ni], 0, 0, 0);
     };
     // chunk c: LDS buffer c & 1 holds it; the staging registers hold chunk c + 1 (loaded a chunk ago)
     issue_loads(0);
@@ -176,14 +191,14 @@ __device__ __forceinline__ void proj_gemm_f16_body(const F16Args &a, char *lds, 
     float *slab = reinterpret_cast<float *>(lds) + wave * (16 * (HNH_COLS + 4));
     constexpr int NV = NTILE * 4;
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi) {
+    for (int mi = 0; mi < MT; ++mi) {
 #pragma unroll
         for (int ni = 0; ni < NTILE; ++ni)
 #pragma unroll
             for (int r = 0; r < 4; ++r) slab[(kq * 4 + r) * TS + ni * 16 + lrow] = acc[mi][ni][r] * out_scale;
         for (int i = lane; i < 16 * NV; i += 64) {
             const int rr = i / NV, cv = i - rr * NV;
-            const int row = row0 + (wave & 3) * 32 + mi * 16 + rr;
+            const int row = row0 + rg * 64 + mi * 16 + rr;
             const int col = col0 + cv * 4;
             if (row < count && col < HPROW)
                 *reinterpret_cast<h_f32x4 *>(tw.ptab + (size_t)row * HPROW + col) =
@@ -205,8 +220,8 @@ __global__ __launch_bounds__(H_THREADS) void proj_gemm_f16_kernel(F16Args a) {
 #pragma unroll
         for (int k = 0; k < MAX_TOWERS - 1; ++k)
             if (t == k && local >= nt[k]) { local -= nt[k]; t = k + 1; }
-        if (threadIdx.x >> 8) proj_gemm_f16_body<HNT - HNH>(a, hsmem, t, local * HM);
-        else proj_gemm_f16_body<HNH>(a, hsmem, t, local * HM);
+        if ((threadIdx.x >> 7) == 3) proj_gemm_f16_body<4>(a, hsmem, t, local * HM);   // waves 6, 7: column tiles 15..18
+        else proj_gemm_f16_body<5>(a, hsmem, t, local * HM);
         __syncthreads();
     }
 }

@@ -1226,3 +1226,28 @@ def test_idnet_engine_large_batches_with_popular_rows(kind, L, B):
         # Adam's first steps are lr * g / (|g| + eps): weights whose gradient is ~1e-8 amplify rounding;
         # bound the outliers by one lr step
         assert float((diff > 2e-5 + 1e-4 * v.abs()).float().mean()) < 5e-3 and float(diff.max()) < 2.1 * hp['lr'], k
+
+
+@pytest.mark.parametrize('case', ['deepconn_e20', 'deepconn_e64'])
+def test_engine_trajectory_under_the_fp16_split_gemm(case, monkeypatch):
+    """R4R_GEMM_MATH=f16x2 (opt-in): the DeepCoNN step with the fp16-split projection GEMM follows the
+    reference-generated trajectory at the SAME tolerances as the fp32 GEMM -- SE, weights after 1 and 3 steps."""
+    from reviews4rec_amd import _lib
+    from reviews4rec_amd.engine import DeepCoNNEngine
+    monkeypatch.setenv('R4R_GEMM_MATH', 'f16x2')
+    g = Golden(case)
+    try:
+        model, hp = build_model(g)
+        model.train()
+        eng = DeepCoNNEngine(model, lr=hp['lr'], weight_decay=hp['weight_decay'], conv_algo=2)
+        assert eng.gemm_math == 'f16x2'
+        for step in range(3):
+            data, y = g.batch(step % 2, DEV)
+            se = eng.train_step(data, y).clone()
+            torch.testing.assert_close(se.cpu(), g.arr('se%d' % step), rtol=1e-4, atol=1e-5)
+            if step in (0, 2):
+                sd = model.state_dict()
+                for k, v in g.params('w%d' % (step + 1)).items():
+                    torch.testing.assert_close(sd[k].cpu(), v, rtol=1e-5, atol=5e-6, msg=lambda m: k + ': ' + m)
+    finally:
+        _lib.lib().r4r_gemm_math(0, 0.0, 0.0)

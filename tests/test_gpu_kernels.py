@@ -420,3 +420,40 @@ def test_projection_gemm_balanced_form_is_bit_identical_to_the_tile_form(V):
     if V <= 3000:
         ref_pooled, ref_arg, y = conv_pool_reference(idx, table, w, b)
         torch.testing.assert_close(p1.cpu(), ref_pooled, rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize('N,T,E,V,tscale', [(36, 1000, 300, 1500, 0.011), (700, 100, 64, 2000, 1.0), (64, 1000, 300, 20000, 3.0)])
+def test_fp16_split_gemm_is_as_accurate_as_the_fp32_gemm(N, T, E, V, tscale):
+    """The opt-in arithmetic of the projection GEMM (csrc/project_f16.hip: hi + lo fp16 operands, three f16-MFMA
+    products per fp32 product, fp32 accumulation, exact power-of-two scaling) against a float64 convolution: its
+    error must be of the fp32 GEMM's order (measured: at or below it), the argmax identical, a table row four
+    orders of magnitude below the maximum included."""
+    from reviews4rec_amd import _lib
+    ops = _ops()
+    lib = _lib.lib()
+    g = torch.Generator().manual_seed(N + T)
+    table = (torch.rand((V, E), generator=g) * 2 - 1) * tscale
+    table[5] *= 1e-4
+    w = (torch.rand((100, 1, 3, E), generator=g) - 0.5) * (2 * math.sqrt(6.0 / (3 * E + 300 * E)))
+    b = (torch.rand(100, generator=g) - 0.5) * 0.1
+    zipf = torch.distributions.Categorical(probs=1.0 / torch.arange(1, V + 1).float())
+    idx = zipf.sample((N, T))
+    idx[0, :7] = 5
+    x = F.embedding(idx, table.double()).unsqueeze(1)
+    ref = F.relu(F.conv2d(x, w.double(), b.double(), padding=(2, 0))).squeeze(-1).max(dim=2).values
+    args = (idx.to(DEV), table.to(DEV), w.to(DEV), b.to(DEV))
+    try:
+        lib.r4r_gemm_math(0, 0.0, 0.0)
+        p32, a32 = ops.textcnn_fwd_raw(*args)
+        p32, a32 = p32.cpu().double(), a32.cpu()
+        lib.r4r_gemm_math(2, float(table.abs().max()), float(w.abs().max()))
+        p16, a16 = ops.textcnn_fwd_raw(*args)
+        p16, a16 = p16.cpu().double(), a16.cpu()
+    finally:
+        lib.r4r_gemm_math(0, 0.0, 0.0)
+    scale = float(ref.abs().max())
+    e32, e16 = float((p32 - ref).abs().max()) / scale, float((p16 - ref).abs().max()) / scale
+    assert e16 <= 2.0 * e32 + 1e-7, (e32, e16)
+    assert not torch.equal(p16, p32)                         # (it really ran the other arithmetic)
+    assert float((a16 == a32).float().mean()) > 0.9999
+    torch.testing.assert_close(p16.float(), ref.float(), rtol=1e-5, atol=1e-6)

@@ -23,3 +23,5 @@ run "cfg2 shapes, MF (L=32) native" --workload cfg2_mfdot_electronics --model-ty
 run "cfg2 shapes, MF (L=32) graph" --workload cfg2_mfdot_electronics --model-type MF --latent 32 --engine graph
 run "cfg2 shapes, NeuMF (L=32) native" --workload cfg2_mfdot_electronics --model-type NeuMF --latent 32
 run "cfg2 shapes, NeuMF (L=32) graph" --workload cfg2_mfdot_electronics --model-type NeuMF --latent 32 --engine graph
+run "cfg3 fp16-split GEMM (opt-in) native" --gemm-math f16x2
+run "cfg4 fp16-split GEMM (opt-in) native" --workload cfg4_narre_kindle --gemm-math f16x2
