@@ -473,3 +473,8 @@ def main(hyper_params, gpu_id=None):
     method = main_NeuMF if mt == 'NeuMF' else main_pytorch
     metrics, user_count_mse_map, item_count_mse_map = method(hyper_params, gpu_id=gpu_id)
     return metrics
+
+
+if __name__ == '__main__':                                # main.py:432-434: python -m reviews4rec_amd.main
+    from .hyper_params import hyper_params
+    main(hyper_params)

@@ -78,6 +78,13 @@ def clear_log_file(log_file):
     open(log_file, 'w').close()
 
 
+def pretty_print(h):
+    print('{')
+    for key in h:
+        print(' ' * 4 + str(key) + ': ' + h[key])
+    print('}\n')
+
+
 def log_end_epoch(hyper_params, metrics, epoch, time_elpased, metrics_on='(VAL)'):
     string2 = ''.join(' | ' + m + ' = ' + str(metrics[m]) for m in metrics) + ' ' + metrics_on
     ss = '-' * 89
