@@ -112,7 +112,7 @@ def parse():
                     help='weak: --batch-per-gpu ratings per rank (default); strong: --global-batch ratings per step '
                          'sharded over the ranks')
     ap.add_argument('--global-batch', type=int, default=1024, help='--scaling strong: ratings per step over all ranks')
-    ap.add_argument('--strong-leg', default='1024,8192',
+    ap.add_argument('--strong-leg', default='1024,8192,32768',
                     help='weak runs at N > 1 also time strong-scaling legs at these global batch sizes '
                          "(comma list; '' skips): the fixed global batch is sharded over the ranks")
     ap.add_argument('--doc-fill', choices=['lognormal', 'full'], default='lognormal',
@@ -272,8 +272,8 @@ def main():
     # generator IS its shard -- ratings are i.i.d. draws)
     gen = synthetic.Generator(hp, seed=synthetic.SEED + rank, doc_fill=args.doc_fill, token_dist=args.token_dist)
 
-    def make_pool(b):
-        np_batches = [gen.batch(b) for _ in range(args.pool)]
+    def make_pool(b, n=None):
+        np_batches = [gen.batch(b) for _ in range(n or args.pool)]
         return np_batches, [([torch.from_numpy(d).to(dev) for d in data], torch.from_numpy(y).to(dev))
                             for data, y in np_batches]
 
@@ -419,7 +419,7 @@ def main():
             bs = G // world
             if engine is not None and native_step_limits(dict(hp, batch_size=bs), world):
                 continue
-            _, pool_s = make_pool(bs)
+            _, pool_s = make_pool(bs, n=max(2, min(args.pool, 8192 // bs)))      # (large shards: two resident batches)
             step_s = make_step(pool_s, bs, G)
             for i in range(10):
                 step_s(i)
