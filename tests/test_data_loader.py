@@ -111,3 +111,127 @@ def test_quick_data_writer_round_trip(tmp_path, monkeypatch):
         for s in range(7):
             assert np.array_equal(data[s].numpy(), z['train/%d/%d' % (k, s)])
         assert np.array_equal(y.numpy(), z['train/%d/y' % k])
+
+
+def _random_dataset(seed, U=17, I=11, V=40):
+    """Random interactions in the reference's schema with the awkward cases on purpose: users / items without
+    any train review, empty reviews, owners with more than ten reviews, reviews longer than narre_num_words."""
+    rng = np.random.default_rng(seed)
+    pairs = [(u, i) for u in range(U) for i in range(I) if rng.random() < 0.45 and u != 3 and i != 2]
+    rng.shuffle(pairs)
+    cut = int(0.75 * len(pairs))
+    rev = lambda: [] if rng.random() < 0.15 else [int(t) for t in rng.integers(0, V, size=int(rng.integers(1, 23)))]
+    train = [[u, i, float(rng.integers(1, 6))] for u, i in pairs[:cut]]
+    held = [[u, i, float(rng.integers(1, 6))] for u, i in pairs[cut:]] + [[3, 2, 4.0]]   # a pair of two unseen ids
+    user_reviews, item_reviews, tiui = {u: [] for u in range(U)}, {i: [] for i in range(I)}, {}
+    for u, i, r in train:
+        text = rev()
+        tiui.setdefault(u, {})[i] = [len(user_reviews[u]), len(item_reviews[i])]
+        user_reviews[u].append(text)
+        item_reviews[i].append(text)
+    test_reviews = {}
+    for u, i, r in held:
+        test_reviews.setdefault(u, {})[i] = rev()
+    negs = {}
+    for u in range(U):
+        mine = [i for uu, i, r in held if uu == u]
+        if len(mine) >= 1:
+            others = [int(x) for x in rng.choice(I, size=5, replace=False)]
+            negs[u] = [[mine[0]], others]
+    return dict(train=train, held=held, user_reviews=user_reviews, item_reviews=item_reviews, tiui=tiui,
+                test_reviews=test_reviews, negs=negs, U=U, I=I)
+
+
+def _reference_fields(ds, hp, u, i, pos_i, train):
+    """The five review slots of ONE rating, restated literally from data.py:144-236 + 273-279 (list surgery,
+    nothing shared with reviews4rec_amd.data).  pos_i: the item remove_overlap is called with (iter_negs: the
+    positive's)."""
+    narre, T, R, W = hp['model_type'] == 'NARRE', hp['input_length'], hp['narre_num_reviews'], hp['narre_num_words']
+    u_r, i_r = [list(r) for r in ds['user_reviews'][u]], [list(r) for r in ds['item_reviews'][i]]
+    u2i = [0] * len(ds['user_reviews'][u])
+    for item, (ku, ki) in ds['tiui'].get(u, {}).items():
+        u2i[ku] = item
+    i2u = [0] * len(ds['item_reviews'][pos_i])
+    for user, per in ds['tiui'].items():
+        if pos_i in per:
+            i2u[per[pos_i][1]] = user
+    if train:
+        ku, ki = ds['tiui'][u][pos_i]
+        this = [u_r[ku]]
+        what = [x for k, x in enumerate(u2i) if k != ku]
+        who = [x for k, x in enumerate(i2u) if k != ki]
+        u_r = [r for k, r in enumerate(u_r) if k != ku]
+        i_r = [r for k, r in enumerate(i_r) if k != ki]
+    else:
+        this, what, who = [list(ds['test_reviews'][u][pos_i])], list(u2i), list(i2u)
+    who = (who + [hp['total_users'] + 1] * 10)[:10]
+    what = (what + [hp['total_items'] + 1] * 10)[:10]
+
+    def doc(reviews):
+        if narre:
+            rows = [(r + [0] * W)[:W] for r in reviews]
+            return (rows + [[0] * W] * R)[:R]
+        flat = [t for r in reviews for t in r]
+        return (flat + [0] * T)[:T]
+    return doc(this), who, what, doc(u_r), doc(i_r)
+
+
+@pytest.mark.parametrize('mt', ['deepconn', 'NARRE'])
+@pytest.mark.parametrize('seed', [1, 2, 3])
+def test_pool_arithmetic_equals_the_list_surgery_on_random_datasets(mt, seed):
+    """Property test of the token-pool index arithmetic (host evaluation) against a literal restatement of the
+    reference's per-rating list surgery, on random datasets with the awkward cases (no reviews, empty reviews, more
+    than ten reviews, over-long reviews, held-out pairs of unseen ids), train / held-out / negatives streams."""
+    from reviews4rec_amd.data import DataLoader
+    ds = _random_dataset(seed)
+    hp = dict(model_type=mt, batch_size=7, input_length=19, narre_num_reviews=10, narre_num_words=5,
+              total_users=ds['U'], total_items=ds['I'])
+    train = DataLoader(hp, ds['train'], ds['user_reviews'], ds['item_reviews'], ds['negs'],
+                       this_index_user_item=ds['tiui'], device='cpu')
+    held = DataLoader(hp, ds['held'], ds['user_reviews'], ds['item_reviews'], ds['negs'],
+                      test_reviews=ds['test_reviews'], train_loader=train, device='cpu')
+    for loader, rows, is_train in ((train, ds['train'], True), (held, ds['held'], False)):
+        at = 0
+        for data, y in loader.iter():
+            for b in range(y.shape[0]):
+                u, i, r = rows[at]
+                want = _reference_fields(ds, hp, u, i, i, is_train)
+                for s in range(5):
+                    assert data[s][b].tolist() == want[s], (mt, seed, is_train, at, s)
+                assert (int(data[5][b]), int(data[6][b]), float(y[b])) == (u, i, r)
+                at += 1
+        assert at == len(rows)
+    at = 0
+    users = list(ds['negs'])
+    for data, y in held.iter_negs(True):
+        for b in range(y.shape[0]):
+            u = users[at]
+            cands = [ds['negs'][u][0][0]] + ds['negs'][u][1]
+            for c, i2 in enumerate(cands):
+                want = _reference_fields(ds, hp, u, i2, cands[0], False)
+                for s in range(5):
+                    assert data[s][b, c].tolist() == want[s], (mt, seed, 'negs', at, c, s)
+                assert (int(data[5][b, c]), int(data[6][b, c])) == (u, i2)
+            at += 1
+    assert at == len(users)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('mt', ['deepconn', 'NARRE'])
+def test_device_batches_equal_host_batches_on_random_datasets(mt):
+    """r4r_batch_build against the host evaluation of the same pools, every stream, random awkward datasets."""
+    from reviews4rec_amd.data import DataLoader
+    for seed in (4, 5):
+        ds = _random_dataset(seed, U=60, I=25)
+        hp = dict(model_type=mt, batch_size=16, input_length=37, narre_num_reviews=10, narre_num_words=6,
+                  total_users=ds['U'], total_items=ds['I'])
+        mk = lambda dev: (lambda tr: (tr, DataLoader(hp, ds['held'], ds['user_reviews'], ds['item_reviews'], ds['negs'],
+                                                     test_reviews=ds['test_reviews'], train_loader=tr, device=dev)))(
+            DataLoader(hp, ds['train'], ds['user_reviews'], ds['item_reviews'], ds['negs'],
+                       this_index_user_item=ds['tiui'], device=dev))
+        (ct, ch), (gt, gh) = mk('cpu'), mk('cuda')
+        for a, b in ((ct.iter(), gt.iter()), (ch.iter(), gh.iter()), (ch.iter_negs(True), gh.iter_negs(True))):
+            for (cd, cy), (gd, gy) in zip(a, b):
+                for s in range(7):
+                    assert torch.equal(cd[s], gd[s].cpu()), (seed, s)
+                assert torch.equal(cy, gy.cpu())
