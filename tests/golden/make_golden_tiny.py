@@ -17,7 +17,8 @@ What is written under tests/golden/tiny/ (data only, no reference source):
                           eval.evaluate (eval.py:11-62) returned on the test loader -- metrics, both
                           count -> [SE] maps, the count dicts after their setdefault side effect --
                           and eval.eval_ranking's HR@1 (eval.py:64-92)
-  <mt>_e2e.npz + .json    main.main(hyper_params) end to end (main.py:400-414: load_data, xavier_init,
+  <mt>_e2e.npz + .json    (bias_only, MF_dot, MF, NeuMF -- main_NeuMF's three stages --, deepconn, deepconn++, NARRE)
+                          main.main(hyper_params) end to end (main.py:400-414: load_data, xavier_init,
                           train_complete over 3 epochs with per-epoch validation, best-model reload,
                           test MSE + HR@1), dropout 0: the post-init weights (captured by wrapping
                           utils.xavier_init) and every metrics dict the run logged
@@ -228,8 +229,9 @@ def run_e2e(mt, root, cwd):
 
     def observing_init(model):
         real_init(model)
+        tag = 'w/' if mt != 'NeuMF' else 'w_%s/' % type(model).__name__       # NeuMF: xavier_init runs on GMF and on MLP
         for k, v in model.state_dict().items():
-            captured['w/' + k] = v.detach().numpy().copy()
+            captured[tag + k] = v.detach().numpy().copy()
 
     def observing_log(hyper_params, metrics, epoch, time_elapsed, metrics_on='(VAL)'):
         logged.append({'epoch': epoch, 'on': metrics_on, 'metrics': dict(metrics)})
@@ -262,7 +264,7 @@ def main():
         len(ds['train']), len(ds['test']), len(ds['val']), len(ds['negs'])))
     for mt in ('deepconn', 'NARRE', 'MF_dot', 'transnet++'):
         run_streams_and_eval(mt, root)
-    for mt in ('bias_only', 'MF_dot', 'deepconn', 'deepconn++', 'NARRE'):
+    for mt in ('bias_only', 'MF_dot', 'MF', 'NeuMF', 'deepconn', 'deepconn++', 'NARRE'):
         run_e2e(mt, root, cwd)
 
 

@@ -129,7 +129,7 @@ def materialise_tiny(root):
 def tiny_hp(model_type, data_dir, **kw):
     """hyper_params of a tests/golden/tiny fixture (the generator's tiny_hp) + the data directory."""
     import json
-    name = {'deepconn++': 'deepconn++_e2e', 'bias_only': 'bias_only_e2e'}.get(model_type, model_type + '_eval')
+    name = model_type + ('_eval' if model_type in ('deepconn', 'NARRE', 'MF_dot', 'transnet++') else '_e2e')
     hp = dict(json.load(open(os.path.join(TINY_DIR, name + '.json')))['hp'])
     for k in ('total_users', 'total_items', 'total_words'):
         hp.pop(k, None)                                   # load_data sets them (data.py:469-471)

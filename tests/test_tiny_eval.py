@@ -13,7 +13,7 @@ import torch
 from helpers import TINY_DIR, OracleModule, materialise_tiny, tiny_hp
 
 EVAL_MODELS = ['deepconn', 'NARRE', 'MF_dot', 'transnet++']
-E2E_MODELS = ['bias_only', 'MF_dot', 'deepconn', 'deepconn++', 'NARRE']
+E2E_MODELS = ['bias_only', 'MF_dot', 'MF', 'NeuMF', 'deepconn', 'deepconn++', 'NARRE']
 MSE_TOL = 2e-4          # metrics are rounded to 4 decimals (eval.py:56): one unit of rounding + fp32 noise
 
 
@@ -109,9 +109,9 @@ def test_main_end_to_end_vs_reference(mt, tmp_path, monkeypatch):
     meta, z = _fixture(mt, 'e2e')
     root = materialise_tiny(tmp_path)
     hp = tiny_hp(mt, root, log_file=str(tmp_path / 'log'), model_path=str(tmp_path / 'model'))
-    init = _weights(z)
-
     def fixture_init(model):                   # the reference drew these with its own RNG stream
+        # (NeuMF: main_NeuMF runs xavier_init on the GMF and on the MLP stage model; NeuMF itself is built by init())
+        init = _weights(z, 'w/' if mt != 'NeuMF' else 'w_%s/' % type(model).__name__)
         model.load_state_dict({k: v.to(next(model.parameters()).device) for k, v in init.items()}, strict=True)
 
     logged = []
