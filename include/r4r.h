@@ -527,7 +527,7 @@ int r4r_transnet_rows_apply(const int64_t *uid_all, const int64_t *iid_all, cons
  * Fused native step for the ID-only recommenders with dense layers: model_type 'MF' (MF.py:60-68) and
  * the NeuMF family (NeuMF.py: GMF :10-36, MLP :38-72, NeuMF :74-143; main.py:289-340 trains them in
  * three stages).  Replaces, per training step, the model's forward, MSELoss (loss.py:7-11),
- * loss.backward() and torch.optim.Adam.step() (main.py:56-60,94-96) by 4 launches (5 for NeuMF): a head
+ * loss.backward() and torch.optim.Adam.step() (main.py:56-60,94-96) by 3 launches (4 for NeuMF): a head
  * kernel per rating (forward + backward, compact ID-table gradient rows), the dense-gradient column sums
  * + Adam, and the tagged Adam sweeps over the ID tables and bias vectors (every row moves every step;
  * no dense table gradient is materialised).

@@ -11,11 +11,11 @@
 //                          compact ([B, L] per table), row tags for the sweeps
 //   2  idnet_reduce_kernel column sums of that matrix in a fixed order = the dense gradient, Adam on
 //                          every dense parameter the moment its sum is complete, running sum of SE
-//   3+ the tagged Adam sweeps of mf_engine.hip over the ID tables (one launch per user / item table
-//      pair: NeuMF has two) and over the two bias vectors: every row moves every step (weight decay,
-//      SURVEY fact 4), the dense gradient of a table is never materialised
+//   3+ the tagged Adam sweep of mf_engine.hip over the first user / item table pair AND the two bias vectors
+//      in one launch (NeuMF's second pair in another): every row moves every step (weight decay, SURVEY
+//      fact 4), the dense gradient of a table is never materialised
 //
-// 4 launches per step (5 for NeuMF) against ~40 dependent ones op by op.  Variants share one kernel:
+// 3 launches per step (4 for NeuMF) against ~40 dependent ones op by op.  Variants share one kernel:
 //   variant      rows gathered            z (input of the final layer)            final
 //   0 MF         A                         [mlp(A), uA * iA]        (MF.py:60-66)  TorchFM(2L, L)
 //   1 GMF        A                         uA * iA                  (NeuMF.py:32)  Linear(L, 1)
@@ -81,7 +81,7 @@ __global__ __launch_bounds__(256) void idnet_head_kernel(IdnHead a) {
     __shared__ float W1[ML][2 * ML + 1], W3[ML][ML + 1], FV[2 * ML][ML + 1];
     __shared__ float row[2][2][ML], rm[2][2][ML];          // gathered rows after dropout, their multipliers
     __shared__ float cat[2 * ML], catm[2 * ML], hid[ML], mlp[ML], z[2 * ML], dz[2 * ML], dmlp[ML], dhid[ML], dcat[2 * ML];
-    __shared__ float b1[ML], b3[ML], fw[2 * ML], sfm[ML], misc[8];
+    __shared__ float b1[ML], b3[ML], fw[2 * ML], sfm[ML], tfm[ML], misc[8];
     const int L = a.L, L2 = 2 * L, tid = threadIdx.x, v = a.variant;
     const int64_t b = blockIdx.x;
     const float *fp = a.flat_p;
@@ -152,10 +152,12 @@ __global__ __launch_bounds__(256) void idnet_head_kernel(IdnHead a) {
     }
     __syncthreads();
     // ---- S4: final layer.  FM (common_pytorch_models.py:49-57): 0.5 (|zV|^2 - z^2 . V^2) + lin(z)
-    if (fm && tid < L) {
-        float s = 0.f;
+    if (fm && tid < L) {                                    // column k = tid of z V and of z^2 V^2
+        float s = 0.f, t = 0.f;
         for (int i = 0; i < nz; ++i) s = fmaf(z[i], FV[i][tid], s);
+        for (int i = 0; i < nz; ++i) t = fmaf(z[i] * z[i], FV[i][tid] * FV[i][tid], t);
         sfm[tid] = s;
+        tfm[tid] = t;
     }
     __syncthreads();
     if (tid == 0) {
@@ -165,11 +167,7 @@ __global__ __launch_bounds__(256) void idnet_head_kernel(IdnHead a) {
         if (fm) {
             float s1 = 0.f, s2 = 0.f;
             for (int k = 0; k < L; ++k) s1 = fmaf(sfm[k], sfm[k], s1);
-            for (int k = 0; k < L; ++k) {
-                float t = 0.f;
-                for (int i = 0; i < nz; ++i) t = fmaf(z[i] * z[i], FV[i][k] * FV[i][k], t);
-                s2 += t;
-            }
+            for (int k = 0; k < L; ++k) s2 += tfm[k];
             rating = 0.5f * (s1 - s2) + rating;
         }
         const float pred = ((misc[2] + misc[3]) + misc[1]) + rating;      // user_bias + item_bias + global_bias + rating
@@ -413,13 +411,16 @@ extern "C" int r4r_idnet_step(int variant, const int64_t *uid, const int64_t *ii
         rv[k] = reinterpret_cast<float *>(rows_v[k]);
         R4R_REQUIRE(!used || (rp[k] && rm[k] && rv[k]), "idnet_step: table / bias %d: null parameter / moment pointer", k);
     }
-    for (int pr = 0; pr < npair; ++pr)
-        if (int rc = mf_table_rows_launch(rp[2 * pr], rm[2 * pr], rv[2 * pr], rp[2 * pr + 1], rm[2 * pr + 1], rv[2 * pr + 1],
-                                          n_users, n_items, L, uid, iid, w.grow[pr][0], w.grow[pr][1], w.tag[0], w.tag[1],
-                                          nullptr, nullptr, B, (int)adam_step, sc, st))
-            return rc;
-    return mf_bias_rows_launch(rp[4], rm[4], rv[4], rp[5], rm[5], rv[5], n_users, n_items, uid, iid, w.g, w.tag[0], w.tag[1], B,
-                               (int)adam_step, sc, st);
+    // the first table pair and the two bias vectors in one launch (an entry wave that owns a row updates the row
+    // and its bias element); NeuMF's second pair in another
+    if (int rc = mf_table_bias_rows_launch(rp[0], rm[0], rv[0], rp[1], rm[1], rv[1], rp[4], rm[4], rv[4], rp[5], rm[5], rv[5],
+                                           n_users, n_items, L, uid, iid, w.grow[0][0], w.grow[0][1], w.g, w.tag[0], w.tag[1],
+                                           B, (int)adam_step, sc, st))
+        return rc;
+    if (npair == 2)
+        return mf_table_rows_launch(rp[2], rm[2], rv[2], rp[3], rm[3], rv[3], n_users, n_items, L, uid, iid, w.grow[1][0],
+                                    w.grow[1][1], w.tag[0], w.tag[1], nullptr, nullptr, B, (int)adam_step, sc, st);
+    return R4R_OK;
 }
 
 // Data parallel: the ID-table / bias updates from ALL ranks' compact rows, gathered by the caller in rank order
@@ -463,14 +464,17 @@ extern "C" int r4r_idnet_rows_apply(int variant, const int64_t *uid_all, const i
     }
     idn_tag_rows_kernel<<<(unsigned)cdiv(B_all, 256), 256, 0, st>>>(uid_all, iid_all, B_all, w.tag[0], w.tag[1], (int)adam_step);
     const AdamScalars sc = adam_make_scalars(lr, beta1, beta2, eps, weight_decay, adam_step, nullptr);
+    const float *gu[2], *gi[2];
     for (int pr = 0; pr < npair; ++pr) {
-        const float *gu = reinterpret_cast<const float *>(gu_all[pr]), *gi = reinterpret_cast<const float *>(gi_all[pr]);
-        R4R_REQUIRE(gu && gi, "idnet_rows_apply: null gradient rows of pair %d", pr);
-        if (int rc = mf_table_rows_launch(rp[2 * pr], rm[2 * pr], rv[2 * pr], rp[2 * pr + 1], rm[2 * pr + 1], rv[2 * pr + 1],
-                                          n_users, n_items, L, uid_all, iid_all, gu, gi, w.tag[0], w.tag[1], nullptr, nullptr,
-                                          B_all, (int)adam_step, sc, st))
-            return rc;
+        gu[pr] = reinterpret_cast<const float *>(gu_all[pr]); gi[pr] = reinterpret_cast<const float *>(gi_all[pr]);
+        R4R_REQUIRE(gu[pr] && gi[pr], "idnet_rows_apply: null gradient rows of pair %d", pr);
     }
-    return mf_bias_rows_launch(rp[4], rm[4], rv[4], rp[5], rm[5], rv[5], n_users, n_items, uid_all, iid_all, g_all, w.tag[0],
-                               w.tag[1], B_all, (int)adam_step, sc, st);
+    if (int rc = mf_table_bias_rows_launch(rp[0], rm[0], rv[0], rp[1], rm[1], rv[1], rp[4], rm[4], rv[4], rp[5], rm[5], rv[5],
+                                           n_users, n_items, L, uid_all, iid_all, gu[0], gi[0], g_all, w.tag[0], w.tag[1],
+                                           B_all, (int)adam_step, sc, st))
+        return rc;
+    if (npair == 2)
+        return mf_table_rows_launch(rp[2], rm[2], rv[2], rp[3], rm[3], rv[3], n_users, n_items, L, uid_all, iid_all, gu[1],
+                                    gi[1], w.tag[0], w.tag[1], nullptr, nullptr, B_all, (int)adam_step, sc, st);
+    return R4R_OK;
 }

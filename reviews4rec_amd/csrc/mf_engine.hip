@@ -730,6 +730,46 @@ int mf_table_rows_launch(float *ut, float *ut_m, float *ut_v, float *it, float *
     return check_launch("table rows");
 }
 
+// Both of the above in ONE launch: two ID tables of width D with compact gradient rows AND the two ID bias
+// vectors whose gradient is d loss / d pred of the ratings that name the id (r4r_idnet_step: MF, GMF, MLP, NeuMF's
+// first table pair).  An entry wave that owns a row updates the table row and the row's bias element together.
+int mf_table_bias_rows_launch(float *ut, float *ut_m, float *ut_v, float *it, float *it_m, float *it_v,
+                              float *ub, float *ub_m, float *ub_v, float *ib, float *ib_m, float *ib_v,
+                              int64_t n_users, int64_t n_items, int D, const int64_t *uid, const int64_t *iid,
+                              const float *gu, const float *gi, const float *g, const int *tag_u, const int *tag_i,
+                              int64_t B, int now, const AdamScalars &sc, hipStream_t st) {
+    if (B > MF_MAX_B || D < 1 || D > MF_MAX_D) {
+        set_error("table + bias rows: batch %lld > %d or width %d outside 1..%d", (long long)B, MF_MAX_B, D, MF_MAX_D);
+        return R4R_ERR_ARG;
+    }
+    MfSweep sw{};
+    sw.p0 = ut; sw.m0 = ut_m; sw.v0 = ut_v; sw.p1 = it; sw.m1 = it_m; sw.v1 = it_v;
+    sw.p2 = ub; sw.m2 = ub_m; sw.v2 = ub_v; sw.p3 = ib; sw.m3 = ib_m; sw.v3 = ib_v;
+    sw.n0 = n_users * D; sw.n1 = n_items * D; sw.n2 = n_users; sw.n3 = n_items;
+    int64_t chunks = cdiv(sw.n0, mf_chunk(0));
+    sw.cb1 = (int)chunks;
+    chunks += cdiv(sw.n1, mf_chunk(1));
+    sw.cb2 = (int)chunks;
+    chunks += cdiv(sw.n2, mf_chunk(2));
+    sw.cb3 = (int)chunks;
+    chunks += cdiv(sw.n3, mf_chunk(3));
+    sw.cb_global = sw.cb_entries = (int)chunks;             // no global-bias workgroup: the caller keeps it elsewhere
+    sw.epw = mf_epw(B);
+    sw.n_entry_wgs = (int)(2 * cdiv(B, 4 * sw.epw));
+    chunks += sw.n_entry_wgs;
+    if (chunks >= (1ll << 31)) {
+        set_error("table + bias rows: too many workgroups");
+        return R4R_ERR_ARG;
+    }
+    sw.uid = uid; sw.iid = iid; sw.gu = gu; sw.gi = gi; sw.g = g; sw.se = nullptr; sw.sse_accum = nullptr;
+    sw.tag_u = tag_u; sw.tag_i = tag_i; sw.B = B; sw.D = D; sw.now = now; sw.s = sc;
+    {
+        ScopedTiming tm(R4R_TIMING_ADAM, st);
+        mf_adam_kernel<4><<<(unsigned)chunks, MF_THREADS, (size_t)B * sizeof(int), st>>>(sw);
+    }
+    return check_launch("table + bias rows");
+}
+
 }  // namespace r4r
 
 using namespace r4r;
