@@ -72,32 +72,63 @@ __global__ __launch_bounds__(256) void dcpp_head_kernel(DcppHead a) {
     };
     const float invL2 = 1.f / (float)L2;
     auto qd = [](int v, float inv) { return (int)(((float)v + 0.5f) * inv); };
-    // ---- S0: weights, pool finish (max over tiles, relu, first argmax), biases
-    for (int i = tid; i < 2 * L * NF; i += 256) {
-        const int s = i >= L * NF, r = i - s * L * NF, l = r / NF;
-        fcw[s][l][r - l * NF] = fp[a.off[s ? DP_IFW : DP_UFW] + r];
+    // ---- S0: weights, pool finish (max over tiles, relu, first argmax), biases.  All global reads are
+    // issued into registers before anything waits (a load -> LDS-store loop is one memory round
+    // trip per iteration, the tile loop of the pool finish one per tile)
+    constexpr int WREG = (2 * ML * NF + 255) / 256, AREG = (ML * 2 * ML + 255) / 256, PT = 8;
+    float wv[WREG], av[AREG];
+    const int wtot = 2 * L * NF;
+#pragma unroll
+    for (int u = 0; u < WREG; ++u) {
+        wv[u] = 0.f;
+        if (256 * u < wtot) {
+            const int i = min(tid + 256 * u, wtot - 1), s = i >= L * NF;
+            wv[u] = fp[a.off[s ? DP_IFW : DP_UFW] + i - s * L * NF];
+        }
     }
-    for (int i = tid; i < L * L2; i += 256) { const int k = qd(i, invL2); W1[k][i - k * L2] = fp[a.off[DP_F0W] + i]; }
-    if (tid < L2) fcbs[tid] = fp[a.off[tid >= L ? DP_IFB : DP_UFB] + (tid >= L ? tid - L : tid)];
-    if (tid < L) { b1s[tid] = fp[a.off[DP_F0B] + tid]; w3s[tid] = fp[a.off[DP_F3W] + tid]; }
-    if (tid == 0) {
-        misc[0] = fp[a.off[DP_F3B]]; misc[1] = fp[a.off[DP_GB]];
-        misc[2] = a.bias[0][a.id[0][b]]; misc[3] = a.bias[1][a.id[1][b]];
-    }
+#pragma unroll
+    for (int u = 0; u < AREG; ++u) av[u] = 256 * u < L * L2 ? fp[a.off[DP_F0W] + min(tid + 256 * u, L * L2 - 1)] : 0.f;
+    const int t2 = min(tid, L2 - 1), tl = min(tid, L - 1);
+    const float fcb_r = fp[a.off[t2 >= L ? DP_IFB : DP_UFB] + (t2 >= L ? t2 - L : t2)];
+    const float b1_r = fp[a.off[DP_F0B] + tl], w3_r = fp[a.off[DP_F3W] + tl];
+    const float m0 = fp[a.off[DP_F3B]], m1 = fp[a.off[DP_GB]];
+    const float m2 = a.bias[0][a.id[0][b]], m3 = a.bias[1][a.id[1][b]];
     if (tid < 2 * NF) {
         const int s = tid >= NF, f = tid - s * NF;
         float best = -INFINITY;
         int bp = -1;
-        for (int k = 0; k < a.tiles; ++k) {
-            const size_t q = ((size_t)b * a.tiles + k) * NP + f;
-            const float val = a.pmax[s][q];
-            if (val > best) { best = val; bp = a.parg[s][q]; }
+        for (int k0 = 0; k0 < a.tiles; k0 += PT) {
+            float v[PT];
+            int pp[PT];
+#pragma unroll
+            for (int k = 0; k < PT; ++k) {
+                const bool in = k0 + k < a.tiles;
+                const size_t q = ((size_t)b * a.tiles + (in ? k0 + k : 0)) * NP + f;
+                v[k] = in ? a.pmax[s][q] : -INFINITY;
+                pp[k] = a.parg[s][q];
+            }
+#pragma unroll
+            for (int k = 0; k < PT; ++k)
+                if (v[k] > best) { best = v[k]; bp = pp[k]; }
         }
         if (!(best > 0.f)) { best = 0.f; bp = -1; }
         P[s][f] = best;
         a.pooled[s][b * NF + f] = best;
         a.argmax[s][b * NF + f] = bp;
     }
+#pragma unroll
+    for (int u = 0; u < WREG; ++u) {
+        const int i = tid + 256 * u;
+        if (i < wtot) { const int s = i >= L * NF, r = i - s * L * NF, l = r / NF; fcw[s][l][r - l * NF] = wv[u]; }
+    }
+#pragma unroll
+    for (int u = 0; u < AREG; ++u) {
+        const int i = tid + 256 * u;
+        if (i < L * L2) { const int k = qd(i, invL2); W1[k][i - k * L2] = av[u]; }
+    }
+    if (tid < L2) fcbs[tid] = fcb_r;
+    if (tid < L) { b1s[tid] = b1_r; w3s[tid] = w3_r; }
+    if (tid == 0) { misc[0] = m0; misc[1] = m1; misc[2] = m2; misc[3] = m3; }
     __syncthreads();
     // ---- S1: TextCNN FC + dropout (common_pytorch_models.py:35-37)
     if (tid < L2) {
@@ -376,7 +407,7 @@ extern "C" int r4r_deepconnpp_step(const float *table, int64_t V, const int64_t 
         wa, cs, cs_blocks, nx, packed, RowSweep{}, 0, 2);
 
     const int red_blocks = (NF * 3 * E + NF + NRED_THREADS - 1) / NRED_THREADS;
-    const int comp_blocks = prefetch ? (int)cdiv((V + 3) / 4, NRED_THREADS) : 0;
+    const int comp_blocks = prefetch ? (int)cdiv((V + 3) / 4, NRED_THREADS * COMPACT_G) : 0;
     DenseAdam opt;
     opt.on = apply ? 1 : 0; opt.p = flat_p; opt.m = flat_m; opt.v = flat_v; opt.g = flat_g;
     opt.lo0 = lo0; opt.hi0 = hi0; opt.lo1 = lo1; opt.hi1 = hi1;

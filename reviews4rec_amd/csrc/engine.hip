@@ -23,6 +23,7 @@
 // SURVEY.md fact 7), so they are not in the flat buffer and Adam never sees them.
 #include <stdlib.h>
 
+#include "trace_device.h"
 #include "textcnn.h"
 #include "wgrad_device.h"
 #include "tokens_device.h"
@@ -82,8 +83,10 @@ constexpr int HEAD_MAX_TILES = 8;
 
 // ML: compile-time cap of the latent size (LDS arrays, register arrays and unrolled staging loops
 // are sized by it; instantiated for <= 16 and <= 32)
+HEAD_TRACE_DEFINE(r4r_debug_dc_head_trace)
 template <int ML>
 __global__ __launch_bounds__(256) void deepconn_head_kernel(HeadArgs a) {
+    HEAD_STAMP(0)
     __shared__ float sw[2][ML][F_CONV + 1];   // FC weights, +1 pad: lane i reads row i
     __shared__ float sfb[2][ML];
     __shared__ float sV[2 * ML][FM_K];
@@ -202,8 +205,10 @@ __global__ __launch_bounds__(256) void deepconn_head_kernel(HeadArgs a) {
             }
         }
     }
+    HEAD_STAMP(1)
     stage_weights();
     __syncthreads();
+    HEAD_STAMP(2)
 
     // ---- FC: lane i < 2L computes z[t][l] = b[l] + sum_f pooled[t][f] W[t][l][f]
     float xi = 0.f;
@@ -264,6 +269,7 @@ __global__ __launch_bounds__(256) void deepconn_head_kernel(HeadArgs a) {
     }
     if (lane == 0 && live) a.g[b] = g;
     __syncthreads();
+    HEAD_STAMP(3)
 #pragma unroll
     for (int t = 0; t < 2; ++t)
         for (int f = lane; f < F_CONV; f += 64) {
@@ -271,6 +277,7 @@ __global__ __launch_bounds__(256) void deepconn_head_kernel(HeadArgs a) {
             for (int l = 0; l < L; ++l) acc = fmaf(sz[w][t * L + l], sw[t][l][f], acc);
             if (live) a.g_pooled[t][b * F_CONV + f] = acc;
         }
+    HEAD_STAMP(4)
 }
 
 struct HeadGradArgs {
@@ -400,7 +407,7 @@ __global__ __launch_bounds__(RED_THREADS) void deepconn_reduce_kernel(WgradArgs 
             }
         }
     } else if (bx < red_blocks + comp_blocks) {
-        token_compact_block<RED_THREADS / 64>(nx.t[blockIdx.y], nx.V, bx - red_blocks);
+        token_compact_block<RED_THREADS / 64, COMPACT_G>(nx.t[blockIdx.y], nx.V, bx - red_blocks);
     } else {
         const int64_t o = opt.lo[blockIdx.y] + (int64_t)(bx - red_blocks - comp_blocks) * RED_THREADS + threadIdx.x;
         if (o < opt.hi[blockIdx.y]) {
@@ -666,7 +673,7 @@ extern "C" int r4r_deepconn_step(const float *table, int64_t V, const int64_t *u
     }
     // 6: wgrad partial reduce -> flat gradient buffer (+ compaction of the next batch's tokens)
     const int red_blocks = (F_CONV * 3 * E + F_CONV + RED_THREADS - 1) / RED_THREADS;
-    const int comp_blocks = prefetch ? (int)cdiv((V + 3) / 4, RED_THREADS) : 0;
+    const int comp_blocks = prefetch ? (int)cdiv((V + 3) / 4, RED_THREADS * COMPACT_G) : 0;
     FusedAdam opt{};
     int opt_blocks = 0;
     if (flat_m) {

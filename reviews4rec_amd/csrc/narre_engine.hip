@@ -22,6 +22,7 @@
 //
 // The op-by-op path issues ~130 launches for the same step.
 #include "step_device.h"
+#include "trace_device.h"
 
 namespace r4r {
 
@@ -96,8 +97,10 @@ __device__ __forceinline__ int head_col(const NarreHead &a, int flat_off) {
 // The kernel is bound by vector-ALU issue (index arithmetic around ~2000-element loops), with one
 // workgroup per CU on half the CUs -- so more waves per rating, not fewer instructions per
 // memory access, is what shortens it.
+HEAD_TRACE_DEFINE(r4r_debug_narre_head_trace)
 template <int MR, int ML, int NT>
 __global__ __launch_bounds__(NT) void narre_head_kernel(NarreHead a) {
+    HEAD_STAMP(0)
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int R = a.R, L = a.L, RL = R * L, L2 = 2 * L;
     const int tid = threadIdx.x;
@@ -230,16 +233,11 @@ __global__ __launch_bounds__(NT) void narre_head_kernel(NarreHead a) {
         if (i < L * L) { const int k = qd(i, invL); F1[k * (L + 1) + i - k * L] = f1v[u]; }
     }
     if (tid < L2) {
-        fcb[tid] = fcb_r; b0[tid] = b0_r; w3[tid] = w3_r; ev[tid] = ev_r;
+        fcb[tid] = fcb_r; b0[tid] = b0_r; w3[tid] = w3_r;
         evm[tid] = draw(4 * RL + ts * L + tl);
     }
     if (tid < L) { fv[tid] = f1b_r; fv[L + tid] = f3w_r; }
-    if (tid == 0) { misc[0] = m0; misc[1] = m1; misc[2] = m2; misc[3] = m3; misc[4] = ub_r; misc[5] = ib_r; }
-#pragma unroll
-    for (int u = 0; u < OREG; ++u) {                        // other side's ID vectors: side s reads table 1-s
-        const int i = tid + NT * u;
-        if (i < 2 * RL) o[i] = ov[u];
-    }
+    if (tid == 0) { misc[0] = m0; misc[1] = m1; misc[2] = m2; misc[3] = m3; }
     if (one_tile) {                                         // pool finish of a one-tile document: relu + argmax
 #pragma unroll
         for (int u = 0; u < PREG; ++u) {
@@ -273,6 +271,7 @@ __global__ __launch_bounds__(NT) void narre_head_kernel(NarreHead a) {
         }
     }
     __syncthreads();
+    HEAD_STAMP(1)
     // ---- S1: TextCNN FC + dropout per review (common_pytorch_models.py:35-37)
     for (int i = tid; i < 2 * RL; i += NT) {
         const int s = i >= RL, rem = i - s * RL, r = qd(rem, invL), l = rem - r * L;
@@ -283,7 +282,16 @@ __global__ __launch_bounds__(NT) void narre_head_kernel(NarreHead a) {
         xm[i] = m;
         x[i] = (acc + fcb[s * L + l]) * m;
     }
+    // the round-2 reads (ID vectors, biases) land in LDS only now: S1 ran under their latency
+    if (tid < L2) ev[tid] = ev_r;
+    if (tid == 0) { misc[4] = ub_r; misc[5] = ib_r; }
+#pragma unroll
+    for (int u = 0; u < OREG; ++u) {                        // other side's ID vectors: side s reads table 1-s
+        const int i = tid + NT * u;
+        if (i < 2 * RL) o[i] = ov[u];
+    }
     __syncthreads();
+    HEAD_STAMP(2)
     // ---- S2: scorer hidden layer on [x ; other] (NARRE.py:55-58)
     for (int i = tid; i < 2 * RL; i += NT) {
         const int s = i >= RL, rem = i - s * RL, r = qd(rem, invL), k = rem - r * L;
@@ -296,6 +304,7 @@ __global__ __launch_bounds__(NT) void narre_head_kernel(NarreHead a) {
         hm[i] = draw(2 * RL + s * RL + r * L + k);
     }
     __syncthreads();
+    HEAD_STAMP(3)
     // ---- S3: scores
     for (int i = tid; i < 2 * R; i += NT) {
         const int s = i >= R;
@@ -304,14 +313,17 @@ __global__ __launch_bounds__(NT) void narre_head_kernel(NarreHead a) {
         sc[i] = acc + misc[s];
     }
     __syncthreads();
+    HEAD_STAMP(4)
     // ---- S4: softmax over the R reviews of a side (pads are not masked, like the reference)
-    if (tid < 2) {
-        float mx = -INFINITY, den = 0.f;
-        for (int r = 0; r < R; ++r) mx = fmaxf(mx, sc[tid * R + r]);
-        for (int r = 0; r < R; ++r) { const float e = expf(sc[tid * R + r] - mx); sc[tid * R + r] = e; den += e; }
-        for (int r = 0; r < R; ++r) sc[tid * R + r] /= den;
+    if (tid < 128) {                                        // wave s = side s, one review per lane (R <= MR <= 32)
+        const int s = tid >> 6, ln = tid & 63;
+        const float val = ln < R ? sc[s * R + ln] : -INFINITY;
+        const float e = ln < R ? expf(val - wave_max(val)) : 0.f;
+        const float den = wave_sum(e);
+        if (ln < R) sc[s * R + ln] = e / den;
     }
     __syncthreads();
+    HEAD_STAMP(5)
     // ---- S5: attended review vector + the ID vector (NARRE.py:110-111)
     for (int i = tid; i < L2; i += NT) {
         const int s = i >= L, l = i - s * L;
@@ -320,6 +332,7 @@ __global__ __launch_bounds__(NT) void narre_head_kernel(NarreHead a) {
         v[i] = acc + ev[i] * evm[i];
     }
     __syncthreads();
+    HEAD_STAMP(6)
     // ---- S6: interaction + dropout (final.0)
     for (int i = tid; i < L; i += NT) {
         const float m = draw(4 * RL + 2 * L + i);
@@ -327,6 +340,7 @@ __global__ __launch_bounds__(NT) void narre_head_kernel(NarreHead a) {
         cdv[i] = v[i] * v[L + i] * m;
     }
     __syncthreads();
+    HEAD_STAMP(7)
     // ---- S7: final.1 + relu
     for (int k = tid; k < L; k += NT) {
         float acc = 0.f;
@@ -335,6 +349,7 @@ __global__ __launch_bounds__(NT) void narre_head_kernel(NarreHead a) {
         fh[k] = acc > 0.f ? acc : 0.f;
     }
     __syncthreads();
+    HEAD_STAMP(8)
     // ---- S8: final.3, bias head, SE
     if (tid == 0) {
         float acc = 0.f;
@@ -353,6 +368,7 @@ __global__ __launch_bounds__(NT) void narre_head_kernel(NarreHead a) {
     }
     if (!a.want_grad) return;                               // uniform
     __syncthreads();
+    HEAD_STAMP(9)
     const float g = misc[6];
     float *prow = a.part + (size_t)b * a.nhp;
     const int64_t nself = a.B;                              // entries [0, B): self rows, then B*R others
@@ -380,6 +396,7 @@ __global__ __launch_bounds__(NT) void narre_head_kernel(NarreHead a) {
         a.tag[1 - s][id] = a.now;
     }
     __syncthreads();
+    HEAD_STAMP(10)
     // ---- B2: final.1 weight, d interaction -> d v
     for (int i = tid; i < L * L; i += NT) { const int k = qd(i, invL); prow[head_col(a, a.off[NP_F1W] + i)] = fh[L + k] * cdv[i - k * L]; }
     for (int l = tid; l < L; l += NT) {
@@ -390,6 +407,7 @@ __global__ __launch_bounds__(NT) void narre_head_kernel(NarreHead a) {
         dv[L + l] = dcat * v[l];
     }
     __syncthreads();
+    HEAD_STAMP(11)
     // ---- B3: self ID rows (compact), d attention weights
     for (int i = tid; i < L2; i += NT) {
         const int s = i >= L, l = i - s * L;
@@ -402,15 +420,16 @@ __global__ __launch_bounds__(NT) void narre_head_kernel(NarreHead a) {
         da[i] = acc;
     }
     __syncthreads();
+    HEAD_STAMP(12)
     // ---- B4: softmax backward
-    if (tid < 2) {
-        float dot = 0.f;
-        for (int r = 0; r < R; ++r) dot = fmaf(sc[tid * R + r], da[tid * R + r], dot);
-        misc[7 + tid] = dot;
+    if (tid < 128) {                                        // wave s = side s: d score = a (d a - <a, d a>)
+        const int s = tid >> 6, ln = tid & 63;
+        const float av = ln < R ? sc[s * R + ln] : 0.f, dav = ln < R ? da[s * R + ln] : 0.f;
+        const float dot = wave_sum(av * dav);
+        if (ln < R) da[s * R + ln] = av * (dav - dot);
     }
     __syncthreads();
-    for (int i = tid; i < 2 * R; i += NT) da[i] = sc[i] * (da[i] - misc[7 + (i >= R)]);   // d score
-    __syncthreads();
+    HEAD_STAMP(13)
     // ---- B5: scorer output layer, d hidden
     if (tid < 2) {
         float acc = 0.f;
@@ -428,6 +447,7 @@ __global__ __launch_bounds__(NT) void narre_head_kernel(NarreHead a) {
         dz[i] = h[i] > 0.f ? da[s * R + r] * w3[s * L + k] * hm[i] : 0.f;     // d hpre
     }
     __syncthreads();
+    HEAD_STAMP(14)
     // ---- B6: scorer hidden layer gradients, d x (-> d z), d other (compact rows)
     for (int i = tid; i < L2; i += NT) {
         const int s = i >= L, k = i - s * L;
@@ -462,12 +482,14 @@ __global__ __launch_bounds__(NT) void narre_head_kernel(NarreHead a) {
         }
     }
     __syncthreads();
+    HEAD_STAMP(15)
 #pragma unroll
     for (int it = 0; it < (2 * MR * ML + NT - 1) / NT; ++it) {
         const int i = tid + NT * it;
         if (i < 2 * RL) dz[i] = dzv[it];
     }
     __syncthreads();
+    HEAD_STAMP(16)
     // ---- B7: TextCNN FC gradients, d pooled
     for (int i = tid; i < L2; i += NT) {
         const int s = i >= L, l = i - s * L;
@@ -478,15 +500,18 @@ __global__ __launch_bounds__(NT) void narre_head_kernel(NarreHead a) {
     for (int i = tid; i < 2 * L * NF; i += NT) {
         const int s = i >= L * NF, rem = i - s * L * NF, l = rem / NF, f = rem - l * NF;
         float acc = 0.f;
+#pragma unroll 5
         for (int r = 0; r < R; ++r) acc = fmaf(dz[(s * R + r) * L + l], P[(s * R + r) * NF + f], acc);
         prow[head_col(a, a.off[s ? NP_IFW : NP_UFW] + l * NF + f)] = acc;
     }
     for (int i = tid; i < 2 * R * NF; i += NT) {
         const int s = i >= R * NF, rem = i - s * R * NF, r = rem / NF, f = rem - r * NF;
         float acc = 0.f;
+#pragma unroll 5
         for (int l = 0; l < L; ++l) acc = fmaf(dz[(s * R + r) * L + l], fcw[(s * L + l) * (NF + 1) + f], acc);
         a.g_pooled[s][(b * R + r) * NF + f] = acc;
     }
+    HEAD_STAMP(17)
 }
 
 static size_t narre_head_lds_bytes(int R, int L) {
@@ -751,7 +776,7 @@ extern "C" int r4r_narre_step(const float *table, int64_t V,
 
     // 5: wgrad reduce + Adam on the dense parameters (+ next batch's compaction)
     const int red_blocks = (NF * 3 * E + NF + NRED_THREADS - 1) / NRED_THREADS;
-    const int comp_blocks = prefetch ? (int)cdiv((V + 3) / 4, NRED_THREADS) : 0;
+    const int comp_blocks = prefetch ? (int)cdiv((V + 3) / 4, NRED_THREADS * COMPACT_G) : 0;
     DenseAdam opt;
     opt.on = apply ? 1 : 0; opt.p = flat_p; opt.m = flat_m; opt.v = flat_v; opt.g = flat_g;
     opt.lo0 = hc.lo0; opt.hi0 = hc.hi0; opt.lo1 = hc.lo1; opt.hi1 = hc.hi1;

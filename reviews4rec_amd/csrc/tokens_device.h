@@ -29,40 +29,53 @@ __device__ __forceinline__ void token_mark_block(const TokenArgs &a, int blk, in
 }
 
 // ---- compact: slot[v] = dense row id of token v (or -1), list[row] = v, count.
-// A workgroup of NW waves owns 256 NW consecutive tokens (one int4 of flags per thread),
-// scans its flags in LDS and reserves a contiguous row range with ONE atomicAdd on the
-// tower's counter.  The order in which workgroups reserve ranges varies from run to run, but
-// any token <-> row bijection gives bit-identical results downstream (a projected row depends
-// only on its own token), so no global scan or sort is needed.  Flags are cleared as they are
-// consumed; `count` is reset by the gather kernel: both are all-zero between uses.
-template <int NW>
+// A workgroup of NW waves owns 256 NW G consecutive tokens (G int4 of flags per thread, all
+// loaded up front), scans its flags in LDS and reserves a contiguous row range with ONE
+// atomicAdd on the tower's counter (G > 1 keeps the number of atomics on that one address in
+// the low hundreds at V = 1M).  The order in which workgroups reserve ranges varies from run to
+// run, but any token <-> row bijection gives bit-identical results downstream (a projected row
+// depends only on its own token), so no global scan or sort is needed.  Flags are cleared as
+// they are consumed; `count` is reset by the gather kernel: both are all-zero between uses.
+template <int NW, int G = 1>
 __device__ __forceinline__ void token_compact_block(const TokenTower &tw, int64_t V, int blk) {
-    __shared__ int wsum[NW];
+    __shared__ int wsum[G * NW];
     __shared__ int base_row;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int64_t gi = (int64_t)blk * (64 * NW) + tid;      // int4 group: tokens 4 gi .. 4 gi + 3
+    const int64_t g0 = (int64_t)blk * (64 * NW * G) + tid;  // int4 group g0 + 64 NW g: tokens 4 gi .. 4 gi + 3
     const int64_t ngroups = (V + 3) / 4;                    // flags / slot buffers are padded to 4
-    int4 f = make_int4(0, 0, 0, 0);
-    if (gi < ngroups) f = reinterpret_cast<int4 *>(tw.flags)[gi];
-    const int fl[4] = {f.x, f.y, f.z, f.w};
-    const int cnt = f.x + f.y + f.z + f.w;
-    // exclusive prefix of cnt inside the workgroup: wave scan + NW-entry LDS scan
-    int incl = cnt;
+    int4 f[G];
 #pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const int up = __shfl_up(incl, off);
-        if (lane >= off) incl += up;
+    for (int g = 0; g < G; ++g) {
+        const int64_t gi = g0 + (int64_t)g * (64 * NW);
+        f[g] = make_int4(0, 0, 0, 0);
+        if (gi < ngroups) f[g] = reinterpret_cast<int4 *>(tw.flags)[gi];
     }
-    if (lane == 63) wsum[wave] = incl;
+    // exclusive prefix of the counts inside the workgroup: wave scans + (G NW)-entry LDS scan
+    int cnt[G], incl[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        cnt[g] = f[g].x + f[g].y + f[g].z + f[g].w;
+        incl[g] = cnt[g];
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int up = __shfl_up(incl[g], off);
+            if (lane >= off) incl[g] += up;
+        }
+        if (lane == 63) wsum[g * NW + wave] = incl[g];
+    }
     __syncthreads();
     if (tid == 0) {
         int run = 0;
-        for (int w = 0; w < NW; ++w) { const int c = wsum[w]; wsum[w] = run; run += c; }
+        for (int w = 0; w < G * NW; ++w) { const int c = wsum[w]; wsum[w] = run; run += c; }
         base_row = run ? atomicAdd(tw.count, run) : 0;
     }
     __syncthreads();
-    int at = base_row + wsum[wave] + incl - cnt;
-    if (gi < ngroups) {
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        const int64_t gi = g0 + (int64_t)g * (64 * NW);
+        if (gi >= ngroups) continue;
+        int at = base_row + wsum[g * NW + wave] + incl[g] - cnt[g];
+        const int fl[4] = {f[g].x, f[g].y, f[g].z, f[g].w};
         int sl[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -70,9 +83,10 @@ __device__ __forceinline__ void token_compact_block(const TokenTower &tw, int64_
             if (fl[k]) { sl[k] = at; tw.list[at] = (int)(gi * 4 + k); ++at; }
         }
         *reinterpret_cast<int4 *>(tw.slot + gi * 4) = make_int4(sl[0], sl[1], sl[2], sl[3]);
-        if (cnt) reinterpret_cast<int4 *>(tw.flags)[gi] = make_int4(0, 0, 0, 0);
+        if (cnt[g]) reinterpret_cast<int4 *>(tw.flags)[gi] = make_int4(0, 0, 0, 0);
     }
 }
+constexpr int COMPACT_G = 8;   // groups per thread inside the fused reduce launches
 
 static inline TokenArgs make_token_args(int64_t V, const ProjTower *tw, int ntower, int64_t N, int T) {
     TokenArgs a;

@@ -1,0 +1,16 @@
+// Stage timeline of a one-workgroup-per-rating kernel (make trace, tools/head_trace.py): under
+// -DR4R_TRACE thread 0 of each workgroup writes s_memrealtime (100 MHz) at each HEAD_STAMP(k),
+// 32 words per workgroup.  Never compiled into the product library.
+#pragma once
+#ifdef R4R_TRACE
+#define HEAD_TRACE_DEFINE(setter)                                                                      \
+    static __device__ unsigned long long *g_head_trace = nullptr;                                      \
+    extern "C" int setter(void *buf) {                                                                 \
+        return hipMemcpyToSymbol(HIP_SYMBOL(g_head_trace), &buf, sizeof(buf)) == hipSuccess ? 0 : -1;   \
+    }
+#define HEAD_STAMP(k)                                                                                  \
+    if (g_head_trace && threadIdx.x == 0) g_head_trace[(size_t)blockIdx.x * 32 + (k)] = wall_clock64();
+#else
+#define HEAD_TRACE_DEFINE(setter)
+#define HEAD_STAMP(k)
+#endif

@@ -1,6 +1,7 @@
 // Fused native training step for TransNet / TransNet++ (launch roles shared with the other review
 // models: step_device.h).
 #include "step_device.h"
+#include "trace_device.h"
 
 namespace r4r {
 
@@ -64,9 +65,11 @@ struct TnHead {
     uint64_t seed, offset;
 };
 
+HEAD_TRACE_DEFINE(r4r_debug_tn_head_trace)
 // One workgroup of 256 threads per rating.
 template <int ML>
 __global__ __launch_bounds__(256) void tn_head_kernel(TnHead a) {
+    HEAD_STAMP(0)
     constexpr int MS = ML + 2 * TN_ID;                      // widest source_fm input
     __shared__ float P[3][NF];
     __shared__ float fcw[3][ML][NF + 1];
@@ -93,43 +96,102 @@ __global__ __launch_bounds__(256) void tn_head_kernel(TnHead a) {
     };
     const float invL2 = 1.f / (float)L2, invL = 1.f / (float)L;
     auto qd = [](int v, float inv) { return (int)(((float)v + 0.5f) * inv); };
-    // ---- S0: weights, pool finish (max over tiles, relu, first argmax), ID vectors
-    for (int i = tid; i < 3 * L * NF; i += 256) {
-        const int s = i / (L * NF), r = i - s * L * NF, l = r / NF;
-        fcw[s][l][r - l * NF] = fp[a.off[s == 0 ? TN_UFW : (s == 1 ? TN_IFW : TN_TFW)] + r];
+    // ---- S0: weights, pool finish (max over tiles, relu, first argmax), ID vectors.  Every global read of
+    // this prologue is issued into registers before anything waits (a load -> LDS-store loop is one
+    // memory round trip per iteration, and the tile loop of the pool finish one per tile: 14.5 us
+    // of a 26 us kernel at cfg5 -- tools/head_trace.py)
+    constexpr int WREG = (ML * NF + 255) / 256, AREG = (ML * 2 * ML + 255) / 256, FREG = (ML * ML + 255) / 256,
+                  SREG = (MS * TN_FM_K + 255) / 256, TREG = (ML * TN_FM_K + 255) / 256, PT = 8;
+    float wreg[3][WREG], av[AREG], f2v[FREG], vsv[SREG], vtv[TREG];
+    const int wtot = L * NF;
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+        const float *src = fp + a.off[s == 0 ? TN_UFW : (s == 1 ? TN_IFW : TN_TFW)];
+#pragma unroll
+        for (int u = 0; u < WREG; ++u) wreg[s][u] = 256 * u < wtot ? src[min(tid + 256 * u, wtot - 1)] : 0.f;
     }
-    for (int i = tid; i < L * L2; i += 256) { const int k = qd(i, invL2); W0[k][i - k * L2] = fp[a.off[TN_P0W] + i]; }
-    for (int i = tid; i < L * L; i += 256) { const int k = qd(i, invL); W2[k][i - k * L] = fp[a.off[TN_P2W] + i]; }
-    for (int i = tid; i < ns * TN_FM_K; i += 256) Vs[i / TN_FM_K][i % TN_FM_K] = fp[a.off[TN_SV] + i];
-    for (int i = tid; i < L * TN_FM_K; i += 256) Vt[i / TN_FM_K][i % TN_FM_K] = fp[a.off[TN_TV] + i];
-    if (tid < ns) lws[tid] = fp[a.off[TN_SLW] + tid];
-    if (tid < L) { lwt[tid] = fp[a.off[TN_TLW] + tid]; b0s[tid] = fp[a.off[TN_P0B] + tid]; b2s[tid] = fp[a.off[TN_P2B] + tid]; }
-    if (tid < L3) {
-        const int s = tid / L;
-        fcb[tid] = fp[a.off[s == 0 ? TN_UFB : (s == 1 ? TN_IFB : TN_TFB)] + (tid - s * L)];
-    }
-    if (tid == 0) { misc[0] = fp[a.off[TN_SLB]]; misc[1] = fp[a.off[TN_TLB]]; }
-    if (a.plus && tid >= 64 && tid < 64 + 2 * TN_ID) {      // dropout.user / dropout.item on the ID vectors
+#pragma unroll
+    for (int u = 0; u < AREG; ++u) av[u] = 256 * u < L * L2 ? fp[a.off[TN_P0W] + min(tid + 256 * u, L * L2 - 1)] : 0.f;
+#pragma unroll
+    for (int u = 0; u < FREG; ++u) f2v[u] = 256 * u < L * L ? fp[a.off[TN_P2W] + min(tid + 256 * u, L * L - 1)] : 0.f;
+#pragma unroll
+    for (int u = 0; u < SREG; ++u) vsv[u] = 256 * u < ns * TN_FM_K ? fp[a.off[TN_SV] + min(tid + 256 * u, ns * TN_FM_K - 1)] : 0.f;
+#pragma unroll
+    for (int u = 0; u < TREG; ++u) vtv[u] = 256 * u < L * TN_FM_K ? fp[a.off[TN_TV] + min(tid + 256 * u, L * TN_FM_K - 1)] : 0.f;
+    const float lws_r = fp[a.off[TN_SLW] + min(tid, ns - 1)];
+    const int tl = min(tid, L - 1), t3 = min(tid, L3 - 1), s3 = t3 / L;
+    const float lwt_r = fp[a.off[TN_TLW] + tl], b0_r = fp[a.off[TN_P0B] + tl], b2_r = fp[a.off[TN_P2B] + tl];
+    const float fcb_r = fp[a.off[s3 == 0 ? TN_UFB : (s3 == 1 ? TN_IFB : TN_TFB)] + (t3 - s3 * L)];
+    const float m0 = fp[a.off[TN_SLB]], m1 = fp[a.off[TN_TLB]];
+    const bool idt = a.plus && tid >= 64 && tid < 64 + 2 * TN_ID;
+    float idv = 0.f;
+    if (idt) {
         const int k = tid - 64, s = k >= TN_ID, c = k - s * TN_ID;
-        const float m = draw(5 * L + k);
-        finm[k] = m;
-        fin[k] = a.emb[s][a.id[s][b] * TN_ID + c] * m;
+        idv = a.emb[s][a.id[s][b] * TN_ID + c];
     }
+    // pool finish: thread i < 3 NF owns (tower, filter) i; threads 0 .. 3 NF - 257 a second one
     for (int i = tid; i < 3 * NF; i += 256) {
         const int s = i / NF, f = i - s * NF;
         float best = -INFINITY;
         int bp = -1;
-        for (int k = 0; k < a.tiles; ++k) {
-            const size_t q = ((size_t)b * a.tiles + k) * NP + f;
-            const float val = a.pmax[s][q];
-            if (val > best) { best = val; bp = a.parg[s][q]; }
+        for (int k0 = 0; k0 < a.tiles; k0 += PT) {
+            float v[PT];
+            int pp[PT];
+#pragma unroll
+            for (int k = 0; k < PT; ++k) {
+                const bool in = k0 + k < a.tiles;
+                const size_t q = ((size_t)b * a.tiles + (in ? k0 + k : 0)) * NP + f;
+                v[k] = in ? a.pmax[s][q] : -INFINITY;
+                pp[k] = a.parg[s][q];
+            }
+#pragma unroll
+            for (int k = 0; k < PT; ++k)
+                if (v[k] > best) { best = v[k]; bp = pp[k]; }
         }
         if (!(best > 0.f)) { best = 0.f; bp = -1; }
         P[s][f] = best;
         a.pooled[s][b * NF + f] = best;
         a.argmax[s][b * NF + f] = bp;
     }
+#pragma unroll
+    for (int s = 0; s < 3; ++s)
+#pragma unroll
+        for (int u = 0; u < WREG; ++u) {
+            const int r = tid + 256 * u;
+            if (r < wtot) { const int l = r / NF; fcw[s][l][r - l * NF] = wreg[s][u]; }
+        }
+#pragma unroll
+    for (int u = 0; u < AREG; ++u) {
+        const int i = tid + 256 * u;
+        if (i < L * L2) { const int k = qd(i, invL2); W0[k][i - k * L2] = av[u]; }
+    }
+#pragma unroll
+    for (int u = 0; u < FREG; ++u) {
+        const int i = tid + 256 * u;
+        if (i < L * L) { const int k = qd(i, invL); W2[k][i - k * L] = f2v[u]; }
+    }
+#pragma unroll
+    for (int u = 0; u < SREG; ++u) {
+        const int i = tid + 256 * u;
+        if (i < ns * TN_FM_K) Vs[i / TN_FM_K][i % TN_FM_K] = vsv[u];
+    }
+#pragma unroll
+    for (int u = 0; u < TREG; ++u) {
+        const int i = tid + 256 * u;
+        if (i < L * TN_FM_K) Vt[i / TN_FM_K][i % TN_FM_K] = vtv[u];
+    }
+    if (tid < ns) lws[tid] = lws_r;
+    if (tid < L) { lwt[tid] = lwt_r; b0s[tid] = b0_r; b2s[tid] = b2_r; }
+    if (tid < L3) fcb[tid] = fcb_r;
+    if (tid == 0) { misc[0] = m0; misc[1] = m1; }
+    if (idt) {                                              // dropout.user / dropout.item on the ID vectors
+        const int k = tid - 64;
+        const float m = draw(5 * L + k);
+        finm[k] = m;
+        fin[k] = idv * m;
+    }
     __syncthreads();
+    HEAD_STAMP(1)
     // ---- S1: the towers' FC + dropout (common_pytorch_models.py:35-37): xu, xi, xt
     if (tid < L3) {
         const int s = tid / L, l = tid - s * L;
@@ -140,6 +202,7 @@ __global__ __launch_bounds__(256) void tn_head_kernel(TnHead a) {
         x[tid] = (acc + fcb[tid]) * m;
     }
     __syncthreads();
+    HEAD_STAMP(2)
     // ---- S2: source.project.0 + relu (TransNet.py:19-22); target: t_ir = dropout(xt) (TransNet.py:58)
     if (tid < L) {
         float acc = 0.f;
@@ -153,6 +216,7 @@ __global__ __launch_bounds__(256) void tn_head_kernel(TnHead a) {
         tir[l] = x[L2 + l] * m;
     }
     __syncthreads();
+    HEAD_STAMP(3)
     // ---- S3: source.project.2 + dropout = s_ir (TransNet.py:33-36)
     if (tid < L) {
         float acc = 0.f;
@@ -164,6 +228,7 @@ __global__ __launch_bounds__(256) void tn_head_kernel(TnHead a) {
         fin[eo + tid] = v;
     }
     __syncthreads();
+    HEAD_STAMP(4)
     // ---- S4: the two factorisation machines (common_pytorch_models.py:49-57): wave 0 source, wave 1 target
     if (wv < 2) {
         const int n = wv ? L : ns;
@@ -189,6 +254,7 @@ __global__ __launch_bounds__(256) void tn_head_kernel(TnHead a) {
         if (lane == 0) misc[4] = tr;
     }
     __syncthreads();
+    HEAD_STAMP(5)
     const float out_s = misc[2], out_t = misc[3];
     float g_s = 0.f, g_t = 0.f;
     if (a.y) {
@@ -239,6 +305,7 @@ __global__ __launch_bounds__(256) void tn_head_kernel(TnHead a) {
         dz[L2 + l] = g_t * dft[l] * tirm[l] * xm[L2 + l];                // d (target FC output)
     }
     __syncthreads();
+    HEAD_STAMP(6)
     // ---- B2: source.project.2 gradients, d hidden
     for (int i = tid; i < L * L; i += 256) { const int k = qd(i, invL); prow[col(a.off[TN_P2W] + i)] = dtmp[k] * hs[i - k * L]; }
     if (tid < L) {
@@ -250,6 +317,7 @@ __global__ __launch_bounds__(256) void tn_head_kernel(TnHead a) {
         prow[col(a.off[TN_P0B] + tid)] = d;
     }
     __syncthreads();
+    HEAD_STAMP(7)
     // ---- B3: source.project.0 weight, d cat -> d (source FC outputs)
     for (int i = tid; i < L * L2; i += 256) { const int k = qd(i, invL2); prow[col(a.off[TN_P0W] + i)] = dhs[k] * x[i - k * L2]; }
     if (tid < L2) {
@@ -258,14 +326,15 @@ __global__ __launch_bounds__(256) void tn_head_kernel(TnHead a) {
         dz[tid] = acc * xm[tid];
     }
     __syncthreads();
+    HEAD_STAMP(8)
     // ---- B4: the towers' FC gradients, d pooled
     if (tid < L3) {
         const int s = tid / L;
         prow[col(a.off[s == 0 ? TN_UFB : (s == 1 ? TN_IFB : TN_TFB)] + (tid - s * L))] = dz[tid];
     }
-    for (int i = tid; i < 3 * L * NF; i += 256) {
-        const int s = i / (L * NF), r = i - s * L * NF, l = r / NF, f = r - l * NF;
-        prow[col(a.off[s == 0 ? TN_UFW : (s == 1 ? TN_IFW : TN_TFW)] + r)] = dz[s * L + l] * P[s][f];
+    for (int s = 0; s < 3; ++s) {
+        float *dst = prow + col(a.off[s == 0 ? TN_UFW : (s == 1 ? TN_IFW : TN_TFW)]);
+        for (int r = tid; r < L * NF; r += 256) { const int l = r / NF; dst[r] = dz[s * L + l] * P[s][r - l * NF]; }
     }
     for (int i = tid; i < 3 * NF; i += 256) {
         const int s = i / NF, f = i - s * NF;
@@ -273,6 +342,7 @@ __global__ __launch_bounds__(256) void tn_head_kernel(TnHead a) {
         for (int l = 0; l < L; ++l) acc = fmaf(dz[s * L + l], fcw[s][l][f], acc);
         a.g_pooled[s][b * NF + f] = acc;
     }
+    HEAD_STAMP(9)
 }
 
 struct TnWs {
@@ -501,7 +571,7 @@ extern "C" int r4r_transnet_step(const float *table, int64_t V,
         wa, cs, cs_blocks, nx, packed, RowSweep{}, 0, 3);
 
     const int red_blocks = (NF * 3 * E + NF + NRED_THREADS - 1) / NRED_THREADS;
-    const int comp_blocks = prefetch ? (int)cdiv((V + 3) / 4, NRED_THREADS) : 0;
+    const int comp_blocks = prefetch ? (int)cdiv((V + 3) / 4, NRED_THREADS * COMPACT_G) : 0;
     DenseAdam opt;
     opt.on = apply ? 1 : 0; opt.p = flat_p; opt.m = flat_m; opt.v = flat_v; opt.g = flat_g;
     opt.lo0 = lo; opt.hi0 = hi; opt.lo1 = hi; opt.hi1 = hi;       // every head parameter in one range (tower 0's slice)
