@@ -176,6 +176,7 @@ class DataLoader():
             self.store = train_loader.store
             if test_reviews is not None and not self.store.has_held:
                 self.store.held, self.store.has_held = _Held(test_reviews), True
+        self.takes_batch = True                              # the iterators accept batch= (eval.py)
         if hyper_params['model_type'] in ['bias_only', 'MF', 'MF_dot', 'NeuMF']:
             self.iter = self.iter_simple
         else:
@@ -327,9 +328,11 @@ class DataLoader():
         return self.device.type == 'cuda'
 
     # ------------------------------------------------------------------ iterators
-    def iter_review(self, eval=False, simple=False):
-        """data.py:250-333: contiguous slices of batch_size ratings (ragged tail), the 7-slot list."""
-        bsz = int(self.hyper_params['batch_size'])
+    def iter_review(self, eval=False, simple=False, batch=None):
+        """data.py:250-333: contiguous slices of batch_size ratings (ragged tail), the 7-slot list.
+        ``batch``: another slice length (eval.py's validation passes launch larger slices of the same
+        stream: a rating's score does not depend on what shares its launch)."""
+        bsz = int(batch or self.hyper_params['batch_size'])
         n = len(self.data)
         if self._on_device() and not simple:
             d = self._device_split()
@@ -349,9 +352,9 @@ class DataLoader():
             else:
                 yield [torch.from_numpy(a) for a in f + [u, i]], torch.from_numpy(self._y[s:e])
 
-    def iter_simple(self, eval=False):
+    def iter_simple(self, eval=False, batch=None):
         """data.py:336-372: ids only; the five review slots are None."""
-        bsz = int(self.hyper_params['batch_size'])
+        bsz = int(batch or self.hyper_params['batch_size'])
         n = len(self.data)
         if self._on_device():
             d = self._device_split_simple()
@@ -392,11 +395,11 @@ class DataLoader():
             self._dev_negs[key] = dict(u=uu, cand=cand, ku=ku, ki=ki, held=held)
         return self._dev_negs[key]
 
-    def iter_negs(self, review):
+    def iter_negs(self, review, batch=None):
         """data.py:375-447 -> ([this [B,6,..], who [B,6,10], what [B,6,10], user docs, item docs,
         user [B,6], item [B,6]], zeros [B]).  With review == False the five review slots are EMPTY
-        tensors, as ``LongTensor([])`` of the reference's unfilled lists."""
-        bsz = int(self.hyper_params['batch_size'])
+        tensors, as ``LongTensor([])`` of the reference's unfilled lists.  ``batch``: rows per slice."""
+        bsz = int(batch or self.hyper_params['batch_size'])
         a = self._negs_arrays(review)
         n = len(a['u'])
         dev = self._on_device()

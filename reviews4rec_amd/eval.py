@@ -27,15 +27,35 @@ def _count_maps(ids, ses, counts):
     return {int(k): grp.tolist() for k, grp in zip(keys, np.split(ss, cuts))}
 
 
+EVAL_LAUNCH = 8          # x batch_size ratings per launch of a validation pass scored by a native engine
+RANK_LAUNCH = 4          # x batch_size ranking rows (of 6 candidates each)
+
+
+def _launch_size(reader, hyper_params, engine, factor):
+    """Slice length of a validation pass.  The reference scores slices of ``batch_size`` (eval.py:24,
+    data.py:379); a native engine's eval forward scores every rating by itself -- distinct-token
+    projection, gather, one workgroup or wave per rating -- so larger slices of the same stream give the
+    same scores with fewer launches and less Python per rating (``eval_batch_size`` overrides; the
+    op-by-op module path keeps the reference's slices: its Linear layers are rocBLAS GEMMs over the
+    batch; TransNet too: its MSE_right / MSE_transform are means of per-slice means, eval.py:33-35)."""
+    if engine is None or not getattr(reader, 'takes_batch', False):
+        return None
+    if hyper_params['model_type'] in ['transnet', 'transnet++']:
+        return None
+    return int(hyper_params.get('eval_batch_size') or factor * int(hyper_params['batch_size']))
+
+
 def evaluate(model, criterion, reader, hyper_params, user_count, item_count, review, engine=None):
     metrics = {}
+    big = _launch_size(reader, hyper_params, engine, EVAL_LAUNCH)
+    batches = reader.iter(eval=True, batch=big) if big else reader.iter(eval=True)
     total_n, total_batches = 0.0, 0.0
     is_tn = hyper_params['model_type'] in ['transnet', 'transnet++']
     se_parts, user_parts, item_parts = [], [], []
     total_se = mse_right = conv_loss = None                  # device scalars: no sync inside the pass
     model.eval()
     with torch.no_grad():
-        for data, y in reader.iter(eval=True):
+        for data, y in batches:
             user, item = data[5], data[6]
             if engine is not None:
                 output, mse = engine.predict(data, y)
@@ -83,8 +103,9 @@ def eval_ranking(model, reader, hyper_params, review=False, engine=None):
     ties differently).  ``engine``: a native engine of `model` -- its fused eval forward scores the batches."""
     parts = []
     is_tn = hyper_params['model_type'] in ['transnet', 'transnet++']
+    big = _launch_size(reader, hyper_params, engine, RANK_LAUNCH)
     with torch.no_grad():
-        for data, y in reader.iter_negs(review):
+        for data, y in (reader.iter_negs(review, batch=big) if big else reader.iter_negs(review)):
             if engine is not None:
                 output = engine.predict(data, None)[0].clone()   # the engine reuses its output buffer
             else:

@@ -100,6 +100,41 @@ def test_evaluate_and_ranking_on_the_device_vs_reference(mt, engine, tmp_path):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('mt', ['deepconn', 'NARRE', 'MF_dot'])
+def test_validation_launch_size_does_not_change_the_scores(mt, tmp_path):
+    """evaluate() / eval_ranking() score larger slices of the stream than the reference's batch_size when a
+    native engine does the scoring (eval._launch_size): same SEs in the same order, same HR@1 as with the
+    reference's slices -- a rating's score does not depend on what shares its launch."""
+    import reviews4rec_amd
+    from reviews4rec_amd import main as M
+    from reviews4rec_amd.data import load_data
+    from reviews4rec_amd.eval import evaluate, eval_ranking, _launch_size, EVAL_LAUNCH
+    from reviews4rec_amd.loss import MSELoss
+    meta, z = _fixture(mt, 'eval')
+    root = materialise_tiny(tmp_path)
+    train, test, val, hp = load_data(tiny_hp(mt, root), device='cuda')
+    model = reviews4rec_amd.get_model_class(mt)(hp)
+    model.load_state_dict(_weights(z), strict=True)
+    model = model.cuda()
+    eng = M.make_engine(dict(hp, engine='native'), model)
+    review = mt not in ('bias_only', 'MF', 'MF_dot', 'NeuMF')
+    assert _launch_size(test, hp, eng, EVAL_LAUNCH) == EVAL_LAUNCH * hp['batch_size']
+    assert _launch_size(test, hp, None, EVAL_LAUNCH) is None           # module path: the reference's slices
+    got = {}
+    for label, size in (('default', None), ('reference', hp['batch_size']), ('odd', 7)):
+        h = dict(hp) if size is None else dict(hp, eval_batch_size=size)
+        uc, ic = _counts(root)
+        got[label] = evaluate(model, MSELoss(hp), test, h, uc, ic, review, engine=eng) + (eval_ranking(model, test, h, review, engine=eng),)
+    for label in ('reference', 'odd'):
+        assert got[label][0] == pytest.approx(got['default'][0], abs=1e-4)
+        for a, b in ((got[label][1], got['default'][1]), (got[label][2], got['default'][2])):
+            assert sorted(a) == sorted(b)
+            for k in a:
+                np.testing.assert_allclose(a[k], b[k], rtol=1e-6, atol=1e-7)
+        assert got[label][3] == got['default'][3]
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize('mt', E2E_MODELS)
 def test_main_end_to_end_vs_reference(mt, tmp_path, monkeypatch):
     """main.main(hyper_params) == the reference's main.main on the same dataset directory from the same
