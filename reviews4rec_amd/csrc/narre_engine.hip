@@ -98,6 +98,7 @@ __device__ __forceinline__ int head_col(const NarreHead &a, int flat_off) {
 // workgroup per CU on half the CUs -- so more waves per rating, not fewer instructions per
 // memory access, is what shortens it.
 HEAD_TRACE_DEFINE(r4r_debug_narre_head_trace)
+BWD_TRACE_DEFINE(r4r_debug_narre_bwd_trace)
 template <int MR, int ML, int NT>
 __global__ __launch_bounds__(NT) void narre_head_kernel(NarreHead a) {
     HEAD_STAMP(0)
@@ -760,8 +761,10 @@ extern "C" int r4r_narre_step(const float *table, int64_t V,
     for (int k = 0; k < 4; ++k) { begin[k] = chunks; chunks += cdiv(numel[k], NROW_CHUNK); }
     rs.n0 = numel[0]; rs.n1 = numel[1]; rs.n2 = numel[2]; rs.n3 = numel[3];
     rs.cb1 = (int)begin[1]; rs.cb2 = (int)begin[2]; rs.cb3 = (int)begin[3]; rs.cb_entries = (int)chunks;
-    chunks += 2 * cdiv(B * (1 + R), 4);                     // the entry waves, 4 per workgroup, per table
+    const int sweep_blocks = (int)chunks;
+    chunks += 2 * cdiv(B * (1 + R), 4 * NROW_EPW);          // the entry waves, 4 per workgroup, per table
     R4R_REQUIRE(chunks < (1ll << 31), "narre_step: too many chunks");
+    rs.sweep_elsewhere = 1;                                 // entry waves here, the sweep in the reduce launch
     rs.gid0 = w.gid[0]; rs.gid1 = w.gid[1]; rs.grow0 = w.grow[0]; rs.grow1 = w.grow[1]; rs.g = w.g;
     rs.tag0 = w.tag[0]; rs.tag1 = w.tag[1]; rs.entries = B * (1 + R); rs.B = B; rs.L = L; rs.now = (int)adam_step;
     rs.s = adam_make_scalars(lr, beta1, beta2, eps, weight_decay, adam_step, nullptr);
@@ -783,8 +786,12 @@ extern "C" int r4r_narre_step(const float *table, int64_t V,
     opt.s = adam_make_scalars(lr, beta1, beta2, eps, weight_decay, adam_step, nullptr);
     const int64_t longest = hc.hi0 - hc.lo0 > hc.hi1 - hc.lo1 ? hc.hi0 - hc.lo0 : hc.hi1 - hc.lo1;
     const int opt_blocks = apply ? (int)cdiv(longest, NRED_THREADS) : 0;
-    narre_reduce_kernel<<<dim3(red_blocks + comp_blocks + opt_blocks, 2), NRED_THREADS, 0, st>>>(wa, red_blocks, comp_blocks,
-                                                                                                nx, opt);
+    if (apply)
+        narre_reduce_kernel<<<dim3(red_blocks + comp_blocks + opt_blocks + (sweep_blocks + 1) / 2, 2), NRED_THREADS, 0, st>>>(
+            wa, red_blocks, comp_blocks, nx, opt, opt_blocks, rs);
+    else
+        narre_reduce_kernel<<<dim3(red_blocks + comp_blocks + opt_blocks, 2), NRED_THREADS, 0, st>>>(wa, red_blocks, comp_blocks,
+                                                                                                    nx, opt);
 
     return check_launch("narre_step");
 }
@@ -838,8 +845,9 @@ extern "C" int r4r_narre_rows_apply(const int64_t *gid0, const int64_t *gid1, co
     for (int k = 0; k < 4; ++k) { begin[k] = chunks; chunks += cdiv(numel[k], NROW_CHUNK); }
     rs.n0 = numel[0]; rs.n1 = numel[1]; rs.n2 = numel[2]; rs.n3 = numel[3];
     rs.cb1 = (int)begin[1]; rs.cb2 = (int)begin[2]; rs.cb3 = (int)begin[3]; rs.cb_entries = (int)chunks;
-    chunks += 2 * cdiv(entries, 4);
+    chunks += 2 * cdiv(entries, 4 * NROW_EPW);
     R4R_REQUIRE(chunks < (1ll << 31), "narre_rows_apply: too many chunks");
+    rs.sweep_elsewhere = 0;
     rs.gid0 = gid0; rs.gid1 = gid1; rs.grow0 = grow0; rs.grow1 = grow1; rs.g = g_entry;
     rs.tag0 = w.tag[0]; rs.tag1 = w.tag[1]; rs.entries = entries; rs.B = entries; rs.L = L; rs.now = (int)adam_step;
     rs.s = adam_make_scalars(lr, beta1, beta2, eps, weight_decay, adam_step, nullptr);

@@ -72,111 +72,10 @@ struct RowSweep {
     int64_t entries, B;
     int L, now;
     AdamScalars s;
+    int sweep_elsewhere;               // the sweep workgroups ride in the reduce launch: the backward launch runs the entry waves only
 };
-// MW: 64-bit words of a lane's hit mask (entries <= 4096 MW: 1 in the fused single-process launch,
-// 4 in the stand-alone data-parallel launch); `sid`: LDS for the entry ids (entries ints).
-template <int ML, int MW>
-__device__ __forceinline__ void narre_rows_block(const RowSweep &w, int bx, int *sid) {
-    if (bx >= w.cb_entries) {
-        // ---- entry waves: 4 per workgroup, all of one table (user table's groups first)
-        const int lane = threadIdx.x & 63;
-        const int groups = (int)((w.entries + 3) / 4);
-        int gi = bx - w.cb_entries;
-        const int t = gi >= groups;
-        if (t) gi -= groups;
-        const int64_t *ids = t ? w.gid1 : w.gid0;
-        const float *rows = t ? w.grow1 : w.grow0;
-        for (int64_t j = threadIdx.x; j < w.entries; j += NROW_THREADS) sid[j] = (int)ids[j];   // one round trip
-        __syncthreads();
-        const int64_t k = (int64_t)gi * 4 + (threadIdx.x >> 6);
-        if (k >= w.entries) return;                         // whole wave
-        const int row = sid[k];
-        if (row < 0) return;                                // a padded entry (gathered ragged shards): whole wave
-        const int L = w.L;
-        const int nch = (int)((w.entries + 63) / 64);
-        // phase 1: is k the first entry of its row?  (scan of the ids in LDS, 64 at a time)
-        bool first = true;
-        for (int c = 0; c < nch && first; ++c) {
-            const int j = c * 64 + lane;
-            const unsigned long long mask = __ballot(j < w.entries && sid[j] == row);
-            if (mask && (int64_t)c * 64 + (__ffsll((long long)mask) - 1) < k) first = false;
-            if (mask && (int64_t)c * 64 + 63 >= k) break;   // reached k's own chunk: nothing earlier matched
-        }
-        if (!first) return;                                 // an earlier entry owns this row (uniform)
-        // phase 2 (one wave per DISTINCT row): every lane adds up the rows of ITS hits, chunk by
-        // chunk in ascending order, then one fixed butterfly per column combines the 64 lanes -- a
-        // fixed order, so the result is deterministic (a butterfly per chunk made a row with
-        // hundreds of entries a 70 us chain of cross-lane permutes)
-        float rv[ML];
-#pragma unroll
-        for (int col = 0; col < ML; ++col) rv[col] = 0.f;
-        float gv = 0.f;
-        unsigned long long mine[MW];                        // bit c of word c / 64: entry c*64 + lane is a hit (nch <= 64 MW)
-#pragma unroll
-        for (int q = 0; q < MW; ++q) mine[q] = 0;
-        for (int c = (int)(k / 64); c < nch; ++c) {         // (no hit before k's chunk: k is the first)
-            const int64_t j = (int64_t)c * 64 + lane;
-            if (j < w.entries && sid[j] == row) {
-#pragma unroll
-                for (int q = 0; q < MW; ++q)
-                    if ((c >> 6) == q) mine[q] |= 1ull << (c & 63);
-            }
-        }
-        auto any = [&]() { unsigned long long o = 0;
-#pragma unroll
-            for (int q = 0; q < MW; ++q) o |= mine[q];
-            return o != 0; };
-        auto pop = [&]() -> int {                           // the lane's lowest remaining hit (ascending order), -1 if none
-#pragma unroll
-            for (int q = 0; q < MW; ++q)
-                if (mine[q]) { const int c = __ffsll((long long)mine[q]) - 1; mine[q] &= mine[q] - 1; return q * 64 + c; }
-            return -1;
-        };
-        while (__ballot(any())) {                           // four of a lane's hits per round, their loads together
-            int cs[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) cs[u] = pop();
-            float tmp[4][ML], tg[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int64_t j = (int64_t)(cs[u] < 0 ? 0 : cs[u]) * 64 + lane;
-#pragma unroll
-                for (int col = 0; col < ML; ++col)
-                    tmp[u][col] = (cs[u] >= 0 && col < L) ? rows[j * L + col] : 0.f;
-                tg[u] = (cs[u] >= 0 && j < w.B) ? w.g[j] : 0.f;         // only the self entries carry a bias gradient
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {                   // ascending entry order within the lane
-#pragma unroll
-                for (int col = 0; col < ML; ++col) rv[col] += tmp[u][col];
-                gv += tg[u];
-            }
-        }
-        float acc = 0.f;                                    // lane < L: column `lane` of the table row
-#pragma unroll
-        for (int col = 0; col < ML; ++col) {
-            if (col < L) {                                  // uniform
-                const float sum = wave_sum(rv[col]);
-                if (lane == col) acc = sum;
-            }
-        }
-        const float accb = wave_sum(gv);
-        if (lane < L) {
-            float *p = (t ? w.p1 : w.p0) + (int64_t)row * L + lane, *m = (t ? w.m1 : w.m0) + (int64_t)row * L + lane,
-                  *v = (t ? w.v1 : w.v0) + (int64_t)row * L + lane;
-            float P = *p, M = *m, V = *v;
-            adam_elem(P, acc, M, V, w.s);
-            *p = P; *m = M; *v = V;
-        }
-        if (lane == 0) {                                    // the row's bias element (gradient zero if no self entry)
-            float *p = (t ? w.p3 : w.p2) + row, *m = (t ? w.m3 : w.m2) + row, *v = (t ? w.v3 : w.v2) + row;
-            float P = *p, M = *m, V = *v;
-            adam_elem(P, accb, M, V, w.s);
-            *p = P; *m = M; *v = V;
-        }
-        return;
-    }
-    // ---- sweep workgroups
+// ---- sweep workgroup `bx` (< cb_entries) of the ID tables / bias vectors: rows no rating touched
+__device__ __forceinline__ void narre_sweep_block(const RowSweep &w, int bx) {
     const int t = (bx >= w.cb1) + (bx >= w.cb2) + (bx >= w.cb3);
     float *bp = w.p0, *bm = w.m0, *bv = w.v0;
     int64_t numel = w.n0;
@@ -212,13 +111,176 @@ __device__ __forceinline__ void narre_rows_block(const RowSweep &w, int bx, int 
     }
 }
 
+constexpr int NROW_EPW = 4;              // entries per wave of an entry workgroup (16 entries share one load of the ids)
+// MW: 64-bit words of a lane's hit mask (entries <= 4096 MW: 1 in the fused single-process launch,
+// 4 in the stand-alone data-parallel launch); `sid`: LDS for the entry ids (entries ints).
+template <int ML, int MW>
+__device__ __forceinline__ void narre_rows_block(const RowSweep &w, int bx, int *sid) {
+    if (bx >= w.cb_entries) {
+        // ---- entry waves: 4 per workgroup, NROW_EPW entries each (interleaved: the owners of popular rows
+        // are early entries), all of one table (user table's groups first)
+        const int lane = threadIdx.x & 63;
+        const int groups = (int)((w.entries + 4 * NROW_EPW - 1) / (4 * NROW_EPW));
+        int gi = bx - w.cb_entries;
+        const int t = gi >= groups;
+        if (t) gi -= groups;
+        const int64_t *ids = t ? w.gid1 : w.gid0;
+        const float *rows = t ? w.grow1 : w.grow0;
+        for (int64_t j = threadIdx.x; j < w.entries; j += NROW_THREADS) sid[j] = (int)ids[j];   // one round trip
+        __syncthreads();
+        const int L = w.L;
+        const int nch = (int)((w.entries + 63) / 64);
+        float *tp = t ? w.p1 : w.p0, *tm = t ? w.m1 : w.m0, *tv = t ? w.v1 : w.v0;      // the table ...
+        float *bp = t ? w.p3 : w.p2, *bm = t ? w.m3 : w.m2, *bv = t ? w.v3 : w.v2;      // ... and its bias vector
+        // Two entries at a time: the LDS-only work of both first (is the entry the first of its row? which
+        // entries hit the row?), then EVERY global read of the pair in one round trip -- the rows' parameters
+        // and moments (their addresses need only the row) next to each lane's first hit -- then the sums.
+        // (One entry at a time was two dependent round trips per owner: 6 us each, 30 us for a wave of 4.)
+        constexpr int PAIR = 2;
+        static_assert(NROW_EPW % PAIR == 0, "entries per wave come in pairs");
+        for (int e0 = 0; e0 < NROW_EPW; e0 += PAIR) {
+            int rowq[PAIR];
+            bool own[PAIR];
+            unsigned long long mine[PAIR][MW];              // bit c of word c / 64: entry c*64 + lane is a hit (nch <= 64 MW)
+#pragma unroll
+            for (int q = 0; q < PAIR; ++q) {
+                const int64_t k = (int64_t)gi * 4 * NROW_EPW + (e0 + q) * 4 + (threadIdx.x >> 6);
+                own[q] = false;
+                rowq[q] = 0;
+#pragma unroll
+                for (int m = 0; m < MW; ++m) mine[q][m] = 0;
+                const int row = k < w.entries ? sid[k] : -1;    // -1: past the end, or a padded entry (gathered ragged shards)
+                // phase 1: is k the first entry of its row?  (scan of the ids in LDS, 64 at a time)
+                bool first = row >= 0;                      // (everything here is uniform over the wave)
+                for (int c = 0; c < nch && first; ++c) {
+                    const int jj = c * 64 + lane;
+                    const unsigned long long mask = __ballot(jj < w.entries && sid[jj] == row);
+                    if (mask && (int64_t)c * 64 + (__ffsll((long long)mask) - 1) < k) first = false;
+                    if (mask && (int64_t)c * 64 + 63 >= k) break;   // reached k's own chunk: nothing earlier matched
+                }
+                if (first) {                                // else an earlier entry owns this row
+                    own[q] = true;
+                    rowq[q] = row;
+                    for (int c = (int)(k / 64); c < nch; ++c) { // (no hit before k's chunk: k is the first)
+                        const int64_t jj = (int64_t)c * 64 + lane;
+                        if (jj < w.entries && sid[jj] == row) {
+#pragma unroll
+                            for (int m = 0; m < MW; ++m)
+                                if ((c >> 6) == m) mine[q][m] |= 1ull << (c & 63);
+                        }
+                    }
+                }
+            }
+            auto any = [&](int q) { unsigned long long o = 0;
+#pragma unroll
+                for (int m = 0; m < MW; ++m) o |= mine[q][m];
+                return o != 0; };
+            auto pop = [&](int q) -> int {                  // the lane's lowest remaining hit (ascending order), -1 if none
+#pragma unroll
+                for (int m = 0; m < MW; ++m)
+                    if (mine[q][m]) { const int c = __ffsll((long long)mine[q][m]) - 1; mine[q][m] &= mine[q][m] - 1; return m * 64 + c; }
+                return -1;
+            };
+            // one round trip: unconditional loads at clamped addresses (row 0 / entry 0 for a non-owner: unused)
+            float P[PAIR], M[PAIR], V[PAIR], Pb[PAIR], Mb[PAIR], Vb[PAIR], h0[PAIR][ML], g0[PAIR];
+            int c0[PAIR];
+#pragma unroll
+            for (int q = 0; q < PAIR; ++q) {
+                const int64_t o = (int64_t)rowq[q] * L + (lane < L ? lane : L - 1);
+                P[q] = tp[o]; M[q] = tm[o]; V[q] = tv[o];
+                Pb[q] = bp[rowq[q]]; Mb[q] = bm[rowq[q]]; Vb[q] = bv[rowq[q]];
+                c0[q] = pop(q);
+                int64_t jj = (int64_t)(c0[q] < 0 ? 0 : c0[q]) * 64 + lane;
+                if (jj >= w.entries) jj = w.entries - 1;
+#pragma unroll
+                for (int col = 0; col < ML; ++col) h0[q][col] = rows[jj * L + (col < L ? col : L - 1)];
+                g0[q] = w.g[jj < w.B ? jj : 0];
+            }
+#pragma unroll
+            for (int q = 0; q < PAIR; ++q) if (own[q]) {    // uniform
+                // phase 2 (one wave per DISTINCT row): every lane adds up the rows of ITS hits, chunk by
+                // chunk in ascending order, then one fixed butterfly per column combines the 64 lanes -- a
+                // fixed order, so the result is deterministic (a butterfly per chunk made a row with
+                // hundreds of entries a 70 us chain of cross-lane permutes)
+                float rv[ML];
+                const int64_t j0 = (int64_t)(c0[q] < 0 ? 0 : c0[q]) * 64 + lane;
+#pragma unroll
+                for (int col = 0; col < ML; ++col) rv[col] = 0.f + ((c0[q] >= 0 && col < L) ? h0[q][col] : 0.f);
+                float gv = 0.f + ((c0[q] >= 0 && j0 < w.B) ? g0[q] : 0.f);     // only the self entries carry a bias gradient
+                while (__ballot(any(q))) {                  // a lane's further hits, two per round, their loads together
+                    constexpr int HR = 2;                   // (registers: the pair's first hits are still live)
+                    int cs[HR];
+#pragma unroll
+                    for (int u = 0; u < HR; ++u) cs[u] = pop(q);
+                    float tmp[HR][ML], tg[HR];
+#pragma unroll
+                    for (int u = 0; u < HR; ++u) {
+                        const int64_t jj = (int64_t)(cs[u] < 0 ? 0 : cs[u]) * 64 + lane;
+#pragma unroll
+                        for (int col = 0; col < ML; ++col)
+                            tmp[u][col] = (cs[u] >= 0 && col < L) ? rows[jj * L + col] : 0.f;
+                        tg[u] = (cs[u] >= 0 && jj < w.B) ? w.g[jj] : 0.f;
+                    }
+#pragma unroll
+                    for (int u = 0; u < HR; ++u) {          // ascending entry order within the lane
+#pragma unroll
+                        for (int col = 0; col < ML; ++col) rv[col] += tmp[u][col];
+                        gv += tg[u];
+                    }
+                }
+                float acc = 0.f;                            // lane < L: column `lane` of the table row
+#pragma unroll
+                for (int col = 0; col < ML; ++col) {
+                    if (col < L) {                          // uniform
+                        const float sum = wave_sum(rv[col]);
+                        if (lane == col) acc = sum;
+                    }
+                }
+                const float accb = wave_sum(gv);
+                const int row = rowq[q];
+                if (lane < L) {
+                    const int64_t o = (int64_t)row * L + lane;
+                    float p1 = P[q], m1 = M[q], v1 = V[q];
+                    adam_elem(p1, acc, m1, v1, w.s);
+                    tp[o] = p1; tm[o] = m1; tv[o] = v1;
+                }
+                if (lane == 0) {                            // the row's bias element (gradient zero if no self entry)
+                    float p1 = Pb[q], m1 = Mb[q], v1 = Vb[q];
+                    adam_elem(p1, accb, m1, v1, w.s);
+                    bp[row] = p1; bm[row] = m1; bv[row] = v1;
+                }
+            }
+        }
+        return;
+    }
+    narre_sweep_block(w, bx);
+}
+
 // ML: 0 = no ID-table role (DeepCoNN++), else the rows role's template argument.  z-slices: the ID
 // tables (ML > 0), the `ntower` towers' weight gradients, the head-parameter column sums, the next
 // batch's token marks (if announced).
+#ifdef R4R_TRACE
+// role timeline of the backward launch (tools/head_trace.py --backward): 4 words per workgroup --
+// start, end (s_memrealtime, 100 MHz), z-slice
+static __device__ unsigned long long *g_bwd_trace = nullptr;
+#define BWD_TRACE_DEFINE(setter)                                                                       \
+    extern "C" int setter(void *buf) {                                                                 \
+        return hipMemcpyToSymbol(HIP_SYMBOL(g_bwd_trace), &buf, sizeof(buf)) == hipSuccess ? 0 : -1;    \
+    }
+#define BWD_STAMP(k, val)                                                                              \
+    if (g_bwd_trace && threadIdx.x == 0)                                                               \
+        g_bwd_trace[((size_t)blockIdx.z * gridDim.y * gridDim.x + blockIdx.y * gridDim.x + blockIdx.x) * 4 + (k)] = (val);
+#else
+#define BWD_TRACE_DEFINE(setter)
+#define BWD_STAMP(k, val)
+#endif
+
 template <int ML>
-__global__ __launch_bounds__(WG_THREADS) void narre_backward_kernel(WgradArgs w, ColSum c, int cs_blocks, TokenArgs nx,
+__global__ __launch_bounds__(WG_THREADS, ML > 16 ? 2 : 4) void narre_backward_kernel(WgradArgs w, ColSum c, int cs_blocks, TokenArgs nx,
                                                                     int packed, RowSweep rows, int row_blocks, int ntower) {
     const int blk0 = blockIdx.y * gridDim.x + blockIdx.x, nblk = gridDim.x * gridDim.y;
+    BWD_STAMP(0, wall_clock64())
+    BWD_STAMP(2, (unsigned long long)blockIdx.z + 1)
     // the ID-table role is dispatched FIRST (slice 0 when present): its owners' dependent chains are
     // the longest thing in the launch, the weight-gradient workgroups fill in around them
     const int z = (int)blockIdx.z - (ML > 0 ? 1 : 0);
@@ -226,8 +288,8 @@ __global__ __launch_bounds__(WG_THREADS) void narre_backward_kernel(WgradArgs w,
         if constexpr (ML > 0) {
             __shared__ int rows_sid[NROW_MAX_ENTRIES];
             // entry workgroups first (the owner of a popular row is the longest), then the sweep
-            for (int blk = blk0; blk < row_blocks; blk += nblk) {
-                const int ne = row_blocks - rows.cb_entries;
+            const int ne = row_blocks - rows.cb_entries;
+            for (int blk = blk0; blk < (rows.sweep_elsewhere ? ne : row_blocks); blk += nblk) {
                 narre_rows_block<ML, 1>(rows, blk < ne ? rows.cb_entries + blk : blk - ne, rows_sid);
                 __syncthreads();
             }
@@ -243,6 +305,10 @@ __global__ __launch_bounds__(WG_THREADS) void narre_backward_kernel(WgradArgs w,
     } else {
         token_mark_block(nx, blk0, nblk, WG_THREADS);
     }
+#ifdef R4R_TRACE
+    __syncthreads();                                        // the workgroup's end, not thread 0's
+#endif
+    BWD_STAMP(1, wall_clock64())
 }
 
 // The ID-table role as a launch of its own (data parallel: the entries of ALL ranks, gathered): up to
@@ -264,8 +330,16 @@ struct DenseAdam {
     int on;
 };
 static __global__ __launch_bounds__(NRED_THREADS) void narre_reduce_kernel(WgradArgs w, int red_blocks, int comp_blocks,
-                                                                    TokenArgs nx, DenseAdam opt) {
+                                                                    TokenArgs nx, DenseAdam opt, int opt_blocks = 0,
+                                                                    RowSweep rows = RowSweep{}) {
     const int bx = blockIdx.x;
+    if (rows.sweep_elsewhere && bx >= red_blocks + comp_blocks + opt_blocks) {
+        // NARRE: the ID tables' untouched rows (the touched ones were updated by the backward launch's
+        // entry waves; the two sets are disjoint), two sweep workgroups per grid column
+        const int sb = (bx - red_blocks - comp_blocks - opt_blocks) * (int)gridDim.y + (int)blockIdx.y;
+        if (sb < rows.cb_entries) narre_sweep_block(rows, sb);
+        return;
+    }
     if (bx < red_blocks) {
         wgrad_reduce_block(w, blockIdx.y, bx);
         if (opt.on) {

@@ -14,7 +14,7 @@ import reviews4rec_amd
 from reviews4rec_amd import synthetic
 from reviews4rec_amd.utils import xavier_init
 
-workload = sys.argv[1] if len(sys.argv) > 1 else 'cfg4_narre_kindle'
+workload = sys.argv[1] if len(sys.argv) > 1 and not sys.argv[1].startswith('--') else 'cfg4_narre_kindle'
 hp = synthetic.hyper_params_for(workload, dropout=0.6)
 B = hp['batch_size']
 hp['word_vectors'] = synthetic.word_table(hp['vocab'], hp['word_embed_size'])
@@ -32,7 +32,11 @@ eng = {'NARRE': E.NarreEngine, 'deepconn': E.DeepCoNNEngine}.get(hp['model_type'
 lib = ctypes.CDLL(os.environ['R4R_LIBRARY'])
 setter = {'NARRE': lib.r4r_debug_narre_head_trace, 'deepconn': lib.r4r_debug_dc_head_trace}.get(hp['model_type'], lib.r4r_debug_tn_head_trace)
 setter.argtypes = [ctypes.c_void_p]
-trace = torch.zeros(B * 32, dtype=torch.int64, device='cuda')
+backward = '--backward' in sys.argv
+if backward:
+    setter = lib.r4r_debug_narre_bwd_trace
+    setter.argtypes = [ctypes.c_void_p]
+trace = torch.zeros(max(B * 32, 65536 * 4), dtype=torch.int64, device='cuda')
 for i in range(20):
     eng.train_step(*pool[i % 4])
 torch.cuda.synchronize()
@@ -41,7 +45,23 @@ for i in range(4):
     trace.zero_()
     eng.train_step(*pool[i % 4])
 torch.cuda.synchronize()
-tr = trace.cpu().numpy().reshape(B, 32)
+if backward:
+    tr = trace.cpu().numpy().reshape(-1, 4)
+    tr = tr[tr[:, 0] > 0]
+    t0 = tr[:, 0].min()
+    print('%s backward launch: %d workgroups, first start -> last end %.2f us' % (workload, len(tr), (tr[:, 1].max() - t0) / 100.0))
+    for z in sorted(set(tr[:, 2].tolist())):
+        r = tr[tr[:, 2] == z]
+        d = (r[:, 1] - r[:, 0]) / 100.0
+        print('z-slice %d: %4d workgroups, start %5.2f .. %5.2f us, duration med %5.2f max %5.2f, last end %5.2f us'
+              % (z - 1, len(r), (r[:, 0].min() - t0) / 100.0, (r[:, 0].max() - t0) / 100.0, np.median(d), d.max(),
+                 (r[:, 1].max() - t0) / 100.0))
+        busy = np.sort(d[d > 2.0])
+        if len(busy) and z == 1:                             # the ID-table role: most workgroups exit at once
+            print('           %d busy workgroups: p50 %.2f p90 %.2f p99 %.2f max %.2f us' % (
+                len(busy), busy[len(busy) // 2], busy[int(len(busy) * 0.9)], busy[int(len(busy) * 0.99)], busy[-1]))
+    sys.exit(0)
+tr = trace.cpu().numpy().reshape(-1, 32)[:B]
 tr = tr[tr[:, 0] > 0]                                      # (DeepCoNN: one workgroup per 4 ratings)
 n = int((tr[0, :20] > 0).sum())
 t0 = tr[:, 0].min()
