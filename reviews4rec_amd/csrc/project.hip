@@ -550,8 +550,8 @@ __global__ __launch_bounds__(GEMM_THREADS) void proj_gemm_kernel(ProjArgs a) {
     }
 }
 
-// ---- 3. gather-add-max.  One workgroup = TWO 128-position segments of one document
-// (grid = (N * ceil(tiles / 2), ntower)); its 8 workers of 32 lanes each walk a
+// ---- 3. gather-add-max.  One workgroup = TWO consecutive 128-position segments of the launch's
+// document-major segment list (grid = (ceil(N * tiles / 2), ntower)); its 8 workers of 32 lanes each walk a
 // 32-position slice, so a worker's dependent chain is 34 tokens / 8 in flight = 5 memory
 // round trips (it was 130 / 4 = 33: at batch 128 the kernel was pure latency).  Lane
 // wl < 25 owns filters 4wl..4wl+3 (one float4 of each 400-byte tap row).  Token t completes
@@ -570,10 +570,13 @@ __global__ __launch_bounds__(256) void proj_gather_max_kernel(ProjArgs a) {
     __shared__ float sbest[8][PF];
     __shared__ int sbp[8][PF];
     const ProjTower &tw = a.t[blockIdx.y];
-    const int pairs = (a.tiles + 1) / 2;
-    const int64_t doc = blockIdx.x / pairs;
-    const int seg_base = (blockIdx.x - doc * pairs) * 2;
     const int worker = threadIdx.x >> 5, wl = threadIdx.x & 31;
+    // segment `unit` of the launch's N * tiles segments (document-major): workers 0-3 take the
+    // workgroup's first segment, 4-7 its second -- of the same document, or (odd tile counts, e.g.
+    // NARRE's one-tile reviews) the first of the next one
+    const int64_t unit = (int64_t)blockIdx.x * 2 + (worker >> 2), units = a.N * a.tiles;
+    const int64_t doc = unit < units ? unit / a.tiles : 0;
+    const int seg = unit < units ? (int)(unit - doc * a.tiles) : a.tiles;     // a.tiles: no such segment
     const int T = a.T, P = T + 2;
     const bool act = wl < PF / 4;
     const f32x4 zero = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -582,7 +585,6 @@ __global__ __launch_bounds__(256) void proj_gather_max_kernel(ProjArgs a) {
         tw.count[0] = 0;
     }
 
-    const int seg = seg_base + (worker >> 2);               // workers 0-3: first segment, 4-7: second
     const int p_lo = seg * SEG + (worker & 3) * SLICE;
     const int p_hi = min(P, p_lo + SLICE);
     const int t_lo = p_lo - 2;
@@ -657,8 +659,8 @@ __global__ __launch_bounds__(256) void proj_gather_max_kernel(ProjArgs a) {
     __syncthreads();
     // merge the 4 slices of each segment in position order; thread f (< 100) of each half
     const int half = threadIdx.x >> 7, f = threadIdx.x & 127;
-    const int oseg = seg_base + half;
-    if (f < PF && oseg < a.tiles) {
+    const int64_t ounit = (int64_t)blockIdx.x * 2 + half;
+    if (f < PF && ounit < units) {
         float mb = sbest[half * 4][f];
         int mp = sbp[half * 4][f];
 #pragma unroll
@@ -666,7 +668,7 @@ __global__ __launch_bounds__(256) void proj_gather_max_kernel(ProjArgs a) {
             const float v = sbest[half * 4 + w][f];
             if (v > mb) { mb = v; mp = sbp[half * 4 + w][f]; }
         }
-        const size_t o = ((size_t)doc * a.tiles + oseg) * NP + f;
+        const size_t o = (size_t)ounit * NP + f;           // [doc][tile][NP]
         tw.pmax[o] = mb;
         tw.parg[o] = mp;
     }
@@ -749,7 +751,7 @@ int textcnn_proj_compute_launch(const float *table, int64_t V, const ProjTower *
     }
     {
         ScopedTiming tm(R4R_TIMING_PROJ_GATHER, st);
-        proj_gather_max_kernel<<<dim3((unsigned)(N * ((a.tiles + 1) / 2)), ntower), 256, 0, st>>>(a);
+        proj_gather_max_kernel<<<dim3((unsigned)cdiv(N * a.tiles, 2), ntower), 256, 0, st>>>(a);
     }
     return check_launch("textcnn_proj_fwd");
 }
