@@ -361,11 +361,16 @@ __device__ __forceinline__ void head_grad_block(const HeadGradArgs &a, int blk) 
 // With a 4th z-slice the launch also marks the tokens of the NEXT batch (`nx`): that work depends
 // only on the next batch's indices, the slice's workgroups fill CUs the latency-bound wgrad
 // leaves idle, and the next step then starts at its GEMM.
-__global__ __launch_bounds__(WG_THREADS) void deepconn_backward_kernel(WgradArgs w, HeadGradArgs h, int hg_blocks,
+BWD_TRACE_DEFINE(r4r_debug_dc_bwd_trace)
+__global__ __launch_bounds__(WG_THREADS, 8) void deepconn_backward_kernel(WgradArgs w, HeadGradArgs h, int hg_blocks,
                                                                        TokenArgs nx) {
-    if (blockIdx.z < 2) {
-        wgrad_block(w, blockIdx.x, blockIdx.y, blockIdx.z);
-    } else if (blockIdx.z == 2) {
+    BWD_STAMP(0, wall_clock64())
+    BWD_STAMP(2, (unsigned long long)blockIdx.z + 1)
+    // (slice 0 = the head gradients: its ~140 working workgroups are the longest chains of the launch and
+    // start first; 1,600 wgrad workgroups follow, all resident at 8 waves per SIMD)
+    if (blockIdx.z == 1 || blockIdx.z == 2) {
+        wgrad_block(w, blockIdx.x, blockIdx.y, blockIdx.z - 1);
+    } else if (blockIdx.z == 0) {
         for (int blk = blockIdx.y * gridDim.x + blockIdx.x; blk < hg_blocks; blk += gridDim.x * gridDim.y) {
             head_grad_block(h, blk);
             __syncthreads();
@@ -373,6 +378,10 @@ __global__ __launch_bounds__(WG_THREADS) void deepconn_backward_kernel(WgradArgs
     } else {
         token_mark_block(nx, blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y, WG_THREADS);
     }
+#ifdef R4R_TRACE
+    __syncthreads();                                        // the workgroup's end, not thread 0's
+#endif
+    BWD_STAMP(1, wall_clock64())
 }
 
 // Second stage of the wgrad (fixed-order sum of the partials) and, in the extra workgroups, the

@@ -11,6 +11,7 @@
 #include "rows_device.h"
 #include "textcnn.h"
 #include "tokens_device.h"
+#include "trace_device.h"
 #include "wgrad_device.h"
 
 namespace r4r {
@@ -259,22 +260,6 @@ __device__ __forceinline__ void narre_rows_block(const RowSweep &w, int bx, int 
 // ML: 0 = no ID-table role (DeepCoNN++), else the rows role's template argument.  z-slices: the ID
 // tables (ML > 0), the `ntower` towers' weight gradients, the head-parameter column sums, the next
 // batch's token marks (if announced).
-#ifdef R4R_TRACE
-// role timeline of the backward launch (tools/head_trace.py --backward): 4 words per workgroup --
-// start, end (s_memrealtime, 100 MHz), z-slice
-static __device__ unsigned long long *g_bwd_trace = nullptr;
-#define BWD_TRACE_DEFINE(setter)                                                                       \
-    extern "C" int setter(void *buf) {                                                                 \
-        return hipMemcpyToSymbol(HIP_SYMBOL(g_bwd_trace), &buf, sizeof(buf)) == hipSuccess ? 0 : -1;    \
-    }
-#define BWD_STAMP(k, val)                                                                              \
-    if (g_bwd_trace && threadIdx.x == 0)                                                               \
-        g_bwd_trace[((size_t)blockIdx.z * gridDim.y * gridDim.x + blockIdx.y * gridDim.x + blockIdx.x) * 4 + (k)] = (val);
-#else
-#define BWD_TRACE_DEFINE(setter)
-#define BWD_STAMP(k, val)
-#endif
-
 template <int ML>
 __global__ __launch_bounds__(WG_THREADS, ML > 16 ? 2 : 4) void narre_backward_kernel(WgradArgs w, ColSum c, int cs_blocks, TokenArgs nx,
                                                                     int packed, RowSweep rows, int row_blocks, int ntower) {

@@ -14,3 +14,20 @@
 #define HEAD_TRACE_DEFINE(setter)
 #define HEAD_STAMP(k)
 #endif
+
+#ifdef R4R_TRACE
+// Role timeline of a backward launch (tools/head_trace.py --backward): 4 words per workgroup --
+// start, end (s_memrealtime, 100 MHz), z-slice
+static __device__ unsigned long long *g_bwd_trace = nullptr;
+#define BWD_TRACE_DEFINE(setter)                                                                       \
+    extern "C" int setter(void *buf) {                                                                 \
+        return hipMemcpyToSymbol(HIP_SYMBOL(g_bwd_trace), &buf, sizeof(buf)) == hipSuccess ? 0 : -1;    \
+    }
+#define BWD_STAMP(k, val)                                                                              \
+    if (g_bwd_trace && threadIdx.x == 0)                                                               \
+        g_bwd_trace[((size_t)blockIdx.z * gridDim.y * gridDim.x + blockIdx.y * gridDim.x + blockIdx.x) * 4 + (k)] = (val);
+#else
+#define BWD_TRACE_DEFINE(setter)
+#define BWD_STAMP(k, val)
+#endif
+

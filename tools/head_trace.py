@@ -34,7 +34,7 @@ setter = {'NARRE': lib.r4r_debug_narre_head_trace, 'deepconn': lib.r4r_debug_dc_
 setter.argtypes = [ctypes.c_void_p]
 backward = '--backward' in sys.argv
 if backward:
-    setter = lib.r4r_debug_narre_bwd_trace
+    setter = lib.r4r_debug_dc_bwd_trace if hp['model_type'] == 'deepconn' else lib.r4r_debug_narre_bwd_trace
     setter.argtypes = [ctypes.c_void_p]
 trace = torch.zeros(max(B * 32, 65536 * 4), dtype=torch.int64, device='cuda')
 for i in range(20):
@@ -57,7 +57,7 @@ if backward:
               % (z - 1, len(r), (r[:, 0].min() - t0) / 100.0, (r[:, 0].max() - t0) / 100.0, np.median(d), d.max(),
                  (r[:, 1].max() - t0) / 100.0))
         busy = np.sort(d[d > 2.0])
-        if len(busy) and z == 1:                             # the ID-table role: most workgroups exit at once
+        if len(busy) and z == 1 and hp['model_type'] == 'NARRE':   # the ID-table role: most workgroups exit at once
             print('           %d busy workgroups: p50 %.2f p90 %.2f p99 %.2f max %.2f us' % (
                 len(busy), busy[len(busy) // 2], busy[int(len(busy) * 0.9)], busy[int(len(busy) * 0.99)], busy[-1]))
     sys.exit(0)
