@@ -122,6 +122,7 @@ def parse():
     ap.add_argument('--ramp', type=int, default=30,
                     help='untimed steps before the requested warm-up when --warmup is shorter than this: clocks '
                          'and launch queue reach steady state whatever --warmup says (reported as warmup_effective)')
+    ap.add_argument('--no-opt-in-leg', action='store_true', help='skip the extra fp16-split-GEMM leg at N = 1')
     ap.add_argument('--gemm-math', choices=['f32', 'f16x2'], default='f32',
                     help='arithmetic of the projection GEMM: f32 (default, the headline: fp32 operands on the fp32 MFMA) or '
                          'the opt-in fp16-split form (every operand = hi + lo fp16, three f16-MFMA products per fp32 '
@@ -429,6 +430,30 @@ def main():
                                 'ms_per_step': round(1000.0 * el_s / args.steps, 4), 'steps': args.steps})
             del pool_s
 
+    # N = 1: a separately timed leg with the OPT-IN arithmetic of the projection GEMM (fp16-split operands,
+    # fp32 accumulation: DESIGN.md 4.1d).  Reported beside the fp32 line, never as `value`.
+    opt_in = None
+    if (world == 1 and args.gemm_math == 'f32' and getattr(engine, 'gemm_math', None) == 'f32'
+            and 'proj_gemm_kernel' in timed and not args.from_host and not args.no_opt_in_leg):
+        from reviews4rec_amd import engine as E
+        os.environ['R4R_GEMM_MATH'] = 'f16x2'
+        engine.gemm_math = 'f16x2'
+        E._MATH_OWNER[0] = None                              # the next step reads the scales and switches the GEMM
+        try:
+            for i in range(10):
+                step(steps_run + i)
+            el_o = timed_region(step, args.steps, steps_run + 10, 0)
+            opt_in = {'gemm_math': 'f16x2', 'ratings_per_s': round(args.steps * B_global / el_o, 1),
+                      'ms_per_step': round(1000.0 * el_o / args.steps, 4), 'steps': args.steps,
+                      'note': 'opt-in (R4R_GEMM_MATH=f16x2): projection GEMM on fp16-split operands, 3 f16-MFMA '
+                              'products per fp32 product, fp32 accumulation; error vs float64 at or below the '
+                              'fp32 GEMM\'s (tests/test_gpu_kernels.py); NOT the headline'}
+        finally:
+            os.environ['R4R_GEMM_MATH'] = 'f32'
+            engine.gemm_math = 'f32'
+            E.apply_gemm_math(engine.table, engine._conv_weights())
+            lib.r4r_timing_read(0, ctypes.byref(ctypes.c_double()), ctypes.byref(ctypes.c_int64()), 1)
+
     # replica check: after identical gradient sums and the identical dense Adam every rank must hold
     # the same bits; a broken exchange shows up here, not in a throughput number
     replicas = None
@@ -468,6 +493,8 @@ def main():
                                  'users': hp['total_users'], 'items': hp['total_items'],
                                  'dropout': hp['dropout']}},
         }
+        if opt_in:
+            result['opt_in_f16_split'] = opt_in
         if strong_legs:
             result['strong'] = strong_legs[0]                 # G = 1024 (2.70 M ratings/s at N = 1)
             result['strong_legs'] = strong_legs
