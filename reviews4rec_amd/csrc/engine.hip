@@ -416,7 +416,7 @@ __global__ __launch_bounds__(RED_THREADS) void deepconn_reduce_kernel(WgradArgs 
             }
         }
     } else if (bx < red_blocks + comp_blocks) {
-        token_compact_block<RED_THREADS / 64, COMPACT_G>(nx.t[blockIdx.y], nx.V, bx - red_blocks);
+        token_compact_auto<RED_THREADS / 64>(nx.t[blockIdx.y], nx.V, bx - red_blocks);
     } else {
         const int64_t o = opt.lo[blockIdx.y] + (int64_t)(bx - red_blocks - comp_blocks) * RED_THREADS + threadIdx.x;
         if (o < opt.hi[blockIdx.y]) {
@@ -682,7 +682,7 @@ extern "C" int r4r_deepconn_step(const float *table, int64_t V, const int64_t *u
     }
     // 6: wgrad partial reduce -> flat gradient buffer (+ compaction of the next batch's tokens)
     const int red_blocks = (F_CONV * 3 * E + F_CONV + RED_THREADS - 1) / RED_THREADS;
-    const int comp_blocks = prefetch ? (int)cdiv((V + 3) / 4, RED_THREADS * COMPACT_G) : 0;
+    const int comp_blocks = prefetch ? (int)cdiv((V + 3) / 4, RED_THREADS * compact_groups(V)) : 0;
     FusedAdam opt{};
     int opt_blocks = 0;
     if (flat_m) {

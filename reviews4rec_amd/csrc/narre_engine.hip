@@ -779,7 +779,7 @@ extern "C" int r4r_narre_step(const float *table, int64_t V,
 
     // 5: wgrad reduce + Adam on the dense parameters (+ next batch's compaction)
     const int red_blocks = (NF * 3 * E + NF + NRED_THREADS - 1) / NRED_THREADS;
-    const int comp_blocks = prefetch ? (int)cdiv((V + 3) / 4, NRED_THREADS * COMPACT_G) : 0;
+    const int comp_blocks = prefetch ? (int)cdiv((V + 3) / 4, NRED_THREADS * compact_groups(V)) : 0;
     DenseAdam opt;
     opt.on = apply ? 1 : 0; opt.p = flat_p; opt.m = flat_m; opt.v = flat_v; opt.g = flat_g;
     opt.lo0 = hc.lo0; opt.hi0 = hc.hi0; opt.lo1 = hc.lo1; opt.hi1 = hc.hi1;

@@ -340,7 +340,7 @@ static __global__ __launch_bounds__(NRED_THREADS) void narre_reduce_kernel(Wgrad
             }
         }
     } else if (bx < red_blocks + comp_blocks) {
-        token_compact_block<NRED_THREADS / 64, COMPACT_G>(nx.t[blockIdx.y], nx.V, bx - red_blocks);
+        token_compact_auto<NRED_THREADS / 64>(nx.t[blockIdx.y], nx.V, bx - red_blocks);
     } else {
         const int64_t base = blockIdx.y == 0 ? opt.lo0 : opt.lo1, end = blockIdx.y == 0 ? opt.hi0 : (blockIdx.y == 1 ? opt.hi1 : opt.lo1);
         const int64_t o = base + (int64_t)(bx - red_blocks - comp_blocks) * NRED_THREADS + threadIdx.x;

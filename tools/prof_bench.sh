@@ -5,7 +5,7 @@ cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/prof_$1
 mkdir -p $OUT
-CMD="python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline $BENCH_ARGS"   # BENCH_ARGS: e.g. "--workload cfg5_transnetpp_synthetic"
+CMD="python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-opt-in-leg $BENCH_ARGS"   # BENCH_ARGS: e.g. "--workload cfg5_transnetpp_synthetic"
 rocprofv3 --kernel-trace --stats -d $OUT/kt -- $CMD > $OUT/bench.log 2>&1
 tail -1 $OUT/bench.log | cut -c1-160
 DB=$(find $OUT/kt -name "*.db" | head -1)
