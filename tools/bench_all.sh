@@ -25,3 +25,6 @@ run "cfg2 shapes, NeuMF (L=32) native" --workload cfg2_mfdot_electronics --model
 run "cfg2 shapes, NeuMF (L=32) graph" --workload cfg2_mfdot_electronics --model-type NeuMF --latent 32 --engine graph
 run "cfg3 fp16-split GEMM (opt-in) native" --gemm-math f16x2
 run "cfg4 fp16-split GEMM (opt-in) native" --workload cfg4_narre_kindle --gemm-math f16x2
+run "cfg4 shapes, NARRE E=300 native" --workload cfg4_narre_kindle --embed 300
+run "cfg4 shapes, NARRE E=300 graph" --workload cfg4_narre_kindle --embed 300 --engine graph
+run "cfg3 batch 1024 native" --batch-per-gpu 1024
