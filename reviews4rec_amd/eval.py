@@ -37,12 +37,15 @@ def _launch_size(reader, hyper_params, engine, factor):
     projection, gather, one workgroup or wave per rating -- so larger slices of the same stream give the
     same scores with fewer launches and less Python per rating (``eval_batch_size`` overrides; the
     op-by-op module path keeps the reference's slices: its Linear layers are rocBLAS GEMMs over the
-    batch; TransNet too: its MSE_right / MSE_transform are means of per-slice means, eval.py:33-35)."""
+    batch).  TransNet's MSE_right / MSE_transform are means of per-slice means (eval.py:33-35): evaluate()
+    takes them over the reference's slices INSIDE each launch, from the engine's per-rating values."""
     if engine is None or not getattr(reader, 'takes_batch', False):
         return None
+    bsz = int(hyper_params['batch_size'])
+    n = int(hyper_params.get('eval_batch_size') or factor * bsz)
     if hyper_params['model_type'] in ['transnet', 'transnet++']:
-        return None
-    return int(hyper_params.get('eval_batch_size') or factor * int(hyper_params['batch_size']))
+        n = max(bsz, n - n % bsz)                            # launches must start on the reference's slice boundaries
+    return n
 
 
 def evaluate(model, criterion, reader, hyper_params, user_count, item_count, review, engine=None):
@@ -50,6 +53,7 @@ def evaluate(model, criterion, reader, hyper_params, user_count, item_count, rev
     big = _launch_size(reader, hyper_params, engine, EVAL_LAUNCH)
     batches = reader.iter(eval=True, batch=big) if big else reader.iter(eval=True)
     total_n, total_batches = 0.0, 0.0
+    bsz = int(hyper_params['batch_size'])
     is_tn = hyper_params['model_type'] in ['transnet', 'transnet++']
     se_parts, user_parts, item_parts = [], [], []
     total_se = mse_right = conv_loss = None                  # device scalars: no sync inside the pass
@@ -61,10 +65,17 @@ def evaluate(model, criterion, reader, hyper_params, user_count, item_count, rev
                 output, mse = engine.predict(data, y)
                 mse = mse.clone()                            # the engine reuses its output buffer
                 if is_tn:                                    # TransNetEngine: per rating (target pred, its SE, transform)
-                    aux = engine.aux(data)
-                    r, c = aux[:, 1].mean(), aux[:, 2].mean()
-                    mse_right = r if mse_right is None else mse_right + r
-                    conv_loss = c if conv_loss is None else conv_loss + c
+                    aux = engine.aux(data)[:, 1:3]
+                    n_here, full = aux.shape[0], aux.shape[0] // bsz
+                    if full:                                 # the reference's slices of batch_size inside this launch
+                        rc = aux[:full * bsz].reshape(full, bsz, 2).mean(dim=1).sum(dim=0)
+                        mse_right = rc[0] if mse_right is None else mse_right + rc[0]
+                        conv_loss = rc[1] if conv_loss is None else conv_loss + rc[1]
+                    if n_here > full * bsz:                  # ... and the ragged last one
+                        rc = aux[full * bsz:].mean(dim=0)
+                        mse_right = rc[0] if mse_right is None else mse_right + rc[0]
+                        conv_loss = rc[1] if conv_loss is None else conv_loss + rc[1]
+                    total_batches += float(full + (n_here > full * bsz)) - 1.0      # (+ 1.0 below)
             else:
                 output = model(data)
                 if is_tn:
