@@ -185,14 +185,16 @@ def test_projection_and_direct_conv_agree_on_argmax_and_pooled():
         torch.testing.assert_close(outs[1][1][k], outs[2][1][k], rtol=1e-4, atol=1e-7, msg=lambda mm: k + ': ' + mm)
 
 
+@pytest.mark.parametrize('shape', [(64, 400, 128, 3000), (32, 200, 32, 300000)], ids=['v3k', 'v300k'])
 @pytest.mark.parametrize('how', ['fused', 'side_stream'])
-def test_token_prefetch_is_bit_identical_and_survives_mispredicted_batches(how):
+def test_token_prefetch_is_bit_identical_and_survives_mispredicted_batches(how, shape):
     """Token compaction of batch k+1 prepared during step k -- riding on step k's backward /
     reduce launches ('fused') or on a side stream -- must not change a single bit; a prepared
-    batch that is never trained on (wrong guess, an eval in between) is discarded cleanly."""
+    batch that is never trained on (wrong guess, an eval in between) is discarded cleanly.
+    (v300k: above 262,144 words the fused compaction takes eight int4 groups per thread, tokens_device.h.)"""
     import reviews4rec_amd
     from reviews4rec_amd.engine import DeepCoNNEngine
-    B, T, E, V, U, I = 64, 400, 128, 3000, 100, 50
+    (B, T, E, V), U, I = shape, 100, 50
     hp = dict(model_type='deepconn', latent_size=10, word_embed_size=E, input_length=T, dropout=0.0,
               total_users=U, total_items=I, lr=0.002, weight_decay=1e-6)
     P = oracle.init_params(hp, vocab_size=V, seed=4)
