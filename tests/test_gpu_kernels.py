@@ -63,7 +63,8 @@ def test_textcnn_forward_matches_aten(N, T, E, V):
     assert (arg[pos] == ref_arg[pos]).float().mean() > 0.999
 
 
-@pytest.mark.parametrize('N,T,E,V', [(70, 1000, 64, 3000), (700, 100, 64, 2000), (36, 1000, 300, 1500)])
+@pytest.mark.parametrize('N,T,E,V', [(70, 1000, 64, 3000), (700, 100, 64, 2000), (36, 1000, 300, 1500),
+                                     (301, 300, 64, 2000), (701, 100, 64, 2000)])   # odd segment counts: a gather workgroup straddles documents
 def test_textcnn_forward_auto_algorithm_at_scale(N, T, E, V):
     """>= 65536 positions (or E >= 128): R4R_CONV_AUTO runs project-then-gather inside
     r4r_textcnn_fwd (the small narrow shapes above run the direct conv); both must match ATen.  The whole suite is additionally run
