@@ -564,6 +564,42 @@ def test_narre_engine_wide_latent_uses_the_general_instantiation():
             assert float((diff > 2e-5 + 1e-4 * v.abs()).float().mean()) < 2e-3 and float(diff.max()) < 5e-4, k
 
 
+def test_narre_engine_popular_id_rows_in_the_fused_step():
+    """The fused step's ID-table role (entry waves in pairs, narre_rows_block) with rows that hundreds of the
+    batch's 1,056 compact entries hit -- several hits per lane, further rounds after the pair's common round
+    trip -- and users / items rated more than once: two steps against the CPU oracle (dense Adam)."""
+    import reviews4rec_amd
+    from reviews4rec_amd.engine import NarreEngine
+    from test_oracle_golden import ill_conditioned
+    B, R, W, E, V, U, I, L = 96, 10, 12, 32, 300, 60, 50, 10
+    hp = dict(model_type='NARRE', latent_size=L, word_embed_size=E, dropout=0.0, total_users=U, total_items=I,
+              lr=0.002, weight_decay=1e-6, narre_num_reviews=R, narre_num_words=W)
+    P = oracle.init_params(hp, vocab_size=V, seed=12)
+    model = reviews4rec_amd.get_model_class('NARRE')(dict(hp, word_vectors=P['word2vec.weight'].numpy()))
+    model.load_state_dict(P)
+    model = model.to(DEV).train()
+    eng = NarreEngine(model, lr=hp['lr'], weight_decay=hp['weight_decay'])
+    state = oracle.AdamState()
+    gen = torch.Generator().manual_seed(5)
+    data, y = synthetic_review_batch(B, W, V, U, I, seed=4, R=R, W=W)
+    who = torch.randint(0, U + 2, (B, R), generator=gen)
+    what = torch.randint(0, I + 2, (B, R), generator=gen)
+    who[torch.rand((B, R), generator=gen) < 0.45] = 7        # ~430 of the 960 neighbour entries on one user row
+    what[torch.rand((B, R), generator=gen) < 0.30] = 3
+    data[1], data[2] = who, what
+    data[5] = torch.randint(0, 12, (B,), generator=gen)      # a dozen users rate everything: self rows repeat
+    data[6] = torch.randint(0, I, (B,), generator=gen)
+    for step in range(2):
+        se = eng.train_step([d.to(DEV) for d in data], y.to(DEV)).cpu().clone()
+        sse, _ = oracle.train_step(P, data, y, hp, state)
+        torch.testing.assert_close(se.sum(), torch.tensor(sse), rtol=1e-4, atol=1e-4)
+    sd = model.state_dict()
+    for k, v in P.items():
+        if not ill_conditioned(k):
+            diff = (sd[k].cpu() - v).abs()
+            assert float((diff > 2e-5 + 1e-4 * v.abs()).float().mean()) < 2e-3 and float(diff.max()) < 5e-4, k
+
+
 def test_narre_engine_token_prefetch_is_bit_identical_with_wrong_guesses():
     """NARRE: the next batch's token state prepared on the current step's launches (project path)
     changes no bit; a wrong guess and an eval in between are handled."""
