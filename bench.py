@@ -366,9 +366,11 @@ def main():
         """EXACTLY `steps` steps between two fences; -> max-over-ranks wall seconds."""
         fence()
         t0 = time.perf_counter()
-        # sampled kernel timing: every 10th step, or -- short regions, where two instrumented steps are
-        # already 1.5 % of the window -- one step in the middle
-        sample = (lambda i: i % 10 == 5) if steps >= 50 else (lambda i: i == steps // 2)
+        # sampled kernel timing: every 20th step (an instrumented step costs ~30 us more: its HIP events
+        # carry release fences, and without them the spans stop agreeing with rocprofv3's kernel
+        # durations -- measured: 56.0 vs 59.4 us for the GEMM), or -- short regions, where two
+        # instrumented steps are already 1.5 % of the window -- one step in the middle
+        sample = (lambda i: i % 20 == 10) if steps >= 50 else (lambda i: i == steps // 2)
         for i in range(steps):
             lib.r4r_timing_enable(mask if sample(i) else 0)
             step_fn(first + i)
@@ -393,7 +395,7 @@ def main():
     for i in range(ramp + args.warmup):
         step(i)
     # Kernel timing for the roofline legs happens INSIDE the timed region but is sampled: only every
-    # 10th step is instrumented, and only the kernels the legs need (direct conv: slot 0; projection
+    # 20th step is instrumented, and only the kernels the legs need (direct conv: slot 0; projection
     # GEMM + gather: slots 3, 4).  A HIP event record serialises the queue for ~3 us; instrumenting
     # every launch of every step cost 20 % of a 0.13 ms step, sampling costs ~1 %.
     mask = 0 if args.no_kernel_timing else (1 << 0) | (1 << 3) | (1 << 4) | \
