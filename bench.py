@@ -227,6 +227,8 @@ def main():
 
     os.environ['R4R_GEMM_MATH'] = args.gemm_math             # read by the engines when they are built
     rank, world, local = r4dist.init_from_env()
+    # a data-parallel job: N > 1 -- or ONE rank with R4R_DP_SINGLE=1 (tests: the whole N > 1 path over RCCL on one GPU)
+    dp_job = world > 1 or os.environ.get('R4R_DP_SINGLE') == '1'
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a GPU: the HIP path has no CPU fallback')
     if world != args.gpus:
@@ -284,16 +286,16 @@ def main():
     B_global = B * world
 
     engine = make_engine(args, hp, model, dp, rank, world, B)
-    if engine is None and is_tn and world > 1:
+    if engine is None and is_tn and dp_job:
         raise SystemExit('TransNet under data parallelism needs the native step (see reviews4rec_amd.main.train)')
     # N > 1: measure the two gradient-exchange forms on this node's fabric once, before any timed
     # step, and keep the faster (R4R_DP_EXCHANGE=allreduce|gather pins one)
-    exchange_ms = engine.autotune_exchange() if (engine is not None and world > 1
+    exchange_ms = engine.autotune_exchange() if (engine is not None and dp_job
                                                  and hasattr(engine, 'autotune_exchange')) else {}
 
     graphed = None
     if args.engine == 'graph':
-        if world > 1:
+        if dp_job:
             raise SystemExit('--engine graph is single-GPU for now (the all-reduce is not captured)')
         from reviews4rec_amd.graph import GraphedStep
         graphed = GraphedStep(model, criterion, optimizer, *pool[0])   # TransNet: the optimiser list
@@ -358,7 +360,7 @@ def main():
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if dp_job:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
@@ -378,7 +380,7 @@ def main():
         elapsed = time.perf_counter() - t0
         lib.r4r_timing_enable(0)
         el = torch.tensor([elapsed], device=dev)
-        if world > 1:
+        if dp_job:
             torch.distributed.all_reduce(el, op=torch.distributed.ReduceOp.MAX)
         return float(el.item())
 
@@ -416,7 +418,7 @@ def main():
 
     # N > 1, weak: separately timed strong-scaling legs, each at a fixed global batch sharded over the ranks
     strong_legs = []
-    if world > 1 and not strong and not args.from_host and graphed is None:
+    if dp_job and not strong and not args.from_host and graphed is None:
         for G in [int(x) for x in str(args.strong_leg).split(',') if x.strip()]:
             if G % world:
                 continue
@@ -436,7 +438,7 @@ def main():
     # N = 1: a separately timed leg with the OPT-IN arithmetic of the projection GEMM (fp16-split operands,
     # fp32 accumulation: DESIGN.md 4.1d).  Reported beside the fp32 line, never as `value`.
     opt_in = None
-    if (world == 1 and args.gemm_math == 'f32' and getattr(engine, 'gemm_math', None) == 'f32'
+    if (not dp_job and args.gemm_math == 'f32' and getattr(engine, 'gemm_math', None) == 'f32'
             and 'proj_gemm_kernel' in timed and not args.from_host and not args.no_opt_in_leg):
         from reviews4rec_amd import engine as E
         os.environ['R4R_GEMM_MATH'] = 'f16x2'
@@ -460,7 +462,7 @@ def main():
     # replica check: after identical gradient sums and the identical dense Adam every rank must hold
     # the same bits; a broken exchange shows up here, not in a throughput number
     replicas = None
-    if world > 1:
+    if dp_job:
         flat = torch.cat([p.detach().reshape(-1).view(torch.int32).to(torch.int64) for p in model.parameters()
                           if p.dtype == torch.float32])
         digest = torch.stack([flat.sum(), (flat * (torch.arange(flat.numel(), device=dev) % 8191 + 1)).sum()])
@@ -487,7 +489,7 @@ def main():
                        'conv_algo': args.conv_algo, 'gemm_math': args.gemm_math, 'doc_fill': args.doc_fill,
                        'token_dist': args.token_dist,
                        **({'rccl_ranks': world, 'dist_backend': torch.distributed.get_backend(),
-                           'replicas_identical': replicas} if world > 1 else {}),
+                           'replicas_identical': replicas} if dp_job else {}),
                        **({'dp_exchange': engine.exchange,
                            'dp_exchange_ms': {k: round(v, 4) for k, v in exchange_ms.items()}} if exchange_ms else {}),
                        'shape': {'recommender': hp['model_type'], 'word_embed_size': hp['word_embed_size'],
@@ -587,12 +589,12 @@ def main():
                                   'frac': round(ach_b / PEAK_HBM_GBS, 4), 'traffic': traffic, 'traffic_source': src,
                                   'launches': timed['adam_multi_kernel'][1], 'avg_launch_ms': round(1000 * avg_s, 4),
                                   'bytes_per_launch': int(nparam * per), 'parameters': int(nparam)}
-        if world == 1 and not args.no_cpu_baseline:
+        if not dp_job and not args.no_cpu_baseline:
             cpu_hp = {k: v for k, v in hp.items() if k != 'word_vectors'}
             result['cpu_baseline'] = cpu_baseline(cpu_hp, table, batches_np[:4], args.cpu_seconds)
         result['train_mse_running'] = round(run_sse / (steps_run * B), 4)
         print(json.dumps(result))
-    if world > 1:
+    if dp_job:
         torch.distributed.destroy_process_group()
 
 

@@ -43,7 +43,7 @@ def init_from_env(backend=None):
         # the rank -> device map wraps around instead of failing
         local = local % torch.cuda.device_count()
         torch.cuda.set_device(local)
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or os.environ.get('R4R_DP_SINGLE') == '1') and not dist.is_initialized():
         if backend is None:
             backend = os.environ.get('R4R_DIST_BACKEND') or ('nccl' if torch.cuda.is_available() else 'gloo')
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
@@ -70,7 +70,10 @@ class DataParallel:
         gradient (default: the HIP ordered scatter; tests on the CPU inject their own)."""
         self.model = model
         self.group = group
-        self.on = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+        # (R4R_DP_SINGLE=1: a ONE-rank job keeps the data-parallel path on -- the collectives move nothing, but
+        # every one of them is issued, which is how a single-GPU box exercises RCCL: tests/test_gpu_dist.py)
+        self.on = dist.is_available() and dist.is_initialized() and (
+            dist.get_world_size(group) > 1 or os.environ.get('R4R_DP_SINGLE') == '1')
         self.world = dist.get_world_size(group) if self.on else 1
         self.rank = dist.get_rank(group) if self.on else 0
         self.params = [p for p in model.parameters() if p.requires_grad]

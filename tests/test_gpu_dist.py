@@ -27,7 +27,8 @@ def _worker(rank, world, port, case, out_dir):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, TESTS)
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
-                      LOCAL_RANK=str(rank), R4R_DIST_BACKEND='gloo')
+                      LOCAL_RANK=str(rank), R4R_DIST_BACKEND=os.environ.get('R4R_TEST_BACKEND', 'gloo'),
+                      R4R_DP_SINGLE='1' if world == 1 else '')
     from helpers import Golden
     from test_gpu_models import build_model
     from reviews4rec_amd import dist as r4dist
@@ -75,7 +76,8 @@ def _engine_worker(rank, world, port, case, out_dir, exchange):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, TESTS)
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
-                      LOCAL_RANK=str(rank), R4R_DIST_BACKEND='gloo')
+                      LOCAL_RANK=str(rank), R4R_DIST_BACKEND=os.environ.get('R4R_TEST_BACKEND', 'gloo'),
+                      R4R_DP_SINGLE='1' if world == 1 else '')
     if exchange != 'autotune':
         os.environ['R4R_DP_EXCHANGE'] = exchange
     from helpers import Golden
@@ -134,7 +136,8 @@ def _mf_worker(rank, world, port, case, out_dir):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, TESTS)
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
-                      LOCAL_RANK=str(rank), R4R_DIST_BACKEND='gloo')
+                      LOCAL_RANK=str(rank), R4R_DIST_BACKEND=os.environ.get('R4R_TEST_BACKEND', 'gloo'),
+                      R4R_DP_SINGLE='1' if world == 1 else '')
     from helpers import Golden
     from test_gpu_models import build_model
     from reviews4rec_amd import dist as r4dist, main as M
@@ -145,6 +148,7 @@ def _mf_worker(rank, world, port, case, out_dir):
     model.train()
     dp = r4dist.DataParallel(model)
     dp.broadcast_parameters()
+    model.hyper_params['batch_size'] = 64                    # per-rank batch: every shard below fits it
     eng = M.make_engine(dict(hp, engine='auto', batch_size=64), model, dp=dp, rank=rank)
     assert isinstance(eng, MFEngine) and eng.dp is not None
     ses = []
@@ -193,7 +197,8 @@ def _empty_shard_worker(rank, world, port, out_dir):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, TESTS)
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
-                      LOCAL_RANK=str(rank), R4R_DIST_BACKEND='gloo', R4R_DP_EXCHANGE='allreduce')
+                      LOCAL_RANK=str(rank), R4R_DIST_BACKEND=os.environ.get('R4R_TEST_BACKEND', 'gloo'),
+                      R4R_DP_SINGLE='1' if world == 1 else '', R4R_DP_EXCHANGE='allreduce')
     from helpers import Golden
     from test_gpu_models import build_model
     from reviews4rec_amd import dist as r4dist
@@ -244,7 +249,8 @@ def _transnet_worker(rank, world, port, case, out_dir):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, TESTS)
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
-                      LOCAL_RANK=str(rank), R4R_DIST_BACKEND='gloo')
+                      LOCAL_RANK=str(rank), R4R_DIST_BACKEND=os.environ.get('R4R_TEST_BACKEND', 'gloo'),
+                      R4R_DP_SINGLE='1' if world == 1 else '')
     from helpers import Golden
     from test_gpu_models import build_model
     from reviews4rec_amd import dist as r4dist, main as M
@@ -255,6 +261,7 @@ def _transnet_worker(rank, world, port, case, out_dir):
     model.train()
     dp = r4dist.DataParallel(model)
     dp.broadcast_parameters()
+    model.hyper_params['batch_size'] = 64                    # per-rank batch: every shard below fits it
     eng = M.make_engine(dict(hp, engine='auto', batch_size=64), model, dp=dp, rank=rank)
     assert isinstance(eng, TransNetEngine) and eng.dp is not None
     ses, aux = [], []
@@ -295,7 +302,8 @@ def _dcpp_worker(rank, world, port, out_dir):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, TESTS)
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
-                      LOCAL_RANK=str(rank), R4R_DIST_BACKEND='gloo')
+                      LOCAL_RANK=str(rank), R4R_DIST_BACKEND=os.environ.get('R4R_TEST_BACKEND', 'gloo'),
+                      R4R_DP_SINGLE='1' if world == 1 else '')
     from helpers import Golden
     from test_gpu_models import build_model
     from reviews4rec_amd import dist as r4dist, main as M
@@ -306,6 +314,7 @@ def _dcpp_worker(rank, world, port, out_dir):
     model.train()
     dp = r4dist.DataParallel(model)
     dp.broadcast_parameters()
+    model.hyper_params['batch_size'] = 64                    # per-rank batch: every shard below fits it
     eng = M.make_engine(dict(hp, engine='auto', batch_size=64), model, dp=dp, rank=rank)
     assert isinstance(eng, DeepCoNNPPEngine) and eng.dp is not None
     ses = []
@@ -341,7 +350,8 @@ def _narre_worker(rank, world, port, out_dir):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, TESTS)
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
-                      LOCAL_RANK=str(rank), R4R_DIST_BACKEND='gloo')
+                      LOCAL_RANK=str(rank), R4R_DIST_BACKEND=os.environ.get('R4R_TEST_BACKEND', 'gloo'),
+                      R4R_DP_SINGLE='1' if world == 1 else '')
     from helpers import Golden
     from test_gpu_models import build_model
     from reviews4rec_amd import dist as r4dist, main as M
@@ -352,6 +362,7 @@ def _narre_worker(rank, world, port, out_dir):
     model.train()
     dp = r4dist.DataParallel(model)
     dp.broadcast_parameters()
+    model.hyper_params['batch_size'] = 64                    # per-rank batch: every shard below fits it
     eng = M.make_engine(dict(hp, engine='auto', batch_size=64), model, dp=dp, rank=rank)
     assert type(eng) is NarreEngine and eng.dp is not None
     ses = []
@@ -391,7 +402,8 @@ def _idnet_worker(rank, world, port, case, out_dir):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, TESTS)
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
-                      LOCAL_RANK=str(rank), R4R_DIST_BACKEND='gloo')
+                      LOCAL_RANK=str(rank), R4R_DIST_BACKEND=os.environ.get('R4R_TEST_BACKEND', 'gloo'),
+                      R4R_DP_SINGLE='1' if world == 1 else '')
     from helpers import Golden
     from test_gpu_models import build_model
     from reviews4rec_amd import dist as r4dist, main as M
@@ -438,3 +450,60 @@ def test_dp2_native_idnet_step_follows_the_reference_trajectory(tmp_path, case):
     for k, v in g.params('w3').items():
         assert torch.equal(r0['w'][k], r1['w'][k]), k               # replicas stay bit-identical
         torch.testing.assert_close(r0['w'][k], v, rtol=1e-5, atol=5e-6, msg=lambda m: k + ': ' + m)
+
+
+# ---- RCCL itself, on the one GPU of the test box: a ONE-rank job (R4R_DP_SINGLE=1 keeps the data-parallel
+# path on at world size 1).  The collectives move nothing, but every call the N > 1 job makes -- process-group
+# init over torch's 'nccl' backend, broadcast, the flat all-reduce, all_gather of the compact rows, the MIN / MAX /
+# SUM reductions of the epoch counts, barrier -- goes through RCCL with the real tensors (device placement,
+# dtypes, contiguity: what gloo forgives and RCCL does not), and the trajectory must still be the reference's.
+RCCL_CASES = {
+    'deepconn-allreduce': (_engine_worker, ('deepconn_e20', 'allreduce'), 'e', 'deepconn_e20', 'se', 'w3'),
+    'deepconn-gather': (_engine_worker, ('deepconn_e20', 'gather'), 'e', 'deepconn_e20', 'se', 'w3'),
+    'deepconn-autotune': (_engine_worker, ('deepconn_e20', 'autotune'), 'e', 'deepconn_e20', 'se', 'w3'),
+    'mf_dot': (_mf_worker, ('mf_dot',), 'm', 'mf_dot', 'se', 'w3'),
+    'transnetpp': (_transnet_worker, ('transnetpp_e16',), 't', 'transnetpp_e16', 'tn_se', 'tn_w3'),
+    'deepconnpp': (_dcpp_worker, (), 'd', 'deepconnpp_e20', 'se', 'w3'),
+    'narre': (_narre_worker, (), 'n', 'narre_e16', 'se', 'w3'),
+    'neumf': (_idnet_worker, ('neumf_full',), 'i', 'neumf_full', 'se', 'w3'),
+}
+
+
+@pytest.mark.parametrize('which', sorted(RCCL_CASES))
+def test_rccl_one_rank_job_runs_every_data_parallel_path(tmp_path, monkeypatch, which):
+    sys.path.insert(0, TESTS)
+    from helpers import Golden
+    from test_oracle_golden import ill_conditioned
+    worker, extra, tag, case, se_key, w_key = RCCL_CASES[which]
+    monkeypatch.setenv('R4R_TEST_BACKEND', 'nccl')
+    port = _free_port()
+    args = (1, port) + extra[:1] + (str(tmp_path),) + extra[1:]
+    mp.spawn(worker, args=args, nprocs=1, join=True)
+    g = Golden(case)
+    r0 = torch.load(os.path.join(tmp_path, '%s0.pt' % tag))
+    for step in range(3):
+        torch.testing.assert_close(r0['se'][step], g.arr('%s%d' % (se_key, step)), rtol=1e-4, atol=1e-5)
+    loose = which == 'narre'
+    for k, v in g.params(w_key).items():
+        if not ill_conditioned(k):
+            torch.testing.assert_close(r0['w'][k], v, rtol=1e-4 if loose else 1e-5, atol=2e-5 if loose else 5e-6,
+                                       msg=lambda m: k + ': ' + m)
+
+
+def test_rccl_one_rank_bench_line(tmp_path):
+    """bench.py as the driver launches it for N > 1 (torch.distributed.run, backend 'nccl' = RCCL), with one rank:
+    the data-parallel step, the exchange autotune, the strong legs and the replica check all run over RCCL."""
+    import json
+    import subprocess
+    env = dict(os.environ, R4R_DP_SINGLE='1', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    env.pop('R4R_DIST_BACKEND', None)
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1', '--master-addr',
+           '127.0.0.1', '--master-port', str(_free_port()), os.path.join(ROOT, 'bench.py'), '--gpus', '1', '--steps', '10',
+           '--warmup', '3', '--no-cpu-baseline', '--strong-leg', '1024']
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    cfg = line['config']
+    assert cfg['dist_backend'] == 'nccl' and cfg['rccl_ranks'] == 1 and cfg['replicas_identical'] is True
+    assert cfg['dp_exchange'] in ('allreduce', 'gather') and set(cfg['dp_exchange_ms']) == {'allreduce', 'gather'}
+    assert line['value'] > 0 and line['strong']['global_batch'] == 1024
