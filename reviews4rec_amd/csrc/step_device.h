@@ -91,51 +91,6 @@ __device__ __forceinline__ void narre_sweep_block(const RowSweep &w, int bx) {
     if (cnt > NROW_CHUNK) cnt = NROW_CHUNK;
     const int64_t row0 = start / W;                         // one 64-bit division per workgroup
     const unsigned col0 = (unsigned)(start - row0 * W);
-    if ((cnt & 3) == 0 && (((uintptr_t)(bp + start) | (uintptr_t)(bm + start) | (uintptr_t)(bv + start)) & 15) == 0) {
-        // whole float4s (every chunk but a table's last): 16-byte accesses; the tags of the first and last
-        // row a float4 covers (W >= 4: it covers at most two), per element only when one of them was touched.
-        // (Worth 0.3 us on cfg4: what the sweep costs wherever it runs is its 31 MB through HBM, ~4 us.)
-        constexpr int PV = NROW_CHUNK / 4 / NROW_THREADS;   // float4s per thread
-        wg_f32x4 P4[PV], M4[PV], V4[PV];
-        int Tf[PV], Tl[PV], Tm[PV][2] = {};
-#pragma unroll
-        for (int u = 0; u < PV; ++u) {                      // all loads of the thread before any use
-            const unsigned i4 = threadIdx.x + (unsigned)u * NROW_THREADS;
-            const unsigned e = (i4 * 4 < (unsigned)cnt) ? i4 * 4 : 0;
-            P4[u] = *reinterpret_cast<const wg_f32x4 *>(bp + start + e);
-            M4[u] = *reinterpret_cast<const wg_f32x4 *>(bm + start + e);
-            V4[u] = *reinterpret_cast<const wg_f32x4 *>(bv + start + e);
-            Tf[u] = tag[row0 + (col0 + e) / W];
-            Tl[u] = tag[row0 + (col0 + e + 3) / W];
-            if (W == 1) { Tm[u][0] = tag[start + e + 1]; Tm[u][1] = tag[start + e + 2]; }   // (bias vectors: a tag per element)
-        }
-#pragma unroll
-        for (int u = 0; u < PV; ++u) {
-            const unsigned i4 = threadIdx.x + (unsigned)u * NROW_THREADS;
-            if (i4 * 4 >= (unsigned)cnt) continue;
-            const unsigned e = i4 * 4;
-            bool skip[4] = {false, false, false, false};
-            if (W == 1) {
-                skip[0] = Tf[u] == w.now; skip[1] = Tm[u][0] == w.now; skip[2] = Tm[u][1] == w.now; skip[3] = Tl[u] == w.now;
-            } else if (Tf[u] == w.now || Tl[u] == w.now || W < 4) {   // rare: a second look, per element
-#pragma unroll
-                for (int k = 0; k < 4; ++k) skip[k] = tag[row0 + (col0 + e + k) / W] == w.now;
-            }
-#pragma unroll
-            for (int k = 0; k < 4; ++k)
-                if (!skip[k]) adam_elem(P4[u][k], 0.f, M4[u][k], V4[u][k], w.s);
-            if (!(skip[0] | skip[1] | skip[2] | skip[3])) {
-                *reinterpret_cast<wg_f32x4 *>(bp + start + e) = P4[u];
-                *reinterpret_cast<wg_f32x4 *>(bm + start + e) = M4[u];
-                *reinterpret_cast<wg_f32x4 *>(bv + start + e) = V4[u];
-            } else {                                        // elements of a touched row are their entry wave's: not stored
-#pragma unroll
-                for (int k = 0; k < 4; ++k)
-                    if (!skip[k]) { bp[start + e + k] = P4[u][k]; bm[start + e + k] = M4[u][k]; bv[start + e + k] = V4[u][k]; }
-            }
-        }
-        return;
-    }
     constexpr int PER = NROW_CHUNK / NROW_THREADS;
     float P[PER], M[PER], V[PER];
     int T[PER];
