@@ -44,7 +44,7 @@ struct ProjArgs {
     const float *table;
     int64_t N, V;
     int T, E, F, nchunk, tiles, cap;
-    int ntower, balanced;          // balanced: the GEMM may use its 7-row-tile form (R4R_GEMM=tile pins the tile form)
+    int ntower, balanced;          // 1: the GEMM may use its 7-row-tile form; 0: tile form (R4R_GEMM=tile); 2: tile form, whole tiles only (R4R_GEMM=whole)
 };
 
 #ifdef R4R_TRACE
@@ -104,8 +104,12 @@ constexpr int WB_ROWS = 320;                              // B rows staged: 304 
 constexpr int GEMM_BUF = (PM + WB_ROWS) * PS;               // floats per LDS buffer
 constexpr int GEMM_LDS_BYTES = 2 * GEMM_BUF * 4;              // 86,016 B
 
-template <int NTILE, int NB>
-__device__ __forceinline__ void proj_gemm_body(const ProjArgs &a, float *lds, int tower, int row0) {
+// GMT = row tiles of 16 per wave.  2: the full tile -- wave w owns rows 32 (w & 3) .. of the 128 and the column
+// half (w >> 2); `colbase` is 0 and the workgroup stages all 320 B rows (NB = 3 | 2 of them per thread).  1: a
+// COLUMN PART of a tile (the last, partial round of the tile list, below) -- wave w owns rows 16 w ..; all eight
+// waves share the NTILE column tiles from `colbase` on, and only those B rows are staged (NB rounds of 128).
+template <int NTILE, int NB, int GMT = GM>
+__device__ __forceinline__ void proj_gemm_body(const ProjArgs &a, float *lds, int tower, int row0, int colbase = 0) {
     const ProjTower &tw = a.t[tower];
     const int count = tw.count[0];
     TRACE_STAMP(0)
@@ -121,7 +125,8 @@ __device__ __forceinline__ void proj_gemm_body(const ProjArgs &a, float *lds, in
     const int E = a.E, nchunk = a.nchunk;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lrow = lane & 15, q = lane >> 4;
-    const int half = wave >> 2, col0 = half * PNH_COLS;
+    const int col0 = GMT == GM ? (wave >> 2) * PNH_COLS : 0;   // first column inside the staged B rows
+    const int rowgrp = GMT == GM ? (wave & 3) : wave;
 
     // staging role: float4 column c4 of A row (tid >> 2) and of B rows (tid >> 2) + 128 k
     // (k < NB: waves 0..3 stage three, rows 0..319; waves 4..7 two).
@@ -131,7 +136,7 @@ __device__ __forceinline__ void proj_gemm_body(const ProjArgs &a, float *lds, in
     const float *__restrict__ conv_w = tw.conv_w;
 #pragma unroll
     for (int k = 0; k < NB; ++k) {
-        const int n = srow + 128 * k;                       // n = j * 100 + f
+        const int n = colbase + srow + 128 * k;             // n = j * 100 + f
         const int j = n / PF, f = n - j * PF;
         bptr[k] = conv_w + (n < PROW ? ((long)f * 3 + j) * E : 0);
     }
@@ -155,21 +160,21 @@ __device__ __forceinline__ void proj_gemm_body(const ProjArgs &a, float *lds, in
         for (int k = 0; k < NB; ++k)
             *reinterpret_cast<f32x4 *>(Bl + (srow + 128 * k) * PS + c4 * 4) = br[k] * keep;
     };
-    f32x4 acc[GM][NTILE];
+    f32x4 acc[GMT][NTILE];
 #pragma unroll
-    for (int mi = 0; mi < GM; ++mi)
+    for (int mi = 0; mi < GMT; ++mi)
 #pragma unroll
         for (int ni = 0; ni < NTILE; ++ni) acc[mi][ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const int aoffl = ((wave & 3) * 16 * GM + lrow) * PS + q * 4, boffl = (PM + col0 + lrow) * PS + q * 4;
-    auto read_ops = [&](const float *buf, f32x4 (&av)[GM], f32x4 (&b)[NTILE]) {
+    const int aoffl = (rowgrp * 16 * GMT + lrow) * PS + q * 4, boffl = (PM + col0 + lrow) * PS + q * 4;
+    auto read_ops = [&](const float *buf, f32x4 (&av)[GMT], f32x4 (&b)[NTILE]) {
 #pragma unroll
-        for (int mi = 0; mi < GM; ++mi) av[mi] = *reinterpret_cast<const f32x4 *>(buf + aoffl + mi * 16 * PS);
+        for (int mi = 0; mi < GMT; ++mi) av[mi] = *reinterpret_cast<const f32x4 *>(buf + aoffl + mi * 16 * PS);
 #pragma unroll
         for (int ni = 0; ni < NTILE; ++ni) b[ni] = *reinterpret_cast<const f32x4 *>(buf + boffl + ni * 16 * PS);
     };
-    auto mfma = [&](const f32x4 (&av)[GM], const f32x4 (&b)[NTILE], int kk) {
+    auto mfma = [&](const f32x4 (&av)[GMT], const f32x4 (&b)[NTILE], int kk) {
 #pragma unroll
-        for (int mi = 0; mi < GM; ++mi)
+        for (int mi = 0; mi < GMT; ++mi)
 #pragma unroll
             for (int ni = 0; ni < NTILE; ++ni)
                 acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mi][kk], b[ni][kk], acc[mi][ni], 0, 0, 0);
@@ -183,7 +188,7 @@ __device__ __forceinline__ void proj_gemm_body(const ProjArgs &a, float *lds, in
     // the reads, the stores and the loads as three bursts during which the pipe idles.
     // chunk c: operands `cur` are in registers; LDS buffer (c+1)&1 holds chunk c+1 once the
     // barrier is passed; the staging registers hold chunk c+2 (loaded a whole chunk ago).
-    auto step = [&](int c, const f32x4 (&cav)[GM], const f32x4 (&cb)[NTILE], f32x4 (&nav)[GM], f32x4 (&nb)[NTILE]) {
+    auto step = [&](int c, const f32x4 (&cav)[GMT], const f32x4 (&cb)[NTILE], f32x4 (&nav)[GMT], f32x4 (&nb)[NTILE]) {
         __syncthreads();                                    // chunk c+1 visible; buffer c&1 fully read
         write_lds(lds + (c & 1) * GEMM_BUF, c + 2);
         issue_loads(c + 3);
@@ -193,27 +198,30 @@ __device__ __forceinline__ void proj_gemm_body(const ProjArgs &a, float *lds, in
         mfma(cav, cb, 2);
         mfma(cav, cb, 3);
         // schedule: (1 LDS write, 3 MFMA) x NSTG | (1 load, 3 MFMA) x NSTG | (1 LDS read, 3 MFMA) x NREAD, rest
-        constexpr int NREAD = GM + NTILE, NSTG = 1 + NB, NM = 4 * GM * NTILE;
+        // (PER MFMAs behind every memory instruction: 3 for the full tile's 80 | 72 MFMAs per chunk, fewer for
+        // the column parts' 40 .. 16)
+        constexpr int NREAD = GMT + NTILE, NSTG = 1 + NB, NM = 4 * GMT * NTILE;
+        constexpr int PER = NM / (NREAD + 2 * NSTG) >= 3 ? 3 : (NM / (NREAD + 2 * NSTG) >= 1 ? NM / (NREAD + 2 * NSTG) : 1);
 #pragma unroll
         for (int i = 0; i < NSTG; ++i) {
             __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
             __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, PER, 0);
         }
 #pragma unroll
         for (int i = 0; i < NSTG; ++i) {
             __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
             __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, PER, 0);
         }
 #pragma unroll
         for (int i = 0; i < NREAD; ++i) {
             __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, PER, 0);
         }
-        __builtin_amdgcn_sched_group_barrier(0x008, NM - 3 * (NREAD + 2 * NSTG), 0);
+        if constexpr (NM > PER * (NREAD + 2 * NSTG)) __builtin_amdgcn_sched_group_barrier(0x008, NM - PER * (NREAD + 2 * NSTG), 0);
     };
-    f32x4 av0[GM], b0[NTILE], av1[GM], b1[NTILE];
+    f32x4 av0[GMT], b0[NTILE], av1[GMT], b1[NTILE];
     issue_loads(0);
     write_lds(lds, 0);
     issue_loads(1);
@@ -247,15 +255,15 @@ __device__ __forceinline__ void proj_gemm_body(const ProjArgs &a, float *lds, in
     float *slab = lds + wave * (16 * (PNH_COLS + 4));
     constexpr int NV = NTILE * 4;
 #pragma unroll
-    for (int mi = 0; mi < GM; ++mi) {
+    for (int mi = 0; mi < GMT; ++mi) {
 #pragma unroll
         for (int ni = 0; ni < NTILE; ++ni)
 #pragma unroll
             for (int r = 0; r < 4; ++r) slab[(q * 4 + r) * TS + ni * 16 + lrow] = acc[mi][ni][r];
         for (int i = lane; i < 16 * NV; i += 64) {
             const int rr = i / NV, cv = i - rr * NV;
-            const int row = row0 + (wave & 3) * 16 * GM + mi * 16 + rr;
-            const int col = col0 + cv * 4;
+            const int row = row0 + rowgrp * 16 * GMT + mi * 16 + rr;
+            const int col = colbase + col0 + cv * 4;
             if (row < count && col < PROW)
                 *reinterpret_cast<f32x4 *>(tw.ptab + (size_t)row * PROW + col) =
                     *reinterpret_cast<const f32x4 *>(slab + rr * TS + cv * 4);
@@ -520,7 +528,12 @@ __device__ __forceinline__ void proj_gemm7_body(const ProjArgs &a, float *lds, c
 __global__ __launch_bounds__(GEMM_THREADS) void proj_gemm_kernel(ProjArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float *lds = reinterpret_cast<float *>(smem);
-    if (a.balanced) {
+    int first[MAX_TOWERS + 1];
+    first[0] = 0;
+    for (int t = 0; t < a.ntower; ++t) first[t + 1] = first[t] + (a.t[t].count[0] + PM - 1) / PM;
+    // (a launch whose tiles fill at most half of the grid is faster in column parts -- below -- than in the
+    // balanced form, which keeps 112 rows per workgroup whatever the count)
+    if (a.balanced == 1 && first[a.ntower] * 2 > (int)gridDim.x) {
         Gemm7Plan p;
         if (gemm7_plan(a, (int)blockIdx.x, (int)gridDim.x, p)) {
             if (p.tower < 0) return;                         // uniform: this workgroup has no rows
@@ -537,16 +550,34 @@ __global__ __launch_bounds__(GEMM_THREADS) void proj_gemm_kernel(ProjArgs a) {
     }
     // tile form, persistent: the 128-row tiles of all towers form one list; workgroup w takes tiles
     // w, w + gridDim.x, ... (a grid of one workgroup per CU: nothing is launched only to exit)
-    int first[MAX_TOWERS + 1];
-    first[0] = 0;
-    for (int t = 0; t < a.ntower; ++t) first[t + 1] = first[t] + (a.t[t].count[0] + PM - 1) / PM;
-    for (int tile = blockIdx.x; tile < first[a.ntower]; tile += gridDim.x) {
+    // The LAST round of the list is usually partial -- 536 tiles on 256 workgroups are two full rounds and 24
+    // tiles, for which 232 workgroups used to wait a whole tile time.  When it fills at most half (a quarter) of
+    // the grid, each of its tiles is cut into 2 (4) COLUMN PARTS (10 + 9, or 5 + 5 + 5 + 4 column tiles) that as
+    // many workgroups compute side by side, every wave on its own 16 rows: same per-element summation order,
+    // same bits, and the round costs 0.55 (0.3) of a tile time.
+    const int total = first[a.ntower], G = (int)gridDim.x;
+    const int full = total / G * G, tail = total - full;
+    const int parts = a.balanced == 2 ? 1 : (tail * 4 <= G ? 4 : (tail * 2 <= G ? 2 : 1));   // (2: whole tiles only -- A/B runs, tests)
+    for (int tile = blockIdx.x; tile < (parts == 1 ? total : full); tile += gridDim.x) {
         int t = 0;
         while (tile >= first[t + 1]) ++t;
         const int row0 = (tile - first[t]) * PM;
         if (threadIdx.x >> 8) proj_gemm_body<PNT - PNH, 2>(a, lds, t, row0);   // waves 4..7: columns 160..303
         else proj_gemm_body<PNH, 3>(a, lds, t, row0);                          // waves 0..3: columns 0..159
         __syncthreads();                                    // the epilogue's LDS slabs are free again
+    }
+    if (parts > 1 && (int)blockIdx.x < tail * parts) {
+        const int tile = full + (int)blockIdx.x / parts, part = (int)blockIdx.x % parts;
+        int t = 0;
+        while (tile >= first[t + 1]) ++t;
+        const int row0 = (tile - first[t]) * PM;
+        if (parts == 2) {
+            if (part == 0) proj_gemm_body<PNH, 2, 1>(a, lds, t, row0, 0);
+            else proj_gemm_body<PNT - PNH, 2, 1>(a, lds, t, row0, PNH_COLS);
+        } else {
+            if (part < 3) proj_gemm_body<5, 1, 1>(a, lds, t, row0, part * 80);
+            else proj_gemm_body<4, 1, 1>(a, lds, t, row0, 240);
+        }
     }
 }
 
@@ -679,7 +710,7 @@ int proj_tiles(int T) { return (T + 2 + SEG - 1) / SEG; }
 int64_t proj_row_capacity(int64_t N, int T, int64_t V) { return (N * T < V) ? N * T : V; }
 size_t proj_ptab_floats(int64_t N, int T, int64_t V) { return (size_t)proj_row_capacity(N, T, V) * PROW; }
 
-static int g_gemm_balanced = -1;       // -1: from the environment (R4R_GEMM=tile pins the tile form) on first use
+static int g_gemm_balanced = -1;       // -1: from the environment (R4R_GEMM=tile | whole pin the tile form) on first use
 static int g_gemm_math = 0;            // 0: fp32 MFMA (the default and the headline); 1: fp16-split operands (project_f16.hip)
 static float g_table_maxabs = 0.f;     // max |table|, given with mode 1 (the table is frozen: the host computes it once)
 static float g_weight_maxabs = 0.f;    // max |conv weights|, likewise (re-read by the host every few steps)
@@ -698,7 +729,7 @@ static ProjArgs make_args(const float *table, int64_t V, const ProjTower *tw, in
     a.ntower = ntower;
     if (g_gemm_balanced < 0) {
         const char *e = getenv("R4R_GEMM");
-        g_gemm_balanced = (e && e[0] == 't') ? 0 : 1;
+        g_gemm_balanced = (e && e[0] == 't') ? 0 : ((e && e[0] == 'w') ? 2 : 1);
     }
     a.balanced = g_gemm_balanced;
     return a;

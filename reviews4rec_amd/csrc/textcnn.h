@@ -54,7 +54,7 @@ int textcnn_proj_compute_launch(const float *table, int64_t V, const ProjTower *
                                 int64_t N, int T, int E, int F, hipStream_t st);
 void proj_gemm_set_math(int mode, float table_maxabs, float weight_maxabs);
 int proj_gemm_math_mode();   // 0: fp32 MFMA (default), 1: fp16-split operands, fp32 accumulate
-void proj_gemm_set_form(int balanced);          // 1: balanced 7-row-tile form where it applies (default), 0: tile form, -1: env
+void proj_gemm_set_form(int balanced);          // 1: balanced 7-row-tile form where it applies (default), 0: tile form, 2: tile form with whole tiles only, -1: env
 // R4R_CONV_AUTO / _DIRECT / _PROJECT (include/r4r.h) -> the algorithm to run; honours R4R_CONV_ALGO
 int textcnn_pick_algo(int requested, int64_t N, int T, int E, int F);
 

@@ -150,7 +150,7 @@ def test_integration_stub_matches_the_header():
 
 
 def test_conv_pick_reproduces_the_measured_decisions():
-    """r4r_conv_pick's cost model against the twelve (configuration, data) points measured on MI355X
+    """r4r_conv_pick's cost model against the (configuration, data) points measured on MI355X
     (profiles/r02_conv_rule.txt): distinct rows -> the algorithm that was faster."""
     from reviews4rec_amd import _lib
     lib = _lib.lib()
@@ -159,6 +159,8 @@ def test_conv_pick_reproduces_the_measured_decisions():
         (300, 1000, 256, 50002, [(29547, PROJECT), (45464, PROJECT), (71421, PROJECT), (92264, PROJECT)]),      # cfg3
         (64, 100, 2560, 50002, [(19741, PROJECT), (31970, PROJECT), (49182, PROJECT), (75188, PROJECT)]),       # cfg4
         (64, 1000, 384, 1000000, [(76899, PROJECT), (137449, DIRECT), (177702, DIRECT), (360391, DIRECT)]),     # cfg5
+        (300, 1000, 16, 50002, [(3757, PROJECT)]), (300, 1000, 32, 50002, [(6402, PROJECT)]),                    # cfg3 at B = 8, 16:
+        (300, 1000, 64, 50002, [(11055, PROJECT)]),                                                              # ... 32 (column parts)
     ]
     for E, T, docs, V, cases in points:
         for rows, want in cases:

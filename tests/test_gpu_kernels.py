@@ -392,13 +392,16 @@ def test_fused_adam_unaligned_views_and_untouched_rows():
     assert (p.detach().cpu()[10:] != before[10:]).all()
 
 
-@pytest.mark.parametrize('V', [336, 340, 1000, 3000, 28672, 29500, 30100, 41000])
+@pytest.mark.parametrize('V', [336, 340, 1000, 3000, 28672, 29500, 30100, 36000, 41000, 70000])
 def test_projection_gemm_balanced_form_is_bit_identical_to_the_tile_form(V):
     """The projection GEMM has two decompositions (csrc/project.hip): 128-row tiles, and the balanced form --
     7 private row tiles per workgroup + a row tile shared column-wise by >= 3 workgroups -- chosen on the
     device from the distinct-token count.  Counts on both sides of every edge of that plan (exactly 7 row
     tiles per workgroup, a shared tile split 3 / 4 / 5 ways, the 256-workgroup cap, counts where the plan
-    does not apply): same bits either way, and equal to ATen."""
+    does not apply): same bits either way, and equal to ATen.  The tile form cuts the tiles of its last, partial
+    round into column parts when that round fills at most half of the grid (36,000 rows: 26 tiles in 4 parts;
+    41,000: 65 tiles in 2; 70,000: two full rounds + 35 tiles in 4): r4r_gemm_form(2) -- whole tiles only -- must
+    give the same bits too."""
     from reviews4rec_amd import _lib
     ops = _ops()
     E, T = 128, 100
@@ -416,9 +419,13 @@ def test_projection_gemm_balanced_form_is_bit_identical_to_the_tile_form(V):
         p0, a0 = p0.clone(), a0.clone()
         lib.r4r_gemm_form(1)
         p1, a1 = ops.textcnn_fwd_raw(*args)
+        p1, a1 = p1.clone(), a1.clone()
+        lib.r4r_gemm_form(2)
+        p2, a2 = ops.textcnn_fwd_raw(*args)
     finally:
         lib.r4r_gemm_form(-1)
     assert torch.equal(p0, p1) and torch.equal(a0, a1)
+    assert torch.equal(p0, p2) and torch.equal(a0, a2)
     if V <= 3000:
         ref_pooled, ref_arg, y = conv_pool_reference(idx, table, w, b)
         torch.testing.assert_close(p1.cpu(), ref_pooled, rtol=1e-5, atol=1e-6)
