@@ -1,4 +1,4 @@
-import os, sys, time, torch, ctypes
+import os, sys, torch, ctypes
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from reviews4rec_amd import ops, synthetic, _lib
 B = int(os.environ.get('B', 128)); T = 1000; E = int(os.environ.get('E', 300)); V = 50002

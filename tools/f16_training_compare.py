@@ -11,7 +11,6 @@ fp32 reordering does.  DESIGN.md 4.1d quotes the output (profiles/r02k_f16_train
 import os
 import sys
 
-import numpy as np
 import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -11,7 +11,7 @@ sys.path.insert(0, ROOT)
 os.environ['R4R_LIBRARY'] = os.path.join(ROOT, 'reviews4rec_amd/csrc', os.environ.get('TRACE_SO', 'libr4r_hip_trace.so'))
 import torch
 import reviews4rec_amd
-from reviews4rec_amd import synthetic, _lib
+from reviews4rec_amd import synthetic
 from reviews4rec_amd.engine import DeepCoNNEngine
 from reviews4rec_amd.utils import xavier_init
 
