@@ -181,6 +181,42 @@ def test_deepconn_full_size_batch_against_oracle_and_properties():
     assert float(((out[rows] - ref) ** 2).mean()) < 1e-4
 
 
+@pytest.mark.parametrize('mt', ['NARRE', 'transnet++'])
+def test_review_models_at_baseline_shapes_against_oracle_and_properties(mt):
+    """BASELINE configs 4 and 5 at their batch shapes -- NARRE: B=128 x 10 reviews x 100 words per side, E=64,
+    Kindle's 68,223 users / 61,934 items; TransNet++: B=128, three 1,000-word documents per rating, E=64, a
+    100,000-word vocabulary -- through the fused native engines' eval forward.  The oracle checks a sample of rows
+    (seconds on CPU); the whole batch through size-independent properties: row-permutation equivariance (bit-exact:
+    no tile, segment or workgroup spans ratings in a way that depends on their order) and duplicated ratings."""
+    import reviews4rec_amd
+    from reviews4rec_amd import main as M
+    if mt == 'NARRE':
+        B, T, E, V, U, I, R, W = 128, 100, 64, 50002, 68223, 61934, 10, 100
+    else:
+        B, T, E, V, U, I, R, W = 128, 1000, 64, 100000, 50000, 20000, None, None
+    hp = dict(model_type=mt, latent_size=10, word_embed_size=E, input_length=T, dropout=0.0, total_users=U,
+              total_items=I, lr=0.002, weight_decay=1e-6, narre_num_reviews=10, narre_num_words=100, batch_size=B)
+    P = oracle.init_params(hp, vocab_size=V, seed=21)
+    table = P['target.word2vec.weight' if mt.startswith('transnet') else 'word2vec.weight']
+    model = reviews4rec_amd.get_model_class(mt)(dict(hp, word_vectors=table.numpy()))
+    model.load_state_dict(P)
+    model = model.to(DEV).eval()
+    eng = M.make_engine(dict(hp, engine='native'), model)
+    data, y = synthetic_review_batch(B, T, V, U, I, seed=31, R=R, W=W)
+    for slot in range(7):                                   # rating 5 := rating 4
+        data[slot][5] = data[slot][4]
+    out = eng.predict([d.to(DEV) for d in data], None)[0].cpu().clone()
+    perm = torch.randperm(B, generator=torch.Generator().manual_seed(1))
+    out_p = eng.predict([d[perm].to(DEV) for d in data], None)[0].cpu().clone()
+    assert torch.equal(out_p, out[perm])
+    assert out[4] == out[5]
+    rows = [0, 4, 77, 127]
+    ref = oracle.model_forward(P, [d[rows] for d in data], hp, train=False)
+    ref = ref[0] if isinstance(ref, (list, tuple)) else ref
+    torch.testing.assert_close(out[rows], ref, rtol=1e-4, atol=1e-4)
+    assert float(((out[rows] - ref) ** 2).mean()) < 1e-4    # SURVEY 8d's parity bound
+
+
 def test_deepconn_one_step_at_baseline_shape_against_oracle():
     """One full training step (B=16 rows of the config-3 shape) vs the CPU oracle."""
     import reviews4rec_amd
