@@ -185,6 +185,35 @@ def test_projection_and_direct_conv_agree_on_argmax_and_pooled():
         torch.testing.assert_close(outs[1][1][k], outs[2][1][k], rtol=1e-4, atol=1e-7, msg=lambda mm: k + ': ' + mm)
 
 
+def test_full_size_batch_gradient_is_the_sum_of_its_shards_gradients():
+    """BASELINE config 3 shape (B=128, T=1000, E=300): the fused step's gradient of the whole batch equals the sum of
+    the gradients of its two halves computed with the same 1 / B_global loss scale -- the property data parallelism
+    rests on, at full size (the small-shape DP tests pin it against the reference's trajectories)."""
+    import reviews4rec_amd
+    from reviews4rec_amd import synthetic
+    from reviews4rec_amd.engine import DeepCoNNEngine
+    from reviews4rec_amd.utils import xavier_init
+    hp = synthetic.hyper_params_for('cfg3_deepconn_electronics_e300', dropout=0.0, vocab=20000)
+    hp['word_vectors'] = synthetic.word_table(hp['vocab'], hp['word_embed_size'])
+    gen = synthetic.Generator(hp, seed=9)
+    data, y = gen.batch(128)
+    data = [torch.from_numpy(d).to(DEV) for d in data]
+    y = torch.from_numpy(y).to(DEV)
+    torch.manual_seed(0)
+    m = reviews4rec_amd.get_model_class('deepconn')(hp)
+    xavier_init(m)
+    eng = DeepCoNNEngine(m.to(DEV).train(), conv_algo=2)
+
+    def grad_of(lo, hi):
+        d = [t[lo:hi].contiguous() for t in data]
+        eng._launch(d, y[lo:hi].contiguous(), grad=True, training=True, inv_denom=1.0 / 128)   # gradients only: no Adam
+        return eng.flat_g.clone()
+    whole = grad_of(0, 128)
+    parts = grad_of(0, 64) + grad_of(64, 128)
+    assert float(whole.abs().max()) > 0
+    torch.testing.assert_close(parts, whole, rtol=2e-4, atol=2e-7 * float(whole.abs().max()) + 1e-9)
+
+
 @pytest.mark.parametrize('shape', [(64, 400, 128, 3000), (32, 200, 32, 300000)], ids=['v3k', 'v300k'])
 @pytest.mark.parametrize('how', ['fused', 'side_stream'])
 def test_token_prefetch_is_bit_identical_and_survives_mispredicted_batches(how, shape):
