@@ -888,14 +888,16 @@ def test_transnet_engine_through_the_host_loop(case):
         torch.testing.assert_close(sd[k].cpu(), v, rtol=1e-5, atol=5e-6, msg=lambda m: k + ': ' + m)
 
 
+@pytest.mark.parametrize('T,L', [(200, 24), (1100, 10)], ids=['wide', 'tall'])
 @pytest.mark.parametrize('mt', ['transnet', 'transnet++'])
-def test_transnet_engine_wide_latent_and_larger_shapes(mt):
+def test_transnet_engine_wide_latent_and_larger_shapes(mt, T, L):
     """latent_size 24 (> 16: the <= 32 head instantiation), E = 64, T = 200 (project-then-gather by
-    choice), duplicated ids, against the CPU oracle's literal three-optimiser step: two steps."""
+    choice), duplicated ids -- and tall documents (T = 1100: nine 128-position segments, the head's pool
+    finish takes a second round of tiles) -- against the CPU oracle's literal three-optimiser step: two steps."""
     import reviews4rec_amd
     from reviews4rec_amd.engine import TransNetEngine
     from test_oracle_golden import ill_conditioned
-    B, T, E, V, U, I, L = 12, 200, 64, 400, 30, 20, 24
+    B, E, V, U, I = 12, 64, 400, 30, 20
     hp = dict(model_type=mt, latent_size=L, word_embed_size=E, input_length=T, dropout=0.0, total_users=U, total_items=I,
               lr=0.002, weight_decay=1e-6)
     P = oracle.init_params(hp, vocab_size=V, seed=4)
