@@ -1071,7 +1071,7 @@ def test_narre_rows_apply_thousands_of_gathered_entries():
     from reviews4rec_amd import _lib
     from reviews4rec_amd._lib import ptr
     lib = _lib.lib()
-    U, I, L, n = 3000, 2000, 10, 6000
+    U, I, L, n = 3000, 2000, 10, 6007                       # (not a multiple of the 16 entries an entry workgroup owns)
     B, R, T, E, V = 8, 4, 30, 16, 100                       # (only sizes the workspace that holds the row tags)
     gen = torch.Generator().manual_seed(23)
     tabs = [torch.randn(U, L, generator=gen), torch.randn(I, L, generator=gen), torch.randn(U, generator=gen),
