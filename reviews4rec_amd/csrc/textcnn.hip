@@ -475,8 +475,9 @@ extern "C" int r4r_conv_algo(int requested, int64_t N, int T, int E, int F) {
 // fitted to MI355X measurements at E = 64 and 300 (DESIGN.md 4.1c lists them, profiles/r02_conv_rule.txt):
 //   direct      0.12 + 0.0051 E ns per position, positions rounded up to 128 per document and to launches'
 //               waves of 65,536 positions (B = 8 .. 32 at T = 1000 all take the 110 us of one wave at E = 300)
-//   GEMM        (11 + 0.14 E) us per round of 256 row tiles of 128 rows; the last, partial round 0.42 / 0.66 of
-//               that when it is cut into 4 / 2 column parts (at most a quarter / half of the grid: project.hip)
+//   GEMM        (11 + 0.14 E) us per round of 256 row tiles of 128 rows; the last, partial round (9.3 + 0.044 E) /
+//               (13.8 + 0.071 E) us when it is cut into 4 / 2 column parts (at most a quarter / half of the grid:
+//               project.hip; fitted at E = 64 and 300: 12 / 18 and 22.5 / 35 us)
 //   gather      0.085 ns + 0.0006 ns per MB of projected rows (1200 B each), per position
 //   tokens      4 us + 0.027 us per 1000 words of vocabulary
 extern "C" int r4r_conv_pick(int E, int T, int64_t docs, int64_t rows, int64_t V) {
@@ -485,8 +486,9 @@ extern "C" int r4r_conv_pick(int E, int T, int64_t docs, int64_t rows, int64_t V
     const double padded = (double)docs * (double)(((int64_t)P + 127) / 128 * 128);
     const double t_direct = ceil(padded / 65536.0) * 65536.0 * (0.12 + 0.0051 * E) * 1e-3;   // us
     const int64_t tiles = (rows + 127) / 128 + 1, tail = tiles % 256;
-    const double last = tail == 0 ? 0.0 : (tail * 4 <= 256 ? 0.42 : (tail * 2 <= 256 ? 0.66 : 1.0));
-    const double t_gemm = ((double)(tiles / 256) + last) * (11.0 + 0.14 * E);
+    const double round = 11.0 + 0.14 * E;
+    const double last = tail == 0 ? 0.0 : (tail * 4 <= 256 ? 9.3 + 0.044 * E : (tail * 2 <= 256 ? 13.8 + 0.071 * E : round));
+    const double t_gemm = (double)(tiles / 256) * round + last;
     const double t_gather = (double)docs * P * (0.085 + 0.0006 * ((double)rows * 1200.0 / 1e6)) * 1e-3;
     const double t_tokens = 4.0 + 0.027 * ((double)V / 1000.0);
     return (t_gemm + t_gather + t_tokens < t_direct) ? R4R_CONV_PROJECT : R4R_CONV_DIRECT;
