@@ -7,11 +7,14 @@ and importing this module has no filesystem side effects -- directories are
 created by ``finalize()``.
 
 Namespaced extras understood by this package (all default to reference behaviour):
-  engine         'auto' (default: fused native step where one exists -- DeepCoNN 'deepconn' and
-                 'deepconn++', NARRE, TransNet(++), MF_dot, bias_only -- else the op-by-op step captured into one hipGraph) | 'native' (native
-                 or plain eager) | 'graph' | 'module' (op-by-op autograd, eager)
-  word_vectors   in-memory V x E table instead of data_dir/word2vec.pkl (synthetic runs)
-  seed           dropout Philox seed
+  engine           'auto' (default: the fused native step -- every model family has one -- and, where a configuration
+                   exceeds one of its limits, the op-by-op step captured into one hipGraph, with a warning that says
+                   why) | 'native' (native or an error) | 'graph' | 'module' (op-by-op autograd, eager)
+  word_vectors     in-memory V x E table instead of data_dir/word2vec.pkl (synthetic runs)
+  seed             dropout Philox seed
+  eval_batch_size  ratings per launch of a validation pass scored by a native engine (default 8 x batch_size; 4 x
+                   batch_size rows for HR@1): same scores, fewer launches (eval.py)
+  checkpoint_path  epoch-level resume file of main.train_complete (absent upstream)
 """
 import os
 
