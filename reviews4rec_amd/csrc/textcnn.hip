@@ -478,7 +478,7 @@ extern "C" int r4r_conv_algo(int requested, int64_t N, int T, int E, int F) {
 //   GEMM        (11 + 0.14 E) us per round of 256 row tiles of 128 rows; the last, partial round (9.3 + 0.044 E) /
 //               (13.8 + 0.071 E) us when it is cut into 4 / 2 column parts (at most a quarter / half of the grid:
 //               project.hip; fitted at E = 64 and 300: 12 / 18 and 22.5 / 35 us)
-//   gather      0.085 ns + 0.0006 ns per MB of projected rows (1200 B each), per position
+//   gather      0.085 ns + 0.0006 ns per MB of projected rows (1200 B each), per position; at least 10 us
 //   tokens      4 us + 0.027 us per 1000 words of vocabulary
 extern "C" int r4r_conv_pick(int E, int T, int64_t docs, int64_t rows, int64_t V) {
     if (E <= 0 || T <= 0 || docs <= 0 || rows <= 0) return R4R_CONV_PROJECT;
@@ -489,7 +489,8 @@ extern "C" int r4r_conv_pick(int E, int T, int64_t docs, int64_t rows, int64_t V
     const double round = 11.0 + 0.14 * E;
     const double last = tail == 0 ? 0.0 : (tail * 4 <= 256 ? 9.3 + 0.044 * E : (tail * 2 <= 256 ? 13.8 + 0.071 * E : round));
     const double t_gemm = (double)(tiles / 256) * round + last;
-    const double t_gather = (double)docs * P * (0.085 + 0.0006 * ((double)rows * 1200.0 / 1e6)) * 1e-3;
+    double t_gather = (double)docs * P * (0.085 + 0.0006 * ((double)rows * 1200.0 / 1e6)) * 1e-3;
+    if (t_gather < 10.0) t_gather = 10.0;                                                  // a launch's latency floor
     const double t_tokens = 4.0 + 0.027 * ((double)V / 1000.0);
     return (t_gemm + t_gather + t_tokens < t_direct) ? R4R_CONV_PROJECT : R4R_CONV_DIRECT;
 }

@@ -57,11 +57,21 @@ class _ConvRule:
     pure function of the probed batch.  Both algorithms compute the same function (parity-tested against
     each other and the reference), so a switch only changes fp32 summation order."""
     PROBE_AT, PROBE_EVERY = 4, 1024
+    SMALL_LAUNCH_MAX_V = 262144       # vocabulary up to which small training launches try the projection
 
     def _rule_reset(self):
         self._rule_n = 0                 # training steps the rule has seen
         self._rule_choice = None         # None until the first probe
         self.conv_rows = None            # distinct rows (all towers) of the last probe
+
+    def _rule_state(self):
+        """What a checkpoint must carry for a resumed run to pick the algorithm its uninterrupted twin runs (the
+        two sum in different orders: without it a resume is right to rounding, not to the bit)."""
+        return {'n': self._rule_n, 'choice': self._rule_choice}
+
+    def _rule_load(self, st):
+        if st:
+            self._rule_n, self._rule_choice = int(st['n']), (None if st['choice'] is None else int(st['choice']))
 
     def _rule_request(self, docs_per_tower, T, training):
         """-> (algorithm to request from the C step, the one that will actually run, probe this step?)"""
@@ -72,7 +82,14 @@ class _ConvRule:
                 apply_gemm_math(self.table, self._conv_weights())       # (several engines in one process: re-own)
                 _MATH_OWNER[0] = self
         req, probe = self.conv_algo, False
-        if req == 0 and lib.r4r_conv_algo(0, docs_per_tower, T, self.E, 100) == 2:
+        static = lib.r4r_conv_algo(0, docs_per_tower, T, self.E, 100) if req == 0 else req
+        # Training launches the static rule sends to the direct conv (E < 128, under 65,536 positions) start on
+        # the projection as well when the vocabulary is small enough for its compaction to be cheap: since the
+        # projection GEMM cuts a partial round into column parts they are faster there too (E = 64, B = 8 .. 64:
+        # 0.040 .. 0.059 ms against 0.050 .. 0.082), and the probe below lets the measured rule confirm or revert.
+        small = (req == 0 and static != 2 and bool(training) and self.V <= self.SMALL_LAUNCH_MAX_V
+                 and lib.r4r_conv_algo(2, docs_per_tower, T, self.E, 100) == 2)       # (== 2: no R4R_CONV_ALGO pin)
+        if req == 0 and (static == 2 or small):
             n = self._rule_n
             probe = bool(training) and n >= self.PROBE_AT and (n - self.PROBE_AT) % self.PROBE_EVERY == 0
             req = 2 if (probe or self._rule_choice is None) else self._rule_choice
@@ -376,12 +393,13 @@ class DeepCoNNEngine(_ConvRule):
         state_dict): Adam moments and step count, the dropout stream position."""
         return {'exp_avg': self.flat_m.clone(), 'exp_avg_sq': self.flat_v.clone(), 'step': self.step_count,
                 'dropout_offset': self.offset, 'lr': self.lr, 'weight_decay': self.wd, 'betas': self.betas,
-                'eps': self.eps}
+                'eps': self.eps, 'conv_rule': self._rule_state()}
 
     def load_state_dict(self, sd):
         if sd['exp_avg'].numel() != self.total:
             raise ValueError('DeepCoNNEngine.load_state_dict: %d moment elements for a %d-element layout'
                              % (sd['exp_avg'].numel(), self.total))
+        self._rule_load(sd.get('conv_rule'))
         self.flat_m.copy_(sd['exp_avg'].to(self.dev))
         self.flat_v.copy_(sd['exp_avg_sq'].to(self.dev))
         self.step_count = int(sd['step'])
@@ -930,7 +948,7 @@ class NarreEngine(_ConvRule):
         m, v = self.moments()
         return {'exp_avg': {k: t.clone() for k, t in m.items()}, 'exp_avg_sq': {k: t.clone() for k, t in v.items()},
                 'step': self.step_count, 'dropout_offset': self.offset, 'lr': self.lr, 'weight_decay': self.wd,
-                'betas': self.betas, 'eps': self.eps}
+                'betas': self.betas, 'eps': self.eps, 'conv_rule': self._rule_state()}
 
     def load_state_dict(self, sd):
         m, v = self.moments()
@@ -940,6 +958,7 @@ class NarreEngine(_ConvRule):
         self.step_count, self.offset = int(sd['step']), int(sd['dropout_offset'])
         self.lr, self.wd = float(sd['lr']), float(sd['weight_decay'])
         self.betas, self.eps = tuple(sd['betas']), float(sd['eps'])
+        self._rule_load(sd.get('conv_rule'))
         for ws in self.__dict__.get('_ws_cache', {}).values():
             ws.zero_()
         self._prepared = None
