@@ -48,6 +48,7 @@ struct DcppHead {
     uint64_t seed, offset;
 };
 
+BWD_TRACE_DEFINE(r4r_debug_dcpp_bwd_trace)
 // One workgroup of 256 threads per rating (the work is ~2000-element loops: FC gradients, d pooled).
 template <int ML>
 __global__ __launch_bounds__(256) void dcpp_head_kernel(DcppHead a) {
@@ -403,8 +404,9 @@ extern "C" int r4r_deepconnpp_step(const float *table, int64_t V, const int64_t 
         nx = make_token_args(V, nt, 2, B, T);
     }
     const int packed = 3 * E / 4 <= 64;
-    narre_backward_kernel<0><<<dim3(packed ? (NF + 3) / 4 : NF, wa.nsplit, prefetch ? 4 : 3), WG_THREADS, 0, st>>>(
-        wa, cs, cs_blocks, nx, packed, RowSweep{}, 0, 2);
+    const int gx = packed ? (NF + 3) / 4 : NF;
+    narre_backward_kernel<0><<<dim3(gx, wa.nsplit, 2 + backward_cs_slices(cs_blocks, gx * wa.nsplit) + (prefetch ? 1 : 0)),
+                               WG_THREADS, 0, st>>>(wa, cs, cs_blocks, nx, packed, RowSweep{}, 0, 2);
 
     const int red_blocks = (NF * 3 * E + NF + NRED_THREADS - 1) / NRED_THREADS;
     const int comp_blocks = prefetch ? (int)cdiv((V + 3) / 4, NRED_THREADS * compact_groups(V)) : 0;

@@ -770,7 +770,8 @@ extern "C" int r4r_narre_step(const float *table, int64_t V,
     rs.s = adam_make_scalars(lr, beta1, beta2, eps, weight_decay, adam_step, nullptr);
 
     const int packed = 3 * E / 4 <= 64;                     // narrow windows: one wave per filter
-    const dim3 bgrid(packed ? (NF + 3) / 4 : NF, wa.nsplit, prefetch ? 5 : 4);
+    const int gx = packed ? (NF + 3) / 4 : NF;              // slices: ID tables, two towers, the column sums, the marks
+    const dim3 bgrid(gx, wa.nsplit, 3 + backward_cs_slices(cs_blocks, gx * wa.nsplit) + (prefetch ? 1 : 0));
     if (!apply)                                             // gradients only: no ID-table role in this launch
         narre_backward_kernel<0><<<dim3(bgrid.x, bgrid.y, bgrid.z - 1), WG_THREADS, 0, st>>>(wa, cs, cs_blocks, nx, packed,
                                                                                              RowSweep{}, 0, 2);

@@ -260,6 +260,11 @@ __device__ __forceinline__ void narre_rows_block(const RowSweep &w, int bx, int 
 // ML: 0 = no ID-table role (DeepCoNN++), else the rows role's template argument.  z-slices: the ID
 // tables (ML > 0), the `ntower` towers' weight gradients, the head-parameter column sums, the next
 // batch's token marks (if announced).
+// z-slices the head-parameter column sums take: one block per workgroup
+__host__ __device__ inline int backward_cs_slices(int cs_blocks, int wgs_per_slice) {
+    return (cs_blocks + wgs_per_slice - 1) / wgs_per_slice;
+}
+
 template <int ML>
 __global__ __launch_bounds__(WG_THREADS, ML > 16 ? 2 : 4) void narre_backward_kernel(WgradArgs w, ColSum c, int cs_blocks, TokenArgs nx,
                                                                     int packed, RowSweep rows, int row_blocks, int ntower) {
@@ -282,11 +287,11 @@ __global__ __launch_bounds__(WG_THREADS, ML > 16 ? 2 : 4) void narre_backward_ke
     } else if (z < ntower) {
         if (packed) wgrad_block_packed(w, blockIdx.x, blockIdx.y, z);   // grid.x = ceil(F / 4)
         else wgrad_block(w, blockIdx.x, blockIdx.y, z);
-    } else if (z == ntower) {
-        for (int blk = blk0; blk < cs_blocks; blk += nblk) {
-            colsum_block(c, blk);
-            __syncthreads();
-        }
+    } else if (z < ntower + backward_cs_slices(cs_blocks, nblk)) {
+        // (one block per workgroup, over as many slices as that takes: TransNet's 220 blocks on a 200-workgroup
+        // slice made 20 workgroups take two in a row -- the launch's tail, 10.9 us instead of 5.6)
+        const int blk = (z - ntower) * nblk + blk0;
+        if (blk < cs_blocks) colsum_block(c, blk);
     } else {
         token_mark_block(nx, blk0, nblk, WG_THREADS);
     }

@@ -66,6 +66,7 @@ struct TnHead {
 };
 
 HEAD_TRACE_DEFINE(r4r_debug_tn_head_trace)
+BWD_TRACE_DEFINE(r4r_debug_tn_bwd_trace)
 // One workgroup of 256 threads per rating.
 template <int ML>
 __global__ __launch_bounds__(256) void tn_head_kernel(TnHead a) {
@@ -567,8 +568,9 @@ extern "C" int r4r_transnet_step(const float *table, int64_t V,
         nx = make_token_args(V, nt, 3, B, T);
     }
     const int packed = 3 * E / 4 <= 64;
-    narre_backward_kernel<0><<<dim3(packed ? (NF + 3) / 4 : NF, wa.nsplit, prefetch ? 5 : 4), WG_THREADS, 0, st>>>(
-        wa, cs, cs_blocks, nx, packed, RowSweep{}, 0, 3);
+    const int gx = packed ? (NF + 3) / 4 : NF;
+    narre_backward_kernel<0><<<dim3(gx, wa.nsplit, 3 + backward_cs_slices(cs_blocks, gx * wa.nsplit) + (prefetch ? 1 : 0)),
+                               WG_THREADS, 0, st>>>(wa, cs, cs_blocks, nx, packed, RowSweep{}, 0, 3);
 
     const int red_blocks = (NF * 3 * E + NF + NRED_THREADS - 1) / NRED_THREADS;
     const int comp_blocks = prefetch ? (int)cdiv((V + 3) / 4, NRED_THREADS * compact_groups(V)) : 0;

@@ -34,8 +34,14 @@ setter = {'NARRE': lib.r4r_debug_narre_head_trace, 'deepconn': lib.r4r_debug_dc_
 setter.argtypes = [ctypes.c_void_p]
 backward = '--backward' in sys.argv
 if backward:
-    setter = lib.r4r_debug_dc_bwd_trace if hp['model_type'] == 'deepconn' else lib.r4r_debug_narre_bwd_trace
-    setter.argtypes = [ctypes.c_void_p]
+    # (narre_backward_kernel<0> is instantiated by the NARRE, DeepCoNN++ AND TransNet translation units; which copy a
+    # launch runs is the linker's choice, and each reads its own unit's trace pointer: set both)
+    names = ['r4r_debug_dc_bwd_trace'] if hp['model_type'] == 'deepconn' else [
+        'r4r_debug_narre_bwd_trace', 'r4r_debug_tn_bwd_trace', 'r4r_debug_dcpp_bwd_trace']
+    fns = [getattr(lib, n) for n in names]
+    for f in fns:
+        f.argtypes = [ctypes.c_void_p]
+    setter = lambda p: max(f(p) for f in fns)
 trace = torch.zeros(max(B * 32, 65536 * 4), dtype=torch.int64, device='cuda')
 for i in range(20):
     eng.train_step(*pool[i % 4])
