@@ -33,18 +33,27 @@ __device__ __forceinline__ void colsum_block(const ColSum &c, int blk) {
     __shared__ float red[CS_ROWS][CS_COLS];
     const int ox = threadIdx.x & (CS_COLS - 1), rg = threadIdx.x / CS_COLS;
     const int col = blk * CS_COLS + ox;                     // column nhp = the SE accumulator
+    // (the running sums are read now, not after the reduction: the launch's last block was a round trip longer
+    // than every other one -- its tail)
+    const bool acc_col = rg == 0 && c.sse_accum && col >= c.nhp && col <= c.nhp + (c.aux ? 2 : 0);
+    const float prev = acc_col ? c.sse_accum[col - c.nhp] : 0.f;
+    // ONE loop for the three kinds of column (a matrix column, the SE vector, an aux column): as three loops the
+    // last block's waves ran them one after the other -- 8.3 us where every other block takes 4.6
+    const float *src = nullptr;
+    size_t stride = 0;
+    if (col < c.nhp) { src = c.part + col; stride = (size_t)c.nhp; }
+    else if (col == c.nhp) { src = c.se; stride = 1; }
+    else if (c.aux && col <= c.nhp + 2) { src = c.aux + (col - c.nhp); stride = 3; }
     float s = 0.f;
-    if (col < c.nhp) for (int64_t b = rg; b < c.B; b += CS_ROWS) s += c.part[(size_t)b * c.nhp + col];
-    else if (col == c.nhp) for (int64_t b = rg; b < c.B; b += CS_ROWS) s += c.se[b];
-    else if (c.aux && col <= c.nhp + 2) for (int64_t b = rg; b < c.B; b += CS_ROWS) s += c.aux[b * 3 + (col - c.nhp)];
+    if (src) for (int64_t b = rg; b < c.B; b += CS_ROWS) s += src[(size_t)b * stride];
     red[rg][ox] = s;
     __syncthreads();
     if (rg == 0 && col <= c.nhp + (c.aux ? 2 : 0)) {
         float t = 0.f;
 #pragma unroll
         for (int r = 0; r < CS_ROWS; ++r) t += red[r][ox];
-        if (col == c.nhp) { if (c.sse_accum) c.sse_accum[0] += t; }
-        else if (col > c.nhp) { if (c.sse_accum) c.sse_accum[col - c.nhp] += t * c.inv_denom; }
+        if (col == c.nhp) { if (c.sse_accum) c.sse_accum[0] = prev + t; }
+        else if (col > c.nhp) { if (c.sse_accum) c.sse_accum[col - c.nhp] = prev + t * c.inv_denom; }
         else c.flat_g[col < c.col0_n ? c.col0_lo + col : c.col1_lo + (col - c.col0_n)] = t;
     }
 }
@@ -265,8 +274,11 @@ __host__ __device__ inline int backward_cs_slices(int cs_blocks, int wgs_per_sli
     return (cs_blocks + wgs_per_slice - 1) / wgs_per_slice;
 }
 
-template <int ML>
-__global__ __launch_bounds__(WG_THREADS, ML > 16 ? 2 : 4) void narre_backward_kernel(WgradArgs w, ColSum c, int cs_blocks, TokenArgs nx,
+// WIDE: the generic wgrad (3E/4 > 64 float4: wgrad_block) instead of the packed one-wave-per-filter form.  Without
+// an ID-table role that variant fits 64 VGPRs -- 8 waves per SIMD, every workgroup of a DeepCoNN++ launch resident
+// (13.7 -> 11.0 us); the packed form spills at that cap (its workgroups went 4.6 -> 7.2 us) and keeps 4.
+template <int ML, bool WIDE = false>
+__global__ __launch_bounds__(WG_THREADS, ML > 16 ? 2 : (ML == 0 && WIDE ? 8 : 4)) void narre_backward_kernel(WgradArgs w, ColSum c, int cs_blocks, TokenArgs nx,
                                                                     int packed, RowSweep rows, int row_blocks, int ntower) {
     const int blk0 = blockIdx.y * gridDim.x + blockIdx.x, nblk = gridDim.x * gridDim.y;
     BWD_STAMP(0, wall_clock64())
@@ -285,7 +297,8 @@ __global__ __launch_bounds__(WG_THREADS, ML > 16 ? 2 : 4) void narre_backward_ke
             }
         }
     } else if (z < ntower) {
-        if (packed) wgrad_block_packed(w, blockIdx.x, blockIdx.y, z);   // grid.x = ceil(F / 4)
+        if constexpr (WIDE) wgrad_block(w, blockIdx.x, blockIdx.y, z);
+        else if (packed) wgrad_block_packed(w, blockIdx.x, blockIdx.y, z);   // grid.x = ceil(F / 4)
         else wgrad_block(w, blockIdx.x, blockIdx.y, z);
     } else if (z < ntower + backward_cs_slices(cs_blocks, nblk)) {
         // (one block per workgroup, over as many slices as that takes: TransNet's 220 blocks on a 200-workgroup

@@ -53,6 +53,7 @@ for i in range(4):
 torch.cuda.synchronize()
 if backward:
     tr = trace.cpu().numpy().reshape(-1, 4)
+    tr[:, 3] = np.arange(len(tr))                            # linear workgroup index (x fastest, then y, then z)
     tr = tr[tr[:, 0] > 0]
     t0 = tr[:, 0].min()
     print('%s backward launch: %d workgroups, first start -> last end %.2f us' % (workload, len(tr), (tr[:, 1].max() - t0) / 100.0))
@@ -62,6 +63,8 @@ if backward:
         print('z-slice %d: %4d workgroups, start %5.2f .. %5.2f us, duration med %5.2f max %5.2f, last end %5.2f us'
               % (z - 1, len(r), (r[:, 0].min() - t0) / 100.0, (r[:, 0].max() - t0) / 100.0, np.median(d), d.max(),
                  (r[:, 1].max() - t0) / 100.0))
+        per = len(r)
+        print('           longest: workgroup %d of the slice (%.2f us)' % (int(r[np.argmax(d), 3]) % per if per else -1, d.max()))
         busy = np.sort(d[d > 2.0])
         if len(busy) and z == 1 and hp['model_type'] == 'NARRE':   # the ID-table role: most workgroups exit at once
             print('           %d busy workgroups: p50 %.2f p90 %.2f p99 %.2f max %.2f us' % (
