@@ -402,18 +402,20 @@ __global__ __launch_bounds__(RED_THREADS) void deepconn_reduce_kernel(WgradArgs 
                                                                       TokenArgs nx, FusedAdam opt) {
     const int bx = blockIdx.x;
     if (bx < red_blocks) {
-        wgrad_reduce_block(w, blockIdx.y, bx);
-        if (opt.on) {                                       // this thread's element, just written
-            const WgradTower &tw = w.t[blockIdx.y];
-            const int nw = w.F * 3 * w.E;
-            const int i = bx * RED_THREADS + threadIdx.x;
-            const float *gp = i < nw ? tw.d_w + i : (i < nw + w.F ? tw.d_b + (i - nw) : nullptr);
-            if (gp) {
-                const int64_t o = gp - opt.g;
-                float P = opt.p[o], M = opt.m[o], V = opt.v[o];
-                adam_elem(P, *gp, M, V, opt.s);
-                opt.p[o] = P; opt.m[o] = M; opt.v[o] = V;
-            }
+        // the element's parameter and moments are requested WITH its partials (their addresses need nothing
+        // from them), and Adam takes the sum from the register, not back from memory: one round trip, not three
+        const WgradTower &tw = w.t[blockIdx.y];
+        const int nw = w.F * 3 * w.E;
+        const int i = bx * RED_THREADS + threadIdx.x;
+        const float *gp0 = i < nw ? tw.d_w + i : (i < nw + w.F ? tw.d_b + (i - nw) : nullptr);
+        const int64_t o = gp0 ? gp0 - opt.g : 0;
+        float P = 0.f, M = 0.f, V = 0.f;
+        if (opt.on && gp0) { P = opt.p[o]; M = opt.m[o]; V = opt.v[o]; }
+        float *dst;
+        const float g = wgrad_reduce_elem(w, blockIdx.y, i, dst);
+        if (opt.on && dst) {
+            adam_elem(P, g, M, V, opt.s);
+            opt.p[o] = P; opt.m[o] = M; opt.v[o] = V;
         }
     } else if (bx < red_blocks + comp_blocks) {
         token_compact_auto<RED_THREADS / 64>(nx.t[blockIdx.y], nx.V, bx - red_blocks);

@@ -344,18 +344,19 @@ static __global__ __launch_bounds__(NRED_THREADS) void narre_reduce_kernel(Wgrad
         return;
     }
     if (bx < red_blocks) {
-        wgrad_reduce_block(w, blockIdx.y, bx);
-        if (opt.on) {
-            const WgradTower &tw = w.t[blockIdx.y];
-            const int nw = w.F * 3 * w.E;
-            const int i = bx * NRED_THREADS + threadIdx.x;
-            const float *gp = i < nw ? tw.d_w + i : (i < nw + w.F ? tw.d_b + (i - nw) : nullptr);
-            if (gp) {
-                const int64_t o = gp - opt.g;
-                float P = opt.p[o], M = opt.m[o], V = opt.v[o];
-                adam_elem(P, *gp, M, V, opt.s);
-                opt.p[o] = P; opt.m[o] = M; opt.v[o] = V;
-            }
+        // (parameter + moments requested with the partials, Adam fed from the register: engine.hip)
+        const WgradTower &tw = w.t[blockIdx.y];
+        const int nw = w.F * 3 * w.E;
+        const int i = bx * NRED_THREADS + threadIdx.x;
+        const float *gp0 = i < nw ? tw.d_w + i : (i < nw + w.F ? tw.d_b + (i - nw) : nullptr);
+        const int64_t o = gp0 ? gp0 - opt.g : 0;
+        float P = 0.f, M = 0.f, V = 0.f;
+        if (opt.on && gp0) { P = opt.p[o]; M = opt.m[o]; V = opt.v[o]; }
+        float *dst;
+        const float g = wgrad_reduce_elem(w, blockIdx.y, i, dst);
+        if (opt.on && dst) {
+            adam_elem(P, g, M, V, opt.s);
+            opt.p[o] = P; opt.m[o] = M; opt.v[o] = V;
         }
     } else if (bx < red_blocks + comp_blocks) {
         token_compact_auto<NRED_THREADS / 64>(nx.t[blockIdx.y], nx.V, bx - red_blocks);

@@ -146,20 +146,33 @@ __device__ __forceinline__ void wgrad_block_packed(const WgradArgs &a, int fgrou
 
 // Second stage: element i of tower `tw`'s [F*3E weight | F bias] gradient = sum of the nsplit
 // partials in a fixed order (deterministic).
-__device__ __forceinline__ void wgrad_reduce_block(const WgradArgs &a, int tower, int blk) {
+constexpr int WG_MAX_SPLITS = 16;      // textcnn_wgrad_splits never returns more
+
+// Element i of the concatenated [F*3E | F] gradient: every partial is requested before the first is added (a
+// loop with a run-time trip count made them dependent round trips), summed in split order like before.  Writes
+// the element, returns it and its address (nullptr past the end).
+__device__ __forceinline__ float wgrad_reduce_elem(const WgradArgs &a, int tower, int i, float *&dst) {
     const WgradTower &tw = a.t[tower];
     const int nw = a.F * 3 * a.E;
-    const int i = blk * blockDim.x + threadIdx.x;
-    if (i < nw) {
-        float s = 0.f;
-        for (int k = 0; k < a.nsplit; ++k) s += tw.part_w[(size_t)k * nw + i];
-        tw.d_w[i] = s;
-    } else if (i < nw + a.F) {
-        const int f = i - nw;
-        float s = 0.f;
-        for (int k = 0; k < a.nsplit; ++k) s += tw.part_b[(size_t)k * a.F + f];
-        tw.d_b[f] = s;
-    }
+    const float *src;
+    size_t stride;
+    if (i < nw) { src = tw.part_w + i; stride = (size_t)nw; dst = tw.d_w + i; }
+    else if (i < nw + a.F) { src = tw.part_b + (i - nw); stride = (size_t)a.F; dst = tw.d_b + (i - nw); }
+    else { dst = nullptr; return 0.f; }
+    float v[WG_MAX_SPLITS];
+#pragma unroll
+    for (int k = 0; k < WG_MAX_SPLITS; ++k) v[k] = src[(size_t)(k < a.nsplit ? k : 0) * stride];   // unconditional loads
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < WG_MAX_SPLITS; ++k)
+        if (k < a.nsplit) s += v[k];                        // uniform
+    *dst = s;
+    return s;
+}
+
+__device__ __forceinline__ void wgrad_reduce_block(const WgradArgs &a, int tower, int blk) {
+    float *dst;
+    (void)wgrad_reduce_elem(a, tower, blk * (int)blockDim.x + (int)threadIdx.x, dst);
 }
 
 }  // namespace r4r
