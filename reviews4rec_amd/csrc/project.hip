@@ -624,10 +624,16 @@ __global__ __launch_bounds__(256) void proj_gather_max_kernel(ProjArgs a) {
     // (typically the zero-padded tail of a document, data.py:198-199): then every position of the
     // slice has the same window sum and its first position decides the slice (first-max wins).
     bool same = true;
-    for (int k = wl; k < ntok; k += 32) {
-        const int t = t_lo + k;
-        const int sv = (t >= 0 && t < T) ? tw.slot[tw.idx[doc * T + t]] : -1;
-        sl[worker][k] = sv;
+    {
+        // a slice is at most SLICE + 2 = 34 tokens: lane wl takes token wl and (wl < 2) token 32 + wl, both
+        // requested together -- as a loop the second pass (two lanes) was two more dependent round trips
+        static_assert(SLICE == 32, "two tokens per lane cover a slice");
+        const int ta = t_lo + wl, tb = t_lo + 32 + wl;
+        const bool va = wl < ntok && ta >= 0 && ta < T, vb = 32 + wl < ntok && tb >= 0 && tb < T;
+        const int64_t ia = tw.idx[doc * T + (va ? ta : 0)], ib = tw.idx[doc * T + (vb ? tb : 0)];
+        const int sa = tw.slot[ia], sb = tw.slot[ib];
+        if (wl < ntok) sl[worker][wl] = va ? sa : -1;
+        if (32 + wl < ntok) sl[worker][32 + wl] = vb ? sb : -1;
     }
     __syncthreads();
     if (ntok > 0) {
