@@ -22,6 +22,7 @@
 
 #include "textcnn.h"
 #include "tokens_device.h"
+#include "trace_device.h"
 
 namespace r4r {
 
@@ -596,7 +597,9 @@ constexpr int SLICE = 32;                 // positions per worker
 constexpr int GDEPTH = R4R_GDEPTH;        // tokens in flight per lane (7: 124 VGPRs, four waves per SIMD -- every workgroup of the
                                           // cfg3 launch resident at once; 8: 136 VGPRs, three, 1 us slower; 4..6 within 0.5 us of 7)
 
+HEAD_TRACE_DEFINE(r4r_debug_gather_trace)
 __global__ __launch_bounds__(256) void proj_gather_max_kernel(ProjArgs a) {
+    HEAD_STAMP(0)
     __shared__ int sl[8][SLICE + 2];
     __shared__ float sbest[8][PF];
     __shared__ int sbp[8][PF];
@@ -636,6 +639,7 @@ __global__ __launch_bounds__(256) void proj_gather_max_kernel(ProjArgs a) {
         if (32 + wl < ntok) sl[worker][32 + wl] = vb ? sb : -1;
     }
     __syncthreads();
+    HEAD_STAMP(1)
     if (ntok > 0) {
         const int s_first = sl[worker][0];
         for (int k = wl; k < ntok; k += 32) same &= (sl[worker][k] == s_first);
@@ -694,6 +698,7 @@ __global__ __launch_bounds__(256) void proj_gather_max_kernel(ProjArgs a) {
         for (int c = 0; c < 4; ++c) { sbest[worker][wl * 4 + c] = best[c]; sbp[worker][wl * 4 + c] = bp[c]; }
     }
     __syncthreads();
+    HEAD_STAMP(2)
     // merge the 4 slices of each segment in position order; thread f (< 100) of each half
     const int half = threadIdx.x >> 7, f = threadIdx.x & 127;
     const int64_t ounit = (int64_t)blockIdx.x * 2 + half;
@@ -709,6 +714,7 @@ __global__ __launch_bounds__(256) void proj_gather_max_kernel(ProjArgs a) {
         tw.pmax[o] = mb;
         tw.parg[o] = mp;
     }
+    HEAD_STAMP(3)
 }
 
 // ----------------------------------------------------------------- launchers

@@ -33,6 +33,10 @@ lib = ctypes.CDLL(os.environ['R4R_LIBRARY'])
 setter = {'NARRE': lib.r4r_debug_narre_head_trace, 'deepconn': lib.r4r_debug_dc_head_trace}.get(hp['model_type'], lib.r4r_debug_tn_head_trace)
 setter.argtypes = [ctypes.c_void_p]
 backward = '--backward' in sys.argv
+gather = '--gather' in sys.argv                           # stage timeline of proj_gather_max_kernel's workgroups instead
+if gather:
+    setter = lib.r4r_debug_gather_trace
+    setter.argtypes = [ctypes.c_void_p]
 if backward:
     # (narre_backward_kernel<0> is instantiated by the NARRE, DeepCoNN++ AND TransNet translation units; which copy a
     # launch runs is the linker's choice, and each reads its own unit's trace pointer: set both)
@@ -70,7 +74,7 @@ if backward:
             print('           %d busy workgroups: p50 %.2f p90 %.2f p99 %.2f max %.2f us' % (
                 len(busy), busy[len(busy) // 2], busy[int(len(busy) * 0.9)], busy[int(len(busy) * 0.99)], busy[-1]))
     sys.exit(0)
-tr = trace.cpu().numpy().reshape(-1, 32)[:B]
+tr = trace.cpu().numpy().reshape(-1, 32)[:(8192 if gather else B)]
 tr = tr[tr[:, 0] > 0]                                      # (DeepCoNN: one workgroup per 4 ratings)
 n = int((tr[0, :20] > 0).sum())
 t0 = tr[:, 0].min()
