@@ -45,7 +45,10 @@ __device__ __forceinline__ void colsum_block(const ColSum &c, int blk) {
     else if (col == c.nhp) { src = c.se; stride = 1; }
     else if (c.aux && col <= c.nhp + 2) { src = c.aux + (col - c.nhp); stride = 3; }
     float s = 0.f;
-    if (src) for (int64_t b = rg; b < c.B; b += CS_ROWS) s += src[(size_t)b * stride];
+    if (src) {
+#pragma unroll 8                                             // (eight of a thread's loads in flight: B = 128 is one round)
+        for (int64_t b = rg; b < c.B; b += CS_ROWS) s += src[(size_t)b * stride];
+    }
     red[rg][ox] = s;
     __syncthreads();
     if (rg == 0 && col <= c.nhp + (c.aux ? 2 : 0)) {
