@@ -36,6 +36,7 @@ constexpr int NEIGHBOURS = 10;
 // tokens of reviews [rb, re) of a pool minus review rb + skip, as a [T] document
 __device__ __forceinline__ void write_doc(const int32_t *tok, const int64_t *rev_off, int64_t rb, int64_t re,
                                           int64_t skip, int T, int64_t *dst) {
+    if (skip >= re - rb) skip = -1;      // an index past this owner's list removes nothing (data.py:223-235: `i != indices[k]` holds for every i)
     const int64_t start = rev_off[rb], end = rev_off[re > rb ? re : rb];
     int64_t hb = end, hl = 0;
     if (skip >= 0) {
@@ -52,6 +53,7 @@ __device__ __forceinline__ void write_doc(const int32_t *tok, const int64_t *rev
 // the same reviews in NARRE's [R, W] layout: slot r = the r-th remaining review, cut / padded to W
 __device__ __forceinline__ void write_reviews(const int32_t *tok, const int64_t *rev_off, int64_t rb, int64_t re,
                                               int64_t skip, int R, int W, int64_t *dst) {
+    if (skip >= re - rb) skip = -1;
     for (int p = threadIdx.x; p < R * W; p += blockDim.x) {
         const int r = p / W, w = p - r * W;
         const int64_t rev = rb + r + ((skip >= 0 && r >= skip) ? 1 : 0);
@@ -66,6 +68,7 @@ __device__ __forceinline__ void write_reviews(const int32_t *tok, const int64_t 
 
 __device__ __forceinline__ void write_neighbours(const int64_t *nb, int64_t rb, int64_t re, int64_t skip,
                                                  int64_t pad, int64_t *dst) {
+    if (skip >= re - rb) skip = -1;
     if (threadIdx.x < NEIGHBOURS) {
         const int r = threadIdx.x;
         const int64_t at = rb + r + ((skip >= 0 && r >= skip) ? 1 : 0);

@@ -319,7 +319,8 @@ __global__ __launch_bounds__(NT) void narre_head_kernel(NarreHead a) {
     if (tid < 128) {                                        // wave s = side s, one review per lane (R <= MR <= 32)
         const int s = tid >> 6, ln = tid & 63;
         const float val = ln < R ? sc[s * R + ln] : -INFINITY;
-        const float e = ln < R ? expf(val - wave_max(val)) : 0.f;
+        const float mx = wave_max(val);                     // all 64 lanes take part: never reduce under a lane-divergent branch
+        const float e = ln < R ? expf(val - mx) : 0.f;
         const float den = wave_sum(e);
         if (ln < R) sc[s * R + ln] = e / den;
     }

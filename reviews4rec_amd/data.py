@@ -116,7 +116,7 @@ def _rows(pool_first, ids, skip):
 def _np_docs(tok, rev_off, rb, re, skip, T):
     """[N, T]: tokens of reviews [rb, re) minus review rb + skip (skip < 0: none), zero padded / cut."""
     start, end = rev_off[rb], rev_off[np.maximum(re, rb)]
-    has = skip >= 0
+    has = (skip >= 0) & (skip < re - rb)        # an index past the owner's list removes nothing (data.py:223-235)
     hb = np.where(has, rev_off[np.where(has, rb + skip, rb)], end)
     hl = np.where(has, rev_off[np.where(has, rb + skip + 1, rb)] - hb, 0)
     src = start[:, None] + np.arange(T, dtype=np.int64)[None, :]
@@ -129,6 +129,7 @@ def _np_docs(tok, rev_off, rb, re, skip, T):
 def _np_reviews(tok, rev_off, rb, re, skip, R, W):
     """[N, R, W] (NARRE, data.py:144-172): review slot r = the r-th remaining review, each cut / padded to W."""
     r = np.arange(R, dtype=np.int64)[None, :]
+    skip = np.where(skip >= re - rb, -1, skip)
     k = r + ((skip[:, None] >= 0) & (r >= skip[:, None]))
     rev = rb[:, None] + k
     okr = rev < re[:, None]
@@ -144,6 +145,7 @@ def _np_reviews(tok, rev_off, rb, re, skip, R, W):
 
 def _np_neighbours(nb, rb, re, skip, pad):
     r = np.arange(NEIGHBOURS, dtype=np.int64)[None, :]
+    skip = np.where(skip >= re - rb, -1, skip)
     k = r + ((skip[:, None] >= 0) & (r >= skip[:, None]))
     at = rb[:, None] + k
     ok = at < re[:, None]
@@ -287,9 +289,19 @@ class DataLoader():
     def _device_split(self):
         if self._dev_split is None:
             ku, ki, held = self._split_arrays()
+            self._check_owners(self._u, self._i)
             t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(self.device)
             self._dev_split = dict(u=t(self._u), i=t(self._i), y=t(self._y), ku=t(ku), ki=t(ki), held=t(held))
         return self._dev_split
+
+    def _check_owners(self, u, i):
+        """The device batcher indexes the pools' ``first`` arrays by id: an id outside the pools is the
+        reference's KeyError (``self.user_reviews[u]``, data.py:283-284), raised once on the host."""
+        st = self.store
+        if len(u) and (int(np.max(u)) >= st.users.owners or int(np.min(u)) < 0):
+            raise KeyError('user id outside the review pools: {}'.format(int(np.max(u))))
+        if len(i) and (int(np.max(i)) >= st.items.owners or int(np.min(i)) < 0):
+            raise KeyError('item id outside the review pools: {}'.format(int(np.max(i))))
 
     def _review_fields_device(self, u, i, ku, ki, held, lead, nb_item=None, rep_user=1):
         """Same five slots, built by ONE launch of r4r_batch_build from the HBM-resident pools.
@@ -392,6 +404,7 @@ class DataLoader():
                         ku[r], ki[r] = self.store.pair[k]                      # KeyError like data.py:217
                     elif self.test_reviews is not None:
                         held[r] = self.store.held.index[k]                     # KeyError like data.py:244
+                self._check_owners(uu, cand.reshape(-1))
             self._dev_negs[key] = dict(u=uu, cand=cand, ku=ku, ki=ki, held=held)
         return self._dev_negs[key]
 

@@ -305,6 +305,7 @@ class DeepCoNNEngine(_ConvRule):
             self._rule_decide([ws[a:a + 8] for a in at], 2 * n, T)
         return pred, se
 
+    @torch.no_grad()
     def train_step(self, data, y, n_global=None, next_data=None):
         """One optimisation step on this rank's shard.  Returns the per-example SE tensor
         (device); the running sum is in ``self.sse``.  ``next_data``: the batch that will be
@@ -498,6 +499,7 @@ class MFEngine:
             self.offset += n * 2 * self.D
         return pred, se
 
+    @torch.no_grad()
     def _train_step_dp(self, data, y, n_global):
         """Data parallel: this rank's compact gradient rows into a packed block, ONE
         all_gather of the blocks, then the same tagged sweep over all ranks' entries in rank order
@@ -1299,6 +1301,7 @@ class IdNetEngine:
             self.offset += n * self.draws()
         return pred, se
 
+    @torch.no_grad()
     def train_step(self, data, y, n_global=None, next_data=None):
         """One optimisation step.  Returns the per-example SE tensor (device, reused by the next call);
         the running sum is in ``self.sse``."""
@@ -1312,6 +1315,7 @@ class IdNetEngine:
                              1.0 / float(n_global if n_global is not None else n), self.step_count)
         return se
 
+    @torch.no_grad()
     def _train_step_dp(self, data, y, n_global):
         lib, dist = _lib.lib(), torch.distributed
         n, world, L = data[5].numel(), self.dp.world, self.L
@@ -1433,3 +1437,6 @@ class IdNetEngine:
         self.offset = int(sd['dropout_offset'])
         self.lr, self.wd = float(sd['lr']), float(sd['weight_decay'])
         self.betas, self.eps = tuple(sd['betas']), float(sd['eps'])
+        # row tags written by earlier steps of THIS process must not collide with resumed step numbers
+        for ws in self.__dict__.get('_ws_cache', {}).values():
+            ws.zero_()

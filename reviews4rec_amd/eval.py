@@ -28,6 +28,7 @@ def _count_maps(ids, ses, counts):
 
 
 EVAL_LAUNCH = 8          # x batch_size ratings per launch of a validation pass scored by a native engine
+EVAL_LAUNCH_CAP = 4096   # ... but never more than max(batch_size, this) ratings
 RANK_LAUNCH = 4          # x batch_size ranking rows (of 6 candidates each)
 
 
@@ -42,7 +43,10 @@ def _launch_size(reader, hyper_params, engine, factor):
     if engine is None or not getattr(reader, 'takes_batch', False):
         return None
     bsz = int(hyper_params['batch_size'])
-    n = int(hyper_params.get('eval_batch_size') or factor * bsz)
+    # the larger slices only pay while a launch is small: past EVAL_LAUNCH_CAP ratings the slice stays at
+    # batch_size (the device batcher allocates n * (3 * doc + 20) * 8 bytes per launch and the engine keeps a
+    # workspace per launch shape: a batch_size that trains must not run the validation pass out of memory)
+    n = int(hyper_params.get('eval_batch_size') or min(factor * bsz, max(bsz, EVAL_LAUNCH_CAP)))
     if hyper_params['model_type'] in ['transnet', 'transnet++']:
         n = max(bsz, n - n % bsz)                            # launches must start on the reference's slice boundaries
     return n

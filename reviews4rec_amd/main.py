@@ -294,6 +294,9 @@ def train_complete(hyper_params, Model, train_reader, val_reader, user_count, it
     first_epoch, best_MSE = 1, float(INF)
     if ckpt_path and os.path.exists(ckpt_path):
         ck = torch.load(ckpt_path, map_location='cpu')
+        if ck.get('model_class', type(model).__name__) != type(model).__name__:
+            raise RuntimeError('checkpoint {} holds a {} run, this run trains a {}'.format(
+                ckpt_path, ck['model_class'], type(model).__name__))
         model.load_state_dict(ck['model'])
         if engine is not None:
             engine.load_state_dict(ck['optimizer'])
@@ -345,6 +348,7 @@ def train_complete(hyper_params, Model, train_reader, val_reader, user_count, it
                     opt_sd = optimizer.state_dict()
                 tmp = ckpt_path + '.tmp'
                 torch.save({'epoch': epoch, 'best_MSE': best_MSE, 'model': model.state_dict(),
+                            'model_class': type(model).__name__,
                             'optimizer': opt_sd, 'dropout_offset': drop_at, 'rank_offsets': rank_offsets}, tmp)
                 os.replace(tmp, ckpt_path)                  # a crash mid-write leaves the previous one intact
     except KeyboardInterrupt:
@@ -400,10 +404,12 @@ def main_NeuMF(hyper_params, readers=None, user_count=None, item_count=None, dp=
     user_count = {} if user_count is None else user_count
     item_count = {} if item_count is None else item_count
     start_time = time.time()
-    initial_path = hyper_params['model_path']
+    initial_path, initial_ckpt = hyper_params['model_path'], hyper_params.get('checkpoint_path')
     stage_models = {}
     for tag, cls in (('_gmf', GMF), ('_mlp', MLP)):
         hyper_params['model_path'] = initial_path + tag
+        if initial_ckpt:                                  # every stage resumes from its OWN epoch checkpoint
+            hyper_params['checkpoint_path'] = initial_ckpt + tag
         model = cls(hyper_params)
         if is_cuda_available:
             model = model.cuda()
@@ -411,6 +417,8 @@ def main_NeuMF(hyper_params, readers=None, user_count=None, item_count=None, dp=
         stage_models[tag] = train_complete(hyper_params, cls, train_reader, val_reader, user_count, item_count,
                                            model, review=False, dp=dp)
     hyper_params['model_path'] = initial_path
+    if initial_ckpt:
+        hyper_params['checkpoint_path'] = initial_ckpt
     model = NeuMF(hyper_params)
     if is_cuda_available:
         model = model.cuda()
