@@ -123,7 +123,10 @@ def parse():
     ap.add_argument('--ramp', type=int, default=30,
                     help='untimed steps before the requested warm-up when --warmup is shorter than this: clocks '
                          'and launch queue reach steady state whatever --warmup says (reported as warmup_effective)')
-    ap.add_argument('--no-opt-in-leg', action='store_true', help='skip the extra fp16-split-GEMM leg at N = 1')
+    ap.add_argument('--opt-in-leg', action='store_true',
+                    help='also time the opt-in fp16-split-GEMM leg at N = 1 (off by default: it is not fp32 arithmetic '
+                         'and earns the line nothing)')
+    ap.add_argument('--no-opt-in-leg', action='store_true', help='(accepted for older scripts: the leg is off by default)')
     ap.add_argument('--gemm-math', choices=['f32', 'f16x2'], default='f32',
                     help='arithmetic of the projection GEMM: f32 (default, the headline: fp32 operands on the fp32 MFMA) or '
                          'the opt-in fp16-split form (every operand = hi + lo fp16, three f16-MFMA products per fp32 '
@@ -364,10 +367,14 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
+    gpu_span_ms = [0.0]
+
     def timed_region(step_fn, steps, first, mask):
         """EXACTLY `steps` steps between two fences; -> max-over-ranks wall seconds."""
         fence()
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         t0 = time.perf_counter()
+        ev0.record()                                         # (torch's current stream = the one every launch goes to)
         # sampled kernel timing: every 20th step (an instrumented step costs ~30 us more: its HIP events
         # carry release fences, and without them the spans stop agreeing with rocprofv3's kernel
         # durations -- measured: 56.0 vs 59.4 us for the GEMM), or -- short regions, where two
@@ -376,8 +383,12 @@ def main():
         for i in range(steps):
             lib.r4r_timing_enable(mask if sample(i) else 0)
             step_fn(first + i)
+        ev1.record()
         fence()
         elapsed = time.perf_counter() - t0
+        # first launch's start -> last launch's end on the device: what the steps cost the GPU, without the two
+        # host fences and the launch-queue fill the host clock also sees (value stays host-clock)
+        gpu_span_ms[0] = ev0.elapsed_time(ev1)
         lib.r4r_timing_enable(0)
         el = torch.tensor([elapsed], device=dev)
         if dp_job:
@@ -403,6 +414,7 @@ def main():
     mask = 0 if args.no_kernel_timing else (1 << 0) | (1 << 3) | (1 << 4) | \
         ((1 << 2) if hp['model_type'] in ('MF_dot', 'bias_only', 'transnet++') else 0)   # the Adam sweep is the leg
     elapsed = timed_region(step, args.steps, ramp + args.warmup, mask)
+    gpu_ms_per_step = gpu_span_ms[0] / args.steps
     steps_run = ramp + args.warmup + args.steps
     slots = {'textcnn_fwd_kernel': 0, 'textcnn_wgrad_kernel': 1, 'adam_multi_kernel': 2,
              'proj_gemm_kernel': 3, 'proj_gather_max_kernel': 4}
@@ -439,7 +451,7 @@ def main():
     # fp32 accumulation: DESIGN.md 4.1d).  Reported beside the fp32 line, never as `value`.
     opt_in = None
     if (not dp_job and args.gemm_math == 'f32' and getattr(engine, 'gemm_math', None) == 'f32'
-            and 'proj_gemm_kernel' in timed and not args.from_host and not args.no_opt_in_leg):
+            and 'proj_gemm_kernel' in timed and not args.from_host and args.opt_in_leg and not args.no_opt_in_leg):
         from reviews4rec_amd import engine as E
         os.environ['R4R_GEMM_MATH'] = 'f16x2'
         engine.gemm_math = 'f16x2'
@@ -479,10 +491,12 @@ def main():
             'metric': 'train ratings/sec', 'value': round(value, 1), 'unit': 'ratings/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'warmup_effective': ramp + args.warmup,
             'ms_per_step': round(1000.0 * elapsed / args.steps, 4),
+            'gpu_ms_per_step': round(gpu_ms_per_step, 4),     # HIP events around the same steps (rank 0's device)
             'higher_is_better': True, 'scaling': 'strong' if strong else 'weak', 'vs_baseline': None,
             'dtype': 'f32' if args.gemm_math == 'f32' else 'f32 with an fp16-split projection GEMM (3 f16-MFMA products per '
                                                             'fp32 product, fp32 accumulate; opt-in, not the headline)',
-            'data': 'synthetic' + (' (streamed from pinned host memory)' if args.from_host else ''),
+            'data': 'synthetic' + (' (streamed from pinned host memory)' if args.from_host else
+                                   ' (HBM-resident: a pool of %d batches on the device before the timed region)' % args.pool),
             'config': {'workload': args.workload, 'ratings_per_step': B_global, 'batch_per_gpu': B,
                        'parallelism': 'dp%d' % world,
                        'engine': 'native' if engine is not None else ('graph' if graphed is not None else 'module'),

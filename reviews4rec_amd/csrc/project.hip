@@ -40,6 +40,39 @@ constexpr int PNH = 10;                                // column tiles of the wi
 constexpr int PNH_COLS = PNH * 16;                     // 160
 constexpr int SEG = 128;           // positions per partial (matches the direct kernel's NW=4 tile)
 
+// Experiment switches of the projection GEMM (make variant EXTRA="-D..."; defaults = the shipped form)
+#ifndef R4R_STG_PERM
+#define R4R_STG_PERM 1             // staging threads take rows in the order 0,2,1,3: conflict-free ds_write_b128
+#endif
+#ifndef R4R_EPI
+#define R4R_EPI 1                  // 0: LDS-transposed epilogue; 1: direct float4 stores (operand roles swapped); 2: no stores (timing only)
+#endif
+#ifndef R4R_EPI_NT
+#define R4R_EPI_NT 0               // 1: nontemporal epilogue stores
+#endif
+#ifndef R4R_PRIO
+#define R4R_PRIO 0                 // 1: waves 4..7 at s_setprio 1 for the K loop
+#endif
+
+// Staging row of thread-quad s (= tid >> 2).  A ds_write_b128 is served in groups of 8 consecutive lanes = two
+// quads over 32 banks; rows s and s + 1 at the 24-float stride overlap in 8 banks (a 2-way conflict: 27 % of the
+// kernel's LDS cycles, profiles/r02k_bench_pmc_summary.json), rows s and s + 2 are 48 floats apart = 16 banks: none.
+__device__ __forceinline__ int stage_row(int s) {
+#if R4R_STG_PERM
+    return (s & ~3) | ((s & 1) << 1) | ((s >> 1) & 1);
+#else
+    return s;
+#endif
+}
+
+__device__ __forceinline__ void store_row4(float *dst, const f32x4 v) {
+#if R4R_EPI_NT
+    __builtin_nontemporal_store(v, reinterpret_cast<f32x4 *>(dst));
+#else
+    *reinterpret_cast<f32x4 *>(dst) = v;
+#endif
+}
+
 struct ProjArgs {
     ProjTower t[MAX_TOWERS];
     const float *table;
@@ -131,7 +164,7 @@ __device__ __forceinline__ void proj_gemm_body(const ProjArgs &a, float *lds, in
 
     // staging role: float4 column c4 of A row (tid >> 2) and of B rows (tid >> 2) + 128 k
     // (k < NB: waves 0..3 stage three, rows 0..319; waves 4..7 two).
-    const int c4 = tid & 3, srow = tid >> 2;
+    const int c4 = tid & 3, srow = stage_row(tid >> 2);
     const float *aptr = table + (long)tw.list[min(row0 + srow, count - 1)] * E;
     const float *bptr[NB];
     const float *__restrict__ conv_w = tw.conv_w;
@@ -178,7 +211,11 @@ __device__ __forceinline__ void proj_gemm_body(const ProjArgs &a, float *lds, in
         for (int mi = 0; mi < GMT; ++mi)
 #pragma unroll
             for (int ni = 0; ni < NTILE; ++ni)
+#if R4R_EPI == 0
                 acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mi][kk], b[ni][kk], acc[mi][ni], 0, 0, 0);
+#else           // roles swapped: the lane ends up with 4 consecutive COLUMNS of one table row (same fma chain, same bits)
+                acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[ni][kk], av[mi][kk], acc[mi][ni], 0, 0, 0);
+#endif
     };
     // Operand registers are double-buffered too: the staging of chunk c+2 (registers -> LDS),
     // the global loads of chunk c+3 and the ds_reads of chunk c+1 are all issued among the
@@ -236,6 +273,9 @@ __device__ __forceinline__ void proj_gemm_body(const ProjArgs &a, float *lds, in
 #endif
     // (the odd last chunk is peeled: with an exit in the middle of the loop body hipcc's counter
     // analysis falls back to vmcnt(0) at the loop head)
+#if R4R_PRIO
+    if (wave >= 4) __builtin_amdgcn_s_setprio(1);
+#endif
     int c = 0;
     for (; c + 1 < nchunk; c += 2) {
         step(c, av0, b0, av1, b1);
@@ -246,12 +286,15 @@ __device__ __forceinline__ void proj_gemm_body(const ProjArgs &a, float *lds, in
     if (g_trace && threadIdx.x == 0)                        // shader cycles of the loop (vs the 100 MHz stamps: the clock)
         g_trace[((size_t)blockIdx.x) * 8 + 7] = __builtin_readcyclecounter() - clk0;
 #endif
+#if R4R_EPI == 0
     __syncthreads();                                        // all operand reads done: LDS is free
+#endif
     TRACE_STAMP(2)
     // Epilogue.  C layout of the MFMA: col = lane & 15, row = (lane >> 4) * 4 + reg -- storing
     // that directly is 80 scattered 4-byte stores per lane.  Instead each wave transposes one
     // 16-row tile at a time through its own LDS slab and writes whole row segments as float4
     // (an LDS queue is in-order per wave, so no barrier is needed inside a wave).
+#if R4R_EPI == 0
     constexpr int TS = NTILE * 16 + 4;
     float *slab = lds + wave * (16 * (PNH_COLS + 4));
     constexpr int NV = NTILE * 4;
@@ -270,6 +313,23 @@ __device__ __forceinline__ void proj_gemm_body(const ProjArgs &a, float *lds, in
                     *reinterpret_cast<const f32x4 *>(slab + rr * TS + cv * 4);
         }
     }
+#elif R4R_EPI == 1
+    // With the operand roles swapped the MFMA leaves lane (lrow, q) with columns 4q .. 4q+3 of table row lrow of
+    // each 16 x 16 tile: one float4 store per tile and lane, 16 rows x 64 B per instruction, no LDS round trip.
+#pragma unroll
+    for (int mi = 0; mi < GMT; ++mi) {
+        const int row = row0 + rowgrp * 16 * GMT + mi * 16 + lrow;
+        float *dst = tw.ptab + (size_t)row * PROW + colbase + col0 + q * 4;
+#pragma unroll
+        for (int ni = 0; ni < NTILE; ++ni)
+            if (row < count && colbase + col0 + ni * 16 + q * 4 < PROW) store_row4(dst + ni * 16, acc[mi][ni]);
+    }
+#else
+#pragma unroll
+    for (int mi = 0; mi < GMT; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NTILE; ++ni) asm volatile("" ::"v"(acc[mi][ni]));
+#endif
     TRACE_STAMP(3)
 }
 
@@ -328,6 +388,13 @@ __device__ __forceinline__ bool gemm7_plan(const ProjArgs &a, int wg, int nwg, G
     return true;                                            // p.tower < 0: nothing to do for this workgroup
 }
 
+// table operand x weight operand -> accumulator (R4R_EPI >= 1: roles swapped, see the tile form)
+#if R4R_EPI == 0
+#define MFMA4(tab, wgt, c) __builtin_amdgcn_mfma_f32_16x16x4f32(tab, wgt, c, 0, 0, 0)
+#else
+#define MFMA4(tab, wgt, c) __builtin_amdgcn_mfma_f32_16x16x4f32(wgt, tab, c, 0, 0, 0)
+#endif
+
 // One wave of the balanced form.  SIMD = wave & 3 owns NC column tiles (5, 5, 5, 4) of the 7 private row
 // tiles; its two waves split that 7 x NC block CHECKERBOARD-wise so that both carry the same load (18 / 17
 // tiles at NC = 5) -- a 4 + 3 row split leaves the lighter wave waiting at the chunk barrier while the
@@ -362,7 +429,7 @@ __device__ __forceinline__ void proj_gemm7_body(const ProjArgs &a, float *lds, c
 
     // staging role, as in the tile form: float4 column c4 of A row (tid >> 2) -- LDS rows 0..111 are the
     // private rows, 112..127 the shared row tile -- and of B rows (tid >> 2) + 128 k
-    const int c4 = tid & 3, srow = tid >> 2;
+    const int c4 = tid & 3, srow = stage_row(tid >> 2);
     int grow = srow < G7_ROWS * 16 ? p.row0 + srow : (p.sh_row0 < 0 ? 0 : p.sh_row0 + srow - G7_ROWS * 16);
     grow = grow < count ? grow : count - 1;
     const float *aptr = table + (long)tw.list[grow] * E;
@@ -427,16 +494,16 @@ __device__ __forceinline__ void proj_gemm7_body(const ProjArgs &a, float *lds, c
         for (int mi = 0; mi < RT; ++mi)
 #pragma unroll
             for (int ni = 0; ni < CT; ++ni)
-                acct[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(o.av[mi][kk], o.b[CT0 + ni][kk], acct[mi][ni], 0, 0, 0);
+                acct[mi][ni] = MFMA4(o.av[mi][kk], o.b[CT0 + ni][kk], acct[mi][ni]);
 #pragma unroll
         for (int mi = 0; mi < RB; ++mi)
 #pragma unroll
             for (int ni = 0; ni < CB; ++ni)
-                accb[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(o.av[RT + mi][kk], o.b[CB0 + ni][kk], accb[mi][ni], 0, 0, 0);
+                accb[mi][ni] = MFMA4(o.av[RT + mi][kk], o.b[CB0 + ni][kk], accb[mi][ni]);
         if (EX > 0) {
 #pragma unroll
             for (int j = 0; j < NE; ++j)
-                ex[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(o.sa[kk], o.eb[j][kk], ex[j], 0, 0, 0);
+                ex[j] = MFMA4(o.sa[kk], o.eb[j][kk], ex[j]);
         }
     };
     // the tile form's software pipeline (see there): LDS and operand registers double-buffered, staging
@@ -485,6 +552,9 @@ __device__ __forceinline__ void proj_gemm7_body(const ProjArgs &a, float *lds, c
 #ifdef R4R_TRACE
     const unsigned long long clk0 = __builtin_readcyclecounter();
 #endif
+#if R4R_PRIO
+    if (wave >= 4) __builtin_amdgcn_s_setprio(1);
+#endif
     int c = 0;
     for (; c + 1 < nchunk; c += 2) {
         step(c, o0, o1);
@@ -495,8 +565,11 @@ __device__ __forceinline__ void proj_gemm7_body(const ProjArgs &a, float *lds, c
     if (g_trace && threadIdx.x == 0)
         g_trace[((size_t)blockIdx.x) * 8 + 7] = __builtin_readcyclecounter() - clk0;
 #endif
+#if R4R_EPI == 0
     __syncthreads();                                        // all operand reads done: LDS is free
+#endif
     TRACE_STAMP(2)
+#if R4R_EPI == 0
     // epilogue: per wave, one 16-row tile at a time through its own LDS slab, whole row segments as float4
     constexpr int CMAX = CT > CB ? CT : CB;
     constexpr int TS = CMAX * 16 + 4;
@@ -514,6 +587,22 @@ __device__ __forceinline__ void proj_gemm7_body(const ProjArgs &a, float *lds, c
                     *reinterpret_cast<const f32x4 *>(slab + rr * TS + cv * 4);
         }
     };
+#elif R4R_EPI == 1
+    // epilogue: operand roles are swapped (MFMA4), so lane (lrow, q) holds columns 4q .. 4q+3 of table row lrow of
+    // every tile: one float4 store per tile, straight from the accumulator
+    auto store_tile = [&](const f32x4 *row_acc, int ntile, int row_first, int col_tile0) {
+        const int row = row_first + lrow;
+        float *dst = tw.ptab + (size_t)row * PROW + col_tile0 * 16 + q * 4;
+#pragma unroll
+        for (int ni = 0; ni < ntile; ++ni)
+            if (row < count && (col_tile0 + ni) * 16 + q * 4 < PROW) store_row4(dst + ni * 16, row_acc[ni]);
+    };
+#else
+    auto store_tile = [&](const f32x4 *row_acc, int ntile, int, int) {
+#pragma unroll
+        for (int ni = 0; ni < ntile; ++ni) asm volatile("" ::"v"(row_acc[ni]));
+    };
+#endif
 #pragma unroll
     for (int mi = 0; mi < RT; ++mi) store_tile(acct[mi], CT, p.row0 + mi * 16, cbase + CT0);
 #pragma unroll
@@ -565,7 +654,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void proj_gemm_kernel(ProjArgs a) {
         const int row0 = (tile - first[t]) * PM;
         if (threadIdx.x >> 8) proj_gemm_body<PNT - PNH, 2>(a, lds, t, row0);   // waves 4..7: columns 160..303
         else proj_gemm_body<PNH, 3>(a, lds, t, row0);                          // waves 0..3: columns 0..159
-        __syncthreads();                                    // the epilogue's LDS slabs are free again
+        __syncthreads();                                    // every wave is done with the LDS buffers (operand reads, epilogue slabs)
     }
     if (parts > 1 && (int)blockIdx.x < tail * parts) {
         const int tile = full + (int)blockIdx.x / parts, part = (int)blockIdx.x % parts;

@@ -1,0 +1,95 @@
+"""Parity at the sizes bench.py measures (BASELINE.json configs 2 and 5): the tagged dense-Adam sweeps of
+r4r_mf_step and r4r_transnet_step over the FULL ID tables -- 192,403 x 64 / 63,001 x 64 (16.6 M parameters)
+and 10 M x 5 / 1 M x 5 (55 M parameters) next to a 1 M-word table -- against the CPU oracle's dense Adam
+(MF.py:52-58, TransNet.py:74-77,107-110, main.py:94-96: torch.optim.Adam updates every row, touched or not).
+Every element of every table is compared; the oracle takes seconds at these sizes."""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+
+
+@pytest.mark.parametrize('B', [128, 8192])
+def test_mf_step_at_cfg2_cardinalities(B):
+    """cfg2 (MF_dot, Electronics: 192,403 users / 63,001 items, D = 64) at SURVEY 8d's two batch sizes, Zipf ids
+    from the bench's generator, dropout masks drawn on the device and injected into the oracle, two steps:
+    per-step SSE, then all 16.6 M parameters."""
+    import reviews4rec_amd
+    from reviews4rec_amd import synthetic
+    from reviews4rec_amd.engine import MFEngine
+    hp = synthetic.hyper_params_for('cfg2_mfdot_electronics', dropout=0.5)
+    D = hp['latent_size']
+    P = oracle.init_params(hp, seed=23)
+    model = reviews4rec_amd.get_model_class('MF_dot')(hp)
+    model.load_state_dict(P)
+    model = model.to(DEV).train()
+    eng = MFEngine(model, lr=hp['lr'], weight_decay=hp['weight_decay'])
+    gen = synthetic.Generator(hp, seed=3)
+    state = oracle.AdamState()
+    for step in range(2):
+        data, y = gen.batch(B)
+        uid, iid, y = torch.from_numpy(data[5]), torch.from_numpy(data[6]), torch.from_numpy(y)
+        uid[0] = uid[B - 1] = hp['total_users'] - 1                   # the table's last row, at both ends of the batch
+        iid[1] = iid[B - 2] = hp['total_items'] - 1
+        se = eng.train_step([None] * 5 + [uid.to(DEV), iid.to(DEV)], y.to(DEV)).cpu().clone()
+        mult = eng.dropout_multipliers(B).cpu()
+        masks = {'dropout.user': mult[:, :D], 'dropout.item': mult[:, D:]}
+        sse, _ = oracle.train_step(P, [None] * 5 + [uid, iid], y, hp, state, masks=masks)
+        torch.testing.assert_close(se.sum(), torch.tensor(sse), rtol=1e-4, atol=1e-3)
+    sd = model.state_dict()
+    assert sd['user_embedding.weight'].shape == (hp['total_users'] + 1, D)          # MF.py:21
+    for k, v in P.items():
+        torch.testing.assert_close(sd[k].cpu(), v, rtol=1e-5, atol=5e-6, msg=lambda m: k + ': ' + m)
+
+
+def test_transnet_step_at_cfg5_cardinalities():
+    """cfg5 (TransNet++, 10 M users / 1 M items / 1 M words, E = 64, T = 1000, B = 128): one training step of the
+    native engine against the oracle's literal three-optimiser step.  Per-rating source SE, the two auxiliary
+    losses, every dense parameter, and EVERY element of both ID tables (the chunk-tagged sweep: touched rows
+    by the entry waves, the other 10,999,9xx rows by weight decay alone)."""
+    import reviews4rec_amd
+    from reviews4rec_amd import synthetic
+    from reviews4rec_amd.engine import TransNetEngine
+    from test_oracle_golden import ill_conditioned
+    B = 128
+    hp = synthetic.hyper_params_for('cfg5_transnetpp_synthetic', dropout=0.0)
+    V, U, I = hp['vocab'], hp['total_users'], hp['total_items']
+    P = oracle.init_params(hp, vocab_size=V, seed=29)
+    model = reviews4rec_amd.get_model_class('transnet++')(dict(hp, word_vectors=P['target.word2vec.weight'].numpy()))
+    model.load_state_dict(P)
+    model = model.to(DEV).train()
+    eng = TransNetEngine(model, lr=hp['lr'], weight_decay=hp['weight_decay'])
+    data, y = synthetic.Generator(hp, seed=7).batch(B)
+    data = [torch.from_numpy(d) for d in data]
+    y = torch.from_numpy(y)
+    data[5][:3] = data[5][0]                                 # a user named three times, an item twice
+    data[6][4:6] = data[6][4]
+    data[5][B - 1] = U - 1                                    # the tables' last rows
+    data[6][B - 2] = I - 1
+    se = eng.train_step([d.to(DEV) for d in data], y.to(DEV)).cpu().clone()
+    aux = eng.aux([d.to(DEV) for d in data]).cpu()
+    states = dict(source=oracle.AdamState(), source_fm=oracle.AdamState(), target=oracle.AdamState())
+    ref_se, lt, ltr = oracle.transnet_train_step(P, data, y, hp, states)
+    torch.testing.assert_close(se, ref_se, rtol=1e-4, atol=1e-4)
+    assert float(((se - ref_se) ** 2).mean()) < 1e-4
+    torch.testing.assert_close(aux[:, 1].mean(), torch.tensor(lt), rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(aux[:, 2].mean(), torch.tensor(ltr), rtol=1e-4, atol=1e-4)
+    sd = model.state_dict()
+    assert sd['user_embedding.weight'].shape == (U + 2, 5) and sd['item_embedding.weight'].shape == (I + 2, 5)
+    touched = {'user_embedding.weight': data[5].unique(), 'item_embedding.weight': data[6].unique()}
+    for k, v in P.items():
+        mine = sd[k].cpu()
+        if k in touched:
+            # rows no rating names: weight decay alone, the same arithmetic on both sides
+            rest = torch.ones(v.shape[0], dtype=torch.bool)
+            rest[touched[k]] = False
+            torch.testing.assert_close(mine[rest], v[rest], rtol=1e-5, atol=1e-7, msg=lambda m: k + ' (untouched rows): ' + m)
+            torch.testing.assert_close(mine[touched[k]], v[touched[k]], rtol=1e-4, atol=2e-5,
+                                       msg=lambda m: k + ' (touched rows): ' + m)
+        elif not ill_conditioned(k):
+            diff = (mine - v).abs()
+            assert float((diff > 2e-5 + 1e-4 * v.abs()).float().mean()) < 2e-3 and float(diff.max()) < 5e-4, k
