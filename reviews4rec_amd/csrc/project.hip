@@ -20,6 +20,8 @@
 // level, covered by the same parity tests.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "textcnn.h"
 #include "tokens_device.h"
 #include "trace_device.h"
@@ -45,7 +47,7 @@ constexpr int SEG = 128;           // positions per partial (matches the direct 
 #define R4R_STG_PERM 1             // staging threads take rows in the order 0,2,1,3: conflict-free ds_write_b128
 #endif
 #ifndef R4R_EPI
-#define R4R_EPI 1                  // 0: LDS-transposed epilogue; 1: direct float4 stores (operand roles swapped); 2: no stores (timing only)
+#define R4R_EPI 0                  // tile / balanced forms -- 0: LDS-transposed epilogue (measured 1 us faster there); 1: direct float4 stores (operand roles swapped); 2: no stores (timing only, every form)
 #endif
 #ifndef R4R_EPI_NT
 #define R4R_EPI_NT 0               // 1: nontemporal epilogue stores
@@ -615,6 +617,382 @@ __device__ __forceinline__ void proj_gemm7_body(const ProjArgs &a, float *lds, c
     TRACE_STAMP(3)
 }
 
+// ---- 2c. the A-resident form of the balanced decomposition (form 3).
+// What the two forms above leave on the table (profiles/r03a_gemm_variants.txt): a timing-only build that stores
+// nothing runs 51-52 us where the real kernel takes 58 -- every workgroup finishes its K loop at the same moment,
+// 35.5 MB of projected rows are written in one burst, sit dirty in the L2s and are written back when the kernel
+// ends (~6 TB/s), with no MFMA issued meanwhile.  Output can only leave earlier if it is COMPLETE earlier, i.e. if
+// a workgroup runs all of K over part of its tile, then all of K again over the rest -- which the forms above
+// cannot do without staging their operands twice.
+// Here the workgroup's A rows (7 private row tiles + the shared one = 128 rows x all of K, swizzled 64-byte chunk
+// rows: 155,648 B of the CU's 160 KB at E = 300) stay RESIDENT in LDS once staged, and the B operand never passes
+// through LDS: every wave owns whole COLUMN tiles (3 or 2 of the 19: waves w and w + 4 of a SIMD share its 5, SIMD
+// 3 has 4 and adds the shared row tile's units like the balanced form) and loads its W fragments straight from the
+// conv weight in the MFMA operand layout (16 filters x 64 B per instruction -- the shape the staging loads had).
+// The wave then sweeps K once per PASS over a group of row tiles:
+//   pass 1 (row tiles 0 .. R1-1): the K loop of the forms above minus the B staging -- per chunk and thread one
+//           table-row piece global -> register -> LDS (all 128 rows: the later passes' rows arrive here too), R1
+//           operand reads, NCW weight-fragment loads, 4 R1 NCW MFMAs; every chunk has its own LDS region, so the
+//           barriers only publish data (no buffer is ever reused) and one per AR_S chunks is enough;
+//   later passes: no staging and NO barrier -- the waves run free over the resident chunks (measured: ~97 % MFMA
+//           pipe time against ~85 % for the barrier-paced pass); the previous pass's results are stored straight
+//           from the accumulators (float4 per tile: the operand roles are swapped, see MFMA4S) behind the new pass's
+//           first operand requests, WRITE-THROUGH (sc1): they leave the L2 while the MFMAs run instead of waiting
+//           dirty for the end of the kernel.
+// Only the last pass's share of the output is still written in the final burst.  Same K order per output element
+// as the other forms: identical bits.
+// weight operand x table operand: the lane ends up with 4 consecutive COLUMNS of one table row (same fma chain as
+// the other forms' table x weight order: identical bits), which it stores as one float4
+#define MFMA4S(tab, wgt, c) __builtin_amdgcn_mfma_f32_16x16x4f32(wgt, tab, c, 0, 0, 0)
+constexpr int AR_ROWS = 128;                       // LDS rows per K chunk
+constexpr int AR_CHUNK = AR_ROWS * PEC;            // floats per chunk region
+constexpr int AR_MAX_CHUNKS = 20;                  // 20 x 8 KB = 160 KB: E <= 320
+#ifndef R4R_AR_R1
+#define R4R_AR_R1 4                                // row tiles of pass 1, 2 (the rest of the 7: pass 3, may be 0)
+#endif
+#ifndef R4R_AR_R2
+#define R4R_AR_R2 3
+#endif
+#ifndef R4R_AR_S
+#define R4R_AR_S 2                                 // chunks staged per barrier in pass 1 (1, 2 or 4)
+#endif
+#ifndef R4R_AR_AUX
+#define R4R_AR_AUX 0                               // cache bits of the early passes' stores: 0 = plain (measured best), 16 = sc1 (write-through), 2 = nt
+#endif
+#ifndef R4R_AR_AUX_LAST
+#define R4R_AR_AUX_LAST 0                          // ... and of the last pass's
+#endif
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+// 16-byte slot of logical float4 column q in a 64-byte chunk row: q ^ g((row >> 2) & 3), g = [0, 3, 2, 1].  A
+// ds_read_b128 lane group holds rows {a, a+4, a+8, a+12} x two q values per residue a = row & 3 (bank slot =
+// 4 a + physical column): this g makes the four physical columns distinct; a ds_write_b128 lane group (two
+// consecutive rows x 4 columns, 32 banks) is conflict-free by construction.
+__device__ __forceinline__ int ar_col(int row, int q) { return q ^ ((4 - ((row >> 2) & 3)) & 3); }
+
+#ifdef R4R_TRACE
+// (word 5 of the trace record: XCC id in the low byte, the end of the staging pass's prologue above it)
+#define PRO_STAMP if (g_trace && threadIdx.x == 0) g_trace[((size_t)blockIdx.x) * 8 + 5] |= (wall_clock64() << 8);
+#else
+#define PRO_STAMP
+#endif
+
+struct AresCtx {
+    const float *aptr;             // this thread's table row (staging)
+    float *st_dst;                 // ... and where its piece lands inside a chunk region
+    const float *lds;
+    int E, nchunk, c4, q, a_off;
+};
+
+template <int NR, int NCW, int NEX>
+struct AresOps { f32x4 a[NR], b[NCW], sa, eb[NEX > 0 ? NEX : 1]; };
+
+// One pass: row tiles rt0 .. rt0 + NR - 1 (of the 8 resident ones) x this wave's NCW column tiles, plus NEX units of
+// the shared row tile (row tile 7).  S > 0: this pass also brings the A rows in, S chunks per barrier (pass 1).
+// `store_prev(k)`, k = 0 .. NPS - 1 (compile-time), stores one tile of the PREVIOUS pass's results; one is issued per
+// K step of this pass.  A wave's loads and stores share ONE in-order counter (vmcnt): the wait for step c + 1's weight
+// fragments also waits for every store issued before them, so a burst of stores ahead of the loop stalls the wave
+// until the last of them is acknowledged (measured: the whole "overlap" lost), while one store per step has a K
+// step's time to land.  Results stay in acc / ex.
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for(F &&f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
+template <int NR, int NCW, int NEX, int S, int NPS, typename F>
+__device__ __forceinline__ void ares_pass(const AresCtx &x, int rt0, const float *const (&bptr)[NCW],
+                                          const float *const (&ebptr)[NEX > 0 ? NEX : 1], f32x4 (&acc)[NR][NCW],
+                                          f32x4 (&ex)[NEX > 0 ? NEX : 1], F store_prev) {
+    constexpr int NE = NEX > 0 ? NEX : 1, SS = S > 0 ? S : 1;
+    const int E = x.E, nchunk = x.nchunk;
+    f32x4 ar[SS];
+    auto ld_a = [&](int s, f32x4 (&r)[SS]) {                 // super-chunk s = chunks s S .. s S + S - 1 (past the end: the last chunk again)
+#pragma unroll
+        for (int k = 0; k < SS; ++k) {
+            const int c = min(s * SS + k, nchunk - 1);
+            r[k] = *reinterpret_cast<const f32x4 *>(x.aptr + min(c * PEC + x.c4 * 4, E - 4));
+        }
+    };
+    auto st_a = [&](int s, const f32x4 (&r)[SS]) {           // the K tail (E % 16) is zeroed on this side
+#pragma unroll
+        for (int k = 0; k < SS; ++k) {
+            const int c = min(s * SS + k, nchunk - 1);
+            const bool keep = c * PEC + x.c4 * 4 < E;
+            f32x4 v;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = keep ? r[k][i] : 0.f;
+            *reinterpret_cast<f32x4 *>(x.st_dst + c * AR_CHUNK) = v;
+        }
+    };
+    auto req_b = [&](int c, AresOps<NR, NCW, NEX> &o) {      // weight fragments: global -> registers
+        const int e = min(min(c, nchunk - 1) * PEC + x.q * 4, E - 4);
+#pragma unroll
+        for (int j = 0; j < NCW; ++j) o.b[j] = *reinterpret_cast<const f32x4 *>(bptr[j] + e);
+        if (NEX > 0) {
+#pragma unroll
+            for (int j = 0; j < NE; ++j) o.eb[j] = *reinterpret_cast<const f32x4 *>(ebptr[j] + e);
+        }
+    };
+    auto req_a = [&](int c, AresOps<NR, NCW, NEX> &o) {      // table fragments: resident LDS -> registers
+        const float *ab = x.lds + min(c, nchunk - 1) * AR_CHUNK + x.a_off;
+#pragma unroll
+        for (int i = 0; i < NR; ++i) o.a[i] = *reinterpret_cast<const f32x4 *>(ab + (rt0 + i) * 16 * PEC);
+        if (NEX > 0) o.sa = *reinterpret_cast<const f32x4 *>(ab + G7_ROWS * 16 * PEC);
+    };
+    auto mfma = [&](const AresOps<NR, NCW, NEX> &o) {
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+#pragma unroll
+            for (int i = 0; i < NR; ++i)
+#pragma unroll
+                for (int j = 0; j < NCW; ++j) acc[i][j] = MFMA4S(o.a[i][kk], o.b[j][kk], acc[i][j]);
+            if (NEX > 0) {
+#pragma unroll
+                for (int j = 0; j < NE; ++j) ex[j] = MFMA4S(o.sa[kk], o.eb[j][kk], ex[j]);
+            }
+        }
+    };
+#pragma unroll
+    for (int i = 0; i < NR; ++i)
+#pragma unroll
+        for (int j = 0; j < NCW; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < NE; ++j) ex[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    AresOps<NR, NCW, NEX> o0, o1;
+    if (S > 0) {
+        ld_a(0, ar);
+        req_b(0, o0);                                        // weight fragments of chunk 0: in flight under the staging
+        st_a(0, ar);
+        ld_a(1, ar);
+        __syncthreads();                                     // super-chunk 0 in LDS
+        req_a(0, o0);
+        st_a(1, ar);
+        ld_a(2, ar);
+        PRO_STAMP
+    } else {
+        req_b(0, o0);
+        req_a(0, o0);
+    }
+    // chunk c: operands `cur` in registers.  HEAD (first chunk of super-chunk s, staging passes): behind the barrier
+    // super-chunk s + 1 is visible, the staging registers (super-chunk s + 2, requested a super-step ago) go to LDS
+    // and super-chunk s + 3 is requested.  One memory instruction behind every few MFMAs, like the forms above.
+    auto step = [&](int c, const AresOps<NR, NCW, NEX> &cur, AresOps<NR, NCW, NEX> &nxt, auto headc, auto storec) {
+        constexpr bool head = decltype(headc)::value;
+        constexpr int store_k = decltype(storec)::value;        // >= 0: this step also issues store_prev(store_k)
+        // (the table-row loads go out BEHIND the weight-fragment loads: the next step waits for those with a
+        // counted vmcnt, which an older, slower load -- table rows come from the Infinity Cache or HBM -- would hold up)
+        if (S > 0 && head) __syncthreads();
+        req_b(c + 1, nxt);
+        req_a(c + 1, nxt);
+        if constexpr (store_k >= 0) store_prev(storec);
+        if (S > 0 && head) {
+            st_a(c / SS + 2, ar);
+            ld_a(c / SS + 3, ar);
+        }
+        mfma(cur);
+        constexpr int NRD = NR + (NEX > 0 ? 1 : 0), NLD = NCW + NEX + ((S > 0 && head) ? SS : 0), NWR = (S > 0 && head) ? SS : 0;
+        constexpr int NM = 4 * (NR * NCW + NEX);
+        constexpr int NMEM_MAX = NR + 1 + NCW + NEX + 2 * SS + 1;
+        constexpr int GAP = NM / NMEM_MAX >= 4 ? 4 : (NM / NMEM_MAX >= 1 ? NM / NMEM_MAX : 1);
+#pragma unroll
+        for (int i = 0; i < NCW + NEX; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, GAP, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < NR + (NEX > 0 ? 1 : 0); ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, GAP, 0);
+        }
+        if constexpr (store_k >= 0) {
+            __builtin_amdgcn_sched_group_barrier(0x040, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, GAP, 0);
+        }
+        if (S > 0 && head) {
+#pragma unroll
+            for (int i = 0; i < SS; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, GAP, 0);
+            }
+#pragma unroll
+            for (int i = 0; i < SS; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, GAP, 0);
+            }
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, NM - GAP * (NRD + NLD + NWR + (store_k >= 0 ? 1 : 0)), 0);
+    };
+    // U chunks per loop iteration: whole super-chunks, an even number of them (the operand sets alternate)
+    using T = std::true_type;
+    using H1 = std::bool_constant<SS == 1>;                  // is the second chunk of a pair the head of a super-chunk?
+    using Fa = std::false_type;
+    using NoSt = std::integral_constant<int, -1>;
+    constexpr int U = SS >= 2 ? SS : 2;
+    static_assert(SS == 1 || SS == 2 || SS == 4, "chunks per barrier");
+    static_assert(NPS == 0 || S == 0, "the staging pass has no previous pass to store");
+    int c = 0;
+    if constexpr (NPS > 0) {
+        // the first NPS steps, peeled: step k carries store k of the previous pass (the accumulator index must be a
+        // compile-time constant).  Launches with fewer chunks than stores (small E) issue them all up front.
+        constexpr int NPE = (NPS + 1) & ~1;                  // an even count: the loop below starts on operand set 0
+        if (nchunk >= NPE) {
+            static_for<0, NPE>([&](auto kc) {
+                constexpr int k = decltype(kc)::value;
+                using St = std::integral_constant<int, (k < NPS ? k : -1)>;
+                if constexpr (k % 2 == 0) step(k, o0, o1, Fa{}, St{});
+                else step(k, o1, o0, Fa{}, St{});
+            });
+            c = NPE;
+        } else {
+            static_for<0, NPS>([&](auto kc) { store_prev(kc); });
+        }
+    }
+    for (; c + U <= nchunk; c += U) {
+        step(c, o0, o1, T{}, NoSt{});
+        step(c + 1, o1, o0, H1{}, NoSt{});
+        if constexpr (U == 4) {
+            step(c + 2, o0, o1, Fa{}, NoSt{});
+            step(c + 3, o1, o0, Fa{}, NoSt{});
+        }
+    }
+    // the last, partial group (peeled: an exit inside the loop body makes hipcc wait vmcnt(0) at its head)
+    if (c < nchunk) step(c, o0, o1, T{}, NoSt{});
+    if constexpr (U == 4) {
+        if (c + 1 < nchunk) step(c + 1, o1, o0, Fa{}, NoSt{});
+        if (c + 2 < nchunk) step(c + 2, o0, o1, Fa{}, NoSt{});
+    }
+}
+
+// NCW: column tiles of this wave (from ct0); NEX: units of the shared row tile it adds (SIMD 3: 4 | 3, from eoff), in
+// pass EXP (SIMD 3's two waves take theirs in DIFFERENT passes: with R1 = 4 the SIMDs then carry 20 / 20 / 20 / 16 + 4
+// tiles in pass 1 and 15 / 15 / 15 / 12 + 3 in pass 2 -- all of them in the last pass made SIMD 3 its pole, 19 : 15)
+template <int NCW, int NEX, int EXP = 2>
+__device__ __forceinline__ void proj_gemm_ares_body(const ProjArgs &a, float *lds, const Gemm7Plan &p, int ct0, int eoff) {
+    constexpr int NE = NEX > 0 ? NEX : 1;
+    constexpr int R1 = R4R_AR_R1, R2 = R4R_AR_R2, R3 = G7_ROWS - R1 - R2, R3A = R3 > 0 ? R3 : 1;
+    static_assert(R1 >= 1 && R2 >= 1 && R3 >= 0, "pass split");
+    const ProjTower &tw = a.t[p.tower];
+    const int count = tw.count[0];
+    TRACE_STAMP(0)
+#ifdef R4R_TRACE
+    if (g_trace && threadIdx.x == 0) {
+        unsigned long long *tr = g_trace + ((size_t)blockIdx.x) * 8;
+        tr[4] = __builtin_amdgcn_s_getreg((31 << 11) | 4);
+        tr[5] = __builtin_amdgcn_s_getreg((31 << 11) | 20) & 0xf;
+        tr[6] = 1;
+    }
+#endif
+    const int tid = threadIdx.x, lane = tid & 63, lrow = lane & 15;
+    AresCtx x;
+    x.lds = lds; x.E = a.E; x.nchunk = a.nchunk;
+    x.q = lane >> 4;
+    x.a_off = lrow * PEC + ar_col(lrow, x.q) * 4;
+    // staging role: float4 column c4 of LDS row tid >> 2 (rows 0..111 private, 112..127 the shared row tile)
+    x.c4 = tid & 3;
+    const int srow = tid >> 2;
+    int grow = srow < G7_ROWS * 16 ? p.row0 + srow : (p.sh_row0 < 0 ? 0 : p.sh_row0 + srow - G7_ROWS * 16);
+    grow = grow < count ? grow : count - 1;
+    x.aptr = a.table + (long)tw.list[grow] * a.E;
+    x.st_dst = lds + srow * PEC + ar_col(srow, x.c4) * 4;
+    // weight fragments: lane (lrow, q) of column tile ct holds W[f][j][16 c + 4 q ..], n = 16 ct + lrow = 100 j + f
+    const float *__restrict__ conv_w = tw.conv_w;
+    const float *bptr[NCW], *ebptr[NE];
+    int ecol[NE];
+    auto wrow = [&](int ct) {
+        const int n = ct * 16 + lrow;
+        const int j = n / PF, f = n - j * PF;
+        return conv_w + (n < PROW ? ((long)f * 3 + j) * a.E : 0);       // padding columns re-read W[0][0]: never stored
+    };
+#pragma unroll
+    for (int j = 0; j < NCW; ++j) bptr[j] = wrow(ct0 + j);
+#pragma unroll
+    for (int j = 0; j < NE; ++j) {
+        ecol[j] = min(p.sh_c0 + eoff + j, PNT - 1);                        // beyond the assignment: computed, never stored
+        ebptr[j] = wrow(ecol[j]);
+    }
+    // Stores go through a buffer descriptor over this tower's projected rows (wave-uniform words), so that they can
+    // carry cache bits; 32-bit byte offsets: the launcher keeps form 3 to outputs under 2 GB.
+    const unsigned long long pbase = reinterpret_cast<unsigned long long>(tw.ptab);
+    const unsigned plo = __builtin_amdgcn_readfirstlane((unsigned)pbase), phi = __builtin_amdgcn_readfirstlane((unsigned)(pbase >> 32));
+    float *pt = reinterpret_cast<float *>(((unsigned long long)phi << 32) | plo);
+    [[maybe_unused]] const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(pt, 0, __builtin_amdgcn_readfirstlane(count) * (PROW * 4), 0x00020000);
+    auto store_tile = [&](const f32x4 &v, int row_first, int ct, auto AUXc, bool ok = true) {
+#if R4R_EPI == 2
+        asm volatile("" ::"v"(v));
+#else
+        constexpr int AUX = decltype(AUXc)::value;
+        const int row = row_first + lrow, col = ct * 16 + x.q * 4;
+        // branch-free (a branch would end the K step's scheduling region): rows past `count` and the padding columns
+        // get an offset outside the descriptor, which the hardware drops
+        const int off = (ok && row < count && col < PROW) ? (row * PROW + col) * 4 : 0x7ffffff0;
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsrc, off, 0, AUX);
+#endif
+    };
+    using AuxEarly = std::integral_constant<int, R4R_AR_AUX>;
+    using AuxLast = std::integral_constant<int, R4R_AR_AUX_LAST>;
+    const float *const nonep[1] = {conv_w};
+    f32x4 acc1[R1][NCW], acc2[R2][NCW], acc3[R3A][NCW], none[1], ex[NE];
+    constexpr int NEX1 = EXP == 1 ? NEX : 0, NEXL = EXP == 1 ? 0 : NEX;
+    auto nothing = [](auto) {};
+#ifdef R4R_TRACE
+    const unsigned long long clk0 = __builtin_readcyclecounter();
+#endif
+    if constexpr (NEX1 > 0) ares_pass<R1, NCW, NEX1, R4R_AR_S, 0>(x, 0, bptr, ebptr, acc1, ex, nothing);
+    else ares_pass<R1, NCW, 0, R4R_AR_S, 0>(x, 0, bptr, nonep, acc1, none, nothing);
+    TRACE_STAMP(1)
+#ifdef R4R_TRACE
+    const unsigned long long clk1 = __builtin_readcyclecounter();
+    if (g_trace && threadIdx.x == 0) g_trace[((size_t)blockIdx.x) * 8 + 7] = clk1 - clk0;    // shader cycles of pass 1
+#endif
+    __syncthreads();                                         // every chunk of every row is in LDS: the waves run free from here
+    auto store_ex = [&](int j, auto AUXc) {
+        store_tile(ex[j], p.sh_row0, ecol[j], AUXc, eoff + j < p.sh_n && p.sh_row0 >= 0);
+    };
+    // store k of pass 1's results: tile (k / NCW, k % NCW), then the shared-tile units
+    constexpr int NS1 = R1 * NCW + NEX1;
+    auto store1 = [&](auto kc) {
+        constexpr int k = decltype(kc)::value;
+        if constexpr (k < R1 * NCW) store_tile(acc1[k / NCW][k % NCW], p.row0 + (k / NCW) * 16, ct0 + k % NCW, AuxEarly{});
+        else store_ex(k - R1 * NCW, AuxEarly{});
+    };
+    if constexpr (R3 == 0) {
+        if constexpr (NEXL > 0) ares_pass<R2, NCW, NEXL, 0, NS1>(x, R1, bptr, ebptr, acc2, ex, store1);
+        else ares_pass<R2, NCW, 0, 0, NS1>(x, R1, bptr, nonep, acc2, none, store1);
+        TRACE_STAMP(2)
+#ifdef R4R_TRACE
+        if (g_trace && threadIdx.x == 0)                     // ... and of pass 2 (word 6: bit 0 = active)
+            g_trace[((size_t)blockIdx.x) * 8 + 6] = ((__builtin_readcyclecounter() - clk1) << 1) | 1;
+#endif
+#pragma unroll
+        for (int i = 0; i < R2; ++i)
+#pragma unroll
+            for (int j = 0; j < NCW; ++j) store_tile(acc2[i][j], p.row0 + (R1 + i) * 16, ct0 + j, AuxLast{});
+    } else {
+        ares_pass<R2, NCW, 0, 0, NS1>(x, R1, bptr, nonep, acc2, none, store1);
+        auto store2 = [&](auto kc) {
+            constexpr int k = decltype(kc)::value;
+            store_tile(acc2[k / NCW][k % NCW], p.row0 + (R1 + k / NCW) * 16, ct0 + k % NCW, AuxEarly{});
+        };
+        if constexpr (NEXL > 0) ares_pass<R3A, NCW, NEXL, 0, R2 * NCW>(x, R1 + R2, bptr, ebptr, acc3, ex, store2);
+        else ares_pass<R3A, NCW, 0, 0, R2 * NCW>(x, R1 + R2, bptr, nonep, acc3, none, store2);
+        TRACE_STAMP(2)
+#pragma unroll
+        for (int i = 0; i < R3A; ++i)
+#pragma unroll
+            for (int j = 0; j < NCW; ++j) store_tile(acc3[i][j], p.row0 + (R1 + R2 + i) * 16, ct0 + j, AuxLast{});
+    }
+    if constexpr (NEXL > 0) {
+#pragma unroll
+        for (int j = 0; j < NE; ++j) store_ex(j, AuxLast{});
+    }
+    TRACE_STAMP(3)
+}
+
 __global__ __launch_bounds__(GEMM_THREADS) void proj_gemm_kernel(ProjArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float *lds = reinterpret_cast<float *>(smem);
@@ -623,11 +1001,22 @@ __global__ __launch_bounds__(GEMM_THREADS) void proj_gemm_kernel(ProjArgs a) {
     for (int t = 0; t < a.ntower; ++t) first[t + 1] = first[t] + (a.t[t].count[0] + PM - 1) / PM;
     // (a launch whose tiles fill at most half of the grid is faster in column parts -- below -- than in the
     // balanced form, which keeps 112 rows per workgroup whatever the count)
-    if (a.balanced == 1 && first[a.ntower] * 2 > (int)gridDim.x) {
+    if ((a.balanced == 1 || a.balanced == 3) && first[a.ntower] * 2 > (int)gridDim.x) {
         Gemm7Plan p;
         if (gemm7_plan(a, (int)blockIdx.x, (int)gridDim.x, p)) {
             if (p.tower < 0) return;                         // uniform: this workgroup has no rows
             const int wave = threadIdx.x >> 6;
+            if (a.balanced == 3) {                           // A-resident form: waves w / w + 4 take 3 / 2 column tiles of SIMD w & 3's five
+                const int simd = wave & 3;
+                if (wave < 4) {
+                    if (simd == 3) proj_gemm_ares_body<2, 4, 1>(a, lds, p, 15, 0);
+                    else proj_gemm_ares_body<3, 0>(a, lds, p, simd * 5, 0);
+                } else {
+                    if (simd == 3) proj_gemm_ares_body<2, 3>(a, lds, p, 17, 4);
+                    else proj_gemm_ares_body<2, 0>(a, lds, p, simd * 5 + 3, 0);
+                }
+                return;
+            }
             if (wave < 4) {                                  // HALF 1 (17 tiles), three B rows to stage
                 if ((wave & 3) == 3) proj_gemm7_body<4, 1, 3, 3>(a, lds, p);
                 else proj_gemm7_body<5, 1, 0, 3>(a, lds, p);
@@ -811,6 +1200,10 @@ int proj_tiles(int T) { return (T + 2 + SEG - 1) / SEG; }
 int64_t proj_row_capacity(int64_t N, int T, int64_t V) { return (N * T < V) ? N * T : V; }
 size_t proj_ptab_floats(int64_t N, int T, int64_t V) { return (size_t)proj_row_capacity(N, T, V) * PROW; }
 
+#ifndef R4R_GEMM_DEFAULT
+#define R4R_GEMM_DEFAULT 3
+#endif
+constexpr int GEMM_DEFAULT_FORM = R4R_GEMM_DEFAULT;
 static int g_gemm_balanced = -1;       // -1: from the environment (R4R_GEMM=tile | whole pin the tile form) on first use
 static int g_gemm_math = 0;            // 0: fp32 MFMA (the default and the headline); 1: fp16-split operands (project_f16.hip)
 static float g_table_maxabs = 0.f;     // max |table|, given with mode 1 (the table is frozen: the host computes it once)
@@ -830,9 +1223,11 @@ static ProjArgs make_args(const float *table, int64_t V, const ProjTower *tw, in
     a.ntower = ntower;
     if (g_gemm_balanced < 0) {
         const char *e = getenv("R4R_GEMM");
-        g_gemm_balanced = (e && e[0] == 't') ? 0 : ((e && e[0] == 'w') ? 2 : 1);
+        g_gemm_balanced = (e && e[0] == 't') ? 0 : ((e && e[0] == 'w') ? 2 : ((e && e[0] == 'a') ? 3 : ((e && e[0] == 'b') ? 1 : GEMM_DEFAULT_FORM)));
     }
     a.balanced = g_gemm_balanced;
+    // the A-resident form holds all of K in LDS (E <= 320) and addresses its output with 32-bit byte offsets
+    if (a.balanced == 3 && (a.nchunk > AR_MAX_CHUNKS || (int64_t)a.cap * PROW * 4 >= (1ll << 31))) a.balanced = 1;
     return a;
 }
 
@@ -865,7 +1260,7 @@ int textcnn_proj_compute_launch(const float *table, int64_t V, const ProjTower *
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(proj_gemm_kernel),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES);
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, AR_MAX_CHUNKS * AR_CHUNK * 4);
         attr_set = true;
     }
     const ProjArgs a = make_args(table, V, tw, ntower, N, T, E, F);
@@ -879,7 +1274,9 @@ int textcnn_proj_compute_launch(const float *table, int64_t V, const ProjTower *
         // persistent: one workgroup per CU at most (86 KB of LDS each), fewer when the row capacity is small
         int64_t wgs = ((int64_t)a.cap + G7_ROWS * 16 - 1) / (G7_ROWS * 16) * ntower;
         if (wgs > G7_WGS) wgs = G7_WGS;
-        proj_gemm_kernel<<<dim3((unsigned)wgs), GEMM_THREADS, GEMM_LDS_BYTES, st>>>(a);
+        const int ares_bytes = a.nchunk * AR_CHUNK * 4;     // form 3 keeps every K chunk of its 128 rows resident
+        const int lds_bytes = (a.balanced == 3 && ares_bytes > GEMM_LDS_BYTES) ? ares_bytes : GEMM_LDS_BYTES;
+        proj_gemm_kernel<<<dim3((unsigned)wgs), GEMM_THREADS, lds_bytes, st>>>(a);
     }
     {
         ScopedTiming tm(R4R_TIMING_PROJ_GATHER, st);

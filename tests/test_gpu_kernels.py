@@ -422,10 +422,14 @@ def test_projection_gemm_balanced_form_is_bit_identical_to_the_tile_form(V):
         p1, a1 = p1.clone(), a1.clone()
         lib.r4r_gemm_form(2)
         p2, a2 = ops.textcnn_fwd_raw(*args)
+        p2, a2 = p2.clone(), a2.clone()
+        lib.r4r_gemm_form(3)                                # the A-resident form of the balanced plan (E = 128: 8 resident chunks)
+        p3, a3 = ops.textcnn_fwd_raw(*args)
     finally:
         lib.r4r_gemm_form(-1)
     assert torch.equal(p0, p1) and torch.equal(a0, a1)
     assert torch.equal(p0, p2) and torch.equal(a0, a2)
+    assert torch.equal(p0, p3) and torch.equal(a0, a3)
     if V <= 3000:
         ref_pooled, ref_arg, y = conv_pool_reference(idx, table, w, b)
         torch.testing.assert_close(p1.cpu(), ref_pooled, rtol=1e-5, atol=1e-6)

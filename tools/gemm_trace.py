@@ -41,7 +41,7 @@ for i in range(6):
 torch.cuda.synchronize()
 tr = trace.cpu().numpy().reshape(NWG, 8)
 launched = tr[:, 0] > 0
-act = launched & (tr[:, 6] == 1)
+act = launched & ((tr[:, 6] & 1) == 1)
 t0 = tr[launched, 0].min()
 us = lambda x: (x - t0) / 100.0
 print('workgroups launched %d, active %d' % (launched.sum(), act.sum()))
@@ -54,10 +54,17 @@ print('loop: min %.2f med %.2f max %.2f' % ((loop - staged).min(), np.median(loo
 print('epilogue: med %.2f max %.2f' % (np.median(end - loop), (end - loop).max()))
 print('active end: min %.2f med %.2f max %.2f' % (end.min(), np.median(end), end.max()))
 w7 = a[:, 7]
-if w7.any():
+if (a[:, 6] >> 1).any():                                   # A-resident form: word 7 = cycles of pass 1, word 6 >> 1 = of pass 2
+    m1, m2 = w7 / (staged - st), (a[:, 6] >> 1) / (loop - staged)
+    print('A-resident form: pass 1 (start->stamp 1) clock med %.0f MHz, cycles med %d; pass 2 clock med %.0f MHz, cycles med %d'
+          % (np.median(m1), np.median(w7), np.median(m2), np.median(a[:, 6] >> 1)))
+elif w7.any():
     mhz = w7 / (loop - staged)
     print('shader clock over the loop: med %.0f MHz (min %.0f, max %.0f); cycles med %d' % (np.median(mhz), mhz.min(), mhz.max(), np.median(w7)))
 hw = a[:, 4]; xcc = a[:, 5] & 0xf
+if (a[:, 5] >> 8).any():
+    pro = ((a[:, 5] >> 8) - t0) / 100.0 - st
+    print('A-resident form: prologue of pass 1 (start -> first operands read): med %.2f max %.2f us' % (np.median(pro), pro.max()))
 cu = (hw >> 8) & 0xf; sh = (hw >> 12) & 1; se = (hw >> 13) & 0x7
 cuid = xcc * 1000 + se * 100 + sh * 10 + cu
 ids, cnt = np.unique(cuid, return_counts=True)
