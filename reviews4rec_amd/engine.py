@@ -42,6 +42,40 @@ def apply_gemm_math(table, conv_weights=()):
     return mode
 
 
+def pad4(E):
+    return (int(E) + 3) // 4 * 4
+
+
+def padded_word_table(table):
+    """The HIP kernels read table rows and conv-weight windows as float4: rows must be 16-byte aligned.  The
+    reference accepts any ``word_embed_size`` (hyper_params.py:64, common_pytorch_models.py:15; GloVe-50 is a
+    common choice), so a table whose width is not a multiple of 4 gets a zero-padded device copy -- it is frozen
+    (Embedding.from_pretrained, DeepCoNN.py:15), one copy at engine construction is all it takes -- and the conv
+    weights live in the engines' flat buffers with the same padded width, their Parameters being the [..., :E]
+    views.  Exact: every added term of the convolution is 0 * 0; the pad columns of the weights get a zero
+    gradient (g * 0) and a zero weight-decay term, so Adam leaves them at exactly 0."""
+    V, E = table.shape
+    E4 = pad4(E)
+    if E4 == E:
+        return table
+    out = torch.zeros((V, E4), dtype=table.dtype, device=table.device)
+    out[:, :E].copy_(table.detach())
+    return out
+
+
+def slot_view(flat, o, s, shape, E_model, E):
+    """View of flat[o : o + s] with a parameter's shape; conv weights ([F, 1, 3, E_model]) of a padded engine are
+    the leading E_model columns of their [F, 1, 3, E] slot."""
+    shape = tuple(shape)
+    if E != E_model and len(shape) == 4 and shape[-1] == E_model:
+        n = 1
+        for d in shape[:-1]:
+            n *= d
+        if n * E == s:
+            return flat[o:o + s].view(*shape[:-1], E)[..., :E_model]
+    return flat[o:o + s].view(shape)
+
+
 class _ConvRule:
     """The engines' automatic choice between the two convolution algorithms (conv_algo = 0).
 
@@ -129,6 +163,8 @@ class DeepCoNNEngine(_ConvRule):
             raise RuntimeError('DeepCoNNEngine: move the model to a ROCm device first; the HIP path has no '
                                'CPU fallback')
         self.dev = self.table.device
+        self.E_model = int(self.table.shape[1])
+        self.table = padded_word_table(self.table)           # word_embed_size % 4 != 0: zero-padded copy (exact)
         self.V, self.E = self.table.shape
         self.L = hp['latent_size']
         self.gemm_math = apply_gemm_math(self.table, self._conv_weights())
@@ -144,8 +180,8 @@ class DeepCoNNEngine(_ConvRule):
         self.offsets, self.sizes, self.total = list(off), list(size), int(total.value)
         self.flat_p = torch.zeros(self.total, dtype=torch.float32, device=self.dev)
         for p, o, s in zip(self.slots, self.offsets, self.sizes):
-            assert p.numel() == s, (tuple(p.shape), s)
-            view = self.flat_p[o:o + s].view(p.shape)
+            view = slot_view(self.flat_p, o, s, p.shape, self.E_model, self.E)
+            assert view.shape == p.shape and (p.numel() == s or self.E != self.E_model), (tuple(p.shape), s)
             view.copy_(p.data)
             p.data = view                       # the Parameter now aliases the flat buffer
         self.flat_g = torch.zeros_like(self.flat_p)
@@ -413,14 +449,14 @@ class DeepCoNNEngine(_ConvRule):
         names = ['user_conv.convs.0.weight', 'user_conv.convs.0.bias', 'user_conv.fc.weight', 'user_conv.fc.bias',
                  'item_conv.convs.0.weight', 'item_conv.convs.0.bias', 'item_conv.fc.weight', 'item_conv.fc.bias',
                  'fm.V', 'fm.lin.weight', 'fm.lin.bias', 'global_bias']
-        return {k: self.flat_g[o:o + s].view(p.shape) for k, p, o, s in
+        return {k: slot_view(self.flat_g, o, s, p.shape, getattr(self, 'E_model', 0), getattr(self, 'E', 0)) for k, p, o, s in
                 zip(names, self.slots, self.offsets, self.sizes)}
 
     def moments(self):
         names = list(self.grads())
-        return ({k: self.flat_m[o:o + s].view(p.shape) for k, p, o, s in
+        return ({k: slot_view(self.flat_m, o, s, p.shape, getattr(self, 'E_model', 0), getattr(self, 'E', 0)) for k, p, o, s in
                  zip(names, self.slots, self.offsets, self.sizes)},
-                {k: self.flat_v[o:o + s].view(p.shape) for k, p, o, s in
+                {k: slot_view(self.flat_v, o, s, p.shape, getattr(self, 'E_model', 0), getattr(self, 'E', 0)) for k, p, o, s in
                  zip(names, self.slots, self.offsets, self.sizes)})
 
 
@@ -650,6 +686,8 @@ class NarreEngine(_ConvRule):
         if not self.table.is_cuda:
             raise RuntimeError('NarreEngine: move the model to a ROCm device first; the HIP path has no CPU fallback')
         self.dev = self.table.device
+        self.E_model = int(self.table.shape[1])
+        self.table = padded_word_table(self.table)           # word_embed_size % 4 != 0: zero-padded copy (exact)
         self.V, self.E = self.table.shape
         self.L = int(hp['latent_size'])
         self.gemm_math = apply_gemm_math(self.table, self._conv_weights())
@@ -663,8 +701,8 @@ class NarreEngine(_ConvRule):
         self.offsets, self.sizes, self.total = list(off), list(size), int(total.value)
         self.flat_p = torch.zeros(self.total, dtype=torch.float32, device=self.dev)
         for p, o, s in zip(self.slots, self.offsets, self.sizes):
-            assert p.numel() == s, (tuple(p.shape), s)
-            view = self.flat_p[o:o + s].view(p.shape)
+            view = slot_view(self.flat_p, o, s, p.shape, self.E_model, self.E)
+            assert view.shape == p.shape and (p.numel() == s or self.E != self.E_model), (tuple(p.shape), s)
             view.copy_(p.data)
             p.data = view                       # the Parameter now aliases the flat buffer
         self.flat_g = torch.zeros_like(self.flat_p)
@@ -929,7 +967,7 @@ class NarreEngine(_ConvRule):
     def grads(self, data):
         """Gradients of the LAST training step by reference parameter name; the ID-table / bias
         gradients are rebuilt from their compact rows (introspection for tests)."""
-        out = {k: self.flat_g[o:o + s].view(p.shape) for k, p, o, s in
+        out = {k: slot_view(self.flat_g, o, s, p.shape, getattr(self, 'E_model', 0), getattr(self, 'E', 0)) for k, p, o, s in
                zip(self.NAMES, self.slots, self.offsets, self.sizes)}
         B = data[5].numel()
         g = self._ws_view(data, 5, 1)[:, 0]
@@ -940,8 +978,8 @@ class NarreEngine(_ConvRule):
         return out
 
     def moments(self):
-        m = {k: self.flat_m[o:o + s].view(p.shape) for k, p, o, s in zip(self.NAMES, self.slots, self.offsets, self.sizes)}
-        v = {k: self.flat_v[o:o + s].view(p.shape) for k, p, o, s in zip(self.NAMES, self.slots, self.offsets, self.sizes)}
+        m = {k: slot_view(self.flat_m, o, s, p.shape, getattr(self, 'E_model', 0), getattr(self, 'E', 0)) for k, p, o, s in zip(self.NAMES, self.slots, self.offsets, self.sizes)}
+        v = {k: slot_view(self.flat_v, o, s, p.shape, getattr(self, 'E_model', 0), getattr(self, 'E', 0)) for k, p, o, s in zip(self.NAMES, self.slots, self.offsets, self.sizes)}
         m.update(zip(self.ROW_NAMES, self.rows_m))
         v.update(zip(self.ROW_NAMES, self.rows_v))
         return m, v
@@ -1037,7 +1075,7 @@ class DeepCoNNPPEngine(NarreEngine):
             self.lr, self.betas[0], self.betas[1], self.eps, self.wd, int(adam_step), _lib.current_stream())
 
     def grads(self, data):
-        out = {k: self.flat_g[o:o + s].view(p.shape) for k, p, o, s in
+        out = {k: slot_view(self.flat_g, o, s, p.shape, getattr(self, 'E_model', 0), getattr(self, 'E', 0)) for k, p, o, s in
                zip(self.NAMES, self.slots, self.offsets, self.sizes)}
         f, n, R, T = self._fields(data)
         off = self._ws_offset(n, R, T, 5)
@@ -1161,7 +1199,7 @@ class TransNetEngine(NarreEngine):
         return super().predict(data, y)
 
     def grads(self, data):
-        out = {k: self.flat_g[o:o + s].view(p.shape) for k, p, o, s in
+        out = {k: slot_view(self.flat_g, o, s, p.shape, getattr(self, 'E_model', 0), getattr(self, 'E', 0)) for k, p, o, s in
                zip(self.NAMES, self.slots, self.offsets, self.sizes)}
         if self.plus:
             f, n, R, T = self._fields(data)
@@ -1395,7 +1433,7 @@ class IdNetEngine:
     def grads(self, data):
         """Reference-named gradients of the LAST training step on `data`: the dense ones are views of the
         flat buffer, the ID tables / bias vectors are rebuilt from their compact rows."""
-        out = {k: self.flat_g[o:o + s].view(p.shape) for k, p, o, s in
+        out = {k: slot_view(self.flat_g, o, s, p.shape, getattr(self, 'E_model', 0), getattr(self, 'E', 0)) for k, p, o, s in
                zip(self.names, self.slots, self.offsets, self.sizes) if k is not None}
         uid, iid = data[5].reshape(-1), data[6].reshape(-1)
         B = uid.numel()
@@ -1408,9 +1446,9 @@ class IdNetEngine:
         return out
 
     def moments(self):
-        m = {k: self.flat_m[o:o + s].view(p.shape) for k, p, o, s in
+        m = {k: slot_view(self.flat_m, o, s, p.shape, getattr(self, 'E_model', 0), getattr(self, 'E', 0)) for k, p, o, s in
              zip(self.names, self.slots, self.offsets, self.sizes) if k is not None}
-        v = {k: self.flat_v[o:o + s].view(p.shape) for k, p, o, s in
+        v = {k: slot_view(self.flat_v, o, s, p.shape, getattr(self, 'E_model', 0), getattr(self, 'E', 0)) for k, p, o, s in
              zip(self.names, self.slots, self.offsets, self.sizes) if k is not None}
         for t, name in enumerate(self.TABLE_NAMES[self.kind] + ['user_bias', 'item_bias']):
             i = t if t < len(self.tables) else 4 + t - len(self.tables)

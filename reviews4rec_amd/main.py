@@ -183,8 +183,7 @@ def native_step_limits(hyper_params, world=1):
         return 'no fused native step for model_type %r' % (mt,)
     if L > 32:
         return 'latent_size %d > 32' % L
-    if E % 4 != 0:
-        return 'word_embed_size %d is not a multiple of 4' % E
+    E = (E + 3) // 4 * 4            # the engines pad rows to a multiple of 4 floats (engine.padded_word_table: exact)
     if 3 * E // 4 > 512:
         return 'word_embed_size %d > 680' % E
     if mt == 'NARRE':
@@ -207,8 +206,7 @@ def module_path_limits(hyper_params):
     L = int(hyper_params.get('latent_size', 10))
     E = int(hyper_params.get('word_embed_size', 64))
     if mt in ('deepconn', 'deepconn++', 'NARRE', 'transnet', 'transnet++'):
-        if E % 4 != 0:
-            return 'word_embed_size %d is not a multiple of 4' % E
+        E = (E + 3) // 4 * 4        # ops._padded_table: zero-padded rows, exact
         if 3 * E // 4 > 512:
             return 'word_embed_size %d > 680' % E
     fm_in = {'MF': 2 * L, 'deepconn': 2 * L, 'transnet': L, 'transnet++': L + 10}.get(mt)

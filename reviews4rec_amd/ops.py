@@ -37,10 +37,37 @@ def _workspace(nbytes, device):
 
 
 # ------------------------------------------------------------------ TextCNN
+_PADDED_TABLES = {}     # (data_ptr, shape, _version) of a frozen table -> its zero-padded device copy
+
+
+def _padded_table(table):
+    """word_embed_size % 4 != 0 (the reference takes any width, hyper_params.py:64, common_pytorch_models.py:15):
+    the kernels read 16-byte aligned rows, so the frozen table gets a cached zero-padded copy; the conv weight is
+    padded per call (100 x 3 x E floats) and the pad columns of its gradient -- exactly 0: g * 0 -- are dropped."""
+    E = table.shape[1]
+    E4 = (E + 3) // 4 * 4
+    if E4 == E:
+        return table
+    key = (table.data_ptr(), tuple(table.shape), table._version)
+    pt = _PADDED_TABLES.get(key)
+    if pt is None:
+        _PADDED_TABLES.clear()                              # one table per model: no unbounded growth
+        pt = torch.zeros((table.shape[0], E4), dtype=table.dtype, device=table.device)
+        pt[:, :E].copy_(table.detach())
+        _PADDED_TABLES[key] = pt
+    return pt
+
+
 def textcnn_fwd_raw(idx, table, conv_w, conv_b):
     """idx [N,T] -> (pooled [N,F] fp32, argmax [N,F] int32).  No autograd."""
     idx, table = _i64(idx, 'idx'), _f32(table, 'table')
     conv_w, conv_b = _f32(conv_w, 'conv_w'), _f32(conv_b, 'conv_b')
+    if table.shape[1] % 4:
+        E0 = table.shape[1]
+        table = _padded_table(table)
+        pw = torch.zeros(tuple(conv_w.shape[:-1]) + (table.shape[1],), dtype=conv_w.dtype, device=conv_w.device)
+        pw[..., :E0].copy_(conv_w)
+        conv_w = pw
     N, T = idx.shape
     V, E = table.shape
     F = conv_b.numel()
@@ -55,6 +82,9 @@ def textcnn_fwd_raw(idx, table, conv_w, conv_b):
 
 def textcnn_wgrad_raw(idx, table, g_pooled, argmax, conv_w_shape):
     idx, table, g_pooled = _i64(idx, 'idx'), _f32(table, 'table'), _f32(g_pooled, 'g_pooled')
+    E_model = table.shape[1]
+    table = _padded_table(table)
+    conv_w_shape = tuple(conv_w_shape[:-1]) + (table.shape[1],)
     N, T = idx.shape
     V, E = table.shape
     F = g_pooled.shape[1]
@@ -64,6 +94,8 @@ def textcnn_wgrad_raw(idx, table, g_pooled, argmax, conv_w_shape):
     ws = _workspace(nb, idx.device)
     call('r4r_textcnn_wgrad', ptr(table), V, ptr(idx), ptr(g_pooled), ptr(argmax), ptr(d_w), ptr(d_b),
          ptr(ws), ws.numel(), N, T, E, F)
+    if E != E_model:
+        d_w = d_w[..., :E_model].contiguous()
     return d_w, d_b
 
 

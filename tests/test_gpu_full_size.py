@@ -93,3 +93,84 @@ def test_transnet_step_at_cfg5_cardinalities():
         elif not ill_conditioned(k):
             diff = (mine - v).abs()
             assert float((diff > 2e-5 + 1e-4 * v.abs()).float().mean()) < 2e-3 and float(diff.max()) < 5e-4, k
+
+
+@pytest.mark.parametrize('mt', ['deepconn', 'deepconn++', 'NARRE', 'transnet', 'transnet++'])
+def test_word_embed_size_not_a_multiple_of_four(mt):
+    """The reference takes any word_embed_size (hyper_params.py:64; the conv window is [3, E],
+    common_pytorch_models.py:15): E = 50 (GloVe-50) on the native engines -- zero-padded table rows and conv
+    weights inside the engine, the Parameters stay [100, 1, 3, 50] views -- two training steps and an eval forward
+    against the CPU oracle at E = 50; the state_dict keeps the reference's shapes and the pad columns stay 0."""
+    import reviews4rec_amd
+    from reviews4rec_amd import main as M
+    from helpers import synthetic_review_batch
+    from test_oracle_golden import ill_conditioned
+    B, T, E, V, U, I, L = 12, 60, 50, 300, 40, 30, 8
+    R, W = (10, 20) if mt == 'NARRE' else (None, None)
+    hp = dict(model_type=mt, latent_size=L, word_embed_size=E, input_length=T, dropout=0.0, total_users=U,
+              total_items=I, lr=0.002, weight_decay=1e-6, narre_num_reviews=10, narre_num_words=20, batch_size=B)
+    P = oracle.init_params(hp, vocab_size=V, seed=41)
+    tkey = 'target.word2vec.weight' if mt.startswith('transnet') else 'word2vec.weight'
+    model = reviews4rec_amd.get_model_class(mt)(dict(hp, word_vectors=P[tkey].numpy()))
+    model.load_state_dict(P)
+    model = model.to(DEV).train()
+    assert M.native_step_limits(hp) is None
+    eng = M.make_engine(dict(hp, engine='native'), model)
+    assert eng is not None and eng.E == 52 and eng.E_model == 50
+    is_tn = mt.startswith('transnet')
+    states = dict(source=oracle.AdamState(), source_fm=oracle.AdamState(), target=oracle.AdamState()) if is_tn \
+        else oracle.AdamState()
+    for step in range(2):
+        data, y = synthetic_review_batch(B, T, V, U, I, seed=50 + step, R=R, W=W)
+        se = eng.train_step([d.to(DEV) for d in data], y.to(DEV)).cpu().clone()
+        if is_tn:
+            ref_se, _, _ = oracle.transnet_train_step(P, data, y, hp, states)
+            torch.testing.assert_close(se, ref_se, rtol=1e-4, atol=1e-4)
+        else:
+            sse, _ = oracle.train_step(P, data, y, hp, states)
+            torch.testing.assert_close(se.sum(), torch.tensor(sse), rtol=1e-4, atol=1e-4)
+    sd = model.state_dict()
+    for k, v in P.items():
+        assert tuple(sd[k].shape) == tuple(v.shape), k
+        if not ill_conditioned(k):
+            diff = (sd[k].cpu() - v).abs()
+            assert float((diff > 2e-5 + 1e-4 * v.abs()).float().mean()) < 2e-3 and float(diff.max()) < 5e-4, k
+    for k, p in model.named_parameters():
+        if k.endswith('convs.0.weight'):
+            assert tuple(p.shape) == (100, 1, 3, 50) and p.stride()[-2] == 52      # a view of the padded slot
+            full = p.data.as_strided((100, 1, 3, 52), p.stride(), p.storage_offset())
+            assert float(full[..., 50:].abs().max()) == 0.0                          # pad columns: exactly 0
+    model.eval()
+    data, y = synthetic_review_batch(B, T, V, U, I, seed=60, R=R, W=W)
+    out = eng.predict([d.to(DEV) for d in data], None)[0].cpu()
+    ref = oracle.model_forward(P, data, hp, train=False)
+    ref = ref[0] if isinstance(ref, (list, tuple)) else ref
+    torch.testing.assert_close(out, ref, rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize('mt', ['deepconn', 'NARRE'])
+def test_word_embed_size_not_a_multiple_of_four_module_path(mt):
+    """The same configuration on the op-by-op module path (ops._padded_table): eval forward and one
+    autograd step's gradients against the oracle."""
+    import reviews4rec_amd
+    from reviews4rec_amd.loss import MSELoss
+    from helpers import synthetic_review_batch
+    from test_oracle_golden import ill_conditioned
+    B, T, E, V, U, I, L = 9, 60, 50, 300, 40, 30, 8
+    R, W = (10, 20) if mt == 'NARRE' else (None, None)
+    hp = dict(model_type=mt, latent_size=L, word_embed_size=E, input_length=T, dropout=0.0, total_users=U,
+              total_items=I, lr=0.002, weight_decay=1e-6, narre_num_reviews=10, narre_num_words=20, batch_size=B)
+    P = oracle.init_params(hp, vocab_size=V, seed=43)
+    model = reviews4rec_amd.get_model_class(mt)(dict(hp, word_vectors=P['word2vec.weight'].numpy()))
+    model.load_state_dict(P)
+    model = model.to(DEV).train()
+    data, y = synthetic_review_batch(B, T, V, U, I, seed=70, R=R, W=W)
+    out = model([d.to(DEV) for d in data])
+    se = MSELoss(hp)(out, y.to(DEV), return_mean=False)
+    torch.mean(se).backward()
+    sse, grads = oracle.train_step(dict(P), data, y, hp, oracle.AdamState())
+    torch.testing.assert_close(se.detach().sum().cpu(), torch.tensor(sse), rtol=1e-4, atol=1e-4)
+    got = {k: p.grad.cpu() for k, p in model.named_parameters() if p.grad is not None}
+    for k, v in grads.items():
+        if v is not None and not ill_conditioned(k):
+            torch.testing.assert_close(got[k], v, rtol=2e-4, atol=1e-6, msg=lambda m: k + ': ' + m)
