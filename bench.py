@@ -54,7 +54,9 @@ WORKLOAD = 'cfg3_deepconn_electronics_e300'
 PMC_SUMMARIES = {WORKLOAD: 'r02k_bench_pmc_summary.json',
                  'cfg2_mfdot_electronics': 'r01k_bench_cfg2_pmc_summary.json',
                  'cfg4_narre_kindle': 'r02k_bench_cfg4_pmc_summary.json',
-                 'cfg5_transnetpp_synthetic': 'r02k_bench_cfg5_pmc_summary.json'}
+                 'cfg5_transnetpp_synthetic': 'r02k_bench_cfg5_pmc_summary.json',
+                 # the one true HBM gather: full-length documents of uniformly drawn words at a 1 M-word vocabulary
+                 ('cfg5_transnetpp_synthetic', 'full', 'uniform'): 'r03_cfg5_fullunif_pmc_summary.json'}
 
 
 def measured_traffic(kernel, args, live_launch_s=None):
@@ -63,12 +65,13 @@ def measured_traffic(kernel, args, live_launch_s=None):
     MI355X_MICROARCH.md prescribes) -- only for the configuration those passes ran, and only while the
     summary still describes this build: if the kernel duration recorded with the counters is more than
     25 % away from the one measured live in this run, the summary is stale and no traffic is reported."""
-    name = PMC_SUMMARIES.get(args.workload)
+    name = PMC_SUMMARIES.get((args.workload, args.doc_fill, args.token_dist))      # a stress point with its own passes
+    if name is None and args.doc_fill == 'lognormal' and args.token_dist == 'zipf':
+        name = PMC_SUMMARIES.get(args.workload)
     path = os.path.join(ROOT, 'profiles', name) if name else None
     if not (path and os.path.exists(path) and args.batch_per_gpu == 128 and args.engine == 'native'
             and args.conv_algo in ('auto', 'project') and not args.model_type and not args.embed
-            and args.scaling == 'weak' and args.doc_fill == 'lognormal' and args.token_dist == 'zipf'
-            and args.gemm_math == 'f32'):
+            and args.scaling == 'weak' and args.gemm_math == 'f32'):
         return None, None
     kernels = json.load(open(path))['kernels']
     for k, v in kernels.items():
