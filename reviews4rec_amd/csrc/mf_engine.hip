@@ -204,6 +204,13 @@ __device__ __forceinline__ void mf_stream_chunk(float *p, float *m, float *v, in
     }
 }
 
+// Cache policy of the untouched-chunk stream: nontemporal for a sweep of more than 3 x the Infinity Cache
+// (R4R_SWEEP_NT=0 / 1 pins it for A/B runs)
+static int mf_sweep_nt(int64_t table_elements) {
+    static const char *e = getenv("R4R_SWEEP_NT");
+    return e ? (e[0] == '1') : (table_elements * 24 > ((int64_t)768 << 20));
+}
+
 // entries per wave: one up to batch 1024, then enough that a side has <= 256 workgroups (each stages
 // the side's B ids in LDS once)
 static int mf_epw(int64_t B) { return (int)(B <= 1024 ? 1 : (B + 1023) / 1024); }
@@ -749,10 +756,7 @@ int mf_table_rows_launch(float *ut, float *ut_m, float *ut_v, float *it, float *
     sw.uid = uid; sw.iid = iid; sw.gu = gu; sw.gi = gi; sw.g = nullptr; sw.se = nullptr; sw.sse_accum = nullptr;
     sw.tag_u = tag_u; sw.tag_i = tag_i; sw.ctag_u = ctag_u; sw.ctag_i = ctag_i;
     sw.B = B; sw.D = D; sw.now = now; sw.s = sc;
-    {
-        static const char *e = getenv("R4R_SWEEP_NT");     // (A/B runs: 0 / 1 pin the cache policy)
-        sw.nt = e ? (e[0] == '1') : ((sw.n0 + sw.n1) * 24 > (int64_t)768 << 20);   // a sweep of more than 3 x the Infinity Cache
-    }
+    sw.nt = mf_sweep_nt(sw.n0 + sw.n1);
     {
         ScopedTiming tm(R4R_TIMING_ADAM, st);
         mf_adam_kernel<4><<<(unsigned)chunks, MF_THREADS, (size_t)B * sizeof(int), st>>>(sw);

@@ -50,6 +50,68 @@ def init_from_env(backend=None):
     return rank, world, local
 
 
+class StreamRccl:
+    """A RCCL communicator of this package's own, called through ctypes ON THE CALLER'S STREAM.
+
+    torch.distributed issues a collective on its process group's internal stream and brackets it with two event
+    hand-overs (compute -> collective stream -> compute); at the sizes of this path (DeepCoNN: one 0.73 MB
+    bucket per step on a 0.1 ms step) those hand-overs and the extra dependent launch cost more than the
+    collective (measured at one rank: 17-24 us per step).  ncclAllReduce / ncclAllGather take the
+    stream as an argument: issued on the step's own stream the collective is one more launch in the chain
+    -- no events, and the optimiser launch behind it needs no synchronisation either.  The unique id travels
+    over the torch.distributed group that already exists (any backend).  RCCL is the library torch itself loaded
+    (torch/lib/librccl.so): no second copy in the process."""
+    FLOAT32, SUM = 7, 0                                    # ncclDataType_t / ncclRedOp_t (rccl.h)
+
+    class _UniqueId(__import__('ctypes').Structure):
+        _fields_ = [('internal', __import__('ctypes').c_byte * 128)]
+
+    def __init__(self, group=None):
+        import ctypes
+        self.ct = ctypes
+        path = os.environ.get('R4R_RCCL_LIBRARY') or os.path.join(os.path.dirname(torch.__file__), 'lib', 'librccl.so')
+        lib = self.lib = ctypes.CDLL(path)
+        lib.ncclGetErrorString.restype = ctypes.c_char_p
+        lib.ncclCommInitRank.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, self._UniqueId, ctypes.c_int]
+        lib.ncclAllReduce.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_int,
+                                      ctypes.c_void_p, ctypes.c_void_p]
+        lib.ncclAllGather.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p,
+                                      ctypes.c_void_p]
+        lib.ncclCommDestroy.argtypes = [ctypes.c_void_p]
+        self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
+        uid = self._UniqueId()
+        if self.rank == 0:
+            self._check(lib.ncclGetUniqueId(ctypes.byref(uid)), 'ncclGetUniqueId')
+        box = [bytes(bytearray(uid.internal)) if self.rank == 0 else None]
+        dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        ctypes.memmove(ctypes.byref(uid), box[0], 128)
+        self.comm = ctypes.c_void_p()
+        self._check(lib.ncclCommInitRank(ctypes.byref(self.comm), self.world, uid, self.rank), 'ncclCommInitRank')
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise RuntimeError('RCCL %s failed: %s' % (what, self.lib.ncclGetErrorString(rc).decode()))
+
+    def all_reduce(self, t):
+        """In-place fp32 sum of `t` over the ranks, enqueued on torch's current stream."""
+        assert t.dtype == torch.float32 and t.is_contiguous()
+        self._check(self.lib.ncclAllReduce(t.data_ptr(), t.data_ptr(), t.numel(), self.FLOAT32, self.SUM, self.comm,
+                                           torch.cuda.current_stream(t.device).cuda_stream), 'ncclAllReduce')
+
+    def all_gather(self, out, t):
+        """Rank r's `t` into out[r * n : (r + 1) * n], enqueued on torch's current stream."""
+        nbytes = t.numel() * t.element_size()
+        assert t.dtype == out.dtype and t.is_contiguous() and out.is_contiguous() and out.numel() == self.world * t.numel()
+        assert nbytes % 4 == 0                               # (moved as 4-byte words: an all_gather does no arithmetic)
+        self._check(self.lib.ncclAllGather(t.data_ptr(), out.data_ptr(), nbytes // 4, self.FLOAT32,
+                                           self.comm, torch.cuda.current_stream(t.device).cuda_stream), 'ncclAllGather')
+
+    def close(self):
+        if getattr(self, 'comm', None):
+            self.lib.ncclCommDestroy(self.comm)
+            self.comm = None
+
+
 def shard_bounds(n, rank, world):
     """Contiguous split of n rows: the first n % world ranks get one extra row."""
     base, extra = divmod(n, world)
@@ -87,6 +149,11 @@ class DataParallel:
             from . import ops
             ops.SparseGradCapture.active = True
             ops.SparseGradCapture.clear()
+        # the fused engines' exchanges go through a communicator of our own on the compute stream where the job
+        # runs over RCCL (R4R_DP_RCCL=0: torch.distributed's collectives, as before)
+        self.stream_rccl = None
+        if self.on and os.environ.get('R4R_DP_RCCL', '1') != '0' and dist.get_backend(group) == 'nccl':
+            self.stream_rccl = StreamRccl(group)
 
     def rebind(self, model):
         """Point the exchange at `model` (a new training stage, a freshly built model): its parameters
@@ -244,14 +311,28 @@ class DataParallel:
     def allreduce_flat(self, flat):
         """The fused engine's gradients already live in one flat buffer: one all-reduce, no copies."""
         if self.on:
-            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+            if self.stream_rccl is not None and flat.dtype == torch.float32:
+                self.stream_rccl.all_reduce(flat)
+            else:
+                dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+
+    def all_gather(self, out, t):
+        """Rank r's contiguous `t` into out[r * n : (r + 1) * n] (flat views; any 4- or 8-byte dtype), on the
+        compute stream through the package's own communicator where the job runs over RCCL."""
+        if self.stream_rccl is not None and (t.numel() * t.element_size()) % 4 == 0 and t.is_cuda:
+            self.stream_rccl.all_gather(out, t)
+        else:
+            dist.all_gather_into_tensor(out, t, group=self.group)
 
     def gather_flat(self, flat, out):
         """All ranks' flat gradient buffers back to back in `out` [world * n] (rank order): the
         one-phase alternative to the all-reduce; the sum happens in the optimiser kernel
         (r4r_adam_gathered), in rank order, so every rank computes the same bits."""
         if self.on:
-            dist.all_gather_into_tensor(out, flat, group=self.group)
+            if self.stream_rccl is not None and (flat.numel() * flat.element_size()) % 4 == 0:
+                self.stream_rccl.all_gather(out, flat)
+            else:
+                dist.all_gather_into_tensor(out, flat, group=self.group)
         else:
             out[:flat.numel()].copy_(flat)
 

@@ -567,7 +567,7 @@ class MFEngine:
                                    ptr(pred), ptr(se), ptr(block), None, n, B_pad, float(self.hp['dropout']),
                                    int(self.model.training), self.seed, self.offset, 1.0 / float(n_global),
                                    _lib.current_stream()), 'r4r_mf_grad')
-        dist.all_gather_into_tensor(blocks, block, group=self.dp.group)
+        self.dp.all_gather(blocks, block)
         ws = self._workspace(world * B_pad)
         _lib.check(lib.r4r_mf_apply(ptr(blocks), world, B_pad, self._ptrs(self.params), self._ptrs(self.m),
                                     self._ptrs(self.v), self.n_users, self.n_items, self.D, ptr(ws), ws.numel(),
@@ -921,8 +921,8 @@ class NarreEngine(_ConvRule):
             self._dp_payload(f, n, R, T, ids, vals)
         all_ids = torch.empty((world, B_pad, id_cols), dtype=torch.int64, device=self.dev)
         all_vals = torch.empty((world, B_pad, val_cols), dtype=torch.float32, device=self.dev)
-        dist.all_gather_into_tensor(all_ids.view(-1), ids.view(-1), group=self.dp.group)
-        dist.all_gather_into_tensor(all_vals.view(-1), vals.view(-1), group=self.dp.group)
+        self.dp.all_gather(all_ids.view(-1), ids.view(-1))
+        self.dp.all_gather(all_vals.view(-1), vals.view(-1))
         nb = max(n, 1)                                       # (the workspace of this rank's own shape holds the row tags)
         self._dp_apply(all_ids.view(world * B_pad, id_cols), all_vals.view(world * B_pad, val_cols), world * B_pad,
                        self._workspace(nb, R, T), nb, R, T)
@@ -1392,8 +1392,8 @@ class IdNetEngine:
                 vals[:n, 1 + t * L:1 + (t + 1) * L] = self._ws_view(n, 4 + t, L)
         all_ids = torch.empty((world * B_pad, 2), dtype=torch.int64, device=self.dev)
         all_vals = torch.empty((world * B_pad, 1 + ntab * L), dtype=torch.float32, device=self.dev)
-        dist.all_gather_into_tensor(all_ids.view(-1), ids.view(-1), group=self.dp.group)
-        dist.all_gather_into_tensor(all_vals.view(-1), vals.view(-1), group=self.dp.group)
+        self.dp.all_gather(all_ids.view(-1), ids.view(-1))
+        self.dp.all_gather(all_vals.view(-1), vals.view(-1))
         uid_all, iid_all = all_ids[:, 0].contiguous(), all_ids[:, 1].contiguous()
         g_all = all_vals[:, 0].contiguous()
         rows = [all_vals[:, 1 + t * L:1 + (t + 1) * L].contiguous() for t in range(ntab)]
