@@ -438,7 +438,9 @@ def main():
             if G % world:
                 continue
             bs = G // world
-            if engine is not None and native_step_limits(dict(hp, batch_size=bs), world):
+            why = native_step_limits(dict(hp, batch_size=bs), world) if engine is not None else None
+            if why:                                          # said, not skipped silently: the leg did not run on the native step
+                strong_legs.append({'global_batch': G, 'batch_per_gpu': bs, 'skipped': 'native step limit: ' + why})
                 continue
             _, pool_s = make_pool(bs, n=max(2, min(args.pool, 8192 // bs)))      # (large shards: two resident batches)
             step_s = make_step(pool_s, bs, G)
@@ -518,7 +520,9 @@ def main():
         if opt_in:
             result['opt_in_f16_split'] = opt_in
         if strong_legs:
-            result['strong'] = strong_legs[0]                 # G = 1024 (2.70 M ratings/s at N = 1)
+            ran = [l for l in strong_legs if 'skipped' not in l]
+            if ran:
+                result['strong'] = ran[0]                     # G = 1024 (2.70 M ratings/s at N = 1)
             result['strong_legs'] = strong_legs
         result['kernel_ms'] = {k: round(v[0], 4) for k, v in timed.items()}
         towers = (3 if is_tn else 2) if engine is not None else 1    # the native step runs all towers per launch
