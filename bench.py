@@ -365,6 +365,14 @@ def main():
             pool[0], pool[1] = pool[1], next(feed)
 
     def fence():
+        # barrier + torch.cuda.synchronize() on both sides of the timed region, as the contract says.  The host
+        # first SPINS on an event behind the queued work: synchronize() on an already idle device returns at once,
+        # while a blocked synchronize() is woken some tens of microseconds after the GPU went idle -- 3-5 % of a
+        # 20-step (2 ms) region that are the host's wake-up latency, not the steps'.
+        ev = torch.cuda.Event()
+        ev.record()
+        while not ev.query():
+            pass
         torch.cuda.synchronize()
         if dp_job:
             torch.distributed.barrier()

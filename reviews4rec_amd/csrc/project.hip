@@ -93,8 +93,13 @@ extern "C" int r4r_debug_trace(void *buf) {
 #define TRACE_STAMP(k)                                                                                  \
     if (g_trace && threadIdx.x == 0)                                                                    \
         g_trace[((size_t)blockIdx.x) * 8 + (k)] = wall_clock64();
+// the LAST wave's time (the A-resident form's waves run free in their later passes: wave 0 is not the workgroup)
+#define TRACE_STAMP_LAST(k)                                                                             \
+    if (g_trace && (threadIdx.x & 63) == 0)                                                             \
+        atomicMax(g_trace + ((size_t)blockIdx.x) * 8 + (k), (unsigned long long)wall_clock64());
 #else
 #define TRACE_STAMP(k)
+#define TRACE_STAMP_LAST(k)
 #endif
 
 // ---- 0. zero the token-state (callers whose workspace is not persistently zeroed).  A kernel
@@ -659,6 +664,9 @@ constexpr int AR_MAX_CHUNKS = 20;                  // 20 x 8 KB = 160 KB: E <= 3
 #ifndef R4R_AR_AUX
 #define R4R_AR_AUX 0                               // cache bits of the early passes' stores: 0 = plain (measured best), 16 = sc1 (write-through), 2 = nt
 #endif
+#ifndef R4R_AR_SPLIT
+#define R4R_AR_SPLIT 1                             // 1: passes over column groups (measured best: every weight fragment loaded once); 0: over row-tile groups (R1 | R2 | rest)
+#endif
 #ifndef R4R_AR_AUX_LAST
 #define R4R_AR_AUX_LAST 0                          // ... and of the last pass's
 #endif
@@ -936,9 +944,42 @@ __device__ __forceinline__ void proj_gemm_ares_body(const ProjArgs &a, float *ld
     using AuxEarly = std::integral_constant<int, R4R_AR_AUX>;
     using AuxLast = std::integral_constant<int, R4R_AR_AUX_LAST>;
     const float *const nonep[1] = {conv_w};
+    auto nothing = [](auto) {};
+#if R4R_AR_SPLIT == 1
+    {
+        // Passes over COLUMN groups: pass 1 = all 7 row tiles x the first C1 of this wave's column tiles (+ ALL of SIMD
+        // 3's shared-tile units: 14 + 7 | 7 + 4 + 7 + 3 = 21 tiles per SIMD), pass 2 = all 7 x the other C2 (14 per
+        // SIMD).  Every weight fragment is loaded once per launch (row-group passes load each twice); the resident A
+        // rows are read twice.
+        constexpr int C1 = NCW == 3 ? 2 : 1, C2 = NCW - C1;
+        const float *b1[C1], *b2[C2];
+#pragma unroll
+        for (int j = 0; j < C1; ++j) b1[j] = bptr[j];
+#pragma unroll
+        for (int j = 0; j < C2; ++j) b2[j] = bptr[C1 + j];
+        f32x4 a1[G7_ROWS][C1], a2[G7_ROWS][C2], none[1], ex[NE];
+        if constexpr (NEX > 0) ares_pass<G7_ROWS, C1, NEX, R4R_AR_S, 0>(x, 0, b1, ebptr, a1, ex, nothing);
+        else ares_pass<G7_ROWS, C1, 0, R4R_AR_S, 0>(x, 0, b1, nonep, a1, none, nothing);
+        TRACE_STAMP(1)
+        __syncthreads();
+        auto store1 = [&](auto kc) {
+            constexpr int k = decltype(kc)::value;
+            if constexpr (k < G7_ROWS * C1) store_tile(a1[k / C1][k % C1], p.row0 + (k / C1) * 16, ct0 + k % C1, AuxEarly{});
+            else store_tile(ex[k - G7_ROWS * C1], p.sh_row0, ecol[k - G7_ROWS * C1], AuxEarly{},
+                            eoff + (k - G7_ROWS * C1) < p.sh_n && p.sh_row0 >= 0);
+        };
+        ares_pass<G7_ROWS, C2, 0, 0, G7_ROWS * C1 + NEX>(x, 0, b2, nonep, a2, none, store1);
+        TRACE_STAMP_LAST(2)
+#pragma unroll
+        for (int i = 0; i < G7_ROWS; ++i)
+#pragma unroll
+            for (int j = 0; j < C2; ++j) store_tile(a2[i][j], p.row0 + i * 16, ct0 + C1 + j, AuxLast{});
+        TRACE_STAMP_LAST(3)
+        return;
+    }
+#endif
     f32x4 acc1[R1][NCW], acc2[R2][NCW], acc3[R3A][NCW], none[1], ex[NE];
     constexpr int NEX1 = EXP == 1 ? NEX : 0, NEXL = EXP == 1 ? 0 : NEX;
-    auto nothing = [](auto) {};
 #ifdef R4R_TRACE
     const unsigned long long clk0 = __builtin_readcyclecounter();
 #endif
@@ -963,7 +1004,7 @@ __device__ __forceinline__ void proj_gemm_ares_body(const ProjArgs &a, float *ld
     if constexpr (R3 == 0) {
         if constexpr (NEXL > 0) ares_pass<R2, NCW, NEXL, 0, NS1>(x, R1, bptr, ebptr, acc2, ex, store1);
         else ares_pass<R2, NCW, 0, 0, NS1>(x, R1, bptr, nonep, acc2, none, store1);
-        TRACE_STAMP(2)
+        TRACE_STAMP_LAST(2)
 #ifdef R4R_TRACE
         if (g_trace && threadIdx.x == 0)                     // ... and of pass 2 (word 6: bit 0 = active)
             g_trace[((size_t)blockIdx.x) * 8 + 6] = ((__builtin_readcyclecounter() - clk1) << 1) | 1;
@@ -980,7 +1021,7 @@ __device__ __forceinline__ void proj_gemm_ares_body(const ProjArgs &a, float *ld
         };
         if constexpr (NEXL > 0) ares_pass<R3A, NCW, NEXL, 0, R2 * NCW>(x, R1 + R2, bptr, ebptr, acc3, ex, store2);
         else ares_pass<R3A, NCW, 0, 0, R2 * NCW>(x, R1 + R2, bptr, nonep, acc3, none, store2);
-        TRACE_STAMP(2)
+        TRACE_STAMP_LAST(2)
 #pragma unroll
         for (int i = 0; i < R3A; ++i)
 #pragma unroll
@@ -990,7 +1031,7 @@ __device__ __forceinline__ void proj_gemm_ares_body(const ProjArgs &a, float *ld
 #pragma unroll
         for (int j = 0; j < NE; ++j) store_ex(j, AuxLast{});
     }
-    TRACE_STAMP(3)
+    TRACE_STAMP_LAST(3)
 }
 
 __global__ __launch_bounds__(GEMM_THREADS) void proj_gemm_kernel(ProjArgs a) {

@@ -19,6 +19,9 @@ declare -A V=(
   [a43nt]="-DR4R_AR_R1=4 -DR4R_AR_R2=3 -DR4R_AR_S=2 -DR4R_AR_AUX=2"
   [a52s1]="-DR4R_AR_R1=5 -DR4R_AR_R2=2 -DR4R_AR_S=1 -DR4R_AR_AUX=0"
   [a52ns]="-DR4R_AR_R1=5 -DR4R_AR_R2=2 -DR4R_AR_S=2 -DR4R_AR_AUX=0 -DR4R_EPI=2"
+  [cols]="-DR4R_AR_SPLIT=1"
+  [colss1]="-DR4R_AR_SPLIT=1 -DR4R_AR_S=1"
+  [colsns]="-DR4R_AR_SPLIT=1 -DR4R_EPI=2"
   [a43ns]="-DR4R_AR_R1=4 -DR4R_AR_R2=3 -DR4R_AR_S=2 -DR4R_EPI=2"
 )
 ORDER=${ORDER:-"a43s2 a43s1 a43s4 a43pl a43wt a34s2 a322 a232 a331 a43ns"}
