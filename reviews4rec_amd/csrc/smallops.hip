@@ -147,48 +147,77 @@ __global__ void add_kernel(const float *__restrict__ a, const float *__restrict_
 }
 
 // ---------------------------------------------------------------------- FM
-// One wave per example: lane i < n holds x_i; s_k = sum_i x_i V_ik by a wave
-// reduction (K12 of the survey: "wavefront reductions for the FM second-order
-// term").  n, k <= 64.
+// One wave per example: lane l holds inputs l, l + 64, ... (FM_MAX_SLOTS of them: n <= 512; the reference puts
+// no bound on latent_size, hyper_params.py:63, and the FM reads 2 x latent_size inputs, DeepCoNN.py:32);
+// s_k = sum_i x_i V_ik by a wave reduction (K12 of the survey: "wavefront reductions for the FM second-order
+// term").  With n <= 64 every lane holds one input and the arithmetic is the single-slot form's, bit for bit.
+constexpr int FM_MAX_SLOTS = 8;
+
 __global__ void fm_fwd_kernel(const float *__restrict__ x, const float *__restrict__ V,
                               const float *__restrict__ lw, const float *__restrict__ lb,
                               float *__restrict__ out, int64_t N, int n, int k) {
     const int lane = threadIdx.x & 63;
     const int64_t b = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     if (b >= N) return;
-    const float xi = (lane < n) ? x[b * n + lane] : 0.f;
+    float xi[FM_MAX_SLOTS];
+#pragma unroll
+    for (int t = 0; t < FM_MAX_SLOTS; ++t) xi[t] = (lane + 64 * t < n) ? x[b * n + lane + 64 * t] : 0.f;
     float inter = 0.f;
     for (int kk = 0; kk < k; ++kk) {
-        const float v = (lane < n) ? V[lane * k + kk] : 0.f;
-        const float s = wave_sum(xi * v);
-        const float s2 = wave_sum(xi * xi * v * v);
+        float a = 0.f, a2 = 0.f;
+#pragma unroll
+        for (int t = 0; t < FM_MAX_SLOTS; ++t) {
+            if (64 * t < n) {                               // uniform
+                const float v = (lane + 64 * t < n) ? V[(lane + 64 * t) * k + kk] : 0.f;
+                a += xi[t] * v;
+                a2 += xi[t] * xi[t] * v * v;
+            }
+        }
+        const float s = wave_sum(a);
+        const float s2 = wave_sum(a2);
         inter += s * s - s2;
     }
-    const float lin = wave_sum((lane < n) ? xi * lw[lane] : 0.f);
+    float l = 0.f;
+#pragma unroll
+    for (int t = 0; t < FM_MAX_SLOTS; ++t)
+        if (lane + 64 * t < n) l += xi[t] * lw[lane + 64 * t];
+    const float lin = wave_sum(l);
     if (lane == 0) out[b] = 0.5f * inter + lin + lb[0];
 }
 
-// g_x[b][i] = g_b * (sum_k (s_k V_ik - x_i V_ik^2) + w_i); also writes s[b][k] to ws.
+// g_x[b][i] = g_b * (sum_k (s_k V_ik - x_i V_ik^2) + w_i)
 __global__ void fm_bwd_x_kernel(const float *__restrict__ x, const float *__restrict__ V,
                                 const float *__restrict__ lw, const float *__restrict__ gout,
                                 float *__restrict__ gx, int64_t N, int n, int k) {
     const int lane = threadIdx.x & 63;
     const int64_t b = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     if (b >= N) return;
-    const float xi = (lane < n) ? x[b * n + lane] : 0.f;
-    float acc = 0.f;
-    for (int kk = 0; kk < k; ++kk) {
-        const float v = (lane < n) ? V[lane * k + kk] : 0.f;
-        const float s = wave_sum(xi * v);
-        acc += s * v - xi * v * v;
+    float xi[FM_MAX_SLOTS], acc[FM_MAX_SLOTS];
+#pragma unroll
+    for (int t = 0; t < FM_MAX_SLOTS; ++t) {
+        xi[t] = (lane + 64 * t < n) ? x[b * n + lane + 64 * t] : 0.f;
+        acc[t] = 0.f;
     }
-    if (lane < n) gx[b * n + lane] = gout[b] * (acc + lw[lane]);
+    for (int kk = 0; kk < k; ++kk) {
+        float v[FM_MAX_SLOTS], a = 0.f;
+#pragma unroll
+        for (int t = 0; t < FM_MAX_SLOTS; ++t) {
+            v[t] = (64 * t < n && lane + 64 * t < n) ? V[(lane + 64 * t) * k + kk] : 0.f;
+            a += xi[t] * v[t];
+        }
+        const float s = wave_sum(a);
+#pragma unroll
+        for (int t = 0; t < FM_MAX_SLOTS; ++t) acc[t] += s * v[t] - xi[t] * v[t] * v[t];
+    }
+#pragma unroll
+    for (int t = 0; t < FM_MAX_SLOTS; ++t)
+        if (lane + 64 * t < n) gx[b * n + lane + 64 * t] = gout[b] * (acc[t] + lw[lane + 64 * t]);
 }
 
 // g_V[i][kk] = sum_b g_b (s_bk x_bi - x_bi^2 V_ik); g_lw[i] = sum_b g_b x_bi; g_lb = sum_b g_b.
-// One workgroup of 64 x 4 threads per (kk) column plus one for the linear part;
-// s_bk is recomputed per example by a wave reduction; rows of 4 example groups are
-// combined through LDS in a fixed order.
+// One workgroup of 64 x 4 threads per (kk column, block of 64 inputs) plus the linear part's (kk == k);
+// s_bk (over ALL n inputs) is recomputed per example by a wave reduction; rows of 4 example groups are combined
+// through LDS in a fixed order.
 __global__ void fm_bwd_p_kernel(const float *__restrict__ x, const float *__restrict__ V,
                                 const float *__restrict__ gout, float *__restrict__ gV,
                                 float *__restrict__ glw, float *__restrict__ glb,
@@ -196,16 +225,24 @@ __global__ void fm_bwd_p_kernel(const float *__restrict__ x, const float *__rest
     __shared__ float red[4][65];
     const int lane = threadIdx.x, rg = threadIdx.y;   // blockDim = (64, 4)
     const int kk = blockIdx.x;                        // kk == k -> linear part
+    const int i0 = blockIdx.y * 64, mine = i0 + lane; // this workgroup's inputs
     float acc = 0.f, accb = 0.f;
-    const float v = (kk < k && lane < n) ? V[lane * k + kk] : 0.f;
+    float v[FM_MAX_SLOTS];
+#pragma unroll
+    for (int t = 0; t < FM_MAX_SLOTS; ++t) v[t] = (kk < k && lane + 64 * t < n) ? V[(lane + 64 * t) * k + kk] : 0.f;
+    const float vm = (kk < k && mine < n) ? V[mine * k + kk] : 0.f;
     for (int64_t b = rg; b < N; b += 4) {
-        const float xi = (lane < n) ? x[b * n + lane] : 0.f;
+        const float xm = (mine < n) ? x[b * n + mine] : 0.f;
         const float g = gout[b];
         if (kk < k) {
-            const float s = wave_sum(xi * v);
-            acc += g * (s * xi - xi * xi * v);
+            float a = 0.f;
+#pragma unroll
+            for (int t = 0; t < FM_MAX_SLOTS; ++t)
+                if (64 * t < n) a += ((lane + 64 * t < n) ? x[b * n + lane + 64 * t] : 0.f) * v[t];
+            const float s = wave_sum(a);
+            acc += g * (s * xm - xm * xm * vm);
         } else {
-            acc += g * xi;
+            acc += g * xm;
             accb += g;
         }
     }
@@ -214,10 +251,10 @@ __global__ void fm_bwd_p_kernel(const float *__restrict__ x, const float *__rest
     __syncthreads();
     if (rg == 0) {
         const float t = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
-        if (kk < k) { if (lane < n) gV[lane * k + kk] = t; }
+        if (kk < k) { if (mine < n) gV[mine * k + kk] = t; }
         else {
-            if (lane < n) glw[lane] = t;
-            if (lane == 0) glb[0] = red[0][64] + red[1][64] + red[2][64] + red[3][64];
+            if (mine < n) glw[mine] = t;
+            if (lane == 0 && blockIdx.y == 0) glb[0] = red[0][64] + red[1][64] + red[2][64] + red[3][64];
         }
     }
 }
@@ -442,7 +479,7 @@ extern "C" int r4r_add(const float *a, const float *b, float *out, int64_t n, vo
 extern "C" int r4r_fm_fwd(const float *x, const float *V, const float *lin_w, const float *lin_b,
                           float *out, int64_t N, int n, int k, void *stream) {
     R4R_REQUIRE(x && V && lin_w && lin_b && out, "fm_fwd: null pointer");
-    R4R_REQUIRE(n > 0 && n <= 64 && k > 0 && k <= 64, "fm_fwd: n=%d k=%d outside 1..64", n, k);
+    R4R_REQUIRE(n > 0 && n <= 64 * FM_MAX_SLOTS && k > 0 && k <= 4096, "fm_fwd: n=%d outside 1..%d or k=%d outside 1..4096", n, 64 * FM_MAX_SLOTS, k);
     if (N <= 0) return R4R_OK;
     fm_fwd_kernel<<<blocks_for(N * 64), 256, 0, as_stream(stream)>>>(x, V, lin_w, lin_b, out, N, n, k);
     return check_launch("fm_fwd");
@@ -452,10 +489,10 @@ extern "C" int r4r_fm_bwd(const float *x, const float *V, const float *lin_w, co
                           float *g_x, float *g_V, float *g_lin_w, float *g_lin_b,
                           int64_t N, int n, int k, void *stream) {
     R4R_REQUIRE(x && V && lin_w && g_out && g_x && g_V && g_lin_w && g_lin_b, "fm_bwd: null pointer");
-    R4R_REQUIRE(n > 0 && n <= 64 && k > 0 && k <= 64, "fm_bwd: n=%d k=%d outside 1..64", n, k);
+    R4R_REQUIRE(n > 0 && n <= 64 * FM_MAX_SLOTS && k > 0 && k <= 4096, "fm_bwd: n=%d outside 1..%d or k=%d outside 1..4096", n, 64 * FM_MAX_SLOTS, k);
     hipStream_t st = as_stream(stream);
     if (N > 0) fm_bwd_x_kernel<<<blocks_for(N * 64), 256, 0, st>>>(x, V, lin_w, g_out, g_x, N, n, k);
-    fm_bwd_p_kernel<<<k + 1, dim3(64, 4), 0, st>>>(x, V, g_out, g_V, g_lin_w, g_lin_b, N, n, k);
+    fm_bwd_p_kernel<<<dim3(k + 1, (n + 63) / 64), dim3(64, 4), 0, st>>>(x, V, g_out, g_V, g_lin_w, g_lin_b, N, n, k);
     return check_launch("fm_bwd");
 }
 

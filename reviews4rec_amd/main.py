@@ -210,10 +210,8 @@ def module_path_limits(hyper_params):
         if 3 * E // 4 > 512:
             return 'word_embed_size %d > 680' % E
     fm_in = {'MF': 2 * L, 'deepconn': 2 * L, 'transnet': L, 'transnet++': L + 10}.get(mt)
-    if fm_in is not None and fm_in > 64:
-        return 'factorization machine over %d inputs > 64 (latent_size %d)' % (fm_in, L)
-    if mt == 'MF' and L > 64:
-        return 'factorization machine of rank %d > 64' % L
+    if fm_in is not None and fm_in > 512:
+        return 'factorization machine over %d inputs > 512 (latent_size %d)' % (fm_in, L)
     if mt in ('MF', 'NeuMF', 'NARRE', 'deepconn++') and 2 * L > 255:
         return 'dense layer over %d inputs > 255' % (2 * L)
     if mt == 'NARRE' and (int(hyper_params.get('narre_num_reviews', 10)) > 32 or L > 32):

@@ -174,3 +174,41 @@ def test_word_embed_size_not_a_multiple_of_four_module_path(mt):
     for k, v in grads.items():
         if v is not None and not ill_conditioned(k):
             torch.testing.assert_close(got[k], v, rtol=2e-4, atol=1e-6, msg=lambda m: k + ': ' + m)
+
+
+@pytest.mark.parametrize('mt,L', [('deepconn', 48), ('MF', 48), ('transnet++', 80)])
+def test_latent_size_beyond_the_native_steps(mt, L):
+    """latent_size has no bound in the reference (hyper_params.py:63).  The fused native steps are built for
+    latent_size <= 32; beyond that ``engine='auto'`` falls back -- with the reason -- to the op-by-op HIP path,
+    whose factorization machine now takes up to 512 inputs (DeepCoNN's FM reads 2 x latent_size): one training
+    step's loss and gradients and an eval forward against the CPU oracle at latent_size 48 / 80."""
+    import reviews4rec_amd
+    from reviews4rec_amd import main as M
+    from reviews4rec_amd.loss import MSELoss
+    from helpers import synthetic_review_batch
+    B, T, E, V, U, I = 10, 50, 16, 200, 40, 30
+    hp = dict(model_type=mt, latent_size=L, word_embed_size=E, input_length=T, dropout=0.0, total_users=U,
+              total_items=I, lr=0.002, weight_decay=1e-6, batch_size=B)
+    assert M.native_step_limits(hp) is not None and M.module_path_limits(hp) is None
+    P = oracle.init_params(hp, vocab_size=V, seed=47)
+    tkey = 'target.word2vec.weight' if mt.startswith('transnet') else 'word2vec.weight'
+    extra = dict(word_vectors=P[tkey].numpy()) if tkey in P else {}
+    model = reviews4rec_amd.get_model_class(mt)(dict(hp, **extra))
+    model.load_state_dict(P)
+    model = model.to(DEV).train()
+    assert M.make_engine(dict(hp, engine='auto', log_file=None), model) is None       # no native step: module path
+    data, y = synthetic_review_batch(B, T, V, U, I, seed=80)
+    out = model([d.to(DEV) for d in data])
+    pred = out[0] if isinstance(out, (list, tuple)) else out
+    ref = oracle.model_forward(P, data, hp, train=True)
+    ref = ref[0] if isinstance(ref, (list, tuple)) else ref
+    torch.testing.assert_close(pred.detach().cpu(), ref.detach(), rtol=1e-4, atol=1e-4)
+    if not mt.startswith('transnet'):
+        se = MSELoss(hp)(pred, y.to(DEV), return_mean=False)
+        torch.mean(se).backward()
+        sse, grads = oracle.train_step(dict(P), data, y, hp, oracle.AdamState())
+        torch.testing.assert_close(se.detach().sum().cpu(), torch.tensor(sse), rtol=1e-4, atol=1e-4)
+        got = {k: p.grad.cpu() for k, p in model.named_parameters() if p.grad is not None}
+        for k, v in grads.items():
+            if v is not None:
+                torch.testing.assert_close(got[k], v, rtol=2e-4, atol=1e-6, msg=lambda m: k + ': ' + m)

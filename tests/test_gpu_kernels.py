@@ -171,7 +171,8 @@ def test_linear_fwd_bwd(N, n_in, n_out, relu):
     torch.testing.assert_close(bd.grad.cpu(), b.grad, rtol=1e-4, atol=1e-4)
 
 
-@pytest.mark.parametrize('N,n,k', [(9, 20, 8), (128, 10, 8), (3, 64, 64), (1, 12, 6)])
+@pytest.mark.parametrize('N,n,k', [(9, 20, 8), (128, 10, 8), (3, 64, 64), (1, 12, 6), (7, 96, 8), (5, 128, 64), (3, 300, 5),
+                                   (2, 512, 70)])      # n > 64: several inputs per lane (latent_size > 32)
 def test_fm_fwd_bwd(N, n, k):
     ops = _ops()
     g = torch.Generator().manual_seed(N + n + k)
@@ -186,8 +187,9 @@ def test_fm_fwd_bwd(N, n, k):
     Pd = {k2: v.detach().to(DEV).requires_grad_(True) for k2, v in P.items()}
     out = ops.fm(xd, Pd['fm.V'], Pd['fm.lin.weight'], Pd['fm.lin.bias'])
     out.backward(go.to(DEV))
-    torch.testing.assert_close(out.detach().cpu(), ref.detach(), rtol=1e-5, atol=1e-5)
-    torch.testing.assert_close(xd.grad.cpu(), x.grad, rtol=1e-4, atol=1e-5)
+    tol = 1e-5 if n <= 64 else 1e-4                        # (0.5 (s^2 - s2) cancels: the rounding grows with the input count)
+    torch.testing.assert_close(out.detach().cpu(), ref.detach(), rtol=tol, atol=tol)
+    torch.testing.assert_close(xd.grad.cpu(), x.grad, rtol=1e-4, atol=tol)
     for k2 in P:
         torch.testing.assert_close(Pd[k2].grad.cpu(), P[k2].grad, rtol=1e-4, atol=1e-4, msg=lambda m: k2 + ': ' + m)
 
