@@ -139,7 +139,8 @@ int r4r_add(const float *a, const float *b, float *out, int64_t n, void *stream)
  * Factorisation machine head (no global bias).
  * Replaces  TorchFM.forward            common_pytorch_models.py:49-57
  *   out[b] = 0.5 * (sum_k (x V)_k^2 - sum_k (x^2 V^2)_k) + lin_w . x + lin_b
- *   x [N, n], V [n, k], lin_w [n], lin_b [1], out [N]     (n <= 64, k <= 64)
+ *   x [N, n], V [n, k], lin_w [n], lin_b [1], out [N]     (n <= 512: the reference bounds neither latent_size nor
+ *   the FM width -- hyper_params.py:63, DeepCoNN.py:32 reads 2 x latent_size inputs; k <= 4096)
  * bwd overwrites g_x [N,n], g_V [n,k], g_lin_w [n], g_lin_b [1]. */
 int r4r_fm_fwd(const float *x, const float *V, const float *lin_w, const float *lin_b,
                float *out, int64_t N, int n, int k, void *stream);

@@ -51,7 +51,7 @@ def test_argument_validation_needs_no_gpu(lib):
     rc = lib.r4r_textcnn_fwd(1, 10, 1, 1, 1, 1, 1, 1, 16, 2, 8, 8, 100, None)
     assert rc == -3 and b'workspace' in lib.r4r_last_error()
     assert lib.r4r_textcnn_ws_bytes(128, 1000, 300, 100, 50002) > 0
-    rc = lib.r4r_fm_fwd(1, 1, 1, 1, 1, 4, 65, 8, None)
+    rc = lib.r4r_fm_fwd(1, 1, 1, 1, 1, 4, 513, 8, None)             # (n <= 512 since round 3: several inputs per lane)
     assert rc == -1
     rc = lib.r4r_dropout_fwd(1, 1, 1, 4, ctypes.c_float(1.5), 0, 0, None, None)
     assert rc == -1
