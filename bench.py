@@ -51,7 +51,7 @@ PEAK_HBM_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E spec peak (6.3 TB
 WORKLOAD = 'cfg3_deepconn_electronics_e300'
 
 
-PMC_SUMMARIES = {WORKLOAD: 'r02k_bench_pmc_summary.json',
+PMC_SUMMARIES = {WORKLOAD: 'r03c_bench_pmc_summary.json',
                  'cfg2_mfdot_electronics': 'r01k_bench_cfg2_pmc_summary.json',
                  'cfg4_narre_kindle': 'r02k_bench_cfg4_pmc_summary.json',
                  'cfg5_transnetpp_synthetic': 'r02k_bench_cfg5_pmc_summary.json',

@@ -659,13 +659,13 @@ constexpr int AR_MAX_CHUNKS = 20;                  // 20 x 8 KB = 160 KB: E <= 3
 #define R4R_AR_R2 3
 #endif
 #ifndef R4R_AR_S
-#define R4R_AR_S 2                                 // chunks staged per barrier in pass 1 (1, 2 or 4)
+#define R4R_AR_S 1                                 // chunks staged per barrier in pass 1 (1, 2 or 4: no measurable difference)
 #endif
 #ifndef R4R_AR_AUX
 #define R4R_AR_AUX 0                               // cache bits of the early passes' stores: 0 = plain (measured best), 16 = sc1 (write-through), 2 = nt
 #endif
 #ifndef R4R_AR_SPLIT
-#define R4R_AR_SPLIT 1                             // 1: passes over column groups (measured best: every weight fragment loaded once); 0: over row-tile groups (R1 | R2 | rest)
+#define R4R_AR_SPLIT 2                             // 2: every wave 7 x 2 tiles in pass 1, third columns + shared units in pass 2 (measured best); 1: column groups 2 | 1; 0: row-tile groups (R1 | R2 | rest)
 #endif
 #ifndef R4R_AR_AUX_LAST
 #define R4R_AR_AUX_LAST 0                          // ... and of the last pass's
@@ -945,7 +945,48 @@ __device__ __forceinline__ void proj_gemm_ares_body(const ProjArgs &a, float *ld
     using AuxLast = std::integral_constant<int, R4R_AR_AUX_LAST>;
     const float *const nonep[1] = {conv_w};
     auto nothing = [](auto) {};
-#if R4R_AR_SPLIT == 1
+#if R4R_AR_SPLIT == 2
+    {
+        // Pass 1: EVERY wave takes all 7 row tiles x 2 of its column tiles (14 tiles, 28 per SIMD: the barrier-paced
+        // pass is perfectly balanced).  Pass 2: the three-column waves finish their third column (7 tiles, alone on
+        // their SIMD: the two-column partner has stored its results and left), SIMD 3's waves compute the shared row
+        // tile's units (4 | 3).  Only a fifth of the output is still written in the final burst.
+        constexpr int C2 = NCW - 2;
+        const float *b1[2] = {bptr[0], bptr[1]};
+        f32x4 a1[G7_ROWS][2], none[1];
+        ares_pass<G7_ROWS, 2, 0, R4R_AR_S, 0>(x, 0, b1, nonep, a1, none, nothing);
+        TRACE_STAMP(1)
+        __syncthreads();
+        auto store1 = [&](auto kc) {
+            constexpr int k = decltype(kc)::value;
+            store_tile(a1[k / 2][k % 2], p.row0 + (k / 2) * 16, ct0 + k % 2, AuxEarly{});
+        };
+        if constexpr (C2 > 0) {
+            const float *b2[C2];
+#pragma unroll
+            for (int j = 0; j < C2; ++j) b2[j] = bptr[2 + j];
+            f32x4 a2[G7_ROWS][C2];
+            ares_pass<G7_ROWS, C2, 0, 0, G7_ROWS * 2>(x, 0, b2, nonep, a2, none, store1);
+            TRACE_STAMP_LAST(2)
+#pragma unroll
+            for (int i = 0; i < G7_ROWS; ++i)
+#pragma unroll
+                for (int j = 0; j < C2; ++j) store_tile(a2[i][j], p.row0 + i * 16, ct0 + 2 + j, AuxLast{});
+        } else if constexpr (NEX > 0) {
+            f32x4 ax[1][NEX];                                // the shared row tile (resident row tile 7) x this wave's units
+            ares_pass<1, NEX, 0, 0, G7_ROWS * 2>(x, G7_ROWS, ebptr, nonep, ax, none, store1);
+            TRACE_STAMP_LAST(2)
+#pragma unroll
+            for (int j = 0; j < NEX; ++j)
+                store_tile(ax[0][j], p.sh_row0, ecol[j], AuxLast{}, eoff + j < p.sh_n && p.sh_row0 >= 0);
+        } else {
+            static_for<0, G7_ROWS * 2>([&](auto kc) { store1(kc); });     // nothing left to compute: store and leave
+            TRACE_STAMP_LAST(2)
+        }
+        TRACE_STAMP_LAST(3)
+        return;
+    }
+#elif R4R_AR_SPLIT == 1
     {
         // Passes over COLUMN groups: pass 1 = all 7 row tiles x the first C1 of this wave's column tiles (+ ALL of SIMD
         // 3's shared-tile units: 14 + 7 | 7 + 4 + 7 + 3 = 21 tiles per SIMD), pass 2 = all 7 x the other C2 (14 per
