@@ -693,9 +693,6 @@ struct AresCtx {
     int E, nchunk, c4, q, a_off;
 };
 
-template <int NR, int NCW, int NEX>
-struct AresOps { f32x4 a[NR], b[NCW], sa, eb[NEX > 0 ? NEX : 1]; };
-
 // One pass: row tiles rt0 .. rt0 + NR - 1 (of the 8 resident ones) x this wave's NCW column tiles, plus NEX units of
 // the shared row tile (row tile 7).  S > 0: this pass also brings the A rows in, S chunks per barrier (pass 1).
 // `store_prev(k)`, k = 0 .. NPS - 1 (compile-time), stores one tile of the PREVIOUS pass's results; one is issued per
@@ -711,11 +708,25 @@ __device__ __forceinline__ void static_for(F &&f) {
     }
 }
 
+#ifndef R4R_AR_DB
+#define R4R_AR_DB 1                                // free passes: chunks the weight fragments are requested ahead of their MFMAs (1 or 3; 3 measured no faster)
+#endif
+
+template <int NR, int NEX>
+struct AresA { f32x4 a[NR], sa; };
+template <int NCW, int NEX>
+struct AresB { f32x4 b[NCW], eb[NEX > 0 ? NEX : 1]; };
+
 template <int NR, int NCW, int NEX, int S, int NPS, typename F>
 __device__ __forceinline__ void ares_pass(const AresCtx &x, int rt0, const float *const (&bptr)[NCW],
                                           const float *const (&ebptr)[NEX > 0 ? NEX : 1], f32x4 (&acc)[NR][NCW],
                                           f32x4 (&ex)[NEX > 0 ? NEX : 1], F store_prev) {
     constexpr int NE = NEX > 0 ? NEX : 1, SS = S > 0 ? S : 1;
+    // Operand registers: the table fragments (LDS) are double-buffered; the weight fragments come from L2 and are
+    // requested DB chunks ahead into a ring of DB + 1 sets.  (A timing ablation with the free passes' weight loads
+    // aimed at one hot line took pass 2 from 11.7 to 8.8 us; requesting them 3 chunks ahead instead of 1 did NOT
+    // -- 12.3 us: what those loads cost is their 16 lines per instruction in the address path, not their latency.)
+    constexpr int DB = S > 0 ? 1 : R4R_AR_DB, RB = DB + 1;
     const int E = x.E, nchunk = x.nchunk;
     f32x4 ar[SS];
     auto ld_a = [&](int s, f32x4 (&r)[SS]) {                 // super-chunk s = chunks s S .. s S + S - 1 (past the end: the last chunk again)
@@ -736,7 +747,7 @@ __device__ __forceinline__ void ares_pass(const AresCtx &x, int rt0, const float
             *reinterpret_cast<f32x4 *>(x.st_dst + c * AR_CHUNK) = v;
         }
     };
-    auto req_b = [&](int c, AresOps<NR, NCW, NEX> &o) {      // weight fragments: global -> registers
+    auto req_b = [&](int c, AresB<NCW, NEX> &o) {            // weight fragments: global -> registers
         const int e = min(min(c, nchunk - 1) * PEC + x.q * 4, E - 4);
 #pragma unroll
         for (int j = 0; j < NCW; ++j) o.b[j] = *reinterpret_cast<const f32x4 *>(bptr[j] + e);
@@ -745,22 +756,22 @@ __device__ __forceinline__ void ares_pass(const AresCtx &x, int rt0, const float
             for (int j = 0; j < NE; ++j) o.eb[j] = *reinterpret_cast<const f32x4 *>(ebptr[j] + e);
         }
     };
-    auto req_a = [&](int c, AresOps<NR, NCW, NEX> &o) {      // table fragments: resident LDS -> registers
+    auto req_a = [&](int c, AresA<NR, NEX> &o) {             // table fragments: resident LDS -> registers
         const float *ab = x.lds + min(c, nchunk - 1) * AR_CHUNK + x.a_off;
 #pragma unroll
         for (int i = 0; i < NR; ++i) o.a[i] = *reinterpret_cast<const f32x4 *>(ab + (rt0 + i) * 16 * PEC);
         if (NEX > 0) o.sa = *reinterpret_cast<const f32x4 *>(ab + G7_ROWS * 16 * PEC);
     };
-    auto mfma = [&](const AresOps<NR, NCW, NEX> &o) {
+    auto mfma = [&](const AresA<NR, NEX> &oa, const AresB<NCW, NEX> &ob) {
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
 #pragma unroll
             for (int i = 0; i < NR; ++i)
 #pragma unroll
-                for (int j = 0; j < NCW; ++j) acc[i][j] = MFMA4S(o.a[i][kk], o.b[j][kk], acc[i][j]);
+                for (int j = 0; j < NCW; ++j) acc[i][j] = MFMA4S(oa.a[i][kk], ob.b[j][kk], acc[i][j]);
             if (NEX > 0) {
 #pragma unroll
-                for (int j = 0; j < NE; ++j) ex[j] = MFMA4S(o.sa[kk], o.eb[j][kk], ex[j]);
+                for (int j = 0; j < NE; ++j) ex[j] = MFMA4S(oa.sa[kk], ob.eb[j][kk], ex[j]);
             }
         }
     };
@@ -771,38 +782,41 @@ __device__ __forceinline__ void ares_pass(const AresCtx &x, int rt0, const float
 #pragma unroll
     for (int j = 0; j < NE; ++j) ex[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    AresOps<NR, NCW, NEX> o0, o1;
+    AresA<NR, NEX> oa[2];
+    AresB<NCW, NEX> ob[RB];
     if (S > 0) {
         ld_a(0, ar);
-        req_b(0, o0);                                        // weight fragments of chunk 0: in flight under the staging
+        req_b(0, ob[0]);                                     // weight fragments of chunk 0: in flight under the staging
         st_a(0, ar);
         ld_a(1, ar);
         __syncthreads();                                     // super-chunk 0 in LDS
-        req_a(0, o0);
+        req_a(0, oa[0]);
         st_a(1, ar);
         ld_a(2, ar);
         PRO_STAMP
     } else {
-        req_b(0, o0);
-        req_a(0, o0);
+        static_for<0, DB>([&](auto kc) { req_b(decltype(kc)::value, ob[decltype(kc)::value]); });
+        req_a(0, oa[0]);
     }
-    // chunk c: operands `cur` in registers.  HEAD (first chunk of super-chunk s, staging passes): behind the barrier
-    // super-chunk s + 1 is visible, the staging registers (super-chunk s + 2, requested a super-step ago) go to LDS
-    // and super-chunk s + 3 is requested.  One memory instruction behind every few MFMAs, like the forms above.
-    auto step = [&](int c, const AresOps<NR, NCW, NEX> &cur, AresOps<NR, NCW, NEX> &nxt, auto headc, auto storec) {
+    // chunk c (ring position r = c mod lcm(2, RB), compile-time): its operands are in oa[r & 1] / ob[r % RB].  HEAD
+    // (first chunk of super-chunk s, staging passes): behind the barrier super-chunk s + 1 is visible, the staging
+    // registers (super-chunk s + 2, requested a super-step ago) go to LDS and super-chunk s + 3 is requested.  One
+    // memory instruction behind every few MFMAs, like the forms above.
+    auto step = [&](int c, auto rc, auto headc, auto storec) {
+        constexpr int r = decltype(rc)::value;
         constexpr bool head = decltype(headc)::value;
         constexpr int store_k = decltype(storec)::value;        // >= 0: this step also issues store_prev(store_k)
         // (the table-row loads go out BEHIND the weight-fragment loads: the next step waits for those with a
         // counted vmcnt, which an older, slower load -- table rows come from the Infinity Cache or HBM -- would hold up)
         if (S > 0 && head) __syncthreads();
-        req_b(c + 1, nxt);
-        req_a(c + 1, nxt);
+        req_b(c + DB, ob[(r + DB) % RB]);
+        req_a(c + 1, oa[(r + 1) & 1]);
         if constexpr (store_k >= 0) store_prev(storec);
         if (S > 0 && head) {
             st_a(c / SS + 2, ar);
             ld_a(c / SS + 3, ar);
         }
-        mfma(cur);
+        mfma(oa[r & 1], ob[r % RB]);
         constexpr int NRD = NR + (NEX > 0 ? 1 : 0), NLD = NCW + NEX + ((S > 0 && head) ? SS : 0), NWR = (S > 0 && head) ? SS : 0;
         constexpr int NM = 4 * (NR * NCW + NEX);
         constexpr int NMEM_MAX = NR + 1 + NCW + NEX + 2 * SS + 1;
@@ -835,45 +849,37 @@ __device__ __forceinline__ void ares_pass(const AresCtx &x, int rt0, const float
         }
         __builtin_amdgcn_sched_group_barrier(0x008, NM - GAP * (NRD + NLD + NWR + (store_k >= 0 ? 1 : 0)), 0);
     };
-    // U chunks per loop iteration: whole super-chunks, an even number of them (the operand sets alternate)
-    using T = std::true_type;
-    using H1 = std::bool_constant<SS == 1>;                  // is the second chunk of a pair the head of a super-chunk?
-    using Fa = std::false_type;
+    // U chunks per loop iteration: whole super-chunks and whole turns of both operand rings
     using NoSt = std::integral_constant<int, -1>;
-    constexpr int U = SS >= 2 ? SS : 2;
     static_assert(SS == 1 || SS == 2 || SS == 4, "chunks per barrier");
+    static_assert(RB == 2 || RB == 4, "weight-fragment ring of 2 or 4 sets");
     static_assert(NPS == 0 || S == 0, "the staging pass has no previous pass to store");
+    constexpr int U = (SS == 4 || RB == 4) ? 4 : 2;
     int c = 0;
     if constexpr (NPS > 0) {
         // the first NPS steps, peeled: step k carries store k of the previous pass (the accumulator index must be a
         // compile-time constant).  Launches with fewer chunks than stores (small E) issue them all up front.
-        constexpr int NPE = (NPS + 1) & ~1;                  // an even count: the loop below starts on operand set 0
+        constexpr int NPE = (NPS + U - 1) / U * U;           // whole turns: the loop below starts at ring position 0
         if (nchunk >= NPE) {
             static_for<0, NPE>([&](auto kc) {
                 constexpr int k = decltype(kc)::value;
-                using St = std::integral_constant<int, (k < NPS ? k : -1)>;
-                if constexpr (k % 2 == 0) step(k, o0, o1, Fa{}, St{});
-                else step(k, o1, o0, Fa{}, St{});
+                step(k, std::integral_constant<int, k % U>{}, std::false_type{}, std::integral_constant<int, (k < NPS ? k : -1)>{});
             });
             c = NPE;
         } else {
             static_for<0, NPS>([&](auto kc) { store_prev(kc); });
         }
     }
-    for (; c + U <= nchunk; c += U) {
-        step(c, o0, o1, T{}, NoSt{});
-        step(c + 1, o1, o0, H1{}, NoSt{});
-        if constexpr (U == 4) {
-            step(c + 2, o0, o1, Fa{}, NoSt{});
-            step(c + 3, o1, o0, Fa{}, NoSt{});
-        }
-    }
-    // the last, partial group (peeled: an exit inside the loop body makes hipcc wait vmcnt(0) at its head)
-    if (c < nchunk) step(c, o0, o1, T{}, NoSt{});
-    if constexpr (U == 4) {
-        if (c + 1 < nchunk) step(c + 1, o1, o0, Fa{}, NoSt{});
-        if (c + 2 < nchunk) step(c + 2, o0, o1, Fa{}, NoSt{});
-    }
+    for (; c + U <= nchunk; c += U)
+        static_for<0, U>([&](auto kc) {
+            constexpr int k = decltype(kc)::value;
+            step(c + k, kc, std::bool_constant<k % SS == 0>{}, NoSt{});
+        });
+    // the last, partial turn (peeled: an exit inside the loop body makes hipcc wait vmcnt(0) at its head)
+    static_for<0, U - 1>([&](auto kc) {
+        constexpr int k = decltype(kc)::value;
+        if (c + k < nchunk) step(c + k, kc, std::bool_constant<k % SS == 0>{}, NoSt{});
+    });
 }
 
 // NCW: column tiles of this wave (from ct0); NEX: units of the shared row tile it adds (SIMD 3: 4 | 3, from eoff), in

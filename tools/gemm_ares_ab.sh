@@ -19,6 +19,9 @@ declare -A V=(
   [a43nt]="-DR4R_AR_R1=4 -DR4R_AR_R2=3 -DR4R_AR_S=2 -DR4R_AR_AUX=2"
   [a52s1]="-DR4R_AR_R1=5 -DR4R_AR_R2=2 -DR4R_AR_S=1 -DR4R_AR_AUX=0"
   [a52ns]="-DR4R_AR_R1=5 -DR4R_AR_R2=2 -DR4R_AR_S=2 -DR4R_AR_AUX=0 -DR4R_EPI=2"
+  [db1]="-DR4R_AR_DB=1"
+  [db3]="-DR4R_AR_DB=3"
+  [db3ns]="-DR4R_AR_DB=3 -DR4R_EPI=2"
   [c2]="-DR4R_AR_SPLIT=2"
   [c2s1]="-DR4R_AR_SPLIT=2 -DR4R_AR_S=1"
   [c2ns]="-DR4R_AR_SPLIT=2 -DR4R_EPI=2"
