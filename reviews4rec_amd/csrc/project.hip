@@ -629,49 +629,104 @@ __device__ __forceinline__ void proj_gemm7_body(const ProjArgs &a, float *lds, c
 // ends (~6 TB/s), with no MFMA issued meanwhile.  Output can only leave earlier if it is COMPLETE earlier, i.e. if
 // a workgroup runs all of K over part of its tile, then all of K again over the rest -- which the forms above
 // cannot do without staging their operands twice.
-// Here the workgroup's A rows (7 private row tiles + the shared one = 128 rows x all of K, swizzled 64-byte chunk
+// Here the workgroup's A rows (P private row tiles + the shared one, <= 128 rows x all of K, swizzled 64-byte chunk
 // rows: 155,648 B of the CU's 160 KB at E = 300) stay RESIDENT in LDS once staged, and the B operand never passes
 // through LDS: every wave owns whole COLUMN tiles (3 or 2 of the 19: waves w and w + 4 of a SIMD share its 5, SIMD
 // 3 has 4 and adds the shared row tile's units like the balanced form) and loads its W fragments straight from the
 // conv weight in the MFMA operand layout (16 filters x 64 B per instruction -- the shape the staging loads had).
-// The wave then sweeps K once per PASS over a group of row tiles:
-//   pass 1 (row tiles 0 .. R1-1): the K loop of the forms above minus the B staging -- per chunk and thread one
-//           table-row piece global -> register -> LDS (all 128 rows: the later passes' rows arrive here too), R1
-//           operand reads, NCW weight-fragment loads, 4 R1 NCW MFMAs; every chunk has its own LDS region, so the
-//           barriers only publish data (no buffer is ever reused) and one per AR_S chunks is enough;
-//   later passes: no staging and NO barrier -- the waves run free over the resident chunks (measured: ~97 % MFMA
-//           pipe time against ~85 % for the barrier-paced pass); the previous pass's results are stored straight
-//           from the accumulators (float4 per tile: the operand roles are swapped, see MFMA4S) behind the new pass's
-//           first operand requests, WRITE-THROUGH (sc1): they leave the L2 while the MFMAs run instead of waiting
-//           dirty for the end of the kernel.
-// Only the last pass's share of the output is still written in the final burst.  Same K order per output element
-// as the other forms: identical bits.
+// The wave then sweeps K once per PASS:
+//   pass 1: EVERY wave all P row tiles x 2 of its column tiles (2 P tiles, 4 P per SIMD: perfectly balanced) --
+//           the K loop of the forms above minus the B staging: per chunk and thread one table-row piece global ->
+//           register -> LDS (all 128 rows), P operand reads, 2 weight-fragment loads, 8 P MFMAs; every chunk has its
+//           own LDS region, so the barriers only publish data (no buffer is ever reused);
+//   pass 2: no staging and NO barrier -- the waves run free over the resident chunks: the three-column waves finish
+//           their third column (P tiles), SIMD 3's waves compute the shared row tile's units (4 | 3), the two-column
+//           waves store their results and leave.  Pass 1's results are stored straight from the accumulators (float4
+//           per tile: the operand roles are swapped, see MFMA4S), ONE TILE PER K STEP of pass 2: a wave's loads wait
+//           behind its older stores (one in-order counter), so a burst of stores ahead of the loop stalled every wave
+//           until its last store was acknowledged, while one store per step has a K step's time to land.
+// Only pass 2's share of the output (a fifth at P = 7) is still written in the final burst.  Same K order per output
+// element as the other forms: identical bits.  P = 4 .. 7 (the balanced form's plan generalised: the smallest P whose
+// plan applies puts the most CUs to work -- cfg4's 1,234 row tiles run as 246 workgroups of 5 instead of 176 of 7).
+// Measured alternatives (row-group passes, column groups 2 | 1, chunks per barrier, write-through / nontemporal
+// stores, mid-kernel write-back requests, deeper weight prefetch, several rounds of tiles per workgroup): DESIGN.md
+// 4.1b, profiles/r03a_gemm_variants.txt.
+//
 // weight operand x table operand: the lane ends up with 4 consecutive COLUMNS of one table row (same fma chain as
 // the other forms' table x weight order: identical bits), which it stores as one float4
 #define MFMA4S(tab, wgt, c) __builtin_amdgcn_mfma_f32_16x16x4f32(wgt, tab, c, 0, 0, 0)
 constexpr int AR_ROWS = 128;                       // LDS rows per K chunk
 constexpr int AR_CHUNK = AR_ROWS * PEC;            // floats per chunk region
 constexpr int AR_MAX_CHUNKS = 20;                  // 20 x 8 KB = 160 KB: E <= 320
-#ifndef R4R_AR_R1
-#define R4R_AR_R1 4                                // row tiles of pass 1, 2 (the rest of the 7: pass 3, may be 0)
+#ifndef R4R_AR_PMIN
+#define R4R_AR_PMIN 4
 #endif
-#ifndef R4R_AR_R2
-#define R4R_AR_R2 3
-#endif
+constexpr int AR_PMIN = R4R_AR_PMIN, AR_PMAX = 7;  // private row tiles per workgroup
 #ifndef R4R_AR_S
 #define R4R_AR_S 1                                 // chunks staged per barrier in pass 1 (1, 2 or 4: no measurable difference)
 #endif
-#ifndef R4R_AR_AUX
-#define R4R_AR_AUX 0                               // cache bits of the early passes' stores: 0 = plain (measured best), 16 = sc1 (write-through), 2 = nt
-#endif
-#ifndef R4R_AR_SPLIT
-#define R4R_AR_SPLIT 2                             // 2: every wave 7 x 2 tiles in pass 1, third columns + shared units in pass 2 (measured best); 1: column groups 2 | 1; 0: row-tile groups (R1 | R2 | rest)
-#endif
-#ifndef R4R_AR_AUX_LAST
-#define R4R_AR_AUX_LAST 0                          // ... and of the last pass's
+#ifndef R4R_AR_DB
+#define R4R_AR_DB 1                                // pass 2: chunks the weight fragments are requested ahead of their MFMAs (1 or 3; 3 measured no faster)
 #endif
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+struct AresPlan { int tower, P, row0, sh_row0, sh_c0, sh_n; };
+struct AresFit { int rt[MAX_TOWERS], g[MAX_TOWERS], U, P; };
+
+// gemm7_plan for P private row tiles per workgroup on `cap` workgroups: G = min(U / P, cap) of them split over the
+// towers in proportion to their row tiles, the left-over row tiles of a tower each shared column-wise by >= 3 of its
+// workgroups.  A pure function of the towers' distinct-token counts, evaluated by every workgroup.
+__device__ __forceinline__ bool ares_fit(const ProjArgs &a, AresFit &f, int P, int cap) {
+    int G = f.U / P;
+    if (G > cap) G = cap;
+    if (G < a.ntower || G * 2 <= cap) return false;         // (launches that fill at most half of the grid: column parts of the tile form)
+    for (int t = 0; t < a.ntower; ++t) {
+        f.g[t] = f.rt[t] * G / f.U;                         // (products < 2^24: 32-bit arithmetic)
+        const int left = f.rt[t] - P * f.g[t];              // row tiles nobody owns: shared, >= 3 workgroups each
+        if (f.g[t] < 1 || left < 0 || 3 * left > f.g[t]) return false;
+    }
+    f.P = P;
+    return true;
+}
+
+// The plan of a launch on `nwg` persistent workgroups: the smallest P that fits -- the most workgroups at work.
+__device__ __forceinline__ bool ares_plan_fit(const ProjArgs &a, int nwg, AresFit &f) {
+    f.U = 0;
+    for (int t = 0; t < MAX_TOWERS; ++t) f.rt[t] = 0;
+    for (int t = 0; t < a.ntower; ++t) { f.rt[t] = (a.t[t].count[0] + 15) >> 4; f.U += f.rt[t]; }
+    if (f.U == 0 || f.U >= (1 << 15)) return false;
+    const int grid = nwg < G7_WGS ? nwg : G7_WGS;
+    for (int P = AR_PMIN; P <= AR_PMAX; ++P)
+        if (ares_fit(a, f, P, grid)) return true;
+    return false;
+}
+
+// workgroup wg's share of the plan (p.tower < 0: nothing)
+__device__ __forceinline__ void ares_assign(const ProjArgs &a, const AresFit &f, int wg, AresPlan &p) {
+    const int P = f.P;
+    p.tower = -1;
+    p.P = P;
+    int base = 0;
+    for (int t = 0; t < a.ntower; ++t) {
+        if (wg >= base && wg < base + f.g[t]) {
+            const int wl = wg - base, left = f.rt[t] - P * f.g[t];
+            p.tower = t;
+            p.row0 = wl * P * 16;
+            p.sh_row0 = -1; p.sh_c0 = 0; p.sh_n = 0;
+            if (left > 0) {
+                const int lt = wl * left / f.g[t];                                 // the shared row tile of this workgroup
+                const int w_lo = (lt * f.g[t] + left - 1) / left;                   // its sharers: [w_lo, w_hi)
+                const int w_hi = ((lt + 1) * f.g[t] + left - 1) / left;
+                const int n = w_hi - w_lo, k = wl - w_lo;
+                p.sh_row0 = (P * f.g[t] + lt) * 16;
+                p.sh_c0 = PNT * k / n;
+                p.sh_n = PNT * (k + 1) / n - p.sh_c0;                               // <= ceil(19 / 3) = 7
+            }
+        }
+        base += f.g[t];
+    }
+}
 
 // 16-byte slot of logical float4 column q in a 64-byte chunk row: q ^ g((row >> 2) & 3), g = [0, 3, 2, 1].  A
 // ds_read_b128 lane group holds rows {a, a+4, a+8, a+12} x two q values per residue a = row & 3 (bank slot =
@@ -693,13 +748,6 @@ struct AresCtx {
     int E, nchunk, c4, q, a_off;
 };
 
-// One pass: row tiles rt0 .. rt0 + NR - 1 (of the 8 resident ones) x this wave's NCW column tiles, plus NEX units of
-// the shared row tile (row tile 7).  S > 0: this pass also brings the A rows in, S chunks per barrier (pass 1).
-// `store_prev(k)`, k = 0 .. NPS - 1 (compile-time), stores one tile of the PREVIOUS pass's results; one is issued per
-// K step of this pass.  A wave's loads and stores share ONE in-order counter (vmcnt): the wait for step c + 1's weight
-// fragments also waits for every store issued before them, so a burst of stores ahead of the loop stalls the wave
-// until the last of them is acknowledged (measured: the whole "overlap" lost), while one store per step has a K
-// step's time to land.  Results stay in acc / ex.
 template <int I, int N, typename F>
 __device__ __forceinline__ void static_for(F &&f) {
     if constexpr (I < N) {
@@ -708,22 +756,20 @@ __device__ __forceinline__ void static_for(F &&f) {
     }
 }
 
-#ifndef R4R_AR_DB
-#define R4R_AR_DB 1                                // free passes: chunks the weight fragments are requested ahead of their MFMAs (1 or 3; 3 measured no faster)
-#endif
+template <int NR>
+struct AresA { f32x4 a[NR]; };
+template <int NCW>
+struct AresB { f32x4 b[NCW]; };
 
-template <int NR, int NEX>
-struct AresA { f32x4 a[NR], sa; };
-template <int NCW, int NEX>
-struct AresB { f32x4 b[NCW], eb[NEX > 0 ? NEX : 1]; };
-
-template <int NR, int NCW, int NEX, int S, int NPS, typename F>
+// One pass: resident row tiles rt0 .. rt0 + NR - 1 x the NCW column tiles whose weight rows `bptr` names.  S > 0: this
+// pass also brings the A rows in, S chunks per barrier (pass 1).  `store_prev(k)`, k = 0 .. NPS - 1 (compile-time),
+// stores one tile of the PREVIOUS pass's results; one is issued per K step of this pass.  Results stay in acc.
+template <int NR, int NCW, int S, int NPS, typename F>
 __device__ __forceinline__ void ares_pass(const AresCtx &x, int rt0, const float *const (&bptr)[NCW],
-                                          const float *const (&ebptr)[NEX > 0 ? NEX : 1], f32x4 (&acc)[NR][NCW],
-                                          f32x4 (&ex)[NEX > 0 ? NEX : 1], F store_prev) {
-    constexpr int NE = NEX > 0 ? NEX : 1, SS = S > 0 ? S : 1;
+                                          f32x4 (&acc)[NR][NCW], F store_prev) {
+    constexpr int SS = S > 0 ? S : 1;
     // Operand registers: the table fragments (LDS) are double-buffered; the weight fragments come from L2 and are
-    // requested DB chunks ahead into a ring of DB + 1 sets.  (A timing ablation with the free passes' weight loads
+    // requested DB chunks ahead into a ring of DB + 1 sets.  (A timing ablation with the free pass's weight loads
     // aimed at one hot line took pass 2 from 11.7 to 8.8 us; requesting them 3 chunks ahead instead of 1 did NOT
     // -- 12.3 us: what those loads cost is their 16 lines per instruction in the address path, not their latency.)
     constexpr int DB = S > 0 ? 1 : R4R_AR_DB, RB = DB + 1;
@@ -747,43 +793,31 @@ __device__ __forceinline__ void ares_pass(const AresCtx &x, int rt0, const float
             *reinterpret_cast<f32x4 *>(x.st_dst + c * AR_CHUNK) = v;
         }
     };
-    auto req_b = [&](int c, AresB<NCW, NEX> &o) {            // weight fragments: global -> registers
+    auto req_b = [&](int c, AresB<NCW> &o) {                 // weight fragments: global -> registers
         const int e = min(min(c, nchunk - 1) * PEC + x.q * 4, E - 4);
 #pragma unroll
         for (int j = 0; j < NCW; ++j) o.b[j] = *reinterpret_cast<const f32x4 *>(bptr[j] + e);
-        if (NEX > 0) {
-#pragma unroll
-            for (int j = 0; j < NE; ++j) o.eb[j] = *reinterpret_cast<const f32x4 *>(ebptr[j] + e);
-        }
     };
-    auto req_a = [&](int c, AresA<NR, NEX> &o) {             // table fragments: resident LDS -> registers
+    auto req_a = [&](int c, AresA<NR> &o) {                  // table fragments: resident LDS -> registers
         const float *ab = x.lds + min(c, nchunk - 1) * AR_CHUNK + x.a_off;
 #pragma unroll
         for (int i = 0; i < NR; ++i) o.a[i] = *reinterpret_cast<const f32x4 *>(ab + (rt0 + i) * 16 * PEC);
-        if (NEX > 0) o.sa = *reinterpret_cast<const f32x4 *>(ab + G7_ROWS * 16 * PEC);
     };
-    auto mfma = [&](const AresA<NR, NEX> &oa, const AresB<NCW, NEX> &ob) {
+    auto mfma = [&](const AresA<NR> &oa, const AresB<NCW> &ob) {
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
+        for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
             for (int i = 0; i < NR; ++i)
 #pragma unroll
                 for (int j = 0; j < NCW; ++j) acc[i][j] = MFMA4S(oa.a[i][kk], ob.b[j][kk], acc[i][j]);
-            if (NEX > 0) {
-#pragma unroll
-                for (int j = 0; j < NE; ++j) ex[j] = MFMA4S(oa.sa[kk], ob.eb[j][kk], ex[j]);
-            }
-        }
     };
 #pragma unroll
     for (int i = 0; i < NR; ++i)
 #pragma unroll
         for (int j = 0; j < NCW; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int j = 0; j < NE; ++j) ex[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    AresA<NR, NEX> oa[2];
-    AresB<NCW, NEX> ob[RB];
+    AresA<NR> oa[2];
+    AresB<NCW> ob[RB];
     if (S > 0) {
         ld_a(0, ar);
         req_b(0, ob[0]);                                     // weight fragments of chunk 0: in flight under the staging
@@ -799,7 +833,7 @@ __device__ __forceinline__ void ares_pass(const AresCtx &x, int rt0, const float
         req_a(0, oa[0]);
     }
     // chunk c (ring position r = c mod lcm(2, RB), compile-time): its operands are in oa[r & 1] / ob[r % RB].  HEAD
-    // (first chunk of super-chunk s, staging passes): behind the barrier super-chunk s + 1 is visible, the staging
+    // (first chunk of super-chunk s, staging pass): behind the barrier super-chunk s + 1 is visible, the staging
     // registers (super-chunk s + 2, requested a super-step ago) go to LDS and super-chunk s + 3 is requested.  One
     // memory instruction behind every few MFMAs, like the forms above.
     auto step = [&](int c, auto rc, auto headc, auto storec) {
@@ -817,17 +851,17 @@ __device__ __forceinline__ void ares_pass(const AresCtx &x, int rt0, const float
             ld_a(c / SS + 3, ar);
         }
         mfma(oa[r & 1], ob[r % RB]);
-        constexpr int NRD = NR + (NEX > 0 ? 1 : 0), NLD = NCW + NEX + ((S > 0 && head) ? SS : 0), NWR = (S > 0 && head) ? SS : 0;
-        constexpr int NM = 4 * (NR * NCW + NEX);
-        constexpr int NMEM_MAX = NR + 1 + NCW + NEX + 2 * SS + 1;
+        constexpr int NLD = NCW + ((S > 0 && head) ? SS : 0), NWR = (S > 0 && head) ? SS : 0;
+        constexpr int NM = 4 * NR * NCW;
+        constexpr int NMEM_MAX = NR + NCW + 2 * SS + 1;
         constexpr int GAP = NM / NMEM_MAX >= 4 ? 4 : (NM / NMEM_MAX >= 1 ? NM / NMEM_MAX : 1);
 #pragma unroll
-        for (int i = 0; i < NCW + NEX; ++i) {
+        for (int i = 0; i < NCW; ++i) {
             __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
             __builtin_amdgcn_sched_group_barrier(0x008, GAP, 0);
         }
 #pragma unroll
-        for (int i = 0; i < NR + (NEX > 0 ? 1 : 0); ++i) {
+        for (int i = 0; i < NR; ++i) {
             __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
             __builtin_amdgcn_sched_group_barrier(0x008, GAP, 0);
         }
@@ -847,7 +881,8 @@ __device__ __forceinline__ void ares_pass(const AresCtx &x, int rt0, const float
                 __builtin_amdgcn_sched_group_barrier(0x008, GAP, 0);
             }
         }
-        __builtin_amdgcn_sched_group_barrier(0x008, NM - GAP * (NRD + NLD + NWR + (store_k >= 0 ? 1 : 0)), 0);
+        constexpr int REST = NM - GAP * (NR + NLD + NWR + (store_k >= 0 ? 1 : 0));
+        if constexpr (REST > 0) __builtin_amdgcn_sched_group_barrier(0x008, REST, 0);
     };
     // U chunks per loop iteration: whole super-chunks and whole turns of both operand rings
     using NoSt = std::integral_constant<int, -1>;
@@ -882,14 +917,11 @@ __device__ __forceinline__ void ares_pass(const AresCtx &x, int rt0, const float
     });
 }
 
-// NCW: column tiles of this wave (from ct0); NEX: units of the shared row tile it adds (SIMD 3: 4 | 3, from eoff), in
-// pass EXP (SIMD 3's two waves take theirs in DIFFERENT passes: with R1 = 4 the SIMDs then carry 20 / 20 / 20 / 16 + 4
-// tiles in pass 1 and 15 / 15 / 15 / 12 + 3 in pass 2 -- all of them in the last pass made SIMD 3 its pole, 19 : 15)
-template <int NCW, int NEX, int EXP = 2>
-__device__ __forceinline__ void proj_gemm_ares_body(const ProjArgs &a, float *lds, const Gemm7Plan &p, int ct0, int eoff) {
+// P: private row tiles of the workgroup; NCW: column tiles of this wave (from ct0); NEX: units of the shared row tile
+// it adds in pass 2 (SIMD 3: 4 | 3, from eoff)
+template <int P, int NCW, int NEX>
+__device__ __forceinline__ void proj_gemm_ares_body(const ProjArgs &a, float *lds, const AresPlan &p, int ct0, int eoff) {
     constexpr int NE = NEX > 0 ? NEX : 1;
-    constexpr int R1 = R4R_AR_R1, R2 = R4R_AR_R2, R3 = G7_ROWS - R1 - R2, R3A = R3 > 0 ? R3 : 1;
-    static_assert(R1 >= 1 && R2 >= 1 && R3 >= 0, "pass split");
     const ProjTower &tw = a.t[p.tower];
     const int count = tw.count[0];
     TRACE_STAMP(0)
@@ -906,179 +938,98 @@ __device__ __forceinline__ void proj_gemm_ares_body(const ProjArgs &a, float *ld
     x.lds = lds; x.E = a.E; x.nchunk = a.nchunk;
     x.q = lane >> 4;
     x.a_off = lrow * PEC + ar_col(lrow, x.q) * 4;
-    // staging role: float4 column c4 of LDS row tid >> 2 (rows 0..111 private, 112..127 the shared row tile)
+    // staging role: float4 column c4 of LDS row tid >> 2 (rows 0 .. 16 P - 1 private, the next 16 the shared row tile;
+    // threads beyond them re-stage its last row: unconditional loads, nothing reads what they write)
     x.c4 = tid & 3;
     const int srow = tid >> 2;
-    int grow = srow < G7_ROWS * 16 ? p.row0 + srow : (p.sh_row0 < 0 ? 0 : p.sh_row0 + srow - G7_ROWS * 16);
+    int grow = srow < P * 16 ? p.row0 + srow : (p.sh_row0 < 0 ? 0 : p.sh_row0 + min(srow - P * 16, 15));
     grow = grow < count ? grow : count - 1;
     x.aptr = a.table + (long)tw.list[grow] * a.E;
     x.st_dst = lds + srow * PEC + ar_col(srow, x.c4) * 4;
     // weight fragments: lane (lrow, q) of column tile ct holds W[f][j][16 c + 4 q ..], n = 16 ct + lrow = 100 j + f
     const float *__restrict__ conv_w = tw.conv_w;
-    const float *bptr[NCW], *ebptr[NE];
-    int ecol[NE];
     auto wrow = [&](int ct) {
         const int n = ct * 16 + lrow;
         const int j = n / PF, f = n - j * PF;
         return conv_w + (n < PROW ? ((long)f * 3 + j) * a.E : 0);       // padding columns re-read W[0][0]: never stored
     };
-#pragma unroll
-    for (int j = 0; j < NCW; ++j) bptr[j] = wrow(ct0 + j);
-#pragma unroll
-    for (int j = 0; j < NE; ++j) {
-        ecol[j] = min(p.sh_c0 + eoff + j, PNT - 1);                        // beyond the assignment: computed, never stored
-        ebptr[j] = wrow(ecol[j]);
-    }
-    // Stores go through a buffer descriptor over this tower's projected rows (wave-uniform words), so that they can
-    // carry cache bits; 32-bit byte offsets: the launcher keeps form 3 to outputs under 2 GB.
+    // Stores go through a buffer descriptor over this tower's projected rows (wave-uniform words): branch-free (a
+    // branch would end the K step's scheduling region) -- rows past `count`, padding columns and unassigned shared
+    // units get an offset outside the descriptor, which the hardware drops.  32-bit byte offsets: the launcher keeps
+    // form 3 to outputs under 2 GB.
     const unsigned long long pbase = reinterpret_cast<unsigned long long>(tw.ptab);
     const unsigned plo = __builtin_amdgcn_readfirstlane((unsigned)pbase), phi = __builtin_amdgcn_readfirstlane((unsigned)(pbase >> 32));
     float *pt = reinterpret_cast<float *>(((unsigned long long)phi << 32) | plo);
     [[maybe_unused]] const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(pt, 0, __builtin_amdgcn_readfirstlane(count) * (PROW * 4), 0x00020000);
-    auto store_tile = [&](const f32x4 &v, int row_first, int ct, auto AUXc, bool ok = true) {
+    auto store_tile = [&](const f32x4 &v, int row_first, int ct, bool ok = true) {
 #if R4R_EPI == 2
         asm volatile("" ::"v"(v));
 #else
-        constexpr int AUX = decltype(AUXc)::value;
         const int row = row_first + lrow, col = ct * 16 + x.q * 4;
-        // branch-free (a branch would end the K step's scheduling region): rows past `count` and the padding columns
-        // get an offset outside the descriptor, which the hardware drops
         const int off = (ok && row < count && col < PROW) ? (row * PROW + col) * 4 : 0x7ffffff0;
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsrc, off, 0, AUX);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsrc, off, 0, 0);
 #endif
     };
-    using AuxEarly = std::integral_constant<int, R4R_AR_AUX>;
-    using AuxLast = std::integral_constant<int, R4R_AR_AUX_LAST>;
-    const float *const nonep[1] = {conv_w};
-    auto nothing = [](auto) {};
-#if R4R_AR_SPLIT == 2
-    {
-        // Pass 1: EVERY wave takes all 7 row tiles x 2 of its column tiles (14 tiles, 28 per SIMD: the barrier-paced
-        // pass is perfectly balanced).  Pass 2: the three-column waves finish their third column (7 tiles, alone on
-        // their SIMD: the two-column partner has stored its results and left), SIMD 3's waves compute the shared row
-        // tile's units (4 | 3).  Only a fifth of the output is still written in the final burst.
-        constexpr int C2 = NCW - 2;
-        const float *b1[2] = {bptr[0], bptr[1]};
-        f32x4 a1[G7_ROWS][2], none[1];
-        ares_pass<G7_ROWS, 2, 0, R4R_AR_S, 0>(x, 0, b1, nonep, a1, none, nothing);
-        TRACE_STAMP(1)
-        __syncthreads();
-        auto store1 = [&](auto kc) {
-            constexpr int k = decltype(kc)::value;
-            store_tile(a1[k / 2][k % 2], p.row0 + (k / 2) * 16, ct0 + k % 2, AuxEarly{});
-        };
-        if constexpr (C2 > 0) {
-            const float *b2[C2];
-#pragma unroll
-            for (int j = 0; j < C2; ++j) b2[j] = bptr[2 + j];
-            f32x4 a2[G7_ROWS][C2];
-            ares_pass<G7_ROWS, C2, 0, 0, G7_ROWS * 2>(x, 0, b2, nonep, a2, none, store1);
-            TRACE_STAMP_LAST(2)
-#pragma unroll
-            for (int i = 0; i < G7_ROWS; ++i)
-#pragma unroll
-                for (int j = 0; j < C2; ++j) store_tile(a2[i][j], p.row0 + i * 16, ct0 + 2 + j, AuxLast{});
-        } else if constexpr (NEX > 0) {
-            f32x4 ax[1][NEX];                                // the shared row tile (resident row tile 7) x this wave's units
-            ares_pass<1, NEX, 0, 0, G7_ROWS * 2>(x, G7_ROWS, ebptr, nonep, ax, none, store1);
-            TRACE_STAMP_LAST(2)
-#pragma unroll
-            for (int j = 0; j < NEX; ++j)
-                store_tile(ax[0][j], p.sh_row0, ecol[j], AuxLast{}, eoff + j < p.sh_n && p.sh_row0 >= 0);
-        } else {
-            static_for<0, G7_ROWS * 2>([&](auto kc) { store1(kc); });     // nothing left to compute: store and leave
-            TRACE_STAMP_LAST(2)
-        }
-        TRACE_STAMP_LAST(3)
-        return;
-    }
-#elif R4R_AR_SPLIT == 1
-    {
-        // Passes over COLUMN groups: pass 1 = all 7 row tiles x the first C1 of this wave's column tiles (+ ALL of SIMD
-        // 3's shared-tile units: 14 + 7 | 7 + 4 + 7 + 3 = 21 tiles per SIMD), pass 2 = all 7 x the other C2 (14 per
-        // SIMD).  Every weight fragment is loaded once per launch (row-group passes load each twice); the resident A
-        // rows are read twice.
-        constexpr int C1 = NCW == 3 ? 2 : 1, C2 = NCW - C1;
-        const float *b1[C1], *b2[C2];
-#pragma unroll
-        for (int j = 0; j < C1; ++j) b1[j] = bptr[j];
-#pragma unroll
-        for (int j = 0; j < C2; ++j) b2[j] = bptr[C1 + j];
-        f32x4 a1[G7_ROWS][C1], a2[G7_ROWS][C2], none[1], ex[NE];
-        if constexpr (NEX > 0) ares_pass<G7_ROWS, C1, NEX, R4R_AR_S, 0>(x, 0, b1, ebptr, a1, ex, nothing);
-        else ares_pass<G7_ROWS, C1, 0, R4R_AR_S, 0>(x, 0, b1, nonep, a1, none, nothing);
-        TRACE_STAMP(1)
-        __syncthreads();
-        auto store1 = [&](auto kc) {
-            constexpr int k = decltype(kc)::value;
-            if constexpr (k < G7_ROWS * C1) store_tile(a1[k / C1][k % C1], p.row0 + (k / C1) * 16, ct0 + k % C1, AuxEarly{});
-            else store_tile(ex[k - G7_ROWS * C1], p.sh_row0, ecol[k - G7_ROWS * C1], AuxEarly{},
-                            eoff + (k - G7_ROWS * C1) < p.sh_n && p.sh_row0 >= 0);
-        };
-        ares_pass<G7_ROWS, C2, 0, 0, G7_ROWS * C1 + NEX>(x, 0, b2, nonep, a2, none, store1);
-        TRACE_STAMP_LAST(2)
-#pragma unroll
-        for (int i = 0; i < G7_ROWS; ++i)
-#pragma unroll
-            for (int j = 0; j < C2; ++j) store_tile(a2[i][j], p.row0 + i * 16, ct0 + C1 + j, AuxLast{});
-        TRACE_STAMP_LAST(3)
-        return;
-    }
-#endif
-    f32x4 acc1[R1][NCW], acc2[R2][NCW], acc3[R3A][NCW], none[1], ex[NE];
-    constexpr int NEX1 = EXP == 1 ? NEX : 0, NEXL = EXP == 1 ? 0 : NEX;
+    // ---- pass 1: all P row tiles x the wave's first two column tiles; stages the A rows
+    const float *b1[2] = {wrow(ct0), wrow(ct0 + 1)};
+    f32x4 a1[P][2];
 #ifdef R4R_TRACE
     const unsigned long long clk0 = __builtin_readcyclecounter();
 #endif
-    if constexpr (NEX1 > 0) ares_pass<R1, NCW, NEX1, R4R_AR_S, 0>(x, 0, bptr, ebptr, acc1, ex, nothing);
-    else ares_pass<R1, NCW, 0, R4R_AR_S, 0>(x, 0, bptr, nonep, acc1, none, nothing);
+    ares_pass<P, 2, R4R_AR_S, 0>(x, 0, b1, a1, [](auto) {});
     TRACE_STAMP(1)
 #ifdef R4R_TRACE
     const unsigned long long clk1 = __builtin_readcyclecounter();
     if (g_trace && threadIdx.x == 0) g_trace[((size_t)blockIdx.x) * 8 + 7] = clk1 - clk0;    // shader cycles of pass 1
 #endif
     __syncthreads();                                         // every chunk of every row is in LDS: the waves run free from here
-    auto store_ex = [&](int j, auto AUXc) {
-        store_tile(ex[j], p.sh_row0, ecol[j], AUXc, eoff + j < p.sh_n && p.sh_row0 >= 0);
-    };
-    // store k of pass 1's results: tile (k / NCW, k % NCW), then the shared-tile units
-    constexpr int NS1 = R1 * NCW + NEX1;
-    auto store1 = [&](auto kc) {
+    auto store1 = [&](auto kc) {                             // store k of pass 1's results: tile (k / 2, k % 2)
         constexpr int k = decltype(kc)::value;
-        if constexpr (k < R1 * NCW) store_tile(acc1[k / NCW][k % NCW], p.row0 + (k / NCW) * 16, ct0 + k % NCW, AuxEarly{});
-        else store_ex(k - R1 * NCW, AuxEarly{});
+        store_tile(a1[k / 2][k % 2], p.row0 + (k / 2) * 16, ct0 + k % 2);
     };
-    if constexpr (R3 == 0) {
-        if constexpr (NEXL > 0) ares_pass<R2, NCW, NEXL, 0, NS1>(x, R1, bptr, ebptr, acc2, ex, store1);
-        else ares_pass<R2, NCW, 0, 0, NS1>(x, R1, bptr, nonep, acc2, none, store1);
+    // ---- pass 2
+    if constexpr (NCW == 3) {                                // the third column tile
+        const float *b2[1] = {wrow(ct0 + 2)};
+        f32x4 a2[P][1];
+        ares_pass<P, 1, 0, P * 2>(x, 0, b2, a2, store1);
         TRACE_STAMP_LAST(2)
-#ifdef R4R_TRACE
-        if (g_trace && threadIdx.x == 0)                     // ... and of pass 2 (word 6: bit 0 = active)
-            g_trace[((size_t)blockIdx.x) * 8 + 6] = ((__builtin_readcyclecounter() - clk1) << 1) | 1;
-#endif
 #pragma unroll
-        for (int i = 0; i < R2; ++i)
+        for (int i = 0; i < P; ++i) store_tile(a2[i][0], p.row0 + i * 16, ct0 + 2);
+    } else if constexpr (NEX > 0) {                          // the shared row tile (resident row tile P) x this wave's units
+        const float *be[NE];
+        int ecol[NE];
 #pragma unroll
-            for (int j = 0; j < NCW; ++j) store_tile(acc2[i][j], p.row0 + (R1 + i) * 16, ct0 + j, AuxLast{});
+        for (int j = 0; j < NE; ++j) {
+            ecol[j] = min(p.sh_c0 + eoff + j, PNT - 1);      // beyond the assignment: computed, never stored
+            be[j] = wrow(ecol[j]);
+        }
+        f32x4 ax[1][NE];
+        ares_pass<1, NE, 0, P * 2>(x, P, be, ax, store1);
+        TRACE_STAMP_LAST(2)
+#pragma unroll
+        for (int j = 0; j < NE; ++j) store_tile(ax[0][j], p.sh_row0, ecol[j], eoff + j < p.sh_n && p.sh_row0 >= 0);
     } else {
-        ares_pass<R2, NCW, 0, 0, NS1>(x, R1, bptr, nonep, acc2, none, store1);
-        auto store2 = [&](auto kc) {
-            constexpr int k = decltype(kc)::value;
-            store_tile(acc2[k / NCW][k % NCW], p.row0 + (R1 + k / NCW) * 16, ct0 + k % NCW, AuxEarly{});
-        };
-        if constexpr (NEXL > 0) ares_pass<R3A, NCW, NEXL, 0, R2 * NCW>(x, R1 + R2, bptr, ebptr, acc3, ex, store2);
-        else ares_pass<R3A, NCW, 0, 0, R2 * NCW>(x, R1 + R2, bptr, nonep, acc3, none, store2);
+        static_for<0, P * 2>([&](auto kc) { store1(kc); });  // nothing left to compute: store and leave
         TRACE_STAMP_LAST(2)
-#pragma unroll
-        for (int i = 0; i < R3A; ++i)
-#pragma unroll
-            for (int j = 0; j < NCW; ++j) store_tile(acc3[i][j], p.row0 + (R1 + R2 + i) * 16, ct0 + j, AuxLast{});
     }
-    if constexpr (NEXL > 0) {
-#pragma unroll
-        for (int j = 0; j < NE; ++j) store_ex(j, AuxLast{});
-    }
+#ifdef R4R_TRACE
+    if (g_trace && threadIdx.x == 0)                         // shader cycles of wave 0's pass 2 (word 6: bit 0 = active)
+        g_trace[((size_t)blockIdx.x) * 8 + 6] = ((__builtin_readcyclecounter() - clk1) << 1) | 1;
+#endif
     TRACE_STAMP_LAST(3)
+}
+
+// the four wave roles of the A-resident form: waves w / w + 4 take 3 / 2 column tiles of SIMD w & 3's five
+template <int P>
+__device__ __forceinline__ void proj_gemm_ares_wg(const ProjArgs &a, float *lds, const AresPlan &p) {
+    const int wave = threadIdx.x >> 6, simd = wave & 3;
+    if (wave < 4) {
+        if (simd == 3) proj_gemm_ares_body<P, 2, 4>(a, lds, p, 15, 0);
+        else proj_gemm_ares_body<P, 3, 0>(a, lds, p, simd * 5, 0);
+    } else {
+        if (simd == 3) proj_gemm_ares_body<P, 2, 3>(a, lds, p, 17, 4);
+        else proj_gemm_ares_body<P, 2, 0>(a, lds, p, simd * 5 + 3, 0);
+    }
 }
 
 __global__ __launch_bounds__(GEMM_THREADS) void proj_gemm_kernel(ProjArgs a) {
@@ -1089,22 +1040,35 @@ __global__ __launch_bounds__(GEMM_THREADS) void proj_gemm_kernel(ProjArgs a) {
     for (int t = 0; t < a.ntower; ++t) first[t + 1] = first[t] + (a.t[t].count[0] + PM - 1) / PM;
     // (a launch whose tiles fill at most half of the grid is faster in column parts -- below -- than in the
     // balanced form, which keeps 112 rows per workgroup whatever the count)
-    if ((a.balanced == 1 || a.balanced == 3) && first[a.ntower] * 2 > (int)gridDim.x) {
+    if (a.balanced == 3) {
+        // One round only.  (Several rounds of tiles per workgroup -- 45 k rows as 474 tiles of 6 in two rounds -- were
+        // built and measured: 104 us against the tile form's 88 for unpadded documents, 155 against 129 for uniform
+        // words, and the round loop around the tile bodies cost the headline launch 6 us in register allocation.)
+        AresFit f;
+        AresPlan p;
+        if (ares_plan_fit(a, (int)gridDim.x, f)) {
+            ares_assign(a, f, (int)blockIdx.x, p);
+            if (p.tower < 0) return;                         // uniform: this workgroup has no rows
+            switch (p.P) {
+#if R4R_AR_PMIN <= 4
+                case 4: proj_gemm_ares_wg<4>(a, lds, p); break;
+#endif
+#if R4R_AR_PMIN <= 5
+                case 5: proj_gemm_ares_wg<5>(a, lds, p); break;
+#endif
+#if R4R_AR_PMIN <= 6
+                case 6: proj_gemm_ares_wg<6>(a, lds, p); break;
+#endif
+                default: proj_gemm_ares_wg<7>(a, lds, p); break;
+            }
+            return;
+        }
+    }
+    if (a.balanced == 1 && first[a.ntower] * 2 > (int)gridDim.x) {
         Gemm7Plan p;
         if (gemm7_plan(a, (int)blockIdx.x, (int)gridDim.x, p)) {
             if (p.tower < 0) return;                         // uniform: this workgroup has no rows
             const int wave = threadIdx.x >> 6;
-            if (a.balanced == 3) {                           // A-resident form: waves w / w + 4 take 3 / 2 column tiles of SIMD w & 3's five
-                const int simd = wave & 3;
-                if (wave < 4) {
-                    if (simd == 3) proj_gemm_ares_body<2, 4, 1>(a, lds, p, 15, 0);
-                    else proj_gemm_ares_body<3, 0>(a, lds, p, simd * 5, 0);
-                } else {
-                    if (simd == 3) proj_gemm_ares_body<2, 3>(a, lds, p, 17, 4);
-                    else proj_gemm_ares_body<2, 0>(a, lds, p, simd * 5 + 3, 0);
-                }
-                return;
-            }
             if (wave < 4) {                                  // HALF 1 (17 tiles), three B rows to stage
                 if ((wave & 3) == 3) proj_gemm7_body<4, 1, 3, 3>(a, lds, p);
                 else proj_gemm7_body<5, 1, 0, 3>(a, lds, p);
@@ -1360,7 +1324,8 @@ int textcnn_proj_compute_launch(const float *table, int64_t V, const ProjTower *
     } else {
         ScopedTiming tm(R4R_TIMING_PROJ_GEMM, st);
         // persistent: one workgroup per CU at most (86 KB of LDS each), fewer when the row capacity is small
-        int64_t wgs = ((int64_t)a.cap + G7_ROWS * 16 - 1) / (G7_ROWS * 16) * ntower;
+        const int rows_wg = (a.balanced == 3 ? AR_PMIN : G7_ROWS) * 16;     // fewest rows a workgroup may own
+        int64_t wgs = ((int64_t)a.cap + rows_wg - 1) / rows_wg * ntower;
         if (wgs > G7_WGS) wgs = G7_WGS;
         const int ares_bytes = a.nchunk * AR_CHUNK * 4;     // form 3 keeps every K chunk of its 128 rows resident
         const int lds_bytes = (a.balanced == 3 && ares_bytes > GEMM_LDS_BYTES) ? ares_bytes : GEMM_LDS_BYTES;

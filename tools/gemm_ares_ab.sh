@@ -1,36 +1,17 @@
 #!/bin/bash
-# A/B of the projection GEMM's forms and of the A-resident form's knobs (pass split R1 / R2 / rest, chunks per
-# barrier S, cache bits of the early / last stores).
+# A/B of the projection GEMM's forms and of the A-resident form's remaining build knobs (chunks per barrier, weight
+# prefetch depth, the no-store timing build).  The pass-structure variants of round 3 (profiles/r03a_gemm_variants.txt)
+# were measured with earlier versions of this script and are no longer in the source.
 #   bash tools/gemm_ares_ab.sh build | run [bench args]
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 C=$R/reviews4rec_amd/csrc
 declare -A V=(
-  [a43s2]="-DR4R_AR_R1=4 -DR4R_AR_R2=3 -DR4R_AR_S=2"
-  [a43s1]="-DR4R_AR_R1=4 -DR4R_AR_R2=3 -DR4R_AR_S=1"
-  [a43s4]="-DR4R_AR_R1=4 -DR4R_AR_R2=3 -DR4R_AR_S=4"
-  [a43pl]="-DR4R_AR_R1=4 -DR4R_AR_R2=3 -DR4R_AR_S=2 -DR4R_AR_AUX=0"
-  [a43wt]="-DR4R_AR_R1=4 -DR4R_AR_R2=3 -DR4R_AR_S=2 -DR4R_AR_AUX_LAST=16"
-  [a34s2]="-DR4R_AR_R1=3 -DR4R_AR_R2=4 -DR4R_AR_S=2"
-  [a322]="-DR4R_AR_R1=3 -DR4R_AR_R2=2 -DR4R_AR_S=2"
-  [a232]="-DR4R_AR_R1=2 -DR4R_AR_R2=3 -DR4R_AR_S=2"
-  [a331]="-DR4R_AR_R1=3 -DR4R_AR_R2=3 -DR4R_AR_S=2"
-  [a52]="-DR4R_AR_R1=5 -DR4R_AR_R2=2 -DR4R_AR_S=2 -DR4R_AR_AUX=0"
-  [a61]="-DR4R_AR_R1=6 -DR4R_AR_R2=1 -DR4R_AR_S=2 -DR4R_AR_AUX=0"
-  [a43nt]="-DR4R_AR_R1=4 -DR4R_AR_R2=3 -DR4R_AR_S=2 -DR4R_AR_AUX=2"
-  [a52s1]="-DR4R_AR_R1=5 -DR4R_AR_R2=2 -DR4R_AR_S=1 -DR4R_AR_AUX=0"
-  [a52ns]="-DR4R_AR_R1=5 -DR4R_AR_R2=2 -DR4R_AR_S=2 -DR4R_AR_AUX=0 -DR4R_EPI=2"
-  [db1]="-DR4R_AR_DB=1"
+  [def]=""
+  [s2]="-DR4R_AR_S=2"
   [db3]="-DR4R_AR_DB=3"
-  [db3ns]="-DR4R_AR_DB=3 -DR4R_EPI=2"
-  [c2]="-DR4R_AR_SPLIT=2"
-  [c2s1]="-DR4R_AR_SPLIT=2 -DR4R_AR_S=1"
-  [c2ns]="-DR4R_AR_SPLIT=2 -DR4R_EPI=2"
-  [cols]="-DR4R_AR_SPLIT=1"
-  [colss1]="-DR4R_AR_SPLIT=1 -DR4R_AR_S=1"
-  [colsns]="-DR4R_AR_SPLIT=1 -DR4R_EPI=2"
-  [a43ns]="-DR4R_AR_R1=4 -DR4R_AR_R2=3 -DR4R_AR_S=2 -DR4R_EPI=2"
+  [ns]="-DR4R_EPI=2"
 )
-ORDER=${ORDER:-"a43s2 a43s1 a43s4 a43pl a43wt a34s2 a322 a232 a331 a43ns"}
+ORDER=${ORDER:-"def s2 db3 ns"}
 if [ "$1" = build ]; then
   for t in $ORDER; do make -s -C $C variant TAG=$t EXTRA="${V[$t]}" || exit 1; done
   exit 0
