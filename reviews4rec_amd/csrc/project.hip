@@ -680,7 +680,7 @@ struct AresFit { int rt[MAX_TOWERS], g[MAX_TOWERS], U, P; };
 __device__ __forceinline__ bool ares_fit(const ProjArgs &a, AresFit &f, int P, int cap) {
     int G = f.U / P;
     if (G > cap) G = cap;
-    if (G < a.ntower || G * 2 <= cap) return false;         // (launches that fill at most half of the grid: column parts of the tile form)
+    if (G < a.ntower) return false;
     for (int t = 0; t < a.ntower; ++t) {
         f.g[t] = f.rt[t] * G / f.U;                         // (products < 2^24: 32-bit arithmetic)
         const int left = f.rt[t] - P * f.g[t];              // row tiles nobody owns: shared, >= 3 workgroups each
@@ -694,9 +694,18 @@ __device__ __forceinline__ bool ares_fit(const ProjArgs &a, AresFit &f, int P, i
 __device__ __forceinline__ bool ares_plan_fit(const ProjArgs &a, int nwg, AresFit &f) {
     f.U = 0;
     for (int t = 0; t < MAX_TOWERS; ++t) f.rt[t] = 0;
-    for (int t = 0; t < a.ntower; ++t) { f.rt[t] = (a.t[t].count[0] + 15) >> 4; f.U += f.rt[t]; }
+    int tiles128 = 0;
+    for (int t = 0; t < a.ntower; ++t) {
+        const int cnt = a.t[t].count[0];
+        f.rt[t] = (cnt + 15) >> 4;
+        f.U += f.rt[t];
+        tiles128 += (cnt + PM - 1) / PM;
+    }
     if (f.U == 0 || f.U >= (1 << 15)) return false;
     const int grid = nwg < G7_WGS ? nwg : G7_WGS;
+    // (a launch whose 128-row tiles fill at most half of the grid is faster in the tile form's column parts:
+    // B = 32 / 48: 35 / 36 us against 40 with 4 row tiles per workgroup here)
+    if (tiles128 * 2 <= grid) return false;
     for (int P = AR_PMIN; P <= AR_PMAX; ++P)
         if (ares_fit(a, f, P, grid)) return true;
     return false;
@@ -1035,11 +1044,6 @@ __device__ __forceinline__ void proj_gemm_ares_wg(const ProjArgs &a, float *lds,
 __global__ __launch_bounds__(GEMM_THREADS) void proj_gemm_kernel(ProjArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float *lds = reinterpret_cast<float *>(smem);
-    int first[MAX_TOWERS + 1];
-    first[0] = 0;
-    for (int t = 0; t < a.ntower; ++t) first[t + 1] = first[t] + (a.t[t].count[0] + PM - 1) / PM;
-    // (a launch whose tiles fill at most half of the grid is faster in column parts -- below -- than in the
-    // balanced form, which keeps 112 rows per workgroup whatever the count)
     if (a.balanced == 3) {
         // One round only.  (Several rounds of tiles per workgroup -- 45 k rows as 474 tiles of 6 in two rounds -- were
         // built and measured: 104 us against the tile form's 88 for unpadded documents, 155 against 129 for uniform
@@ -1064,6 +1068,11 @@ __global__ __launch_bounds__(GEMM_THREADS) void proj_gemm_kernel(ProjArgs a) {
             return;
         }
     }
+    int first[MAX_TOWERS + 1];
+    first[0] = 0;
+    for (int t = 0; t < a.ntower; ++t) first[t + 1] = first[t] + (a.t[t].count[0] + PM - 1) / PM;
+    // (a launch whose tiles fill at most half of the grid is faster in column parts -- below -- than in the
+    // balanced form, which keeps 112 rows per workgroup whatever the count)
     if (a.balanced == 1 && first[a.ntower] * 2 > (int)gridDim.x) {
         Gemm7Plan p;
         if (gemm7_plan(a, (int)blockIdx.x, (int)gridDim.x, p)) {
