@@ -250,6 +250,21 @@ int r4r_adam_gathered(float *p, const float *gathered, int world, float *g_sum, 
                       int64_t numel, float lr, double beta1, double beta2, float eps,
                       float weight_decay, int64_t step, void *stream);
 
+/* Device-side form of that all_gather over peer-mapped buffers (the exchange step of the data-parallel form of
+ * main.py:56-60; the reference itself is single-process, main.py:407).  Every rank owns two gathered buffers
+ * [world][numel] (alternating by step parity) and a flag array [world] of uint32, all zero-initialised, and has
+ * them mapped by its peers (hipIpcGetMemHandle / hipIpcOpenMemHandle on the host side).
+ *   r4r_peer_push: copies `src` [numel] into slot `rank` of every rank's gathered buffer (peer_dst[r] = rank r's
+ *     buffer of this step's parity, device pointers as uint64), then -- once every workgroup's stores are fenced at
+ *     system scope -- writes `epoch` (the 1-based step) to element `rank` of every rank's flag array
+ *     (peer_flags[r]).  `arrive`: one zero-initialised uint32 in this rank's memory.  numel % 4 == 0, 16-byte aligned.
+ *   r4r_peer_wait: one wave spins until all `world` elements of MY flag array have reached `epoch`, at most
+ *     `timeout_s` seconds (then *timed_out = 1 + the missing rank, and the launch ends: the caller checks it).
+ * r4r_adam_gathered on the buffer then sums the slots in rank order: identical bits on every rank.  world <= 16. */
+int r4r_peer_push(const float *src, int64_t numel, const uint64_t *peer_dst, const uint64_t *peer_flags,
+                  uint32_t *arrive, int rank, int world, uint32_t epoch, void *stream);
+int r4r_peer_wait(const uint32_t *flags, int world, uint32_t epoch, uint32_t *timed_out, double timeout_s, void *stream);
+
 
 /* ------------------------------------------------------------------------
  * Fused DeepCoNN step ('deepconn' mode): the whole of DeepCoNN.forward

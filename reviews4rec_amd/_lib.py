@@ -17,7 +17,7 @@ HEADER_PATH = os.path.join(os.path.dirname(_HERE), 'include', 'r4r.h')
 
 _SCALARS = {
     'int': ctypes.c_int, 'float': ctypes.c_float, 'double': ctypes.c_double, 'int64_t': ctypes.c_int64,
-    'uint64_t': ctypes.c_uint64, 'size_t': ctypes.c_size_t, 'int32_t': ctypes.c_int32,
+    'uint64_t': ctypes.c_uint64, 'size_t': ctypes.c_size_t, 'int32_t': ctypes.c_int32, 'uint32_t': ctypes.c_uint32,
 }
 
 _lib = None

@@ -1,0 +1,106 @@
+// Device-side gradient exchange over peer-mapped buffers (data parallel, SURVEY.md 8e C1').
+//
+// The reference is single-process (main.py:407); this is the exchange step of the data-parallel form of its
+// training step (main.py:56-60: mean loss -> backward -> optimizer.step on the SUM of the ranks' gradients).
+// With RCCL the 0.73 MB gradient bucket of DeepCoNN costs a collective launch and its protocol's hops; on an
+// xGMI mesh every GPU can write every other GPU's memory directly, so the exchange can be ONE kernel per rank:
+//   r4r_peer_push   copies this rank's flat gradient into slot `rank` of EVERY rank's gathered buffer (peer
+//                   pointers: hipIpcOpenMemHandle on the host side), fences at system scope, and the last
+//                   workgroup to finish raises this rank's flag (= the step's epoch) in every rank's flag array;
+//   r4r_peer_wait   one workgroup: lane r spins (bounded) until rank r's flag in MY flag array reaches the epoch;
+//   r4r_adam_gathered (adam.hip) then sums the `world` slots in rank order inside the optimiser launch: identical
+//                   bits on every rank.
+// Two gathered buffers alternate by epoch parity: a rank can run at most one step ahead of its peers (it waits for
+// their step-k flags before its step-k update), and a peer's step-k read is stream-ordered before its step-(k+1)
+// push, so the buffer a fast rank writes for step k+1 is never the one a slow rank still reads for step k.
+// Nothing here assumes a placement: correctness comes from the system-scope release (push) / acquire (wait).
+#include "common.h"
+
+namespace r4r {
+
+constexpr int PEER_MAX_WORLD = 16;
+constexpr int PEER_THREADS = 256;
+
+struct PeerPush {
+    const float *src;
+    float *dst[PEER_MAX_WORLD];        // rank r's gathered buffer of this epoch's parity (r == rank: my own)
+    unsigned *flags[PEER_MAX_WORLD];   // rank r's flag array [world]
+    unsigned *arrive;                  // my arrival counter (device memory, zeroed by the host once)
+    int64_t n4;                        // float4 elements
+    int rank, world;
+    unsigned epoch;
+};
+
+typedef float peer_f32x4 __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(PEER_THREADS) void peer_push_kernel(PeerPush a) {
+    const int64_t stride = (int64_t)gridDim.x * PEER_THREADS;
+    const peer_f32x4 *src = reinterpret_cast<const peer_f32x4 *>(a.src);
+    for (int64_t i = (int64_t)blockIdx.x * PEER_THREADS + threadIdx.x; i < a.n4; i += stride) {
+        const peer_f32x4 v = src[i];
+        for (int r = 0; r < a.world; ++r)
+            reinterpret_cast<peer_f32x4 *>(a.dst[r])[(int64_t)a.rank * a.n4 + i] = v;
+    }
+    // every thread's stores reach the peers' memories before this workgroup counts as arrived
+    __threadfence_system();
+    __syncthreads();
+    __shared__ unsigned last;
+    if (threadIdx.x == 0) {
+        const unsigned k = __hip_atomic_fetch_add(a.arrive, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        last = (k == gridDim.x - 1);
+    }
+    __syncthreads();
+    if (last && threadIdx.x < (unsigned)a.world) {
+        if (threadIdx.x == 0) __hip_atomic_store(a.arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // for the next push
+        __hip_atomic_store(a.flags[threadIdx.x] + a.rank, a.epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
+// One wave: lane r waits for rank r.  Bounded: a peer that never arrives sets *timed_out instead of hanging the GPU.
+__global__ __launch_bounds__(64) void peer_wait_kernel(const unsigned *flags, int world, unsigned epoch, unsigned *timed_out,
+                                                       unsigned long long max_ticks) {
+    const int r = threadIdx.x;
+    if (r < world) {
+        const unsigned long long t0 = wall_clock64();       // 100 MHz
+        for (;;) {
+            const unsigned f = __hip_atomic_load(flags + r, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
+            if ((int)(f - epoch) >= 0) break;
+            if (wall_clock64() - t0 > max_ticks) { __hip_atomic_store(timed_out, 1u + (unsigned)r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
+            __builtin_amdgcn_s_sleep(8);
+        }
+    }
+    __threadfence_system();
+}
+
+}  // namespace r4r
+
+using namespace r4r;
+
+extern "C" int r4r_peer_push(const float *src, int64_t numel, const uint64_t *peer_dst, const uint64_t *peer_flags,
+                             uint32_t *arrive, int rank, int world, uint32_t epoch, void *stream) {
+    R4R_REQUIRE(src && peer_dst && peer_flags && arrive, "peer_push: null pointer");
+    R4R_REQUIRE(world >= 1 && world <= PEER_MAX_WORLD && rank >= 0 && rank < world, "peer_push: rank %d of %d (<= %d ranks)", rank,
+                world, PEER_MAX_WORLD);
+    R4R_REQUIRE(numel >= 0 && numel % 4 == 0, "peer_push: numel %lld must be a multiple of 4", (long long)numel);
+    PeerPush a;
+    a.src = src; a.n4 = numel / 4; a.rank = rank; a.world = world; a.epoch = epoch; a.arrive = arrive;
+    for (int r = 0; r < PEER_MAX_WORLD; ++r) {
+        a.dst[r] = reinterpret_cast<float *>(peer_dst[r < world ? r : 0]);
+        a.flags[r] = reinterpret_cast<unsigned *>(peer_flags[r < world ? r : 0]);
+        R4R_REQUIRE(a.dst[r] && a.flags[r] && (reinterpret_cast<uintptr_t>(a.dst[r]) & 15) == 0, "peer_push: bad peer buffer %d", r);
+    }
+    R4R_REQUIRE((reinterpret_cast<uintptr_t>(src) & 15) == 0, "peer_push: source must be 16-byte aligned");
+    int64_t blocks = cdiv(a.n4, PEER_THREADS * 4);
+    if (blocks < 1) blocks = 1;
+    if (blocks > 256) blocks = 256;
+    peer_push_kernel<<<(unsigned)blocks, PEER_THREADS, 0, as_stream(stream)>>>(a);
+    return check_launch("peer_push");
+}
+
+extern "C" int r4r_peer_wait(const uint32_t *flags, int world, uint32_t epoch, uint32_t *timed_out, double timeout_s, void *stream) {
+    R4R_REQUIRE(flags && timed_out, "peer_wait: null pointer");
+    R4R_REQUIRE(world >= 1 && world <= PEER_MAX_WORLD, "peer_wait: %d ranks (<= %d)", world, PEER_MAX_WORLD);
+    R4R_REQUIRE(timeout_s > 0 && timeout_s <= 60, "peer_wait: timeout %.3f s outside (0, 60]", timeout_s);
+    peer_wait_kernel<<<1, 64, 0, as_stream(stream)>>>(flags, world, epoch, timed_out, (unsigned long long)(timeout_s * 1e8));
+    return check_launch("peer_wait");
+}

@@ -194,8 +194,9 @@ class DeepCoNNEngine(_ConvRule):
         # data-parallel gradient exchange: 'allreduce' (all-reduce flat_g, then r4r_adam_multi) or
         # 'gather' (all_gather the flat buffers, sum + Adam in one launch); see autotune_exchange()
         self.exchange = os.environ.get('R4R_DP_EXCHANGE', 'allreduce')
-        if self.exchange not in ('allreduce', 'gather'):
-            raise ValueError("R4R_DP_EXCHANGE must be 'allreduce' or 'gather', got %r" % (self.exchange,))
+        if self.exchange not in ('allreduce', 'gather', 'peer'):
+            raise ValueError("R4R_DP_EXCHANGE must be 'allreduce', 'gather' or 'peer', got %r" % (self.exchange,))
+        self._peer = None               # dist.PeerExchange, built on first use ('peer': device-side exchange over mapped buffers)
         self._gathered = None
         self._ws = None
         self._ws_key = None
@@ -370,6 +371,18 @@ class DeepCoNNEngine(_ConvRule):
 
     def _exchange_and_update(self, p, g, m, v, step):
         """Sum the ranks' gradients and apply Adam update number `step` to (p, m, v)."""
+        if self.exchange == 'peer':
+            if self._peer is None:
+                from .dist import PeerExchange
+                self._peer = PeerExchange(self.total, self.dev, self.dp.group)
+                self._peer_epoch = 0
+            self._peer_epoch += 1                            # (its own count: autotune / scratch calls advance it too)
+            gathered = self._peer.exchange(g, self._peer_epoch)
+            rc = _lib.lib().r4r_adam_gathered(ptr(p), ptr(gathered), self.dp.world, ptr(g), ptr(m), ptr(v),
+                                              self.total, self.lr, self.betas[0], self.betas[1], self.eps, self.wd,
+                                              int(step), _lib.current_stream())
+            _lib.check(rc, 'r4r_adam_gathered')
+            return
         if self.exchange == 'gather':
             if self._gathered is None:
                 self._gathered = torch.empty(self.dp.world * self.total, dtype=torch.float32, device=self.dev)

@@ -105,17 +105,21 @@ def _engine_worker(rank, world, port, case, out_dir, exchange):
         nxt = shards[(step + 1) % 2][0] if step < 2 else None      # shapes differ: the guess is declined
         n_global = dp.global_count(sy.shape[0], sy.device)
         ses.append(eng.train_step(sd, sy, n_global=n_global, next_data=nxt).cpu().clone())
+    if exchange == 'peer':
+        assert eng._peer is not None and eng._peer.world == world
+        eng._peer.check()                                          # no wait timed out
     torch.save({'w': {k: v.detach().cpu() for k, v in model.state_dict().items()}, 'se': ses},
                os.path.join(out_dir, 'e%d.pt' % rank))
     torch.distributed.destroy_process_group()
 
 
-@pytest.mark.parametrize('exchange', ['allreduce', 'gather', 'autotune'])
+@pytest.mark.parametrize('exchange', ['allreduce', 'gather', 'autotune', 'peer'])
 def test_dp2_native_engine_follows_the_reference_trajectory(tmp_path, exchange):
     """The fused DeepCoNN step under data parallelism -- gradients summed by one all-reduce and a
     separate Adam launch, or all_gathered and summed in rank order inside the Adam launch, or
-    whichever of the two the engine measures to be faster: 2 ranks x half batches == the
-    reference's 3 single-process steps."""
+    whichever of the two the engine measures to be faster, or ('peer') pushed by each rank's own kernel into
+    buffers the two processes map from each other over CUDA IPC on the one GPU (dist.PeerExchange, csrc/peer.hip)
+    and summed the same way: 2 ranks x half batches == the reference's 3 single-process steps."""
     sys.path.insert(0, TESTS)
     from helpers import Golden
     case = 'deepconn_e20'
@@ -461,6 +465,7 @@ RCCL_CASES = {
     'deepconn-allreduce': (_engine_worker, ('deepconn_e20', 'allreduce'), 'e', 'deepconn_e20', 'se', 'w3'),
     'deepconn-gather': (_engine_worker, ('deepconn_e20', 'gather'), 'e', 'deepconn_e20', 'se', 'w3'),
     'deepconn-autotune': (_engine_worker, ('deepconn_e20', 'autotune'), 'e', 'deepconn_e20', 'se', 'w3'),
+    'deepconn-peer': (_engine_worker, ('deepconn_e20', 'peer'), 'e', 'deepconn_e20', 'se', 'w3'),
     'mf_dot': (_mf_worker, ('mf_dot',), 'm', 'mf_dot', 'se', 'w3'),
     'transnetpp': (_transnet_worker, ('transnetpp_e16',), 't', 'transnetpp_e16', 'tn_se', 'tn_w3'),
     'deepconnpp': (_dcpp_worker, (), 'd', 'deepconnpp_e20', 'se', 'w3'),

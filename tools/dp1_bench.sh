@@ -14,4 +14,6 @@ for rep in 1 2; do
     R4R_DP_SINGLE=1 R4R_DP_RCCL=$rccl R4R_DP_EXCHANGE=$ex python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port $((29600 + RANDOM % 300)) \
       $R/bench.py --gpus 1 --no-cpu-baseline --strong-leg "" "$@" 2>/dev/null | line "dp1 stream_rccl=$rccl $ex"
   done; done
+  R4R_DP_SINGLE=1 R4R_DP_EXCHANGE=peer python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port $((29600 + RANDOM % 300)) \
+      $R/bench.py --gpus 1 --no-cpu-baseline --strong-leg "" "$@" 2>/dev/null | line "dp1 peer-mapped exchange"
 done
