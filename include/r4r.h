@@ -253,16 +253,26 @@ int r4r_adam_gathered(float *p, const float *gathered, int world, float *g_sum, 
 /* Device-side form of that all_gather over peer-mapped buffers (the exchange step of the data-parallel form of
  * main.py:56-60; the reference itself is single-process, main.py:407).  Every rank owns two gathered buffers
  * [world][numel] (alternating by step parity) and a flag array [world] of uint32, all zero-initialised, and has
- * them mapped by its peers (hipIpcGetMemHandle / hipIpcOpenMemHandle on the host side).
+ * them mapped by its peers:
+ *   r4r_peer_segment_create: one zero-filled FINE-GRAINED device allocation of `bytes` on the current device (the
+ *     flags are polled while peers write them: coarse-grained memory promises visibility at kernel boundaries only)
+ *     and its 64-byte IPC handle, which the host ships to the peers by any means it has;
+ *     r4r_peer_segment_open maps a peer's handle (-> *ptr), _close unmaps it, _destroy frees one's own segment.
  *   r4r_peer_push: copies `src` [numel] into slot `rank` of every rank's gathered buffer (peer_dst[r] = rank r's
  *     buffer of this step's parity, device pointers as uint64), then -- once every workgroup's stores are fenced at
  *     system scope -- writes `epoch` (the 1-based step) to element `rank` of every rank's flag array
  *     (peer_flags[r]).  `arrive`: one zero-initialised uint32 in this rank's memory.  numel % 4 == 0, 16-byte aligned.
+ *     With `wait_flags` (MY flag array) the same launch then waits as r4r_peer_wait does: the exchange is one launch.
  *   r4r_peer_wait: one wave spins until all `world` elements of MY flag array have reached `epoch`, at most
  *     `timeout_s` seconds (then *timed_out = 1 + the missing rank, and the launch ends: the caller checks it).
  * r4r_adam_gathered on the buffer then sums the slots in rank order: identical bits on every rank.  world <= 16. */
+int r4r_peer_segment_create(int64_t bytes, void **ptr, uint8_t *handle);
+int r4r_peer_segment_open(const uint8_t *handle, void **ptr);
+int r4r_peer_segment_close(void *ptr);
+int r4r_peer_segment_destroy(void *ptr);
 int r4r_peer_push(const float *src, int64_t numel, const uint64_t *peer_dst, const uint64_t *peer_flags,
-                  uint32_t *arrive, int rank, int world, uint32_t epoch, void *stream);
+                  uint32_t *arrive, int rank, int world, uint32_t epoch, const uint32_t *wait_flags,
+                  uint32_t *timed_out, double timeout_s, void *stream);
 int r4r_peer_wait(const uint32_t *flags, int world, uint32_t epoch, uint32_t *timed_out, double timeout_s, void *stream);
 
 

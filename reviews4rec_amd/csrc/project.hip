@@ -387,7 +387,7 @@ __device__ __forceinline__ bool gemm7_plan(const ProjArgs &a, int wg, int nwg, G
                 const int n = w_hi - w_lo, k = wl - w_lo;
                 p.sh_row0 = (G7_ROWS * g[t] + lt) * 16;
                 p.sh_c0 = PNT * k / n;
-                p.sh_n = PNT * (k + 1) / n - p.sh_c0;                               // <= ceil(19 / 3) = 7
+                p.sh_n = PNT * (k + 1) / n - p.sh_c0;                               // <= ceil(19 / 3) = 7 (10 with two sharers)
             }
         }
         base += g[t];
@@ -665,6 +665,9 @@ constexpr int AR_PMIN = R4R_AR_PMIN, AR_PMAX = 7;  // private row tiles per work
 #ifndef R4R_AR_S
 #define R4R_AR_S 1                                 // chunks staged per barrier in pass 1 (1, 2 or 4: no measurable difference)
 #endif
+#ifndef R4R_AR_HALF
+#define R4R_AR_HALF 1                              // row tiles shared by two workgroups past 7 1/3 row tiles per workgroup (0: those launches take form 1)
+#endif
 #ifndef R4R_AR_DB
 #define R4R_AR_DB 1                                // pass 2: chunks the weight fragments are requested ahead of their MFMAs (1 or 3; 3 measured no faster)
 #endif
@@ -675,22 +678,39 @@ struct AresPlan { int tower, P, row0, sh_row0, sh_c0, sh_n; };
 struct AresFit { int rt[MAX_TOWERS], g[MAX_TOWERS], U, P; };
 
 // gemm7_plan for P private row tiles per workgroup on `cap` workgroups: G = min(U / P, cap) of them split over the
-// towers in proportion to their row tiles, the left-over row tiles of a tower each shared column-wise by >= 3 of its
-// workgroups.  A pure function of the towers' distinct-token counts, evaluated by every workgroup.
-__device__ __forceinline__ bool ares_fit(const ProjArgs &a, AresFit &f, int P, int cap) {
+// towers in proportion to their row tiles (workgroups the flooring leaves over go where the most row tiles are left),
+// the left-over row tiles of a tower each shared column-wise by >= SH of its workgroups (SH = 3: at most 7 column
+// units per sharer, all on SIMD 3; SH = 2: up to 10, the three units past the seventh on the two-column waves of
+// SIMDs 0 - 2).  A pure function of the towers' distinct-token counts, evaluated by every workgroup.
+__device__ __forceinline__ bool ares_fit(const ProjArgs &a, AresFit &f, int P, int cap, int SH) {
     int G = f.U / P;
     if (G > cap) G = cap;
     if (G < a.ntower) return false;
+    int used = 0;
     for (int t = 0; t < a.ntower; ++t) {
         f.g[t] = f.rt[t] * G / f.U;                         // (products < 2^24: 32-bit arithmetic)
-        const int left = f.rt[t] - P * f.g[t];              // row tiles nobody owns: shared, >= 3 workgroups each
-        if (f.g[t] < 1 || left < 0 || 3 * left > f.g[t]) return false;
+        if (f.g[t] < 1) return false;
+        used += f.g[t];
+    }
+    for (; used < G; ++used) {                              // (fewer than ntower of them)
+        int best = -1, most = 0;
+        for (int t = 0; t < a.ntower; ++t) {
+            const int left = f.rt[t] - P * (f.g[t] + 1);
+            if (left >= 0 && f.rt[t] - P * f.g[t] > most) { most = f.rt[t] - P * f.g[t]; best = t; }
+        }
+        if (best < 0) break;
+        for (int t = 0; t < a.ntower; ++t) f.g[t] += (t == best);
+    }
+    for (int t = 0; t < a.ntower; ++t) {
+        const int left = f.rt[t] - P * f.g[t];              // row tiles nobody owns: shared, >= SH workgroups each
+        if (left < 0 || SH * left > f.g[t]) return false;
     }
     f.P = P;
     return true;
 }
 
-// The plan of a launch on `nwg` persistent workgroups: the smallest P that fits -- the most workgroups at work.
+// The plan of a launch on `nwg` persistent workgroups: the smallest P that fits -- the most workgroups at work; past
+// 7 1/3 row tiles per workgroup, 7 private ones and half a shared one (30,720 rows on 256 workgroups).
 __device__ __forceinline__ bool ares_plan_fit(const ProjArgs &a, int nwg, AresFit &f) {
     f.U = 0;
     for (int t = 0; t < MAX_TOWERS; ++t) f.rt[t] = 0;
@@ -707,8 +727,8 @@ __device__ __forceinline__ bool ares_plan_fit(const ProjArgs &a, int nwg, AresFi
     // B = 32 / 48: 35 / 36 us against 40 with 4 row tiles per workgroup here)
     if (tiles128 * 2 <= grid) return false;
     for (int P = AR_PMIN; P <= AR_PMAX; ++P)
-        if (ares_fit(a, f, P, grid)) return true;
-    return false;
+        if (ares_fit(a, f, P, grid, 3)) return true;
+    return R4R_AR_HALF && ares_fit(a, f, AR_PMAX, grid, 2);
 }
 
 // workgroup wg's share of the plan (p.tower < 0: nothing)
@@ -730,7 +750,7 @@ __device__ __forceinline__ void ares_assign(const ProjArgs &a, const AresFit &f,
                 const int n = w_hi - w_lo, k = wl - w_lo;
                 p.sh_row0 = (P * f.g[t] + lt) * 16;
                 p.sh_c0 = PNT * k / n;
-                p.sh_n = PNT * (k + 1) / n - p.sh_c0;                               // <= ceil(19 / 3) = 7
+                p.sh_n = PNT * (k + 1) / n - p.sh_c0;                               // <= ceil(19 / 3) = 7 (10 with two sharers)
             }
         }
         base += f.g[t];
@@ -927,7 +947,7 @@ __device__ __forceinline__ void ares_pass(const AresCtx &x, int rt0, const float
 }
 
 // P: private row tiles of the workgroup; NCW: column tiles of this wave (from ct0); NEX: units of the shared row tile
-// it adds in pass 2 (SIMD 3: 4 | 3, from eoff)
+// it adds in pass 2 (SIMD 3: 4 | 3, from eoff; the two-column waves of SIMDs 0 - 2: one of units 7 .. 9)
 template <int P, int NCW, int NEX>
 __device__ __forceinline__ void proj_gemm_ares_body(const ProjArgs &a, float *lds, const AresPlan &p, int ct0, int eoff) {
     constexpr int NE = NEX > 0 ? NEX : 1;
@@ -1036,8 +1056,10 @@ __device__ __forceinline__ void proj_gemm_ares_wg(const ProjArgs &a, float *lds,
         if (simd == 3) proj_gemm_ares_body<P, 2, 4>(a, lds, p, 15, 0);
         else proj_gemm_ares_body<P, 3, 0>(a, lds, p, simd * 5, 0);
     } else {
-        if (simd == 3) proj_gemm_ares_body<P, 2, 3>(a, lds, p, 17, 4);
-        else proj_gemm_ares_body<P, 2, 0>(a, lds, p, simd * 5 + 3, 0);
+        if (simd == 3) { proj_gemm_ares_body<P, 2, 3>(a, lds, p, 17, 4); return; }
+        if constexpr (P == AR_PMAX)                          // units 7 .. 9 of a row tile shared by two workgroups only
+            if (p.sh_n > 7 + simd) { proj_gemm_ares_body<P, 2, 1>(a, lds, p, simd * 5 + 3, 7 + simd); return; }
+        proj_gemm_ares_body<P, 2, 0>(a, lds, p, simd * 5 + 3, 0);
     }
 }
 

@@ -114,55 +114,62 @@ class StreamRccl:
 
 class PeerExchange:
     """The all_gather of the ranks' flat gradient buffers done by ONE kernel per rank over peer-mapped memory
-    (csrc/peer.hip): every rank maps every other rank's gathered buffers and flag array (CUDA IPC handles, shipped
-    through the process group with torch's own tensor reductions), `push` writes this rank's gradient into its slot
-    on every rank and raises a flag there, `wait` spins (bounded) on this rank's flag array; r4r_adam_gathered then
-    sums the slots in rank order.  No collective library call in the step: on the xGMI mesh the exchange is one
-    store stream per link plus a flag.  Functionally testable on one GPU (two processes map each other's buffers on
+    (csrc/peer.hip).  Every rank owns one fine-grained segment [flag array | gathered buffer, even steps | odd steps]
+    (r4r_peer_segment_create), ships its 64-byte IPC handle through the process group and maps everybody else's
+    (r4r_peer_segment_open).  `exchange` is one launch: r4r_peer_push writes this rank's gradient into its slot on
+    every rank, raises a flag there, and waits (bounded) for every rank's flag in its own array; r4r_adam_gathered
+    then sums the slots in rank order.  No collective library call in the step: on the xGMI mesh the exchange is one
+    store stream per link plus a flag.  Functionally testable on one GPU (two processes map each other's segments on
     the same device: tests/test_gpu_dist.py); `R4R_DP_EXCHANGE=peer` selects it in the DeepCoNN engine.
 
     Two gathered buffers alternate by step parity (csrc/peer.hip explains why that is enough)."""
     TIMEOUT_S = 20.0
+    FLAG_BYTES = 4096
 
     def __init__(self, numel, device, group=None):
-        from torch.multiprocessing.reductions import reduce_tensor
-        self.group, self.dev = group, device
+        import ctypes
+        from . import _lib
+        lib = _lib.lib()
+        self.group, self.dev = group, torch.device(device)
         self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
         self.numel = int(numel)
-        # one allocation per kind, each shared as a whole
-        self.gathered = [torch.zeros(self.world * self.numel, dtype=torch.float32, device=device) for _ in range(2)]
-        self.flags = torch.zeros(max(self.world, 16), dtype=torch.int32, device=device)
+        half = -(-self.world * self.numel * 4 // 4096) * 4096
+        self.bytes = self.FLAG_BYTES + 2 * half
         self.local = torch.zeros(16, dtype=torch.int32, device=device)          # [0] arrival counter, [1] timeout word
-        torch.cuda.synchronize(device)
-        mine = [reduce_tensor(t) for t in (self.gathered[0], self.gathered[1], self.flags)]
+        handle = (ctypes.c_uint8 * 64)()
+        mine = ctypes.c_void_p()
+        with torch.cuda.device(self.dev):
+            _lib.check(lib.r4r_peer_segment_create(self.bytes, ctypes.byref(mine), handle), 'r4r_peer_segment_create')
+        self._mine, self._mapped = mine.value, []
         everyone = [None] * self.world
-        dist.all_gather_object(everyone, mine, group=group)
-        self._peers = []                                     # keeps the mapped tensors alive
-        dst = [[0] * self.world, [0] * self.world]
-        flg = [0] * self.world
-        for r, handles in enumerate(everyone):
+        dist.all_gather_object(everyone, bytes(handle), group=group)
+        base = [0] * self.world
+        for r, h in enumerate(everyone):
             if r == self.rank:
-                ts = (self.gathered[0], self.gathered[1], self.flags)
-            else:
-                ts = tuple(fn(*args) for fn, args in handles)
-                self._peers.append(ts)
-            dst[0][r], dst[1][r], flg[r] = ts[0].data_ptr(), ts[1].data_ptr(), ts[2].data_ptr()
+                base[r] = self._mine
+                continue
+            p = ctypes.c_void_p()
+            with torch.cuda.device(self.dev):
+                _lib.check(lib.r4r_peer_segment_open((ctypes.c_uint8 * 64).from_buffer_copy(h), ctypes.byref(p)),
+                           'r4r_peer_segment_open')
+            self._mapped.append(p.value)
+            base[r] = p.value
         u64 = lambda v: torch.tensor(v + [0] * (16 - len(v)), dtype=torch.int64)
-        self._dst = [u64(dst[0]), u64(dst[1])]               # host arrays (the launcher copies them into the kernel arguments)
-        self._flg = u64(flg)
+        # host arrays (the launcher copies them into the kernel arguments)
+        self._dst = [u64([b + self.FLAG_BYTES + par * half for b in base]) for par in (0, 1)]
+        self._flg = u64(base)
+        self.gathered = [self._mine + self.FLAG_BYTES + par * half for par in (0, 1)]   # device addresses
         dist.barrier(group=group)                            # nobody pushes before everybody has mapped
 
     def exchange(self, flat, epoch):
-        """Push `flat` for step `epoch` (1-based) and wait for every rank's push: -> this step's gathered buffer."""
+        """Push `flat` for step `epoch` (1-based) and wait for every rank's push: -> the device address of this
+        step's gathered buffer [world][numel]."""
         from . import _lib
-        from ._lib import ptr
-        lib = _lib.lib()
         par = int(epoch) & 1
-        st = _lib.current_stream()
-        _lib.check(lib.r4r_peer_push(ptr(flat), self.numel, self._dst[par].data_ptr(), self._flg.data_ptr(),
-                                     self.local.data_ptr(), self.rank, self.world, int(epoch) & 0x7fffffff, st), 'r4r_peer_push')
-        _lib.check(lib.r4r_peer_wait(ptr(self.flags), self.world, int(epoch) & 0x7fffffff, self.local.data_ptr() + 4,
-                                     self.TIMEOUT_S, st), 'r4r_peer_wait')
+        _lib.check(_lib.lib().r4r_peer_push(flat.data_ptr(), self.numel, self._dst[par].data_ptr(), self._flg.data_ptr(),
+                                            self.local.data_ptr(), self.rank, self.world, int(epoch) & 0x7fffffff,
+                                            self._mine, self.local.data_ptr() + 4, self.TIMEOUT_S, _lib.current_stream()),
+                   'r4r_peer_push')
         return self.gathered[par]
 
     def check(self):
@@ -170,6 +177,19 @@ class PeerExchange:
         word = int(self.local[1].item())
         if word:
             raise RuntimeError('PeerExchange: rank %d never raised its flag (waited %.0f s)' % (word - 1, self.TIMEOUT_S))
+
+    def close(self):
+        """Unmap the peers' segments and free this rank's (after a barrier: nobody still writes into it)."""
+        from . import _lib
+        if self._mine is None:
+            return
+        torch.cuda.synchronize(self.dev)
+        dist.barrier(group=self.group)
+        for p in self._mapped:
+            _lib.check(_lib.lib().r4r_peer_segment_close(p), 'r4r_peer_segment_close')
+        dist.barrier(group=self.group)
+        _lib.check(_lib.lib().r4r_peer_segment_destroy(self._mine), 'r4r_peer_segment_destroy')
+        self._mine, self._mapped = None, []
 
 
 def shard_bounds(n, rank, world):

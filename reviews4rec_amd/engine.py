@@ -378,7 +378,7 @@ class DeepCoNNEngine(_ConvRule):
                 self._peer_epoch = 0
             self._peer_epoch += 1                            # (its own count: autotune / scratch calls advance it too)
             gathered = self._peer.exchange(g, self._peer_epoch)
-            rc = _lib.lib().r4r_adam_gathered(ptr(p), ptr(gathered), self.dp.world, ptr(g), ptr(m), ptr(v),
+            rc = _lib.lib().r4r_adam_gathered(ptr(p), gathered, self.dp.world, ptr(g), ptr(m), ptr(v),
                                               self.total, self.lr, self.betas[0], self.betas[1], self.eps, self.wd,
                                               int(step), _lib.current_stream())
             _lib.check(rc, 'r4r_adam_gathered')

@@ -108,6 +108,7 @@ def _engine_worker(rank, world, port, case, out_dir, exchange):
     if exchange == 'peer':
         assert eng._peer is not None and eng._peer.world == world
         eng._peer.check()                                          # no wait timed out
+        eng._peer.close()
     torch.save({'w': {k: v.detach().cpu() for k, v in model.state_dict().items()}, 'se': ses},
                os.path.join(out_dir, 'e%d.pt' % rank))
     torch.distributed.destroy_process_group()
@@ -454,6 +455,51 @@ def test_dp2_native_idnet_step_follows_the_reference_trajectory(tmp_path, case):
     for k, v in g.params('w3').items():
         assert torch.equal(r0['w'][k], r1['w'][k]), k               # replicas stay bit-identical
         torch.testing.assert_close(r0['w'][k], v, rtol=1e-5, atol=5e-6, msg=lambda m: k + ': ' + m)
+
+
+def _peer_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank), R4R_DIST_BACKEND='gloo', R4R_DP_SINGLE='1' if world == 1 else '')
+    import time
+    from reviews4rec_amd import _lib, dist as r4dist
+    r4dist.init_from_env()
+    n = 4 * 12345
+    px = r4dist.PeerExchange(n, 'cuda')
+    lib = _lib.lib()
+    sums = []
+    for epoch in range(1, 8):
+        gen = torch.Generator().manual_seed(100 * epoch + rank)
+        flat = torch.randn(n, generator=gen).cuda()
+        if (epoch + rank) % 3 == 0:
+            torch.cuda.synchronize()
+            time.sleep(0.05)                                       # the ranks drift apart: the flags must hold them
+        gathered = px.exchange(flat, epoch)
+        p, m, v, gs = (torch.zeros(n, device='cuda') for _ in range(4))
+        _lib.check(lib.r4r_adam_gathered(p.data_ptr(), gathered, world, gs.data_ptr(), m.data_ptr(), v.data_ptr(), n,
+                                         1e-3, 0.9, 0.999, 1e-8, 0.0, 1, _lib.current_stream()), 'r4r_adam_gathered')
+        sums.append(gs.cpu())
+    px.check()
+    px.close()
+    torch.save(sums, os.path.join(out_dir, 'p%d.pt' % rank))
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.parametrize('world', [1, 2, 3])
+def test_peer_exchange_gathers_every_ranks_buffer(tmp_path, world):
+    """dist.PeerExchange alone: `world` processes on the one GPU map each other's fine-grained segments
+    (r4r_peer_segment_*), push seven epochs of seeded buffers with the ranks drifting apart, and the rank-ordered
+    sum r4r_adam_gathered forms from the gathered slots is the sum of the seeded buffers, bit for bit, on every rank."""
+    port = _free_port()
+    mp.spawn(_peer_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    got = [torch.load(os.path.join(tmp_path, 'p%d.pt' % r)) for r in range(world)]
+    for epoch in range(1, 8):
+        want = None
+        for r in range(world):
+            t = torch.randn(4 * 12345, generator=torch.Generator().manual_seed(100 * epoch + r))
+            want = t if want is None else want + t
+        for r in range(world):
+            assert torch.equal(got[r][epoch - 1], want), (epoch, r)
 
 
 # ---- RCCL itself, on the one GPU of the test box: a ONE-rank job (R4R_DP_SINGLE=1 keeps the data-parallel

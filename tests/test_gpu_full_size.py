@@ -212,3 +212,41 @@ def test_latent_size_beyond_the_native_steps(mt, L):
         for k, v in grads.items():
             if v is not None:
                 torch.testing.assert_close(got[k], v, rtol=2e-4, atol=1e-6, msg=lambda m: k + ': ' + m)
+
+
+def test_headline_batches_on_both_sides_of_the_resident_plans_edge():
+    """cfg3's own batches (128 ratings x 2 documents of 1,000 words, E = 300) have 1,735 .. 1,914 row tiles of
+    distinct words over the two towers: some fit the A-resident GEMM's plan with a row tile shared by >= 3
+    workgroups (<= 7 1/3 row tiles per workgroup), some need the half-tile shares (two sharers, units 7 .. 9 on the
+    two-column waves of SIMDs 0 - 2).  Each of the bench's first four batches, one training step from the same
+    state under r4r_gemm_form 1 (balanced tile form) and 3 (A-resident): same bits in every parameter."""
+    import reviews4rec_amd
+    from reviews4rec_amd import _lib, synthetic
+    from reviews4rec_amd.engine import DeepCoNNEngine
+    from reviews4rec_amd.utils import xavier_init
+    hp = synthetic.hyper_params_for('cfg3_deepconn_electronics_e300', dropout=0.0)
+    hp['word_vectors'] = synthetic.word_table(hp['vocab'], hp['word_embed_size'])
+    gen = synthetic.Generator(hp, seed=synthetic.SEED)
+    batches = [gen.batch(128) for _ in range(4)]
+    tiles = [sum((len(np.unique(d[k])) + 15) // 16 for k in (3, 4)) for d, _ in batches]
+    assert min(tiles) <= 1850 and max(tiles) > 1880, tiles          # both kinds of plan are exercised
+    torch.manual_seed(0)
+    m = reviews4rec_amd.get_model_class('deepconn')(hp)
+    xavier_init(m)
+    m = m.to(DEV).train()
+    start = {k: v.clone() for k, v in m.state_dict().items()}
+    lib = _lib.lib()
+    out = {}
+    try:
+        for form in (1, 3):
+            lib.r4r_gemm_form(form)
+            for i, (data, y) in enumerate(batches):
+                m.load_state_dict(start)
+                eng = DeepCoNNEngine(m, lr=hp['lr'], weight_decay=hp['weight_decay'])
+                se = eng.train_step([None if d is None else torch.from_numpy(d).to(DEV) for d in data], torch.from_numpy(y).to(DEV))
+                out[form, i] = (se.cpu().clone(), eng.flat_p.cpu().clone())
+    finally:
+        lib.r4r_gemm_form(-1)
+    for i in range(len(batches)):
+        assert torch.equal(out[1, i][0], out[3, i][0]), i
+        assert torch.equal(out[1, i][1], out[3, i][1]), i

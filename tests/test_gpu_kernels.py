@@ -399,7 +399,7 @@ def test_fused_adam_unaligned_views_and_untouched_rows():
     assert (p.detach().cpu()[10:] != before[10:]).all()
 
 
-@pytest.mark.parametrize('V', [336, 340, 1000, 3000, 8200, 9000, 16000, 16390, 17300, 20300, 21000, 24100, 25000, 28672, 29500, 30100,
+@pytest.mark.parametrize('V', [336, 340, 1000, 3000, 8200, 9000, 16000, 16390, 17300, 20300, 21000, 24100, 25000, 28672, 29500, 30100, 30300, 30700, 30720, 30730,
                                36000, 41000, 45000, 70000, 100000])
 def test_projection_gemm_balanced_form_is_bit_identical_to_the_tile_form(V):
     """The projection GEMM has two decompositions (csrc/project.hip): 128-row tiles, and the balanced form --
@@ -410,8 +410,9 @@ def test_projection_gemm_balanced_form_is_bit_identical_to_the_tile_form(V):
     round into column parts when that round fills at most half of the grid (36,000 rows: 26 tiles in 4 parts;
     41,000: 65 tiles in 2; 70,000: two full rounds + 35 tiles in 4): r4r_gemm_form(2) -- whole tiles only -- must
     give the same bits too.  Form 3 (A-resident) takes 4 .. 7 private row tiles per workgroup -- 8,200 .. 17,300 rows:
-    4; 20,300 / 21,000: 5; 24,100 / 25,000: 6; 28,672 .. 30,100: 7, each with and without shared row tiles; larger
-    counts in several rounds of tiles (36,000 .. 100,000: 2 to 4 rounds) -- and falls back to the tile form elsewhere."""
+    4; 20,300 / 21,000: 5; 24,100 / 25,000: 6; 28,672 .. 30,720: 7, each with and without shared row tiles, from
+    30,100 on with row tiles shared by only two workgroups (up to 10 column units per sharer: 30,720 rows = 7 1/2
+    row tiles on each of the 256 workgroups is the form's capacity) -- and falls back to the tile form elsewhere."""
     from reviews4rec_amd import _lib
     ops = _ops()
     E, T = 128, 100
