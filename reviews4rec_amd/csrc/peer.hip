@@ -149,9 +149,9 @@ extern "C" int r4r_peer_push(const float *src, int64_t numel, const uint64_t *pe
         R4R_REQUIRE(a.dst[r] && a.flags[r] && (reinterpret_cast<uintptr_t>(a.dst[r]) & 15) == 0, "peer_push: bad peer buffer %d", r);
     }
     R4R_REQUIRE((reinterpret_cast<uintptr_t>(src) & 15) == 0, "peer_push: source must be 16-byte aligned");
-    int64_t blocks = cdiv(a.n4, PEER_THREADS * 4);
+    int64_t blocks = cdiv(a.n4, PEER_THREADS);            // one float4 per thread: every load of the copy in one round trip
     if (blocks < 1) blocks = 1;
-    if (blocks > 256) blocks = 256;
+    if (blocks > 512) blocks = 512;
     peer_push_kernel<<<(unsigned)blocks, PEER_THREADS, 0, as_stream(stream)>>>(a);
     return check_launch("peer_push");
 }
