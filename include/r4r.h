@@ -83,9 +83,12 @@ int r4r_gemm_math(int mode, float table_maxabs, float weight_maxabs);
  * 1 = the balanced 7-row-tile form wherever its plan applies, 3 = the same plan in its A-resident form (the
  * workgroup's table rows stay in LDS for all of K, weight fragments go global -> registers, the K sweep runs once per
  * group of row tiles so that finished rows leave the chip while the rest is computed; word_embed_size <= 320, else
- * form 1), 0 = always the 128-row tile form (its last, partial round cut into column parts where that fills idle
- * workgroups), 2 = the tile form with whole tiles only, -1 = take it from the environment again
- * (R4R_GEMM=tile / whole / balanced / ares pin 0 / 2 / 1 / 3). */
+ * form 1), 4 = the weight-resident form (the tower's
+ * 300 x E weights stay in LDS, table fragments go global -> registers, units of 16 rows x 64 columns round-robin
+ * over the waves; word_embed_size <= 128, else form 3), 0 = always the 128-row tile form (its last, partial round
+ * cut into column parts where that fills idle workgroups), 2 = the tile form with whole tiles only, -1 = take it
+ * from the environment again (R4R_GEMM=tile / whole / balanced / ares / resident-weights pin 0 / 2 / 1 / 3 / 4;
+ * unset: form 4 for word_embed_size <= 64, form 3 above). */
 int r4r_gemm_form(int balanced);
 
 /* Backward of the tower w.r.t. conv weight and bias (the word table is frozen:

@@ -1143,6 +1143,210 @@ __global__ __launch_bounds__(GEMM_THREADS) void proj_gemm_kernel(ProjArgs a) {
     }
 }
 
+// ---- 2d. the weight-resident form (form 4) for narrow tables (E <= 128: NARRE / TransNet at E = 64).
+//
+// At E = 64 the GEMM has four K chunks: 0.76 GFLOP against 24 MB of output at cfg4 -- the A-resident form above is
+// then all prologue (stage the rows, barrier per chunk) and epilogue (its stores come in one burst), 19.4 us for 6 us
+// of MFMA work.  Here the roles are turned round: the WEIGHTS of the workgroup's tower -- all 304 x E of them, 78 KB
+// at E = 64 -- go to LDS once (every workgroup reads the same lines: L2 hits), and after ONE barrier the eight waves
+// run free over units of (16-row tile) x (four column tiles): the table fragments of a unit are 4 nchunk floats per
+// lane straight from global memory into registers (requested one unit ahead: the loads of unit k + 1 are older than
+// the stores of unit k in the wave's in-order counter, so waiting for them does not wait for those stores), the
+// weight fragments come from LDS (rows padded by one 16-byte slot: an odd slot stride spreads the 16 lanes of a
+// ds_read_b128 group over all 64 banks), 16 nchunk MFMAs per unit on four independent accumulators, four float4
+// stores.  Units go round-robin over the waves of the tower's workgroups (split over the towers in proportion to
+// their row tiles), so the tail is one unit, and a launch stores steadily from its first microsecond.  Same operand
+// arrangement and K order per output element as the other forms: identical bits.
+#ifndef R4R_WR_THREADS
+#define R4R_WR_THREADS 512
+#endif
+#ifndef R4R_WR_ABL
+#define R4R_WR_ABL 0
+#endif
+#ifndef R4R_WR_NB
+#define R4R_WR_NB 1                                 // units the table-fragment loads run ahead
+#endif
+constexpr int WR_THREADS = R4R_WR_THREADS, WR_WAVES = WR_THREADS / 64;
+constexpr int WR_MAX_CHUNKS = 8;                       // 304 rows x (128 + 4) floats = 160,512 B
+constexpr int WR_NQ = (PNT + 3) / 4;                   // 5 column quads (the last one: 3 tiles)
+__host__ __device__ constexpr int wr_stride(int nch) { return nch * PEC + 4; }
+__host__ __device__ constexpr int wr_lds_bytes(int nch) { return PN * wr_stride(nch) * 4; }
+
+template <int NCH>
+__global__ __launch_bounds__(WR_THREADS) void proj_gemm_wres_kernel(ProjArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float *lds = reinterpret_cast<float *>(smem);
+    constexpr int STR = wr_stride(NCH), SLOTS = NCH * 4;
+    // the towers' workgroups: in proportion to their row tiles, every tower with rows at least one
+    int rt[MAX_TOWERS], g[MAX_TOWERS], U = 0, live = 0;
+    for (int t = 0; t < MAX_TOWERS; ++t) {
+        rt[t] = t < a.ntower ? (a.t[t].count[0] + 15) >> 4 : 0;
+        U += rt[t];
+        live += rt[t] > 0;
+    }
+    if (U == 0) return;
+    const int G = (int)gridDim.x;                            // (the launcher gives every tower a workgroup: G >= ntower)
+    int used = 0, big = 0;
+    for (int t = 0; t < MAX_TOWERS; ++t) {
+        g[t] = rt[t] > 0 ? max(1, (int)((long)rt[t] * (G - live) / U)) : 0;
+        used += g[t];
+        if (rt[t] > rt[big]) big = t;
+    }
+    for (int t = 0; t < MAX_TOWERS; ++t) g[t] += (t == big) ? G - used : 0;     // (>= 0: the floors sum to <= G - live + live)
+    int tower = -1, wl = 0, base = 0;
+    for (int t = 0; t < MAX_TOWERS; ++t) {
+        if ((int)blockIdx.x >= base && (int)blockIdx.x < base + g[t]) { tower = t; wl = (int)blockIdx.x - base; }
+        base += g[t];
+    }
+    if (tower < 0) return;
+    const ProjTower &tw = a.t[tower];
+    const int count = tw.count[0], E = a.E;
+    const int tid = threadIdx.x, lane = tid & 63, lrow = lane & 15, q = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);           // (a scalar: the unit loop below branches on scalars)
+    // (32-bit byte offsets into this tower's projected rows: the launcher keeps the form to outputs under 2 GB)
+    const unsigned long long pbase = reinterpret_cast<unsigned long long>(tw.ptab);
+    const unsigned plo = __builtin_amdgcn_readfirstlane((unsigned)pbase), phi = __builtin_amdgcn_readfirstlane((unsigned)(pbase >> 32));
+    float *pt = reinterpret_cast<float *>(((unsigned long long)phi << 32) | plo);
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(pt, 0, __builtin_amdgcn_readfirstlane(count) * (PROW * 4), 0x00020000);
+    const int units = rt[tower] * WR_NQ, stride = g[tower] * WR_WAVES;
+    // The table fragments of a unit's row tile take two dependent reads -- the token of the lane's row, then the row --
+    // so they run NB units ahead through a ring of NB register sets, the tokens 2 NB units ahead (NB = 1 .. 5 measured:
+    // no difference at cfg5, where the rows come from HBM -- the launch is bound by its stores --, and a longer
+    // prologue at cfg4; NB = 1).  Rows past the end read row count - 1 and are never stored; units past the end
+    // re-read the last unit's rows and are not computed.
+    constexpr int NB = R4R_WR_NB;
+    auto load_tok = [&](int u) { return tw.list[min((min(u, units - 1) / WR_NQ) * 16 + lrow, count - 1)]; };
+    auto load_a = [&](int tok, f32x4 (&o)[NCH]) {
+        const float *ap = a.table + (long)tok * E;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) o[c] = *reinterpret_cast<const f32x4 *>(ap + min(c * PEC + q * 4, E - 4));
+    };
+    // (the K tail, E % 16, lies in the last chunk only: zeroed on this side too when the fragment is used)
+    const bool tail_keep = (NCH - 1) * PEC + q * 4 < E;
+    int u = wl * WR_WAVES + wave;
+    f32x4 ring[NB][NCH];
+    int tokr[NB];
+    // ---- prologue, ordered by what depends on what: the first units' tokens are requested FIRST, then the weights
+    // (one round trip to L2: every load of the fill is issued before the first LDS write), then -- the tokens are
+    // older in the wave's in-order counter: waiting for them does not wait for the weights -- the first units' rows;
+    // only then are the weights written to LDS (row n = 100 j + f holds W[f][j][:], zero past E and past row 299).
+    const bool has_units = u < units;
+    if (has_units) {
+#pragma unroll
+        for (int j = 0; j < NB; ++j) tokr[j] = load_tok(u + j * stride);
+    }
+    const float *__restrict__ conv_w = tw.conv_w;
+    constexpr int NFILL = (PN * SLOTS + WR_THREADS - 1) / WR_THREADS;
+    f32x4 wv[NFILL];
+    bool wreal[NFILL];
+#pragma unroll
+    for (int k = 0; k < NFILL; ++k) {
+        const int i = tid + k * WR_THREADS;
+        const int n = i / SLOTS, sl = i - n * SLOTS;
+        const int j = n / PF, f = n - j * PF;
+        wreal[k] = n < PROW && sl * 4 < E;
+        wv[k] = *reinterpret_cast<const f32x4 *>(conv_w + (wreal[k] ? ((long)f * 3 + j) * E + sl * 4 : 0));
+    }
+    // Entry state of the unit loop: the queue the loop has on its back edge -- per ring set: table-fragment loads, a
+    // token load, four stores (here to an offset outside the descriptor: dropped by the hardware).  hipcc merges the
+    // entry and back-edge states at the loop head; with nothing behind the loads on the entry side it waited
+    // vmcnt(0) in every iteration, i.e. for the previous unit's stores to be acknowledged, where the loads alone are
+    // what the data needs.
+    if (has_units) {
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            load_a(tokr[j], ring[j]);
+            tokr[j] = load_tok(u + (NB + j) * stride);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < NFILL; ++k) {
+        const int i = tid + k * WR_THREADS;
+        const int n = i / SLOTS, sl = i - n * SLOTS;
+        f32x4 v;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) v[c] = wreal[k] ? wv[k][c] : 0.f;
+        if (i < PN * SLOTS) *reinterpret_cast<f32x4 *>(lds + n * STR + sl * 4) = v;
+    }
+    if (has_units) {
+        const f32x4 z = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < 4 * NB; ++i)                     // (distinct offsets: identical stores are merged)
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, z), rsrc, 0x7ffffff0 - 64 * i, 0, 0);
+    }
+    __syncthreads();                                         // the weights are in LDS: the waves run free from here
+#if R4R_WR_ABL == 4                                          // timing ablation: the prologue alone
+    if (count >= 0) return;
+#endif
+    const float *bl = lds + lrow * STR + q * 4;
+    auto unit = [&](int uu, f32x4 (&slot)[NCH], int &tok) {
+        f32x4 cur[NCH];
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) cur[c] = slot[c];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) cur[NCH - 1][i] = tail_keep ? cur[NCH - 1][i] : 0.f;
+        load_a(tok, slot);                                   // unit uu + NB stride
+        tok = load_tok(uu + 2 * NB * stride);
+        const int rt0 = (uu / WR_NQ) * 16, ct0 = (uu % WR_NQ) * 4;
+        f32x4 acc[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        const float *bu = bl + ct0 * 16 * STR;
+        if (ct0 + 4 <= PNT) {
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+                f32x4 b[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) b[i] = *reinterpret_cast<const f32x4 *>(bu + i * 16 * STR + c * PEC);
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#if R4R_WR_ABL == 2                                          // timing ablation: no MFMAs (operands still consumed)
+                        acc[i][kk] += cur[c][kk] + b[i][kk];
+#else
+                        acc[i] = MFMA4S(cur[c][kk], b[i][kk], acc[i]);
+#endif
+            }
+        } else {                                             // the last quad: three column tiles
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+                f32x4 b[3];
+#pragma unroll
+                for (int i = 0; i < 3; ++i) b[i] = *reinterpret_cast<const f32x4 *>(bu + i * 16 * STR + c * PEC);
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) acc[i] = MFMA4S(cur[c][kk], b[i][kk], acc[i]);
+            }
+        }
+        const int row = rt0 + lrow;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int col = (ct0 + i) * 16 + q * 4;
+            const int off = (row < count && col < PROW) ? (row * PROW + col) * 4 : 0x7ffffff0;   // out of range: dropped by the hardware
+#if R4R_WR_ABL == 1                                          // timing ablation: no stores
+            asm volatile("" ::"v"(acc[i]), "v"(off));
+#elif R4R_WR_ABL == 3                                        // timing ablation: same bytes, every store 1 KB contiguous (wrong layout)
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[i]), rsrc, (uu * 4 + i) * 1024 + lane * 16 + (off & 0), 0, 0);
+#else
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[i]), rsrc, off, 0, 0);
+#endif
+        }
+    };
+    // whole turns of the ring without a branch between the units (a skipped unit would leave a different queue
+    // behind, and the merged state costs every iteration a full wait), then the last, partial turn
+    for (; u + (NB - 1) * stride < units; u += NB * stride)
+        static_for<0, NB>([&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+            unit(u + j * stride, ring[j], tokr[j]);
+        });
+    static_for<0, NB - 1>([&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+        if (u + j * stride < units) unit(u + j * stride, ring[j], tokr[j]);
+    });
+}
+
 // ---- 3. gather-add-max.  One workgroup = TWO consecutive 128-position segments of the launch's
 // document-major segment list (grid = (ceil(N * tiles / 2), ntower)); its 8 workers of 32 lanes each walk a
 // 32-position slice, so a worker's dependent chain is 34 tokens / 8 in flight = 5 memory
@@ -1284,9 +1488,13 @@ int64_t proj_row_capacity(int64_t N, int T, int64_t V) { return (N * T < V) ? N 
 size_t proj_ptab_floats(int64_t N, int T, int64_t V) { return (size_t)proj_row_capacity(N, T, V) * PROW; }
 
 #ifndef R4R_GEMM_DEFAULT
-#define R4R_GEMM_DEFAULT 3
+#define R4R_GEMM_DEFAULT 5
 #endif
 constexpr int GEMM_DEFAULT_FORM = R4R_GEMM_DEFAULT;
+#ifndef R4R_WR_DEFAULT_CHUNKS
+#define R4R_WR_DEFAULT_CHUNKS 4
+#endif
+constexpr int WR_DEFAULT_CHUNKS = R4R_WR_DEFAULT_CHUNKS;   // form 3 hands launches with at most this many K chunks to form 4
 static int g_gemm_balanced = -1;       // -1: from the environment (R4R_GEMM=tile | whole pin the tile form) on first use
 static int g_gemm_math = 0;            // 0: fp32 MFMA (the default and the headline); 1: fp16-split operands (project_f16.hip)
 static float g_table_maxabs = 0.f;     // max |table|, given with mode 1 (the table is frozen: the host computes it once)
@@ -1306,9 +1514,12 @@ static ProjArgs make_args(const float *table, int64_t V, const ProjTower *tw, in
     a.ntower = ntower;
     if (g_gemm_balanced < 0) {
         const char *e = getenv("R4R_GEMM");
-        g_gemm_balanced = (e && e[0] == 't') ? 0 : ((e && e[0] == 'w') ? 2 : ((e && e[0] == 'a') ? 3 : ((e && e[0] == 'b') ? 1 : GEMM_DEFAULT_FORM)));
+        g_gemm_balanced = (e && e[0] == 't') ? 0 : ((e && e[0] == 'w') ? 2 : ((e && e[0] == 'a') ? 3 : ((e && e[0] == 'b') ? 1 : ((e && e[0] == 'r') ? 4 : GEMM_DEFAULT_FORM))));
     }
     a.balanced = g_gemm_balanced;
+    // narrow tables (E <= 64: four K chunks) take the weight-resident form by default; R4R_GEMM=r asks for it up to E = 128
+    if (a.balanced == 5) a.balanced = a.nchunk <= WR_DEFAULT_CHUNKS ? 4 : 3;    // (5 = the default: the form by table width)
+    if (a.balanced == 4 && (a.nchunk > WR_MAX_CHUNKS || E % 4 != 0 || (int64_t)a.cap * PROW * 4 >= (1ll << 31))) a.balanced = 3;
     // the A-resident form holds all of K in LDS (E <= 320) and addresses its output with 32-bit byte offsets
     if (a.balanced == 3 && (a.nchunk > AR_MAX_CHUNKS || (int64_t)a.cap * PROW * 4 >= (1ll << 31))) a.balanced = 1;
     return a;
@@ -1333,6 +1544,29 @@ int textcnn_proj_tokens_launch(int64_t V, const ProjTower *tw, int ntower, int64
     return check_launch("textcnn_proj_tokens");
 }
 
+template <int NCH>
+static void wres_launch_n(const ProjArgs &a, unsigned wgs, hipStream_t st) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(proj_gemm_wres_kernel<NCH>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, wr_lds_bytes(NCH));
+        attr_set = true;
+    }
+    proj_gemm_wres_kernel<NCH><<<dim3(wgs), WR_THREADS, wr_lds_bytes(NCH), st>>>(a);
+}
+static void wres_launch(const ProjArgs &a, unsigned wgs, hipStream_t st) {
+    switch (a.nchunk) {
+        case 1: wres_launch_n<1>(a, wgs, st); break;
+        case 2: wres_launch_n<2>(a, wgs, st); break;
+        case 3: wres_launch_n<3>(a, wgs, st); break;
+        case 4: wres_launch_n<4>(a, wgs, st); break;
+        case 5: wres_launch_n<5>(a, wgs, st); break;
+        case 6: wres_launch_n<6>(a, wgs, st); break;
+        case 7: wres_launch_n<7>(a, wgs, st); break;
+        default: wres_launch_n<8>(a, wgs, st); break;
+    }
+}
+
 // Phase B: projection GEMM + gather-add-max, given the token state.
 int textcnn_proj_compute_launch(const float *table, int64_t V, const ProjTower *tw, int ntower,
                                 int64_t N, int T, int E, int F, hipStream_t st) {
@@ -1352,6 +1586,13 @@ int textcnn_proj_compute_launch(const float *table, int64_t V, const ProjTower *
     if (f16) {
         ScopedTiming tm(R4R_TIMING_PROJ_GEMM, st);           // (the opt-in arithmetic: its weight-scale launch included)
         if (int rc = proj_gemm_f16_launch(table, tw, ntower, a.cap, E, g_table_maxabs, g_weight_maxabs, st)) return rc;
+    } else if (a.balanced == 4) {
+        ScopedTiming tm(R4R_TIMING_PROJ_GEMM, st);
+        // one workgroup per CU at most; fewer when the row capacity is small (a workgroup's 8 waves take 8 units per round)
+        int64_t wgs = ((int64_t)a.cap + 15) / 16 * WR_NQ / WR_WAVES + ntower;
+        if (wgs > G7_WGS) wgs = G7_WGS;
+        if (wgs < ntower) wgs = ntower;
+        wres_launch(a, (unsigned)wgs, st);
     } else {
         ScopedTiming tm(R4R_TIMING_PROJ_GEMM, st);
         // persistent: one workgroup per CU at most (86 KB of LDS each), fewer when the row capacity is small

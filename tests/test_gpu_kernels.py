@@ -436,14 +436,50 @@ def test_projection_gemm_balanced_form_is_bit_identical_to_the_tile_form(V):
         p2, a2 = p2.clone(), a2.clone()
         lib.r4r_gemm_form(3)                                # the A-resident form of the balanced plan (E = 128: 8 resident chunks)
         p3, a3 = ops.textcnn_fwd_raw(*args)
+        p3, a3 = p3.clone(), a3.clone()
+        lib.r4r_gemm_form(4)                                # the weight-resident form (E = 128: its widest table)
+        p4, a4 = ops.textcnn_fwd_raw(*args)
     finally:
         lib.r4r_gemm_form(-1)
     assert torch.equal(p0, p1) and torch.equal(a0, a1)
     assert torch.equal(p0, p2) and torch.equal(a0, a2)
     assert torch.equal(p0, p3) and torch.equal(a0, a3)
+    assert torch.equal(p0, p4) and torch.equal(a0, a4)
     if V <= 3000:
         ref_pooled, ref_arg, y = conv_pool_reference(idx, table, w, b)
         torch.testing.assert_close(p1.cpu(), ref_pooled, rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize('E,V', [(4, 40), (16, 500), (20, 3000), (48, 7000), (64, 19744), (64, 19750), (64, 50000), (64, 77000),
+                                 (100, 9000), (128, 20000)])
+def test_projection_gemm_weight_resident_form_is_bit_identical_to_the_tile_form(E, V):
+    """Form 4 of the projection GEMM (csrc/project.hip 2d: the tower's weights resident in LDS, units of 16 rows x 4
+    column tiles round-robin over the waves; the default for E <= 64, i.e. NARRE's and TransNet's tables) against the
+    128-row tile form: every K-chunk count 1 .. 8 incl. ragged K tails (E = 20, 100), cfg4's row count (19,744 =
+    1,234 row tiles exactly; 19,750: a partial last tile) and cfg5's (77,000), one unit per wave and many."""
+    from reviews4rec_amd import _lib
+    ops = _ops()
+    T = 100
+    N = max(-(-V // T) + 3, 660)                             # >= 65,536 positions: the static rule runs project-then-gather
+    g = torch.Generator().manual_seed(V + E)
+    table = (torch.rand((V, E), generator=g) - 0.5) * 0.2
+    w = (torch.rand((100, 1, 3, E), generator=g) - 0.5) * (2 * math.sqrt(6.0 / (3 * E + 300 * E)))
+    b = (torch.rand(100, generator=g) - 0.5) * 0.1
+    idx = torch.cat([torch.randperm(V, generator=g), torch.randint(0, V, (N * T - V,), generator=g)]).view(N, T)
+    args = (idx.to(DEV), table.to(DEV), w.to(DEV), b.to(DEV))
+    lib = _lib.lib()
+    try:
+        lib.r4r_gemm_form(0)
+        p0, a0 = ops.textcnn_fwd_raw(*args)
+        p0, a0 = p0.clone(), a0.clone()
+        lib.r4r_gemm_form(4)
+        p4, a4 = ops.textcnn_fwd_raw(*args)
+    finally:
+        lib.r4r_gemm_form(-1)
+    assert torch.equal(p0, p4) and torch.equal(a0, a4)
+    if V <= 3000:
+        ref_pooled, ref_arg, y = conv_pool_reference(idx, table, w, b)
+        torch.testing.assert_close(p4.cpu(), ref_pooled, rtol=1e-5, atol=1e-6)
 
 
 @pytest.mark.parametrize('N,T,E,V,tscale', [(36, 1000, 300, 1500, 0.011), (700, 100, 64, 2000, 1.0), (64, 1000, 300, 20000, 3.0)])
