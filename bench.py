@@ -516,6 +516,8 @@ def main():
                        'conv_algo': args.conv_algo, 'gemm_math': args.gemm_math, 'doc_fill': args.doc_fill,
                        'token_dist': args.token_dist,
                        **({'rccl_ranks': world, 'dist_backend': torch.distributed.get_backend(),
+                           # True: the collectives ran on the step's own stream through the package's communicator
+                           'collectives_on_compute_stream': bool(dp is not None and getattr(dp, 'stream_rccl', None) is not None),
                            'replicas_identical': replicas} if dp_job else {}),
                        **({'dp_exchange': engine.exchange,
                            'dp_exchange_ms': {k: round(v, 4) for k, v in exchange_ms.items()}} if exchange_ms else {}),
@@ -543,17 +545,23 @@ def main():
             g_s = timed['proj_gemm_kernel'][0] / 1000.0
             gflops = rows * hp['word_embed_size'] * 300 * 2
             ach = gflops / g_s / 1e12
-            traffic, src = measured_traffic('proj_gemm_kernel', args, g_s)
+            # (tables of E <= 64 run the weight-resident form of the GEMM, csrc/project.hip 2d, unless R4R_GEMM pins one)
+            wres = -(-hp['word_embed_size'] // 16) <= 4 and os.environ.get('R4R_GEMM', 'r')[0] == 'r'
+            gemm_name = 'proj_gemm_wres_kernel' if wres else 'proj_gemm_kernel'
+            traffic, src = measured_traffic(gemm_name, args, g_s)
             f16 = args.gemm_math == 'f16x2'
             # fp16-split form: three f16 MFMA products per useful fp32 product -> a third of the dense f16 peak
             peak = PEAK_F16_MFMA_TFLOPS / 3.0 if f16 else PEAK_FP32_MFMA_TFLOPS
-            result['roofline'] = {'kernel': 'proj_gemm_f16_kernel (+ its weight-pack launch)' if f16 else 'proj_gemm_kernel',
+            result['roofline'] = {'kernel': 'proj_gemm_f16_kernel (+ its weight-pack launch)' if f16 else gemm_name,
                                   'bound': 'mfma', 'achieved': round(ach, 2),
                                   'peak': round(peak, 1), 'unit': 'TFLOP/s',
                                   'frac': round(ach / peak, 4),
                                   'traffic': traffic, 'traffic_source': src,
                                   'launches': timed['proj_gemm_kernel'][1], 'avg_launch_ms': round(1000 * g_s, 4),
                                   'flops_per_launch': int(gflops), 'distinct_token_rows_per_launch': int(rows),
+                                  # what the launch must move whatever its form: the distinct rows in, 1,200 B per row out
+                                  # (at E = 64 the stores, not the MFMAs, bound it: DESIGN 4.1b round 3)
+                                  'algorithmic_GBs': round(rows * (hp['word_embed_size'] * 4 + 1200) / g_s / 1e9, 1),
                                   'positions_per_launch': int(towers * B * hp['input_length'])}
             # second leg: the gather-add-max kernel streams every position's three 400-B tap rows + an 8-B
             # token id (1.2 KB + 8 B per position).  The projected rows it reads were written by

@@ -2,6 +2,7 @@
 #include <hip/hip_runtime.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <vector>
@@ -40,8 +41,12 @@ bool timing_on() { return g_timing_mask != 0; }
 
 static hipEvent_t take_event() {
     if (!g_pool.empty()) { hipEvent_t e = g_pool.back(); g_pool.pop_back(); return e; }
+    // Timing-only events: no system-scope fence when the event completes (hipEventRecord's default release writes
+    // the L2 back -- 35 MB of projected rows between the GEMM and the gather that reads them -- which made an
+    // instrumented step ~30 us longer than the steps it samples).  R4R_TIMING_SYSTEM_FENCE=1 restores the default.
+    static const unsigned flags = getenv("R4R_TIMING_SYSTEM_FENCE") ? hipEventDefault : hipEventDisableSystemFence;
     hipEvent_t e;
-    (void)hipEventCreate(&e);
+    (void)hipEventCreateWithFlags(&e, flags);
     return e;
 }
 

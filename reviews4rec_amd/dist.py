@@ -233,7 +233,37 @@ class DataParallel:
         # runs over RCCL (R4R_DP_RCCL=0: torch.distributed's collectives, as before)
         self.stream_rccl = None
         if self.on and os.environ.get('R4R_DP_RCCL', '1') != '0' and dist.get_backend(group) == 'nccl':
-            self.stream_rccl = StreamRccl(group)
+            self.stream_rccl = self._checked_stream_rccl(group)
+
+    @staticmethod
+    def _checked_stream_rccl(group):
+        """StreamRccl, proven on this job's fabric before anything depends on it: one all-reduce and one all-gather
+        with known answers; every rank must see both right, or ALL ranks fall back to torch.distributed's
+        collectives together (a warning, not an error: the exchange is an optimisation of the same sums)."""
+        import warnings
+        comm, ok, why = None, 1, ''
+        try:
+            comm = StreamRccl(group)
+            dev = torch.device('cuda', torch.cuda.current_device())
+            t = torch.full((1024,), float(comm.rank + 1), device=dev)
+            comm.all_reduce(t)
+            g = torch.empty(comm.world * 256, device=dev)
+            comm.all_gather(g, torch.full((256,), float(comm.rank), device=dev))
+            torch.cuda.synchronize(dev)
+            want = torch.arange(comm.world, device=dev, dtype=torch.float32).repeat_interleave(256)
+            if not (bool((t == comm.world * (comm.world + 1) / 2).all()) and torch.equal(g, want)):
+                ok, why = 0, 'a collective returned wrong values'
+        except Exception as e:                               # noqa: BLE001 -- whatever went wrong, every rank must hear of it
+            ok, why = 0, '%s: %s' % (type(e).__name__, e)
+        flag = torch.tensor([ok], device='cuda', dtype=torch.int32)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+        if int(flag.item()) == 1:
+            return comm
+        if comm is not None:
+            comm.close()
+        warnings.warn('reviews4rec_amd.dist: the on-stream RCCL communicator is not usable here (%s); using '
+                      "torch.distributed's collectives" % (why or 'another rank reported a failure'), RuntimeWarning)
+        return None
 
     def rebind(self, model):
         """Point the exchange at `model` (a new training stage, a freshly built model): its parameters
