@@ -123,7 +123,7 @@ def parse():
                     help='lognormal: documents zero-padded to T (SURVEY 8d, default); full: no padding')
     ap.add_argument('--token-dist', choices=['zipf', 'uniform'], default='zipf',
                     help='zipf (SURVEY 8d, default) or uniform word ids (most distinct tokens per batch)')
-    ap.add_argument('--ramp', type=int, default=30,
+    ap.add_argument('--ramp', type=int, default=300,
                     help='untimed steps before the requested warm-up when --warmup is shorter than this: clocks '
                          'and launch queue reach steady state whatever --warmup says (reported as warmup_effective)')
     ap.add_argument('--opt-in-leg', action='store_true',
@@ -414,7 +414,9 @@ def main():
     gc.freeze()
     # Untimed ramp: a 20-step timed region is 2 ms of GPU time, and a GPU that was idle a moment ago
     # has neither its clocks nor its launch queue in steady state after a 5-step warm-up (that run read
-    # 6 % low).  Whatever --warmup says, at least --ramp untimed steps precede the timed region.
+    # 6 % low).  Whatever --warmup says, at least --ramp untimed steps precede the timed region.  How many it takes:
+    # profiles/r03e_ramp_ab.txt -- the driver's 20-step command after 30 / 100 / 300 untimed steps reads 1.13 / 1.15 /
+    # 1.18 M ratings/s (its sampled GEMM launch 59-61 / 57 / 55 us): the clocks settle over the first ~30 ms of work.
     ramp = max(0, args.ramp - args.warmup)
     for i in range(ramp + args.warmup):
         step(i)
