@@ -7,11 +7,13 @@ make_quick_data.py:23-32 writes), ``len(loader)`` is the number of batches, and
 ``iter()`` yields contiguous slices of ``batch_size`` rows -- no shuffling, ragged
 last batch -- as ``([7 int64 device tensors], float32 device tensor)``.
 
-On-disk format: the reference uses gzip HDF5 through h5py, which does not exist in
-this image; the same 8 datasets are stored as one ``.npz`` per split
-(``train.npz`` / ``val.npz`` / ``test.npz`` under ``quick_data_*/<data_dir>``), i8 / f8
-like the HDF5 writer.  ``from_arrays`` builds a loader from in-memory arrays
-(synthetic data).
+On-disk format: the reference's own gzip HDF5 epoch files (``train.hdf5`` / ``val.hdf5`` /
+``test.hdf5`` under ``quick_data_*/<data_dir>``, written by data_scripts/make_quick_data.py:21-44)
+are read as they are -- through h5py where it exists, otherwise through ``hdf5_lite``, this
+package's own reader of that container format (the MI355X image has no h5py / libhdf5).  Where
+no ``.hdf5`` file exists the same 8 datasets are taken from one ``.npz`` per split (``train.npz``
+..., i8 / f8 like the HDF5 writer; ``save_split`` / tools/make_quick_data.py write them).
+``from_arrays`` builds a loader from in-memory arrays (synthetic data).
 
 Host->device: the reference builds 8 tensors per batch from pageable numpy slices
 (3 MB of int64 per DeepCoNN batch, synchronous, on the compute stream).  Here the arrays
@@ -41,11 +43,7 @@ class DataLoader():
         if arrays is None:
             init_path = '/'.join(hyper_params['data_dir'].split('/')[1:])
             root = 'quick_data_narre/' if hyper_params['model_type'] in ['NARRE'] else 'quick_data_deepconn/'
-            path = root + init_path + file_name
-            if not os.path.exists(path) and path.endswith('.hdf5'):
-                path = path[:-5] + '.npz'
-            with np.load(path) as z:
-                arrays = {k: z[k] for k in KEYS}
+            arrays = read_split(root + init_path + file_name)
         self.total = len(arrays['a'])
         self._copy_stream = None
         pin = torch.cuda.is_available()
@@ -163,6 +161,24 @@ class DataLoader():
             dev.record_stream(cur)                          # the allocator must not reuse it under the trainer
             for item in batches:
                 yield item
+
+
+def read_split(path):
+    """The 8 arrays of one split: the reference's HDF5 file (data_fast.py:31-45 reads it whole, and so does this),
+    or the ``.npz`` beside it when there is no such file."""
+    if path.endswith('.hdf5') and not os.path.exists(path) and os.path.exists(path[:-5] + '.npz'):
+        path = path[:-5] + '.npz'
+    if path.endswith('.npz'):
+        with np.load(path) as z:
+            return {k: z[k] for k in KEYS}
+    try:
+        import h5py
+        opener = h5py.File
+    except ImportError:
+        from . import hdf5_lite
+        opener = hdf5_lite.File
+    with opener(path, 'r') as f:
+        return {k: f[k][:] for k in KEYS}
 
 
 def save_split(path, data, y):
