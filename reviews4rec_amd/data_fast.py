@@ -182,11 +182,16 @@ def read_split(path):
 
 
 def save_split(path, data, y):
-    """Write one split in the on-disk format above (i8 ids, f8 ratings)."""
+    """Write one split (i8 ids, f8 ratings): ``*.hdf5`` in the reference's own format -- the eight gzip datasets
+    make_quick_data.py:21-32 creates, readable by the reference's h5py loader -- or ``*.npz``."""
     os.makedirs(os.path.dirname(path) or '.', exist_ok=True)
     arrays = {k: np.asarray(d, dtype=np.int64) for k, d in zip(KEYS[:7], data)}
     arrays['h'] = np.asarray(y, dtype=np.float64)
-    np.savez(path, **arrays)
+    if path.endswith('.hdf5'):
+        from . import hdf5_lite
+        hdf5_lite.write_file(path, arrays, compression='gzip')
+    else:
+        np.savez(path, **arrays)
 
 
 def load_data_fast(hyper_params):

@@ -429,3 +429,170 @@ class Dataset:
         if not rest:
             return got
         return got[rest] if isinstance(key, (int, np.integer)) else got[(slice(None),) + rest]
+
+
+# ----------------------------------------------------------------------------------------------------- writing
+# The counterpart of data_scripts/make_quick_data.py:21-44's h5py calls: a file of root-group datasets that libhdf5 /
+# h5py (and the reference's data_fast.py) read.  Same structures the reader above takes apart, laid out the way
+# libhdf5 1.10 lays out a default (libver='earliest') file -- the byte patterns of the messages are those of the
+# h5py-written fixtures under tests/golden/hdf5/.  Chunks are cut along the first axis only (whole rows, ~1 MB),
+# which is what a loader that reads row slabs wants.
+_UNDEF = b'\xff' * 8
+_GROUP_INTERNAL_K, _CHUNK_K = 16, 32                         # libhdf5's defaults (superblock v0 stores only the group ones)
+
+
+def _u64(*v):
+    return b''.join(int(x).to_bytes(8, 'little') for x in v)
+
+
+def _datatype_message(dt):
+    dt = np.dtype(dt)
+    if dt.byteorder == '>':
+        raise Hdf5Error('write: big-endian arrays are not written (%s)' % dt)
+    n = dt.itemsize
+    if dt.kind in 'iu':
+        body = bytes([0x10, 0x08 if dt.kind == 'i' else 0x00, 0, 0]) + n.to_bytes(4, 'little') + (0).to_bytes(2, 'little') + (8 * n).to_bytes(2, 'little')
+    elif dt.kind == 'f' and n in (4, 8):
+        sign, eloc, esz, msz, bias = (63, 52, 11, 52, 1023) if n == 8 else (31, 23, 8, 23, 127)
+        body = bytes([0x11, 0x20, sign, 0]) + n.to_bytes(4, 'little') + (0).to_bytes(2, 'little') + (8 * n).to_bytes(2, 'little') + \
+            bytes([eloc, esz, 0, msz]) + bias.to_bytes(4, 'little')
+    else:
+        raise Hdf5Error('write: dtype %s (integers, float32 and float64 are written)' % dt)
+    return body
+
+
+def _message(mtype, flags, body):
+    body = body + b'\0' * (-len(body) % 8)
+    return mtype.to_bytes(2, 'little') + len(body).to_bytes(2, 'little') + bytes([flags, 0, 0, 0]) + body
+
+
+def _object_header(messages):
+    body = b''.join(messages)
+    return bytes([1, 0]) + len(messages).to_bytes(2, 'little') + (1).to_bytes(4, 'little') + len(body).to_bytes(4, 'little') + b'\0' * 4 + body
+
+
+class _Out:
+    def __init__(self, fh):
+        self.fh = fh
+
+    def put(self, data):
+        """Append `data` at the next 8-byte boundary; -> its address."""
+        at = self.fh.tell()
+        pad = -at % 8
+        if pad:
+            self.fh.write(b'\0' * pad)
+        self.fh.write(data)
+        return at + pad
+
+
+def _chunk_btree(out, entries, rank, itemsize):
+    """Version-1 B-tree (node type 1) over `entries` = [(address, stored bytes, origin)] in ascending origin order;
+    -> root address.  Nodes are written at full size (2K children, 2K + 1 keys), as libhdf5 reads them."""
+    nd = rank + 1
+    ksz, cap = 8 + 8 * nd, 2 * _CHUNK_K
+
+    def key(nbytes, origin, last=0):
+        return int(nbytes).to_bytes(4, 'little') + (0).to_bytes(4, 'little') + _u64(*origin, last)
+    # level 0: (first key, final key, address) per node, then levels of nodes over nodes until one is left
+    final = key(0, entries[-1][2], itemsize)                 # (what libhdf5 leaves there: the last origin, element size in the extra slot)
+    level, nodes = 0, [(key(n, o), a) for a, n, o in entries]
+    while True:
+        groups = [nodes[i:i + cap] for i in range(0, len(nodes), cap)]
+        size = 24 + cap * 8 + (cap + 1) * ksz
+        base = out.put(b'')                                  # the level's nodes are consecutive: siblings are known up front
+        made = []
+        for g, grp in enumerate(groups):
+            right_key = groups[g + 1][0][0] if g + 1 < len(groups) else final
+            body = b'TREE' + bytes([1, level]) + len(grp).to_bytes(2, 'little')
+            body += (_u64(base + (g - 1) * size) if g else _UNDEF) + (_u64(base + (g + 1) * size) if g + 1 < len(groups) else _UNDEF)
+            body += b''.join(k + _u64(a) for k, a in grp) + right_key
+            body += b'\0' * (size - len(body))
+            assert size % 8 == 0
+            addr = out.put(body)
+            assert addr == base + g * size
+            made.append((grp[0][0], addr))
+        if len(made) == 1:
+            return made[0][1]
+        nodes, level = made, level + 1
+
+
+def write_file(path, datasets, compression='gzip', level=4, chunk_bytes=1 << 20):
+    """Write `datasets` (name -> array; names without '/') as the root-group datasets of a new HDF5 file:
+    ``compression='gzip'`` -- chunked + deflate like make_quick_data.py:23-32 -- or ``None`` (contiguous)."""
+    if compression not in ('gzip', None):
+        raise Hdf5Error('write: compression %r (gzip or None)' % (compression,))
+    names = sorted(datasets, key=lambda s: s.encode('utf-8'))
+    for nm in names:
+        if not nm or '/' in nm or '\0' in nm:
+            raise Hdf5Error('write: dataset name %r' % nm)
+    tmp = path + '.part'
+    with open(tmp, 'wb') as fh:
+        out = _Out(fh)
+        fh.write(b'\0' * 96)                                 # the superblock, filled in last
+        headers = {}
+        for nm in names:
+            a = np.ascontiguousarray(datasets[nm])
+            if a.dtype.byteorder == '>':
+                a = a.astype(a.dtype.newbyteorder('<'))
+            if a.ndim < 1:
+                raise Hdf5Error('write: %r is a scalar (arrays of one or more axes are written)' % nm)
+            dims = a.shape
+            space = bytes([1, a.ndim, 1, 0, 0, 0, 0, 0]) + _u64(*dims) + _u64(*dims)      # maxshape = shape
+            msgs = [_message(0x01, 0, space), _message(0x03, 1, _datatype_message(a.dtype))]
+            rowbytes = int(np.prod(dims[1:])) * a.itemsize
+            if compression is None:
+                raw = a.tobytes()
+                addr = out.put(raw) if raw else None
+                msgs.append(_message(0x05, 1, bytes([2, 2, 2, 1, 0, 0, 0, 0])))
+                msgs.append(_message(0x08, 0, bytes([3, 1]) + (_u64(addr) if raw else _UNDEF) + _u64(len(raw))))
+            else:
+                rows = max(1, min(max(dims[0], 1), chunk_bytes // max(rowbytes, 1)))
+                cdims = (rows,) + tuple(max(d, 1) for d in dims[1:])
+                entries = []
+                if a.size:
+                    def pack(r0):
+                        blk = a[r0:r0 + rows]
+                        if len(blk) < rows:                  # an edge chunk is stored whole
+                            blk = np.concatenate([blk, np.zeros((rows - len(blk),) + dims[1:], a.dtype)])
+                        return zlib.compress(blk.tobytes(), level)
+                    starts = list(range(0, dims[0], rows))
+                    with ThreadPoolExecutor(min(8, os.cpu_count() or 1)) as pool:
+                        for g0 in range(0, len(starts), 64):                 # bounded: 64 chunks in flight
+                            for r0, z in zip(starts[g0:g0 + 64], pool.map(pack, starts[g0:g0 + 64])):
+                                entries.append((out.put(z), len(z), (r0,) + (0,) * (a.ndim - 1)))
+                root = _chunk_btree(out, entries, a.ndim, a.itemsize) if entries else None
+                msgs.append(_message(0x05, 1, bytes([2, 3, 0, 1, 0, 0, 0, 0])))
+                msgs.append(_message(0x0B, 1, bytes([1, 1, 0, 0, 0, 0, 0, 0]) + bytes([1, 0, 8, 0, 1, 0, 1, 0]) + b'deflate\0' +
+                                     int(level).to_bytes(4, 'little') + b'\0' * 4))
+                msgs.append(_message(0x08, 0, bytes([3, 2, a.ndim + 1]) + (_u64(root) if root is not None else _UNDEF) +
+                                     b''.join(int(c).to_bytes(4, 'little') for c in cdims + (a.itemsize,))))
+            headers[nm] = out.put(_object_header(msgs))
+        # root group: local heap (names), one symbol-table node (its K sized for the links), a one-entry B-tree
+        heap_data, offs = bytearray(8), {}
+        for nm in names:
+            offs[nm] = len(heap_data)
+            b = nm.encode('utf-8') + b'\0'
+            heap_data += b + b'\0' * (-len(b) % 8)
+        free_at = len(heap_data)
+        heap_data += _u64(1, 16)                             # one free block, end of list: how libhdf5 closes a heap
+        data_addr = out.put(bytes(heap_data))
+        heap = out.put(b'HEAP' + b'\0' * 4 + _u64(len(heap_data), free_at, data_addr))
+        leaf_k = max(4, (len(names) + 1) // 2)
+        snod = b'SNOD' + bytes([1, 0]) + len(names).to_bytes(2, 'little')
+        snod += b''.join(_u64(offs[nm], headers[nm]) + b'\0' * 24 for nm in names)
+        snod += b'\0' * (8 + 2 * leaf_k * 40 - len(snod))
+        snod_addr = out.put(snod)
+        tree = b'TREE' + bytes([0, 0]) + (1 if names else 0).to_bytes(2, 'little') + _UNDEF + _UNDEF
+        tree += (_u64(0, snod_addr, offs[names[-1]]) if names else b'')
+        tree += b'\0' * (24 + 2 * _GROUP_INTERNAL_K * 8 + (2 * _GROUP_INTERNAL_K + 1) * 8 - len(tree))
+        tree_addr = out.put(tree)
+        root_header = out.put(_object_header([_message(0x11, 0, _u64(tree_addr, heap))]))
+        eof = out.put(b'')
+        fh.truncate(eof)
+        sb = SIGNATURE + bytes([0, 0, 0, 0, 0, 8, 8, 0]) + leaf_k.to_bytes(2, 'little') + _GROUP_INTERNAL_K.to_bytes(2, 'little') + b'\0' * 4
+        sb += _u64(0) + _UNDEF + _u64(eof) + _UNDEF
+        sb += _u64(0, root_header) + (1).to_bytes(4, 'little') + b'\0' * 4 + _u64(tree_addr, heap)
+        assert len(sb) == 96
+        fh.seek(0)
+        fh.write(sb)
+    os.replace(tmp, path)

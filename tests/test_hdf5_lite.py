@@ -165,3 +165,83 @@ with h5py.File(sys.argv[1] + '/latest.hdf5', 'w', libver='latest') as f:
     with pytest.raises(hdf5_lite.Hdf5Error, match='latest'):
         with hdf5_lite.File(str(tmp_path / 'latest.hdf5')) as f:
             f['a'][:]
+
+
+def _sample_arrays(seed=7, n=1000):
+    rng = np.random.default_rng(seed)
+    return {'a': rng.integers(0, 50000, size=(n, 37)), 'b': rng.integers(0, 9, size=(n, 10)), 'h': rng.random(n) * 5,
+            'f4': rng.random((7, 3)).astype(np.float32), 'e0': np.zeros((0, 12), np.int64),
+            'u2': rng.integers(0, 60000, size=(33, 2, 3)).astype(np.uint16), 'i1': rng.integers(-9, 9, size=5).astype(np.int8)}
+
+
+def test_writer_round_trip_through_the_reader(tmp_path):
+    """write_file -> File: gzip chunks (one node, several nodes, two levels of nodes) and contiguous storage."""
+    from reviews4rec_amd import hdf5_lite
+    d = _sample_arrays()
+    for kw in (dict(), dict(chunk_bytes=4096), dict(chunk_bytes=296), dict(compression=None)):
+        p = str(tmp_path / 'w.hdf5')
+        hdf5_lite.write_file(p, d, **kw)
+        with hdf5_lite.File(p) as f:
+            assert f.keys() == sorted(d)
+            for k, want in d.items():
+                assert np.array_equal(f[k][:], want) and f[k][:].dtype == want.dtype, (kw, k)
+            assert np.array_equal(f['a'][123:777], d['a'][123:777])
+            if kw.get('chunk_bytes') == 296:
+                assert f['a'].chunks == (1, 37) and len(f['a']._chunk_list(0, 1000)) == 1000      # 1,000 chunks: 16 leaves + a root
+    with pytest.raises(hdf5_lite.Hdf5Error):
+        hdf5_lite.write_file(str(tmp_path / 'x.hdf5'), {'s': np.array(['a', 'b'])})
+    with pytest.raises(hdf5_lite.Hdf5Error):
+        hdf5_lite.write_file(str(tmp_path / 'x.hdf5'), {'a/b': np.zeros(3)})
+    assert not os.path.exists(str(tmp_path / 'x.hdf5'))
+
+
+def test_save_split_writes_the_reference_container(tmp_path, monkeypatch):
+    from reviews4rec_amd import data_fast, hdf5_lite
+    monkeypatch.chdir(tmp_path)
+    z = np.load(os.path.join(TINY_DIR, 'deepconn_streams.npz'))
+    nb = int(z['len'][0])
+    data = [np.concatenate([z['train/%d/%d' % (k, s)] for k in range(nb)]) for s in range(7)]
+    y = np.concatenate([z['train/%d/y' % k] for k in range(nb)])
+    data_fast.save_split('quick_data_deepconn/Tiny/5_core/train.hdf5', data, y)
+    with hdf5_lite.File('quick_data_deepconn/Tiny/5_core/train.hdf5') as f:
+        assert f.keys() == list('abcdefgh') and f['h'].dtype == np.float64 and f['a'].dtype == np.int64
+        assert f['a']._filters == [(1, [4])]
+    exp = np.load(os.path.join(H5, 'expected.npz'))
+    got = data_fast.read_split('quick_data_deepconn/Tiny/5_core/train.hdf5')
+    for k in 'abcdefgh':                                     # the same arrays the h5py-written fixture holds
+        assert np.array_equal(got[k], exp['deepconn_train.hdf5/' + k])
+    fast = data_fast.DataLoader({'batch_size': 16, 'data_dir': 'data/Tiny/5_core/', 'model_type': 'deepconn'}, 'train.hdf5',
+                                device=torch.device('cpu'))
+    for k, (fields, yy) in enumerate(fast.iter()):
+        assert all(np.array_equal(fields[s].numpy(), z['train/%d/%d' % (k, s)]) for s in range(7))
+
+
+@pytest.mark.skipif(not _have_h5py(), reason='no interpreter with h5py on this machine')
+def test_h5py_reads_what_the_writer_writes(tmp_path):
+    """The other direction of the interchange: the reference's loader (h5py.File(...)[k][:], [a:b]) on our files."""
+    from reviews4rec_amd import hdf5_lite
+    d = _sample_arrays()
+    np.savez(str(tmp_path / 'w.npz'), **d)
+    hdf5_lite.write_file(str(tmp_path / 'w0.hdf5'), d)
+    hdf5_lite.write_file(str(tmp_path / 'w1.hdf5'), d, chunk_bytes=296)
+    hdf5_lite.write_file(str(tmp_path / 'w2.hdf5'), d, compression=None)
+    script = r'''
+import sys, h5py, numpy as np
+exp = np.load(sys.argv[1] + '/w.npz')
+for fn in ('w0', 'w1', 'w2'):
+    with h5py.File(sys.argv[1] + '/' + fn + '.hdf5', 'r') as f:
+        assert sorted(f.keys()) == sorted(exp.files)
+        assert len(f['a']) == 1000
+        for k in exp.files:
+            assert f[k].dtype == exp[k].dtype and f[k].shape == exp[k].shape and f[k].maxshape == exp[k].shape
+            assert np.array_equal(f[k][:], exp[k]), (fn, k)
+        assert np.array_equal(f['a'][200:400], exp['a'][200:400])
+        assert (f['a'].compression == 'gzip' and f['a'].compression_opts == 4) if fn != 'w2' else f['a'].chunks is None
+print('ok')
+'''
+    r = subprocess.run([H5PY_PYTHON, '-c', script, str(tmp_path)], capture_output=True, text=True)
+    assert r.returncode == 0 and r.stdout.strip() == 'ok', r.stderr
+    h5ls = os.path.join(os.path.dirname(H5PY_PYTHON), 'h5ls')
+    if os.path.exists(h5ls):                                  # libhdf5's own tool walks every structure
+        r = subprocess.run([h5ls, '-r', '-v', str(tmp_path / 'w1.hdf5')], capture_output=True, text=True)
+        assert r.returncode == 0 and 'Dataset {1000/1000, 37/37}' in r.stdout, r.stdout + r.stderr

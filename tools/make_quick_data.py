@@ -1,10 +1,11 @@
 #!/usr/bin/env python3
 """Write the preprocessed-epoch files reviews4rec_amd.data_fast reads, from a dataset's pickles
-(counterpart of the reference's data_scripts/make_quick_data.py: same eight datasets a..h, i8 / f8,
-same directory layout -- quick_data_deepconn/ or quick_data_narre/ + <dataset>/<k>_core/ -- stored as
-one .npz per split because h5py is not available here).
+(counterpart of the reference's data_scripts/make_quick_data.py: same eight gzip datasets a..h, i8 / f8,
+same directory layout -- quick_data_deepconn/ or quick_data_narre/ + <dataset>/<k>_core/ -- and the same
+container: train.hdf5 / test.hdf5 / val.hdf5, written by reviews4rec_amd.hdf5_lite (no h5py here) and
+readable by the reference's own h5py loader; pass `npz` as the last argument for .npz files instead).
 
-    python tools/make_quick_data.py <dataset> <k_core> <percent> <model_type> [data_root=data/]
+    python tools/make_quick_data.py <dataset> <k_core> <percent> <model_type> [data_root=data/] [hdf5|npz]
 
 Needed only for hyper_params['loader'] = 'fast'; the default loader (reviews4rec_amd/data.py) builds
 batches on the device straight from the pickles.
@@ -39,9 +40,12 @@ def main(argv):
     hp['data_dir'] = data_root + rel
     train, test, val, hp = load_data(hp, load_negs=False, device='cpu')
     out = ('quick_data_narre/' if model_type == 'NARRE' else 'quick_data_deepconn/') + rel
+    ext = '.' + (argv[6] if len(argv) > 6 else 'hdf5')
+    if ext not in ('.hdf5', '.npz'):
+        raise SystemExit('format %r: hdf5 or npz' % ext[1:])
     for name, reader in (('train', train), ('test', test), ('val', val)):
-        write_split(reader, out + name + '.npz')
-        print('wrote', out + name + '.npz', len(reader.data), 'ratings')
+        write_split(reader, out + name + ext)
+        print('wrote', out + name + ext, len(reader.data), 'ratings')
 
 
 if __name__ == '__main__':
