@@ -315,8 +315,13 @@ def main():
             if engine is not None:
                 # forward + loss + backward + all-reduce + Adam; the next batch's token compaction overlaps it
                 nxt = pool[(i + 1) % len(pool)][0]
-                engine.train_step(data, y, n_global=b_global,
-                                  next_data=nxt if args.token_prefetch == 'fused' else None)
+                if getattr(engine, 'TEMPORAL_SWEEP', False) and args.token_prefetch == 'fused':
+                    # (TransNet++: the ID-vector sweep temporally blocked, as main.train runs it; what it leaves
+                    # pending is applied by engine.flush() INSIDE the timed region, before the closing fence)
+                    engine.train_step(data, y, n_global=b_global, next_data=nxt, defer_sweep=True)
+                else:
+                    engine.train_step(data, y, n_global=b_global,
+                                      next_data=nxt if args.token_prefetch == 'fused' else None)
                 if args.token_prefetch == 'side-stream':
                     engine.prefetch_tokens(nxt)
                 return
@@ -394,6 +399,8 @@ def main():
         for i in range(steps):
             lib.r4r_timing_enable(mask if sample(i) else 0)
             step_fn(first + i)
+        if hasattr(engine, 'flush'):                         # every optimizer update of the K steps lands inside the region
+            engine.flush(check=False)
         ev1.record()
         fence()
         elapsed = time.perf_counter() - t0
@@ -427,6 +434,8 @@ def main():
     mask = 0 if args.no_kernel_timing else (1 << 0) | (1 << 3) | (1 << 4) | \
         ((1 << 2) if hp['model_type'] in ('MF_dot', 'bias_only', 'transnet++') else 0)   # the Adam sweep is the leg
     elapsed = timed_region(step, args.steps, ramp + args.warmup, mask)
+    if hasattr(engine, 'check_announcements'):               # (outside the region: one int read back from the device)
+        engine.check_announcements()
     gpu_ms_per_step = gpu_span_ms[0] / args.steps
     steps_run = ramp + args.warmup + args.steps
     slots = {'textcnn_fwd_kernel': 0, 'textcnn_wgrad_kernel': 1, 'adam_multi_kernel': 2,
@@ -517,6 +526,11 @@ def main():
                        'engine': 'native' if engine is not None else ('graph' if graphed is not None else 'module'),
                        'conv_algo': args.conv_algo, 'gemm_math': args.gemm_math, 'doc_fill': args.doc_fill,
                        'token_dist': args.token_dist,
+                       **({'id_vector_sweep': 'temporally blocked: chunks neither this batch nor the announced next one names are '
+                                              'visited every %d-th step and take their pending Adam updates together (same bits as the '
+                                              'dense sweep, tests/test_gpu_full_size.py); flushed inside the timed region' % engine.sweep_period}
+                          if getattr(engine, 'TEMPORAL_SWEEP', False) and getattr(engine, 'plus', 0) and not dp_job
+                          and engine.sweep_period > 1 and args.token_prefetch == 'fused' else {}),
                        **({'rccl_ranks': world, 'dist_backend': torch.distributed.get_backend(),
                            # True: the collectives ran on the step's own stream through the package's communicator
                            'collectives_on_compute_stream': bool(dp is not None and getattr(dp, 'stream_rccl', None) is not None),

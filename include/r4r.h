@@ -529,7 +529,7 @@ int r4r_transnet_nparam(void);
 int r4r_transnet_layout(int E, int L, int plus, int64_t *offsets, int64_t *sizes, int64_t *total);
 size_t r4r_transnet_ws_bytes(int64_t B, int T, int E, int L, int plus, int64_t V, int64_t n_users, int64_t n_items);
 size_t r4r_transnet_ws_offset(int64_t B, int T, int E, int L, int plus, int64_t V, int64_t n_users, int64_t n_items,
-                              int which);   /* 0 dropout multipliers, 1 / 2 ID-vector gradient rows [B,5], 3 aux [B,3], 4 size of the persistent head, 6 + 2*tower + buffer: token counter */
+                              int which);   /* 0 dropout multipliers, 1 / 2 ID-vector gradient rows [B,5], 3 aux [B,3], 4 size of the persistent head, 5 the broken-announcement flag (int), 6 + 2*tower + buffer: token counter */
 int r4r_transnet_step(const float *table, int64_t V,
                       const int64_t *user_idx, const int64_t *item_idx, const int64_t *this_idx,
                       const int64_t *uid, const int64_t *iid, const float *y,
@@ -541,8 +541,30 @@ int r4r_transnet_step(const float *table, int64_t V,
                       float dropout_p, int training, uint64_t seed, uint64_t offset, float inv_denom,
                       int conv_algo, int token_buffer, int tokens_ready,
                       const int64_t *next_user_idx, const int64_t *next_item_idx, const int64_t *next_this_idx,
+                      const int64_t *next_uid, const int64_t *next_iid, int64_t next_B, int sweep_period,
                       float lr, double beta1, double beta2, float eps, float weight_decay, int64_t adam_step,
                       void *stream);
+
+/* The ID-vector sweep, temporally blocked (TransNet++, a training step that updates: flat_m != NULL).
+ * torch.optim.Adam moves EVERY row of user_embedding / item_embedding every step (main.py:94-96: weight decay,
+ * decaying moments), 24 bytes of traffic per element -- but an element no rating of the batch names goes through
+ * the same gradient-zero update whether it is applied now or together with the next few: the update reads nothing
+ * but the element's own (p, m, v) and the step's two bias corrections.  With sweep_period P > 1 and the ids of the
+ * batch the NEXT call will train on (next_uid / next_iid [next_B]), a chunk of 8,192 table elements that neither
+ * this batch nor the next names is visited every P-th step only and then takes all its pending updates at once, in
+ * step order, each with its own step's scalars: the same fp32 operations per element as P = 1, a P-th of the bytes.
+ * Chunks the next batch names are brought up to date by this call, so the next call reads current rows.
+ * Contract: (1) the next call trains on exactly the announced ids, or r4r_transnet_rows_flush runs first (the
+ * sweep sets the int at r4r_transnet_ws_offset(which = 5) if a batch was not the announced one); (2) lr, betas,
+ * eps, weight_decay do not change while updates are pending; (3) r4r_transnet_rows_flush before anything else
+ * reads or writes the tables or their moments (evaluation through r4r_transnet_step included).  A call WITHOUT
+ * next_uid (or with P = 1) applies everything that is pending and leaves nothing behind: the plain dense sweep.
+ * 1 <= P <= 8.  r4r_transnet_rows_flush: adam_step = the last completed step; same `ws` / shapes as the steps. */
+int r4r_transnet_rows_flush(const uint64_t *rows_p, const uint64_t *rows_m, const uint64_t *rows_v,
+                            int64_t n_users, int64_t n_items, void *ws, size_t ws_bytes,
+                            int64_t B, int T, int E, int L, int64_t V,
+                            float lr, double beta1, double beta2, float eps, float weight_decay, int64_t adam_step,
+                            void *stream);
 
 /* Data parallel: call r4r_transnet_step with flat_m == NULL (gradients only: flat_g and, TransNet++,
  * the compact ID-vector rows at r4r_transnet_ws_offset 1 / 2), exchange -- all-reduce flat_g and apply

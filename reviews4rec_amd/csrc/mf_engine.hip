@@ -152,6 +152,7 @@ struct MfSweep {
     int64_t B;
     int D, now;
     int nt = 0;                        // untouched chunks: nontemporal loads / stores (tables far larger than the Infinity Cache)
+    MfTimeBlock tb = MfTimeBlock{};    // temporally blocked sweep (rows_device.h); tb.lag_u == NULL: off
     AdamScalars s;
 };
 
@@ -200,6 +201,69 @@ __device__ __forceinline__ void mf_stream_chunk(float *p, float *m, float *v, in
     if (k < cnt) {
         float P = p[k], M = m[k], V = v[k];
         adam_elem(P, 0.f, M, V, sc);
+        p[k] = P; m[k] = M; v[k] = V;
+    }
+}
+
+// The same stream for a chunk that carries `pend` (1 .. MF_TB_MAX) pending gradient-zero updates: one read and one
+// write of the element, the updates applied in step order with each step's own bias corrections (slot j of the
+// scalar arrays = step now - (MF_TB_MAX - 1 - j); compile-time indices: a run-time index into kernel arguments
+// would send them through scratch).
+template <bool NT>
+__device__ __forceinline__ void mf_stream_chunk_tb(float *p, float *m, float *v, int64_t cnt, int tid, const AdamScalars &sc0,
+                                                   const MfTimeBlock &tb, int pend) {
+    auto ld = [](const float *a, int64_t i) {
+        const mf_f32x4 *q = reinterpret_cast<const mf_f32x4 *>(a) + i;
+        return NT ? __builtin_nontemporal_load(q) : *q;
+    };
+    auto st = [](float *a, int64_t i, mf_f32x4 x) {
+        mf_f32x4 *q = reinterpret_cast<mf_f32x4 *>(a) + i;
+        if (NT) __builtin_nontemporal_store(x, q);
+        else *q = x;
+    };
+    auto upd = [&](mf_f32x4 &P, mf_f32x4 &M, mf_f32x4 &V) {
+#pragma unroll
+        for (int j = 0; j < MF_TB_MAX; ++j) {
+            if (j >= MF_TB_MAX - pend) {                     // uniform
+                AdamScalars sc = sc0;
+                sc.lr_over_bc1 = tb.lr_bc1[j];
+                sc.inv_sqrt_bc2 = tb.isb2[j];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    float pc = P[c], mc = M[c], vc = V[c];
+                    adam_elem(pc, 0.f, mc, vc, sc);
+                    P[c] = pc; M[c] = mc; V[c] = vc;
+                }
+            }
+        }
+    };
+    const int64_t nvec = cnt >> 2;
+    int64_t i = tid;
+    for (; i + MF_THREADS < nvec; i += 2 * MF_THREADS) {
+        const int64_t j = i + MF_THREADS;
+        mf_f32x4 P0 = ld(p, i), P1 = ld(p, j), M0 = ld(m, i), M1 = ld(m, j), V0 = ld(v, i), V1 = ld(v, j);
+        upd(P0, M0, V0);
+        upd(P1, M1, V1);
+        st(p, i, P0); st(m, i, M0); st(v, i, V0);
+        st(p, j, P1); st(m, j, M1); st(v, j, V1);
+    }
+    for (; i < nvec; i += MF_THREADS) {
+        mf_f32x4 P = ld(p, i), M = ld(m, i), V = ld(v, i);
+        upd(P, M, V);
+        st(p, i, P); st(m, i, M); st(v, i, V);
+    }
+    const int64_t k = (nvec << 2) + tid;                    // cnt % 4 elements at the end of a table
+    if (k < cnt) {
+        float P = p[k], M = m[k], V = v[k];
+#pragma unroll
+        for (int j = 0; j < MF_TB_MAX; ++j) {
+            if (j >= MF_TB_MAX - pend) {
+                AdamScalars sc = sc0;
+                sc.lr_over_bc1 = tb.lr_bc1[j];
+                sc.inv_sqrt_bc2 = tb.isb2[j];
+                adam_elem(P, 0.f, M, V, sc);
+            }
+        }
         p[k] = P; m[k] = M; v[k] = V;
     }
 }
@@ -527,7 +591,35 @@ __global__ __launch_bounds__(MF_THREADS) void mf_adam_kernel(MfSweep w) {
     const int *tag = (t == 0 || t == 2) ? w.tag_u : w.tag_i;
     const bool aligned = (((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(m) | reinterpret_cast<uintptr_t>(v)) & 15) == 0);
     const int *ctag = t == 0 ? w.ctag_u : (t == 1 ? w.ctag_i : nullptr);
-    if (ctag && aligned && ctag[bx - cb] != w.now) {
+    if (w.tb.lag_u && t < 2) {
+        // temporally blocked (rows_device.h): is this chunk visited now, and with how many updates?
+        int *lag = t == 0 ? w.tb.lag_u : w.tb.lag_i;
+        const int *ntag = t == 0 ? w.tb.ntag_u : w.tb.ntag_i;
+        const int ci = bx - cb;
+        const int pend = lag[ci] + w.tb.inc;
+        const bool touched = w.tb.inc && ctag[ci] == w.now;
+        // (the phase of a chunk is a hash of its number: "every period-th chunk" is a power-of-two address stride at
+        // periods 4 and 8, which lands on a subset of the HBM channels -- measured: period 4 slower than period 3)
+        const unsigned phase = ((unsigned)ci * 2654435761u) >> 16;
+        const bool due = w.tb.flush || touched || ntag[ci] == w.now || (phase + (unsigned)w.now) % (unsigned)w.tb.period == 0 ||
+                         pend >= MF_TB_MAX;
+        __syncthreads();                                    // every thread has read the lag before thread 0 rewrites it
+        if (!due) {
+            if (tid == 0) lag[ci] = pend;
+            return;
+        }
+        if (tid == 0) {
+            lag[ci] = 0;
+            if (touched && pend != 1) *w.tb.err = 1;        // the batch was not the announced one: its rows were read stale
+        }
+        if (pend == 0) return;
+        if (!touched) {
+            if (w.nt) mf_stream_chunk_tb<true>(p, m, v, cnt, tid, w.s, w.tb, pend);
+            else mf_stream_chunk_tb<false>(p, m, v, cnt, tid, w.s, w.tb, pend);
+            return;
+        }
+        // a chunk this batch names: one pending update (this step's), row by row below
+    } else if (ctag && aligned && ctag[bx - cb] != w.now) {
         // no rating touched a row of this chunk (all but a handful of chunks of a 10^7-row table):
         // stream it -- no row tags, no row / column bookkeeping
         if (w.nt) mf_stream_chunk<true>(p, m, v, cnt, tid, w.s);
@@ -727,6 +819,18 @@ int mf_bias_rows_launch(float *ub, float *ub_m, float *ub_v, float *ib, float *i
     return check_launch("bias rows");
 }
 
+void mf_time_block_scalars(MfTimeBlock &tb, float lr, double beta1, double beta2, float eps, float weight_decay, int64_t now) {
+    for (int j = 0; j < MF_TB_MAX; ++j) {
+        const int64_t step = now - (MF_TB_MAX - 1 - j);
+        tb.lr_bc1[j] = tb.isb2[j] = 0.f;
+        if (step >= 1) {
+            const AdamScalars s = adam_make_scalars(lr, beta1, beta2, eps, weight_decay, step, nullptr);
+            tb.lr_bc1[j] = s.lr_over_bc1;
+            tb.isb2[j] = s.inv_sqrt_bc2;
+        }
+    }
+}
+
 // Adam on two ID tables of width D whose gradient rows are compact ([B, D] per table, one row per
 // rating; TransNet++'s user / item vectors, TransNet.py:75-76): the sweep + entry waves above
 // without bias vectors.  `tag_*`: per-row step tags the caller's forward kernel set to `now`.
@@ -734,12 +838,23 @@ int mf_table_rows_launch(float *ut, float *ut_m, float *ut_v, float *it, float *
                          int64_t n_users, int64_t n_items, int D, const int64_t *uid, const int64_t *iid,
                          const float *gu, const float *gi, const int *tag_u, const int *tag_i,
                          const int *ctag_u, const int *ctag_i, int64_t B, int now,
-                         const AdamScalars &sc, hipStream_t st) {
+                         const AdamScalars &sc, hipStream_t st, const MfTimeBlock *tb) {
     if (B > MF_MAX_B || D < 1 || D > MF_MAX_D) {
         set_error("table rows: batch %lld > %d or width %d outside 1..%d", (long long)B, MF_MAX_B, D, MF_MAX_D);
         return R4R_ERR_ARG;
     }
     MfSweep sw{};
+    if (tb) {
+        const uintptr_t all = reinterpret_cast<uintptr_t>(ut) | reinterpret_cast<uintptr_t>(ut_m) | reinterpret_cast<uintptr_t>(ut_v) |
+                              reinterpret_cast<uintptr_t>(it) | reinterpret_cast<uintptr_t>(it_m) | reinterpret_cast<uintptr_t>(it_v);
+        if (!ctag_u || !ctag_i || !tb->lag_u || !tb->lag_i || !tb->ntag_u || !tb->ntag_i || !tb->err || (all & 15) ||
+            tb->period < 1 || tb->period > MF_TB_MAX) {
+            set_error("table rows: the temporally blocked sweep needs chunk tags, lag / next-tag arrays, 16-byte aligned tables "
+                      "and a period in 1..%d", MF_TB_MAX);
+            return R4R_ERR_ARG;
+        }
+        sw.tb = *tb;
+    }
     sw.p0 = ut; sw.m0 = ut_m; sw.v0 = ut_v; sw.p1 = it; sw.m1 = it_m; sw.v1 = it_v;
     sw.n0 = n_users * D; sw.n1 = n_items * D; sw.n2 = sw.n3 = 0;
     int64_t chunks = cdiv(sw.n0, mf_chunk(0));

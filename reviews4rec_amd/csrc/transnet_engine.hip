@@ -56,6 +56,8 @@ struct TnHead {
     float *part;                                    // [B, NHP]
     float *grow[2];                                 // [B, 5] compact gradient rows of the ID vectors
     int *tag[2], *ctag[2];                          // row tags; sweep-chunk tags (rows_device.h)
+    const int64_t *next_id[2]; int64_t next_B;      // the announced next batch's uid / iid (temporally blocked sweep), or NULL
+    int *ntag[2];                                   // ... and the chunk tags its rows get
     float *mult;                                    // [B, 5L + 10] dropout multipliers (see r4r.h)
     float *pred, *se;                               // source prediction and its SE
     float *aux;                                     // [B, 3]: target prediction, its SE, ||s_ir - t_ir||^2
@@ -277,6 +279,12 @@ __global__ __launch_bounds__(256) void tn_head_kernel(TnHead a) {
                 a.tag[s][r] = a.now;
                 a.ctag[s][r * TN_ID / MF_CHUNK] = a.now;              // (a row can straddle two chunks)
                 a.ctag[s][(r * TN_ID + TN_ID - 1) / MF_CHUNK] = a.now;
+                if (a.next_id[s])                           // the chunks the NEXT batch names are brought up to date by this step's sweep
+                    for (int64_t j = b; j < a.next_B; j += a.B) {
+                        const int64_t q = a.next_id[s][j];
+                        a.ntag[s][q * TN_ID / MF_CHUNK] = a.now;
+                        a.ntag[s][(q * TN_ID + TN_ID - 1) / MF_CHUNK] = a.now;
+                    }
             }
         }
     }
@@ -351,7 +359,7 @@ struct TnWs {
     int *flags[2][3], *slot[2][3], *list[2][3], *count[2][3]; float *ptab[3];
     float *pooled[3]; int *argmax[3]; float *g_pooled[3];
     float *part_w[3], *part_b[3];
-    int *tag[2], *ctag[2];
+    int *tag[2], *ctag[2], *ntag[2], *lag[2], *tb_err;
     float *part, *grow[2], *mult, *aux;
     size_t bytes, persist;
 };
@@ -366,6 +374,12 @@ static TnWs tn_carve(void *ws, int64_t B, int T, int E, int L, int plus, int64_t
     w.tag[1] = reinterpret_cast<int *>(take((size_t)n_items * 4));
     w.ctag[0] = reinterpret_cast<int *>(take((size_t)cdiv(n_users * TN_ID, MF_CHUNK) * 4));
     w.ctag[1] = reinterpret_cast<int *>(take((size_t)cdiv(n_items * TN_ID, MF_CHUNK) * 4));
+    for (int t = 0; t < 2; ++t) {                           // the temporally blocked sweep's state (rows_device.h)
+        const size_t chunks = (size_t)cdiv((t ? n_items : n_users) * TN_ID, MF_CHUNK);
+        w.ntag[t] = reinterpret_cast<int *>(take(chunks * 4));
+        w.lag[t] = reinterpret_cast<int *>(take(chunks * 4));
+    }
+    w.tb_err = reinterpret_cast<int *>(take(4));
     w.persist = o;
     for (int t = 0; t < 3; ++t)
         for (int bf = 0; bf < 2; ++bf) {
@@ -420,12 +434,14 @@ extern "C" size_t r4r_transnet_ws_bytes(int64_t B, int T, int E, int L, int plus
 
 // which: 0 dropout multipliers [B, 5L + 10]; 1 / 2 compact gradient rows of the user / item ID vectors
 // [B, 5]; 3 the per-rating auxiliary outputs [B, 3]; 4 the SIZE of the persistent head of the workspace
-// (row and chunk tags: zero once, carry over when switching buffers); 6 + 2 * tower + buffer: a token
+// (row and chunk tags, the temporally blocked sweep's pending counts: zero once, carry over when switching
+// buffers); 5 the int the sweep sets when a batch was not the announced one; 6 + 2 * tower + buffer: a token
 // buffer's counter (towers 0 user, 1 item, 2 this review)
 extern "C" size_t r4r_transnet_ws_offset(int64_t B, int T, int E, int L, int plus, int64_t V, int64_t n_users,
                                          int64_t n_items, int which) {
     const TnWs w = tn_carve(reinterpret_cast<void *>(256), B, T, E, L, plus, V, n_users, n_items);
     if (which == 4) return w.persist;
+    if (which == 5) return (size_t)(reinterpret_cast<char *>(w.tb_err) - reinterpret_cast<char *>(256));
     if (which >= 6 && which < 12)
         return (size_t)(reinterpret_cast<char *>(w.count[(which - 6) & 1][(which - 6) >> 1]) - reinterpret_cast<char *>(256));
     const char *q = which == 0 ? reinterpret_cast<char *>(w.mult) : which == 1 ? reinterpret_cast<char *>(w.grow[0])
@@ -444,9 +460,12 @@ extern "C" int r4r_transnet_step(const float *table, int64_t V,
                                  float dropout_p, int training, uint64_t seed, uint64_t offset, float inv_denom,
                                  int conv_algo, int token_buffer, int tokens_ready,
                                  const int64_t *next_user_idx, const int64_t *next_item_idx, const int64_t *next_this_idx,
+                                 const int64_t *next_uid, const int64_t *next_iid, int64_t next_B, int sweep_period,
                                  float lr, double beta1, double beta2, float eps, float weight_decay, int64_t adam_step,
                                  void *stream) {
     R4R_REQUIRE(table && user_idx && item_idx && this_idx && flat_p && pred && ws, "transnet_step: null pointer");
+    R4R_REQUIRE(sweep_period >= 1 && sweep_period <= MF_TB_MAX, "transnet_step: sweep_period %d outside 1..%d", sweep_period, MF_TB_MAX);
+    R4R_REQUIRE(!next_uid == !next_iid && (!next_uid || next_B > 0), "transnet_step: next_uid, next_iid and next_B > 0 go together");
     R4R_REQUIRE(!plus || (uid && iid && rows_p), "transnet_step: TransNet++ needs the ids and the ID-vector tables");
     R4R_REQUIRE(V > 0 && B >= 0 && T > 0 && n_users > 0 && n_items > 0, "transnet_step: bad sizes");
     R4R_REQUIRE(L > 0 && L <= NR_MAX_L, "transnet_step: latent_size %d outside 1..%d", L, NR_MAX_L);
@@ -529,6 +548,10 @@ extern "C" int r4r_transnet_step(const float *table, int64_t V,
         h.emb[t] = rp[t]; h.tag[t] = w.tag[t]; h.ctag[t] = w.ctag[t]; h.grow[t] = w.grow[t];
     }
     h.id[0] = uid; h.id[1] = iid; h.flat_p = flat_p;
+    // the announced next batch (training steps that update in this call only: the sweep is what consumes the tags)
+    const bool announce = plus && train_step && apply && next_uid && sweep_period > 1;
+    h.next_id[0] = announce ? next_uid : nullptr; h.next_id[1] = announce ? next_iid : nullptr;
+    h.next_B = announce ? next_B : 0; h.ntag[0] = w.ntag[0]; h.ntag[1] = w.ntag[1];
     for (int i = 0; i < TN_COUNT; ++i) h.off[i] = (int)lay.off[i];
     h.lo = (int)lo;
     h.y = y; h.part = w.part; h.mult = w.mult; h.pred = pred; h.se = se; h.aux = w.aux;
@@ -583,8 +606,45 @@ extern "C" int r4r_transnet_step(const float *table, int64_t V,
     narre_reduce_kernel<<<dim3(red_blocks + comp_blocks + opt_blocks, 3), NRED_THREADS, 0, st>>>(
         wa, red_blocks, comp_blocks, nx, opt);
     if (!plus || !apply) return check_launch("transnet_step");
+    // the ID-vector tables: temporally blocked when the caller announced the next batch's ids, a flush of whatever
+    // earlier steps left pending otherwise (nothing pending: the plain sweep)
+    MfTimeBlock tb{};
+    tb.lag_u = w.lag[0]; tb.lag_i = w.lag[1]; tb.ntag_u = w.ntag[0]; tb.ntag_i = w.ntag[1]; tb.err = w.tb_err;
+    tb.period = announce ? sweep_period : 1; tb.flush = announce ? 0 : 1; tb.inc = 1;
+    mf_time_block_scalars(tb, lr, beta1, beta2, eps, weight_decay, adam_step);
     return mf_table_rows_launch(rp[0], rm[0], rv[0], rp[1], rm[1], rv[1], n_users, n_items, TN_ID, uid, iid, w.grow[0], w.grow[1],
-                                w.tag[0], w.tag[1], w.ctag[0], w.ctag[1], B, (int)adam_step, opt.s, st);
+                                w.tag[0], w.tag[1], w.ctag[0], w.ctag[1], B, (int)adam_step, opt.s, st, &tb);
+}
+
+// What the temporally blocked sweep left pending (r4r_transnet_step with next_uid and sweep_period > 1): every chunk
+// of the two ID-vector tables takes its pending updates now.  adam_step = the LAST COMPLETED step; same optimiser
+// scalars as the steps that deferred; `ws` and the shape arguments are the step's.
+extern "C" int r4r_transnet_rows_flush(const uint64_t *rows_p, const uint64_t *rows_m, const uint64_t *rows_v,
+                                       int64_t n_users, int64_t n_items, void *ws, size_t ws_bytes,
+                                       int64_t B, int T, int E, int L, int64_t V,
+                                       float lr, double beta1, double beta2, float eps, float weight_decay, int64_t adam_step,
+                                       void *stream) {
+    R4R_REQUIRE(rows_p && rows_m && rows_v && ws, "transnet_rows_flush: null pointer");
+    R4R_REQUIRE(adam_step >= 0 && adam_step < (1ll << 31), "transnet_rows_flush: bad adam_step");
+    if (ws_bytes < r4r_transnet_ws_bytes(B, T, E, L, 1, V, n_users, n_items)) {
+        set_error("transnet_rows_flush: workspace %zu < %zu bytes", ws_bytes, r4r_transnet_ws_bytes(B, T, E, L, 1, V, n_users, n_items));
+        return R4R_ERR_WORKSPACE;
+    }
+    if (adam_step == 0) return R4R_OK;                      // no step yet: nothing can be pending
+    const TnWs w = tn_carve(ws, B, T, E, L, 1, V, n_users, n_items);
+    float *rp[2], *rm[2], *rv[2];
+    for (int t = 0; t < 2; ++t) {
+        rp[t] = reinterpret_cast<float *>(rows_p[t]); rm[t] = reinterpret_cast<float *>(rows_m[t]);
+        rv[t] = reinterpret_cast<float *>(rows_v[t]);
+        R4R_REQUIRE(rp[t] && rm[t] && rv[t], "transnet_rows_flush: ID-vector table %d: null pointer", t);
+    }
+    MfTimeBlock tb{};
+    tb.lag_u = w.lag[0]; tb.lag_i = w.lag[1]; tb.ntag_u = w.ntag[0]; tb.ntag_i = w.ntag[1]; tb.err = w.tb_err;
+    tb.period = 1; tb.flush = 1; tb.inc = 0;
+    mf_time_block_scalars(tb, lr, beta1, beta2, eps, weight_decay, adam_step);
+    const AdamScalars sc = adam_make_scalars(lr, beta1, beta2, eps, weight_decay, adam_step, nullptr);
+    return mf_table_rows_launch(rp[0], rm[0], rv[0], rp[1], rm[1], rv[1], n_users, n_items, TN_ID, nullptr, nullptr, nullptr, nullptr,
+                                w.tag[0], w.tag[1], w.ctag[0], w.ctag[1], 0, (int)adam_step, sc, as_stream(stream), &tb);
 }
 
 // Data parallel, TransNet++: the ID-vector update from ALL ranks' compact rows (gathered by the

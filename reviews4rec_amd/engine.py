@@ -1120,10 +1120,15 @@ class TransNetEngine(NarreEngine):
     NTOWER = 3
     SSE_SLOTS = 3
 
+    TEMPORAL_SWEEP = True        # train_step(..., defer_sweep=True) + flush(): the ID-vector sweep, temporally blocked
+
     def __init__(self, model, dp=None, **kw):
         if dp is not None and dp.on:
             self.dp = dp
         self.plus = int(model.hyper_params['model_type'] == 'transnet++')
+        # visit period of the temporally blocked ID-vector sweep (include/r4r.h; 1 = the plain dense sweep)
+        self.sweep_period = max(1, min(8, int(os.environ.get('R4R_SWEEP_PERIOD', model.hyper_params.get('sweep_period', 4)))))
+        self._tb_promised, self._tb_next, self._defer_req = None, None, False
         if not self.plus:
             self.DP_COLS = 0                                 # plain TransNet: no ID rows to exchange
         self.ROW_NAMES = ['user_embedding.weight', 'item_embedding.weight'] if self.plus else []
@@ -1161,8 +1166,76 @@ class TransNetEngine(NarreEngine):
     def _draws(self, R):
         return 5 * self.L + 10
 
+    # ---- the temporally blocked sweep (TransNet++, single process).  A step that was told `defer_sweep=True` and the
+    # next batch leaves gradient-zero updates of untouched table chunks pending; whatever is not the announced next
+    # training step flushes them first, so that nothing ever reads a table that is behind.
+    def _tb_key(self, f, n):
+        return (f[3].data_ptr(), f[4].data_ptr(), n)
+
+    def _launch(self, data, y, train_mode, inv_denom, adam_step, next_data=None):
+        if self._tb_promised is not None:
+            f, n, _, _ = self._fields(data)
+            if not adam_step or self._tb_key(f, n) != self._tb_promised[0]:
+                self.flush()
+        self._tb_next = None
+        if (self._defer_req and adam_step and self.plus and self.dp is None and next_data is not None
+                and self.sweep_period > 1 and next_data[5].numel() > 0):
+            nf, nn, _, _ = self._fields(next_data)
+            self._tb_next = (nf[3], nf[4], nn)
+        self._tb_promised = None
+        out = super()._launch(data, y, train_mode, inv_denom, adam_step, next_data)
+        if self._tb_next is not None:                        # (the id tensors stay referenced until the promise is kept)
+            self._tb_promised = (self._tb_key([None] * 3 + list(self._tb_next[:2]), self._tb_next[2]), self._tb_next)
+        return out
+
+    @torch.no_grad()
+    def train_step(self, data, y, n_global=None, next_data=None, defer_sweep=False):
+        """defer_sweep: with `next_data`, TransNet++'s ID-vector sweep is temporally blocked (chunks neither batch
+        names are visited every `sweep_period`-th step and take their pending updates together: same bits, a
+        fraction of the traffic).  The caller promises that the next call trains on `next_data`; any other call
+        (and `flush()`, `state_dict()`, `predict()`) brings the tables up to date first.  Code that reads the
+        embedding Parameters directly calls `flush()` before."""
+        self._defer_req = bool(defer_sweep)
+        try:
+            return super().train_step(data, y, n_global, next_data)
+        finally:
+            self._defer_req = False
+
+    def flush(self, check=True):
+        """Apply every pending ID-vector update (no-op when nothing is pending)."""
+        if self._tb_promised is None:
+            return
+        self._tb_promised = None
+        B, R, T = self._ws_key
+        p2 = lambda ts: (ctypes.c_uint64 * 2)(*[t.data_ptr() for t in ts])   # noqa: E731
+        _lib.check(_lib.lib().r4r_transnet_rows_flush(
+            p2(self.rows), p2(self.rows_m), p2(self.rows_v), self.n_users, self.n_items, ptr(self._ws), self._ws.numel(),
+            B, T, self.E, self.L, self.V, self.lr, self.betas[0], self.betas[1], self.eps, self.wd, int(self.step_count),
+            _lib.current_stream()), 'r4r_transnet_rows_flush')
+        if check:
+            self.check_announcements()
+
+    def check_announcements(self):
+        """Raise if a step trained on a batch other than the announced one while updates were pending (its rows
+        were read before they were brought up to date).  Reads one int from the device."""
+        if not self.plus or self._ws is None:
+            return
+        B, R, T = self._ws_key
+        off = self._ws_offset(B, R, T, 5)
+        if int(self._ws[off:off + 4].view(torch.int32).item()):
+            raise RuntimeError('TransNetEngine: a deferred ID-vector sweep met a batch that was not the announced one')
+
+    def moments(self):
+        self.flush()
+        return super().moments()
+
+    def load_state_dict(self, sd):
+        self._tb_promised = None                             # (the workspaces are zeroed: nothing pending any more)
+        super().load_state_dict(sd)
+
     def _step(self, f, y, pred, se, ws, n, R, T, train_mode, inv_denom, adam_step, buf, ready, nxt):
         p2 = lambda ts: (ctypes.c_uint64 * 2)(*[t.data_ptr() for t in ts]) if ts else None   # noqa: E731
+        tbn = self._tb_next
         return _lib.lib().r4r_transnet_step(
             ptr(self.table), self.V, ptr(f[0]), ptr(f[1]), ptr(f[2]), ptr(f[3]), ptr(f[4]), ptr(y),
             ptr(self.flat_p), ptr(self.flat_g) if adam_step else None,
@@ -1174,6 +1247,7 @@ class TransNetEngine(NarreEngine):
             ptr(ws), ws.numel(), n, T, self.E, self.L, self.plus, float(self.hp['dropout']), int(train_mode), self.seed,
             self.offset, float(inv_denom), self._algo_req, buf, ready,
             ptr(nxt[0]) if nxt else None, ptr(nxt[1]) if nxt else None, ptr(nxt[2]) if nxt else None,
+            ptr(tbn[0]) if tbn else None, ptr(tbn[1]) if tbn else None, tbn[2] if tbn else 0, self.sweep_period,
             self.lr, self.betas[0], self.betas[1], self.eps, self.wd, int(adam_step), _lib.current_stream())
 
     DP_COLS = 10

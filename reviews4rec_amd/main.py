@@ -85,7 +85,11 @@ def train(model, criterion, optimizer, reader, hyper_params, engine=None, dp=Non
         else:                                                 # a reader that cannot say its batch sizes up front
             n_global = dp.global_count(n_local, y.device)
         if engine is not None:
-            engine.train_step(data, y, n_global=n_global, next_data=upcoming[0] if upcoming is not None else None)
+            nxt = upcoming[0] if upcoming is not None else None
+            if getattr(engine, 'TEMPORAL_SWEEP', False):       # TransNet++: untouched table chunks take their updates every
+                engine.train_step(data, y, n_global=n_global, next_data=nxt, defer_sweep=True)   # few steps, together
+            else:
+                engine.train_step(data, y, n_global=n_global, next_data=nxt)
             total_x += float(n_local)
             total_batches += 1
             continue

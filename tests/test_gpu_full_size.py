@@ -250,3 +250,90 @@ def test_headline_batches_on_both_sides_of_the_resident_plans_edge():
     for i in range(len(batches)):
         assert torch.equal(out[1, i][0], out[3, i][0]), i
         assert torch.equal(out[1, i][1], out[3, i][1]), i
+
+
+def _transnetpp_pair(hp, V, seed, n=2):
+    import reviews4rec_amd
+    from reviews4rec_amd.engine import TransNetEngine
+    P = oracle.init_params(hp, vocab_size=V, seed=seed)
+    out = []
+    for _ in range(n):
+        model = reviews4rec_amd.get_model_class('transnet++')(dict(hp, word_vectors=P['target.word2vec.weight'].numpy()))
+        model.load_state_dict(P)
+        model = model.to(DEV).train()
+        out.append((model, TransNetEngine(model, lr=hp['lr'], weight_decay=hp['weight_decay'], seed=5)))
+    return out
+
+
+def _same_bits(a, b, what):
+    sa, sb = a[0].state_dict(), b[0].state_dict()
+    for k in sa:
+        assert torch.equal(sa[k], sb[k]), '%s: parameter %s differs' % (what, k)
+    (ma, va), (mb, vb) = a[1].moments(), b[1].moments()
+    for k in ma:
+        assert torch.equal(ma[k], mb[k]) and torch.equal(va[k], vb[k]), '%s: moments of %s differ' % (what, k)
+
+
+@pytest.mark.parametrize('period', [2, 4, 8])
+def test_temporally_blocked_sweep_is_the_dense_sweep_bit_for_bit(period, monkeypatch):
+    """TransNet++'s ID-vector Adam with untouched chunks visited every `period`-th step (their pending gradient-zero
+    updates applied together, include/r4r.h) against the plain sweep that visits every element every step: 13
+    training steps over tables of 13 + 4 chunks, dropout on, a ragged batch, an announcement that is NOT kept (the
+    engine flushes), an evaluation in the middle -- every parameter and both Adam moments identical to the bit."""
+    from reviews4rec_amd import synthetic
+    monkeypatch.setenv('R4R_SWEEP_PERIOD', str(period))
+    hp = dict(synthetic.hyper_params_for('cfg5_transnetpp_synthetic', dropout=0.5), total_users=21000, total_items=6000,
+              input_length=60, vocab=3000)
+    plain, blocked = _transnetpp_pair(hp, hp['vocab'], seed=3)
+    assert blocked[1].sweep_period == period
+    gen = synthetic.Generator(hp, seed=11)
+    pool = []
+    for k in range(6):
+        data, y = gen.batch(32 if k != 4 else 19)
+        pool.append(([torch.from_numpy(d).to(DEV) for d in data], torch.from_numpy(y).to(DEV)))
+    pool[2][0][5][:4] = 20999                                # the last chunk of the user table, a row named four times
+    order = [0, 1, 2, 3, 4, 5, 0, 2, 4, 1, 3, 5, 0]
+    for s, k in enumerate(order):
+        nxt = pool[order[s + 1]][0] if s + 1 < len(order) else None
+        announced = pool[5][0] if s == 6 else nxt            # step 6 announces batch 5, step 7 trains on batch 2
+        plain[1].train_step(*pool[k], next_data=nxt)
+        blocked[1].train_step(*pool[k], next_data=announced, defer_sweep=True)
+        if s == 3:                                           # an evaluation between two steps flushes first
+            pa, pb = plain[1].predict(pool[1][0])[0], blocked[1].predict(pool[1][0])[0]
+            assert torch.equal(pa, pb)
+        if s in (1, 8):                                      # an announcement is outstanding: updates may be pending
+            assert blocked[1]._tb_promised is not None
+        if s == 8 and period == 8:                           # ... and are: the tables are behind until the flush
+            assert not torch.equal(plain[0].user_embedding.weight, blocked[0].user_embedding.weight)
+    assert blocked[1]._tb_promised is None                   # the last step announced nothing: it flushed itself
+    blocked[1].check_announcements()
+    _same_bits(plain, blocked, 'period %d' % period)
+    if period < 8:
+        return
+    # a promise broken behind the engine's back is detected by the sweep itself: a batch that names a row in every
+    # chunk of the user table arrives unannounced while most chunks are a step behind
+    blocked[1].train_step(*pool[0], next_data=pool[1][0], defer_sweep=True)
+    pool[3][0][5][:13] = torch.arange(13, device=DEV) * 1639
+    blocked[1]._tb_promised = (blocked[1]._tb_key(blocked[1]._fields(pool[3][0])[0], 32), blocked[1]._tb_promised[1])
+    blocked[1].train_step(*pool[3], next_data=None, defer_sweep=True)
+    with pytest.raises(RuntimeError, match='not the announced one'):
+        blocked[1].check_announcements()
+
+
+def test_temporally_blocked_sweep_at_cfg5_cardinalities():
+    """The same equality on cfg5's own tables (10 M x 5 + 1 M x 5: 6,714 chunks), six steps at the default period,
+    the flush as its own launch (the way bench.py ends its timed region)."""
+    from reviews4rec_amd import synthetic
+    hp = dict(synthetic.hyper_params_for('cfg5_transnetpp_synthetic', dropout=0.0), input_length=100, vocab=5000)
+    plain, blocked = _transnetpp_pair(hp, hp['vocab'], seed=19)
+    gen = synthetic.Generator(hp, seed=23)
+    pool = []
+    for _ in range(4):
+        data, y = gen.batch(128)
+        pool.append(([torch.from_numpy(d).to(DEV) for d in data], torch.from_numpy(y).to(DEV)))
+    for s in range(6):
+        plain[1].train_step(*pool[s % 4], next_data=pool[(s + 1) % 4][0])
+        blocked[1].train_step(*pool[s % 4], next_data=pool[(s + 1) % 4][0], defer_sweep=True)
+    assert blocked[1]._tb_promised is not None
+    blocked[1].flush()
+    _same_bits(plain, blocked, 'cfg5 tables')
