@@ -526,10 +526,11 @@ def main():
                        'engine': 'native' if engine is not None else ('graph' if graphed is not None else 'module'),
                        'conv_algo': args.conv_algo, 'gemm_math': args.gemm_math, 'doc_fill': args.doc_fill,
                        'token_dist': args.token_dist,
-                       **({'id_vector_sweep': 'temporally blocked: chunks neither this batch nor the announced next one names are '
+                       **({'table_sweep': 'temporally blocked: chunks neither this batch nor the announced next one names are '
                                               'visited every %d-th step and take their pending Adam updates together (same bits as the '
                                               'dense sweep, tests/test_gpu_full_size.py); flushed inside the timed region' % engine.sweep_period}
-                          if getattr(engine, 'TEMPORAL_SWEEP', False) and getattr(engine, 'plus', 0) and not dp_job
+                          if getattr(engine, 'TEMPORAL_SWEEP', False) and not dp_job
+                          and (getattr(engine, 'plus', 0) or getattr(engine, 'has_tables', False))
                           and engine.sweep_period > 1 and args.token_prefetch == 'fused' else {}),
                        **({'rccl_ranks': world, 'dist_backend': torch.distributed.get_backend(),
                            # True: the collectives ran on the step's own stream through the package's communicator

@@ -388,8 +388,22 @@ int r4r_mf_step(const int64_t *uid, const int64_t *iid, const float *y,
                 int64_t n_users, int64_t n_items, int D,
                 float *pred, float *se, float *sse_accum, void *ws, size_t ws_bytes, int64_t B,
                 float dropout_p, int training, uint64_t seed, uint64_t offset, float inv_denom,
+                const int64_t *next_uid, const int64_t *next_iid, int64_t next_B, int sweep_period,
                 float lr, double beta1, double beta2, float eps, float weight_decay, int64_t adam_step,
                 void *stream);
+
+/* next_uid / next_iid [next_B] + sweep_period P in 2..8: the Adam sweep over the two ID tables, temporally blocked
+ * (the contract is spelled out at r4r_transnet_rows_flush below: chunks of 8,192 table elements that neither this
+ * batch nor the announced next batch names are visited every P-th step and take their pending gradient-zero
+ * updates together -- the same fp32 operations per element, a fraction of the traffic; the caller trains on exactly
+ * the announced ids next, keeps the optimiser scalars unchanged meanwhile, and calls r4r_mf_rows_flush before
+ * anything else reads the tables).  Without next_uid, or with P = 1, the call applies everything that is pending:
+ * the plain dense sweep.  r4r_mf_ws_flag_offset: the int the sweep sets when a batch was not the announced one. */
+int r4r_mf_rows_flush(const uint64_t *p, const uint64_t *m, const uint64_t *v,
+                      int64_t n_users, int64_t n_items, int D, void *ws, size_t ws_bytes, int64_t B,
+                      float lr, double beta1, double beta2, float eps, float weight_decay, int64_t adam_step,
+                      void *stream);
+size_t r4r_mf_ws_flag_offset(int64_t B, int D, int64_t n_users, int64_t n_items);
 
 /* ---- MF under data parallelism: one process per GPU, replicated tables.
  * r4r_mf_grad: this rank's forward + compact gradient rows into one packed `block`

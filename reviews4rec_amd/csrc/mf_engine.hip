@@ -54,6 +54,10 @@ struct MfStep {
     unsigned long long *first_u, *first_i;   // [U+1], [I+1]: mf_first_pack of the row's first rating
     unsigned long long *last_u, *last_i;     // [U+1], [I+1]: (step << 32 | the row's last rating)
     int *uid32, *iid32;                      // [B] compact copies of the ids
+    int *ctag_u = nullptr, *ctag_i = nullptr;       // per sweep chunk of the tables: the last step that touched a row in it
+    const int64_t *next_uid = nullptr, *next_iid = nullptr;   // the announced next batch (temporally blocked sweep) ...
+    int64_t next_B = 0;
+    int *ntag_u = nullptr, *ntag_i = nullptr;       // ... and the chunk tags its rows get
     float *pred, *se, *sse_accum;
     int64_t B;
     int64_t B_pad = 0;                 // data parallel: rows [B, B_pad) of the entry arrays are filled as padding (id -1)
@@ -113,6 +117,16 @@ __global__ __launch_bounds__(256) void mf_fwd_bwd_kernel(MfStep a) {
             const unsigned long long lastv = ((unsigned long long)(unsigned)a.tag << 32) | (unsigned long long)b;
             atomicMax(a.last_u + u, lastv);
             atomicMax(a.last_i + i, lastv);
+            if (a.ctag_u && D > 0) {                        // chunk tags (a row may straddle two chunks)
+                a.ctag_u[u * D / MF_CHUNK] = a.tag; a.ctag_u[(u * D + D - 1) / MF_CHUNK] = a.tag;
+                a.ctag_i[i * D / MF_CHUNK] = a.tag; a.ctag_i[(i * D + D - 1) / MF_CHUNK] = a.tag;
+                if (a.next_uid)                             // the chunks the NEXT batch names are brought up to date by this step's sweep
+                    for (int64_t j = b; j < a.next_B; j += a.B) {
+                        const int64_t nu = a.next_uid[j], ni = a.next_iid[j];
+                        a.ntag_u[nu * D / MF_CHUNK] = a.tag; a.ntag_u[(nu * D + D - 1) / MF_CHUNK] = a.tag;
+                        a.ntag_i[ni * D / MF_CHUNK] = a.tag; a.ntag_i[(ni * D + D - 1) / MF_CHUNK] = a.tag;
+                    }
+            }
         }
         a.uid32[b] = (int)u;
         a.iid32[b] = (int)i;
@@ -760,6 +774,7 @@ struct MfWs {
     int *tag_u, *tag_i;
     unsigned long long *first_u, *first_i, *last_u, *last_i;
     int *uid32, *iid32;
+    int *ctag_u, *ctag_i, *ntag_u, *ntag_i, *lag_u, *lag_i, *tb_err;   // the temporally blocked sweep's state (rows_device.h)
     size_t bytes, persist;             // persist: the head of the buffer that carries state across steps
 };
 
@@ -776,6 +791,11 @@ static MfWs mf_carve(void *ws, int64_t B, int D, int64_t n_users, int64_t n_item
     w.first_i = reinterpret_cast<unsigned long long *>(take((size_t)n_items * 8));
     w.last_u = reinterpret_cast<unsigned long long *>(take((size_t)n_users * 8));
     w.last_i = reinterpret_cast<unsigned long long *>(take((size_t)n_items * 8));
+    const size_t cu = (size_t)cdiv(n_users * (int64_t)D, MF_CHUNK), ci = (size_t)cdiv(n_items * (int64_t)D, MF_CHUNK);
+    w.ctag_u = reinterpret_cast<int *>(take(cu * 4)); w.ctag_i = reinterpret_cast<int *>(take(ci * 4));
+    w.ntag_u = reinterpret_cast<int *>(take(cu * 4)); w.ntag_i = reinterpret_cast<int *>(take(ci * 4));
+    w.lag_u = reinterpret_cast<int *>(take(cu * 4)); w.lag_i = reinterpret_cast<int *>(take(ci * 4));
+    w.tb_err = reinterpret_cast<int *>(take(4));
     w.persist = o;
     w.uid32 = reinterpret_cast<int *>(take((size_t)B * 4));
     w.iid32 = reinterpret_cast<int *>(take((size_t)B * 4));
@@ -950,9 +970,12 @@ extern "C" int r4r_mf_step(const int64_t *uid, const int64_t *iid, const float *
                            int64_t n_users, int64_t n_items, int D,
                            float *pred, float *se, float *sse_accum, void *ws, size_t ws_bytes, int64_t B,
                            float dropout_p, int training, uint64_t seed, uint64_t offset, float inv_denom,
+                           const int64_t *next_uid, const int64_t *next_iid, int64_t next_B, int sweep_period,
                            float lr, double beta1, double beta2, float eps, float weight_decay, int64_t adam_step,
                            void *stream) {
     R4R_REQUIRE(uid && iid && p && pred && ws, "mf_step: null pointer");
+    R4R_REQUIRE(sweep_period >= 1 && sweep_period <= MF_TB_MAX, "mf_step: sweep_period %d outside 1..%d", sweep_period, MF_TB_MAX);
+    R4R_REQUIRE(!next_uid == !next_iid && (!next_uid || next_B > 0), "mf_step: next_uid, next_iid and next_B > 0 go together");
     R4R_REQUIRE(n_users > 0 && n_items > 0 && B >= 0, "mf_step: bad sizes");
     R4R_REQUIRE(D >= 0 && D <= MF_MAX_D, "mf_step: latent_size %d outside 0..%d", D, MF_MAX_D);
     R4R_REQUIRE(!m == !v, "mf_step: m and v go together");
@@ -991,6 +1014,13 @@ extern "C" int r4r_mf_step(const int64_t *uid, const int64_t *iid, const float *
     a.pred = pred; a.se = se; a.sse_accum = sse_accum;
     a.B = B; a.D = D; a.training = training; a.want_grad = m != nullptr; a.tag = (int)adam_step;
     a.p_drop = dropout_p; a.inv_denom = inv_denom; a.seed = seed; a.offset = offset;
+    // the temporally blocked sweep (rows_device.h) applies to 16-byte aligned tables; without it the chunk tags stay unused
+    const bool tb_on = m && D > 0 && (((p[0] | p[1] | m[0] | m[1] | v[0] | v[1]) & 15) == 0);
+    const bool announce = tb_on && next_uid && sweep_period > 1;
+    if (tb_on) {
+        a.ctag_u = w.ctag_u; a.ctag_i = w.ctag_i; a.ntag_u = w.ntag_u; a.ntag_i = w.ntag_i;
+        if (announce) { a.next_uid = next_uid; a.next_iid = next_iid; a.next_B = next_B; }
+    }
     mf_fwd_bwd_kernel<<<(unsigned)cdiv(B, 4), 256, 0, st>>>(a);
     if (!m) return check_launch("mf_step(forward)");
     MfSweep sw;
@@ -1018,6 +1048,13 @@ extern "C" int r4r_mf_step(const int64_t *uid, const int64_t *iid, const float *
     sw.uid = uid; sw.iid = iid; sw.gu = w.gu; sw.gi = w.gi; sw.g = w.g; sw.se = se; sw.sse_accum = sse_accum;
     sw.tag_u = w.tag_u; sw.tag_i = w.tag_i; sw.B = B; sw.D = D; sw.now = (int)adam_step;
     sw.s = adam_make_scalars(lr, beta1, beta2, eps, weight_decay, adam_step, nullptr);
+    if (tb_on) {
+        sw.ctag_u = w.ctag_u; sw.ctag_i = w.ctag_i;
+        sw.tb.lag_u = w.lag_u; sw.tb.lag_i = w.lag_i; sw.tb.ntag_u = w.ntag_u; sw.tb.ntag_i = w.ntag_i; sw.tb.err = w.tb_err;
+        sw.tb.period = announce ? sweep_period : 1; sw.tb.flush = announce ? 0 : 1; sw.tb.inc = 1;
+        mf_time_block_scalars(sw.tb, lr, beta1, beta2, eps, weight_decay, adam_step);
+        sw.nt = mf_sweep_nt(sw.n0 + sw.n1);
+    }
     {
         ScopedTiming tm(R4R_TIMING_ADAM, st);
         // more loads in flight per entry wave (and fewer waves per SIMD: 156 vs 116 VGPRs) once rows can
@@ -1026,6 +1063,39 @@ extern "C" int r4r_mf_step(const int64_t *uid, const int64_t *iid, const float *
         else mf_adam_kernel<4><<<(unsigned)chunks, MF_THREADS, 0, st>>>(sw);
     }
     return check_launch("mf_step");
+}
+
+// What the temporally blocked sweep left pending (r4r_mf_step with next_uid and sweep_period > 1): every chunk of the
+// two ID tables takes its pending updates now.  adam_step = the LAST COMPLETED step.
+extern "C" int r4r_mf_rows_flush(const uint64_t *p, const uint64_t *m, const uint64_t *v,
+                                 int64_t n_users, int64_t n_items, int D, void *ws, size_t ws_bytes, int64_t B,
+                                 float lr, double beta1, double beta2, float eps, float weight_decay, int64_t adam_step,
+                                 void *stream) {
+    R4R_REQUIRE(p && m && v && ws, "mf_rows_flush: null pointer");
+    R4R_REQUIRE(n_users > 0 && n_items > 0 && B >= 0 && D >= 0 && D <= MF_MAX_D, "mf_rows_flush: bad sizes");
+    R4R_REQUIRE(adam_step >= 0 && adam_step < (1ll << 31), "mf_rows_flush: bad adam_step");
+    if (ws_bytes < r4r_mf_ws_bytes(B, D, n_users, n_items)) {
+        set_error("mf_rows_flush: workspace %zu < %zu bytes", ws_bytes, r4r_mf_ws_bytes(B, D, n_users, n_items));
+        return R4R_ERR_WORKSPACE;
+    }
+    if (adam_step == 0 || D == 0) return R4R_OK;            // no step yet / no tables: nothing can be pending
+    for (int k = 0; k < 2; ++k) R4R_REQUIRE(p[k] && m[k] && v[k], "mf_rows_flush: table %d: null pointer", k);
+    if ((p[0] | p[1] | m[0] | m[1] | v[0] | v[1]) & 15) return R4R_OK;   // (unaligned tables never defer)
+    const MfWs w = mf_carve(ws, B, D, n_users, n_items);
+    MfTimeBlock tb{};
+    tb.lag_u = w.lag_u; tb.lag_i = w.lag_i; tb.ntag_u = w.ntag_u; tb.ntag_i = w.ntag_i; tb.err = w.tb_err;
+    tb.period = 1; tb.flush = 1; tb.inc = 0;
+    mf_time_block_scalars(tb, lr, beta1, beta2, eps, weight_decay, adam_step);
+    const AdamScalars sc = adam_make_scalars(lr, beta1, beta2, eps, weight_decay, adam_step, nullptr);
+    auto f = [](uint64_t x) { return reinterpret_cast<float *>(x); };
+    return mf_table_rows_launch(f(p[0]), f(m[0]), f(v[0]), f(p[1]), f(m[1]), f(v[1]), n_users, n_items, D, nullptr, nullptr,
+                                nullptr, nullptr, w.tag_u, w.tag_i, w.ctag_u, w.ctag_i, 0, (int)adam_step, sc, as_stream(stream), &tb);
+}
+
+// offset of the int the temporally blocked sweep sets when a batch was not the announced one
+extern "C" size_t r4r_mf_ws_flag_offset(int64_t B, int D, int64_t n_users, int64_t n_items) {
+    const MfWs w = mf_carve(reinterpret_cast<void *>(256), B, D, n_users, n_items);
+    return (size_t)(reinterpret_cast<char *>(w.tb_err) - reinterpret_cast<char *>(256));
 }
 
 // ------------------------------------------------------------------ data parallel

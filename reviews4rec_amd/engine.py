@@ -506,9 +506,36 @@ class MFEngine:
         self.seed = (int(seed) * 0x9E3779B97F4A7C15 + int(rank) * 0xD1B54A32D192ED03) & 0xFFFFFFFFFFFFFFFF
         self.offset = 0
         self._ws, self._ws_B, self._out = None, None, {}
+        # visit period of the temporally blocked table sweep (include/r4r.h; 1 = the plain dense sweep)
+        self.sweep_period = max(1, min(8, int(os.environ.get('R4R_SWEEP_PERIOD', hp.get('sweep_period', 3)))))   # (cfg2: 3 measured best)
+        self._tb_promised, self._tb_next = None, None
+
+    TEMPORAL_SWEEP = True        # train_step(..., defer_sweep=True) + flush(): the table sweep, temporally blocked
 
     def _ptrs(self, tensors):
         return (ctypes.c_uint64 * 5)(*[0 if t is None else t.data_ptr() for t in tensors])
+
+    def flush(self, check=True, last_step=None):
+        """Apply every pending table update of the temporally blocked sweep (no-op when nothing is pending).
+        last_step: the last COMPLETED step (default: step_count; a training step that finds a broken announcement
+        has already counted itself)."""
+        if self._tb_promised is None:
+            return
+        self._tb_promised = None
+        _lib.check(_lib.lib().r4r_mf_rows_flush(
+            self._ptrs(self.params), self._ptrs(self.m), self._ptrs(self.v), self.n_users, self.n_items, self.D,
+            ptr(self._ws), self._ws.numel(), self._ws_B, self.lr, self.betas[0], self.betas[1], self.eps, self.wd,
+            int(self.step_count if last_step is None else last_step), _lib.current_stream()), 'r4r_mf_rows_flush')
+        if check:
+            self.check_announcements()
+
+    def check_announcements(self):
+        """Raise if a step trained on a batch other than the announced one while updates were pending."""
+        if self._ws is None or not self.has_tables:
+            return
+        off = _lib.lib().r4r_mf_ws_flag_offset(self._ws_B, self.D, self.n_users, self.n_items)
+        if int(self._ws[off:off + 4].view(torch.int32).item()):
+            raise RuntimeError('MFEngine: a deferred table sweep met a batch that was not the announced one')
 
     def _workspace(self, B):
         """One workspace per batch size (the ragged last batch alternates with the full ones); the
@@ -525,12 +552,18 @@ class MFEngine:
             self._ws, self._ws_B = nxt, B
         return self._ws
 
-    def _launch(self, data, y, train_mode, inv_denom, adam_step):
+    def _launch(self, data, y, train_mode, inv_denom, adam_step, next_data=None):
         uid, iid = data[5].reshape(-1), data[6].reshape(-1)
         if not (uid.is_cuda and uid.dtype == torch.int64):
             raise RuntimeError('MFEngine: batches must be int64 tensors on the ROCm device')
         uid, iid = uid.contiguous(), iid.contiguous()
         n = uid.numel()
+        if self._tb_promised is not None and (not adam_step or (uid.data_ptr(), iid.data_ptr(), n) != self._tb_promised[0]):
+            self.flush(last_step=adam_step - 1 if adam_step else None)   # not the announced training step: the tables catch up first
+        self._tb_promised, tbn = None, None
+        if next_data is not None and adam_step and self.has_tables and self.sweep_period > 1 and next_data[5].numel() > 0:
+            nu, ni = next_data[5].reshape(-1).contiguous(), next_data[6].reshape(-1).contiguous()
+            tbn = (nu, ni, nu.numel())
         if n not in self._out:
             self._out[n] = (torch.empty(n, dtype=torch.float32, device=self.dev),
                             torch.empty(n, dtype=torch.float32, device=self.dev))
@@ -541,9 +574,12 @@ class MFEngine:
             self._ptrs(self.m) if adam_step else None, self._ptrs(self.v) if adam_step else None,
             self.n_users, self.n_items, self.D, ptr(pred), ptr(se), ptr(self.sse) if adam_step else None,
             ptr(ws), ws.numel(), n, float(self.hp['dropout']), int(train_mode), self.seed, self.offset,
-            float(inv_denom), self.lr, self.betas[0], self.betas[1], self.eps, self.wd, int(adam_step),
+            float(inv_denom), ptr(tbn[0]) if tbn else None, ptr(tbn[1]) if tbn else None, tbn[2] if tbn else 0,
+            self.sweep_period, self.lr, self.betas[0], self.betas[1], self.eps, self.wd, int(adam_step),
             _lib.current_stream())
         _lib.check(rc, 'r4r_mf_step')
+        if tbn is not None:                                  # (the id tensors stay referenced until the promise is kept)
+            self._tb_promised = ((tbn[0].data_ptr(), tbn[1].data_ptr(), tbn[2]), tbn)
         if train_mode and float(self.hp['dropout']) > 0.0:
             self.offset += n * 2 * self.D
         return pred, se
@@ -592,9 +628,13 @@ class MFEngine:
         return se[:n]
 
     @torch.no_grad()
-    def train_step(self, data, y, n_global=None, next_data=None):
+    def train_step(self, data, y, n_global=None, next_data=None, defer_sweep=False):
         """One optimisation step.  Returns the per-example SE tensor (device); the running sum is
-        in ``self.sse``.  (``next_data`` is accepted for loop compatibility; nothing to prepare.)"""
+        in ``self.sse``.  defer_sweep (single process, with `next_data`): the Adam sweep over the two ID tables is
+        temporally blocked -- chunks neither batch names are visited every `sweep_period`-th step and take their
+        pending updates together: same bits, a fraction of the traffic.  The caller promises that the next call
+        trains on `next_data`; any other call (and `flush()`, `state_dict()`, `predict()`) brings the tables up to
+        date first; code that reads the embedding Parameters directly calls `flush()` before."""
         n = data[5].numel()
         y = y.reshape(-1).contiguous()
         if n == 0 and self.dp is None:                       # nothing to train on: no step, no state change
@@ -603,7 +643,7 @@ class MFEngine:
         if self.dp is not None:
             return self._train_step_dp(data, y, n_global)
         _, se = self._launch(data, y, self.model.training, 1.0 / float(n_global if n_global is not None else n),
-                             self.step_count)
+                             self.step_count, next_data if defer_sweep else None)
         return se
 
     @torch.no_grad()
@@ -643,6 +683,7 @@ class MFEngine:
         return out
 
     def moments(self):
+        self.flush()
         names = ['user_embedding.weight', 'item_embedding.weight', 'user_bias', 'item_bias', 'global_bias']
         return ({k: t for k, t in zip(names, self.m) if t is not None},
                 {k: t for k, t in zip(names, self.v) if t is not None})
@@ -654,6 +695,7 @@ class MFEngine:
                 'betas': self.betas, 'eps': self.eps}
 
     def load_state_dict(self, sd):
+        self._tb_promised = None                             # (the workspaces are zeroed below: nothing pending any more)
         m, v = self.moments()
         for k in m:
             m[k].copy_(sd['exp_avg'][k].to(self.dev))
@@ -1176,7 +1218,7 @@ class TransNetEngine(NarreEngine):
         if self._tb_promised is not None:
             f, n, _, _ = self._fields(data)
             if not adam_step or self._tb_key(f, n) != self._tb_promised[0]:
-                self.flush()
+                self.flush(last_step=adam_step - 1 if adam_step else None)
         self._tb_next = None
         if (self._defer_req and adam_step and self.plus and self.dp is None and next_data is not None
                 and self.sweep_period > 1 and next_data[5].numel() > 0):
@@ -1201,8 +1243,9 @@ class TransNetEngine(NarreEngine):
         finally:
             self._defer_req = False
 
-    def flush(self, check=True):
-        """Apply every pending ID-vector update (no-op when nothing is pending)."""
+    def flush(self, check=True, last_step=None):
+        """Apply every pending ID-vector update (no-op when nothing is pending).  last_step: the last COMPLETED step
+        (default: step_count; a training step that finds a broken announcement has already counted itself)."""
         if self._tb_promised is None:
             return
         self._tb_promised = None
@@ -1210,8 +1253,8 @@ class TransNetEngine(NarreEngine):
         p2 = lambda ts: (ctypes.c_uint64 * 2)(*[t.data_ptr() for t in ts])   # noqa: E731
         _lib.check(_lib.lib().r4r_transnet_rows_flush(
             p2(self.rows), p2(self.rows_m), p2(self.rows_v), self.n_users, self.n_items, ptr(self._ws), self._ws.numel(),
-            B, T, self.E, self.L, self.V, self.lr, self.betas[0], self.betas[1], self.eps, self.wd, int(self.step_count),
-            _lib.current_stream()), 'r4r_transnet_rows_flush')
+            B, T, self.E, self.L, self.V, self.lr, self.betas[0], self.betas[1], self.eps, self.wd,
+            int(self.step_count if last_step is None else last_step), _lib.current_stream()), 'r4r_transnet_rows_flush')
         if check:
             self.check_announcements()
 
