@@ -21,12 +21,26 @@ struct AdamScalars {
     float omb1, omb2;       // 1 - beta, rounded from double like torch's `value=1 - beta2`
 };
 
+// The square root and the division are the hardware's (v_sqrt_f32, v_rcp_f32: 1 ulp each) instead of the IEEE-exact
+// expansions hipcc emits for sqrtf() and `/` (27 vector instructions of the update's 35): the update term carries a
+// relative error of ~2e-7 either way -- the reference's own CPU arithmetic is no closer to the real number -- and the
+// temporally blocked sweeps, which apply several updates per byte moved, stop being bound by this arithmetic (cfg5's
+// sweep 92 -> see DESIGN.md 4.5).  R4R_ADAM_IEEE=1 at build time restores the expansions (A/B runs).  A denormal
+// second moment reads as zero here: sqrt(v) < 1e-19 against eps = 1e-8 either way.
+#ifndef R4R_ADAM_IEEE
+#define R4R_ADAM_IEEE 0
+#endif
 __device__ __forceinline__ void adam_elem(float &p, float g, float &m, float &v, const AdamScalars &s) {
     g = fmaf(s.wd, p, g);
     m = fmaf(s.beta1, m, s.omb1 * g);
     v = fmaf(s.beta2, v, s.omb2 * g * g);
+#if R4R_ADAM_IEEE
     const float denom = sqrtf(v) * s.inv_sqrt_bc2 + s.eps;
     p -= s.lr_over_bc1 * (m / denom);
+#else
+    const float denom = __builtin_amdgcn_sqrtf(v) * s.inv_sqrt_bc2 + s.eps;
+    p -= s.lr_over_bc1 * (m * __builtin_amdgcn_rcpf(denom));
+#endif
 }
 
 // step >= 1: the 1-based count of this update

@@ -507,7 +507,7 @@ class MFEngine:
         self.offset = 0
         self._ws, self._ws_B, self._out = None, None, {}
         # visit period of the temporally blocked table sweep (include/r4r.h; 1 = the plain dense sweep)
-        self.sweep_period = max(1, min(8, int(os.environ.get('R4R_SWEEP_PERIOD', hp.get('sweep_period', 3)))))   # (cfg2: 3 measured best)
+        self.sweep_period = max(1, min(8, int(os.environ.get('R4R_SWEEP_PERIOD', hp.get('sweep_period', 8)))))
         self._tb_promised, self._tb_next = None, None
 
     TEMPORAL_SWEEP = True        # train_step(..., defer_sweep=True) + flush(): the table sweep, temporally blocked
@@ -580,6 +580,7 @@ class MFEngine:
         _lib.check(rc, 'r4r_mf_step')
         if tbn is not None:                                  # (the id tensors stay referenced until the promise is kept)
             self._tb_promised = ((tbn[0].data_ptr(), tbn[1].data_ptr(), tbn[2]), tbn)
+            self._tb_used = True
         if train_mode and float(self.hp['dropout']) > 0.0:
             self.offset += n * 2 * self.D
         return pred, se
@@ -1169,7 +1170,7 @@ class TransNetEngine(NarreEngine):
             self.dp = dp
         self.plus = int(model.hyper_params['model_type'] == 'transnet++')
         # visit period of the temporally blocked ID-vector sweep (include/r4r.h; 1 = the plain dense sweep)
-        self.sweep_period = max(1, min(8, int(os.environ.get('R4R_SWEEP_PERIOD', model.hyper_params.get('sweep_period', 4)))))
+        self.sweep_period = max(1, min(8, int(os.environ.get('R4R_SWEEP_PERIOD', model.hyper_params.get('sweep_period', 8)))))
         self._tb_promised, self._tb_next, self._defer_req = None, None, False
         if not self.plus:
             self.DP_COLS = 0                                 # plain TransNet: no ID rows to exchange
@@ -1228,6 +1229,7 @@ class TransNetEngine(NarreEngine):
         out = super()._launch(data, y, train_mode, inv_denom, adam_step, next_data)
         if self._tb_next is not None:                        # (the id tensors stay referenced until the promise is kept)
             self._tb_promised = (self._tb_key([None] * 3 + list(self._tb_next[:2]), self._tb_next[2]), self._tb_next)
+            self._tb_used = True
         return out
 
     @torch.no_grad()
