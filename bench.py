@@ -51,10 +51,10 @@ PEAK_HBM_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E spec peak (6.3 TB
 WORKLOAD = 'cfg3_deepconn_electronics_e300'
 
 
-PMC_SUMMARIES = {WORKLOAD: 'r03c_bench_pmc_summary.json',
-                 'cfg2_mfdot_electronics': 'r03d_bench_cfg2_pmc_summary.json',
-                 'cfg4_narre_kindle': 'r03d_bench_cfg4_pmc_summary.json',
-                 'cfg5_transnetpp_synthetic': 'r03d_bench_cfg5_pmc_summary.json',
+PMC_SUMMARIES = {WORKLOAD: 'r03f_bench_pmc_summary.json',
+                 'cfg2_mfdot_electronics': 'r03f_bench_cfg2_pmc_summary.json',
+                 'cfg4_narre_kindle': 'r03f_bench_cfg4_pmc_summary.json',
+                 'cfg5_transnetpp_synthetic': 'r03f_bench_cfg5_pmc_summary.json',
                  # the one true HBM gather: full-length documents of uniformly drawn words at a 1 M-word vocabulary
                  ('cfg5_transnetpp_synthetic', 'full', 'uniform'): 'r03_cfg5_fullunif_pmc_summary.json'}
 
@@ -174,17 +174,25 @@ def cpu_baseline(hp, table, batches_np, budget_s):
         P0[key] = torch.from_numpy(table.copy())
     batches = [([torch.from_numpy(d) for d in data], torch.from_numpy(y)) for data, y in batches_np]
 
+    tn = hp['model_type'].startswith('transnet')            # the three-optimiser step of main.py:35-53
+
     def one_step(P, state, i):
         data, y = batches[i % len(batches)]
         t = time.perf_counter()
-        oracle.train_step(P, data, y, hp, state)
+        if tn:
+            oracle.transnet_train_step(P, data, y, hp, state)
+        else:
+            oracle.train_step(P, data, y, hp, state)
         return time.perf_counter() - t
+
+    def fresh_state():
+        return dict(source=oracle.AdamState(), source_fm=oracle.AdamState(), target=oracle.AdamState()) if tn else oracle.AdamState()
 
     best, best_t = None, None
     t_cal = time.perf_counter()
     for threads in sorted({min(ncpu, c) for c in (8, 16, 32, 64, ncpu)}):
         torch.set_num_threads(threads)
-        P, state = {k: v.clone() for k, v in P0.items()}, oracle.AdamState()
+        P, state = {k: v.clone() for k, v in P0.items()}, fresh_state()
         one_step(P, state, 0)                               # warm-up at this thread count
         dt = one_step(P, state, 1)
         if best_t is None or dt < best_t:
@@ -192,7 +200,7 @@ def cpu_baseline(hp, table, batches_np, budget_s):
         if time.perf_counter() - t_cal > budget_s:          # bounded calibration
             break
     torch.set_num_threads(best)
-    P, state = {k: v.clone() for k, v in P0.items()}, oracle.AdamState()
+    P, state = {k: v.clone() for k, v in P0.items()}, fresh_state()
     one_step(P, state, 0)
     n, t0 = 0, time.perf_counter()
     while True:

@@ -219,6 +219,9 @@ __device__ __forceinline__ void mf_stream_chunk(float *p, float *m, float *v, in
     }
 }
 
+#ifndef R4R_TB_BATCH
+#define R4R_TB_BATCH 2                 // float4 per array a thread has in flight (4: 160 VGPRs, 3 waves per SIMD -- cfg5's sweep 53 -> 74 us)
+#endif
 // The same stream for a chunk that carries `pend` (1 .. MF_TB_MAX) pending gradient-zero updates: one read and one
 // write of the element, the updates applied in step order with each step's own bias corrections (slot j of the
 // scalar arrays = step now - (MF_TB_MAX - 1 - j); compile-time indices: a run-time index into kernel arguments
@@ -252,19 +255,24 @@ __device__ __forceinline__ void mf_stream_chunk_tb(float *p, float *m, float *v,
         }
     };
     const int64_t nvec = cnt >> 2;
-    int64_t i = tid;
-    for (; i + MF_THREADS < nvec; i += 2 * MF_THREADS) {
-        const int64_t j = i + MF_THREADS;
-        mf_f32x4 P0 = ld(p, i), P1 = ld(p, j), M0 = ld(m, i), M1 = ld(m, j), V0 = ld(v, i), V1 = ld(v, j);
-        upd(P0, M0, V0);
-        upd(P1, M1, V1);
-        st(p, i, P0); st(m, i, M0); st(v, i, V0);
-        st(p, j, P1); st(m, j, M1); st(v, j, V1);
-    }
-    for (; i < nvec; i += MF_THREADS) {
-        mf_f32x4 P = ld(p, i), M = ld(m, i), V = ld(v, i);
-        upd(P, M, V);
-        st(p, i, P); st(m, i, M); st(v, i, V);
+    constexpr int NV = MF_CHUNK / 4 / MF_THREADS, NB = R4R_TB_BATCH;     // float4 per thread and array; in flight together
+    static_assert(NV % NB == 0, "batches of the thread's float4");
+#pragma unroll 1
+    for (int u0 = 0; u0 < NV; u0 += NB) {
+        mf_f32x4 P[NB], M[NB], V[NB];
+#pragma unroll
+        for (int u = 0; u < NB; ++u) {
+            const int64_t i = tid + (int64_t)(u0 + u) * MF_THREADS;
+            const int64_t ii = i < nvec ? i : 0;            // (the last chunk of a table: clamped, not stored)
+            P[u] = ld(p, ii); M[u] = ld(m, ii); V[u] = ld(v, ii);
+        }
+#pragma unroll
+        for (int u = 0; u < NB; ++u) upd(P[u], M[u], V[u]);
+#pragma unroll
+        for (int u = 0; u < NB; ++u) {
+            const int64_t i = tid + (int64_t)(u0 + u) * MF_THREADS;
+            if (i < nvec) { st(p, i, P[u]); st(m, i, M[u]); st(v, i, V[u]); }
+        }
     }
     const int64_t k = (nvec << 2) + tid;                    // cnt % 4 elements at the end of a table
     if (k < cnt) {
