@@ -393,7 +393,7 @@ int r4r_mf_step(const int64_t *uid, const int64_t *iid, const float *y,
                 void *stream);
 
 /* next_uid / next_iid [next_B] + sweep_period P in 2..8: the Adam sweep over the two ID tables, temporally blocked
- * (the contract is spelled out at r4r_transnet_rows_flush below: chunks of 8,192 table elements that neither this
+ * (the contract is spelled out at r4r_transnet_rows_flush below: chunks of 4,096 table elements that neither this
  * batch nor the announced next batch names are visited every P-th step and take their pending gradient-zero
  * updates together -- the same fp32 operations per element, a fraction of the traffic; the caller trains on exactly
  * the announced ids next, keeps the optimiser scalars unchanged meanwhile, and calls r4r_mf_rows_flush before
@@ -564,7 +564,7 @@ int r4r_transnet_step(const float *table, int64_t V,
  * decaying moments), 24 bytes of traffic per element -- but an element no rating of the batch names goes through
  * the same gradient-zero update whether it is applied now or together with the next few: the update reads nothing
  * but the element's own (p, m, v) and the step's two bias corrections.  With sweep_period P > 1 and the ids of the
- * batch the NEXT call will train on (next_uid / next_iid [next_B]), a chunk of 8,192 table elements that neither
+ * batch the NEXT call will train on (next_uid / next_iid [next_B]), a chunk of 4,096 table elements that neither
  * this batch nor the next names is visited every P-th step only and then takes all its pending updates at once, in
  * step order, each with its own step's scalars: the same fp32 operations per element as P = 1, a P-th of the bytes.
  * Chunks the next batch names are brought up to date by this call, so the next call reads current rows.

@@ -4,7 +4,10 @@
 
 namespace r4r {
 
-constexpr int MF_CHUNK = 8192;         // elements of a table per sweep workgroup (and per chunk tag)
+#ifndef R4R_MF_CHUNK
+#define R4R_MF_CHUNK 4096                  // (8192 until late round 3; A/B in profiles/r03f_chunk_ab.txt: cfg2 +12 % at B = 128, +6 % at 8,192; cfg5 within 1 %; 2048: cfg5 -10 %)
+#endif
+constexpr int MF_CHUNK = R4R_MF_CHUNK;         // elements of a table per sweep workgroup (and per chunk tag)
 
 int mf_bias_rows_launch(float *ub, float *ub_m, float *ub_v, float *ib, float *ib_m, float *ib_v,
                         int64_t n_users, int64_t n_items, const int64_t *uid, const int64_t *iid, const float *g,

@@ -278,7 +278,7 @@ def _same_bits(a, b, what):
 def test_temporally_blocked_sweep_is_the_dense_sweep_bit_for_bit(period, monkeypatch):
     """TransNet++'s ID-vector Adam with untouched chunks visited every `period`-th step (their pending gradient-zero
     updates applied together, include/r4r.h) against the plain sweep that visits every element every step: 13
-    training steps over tables of 13 + 4 chunks, dropout on, a ragged batch, an announcement that is NOT kept (the
+    training steps over tables of 26 + 8 chunks, dropout on, a ragged batch, an announcement that is NOT kept (the
     engine flushes), an evaluation in the middle -- every parameter and both Adam moments identical to the bit."""
     from reviews4rec_amd import synthetic
     monkeypatch.setenv('R4R_SWEEP_PERIOD', str(period))
@@ -309,7 +309,7 @@ def test_temporally_blocked_sweep_is_the_dense_sweep_bit_for_bit(period, monkeyp
 
 
 def test_temporally_blocked_sweep_at_cfg5_cardinalities():
-    """The same equality on cfg5's own tables (10 M x 5 + 1 M x 5: 6,714 chunks), six steps at the default period,
+    """The same equality on cfg5's own tables (10 M x 5 + 1 M x 5: 13,428 chunks), six steps at the default period,
     the flush as its own launch (the way bench.py ends its timed region)."""
     from reviews4rec_amd import synthetic
     hp = dict(synthetic.hyper_params_for('cfg5_transnetpp_synthetic', dropout=0.0), input_length=100, vocab=5000)
@@ -339,7 +339,7 @@ def test_temporally_blocked_sweep_at_cfg5_cardinalities():
 @pytest.mark.parametrize('period,B', [(2, 128), (4, 128), (8, 128), (4, 2500)])
 def test_temporally_blocked_mf_sweep_is_the_dense_sweep_bit_for_bit(period, B, monkeypatch):
     """r4r_mf_step's table sweep with untouched chunks visited every `period`-th step against the sweep that visits
-    every element every step, on cfg2's own tables (192,403 x 64 + 63,001 x 64: 1,996 chunks): twelve training steps,
+    every element every step, on cfg2's own tables (192,403 x 64 + 63,001 x 64: 3,991 chunks): twelve training steps,
     dropout on, a ragged batch, an evaluation in the middle, an announcement that is not kept -- every parameter and
     both Adam moments identical to the bit (B = 2,500 runs the wide entry waves, mf_adam_kernel<8>)."""
     import reviews4rec_amd
