@@ -612,15 +612,23 @@ int r4r_idnet_nparam(void);
 int r4r_idnet_layout(int variant, int L, int64_t *offsets, int64_t *sizes, int64_t *total);
 size_t r4r_idnet_ws_bytes(int variant, int64_t B, int L, int64_t n_users, int64_t n_items);
 size_t r4r_idnet_ws_offset(int variant, int64_t B, int L, int64_t n_users, int64_t n_items,
-                           int which);   /* 0 dropout multipliers [B, draws], 1 d loss/d pred [B], 2 size of the persistent head (row tags), 4 + 2*pair + side: compact gradient rows [B, L] */
+                           int which);   /* 0 dropout multipliers [B, draws], 1 d loss/d pred [B], 2 size of the persistent head (row tags), 3 the broken-announcement flag (int), 4 + 2*pair + side: compact gradient rows [B, L] */
 int r4r_idnet_step(int variant, const int64_t *uid, const int64_t *iid, const float *y,
                    float *flat_p, float *flat_g, float *flat_m, float *flat_v,
                    const uint64_t *rows_p, const uint64_t *rows_m, const uint64_t *rows_v,
                    int64_t n_users, int64_t n_items,
                    float *pred, float *se, float *sse_accum, void *ws, size_t ws_bytes,
                    int64_t B, int L, float dropout_p, int training, uint64_t seed, uint64_t offset,
-                   float inv_denom, float lr, double beta1, double beta2, float eps, float weight_decay,
+                   float inv_denom, const int64_t *next_uid, const int64_t *next_iid, int64_t next_B,
+                   int sweep_period, float lr, double beta1, double beta2, float eps, float weight_decay,
                    int64_t adam_step, void *stream);
+/* next_uid / next_iid / next_B / sweep_period: the sweeps over the variant's table pair(s), temporally blocked
+ * (contract at r4r_transnet_rows_flush; r4r_idnet_ws_offset which = 3: the broken-announcement flag).
+ * r4r_idnet_rows_flush applies what is pending; adam_step = the last completed step. */
+int r4r_idnet_rows_flush(int variant, const uint64_t *rows_p, const uint64_t *rows_m, const uint64_t *rows_v,
+                         int64_t n_users, int64_t n_items, void *ws, size_t ws_bytes, int64_t B, int L,
+                         float lr, double beta1, double beta2, float eps, float weight_decay, int64_t adam_step,
+                         void *stream);
 
 /* Data parallel: r4r_idnet_step with flat_m == NULL computes gradients only (flat_g, and in the workspace
  * d loss/d pred [B] and the compact rows [B, L] per table: r4r_idnet_ws_offset 1, 4..7); after the exchange --

@@ -68,6 +68,10 @@ struct IdnHead {
     float *grow[2][2];                 // [pair][side] compact gradient rows [B, L]
     float *g;                          // [B] d mean(SE) / d pred
     int *tag[2];
+    int *ctag[2];                      // per sweep chunk of a table: the last step that touched a row in it (NULL: not kept)
+    const int64_t *next_id[2];         // the announced next batch's uid / iid (temporally blocked sweep), or NULL
+    int64_t next_B;
+    int *ntag[2];                      // ... and the chunk tags its rows get
     float *mult;                       // [B, draws]
     float *pred, *se;
     int64_t B;
@@ -183,6 +187,18 @@ __global__ __launch_bounds__(256) void idnet_head_kernel(IdnHead a) {
             a.g[b] = g;
             a.tag[0][uid] = a.now;
             a.tag[1][iid] = a.now;
+            if (a.ctag[0]) {                                // chunk tags of both table pairs (same ids, same width)
+                const int64_t id2[2] = {uid, iid};
+                for (int s = 0; s < 2; ++s) {
+                    const int64_t e0 = id2[s] * a.L;
+                    a.ctag[s][e0 / MF_CHUNK] = a.now; a.ctag[s][(e0 + a.L - 1) / MF_CHUNK] = a.now;
+                    if (a.next_id[s])                       // the chunks the NEXT batch names are brought up to date by this step's sweeps
+                        for (int64_t j = b; j < a.next_B; j += a.B) {
+                            const int64_t q0 = a.next_id[s][j] * a.L;
+                            a.ntag[s][q0 / MF_CHUNK] = a.now; a.ntag[s][(q0 + a.L - 1) / MF_CHUNK] = a.now;
+                        }
+                }
+            }
         }
     }
     if (!a.want_grad) return;                               // uniform
@@ -286,6 +302,7 @@ __global__ __launch_bounds__(IR_ROWS * IR_COLS) void idnet_reduce_kernel(IdnRedu
 
 struct IdnWs {
     int *tag[2];
+    int *ctag[2], *ntag[2], *lag[2][2], *tb_err;       // the temporally blocked sweeps' state (rows_device.h); lag per [pair][side]
     float *part, *g, *mult, *grow[2][2];
     size_t bytes, persist;
 };
@@ -296,6 +313,14 @@ static IdnWs idn_carve(void *ws, int variant, int64_t B, int L, int64_t n_users,
     auto take = [&](size_t nbytes) { char *r = p ? p + o : nullptr; o += align256(nbytes); return r; };
     w.tag[0] = reinterpret_cast<int *>(take((size_t)n_users * 4));          // persistent state first (zeroed once)
     w.tag[1] = reinterpret_cast<int *>(take((size_t)n_items * 4));
+    for (int s = 0; s < 2; ++s) {
+        const size_t chunks = (size_t)cdiv((s ? n_items : n_users) * (int64_t)L, MF_CHUNK);
+        w.ctag[s] = reinterpret_cast<int *>(take(chunks * 4));
+        w.ntag[s] = reinterpret_cast<int *>(take(chunks * 4));
+        w.lag[0][s] = reinterpret_cast<int *>(take(chunks * 4));
+        w.lag[1][s] = reinterpret_cast<int *>(take(chunks * 4));
+    }
+    w.tb_err = reinterpret_cast<int *>(take(4));
     w.persist = o;
     const ILayout lay = idn_layout(variant, L);
     w.part = reinterpret_cast<float *>(take((size_t)B * lay.total * 4));
@@ -328,11 +353,13 @@ extern "C" size_t r4r_idnet_ws_bytes(int variant, int64_t B, int L, int64_t n_us
     return idn_carve(nullptr, variant, B, L, n_users, n_items).bytes;
 }
 
-// which: 0 dropout multipliers [B, draws]; 1 d loss / d pred [B]; 2 the persistent head's size;
+// which: 0 dropout multipliers [B, draws]; 1 d loss / d pred [B]; 2 the persistent head's size; 3 the int the
+// temporally blocked sweeps set when a batch was not the announced one;
 // 4 + 2 * pair + side: compact gradient rows [B, L] of that ID table
 extern "C" size_t r4r_idnet_ws_offset(int variant, int64_t B, int L, int64_t n_users, int64_t n_items, int which) {
     const IdnWs w = idn_carve(reinterpret_cast<void *>(256), variant, B, L, n_users, n_items);
     if (which == 2) return w.persist;
+    if (which == 3) return (size_t)(reinterpret_cast<char *>(w.tb_err) - reinterpret_cast<char *>(256));
     const char *q = which == 0 ? reinterpret_cast<char *>(w.mult)
                                : which == 1 ? reinterpret_cast<char *>(w.g)
                                             : reinterpret_cast<char *>(w.grow[((which - 4) >> 1) & 1][(which - 4) & 1]);
@@ -345,9 +372,12 @@ extern "C" int r4r_idnet_step(int variant, const int64_t *uid, const int64_t *ii
                               int64_t n_users, int64_t n_items,
                               float *pred, float *se, float *sse_accum, void *ws, size_t ws_bytes,
                               int64_t B, int L, float dropout_p, int training, uint64_t seed, uint64_t offset,
-                              float inv_denom, float lr, double beta1, double beta2, float eps, float weight_decay,
+                              float inv_denom, const int64_t *next_uid, const int64_t *next_iid, int64_t next_B,
+                              int sweep_period, float lr, double beta1, double beta2, float eps, float weight_decay,
                               int64_t adam_step, void *stream) {
     R4R_REQUIRE(uid && iid && flat_p && rows_p && pred && ws, "idnet_step: null pointer");
+    R4R_REQUIRE(sweep_period >= 1 && sweep_period <= MF_TB_MAX, "idnet_step: sweep_period %d outside 1..%d", sweep_period, MF_TB_MAX);
+    R4R_REQUIRE(!next_uid == !next_iid && (!next_uid || next_B > 0), "idnet_step: next_uid, next_iid and next_B > 0 go together");
     R4R_REQUIRE(variant >= 0 && variant <= IDN_NEUMF, "idnet_step: variant %d outside 0..3", variant);
     R4R_REQUIRE(L > 0 && L <= IDN_MAX_L, "idnet_step: latent_size %d outside 1..%d", L, IDN_MAX_L);
     R4R_REQUIRE(n_users > 0 && n_items > 0 && B >= 0, "idnet_step: bad sizes");
@@ -389,6 +419,15 @@ extern "C" int r4r_idnet_step(int variant, const int64_t *uid, const int64_t *ii
         R4R_REQUIRE(h.bias[s], "idnet_step: null bias vector");
     }
     h.id[0] = uid; h.id[1] = iid; h.y = y; h.part = w.part; h.g = w.g; h.mult = w.mult; h.pred = pred; h.se = se;
+    // the temporally blocked sweeps (rows_device.h): 16-byte aligned tables, a training step that updates in this call
+    bool tb_on = train_step && apply;
+    for (int k = 0; k < 2 * npair && tb_on; ++k) tb_on = ((rows_p[k] | rows_m[k] | rows_v[k]) & 15) == 0;
+    const bool announce = tb_on && next_uid && sweep_period > 1;
+    for (int s = 0; s < 2; ++s) {
+        h.ctag[s] = tb_on ? w.ctag[s] : nullptr; h.ntag[s] = w.ntag[s];
+        h.next_id[s] = announce ? (s ? next_iid : next_uid) : nullptr;
+    }
+    h.next_B = announce ? next_B : 0;
     h.B = B; h.L = L; h.np = (int)lay.total; h.variant = variant; h.training = training; h.want_grad = train_step;
     h.now = (int)adam_step; h.p_drop = dropout_p; h.inv_denom = inv_denom; h.seed = seed; h.offset = offset;
     if (L <= 16) idnet_head_kernel<16><<<(unsigned)B, 256, 0, st>>>(h);
@@ -413,13 +452,59 @@ extern "C" int r4r_idnet_step(int variant, const int64_t *uid, const int64_t *ii
     }
     // the first table pair and the two bias vectors in one launch (an entry wave that owns a row updates the row
     // and its bias element); NeuMF's second pair in another
+    MfTimeBlock tb[2];
+    for (int pr = 0; pr < 2; ++pr) {
+        tb[pr] = MfTimeBlock{};
+        tb[pr].lag_u = w.lag[pr][0]; tb[pr].lag_i = w.lag[pr][1]; tb[pr].ntag_u = w.ntag[0]; tb[pr].ntag_i = w.ntag[1];
+        tb[pr].err = w.tb_err; tb[pr].period = announce ? sweep_period : 1; tb[pr].flush = announce ? 0 : 1; tb[pr].inc = 1;
+        mf_time_block_scalars(tb[pr], lr, beta1, beta2, eps, weight_decay, adam_step);
+    }
     if (int rc = mf_table_bias_rows_launch(rp[0], rm[0], rv[0], rp[1], rm[1], rv[1], rp[4], rm[4], rv[4], rp[5], rm[5], rv[5],
                                            n_users, n_items, L, uid, iid, w.grow[0][0], w.grow[0][1], w.g, w.tag[0], w.tag[1],
-                                           B, (int)adam_step, sc, st))
+                                           B, (int)adam_step, sc, st, tb_on ? w.ctag[0] : nullptr, tb_on ? w.ctag[1] : nullptr,
+                                           tb_on ? &tb[0] : nullptr))
         return rc;
     if (npair == 2)
         return mf_table_rows_launch(rp[2], rm[2], rv[2], rp[3], rm[3], rv[3], n_users, n_items, L, uid, iid, w.grow[1][0],
-                                    w.grow[1][1], w.tag[0], w.tag[1], nullptr, nullptr, B, (int)adam_step, sc, st);
+                                    w.grow[1][1], w.tag[0], w.tag[1], tb_on ? w.ctag[0] : nullptr, tb_on ? w.ctag[1] : nullptr,
+                                    B, (int)adam_step, sc, st, tb_on ? &tb[1] : nullptr);
+    return R4R_OK;
+}
+
+// What the temporally blocked sweeps left pending (r4r_idnet_step with next_uid and sweep_period > 1): every chunk of
+// the variant's table pair(s) takes its pending updates now.  adam_step = the LAST COMPLETED step.
+extern "C" int r4r_idnet_rows_flush(int variant, const uint64_t *rows_p, const uint64_t *rows_m, const uint64_t *rows_v,
+                                    int64_t n_users, int64_t n_items, void *ws, size_t ws_bytes, int64_t B, int L,
+                                    float lr, double beta1, double beta2, float eps, float weight_decay, int64_t adam_step,
+                                    void *stream) {
+    R4R_REQUIRE(rows_p && rows_m && rows_v && ws, "idnet_rows_flush: null pointer");
+    R4R_REQUIRE(variant >= 0 && variant <= IDN_NEUMF && L > 0 && L <= IDN_MAX_L && n_users > 0 && n_items > 0 && B >= 0,
+                "idnet_rows_flush: bad arguments");
+    R4R_REQUIRE(adam_step >= 0 && adam_step < (1ll << 31), "idnet_rows_flush: bad adam_step");
+    if (ws_bytes < r4r_idnet_ws_bytes(variant, B, L, n_users, n_items)) {
+        set_error("idnet_rows_flush: workspace %zu < %zu bytes", ws_bytes, r4r_idnet_ws_bytes(variant, B, L, n_users, n_items));
+        return R4R_ERR_WORKSPACE;
+    }
+    if (adam_step == 0) return R4R_OK;
+    const IdnWs w = idn_carve(ws, variant, B, L, n_users, n_items);
+    const int npair = idn_pairs(variant);
+    for (int k = 0; k < 2 * npair; ++k) {
+        R4R_REQUIRE(rows_p[k] && rows_m[k] && rows_v[k], "idnet_rows_flush: table %d: null pointer", k);
+        if ((rows_p[k] | rows_m[k] | rows_v[k]) & 15) return R4R_OK;       // (unaligned tables never defer)
+    }
+    const AdamScalars sc = adam_make_scalars(lr, beta1, beta2, eps, weight_decay, adam_step, nullptr);
+    auto f = [](uint64_t x) { return reinterpret_cast<float *>(x); };
+    for (int pr = 0; pr < npair; ++pr) {
+        MfTimeBlock tb{};
+        tb.lag_u = w.lag[pr][0]; tb.lag_i = w.lag[pr][1]; tb.ntag_u = w.ntag[0]; tb.ntag_i = w.ntag[1]; tb.err = w.tb_err;
+        tb.period = 1; tb.flush = 1; tb.inc = 0;
+        mf_time_block_scalars(tb, lr, beta1, beta2, eps, weight_decay, adam_step);
+        if (int rc = mf_table_rows_launch(f(rows_p[2 * pr]), f(rows_m[2 * pr]), f(rows_v[2 * pr]), f(rows_p[2 * pr + 1]),
+                                          f(rows_m[2 * pr + 1]), f(rows_v[2 * pr + 1]), n_users, n_items, L, nullptr, nullptr, nullptr,
+                                          nullptr, w.tag[0], w.tag[1], w.ctag[0], w.ctag[1], 0, (int)adam_step, sc,
+                                          as_stream(stream), &tb))
+            return rc;
+    }
     return R4R_OK;
 }
 

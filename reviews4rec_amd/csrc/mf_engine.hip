@@ -914,12 +914,26 @@ int mf_table_bias_rows_launch(float *ut, float *ut_m, float *ut_v, float *it, fl
                               float *ub, float *ub_m, float *ub_v, float *ib, float *ib_m, float *ib_v,
                               int64_t n_users, int64_t n_items, int D, const int64_t *uid, const int64_t *iid,
                               const float *gu, const float *gi, const float *g, const int *tag_u, const int *tag_i,
-                              int64_t B, int now, const AdamScalars &sc, hipStream_t st) {
+                              int64_t B, int now, const AdamScalars &sc, hipStream_t st,
+                              const int *ctag_u, const int *ctag_i, const MfTimeBlock *tb) {
     if (B > MF_MAX_B || D < 1 || D > MF_MAX_D) {
         set_error("table + bias rows: batch %lld > %d or width %d outside 1..%d", (long long)B, MF_MAX_B, D, MF_MAX_D);
         return R4R_ERR_ARG;
     }
     MfSweep sw{};
+    if (tb) {
+        const uintptr_t all = reinterpret_cast<uintptr_t>(ut) | reinterpret_cast<uintptr_t>(ut_m) | reinterpret_cast<uintptr_t>(ut_v) |
+                              reinterpret_cast<uintptr_t>(it) | reinterpret_cast<uintptr_t>(it_m) | reinterpret_cast<uintptr_t>(it_v);
+        if (!ctag_u || !ctag_i || !tb->lag_u || !tb->lag_i || !tb->ntag_u || !tb->ntag_i || !tb->err || (all & 15) ||
+            tb->period < 1 || tb->period > MF_TB_MAX) {
+            set_error("table + bias rows: the temporally blocked sweep needs chunk tags, lag / next-tag arrays, 16-byte aligned "
+                      "tables and a period in 1..%d", MF_TB_MAX);
+            return R4R_ERR_ARG;
+        }
+        sw.tb = *tb;
+        sw.ctag_u = ctag_u; sw.ctag_i = ctag_i;
+        sw.nt = mf_sweep_nt((int64_t)n_users * D + (int64_t)n_items * D);
+    }
     sw.p0 = ut; sw.m0 = ut_m; sw.v0 = ut_v; sw.p1 = it; sw.m1 = it_m; sw.v1 = it_v;
     sw.p2 = ub; sw.m2 = ub_m; sw.v2 = ub_v; sw.p3 = ib; sw.m3 = ib_m; sw.v3 = ib_v;
     sw.n0 = n_users * D; sw.n1 = n_items * D; sw.n2 = n_users; sw.n3 = n_items;

@@ -44,6 +44,7 @@ int mf_table_bias_rows_launch(float *ut, float *ut_m, float *ut_v, float *it, fl
                               float *ub, float *ub_m, float *ub_v, float *ib, float *ib_m, float *ib_v,
                               int64_t n_users, int64_t n_items, int D, const int64_t *uid, const int64_t *iid,
                               const float *gu, const float *gi, const float *g, const int *tag_u, const int *tag_i,
-                              int64_t B, int now, const AdamScalars &sc, hipStream_t st);
+                              int64_t B, int now, const AdamScalars &sc, hipStream_t st,
+                              const int *ctag_u = nullptr, const int *ctag_i = nullptr, const MfTimeBlock *tb = nullptr);
 
 }  // namespace r4r

@@ -1426,10 +1426,37 @@ class IdNetEngine:
         self.seed = (int(seed) * 0x9E3779B97F4A7C15 + int(rank) * 0xD1B54A32D192ED03) & 0xFFFFFFFFFFFFFFFF
         self.offset = 0
         self._ws, self._ws_B, self._out = None, None, {}
+        # visit period of the temporally blocked table sweeps (include/r4r.h; 1 = the plain dense sweeps)
+        self.sweep_period = max(1, min(8, int(os.environ.get('R4R_SWEEP_PERIOD', hp.get('sweep_period', 8)))))
+        self._tb_promised = None
+
+    TEMPORAL_SWEEP = True        # train_step(..., defer_sweep=True) + flush(): the table sweeps, temporally blocked
+    has_tables = True
 
     @staticmethod
     def _p6(tensors):
         return (ctypes.c_uint64 * 6)(*[0 if t is None else t.data_ptr() for t in tensors])
+
+    def flush(self, check=True, last_step=None):
+        """Apply every pending table update of the temporally blocked sweeps (no-op when nothing is pending).
+        last_step: the last COMPLETED step (default: step_count)."""
+        if self._tb_promised is None:
+            return
+        self._tb_promised = None
+        _lib.check(_lib.lib().r4r_idnet_rows_flush(
+            self.variant, self._p6(self.rows), self._p6(self.rows_m), self._p6(self.rows_v), self.n_users, self.n_items,
+            ptr(self._ws), self._ws.numel(), self._ws_B, self.L, self.lr, self.betas[0], self.betas[1], self.eps, self.wd,
+            int(self.step_count if last_step is None else last_step), _lib.current_stream()), 'r4r_idnet_rows_flush')
+        if check:
+            self.check_announcements()
+
+    def check_announcements(self):
+        """Raise if a step trained on a batch other than the announced one while updates were pending."""
+        if self._ws is None:
+            return
+        off = _lib.lib().r4r_idnet_ws_offset(self.variant, self._ws_B, self.L, self.n_users, self.n_items, 3)
+        if int(self._ws[off:off + 4].view(torch.int32).item()):
+            raise RuntimeError('IdNetEngine: a deferred table sweep met a batch that was not the announced one')
 
     def draws(self):
         return 2 * self.L * (2 if self.variant == 3 else 1) + (0 if self.variant == 1 else 2 * self.L)
@@ -1445,11 +1472,17 @@ class IdNetEngine:
             self._ws, self._ws_B = nxt, B
         return self._ws
 
-    def _launch(self, data, y, train_mode, inv_denom, adam_step):
+    def _launch(self, data, y, train_mode, inv_denom, adam_step, next_data=None):
         uid, iid = data[5].reshape(-1).contiguous(), data[6].reshape(-1).contiguous()
         if not (uid.is_cuda and uid.dtype == torch.int64 and iid.is_cuda and iid.dtype == torch.int64):
             raise RuntimeError('IdNetEngine: batches must be int64 tensors on the ROCm device')
         n = uid.numel()
+        if self._tb_promised is not None and (not adam_step or (uid.data_ptr(), iid.data_ptr(), n) != self._tb_promised[0]):
+            self.flush(last_step=adam_step - 1 if adam_step else None)   # not the announced training step: the tables catch up first
+        self._tb_promised, tbn = None, None
+        if next_data is not None and adam_step and self.dp is None and self.sweep_period > 1 and next_data[5].numel() > 0:
+            nu, ni = next_data[5].reshape(-1).contiguous(), next_data[6].reshape(-1).contiguous()
+            tbn = (nu, ni, nu.numel())
         if adam_step and n > self.MAX_TRAIN_BATCH:
             raise RuntimeError('IdNetEngine: training batch %d > %d' % (n, self.MAX_TRAIN_BATCH))
         if n not in self._out:
@@ -1464,17 +1497,22 @@ class IdNetEngine:
             self._p6(self.rows), self._p6(self.rows_m) if apply else None,
             self._p6(self.rows_v) if apply else None, self.n_users, self.n_items, ptr(pred), ptr(se),
             ptr(self.sse) if adam_step else None, ptr(ws), ws.numel(), n, self.L, float(self.hp['dropout']),
-            int(train_mode), self.seed, self.offset, float(inv_denom), self.lr, self.betas[0], self.betas[1], self.eps,
-            self.wd, int(adam_step), _lib.current_stream())
+            int(train_mode), self.seed, self.offset, float(inv_denom),
+            ptr(tbn[0]) if tbn else None, ptr(tbn[1]) if tbn else None, tbn[2] if tbn else 0, self.sweep_period,
+            self.lr, self.betas[0], self.betas[1], self.eps, self.wd, int(adam_step), _lib.current_stream())
         _lib.check(rc, 'r4r_idnet_step')
+        if tbn is not None:                                  # (the id tensors stay referenced until the promise is kept)
+            self._tb_promised = ((tbn[0].data_ptr(), tbn[1].data_ptr(), tbn[2]), tbn)
+            self._tb_used = True
         if train_mode and float(self.hp['dropout']) > 0.0:
             self.offset += n * self.draws()
         return pred, se
 
     @torch.no_grad()
-    def train_step(self, data, y, n_global=None, next_data=None):
+    def train_step(self, data, y, n_global=None, next_data=None, defer_sweep=False):
         """One optimisation step.  Returns the per-example SE tensor (device, reused by the next call);
-        the running sum is in ``self.sse``."""
+        the running sum is in ``self.sse``.  defer_sweep (single process, with `next_data`): the Adam sweeps over
+        the ID tables are temporally blocked (MFEngine.train_step has the contract)."""
         if self.dp is not None:
             return self._train_step_dp(data, y, n_global)
         n = data[5].numel()
@@ -1482,7 +1520,8 @@ class IdNetEngine:
             return torch.empty(0, dtype=torch.float32, device=self.dev)
         self.step_count += 1
         _, se = self._launch(data, y.reshape(-1).contiguous(), self.model.training,
-                             1.0 / float(n_global if n_global is not None else n), self.step_count)
+                             1.0 / float(n_global if n_global is not None else n), self.step_count,
+                             next_data if defer_sweep else None)
         return se
 
     @torch.no_grad()
@@ -1578,6 +1617,7 @@ class IdNetEngine:
         return out
 
     def moments(self):
+        self.flush()
         m = {k: slot_view(self.flat_m, o, s, p.shape, getattr(self, 'E_model', 0), getattr(self, 'E', 0)) for k, p, o, s in
              zip(self.names, self.slots, self.offsets, self.sizes) if k is not None}
         v = {k: slot_view(self.flat_v, o, s, p.shape, getattr(self, 'E_model', 0), getattr(self, 'E', 0)) for k, p, o, s in
@@ -1588,6 +1628,7 @@ class IdNetEngine:
         return m, v
 
     def state_dict(self):
+        self.flush()
         return {'exp_avg': self.flat_m.clone(), 'exp_avg_sq': self.flat_v.clone(),
                 'rows_exp_avg': [None if t is None else t.clone() for t in self.rows_m],
                 'rows_exp_avg_sq': [None if t is None else t.clone() for t in self.rows_v],
@@ -1595,6 +1636,7 @@ class IdNetEngine:
                 'betas': self.betas, 'eps': self.eps}
 
     def load_state_dict(self, sd):
+        self._tb_promised = None                             # (the workspace is zeroed below: nothing pending any more)
         if sd['exp_avg'].numel() != self.total:
             raise ValueError('IdNetEngine.load_state_dict: %d moment elements for a %d-element layout'
                              % (sd['exp_avg'].numel(), self.total))
@@ -1608,5 +1650,5 @@ class IdNetEngine:
         self.lr, self.wd = float(sd['lr']), float(sd['weight_decay'])
         self.betas, self.eps = tuple(sd['betas']), float(sd['eps'])
         # row tags written by earlier steps of THIS process must not collide with resumed step numbers
-        for ws in self.__dict__.get('_ws_cache', {}).values():
-            ws.zero_()
+        if self._ws is not None:
+            self._ws.zero_()

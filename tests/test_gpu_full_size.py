@@ -390,3 +390,52 @@ def test_temporally_blocked_mf_sweep_is_the_dense_sweep_bit_for_bit(period, B, m
         blocked[1].train_step(*pool[3])
         with pytest.raises(RuntimeError, match='not the announced one'):
             blocked[1].check_announcements()
+
+
+@pytest.mark.parametrize('kind,L,period', [('MF', 32, 8), ('NeuMF', 32, 4), ('GMF', 10, 2), ('MLP', 24, 8)])
+def test_temporally_blocked_idnet_sweeps_are_the_dense_sweeps_bit_for_bit(kind, L, period, monkeypatch):
+    """r4r_idnet_step's table sweeps (one pair + the bias vectors in one launch; NeuMF's second pair in another, with
+    its own pending counts) blocked against plain, on Electronics-sized tables: eleven steps, dropout on, a ragged
+    batch, an evaluation, an announcement that is not kept -- parameters and moments identical to the bit."""
+    import reviews4rec_amd
+    from reviews4rec_amd import synthetic
+    from reviews4rec_amd.engine import IdNetEngine
+    monkeypatch.setenv('R4R_SWEEP_PERIOD', str(period))
+    U, I = 192403, 63001
+    hp = dict(model_type='MF' if kind == 'MF' else 'NeuMF', latent_size=L, dropout=0.3, total_users=U, total_items=I,
+              lr=0.002, weight_decay=1e-6, word_embed_size=16, input_length=10, batch_size=128)
+    if kind != 'MF':
+        hp['neumf_stage'] = kind
+    P = oracle.init_params(hp, vocab_size=None, seed=5)
+    pair = []
+    for _ in range(2):
+        model = reviews4rec_amd.get_model_class(hp['model_type'])(hp)
+        model.load_state_dict(P)
+        model = model.to(DEV).train()
+        pair.append((model, IdNetEngine(model, lr=hp['lr'], weight_decay=hp['weight_decay'], seed=9)))
+    plain, blocked = pair
+    assert blocked[1].sweep_period == period
+    gen = synthetic.Generator(dict(hp, vocab=0), seed=17)
+    pool = []
+    for k in range(5):
+        data, y = gen.batch(128 if k != 2 else 77)
+        pool.append(([None] * 5 + [torch.from_numpy(data[5]).to(DEV), torch.from_numpy(data[6]).to(DEV)], torch.from_numpy(y).to(DEV)))
+    pool[0][0][5][:2] = U                                    # the user table's last row (MF.py:21: U + 1 rows)
+    order = [0, 1, 2, 3, 4, 0, 3, 1, 4, 2, 0]
+    for s, k in enumerate(order):
+        nxt = pool[order[s + 1]][0] if s + 1 < len(order) else None
+        announced = pool[4][0] if s == 5 else nxt            # step 5 announces batch 4, step 6 trains on batch 3
+        plain[1].train_step(*pool[k])
+        blocked[1].train_step(*pool[k], next_data=announced, defer_sweep=True)
+        if s == 3:
+            assert torch.equal(plain[1].predict(pool[1][0])[0], blocked[1].predict(pool[1][0])[0])
+        if s == 8:
+            assert blocked[1]._tb_promised is not None
+    assert blocked[1]._tb_promised is None
+    blocked[1].check_announcements()
+    sa, sb = plain[0].state_dict(), blocked[0].state_dict()
+    for k in sa:
+        assert torch.equal(sa[k], sb[k]), k
+    (ma, va), (mb, vb) = plain[1].moments(), blocked[1].moments()
+    for k in ma:
+        assert torch.equal(ma[k], mb[k]) and torch.equal(va[k], vb[k]), k
