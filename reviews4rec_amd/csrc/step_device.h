@@ -124,7 +124,10 @@ __device__ __forceinline__ void narre_sweep_block(const RowSweep &w, int bx) {
     }
 }
 
-constexpr int NROW_EPW = 4;              // entries per wave of an entry workgroup (16 entries share one load of the ids)
+#ifndef R4R_NROW_EPW
+#define R4R_NROW_EPW 4
+#endif
+constexpr int NROW_EPW = R4R_NROW_EPW;              // entries per wave of an entry workgroup (16 entries share one load of the ids)
 // MW: 64-bit words of a lane's hit mask (entries <= 4096 MW: 1 in the fused single-process launch,
 // 4 in the stand-alone data-parallel launch); `sid`: LDS for the entry ids (entries ints).
 template <int ML, int MW>
