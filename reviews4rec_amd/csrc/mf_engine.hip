@@ -219,6 +219,9 @@ __device__ __forceinline__ void mf_stream_chunk(float *p, float *m, float *v, in
     }
 }
 
+#ifndef R4R_TB_PIPE
+#define R4R_TB_PIPE 1                  // (0: load, update, store in turn -- cfg2 4.33-4.40 M ratings/s against 4.85 M pipelined; cfg5 within 1 %)
+#endif
 #ifndef R4R_TB_BATCH
 #define R4R_TB_BATCH 2                 // float4 per array a thread has in flight (4: 160 VGPRs, 3 waves per SIMD -- cfg5's sweep 53 -> 74 us)
 #endif
@@ -257,6 +260,34 @@ __device__ __forceinline__ void mf_stream_chunk_tb(float *p, float *m, float *v,
     const int64_t nvec = cnt >> 2;
     constexpr int NV = MF_CHUNK / 4 / MF_THREADS, NB = R4R_TB_BATCH;     // float4 per thread and array; in flight together
     static_assert(NV % NB == 0, "batches of the thread's float4");
+#if R4R_TB_PIPE
+    // software pipeline: group g + 1's loads are requested before group g's updates (a wave's memory time and its
+    // arithmetic otherwise add up: every wave of the launch starts together and few of them carry work)
+    constexpr int NG = NV / NB;
+    mf_f32x4 P[2][NB], M[2][NB], V[2][NB];
+    auto load = [&](int g, mf_f32x4 (&Pg)[NB], mf_f32x4 (&Mg)[NB], mf_f32x4 (&Vg)[NB]) {
+#pragma unroll
+        for (int u = 0; u < NB; ++u) {
+            const int64_t i = tid + (int64_t)(g * NB + u) * MF_THREADS;
+            const int64_t ii = i < nvec ? i : 0;            // (the last chunk of a table: clamped, not stored)
+            Pg[u] = ld(p, ii); Mg[u] = ld(m, ii); Vg[u] = ld(v, ii);
+        }
+    };
+    load(0, P[0], M[0], V[0]);
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        if (g + 1 < NG) load(g + 1, P[(g + 1) & 1], M[(g + 1) & 1], V[(g + 1) & 1]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < NB; ++u) upd(P[g & 1][u], M[g & 1][u], V[g & 1][u]);
+#pragma unroll
+        for (int u = 0; u < NB; ++u) {
+            const int64_t i = tid + (int64_t)(g * NB + u) * MF_THREADS;
+            if (i < nvec) { st(p, i, P[g & 1][u]); st(m, i, M[g & 1][u]); st(v, i, V[g & 1][u]); }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#else
 #pragma unroll 1
     for (int u0 = 0; u0 < NV; u0 += NB) {
         mf_f32x4 P[NB], M[NB], V[NB];
@@ -274,6 +305,7 @@ __device__ __forceinline__ void mf_stream_chunk_tb(float *p, float *m, float *v,
             if (i < nvec) { st(p, i, P[u]); st(m, i, M[u]); st(v, i, V[u]); }
         }
     }
+#endif
     const int64_t k = (nvec << 2) + tid;                    // cnt % 4 elements at the end of a table
     if (k < cnt) {
         float P = p[k], M = m[k], V = v[k];
