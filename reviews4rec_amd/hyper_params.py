@@ -15,6 +15,9 @@ Namespaced extras understood by this package (all default to reference behaviour
   eval_batch_size  ratings per launch of a validation pass scored by a native engine (default 8 x batch_size; 4 x
                    batch_size rows for HR@1): same scores, fewer launches (eval.py)
   checkpoint_path  epoch-level resume file of main.train_complete (absent upstream)
+  sweep_period     1 .. 8 (default 8): visit period of the temporally blocked Adam sweeps over the ID tables of MF_dot /
+                   MF / NeuMF / TransNet++ in main.train's loop (same weights and moments as the dense sweep, bit for
+                   bit; 1 = the dense sweep every step; the environment's R4R_SWEEP_PERIOD overrides it)
 """
 import os
 
