@@ -439,3 +439,90 @@ def test_temporally_blocked_idnet_sweeps_are_the_dense_sweeps_bit_for_bit(kind, 
     (ma, va), (mb, vb) = plain[1].moments(), blocked[1].moments()
     for k in ma:
         assert torch.equal(ma[k], mb[k]) and torch.equal(va[k], vb[k]), k
+
+
+@pytest.mark.parametrize('family', ['MF_dot', 'transnet++', 'NeuMF'])
+def test_temporally_blocked_sweeps_under_a_random_schedule(family, monkeypatch):
+    """150 steps of whatever a host loop might do -- announced batches, announcements that are not kept, steps that
+    announce nothing, ragged batches, evaluations, optimiser state_dict round trips, a changing visit period -- the
+    blocked engine against the plain one after every tenth step and at the end: identical bits."""
+    import random
+    import reviews4rec_amd
+    from reviews4rec_amd import synthetic
+    from reviews4rec_amd.engine import MFEngine, TransNetEngine, IdNetEngine
+    rnd = random.Random(20200725)
+    U, I = 60000, 9000
+    if family == 'MF_dot':
+        hp = dict(synthetic.hyper_params_for('cfg2_mfdot_electronics', dropout=0.4), total_users=U, total_items=I)
+        mk = lambda m: MFEngine(m, lr=hp['lr'], weight_decay=hp['weight_decay'], seed=3)
+        P = oracle.init_params(hp, seed=7)
+        tables = ['user_embedding.weight', 'item_embedding.weight']
+    elif family == 'NeuMF':
+        hp = dict(model_type='NeuMF', neumf_stage='NeuMF', latent_size=16, dropout=0.4, total_users=U, total_items=I, lr=0.002,
+                  weight_decay=1e-6, word_embed_size=16, input_length=10, batch_size=64, vocab=0)
+        mk = lambda m: IdNetEngine(m, lr=hp['lr'], weight_decay=hp['weight_decay'], seed=3)
+        P = oracle.init_params(hp, vocab_size=None, seed=7)
+        tables = ['gmf_user_embedding.weight', 'mlp_item_embedding.weight']
+    else:
+        hp = dict(synthetic.hyper_params_for('cfg5_transnetpp_synthetic', dropout=0.4), total_users=U, total_items=I,
+                  input_length=40, vocab=2000)
+        mk = lambda m: TransNetEngine(m, lr=hp['lr'], weight_decay=hp['weight_decay'], seed=3)
+        P = oracle.init_params(hp, vocab_size=hp['vocab'], seed=7)
+        tables = ['user_embedding.weight', 'item_embedding.weight']
+    pair = []
+    for _ in range(2):
+        kw = dict(hp, word_vectors=P['target.word2vec.weight'].numpy()) if family == 'transnet++' else hp
+        model = reviews4rec_amd.get_model_class(hp['model_type'])(kw)
+        model.load_state_dict(P)
+        model = model.to(DEV).train()
+        pair.append((model, mk(model)))
+    plain, blocked = pair
+    gen = synthetic.Generator(hp, seed=5)
+    pool = []
+    for k in range(9):
+        data, y = gen.batch(rnd.choice([64, 64, 64, 41, 17]))
+        pool.append(([None if (d.shape[-1] == 1 and family != 'transnet++' and j < 5) else torch.from_numpy(d).to(DEV)
+                      for j, d in enumerate(data)], torch.from_numpy(y).to(DEV)))
+
+    def same(what):
+        blocked[1].flush()                                   # (whoever reads the Parameters directly brings them up to date first)
+        sa, sb = plain[0].state_dict(), blocked[0].state_dict()
+        assert all(torch.equal(sa[k], sb[k]) for k in sa), what
+        (ma, va), (mb, vb) = plain[1].moments(), blocked[1].moments()
+        assert all(torch.equal(ma[k], mb[k]) and torch.equal(va[k], vb[k]) for k in ma), what
+
+    cur = 0
+    behind = 0
+    for s in range(150):
+        nxt = rnd.randrange(9)
+        act = rnd.random()
+        if act < 0.70:
+            announced = pool[nxt][0]                         # the promise is kept
+        elif act < 0.85:
+            announced = pool[(nxt + 1) % 9][0]               # ... is not
+        else:
+            announced = None                                 # nothing announced: this step flushes
+        plain[1].train_step(*pool[cur])
+        blocked[1].train_step(*pool[cur], next_data=announced, defer_sweep=True)
+        if announced is not None:
+            behind += int(not torch.equal(getattr_path(plain[0], tables[0]), getattr_path(blocked[0], tables[0])))
+        cur = nxt
+        r = rnd.random()
+        if r < 0.06:
+            assert torch.equal(plain[1].predict(pool[2][0])[0], blocked[1].predict(pool[2][0])[0])
+        elif r < 0.10:
+            for _, e in pair:
+                e.load_state_dict(e.state_dict())            # resume from one's own state: nothing may be lost
+        elif r < 0.14:
+            blocked[1].sweep_period = rnd.choice([2, 3, 5, 8])
+        if s % 10 == 9:
+            same('after step %d' % s)
+    blocked[1].check_announcements()
+    same('at the end')
+    assert behind > 20                                       # the blocked tables really were behind between steps
+
+
+def getattr_path(obj, path):
+    for part in path.split('.'):
+        obj = getattr(obj, part)
+    return obj
