@@ -563,7 +563,8 @@ class MFEngine:
         self._tb_promised, tbn = None, None
         if next_data is not None and adam_step and self.has_tables and self.sweep_period > 1 and next_data[5].numel() > 0:
             nu, ni = next_data[5].reshape(-1).contiguous(), next_data[6].reshape(-1).contiguous()
-            tbn = (nu, ni, nu.numel())
+            if nu.is_cuda and ni.is_cuda and nu.dtype == torch.int64 and ni.dtype == torch.int64 and nu.numel() == ni.numel():
+                tbn = (nu, ni, nu.numel())                   # (anything else: nothing is announced, this step flushes)
         if n not in self._out:
             self._out[n] = (torch.empty(n, dtype=torch.float32, device=self.dev),
                             torch.empty(n, dtype=torch.float32, device=self.dev))
@@ -1482,7 +1483,8 @@ class IdNetEngine:
         self._tb_promised, tbn = None, None
         if next_data is not None and adam_step and self.dp is None and self.sweep_period > 1 and next_data[5].numel() > 0:
             nu, ni = next_data[5].reshape(-1).contiguous(), next_data[6].reshape(-1).contiguous()
-            tbn = (nu, ni, nu.numel())
+            if nu.is_cuda and ni.is_cuda and nu.dtype == torch.int64 and ni.dtype == torch.int64 and nu.numel() == ni.numel():
+                tbn = (nu, ni, nu.numel())                   # (anything else: nothing is announced, this step flushes)
         if adam_step and n > self.MAX_TRAIN_BATCH:
             raise RuntimeError('IdNetEngine: training batch %d > %d' % (n, self.MAX_TRAIN_BATCH))
         if n not in self._out:
