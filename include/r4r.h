@@ -573,7 +573,9 @@ int r4r_transnet_step(const float *table, int64_t V,
  * eps, weight_decay do not change while updates are pending; (3) r4r_transnet_rows_flush before anything else
  * reads or writes the tables or their moments (evaluation through r4r_transnet_step included).  A call WITHOUT
  * next_uid (or with P = 1) applies everything that is pending and leaves nothing behind: the plain dense sweep.
- * 1 <= P <= 8.  r4r_transnet_rows_flush: adam_step = the last completed step; same `ws` / shapes as the steps. */
+ * 1 <= P <= 8.  r4r_transnet_rows_flush: adam_step = the last completed step; same `ws` / shapes as the steps.
+ * The data-parallel update launches (r4r_*_rows_apply, r4r_mf_apply) run the plain sweep: nothing may be pending
+ * when they run (a caller that only ever passes next_uid = NULL never leaves anything pending). */
 int r4r_transnet_rows_flush(const uint64_t *rows_p, const uint64_t *rows_m, const uint64_t *rows_v,
                             int64_t n_users, int64_t n_items, void *ws, size_t ws_bytes,
                             int64_t B, int T, int E, int L, int64_t V,
