@@ -418,11 +418,18 @@ size_t r4r_mf_dp_block_bytes(int64_t B_pad, int D);
 int r4r_mf_grad(const int64_t *uid, const int64_t *iid, const float *y, const uint64_t *p,
                 int64_t n_users, int64_t n_items, int D, float *pred, float *se, void *block, float *mult,
                 int64_t B, int64_t B_pad, float dropout_p, int training, uint64_t seed, uint64_t offset,
-                float inv_denom, void *stream);
+                float inv_denom, const int64_t *next_uid, const int64_t *next_iid, int64_t next_B, void *stream);
 int r4r_mf_apply(const void *blocks, int world, int64_t B_pad, const uint64_t *p, const uint64_t *m,
                  const uint64_t *v, int64_t n_users, int64_t n_items, int D, void *ws, size_t ws_bytes,
+                 int sweep_period, int announce,
                  float lr, double beta1, double beta2, float eps, float weight_decay, int64_t adam_step,
                  void *stream);
+/* The temporally blocked sweep under data parallelism: r4r_mf_grad(next_uid / next_iid [next_B <= B_pad]) puts the ids
+ * of the shard THIS rank trains on next into its block (NULL: none, e.g. an empty next shard); after the all_gather
+ * every rank knows every rank's next ids, and r4r_mf_apply(sweep_period P, announce) -- the SAME P and announce on
+ * every rank -- brings the chunks any of them names up to date and visits the others every P-th step (contract at
+ * r4r_transnet_rows_flush; r4r_mf_rows_flush on every rank before anything else reads the tables).  announce = 0 or
+ * P = 1: the plain sweep, which also applies whatever is pending. */
 
 /* ---- fused native step for NARRE (pytorch_models/NARRE.py:10-124)
  * Replaces, per training step: the word gathers + TextCNN over the B*R review documents of each
@@ -574,8 +581,8 @@ int r4r_transnet_step(const float *table, int64_t V,
  * reads or writes the tables or their moments (evaluation through r4r_transnet_step included).  A call WITHOUT
  * next_uid (or with P = 1) applies everything that is pending and leaves nothing behind: the plain dense sweep.
  * 1 <= P <= 8.  r4r_transnet_rows_flush: adam_step = the last completed step; same `ws` / shapes as the steps.
- * The data-parallel update launches (r4r_*_rows_apply, r4r_mf_apply) run the plain sweep: nothing may be pending
- * when they run (a caller that only ever passes next_uid = NULL never leaves anything pending). */
+ * The data-parallel update launches r4r_*_rows_apply run the plain sweep: nothing may be pending when they run (a
+ * caller that only ever passes next_uid = NULL never leaves anything pending); r4r_mf_apply has the blocked form. */
 int r4r_transnet_rows_flush(const uint64_t *rows_p, const uint64_t *rows_m, const uint64_t *rows_v,
                             int64_t n_users, int64_t n_items, void *ws, size_t ws_bytes,
                             int64_t B, int T, int E, int L, int64_t V,

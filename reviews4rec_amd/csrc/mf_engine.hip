@@ -58,6 +58,9 @@ struct MfStep {
     const int64_t *next_uid = nullptr, *next_iid = nullptr;   // the announced next batch (temporally blocked sweep) ...
     int64_t next_B = 0;
     int *ntag_u = nullptr, *ntag_i = nullptr;       // ... and the chunk tags its rows get
+    int *nuid32 = nullptr, *niid32 = nullptr;       // data parallel: this rank's NEXT shard's ids into its block ([B_pad], -1 padded)
+    const int64_t *dp_next_uid = nullptr, *dp_next_iid = nullptr;
+    int64_t dp_next_B = 0;
     float *pred, *se, *sse_accum;
     int64_t B;
     int64_t B_pad = 0;                 // data parallel: rows [B, B_pad) of the entry arrays are filled as padding (id -1)
@@ -70,6 +73,11 @@ struct MfStep {
 __global__ __launch_bounds__(256) void mf_fwd_bwd_kernel(MfStep a) {
     const int lane = threadIdx.x & 63;
     const int64_t b = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (a.nuid32 && lane == 0 && b < a.B_pad) {             // (data parallel: the announced next shard rides in the block)
+        const bool has = a.dp_next_uid && b < a.dp_next_B;
+        a.nuid32[b] = has ? (int)a.dp_next_uid[b] : -1;
+        a.niid32[b] = has ? (int)a.dp_next_iid[b] : -1;
+    }
     if (b >= a.B) {                                         // whole wave
         if (b < a.B_pad && lane == 0) { a.uid32[b] = -1; a.iid32[b] = -1; a.g[b] = 0.f; }
         return;
@@ -1161,13 +1169,14 @@ extern "C" size_t r4r_mf_ws_flag_offset(int64_t B, int D, int64_t n_users, int64
 // entries past a rank's own count carry id -1 (ragged shards).
 namespace r4r {
 
-struct MfBlock { size_t uid, iid, g, gu, gi, bytes; };
+struct MfBlock { size_t uid, iid, g, gu, gi, nuid, niid, bytes; };
 static MfBlock mf_block(int64_t B_pad, int D) {
     MfBlock k;
     size_t o = 0;
     auto take = [&](size_t n) { size_t r = o; o += a256(n); return r; };
     k.uid = take((size_t)B_pad * 4); k.iid = take((size_t)B_pad * 4); k.g = take((size_t)B_pad * 4);
     k.gu = take((size_t)B_pad * D * 4); k.gi = take((size_t)B_pad * D * 4);
+    k.nuid = take((size_t)B_pad * 4); k.niid = take((size_t)B_pad * 4);      // the rank's announced next shard (-1: none)
     k.bytes = o;
     return k;
 }
@@ -1180,6 +1189,7 @@ struct MfRegister {
     int *tag_u, *tag_i, *uid32, *iid32;
     unsigned long long *first_u, *first_i, *last_u, *last_i;
     float *g, *gu, *gi;                // contiguous [world * B_pad] entry arrays for the update kernel
+    int *ctag_u = nullptr, *ctag_i = nullptr, *ntag_u = nullptr, *ntag_i = nullptr;   // temporally blocked sweep: chunk tags (NULL: not kept)
 };
 
 // one wave per gathered entry: ids, d loss / d pred and the two gradient rows into the contiguous
@@ -1202,6 +1212,18 @@ __global__ __launch_bounds__(256) void mf_register_kernel(MfRegister a) {
             atomicMax(a.last_u + u, lastv);
             atomicMax(a.last_i + i, lastv);
         }
+        if (a.ctag_u && a.D > 0) {                          // chunk tags of every rank's current and announced next ids
+            const int64_t D = a.D;
+            if (u >= 0) {
+                a.ctag_u[u * D / MF_CHUNK] = a.now; a.ctag_u[(u * D + D - 1) / MF_CHUNK] = a.now;
+                a.ctag_i[i * D / MF_CHUNK] = a.now; a.ctag_i[(i * D + D - 1) / MF_CHUNK] = a.now;
+            }
+            const int64_t nu = reinterpret_cast<const int *>(blk + a.k.nuid)[b], ni = reinterpret_cast<const int *>(blk + a.k.niid)[b];
+            if (nu >= 0) {
+                a.ntag_u[nu * D / MF_CHUNK] = a.now; a.ntag_u[(nu * D + D - 1) / MF_CHUNK] = a.now;
+                a.ntag_i[ni * D / MF_CHUNK] = a.now; a.ntag_i[(ni * D + D - 1) / MF_CHUNK] = a.now;
+            }
+        }
     }
     if (u >= 0)
         for (int d = lane; d < a.D; d += 64) {
@@ -1220,8 +1242,10 @@ extern "C" size_t r4r_mf_dp_block_bytes(int64_t B_pad, int D) {
 extern "C" int r4r_mf_grad(const int64_t *uid, const int64_t *iid, const float *y, const uint64_t *p,
                            int64_t n_users, int64_t n_items, int D, float *pred, float *se, void *block, float *mult,
                            int64_t B, int64_t B_pad, float dropout_p, int training, uint64_t seed, uint64_t offset,
-                           float inv_denom, void *stream) {
+                           float inv_denom, const int64_t *next_uid, const int64_t *next_iid, int64_t next_B, void *stream) {
     R4R_REQUIRE(p && pred && se && block, "mf_grad: null pointer");
+    R4R_REQUIRE(!next_uid == !next_iid && next_B >= 0 && next_B <= B_pad && (next_uid || next_B == 0),
+                "mf_grad: next_uid / next_iid go together, 0 <= next_B <= B_pad");
     R4R_REQUIRE(B == 0 || (uid && iid && y), "mf_grad: null ids / ratings");   // (an empty shard has none)
     R4R_REQUIRE(n_users > 0 && n_items > 0 && B >= 0 && B_pad >= B, "mf_grad: bad sizes");
     R4R_REQUIRE(D >= 0 && D <= MF_MAX_D, "mf_grad: latent_size %d outside 0..%d", D, MF_MAX_D);
@@ -1236,6 +1260,8 @@ extern "C" int r4r_mf_grad(const int64_t *uid, const int64_t *iid, const float *
     a.uid32 = reinterpret_cast<int *>(blk + k.uid); a.iid32 = reinterpret_cast<int *>(blk + k.iid);
     a.g = reinterpret_cast<float *>(blk + k.g); a.gu = reinterpret_cast<float *>(blk + k.gu);
     a.gi = reinterpret_cast<float *>(blk + k.gi); a.mult = mult;
+    a.nuid32 = reinterpret_cast<int *>(blk + k.nuid); a.niid32 = reinterpret_cast<int *>(blk + k.niid);
+    a.dp_next_uid = next_uid; a.dp_next_iid = next_iid; a.dp_next_B = next_B;
     a.pred = pred; a.se = se; a.B = B; a.B_pad = B_pad; a.register_rows = 0; a.D = D; a.training = training;
     a.want_grad = 1; a.tag = 0; a.p_drop = dropout_p; a.inv_denom = inv_denom; a.seed = seed; a.offset = offset;
     mf_fwd_bwd_kernel<<<(unsigned)cdiv(B_pad, 4), 256, 0, as_stream(stream)>>>(a);
@@ -1244,9 +1270,11 @@ extern "C" int r4r_mf_grad(const int64_t *uid, const int64_t *iid, const float *
 
 extern "C" int r4r_mf_apply(const void *blocks, int world, int64_t B_pad, const uint64_t *p, const uint64_t *m,
                             const uint64_t *v, int64_t n_users, int64_t n_items, int D, void *ws, size_t ws_bytes,
+                            int sweep_period, int announce,
                             float lr, double beta1, double beta2, float eps, float weight_decay, int64_t adam_step,
                             void *stream) {
     R4R_REQUIRE(blocks && p && m && v && ws, "mf_apply: null pointer");
+    R4R_REQUIRE(sweep_period >= 1 && sweep_period <= MF_TB_MAX, "mf_apply: sweep_period %d outside 1..%d", sweep_period, MF_TB_MAX);
     R4R_REQUIRE(world >= 1 && B_pad >= 0 && n_users > 0 && n_items > 0, "mf_apply: bad sizes");
     const int64_t B = (int64_t)world * B_pad;
     R4R_REQUIRE(B <= MF_MAX_B, "mf_apply: %lld gathered entries > %d", (long long)B, MF_MAX_B);
@@ -1265,6 +1293,10 @@ extern "C" int r4r_mf_apply(const void *blocks, int world, int64_t B_pad, const 
     rg.tag_u = w.tag_u; rg.tag_i = w.tag_i; rg.uid32 = w.uid32; rg.iid32 = w.iid32;
     rg.first_u = w.first_u; rg.first_i = w.first_i; rg.last_u = w.last_u; rg.last_i = w.last_i;
     rg.g = w.g; rg.gu = w.gu; rg.gi = w.gi;
+    // the temporally blocked sweep (rows_device.h) over the gathered entries: 16-byte aligned tables
+    const bool tb_on = D > 0 && (((p[0] | p[1] | m[0] | m[1] | v[0] | v[1]) & 15) == 0);
+    const bool tb_defer = tb_on && announce && sweep_period > 1;
+    if (tb_on) { rg.ctag_u = w.ctag_u; rg.ctag_i = w.ctag_i; rg.ntag_u = w.ntag_u; rg.ntag_i = w.ntag_i; }
     mf_register_kernel<<<(unsigned)cdiv(B, 4), 256, 0, st>>>(rg);
     float *P[MF_SLOTS], *M[MF_SLOTS], *V[MF_SLOTS];
     for (int k = 0; k < MF_SLOTS; ++k) {
@@ -1297,6 +1329,13 @@ extern "C" int r4r_mf_apply(const void *blocks, int world, int64_t B_pad, const 
     sw.uid = nullptr; sw.iid = nullptr; sw.gu = w.gu; sw.gi = w.gi; sw.g = w.g; sw.se = nullptr; sw.sse_accum = nullptr;
     sw.tag_u = w.tag_u; sw.tag_i = w.tag_i; sw.B = B; sw.D = D; sw.now = (int)adam_step;
     sw.s = adam_make_scalars(lr, beta1, beta2, eps, weight_decay, adam_step, nullptr);
+    if (tb_on) {
+        sw.ctag_u = w.ctag_u; sw.ctag_i = w.ctag_i;
+        sw.tb.lag_u = w.lag_u; sw.tb.lag_i = w.lag_i; sw.tb.ntag_u = w.ntag_u; sw.tb.ntag_i = w.ntag_i; sw.tb.err = w.tb_err;
+        sw.tb.period = tb_defer ? sweep_period : 1; sw.tb.flush = tb_defer ? 0 : 1; sw.tb.inc = 1;
+        mf_time_block_scalars(sw.tb, lr, beta1, beta2, eps, weight_decay, adam_step);
+        sw.nt = mf_sweep_nt(sw.n0 + sw.n1);
+    }
     if (B > 2048) mf_adam_kernel<8><<<(unsigned)chunks, MF_THREADS, 0, st>>>(sw);
     else mf_adam_kernel<4><<<(unsigned)chunks, MF_THREADS, 0, st>>>(sw);
     return check_launch("mf_apply");

@@ -587,13 +587,24 @@ class MFEngine:
         return pred, se
 
     @torch.no_grad()
-    def _train_step_dp(self, data, y, n_global):
+    def _train_step_dp(self, data, y, n_global, next_data=None):
         """Data parallel: this rank's compact gradient rows into a packed block, ONE
         all_gather of the blocks, then the same tagged sweep over all ranks' entries in rank order
-        on every rank (r4r_mf_grad / r4r_mf_apply): replicas stay bit-identical."""
+        on every rank (r4r_mf_grad / r4r_mf_apply): replicas stay bit-identical.  next_data (this rank's NEXT
+        shard; every rank passes one or none does): its ids ride in the block, and the sweep is temporally blocked
+        over what ALL ranks announced."""
         lib, dist = _lib.lib(), torch.distributed
         uid, iid = data[5].reshape(-1).contiguous(), data[6].reshape(-1).contiguous()
         n, world = uid.numel(), self.dp.world
+        if self._tb_promised is not None and (uid.data_ptr(), iid.data_ptr(), n) != self._tb_promised[0]:
+            self.flush(last_step=self.step_count - 1)        # (every rank takes the same branch: the loops run in lockstep)
+        self._tb_promised, tbn = None, None
+        # (only with the global count known: every shard, the next one included, then fits hyper_params['batch_size'],
+        # and every rank decides the same way)
+        announce = next_data is not None and self.has_tables and self.sweep_period > 1 and n_global is not None
+        if announce:
+            nu, ni = next_data[5].reshape(-1).contiguous(), next_data[6].reshape(-1).contiguous()
+            tbn = (nu, ni, nu.numel())                       # (an empty next shard announces nothing of its own)
         B_pad = int(self.hp.get('batch_size', 0))            # every rank's shard fits the configured batch: pad to it
         if n_global is not None and n > B_pad:
             # (taking the size-agreement branch on THIS rank only would leave the others in a different
@@ -617,13 +628,18 @@ class MFEngine:
         _lib.check(lib.r4r_mf_grad(ptr(uid), ptr(iid), ptr(y), self._ptrs(self.params), self.n_users, self.n_items, self.D,
                                    ptr(pred), ptr(se), ptr(block), None, n, B_pad, float(self.hp['dropout']),
                                    int(self.model.training), self.seed, self.offset, 1.0 / float(n_global),
-                                   _lib.current_stream()), 'r4r_mf_grad')
+                                   ptr(tbn[0]) if (tbn and tbn[2]) else None, ptr(tbn[1]) if (tbn and tbn[2]) else None,
+                                   tbn[2] if tbn else 0, _lib.current_stream()), 'r4r_mf_grad')
         self.dp.all_gather(blocks, block)
         ws = self._workspace(world * B_pad)
         _lib.check(lib.r4r_mf_apply(ptr(blocks), world, B_pad, self._ptrs(self.params), self._ptrs(self.m),
                                     self._ptrs(self.v), self.n_users, self.n_items, self.D, ptr(ws), ws.numel(),
+                                    self.sweep_period, int(announce),
                                     self.lr, self.betas[0], self.betas[1], self.eps, self.wd, int(self.step_count),
                                     _lib.current_stream()), 'r4r_mf_apply')
+        if tbn is not None:
+            self._tb_promised = ((tbn[0].data_ptr(), tbn[1].data_ptr(), tbn[2]), tbn)
+            self._tb_used = True
         if self.model.training and float(self.hp['dropout']) > 0.0:
             self.offset += n * 2 * self.D
         self.sse += se[:n].sum()                             # this rank's share; the host loop sums the ranks
@@ -643,7 +659,7 @@ class MFEngine:
             return torch.empty(0, dtype=torch.float32, device=self.dev)
         self.step_count += 1
         if self.dp is not None:
-            return self._train_step_dp(data, y, n_global)
+            return self._train_step_dp(data, y, n_global, next_data if defer_sweep else None)
         _, se = self._launch(data, y, self.model.training, 1.0 / float(n_global if n_global is not None else n),
                              self.step_count, next_data if defer_sweep else None)
         return se

@@ -157,19 +157,26 @@ def _mf_worker(rank, world, port, case, out_dir):
     eng = M.make_engine(dict(hp, engine='auto', batch_size=64), model, dp=dp, rank=rank)
     assert isinstance(eng, MFEngine) and eng.dp is not None
     ses = []
+    defer = os.environ.get('R4R_TEST_DEFER') == '1'          # the temporally blocked sweep over all ranks' announced next shards
+    shards = [r4dist.shard_batch(*g.batch(step % 2, 'cuda'), rank, world) for step in range(4)]
     for step in range(3):
         data, y = g.batch(step % 2, 'cuda')
-        sd, sy = r4dist.shard_batch(data, y, rank, world)            # ragged: the ranks' shards differ in length
+        sd, sy = shards[step]                                        # ragged: the ranks' shards differ in length
         # (with the global count known the shards are padded to hyper_params['batch_size'] and no sizes are
         # exchanged; without it the ranks agree on the sizes first: both forms)
-        ses.append(eng.train_step(sd, sy, n_global=int(y.shape[0]) if step != 1 else None).cpu().clone())
+        kw = dict(next_data=shards[step + 1][0] if step < 2 else None, defer_sweep=True) if defer else {}
+        ses.append(eng.train_step(sd, sy, n_global=int(y.shape[0]) if step != 1 else None, **kw).cpu().clone())
+        if defer and step == 0:
+            assert eng._tb_promised is not None              # (step 1 does not know the global count: it flushes)
+    if defer:
+        eng.flush()
     torch.save({'w': {k: v.detach().cpu() for k, v in model.state_dict().items()}, 'se': ses},
                os.path.join(out_dir, 'm%d.pt' % rank))
     torch.distributed.destroy_process_group()
 
 
-@pytest.mark.parametrize('case', ['mf_dot', 'mf_bias_only'])
-def test_dp2_native_mf_step_equals_the_single_process_step(tmp_path, case):
+@pytest.mark.parametrize('case', ['mf_dot', 'mf_bias_only', 'mf_dot+blocked'])
+def test_dp2_native_mf_step_equals_the_single_process_step(tmp_path, case, monkeypatch):
     """MF under data parallelism on the native step (r4r_mf_grad -> all_gather of the packed compact
     rows -> r4r_mf_apply): 2 ranks x ragged shards reproduce the reference's 3 single-process steps,
     replicas bit-identical -- and identical, bit for bit, to the single-process native step on the
@@ -178,6 +185,9 @@ def test_dp2_native_mf_step_equals_the_single_process_step(tmp_path, case):
     from helpers import Golden
     from test_gpu_models import build_model
     from reviews4rec_amd.engine import MFEngine
+    if case.endswith('+blocked'):                            # ... with every rank announcing its next shard (r4r.h)
+        case = case[:-len('+blocked')]
+        monkeypatch.setenv('R4R_TEST_DEFER', '1')
     port = _free_port()
     mp.spawn(_mf_worker, args=(2, port, case, str(tmp_path)), nprocs=2, join=True)
     g = Golden(case)
