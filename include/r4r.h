@@ -581,8 +581,8 @@ int r4r_transnet_step(const float *table, int64_t V,
  * reads or writes the tables or their moments (evaluation through r4r_transnet_step included).  A call WITHOUT
  * next_uid (or with P = 1) applies everything that is pending and leaves nothing behind: the plain dense sweep.
  * 1 <= P <= 8.  r4r_transnet_rows_flush: adam_step = the last completed step; same `ws` / shapes as the steps.
- * The data-parallel update launches r4r_*_rows_apply run the plain sweep: nothing may be pending when they run (a
- * caller that only ever passes next_uid = NULL never leaves anything pending); r4r_mf_apply has the blocked form. */
+ * Of the data-parallel update launches r4r_mf_apply and r4r_transnet_rows_apply have the blocked form; the others
+ * (r4r_idnet_rows_apply, ...) run the plain sweep: nothing may be pending when they run. */
 int r4r_transnet_rows_flush(const uint64_t *rows_p, const uint64_t *rows_m, const uint64_t *rows_v,
                             int64_t n_users, int64_t n_items, void *ws, size_t ws_bytes,
                             int64_t B, int T, int E, int L, int64_t V,
@@ -593,8 +593,11 @@ int r4r_transnet_rows_flush(const uint64_t *rows_p, const uint64_t *rows_m, cons
  * the compact ID-vector rows at r4r_transnet_ws_offset 1 / 2), exchange -- all-reduce flat_g and apply
  * r4r_adam_multi; all_gather the ranks' (uid, iid, gradient rows), ids -1 padding ragged shards --
  * then update the ID-vector tables from ALL ranks' rows (same `ws` and shape arguments as the step:
- * the row tags live there).  B_all <= 16384. */
+ * the row tags live there).  B_all <= 16384.  next_uid_all / next_iid_all [B_all] (ids -1: none) + sweep_period +
+ * announce: the gathered ids of every rank's NEXT shard -- the sweep is then temporally blocked over what all ranks
+ * announced (the same period and announce on every rank; contract above; r4r_transnet_rows_flush on every rank). */
 int r4r_transnet_rows_apply(const int64_t *uid_all, const int64_t *iid_all, const float *gu_all, const float *gi_all,
+                            const int64_t *next_uid_all, const int64_t *next_iid_all, int sweep_period, int announce,
                             int64_t B_all, const uint64_t *rows_p, const uint64_t *rows_m, const uint64_t *rows_v,
                             int64_t n_users, int64_t n_items, void *ws, size_t ws_bytes,
                             int64_t B, int T, int E, int L, int64_t V,

@@ -652,9 +652,15 @@ extern "C" int r4r_transnet_rows_flush(const uint64_t *rows_p, const uint64_t *r
 // (flat_m == NULL).  `ws` and the shape arguments are the step's: the row / chunk tags live there.
 namespace r4r {
 __global__ void tn_tag_rows_kernel(const int64_t *uid, const int64_t *iid, int64_t n, int *tag_u, int *tag_i, int *ctag_u,
-                                   int *ctag_i, int now) {
+                                   int *ctag_i, int now, const int64_t *next_uid, const int64_t *next_iid, int *ntag_u,
+                                   int *ntag_i) {
     const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= n) return;
+    if (next_uid && next_uid[e] >= 0) {                     // what some rank announced for its next shard (temporally blocked sweep)
+        const int64_t nu = next_uid[e], ni = next_iid[e];
+        ntag_u[nu * TN_ID / MF_CHUNK] = now; ntag_u[(nu * TN_ID + TN_ID - 1) / MF_CHUNK] = now;
+        ntag_i[ni * TN_ID / MF_CHUNK] = now; ntag_i[(ni * TN_ID + TN_ID - 1) / MF_CHUNK] = now;
+    }
     const int64_t u = uid[e], i = iid[e];
     if (u < 0) return;
     tag_u[u] = now; tag_i[i] = now;
@@ -664,7 +670,8 @@ __global__ void tn_tag_rows_kernel(const int64_t *uid, const int64_t *iid, int64
 }  // namespace r4r
 
 extern "C" int r4r_transnet_rows_apply(const int64_t *uid_all, const int64_t *iid_all, const float *gu_all,
-                                       const float *gi_all, int64_t B_all,
+                                       const float *gi_all, const int64_t *next_uid_all, const int64_t *next_iid_all,
+                                       int sweep_period, int announce, int64_t B_all,
                                        const uint64_t *rows_p, const uint64_t *rows_m, const uint64_t *rows_v,
                                        int64_t n_users, int64_t n_items, void *ws, size_t ws_bytes,
                                        int64_t B, int T, int E, int L, int64_t V,
@@ -672,6 +679,8 @@ extern "C" int r4r_transnet_rows_apply(const int64_t *uid_all, const int64_t *ii
                                        void *stream) {
     R4R_REQUIRE(uid_all && iid_all && gu_all && gi_all && rows_p && rows_m && rows_v && ws, "transnet_rows_apply: null pointer");
     R4R_REQUIRE(B_all >= 0 && B_all <= 16384, "transnet_rows_apply: %lld gathered ratings outside 0..16384", (long long)B_all);
+    R4R_REQUIRE(sweep_period >= 1 && sweep_period <= MF_TB_MAX && !next_uid_all == !next_iid_all,
+                "transnet_rows_apply: sweep_period outside 1..%d, or only one of the next-id arrays", MF_TB_MAX);
     R4R_REQUIRE(adam_step >= 1 && adam_step < (1ll << 31), "transnet_rows_apply: bad adam_step");
     if (ws_bytes < r4r_transnet_ws_bytes(B, T, E, L, 1, V, n_users, n_items)) {
         set_error("transnet_rows_apply: workspace %zu < %zu bytes", ws_bytes, r4r_transnet_ws_bytes(B, T, E, L, 1, V, n_users, n_items));
@@ -686,9 +695,16 @@ extern "C" int r4r_transnet_rows_apply(const int64_t *uid_all, const int64_t *ii
         rv[t] = reinterpret_cast<float *>(rows_v[t]);
         R4R_REQUIRE(rp[t] && rm[t] && rv[t], "transnet_rows_apply: ID-vector table %d: null pointer", t);
     }
+    // the gathered entries' sweep, temporally blocked over what ALL ranks announced (the same period / announce on every rank)
+    const bool defer = announce && next_uid_all && sweep_period > 1;
     tn_tag_rows_kernel<<<(unsigned)cdiv(B_all, 256), 256, 0, st>>>(uid_all, iid_all, B_all, w.tag[0], w.tag[1], w.ctag[0],
-                                                                 w.ctag[1], (int)adam_step);
+                                                                 w.ctag[1], (int)adam_step, defer ? next_uid_all : nullptr,
+                                                                 defer ? next_iid_all : nullptr, w.ntag[0], w.ntag[1]);
     const AdamScalars sc = adam_make_scalars(lr, beta1, beta2, eps, weight_decay, adam_step, nullptr);
+    MfTimeBlock tb{};
+    tb.lag_u = w.lag[0]; tb.lag_i = w.lag[1]; tb.ntag_u = w.ntag[0]; tb.ntag_i = w.ntag[1]; tb.err = w.tb_err;
+    tb.period = defer ? sweep_period : 1; tb.flush = defer ? 0 : 1; tb.inc = 1;
+    mf_time_block_scalars(tb, lr, beta1, beta2, eps, weight_decay, adam_step);
     return mf_table_rows_launch(rp[0], rm[0], rv[0], rp[1], rm[1], rv[1], n_users, n_items, TN_ID, uid_all, iid_all, gu_all,
-                                gi_all, w.tag[0], w.tag[1], w.ctag[0], w.ctag[1], B_all, (int)adam_step, sc, st);
+                                gi_all, w.tag[0], w.tag[1], w.ctag[0], w.ctag[1], B_all, (int)adam_step, sc, st, &tb);
 }

@@ -940,6 +940,9 @@ class NarreEngine(_ConvRule):
             vals[:n, base:base + L] = grow[:n]
             vals[:n, base + L:base + (1 + R) * L] = grow[n:].reshape(n, R * L)
 
+    def _dp_payload_next(self, ids):
+        """Families whose data-parallel sweep is temporally blocked put the ids of the rank's NEXT shard here."""
+
     def _dp_apply(self, all_ids, all_vals, B_all, ws, nb, R, T):
         L = self.L
         gids, grows = [], []
@@ -992,6 +995,7 @@ class NarreEngine(_ConvRule):
         if n > 0:
             f, _, R, T = self._fields(data)
             self._dp_payload(f, n, R, T, ids, vals)
+        self._dp_payload_next(ids)                           # (also from a rank whose CURRENT shard is empty)
         all_ids = torch.empty((world, B_pad, id_cols), dtype=torch.int64, device=self.dev)
         all_vals = torch.empty((world, B_pad, val_cols), dtype=torch.float32, device=self.dev)
         self.dp.all_gather(all_ids.view(-1), ids.view(-1))
@@ -1325,14 +1329,44 @@ class TransNetEngine(NarreEngine):
         return 1, int(data[3].shape[-1])
 
     def _dp_cols(self, R):
-        return 2, 10
+        return 4, 10                                         # ids: uid, iid, and the rank's announced NEXT uid, iid (-1: none)
+
+    def _dp_payload_next(self, ids):
+        nxt = self.__dict__.get('_dp_tb')
+        if nxt is not None and nxt[2] > 0:
+            ids[:nxt[2], 2], ids[:nxt[2], 3] = nxt[0], nxt[1]
+
+    @torch.no_grad()
+    def _train_step_dp(self, data, y, n_global, next_data):
+        # the temporally blocked sweep under data parallelism: every rank announces its next shard (or none does) and
+        # every rank flushes at the same steps -- the loops run in lockstep, and so do these decisions
+        n = data[5].numel()
+        key = (data[5].reshape(-1).data_ptr(), data[6].reshape(-1).data_ptr(), n)
+        if self._tb_promised is not None and key != self._tb_promised[0]:
+            self.flush(last_step=self.step_count)            # (this step has not counted itself yet)
+        self._tb_promised, self._dp_tb = None, None
+        if (self._defer_req and self.plus and next_data is not None and self.sweep_period > 1 and n_global is not None
+                and next_data[5].numel() <= int(self.hp.get('batch_size', 0))):
+            nu, ni = next_data[5].reshape(-1).contiguous(), next_data[6].reshape(-1).contiguous()
+            self._dp_tb = (nu, ni, nu.numel())
+        try:
+            se = super()._train_step_dp(data, y, n_global, next_data)
+            if self._dp_tb is not None:
+                nu, ni, nn = self._dp_tb
+                self._tb_promised = ((nu.data_ptr(), ni.data_ptr(), nn), self._dp_tb)
+                self._tb_used = True
+        finally:
+            self._dp_tb_announced, self._dp_tb = self._dp_tb is not None, None
+        return se
 
     def _dp_apply(self, all_ids, all_vals, B_all, ws, nb, R, T):
         uid_all, iid_all = all_ids[:, 0].contiguous(), all_ids[:, 1].contiguous()
+        nu_all, ni_all = all_ids[:, 2].contiguous(), all_ids[:, 3].contiguous()
         gu_all, gi_all = all_vals[:, :5].contiguous(), all_vals[:, 5:].contiguous()
         p2 = lambda ts: (ctypes.c_uint64 * 2)(*[t.data_ptr() for t in ts])   # noqa: E731
         _lib.check(_lib.lib().r4r_transnet_rows_apply(
-            ptr(uid_all), ptr(iid_all), ptr(gu_all), ptr(gi_all), B_all, p2(self.rows), p2(self.rows_m), p2(self.rows_v),
+            ptr(uid_all), ptr(iid_all), ptr(gu_all), ptr(gi_all), ptr(nu_all), ptr(ni_all), self.sweep_period,
+            int(self.__dict__.get('_dp_tb') is not None), B_all, p2(self.rows), p2(self.rows_m), p2(self.rows_v),
             self.n_users, self.n_items, ptr(ws), ws.numel(), nb, T, self.E, self.L, self.V, self.lr, self.betas[0],
             self.betas[1], self.eps, self.wd, int(self.step_count), _lib.current_stream()), 'r4r_transnet_rows_apply')
 

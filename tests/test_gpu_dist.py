@@ -291,6 +291,74 @@ def _transnet_worker(rank, world, port, case, out_dir):
     torch.distributed.destroy_process_group()
 
 
+def _blocked_dp_worker(rank, world, port, family, defer, out_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, TESTS)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank), R4R_DIST_BACKEND=os.environ.get('R4R_TEST_BACKEND', 'gloo'), R4R_DP_SINGLE='',
+                      R4R_SWEEP_PERIOD='4')
+    import oracle
+    import reviews4rec_amd
+    from reviews4rec_amd import dist as r4dist, main as M, synthetic
+    r4dist.init_from_env()
+    if family == 'MF_dot':
+        hp = dict(synthetic.hyper_params_for('cfg2_mfdot_electronics', dropout=0.3), total_users=30000, total_items=9000, batch_size=64)
+        P = oracle.init_params(hp, seed=11)
+        model = reviews4rec_amd.get_model_class('MF_dot')(hp)
+    else:
+        hp = dict(synthetic.hyper_params_for('cfg5_transnetpp_synthetic', dropout=0.3), total_users=60000, total_items=9000,
+                  input_length=40, vocab=2000, batch_size=64)
+        P = oracle.init_params(hp, vocab_size=hp['vocab'], seed=11)
+        model = reviews4rec_amd.get_model_class('transnet++')(dict(hp, word_vectors=P['target.word2vec.weight'].numpy()))
+    model.load_state_dict(P)
+    model = model.cuda().train()
+    dp = r4dist.DataParallel(model)
+    dp.broadcast_parameters()
+    eng = M.make_engine(dict(hp, engine='auto'), model, dp=dp, rank=rank)
+    assert eng is not None and eng.dp is not None and eng.sweep_period == 4
+    gen = synthetic.Generator(hp, seed=21)                   # (the same stream on every rank: each takes its shard)
+    shards = []
+    for k in range(6):
+        data, y = gen.batch(96 if k != 3 else 51)            # global batches; the ranks' shards are ragged
+        data = [None if (d.shape[-1] == 1 and family == 'MF_dot' and j < 5) else torch.from_numpy(d).cuda() for j, d in enumerate(data)]
+        shards.append((r4dist.shard_batch(data, torch.from_numpy(y).cuda(), rank, world), int(y.shape[0])))
+    order = [0, 1, 2, 3, 4, 5, 1, 3, 0]
+    for s, k in enumerate(order):
+        (sd, sy), n_global = shards[k]
+        nxt = shards[order[s + 1]][0][0] if s + 1 < len(order) else None
+        if s == 4:
+            nxt = shards[2][0][0]                            # an announcement that is not kept (step 5 trains on batch 5)
+        if s == 6:
+            nxt = None                                       # a step that announces nothing
+        if defer:
+            eng.train_step(sd, sy, n_global=n_global, next_data=nxt, defer_sweep=True)
+        else:
+            eng.train_step(sd, sy, n_global=n_global)
+    eng.flush()
+    m, v = eng.moments()
+    torch.save({'w': {k: t.detach().cpu() for k, t in model.state_dict().items()},
+                'm': {k: t.detach().cpu() for k, t in m.items()}, 'v': {k: t.detach().cpu() for k, t in v.items()},
+                'used': bool(getattr(eng, '_tb_used', False))}, os.path.join(out_dir, 'b%d_%d.pt' % (int(defer), rank)))
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.parametrize('family', ['MF_dot', 'transnet++'])
+def test_dp2_blocked_sweep_equals_the_plain_sweep(tmp_path, family):
+    """The temporally blocked sweep under data parallelism (every rank's next ids ride in the gathered payload;
+    r4r_mf_apply / r4r_transnet_rows_apply block over what ALL ranks announced): 2 ranks x 9 steps of ragged shards,
+    with an announcement that is not kept and a step that announces nothing -- parameters and both moments identical,
+    bit for bit, across the ranks and to the same run with the plain sweep."""
+    for defer in (0, 1):
+        mp.spawn(_blocked_dp_worker, args=(2, _free_port(), family, defer, str(tmp_path)), nprocs=2, join=True)
+    runs = {(d, r): torch.load(os.path.join(tmp_path, 'b%d_%d.pt' % (d, r))) for d in (0, 1) for r in (0, 1)}
+    assert runs[(1, 0)]['used'] and not runs[(0, 0)]['used']
+    ref = runs[(0, 0)]
+    for key, run in runs.items():
+        for part in ('w', 'm', 'v'):
+            for k, t in ref[part].items():
+                assert torch.equal(run[part][k], t), (key, part, k)
+
+
 @pytest.mark.parametrize('case', ['transnet_e16', 'transnetpp_e16'])
 def test_dp2_native_transnet_step_follows_the_reference_trajectory(tmp_path, case):
     """TransNet(++) under data parallelism on the native step: gradients only per rank, one all-reduce
