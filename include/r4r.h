@@ -581,8 +581,8 @@ int r4r_transnet_step(const float *table, int64_t V,
  * reads or writes the tables or their moments (evaluation through r4r_transnet_step included).  A call WITHOUT
  * next_uid (or with P = 1) applies everything that is pending and leaves nothing behind: the plain dense sweep.
  * 1 <= P <= 8.  r4r_transnet_rows_flush: adam_step = the last completed step; same `ws` / shapes as the steps.
- * Of the data-parallel update launches r4r_mf_apply and r4r_transnet_rows_apply have the blocked form; the others
- * (r4r_idnet_rows_apply, ...) run the plain sweep: nothing may be pending when they run. */
+ * The data-parallel update launches of the families above (r4r_mf_apply, r4r_transnet_rows_apply,
+ * r4r_idnet_rows_apply) have the blocked form too: the gathered payload carries every rank's next ids. */
 int r4r_transnet_rows_flush(const uint64_t *rows_p, const uint64_t *rows_m, const uint64_t *rows_v,
                             int64_t n_users, int64_t n_items, void *ws, size_t ws_bytes,
                             int64_t B, int T, int E, int L, int64_t V,
@@ -646,9 +646,12 @@ int r4r_idnet_rows_flush(int variant, const uint64_t *rows_p, const uint64_t *ro
  * d loss/d pred [B] and the compact rows [B, L] per table: r4r_idnet_ws_offset 1, 4..7); after the exchange --
  * all-reduce flat_g + r4r_adam_multi; all_gather of (uid, iid, d loss/d pred, rows), ids -1 padding ragged
  * shards -- the ID tables and bias vectors are updated from ALL ranks' rows.  gu_all / gi_all: HOST arrays of
- * 2 device pointers ([B_all, L] rows of the first / second table pair).  `ws`, B: the step's own.  B_all <= 16384. */
+ * 2 device pointers ([B_all, L] rows of the first / second table pair).  `ws`, B: the step's own.  B_all <= 16384.
+ * next_uid_all / next_iid_all / sweep_period / announce: as for r4r_transnet_rows_apply. */
 int r4r_idnet_rows_apply(int variant, const int64_t *uid_all, const int64_t *iid_all, const float *g_all,
-                         const uint64_t *gu_all, const uint64_t *gi_all, int64_t B_all,
+                         const uint64_t *gu_all, const uint64_t *gi_all,
+                         const int64_t *next_uid_all, const int64_t *next_iid_all, int sweep_period, int announce,
+                         int64_t B_all,
                          const uint64_t *rows_p, const uint64_t *rows_m, const uint64_t *rows_v,
                          int64_t n_users, int64_t n_items, void *ws, size_t ws_bytes, int64_t B, int L,
                          float lr, double beta1, double beta2, float eps, float weight_decay,

@@ -514,16 +514,31 @@ extern "C" int r4r_idnet_rows_flush(int variant, const uint64_t *rows_p, const u
 // arrays of 2 entries; the second pair only for NeuMF); g_all [B_all].  `ws` and B are the step's own: the row
 // tags live in the workspace's persistent head.
 namespace r4r {
-__global__ void idn_tag_rows_kernel(const int64_t *uid, const int64_t *iid, int64_t n, int *tag_u, int *tag_i, int now) {
+__global__ void idn_tag_rows_kernel(const int64_t *uid, const int64_t *iid, int64_t n, int *tag_u, int *tag_i, int now,
+                                    int L, int *ctag_u, int *ctag_i, const int64_t *next_uid, const int64_t *next_iid,
+                                    int *ntag_u, int *ntag_i) {
     const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= n || uid[e] < 0) return;
+    if (e >= n) return;
+    if (next_uid && next_uid[e] >= 0) {                     // what some rank announced for its next shard (temporally blocked sweeps)
+        const int64_t u0 = next_uid[e] * L, i0 = next_iid[e] * L;
+        ntag_u[u0 / MF_CHUNK] = now; ntag_u[(u0 + L - 1) / MF_CHUNK] = now;
+        ntag_i[i0 / MF_CHUNK] = now; ntag_i[(i0 + L - 1) / MF_CHUNK] = now;
+    }
+    if (uid[e] < 0) return;
     tag_u[uid[e]] = now;
     tag_i[iid[e]] = now;
+    if (ctag_u) {
+        const int64_t u0 = uid[e] * L, i0 = iid[e] * L;
+        ctag_u[u0 / MF_CHUNK] = now; ctag_u[(u0 + L - 1) / MF_CHUNK] = now;
+        ctag_i[i0 / MF_CHUNK] = now; ctag_i[(i0 + L - 1) / MF_CHUNK] = now;
+    }
 }
 }  // namespace r4r
 
 extern "C" int r4r_idnet_rows_apply(int variant, const int64_t *uid_all, const int64_t *iid_all, const float *g_all,
-                                    const uint64_t *gu_all, const uint64_t *gi_all, int64_t B_all,
+                                    const uint64_t *gu_all, const uint64_t *gi_all,
+                                    const int64_t *next_uid_all, const int64_t *next_iid_all, int sweep_period, int announce,
+                                    int64_t B_all,
                                     const uint64_t *rows_p, const uint64_t *rows_m, const uint64_t *rows_v,
                                     int64_t n_users, int64_t n_items, void *ws, size_t ws_bytes, int64_t B, int L,
                                     float lr, double beta1, double beta2, float eps, float weight_decay,
@@ -532,6 +547,8 @@ extern "C" int r4r_idnet_rows_apply(int variant, const int64_t *uid_all, const i
     R4R_REQUIRE(variant >= 0 && variant <= IDN_NEUMF && L > 0 && L <= IDN_MAX_L, "idnet_rows_apply: bad variant / latent_size");
     R4R_REQUIRE(B_all >= 0 && B_all <= 16384, "idnet_rows_apply: %lld gathered ratings outside 0..16384", (long long)B_all);
     R4R_REQUIRE(adam_step >= 1 && adam_step < (1ll << 31), "idnet_rows_apply: bad adam_step");
+    R4R_REQUIRE(sweep_period >= 1 && sweep_period <= MF_TB_MAX && !next_uid_all == !next_iid_all,
+                "idnet_rows_apply: sweep_period outside 1..%d, or only one of the next-id arrays", MF_TB_MAX);
     if (ws_bytes < r4r_idnet_ws_bytes(variant, B, L, n_users, n_items)) {
         set_error("idnet_rows_apply: workspace %zu < %zu bytes", ws_bytes, r4r_idnet_ws_bytes(variant, B, L, n_users, n_items));
         return R4R_ERR_WORKSPACE;
@@ -547,8 +564,23 @@ extern "C" int r4r_idnet_rows_apply(int variant, const int64_t *uid_all, const i
         rv[k] = reinterpret_cast<float *>(rows_v[k]);
         R4R_REQUIRE(!used || (rp[k] && rm[k] && rv[k]), "idnet_rows_apply: table / bias %d: null pointer", k);
     }
-    idn_tag_rows_kernel<<<(unsigned)cdiv(B_all, 256), 256, 0, st>>>(uid_all, iid_all, B_all, w.tag[0], w.tag[1], (int)adam_step);
+    // the gathered entries' sweeps, temporally blocked over what ALL ranks announced (16-byte aligned tables; the same
+    // period / announce on every rank)
+    bool tb_on = true;
+    for (int k = 0; k < 2 * npair; ++k) tb_on = tb_on && ((rows_p[k] | rows_m[k] | rows_v[k]) & 15) == 0;
+    const bool defer = tb_on && announce && next_uid_all && sweep_period > 1;
+    idn_tag_rows_kernel<<<(unsigned)cdiv(B_all, 256), 256, 0, st>>>(uid_all, iid_all, B_all, w.tag[0], w.tag[1], (int)adam_step, L,
+                                                                  tb_on ? w.ctag[0] : nullptr, tb_on ? w.ctag[1] : nullptr,
+                                                                  defer ? next_uid_all : nullptr, defer ? next_iid_all : nullptr,
+                                                                  w.ntag[0], w.ntag[1]);
     const AdamScalars sc = adam_make_scalars(lr, beta1, beta2, eps, weight_decay, adam_step, nullptr);
+    MfTimeBlock tb[2];
+    for (int pr = 0; pr < 2; ++pr) {
+        tb[pr] = MfTimeBlock{};
+        tb[pr].lag_u = w.lag[pr][0]; tb[pr].lag_i = w.lag[pr][1]; tb[pr].ntag_u = w.ntag[0]; tb[pr].ntag_i = w.ntag[1];
+        tb[pr].err = w.tb_err; tb[pr].period = defer ? sweep_period : 1; tb[pr].flush = defer ? 0 : 1; tb[pr].inc = 1;
+        mf_time_block_scalars(tb[pr], lr, beta1, beta2, eps, weight_decay, adam_step);
+    }
     const float *gu[2], *gi[2];
     for (int pr = 0; pr < npair; ++pr) {
         gu[pr] = reinterpret_cast<const float *>(gu_all[pr]); gi[pr] = reinterpret_cast<const float *>(gi_all[pr]);
@@ -556,10 +588,12 @@ extern "C" int r4r_idnet_rows_apply(int variant, const int64_t *uid_all, const i
     }
     if (int rc = mf_table_bias_rows_launch(rp[0], rm[0], rv[0], rp[1], rm[1], rv[1], rp[4], rm[4], rv[4], rp[5], rm[5], rv[5],
                                            n_users, n_items, L, uid_all, iid_all, gu[0], gi[0], g_all, w.tag[0], w.tag[1],
-                                           B_all, (int)adam_step, sc, st))
+                                           B_all, (int)adam_step, sc, st, tb_on ? w.ctag[0] : nullptr, tb_on ? w.ctag[1] : nullptr,
+                                           tb_on ? &tb[0] : nullptr))
         return rc;
     if (npair == 2)
         return mf_table_rows_launch(rp[2], rm[2], rv[2], rp[3], rm[3], rv[3], n_users, n_items, L, uid_all, iid_all, gu[1],
-                                    gi[1], w.tag[0], w.tag[1], nullptr, nullptr, B_all, (int)adam_step, sc, st);
+                                    gi[1], w.tag[0], w.tag[1], tb_on ? w.ctag[0] : nullptr, tb_on ? w.ctag[1] : nullptr,
+                                    B_all, (int)adam_step, sc, st, tb_on ? &tb[1] : nullptr);
     return R4R_OK;
 }

@@ -1566,7 +1566,7 @@ class IdNetEngine:
         the running sum is in ``self.sse``.  defer_sweep (single process, with `next_data`): the Adam sweeps over
         the ID tables are temporally blocked (MFEngine.train_step has the contract)."""
         if self.dp is not None:
-            return self._train_step_dp(data, y, n_global)
+            return self._train_step_dp(data, y, n_global, next_data if defer_sweep else None)
         n = data[5].numel()
         if n == 0:
             return torch.empty(0, dtype=torch.float32, device=self.dev)
@@ -1577,10 +1577,19 @@ class IdNetEngine:
         return se
 
     @torch.no_grad()
-    def _train_step_dp(self, data, y, n_global):
+    def _train_step_dp(self, data, y, n_global, next_data=None):
         lib, dist = _lib.lib(), torch.distributed
         n, world, L = data[5].numel(), self.dp.world, self.L
         B_pad = int(self.hp.get('batch_size', 0))
+        # the temporally blocked sweeps under data parallelism: every rank announces its next shard (or none does) and
+        # every rank flushes at the same steps -- the loops run in lockstep, and so do these decisions
+        key = (data[5].reshape(-1).data_ptr(), data[6].reshape(-1).data_ptr(), n)
+        if self._tb_promised is not None and key != self._tb_promised[0]:
+            self.flush(last_step=self.step_count)            # (this step has not counted itself yet)
+        self._tb_promised, tbn = None, None
+        if (next_data is not None and self.sweep_period > 1 and n_global is not None and next_data[5].numel() <= B_pad):
+            nu, ni = next_data[5].reshape(-1).contiguous(), next_data[6].reshape(-1).contiguous()
+            tbn = (nu, ni, nu.numel())
         if n_global is not None and n > B_pad:
             # (taking the size-agreement branch on THIS rank only would leave the others in a different
             # collective: a hang, not an error)
@@ -1606,28 +1615,35 @@ class IdNetEngine:
                                       self.wd, int(self.step_count), None, _lib.current_stream()), 'r4r_adam_multi')
         # C2: per rating (uid, iid) and (d loss / d pred, the compact rows of every table); -1 ids pad ragged shards
         ntab = len(self.tables)
-        ids = torch.full((B_pad, 2), -1, dtype=torch.int64, device=self.dev)
+        ids = torch.full((B_pad, 4), -1, dtype=torch.int64, device=self.dev)     # uid, iid, the announced NEXT uid, iid
+        if tbn is not None and tbn[2] > 0:
+            ids[:tbn[2], 2], ids[:tbn[2], 3] = tbn[0], tbn[1]
         vals = torch.zeros((B_pad, 1 + ntab * L), dtype=torch.float32, device=self.dev)
         if n > 0:
             ids[:n, 0], ids[:n, 1] = data[5].reshape(-1), data[6].reshape(-1)
             vals[:n, 0] = self._ws_view(n, 1, 1)[:, 0]
             for t in range(ntab):
                 vals[:n, 1 + t * L:1 + (t + 1) * L] = self._ws_view(n, 4 + t, L)
-        all_ids = torch.empty((world * B_pad, 2), dtype=torch.int64, device=self.dev)
+        all_ids = torch.empty((world * B_pad, 4), dtype=torch.int64, device=self.dev)
         all_vals = torch.empty((world * B_pad, 1 + ntab * L), dtype=torch.float32, device=self.dev)
         self.dp.all_gather(all_ids.view(-1), ids.view(-1))
         self.dp.all_gather(all_vals.view(-1), vals.view(-1))
         uid_all, iid_all = all_ids[:, 0].contiguous(), all_ids[:, 1].contiguous()
+        nu_all, ni_all = all_ids[:, 2].contiguous(), all_ids[:, 3].contiguous()
         g_all = all_vals[:, 0].contiguous()
         rows = [all_vals[:, 1 + t * L:1 + (t + 1) * L].contiguous() for t in range(ntab)]
         p2 = lambda ts: (ctypes.c_uint64 * 2)(*[t.data_ptr() for t in ts] + [0] * (2 - len(ts)))
         nb = max(n, 1)                                       # (the workspace of this rank's own shape holds the row tags)
         ws = self._workspace(nb)
         _lib.check(lib.r4r_idnet_rows_apply(
-            self.variant, ptr(uid_all), ptr(iid_all), ptr(g_all), p2(rows[0::2]), p2(rows[1::2]), world * B_pad,
+            self.variant, ptr(uid_all), ptr(iid_all), ptr(g_all), p2(rows[0::2]), p2(rows[1::2]),
+            ptr(nu_all), ptr(ni_all), self.sweep_period, int(tbn is not None), world * B_pad,
             self._p6(self.rows), self._p6(self.rows_m), self._p6(self.rows_v), self.n_users, self.n_items, ptr(ws),
             ws.numel(), nb, L, self.lr, self.betas[0], self.betas[1], self.eps, self.wd, int(self.step_count),
             _lib.current_stream()), 'r4r_idnet_rows_apply')
+        if tbn is not None:
+            self._tb_promised = ((tbn[0].data_ptr(), tbn[1].data_ptr(), tbn[2]), tbn)
+            self._tb_used = True
         return se
 
     @torch.no_grad()

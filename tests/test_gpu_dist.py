@@ -305,6 +305,11 @@ def _blocked_dp_worker(rank, world, port, family, defer, out_dir):
         hp = dict(synthetic.hyper_params_for('cfg2_mfdot_electronics', dropout=0.3), total_users=30000, total_items=9000, batch_size=64)
         P = oracle.init_params(hp, seed=11)
         model = reviews4rec_amd.get_model_class('MF_dot')(hp)
+    elif family == 'NeuMF':
+        hp = dict(model_type='NeuMF', neumf_stage='NeuMF', latent_size=16, dropout=0.3, total_users=30000, total_items=9000,
+                  lr=0.002, weight_decay=1e-6, word_embed_size=16, input_length=10, batch_size=64, vocab=0)
+        P = oracle.init_params(hp, vocab_size=None, seed=11)
+        model = reviews4rec_amd.get_model_class('NeuMF')(hp)
     else:
         hp = dict(synthetic.hyper_params_for('cfg5_transnetpp_synthetic', dropout=0.3), total_users=60000, total_items=9000,
                   input_length=40, vocab=2000, batch_size=64)
@@ -320,7 +325,7 @@ def _blocked_dp_worker(rank, world, port, family, defer, out_dir):
     shards = []
     for k in range(6):
         data, y = gen.batch(96 if k != 3 else 51)            # global batches; the ranks' shards are ragged
-        data = [None if (d.shape[-1] == 1 and family == 'MF_dot' and j < 5) else torch.from_numpy(d).cuda() for j, d in enumerate(data)]
+        data = [None if (d.shape[-1] == 1 and family != 'transnet++' and j < 5) else torch.from_numpy(d).cuda() for j, d in enumerate(data)]
         shards.append((r4dist.shard_batch(data, torch.from_numpy(y).cuda(), rank, world), int(y.shape[0])))
     order = [0, 1, 2, 3, 4, 5, 1, 3, 0]
     for s, k in enumerate(order):
@@ -342,10 +347,10 @@ def _blocked_dp_worker(rank, world, port, family, defer, out_dir):
     torch.distributed.destroy_process_group()
 
 
-@pytest.mark.parametrize('family', ['MF_dot', 'transnet++'])
+@pytest.mark.parametrize('family', ['MF_dot', 'transnet++', 'NeuMF'])
 def test_dp2_blocked_sweep_equals_the_plain_sweep(tmp_path, family):
     """The temporally blocked sweep under data parallelism (every rank's next ids ride in the gathered payload;
-    r4r_mf_apply / r4r_transnet_rows_apply block over what ALL ranks announced): 2 ranks x 9 steps of ragged shards,
+    r4r_mf_apply / r4r_transnet_rows_apply / r4r_idnet_rows_apply block over what ALL ranks announced): 2 ranks x 9 steps of ragged shards,
     with an announcement that is not kept and a step that announces nothing -- parameters and both moments identical,
     bit for bit, across the ranks and to the same run with the plain sweep."""
     for defer in (0, 1):
