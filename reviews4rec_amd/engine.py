@@ -1356,7 +1356,7 @@ class TransNetEngine(NarreEngine):
                 self._tb_promised = ((nu.data_ptr(), ni.data_ptr(), nn), self._dp_tb)
                 self._tb_used = True
         finally:
-            self._dp_tb_announced, self._dp_tb = self._dp_tb is not None, None
+            self._dp_tb = None
         return se
 
     def _dp_apply(self, all_ids, all_vals, B_all, ws, nb, R, T):
