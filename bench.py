@@ -104,6 +104,8 @@ def parse():
     ap.add_argument('--cpu-seconds', type=float, default=12.0,
                     help='budget of each half (thread calibration, measurement) of the cpu_baseline leg')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-steady-leg', action='store_true',
+                    help='short regions (--steps < 50): skip the appended 200-step steady leg')
     ap.add_argument('--no-kernel-timing', action='store_true',
                     help='leave the HIP-event kernel timing off (to measure what the instrumentation costs)')
     ap.add_argument('--conv-algo', choices=['auto', 'direct', 'project'], default='auto',
@@ -462,13 +464,42 @@ def main():
     steps_run = ramp + args.warmup + args.steps
     slots = {'textcnn_fwd_kernel': 0, 'textcnn_wgrad_kernel': 1, 'adam_multi_kernel': 2,
              'proj_gemm_kernel': 3, 'proj_gather_max_kernel': 4}
-    timed = {}
-    for name, slot in slots.items():
-        tot, cnt = ctypes.c_double(), ctypes.c_int64()
-        lib.r4r_timing_read(slot, ctypes.byref(tot), ctypes.byref(cnt), 0)
-        if cnt.value:
-            timed[name] = (tot.value / cnt.value, cnt.value)          # (avg ms per launch, launches)
-    lib.r4r_timing_read(0, ctypes.byref(ctypes.c_double()), ctypes.byref(ctypes.c_int64()), 1)   # reset ALL slots
+
+    def read_slots():
+        got = {}
+        for name, slot in slots.items():
+            tot, cnt = ctypes.c_double(), ctypes.c_int64()
+            lib.r4r_timing_read(slot, ctypes.byref(tot), ctypes.byref(cnt), 0)
+            if cnt.value:
+                got[name] = (tot.value, cnt.value)           # (total ms, launches)
+        lib.r4r_timing_read(0, ctypes.byref(ctypes.c_double()), ctypes.byref(ctypes.c_int64()), 1)   # reset ALL slots
+        return got
+
+    region_slots = read_slots()
+    region_counts = {k: v[1] for k, v in region_slots.items()}          # sampled launches inside the requested region
+    # A SHORT timed region (the driver's --steps 20: 2 ms of GPU time) carries ONE instrumented step -- more would
+    # be a visible share of the window (an instrumented step costs ~30 us) -- so its roofline would rest on one
+    # launch, and the region itself on a clock that has not settled.  Such a run appends a separately timed STEADY
+    # leg: the same step function for 200 more steps between the same fences, every 20th step instrumented.  `value`
+    # stays the requested region's; the roofline legs average the sampled launches of both (counts stated).
+    steady = None
+    if (args.steps < 50 and mask and not dp_job and not args.from_host and graphed is None and engine is not None
+            and not args.no_steady_leg):
+        STEADY = 200
+        el_s = timed_region(step, STEADY, steps_run, mask)
+        if hasattr(engine, 'check_announcements'):
+            engine.check_announcements()
+        steady = {'steps': STEADY, 'ratings_per_s': round(STEADY * B_global / el_s, 1),
+                  'ms_per_step': round(1000.0 * el_s / STEADY, 4), 'gpu_ms_per_step': round(gpu_span_ms[0] / STEADY, 4),
+                  'note': 'the same step function, %d more steps between the same fences right after the timed region '
+                          '(never `value`); its sampled launches are averaged into the roofline legs' % STEADY}
+        steps_run += STEADY
+        leg_slots = read_slots()
+        steady['kernel_ms'] = {k: round(v[0] / v[1], 4) for k, v in leg_slots.items()}
+        for k, (tot, cnt) in leg_slots.items():
+            t0, c0 = region_slots.get(k, (0.0, 0))
+            region_slots[k] = (t0 + tot, c0 + cnt)
+    timed = {k: (tot / cnt, cnt) for k, (tot, cnt) in region_slots.items()}   # (avg ms per launch, launches)
     run_sse = float(engine.sse[0].item()) if engine is not None else (
         float(graphed.sse.item()) if graphed is not None else float(metric_sum.item()))
 
@@ -535,7 +566,8 @@ def main():
         value = args.steps * B_global / elapsed
         result = {
             'metric': 'train ratings/sec', 'value': round(value, 1), 'unit': 'ratings/s',
-            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'warmup_effective': ramp + args.warmup,
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'warmup_requested': args.warmup,
+            'warmup_effective': ramp + args.warmup,       # --ramp untimed steps at least (clock ramp, see above)
             'ms_per_step': round(1000.0 * elapsed / args.steps, 4),
             'gpu_ms_per_step': round(gpu_ms_per_step, 4),     # HIP events around the same steps (rank 0's device)
             'higher_is_better': True, 'scaling': 'strong' if strong else 'weak', 'vs_baseline': None,
@@ -568,6 +600,8 @@ def main():
         }
         if opt_in:
             result['opt_in_f16_split'] = opt_in
+        if steady:
+            result['steady'] = steady
         if strong_legs:
             ran = [l for l in strong_legs if 'skipped' not in l]
             if ran:
@@ -596,7 +630,9 @@ def main():
                                   'peak': round(peak, 1), 'unit': 'TFLOP/s',
                                   'frac': round(ach / peak, 4),
                                   'traffic': traffic, 'traffic_source': src,
-                                  'launches': timed['proj_gemm_kernel'][1], 'avg_launch_ms': round(1000 * g_s, 4),
+                                  'launches': timed['proj_gemm_kernel'][1],
+                                  'launches_in_timed_region': region_counts.get('proj_gemm_kernel', 0),
+                                  'avg_launch_ms': round(1000 * g_s, 4),
                                   'flops_per_launch': int(gflops), 'distinct_token_rows_per_launch': int(rows),
                                   # what the launch must move whatever its form: the distinct rows in, 1,200 B per row out
                                   # (at E = 64 the stores, not the MFMAs, bound it: DESIGN 4.1b round 3)

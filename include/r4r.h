@@ -252,6 +252,11 @@ int r4r_adam_multi(int ntensor, const uint64_t *p, const uint64_t *g, const uint
 int r4r_adam_gathered(float *p, const float *gathered, int world, float *g_sum, float *m, float *v,
                       int64_t numel, float lr, double beta1, double beta2, float eps,
                       float weight_decay, int64_t step, void *stream);
+/* The same behind a device-side guard: `abort_word` (nullable, DEVICE uint32) != 0 makes the launch a no-op.  The
+ * peer exchange below passes its timed_out word: slots a missing rank never filled must not be summed. */
+int r4r_adam_gathered_guarded(float *p, const float *gathered, int world, float *g_sum, float *m, float *v,
+                              int64_t numel, float lr, double beta1, double beta2, float eps,
+                              float weight_decay, int64_t step, const uint32_t *abort_word, void *stream);
 
 /* Device-side form of that all_gather over peer-mapped buffers (the exchange step of the data-parallel form of
  * main.py:56-60; the reference itself is single-process, main.py:407).  Every rank owns two gathered buffers

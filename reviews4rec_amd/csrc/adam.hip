@@ -87,7 +87,11 @@ __global__ __launch_bounds__(ADAM_THREADS) void adam_multi_kernel(AdamBatch tb, 
 __global__ __launch_bounds__(ADAM_THREADS) void adam_gathered_kernel(float *__restrict__ p, const float *__restrict__ gathered,
                                                                      int world, float *__restrict__ g_sum,
                                                                      float *__restrict__ m, float *__restrict__ v,
-                                                                     int64_t numel, AdamScalars s) {
+                                                                     int64_t numel, AdamScalars s,
+                                                                     const uint32_t *__restrict__ abort_word) {
+    // a peer exchange whose wait timed out left stale or partial slots behind (peer.hip sets the word and ends):
+    // summing them would give every rank a different gradient -- the update is skipped and the host raises
+    if (abort_word && *abort_word != 0) return;
     const int64_t nvec = numel >> 2;
     const int64_t i = (int64_t)blockIdx.x * ADAM_THREADS + threadIdx.x;
     if (i < nvec) {
@@ -114,9 +118,20 @@ __global__ __launch_bounds__(ADAM_THREADS) void adam_gathered_kernel(float *__re
 
 using namespace r4r;
 
+extern "C" int r4r_adam_gathered_guarded(float *p, const float *gathered, int world, float *g_sum, float *m, float *v,
+                                         int64_t numel, float lr, double beta1, double beta2, float eps,
+                                         float weight_decay, int64_t step, const uint32_t *abort_word, void *stream);
+
 extern "C" int r4r_adam_gathered(float *p, const float *gathered, int world, float *g_sum, float *m, float *v,
                                  int64_t numel, float lr, double beta1, double beta2, float eps,
                                  float weight_decay, int64_t step, void *stream) {
+    return r4r_adam_gathered_guarded(p, gathered, world, g_sum, m, v, numel, lr, beta1, beta2, eps, weight_decay, step,
+                                     nullptr, stream);
+}
+
+extern "C" int r4r_adam_gathered_guarded(float *p, const float *gathered, int world, float *g_sum, float *m, float *v,
+                                         int64_t numel, float lr, double beta1, double beta2, float eps,
+                                         float weight_decay, int64_t step, const uint32_t *abort_word, void *stream) {
     R4R_REQUIRE(p && gathered && m && v, "adam_gathered: null pointer");
     R4R_REQUIRE(world >= 1 && numel >= 0 && step >= 1, "adam_gathered: bad world / numel / step");
     R4R_REQUIRE(numel % 4 == 0, "adam_gathered: numel %lld must be a multiple of 4 (flat buffers are)", (long long)numel);
@@ -127,7 +142,7 @@ extern "C" int r4r_adam_gathered(float *p, const float *gathered, int world, flo
     const AdamScalars s = adam_make_scalars(lr, beta1, beta2, eps, weight_decay, step, nullptr);
     ScopedTiming tm(R4R_TIMING_ADAM, as_stream(stream));
     adam_gathered_kernel<<<(unsigned)cdiv(numel / 4, ADAM_THREADS), ADAM_THREADS, 0, as_stream(stream)>>>(
-        p, gathered, world, g_sum, m, v, numel, s);
+        p, gathered, world, g_sum, m, v, numel, s, abort_word);
     return check_launch("adam_gathered");
 }
 

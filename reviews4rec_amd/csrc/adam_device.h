@@ -21,26 +21,37 @@ struct AdamScalars {
     float omb1, omb2;       // 1 - beta, rounded from double like torch's `value=1 - beta2`
 };
 
-// The square root and the division are the hardware's (v_sqrt_f32, v_rcp_f32: 1 ulp each) instead of the IEEE-exact
-// expansions hipcc emits for sqrtf() and `/` (27 vector instructions of the update's 35): the update term carries a
-// relative error of ~2e-7 either way -- the reference's own CPU arithmetic is no closer to the real number -- and the
-// temporally blocked sweeps, which apply several updates per byte moved, stop being bound by this arithmetic (cfg5's
-// sweep 92 -> see DESIGN.md 4.5).  R4R_ADAM_IEEE=1 at build time restores the expansions (A/B runs).  A denormal
-// second moment reads as zero here: sqrt(v) < 1e-19 against eps = 1e-8 either way.
+// Two forms of the same update.
+//   adam_elem       -- IEEE-exact sqrtf() and `/` (hipcc's expansions: 27 of the update's 35 vector instructions).
+//                      The DEFAULT: the flat dense-parameter buffers (adam.hip, the fused reduce launches) are
+//                      latency- or HBM-bound and pay nothing for it, and their update is torch.optim.Adam's to the bit.
+//   adam_elem_fast  -- the hardware's v_sqrt_f32 / v_rcp_f32 (1 ulp each; m * rcp(denom) for m / denom; a denormal
+//                      second moment reads as zero: sqrt(v) < 1e-19 against eps = 1e-8 either way).  Only for the
+//                      ID-table sweeps (mf_engine.hip, rows_device.h / step_device.h, idnet_engine.hip): temporally
+//                      blocked, they apply several updates per byte moved and were bound by this arithmetic (DESIGN.md
+//                      4.5); every path that can touch a table row uses this form, so blocked and dense sweeps agree to
+//                      the bit.  R4R_ADAM_IEEE=1 at build time makes both forms exact (A/B runs).
 #ifndef R4R_ADAM_IEEE
 #define R4R_ADAM_IEEE 0
 #endif
-__device__ __forceinline__ void adam_elem(float &p, float g, float &m, float &v, const AdamScalars &s) {
+template <bool FAST>
+__device__ __forceinline__ void adam_elem_form(float &p, float g, float &m, float &v, const AdamScalars &s) {
     g = fmaf(s.wd, p, g);
     m = fmaf(s.beta1, m, s.omb1 * g);
     v = fmaf(s.beta2, v, s.omb2 * g * g);
-#if R4R_ADAM_IEEE
-    const float denom = sqrtf(v) * s.inv_sqrt_bc2 + s.eps;
-    p -= s.lr_over_bc1 * (m / denom);
-#else
-    const float denom = __builtin_amdgcn_sqrtf(v) * s.inv_sqrt_bc2 + s.eps;
-    p -= s.lr_over_bc1 * (m * __builtin_amdgcn_rcpf(denom));
-#endif
+    if constexpr (FAST && !R4R_ADAM_IEEE) {
+        const float denom = __builtin_amdgcn_sqrtf(v) * s.inv_sqrt_bc2 + s.eps;
+        p -= s.lr_over_bc1 * (m * __builtin_amdgcn_rcpf(denom));
+    } else {
+        const float denom = sqrtf(v) * s.inv_sqrt_bc2 + s.eps;
+        p -= s.lr_over_bc1 * (m / denom);
+    }
+}
+__device__ __forceinline__ void adam_elem(float &p, float g, float &m, float &v, const AdamScalars &s) {
+    adam_elem_form<false>(p, g, m, v, s);
+}
+__device__ __forceinline__ void adam_elem_fast(float &p, float g, float &m, float &v, const AdamScalars &s) {
+    adam_elem_form<true>(p, g, m, v, s);
 }
 
 // step >= 1: the 1-based count of this update

@@ -22,7 +22,7 @@ static DLayout dcpp_layout(int E, int L) {
     for (int i = 0; i < DP_COUNT; ++i) {
         lay.off[i] = o;
         lay.size[i] = sz[i];
-        o += (sz[i] + 3) & ~(int64_t)3;
+        o += (sz[i] + 31) & ~(int64_t)31;
     }
     lay.total = o;
     return lay;

@@ -51,7 +51,7 @@ static ILayout idn_layout(int variant, int L) {
     for (int i = 0; i < IP_COUNT; ++i) {
         lay.off[i] = o;
         lay.size[i] = sz[i];
-        o += (sz[i] + 3) & ~(int64_t)3;          // 16-byte aligned slots; pad floats stay 0 forever
+        o += (sz[i] + 31) & ~(int64_t)31;          // 128-byte aligned slots (whole cache lines for the GEMM's weight-row pieces); pad floats stay 0 forever
     }
     lay.total = o;
     return lay;

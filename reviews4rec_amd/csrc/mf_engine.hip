@@ -200,7 +200,7 @@ __device__ __forceinline__ void mf_stream_chunk(float *p, float *m, float *v, in
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             float pc = P[c], mc = M[c], vc = V[c];
-            adam_elem(pc, 0.f, mc, vc, sc);
+            adam_elem_fast(pc, 0.f, mc, vc, sc);
             P[c] = pc; M[c] = mc; V[c] = vc;
         }
     };
@@ -222,7 +222,7 @@ __device__ __forceinline__ void mf_stream_chunk(float *p, float *m, float *v, in
     const int64_t k = (nvec << 2) + tid;                    // cnt % 4 elements at the end of a table
     if (k < cnt) {
         float P = p[k], M = m[k], V = v[k];
-        adam_elem(P, 0.f, M, V, sc);
+        adam_elem_fast(P, 0.f, M, V, sc);
         p[k] = P; m[k] = M; v[k] = V;
     }
 }
@@ -259,7 +259,7 @@ __device__ __forceinline__ void mf_stream_chunk_tb(float *p, float *m, float *v,
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
                     float pc = P[c], mc = M[c], vc = V[c];
-                    adam_elem(pc, 0.f, mc, vc, sc);
+                    adam_elem_fast(pc, 0.f, mc, vc, sc);
                     P[c] = pc; M[c] = mc; V[c] = vc;
                 }
             }
@@ -268,6 +268,9 @@ __device__ __forceinline__ void mf_stream_chunk_tb(float *p, float *m, float *v,
     const int64_t nvec = cnt >> 2;
     constexpr int NV = MF_CHUNK / 4 / MF_THREADS, NB = R4R_TB_BATCH;     // float4 per thread and array; in flight together
     static_assert(NV % NB == 0, "batches of the thread's float4");
+    // (nvec == 0 -- a table's last chunk with fewer than four elements: the clamped loads below would read 16 bytes
+    // at index 0 of a chunk that does not hold them, i.e. past the table's end; uniform)
+    if (nvec > 0) {
 #if R4R_TB_PIPE
     // software pipeline: group g + 1's loads are requested before group g's updates (a wave's memory time and its
     // arithmetic otherwise add up: every wave of the launch starts together and few of them carry work)
@@ -314,6 +317,7 @@ __device__ __forceinline__ void mf_stream_chunk_tb(float *p, float *m, float *v,
         }
     }
 #endif
+    }
     const int64_t k = (nvec << 2) + tid;                    // cnt % 4 elements at the end of a table
     if (k < cnt) {
         float P = p[k], M = m[k], V = v[k];
@@ -323,7 +327,7 @@ __device__ __forceinline__ void mf_stream_chunk_tb(float *p, float *m, float *v,
                 AdamScalars sc = sc0;
                 sc.lr_over_bc1 = tb.lr_bc1[j];
                 sc.inv_sqrt_bc2 = tb.isb2[j];
-                adam_elem(P, 0.f, M, V, sc);
+                adam_elem_fast(P, 0.f, M, V, sc);
             }
         }
         p[k] = P; m[k] = M; v[k] = V;
@@ -487,8 +491,8 @@ __device__ __forceinline__ void mf_entry(const MfSweep &w, const int *sid, int *
             const int64_t o = ((int64_t)row * D >> 2) + sub;
             float4 P = reinterpret_cast<float4 *>(bp)[o], M = reinterpret_cast<float4 *>(bm)[o];
             float4 V = reinterpret_cast<float4 *>(bv)[o];
-            adam_elem(P.x, G.x, M.x, V.x, w.s); adam_elem(P.y, G.y, M.y, V.y, w.s);
-            adam_elem(P.z, G.z, M.z, V.z, w.s); adam_elem(P.w, G.w, M.w, V.w, w.s);
+            adam_elem_fast(P.x, G.x, M.x, V.x, w.s); adam_elem_fast(P.y, G.y, M.y, V.y, w.s);
+            adam_elem_fast(P.z, G.z, M.z, V.z, w.s); adam_elem_fast(P.w, G.w, M.w, V.w, w.s);
             reinterpret_cast<float4 *>(bp)[o] = P; reinterpret_cast<float4 *>(bm)[o] = M;
             reinterpret_cast<float4 *>(bv)[o] = V;
         }
@@ -525,7 +529,7 @@ __device__ __forceinline__ void mf_entry(const MfSweep &w, const int *sid, int *
                     const int64_t o = (int64_t)row * D + col;
                     const float G = (acc[0][x] + acc[1][x]) + (acc[2][x] + acc[3][x]);
                     float P = bp[o], M = bm[o], V = bv[o];
-                    adam_elem(P, G, M, V, w.s);
+                    adam_elem_fast(P, G, M, V, w.s);
                     bp[o] = P; bm[o] = M; bv[o] = V;
                 }
             }
@@ -534,7 +538,7 @@ __device__ __forceinline__ void mf_entry(const MfSweep &w, const int *sid, int *
     if (lane == 0 && (t ? w.p3 : w.p2)) {                   // the row's bias element (a caller may have none)
         float *bp = t ? w.p3 : w.p2, *bm = t ? w.m3 : w.m2, *bv = t ? w.v3 : w.v2;
         float P = bp[row], M = bm[row], V = bv[row];
-        adam_elem(P, gb, M, V, w.s);
+        adam_elem_fast(P, gb, M, V, w.s);
         bp[row] = P; bm[row] = M; bv[row] = V;
     }
 }
@@ -583,14 +587,14 @@ __global__ __launch_bounds__(MF_THREADS) void mf_adam_kernel(MfSweep w) {
                     const int64_t o = ((int64_t)row * D >> 2) + sub;
                     float4 P = reinterpret_cast<float4 *>(bp)[o], M = reinterpret_cast<float4 *>(bm)[o];
                     float4 V = reinterpret_cast<float4 *>(bv)[o];
-                    adam_elem(P.x, G.x, M.x, V.x, w.s); adam_elem(P.y, G.y, M.y, V.y, w.s);
-                    adam_elem(P.z, G.z, M.z, V.z, w.s); adam_elem(P.w, G.w, M.w, V.w, w.s);
+                    adam_elem_fast(P.x, G.x, M.x, V.x, w.s); adam_elem_fast(P.y, G.y, M.y, V.y, w.s);
+                    adam_elem_fast(P.z, G.z, M.z, V.z, w.s); adam_elem_fast(P.w, G.w, M.w, V.w, w.s);
                     reinterpret_cast<float4 *>(bp)[o] = P; reinterpret_cast<float4 *>(bm)[o] = M;
                     reinterpret_cast<float4 *>(bv)[o] = V;
                     if (sub == 0) {                         // the row's bias element
                         float *cp = t ? w.p3 : w.p2, *cm = t ? w.m3 : w.m2, *cv = t ? w.v3 : w.v2;
                         float Pb = cp[row], Mb = cm[row], Vb = cv[row];
-                        adam_elem(Pb, w.g[k], Mb, Vb, w.s);
+                        adam_elem_fast(Pb, w.g[k], Mb, Vb, w.s);
                         cp[row] = Pb; cm[row] = Mb; cv[row] = Vb;
                     }
                 }
@@ -630,7 +634,7 @@ __global__ __launch_bounds__(MF_THREADS) void mf_adam_kernel(MfSweep w) {
         if (tid == 0) {
             if (w.p4) {                                     // (absent when the caller keeps its global bias elsewhere)
                 float P = w.p4[0], M = w.m4[0], V = w.v4[0];
-                adam_elem(P, gsum, M, V, w.s);
+                adam_elem_fast(P, gsum, M, V, w.s);
                 w.p4[0] = P; w.m4[0] = M; w.v4[0] = V;
             }
             if (w.sse_accum) w.sse_accum[0] += red[0];
@@ -711,14 +715,14 @@ __global__ __launch_bounds__(MF_THREADS) void mf_adam_kernel(MfSweep w) {
             float4 V0 = reinterpret_cast<float4 *>(v)[i], V1 = reinterpret_cast<float4 *>(v)[j];
             const int t0 = tag[row], t1 = tag[row1];
             if (t0 != w.now) {                              // touched rows belong to their entry wave
-                adam_elem(P0.x, 0.f, M0.x, V0.x, w.s); adam_elem(P0.y, 0.f, M0.y, V0.y, w.s);
-                adam_elem(P0.z, 0.f, M0.z, V0.z, w.s); adam_elem(P0.w, 0.f, M0.w, V0.w, w.s);
+                adam_elem_fast(P0.x, 0.f, M0.x, V0.x, w.s); adam_elem_fast(P0.y, 0.f, M0.y, V0.y, w.s);
+                adam_elem_fast(P0.z, 0.f, M0.z, V0.z, w.s); adam_elem_fast(P0.w, 0.f, M0.w, V0.w, w.s);
                 reinterpret_cast<float4 *>(p)[i] = P0; reinterpret_cast<float4 *>(m)[i] = M0;
                 reinterpret_cast<float4 *>(v)[i] = V0;
             }
             if (t1 != w.now) {
-                adam_elem(P1.x, 0.f, M1.x, V1.x, w.s); adam_elem(P1.y, 0.f, M1.y, V1.y, w.s);
-                adam_elem(P1.z, 0.f, M1.z, V1.z, w.s); adam_elem(P1.w, 0.f, M1.w, V1.w, w.s);
+                adam_elem_fast(P1.x, 0.f, M1.x, V1.x, w.s); adam_elem_fast(P1.y, 0.f, M1.y, V1.y, w.s);
+                adam_elem_fast(P1.z, 0.f, M1.z, V1.z, w.s); adam_elem_fast(P1.w, 0.f, M1.w, V1.w, w.s);
                 reinterpret_cast<float4 *>(p)[j] = P1; reinterpret_cast<float4 *>(m)[j] = M1;
                 reinterpret_cast<float4 *>(v)[j] = V1;
             }
@@ -731,8 +735,8 @@ __global__ __launch_bounds__(MF_THREADS) void mf_adam_kernel(MfSweep w) {
             float4 M = reinterpret_cast<float4 *>(m)[i];
             float4 V = reinterpret_cast<float4 *>(v)[i];
             if (tag[row] != w.now) {
-                adam_elem(P.x, 0.f, M.x, V.x, w.s); adam_elem(P.y, 0.f, M.y, V.y, w.s);
-                adam_elem(P.z, 0.f, M.z, V.z, w.s); adam_elem(P.w, 0.f, M.w, V.w, w.s);
+                adam_elem_fast(P.x, 0.f, M.x, V.x, w.s); adam_elem_fast(P.y, 0.f, M.y, V.y, w.s);
+                adam_elem_fast(P.z, 0.f, M.z, V.z, w.s); adam_elem_fast(P.w, 0.f, M.w, V.w, w.s);
                 reinterpret_cast<float4 *>(p)[i] = P; reinterpret_cast<float4 *>(m)[i] = M;
                 reinterpret_cast<float4 *>(v)[i] = V;
             }
@@ -752,10 +756,10 @@ __global__ __launch_bounds__(MF_THREADS) void mf_adam_kernel(MfSweep w) {
         auto finish = [&](int64_t i, float4 P, float4 M, float4 V, int col_i, int t_lo, int t_hi) {
             const bool f0 = t_lo != w.now, f1 = (col_i + 1 >= W ? t_hi : t_lo) != w.now,
                        f2 = (col_i + 2 >= W ? t_hi : t_lo) != w.now, f3 = (col_i + 3 >= W ? t_hi : t_lo) != w.now;
-            if (f0) adam_elem(P.x, 0.f, M.x, V.x, w.s);
-            if (f1) adam_elem(P.y, 0.f, M.y, V.y, w.s);
-            if (f2) adam_elem(P.z, 0.f, M.z, V.z, w.s);
-            if (f3) adam_elem(P.w, 0.f, M.w, V.w, w.s);
+            if (f0) adam_elem_fast(P.x, 0.f, M.x, V.x, w.s);
+            if (f1) adam_elem_fast(P.y, 0.f, M.y, V.y, w.s);
+            if (f2) adam_elem_fast(P.z, 0.f, M.z, V.z, w.s);
+            if (f3) adam_elem_fast(P.w, 0.f, M.w, V.w, w.s);
             if (f0 && f1 && f2 && f3) {
                 reinterpret_cast<float4 *>(p)[i] = P; reinterpret_cast<float4 *>(m)[i] = M;
                 reinterpret_cast<float4 *>(v)[i] = V;
@@ -795,7 +799,7 @@ __global__ __launch_bounds__(MF_THREADS) void mf_adam_kernel(MfSweep w) {
             const int64_t r = (start + k) / W;
             float P = p[k], M = m[k], V = v[k];
             if (tag[r] != w.now) {
-                adam_elem(P, 0.f, M, V, w.s);
+                adam_elem_fast(P, 0.f, M, V, w.s);
                 p[k] = P; m[k] = M; v[k] = V;
             }
         }
@@ -807,7 +811,7 @@ __global__ __launch_bounds__(MF_THREADS) void mf_adam_kernel(MfSweep w) {
         for (int64_t i = tid; i < cnt; i += MF_THREADS) {
             float P = p[i], M = m[i], V = v[i];
             if (tag[row] != w.now) {
-                adam_elem(P, 0.f, M, V, w.s);
+                adam_elem_fast(P, 0.f, M, V, w.s);
                 p[i] = P; m[i] = M; v[i] = V;
             }
             row += step_row;

@@ -32,6 +32,12 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int PF = 100;            // filters (rows of 100 floats = 400 B per tap)
 constexpr int PROW = 3 * PF;       // projected row: 3 taps x 100 filters
+#ifndef R4R_PSTR
+#define R4R_PSTR 304
+#endif
+constexpr int PSTR = R4R_PSTR;     // its stride in the projected-row table: 1,216 B = 19 whole 64-byte pieces (at 1,200 B three
+                                   // of four 64-byte store pieces straddled two requests, and a gathered row touched 10.4 lines instead of 10)
+static_assert(PSTR >= PROW && PSTR % 4 == 0, "projected-row stride");
 constexpr int PN = 304;            // GEMM N: 300 padded to 19 tiles of 16
 constexpr int PNT = PN / 16;       // 19
 constexpr int PEC = 16;            // K chunk
@@ -316,7 +322,7 @@ __device__ __forceinline__ void proj_gemm_body(const ProjArgs &a, float *lds, in
             const int row = row0 + rowgrp * 16 * GMT + mi * 16 + rr;
             const int col = colbase + col0 + cv * 4;
             if (row < count && col < PROW)
-                *reinterpret_cast<f32x4 *>(tw.ptab + (size_t)row * PROW + col) =
+                *reinterpret_cast<f32x4 *>(tw.ptab + (size_t)row * PSTR + col) =
                     *reinterpret_cast<const f32x4 *>(slab + rr * TS + cv * 4);
         }
     }
@@ -326,7 +332,7 @@ __device__ __forceinline__ void proj_gemm_body(const ProjArgs &a, float *lds, in
 #pragma unroll
     for (int mi = 0; mi < GMT; ++mi) {
         const int row = row0 + rowgrp * 16 * GMT + mi * 16 + lrow;
-        float *dst = tw.ptab + (size_t)row * PROW + colbase + col0 + q * 4;
+        float *dst = tw.ptab + (size_t)row * PSTR + colbase + col0 + q * 4;
 #pragma unroll
         for (int ni = 0; ni < NTILE; ++ni)
             if (row < count && colbase + col0 + ni * 16 + q * 4 < PROW) store_row4(dst + ni * 16, acc[mi][ni]);
@@ -590,7 +596,7 @@ __device__ __forceinline__ void proj_gemm7_body(const ProjArgs &a, float *lds, c
             const int rr = i / nv, cv = i - rr * nv;
             const int row = row_first + rr, col = col_tile0 * 16 + cv * 4;
             if (row < count && col < PROW)
-                *reinterpret_cast<f32x4 *>(tw.ptab + (size_t)row * PROW + col) =
+                *reinterpret_cast<f32x4 *>(tw.ptab + (size_t)row * PSTR + col) =
                     *reinterpret_cast<const f32x4 *>(slab + rr * TS + cv * 4);
         }
     };
@@ -599,7 +605,7 @@ __device__ __forceinline__ void proj_gemm7_body(const ProjArgs &a, float *lds, c
     // every tile: one float4 store per tile, straight from the accumulator
     auto store_tile = [&](const f32x4 *row_acc, int ntile, int row_first, int col_tile0) {
         const int row = row_first + lrow;
-        float *dst = tw.ptab + (size_t)row * PROW + col_tile0 * 16 + q * 4;
+        float *dst = tw.ptab + (size_t)row * PSTR + col_tile0 * 16 + q * 4;
 #pragma unroll
         for (int ni = 0; ni < ntile; ++ni)
             if (row < count && (col_tile0 + ni) * 16 + q * 4 < PROW) store_row4(dst + ni * 16, row_acc[ni]);
@@ -989,13 +995,13 @@ __device__ __forceinline__ void proj_gemm_ares_body(const ProjArgs &a, float *ld
     const unsigned long long pbase = reinterpret_cast<unsigned long long>(tw.ptab);
     const unsigned plo = __builtin_amdgcn_readfirstlane((unsigned)pbase), phi = __builtin_amdgcn_readfirstlane((unsigned)(pbase >> 32));
     float *pt = reinterpret_cast<float *>(((unsigned long long)phi << 32) | plo);
-    [[maybe_unused]] const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(pt, 0, __builtin_amdgcn_readfirstlane(count) * (PROW * 4), 0x00020000);
+    [[maybe_unused]] const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(pt, 0, __builtin_amdgcn_readfirstlane(count) * (PSTR * 4), 0x00020000);
     auto store_tile = [&](const f32x4 &v, int row_first, int ct, bool ok = true) {
 #if R4R_EPI == 2
         asm volatile("" ::"v"(v));
 #else
         const int row = row_first + lrow, col = ct * 16 + x.q * 4;
-        const int off = (ok && row < count && col < PROW) ? (row * PROW + col) * 4 : 0x7ffffff0;
+        const int off = (ok && row < count && col < PROW) ? (row * PSTR + col) * 4 : 0x7ffffff0;
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsrc, off, 0, 0);
 #endif
     };
@@ -1207,7 +1213,7 @@ __global__ __launch_bounds__(WR_THREADS) void proj_gemm_wres_kernel(ProjArgs a) 
     const unsigned long long pbase = reinterpret_cast<unsigned long long>(tw.ptab);
     const unsigned plo = __builtin_amdgcn_readfirstlane((unsigned)pbase), phi = __builtin_amdgcn_readfirstlane((unsigned)(pbase >> 32));
     float *pt = reinterpret_cast<float *>(((unsigned long long)phi << 32) | plo);
-    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(pt, 0, __builtin_amdgcn_readfirstlane(count) * (PROW * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(pt, 0, __builtin_amdgcn_readfirstlane(count) * (PSTR * 4), 0x00020000);
     const int units = rt[tower] * WR_NQ, stride = g[tower] * WR_WAVES;
     // The table fragments of a unit's row tile take two dependent reads -- the token of the lane's row, then the row --
     // so they run NB units ahead through a ring of NB register sets, the tokens 2 NB units ahead (NB = 1 .. 5 measured:
@@ -1324,7 +1330,7 @@ __global__ __launch_bounds__(WR_THREADS) void proj_gemm_wres_kernel(ProjArgs a) 
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int col = (ct0 + i) * 16 + q * 4;
-            const int off = (row < count && col < PROW) ? (row * PROW + col) * 4 : 0x7ffffff0;   // out of range: dropped by the hardware
+            const int off = (row < count && col < PROW) ? (row * PSTR + col) * 4 : 0x7ffffff0;   // out of range: dropped by the hardware
 #if R4R_WR_ABL == 1                                          // timing ablation: no stores
             asm volatile("" ::"v"(acc[i]), "v"(off));
 #elif R4R_WR_ABL == 3                                        // timing ablation: same bytes, every store 1 KB contiguous (wrong layout)
@@ -1426,7 +1432,7 @@ __global__ __launch_bounds__(256) void proj_gather_max_kernel(ProjArgs a) {
         // halo: tokens t_lo and t_lo+1 only seed the sliding sums (tap 0 of t_lo, taps 1 and 0 of
         // t_lo+1): three loads issued together with the first group, not a round of their own
         auto load_row = [&](int s, int tap) {
-            const float *row = base + (size_t)(s < 0 ? 0 : s) * PROW + tap * PF;   // clamped: no branch
+            const float *row = base + (size_t)(s < 0 ? 0 : s) * PSTR + tap * PF;   // clamped: no branch
             const f32x4 v = *reinterpret_cast<const f32x4 *>(row);
             return s < 0 ? zero : v;
         };
@@ -1485,7 +1491,7 @@ __global__ __launch_bounds__(256) void proj_gather_max_kernel(ProjArgs a) {
 // ----------------------------------------------------------------- launchers
 int proj_tiles(int T) { return (T + 2 + SEG - 1) / SEG; }
 int64_t proj_row_capacity(int64_t N, int T, int64_t V) { return (N * T < V) ? N * T : V; }
-size_t proj_ptab_floats(int64_t N, int T, int64_t V) { return (size_t)proj_row_capacity(N, T, V) * PROW; }
+size_t proj_ptab_floats(int64_t N, int T, int64_t V) { return (size_t)proj_row_capacity(N, T, V) * PSTR; }
 
 #ifndef R4R_GEMM_DEFAULT
 #define R4R_GEMM_DEFAULT 5
@@ -1519,9 +1525,9 @@ static ProjArgs make_args(const float *table, int64_t V, const ProjTower *tw, in
     a.balanced = g_gemm_balanced;
     // narrow tables (E <= 64: four K chunks) take the weight-resident form by default; R4R_GEMM=r asks for it up to E = 128
     if (a.balanced == 5) a.balanced = a.nchunk <= WR_DEFAULT_CHUNKS ? 4 : 3;    // (5 = the default: the form by table width)
-    if (a.balanced == 4 && (a.nchunk > WR_MAX_CHUNKS || E % 4 != 0 || (int64_t)a.cap * PROW * 4 >= (1ll << 31))) a.balanced = 3;
+    if (a.balanced == 4 && (a.nchunk > WR_MAX_CHUNKS || E % 4 != 0 || (int64_t)a.cap * PSTR * 4 >= (1ll << 31))) a.balanced = 3;
     // the A-resident form holds all of K in LDS (E <= 320) and addresses its output with 32-bit byte offsets
-    if (a.balanced == 3 && (a.nchunk > AR_MAX_CHUNKS || (int64_t)a.cap * PROW * 4 >= (1ll << 31))) a.balanced = 1;
+    if (a.balanced == 3 && (a.nchunk > AR_MAX_CHUNKS || (int64_t)a.cap * PSTR * 4 >= (1ll << 31))) a.balanced = 1;
     return a;
 }
 

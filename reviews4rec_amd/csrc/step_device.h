@@ -118,7 +118,7 @@ __device__ __forceinline__ void narre_sweep_block(const RowSweep &w, int bx) {
     for (int u = 0; u < PER; ++u) {
         const int64_t i = threadIdx.x + (int64_t)u * NROW_THREADS;
         if (i < cnt && T[u] != w.now) {
-            adam_elem(P[u], 0.f, M[u], V[u], w.s);
+            adam_elem_fast(P[u], 0.f, M[u], V[u], w.s);
             bp[start + i] = P[u]; bm[start + i] = M[u]; bv[start + i] = V[u];
         }
     }
@@ -257,12 +257,12 @@ __device__ __forceinline__ void narre_rows_block(const RowSweep &w, int bx, int 
                 if (lane < L) {
                     const int64_t o = (int64_t)row * L + lane;
                     float p1 = P[q], m1 = M[q], v1 = V[q];
-                    adam_elem(p1, acc, m1, v1, w.s);
+                    adam_elem_fast(p1, acc, m1, v1, w.s);
                     tp[o] = p1; tm[o] = m1; tv[o] = v1;
                 }
                 if (lane == 0) {                            // the row's bias element (gradient zero if no self entry)
                     float p1 = Pb[q], m1 = Mb[q], v1 = Vb[q];
-                    adam_elem(p1, accb, m1, v1, w.s);
+                    adam_elem_fast(p1, accb, m1, v1, w.s);
                     bp[row] = p1; bm[row] = m1; bv[row] = v1;
                 }
             }

@@ -38,7 +38,7 @@ static TLayout tn_layout(int E, int L, int plus) {
     for (int i = 0; i < TN_COUNT; ++i) {
         lay.off[i] = o;
         lay.size[i] = sz[i];
-        o += (sz[i] + 3) & ~(int64_t)3;
+        o += (sz[i] + 31) & ~(int64_t)31;
     }
     lay.total = o;
     return lay;

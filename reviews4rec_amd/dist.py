@@ -66,27 +66,82 @@ class StreamRccl:
     class _UniqueId(__import__('ctypes').Structure):
         _fields_ = [('internal', __import__('ctypes').c_byte * 128)]
 
+    INIT_TIMEOUT_S = 60.0                                  # ncclCommInitRank is bounded by this (R4R_RCCL_INIT_TIMEOUT)
+
     def __init__(self, group=None):
+        """Collective over `group`; every step that can fail on ONE rank only is followed by an agreement over the
+        existing process group, so that a local failure makes every rank raise here together instead of leaving the
+        others inside a broadcast or inside RCCL's bootstrap:
+          1. load the library and resolve its symbols          -> agree
+          2. rank 0 draws the unique id; it broadcasts None when that failed (it always joins the broadcast)
+          3. ncclCommInitRank in a helper thread, joined for at most INIT_TIMEOUT_S -> agree
+        A rank whose init never returns leaves a parked daemon thread behind and reports failure like the others."""
         import ctypes
+        import threading
         self.ct = ctypes
-        path = os.environ.get('R4R_RCCL_LIBRARY') or os.path.join(os.path.dirname(torch.__file__), 'lib', 'librccl.so')
-        lib = self.lib = ctypes.CDLL(path)
-        lib.ncclGetErrorString.restype = ctypes.c_char_p
-        lib.ncclCommInitRank.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, self._UniqueId, ctypes.c_int]
-        lib.ncclAllReduce.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_int,
-                                      ctypes.c_void_p, ctypes.c_void_p]
-        lib.ncclAllGather.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p,
-                                      ctypes.c_void_p]
-        lib.ncclCommDestroy.argtypes = [ctypes.c_void_p]
+        self.comm = None
         self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
+        err = None
+        try:
+            path = os.environ.get('R4R_RCCL_LIBRARY') or os.path.join(os.path.dirname(torch.__file__), 'lib', 'librccl.so')
+            lib = self.lib = ctypes.CDLL(path)
+            lib.ncclGetErrorString.restype = ctypes.c_char_p
+            lib.ncclCommInitRank.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, self._UniqueId, ctypes.c_int]
+            lib.ncclAllReduce.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_int,
+                                          ctypes.c_void_p, ctypes.c_void_p]
+            lib.ncclAllGather.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p,
+                                          ctypes.c_void_p]
+            lib.ncclCommDestroy.argtypes = [ctypes.c_void_p]
+            lib.ncclCommAbort.argtypes = [ctypes.c_void_p]
+            lib.ncclGetUniqueId                               # (resolved now: a missing symbol is a stage-1 failure)
+        except Exception as e:                               # noqa: BLE001
+            err = 'loading RCCL: %s: %s' % (type(e).__name__, e)
+        self._agree(group, err)
         uid = self._UniqueId()
+        box = [None]
         if self.rank == 0:
-            self._check(lib.ncclGetUniqueId(ctypes.byref(uid)), 'ncclGetUniqueId')
-        box = [bytes(bytearray(uid.internal)) if self.rank == 0 else None]
+            rc = lib.ncclGetUniqueId(ctypes.byref(uid))
+            box = [bytes(bytearray(uid.internal)) if rc == 0 else None]
         dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        if box[0] is None:                                   # (every rank sees the same box: a collective decision)
+            raise RuntimeError('RCCL ncclGetUniqueId failed on rank 0')
         ctypes.memmove(ctypes.byref(uid), box[0], 128)
-        self.comm = ctypes.c_void_p()
-        self._check(lib.ncclCommInitRank(ctypes.byref(self.comm), self.world, uid, self.rank), 'ncclCommInitRank')
+        comm, done = ctypes.c_void_p(), {}
+        dev = torch.cuda.current_device()
+
+        def init():
+            try:
+                torch.cuda.set_device(dev)                   # (a new thread starts on device 0)
+                done['rc'] = lib.ncclCommInitRank(ctypes.byref(comm), self.world, uid, self.rank)
+            except Exception as e:                           # noqa: BLE001
+                done['exc'] = e
+
+        th = threading.Thread(target=init, name='r4r-rccl-init', daemon=True)
+        th.start()
+        th.join(float(os.environ.get('R4R_RCCL_INIT_TIMEOUT', self.INIT_TIMEOUT_S)))
+        if th.is_alive():
+            err = 'ncclCommInitRank did not return within its time limit'
+        elif 'exc' in done:
+            err = 'ncclCommInitRank raised %r' % (done['exc'],)
+        elif done.get('rc', 1) != 0:
+            err = 'ncclCommInitRank failed: %s' % lib.ncclGetErrorString(done['rc']).decode()
+        else:
+            self.comm = comm
+        try:
+            self._agree(group, err)
+        except RuntimeError:
+            self.close()
+            raise
+
+    def _agree(self, group, err):
+        """Every rank passes its local error (or None); all raise if any rank has one."""
+        dev = torch.device('cuda', torch.cuda.current_device()) if dist.get_backend(group) == 'nccl' else torch.device('cpu')
+        flag = torch.tensor([0 if err else 1], dtype=torch.int32, device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+        if err:
+            raise RuntimeError('StreamRccl: ' + err)
+        if int(flag.item()) == 0:
+            raise RuntimeError('StreamRccl: another rank failed to set the communicator up')
 
     def _check(self, rc, what):
         if rc != 0:
@@ -106,9 +161,10 @@ class StreamRccl:
         self._check(self.lib.ncclAllGather(t.data_ptr(), out.data_ptr(), nbytes // 4, self.FLOAT32,
                                            self.comm, torch.cuda.current_stream(t.device).cuda_stream), 'ncclAllGather')
 
-    def close(self):
+    def close(self, abort=False):
+        """Destroy the communicator (abort=True: ncclCommAbort -- a communicator with a collective that never ends)."""
         if getattr(self, 'comm', None):
-            self.lib.ncclCommDestroy(self.comm)
+            (self.lib.ncclCommAbort if abort else self.lib.ncclCommDestroy)(self.comm)
             self.comm = None
 
 
@@ -240,27 +296,45 @@ class DataParallel:
         """StreamRccl, proven on this job's fabric before anything depends on it: one all-reduce and one all-gather
         with known answers; every rank must see both right, or ALL ranks fall back to torch.distributed's
         collectives together (a warning, not an error: the exchange is an optimisation of the same sums)."""
+        import time
         import warnings
-        comm, ok, why = None, 1, ''
+        comm, ok, why, hung = None, 1, '', False
         try:
             comm = StreamRccl(group)
             dev = torch.device('cuda', torch.cuda.current_device())
-            t = torch.full((1024,), float(comm.rank + 1), device=dev)
-            comm.all_reduce(t)
-            g = torch.empty(comm.world * 256, device=dev)
-            comm.all_gather(g, torch.full((256,), float(comm.rank), device=dev))
-            torch.cuda.synchronize(dev)
+            # on a stream of its own, waited for with a deadline: a collective that never ends must not sit in the
+            # compute stream (everything enqueued behind it would wait for ever) nor block this thread in a synchronize
+            side = torch.cuda.Stream(device=dev)
+            side.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(side):
+                t = torch.full((1024,), float(comm.rank + 1), device=dev)
+                comm.all_reduce(t)
+                g = torch.empty(comm.world * 256, device=dev)
+                comm.all_gather(g, torch.full((256,), float(comm.rank), device=dev))
+                ev = torch.cuda.Event()
+                ev.record(side)
+            deadline = time.monotonic() + float(os.environ.get('R4R_RCCL_CHECK_TIMEOUT', 30.0))
+            while not ev.query():
+                if time.monotonic() > deadline:
+                    hung = True
+                    raise RuntimeError('the known-answer collectives did not finish within their time limit')
+                time.sleep(0.001)
+            torch.cuda.current_stream(dev).wait_stream(side)
             want = torch.arange(comm.world, device=dev, dtype=torch.float32).repeat_interleave(256)
             if not (bool((t == comm.world * (comm.world + 1) / 2).all()) and torch.equal(g, want)):
                 ok, why = 0, 'a collective returned wrong values'
         except Exception as e:                               # noqa: BLE001 -- whatever went wrong, every rank must hear of it
             ok, why = 0, '%s: %s' % (type(e).__name__, e)
+            if comm is None:                                 # StreamRccl() raised: its own agreements already made
+                warnings.warn('reviews4rec_amd.dist: the on-stream RCCL communicator is not usable here (%s); using '
+                              "torch.distributed's collectives" % why, RuntimeWarning)   # every rank raise together there
+                return None
         flag = torch.tensor([ok], device='cuda', dtype=torch.int32)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
         if int(flag.item()) == 1:
             return comm
         if comm is not None:
-            comm.close()
+            comm.close(abort=hung)
         warnings.warn('reviews4rec_amd.dist: the on-stream RCCL communicator is not usable here (%s); using '
                       "torch.distributed's collectives" % (why or 'another rank reported a failure'), RuntimeWarning)
         return None

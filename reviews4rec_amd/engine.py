@@ -46,16 +46,27 @@ def pad4(E):
     return (int(E) + 3) // 4 * 4
 
 
+def pad_width(E):
+    """Row width the native engines give the frozen table and the conv-weight slots.  Any width is rounded up to whole
+    float4 (the kernels read 16-byte pieces); tables wide enough for project-then-gather (E >= 128) are rounded up
+    to a whole K chunk of 16 floats, which makes every row a whole number of 64-byte pieces: the projection GEMM
+    fetches table rows and weight rows in 64-byte pieces, and at the reference's E = 300 (1,200-byte rows) three of
+    four pieces straddled two 64-byte requests (profiles/r03f: 28 L2 requests per 16-piece load instruction)."""
+    E = int(E)
+    return (E + 15) // 16 * 16 if E >= 128 else pad4(E)
+
+
 def padded_word_table(table):
-    """The HIP kernels read table rows and conv-weight windows as float4: rows must be 16-byte aligned.  The
+    """The HIP kernels read table rows and conv-weight windows as float4: rows must be 16-byte aligned (64-byte
+    aligned from E = 128 on: pad_width).  The
     reference accepts any ``word_embed_size`` (hyper_params.py:64, common_pytorch_models.py:15; GloVe-50 is a
-    common choice), so a table whose width is not a multiple of 4 gets a zero-padded device copy -- it is frozen
+    common choice), so a table whose width is not a multiple of 4 (16) gets a zero-padded device copy -- it is frozen
     (Embedding.from_pretrained, DeepCoNN.py:15), one copy at engine construction is all it takes -- and the conv
     weights live in the engines' flat buffers with the same padded width, their Parameters being the [..., :E]
     views.  Exact: every added term of the convolution is 0 * 0; the pad columns of the weights get a zero
     gradient (g * 0) and a zero weight-decay term, so Adam leaves them at exactly 0."""
     V, E = table.shape
-    E4 = pad4(E)
+    E4 = pad_width(E)
     if E4 == E:
         return table
     out = torch.zeros((V, E4), dtype=table.dtype, device=table.device)
@@ -378,10 +389,14 @@ class DeepCoNNEngine(_ConvRule):
                 self._peer_epoch = 0
             self._peer_epoch += 1                            # (its own count: autotune / scratch calls advance it too)
             gathered = self._peer.exchange(g, self._peer_epoch)
-            rc = _lib.lib().r4r_adam_gathered(ptr(p), gathered, self.dp.world, ptr(g), ptr(m), ptr(v),
-                                              self.total, self.lr, self.betas[0], self.betas[1], self.eps, self.wd,
-                                              int(step), _lib.current_stream())
-            _lib.check(rc, 'r4r_adam_gathered')
+            # guarded by the exchange's timed_out word: after a wait that gave up (a rank that never raised its flag)
+            # the slots are stale or partial, and every rank would apply a different sum -- the update becomes a
+            # no-op on the device and check_exchange() raises on the host (predict / state_dict / every epoch end)
+            rc = _lib.lib().r4r_adam_gathered_guarded(ptr(p), gathered, self.dp.world, ptr(g), ptr(m), ptr(v),
+                                                      self.total, self.lr, self.betas[0], self.betas[1], self.eps,
+                                                      self.wd, int(step), self._peer.local.data_ptr() + 4,
+                                                      _lib.current_stream())
+            _lib.check(rc, 'r4r_adam_gathered_guarded')
             return
         if self.exchange == 'gather':
             if self._gathered is None:
@@ -426,9 +441,23 @@ class DeepCoNNEngine(_ConvRule):
         self.exchange = keep if os.environ.get('R4R_DP_EXCHANGE') else min(res, key=res.get)
         return res
 
+    def check_exchange(self):
+        """Raise if a peer exchange of this engine timed out (one int read back from the device: called by predict(),
+        state_dict() and main.train at every epoch end, never per step)."""
+        if self._peer is not None:
+            self._peer.check()
+
+    def close(self):
+        """Release the peer exchange's IPC mappings and segment (collective: every rank calls it)."""
+        if self._peer is not None:
+            peer, self._peer = self._peer, None
+            peer.check()
+            peer.close()
+
     @torch.no_grad()
     def predict(self, data, y=None):
         """Eval-mode forward (no dropout, no gradients).  Returns (pred, se or None)."""
+        self.check_exchange()
         if data[5].numel() == 0:                             # an empty batch: nothing to launch
             e = torch.empty(tuple(data[5].shape), dtype=torch.float32, device=self.dev)
             return e, (e.clone() if y is not None else None)
@@ -441,6 +470,7 @@ class DeepCoNNEngine(_ConvRule):
     def state_dict(self):
         """Optimiser-side state of the fused step (the weights themselves live in the model's
         state_dict): Adam moments and step count, the dropout stream position."""
+        self.check_exchange()
         return {'exp_avg': self.flat_m.clone(), 'exp_avg_sq': self.flat_v.clone(), 'step': self.step_count,
                 'dropout_offset': self.offset, 'lr': self.lr, 'weight_decay': self.wd, 'betas': self.betas,
                 'eps': self.eps, 'conv_rule': self._rule_state()}

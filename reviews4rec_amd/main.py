@@ -24,6 +24,7 @@ import torch
 
 from .eval import evaluate, eval_ranking
 from .loss import MSELoss
+from .engine import pad_width as engine_pad_width
 from .utils import file_write, init_transnet_optim, is_cuda_available, log_end_epoch, xavier_init
 
 INF = 10000.0
@@ -136,6 +137,12 @@ def train(model, criterion, optimizer, reader, hyper_params, engine=None, dp=Non
         total_x += float(n_local)
         total_batches += 1
 
+    if engine is not None:
+        # once per epoch, one int each: the blocked sweeps' device-side flag (a touched chunk that was not announced:
+        # stale rows were read -- engine.check_announcements) and the peer exchange's timed_out word
+        for probe in ('check_announcements', 'check_exchange'):
+            if hasattr(engine, probe):
+                getattr(engine, probe)()
     sse = float(engine.sse[0].item()) if engine is not None else (float(device_sum) if device_sum is not None else 0.0)
     if engine is not None and tn:                            # TransNetEngine: sums of the per-batch means
         aux = engine.sse[1:3].clone()
@@ -187,7 +194,7 @@ def native_step_limits(hyper_params, world=1):
         return 'no fused native step for model_type %r' % (mt,)
     if L > 32:
         return 'latent_size %d > 32' % L
-    E = (E + 3) // 4 * 4            # the engines pad rows to a multiple of 4 floats (engine.padded_word_table: exact)
+    E = engine_pad_width(E)         # the engines zero-pad rows to whole float4 / whole K chunks (engine.pad_width: exact)
     if 3 * E // 4 > 512:
         return 'word_embed_size %d > 680' % E
     if mt == 'NARRE':

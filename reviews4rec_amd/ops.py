@@ -37,24 +37,28 @@ def _workspace(nbytes, device):
 
 
 # ------------------------------------------------------------------ TextCNN
-_PADDED_TABLES = {}     # (data_ptr, shape, _version) of a frozen table -> its zero-padded device copy
+_PADDED_TABLES = {}     # (data_ptr, shape, _version) of a frozen table -> (weakref to it, its zero-padded device copy)
 
 
 def _padded_table(table):
     """word_embed_size % 4 != 0 (the reference takes any width, hyper_params.py:64, common_pytorch_models.py:15):
     the kernels read 16-byte aligned rows, so the frozen table gets a cached zero-padded copy; the conv weight is
-    padded per call (100 x 3 x E floats) and the pad columns of its gradient -- exactly 0: g * 0 -- are dropped."""
+    padded per call (100 x 3 x E floats) and the pad columns of its gradient -- exactly 0: g * 0 -- are dropped.
+    The entry holds a weak reference to the tensor it was made from: a later table of the same shape that the
+    allocator places at the same address (a second model built in one process) must not get this one's copy."""
+    import weakref
     E = table.shape[1]
     E4 = (E + 3) // 4 * 4
     if E4 == E:
         return table
     key = (table.data_ptr(), tuple(table.shape), table._version)
-    pt = _PADDED_TABLES.get(key)
-    if pt is None:
-        _PADDED_TABLES.clear()                              # one table per model: no unbounded growth
-        pt = torch.zeros((table.shape[0], E4), dtype=table.dtype, device=table.device)
-        pt[:, :E].copy_(table.detach())
-        _PADDED_TABLES[key] = pt
+    hit = _PADDED_TABLES.get(key)
+    if hit is not None and hit[0]() is table:
+        return hit[1]
+    _PADDED_TABLES.clear()                                  # one table per model: no unbounded growth
+    pt = torch.zeros((table.shape[0], E4), dtype=table.dtype, device=table.device)
+    pt[:, :E].copy_(table.detach())
+    _PADDED_TABLES[key] = (weakref.ref(table), pt)
     return pt
 
 

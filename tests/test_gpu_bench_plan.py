@@ -1,0 +1,161 @@
+"""Parity at the EXACT plans bench.py times: the native engines built from
+`synthetic.hyper_params_for(<BASELINE config>)`, fed the bench's own first batch (same generator, same seed, same
+word table), against the CPU oracle directly -- no chain through smaller shapes or through the module path.
+
+cfg3: DeepCoNNEngine at V = 50,002 / E = 300 / T = 1000 / B = 128: the projection GEMM runs the form the headline
+      runs (A-resident, 7 private row tiles per workgroup + shared tiles; chosen on the device from the batch's
+      distinct-token counts), dropout 0.6 with the device-drawn multipliers injected into the oracle.
+cfg4: NarreEngine at Kindle's 68,223 users / 61,934 items, B = 128 x 10 reviews x 100 words, ONE TRAINING STEP:
+      per-rating SE, every dense parameter and EVERY row of both ID tables and both bias vectors against the oracle's
+      dense Adam (NARRE.py:66-124, main.py:94-96).
+The oracle takes seconds at these sizes (one batch)."""
+import copy
+
+import pytest
+import torch
+
+import oracle
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+
+
+def _bench_first_batch(hp):
+    from reviews4rec_amd import synthetic
+    gen = synthetic.Generator(hp, seed=synthetic.SEED)       # bench.py: seed = SEED + rank
+    data, y = gen.batch(hp['batch_size'])
+    return [torch.from_numpy(d) for d in data], torch.from_numpy(y)
+
+
+def test_deepconn_engine_at_the_benchmarked_plan_against_the_oracle():
+    import reviews4rec_amd
+    from reviews4rec_amd import synthetic
+    from reviews4rec_amd.engine import DeepCoNNEngine
+    hp = synthetic.hyper_params_for('cfg3_deepconn_electronics_e300')            # bench.py's default workload, dropout 0.6
+    assert (hp['vocab'], hp['word_embed_size'], hp['input_length'], hp['batch_size'], hp['dropout']) == (50002, 300, 1000, 128, 0.6)
+    table = torch.from_numpy(synthetic.word_table(hp['vocab'], hp['word_embed_size']))   # the bench's word table
+    P = oracle.init_params(hp, vocab_size=hp['vocab'], seed=37)
+    P['word2vec.weight'] = table
+    model = reviews4rec_amd.get_model_class('deepconn')(dict(hp, word_vectors=table.numpy()))
+    model.load_state_dict(P)
+    model = model.to(DEV).train()
+    eng = DeepCoNNEngine(model, lr=hp['lr'], weight_decay=hp['weight_decay'])
+    assert eng.E == 304 and eng.E_model == 300              # rows padded to whole 64-byte pieces (engine.pad_width)
+    data, y = _bench_first_batch(hp)
+    B, T, L = hp['batch_size'], hp['input_length'], hp['latent_size']
+    dev_data = [d.to(DEV) for d in data]
+
+    # eval forward of the whole batch on the device; the oracle on 8 sampled ratings
+    pred = eng.predict(dev_data, None)[0].cpu().clone()
+    rows = [0, 1, 17, 42, 63, 64, 100, 127]
+    ref = oracle.model_forward(P, [d[rows] for d in data], hp, train=False)
+    torch.testing.assert_close(pred[rows], ref, rtol=1e-5, atol=1e-5)
+    assert float(((pred[rows] - ref) ** 2).mean()) < 1e-4   # SURVEY 8d's parity bound
+
+    # one training step, dropout 0.6, the device's multipliers injected into the oracle
+    se = eng.train_step(dev_data, y.to(DEV)).cpu().clone()
+    rows_used = int(sum(int(c) for c in _distinct_rows(data)))
+    assert 24000 < rows_used < 30720                        # the A-resident plan's range (7 .. 7 1/2 row tiles per workgroup)
+    mult = eng.dropout_multipliers(B, T).cpu()
+    assert set(torch.unique(mult).tolist()) <= {0.0, 2.5}
+    masks = {'user_conv.dropout': mult[:, :L], 'item_conv.dropout': mult[:, L:]}
+    ref_P = copy.deepcopy(P)
+    state = oracle.AdamState()
+    full = dict(ref_P)
+    out = oracle.model_forward(full, data, hp, train=True, masks=masks)
+    ref_se = (out - y) ** 2
+    torch.testing.assert_close(se, ref_se.detach(), rtol=1e-4, atol=1e-5)
+    assert float(((se - ref_se.detach()) ** 2).mean()) < 1e-4
+    sse, grads = oracle.train_step(ref_P, data, y, hp, state, masks=masks)
+    torch.testing.assert_close(se.sum(), torch.tensor(sse), rtol=1e-4, atol=1e-3)
+    got = eng.grads()
+    for k, v in grads.items():
+        if v is None:
+            continue
+        torch.testing.assert_close(got[k].cpu(), v, rtol=2e-4, atol=1e-7, msg=lambda m: k + ': ' + m)
+    sd = model.state_dict()
+    for k, v in ref_P.items():
+        mine = sd[k].cpu()
+        if grads.get(k) is not None:
+            # Adam's first step is lr * g / (|g| + eps): compared where the gradient is well above eps = 1e-8 (the
+            # gradients themselves were compared above); nowhere more than about one lr step apart
+            solid = grads[k].abs() > 1e-6
+            torch.testing.assert_close(mine[solid], v[solid], rtol=1e-5, atol=5e-6, msg=lambda m: k + ': ' + m)
+            assert float((mine - v).abs().max()) < 2.5e-3, k
+        else:
+            assert torch.equal(mine, v), k                   # frozen table, unused `final` / biases: untouched bits
+    # the padded columns of the conv-weight slots stay exactly zero (their gradient is g * 0)
+    for t in (0, 4):
+        o, s = eng.offsets[t], eng.sizes[t]
+        slot = eng.flat_p[o:o + s].view(100, 3, eng.E)
+        assert float(slot[..., 300:].abs().max()) == 0.0
+
+
+def _distinct_rows(data):
+    return [d.unique().numel() for d in (data[3], data[4])]
+
+
+def test_narre_engine_one_training_step_at_kindle_cardinalities_against_the_oracle():
+    import reviews4rec_amd
+    from reviews4rec_amd import synthetic
+    from reviews4rec_amd.engine import NarreEngine
+    from test_oracle_golden import ill_conditioned
+    hp = synthetic.hyper_params_for('cfg4_narre_kindle')                        # bench.py --workload cfg4_narre_kindle
+    hp['input_length'] = hp['narre_num_words']
+    assert (hp['total_users'], hp['total_items'], hp['batch_size']) == (68223, 61934, 128)
+    table = torch.from_numpy(synthetic.word_table(hp['vocab'], hp['word_embed_size']))
+    P = oracle.init_params(hp, vocab_size=hp['vocab'], seed=43)
+    P['word2vec.weight'] = table
+    model = reviews4rec_amd.get_model_class('NARRE')(dict(hp, word_vectors=table.numpy()))
+    model.load_state_dict(P)
+    model = model.to(DEV).train()
+    eng = NarreEngine(model, lr=hp['lr'], weight_decay=hp['weight_decay'])
+    data, y = _bench_first_batch(hp)
+    B, R, L = hp['batch_size'], hp['narre_num_reviews'], hp['latent_size']
+    # a user named by three ratings, an item by two, the tables' last real rows and the padding sentinels
+    data[5][:3] = data[5][0]
+    data[6][4:6] = data[6][4]
+    data[5][B - 1] = hp['total_users'] - 1
+    data[6][B - 2] = hp['total_items'] - 1
+    dev_data = [d.to(DEV) for d in data]
+    se = eng.train_step(dev_data, y.to(DEV)).cpu().clone()
+    mult = eng.dropout_multipliers(dev_data).cpu()
+    RL = R * L
+    masks = {'user_conv.dropout': mult[:, 0:RL].reshape(B * R, L),
+             'item_conv.dropout': mult[:, RL:2 * RL].reshape(B * R, L),
+             'attention_scorer_user.2': mult[:, 2 * RL:3 * RL].reshape(B, R, L),
+             'attention_scorer_item.2': mult[:, 3 * RL:4 * RL].reshape(B, R, L),
+             'dropout.user': mult[:, 4 * RL:4 * RL + L], 'dropout.item': mult[:, 4 * RL + L:4 * RL + 2 * L],
+             'final.0': mult[:, 4 * RL + 2 * L:]}
+    ref_P = copy.deepcopy(P)
+    out = oracle.model_forward(dict(ref_P), data, hp, train=True, masks=masks)
+    ref_se = ((out - y) ** 2).detach()
+    torch.testing.assert_close(se, ref_se, rtol=1e-4, atol=1e-4)
+    assert float(((se - ref_se) ** 2).mean()) < 1e-4
+    sse, grads = oracle.train_step(ref_P, data, y, hp, oracle.AdamState(), masks=masks)
+    torch.testing.assert_close(se.sum(), torch.tensor(sse), rtol=1e-4, atol=1e-3)
+    sd = model.state_dict()
+    assert sd['user_embedding.weight'].shape == (hp['total_users'] + 2, L)       # NARRE.py:20-21
+    assert sd['item_embedding.weight'].shape == (hp['total_items'] + 2, L)
+    named = {'user_embedding.weight': torch.cat([data[5], data[1].reshape(-1)]).unique(),
+             'item_embedding.weight': torch.cat([data[6], data[2].reshape(-1)]).unique(),
+             'user_bias': data[5].unique(), 'item_bias': data[6].unique()}
+    for k, v in ref_P.items():
+        mine = sd[k].cpu()
+        if k in named:
+            # EVERY row: those no rating names move by weight decay alone (the same arithmetic on both sides:
+            # the hardware's sqrt / rcp are within 1 ulp each); the named rows by their summed gradient
+            rest = torch.ones(v.shape[0], dtype=torch.bool)
+            rest[named[k]] = False
+            torch.testing.assert_close(mine[rest], v[rest], rtol=1e-5, atol=1e-7, msg=lambda m: k + ' (rows no rating names): ' + m)
+            g = grads[k][named[k]]
+            solid = g.abs() > 1e-6
+            torch.testing.assert_close(mine[named[k]][solid], v[named[k]][solid], rtol=1e-4, atol=2e-5,
+                                       msg=lambda m: k + ' (named rows): ' + m)
+            assert float((mine - v).abs().max()) < 2.5e-3, k
+        elif grads.get(k) is not None and not ill_conditioned(k):
+            solid = grads[k].abs() > 1e-6
+            torch.testing.assert_close(mine[solid], v[solid], rtol=1e-5, atol=5e-6, msg=lambda m: k + ': ' + m)
+            assert float((mine - v).abs().max()) < 2.5e-3, k
+        elif grads.get(k) is None:
+            assert torch.equal(mine, v), k
