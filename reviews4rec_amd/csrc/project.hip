@@ -674,6 +674,9 @@ constexpr int AR_PMIN = R4R_AR_PMIN, AR_PMAX = 7;  // private row tiles per work
 #ifndef R4R_AR_HALF
 #define R4R_AR_HALF 1                              // row tiles shared by two workgroups past 7 1/3 row tiles per workgroup (0: those launches take form 1)
 #endif
+#ifndef R4R_AR_DB1
+#define R4R_AR_DB1 1                               // pass 1: the same (1 or 3)
+#endif
 #ifndef R4R_AR_DB
 #define R4R_AR_DB 1                                // pass 2: chunks the weight fragments are requested ahead of their MFMAs (1 or 3; 3 measured no faster)
 #endif
@@ -807,7 +810,7 @@ __device__ __forceinline__ void ares_pass(const AresCtx &x, int rt0, const float
     // requested DB chunks ahead into a ring of DB + 1 sets.  (A timing ablation with the free pass's weight loads
     // aimed at one hot line took pass 2 from 11.7 to 8.8 us; requesting them 3 chunks ahead instead of 1 did NOT
     // -- 12.3 us: what those loads cost is their 16 lines per instruction in the address path, not their latency.)
-    constexpr int DB = S > 0 ? 1 : R4R_AR_DB, RB = DB + 1;
+    constexpr int DB = S > 0 ? R4R_AR_DB1 : R4R_AR_DB, RB = DB + 1;
     const int E = x.E, nchunk = x.nchunk;
     f32x4 ar[SS];
     auto ld_a = [&](int s, f32x4 (&r)[SS]) {                 // super-chunk s = chunks s S .. s S + S - 1 (past the end: the last chunk again)
@@ -855,7 +858,7 @@ __device__ __forceinline__ void ares_pass(const AresCtx &x, int rt0, const float
     AresB<NCW> ob[RB];
     if (S > 0) {
         ld_a(0, ar);
-        req_b(0, ob[0]);                                     // weight fragments of chunk 0: in flight under the staging
+        static_for<0, DB>([&](auto kc) { req_b(decltype(kc)::value, ob[decltype(kc)::value]); });   // weight fragments of the first chunk(s): in flight under the staging
         st_a(0, ar);
         ld_a(1, ar);
         __syncthreads();                                     // super-chunk 0 in LDS
