@@ -74,6 +74,22 @@ def padded_word_table(table):
     return out
 
 
+def flush_before_state_dict(engine, model):
+    """The temporally blocked sweeps leave table chunks no recent batch named up to `sweep_period - 1` steps behind
+    until engine.flush(); the reference's Parameters are always current (main.py:125 reads state_dict() whenever it
+    likes).  A state_dict pre-hook on the model and every submodule brings the pending updates in first, so
+    ``model.state_dict()`` / ``torch.save(model.state_dict())`` are the model at any point of an epoch.  (A direct read
+    of ``model.user_embedding.weight`` between flushes cannot be intercepted: call ``engine.flush()`` first.)"""
+    import weakref
+    ref = weakref.ref(engine)
+
+    def pre_hook(module, prefix, keep_vars):
+        e = ref()
+        if e is not None:
+            e.flush()
+    return [m.register_state_dict_pre_hook(pre_hook) for m in model.modules()]
+
+
 def slot_view(flat, o, s, shape, E_model, E):
     """View of flat[o : o + s] with a parameter's shape; conv weights ([F, 1, 3, E_model]) of a padded engine are
     the leading E_model columns of their [F, 1, 3, E] slot."""
@@ -539,6 +555,7 @@ class MFEngine:
         # visit period of the temporally blocked table sweep (include/r4r.h; 1 = the plain dense sweep)
         self.sweep_period = max(1, min(8, int(os.environ.get('R4R_SWEEP_PERIOD', hp.get('sweep_period', 8)))))
         self._tb_promised, self._tb_next = None, None
+        self._sd_hooks = flush_before_state_dict(self, model)
 
     TEMPORAL_SWEEP = True        # train_step(..., defer_sweep=True) + flush(): the table sweep, temporally blocked
 
@@ -1228,6 +1245,7 @@ class TransNetEngine(NarreEngine):
         self.ROW_NAMES = ['user_embedding.weight', 'item_embedding.weight'] if self.plus else []
         self._hp_counts = (int(model.hyper_params['total_users']) + 2, int(model.hyper_params['total_items']) + 2)
         super().__init__(model, dp=dp, **kw)
+        self._sd_hooks = flush_before_state_dict(self, model)
 
     @staticmethod
     def _word_table(model):
@@ -1510,6 +1528,7 @@ class IdNetEngine:
         # visit period of the temporally blocked table sweeps (include/r4r.h; 1 = the plain dense sweeps)
         self.sweep_period = max(1, min(8, int(os.environ.get('R4R_SWEEP_PERIOD', hp.get('sweep_period', 8)))))
         self._tb_promised = None
+        self._sd_hooks = flush_before_state_dict(self, model)
 
     TEMPORAL_SWEEP = True        # train_step(..., defer_sweep=True) + flush(): the table sweeps, temporally blocked
     has_tables = True
