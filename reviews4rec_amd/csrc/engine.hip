@@ -280,6 +280,188 @@ __global__ __launch_bounds__(256) void deepconn_head_kernel(HeadArgs a) {
     HEAD_STAMP(4)
 }
 
+// ---- the same head, ONE WORKGROUP PER RATING (the default since round 4; R4R_HEAD_WG=0 builds the launch above).
+// The four-ratings-per-workgroup form puts a batch of 128 on 32 CUs, and each of its lanes waits for 64 partial
+// loads + 13 weight loads in its first round trip: 4.7 us of an 11 us launch (tools/head_trace.py) on a chip whose
+// other 224 CUs idle.  Here wave w finishes the pool of (tower w >> 1, filters 64 (w & 1) ..): 16 partial loads per
+// lane; the FC layers' 2 L x 100 products are spread over all 256 threads (PARTS threads per output, summed in a
+// fixed order through LDS: deterministic); wave 0 alone runs the FM's cross-lane sums; the backward to g_pooled is
+// one output per thread.  Same Philox draws per (rating, output) as the form above: identical dropout masks.
+#ifndef R4R_HEAD_WG
+#define R4R_HEAD_WG 1
+#endif
+template <int ML>
+__global__ __launch_bounds__(256) void deepconn_head_wg_kernel(HeadArgs a) {
+    HEAD_STAMP(0)
+    constexpr int N2 = 2 * ML, PARTS = 256 / N2;      // FC outputs (both towers); threads per output: 8 | 4
+    __shared__ float sw[2][ML][F_CONV + 1];            // FC weights, +1 pad
+    __shared__ float sfb[N2], slw[N2], sz[N2];
+    __shared__ float sV[N2][FM_K];
+    __shared__ float sp[2][F_CONV + 4];                 // pooled
+    __shared__ float red[N2][PARTS + 1];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int64_t b = blockIdx.x;
+    const int L = a.L, n = 2 * L;
+    const float lin_b0 = a.lin_b[0], gbias0 = a.gbias[0], yb = a.y ? a.y[b] : 0.f;
+
+    // every load of the prologue is issued before anything waits: the FC matrices, FM V / lin, and this lane's partials
+    constexpr int WREGS = (2 * ML * F_CONV + 255) / 256;
+    float wreg[WREGS];
+    const int wtot = 2 * L * F_CONV;
+#pragma unroll
+    for (int k = 0; k < WREGS; ++k) {
+        wreg[k] = 0.f;
+        if (256 * k < wtot) {                               // uniform
+            const int i = min(tid + 256 * k, wtot - 1);
+            const int t = i >= L * F_CONV;
+            wreg[k] = a.fc_w[t][i - t * L * F_CONV];
+        }
+    }
+    const float fbreg = (tid < n) ? a.fc_b[tid / L][tid % L] : 0.f;
+    const float lwreg = (tid < n) ? a.lin_w[tid] : 0.f;
+    constexpr int VREGS = (N2 * FM_K + 255) / 256;
+    float vreg[VREGS];
+#pragma unroll
+    for (int k = 0; k < VREGS; ++k) vreg[k] = a.V[min(tid + 256 * k, n * FM_K - 1)];
+
+    // ---- pool finish of (tower t, filter f): max over the tiles, relu, first argmax
+    {
+        const int t = w >> 1, f = lane + 64 * (w & 1), fc = min(f, F_CONV - 1);
+        float best = -INFINITY;
+        int bp = -1;
+        if (a.tiles <= HEAD_MAX_TILES) {
+            float v[HEAD_MAX_TILES];
+            int pp[HEAD_MAX_TILES];
+#pragma unroll
+            for (int k = 0; k < HEAD_MAX_TILES; ++k) {
+                const size_t o = ((size_t)b * a.tiles + min(k, a.tiles - 1)) * NP + fc;
+                v[k] = a.pmax[t][o];
+                pp[k] = a.parg[t][o];
+            }
+#pragma unroll
+            for (int k = 0; k < HEAD_MAX_TILES; ++k)           // a clamped duplicate never wins (strict >)
+                if (v[k] > best) { best = v[k]; bp = pp[k]; }
+        } else {
+            for (int k0 = 0; k0 < a.tiles; k0 += HEAD_MAX_TILES) {
+                float v[HEAD_MAX_TILES];
+                int pp[HEAD_MAX_TILES];
+#pragma unroll
+                for (int k = 0; k < HEAD_MAX_TILES; ++k) {
+                    const bool in = k0 + k < a.tiles;
+                    const size_t o = ((size_t)b * a.tiles + (in ? k0 + k : 0)) * NP + fc;
+                    v[k] = in ? a.pmax[t][o] : -INFINITY;
+                    pp[k] = a.parg[t][o];
+                }
+#pragma unroll
+                for (int k = 0; k < HEAD_MAX_TILES; ++k)
+                    if (v[k] > best) { best = v[k]; bp = pp[k]; }
+            }
+        }
+        if (!(best > 0.f)) { best = 0.f; bp = -1; }
+        if (f < F_CONV) {
+            sp[t][f] = best;
+            a.pooled[t][b * F_CONV + f] = best;
+            a.argmax[t][b * F_CONV + f] = bp;
+        }
+    }
+    HEAD_STAMP(1)
+#pragma unroll
+    for (int k = 0; k < WREGS; ++k) {
+        const int i = tid + 256 * k;
+        if (i < wtot) {
+            const int t = i >= L * F_CONV, r = i - t * L * F_CONV, l = r / F_CONV;
+            sw[t][l][r - l * F_CONV] = wreg[k];
+        }
+    }
+    if (tid < n) { sfb[tid] = fbreg; slw[tid] = lwreg; }
+#pragma unroll
+    for (int k = 0; k < VREGS; ++k) {
+        const int i = tid + 256 * k;
+        if (i < n * FM_K) sV[i / FM_K][i % FM_K] = vreg[k];
+    }
+    __syncthreads();
+    HEAD_STAMP(2)
+
+    // ---- FC: output o = tid / PARTS (tower o / L, row o % L), PARTS partial sums of ~100 / PARTS products each
+    {
+        const int o = tid / PARTS, part = tid - o * PARTS;
+        if (o < n) {
+            const int t = o / L, l = o - t * L;
+            float acc = 0.f;
+            for (int f = part; f < F_CONV; f += PARTS) acc = fmaf(sp[t][f], sw[t][l][f], acc);
+            red[o][part] = acc;
+        }
+    }
+    __syncthreads();
+    const bool has_y = a.y != nullptr, want = has_y && a.want_grad;     // uniform across the grid
+    if (w == 0) {
+        float xi = 0.f;
+        if (lane < n) {
+            float acc = 0.f;
+#pragma unroll
+            for (int q = 0; q < PARTS; ++q) acc += red[lane][q];       // fixed order
+            xi = acc + sfb[lane];
+        }
+        // ---- dropout on the FC output (common_pytorch_models.py:37)
+        float mult = 1.f;
+        if (a.training && a.p_drop > 0.f && lane < n) {
+            const uint32_t r = philox_first_word(a.offset + (uint64_t)(b * n + lane), a.seed);
+            const float u = (float)(r >> 8) * (1.0f / 16777216.0f);
+            mult = (u >= a.p_drop) ? 1.f / (1.f - a.p_drop) : 0.f;
+        }
+        xi *= mult;
+        // ---- FM (common_pytorch_models.py:49-57) + global bias
+        float inter = 0.f, gacc = 0.f;
+        float sk_keep[FM_K];
+#pragma unroll
+        for (int k = 0; k < FM_K; ++k) {
+            const float v = (lane < n) ? sV[lane][k] : 0.f;
+            const float s = wave_sum(xi * v);
+            const float s2 = wave_sum(xi * xi * v * v);
+            inter += s * s - s2;
+            gacc += s * v - xi * v * v;
+            sk_keep[k] = s;
+        }
+        const float lw = (lane < n) ? slw[lane] : 0.f;
+        const float lin = wave_sum(xi * lw);
+        const float pred = (0.5f * inter + lin + lin_b0) + gbias0;
+        if (lane == 0) a.pred[b] = pred;
+        if (has_y) {
+            const float d = pred - yb;
+            if (lane == 0) a.se[b] = d * d;
+            if (want) {
+                // ---- backward of the head down to gz
+                const float g = 2.f * d * a.inv_denom;                 // d mean(SE) / d pred
+                const float gx = g * (gacc + lw);                      // d / d x_i
+                const float gz = gx * mult;                            // through dropout
+                if (lane < n) {
+                    sz[lane] = gz;
+                    a.x[b * n + lane] = xi;
+                    a.gz[b * n + lane] = gz;
+                    a.mult[b * n + lane] = mult;
+                }
+                if (lane < FM_K) {
+                    float sv = 0.f;
+#pragma unroll
+                    for (int k = 0; k < FM_K; ++k) if (lane == k) sv = sk_keep[k];
+                    a.s[b * FM_K + lane] = sv;
+                }
+                if (lane == 0) a.g[b] = g;
+            }
+        }
+    }
+    if (!want) return;                                     // uniform across the grid
+    __syncthreads();
+    HEAD_STAMP(3)
+    if (tid < 2 * F_CONV) {
+        const int t = tid >= F_CONV, f = tid - t * F_CONV;
+        float acc = 0.f;
+        for (int l = 0; l < L; ++l) acc = fmaf(sz[t * L + l], sw[t][l][f], acc);
+        a.g_pooled[t][b * F_CONV + f] = acc;
+    }
+    HEAD_STAMP(4)
+}
+
 struct HeadGradArgs {
     const float *pooled[2];      // [B,100]
     const float *x, *s, *g, *gz; // [B,2L], [B,8], [B], [B,2L]
@@ -311,27 +493,44 @@ __device__ __forceinline__ void head_grad_block(const HeadGradArgs &a, int blk) 
             else acc_o -= seg[k];
         }
     }
+    // Every output is a batch sum of  A[b] * (Bf[b] * C[b] - C[b] * C[b] * cv)  with absent factors 1 and cv 0:
+    // the operand addresses are picked ONCE, and the loop requests HB terms' operands before it adds the first
+    // (with the switch inside the loop hipcc kept the loads behind each other: 8 dependent round trips to data
+    // another XCD wrote a moment ago -- the launch's longest chain, 9.4 us of tools/head_trace.py --backward).
+    // Same ascending-b order per output as before.
     float s = 0.f;
     if (which >= 0) {
-#pragma unroll 4
-        for (int64_t b = rg; b < a.B; b += HG_ROWS) {
-            float term;
-            switch (which) {
-                case 0: case 2: {
-                    const int t = which >> 1, l = local / F_CONV, f = local - l * F_CONV;
-                    term = a.gz[b * n + t * L + l] * a.pooled[t][b * F_CONV + f];
-                } break;
-                case 1: case 3: term = a.gz[b * n + (which >> 1) * L + local]; break;
-                case 4: {
-                    const int i = local / FM_K, k = local - i * FM_K;
-                    const float xi = a.x[b * n + i];
-                    term = a.g[b] * (a.s[b * FM_K + k] * xi - xi * xi * a.V[local]);
-                } break;
-                case 5: term = a.g[b] * a.x[b * n + local]; break;
-                case 6: case 7: term = a.g[b]; break;
-                default: term = a.se[b]; break;
+        // (plain selects, no switch: hipcc's lowering of a divergent switch over these pointer assignments lost the
+        // first operand of the `item fc bias` outputs -- found by the golden trajectory test)
+        const bool is_w = which == 0 || which == 2, is_b = which == 1 || which == 3, is_v = which == 4, is_lw = which == 5;
+        const int t = which >> 1;                            // tower of an FC output
+        const int wl = local / F_CONV, wf = local - wl * F_CONV;     // FC weight (l, f)
+        const int vi = local / FM_K, vk = local - vi * FM_K;         // FM V (i, k)
+        const float *pa = (is_w || is_b) ? a.gz : (which == 8 ? a.se : a.g);
+        const int64_t sa = (is_w || is_b) ? n : 1;
+        const int64_t oa = is_w ? t * L + wl : (is_b ? t * L + local : 0);
+        const bool useb = is_w || is_v, usec = is_v || is_lw;
+        const float *pb = is_w ? a.pooled[t & 1] : (is_v ? a.s : a.g);          // (dummies: any readable [B] array)
+        const int64_t sb = is_w ? F_CONV : (is_v ? FM_K : 1), ob = is_w ? wf : (is_v ? vk : 0);
+        const float *pc = usec ? a.x : a.g;
+        const int64_t sc = usec ? n : 1, oc = is_v ? vi : (is_lw ? local : 0);
+        const float cv = is_v ? a.V[local] : 0.f;
+        constexpr int HB = 8;
+        for (int64_t b0 = rg; b0 < a.B; b0 += (int64_t)HG_ROWS * HB) {
+            float va[HB], vb[HB], vc[HB];
+#pragma unroll
+            for (int k = 0; k < HB; ++k) {
+                const int64_t b = min(b0 + (int64_t)k * HG_ROWS, a.B - 1);      // clamped: never added past the end
+                va[k] = pa[b * sa + oa];
+                vb[k] = pb[b * sb + ob];
+                vc[k] = pc[b * sc + oc];
             }
-            s += term;
+#pragma unroll
+            for (int k = 0; k < HB; ++k) {
+                const float B_ = useb ? vb[k] : 1.f, C_ = usec ? vc[k] : 1.f;
+                const float term = va[k] * (B_ * C_ - C_ * C_ * cv);
+                if (b0 + (int64_t)k * HG_ROWS < a.B) s += term;
+            }
         }
     }
     red[rg][ox] = s;
@@ -630,8 +829,13 @@ extern "C" int r4r_deepconn_step(const float *table, int64_t V, const int64_t *u
     h.pred = pred; h.se = se;
     h.B = B; h.L = L; h.tiles = tiles; h.training = training; h.want_grad = flat_g != nullptr;
     h.p_drop = dropout_p; h.inv_denom = inv_denom; h.seed = seed; h.offset = offset;
+#if R4R_HEAD_WG
+    if (L <= 16) deepconn_head_wg_kernel<16><<<(unsigned)B, 256, 0, st>>>(h);
+    else deepconn_head_wg_kernel<32><<<(unsigned)B, 256, 0, st>>>(h);
+#else
     if (L <= 16) deepconn_head_kernel<16><<<(unsigned)cdiv(B, 4), 256, 0, st>>>(h);
     else deepconn_head_kernel<32><<<(unsigned)cdiv(B, 4), 256, 0, st>>>(h);
+#endif
 
     if (!flat_g) {
         if (y && sse_accum) sse_only_kernel<<<1, 256, 0, st>>>(se, sse_accum, B);

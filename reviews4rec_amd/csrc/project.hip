@@ -674,6 +674,9 @@ constexpr int AR_PMIN = R4R_AR_PMIN, AR_PMAX = 7;  // private row tiles per work
 #ifndef R4R_AR_HALF
 #define R4R_AR_HALF 1                              // row tiles shared by two workgroups past 7 1/3 row tiles per workgroup (0: those launches take form 1)
 #endif
+#ifndef R4R_AR_PRE2
+#define R4R_AR_PRE2 1                              // pass 2's first weight fragments are requested before pass 1 starts
+#endif
 #ifndef R4R_AR_DB1
 #define R4R_AR_DB1 1                               // pass 1: the same (1 or 3)
 #endif
@@ -804,7 +807,7 @@ struct AresB { f32x4 b[NCW]; };
 // stores one tile of the PREVIOUS pass's results; one is issued per K step of this pass.  Results stay in acc.
 template <int NR, int NCW, int S, int NPS, typename F>
 __device__ __forceinline__ void ares_pass(const AresCtx &x, int rt0, const float *const (&bptr)[NCW],
-                                          f32x4 (&acc)[NR][NCW], F store_prev) {
+                                          f32x4 (&acc)[NR][NCW], F store_prev, const AresB<NCW> *pre = nullptr) {
     constexpr int SS = S > 0 ? S : 1;
     // Operand registers: the table fragments (LDS) are double-buffered; the weight fragments come from L2 and are
     // requested DB chunks ahead into a ring of DB + 1 sets.  (A timing ablation with the free pass's weight loads
@@ -867,7 +870,13 @@ __device__ __forceinline__ void ares_pass(const AresCtx &x, int rt0, const float
         ld_a(2, ar);
         PRO_STAMP
     } else {
-        static_for<0, DB>([&](auto kc) { req_b(decltype(kc)::value, ob[decltype(kc)::value]); });
+        // (`pre`: chunk 0's weight fragments were requested long ago -- under the previous pass -- by the caller:
+        // the free pass then starts on its MFMAs instead of an L2 round trip with an idle matrix pipe)
+        static_for<0, DB>([&](auto kc) {
+            constexpr int k = decltype(kc)::value;
+            if (k == 0 && pre) ob[0] = *pre;
+            else req_b(k, ob[k]);
+        });
         req_a(0, oa[0]);
     }
     // chunk c (ring position r = c mod lcm(2, RB), compile-time): its operands are in oa[r & 1] / ob[r % RB].  HEAD
@@ -1008,6 +1017,19 @@ __device__ __forceinline__ void proj_gemm_ares_body(const ProjArgs &a, float *ld
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsrc, off, 0, 0);
 #endif
     };
+    // pass 2's first weight fragments: requested before pass 1 (R4R_AR_PRE2)
+    [[maybe_unused]] auto first_frag = [&](const float *wr) {
+        return *reinterpret_cast<const f32x4 *>(wr + min(x.q * 4, a.E - 4));
+    };
+#if R4R_AR_PRE2
+    [[maybe_unused]] AresB<1> pre3;
+    [[maybe_unused]] AresB<NE> prex;
+    if constexpr (NCW == 3) pre3.b[0] = first_frag(wrow(ct0 + 2));
+    else if constexpr (NEX > 0) {
+#pragma unroll
+        for (int j = 0; j < NE; ++j) prex.b[j] = first_frag(wrow(min(p.sh_c0 + eoff + j, PNT - 1)));
+    }
+#endif
     // ---- pass 1: all P row tiles x the wave's first two column tiles; stages the A rows
     const float *b1[2] = {wrow(ct0), wrow(ct0 + 1)};
     f32x4 a1[P][2];
@@ -1029,7 +1051,11 @@ __device__ __forceinline__ void proj_gemm_ares_body(const ProjArgs &a, float *ld
     if constexpr (NCW == 3) {                                // the third column tile
         const float *b2[1] = {wrow(ct0 + 2)};
         f32x4 a2[P][1];
+#if R4R_AR_PRE2
+        ares_pass<P, 1, 0, P * 2>(x, 0, b2, a2, store1, &pre3);
+#else
         ares_pass<P, 1, 0, P * 2>(x, 0, b2, a2, store1);
+#endif
         TRACE_STAMP_LAST(2)
 #pragma unroll
         for (int i = 0; i < P; ++i) store_tile(a2[i][0], p.row0 + i * 16, ct0 + 2);
@@ -1042,7 +1068,11 @@ __device__ __forceinline__ void proj_gemm_ares_body(const ProjArgs &a, float *ld
             be[j] = wrow(ecol[j]);
         }
         f32x4 ax[1][NE];
+#if R4R_AR_PRE2
+        ares_pass<1, NE, 0, P * 2>(x, P, be, ax, store1, &prex);
+#else
         ares_pass<1, NE, 0, P * 2>(x, P, be, ax, store1);
+#endif
         TRACE_STAMP_LAST(2)
 #pragma unroll
         for (int j = 0; j < NE; ++j) store_tile(ax[0][j], p.sh_row0, ecol[j], eoff + j < p.sh_n && p.sh_row0 >= 0);
