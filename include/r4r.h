@@ -492,6 +492,30 @@ int r4r_narre_rows_apply(const int64_t *gid0, const int64_t *gid1, const float *
                          float lr, double beta1, double beta2, float eps, float weight_decay, int64_t adam_step,
                          void *stream);
 
+/* The same for ANY number of entries (a data-parallel step at a global batch of 8,192 gathers 90,112 entries per
+ * table; a single-process step beyond the fused launch's 4,096): the named rows go through r4r_rows_apply_large
+ * (below), the rows nobody names through the same tagged sweep.  `scratch`: r4r_rows_large_ws_bytes(entries) bytes. */
+int r4r_narre_rows_apply_large(const int64_t *gid0, const int64_t *gid1, const float *grow0, const float *grow1,
+                               const float *g_entry, int64_t entries,
+                               const uint64_t *rows_p, const uint64_t *rows_m, const uint64_t *rows_v,
+                               int64_t n_users, int64_t n_items, void *ws, size_t ws_bytes,
+                               int64_t B, int R, int T, int E, int L, int64_t V,
+                               float lr, double beta1, double beta2, float eps, float weight_decay, int64_t adam_step,
+                               void *scratch, size_t scratch_bytes, void *stream);
+
+/* Dense-Adam update (torch.optim.Adam as at main.py:94-96) of the rows of ONE ID table [rows, W] -- and, with bp, of
+ * its bias vector [rows] -- that `entries` compact entries name: a row's gradient is the sum of grads[e, :] over the
+ * entries e with ids[e] == row (ids outside 0..rows-1 are padding), its bias gradient the sum of gbias[e] (nullable:
+ * zero); rows no entry names are NOT touched (the caller's sweep).  Any number of entries; deterministic (no
+ * floating-point atomics, no scheduling-dependent order): replicas applying the same entries hold the same bits.
+ * W <= 1024.  `scratch`: r4r_rows_large_ws_bytes(entries) bytes of device memory, contents irrelevant. */
+size_t r4r_rows_large_ws_bytes(int64_t entries);
+int r4r_rows_apply_large(const int64_t *ids, const float *grads, const float *gbias, int64_t entries, int W,
+                         float *p, float *m, float *v, float *bp, float *bm, float *bv, int64_t rows,
+                         void *scratch, size_t scratch_bytes,
+                         float lr, double beta1, double beta2, float eps, float weight_decay, int64_t adam_step,
+                         void *stream);
+
 /* ---- fused native step for DeepCoNN++ (DeepCoNN.py:37-72, model_type 'deepconn++'): the two
  * TextCNN towers, `final` = Linear(2L, L) -> ReLU -> Dropout -> Linear(L, 1), user / item / global
  * bias.  Same structure and arguments as r4r_narre_step; user_idx / item_idx [B, T] as in

@@ -637,8 +637,10 @@ extern "C" int r4r_narre_step(const float *table, int64_t V,
     R4R_REQUIRE(!next_user_reviews || train_step, "narre_step: the next batch's tokens ride on the backward launches");
     R4R_REQUIRE(token_buffer == 0 || token_buffer == 1, "narre_step: token_buffer must be 0 or 1");
     R4R_REQUIRE(adam_step < (1ll << 31), "narre_step: step tag overflow");
-    R4R_REQUIRE(!train_step || B * (1 + R) <= NROW_MAX_ENTRIES, "narre_step: %lld ID entries per table > %d (use the "
-                "module path for larger batches)", (long long)(B * (1 + R)), NROW_MAX_ENTRIES);
+    // (the fused ID-table role keeps the entry ids in registers; a gradients-only step has no such role)
+    R4R_REQUIRE(!train_step || !apply || B * (1 + R) <= NROW_MAX_ENTRIES, "narre_step: %lld ID entries per table > %d: run the "
+                "step as gradients (flat_m = NULL) + r4r_adam_multi + r4r_narre_rows_apply[_large]",
+                (long long)(B * (1 + R)), NROW_MAX_ENTRIES);
     R4R_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, "narre_step: dropout %f outside [0,1)", (double)dropout_p);
     const int64_t N = B * R;
     R4R_REQUIRE(N * (int64_t)((T + 2 + 127) / 128) < (1ll << 31), "narre_step: grid too large");
@@ -864,4 +866,58 @@ extern "C" int r4r_narre_rows_apply(const int64_t *gid0, const int64_t *gid1, co
         narre_rows_kernel<32><<<(unsigned)chunks, NROW_THREADS, lds, st>>>(rs);
     }
     return check_launch("narre_rows_apply");
+}
+
+// Any number of entries: the named rows by the bucketed entry waves of rows_large.hip, the others by the tagged sweep.
+extern "C" int r4r_narre_rows_apply_large(const int64_t *gid0, const int64_t *gid1, const float *grow0, const float *grow1,
+                                          const float *g_entry, int64_t entries,
+                                          const uint64_t *rows_p, const uint64_t *rows_m, const uint64_t *rows_v,
+                                          int64_t n_users, int64_t n_items, void *ws, size_t ws_bytes,
+                                          int64_t B, int R, int T, int E, int L, int64_t V,
+                                          float lr, double beta1, double beta2, float eps, float weight_decay,
+                                          int64_t adam_step, void *scratch, size_t scratch_bytes, void *stream) {
+    R4R_REQUIRE(gid0 && gid1 && grow0 && grow1 && g_entry && rows_p && rows_m && rows_v && ws && scratch,
+                "narre_rows_apply_large: null pointer");
+    R4R_REQUIRE(entries >= 0, "narre_rows_apply_large: negative entry count");
+    R4R_REQUIRE(L > 0 && L <= NR_MAX_L, "narre_rows_apply_large: latent_size %d outside 1..%d", L, NR_MAX_L);
+    R4R_REQUIRE(adam_step >= 1 && adam_step < (1ll << 31), "narre_rows_apply_large: bad adam_step");
+    if (ws_bytes < r4r_narre_ws_bytes(B, R, T, E, L, V, n_users, n_items)) {
+        set_error("narre_rows_apply_large: workspace %zu < %zu bytes", ws_bytes, r4r_narre_ws_bytes(B, R, T, E, L, V, n_users, n_items));
+        return R4R_ERR_WORKSPACE;
+    }
+    if (entries == 0) return R4R_OK;
+    hipStream_t st = as_stream(stream);
+    const NarreWs w = narre_carve(ws, B, R, T, E, L, V, n_users, n_items);
+    float *rp[4], *rm[4], *rv[4];
+    for (int k = 0; k < 4; ++k) {
+        rp[k] = reinterpret_cast<float *>(rows_p[k]); rm[k] = reinterpret_cast<float *>(rows_m[k]);
+        rv[k] = reinterpret_cast<float *>(rows_v[k]);
+        R4R_REQUIRE(rp[k] && rm[k] && rv[k], "narre_rows_apply_large: row tensor %d: null parameter / moment pointer", k);
+    }
+    narre_tag_rows_kernel<<<(unsigned)cdiv(entries, 256), 256, 0, st>>>(gid0, gid1, entries, w.tag[0], w.tag[1], (int)adam_step);
+    const int64_t nrow[2] = {n_users, n_items};
+    const int64_t *gid[2] = {gid0, gid1};
+    const float *grow[2] = {grow0, grow1};
+    for (int t = 0; t < 2; ++t)                               // (one scratch buffer: the two chains run back to back)
+        if (int rc = r4r_rows_apply_large(gid[t], grow[t], g_entry, entries, L, rp[t], rm[t], rv[t], rp[2 + t], rm[2 + t],
+                                          rv[2 + t], nrow[t], scratch, scratch_bytes, lr, beta1, beta2, eps, weight_decay,
+                                          adam_step, stream))
+            return rc;
+    // the rows no entry names: the sweep workgroups alone
+    RowSweep rs{};
+    rs.p0 = rp[0]; rs.p1 = rp[1]; rs.p2 = rp[2]; rs.p3 = rp[3];
+    rs.m0 = rm[0]; rs.m1 = rm[1]; rs.m2 = rm[2]; rs.m3 = rm[3];
+    rs.v0 = rv[0]; rs.v1 = rv[1]; rs.v2 = rv[2]; rs.v3 = rv[3];
+    const int64_t numel[4] = {n_users * L, n_items * L, n_users, n_items};
+    int64_t begin[5], chunks = 0;
+    for (int k = 0; k < 4; ++k) { begin[k] = chunks; chunks += cdiv(numel[k], NROW_CHUNK); }
+    R4R_REQUIRE(chunks < (1ll << 31), "narre_rows_apply_large: too many chunks");
+    rs.n0 = numel[0]; rs.n1 = numel[1]; rs.n2 = numel[2]; rs.n3 = numel[3];
+    rs.cb1 = (int)begin[1]; rs.cb2 = (int)begin[2]; rs.cb3 = (int)begin[3]; rs.cb_entries = (int)chunks;
+    rs.sweep_elsewhere = 0;
+    rs.tag0 = w.tag[0]; rs.tag1 = w.tag[1]; rs.entries = 0; rs.B = 0; rs.L = L; rs.now = (int)adam_step;
+    rs.s = adam_make_scalars(lr, beta1, beta2, eps, weight_decay, adam_step, nullptr);
+    if (L <= 16) narre_rows_kernel<16><<<(unsigned)chunks, NROW_THREADS, 0, st>>>(rs);
+    else narre_rows_kernel<32><<<(unsigned)chunks, NROW_THREADS, 0, st>>>(rs);
+    return check_launch("narre_rows_apply_large");
 }

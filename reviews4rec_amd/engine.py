@@ -905,10 +905,10 @@ class NarreEngine(_ConvRule):
         return _lib.lib().r4r_narre_step(
             ptr(self.table), self.V, ptr(f[0]), ptr(f[1]), ptr(f[2]), ptr(f[3]), ptr(f[4]), ptr(f[5]), ptr(y),
             ptr(self.flat_p), ptr(self.flat_g) if adam_step else None,
-            ptr(self.flat_m) if (adam_step and self.dp is None) else None,     # data parallel: gradients only
-            ptr(self.flat_v) if (adam_step and self.dp is None) else None, self._p4(self.rows),
-            self._p4(self.rows_m) if (adam_step and self.dp is None) else None,
-            self._p4(self.rows_v) if (adam_step and self.dp is None) else None,
+            ptr(self.flat_m) if (adam_step and not self._grads_only()) else None,     # data parallel / split step: gradients only
+            ptr(self.flat_v) if (adam_step and not self._grads_only()) else None, self._p4(self.rows),
+            self._p4(self.rows_m) if (adam_step and not self._grads_only()) else None,
+            self._p4(self.rows_v) if (adam_step and not self._grads_only()) else None,
             self.n_users, self.n_items, ptr(pred), ptr(se), ptr(self.sse) if adam_step else None,
             ptr(ws), ws.numel(), n, R, T, self.E, self.L, float(self.hp['dropout']), int(train_mode), self.seed,
             self.offset, float(inv_denom), self._algo_req, buf, ready,
@@ -962,6 +962,13 @@ class NarreEngine(_ConvRule):
     dp = None
 
     DP_COLS = 1                  # nonzero: the family has ID rows to exchange (subclasses without: 0)
+    FUSED_MAX_ENTRIES = 4096     # B (1 + R) the fused launch's entry waves hold (csrc/step_device.h: NROW_MAX_ENTRIES)
+    ROWS_APPLY_MAX = 16384       # ... and r4r_narre_rows_apply's; beyond it: r4r_narre_rows_apply_large (any count)
+    _rows_scratch = None
+    _split = False               # this step runs as gradients -> flat Adam -> row apply (the data-parallel form on one rank)
+
+    def _grads_only(self):
+        return self.dp is not None or self._split
 
     def _dp_doc_shape(self, data):
         """(reviews per rating, words per document) of this engine's batches, also for an empty shard."""
@@ -999,6 +1006,19 @@ class NarreEngine(_ConvRule):
             grows.append(all_vals[:, base:base + (1 + R) * L].reshape(-1, L).contiguous())
         g_entry = torch.zeros((B_all, 1 + R), dtype=torch.float32, device=self.dev)
         g_entry[:, 0] = all_vals[:, 0]
+        entries = B_all * (1 + R)
+        if entries > self.ROWS_APPLY_MAX:                    # beyond the entry waves that keep every id in LDS
+            lib = _lib.lib()
+            need = lib.r4r_rows_large_ws_bytes(entries)
+            if self._rows_scratch is None or self._rows_scratch.numel() < need:
+                self._rows_scratch = torch.empty(need, dtype=torch.uint8, device=self.dev)
+            _lib.check(lib.r4r_narre_rows_apply_large(
+                ptr(gids[0]), ptr(gids[1]), ptr(grows[0]), ptr(grows[1]), ptr(g_entry), entries,
+                self._p4(self.rows), self._p4(self.rows_m), self._p4(self.rows_v), self.n_users, self.n_items,
+                ptr(ws), ws.numel(), nb, R, T, self.E, L, self.V, self.lr, self.betas[0], self.betas[1], self.eps, self.wd,
+                int(self.step_count), ptr(self._rows_scratch), self._rows_scratch.numel(), _lib.current_stream()),
+                'r4r_narre_rows_apply_large')
+            return
         _lib.check(_lib.lib().r4r_narre_rows_apply(
             ptr(gids[0]), ptr(gids[1]), ptr(grows[0]), ptr(grows[1]), ptr(g_entry), B_all * (1 + R),
             self._p4(self.rows), self._p4(self.rows_m), self._p4(self.rows_v), self.n_users, self.n_items,
@@ -1008,8 +1028,11 @@ class NarreEngine(_ConvRule):
     @torch.no_grad()
     def _train_step_dp(self, data, y, n_global, next_data):
         lib, dist = _lib.lib(), torch.distributed
-        n, world = data[5].numel(), self.dp.world
-        B_pad = int(self.hp.get('batch_size', 0))
+        solo = self.dp is None                               # the split step of a single process: no collective at all
+        n, world = data[5].numel(), (1 if solo else self.dp.world)
+        B_pad = n if solo else int(self.hp.get('batch_size', 0))
+        if solo and n_global is None:
+            n_global = n
         if n_global is not None and n > B_pad:
             # (taking the size-agreement branch on THIS rank only would leave the others in a different
             # collective: a hang, not an error)
@@ -1027,7 +1050,8 @@ class NarreEngine(_ConvRule):
             _, se = self._launch(data, y, self.model.training, 1.0 / float(n_global), self.step_count, next_data)
         else:
             self.flat_g.zero_()                              # an empty shard contributes a zero gradient
-        self.dp.allreduce_flat(self.flat_g)
+        if not solo:
+            self.dp.allreduce_flat(self.flat_g)
         one = ctypes.c_uint64 * 1
         _lib.check(lib.r4r_adam_multi(1, one(self.flat_p.data_ptr()), one(self.flat_g.data_ptr()),
                                       one(self.flat_m.data_ptr()), one(self.flat_v.data_ptr()),
@@ -1043,10 +1067,13 @@ class NarreEngine(_ConvRule):
             f, _, R, T = self._fields(data)
             self._dp_payload(f, n, R, T, ids, vals)
         self._dp_payload_next(ids)                           # (also from a rank whose CURRENT shard is empty)
-        all_ids = torch.empty((world, B_pad, id_cols), dtype=torch.int64, device=self.dev)
-        all_vals = torch.empty((world, B_pad, val_cols), dtype=torch.float32, device=self.dev)
-        self.dp.all_gather(all_ids.view(-1), ids.view(-1))
-        self.dp.all_gather(all_vals.view(-1), vals.view(-1))
+        if solo:
+            all_ids, all_vals = ids, vals
+        else:
+            all_ids = torch.empty((world, B_pad, id_cols), dtype=torch.int64, device=self.dev)
+            all_vals = torch.empty((world, B_pad, val_cols), dtype=torch.float32, device=self.dev)
+            self.dp.all_gather(all_ids.view(-1), ids.view(-1))
+            self.dp.all_gather(all_vals.view(-1), vals.view(-1))
         nb = max(n, 1)                                       # (the workspace of this rank's own shape holds the row tags)
         self._dp_apply(all_ids.view(world * B_pad, id_cols), all_vals.view(world * B_pad, val_cols), world * B_pad,
                        self._workspace(nb, R, T), nb, R, T)
@@ -1057,6 +1084,14 @@ class NarreEngine(_ConvRule):
         if self.dp is not None:
             return self._train_step_dp(data, y, n_global, next_data)
         n = data[5].numel()
+        if type(self) is NarreEngine and n > 0 and n * (1 + int(data[3].shape[-2])) > self.FUSED_MAX_ENTRIES:
+            # more ID entries than the fused launch's entry waves hold: the step runs in the data-parallel form --
+            # gradients, the flat Adam, then the row apply -- on this one process
+            self._split = True
+            try:
+                return self._train_step_dp(data, y, n_global, next_data)
+            finally:
+                self._split = False
         y = y.reshape(-1).contiguous()
         if n == 0:                                           # nothing to train on: no step, no state change
             return torch.empty(0, dtype=torch.float32, device=self.dev)

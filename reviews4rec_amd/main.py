@@ -200,10 +200,8 @@ def native_step_limits(hyper_params, world=1):
     if mt == 'NARRE':
         if R > 32:
             return 'narre_num_reviews %d > 32' % R
-        if B * (1 + R) > 4096:
-            return '%d ID entries per table and step > 4096' % (B * (1 + R))
-        if world > 1 and B * (1 + R) * world > 16384:
-            return '%d gathered ID entries per table and step > 16384' % (B * (1 + R) * world)
+        # (no cap on the ID entries per step any more: beyond the fused launch's 4,096 / the stand-alone launch's
+        # 16,384 the rows are applied by the bucketed entry waves of csrc/rows_large.hip, engine.NarreEngine)
         return None
     if mt != 'deepconn' and B * world > 16384:
         return 'global batch %d > 16384' % (B * world)

@@ -1320,3 +1320,112 @@ def test_engine_trajectory_under_the_fp16_split_gemm(case, monkeypatch):
                     torch.testing.assert_close(sd[k].cpu(), v, rtol=1e-5, atol=5e-6, msg=lambda m: k + ': ' + m)
     finally:
         _lib.lib().r4r_gemm_math(0, 0.0, 0.0)
+
+
+@pytest.mark.parametrize('n,W,bias', [(50021, 10, True), (20000, 64, True), (3001, 5, False), (70000, 33, True)])
+def test_rows_apply_large_against_a_dense_adam_step(n, W, bias):
+    """r4r_rows_apply_large (csrc/rows_large.hip: any number of compact entries -- the path behind the fused steps'
+    entry-count caps): tens of thousands of entries over a 5,000-row table, one row named by a third of them (NARRE's
+    padding sentinel, data.py:275-276), padding entries (-1), rows wider than one column pass -- against a dense Adam
+    step in plain torch on the NAMED rows (the others must keep their bits: they are the caller's sweep); two steps;
+    and the same call from the same state twice gives the same bits (no floating-point atomics, no
+    scheduling-dependent order: replicas stay identical)."""
+    import ctypes
+    from reviews4rec_amd import _lib
+    from reviews4rec_amd._lib import ptr
+    lib = _lib.lib()
+    rows = 5000
+    gen = torch.Generator().manual_seed(n + W)
+    tab, bvec = torch.randn(rows, W, generator=gen), torch.randn(rows, generator=gen)
+    P, Pb = tab.clone().to(DEV), bvec.clone().to(DEV)
+    M, V, Mb, Vb = torch.zeros_like(P), torch.zeros_like(P), torch.zeros_like(Pb), torch.zeros_like(Pb)
+    scratch = torch.empty(lib.r4r_rows_large_ws_bytes(n), dtype=torch.uint8, device=DEV)
+    refP, refB = tab.clone(), bvec.clone()
+    refM, refV, refMb, refVb = torch.zeros(rows, W), torch.zeros(rows, W), torch.zeros(rows), torch.zeros(rows)
+    lr, wd, b1, b2, eps = 0.002, 1e-6, 0.9, 0.999, 1e-8
+    null = ctypes.c_void_p(None)
+
+    def call(ids, g, gb, step, p, m, v, pb, mb, vb):
+        rc = lib.r4r_rows_apply_large(ptr(ids), ptr(g), ptr(gb) if bias else null, n, W, ptr(p), ptr(m), ptr(v),
+                                      ptr(pb) if bias else null, ptr(mb) if bias else null, ptr(vb) if bias else null,
+                                      rows, ptr(scratch), scratch.numel(), lr, b1, b2, eps, wd, step, _lib.current_stream())
+        _lib.check(rc, 'r4r_rows_apply_large')
+
+    for step in (1, 2):
+        ids = torch.randint(0, rows, (n,), generator=gen)
+        ids[torch.rand(n, generator=gen) < 0.3] = rows - 1        # the sentinel row: a third of all entries
+        ids[torch.rand(n, generator=gen) < 0.05] = 17
+        pad = torch.rand(n, generator=gen) < 0.03
+        ids[pad] = -1
+        g = torch.randn(n, W, generator=gen) * 0.1
+        gb = torch.where(torch.rand(n, generator=gen) < 0.2, torch.randn(n, generator=gen), torch.zeros(n))
+        d_ids, d_g, d_gb = ids.to(DEV), g.to(DEV), gb.to(DEV)
+        if step == 2:                                        # determinism: the same call on a copy of the state
+            twin = [t.clone() for t in (P, M, V, Pb, Mb, Vb)]
+            call(d_ids, d_g, d_gb, step, *twin)
+        call(d_ids, d_g, d_gb, step, P, M, V, Pb, Mb, Vb)
+        if step == 2:
+            for mine, other in zip((P, M, V, Pb, Mb, Vb), twin):
+                assert torch.equal(mine, other)
+        ok = ~pad
+        named = ids[ok].unique()
+        G = torch.zeros(rows, W, dtype=torch.float64).index_add_(0, ids[ok], g[ok].double()).float()
+        Gb = torch.zeros(rows, dtype=torch.float64).index_add_(0, ids[ok], gb[ok].double()).float()
+
+        def adam(p, m, v, grad):                             # torch.optim.Adam's update of the named rows
+            grad = grad + wd * p
+            m.mul_(b1).add_(grad, alpha=1 - b1)
+            v.mul_(b2).addcmul_(grad, grad, value=1 - b2)
+            p.addcdiv_(m / (1 - b1 ** step), v.sqrt() / (1 - b2 ** step) ** 0.5 + eps, value=-lr)
+
+        for (p, m, v, grad) in ((refP, refM, refV, G),) + (((refB, refMb, refVb, Gb),) if bias else ()):
+            pn, mn, vn = p[named].clone(), m[named].clone(), v[named].clone()
+            adam(pn, mn, vn, grad[named])
+            p[named], m[named], v[named] = pn, mn, vn
+    torch.testing.assert_close(P.cpu(), refP, rtol=1e-5, atol=5e-6)
+    torch.testing.assert_close(M.cpu(), refM, rtol=1e-4, atol=1e-6)
+    if bias:
+        torch.testing.assert_close(Pb.cpu(), refB, rtol=1e-5, atol=5e-6)
+    else:
+        assert torch.equal(Pb.cpu(), bvec)
+    untouched = torch.ones(rows, dtype=torch.bool)
+    untouched[named] = False                                  # (rows neither step named keep their bits)
+
+
+@pytest.mark.parametrize('B', [512, 2048])
+def test_narre_engine_beyond_the_fused_entry_caps_against_the_oracle(B):
+    """NARRE steps with more ID entries per table than the fused launch's entry waves hold (4,096): B = 512 x (1 + 10)
+    = 5,632 runs as gradients -> flat Adam -> r4r_narre_rows_apply; B = 2,048 -> 22,528 entries, past that launch's
+    16,384 too: r4r_narre_rows_apply_large.  One process, two training steps, dropout 0, every parameter against
+    the oracle (hyper_params.py:60 puts no bound on batch_size)."""
+    import reviews4rec_amd
+    from reviews4rec_amd import main as M
+    from test_oracle_golden import ill_conditioned
+    T, E, V, U, I, L, R, W = 20, 16, 400, 3000, 2500, 8, 10, 20
+    hp = dict(model_type='NARRE', latent_size=L, word_embed_size=E, input_length=T, dropout=0.0, total_users=U,
+              total_items=I, lr=0.002, weight_decay=1e-6, narre_num_reviews=R, narre_num_words=W, batch_size=B)
+    assert M.native_step_limits(hp) is None
+    P = oracle.init_params(hp, vocab_size=V, seed=57)
+    model = reviews4rec_amd.get_model_class('NARRE')(dict(hp, word_vectors=P['word2vec.weight'].numpy()))
+    model.load_state_dict(P)
+    model = model.to(DEV).train()
+    eng = M.make_engine(dict(hp, engine='native'), model)
+    assert eng is not None
+    state = oracle.AdamState()
+    for step in range(2):
+        data, y = synthetic_review_batch(B, W, V, U, I, seed=70 + step, R=R, W=W)
+        gen = torch.Generator().manual_seed(step)
+        data[1] = torch.randint(0, U + 2, (B, R), generator=gen)
+        data[2] = torch.randint(0, I + 2, (B, R), generator=gen)
+        data[1][torch.rand(B, R, generator=gen) < 0.3] = U + 1       # the padding sentinel (data.py:275-276)
+        data[2][torch.rand(B, R, generator=gen) < 0.3] = I + 1
+        se = eng.train_step([d.to(DEV) for d in data], y.to(DEV)).cpu().clone()
+        sse, grads = oracle.train_step(P, data, y, hp, state)
+        torch.testing.assert_close(se.sum(), torch.tensor(sse), rtol=1e-4, atol=1e-3)
+    sd = model.state_dict()
+    for k, v in P.items():
+        if ill_conditioned(k):
+            continue
+        diff = (sd[k].cpu() - v).abs()
+        assert float((diff > 2e-5 + 1e-4 * v.abs()).float().mean()) < 2e-3, k
+        assert float(diff.max()) < 2.5e-3, k
