@@ -33,7 +33,7 @@ namespace r4r {
 
 constexpr int F_CONV = 100;     // common_pytorch_models.py:11
 constexpr int FM_K = 8;         // DeepCoNN.py:32
-constexpr int MAX_L = 32;
+constexpr int MAX_L = 64;          // (the FM takes 2 L inputs: two per lane of its wave beyond 32)
 
 enum { P_UCW = 0, P_UCB, P_UFW, P_UFB, P_ICW, P_ICB, P_IFW, P_IFB, P_FMV, P_FMLW, P_FMLB, P_GB, P_COUNT };
 
@@ -395,35 +395,52 @@ __global__ __launch_bounds__(256) void deepconn_head_wg_kernel(HeadArgs a) {
     __syncthreads();
     const bool has_y = a.y != nullptr, want = has_y && a.want_grad;     // uniform across the grid
     if (w == 0) {
-        float xi = 0.f;
-        if (lane < n) {
-            float acc = 0.f;
+        // FM input i = lane + 64 u (NI = 2 inputs per lane once 2 L > 64: latent_size 33 .. 64)
+        constexpr int NI = N2 > 64 ? 2 : 1;
+        float xi[NI], mult[NI], lw[NI], gacc[NI];
 #pragma unroll
-            for (int q = 0; q < PARTS; ++q) acc += red[lane][q];       // fixed order
-            xi = acc + sfb[lane];
+        for (int u = 0; u < NI; ++u) {
+            const int i = lane + 64 * u;
+            xi[u] = 0.f; mult[u] = 1.f; gacc[u] = 0.f;
+            lw[u] = (i < n) ? slw[i] : 0.f;
+            if (i < n) {
+                float acc = 0.f;
+#pragma unroll
+                for (int q = 0; q < PARTS; ++q) acc += red[i][q];      // fixed order
+                xi[u] = acc + sfb[i];
+            }
+            // ---- dropout on the FC output (common_pytorch_models.py:37)
+            if (a.training && a.p_drop > 0.f && i < n) {
+                const uint32_t r = philox_first_word(a.offset + (uint64_t)(b * n + i), a.seed);
+                const float uu = (float)(r >> 8) * (1.0f / 16777216.0f);
+                mult[u] = (uu >= a.p_drop) ? 1.f / (1.f - a.p_drop) : 0.f;
+            }
+            xi[u] *= mult[u];
         }
-        // ---- dropout on the FC output (common_pytorch_models.py:37)
-        float mult = 1.f;
-        if (a.training && a.p_drop > 0.f && lane < n) {
-            const uint32_t r = philox_first_word(a.offset + (uint64_t)(b * n + lane), a.seed);
-            const float u = (float)(r >> 8) * (1.0f / 16777216.0f);
-            mult = (u >= a.p_drop) ? 1.f / (1.f - a.p_drop) : 0.f;
-        }
-        xi *= mult;
         // ---- FM (common_pytorch_models.py:49-57) + global bias
-        float inter = 0.f, gacc = 0.f;
+        float inter = 0.f;
         float sk_keep[FM_K];
 #pragma unroll
         for (int k = 0; k < FM_K; ++k) {
-            const float v = (lane < n) ? sV[lane][k] : 0.f;
-            const float s = wave_sum(xi * v);
-            const float s2 = wave_sum(xi * xi * v * v);
-            inter += s * s - s2;
-            gacc += s * v - xi * v * v;
-            sk_keep[k] = s;
+            float pv = 0.f, pv2 = 0.f, vv[NI];
+#pragma unroll
+            for (int u = 0; u < NI; ++u) {
+                const int i = lane + 64 * u;
+                vv[u] = (i < n) ? sV[i][k] : 0.f;
+                pv += xi[u] * vv[u];
+                pv2 += xi[u] * xi[u] * vv[u] * vv[u];
+            }
+            const float sk = wave_sum(pv);
+            const float s2 = wave_sum(pv2);
+            inter += sk * sk - s2;
+#pragma unroll
+            for (int u = 0; u < NI; ++u) gacc[u] += sk * vv[u] - xi[u] * vv[u] * vv[u];
+            sk_keep[k] = sk;
         }
-        const float lw = (lane < n) ? slw[lane] : 0.f;
-        const float lin = wave_sum(xi * lw);
+        float pl = 0.f;
+#pragma unroll
+        for (int u = 0; u < NI; ++u) pl += xi[u] * lw[u];
+        const float lin = wave_sum(pl);
         const float pred = (0.5f * inter + lin + lin_b0) + gbias0;
         if (lane == 0) a.pred[b] = pred;
         if (has_y) {
@@ -432,13 +449,17 @@ __global__ __launch_bounds__(256) void deepconn_head_wg_kernel(HeadArgs a) {
             if (want) {
                 // ---- backward of the head down to gz
                 const float g = 2.f * d * a.inv_denom;                 // d mean(SE) / d pred
-                const float gx = g * (gacc + lw);                      // d / d x_i
-                const float gz = gx * mult;                            // through dropout
-                if (lane < n) {
-                    sz[lane] = gz;
-                    a.x[b * n + lane] = xi;
-                    a.gz[b * n + lane] = gz;
-                    a.mult[b * n + lane] = mult;
+#pragma unroll
+                for (int u = 0; u < NI; ++u) {
+                    const int i = lane + 64 * u;
+                    const float gx = g * (gacc[u] + lw[u]);            // d / d x_i
+                    const float gz = gx * mult[u];                     // through dropout
+                    if (i < n) {
+                        sz[i] = gz;
+                        a.x[b * n + i] = xi[u];
+                        a.gz[b * n + i] = gz;
+                        a.mult[b * n + i] = mult[u];
+                    }
                 }
                 if (lane < FM_K) {
                     float sv = 0.f;
@@ -831,8 +852,10 @@ extern "C" int r4r_deepconn_step(const float *table, int64_t V, const int64_t *u
     h.p_drop = dropout_p; h.inv_denom = inv_denom; h.seed = seed; h.offset = offset;
 #if R4R_HEAD_WG
     if (L <= 16) deepconn_head_wg_kernel<16><<<(unsigned)B, 256, 0, st>>>(h);
-    else deepconn_head_wg_kernel<32><<<(unsigned)B, 256, 0, st>>>(h);
+    else if (L <= 32) deepconn_head_wg_kernel<32><<<(unsigned)B, 256, 0, st>>>(h);
+    else deepconn_head_wg_kernel<64><<<(unsigned)B, 256, 0, st>>>(h);     // latent_size 33 .. 64 (hyper_params.py:63 has no bound)
 #else
+    R4R_REQUIRE(L <= 32, "deepconn_step: the four-ratings-per-workgroup head is built for latent_size <= 32");
     if (L <= 16) deepconn_head_kernel<16><<<(unsigned)cdiv(B, 4), 256, 0, st>>>(h);
     else deepconn_head_kernel<32><<<(unsigned)cdiv(B, 4), 256, 0, st>>>(h);
 #endif

@@ -192,8 +192,8 @@ def native_step_limits(hyper_params, world=1):
         return None
     if mt not in ('deepconn', 'deepconn++', 'NARRE', 'transnet', 'transnet++'):
         return 'no fused native step for model_type %r' % (mt,)
-    if L > 32:
-        return 'latent_size %d > 32' % L
+    if L > (64 if mt == 'deepconn' else 32):     # (DeepCoNN's head takes two FM inputs per lane beyond 32: csrc/engine.hip)
+        return 'latent_size %d > %d' % (L, 64 if mt == 'deepconn' else 32)
     E = engine_pad_width(E)         # the engines zero-pad rows to whole float4 / whole K chunks (engine.pad_width: exact)
     if 3 * E // 4 > 512:
         return 'word_embed_size %d > 680' % E

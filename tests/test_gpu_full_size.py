@@ -176,10 +176,10 @@ def test_word_embed_size_not_a_multiple_of_four_module_path(mt):
             torch.testing.assert_close(got[k], v, rtol=2e-4, atol=1e-6, msg=lambda m: k + ': ' + m)
 
 
-@pytest.mark.parametrize('mt,L', [('deepconn', 48), ('MF', 48), ('transnet++', 80)])
+@pytest.mark.parametrize('mt,L', [('deepconn', 80), ('MF', 48), ('transnet++', 80)])
 def test_latent_size_beyond_the_native_steps(mt, L):
     """latent_size has no bound in the reference (hyper_params.py:63).  The fused native steps are built for
-    latent_size <= 32; beyond that ``engine='auto'`` falls back -- with the reason -- to the op-by-op HIP path,
+    latent_size <= 32 (DeepCoNN's: <= 64, test_deepconn_native_step_at_latent_sizes_up_to_64); beyond that ``engine='auto'`` falls back -- with the reason -- to the op-by-op HIP path,
     whose factorization machine now takes up to 512 inputs (DeepCoNN's FM reads 2 x latent_size): one training
     step's loss and gradients and an eval forward against the CPU oracle at latent_size 48 / 80."""
     import reviews4rec_amd
@@ -530,3 +530,50 @@ def getattr_path(obj, path):
     for part in path.split('.'):
         obj = getattr(obj, part)
     return obj
+
+
+@pytest.mark.parametrize('L,dropout', [(48, 0.0), (64, 0.5), (33, 0.0)])
+def test_deepconn_native_step_at_latent_sizes_up_to_64(L, dropout):
+    """latent_size 33 .. 64 (hyper_params.py:63 has no bound) on DeepCoNN's fused native step -- the
+    head's FM wave takes two of the 2 L inputs per lane -- instead of the 3x slower op-by-op path: two training steps
+    (dropout multipliers drawn on the device, injected into the oracle) and an eval forward against the CPU oracle."""
+    import copy
+    import reviews4rec_amd
+    from reviews4rec_amd import main as M
+    from helpers import synthetic_review_batch
+    B, T, E, V, U, I = 24, 60, 32, 300, 40, 30
+    hp = dict(model_type='deepconn', latent_size=L, word_embed_size=E, input_length=T, dropout=dropout, total_users=U,
+              total_items=I, lr=0.002, weight_decay=1e-6, batch_size=B)
+    assert M.native_step_limits(hp) is None
+    P = oracle.init_params(hp, vocab_size=V, seed=61)
+    model = reviews4rec_amd.get_model_class('deepconn')(dict(hp, word_vectors=P['word2vec.weight'].numpy()))
+    model.load_state_dict(P)
+    model = model.to(DEV).train()
+    eng = M.make_engine(dict(hp, engine='auto', log_file=None), model)
+    assert eng is not None and type(eng).__name__ == 'DeepCoNNEngine'
+    state = oracle.AdamState()
+    for step in range(2):
+        data, y = synthetic_review_batch(B, T, V, U, I, seed=90 + step)
+        se = eng.train_step([d.to(DEV) for d in data], y.to(DEV)).cpu().clone()
+        masks = None
+        if dropout > 0:
+            mult = eng.dropout_multipliers(B, T).cpu()
+            assert 0.3 < float((mult == 0).float().mean()) < 0.7
+            masks = {'user_conv.dropout': mult[:, :L], 'item_conv.dropout': mult[:, L:]}
+        sse, grads = oracle.train_step(P, data, y, hp, state, masks=masks)
+        torch.testing.assert_close(se.sum(), torch.tensor(sse), rtol=1e-4, atol=1e-3)
+        if step == 0:
+            got = eng.grads()
+            for k, v in grads.items():
+                if v is not None:
+                    torch.testing.assert_close(got[k].cpu(), v, rtol=2e-4, atol=1e-6, msg=lambda m: k + ': ' + m)
+    sd = model.state_dict()
+    for k, v in P.items():
+        diff = (sd[k].cpu() - v).abs()
+        assert float((diff > 2e-5 + 1e-4 * v.abs()).float().mean()) < 2e-3, k
+        assert float(diff.max()) < 2.5e-3, k
+    model.eval()
+    data, y = synthetic_review_batch(B, T, V, U, I, seed=99)
+    pred = eng.predict([d.to(DEV) for d in data], None)[0].cpu()
+    ref = oracle.model_forward(P, data, dict(hp, dropout=0.0), train=False)
+    torch.testing.assert_close(pred, ref, rtol=1e-4, atol=1e-4)
