@@ -30,6 +30,7 @@ namespace r4r {
 #define R4R_NHEAD_THREADS 512
 #endif
 constexpr int NHEAD_THREADS = R4R_NHEAD_THREADS;   // threads of the per-rating head workgroup
+constexpr int NARRE_MAX_L = 64, NARRE_MAX_R = 64;  // the head's widest instantiation (the fused ID-table role: NR_MAX_L / NR_MAX_R = 32)
 
 // flat dense-parameter layout (21 slots); slots 0,1 / 4,5 are the conv weight + bias of the towers
 enum { NP_UCW = 0, NP_UCB, NP_UFW, NP_UFB, NP_ICW, NP_ICB, NP_IFW, NP_IFB,
@@ -623,13 +624,16 @@ extern "C" int r4r_narre_step(const float *table, int64_t V,
     R4R_REQUIRE(table && user_reviews && item_reviews && reviewed_items && users_who_reviewed && uid && iid && flat_p &&
                 rows_p && pred && ws, "narre_step: null pointer");
     R4R_REQUIRE(V > 0 && B >= 0 && T > 0 && n_users > 0 && n_items > 0, "narre_step: bad sizes");
-    R4R_REQUIRE(R > 0 && R <= NR_MAX_R, "narre_step: narre_num_reviews %d outside 1..%d", R, NR_MAX_R);
-    R4R_REQUIRE(L > 0 && L <= NR_MAX_L, "narre_step: latent_size %d outside 1..%d", L, NR_MAX_L);
+    R4R_REQUIRE(R > 0 && R <= NARRE_MAX_R, "narre_step: narre_num_reviews %d outside 1..%d", R, NARRE_MAX_R);
+    R4R_REQUIRE(L > 0 && L <= NARRE_MAX_L, "narre_step: latent_size %d outside 1..%d", L, NARRE_MAX_L);
     R4R_REQUIRE(E > 0 && E % 4 == 0, "narre_step: word_embed_size %d must be a positive multiple of 4", E);
     const bool train_step = flat_g != nullptr;
     // flat_m == NULL on a training step: gradients only (flat_g and the compact ID rows in the workspace) -- the
     // data-parallel form (r4r_adam_multi + r4r_narre_rows_apply after the exchange)
     const bool apply = flat_m != nullptr;
+    // (the fused ID-table role keeps a row's L columns in registers: built for L <= 32; wider rows take the split step)
+    R4R_REQUIRE(!(flat_g && apply) || (L <= NR_MAX_L && R <= NR_MAX_R), "narre_step: latent_size %d / narre_num_reviews %d "
+                "beyond %d: run the step as gradients (flat_m = NULL) + r4r_adam_multi + r4r_narre_rows_apply_large", L, R, NR_MAX_L);
     R4R_REQUIRE(!train_step || (y && se && adam_step >= 1 && (!apply || (flat_v && rows_m && rows_v))),
                 "narre_step: a training step needs ratings, se, gradient buffers and adam_step >= 1 (+ moments to update)");
     R4R_REQUIRE(!y || se, "narre_step: se buffer required when y is given");
@@ -706,16 +710,18 @@ extern "C" int r4r_narre_step(const float *table, int64_t V,
     h.now = (int)adam_step; h.p_drop = dropout_p; h.inv_denom = inv_denom; h.seed = seed; h.offset = offset;
     const size_t lds = narre_head_lds_bytes(R, L);
     R4R_REQUIRE(lds <= 160 * 1024, "narre_step: R = %d, L = %d need %zu bytes of LDS", R, L, lds);
-    const bool small = R <= 16 && L <= 16;
-    static size_t lds_set[2] = {0, 0};
-    if (lds > lds_set[small]) {
-        (void)hipFuncSetAttribute(small ? reinterpret_cast<const void *>(narre_head_kernel<16, 16, NHEAD_THREADS>)
-                                        : reinterpret_cast<const void *>(narre_head_kernel<32, 32, NHEAD_THREADS>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        lds_set[small] = lds;
+    const int cls = (R <= 16 && L <= 16) ? 0 : ((R <= 32 && L <= 32) ? 1 : 2);      // instantiation: caps 16 / 32 / 64
+    static size_t lds_set[3] = {0, 0, 0};
+    if (lds > lds_set[cls]) {
+        const void *fn = cls == 0 ? reinterpret_cast<const void *>(narre_head_kernel<16, 16, NHEAD_THREADS>)
+                       : cls == 1 ? reinterpret_cast<const void *>(narre_head_kernel<32, 32, NHEAD_THREADS>)
+                                  : reinterpret_cast<const void *>(narre_head_kernel<64, 64, NHEAD_THREADS>);
+        (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        lds_set[cls] = lds;
     }
-    if (small) narre_head_kernel<16, 16, NHEAD_THREADS><<<(unsigned)B, NHEAD_THREADS, lds, st>>>(h);
-    else narre_head_kernel<32, 32, NHEAD_THREADS><<<(unsigned)B, NHEAD_THREADS, lds, st>>>(h);
+    if (cls == 0) narre_head_kernel<16, 16, NHEAD_THREADS><<<(unsigned)B, NHEAD_THREADS, lds, st>>>(h);
+    else if (cls == 1) narre_head_kernel<32, 32, NHEAD_THREADS><<<(unsigned)B, NHEAD_THREADS, lds, st>>>(h);
+    else narre_head_kernel<64, 64, NHEAD_THREADS><<<(unsigned)B, NHEAD_THREADS, lds, st>>>(h);     // (hyper_params.py:63,78: no bound)
     if (!train_step) return check_launch("narre_step(forward)");
 
     // 4: conv weight gradients + head-parameter column sums (+ next batch's token marks)
@@ -879,7 +885,7 @@ extern "C" int r4r_narre_rows_apply_large(const int64_t *gid0, const int64_t *gi
     R4R_REQUIRE(gid0 && gid1 && grow0 && grow1 && g_entry && rows_p && rows_m && rows_v && ws && scratch,
                 "narre_rows_apply_large: null pointer");
     R4R_REQUIRE(entries >= 0, "narre_rows_apply_large: negative entry count");
-    R4R_REQUIRE(L > 0 && L <= NR_MAX_L, "narre_rows_apply_large: latent_size %d outside 1..%d", L, NR_MAX_L);
+    R4R_REQUIRE(L > 0 && L <= NARRE_MAX_L, "narre_rows_apply_large: latent_size %d outside 1..%d", L, NARRE_MAX_L);
     R4R_REQUIRE(adam_step >= 1 && adam_step < (1ll << 31), "narre_rows_apply_large: bad adam_step");
     if (ws_bytes < r4r_narre_ws_bytes(B, R, T, E, L, V, n_users, n_items)) {
         set_error("narre_rows_apply_large: workspace %zu < %zu bytes", ws_bytes, r4r_narre_ws_bytes(B, R, T, E, L, V, n_users, n_items));

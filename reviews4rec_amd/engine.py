@@ -1007,7 +1007,7 @@ class NarreEngine(_ConvRule):
         g_entry = torch.zeros((B_all, 1 + R), dtype=torch.float32, device=self.dev)
         g_entry[:, 0] = all_vals[:, 0]
         entries = B_all * (1 + R)
-        if entries > self.ROWS_APPLY_MAX:                    # beyond the entry waves that keep every id in LDS
+        if entries > self.ROWS_APPLY_MAX or L > 32:          # beyond the entry waves that keep every id in LDS / a row in registers
             lib = _lib.lib()
             need = lib.r4r_rows_large_ws_bytes(entries)
             if self._rows_scratch is None or self._rows_scratch.numel() < need:
@@ -1084,8 +1084,10 @@ class NarreEngine(_ConvRule):
         if self.dp is not None:
             return self._train_step_dp(data, y, n_global, next_data)
         n = data[5].numel()
-        if type(self) is NarreEngine and n > 0 and n * (1 + int(data[3].shape[-2])) > self.FUSED_MAX_ENTRIES:
-            # more ID entries than the fused launch's entry waves hold: the step runs in the data-parallel form --
+        if type(self) is NarreEngine and n > 0 and (n * (1 + int(data[3].shape[-2])) > self.FUSED_MAX_ENTRIES
+                                                    or self.L > 32 or int(data[3].shape[-2]) > 32):
+            # more ID entries than the fused launch's entry waves hold (or rows wider than they keep in registers:
+            # latent_size / narre_num_reviews 33 .. 64): the step runs in the data-parallel form --
             # gradients, the flat Adam, then the row apply -- on this one process
             self._split = True
             try:

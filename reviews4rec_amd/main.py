@@ -192,14 +192,15 @@ def native_step_limits(hyper_params, world=1):
         return None
     if mt not in ('deepconn', 'deepconn++', 'NARRE', 'transnet', 'transnet++'):
         return 'no fused native step for model_type %r' % (mt,)
-    if L > (64 if mt == 'deepconn' else 32):     # (DeepCoNN's head takes two FM inputs per lane beyond 32: csrc/engine.hip)
-        return 'latent_size %d > %d' % (L, 64 if mt == 'deepconn' else 32)
+    maxL = 64 if mt in ('deepconn', 'NARRE') else 32     # (csrc/engine.hip: two FM inputs per lane beyond 32; csrc/narre_engine.hip:
+    if L > maxL:                                          # the head's 64 x 64 instantiation + the split step)
+        return 'latent_size %d > %d' % (L, maxL)
     E = engine_pad_width(E)         # the engines zero-pad rows to whole float4 / whole K chunks (engine.pad_width: exact)
     if 3 * E // 4 > 512:
         return 'word_embed_size %d > 680' % E
     if mt == 'NARRE':
-        if R > 32:
-            return 'narre_num_reviews %d > 32' % R
+        if R > 64:
+            return 'narre_num_reviews %d > 64' % R
         # (no cap on the ID entries per step any more: beyond the fused launch's 4,096 / the stand-alone launch's
         # 16,384 the rows are applied by the bucketed entry waves of csrc/rows_large.hip, engine.NarreEngine)
         return None

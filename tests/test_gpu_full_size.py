@@ -577,3 +577,45 @@ def test_deepconn_native_step_at_latent_sizes_up_to_64(L, dropout):
     pred = eng.predict([d.to(DEV) for d in data], None)[0].cpu()
     ref = oracle.model_forward(P, data, dict(hp, dropout=0.0), train=False)
     torch.testing.assert_close(pred, ref, rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize('L,R', [(48, 10), (10, 40), (33, 33)])
+def test_narre_native_step_at_latent_sizes_and_review_counts_up_to_64(L, R):
+    """NARRE with latent_size / narre_num_reviews 33 .. 64 (hyper_params.py:63,78 have no bound) on
+    the native engine: the head's 64 x 64 instantiation, and -- the fused ID-table role keeps a row in registers up to
+    L = 32 -- the step as gradients -> flat Adam -> r4r_narre_rows_apply_large.  Two training steps and an eval forward
+    against the CPU oracle."""
+    import reviews4rec_amd
+    from reviews4rec_amd import main as M
+    from helpers import synthetic_review_batch
+    from test_oracle_golden import ill_conditioned
+    B, W, E, V, U, I = 12, 20, 16, 300, 60, 50
+    hp = dict(model_type='NARRE', latent_size=L, word_embed_size=E, input_length=W, dropout=0.0, total_users=U,
+              total_items=I, lr=0.002, weight_decay=1e-6, narre_num_reviews=R, narre_num_words=W, batch_size=B)
+    assert M.native_step_limits(hp) is None
+    P = oracle.init_params(hp, vocab_size=V, seed=67)
+    model = reviews4rec_amd.get_model_class('NARRE')(dict(hp, word_vectors=P['word2vec.weight'].numpy()))
+    model.load_state_dict(P)
+    model = model.to(DEV).train()
+    eng = M.make_engine(dict(hp, engine='auto', log_file=None), model)
+    assert eng is not None and type(eng).__name__ == 'NarreEngine'
+    state = oracle.AdamState()
+    for step in range(2):
+        data, y = synthetic_review_batch(B, W, V, U, I, seed=110 + step, R=R, W=W)
+        gen = torch.Generator().manual_seed(step)
+        data[1] = torch.randint(0, U + 2, (B, R), generator=gen)
+        data[2] = torch.randint(0, I + 2, (B, R), generator=gen)
+        se = eng.train_step([d.to(DEV) for d in data], y.to(DEV)).cpu().clone()
+        sse, grads = oracle.train_step(P, data, y, hp, state)
+        torch.testing.assert_close(se.sum(), torch.tensor(sse), rtol=1e-4, atol=1e-3)
+    sd = model.state_dict()
+    for k, v in P.items():
+        if ill_conditioned(k):
+            continue
+        diff = (sd[k].cpu() - v).abs()
+        assert float((diff > 2e-5 + 1e-4 * v.abs()).float().mean()) < 2e-3, k
+        assert float(diff.max()) < 2.5e-3, k
+    model.eval()
+    pred = eng.predict([d.to(DEV) for d in data], None)[0].cpu()
+    ref = oracle.model_forward(P, data, hp, train=False)
+    torch.testing.assert_close(pred, ref, rtol=1e-4, atol=1e-4)
