@@ -410,6 +410,9 @@ int r4r_mf_rows_flush(const uint64_t *p, const uint64_t *m, const uint64_t *v,
                       void *stream);
 size_t r4r_mf_ws_flag_offset(int64_t B, int D, int64_t n_users, int64_t n_items);
 
+/* accum[0] += sum of se[0 .. n) in a fixed order (the running train metric of main.py:57, kept on the device). */
+int r4r_sse_accumulate(const float *se, int64_t n, float *accum, void *stream);
+
 /* ---- MF under data parallelism: one process per GPU, replicated tables.
  * r4r_mf_grad: this rank's forward + compact gradient rows into one packed `block`
  *   (r4r_mf_dp_block_bytes(B_pad, D) bytes: uid32 [B_pad] | iid32 | g | gu [B_pad, D] | gi; entries

@@ -927,3 +927,12 @@ extern "C" int r4r_deepconn_step(const float *table, int64_t V, const int64_t *u
         wa, red_blocks, comp_blocks, nx, opt);
     return check_launch("deepconn_step");
 }
+
+// accum[0] += sum of se[0 .. n): one workgroup, strided per-thread sums and a fixed tree (deterministic) -- the
+// running train metric of a step whose launches do not carry it (main.py:57: float(torch.sum(loss)), kept on the device)
+extern "C" int r4r_sse_accumulate(const float *se, int64_t n, float *accum, void *stream) {
+    R4R_REQUIRE(accum && (se || n == 0) && n >= 0, "sse_accumulate: bad arguments");
+    if (n == 0) return R4R_OK;
+    sse_only_kernel<<<1, 256, 0, as_stream(stream)>>>(se, accum, n);
+    return check_launch("sse_accumulate");
+}

@@ -689,7 +689,8 @@ class MFEngine:
             self._tb_used = True
         if self.model.training and float(self.hp['dropout']) > 0.0:
             self.offset += n * 2 * self.D
-        self.sse += se[:n].sum()                             # this rank's share; the host loop sums the ranks
+        # this rank's share of the running metric (the host loop sums the ranks): one deterministic launch
+        _lib.check(lib.r4r_sse_accumulate(ptr(se), n, ptr(self.sse), _lib.current_stream()), 'r4r_sse_accumulate')
         return se[:n]
 
     @torch.no_grad()
