@@ -1395,6 +1395,12 @@ __global__ __launch_bounds__(WR_THREADS) void proj_gemm_wres_kernel(ProjArgs a) 
 // slices of a segment are merged through LDS in position order (strict >, so the first
 // maximum wins like PyTorch's max-pool).
 constexpr int SLICE = 32;                 // positions per worker
+#ifndef R4R_GATHER_ROT
+#define R4R_GATHER_ROT 1
+#endif
+#ifndef R4R_GATHER_ROTDIV
+#define R4R_GATHER_ROTDIV 16            // documents per rotation step (A/B at cfg5: 1 .. 64 all help, 16 most: 34.2 -> 30.8 us; cfg3: neutral)
+#endif
 #ifndef R4R_GDEPTH
 #define R4R_GDEPTH 7
 #endif
@@ -1409,10 +1415,25 @@ __global__ __launch_bounds__(256) void proj_gather_max_kernel(ProjArgs a) {
     __shared__ int sbp[8][PF];
     const ProjTower &tw = a.t[blockIdx.y];
     const int worker = threadIdx.x >> 5, wl = threadIdx.x & 31;
+    // Which pair of segments this workgroup takes.  Document-major order puts segment pair k of every document on
+    // workgroups k mod tiles/2 -- and the dispatcher places workgroups 8 apart on one XCD and (one generation of 1,024
+    // resident workgroups on 256 CUs) 256 apart on one CU: with 4 pairs per 1000-word document every CU, and every
+    // XCD, got four workgroups of the SAME pair index -- all heads of documents (real words, five dependent rounds)
+    // or all zero-padded tails (R4R_GATHER_ROT=0: that order).  The pair index is rotated by document / R4R_GATHER_ROTDIV,
+    // so that a CU's workgroups, and an XCD's, mix heads and tails.  Same work per workgroup, same outputs.
+    int64_t bx = blockIdx.x;
+#if R4R_GATHER_ROT
+    if ((a.tiles & 1) == 0 && a.tiles >= 4) {
+        const int t2 = a.tiles >> 1;
+        const int64_t d = bx / t2;
+        const int pr = (int)(bx - d * t2);
+        bx = d * t2 + (pr + (int)(d / R4R_GATHER_ROTDIV)) % t2;
+    }
+#endif
     // segment `unit` of the launch's N * tiles segments (document-major): workers 0-3 take the
     // workgroup's first segment, 4-7 its second -- of the same document, or (odd tile counts, e.g.
     // NARRE's one-tile reviews) the first of the next one
-    const int64_t unit = (int64_t)blockIdx.x * 2 + (worker >> 2), units = a.N * a.tiles;
+    const int64_t unit = bx * 2 + (worker >> 2), units = a.N * a.tiles;
     const int64_t doc = unit < units ? unit / a.tiles : 0;
     const int seg = unit < units ? (int)(unit - doc * a.tiles) : a.tiles;     // a.tiles: no such segment
     const int T = a.T, P = T + 2;
@@ -1505,7 +1526,7 @@ __global__ __launch_bounds__(256) void proj_gather_max_kernel(ProjArgs a) {
     HEAD_STAMP(2)
     // merge the 4 slices of each segment in position order; thread f (< 100) of each half
     const int half = threadIdx.x >> 7, f = threadIdx.x & 127;
-    const int64_t ounit = (int64_t)blockIdx.x * 2 + half;
+    const int64_t ounit = bx * 2 + half;
     if (f < PF && ounit < units) {
         float mb = sbest[half * 4][f];
         int mp = sbp[half * 4][f];
