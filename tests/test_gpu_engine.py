@@ -141,8 +141,10 @@ def test_engine_matches_module_path_at_baseline_shape(algo):
         if k in ref_g:
             # two Adam steps: lr * m / (sqrt(v) + eps) amplifies 1e-9-level gradient differences
             # on elements whose gradient is ~1e-6; the gradients themselves are compared above
+            # (atol: a gradient of 1e-5 known to the 1e-7 the comparison above allows is lr * 1 % = 2e-5 after one
+            # step; one element of 51,530 sat at 2.5e-5 once the head summed its FC products in 8 parts)
             solid = ref_g[k].abs() > 1e-5
-            torch.testing.assert_close(b[k][solid], a[k][solid], rtol=1e-5, atol=2e-5, msg=lambda m: k + ': ' + m)
+            torch.testing.assert_close(b[k][solid], a[k][solid], rtol=1e-5, atol=5e-5, msg=lambda m: k + ': ' + m)
             assert (b[k] - a[k]).abs().max() < 1e-3
 
 
