@@ -313,7 +313,7 @@ extern "C" int r4r_deepconnpp_step(const float *table, int64_t V, const int64_t 
     R4R_REQUIRE(adam_step < (1ll << 31), "deepconnpp_step: step tag overflow");
     R4R_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, "deepconnpp_step: dropout %f outside [0,1)", (double)dropout_p);
     R4R_REQUIRE(B * (int64_t)((T + 2 + 127) / 128) < (1ll << 31), "deepconnpp_step: grid too large");
-    R4R_REQUIRE(!train_step || B <= 16384, "deepconnpp_step: batch %lld > 16384 (the bias sweep keeps a side's ids in LDS; "
+    R4R_REQUIRE(!train_step || B <= 32768, "deepconnpp_step: batch %lld > 32768 (the bias sweep keeps a side's ids in LDS; "
                 "use the module path for larger batches)", (long long)B);
     if (ws_bytes < r4r_deepconnpp_ws_bytes(B, T, E, L, V, n_users, n_items)) {
         set_error("deepconnpp_step: workspace %zu < %zu bytes", ws_bytes, r4r_deepconnpp_ws_bytes(B, T, E, L, V, n_users, n_items));
@@ -449,7 +449,7 @@ extern "C" int r4r_deepconnpp_rows_apply(const int64_t *uid_all, const int64_t *
                                          float lr, double beta1, double beta2, float eps, float weight_decay,
                                          int64_t adam_step, void *stream) {
     R4R_REQUIRE(uid_all && iid_all && g_all && rows_p && rows_m && rows_v && ws, "deepconnpp_rows_apply: null pointer");
-    R4R_REQUIRE(B_all >= 0 && B_all <= 16384, "deepconnpp_rows_apply: %lld gathered ratings outside 0..16384", (long long)B_all);
+    R4R_REQUIRE(B_all >= 0 && B_all <= 32768, "deepconnpp_rows_apply: %lld gathered ratings outside 0..32768", (long long)B_all);
     R4R_REQUIRE(adam_step >= 1 && adam_step < (1ll << 31), "deepconnpp_rows_apply: bad adam_step");
     if (ws_bytes < r4r_deepconnpp_ws_bytes(B, T, E, L, V, n_users, n_items)) {
         set_error("deepconnpp_rows_apply: workspace %zu < %zu bytes", ws_bytes, r4r_deepconnpp_ws_bytes(B, T, E, L, V, n_users, n_items));

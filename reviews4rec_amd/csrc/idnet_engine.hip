@@ -390,7 +390,7 @@ extern "C" int r4r_idnet_step(int variant, const int64_t *uid, const int64_t *ii
     R4R_REQUIRE(!y || se, "idnet_step: se buffer required when y is given");
     R4R_REQUIRE(adam_step < (1ll << 31), "idnet_step: step tag overflow");
     R4R_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, "idnet_step: dropout %f outside [0,1)", (double)dropout_p);
-    R4R_REQUIRE(!train_step || B <= 16384, "idnet_step: batch %lld > 16384 (the table sweeps keep a side's ids in LDS; use the "
+    R4R_REQUIRE(!train_step || B <= 32768, "idnet_step: batch %lld > 32768 (the table sweeps keep a side's ids in LDS; use the "
                 "module path for larger batches)", (long long)B);
     if (ws_bytes < r4r_idnet_ws_bytes(variant, B, L, n_users, n_items)) {
         set_error("idnet_step: workspace %zu < %zu bytes", ws_bytes, r4r_idnet_ws_bytes(variant, B, L, n_users, n_items));
@@ -545,7 +545,7 @@ extern "C" int r4r_idnet_rows_apply(int variant, const int64_t *uid_all, const i
                                     int64_t adam_step, void *stream) {
     R4R_REQUIRE(uid_all && iid_all && g_all && gu_all && gi_all && rows_p && rows_m && rows_v && ws, "idnet_rows_apply: null pointer");
     R4R_REQUIRE(variant >= 0 && variant <= IDN_NEUMF && L > 0 && L <= IDN_MAX_L, "idnet_rows_apply: bad variant / latent_size");
-    R4R_REQUIRE(B_all >= 0 && B_all <= 16384, "idnet_rows_apply: %lld gathered ratings outside 0..16384", (long long)B_all);
+    R4R_REQUIRE(B_all >= 0 && B_all <= 32768, "idnet_rows_apply: %lld gathered ratings outside 0..32768", (long long)B_all);
     R4R_REQUIRE(adam_step >= 1 && adam_step < (1ll << 31), "idnet_rows_apply: bad adam_step");
     R4R_REQUIRE(sweep_period >= 1 && sweep_period <= MF_TB_MAX && !next_uid_all == !next_iid_all,
                 "idnet_rows_apply: sweep_period outside 1..%d, or only one of the next-id arrays", MF_TB_MAX);

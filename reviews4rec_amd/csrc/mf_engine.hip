@@ -32,7 +32,8 @@ namespace r4r {
 
 constexpr int MF_MAX_D = 256;          // latent size: <= 4 elements per lane of the rating's wave
 constexpr int MF_SLOTS = 5;            // user table, item table, user bias, item bias, global bias
-constexpr int MF_MAX_B = 16384;        // the entry waves keep a side's ids in LDS (4 B each)
+constexpr int MF_MAX_B = 32768;        // the stand-alone row ops' entry waves keep a side's ids in LDS (4 B each: 128 KB of the CU's 160)
+constexpr int MF_MAX_B_STEP = 1 << 20; // r4r_mf_step / r4r_mf_apply: owners come from the forward's election slots, ids from global memory
 
 // Owner election: every rating atomicMax-es (step, ~rating number) into its rows' slots; the slot
 // then names the row's FIRST rating of this step (any order of arrival gives the same result).
@@ -863,6 +864,16 @@ static MfWs mf_carve(void *ws, int64_t B, int D, int64_t n_users, int64_t n_item
 // (DeepCoNN++'s user_bias / item_bias, DeepCoNN.py:69-71): the D = 0 form of the sweep above --
 // untouched elements take the gradient-zero update, a touched element the fixed-order sum of its
 // ratings.  `tag_*`: per-element step tags the caller's forward kernel set to `now`.
+// (more than the default 64 KB of dynamic LDS once a side has more than 16,384 ids)
+static void mf_ids_lds_attr() {
+    static bool done = false;
+    if (!done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(mf_adam_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  MF_MAX_B * (int)sizeof(int));
+        done = true;
+    }
+}
+
 int mf_bias_rows_launch(float *ub, float *ub_m, float *ub_v, float *ib, float *ib_m, float *ib_v,
                         int64_t n_users, int64_t n_items, const int64_t *uid, const int64_t *iid, const float *g,
                         const int *tag_u, const int *tag_i, int64_t B, int now, const AdamScalars &sc, hipStream_t st) {
@@ -887,7 +898,7 @@ int mf_bias_rows_launch(float *ub, float *ub_m, float *ub_v, float *ib, float *i
     sw.uid32 = sw.iid32 = nullptr;
     sw.uid = uid; sw.iid = iid; sw.g = g; sw.se = nullptr; sw.sse_accum = nullptr;
     sw.tag_u = tag_u; sw.tag_i = tag_i; sw.B = B; sw.D = 0; sw.now = now; sw.s = sc;
-    mf_adam_kernel<4><<<(unsigned)chunks, MF_THREADS, (size_t)B * sizeof(int), st>>>(sw);
+    { mf_ids_lds_attr(); mf_adam_kernel<4><<<(unsigned)chunks, MF_THREADS, (size_t)B * sizeof(int), st>>>(sw); }
     return check_launch("bias rows");
 }
 
@@ -946,7 +957,7 @@ int mf_table_rows_launch(float *ut, float *ut_m, float *ut_v, float *it, float *
     sw.nt = mf_sweep_nt(sw.n0 + sw.n1);
     {
         ScopedTiming tm(R4R_TIMING_ADAM, st);
-        mf_adam_kernel<4><<<(unsigned)chunks, MF_THREADS, (size_t)B * sizeof(int), st>>>(sw);
+        { mf_ids_lds_attr(); mf_adam_kernel<4><<<(unsigned)chunks, MF_THREADS, (size_t)B * sizeof(int), st>>>(sw); }
     }
     return check_launch("table rows");
 }
@@ -1000,7 +1011,7 @@ int mf_table_bias_rows_launch(float *ut, float *ut_m, float *ut_v, float *it, fl
     sw.tag_u = tag_u; sw.tag_i = tag_i; sw.B = B; sw.D = D; sw.now = now; sw.s = sc;
     {
         ScopedTiming tm(R4R_TIMING_ADAM, st);
-        mf_adam_kernel<4><<<(unsigned)chunks, MF_THREADS, (size_t)B * sizeof(int), st>>>(sw);
+        { mf_ids_lds_attr(); mf_adam_kernel<4><<<(unsigned)chunks, MF_THREADS, (size_t)B * sizeof(int), st>>>(sw); }
     }
     return check_launch("table + bias rows");
 }
@@ -1048,8 +1059,7 @@ extern "C" int r4r_mf_step(const int64_t *uid, const int64_t *iid, const float *
     R4R_REQUIRE(!m || (y && se && adam_step >= 1), "mf_step: a training step needs ratings, the se buffer and "
                                                    "adam_step >= 1");
     R4R_REQUIRE(!y || se, "mf_step: se buffer required when y is given");
-    R4R_REQUIRE(!m || B <= MF_MAX_B, "mf_step: batch %lld > %d (the entry waves keep a side's ids in LDS; use the "
-                                     "module path for larger batches)", (long long)B, MF_MAX_B);
+    R4R_REQUIRE(!m || B <= MF_MAX_B_STEP, "mf_step: batch %lld > %d", (long long)B, MF_MAX_B_STEP);
     R4R_REQUIRE(adam_step < (1ll << 31), "mf_step: step tag overflow");
     R4R_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, "mf_step: dropout %f outside [0,1)", (double)dropout_p);
     if (ws_bytes < r4r_mf_ws_bytes(B, D, n_users, n_items)) {
@@ -1281,7 +1291,7 @@ extern "C" int r4r_mf_apply(const void *blocks, int world, int64_t B_pad, const 
     R4R_REQUIRE(sweep_period >= 1 && sweep_period <= MF_TB_MAX, "mf_apply: sweep_period %d outside 1..%d", sweep_period, MF_TB_MAX);
     R4R_REQUIRE(world >= 1 && B_pad >= 0 && n_users > 0 && n_items > 0, "mf_apply: bad sizes");
     const int64_t B = (int64_t)world * B_pad;
-    R4R_REQUIRE(B <= MF_MAX_B, "mf_apply: %lld gathered entries > %d", (long long)B, MF_MAX_B);
+    R4R_REQUIRE(B <= MF_MAX_B_STEP, "mf_apply: %lld gathered entries > %d", (long long)B, MF_MAX_B_STEP);
     R4R_REQUIRE(D >= 0 && D <= MF_MAX_D, "mf_apply: latent_size %d outside 0..%d", D, MF_MAX_D);
     R4R_REQUIRE(adam_step >= 1 && adam_step < (1ll << 31), "mf_apply: bad adam_step");
     if (ws_bytes < r4r_mf_ws_bytes(B, D, n_users, n_items)) {

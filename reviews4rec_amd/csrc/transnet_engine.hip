@@ -484,7 +484,7 @@ extern "C" int r4r_transnet_step(const float *table, int64_t V,
     R4R_REQUIRE(adam_step < (1ll << 31), "transnet_step: step tag overflow");
     R4R_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, "transnet_step: dropout %f outside [0,1)", (double)dropout_p);
     R4R_REQUIRE(B * (int64_t)((T + 2 + 127) / 128) < (1ll << 31), "transnet_step: grid too large");
-    R4R_REQUIRE(!(plus && train_step) || B <= 16384, "transnet_step: batch %lld > 16384 (the ID-vector sweep keeps a side's ids "
+    R4R_REQUIRE(!(plus && train_step) || B <= 32768, "transnet_step: batch %lld > 32768 (the ID-vector sweep keeps a side's ids "
                 "in LDS; use the module path for larger batches)", (long long)B);
     if (ws_bytes < r4r_transnet_ws_bytes(B, T, E, L, plus, V, n_users, n_items)) {
         set_error("transnet_step: workspace %zu < %zu bytes", ws_bytes,
@@ -678,7 +678,7 @@ extern "C" int r4r_transnet_rows_apply(const int64_t *uid_all, const int64_t *ii
                                        float lr, double beta1, double beta2, float eps, float weight_decay, int64_t adam_step,
                                        void *stream) {
     R4R_REQUIRE(uid_all && iid_all && gu_all && gi_all && rows_p && rows_m && rows_v && ws, "transnet_rows_apply: null pointer");
-    R4R_REQUIRE(B_all >= 0 && B_all <= 16384, "transnet_rows_apply: %lld gathered ratings outside 0..16384", (long long)B_all);
+    R4R_REQUIRE(B_all >= 0 && B_all <= 32768, "transnet_rows_apply: %lld gathered ratings outside 0..32768", (long long)B_all);
     R4R_REQUIRE(sweep_period >= 1 && sweep_period <= MF_TB_MAX && !next_uid_all == !next_iid_all,
                 "transnet_rows_apply: sweep_period outside 1..%d, or only one of the next-id arrays", MF_TB_MAX);
     R4R_REQUIRE(adam_step >= 1 && adam_step < (1ll << 31), "transnet_rows_apply: bad adam_step");

@@ -525,7 +525,7 @@ class MFEngine:
     dense gradient of an ID table is never materialised.  Same calling surface as DeepCoNNEngine
     (train_step / predict / sse / state_dict).  Under data parallelism (``dp``) the step splits into
     r4r_mf_grad -> one all_gather of the ranks' compact rows -> r4r_mf_apply."""
-    MAX_TRAIN_BATCH = 16384      # r4r_mf_step's limit; larger batches take the module path (main.make_engine)
+    MAX_TRAIN_BATCH = 1 << 20    # r4r_mf_step's limit (csrc/mf_engine.hip: MF_MAX_B_STEP)
 
     def __init__(self, model, lr=0.002, weight_decay=1e-6, betas=(0.9, 0.999), eps=1e-8, seed=0x5EED5EED, rank=0,
                  dp=None):
@@ -1506,7 +1506,7 @@ class IdNetEngine:
         'NeuMF': ['gmf_user_embedding.weight', 'gmf_item_embedding.weight', 'mlp_user_embedding.weight',
                   'mlp_item_embedding.weight'],
     }
-    MAX_L, MAX_TRAIN_BATCH = 32, 16384
+    MAX_L, MAX_TRAIN_BATCH = 32, 32768
 
     @staticmethod
     def kind_of(model):

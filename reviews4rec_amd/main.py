@@ -71,7 +71,7 @@ def train(model, criterion, optimizer, reader, hyper_params, engine=None, dp=Non
         # the op-by-op three-optimiser step has no gradient exchange between its three backward passes:
         # replicas would diverge silently (and the sparse-capture placeholders would reach Adam)
         raise RuntimeError("TransNet under data parallelism needs the native step (hyper_params['engine'] = "
-                           "'auto' or 'native', batch_size * world <= 16384); the op-by-op three-optimiser "
+                           "'auto' or 'native', batch_size * world <= 32768); the op-by-op three-optimiser "
                            "step is single-process only")
     # global batch sizes for the loss scale 1/B_global: ONE collective per epoch from the readers' batch
     # sizes (a per-step all-reduce + .item() would serialise the launch queue behind every batch)
@@ -181,14 +181,14 @@ def native_step_limits(hyper_params, world=1):
     if mt in ('MF_dot', 'bias_only'):
         if mt == 'MF_dot' and L > 256:
             return 'latent_size %d > 256' % L
-        if B * world > 16384:
-            return 'global batch %d > 16384' % (B * world)
+        if B * world > (1 << 20):                            # (csrc/mf_engine.hip: MF_MAX_B_STEP)
+            return 'global batch %d > %d' % (B * world, 1 << 20)
         return None
     if mt in ('MF', 'NeuMF'):
         if L > 32:
             return 'latent_size %d > 32' % L
-        if B * world > 16384:
-            return 'global batch %d > 16384' % (B * world)
+        if B * world > 32768:
+            return 'global batch %d > 32768' % (B * world)
         return None
     if mt not in ('deepconn', 'deepconn++', 'NARRE', 'transnet', 'transnet++'):
         return 'no fused native step for model_type %r' % (mt,)
@@ -204,8 +204,8 @@ def native_step_limits(hyper_params, world=1):
         # (no cap on the ID entries per step any more: beyond the fused launch's 4,096 / the stand-alone launch's
         # 16,384 the rows are applied by the bucketed entry waves of csrc/rows_large.hip, engine.NarreEngine)
         return None
-    if mt != 'deepconn' and B * world > 16384:
-        return 'global batch %d > 16384' % (B * world)
+    if mt not in ('deepconn', 'NARRE') and B * world > 32768:       # (the LDS-staged row sweeps of csrc/mf_engine.hip: MF_MAX_B)
+        return 'global batch %d > 32768' % (B * world)
     return None
 
 

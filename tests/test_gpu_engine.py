@@ -428,7 +428,7 @@ def test_mf_engine_equals_module_path_with_duplicates_and_dropout():
 
 
 @pytest.mark.parametrize('D,B', [(64, 5000), (32, 3000), (10, 2500), (64, 16384), (4, 2100), (8, 1000), (128, 1500),
-                                 (256, 2100), (100, 3000)])
+                                 (256, 2100), (100, 3000), (64, 65536), (10, 40000)])     # (past 16,384: hyper_params.py:60 has no bound)
 def test_mf_engine_large_batch_with_popular_rows(D, B):
     """Batches of thousands (SURVEY 8d quotes MF at B = 8,192): an item named by ~14 % of the
     ratings, a user by ~5 %, rows named once, twice, and ids whose first / last rating sit at the
@@ -1241,7 +1241,8 @@ def test_idnet_engine_dropout_masks_injected_into_oracle(case):
         assert float((diff > 2e-5 + 1e-4 * v.abs()).float().mean()) < 2e-3 and float(diff.max()) < 5e-4, k
 
 
-@pytest.mark.parametrize('kind,L,B', [('MF', 32, 3000), ('NeuMF', 10, 2500), ('MLP', 24, 700), ('GMF', 5, 16384)])
+@pytest.mark.parametrize('kind,L,B', [('MF', 32, 3000), ('NeuMF', 10, 2500), ('MLP', 24, 700), ('GMF', 5, 16384), ('GMF', 5, 32768),
+                                      ('MF', 16, 20000)])
 def test_idnet_engine_large_batches_with_popular_rows(kind, L, B):
     """Wide / odd latent sizes and batches where one item collects 14 % of the ratings and one user 5 %: the
     step against the oracle (dropout masks injected), run-to-run bit equality."""
