@@ -74,6 +74,15 @@ def padded_word_table(table):
     return out
 
 
+def promise_key(uid, iid, n):
+    """Identity of an announced batch for the temporally blocked sweeps: where its id tensors live AND their autograd
+    version counters -- a loader that refills the same device buffers in place (copy_, index assignment: every torch
+    write bumps ``_version``) is a different batch, not the promised one, and the engine flushes first.  (Writes
+    behind torch's back -- a raw pointer handed to another library -- are still caught by the device-side flag only:
+    check_announcements(), read at every epoch end.)"""
+    return (uid.data_ptr(), iid.data_ptr(), int(n), uid._version, iid._version)
+
+
 def flush_before_state_dict(engine, model):
     """The temporally blocked sweeps leave table chunks no recent batch named up to `sweep_period - 1` steps behind
     until engine.flush(); the reference's Parameters are always current (main.py:125 reads state_dict() whenever it
@@ -605,7 +614,7 @@ class MFEngine:
             raise RuntimeError('MFEngine: batches must be int64 tensors on the ROCm device')
         uid, iid = uid.contiguous(), iid.contiguous()
         n = uid.numel()
-        if self._tb_promised is not None and (not adam_step or (uid.data_ptr(), iid.data_ptr(), n) != self._tb_promised[0]):
+        if self._tb_promised is not None and (not adam_step or promise_key(uid, iid, n) != self._tb_promised[0]):
             self.flush(last_step=adam_step - 1 if adam_step else None)   # not the announced training step: the tables catch up first
         self._tb_promised, tbn = None, None
         if next_data is not None and adam_step and self.has_tables and self.sweep_period > 1 and next_data[5].numel() > 0:
@@ -627,7 +636,7 @@ class MFEngine:
             _lib.current_stream())
         _lib.check(rc, 'r4r_mf_step')
         if tbn is not None:                                  # (the id tensors stay referenced until the promise is kept)
-            self._tb_promised = ((tbn[0].data_ptr(), tbn[1].data_ptr(), tbn[2]), tbn)
+            self._tb_promised = (promise_key(tbn[0], tbn[1], tbn[2]), tbn)
             self._tb_used = True
         if train_mode and float(self.hp['dropout']) > 0.0:
             self.offset += n * 2 * self.D
@@ -643,7 +652,7 @@ class MFEngine:
         lib, dist = _lib.lib(), torch.distributed
         uid, iid = data[5].reshape(-1).contiguous(), data[6].reshape(-1).contiguous()
         n, world = uid.numel(), self.dp.world
-        if self._tb_promised is not None and (uid.data_ptr(), iid.data_ptr(), n) != self._tb_promised[0]:
+        if self._tb_promised is not None and promise_key(uid, iid, n) != self._tb_promised[0]:
             self.flush(last_step=self.step_count - 1)        # (every rank takes the same branch: the loops run in lockstep)
         self._tb_promised, tbn = None, None
         # (only with the global count known: every shard, the next one included, then fits hyper_params['batch_size'],
@@ -685,7 +694,7 @@ class MFEngine:
                                     self.lr, self.betas[0], self.betas[1], self.eps, self.wd, int(self.step_count),
                                     _lib.current_stream()), 'r4r_mf_apply')
         if tbn is not None:
-            self._tb_promised = ((tbn[0].data_ptr(), tbn[1].data_ptr(), tbn[2]), tbn)
+            self._tb_promised = (promise_key(tbn[0], tbn[1], tbn[2]), tbn)
             self._tb_used = True
         if self.model.training and float(self.hp['dropout']) > 0.0:
             self.offset += n * 2 * self.D
@@ -1320,7 +1329,7 @@ class TransNetEngine(NarreEngine):
     # next batch leaves gradient-zero updates of untouched table chunks pending; whatever is not the announced next
     # training step flushes them first, so that nothing ever reads a table that is behind.
     def _tb_key(self, f, n):
-        return (f[3].data_ptr(), f[4].data_ptr(), n)
+        return promise_key(f[3], f[4], n)
 
     def _launch(self, data, y, train_mode, inv_denom, adam_step, next_data=None):
         if self._tb_promised is not None:
@@ -1427,7 +1436,7 @@ class TransNetEngine(NarreEngine):
         # the temporally blocked sweep under data parallelism: every rank announces its next shard (or none does) and
         # every rank flushes at the same steps -- the loops run in lockstep, and so do these decisions
         n = data[5].numel()
-        key = (data[5].reshape(-1).data_ptr(), data[6].reshape(-1).data_ptr(), n)
+        key = promise_key(data[5].reshape(-1), data[6].reshape(-1), n)
         if self._tb_promised is not None and key != self._tb_promised[0]:
             self.flush(last_step=self.step_count)            # (this step has not counted itself yet)
         self._tb_promised, self._dp_tb = None, None
@@ -1439,7 +1448,7 @@ class TransNetEngine(NarreEngine):
             se = super()._train_step_dp(data, y, n_global, next_data)
             if self._dp_tb is not None:
                 nu, ni, nn = self._dp_tb
-                self._tb_promised = ((nu.data_ptr(), ni.data_ptr(), nn), self._dp_tb)
+                self._tb_promised = (promise_key(nu, ni, nn), self._dp_tb)
                 self._tb_used = True
         finally:
             self._dp_tb = None
@@ -1615,7 +1624,7 @@ class IdNetEngine:
         if not (uid.is_cuda and uid.dtype == torch.int64 and iid.is_cuda and iid.dtype == torch.int64):
             raise RuntimeError('IdNetEngine: batches must be int64 tensors on the ROCm device')
         n = uid.numel()
-        if self._tb_promised is not None and (not adam_step or (uid.data_ptr(), iid.data_ptr(), n) != self._tb_promised[0]):
+        if self._tb_promised is not None and (not adam_step or promise_key(uid, iid, n) != self._tb_promised[0]):
             self.flush(last_step=adam_step - 1 if adam_step else None)   # not the announced training step: the tables catch up first
         self._tb_promised, tbn = None, None
         if next_data is not None and adam_step and self.dp is None and self.sweep_period > 1 and next_data[5].numel() > 0:
@@ -1641,7 +1650,7 @@ class IdNetEngine:
             self.lr, self.betas[0], self.betas[1], self.eps, self.wd, int(adam_step), _lib.current_stream())
         _lib.check(rc, 'r4r_idnet_step')
         if tbn is not None:                                  # (the id tensors stay referenced until the promise is kept)
-            self._tb_promised = ((tbn[0].data_ptr(), tbn[1].data_ptr(), tbn[2]), tbn)
+            self._tb_promised = (promise_key(tbn[0], tbn[1], tbn[2]), tbn)
             self._tb_used = True
         if train_mode and float(self.hp['dropout']) > 0.0:
             self.offset += n * self.draws()
@@ -1670,7 +1679,7 @@ class IdNetEngine:
         B_pad = int(self.hp.get('batch_size', 0))
         # the temporally blocked sweeps under data parallelism: every rank announces its next shard (or none does) and
         # every rank flushes at the same steps -- the loops run in lockstep, and so do these decisions
-        key = (data[5].reshape(-1).data_ptr(), data[6].reshape(-1).data_ptr(), n)
+        key = promise_key(data[5].reshape(-1), data[6].reshape(-1), n)
         if self._tb_promised is not None and key != self._tb_promised[0]:
             self.flush(last_step=self.step_count)            # (this step has not counted itself yet)
         self._tb_promised, tbn = None, None
@@ -1729,7 +1738,7 @@ class IdNetEngine:
             ws.numel(), nb, L, self.lr, self.betas[0], self.betas[1], self.eps, self.wd, int(self.step_count),
             _lib.current_stream()), 'r4r_idnet_rows_apply')
         if tbn is not None:
-            self._tb_promised = ((tbn[0].data_ptr(), tbn[1].data_ptr(), tbn[2]), tbn)
+            self._tb_promised = (promise_key(tbn[0], tbn[1], tbn[2]), tbn)
             self._tb_used = True
         return se
 

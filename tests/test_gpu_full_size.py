@@ -390,10 +390,28 @@ def test_temporally_blocked_mf_sweep_is_the_dense_sweep_bit_for_bit(period, B, m
         blocked[1].train_step(*pool[0], next_data=pool[1][0], defer_sweep=True)
         t = blocked[1]._tb_promised[1]
         u, i = pool[3][0][5].reshape(-1).contiguous(), pool[3][0][6].reshape(-1).contiguous()
-        blocked[1]._tb_promised = ((u.data_ptr(), i.data_ptr(), u.numel()), t)
+        from reviews4rec_amd.engine import promise_key
+        blocked[1]._tb_promised = (promise_key(u, i, u.numel()), t)
         blocked[1].train_step(*pool[3])
         with pytest.raises(RuntimeError, match='not the announced one'):
             blocked[1].check_announcements()
+    if period == 4 and B == 128:
+        # a loader that REFILLS the announced buffers in place (same pointers, new ids): the promise key carries the
+        # tensors' version counters, the engine sees another batch and flushes first -- nothing stale is read, the
+        # tables still equal the plain sweep's to the bit
+        plain2, blocked2 = pair
+        buf_u, buf_i = pool[1][0][5].clone(), pool[1][0][6].clone()
+        plain2[1].train_step(*pool[0])
+        blocked2[1].train_step(*pool[0], next_data=[None] * 5 + [buf_u, buf_i], defer_sweep=True)
+        assert blocked2[1]._tb_promised is not None
+        buf_u.copy_(pool[2][0][5])                            # the refill: batch 2's ids where batch 1's were announced
+        buf_i.copy_(pool[2][0][6])
+        plain2[1].train_step(*pool[2])
+        blocked2[1].train_step([None] * 5 + [buf_u, buf_i], pool[2][1])
+        blocked2[1].check_announcements()                     # (no stale chunk was read)
+        sa, sb = plain2[0].state_dict(), blocked2[0].state_dict()
+        for k in sa:
+            assert torch.equal(sa[k], sb[k]), k
 
 
 @pytest.mark.parametrize('kind,L,period', [('MF', 32, 8), ('NeuMF', 32, 4), ('GMF', 10, 2), ('MLP', 24, 8)])
