@@ -30,9 +30,10 @@ extern "C" const char *r4r_last_error(void) { return r4r::g_err; }
 // Off by default: zero overhead on the normal path.
 // ---------------------------------------------------------------------------
 namespace r4r {
-struct TimedSpan { int id; hipEvent_t a, b; };
+struct TimedSpan { int id; hipEvent_t a, b; bool a_shared; };   // a_shared: `a` is the previous span's `b` (recycled once)
 static unsigned g_timing_mask = 0;             // bit i set -> slot i is instrumented
 static std::vector<TimedSpan> g_spans;         // spans recorded since the last read
+static size_t g_last_ended = 0;                // 1-based index of the span whose end event was recorded last
 static std::vector<hipEvent_t> g_pool;         // recycled events: no create/destroy per launch
 static double g_total_ms[R4R_TIMING_SLOTS];
 static long long g_count[R4R_TIMING_SLOTS];
@@ -50,21 +51,29 @@ static hipEvent_t take_event() {
     return e;
 }
 
-void timing_begin(int id, hipStream_t st, void **token) {
+// chain: this span starts where the span recorded LAST ended -- same stream, nothing launched in between (the caller
+// says so) -- and takes that span's end event as its start: one event record less per instrumented step (a record is a
+// barrier packet in the queue: several microseconds of bubble each).
+void timing_begin(int id, hipStream_t st, void **token, bool chain) {
     *token = nullptr;
     if (!(g_timing_mask & (1u << id))) return;
     TimedSpan s;
     s.id = id;
-    s.a = take_event();
+    // (only behind a span of ANOTHER slot that has ended and is the last one recorded: with the neighbour's slot
+    // masked off the last span is an older launch's, and chaining to it would time everything in between)
+    s.a_shared = chain && !g_spans.empty() && g_spans.back().id != id && g_last_ended == g_spans.size();
+    s.a = s.a_shared ? g_spans.back().b : take_event();
     s.b = take_event();
-    (void)hipEventRecord(s.a, st);
+    if (!s.a_shared) (void)hipEventRecord(s.a, st);
     g_spans.push_back(s);
     *token = reinterpret_cast<void *>(g_spans.size());
 }
+void timing_begin(int id, hipStream_t st, void **token) { timing_begin(id, st, token, false); }
 
 void timing_end(void *token, hipStream_t st) {
     const size_t i = reinterpret_cast<size_t>(token) - 1;
     (void)hipEventRecord(g_spans[i].b, st);
+    g_last_ended = i + 1;
 }
 }  // namespace r4r
 
@@ -85,10 +94,11 @@ extern "C" int r4r_timing_read(int slot, double *total_ms, int64_t *count, int r
             r4r::g_total_ms[s.id] += ms;
             r4r::g_count[s.id] += 1;
         }
-        r4r::g_pool.push_back(s.a);
+        if (!s.a_shared) r4r::g_pool.push_back(s.a);
         r4r::g_pool.push_back(s.b);
     }
     r4r::g_spans.clear();
+    r4r::g_last_ended = 0;
     *total_ms = r4r::g_total_ms[slot];
     *count = r4r::g_count[slot];
     if (reset) {

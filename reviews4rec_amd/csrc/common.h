@@ -13,12 +13,14 @@ void set_error(const char *fmt, ...);
 // live kernel timing (capi.cpp); slots are the R4R_TIMING_* ids of include/r4r.h
 bool timing_on();
 void timing_begin(int id, hipStream_t st, void **token);
+void timing_begin(int id, hipStream_t st, void **token, bool chain);
 void timing_end(void *token, hipStream_t st);
 
 struct ScopedTiming {
     void *tok = nullptr;
     hipStream_t st;
-    ScopedTiming(int id, hipStream_t s) : st(s) { if (timing_on()) timing_begin(id, s, &tok); }
+    // chain: the span starts at the end event of the span recorded last (nothing was launched in between)
+    ScopedTiming(int id, hipStream_t s, bool chain = false) : st(s) { if (timing_on()) timing_begin(id, s, &tok, chain); }
     ~ScopedTiming() { if (tok) timing_end(tok, st); }
 };
 

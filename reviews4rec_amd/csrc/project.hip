@@ -1664,7 +1664,7 @@ int textcnn_proj_compute_launch(const float *table, int64_t V, const ProjTower *
         proj_gemm_kernel<<<dim3((unsigned)wgs), GEMM_THREADS, lds_bytes, st>>>(a);
     }
     {
-        ScopedTiming tm(R4R_TIMING_PROJ_GATHER, st);
+        ScopedTiming tm(R4R_TIMING_PROJ_GATHER, st, /*chain=*/true);     // (starts where the GEMM's span ended)
         proj_gather_max_kernel<<<dim3((unsigned)cdiv(N * a.tiles, 2), ntower), 256, 0, st>>>(a);
     }
     return check_launch("textcnn_proj_fwd");
