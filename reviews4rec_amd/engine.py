@@ -89,14 +89,33 @@ def flush_before_state_dict(engine, model):
     likes).  A state_dict pre-hook on the model and every submodule brings the pending updates in first, so
     ``model.state_dict()`` / ``torch.save(model.state_dict())`` are the model at any point of an epoch.  (A direct read
     of ``model.user_embedding.weight`` between flushes cannot be intercepted: call ``engine.flush()`` first.)"""
-    import weakref
-    ref = weakref.ref(engine)
+    hook = _FlushHook(engine)
+    return [m.register_state_dict_pre_hook(hook) for m in model.modules()]
 
-    def pre_hook(module, prefix, keep_vars):
-        e = ref()
+
+class _FlushHook:
+    """The pre-hook itself: holds the engine weakly (the model must not keep its engine alive) and pickles as an inert
+    hook (``torch.save(model)`` / ``copy.deepcopy(model)`` of a hooked module must keep working: a copy has no engine)."""
+
+    def __init__(self, engine):
+        import weakref
+        self._ref = weakref.ref(engine)
+
+    def __call__(self, module, prefix, keep_vars):
+        e = self._ref()
         if e is not None:
             e.flush()
-    return [m.register_state_dict_pre_hook(pre_hook) for m in model.modules()]
+
+    def __getstate__(self):
+        return {}
+
+    def __setstate__(self, state):
+        self._ref = lambda: None
+
+    def __deepcopy__(self, memo):
+        h = _FlushHook.__new__(_FlushHook)
+        h._ref = lambda: None
+        return h
 
 
 def slot_view(flat, o, s, shape, E_model, E):

@@ -150,3 +150,38 @@ def test_eval_ranking_hr_at_1():
     scores = g.arr('neg_eval')
     expected = round(100.0 * float((scores.argmax(-1) == 0).sum()) / 3, 2)
     assert eval_ranking(model, Reader(), g.hp) == {'HR@1': expected}
+
+
+def test_state_dict_flush_hook_holds_the_engine_weakly_and_survives_pickling():
+    """engine.flush_before_state_dict (the temporally blocked sweeps' pre-hook): state_dict() of the model and of every
+    submodule flushes first; the hook does not keep the engine alive; a pickled / deep-copied model keeps working
+    (its copy of the hook is inert: the copy has no engine)."""
+    import copy
+    import gc
+    import pickle
+    import torch
+    from reviews4rec_amd.engine import flush_before_state_dict
+
+    class Engine:
+        flushes = 0
+
+        def flush(self):
+            self.flushes += 1
+
+    model = torch.nn.Sequential(torch.nn.Linear(2, 2), torch.nn.Sequential(torch.nn.Linear(2, 1)))
+    eng = Engine()
+    hooks = flush_before_state_dict(eng, model)
+    assert len(hooks) == len(list(model.modules()))
+    model.state_dict()
+    assert eng.flushes >= 1
+    before = eng.flushes
+    model[1].state_dict()                                    # a submodule's own state_dict() flushes as well
+    assert eng.flushes > before
+    clone, deep = pickle.loads(pickle.dumps(model)), copy.deepcopy(model)
+    n = eng.flushes
+    clone.state_dict()
+    deep.state_dict()
+    assert eng.flushes == n                                  # the copies' hooks are inert
+    del eng
+    gc.collect()
+    model.state_dict()                                       # the engine is gone: nothing to flush, nothing raised
