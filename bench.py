@@ -483,8 +483,8 @@ def main():
     # leg: the same step function for 200 more steps between the same fences, every 20th step instrumented.  `value`
     # stays the requested region's; the roofline legs average the sampled launches of both (counts stated).
     steady = None
-    if (args.steps < 50 and mask and not dp_job and not args.from_host and graphed is None and engine is not None
-            and not args.no_steady_leg):
+    if (args.steps < 50 and mask and not args.from_host and graphed is None and engine is not None
+            and not args.no_steady_leg):                     # (every rank takes the same branch: the legs' steps are collective)
         STEADY = 200
         el_s = timed_region(step, STEADY, steps_run, mask)
         if hasattr(engine, 'check_announcements'):
