@@ -393,19 +393,32 @@ int r4r_mf_step(const int64_t *uid, const int64_t *iid, const float *y,
                 int64_t n_users, int64_t n_items, int D,
                 float *pred, float *se, float *sse_accum, void *ws, size_t ws_bytes, int64_t B,
                 float dropout_p, int training, uint64_t seed, uint64_t offset, float inv_denom,
-                const int64_t *next_uid, const int64_t *next_iid, int64_t next_B, int sweep_period,
+                int sweep_period, int64_t sweep_base, int sweep_all,
                 float lr, double beta1, double beta2, float eps, float weight_decay, int64_t adam_step,
                 void *stream);
 
-/* next_uid / next_iid [next_B] + sweep_period P in 2..8: the Adam sweep over the two ID tables, temporally blocked
- * (the contract is spelled out at r4r_transnet_rows_flush below: chunks of 4,096 table elements that neither this
- * batch nor the announced next batch names are visited every P-th step and take their pending gradient-zero
- * updates together -- the same fp32 operations per element, a fraction of the traffic; the caller trains on exactly
- * the announced ids next, keeps the optimiser scalars unchanged meanwhile, and calls r4r_mf_rows_flush before
- * anything else reads the tables).  Without next_uid, or with P = 1, the call applies everything that is pending:
- * the plain dense sweep.  r4r_mf_ws_flag_offset: the int the sweep sets when a batch was not the announced one. */
+/* sweep_period P in 2..8: the Adam sweep over the two ID tables, temporally blocked on a SCHEDULE (round 4).  A table
+ * element no rating names goes through the same gradient-zero update whether it is applied now or together with the
+ * next ones (it reads nothing but its own p, m, v and the step's two bias corrections), so chunk c of 4,096 table
+ * elements is visited only at the steps s with (c % P + c / P + s) % P == 0 -- one chunk of every P consecutive
+ * ones per step, a launch of exactly the due chunks -- and then takes all its pending updates in order, each with its
+ * own step's scalars: the fp32 operations per element are those of the dense sweep (bit-identical tables and
+ * moments: tests/test_gpu_full_size.py), the traffic a P-th.  Nothing is announced and no per-chunk state is kept:
+ * the step of a chunk's last visit is a function of (c, step), a row a rating names is current through
+ * max(sweep_base, that visit, the row's own last update [kept per row in ws]), and whoever needs it newer applies the
+ * missing updates on the way -- the forward in registers, the row's entry wave before its gradient update.
+ *   sweep_base : a completed step through which EVERY element is current (0 before the first step).  The caller keeps
+ *                it: it becomes adam_step after a call with sweep_all = 1 or P = 1 and after r4r_mf_rows_flush, and
+ *                stays otherwise.  At most 8 updates may be pending anywhere (guaranteed while every step since
+ *                sweep_base ran this function with the same P); the int at r4r_mf_ws_flag_offset is set if not.
+ *   sweep_all  : 1 = visit every chunk now (the plain dense sweep, applying whatever is pending under the schedule
+ *                (P, sweep_base)); required on the step that changes P.
+ * r4r_mf_rows_flush(adam_step = the last COMPLETED step) brings every element up to date without a step; a forward-only
+ * r4r_mf_step (m == NULL) and anything else that reads the tables needs it first.  16-byte aligned tables; others
+ * are swept densely every step. */
 int r4r_mf_rows_flush(const uint64_t *p, const uint64_t *m, const uint64_t *v,
                       int64_t n_users, int64_t n_items, int D, void *ws, size_t ws_bytes, int64_t B,
+                      int sweep_period, int64_t sweep_base,
                       float lr, double beta1, double beta2, float eps, float weight_decay, int64_t adam_step,
                       void *stream);
 size_t r4r_mf_ws_flag_offset(int64_t B, int D, int64_t n_users, int64_t n_items);
@@ -424,20 +437,21 @@ int r4r_sse_accumulate(const float *se, int64_t n, float *accum, void *stream);
  *   once; world * B_pad <= 16384. */
 size_t r4r_mf_dp_block_bytes(int64_t B_pad, int D);
 int r4r_mf_grad(const int64_t *uid, const int64_t *iid, const float *y, const uint64_t *p,
+                const uint64_t *m, const uint64_t *v,
                 int64_t n_users, int64_t n_items, int D, float *pred, float *se, void *block, float *mult,
                 int64_t B, int64_t B_pad, float dropout_p, int training, uint64_t seed, uint64_t offset,
-                float inv_denom, const int64_t *next_uid, const int64_t *next_iid, int64_t next_B, void *stream);
+                float inv_denom, void *ws, int sweep_period, int64_t sweep_base,
+                float lr, double beta1, double beta2, float eps, float weight_decay, int64_t adam_step,
+                void *stream);
 int r4r_mf_apply(const void *blocks, int world, int64_t B_pad, const uint64_t *p, const uint64_t *m,
                  const uint64_t *v, int64_t n_users, int64_t n_items, int D, void *ws, size_t ws_bytes,
-                 int sweep_period, int announce,
+                 int sweep_period, int64_t sweep_base, int sweep_all,
                  float lr, double beta1, double beta2, float eps, float weight_decay, int64_t adam_step,
                  void *stream);
-/* The temporally blocked sweep under data parallelism: r4r_mf_grad(next_uid / next_iid [next_B <= B_pad]) puts the ids
- * of the shard THIS rank trains on next into its block (NULL: none, e.g. an empty next shard); after the all_gather
- * every rank knows every rank's next ids, and r4r_mf_apply(sweep_period P, announce) -- the SAME P and announce on
- * every rank -- brings the chunks any of them names up to date and visits the others every P-th step (contract at
- * r4r_transnet_rows_flush; r4r_mf_rows_flush on every rank before anything else reads the tables).  announce = 0 or
- * P = 1: the plain sweep, which also applies whatever is pending. */
+/* The scheduled sweep under data parallelism: r4r_mf_apply(sweep_period, sweep_base, sweep_all) -- the SAME values on
+ * every rank -- is r4r_mf_step's sweep over the gathered entries; r4r_mf_grad(m, v, ws = r4r_mf_apply's workspace,
+ * the same schedule and optimiser scalars; all NULL / ignored when nothing can be pending) reads the rows its ratings
+ * name as of step adam_step - 1.  r4r_mf_rows_flush on every rank before anything else reads the tables. */
 
 /* ---- fused native step for NARRE (pytorch_models/NARRE.py:10-124)
  * Replaces, per training step: the word gathers + TextCNN over the B*R review documents of each
@@ -582,7 +596,7 @@ int r4r_transnet_nparam(void);
 int r4r_transnet_layout(int E, int L, int plus, int64_t *offsets, int64_t *sizes, int64_t *total);
 size_t r4r_transnet_ws_bytes(int64_t B, int T, int E, int L, int plus, int64_t V, int64_t n_users, int64_t n_items);
 size_t r4r_transnet_ws_offset(int64_t B, int T, int E, int L, int plus, int64_t V, int64_t n_users, int64_t n_items,
-                              int which);   /* 0 dropout multipliers, 1 / 2 ID-vector gradient rows [B,5], 3 aux [B,3], 4 size of the persistent head, 5 the broken-announcement flag (int), 6 + 2*tower + buffer: token counter */
+                              int which);   /* 0 dropout multipliers, 1 / 2 ID-vector gradient rows [B,5], 3 aux [B,3], 4 size of the persistent head, 5 the broken-schedule flag (int), 6 + 2*tower + buffer: token counter */
 int r4r_transnet_step(const float *table, int64_t V,
                       const int64_t *user_idx, const int64_t *item_idx, const int64_t *this_idx,
                       const int64_t *uid, const int64_t *iid, const float *y,
@@ -594,30 +608,30 @@ int r4r_transnet_step(const float *table, int64_t V,
                       float dropout_p, int training, uint64_t seed, uint64_t offset, float inv_denom,
                       int conv_algo, int token_buffer, int tokens_ready,
                       const int64_t *next_user_idx, const int64_t *next_item_idx, const int64_t *next_this_idx,
-                      const int64_t *next_uid, const int64_t *next_iid, int64_t next_B, int sweep_period,
+                      int sweep_period, int64_t sweep_base, int sweep_all,
                       float lr, double beta1, double beta2, float eps, float weight_decay, int64_t adam_step,
                       void *stream);
 
-/* The ID-vector sweep, temporally blocked (TransNet++, a training step that updates: flat_m != NULL).
- * torch.optim.Adam moves EVERY row of user_embedding / item_embedding every step (main.py:94-96: weight decay,
- * decaying moments), 24 bytes of traffic per element -- but an element no rating of the batch names goes through
- * the same gradient-zero update whether it is applied now or together with the next few: the update reads nothing
- * but the element's own (p, m, v) and the step's two bias corrections.  With sweep_period P > 1 and the ids of the
- * batch the NEXT call will train on (next_uid / next_iid [next_B]), a chunk of 4,096 table elements that neither
- * this batch nor the next names is visited every P-th step only and then takes all its pending updates at once, in
- * step order, each with its own step's scalars: the same fp32 operations per element as P = 1, a P-th of the bytes.
- * Chunks the next batch names are brought up to date by this call, so the next call reads current rows.
- * Contract: (1) the next call trains on exactly the announced ids, or r4r_transnet_rows_flush runs first (the
- * sweep sets the int at r4r_transnet_ws_offset(which = 5) if a batch was not the announced one); (2) lr, betas,
- * eps, weight_decay do not change while updates are pending; (3) r4r_transnet_rows_flush before anything else
- * reads or writes the tables or their moments (evaluation through r4r_transnet_step included).  A call WITHOUT
- * next_uid (or with P = 1) applies everything that is pending and leaves nothing behind: the plain dense sweep.
- * 1 <= P <= 8.  r4r_transnet_rows_flush: adam_step = the last completed step; same `ws` / shapes as the steps.
- * The data-parallel update launches of the families above (r4r_mf_apply, r4r_transnet_rows_apply,
- * r4r_idnet_rows_apply) have the blocked form too: the gathered payload carries every rank's next ids. */
+/* The ID-vector sweep, temporally blocked on a schedule (TransNet++; the contract is r4r_mf_step's, spelled out
+ * there).  torch.optim.Adam moves EVERY row of user_embedding / item_embedding every step (main.py:94-96: weight
+ * decay, decaying moments), 24 bytes of traffic per element -- but an element no rating of the batch names goes
+ * through the same gradient-zero update whether it is applied now or together with the next few.  With
+ * sweep_period P in 2..8 a chunk of 4,096 table elements is visited every P-th step only (chunk c at the steps s with
+ * (c % P + c / P + s) % P == 0) and then takes its pending updates at once, in step order, each with its own step's
+ * scalars: the same fp32 operations per element as P = 1, a P-th of the bytes.  The ID vectors a rating reads catch
+ * up in the head kernel's registers (rows_m / rows_v are read for that, also on a gradients-only step: pass them
+ * whenever updates may be pending), a named row's entry wave applies what is missing before its gradient update.
+ *   sweep_base / sweep_all: as for r4r_mf_step (the caller keeps the base; it becomes adam_step after sweep_all = 1,
+ *   P = 1 or r4r_transnet_rows_flush).  lr, betas, eps, weight_decay do not change while updates are pending;
+ *   r4r_transnet_rows_flush (adam_step = the last completed step; same `ws` / shapes as the steps) before anything else
+ *   reads or writes the tables or their moments (evaluation through r4r_transnet_step included).  The int at
+ *   r4r_transnet_ws_offset(which = 5) is set if more than 8 updates were ever pending (a broken schedule).
+ * The data-parallel update launches (r4r_mf_apply, r4r_transnet_rows_apply, r4r_idnet_rows_apply) run the same
+ * schedule over the gathered entries -- the same (P, base, all) on every rank. */
 int r4r_transnet_rows_flush(const uint64_t *rows_p, const uint64_t *rows_m, const uint64_t *rows_v,
                             int64_t n_users, int64_t n_items, void *ws, size_t ws_bytes,
                             int64_t B, int T, int E, int L, int64_t V,
+                            int sweep_period, int64_t sweep_base,
                             float lr, double beta1, double beta2, float eps, float weight_decay, int64_t adam_step,
                             void *stream);
 
@@ -625,11 +639,10 @@ int r4r_transnet_rows_flush(const uint64_t *rows_p, const uint64_t *rows_m, cons
  * the compact ID-vector rows at r4r_transnet_ws_offset 1 / 2), exchange -- all-reduce flat_g and apply
  * r4r_adam_multi; all_gather the ranks' (uid, iid, gradient rows), ids -1 padding ragged shards --
  * then update the ID-vector tables from ALL ranks' rows (same `ws` and shape arguments as the step:
- * the row tags live there).  B_all <= 16384.  next_uid_all / next_iid_all [B_all] (ids -1: none) + sweep_period +
- * announce: the gathered ids of every rank's NEXT shard -- the sweep is then temporally blocked over what all ranks
- * announced (the same period and announce on every rank; contract above; r4r_transnet_rows_flush on every rank). */
+ * the row tags live there).  B_all <= 32768.  sweep_period / sweep_base / sweep_all: the schedule of the sweep, the
+ * same on every rank (contract above; r4r_transnet_rows_flush on every rank). */
 int r4r_transnet_rows_apply(const int64_t *uid_all, const int64_t *iid_all, const float *gu_all, const float *gi_all,
-                            const int64_t *next_uid_all, const int64_t *next_iid_all, int sweep_period, int announce,
+                            int sweep_period, int64_t sweep_base, int sweep_all,
                             int64_t B_all, const uint64_t *rows_p, const uint64_t *rows_m, const uint64_t *rows_v,
                             int64_t n_users, int64_t n_items, void *ws, size_t ws_bytes,
                             int64_t B, int T, int E, int L, int64_t V,
@@ -656,21 +669,23 @@ int r4r_idnet_nparam(void);
 int r4r_idnet_layout(int variant, int L, int64_t *offsets, int64_t *sizes, int64_t *total);
 size_t r4r_idnet_ws_bytes(int variant, int64_t B, int L, int64_t n_users, int64_t n_items);
 size_t r4r_idnet_ws_offset(int variant, int64_t B, int L, int64_t n_users, int64_t n_items,
-                           int which);   /* 0 dropout multipliers [B, draws], 1 d loss/d pred [B], 2 size of the persistent head (row tags), 3 the broken-announcement flag (int), 4 + 2*pair + side: compact gradient rows [B, L] */
+                           int which);   /* 0 dropout multipliers [B, draws], 1 d loss/d pred [B], 2 size of the persistent head (row tags), 3 the broken-schedule flag (int), 4 + 2*pair + side: compact gradient rows [B, L] */
 int r4r_idnet_step(int variant, const int64_t *uid, const int64_t *iid, const float *y,
                    float *flat_p, float *flat_g, float *flat_m, float *flat_v,
                    const uint64_t *rows_p, const uint64_t *rows_m, const uint64_t *rows_v,
                    int64_t n_users, int64_t n_items,
                    float *pred, float *se, float *sse_accum, void *ws, size_t ws_bytes,
                    int64_t B, int L, float dropout_p, int training, uint64_t seed, uint64_t offset,
-                   float inv_denom, const int64_t *next_uid, const int64_t *next_iid, int64_t next_B,
-                   int sweep_period, float lr, double beta1, double beta2, float eps, float weight_decay,
+                   float inv_denom, int sweep_period, int64_t sweep_base, int sweep_all,
+                   float lr, double beta1, double beta2, float eps, float weight_decay,
                    int64_t adam_step, void *stream);
-/* next_uid / next_iid / next_B / sweep_period: the sweeps over the variant's table pair(s), temporally blocked
- * (contract at r4r_transnet_rows_flush; r4r_idnet_ws_offset which = 3: the broken-announcement flag).
- * r4r_idnet_rows_flush applies what is pending; adam_step = the last completed step. */
+/* sweep_period / sweep_base / sweep_all: the sweeps over the variant's table pair(s), temporally blocked on the
+ * schedule of r4r_mf_step (contract there and at r4r_transnet_rows_flush; rows_m / rows_v are read by the head kernel
+ * for the catch-up of the rows a rating names, also on a gradients-only step; r4r_idnet_ws_offset which = 3: the
+ * broken-schedule flag).  r4r_idnet_rows_flush applies what is pending; adam_step = the last completed step. */
 int r4r_idnet_rows_flush(int variant, const uint64_t *rows_p, const uint64_t *rows_m, const uint64_t *rows_v,
                          int64_t n_users, int64_t n_items, void *ws, size_t ws_bytes, int64_t B, int L,
+                         int sweep_period, int64_t sweep_base,
                          float lr, double beta1, double beta2, float eps, float weight_decay, int64_t adam_step,
                          void *stream);
 
@@ -679,10 +694,10 @@ int r4r_idnet_rows_flush(int variant, const uint64_t *rows_p, const uint64_t *ro
  * all-reduce flat_g + r4r_adam_multi; all_gather of (uid, iid, d loss/d pred, rows), ids -1 padding ragged
  * shards -- the ID tables and bias vectors are updated from ALL ranks' rows.  gu_all / gi_all: HOST arrays of
  * 2 device pointers ([B_all, L] rows of the first / second table pair).  `ws`, B: the step's own.  B_all <= 16384.
- * next_uid_all / next_iid_all / sweep_period / announce: as for r4r_transnet_rows_apply. */
+ * sweep_period / sweep_base / sweep_all: as for r4r_transnet_rows_apply. */
 int r4r_idnet_rows_apply(int variant, const int64_t *uid_all, const int64_t *iid_all, const float *g_all,
                          const uint64_t *gu_all, const uint64_t *gi_all,
-                         const int64_t *next_uid_all, const int64_t *next_iid_all, int sweep_period, int announce,
+                         int sweep_period, int64_t sweep_base, int sweep_all,
                          int64_t B_all,
                          const uint64_t *rows_p, const uint64_t *rows_m, const uint64_t *rows_v,
                          int64_t n_users, int64_t n_items, void *ws, size_t ws_bytes, int64_t B, int L,

@@ -61,6 +61,9 @@ struct IdnHead {
     const float *flat_p;
     int off[IP_COUNT], size[IP_COUNT];
     const float *tab[2][2];            // [pair][side] ID tables [rows, L]
+    const float *tabm[2][2], *tabv[2][2];   // their Adam moments (scheduled sweeps: pending updates are applied on the way)
+    const int *rl[2][2];               // [pair][side] per row: the last step an entry wave updated it (NULL: nothing can be pending)
+    MfTimeBlock tb; AdamScalars sc0;   // the schedule (rows_device.h): base, period, the steps' scalars
     const float *bias[2];
     const int64_t *id[2];              // uid, iid [B]
     const float *y;
@@ -69,9 +72,6 @@ struct IdnHead {
     float *g;                          // [B] d mean(SE) / d pred
     int *tag[2];
     int *ctag[2];                      // per sweep chunk of a table: the last step that touched a row in it (NULL: not kept)
-    const int64_t *next_id[2];         // the announced next batch's uid / iid (temporally blocked sweep), or NULL
-    int64_t next_B;
-    int *ntag[2];                      // ... and the chunk tags its rows get
     float *mult;                       // [B, draws]
     float *pred, *se;
     int64_t B;
@@ -116,7 +116,20 @@ __global__ __launch_bounds__(256) void idnet_head_kernel(IdnHead a) {
         const int pr = i / L2, r = i - pr * L2, s = r >= L, l = r - s * L;
         const float m = draw(i);
         rm[pr][s][l] = m;
-        row[pr][s][l] = a.tab[pr][s][(s ? iid : uid) * L + l] * m;
+        const int64_t rid = s ? iid : uid, e = rid * L + l;
+        float x = a.tab[pr][s][e];
+        if (a.rl[pr][s]) {                                  // the element's pending gradient-zero updates (not written back)
+            float mq = a.tabm[pr][s][e], vq = a.tabv[pr][s][e];
+            const int cur = tb_current(a.tb, a.rl[pr][s], e, rid, a.now);
+#pragma unroll
+            for (int j = 0; j < MF_TB_MAX - 1; ++j) {       // steps now - 7 .. now - 1
+                AdamScalars sc = a.sc0;
+                sc.lr_over_bc1 = a.tb.lr_bc1[j];
+                sc.inv_sqrt_bc2 = a.tb.isb2[j];
+                if (a.now - (MF_TB_MAX - 1 - j) > cur) adam_elem_fast(x, 0.f, mq, vq, sc);
+            }
+        }
+        row[pr][s][l] = x * m;
     }
     if (tid == 0) {
         misc[0] = fp[a.off[IP_FB]]; misc[1] = fp[a.off[IP_GB]];
@@ -192,11 +205,6 @@ __global__ __launch_bounds__(256) void idnet_head_kernel(IdnHead a) {
                 for (int s = 0; s < 2; ++s) {
                     const int64_t e0 = id2[s] * a.L;
                     a.ctag[s][e0 / MF_CHUNK] = a.now; a.ctag[s][(e0 + a.L - 1) / MF_CHUNK] = a.now;
-                    if (a.next_id[s])                       // the chunks the NEXT batch names are brought up to date by this step's sweeps
-                        for (int64_t j = b; j < a.next_B; j += a.B) {
-                            const int64_t q0 = a.next_id[s][j] * a.L;
-                            a.ntag[s][q0 / MF_CHUNK] = a.now; a.ntag[s][(q0 + a.L - 1) / MF_CHUNK] = a.now;
-                        }
                 }
             }
         }
@@ -302,7 +310,7 @@ __global__ __launch_bounds__(IR_ROWS * IR_COLS) void idnet_reduce_kernel(IdnRedu
 
 struct IdnWs {
     int *tag[2];
-    int *ctag[2], *ntag[2], *lag[2][2], *tb_err;       // the temporally blocked sweeps' state (rows_device.h); lag per [pair][side]
+    int *ctag[2], *rlast[2][2], *tb_err;               // the scheduled sweeps' state (rows_device.h); rlast per [pair][side]
     float *part, *g, *mult, *grow[2][2];
     size_t bytes, persist;
 };
@@ -316,9 +324,8 @@ static IdnWs idn_carve(void *ws, int variant, int64_t B, int L, int64_t n_users,
     for (int s = 0; s < 2; ++s) {
         const size_t chunks = (size_t)cdiv((s ? n_items : n_users) * (int64_t)L, MF_CHUNK);
         w.ctag[s] = reinterpret_cast<int *>(take(chunks * 4));
-        w.ntag[s] = reinterpret_cast<int *>(take(chunks * 4));
-        w.lag[0][s] = reinterpret_cast<int *>(take(chunks * 4));
-        w.lag[1][s] = reinterpret_cast<int *>(take(chunks * 4));
+        w.rlast[0][s] = reinterpret_cast<int *>(take((size_t)(s ? n_items : n_users) * 4));
+        w.rlast[1][s] = reinterpret_cast<int *>(take((size_t)(s ? n_items : n_users) * 4));
     }
     w.tb_err = reinterpret_cast<int *>(take(4));
     w.persist = o;
@@ -372,12 +379,12 @@ extern "C" int r4r_idnet_step(int variant, const int64_t *uid, const int64_t *ii
                               int64_t n_users, int64_t n_items,
                               float *pred, float *se, float *sse_accum, void *ws, size_t ws_bytes,
                               int64_t B, int L, float dropout_p, int training, uint64_t seed, uint64_t offset,
-                              float inv_denom, const int64_t *next_uid, const int64_t *next_iid, int64_t next_B,
-                              int sweep_period, float lr, double beta1, double beta2, float eps, float weight_decay,
+                              float inv_denom, int sweep_period, int64_t sweep_base, int sweep_all,
+                              float lr, double beta1, double beta2, float eps, float weight_decay,
                               int64_t adam_step, void *stream) {
     R4R_REQUIRE(uid && iid && flat_p && rows_p && pred && ws, "idnet_step: null pointer");
     R4R_REQUIRE(sweep_period >= 1 && sweep_period <= MF_TB_MAX, "idnet_step: sweep_period %d outside 1..%d", sweep_period, MF_TB_MAX);
-    R4R_REQUIRE(!next_uid == !next_iid && (!next_uid || next_B > 0), "idnet_step: next_uid, next_iid and next_B > 0 go together");
+    R4R_REQUIRE(sweep_base >= 0 && (!flat_g || sweep_base < adam_step), "idnet_step: sweep_base outside 0..adam_step - 1");
     R4R_REQUIRE(variant >= 0 && variant <= IDN_NEUMF, "idnet_step: variant %d outside 0..3", variant);
     R4R_REQUIRE(L > 0 && L <= IDN_MAX_L, "idnet_step: latent_size %d outside 1..%d", L, IDN_MAX_L);
     R4R_REQUIRE(n_users > 0 && n_items > 0 && B >= 0, "idnet_step: bad sizes");
@@ -419,15 +426,25 @@ extern "C" int r4r_idnet_step(int variant, const int64_t *uid, const int64_t *ii
         R4R_REQUIRE(h.bias[s], "idnet_step: null bias vector");
     }
     h.id[0] = uid; h.id[1] = iid; h.y = y; h.part = w.part; h.g = w.g; h.mult = w.mult; h.pred = pred; h.se = se;
-    // the temporally blocked sweeps (rows_device.h): 16-byte aligned tables, a training step that updates in this call
-    bool tb_on = train_step && apply;
-    for (int k = 0; k < 2 * npair && tb_on; ++k) tb_on = ((rows_p[k] | rows_m[k] | rows_v[k]) & 15) == 0;
-    const bool announce = tb_on && next_uid && sweep_period > 1;
-    for (int s = 0; s < 2; ++s) {
-        h.ctag[s] = tb_on ? w.ctag[s] : nullptr; h.ntag[s] = w.ntag[s];
-        h.next_id[s] = announce ? (s ? next_iid : next_uid) : nullptr;
+    // the scheduled sweeps (rows_device.h): 16-byte aligned tables, a training step that has the moments
+    bool tb_on = train_step && rows_m && rows_v;
+    for (int k = 0; k < 2 * npair && tb_on; ++k) tb_on = rows_m[k] && rows_v[k] && ((rows_p[k] | rows_m[k] | rows_v[k]) & 15) == 0;
+    MfTimeBlock tb0{};
+    if (tb_on) {
+        tb0.err = w.tb_err; tb0.base = (int)sweep_base; tb0.period = sweep_period;
+        tb0.flush = (sweep_all || sweep_period == 1) ? 1 : 0; tb0.inc = 1;
+        mf_time_block_scalars(tb0, lr, beta1, beta2, eps, weight_decay, adam_step);
     }
-    h.next_B = announce ? next_B : 0;
+    h.tb = tb0; h.sc0 = adam_make_scalars(lr, beta1, beta2, eps, weight_decay, adam_step > 0 ? adam_step : 1, nullptr);
+    for (int pr = 0; pr < 2; ++pr)
+        for (int s = 0; s < 2; ++s) {
+            const int k = (pr < npair ? pr : 0) * 2 + s;
+            const bool cu = tb_on && sweep_period > 1;      // (rows the head reads catch up in registers)
+            h.rl[pr][s] = cu ? w.rlast[pr < npair ? pr : 0][s] : nullptr;
+            h.tabm[pr][s] = cu ? reinterpret_cast<const float *>(rows_m[k]) : nullptr;
+            h.tabv[pr][s] = cu ? reinterpret_cast<const float *>(rows_v[k]) : nullptr;
+        }
+    for (int s = 0; s < 2; ++s) h.ctag[s] = (tb_on && apply) ? w.ctag[s] : nullptr;
     h.B = B; h.L = L; h.np = (int)lay.total; h.variant = variant; h.training = training; h.want_grad = train_step;
     h.now = (int)adam_step; h.p_drop = dropout_p; h.inv_denom = inv_denom; h.seed = seed; h.offset = offset;
     if (L <= 16) idnet_head_kernel<16><<<(unsigned)B, 256, 0, st>>>(h);
@@ -454,10 +471,8 @@ extern "C" int r4r_idnet_step(int variant, const int64_t *uid, const int64_t *ii
     // and its bias element); NeuMF's second pair in another
     MfTimeBlock tb[2];
     for (int pr = 0; pr < 2; ++pr) {
-        tb[pr] = MfTimeBlock{};
-        tb[pr].lag_u = w.lag[pr][0]; tb[pr].lag_i = w.lag[pr][1]; tb[pr].ntag_u = w.ntag[0]; tb[pr].ntag_i = w.ntag[1];
-        tb[pr].err = w.tb_err; tb[pr].period = announce ? sweep_period : 1; tb[pr].flush = announce ? 0 : 1; tb[pr].inc = 1;
-        mf_time_block_scalars(tb[pr], lr, beta1, beta2, eps, weight_decay, adam_step);
+        tb[pr] = tb0;
+        tb[pr].rlast_u = w.rlast[pr][0]; tb[pr].rlast_i = w.rlast[pr][1];
     }
     if (int rc = mf_table_bias_rows_launch(rp[0], rm[0], rv[0], rp[1], rm[1], rv[1], rp[4], rm[4], rv[4], rp[5], rm[5], rv[5],
                                            n_users, n_items, L, uid, iid, w.grow[0][0], w.grow[0][1], w.g, w.tag[0], w.tag[1],
@@ -475,9 +490,12 @@ extern "C" int r4r_idnet_step(int variant, const int64_t *uid, const int64_t *ii
 // the variant's table pair(s) takes its pending updates now.  adam_step = the LAST COMPLETED step.
 extern "C" int r4r_idnet_rows_flush(int variant, const uint64_t *rows_p, const uint64_t *rows_m, const uint64_t *rows_v,
                                     int64_t n_users, int64_t n_items, void *ws, size_t ws_bytes, int64_t B, int L,
+                                    int sweep_period, int64_t sweep_base,
                                     float lr, double beta1, double beta2, float eps, float weight_decay, int64_t adam_step,
                                     void *stream) {
     R4R_REQUIRE(rows_p && rows_m && rows_v && ws, "idnet_rows_flush: null pointer");
+    R4R_REQUIRE(sweep_period >= 1 && sweep_period <= MF_TB_MAX && sweep_base >= 0 && sweep_base <= adam_step,
+                "idnet_rows_flush: sweep_period outside 1..%d or sweep_base outside 0..adam_step", MF_TB_MAX);
     R4R_REQUIRE(variant >= 0 && variant <= IDN_NEUMF && L > 0 && L <= IDN_MAX_L && n_users > 0 && n_items > 0 && B >= 0,
                 "idnet_rows_flush: bad arguments");
     R4R_REQUIRE(adam_step >= 0 && adam_step < (1ll << 31), "idnet_rows_flush: bad adam_step");
@@ -485,7 +503,7 @@ extern "C" int r4r_idnet_rows_flush(int variant, const uint64_t *rows_p, const u
         set_error("idnet_rows_flush: workspace %zu < %zu bytes", ws_bytes, r4r_idnet_ws_bytes(variant, B, L, n_users, n_items));
         return R4R_ERR_WORKSPACE;
     }
-    if (adam_step == 0) return R4R_OK;
+    if (adam_step == 0 || sweep_base == adam_step) return R4R_OK;
     const IdnWs w = idn_carve(ws, variant, B, L, n_users, n_items);
     const int npair = idn_pairs(variant);
     for (int k = 0; k < 2 * npair; ++k) {
@@ -496,8 +514,8 @@ extern "C" int r4r_idnet_rows_flush(int variant, const uint64_t *rows_p, const u
     auto f = [](uint64_t x) { return reinterpret_cast<float *>(x); };
     for (int pr = 0; pr < npair; ++pr) {
         MfTimeBlock tb{};
-        tb.lag_u = w.lag[pr][0]; tb.lag_i = w.lag[pr][1]; tb.ntag_u = w.ntag[0]; tb.ntag_i = w.ntag[1]; tb.err = w.tb_err;
-        tb.period = 1; tb.flush = 1; tb.inc = 0;
+        tb.rlast_u = w.rlast[pr][0]; tb.rlast_i = w.rlast[pr][1]; tb.err = w.tb_err; tb.base = (int)sweep_base;
+        tb.period = sweep_period; tb.flush = 1; tb.inc = 0;
         mf_time_block_scalars(tb, lr, beta1, beta2, eps, weight_decay, adam_step);
         if (int rc = mf_table_rows_launch(f(rows_p[2 * pr]), f(rows_m[2 * pr]), f(rows_v[2 * pr]), f(rows_p[2 * pr + 1]),
                                           f(rows_m[2 * pr + 1]), f(rows_v[2 * pr + 1]), n_users, n_items, L, nullptr, nullptr, nullptr,
@@ -515,15 +533,9 @@ extern "C" int r4r_idnet_rows_flush(int variant, const uint64_t *rows_p, const u
 // tags live in the workspace's persistent head.
 namespace r4r {
 __global__ void idn_tag_rows_kernel(const int64_t *uid, const int64_t *iid, int64_t n, int *tag_u, int *tag_i, int now,
-                                    int L, int *ctag_u, int *ctag_i, const int64_t *next_uid, const int64_t *next_iid,
-                                    int *ntag_u, int *ntag_i) {
+                                    int L, int *ctag_u, int *ctag_i) {
     const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= n) return;
-    if (next_uid && next_uid[e] >= 0) {                     // what some rank announced for its next shard (temporally blocked sweeps)
-        const int64_t u0 = next_uid[e] * L, i0 = next_iid[e] * L;
-        ntag_u[u0 / MF_CHUNK] = now; ntag_u[(u0 + L - 1) / MF_CHUNK] = now;
-        ntag_i[i0 / MF_CHUNK] = now; ntag_i[(i0 + L - 1) / MF_CHUNK] = now;
-    }
     if (uid[e] < 0) return;
     tag_u[uid[e]] = now;
     tag_i[iid[e]] = now;
@@ -537,7 +549,7 @@ __global__ void idn_tag_rows_kernel(const int64_t *uid, const int64_t *iid, int6
 
 extern "C" int r4r_idnet_rows_apply(int variant, const int64_t *uid_all, const int64_t *iid_all, const float *g_all,
                                     const uint64_t *gu_all, const uint64_t *gi_all,
-                                    const int64_t *next_uid_all, const int64_t *next_iid_all, int sweep_period, int announce,
+                                    int sweep_period, int64_t sweep_base, int sweep_all,
                                     int64_t B_all,
                                     const uint64_t *rows_p, const uint64_t *rows_m, const uint64_t *rows_v,
                                     int64_t n_users, int64_t n_items, void *ws, size_t ws_bytes, int64_t B, int L,
@@ -546,9 +558,9 @@ extern "C" int r4r_idnet_rows_apply(int variant, const int64_t *uid_all, const i
     R4R_REQUIRE(uid_all && iid_all && g_all && gu_all && gi_all && rows_p && rows_m && rows_v && ws, "idnet_rows_apply: null pointer");
     R4R_REQUIRE(variant >= 0 && variant <= IDN_NEUMF && L > 0 && L <= IDN_MAX_L, "idnet_rows_apply: bad variant / latent_size");
     R4R_REQUIRE(B_all >= 0 && B_all <= 32768, "idnet_rows_apply: %lld gathered ratings outside 0..32768", (long long)B_all);
-    R4R_REQUIRE(adam_step >= 1 && adam_step < (1ll << 31), "idnet_rows_apply: bad adam_step");
-    R4R_REQUIRE(sweep_period >= 1 && sweep_period <= MF_TB_MAX && !next_uid_all == !next_iid_all,
-                "idnet_rows_apply: sweep_period outside 1..%d, or only one of the next-id arrays", MF_TB_MAX);
+    R4R_REQUIRE(adam_step >= 1 && adam_step < (1ll << 31) && sweep_base >= 0 && sweep_base < adam_step,
+                "idnet_rows_apply: bad adam_step, or sweep_base outside 0..adam_step - 1");
+    R4R_REQUIRE(sweep_period >= 1 && sweep_period <= MF_TB_MAX, "idnet_rows_apply: sweep_period outside 1..%d", MF_TB_MAX);
     if (ws_bytes < r4r_idnet_ws_bytes(variant, B, L, n_users, n_items)) {
         set_error("idnet_rows_apply: workspace %zu < %zu bytes", ws_bytes, r4r_idnet_ws_bytes(variant, B, L, n_users, n_items));
         return R4R_ERR_WORKSPACE;
@@ -564,21 +576,17 @@ extern "C" int r4r_idnet_rows_apply(int variant, const int64_t *uid_all, const i
         rv[k] = reinterpret_cast<float *>(rows_v[k]);
         R4R_REQUIRE(!used || (rp[k] && rm[k] && rv[k]), "idnet_rows_apply: table / bias %d: null pointer", k);
     }
-    // the gathered entries' sweeps, temporally blocked over what ALL ranks announced (16-byte aligned tables; the same
-    // period / announce on every rank)
+    // the gathered entries' sweeps on the schedule (16-byte aligned tables; the same period / base / all on every rank)
     bool tb_on = true;
     for (int k = 0; k < 2 * npair; ++k) tb_on = tb_on && ((rows_p[k] | rows_m[k] | rows_v[k]) & 15) == 0;
-    const bool defer = tb_on && announce && next_uid_all && sweep_period > 1;
     idn_tag_rows_kernel<<<(unsigned)cdiv(B_all, 256), 256, 0, st>>>(uid_all, iid_all, B_all, w.tag[0], w.tag[1], (int)adam_step, L,
-                                                                  tb_on ? w.ctag[0] : nullptr, tb_on ? w.ctag[1] : nullptr,
-                                                                  defer ? next_uid_all : nullptr, defer ? next_iid_all : nullptr,
-                                                                  w.ntag[0], w.ntag[1]);
+                                                                  tb_on ? w.ctag[0] : nullptr, tb_on ? w.ctag[1] : nullptr);
     const AdamScalars sc = adam_make_scalars(lr, beta1, beta2, eps, weight_decay, adam_step, nullptr);
     MfTimeBlock tb[2];
     for (int pr = 0; pr < 2; ++pr) {
         tb[pr] = MfTimeBlock{};
-        tb[pr].lag_u = w.lag[pr][0]; tb[pr].lag_i = w.lag[pr][1]; tb[pr].ntag_u = w.ntag[0]; tb[pr].ntag_i = w.ntag[1];
-        tb[pr].err = w.tb_err; tb[pr].period = defer ? sweep_period : 1; tb[pr].flush = defer ? 0 : 1; tb[pr].inc = 1;
+        tb[pr].rlast_u = w.rlast[pr][0]; tb[pr].rlast_i = w.rlast[pr][1]; tb[pr].err = w.tb_err; tb[pr].base = (int)sweep_base;
+        tb[pr].period = sweep_period; tb[pr].flush = (sweep_all || sweep_period == 1) ? 1 : 0; tb[pr].inc = 1;
         mf_time_block_scalars(tb[pr], lr, beta1, beta2, eps, weight_decay, adam_step);
     }
     const float *gu[2], *gi[2];

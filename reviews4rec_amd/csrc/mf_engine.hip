@@ -27,6 +27,7 @@
 #include "adam_device.h"
 #include "common.h"
 #include "rows_device.h"
+#include "trace_device.h"
 
 namespace r4r {
 
@@ -56,12 +57,6 @@ struct MfStep {
     unsigned long long *last_u, *last_i;     // [U+1], [I+1]: (step << 32 | the row's last rating)
     int *uid32, *iid32;                      // [B] compact copies of the ids
     int *ctag_u = nullptr, *ctag_i = nullptr;       // per sweep chunk of the tables: the last step that touched a row in it
-    const int64_t *next_uid = nullptr, *next_iid = nullptr;   // the announced next batch (temporally blocked sweep) ...
-    int64_t next_B = 0;
-    int *ntag_u = nullptr, *ntag_i = nullptr;       // ... and the chunk tags its rows get
-    int *nuid32 = nullptr, *niid32 = nullptr;       // data parallel: this rank's NEXT shard's ids into its block ([B_pad], -1 padded)
-    const int64_t *dp_next_uid = nullptr, *dp_next_iid = nullptr;
-    int64_t dp_next_B = 0;
     float *pred, *se, *sse_accum;
     int64_t B;
     int64_t B_pad = 0;                 // data parallel: rows [B, B_pad) of the entry arrays are filled as padding (id -1)
@@ -69,16 +64,15 @@ struct MfStep {
     int D, training, want_grad, tag;
     float p_drop, inv_denom;
     uint64_t seed, offset;
+    // scheduled sweep (rows_device.h): the rows a rating reads are brought to step now - 1 in registers
+    MfTimeBlock tb = MfTimeBlock{};
+    AdamScalars sc0 = AdamScalars{};
+    int now = 0;
 };
 
 __global__ __launch_bounds__(256) void mf_fwd_bwd_kernel(MfStep a) {
     const int lane = threadIdx.x & 63;
     const int64_t b = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (a.nuid32 && lane == 0 && b < a.B_pad) {             // (data parallel: the announced next shard rides in the block)
-        const bool has = a.dp_next_uid && b < a.dp_next_B;
-        a.nuid32[b] = has ? (int)a.dp_next_uid[b] : -1;
-        a.niid32[b] = has ? (int)a.dp_next_iid[b] : -1;
-    }
     if (b >= a.B) {                                         // whole wave
         if (b < a.B_pad && lane == 0) { a.uid32[b] = -1; a.iid32[b] = -1; a.g[b] = 0.f; }
         return;
@@ -92,10 +86,46 @@ __global__ __launch_bounds__(256) void mf_fwd_bwd_kernel(MfStep a) {
     for (int k = 0; k < MF_MAX_D / 64; ++k) {
         const int d = lane + 64 * k;
         xu[k] = xi[k] = 0.f;
-        mu[k] = mi[k] = 1.f;
         if (d < D) {
             xu[k] = a.p[0][u * D + d];
             xi[k] = a.p[1][i * D + d];
+        }
+    }
+    if (a.tb.rlast_u) {
+        // scheduled sweep: the pending gradient-zero updates of the two rows, in registers (nothing is written back;
+        // the step loop outermost: a step's scalars are fetched once)
+        float ms[2][MF_MAX_D / 64], vs[2][MF_MAX_D / 64];
+        int cur[2][MF_MAX_D / 64];
+#pragma unroll
+        for (int k = 0; k < MF_MAX_D / 64; ++k) {
+            const int d = lane + 64 * k;
+            cur[0][k] = cur[1][k] = a.now;
+            ms[0][k] = ms[1][k] = vs[0][k] = vs[1][k] = 0.f;
+            if (d < D) {
+                ms[0][k] = a.m[0][u * D + d]; vs[0][k] = a.v[0][u * D + d];
+                ms[1][k] = a.m[1][i * D + d]; vs[1][k] = a.v[1][i * D + d];
+                cur[0][k] = tb_current(a.tb, a.tb.rlast_u, u * D + d, u, a.now);
+                cur[1][k] = tb_current(a.tb, a.tb.rlast_i, i * D + d, i, a.now);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < MF_TB_MAX - 1; ++j) {            // steps now - 7 .. now - 1
+            const int sj = a.now - (MF_TB_MAX - 1 - j);
+            AdamScalars sc = a.sc0;
+            sc.lr_over_bc1 = a.tb.lr_bc1[j];
+            sc.inv_sqrt_bc2 = a.tb.isb2[j];
+#pragma unroll
+            for (int k = 0; k < MF_MAX_D / 64; ++k) {
+                if (sj > cur[0][k]) adam_elem_fast(xu[k], 0.f, ms[0][k], vs[0][k], sc);
+                if (sj > cur[1][k]) adam_elem_fast(xi[k], 0.f, ms[1][k], vs[1][k], sc);
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < MF_MAX_D / 64; ++k) {
+        const int d = lane + 64 * k;
+        mu[k] = mi[k] = 1.f;
+        if (d < D) {
             if (a.training && a.p_drop > 0.f) {
                 const float keep = 1.f / (1.f - a.p_drop);
                 const uint32_t ru = philox_first_word(a.offset + (uint64_t)(b * 2 * D + d), a.seed);
@@ -129,12 +159,6 @@ __global__ __launch_bounds__(256) void mf_fwd_bwd_kernel(MfStep a) {
             if (a.ctag_u && D > 0) {                        // chunk tags (a row may straddle two chunks)
                 a.ctag_u[u * D / MF_CHUNK] = a.tag; a.ctag_u[(u * D + D - 1) / MF_CHUNK] = a.tag;
                 a.ctag_i[i * D / MF_CHUNK] = a.tag; a.ctag_i[(i * D + D - 1) / MF_CHUNK] = a.tag;
-                if (a.next_uid)                             // the chunks the NEXT batch names are brought up to date by this step's sweep
-                    for (int64_t j = b; j < a.next_B; j += a.B) {
-                        const int64_t nu = a.next_uid[j], ni = a.next_iid[j];
-                        a.ntag_u[nu * D / MF_CHUNK] = a.tag; a.ntag_u[(nu * D + D - 1) / MF_CHUNK] = a.tag;
-                        a.ntag_i[ni * D / MF_CHUNK] = a.tag; a.ntag_i[(ni * D + D - 1) / MF_CHUNK] = a.tag;
-                    }
             }
         }
         a.uid32[b] = (int)u;
@@ -267,7 +291,7 @@ __device__ __forceinline__ void mf_stream_chunk_tb(float *p, float *m, float *v,
         }
     };
     const int64_t nvec = cnt >> 2;
-    constexpr int NV = MF_CHUNK / 4 / MF_THREADS, NB = R4R_TB_BATCH;     // float4 per thread and array; in flight together
+    constexpr int NV = MF_CHUNK / 4 / MF_THREADS, NB = R4R_TB_BATCH < NV ? R4R_TB_BATCH : NV;   // float4 per thread and array; in flight together
     static_assert(NV % NB == 0, "batches of the thread's float4");
     // (nvec == 0 -- a table's last chunk with fewer than four elements: the clamped loads below would read 16 bytes
     // at index 0 of a chunk that does not hold them, i.e. past the table's end; uniform)
@@ -353,6 +377,16 @@ __host__ __device__ inline bool mf_wide(int D, const float *p, const float *m, c
     const int lpr = D >> 2;
     return D >= 4 && (D & 3) == 0 && lpr <= 64 && (lpr & (lpr - 1)) == 0 &&
            (((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(m) | reinterpret_cast<uintptr_t>(v)) & 15) == 0);
+}
+
+// scheduled sweep: a row's float4 brought to step now - 1 before its entry wave applies step now's gradient
+__device__ __forceinline__ void tb_catch_up4(float4 &P, float4 &M, float4 &V, int cur, int now, const AdamScalars &s,
+                                             const MfTimeBlock &tb) {
+    tb_f32x4 p4[1] = {{P.x, P.y, P.z, P.w}}, m4[1] = {{M.x, M.y, M.z, M.w}}, v4[1] = {{V.x, V.y, V.z, V.w}};
+    const int c1[1] = {cur};
+    tb_catch_up_v<1>(p4, m4, v4, c1, now - 1, now, s, tb);
+    P = make_float4(p4[0][0], p4[0][1], p4[0][2], p4[0][3]); M = make_float4(m4[0][0], m4[0][1], m4[0][2], m4[0][3]);
+    V = make_float4(v4[0][0], v4[0][1], v4[0][2], v4[0][3]);
 }
 
 // One entry of the batch (rating k's id on side t), run by one wave: nothing to do unless k is the
@@ -492,6 +526,11 @@ __device__ __forceinline__ void mf_entry(const MfSweep &w, const int *sid, int *
             const int64_t o = ((int64_t)row * D >> 2) + sub;
             float4 P = reinterpret_cast<float4 *>(bp)[o], M = reinterpret_cast<float4 *>(bm)[o];
             float4 V = reinterpret_cast<float4 *>(bv)[o];
+            if (w.tb.rlast_u) {
+                int *rl = t ? w.tb.rlast_i : w.tb.rlast_u;
+                tb_catch_up4(P, M, V, tb_current(w.tb, rl, o * 4, row, w.now), w.now, w.s, w.tb);
+                if (sub == 0) rl[row] = w.now;              // (every lane of the row has read it: one wave, program order)
+            }
             adam_elem_fast(P.x, G.x, M.x, V.x, w.s); adam_elem_fast(P.y, G.y, M.y, V.y, w.s);
             adam_elem_fast(P.z, G.z, M.z, V.z, w.s); adam_elem_fast(P.w, G.w, M.w, V.w, w.s);
             reinterpret_cast<float4 *>(bp)[o] = P; reinterpret_cast<float4 *>(bm)[o] = M;
@@ -523,16 +562,44 @@ __device__ __forceinline__ void mf_entry(const MfSweep &w, const int *sid, int *
         gb = (gsum[0] + gsum[1]) + (gsum[2] + gsum[3]);
         if (D > 0) {
             float *bp = t ? w.p1 : w.p0, *bm = t ? w.m1 : w.m0, *bv = t ? w.v1 : w.v0;
+            float Px[MF_MAX_D / 64], Mx[MF_MAX_D / 64], Vx[MF_MAX_D / 64];
+            int cx[MF_MAX_D / 64];
+#pragma unroll
+            for (int x = 0; x < MF_MAX_D / 64; ++x) {
+                const int col = lane + 64 * x;
+                cx[x] = w.now;
+                Px[x] = Mx[x] = Vx[x] = 0.f;
+                if (col < D) {
+                    const int64_t o = (int64_t)row * D + col;
+                    Px[x] = bp[o]; Mx[x] = bm[o]; Vx[x] = bv[o];
+                    if (w.tb.rlast_u) cx[x] = tb_current(w.tb, t ? w.tb.rlast_i : w.tb.rlast_u, o, row, w.now);
+                }
+            }
+            if (w.tb.rlast_u) {                             // scheduled sweep: the row's pending gradient-zero updates first
+#pragma unroll
+                for (int j = 0; j < MF_TB_MAX - 1; ++j) {    // steps now - 7 .. now - 1, a step's scalars fetched once
+                    const int sj = w.now - (MF_TB_MAX - 1 - j);
+                    AdamScalars sc = w.s;
+                    sc.lr_over_bc1 = w.tb.lr_bc1[j];
+                    sc.inv_sqrt_bc2 = w.tb.isb2[j];
+#pragma unroll
+                    for (int x = 0; x < MF_MAX_D / 64; ++x)
+                        if (sj > cx[x]) adam_elem_fast(Px[x], 0.f, Mx[x], Vx[x], sc);
+                }
+            }
 #pragma unroll
             for (int x = 0; x < MF_MAX_D / 64; ++x) {
                 const int col = lane + 64 * x;
                 if (col < D) {
                     const int64_t o = (int64_t)row * D + col;
                     const float G = (acc[0][x] + acc[1][x]) + (acc[2][x] + acc[3][x]);
-                    float P = bp[o], M = bm[o], V = bv[o];
-                    adam_elem_fast(P, G, M, V, w.s);
-                    bp[o] = P; bm[o] = M; bv[o] = V;
+                    adam_elem_fast(Px[x], G, Mx[x], Vx[x], w.s);
+                    bp[o] = Px[x]; bm[o] = Mx[x]; bv[o] = Vx[x];
                 }
+            }
+            if (w.tb.rlast_u) {                             // (after every lane's read of it: same wave, program order)
+                __builtin_amdgcn_wave_barrier();
+                if (lane == 0) (t ? w.tb.rlast_i : w.tb.rlast_u)[row] = w.now;
             }
         }
     }
@@ -545,7 +612,7 @@ __device__ __forceinline__ void mf_entry(const MfSweep &w, const int *sid, int *
 }
 
 template <int NACC>
-__global__ __launch_bounds__(MF_THREADS) void mf_adam_kernel(MfSweep w) {
+__device__ __forceinline__ void mf_adam_body(const MfSweep &w) {
     extern __shared__ int sid[];                            // entry waves: the side's ids
     __shared__ float red[MF_THREADS];
     __shared__ int pend[MF_THREADS / 64][128];              // entry waves, wide form: the row's pending entries
@@ -554,6 +621,12 @@ __global__ __launch_bounds__(MF_THREADS) void mf_adam_kernel(MfSweep w) {
     // workgroup; interleaving them with the sweep workgroups measured slower), but keep the highest
     // slot numbers.
     const int bx = (int)blockIdx.x < w.n_entry_wgs ? w.cb_entries + (int)blockIdx.x : (int)blockIdx.x - w.n_entry_wgs;
+#ifdef R4R_MF_ABL                                           // timing-only ablations (wrong results): 1 entries, 2 tables, 4 bias vectors, 8 global
+    if ((R4R_MF_ABL & 1) && bx >= w.cb_entries) return;
+    if ((R4R_MF_ABL & 8) && bx >= w.cb_global && bx < w.cb_entries) return;
+    if ((R4R_MF_ABL & 2) && bx < w.cb2) return;
+    if ((R4R_MF_ABL & 4) && bx >= w.cb2 && bx < w.cb_global) return;
+#endif
     if (bx >= w.cb_entries) {
         // ---- entry waves: 4 per workgroup, all of one side (user side's groups first)
         const int lane = tid & 63;
@@ -588,6 +661,11 @@ __global__ __launch_bounds__(MF_THREADS) void mf_adam_kernel(MfSweep w) {
                     const int64_t o = ((int64_t)row * D >> 2) + sub;
                     float4 P = reinterpret_cast<float4 *>(bp)[o], M = reinterpret_cast<float4 *>(bm)[o];
                     float4 V = reinterpret_cast<float4 *>(bv)[o];
+                    if (w.tb.rlast_u) {
+                        int *rl = t ? w.tb.rlast_i : w.tb.rlast_u;
+                        tb_catch_up4(P, M, V, tb_current(w.tb, rl, o * 4, row, w.now), w.now, w.s, w.tb);
+                        if (sub == 0) rl[row] = w.now;
+                    }
                     adam_elem_fast(P.x, G.x, M.x, V.x, w.s); adam_elem_fast(P.y, G.y, M.y, V.y, w.s);
                     adam_elem_fast(P.z, G.z, M.z, V.z, w.s); adam_elem_fast(P.w, G.w, M.w, V.w, w.s);
                     reinterpret_cast<float4 *>(bp)[o] = P; reinterpret_cast<float4 *>(bm)[o] = M;
@@ -651,13 +729,125 @@ __global__ __launch_bounds__(MF_THREADS) void mf_adam_kernel(MfSweep w) {
     else if (t == 2) { bp = w.p2; bm = w.m2; bv = w.v2; numel = w.n2; cb = w.cb2; }
     else if (t == 3) { bp = w.p3; bm = w.m3; bv = w.v3; numel = w.n3; cb = w.cb3; }
     const int W = t < 2 ? w.D : 1;
-    const int64_t start = (int64_t)(bx - cb) * mf_chunk(t);
+    int64_t ci64 = bx - cb;
+    const bool sched = w.tb.rlast_u && t < 2;               // the scheduled form of the blocked sweep (rows_device.h)
+    if (sched && !w.tb.flush) ci64 = tb_due_chunk(ci64, w.now, w.tb.period);   // one due chunk per block of `period`
+    const int64_t start = ci64 * mf_chunk(t);
+    if (start >= numel) return;                             // (the last block's due chunk may lie past the table)
     int64_t cnt = numel - start;
     if (cnt > mf_chunk(t)) cnt = mf_chunk(t);
     float *p = bp + start, *m = bm + start, *v = bv + start;
     const int *tag = (t == 0 || t == 2) ? w.tag_u : w.tag_i;
     const bool aligned = (((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(m) | reinterpret_cast<uintptr_t>(v)) & 15) == 0);
     const int *ctag = t == 0 ? w.ctag_u : (t == 1 ? w.ctag_i : nullptr);
+    if (sched) {
+        // through which step is the chunk current?  its last scheduled visit, or the base
+        int vis = tb_prev_visit(ci64, w.now - w.tb.inc, w.tb.period);
+        if (vis < w.tb.base) vis = w.tb.base;
+        const int pend = w.now - vis;
+        if (pend > MF_TB_MAX) { if (tid == 0) *w.tb.err = 2; return; }   // (the caller left the schedule without a flush)
+        if (pend <= 0) return;
+        constexpr int NV = MF_CHUNK / 4 / MF_THREADS;       // float4 per thread and array
+        const int64_t nvec = cnt >> 2;
+        auto ld = [&](const float *a, int64_t i) {
+            const mf_f32x4 *q = reinterpret_cast<const mf_f32x4 *>(a) + i;
+            return w.nt ? __builtin_nontemporal_load(q) : *q;
+        };
+        auto st = [&](float *a, int64_t i, mf_f32x4 x) {
+            mf_f32x4 *q = reinterpret_cast<mf_f32x4 *>(a) + i;
+            if (w.nt) __builtin_nontemporal_store(x, q);
+            else *q = x;
+        };
+        // the elements are requested BEFORE the chunk tag is known (one memory round trip per workgroup instead of two)
+        mf_f32x4 P[NV], M[NV], V[NV];
+        int cur[NV];
+        bool on[NV];
+#pragma unroll
+        for (int u = 0; u < NV; ++u) {
+            const int64_t i = tid + (int64_t)u * MF_THREADS, ii = i < nvec ? i : 0;   // (clamped; nvec == 0: handled by the tail below)
+            on[u] = i < nvec;
+            cur[u] = vis;
+            if (nvec > 0) { P[u] = ld(p, ii); M[u] = ld(m, ii); V[u] = ld(v, ii); }
+        }
+        const bool recent = ctag[ci64] > vis;               // a row of the chunk was touched after the visit (or is, now)
+        const int *rlast = t == 0 ? w.tb.rlast_u : w.tb.rlast_i;
+        const bool skip_now = w.tb.inc != 0;
+        const int64_t row_start = start / W;
+        const unsigned col_start = (unsigned)(start - row_start * W);
+        if (!recent || W % 4 == 0) {
+            if (recent) {
+                // rows touched since the visit are current through their own last update (rlast); rows this step
+                // touches belong to their entry waves.  A float4 never straddles a row here.
+#pragma unroll
+                for (int u = 0; u < NV; ++u) {
+                    const int64_t ii = on[u] ? tid + (int64_t)u * MF_THREADS : 0;
+                    const int64_t row = row_start + (col_start + (unsigned)ii * 4u) / (unsigned)W;
+                    const int tg = tag[row], rl = rlast[row];
+                    if (rl > cur[u]) cur[u] = rl;
+                    if (skip_now && tg == w.now) on[u] = false;
+                }
+            }
+            if (nvec > 0) {
+                int lim[NV];
+#pragma unroll
+                for (int u = 0; u < NV; ++u) lim[u] = on[u] ? cur[u] : w.now;
+                tb_catch_up_v<NV>(P, M, V, lim, w.now, w.now, w.s, w.tb);
+#pragma unroll
+                for (int u = 0; u < NV; ++u) {
+                    const int64_t i = tid + (int64_t)u * MF_THREADS;
+                    if (on[u] && cur[u] < w.now) { st(p, i, P[u]); st(m, i, M[u]); st(v, i, V[u]); }
+                }
+            }
+        } else {                                            // 5-wide ID vectors ...: element by element
+            for (int64_t i = tid; i < nvec; i += MF_THREADS) {
+                const mf_f32x4 Pq = reinterpret_cast<const mf_f32x4 *>(p)[i], Mq = reinterpret_cast<const mf_f32x4 *>(m)[i];
+                const mf_f32x4 Vq = reinterpret_cast<const mf_f32x4 *>(v)[i];
+                float Pn[4], Mn[4], Vn[4];
+                int ce[4];
+                bool all = true, oe[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const int64_t row = row_start + (col_start + (unsigned)i * 4u + c) / (unsigned)W;
+                    const int r = rlast[row];
+                    ce[c] = r > vis ? r : vis;
+                    oe[c] = !(skip_now && tag[row] == w.now) && ce[c] < w.now;
+                    all = all && oe[c];
+                    if (!oe[c]) ce[c] = w.now;
+                    Pn[c] = Pq[c]; Mn[c] = Mq[c]; Vn[c] = Vq[c];
+                }
+#pragma unroll
+                for (int j = 0; j < MF_TB_MAX; ++j) {
+                    const int sj = w.now - (MF_TB_MAX - 1 - j);
+                    AdamScalars sc = w.s;
+                    sc.lr_over_bc1 = w.tb.lr_bc1[j];
+                    sc.inv_sqrt_bc2 = w.tb.isb2[j];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+                        if (sj > ce[c]) adam_elem_fast(Pn[c], 0.f, Mn[c], Vn[c], sc);
+                }
+                if (all) {
+                    reinterpret_cast<mf_f32x4 *>(p)[i] = mf_f32x4{Pn[0], Pn[1], Pn[2], Pn[3]};
+                    reinterpret_cast<mf_f32x4 *>(m)[i] = mf_f32x4{Mn[0], Mn[1], Mn[2], Mn[3]};
+                    reinterpret_cast<mf_f32x4 *>(v)[i] = mf_f32x4{Vn[0], Vn[1], Vn[2], Vn[3]};
+                } else {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+                        if (oe[c]) { p[4 * i + c] = Pn[c]; m[4 * i + c] = Mn[c]; v[4 * i + c] = Vn[c]; }
+                }
+            }
+        }
+        const int64_t k = (nvec << 2) + tid;                // cnt % 4 elements at the end of a table
+        if (k < cnt) {
+            const int64_t row = (start + k) / W;
+            const int r = recent ? rlast[row] : 0, c1 = r > vis ? r : vis;
+            if (!(recent && skip_now && tag[row] == w.now) && c1 < w.now) {
+                float Pk = p[k], Mk = m[k], Vk = v[k];
+                tb_catch_up(Pk, Mk, Vk, c1, w.now, w.now, w.s, w.tb);
+                p[k] = Pk; m[k] = Mk; v[k] = Vk;
+            }
+        }
+        return;
+    }
     if (w.tb.lag_u && t < 2) {
         // temporally blocked (rows_device.h): is this chunk visited now, and with how many updates?
         int *lag = t == 0 ? w.tb.lag_u : w.tb.lag_i;
@@ -822,12 +1012,24 @@ __global__ __launch_bounds__(MF_THREADS) void mf_adam_kernel(MfSweep w) {
     }
 }
 
+BWD_TRACE_DEFINE(r4r_debug_mf_adam_trace)
+template <int NACC>
+__global__ __launch_bounds__(MF_THREADS) void mf_adam_kernel(MfSweep w) {
+    BWD_STAMP(0, wall_clock64());                           // (instrumented builds only: tools/sweep_trace.py)
+    mf_adam_body<NACC>(w);
+#ifdef R4R_TRACE
+    const int bx = (int)blockIdx.x < w.n_entry_wgs ? w.cb_entries + (int)blockIdx.x : (int)blockIdx.x - w.n_entry_wgs;
+    BWD_STAMP(1, wall_clock64());
+    BWD_STAMP(2, bx >= w.cb_entries ? 5 : bx >= w.cb_global ? 4 : bx >= w.cb2 ? 3 : 2);   // role + 1: tables, bias vectors, global, entries
+#endif
+}
+
 struct MfWs {
     float *gu, *gi, *g, *mult;
     int *tag_u, *tag_i;
     unsigned long long *first_u, *first_i, *last_u, *last_i;
     int *uid32, *iid32;
-    int *ctag_u, *ctag_i, *ntag_u, *ntag_i, *lag_u, *lag_i, *tb_err;   // the temporally blocked sweep's state (rows_device.h)
+    int *ctag_u, *ctag_i, *rlast_u, *rlast_i, *tb_err;   // the temporally blocked sweep's state (rows_device.h, scheduled form)
     size_t bytes, persist;             // persist: the head of the buffer that carries state across steps
 };
 
@@ -846,8 +1048,7 @@ static MfWs mf_carve(void *ws, int64_t B, int D, int64_t n_users, int64_t n_item
     w.last_i = reinterpret_cast<unsigned long long *>(take((size_t)n_items * 8));
     const size_t cu = (size_t)cdiv(n_users * (int64_t)D, MF_CHUNK), ci = (size_t)cdiv(n_items * (int64_t)D, MF_CHUNK);
     w.ctag_u = reinterpret_cast<int *>(take(cu * 4)); w.ctag_i = reinterpret_cast<int *>(take(ci * 4));
-    w.ntag_u = reinterpret_cast<int *>(take(cu * 4)); w.ntag_i = reinterpret_cast<int *>(take(ci * 4));
-    w.lag_u = reinterpret_cast<int *>(take(cu * 4)); w.lag_i = reinterpret_cast<int *>(take(ci * 4));
+    w.rlast_u = reinterpret_cast<int *>(take((size_t)n_users * 4)); w.rlast_i = reinterpret_cast<int *>(take((size_t)n_items * 4));
     w.tb_err = reinterpret_cast<int *>(take(4));
     w.persist = o;
     w.uid32 = reinterpret_cast<int *>(take((size_t)B * 4));
@@ -914,6 +1115,17 @@ void mf_time_block_scalars(MfTimeBlock &tb, float lr, double beta1, double beta2
     }
 }
 
+// sweep workgroups of one table: every chunk, or -- scheduled form outside an all-chunks launch -- one per block of `period`
+static int64_t mf_sweep_wgs(int64_t numel, int chunk, const MfTimeBlock &tb) {
+    const int64_t nch = cdiv(numel, chunk);
+    return (tb.rlast_u && !tb.flush) ? cdiv(nch, tb.period) : nch;
+}
+static bool mf_tb_args_ok(const MfTimeBlock *tb, const int *ctag_u, const int *ctag_i, uintptr_t all) {
+    const bool announced = tb->lag_u && tb->lag_i && tb->ntag_u && tb->ntag_i, scheduled = tb->rlast_u && tb->rlast_i;
+    return ctag_u && ctag_i && (announced || scheduled) && tb->err && !(all & 15) && tb->period >= 1 && tb->period <= MF_TB_MAX &&
+           (!scheduled || tb->base >= 0);
+}
+
 // Adam on two ID tables of width D whose gradient rows are compact ([B, D] per table, one row per
 // rating; TransNet++'s user / item vectors, TransNet.py:75-76): the sweep + entry waves above
 // without bias vectors.  `tag_*`: per-row step tags the caller's forward kernel set to `now`.
@@ -930,9 +1142,8 @@ int mf_table_rows_launch(float *ut, float *ut_m, float *ut_v, float *it, float *
     if (tb) {
         const uintptr_t all = reinterpret_cast<uintptr_t>(ut) | reinterpret_cast<uintptr_t>(ut_m) | reinterpret_cast<uintptr_t>(ut_v) |
                               reinterpret_cast<uintptr_t>(it) | reinterpret_cast<uintptr_t>(it_m) | reinterpret_cast<uintptr_t>(it_v);
-        if (!ctag_u || !ctag_i || !tb->lag_u || !tb->lag_i || !tb->ntag_u || !tb->ntag_i || !tb->err || (all & 15) ||
-            tb->period < 1 || tb->period > MF_TB_MAX) {
-            set_error("table rows: the temporally blocked sweep needs chunk tags, lag / next-tag arrays, 16-byte aligned tables "
+        if (!mf_tb_args_ok(tb, ctag_u, ctag_i, all)) {
+            set_error("table rows: the temporally blocked sweep needs chunk tags, its state arrays, 16-byte aligned tables "
                       "and a period in 1..%d", MF_TB_MAX);
             return R4R_ERR_ARG;
         }
@@ -940,9 +1151,9 @@ int mf_table_rows_launch(float *ut, float *ut_m, float *ut_v, float *it, float *
     }
     sw.p0 = ut; sw.m0 = ut_m; sw.v0 = ut_v; sw.p1 = it; sw.m1 = it_m; sw.v1 = it_v;
     sw.n0 = n_users * D; sw.n1 = n_items * D; sw.n2 = sw.n3 = 0;
-    int64_t chunks = cdiv(sw.n0, mf_chunk(0));
+    int64_t chunks = mf_sweep_wgs(sw.n0, mf_chunk(0), sw.tb);
     sw.cb1 = (int)chunks;
-    chunks += cdiv(sw.n1, mf_chunk(1));
+    chunks += mf_sweep_wgs(sw.n1, mf_chunk(1), sw.tb);
     sw.cb2 = sw.cb3 = sw.cb_global = sw.cb_entries = (int)chunks;   // no bias vectors, no global-bias workgroup
     sw.epw = mf_epw(B);
     sw.n_entry_wgs = (int)(2 * cdiv(B, 4 * sw.epw));
@@ -979,9 +1190,8 @@ int mf_table_bias_rows_launch(float *ut, float *ut_m, float *ut_v, float *it, fl
     if (tb) {
         const uintptr_t all = reinterpret_cast<uintptr_t>(ut) | reinterpret_cast<uintptr_t>(ut_m) | reinterpret_cast<uintptr_t>(ut_v) |
                               reinterpret_cast<uintptr_t>(it) | reinterpret_cast<uintptr_t>(it_m) | reinterpret_cast<uintptr_t>(it_v);
-        if (!ctag_u || !ctag_i || !tb->lag_u || !tb->lag_i || !tb->ntag_u || !tb->ntag_i || !tb->err || (all & 15) ||
-            tb->period < 1 || tb->period > MF_TB_MAX) {
-            set_error("table + bias rows: the temporally blocked sweep needs chunk tags, lag / next-tag arrays, 16-byte aligned "
+        if (!mf_tb_args_ok(tb, ctag_u, ctag_i, all)) {
+            set_error("table + bias rows: the temporally blocked sweep needs chunk tags, its state arrays, 16-byte aligned "
                       "tables and a period in 1..%d", MF_TB_MAX);
             return R4R_ERR_ARG;
         }
@@ -992,9 +1202,9 @@ int mf_table_bias_rows_launch(float *ut, float *ut_m, float *ut_v, float *it, fl
     sw.p0 = ut; sw.m0 = ut_m; sw.v0 = ut_v; sw.p1 = it; sw.m1 = it_m; sw.v1 = it_v;
     sw.p2 = ub; sw.m2 = ub_m; sw.v2 = ub_v; sw.p3 = ib; sw.m3 = ib_m; sw.v3 = ib_v;
     sw.n0 = n_users * D; sw.n1 = n_items * D; sw.n2 = n_users; sw.n3 = n_items;
-    int64_t chunks = cdiv(sw.n0, mf_chunk(0));
+    int64_t chunks = mf_sweep_wgs(sw.n0, mf_chunk(0), sw.tb);
     sw.cb1 = (int)chunks;
-    chunks += cdiv(sw.n1, mf_chunk(1));
+    chunks += mf_sweep_wgs(sw.n1, mf_chunk(1), sw.tb);
     sw.cb2 = (int)chunks;
     chunks += cdiv(sw.n2, mf_chunk(2));
     sw.cb3 = (int)chunks;
@@ -1047,12 +1257,13 @@ extern "C" int r4r_mf_step(const int64_t *uid, const int64_t *iid, const float *
                            int64_t n_users, int64_t n_items, int D,
                            float *pred, float *se, float *sse_accum, void *ws, size_t ws_bytes, int64_t B,
                            float dropout_p, int training, uint64_t seed, uint64_t offset, float inv_denom,
-                           const int64_t *next_uid, const int64_t *next_iid, int64_t next_B, int sweep_period,
+                           int sweep_period, int64_t sweep_base, int sweep_all,
                            float lr, double beta1, double beta2, float eps, float weight_decay, int64_t adam_step,
                            void *stream) {
     R4R_REQUIRE(uid && iid && p && pred && ws, "mf_step: null pointer");
     R4R_REQUIRE(sweep_period >= 1 && sweep_period <= MF_TB_MAX, "mf_step: sweep_period %d outside 1..%d", sweep_period, MF_TB_MAX);
-    R4R_REQUIRE(!next_uid == !next_iid && (!next_uid || next_B > 0), "mf_step: next_uid, next_iid and next_B > 0 go together");
+    R4R_REQUIRE(sweep_base >= 0 && (!m || sweep_base < adam_step), "mf_step: sweep_base %lld outside 0..adam_step - 1",
+                (long long)sweep_base);
     R4R_REQUIRE(n_users > 0 && n_items > 0 && B >= 0, "mf_step: bad sizes");
     R4R_REQUIRE(D >= 0 && D <= MF_MAX_D, "mf_step: latent_size %d outside 0..%d", D, MF_MAX_D);
     R4R_REQUIRE(!m == !v, "mf_step: m and v go together");
@@ -1092,10 +1303,14 @@ extern "C" int r4r_mf_step(const int64_t *uid, const int64_t *iid, const float *
     a.p_drop = dropout_p; a.inv_denom = inv_denom; a.seed = seed; a.offset = offset;
     // the temporally blocked sweep (rows_device.h) applies to 16-byte aligned tables; without it the chunk tags stay unused
     const bool tb_on = m && D > 0 && (((p[0] | p[1] | m[0] | m[1] | v[0] | v[1]) & 15) == 0);
-    const bool announce = tb_on && next_uid && sweep_period > 1;
+    MfTimeBlock tb{};
     if (tb_on) {
-        a.ctag_u = w.ctag_u; a.ctag_i = w.ctag_i; a.ntag_u = w.ntag_u; a.ntag_i = w.ntag_i;
-        if (announce) { a.next_uid = next_uid; a.next_iid = next_iid; a.next_B = next_B; }
+        a.ctag_u = w.ctag_u; a.ctag_i = w.ctag_i;
+        tb.rlast_u = w.rlast_u; tb.rlast_i = w.rlast_i; tb.err = w.tb_err; tb.base = (int)sweep_base;
+        tb.period = sweep_period; tb.flush = (sweep_all || sweep_period == 1) ? 1 : 0; tb.inc = 1;
+        mf_time_block_scalars(tb, lr, beta1, beta2, eps, weight_decay, adam_step);
+        a.tb = tb; a.now = (int)adam_step;
+        a.sc0 = adam_make_scalars(lr, beta1, beta2, eps, weight_decay, adam_step, nullptr);
     }
     mf_fwd_bwd_kernel<<<(unsigned)cdiv(B, 4), 256, 0, st>>>(a);
     if (!m) return check_launch("mf_step(forward)");
@@ -1104,10 +1319,10 @@ extern "C" int r4r_mf_step(const int64_t *uid, const int64_t *iid, const float *
     sw.m0 = a.m[0]; sw.m1 = a.m[1]; sw.m2 = a.m[2]; sw.m3 = a.m[3]; sw.m4 = a.m[4];
     sw.v0 = a.v[0]; sw.v1 = a.v[1]; sw.v2 = a.v[2]; sw.v3 = a.v[3]; sw.v4 = a.v[4];
     int64_t numel[4], begin[4], chunks = 0;
-    for (int k = 0; k < 4; ++k) {                           // sweep workgroups: tables, bias vectors
+    for (int k = 0; k < 4; ++k) {                           // sweep workgroups: tables (the due chunks), bias vectors
         numel[k] = rows[k] * width[k];
         begin[k] = chunks;
-        chunks += cdiv(numel[k], mf_chunk(k));
+        chunks += k < 2 ? mf_sweep_wgs(numel[k], mf_chunk(k), tb) : cdiv(numel[k], mf_chunk(k));
     }
     sw.n0 = numel[0]; sw.n1 = numel[1]; sw.n2 = numel[2]; sw.n3 = numel[3];
     sw.cb1 = (int)begin[1]; sw.cb2 = (int)begin[2]; sw.cb3 = (int)begin[3];
@@ -1126,9 +1341,7 @@ extern "C" int r4r_mf_step(const int64_t *uid, const int64_t *iid, const float *
     sw.s = adam_make_scalars(lr, beta1, beta2, eps, weight_decay, adam_step, nullptr);
     if (tb_on) {
         sw.ctag_u = w.ctag_u; sw.ctag_i = w.ctag_i;
-        sw.tb.lag_u = w.lag_u; sw.tb.lag_i = w.lag_i; sw.tb.ntag_u = w.ntag_u; sw.tb.ntag_i = w.ntag_i; sw.tb.err = w.tb_err;
-        sw.tb.period = announce ? sweep_period : 1; sw.tb.flush = announce ? 0 : 1; sw.tb.inc = 1;
-        mf_time_block_scalars(sw.tb, lr, beta1, beta2, eps, weight_decay, adam_step);
+        sw.tb = tb;
         sw.nt = mf_sweep_nt(sw.n0 + sw.n1);
     }
     {
@@ -1141,26 +1354,30 @@ extern "C" int r4r_mf_step(const int64_t *uid, const int64_t *iid, const float *
     return check_launch("mf_step");
 }
 
-// What the temporally blocked sweep left pending (r4r_mf_step with next_uid and sweep_period > 1): every chunk of the
-// two ID tables takes its pending updates now.  adam_step = the LAST COMPLETED step.
+// What the temporally blocked sweep left pending (r4r_mf_step with sweep_period > 1): every chunk of the two ID tables
+// takes its pending updates now.  adam_step = the LAST COMPLETED step; (sweep_period, sweep_base): the schedule in force
+// since sweep_base.  The caller's base becomes adam_step.
 extern "C" int r4r_mf_rows_flush(const uint64_t *p, const uint64_t *m, const uint64_t *v,
                                  int64_t n_users, int64_t n_items, int D, void *ws, size_t ws_bytes, int64_t B,
+                                 int sweep_period, int64_t sweep_base,
                                  float lr, double beta1, double beta2, float eps, float weight_decay, int64_t adam_step,
                                  void *stream) {
     R4R_REQUIRE(p && m && v && ws, "mf_rows_flush: null pointer");
     R4R_REQUIRE(n_users > 0 && n_items > 0 && B >= 0 && D >= 0 && D <= MF_MAX_D, "mf_rows_flush: bad sizes");
     R4R_REQUIRE(adam_step >= 0 && adam_step < (1ll << 31), "mf_rows_flush: bad adam_step");
+    R4R_REQUIRE(sweep_period >= 1 && sweep_period <= MF_TB_MAX && sweep_base >= 0 && sweep_base <= adam_step,
+                "mf_rows_flush: sweep_period outside 1..%d or sweep_base outside 0..adam_step", MF_TB_MAX);
     if (ws_bytes < r4r_mf_ws_bytes(B, D, n_users, n_items)) {
         set_error("mf_rows_flush: workspace %zu < %zu bytes", ws_bytes, r4r_mf_ws_bytes(B, D, n_users, n_items));
         return R4R_ERR_WORKSPACE;
     }
-    if (adam_step == 0 || D == 0) return R4R_OK;            // no step yet / no tables: nothing can be pending
+    if (adam_step == 0 || D == 0 || sweep_base == adam_step) return R4R_OK;   // no step yet / no tables / nothing can be pending
     for (int k = 0; k < 2; ++k) R4R_REQUIRE(p[k] && m[k] && v[k], "mf_rows_flush: table %d: null pointer", k);
     if ((p[0] | p[1] | m[0] | m[1] | v[0] | v[1]) & 15) return R4R_OK;   // (unaligned tables never defer)
     const MfWs w = mf_carve(ws, B, D, n_users, n_items);
     MfTimeBlock tb{};
-    tb.lag_u = w.lag_u; tb.lag_i = w.lag_i; tb.ntag_u = w.ntag_u; tb.ntag_i = w.ntag_i; tb.err = w.tb_err;
-    tb.period = 1; tb.flush = 1; tb.inc = 0;
+    tb.rlast_u = w.rlast_u; tb.rlast_i = w.rlast_i; tb.err = w.tb_err; tb.base = (int)sweep_base;
+    tb.period = sweep_period; tb.flush = 1; tb.inc = 0;
     mf_time_block_scalars(tb, lr, beta1, beta2, eps, weight_decay, adam_step);
     const AdamScalars sc = adam_make_scalars(lr, beta1, beta2, eps, weight_decay, adam_step, nullptr);
     auto f = [](uint64_t x) { return reinterpret_cast<float *>(x); };
@@ -1183,14 +1400,13 @@ extern "C" size_t r4r_mf_ws_flag_offset(int64_t B, int D, int64_t n_users, int64
 // entries past a rank's own count carry id -1 (ragged shards).
 namespace r4r {
 
-struct MfBlock { size_t uid, iid, g, gu, gi, nuid, niid, bytes; };
+struct MfBlock { size_t uid, iid, g, gu, gi, bytes; };
 static MfBlock mf_block(int64_t B_pad, int D) {
     MfBlock k;
     size_t o = 0;
     auto take = [&](size_t n) { size_t r = o; o += a256(n); return r; };
     k.uid = take((size_t)B_pad * 4); k.iid = take((size_t)B_pad * 4); k.g = take((size_t)B_pad * 4);
     k.gu = take((size_t)B_pad * D * 4); k.gi = take((size_t)B_pad * D * 4);
-    k.nuid = take((size_t)B_pad * 4); k.niid = take((size_t)B_pad * 4);      // the rank's announced next shard (-1: none)
     k.bytes = o;
     return k;
 }
@@ -1203,7 +1419,7 @@ struct MfRegister {
     int *tag_u, *tag_i, *uid32, *iid32;
     unsigned long long *first_u, *first_i, *last_u, *last_i;
     float *g, *gu, *gi;                // contiguous [world * B_pad] entry arrays for the update kernel
-    int *ctag_u = nullptr, *ctag_i = nullptr, *ntag_u = nullptr, *ntag_i = nullptr;   // temporally blocked sweep: chunk tags (NULL: not kept)
+    int *ctag_u = nullptr, *ctag_i = nullptr;   // temporally blocked sweep: chunk tags (NULL: not kept)
 };
 
 // one wave per gathered entry: ids, d loss / d pred and the two gradient rows into the contiguous
@@ -1226,17 +1442,10 @@ __global__ __launch_bounds__(256) void mf_register_kernel(MfRegister a) {
             atomicMax(a.last_u + u, lastv);
             atomicMax(a.last_i + i, lastv);
         }
-        if (a.ctag_u && a.D > 0) {                          // chunk tags of every rank's current and announced next ids
+        if (a.ctag_u && a.D > 0 && u >= 0) {                // chunk tags of every rank's ids
             const int64_t D = a.D;
-            if (u >= 0) {
-                a.ctag_u[u * D / MF_CHUNK] = a.now; a.ctag_u[(u * D + D - 1) / MF_CHUNK] = a.now;
-                a.ctag_i[i * D / MF_CHUNK] = a.now; a.ctag_i[(i * D + D - 1) / MF_CHUNK] = a.now;
-            }
-            const int64_t nu = reinterpret_cast<const int *>(blk + a.k.nuid)[b], ni = reinterpret_cast<const int *>(blk + a.k.niid)[b];
-            if (nu >= 0) {
-                a.ntag_u[nu * D / MF_CHUNK] = a.now; a.ntag_u[(nu * D + D - 1) / MF_CHUNK] = a.now;
-                a.ntag_i[ni * D / MF_CHUNK] = a.now; a.ntag_i[(ni * D + D - 1) / MF_CHUNK] = a.now;
-            }
+            a.ctag_u[u * D / MF_CHUNK] = a.now; a.ctag_u[(u * D + D - 1) / MF_CHUNK] = a.now;
+            a.ctag_i[i * D / MF_CHUNK] = a.now; a.ctag_i[(i * D + D - 1) / MF_CHUNK] = a.now;
         }
     }
     if (u >= 0)
@@ -1254,12 +1463,17 @@ extern "C" size_t r4r_mf_dp_block_bytes(int64_t B_pad, int D) {
 }
 
 extern "C" int r4r_mf_grad(const int64_t *uid, const int64_t *iid, const float *y, const uint64_t *p,
+                           const uint64_t *m, const uint64_t *v,
                            int64_t n_users, int64_t n_items, int D, float *pred, float *se, void *block, float *mult,
                            int64_t B, int64_t B_pad, float dropout_p, int training, uint64_t seed, uint64_t offset,
-                           float inv_denom, const int64_t *next_uid, const int64_t *next_iid, int64_t next_B, void *stream) {
+                           float inv_denom, void *ws, int sweep_period, int64_t sweep_base,
+                           float lr, double beta1, double beta2, float eps, float weight_decay, int64_t adam_step,
+                           void *stream) {
     R4R_REQUIRE(p && pred && se && block, "mf_grad: null pointer");
-    R4R_REQUIRE(!next_uid == !next_iid && next_B >= 0 && next_B <= B_pad && (next_uid || next_B == 0),
-                "mf_grad: next_uid / next_iid go together, 0 <= next_B <= B_pad");
+    R4R_REQUIRE(!m == !v && !m == !ws, "mf_grad: m, v and the workspace of r4r_mf_apply go together");
+    R4R_REQUIRE(!m || (sweep_period >= 1 && sweep_period <= MF_TB_MAX && sweep_base >= 0 && sweep_base < adam_step &&
+                       adam_step < (1ll << 31)),
+                "mf_grad: sweep_period outside 1..%d, or sweep_base outside 0..adam_step - 1", MF_TB_MAX);
     R4R_REQUIRE(B == 0 || (uid && iid && y), "mf_grad: null ids / ratings");   // (an empty shard has none)
     R4R_REQUIRE(n_users > 0 && n_items > 0 && B >= 0 && B_pad >= B, "mf_grad: bad sizes");
     R4R_REQUIRE(D >= 0 && D <= MF_MAX_D, "mf_grad: latent_size %d outside 0..%d", D, MF_MAX_D);
@@ -1274,8 +1488,17 @@ extern "C" int r4r_mf_grad(const int64_t *uid, const int64_t *iid, const float *
     a.uid32 = reinterpret_cast<int *>(blk + k.uid); a.iid32 = reinterpret_cast<int *>(blk + k.iid);
     a.g = reinterpret_cast<float *>(blk + k.g); a.gu = reinterpret_cast<float *>(blk + k.gu);
     a.gi = reinterpret_cast<float *>(blk + k.gi); a.mult = mult;
-    a.nuid32 = reinterpret_cast<int *>(blk + k.nuid); a.niid32 = reinterpret_cast<int *>(blk + k.niid);
-    a.dp_next_uid = next_uid; a.dp_next_iid = next_iid; a.dp_next_B = next_B;
+    // the tables may carry pending gradient-zero updates (r4r_mf_apply's scheduled sweep): the rows a rating reads
+    // are brought to step adam_step - 1 in registers
+    if (m && D > 0 && sweep_period > 1 && (((p[0] | p[1] | m[0] | m[1] | v[0] | v[1]) & 15) == 0)) {
+        for (int s = 0; s < 2; ++s) { a.m[s] = reinterpret_cast<float *>(m[s]); a.v[s] = reinterpret_cast<float *>(v[s]); }
+        const MfWs w = mf_carve(ws, 0, D, n_users, n_items);
+        a.tb.rlast_u = w.rlast_u; a.tb.rlast_i = w.rlast_i; a.tb.err = w.tb_err; a.tb.base = (int)sweep_base;
+        a.tb.period = sweep_period; a.tb.inc = 1;
+        mf_time_block_scalars(a.tb, lr, beta1, beta2, eps, weight_decay, adam_step);
+        a.sc0 = adam_make_scalars(lr, beta1, beta2, eps, weight_decay, adam_step, nullptr);
+        a.now = (int)adam_step;
+    }
     a.pred = pred; a.se = se; a.B = B; a.B_pad = B_pad; a.register_rows = 0; a.D = D; a.training = training;
     a.want_grad = 1; a.tag = 0; a.p_drop = dropout_p; a.inv_denom = inv_denom; a.seed = seed; a.offset = offset;
     mf_fwd_bwd_kernel<<<(unsigned)cdiv(B_pad, 4), 256, 0, as_stream(stream)>>>(a);
@@ -1284,7 +1507,7 @@ extern "C" int r4r_mf_grad(const int64_t *uid, const int64_t *iid, const float *
 
 extern "C" int r4r_mf_apply(const void *blocks, int world, int64_t B_pad, const uint64_t *p, const uint64_t *m,
                             const uint64_t *v, int64_t n_users, int64_t n_items, int D, void *ws, size_t ws_bytes,
-                            int sweep_period, int announce,
+                            int sweep_period, int64_t sweep_base, int sweep_all,
                             float lr, double beta1, double beta2, float eps, float weight_decay, int64_t adam_step,
                             void *stream) {
     R4R_REQUIRE(blocks && p && m && v && ws, "mf_apply: null pointer");
@@ -1294,6 +1517,7 @@ extern "C" int r4r_mf_apply(const void *blocks, int world, int64_t B_pad, const 
     R4R_REQUIRE(B <= MF_MAX_B_STEP, "mf_apply: %lld gathered entries > %d", (long long)B, MF_MAX_B_STEP);
     R4R_REQUIRE(D >= 0 && D <= MF_MAX_D, "mf_apply: latent_size %d outside 0..%d", D, MF_MAX_D);
     R4R_REQUIRE(adam_step >= 1 && adam_step < (1ll << 31), "mf_apply: bad adam_step");
+    R4R_REQUIRE(sweep_base >= 0 && sweep_base < adam_step, "mf_apply: sweep_base outside 0..adam_step - 1");
     if (ws_bytes < r4r_mf_ws_bytes(B, D, n_users, n_items)) {
         set_error("mf_apply: workspace %zu < %zu bytes", ws_bytes, r4r_mf_ws_bytes(B, D, n_users, n_items));
         return R4R_ERR_WORKSPACE;
@@ -1309,8 +1533,7 @@ extern "C" int r4r_mf_apply(const void *blocks, int world, int64_t B_pad, const 
     rg.g = w.g; rg.gu = w.gu; rg.gi = w.gi;
     // the temporally blocked sweep (rows_device.h) over the gathered entries: 16-byte aligned tables
     const bool tb_on = D > 0 && (((p[0] | p[1] | m[0] | m[1] | v[0] | v[1]) & 15) == 0);
-    const bool tb_defer = tb_on && announce && sweep_period > 1;
-    if (tb_on) { rg.ctag_u = w.ctag_u; rg.ctag_i = w.ctag_i; rg.ntag_u = w.ntag_u; rg.ntag_i = w.ntag_i; }
+    if (tb_on) { rg.ctag_u = w.ctag_u; rg.ctag_i = w.ctag_i; }
     mf_register_kernel<<<(unsigned)cdiv(B, 4), 256, 0, st>>>(rg);
     float *P[MF_SLOTS], *M[MF_SLOTS], *V[MF_SLOTS];
     for (int k = 0; k < MF_SLOTS; ++k) {
@@ -1323,11 +1546,17 @@ extern "C" int r4r_mf_apply(const void *blocks, int world, int64_t B_pad, const 
     sw.v0 = V[0]; sw.v1 = V[1]; sw.v2 = V[2]; sw.v3 = V[3]; sw.v4 = V[4];
     const int64_t rows[4] = {n_users, n_items, n_users, n_items};
     const int width[4] = {D, D, 1, 1};
+    MfTimeBlock tb{};
+    if (tb_on) {
+        tb.rlast_u = w.rlast_u; tb.rlast_i = w.rlast_i; tb.err = w.tb_err; tb.base = (int)sweep_base;
+        tb.period = sweep_period; tb.flush = (sweep_all || sweep_period == 1) ? 1 : 0; tb.inc = 1;
+        mf_time_block_scalars(tb, lr, beta1, beta2, eps, weight_decay, adam_step);
+    }
     int64_t numel[4], begin[4], chunks = 0;
     for (int k = 0; k < 4; ++k) {
         numel[k] = rows[k] * width[k];
         begin[k] = chunks;
-        chunks += cdiv(numel[k], mf_chunk(k));
+        chunks += k < 2 ? mf_sweep_wgs(numel[k], mf_chunk(k), tb) : cdiv(numel[k], mf_chunk(k));
     }
     sw.n0 = numel[0]; sw.n1 = numel[1]; sw.n2 = numel[2]; sw.n3 = numel[3];
     sw.cb1 = (int)begin[1]; sw.cb2 = (int)begin[2]; sw.cb3 = (int)begin[3];
@@ -1345,9 +1574,7 @@ extern "C" int r4r_mf_apply(const void *blocks, int world, int64_t B_pad, const 
     sw.s = adam_make_scalars(lr, beta1, beta2, eps, weight_decay, adam_step, nullptr);
     if (tb_on) {
         sw.ctag_u = w.ctag_u; sw.ctag_i = w.ctag_i;
-        sw.tb.lag_u = w.lag_u; sw.tb.lag_i = w.lag_i; sw.tb.ntag_u = w.ntag_u; sw.tb.ntag_i = w.ntag_i; sw.tb.err = w.tb_err;
-        sw.tb.period = tb_defer ? sweep_period : 1; sw.tb.flush = tb_defer ? 0 : 1; sw.tb.inc = 1;
-        mf_time_block_scalars(sw.tb, lr, beta1, beta2, eps, weight_decay, adam_step);
+        sw.tb = tb;
         sw.nt = mf_sweep_nt(sw.n0 + sw.n1);
     }
     if (B > 2048) mf_adam_kernel<8><<<(unsigned)chunks, MF_THREADS, 0, st>>>(sw);

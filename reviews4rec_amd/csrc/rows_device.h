@@ -24,13 +24,84 @@ int mf_bias_rows_launch(float *ub, float *ub_m, float *ub_v, float *ib, float *i
 // workspace = nothing pending).  A caller that announces nothing flushes (period 1 semantics for this step).
 constexpr int MF_TB_MAX = 8;           // pending updates a chunk may carry (period <= this)
 struct MfTimeBlock {
-    int *lag_u, *lag_i;                // [chunks of the table]
+    int *lag_u, *lag_i;                // [chunks of the table]                                   (announced form)
     const int *ntag_u, *ntag_i;        // [chunks]: == now where the announced next batch names a row (ignored when flushing)
-    int *err;                          // *err = 1 if a chunk this batch names was NOT current (a broken announcement)
+    int *err;                          // *err = 1: a chunk this batch names was NOT current (a broken announcement); 2: more than
+                                       // MF_TB_MAX updates pending somewhere (the caller left the schedule without a flush)
     int period, flush;
     int inc;                           // 1: this launch is step `now` itself; 0: flush only, `now` = the last completed step
     float lr_bc1[MF_TB_MAX], isb2[MF_TB_MAX];   // AdamScalars::lr_over_bc1 / inv_sqrt_bc2 of steps now - 7 .. now
+    // The SCHEDULED form (round 4; rlast_u != NULL selects it): nothing is announced and no per-chunk state is kept.
+    // Chunk c is visited at the steps s with (c % period + c / period + s) % period == 0 -- one chunk of every block of
+    // `period` consecutive chunks per step, on a diagonal, so a launch covers exactly the due chunks and their
+    // addresses are not a power-of-two stride apart -- which makes the step of a chunk's LAST visit a function of
+    // (c, now): tb_prev_visit.  An element is current through max(base, last visit of its chunk, rlast[its row]);
+    // whoever needs it newer applies the missing gradient-zero updates on the way: the forward kernels in registers
+    // (nothing written), the entry waves before their gradient update (they then set rlast[row] = now), the sweep at
+    // its visit.  `base`: a step through which EVERYTHING is current (the last flush or all-chunks step); the caller
+    // keeps (base, period) and changes the period only at an all-chunks launch (`flush` = 1), which uses the OLD period.
+    int *rlast_u = nullptr, *rlast_i = nullptr;   // [rows]: the last step an entry wave updated the row (0: never)
+    int base = 0;
 };
+
+// the last step <= t at which the schedule visits chunk c (may lie before `base`: the caller takes the max)
+__host__ __device__ inline int tb_prev_visit(int64_t c, int t, int period) {
+    const unsigned cu = (unsigned)c, pu = (unsigned)period;   // (chunk numbers fit 31 bits: the launch is one workgroup per chunk)
+    const unsigned ph = (cu % pu + cu / pu) % pu;
+    return t - (int)((ph + (unsigned)t) % pu);
+}
+// the one chunk of block q (chunks q * period ...) the schedule visits at step `now`
+__host__ __device__ inline int64_t tb_due_chunk(int64_t q, int now, int period) {
+    const unsigned pu = (unsigned)period;
+    return q * period + (int)((pu - ((unsigned)q + (unsigned)now) % pu) % pu);
+}
+// the gradient-zero updates of steps cur + 1 .. upto on one element (upto <= now, upto - cur <= MF_TB_MAX; per lane)
+__device__ __forceinline__ void tb_catch_up(float &P, float &M, float &V, int cur, int upto, int now, const AdamScalars &sc0,
+                                            const MfTimeBlock &tb) {
+#pragma unroll
+    for (int j = 0; j < MF_TB_MAX; ++j) {
+        const int s = now - (MF_TB_MAX - 1 - j);
+        if (s > cur && s <= upto) {
+            AdamScalars sc = sc0;
+            sc.lr_over_bc1 = tb.lr_bc1[j];
+            sc.inv_sqrt_bc2 = tb.isb2[j];
+            adam_elem_fast(P, 0.f, M, V, sc);
+        }
+    }
+}
+// the same on N float4 of (p, m, v), float4 u current through cur[u] (per lane): the step loop is the OUTER one, so
+// a step's scalars are fetched once for everything a lane holds (they are kernel arguments; a loop per element made
+// hipcc re-load them from the argument segment in front of every update)
+typedef float tb_f32x4 __attribute__((ext_vector_type(4)));
+template <int N>
+__device__ __forceinline__ void tb_catch_up_v(tb_f32x4 (&P)[N], tb_f32x4 (&M)[N], tb_f32x4 (&V)[N], const int (&cur)[N], int upto,
+                                              int now, const AdamScalars &sc0, const MfTimeBlock &tb) {
+#pragma unroll
+    for (int j = 0; j < MF_TB_MAX; ++j) {
+        const int s = now - (MF_TB_MAX - 1 - j);
+        if (s > upto) continue;                             // uniform
+        AdamScalars sc = sc0;
+        sc.lr_over_bc1 = tb.lr_bc1[j];
+        sc.inv_sqrt_bc2 = tb.isb2[j];
+#pragma unroll
+        for (int u = 0; u < N; ++u)
+            if (s > cur[u]) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    float pc = P[u][c], mc = M[u][c], vc = V[u][c];
+                    adam_elem_fast(pc, 0.f, mc, vc, sc);
+                    P[u][c] = pc; M[u][c] = mc; V[u][c] = vc;
+                }
+            }
+    }
+}
+// through which step is element e of a table (row r) current before step `now`'s own update?
+__device__ __forceinline__ int tb_current(const MfTimeBlock &tb, const int *rlast, int64_t e, int64_t r, int now) {
+    int cur = tb_prev_visit(e / MF_CHUNK, now - 1, tb.period);
+    if (cur < tb.base) cur = tb.base;
+    const int rl = rlast[r];
+    return cur < rl ? rl : cur;
+}
 void mf_time_block_scalars(MfTimeBlock &tb, float lr, double beta1, double beta2, float eps, float weight_decay, int64_t now);
 
 int mf_table_rows_launch(float *ut, float *ut_m, float *ut_v, float *it, float *it_m, float *it_v,

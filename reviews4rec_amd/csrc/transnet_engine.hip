@@ -50,14 +50,14 @@ struct TnHead {
     int off[TN_COUNT];
     int lo;                                         // first head parameter (column 0 of `part`)
     const float *emb[2];                            // user / item ID vectors [*, 5] (TransNet++) or NULL
+    const float *embm[2], *embv[2];                 // their Adam moments (scheduled sweep: pending updates are applied on the way)
+    MfTimeBlock tb; AdamScalars sc0;                // the schedule (rows_device.h; tb.rlast_u == NULL: nothing can be pending)
     const int64_t *id[2];                           // uid, iid [B]
     const float *y;
     float *pooled[3]; int *argmax[3]; float *g_pooled[3];   // [B, 100]
     float *part;                                    // [B, NHP]
     float *grow[2];                                 // [B, 5] compact gradient rows of the ID vectors
     int *tag[2], *ctag[2];                          // row tags; sweep-chunk tags (rows_device.h)
-    const int64_t *next_id[2]; int64_t next_B;      // the announced next batch's uid / iid (temporally blocked sweep), or NULL
-    int *ntag[2];                                   // ... and the chunk tags its rows get
     float *mult;                                    // [B, 5L + 10] dropout multipliers (see r4r.h)
     float *pred, *se;                               // source prediction and its SE
     float *aux;                                     // [B, 3]: target prediction, its SE, ||s_ir - t_ir||^2
@@ -130,7 +130,19 @@ __global__ __launch_bounds__(256) void tn_head_kernel(TnHead a) {
     float idv = 0.f;
     if (idt) {
         const int k = tid - 64, s = k >= TN_ID, c = k - s * TN_ID;
-        idv = a.emb[s][a.id[s][b] * TN_ID + c];
+        const int64_t r = a.id[s][b], e = r * TN_ID + c;
+        idv = a.emb[s][e];
+        if (a.tb.rlast_u) {                                 // the element's pending gradient-zero updates (not written back)
+            float mq = a.embm[s][e], vq = a.embv[s][e];
+            const int cur = tb_current(a.tb, s ? a.tb.rlast_i : a.tb.rlast_u, e, r, a.now);
+#pragma unroll
+            for (int j = 0; j < MF_TB_MAX - 1; ++j) {       // steps now - 7 .. now - 1
+                AdamScalars sc = a.sc0;
+                sc.lr_over_bc1 = a.tb.lr_bc1[j];
+                sc.inv_sqrt_bc2 = a.tb.isb2[j];
+                if (a.now - (MF_TB_MAX - 1 - j) > cur) adam_elem_fast(idv, 0.f, mq, vq, sc);
+            }
+        }
     }
     // pool finish: thread i < 3 NF owns (tower, filter) i; threads 0 .. 3 NF - 257 a second one
     for (int i = tid; i < 3 * NF; i += 256) {
@@ -279,12 +291,6 @@ __global__ __launch_bounds__(256) void tn_head_kernel(TnHead a) {
                 a.tag[s][r] = a.now;
                 a.ctag[s][r * TN_ID / MF_CHUNK] = a.now;              // (a row can straddle two chunks)
                 a.ctag[s][(r * TN_ID + TN_ID - 1) / MF_CHUNK] = a.now;
-                if (a.next_id[s])                           // the chunks the NEXT batch names are brought up to date by this step's sweep
-                    for (int64_t j = b; j < a.next_B; j += a.B) {
-                        const int64_t q = a.next_id[s][j];
-                        a.ntag[s][q * TN_ID / MF_CHUNK] = a.now;
-                        a.ntag[s][(q * TN_ID + TN_ID - 1) / MF_CHUNK] = a.now;
-                    }
             }
         }
     }
@@ -359,7 +365,7 @@ struct TnWs {
     int *flags[2][3], *slot[2][3], *list[2][3], *count[2][3]; float *ptab[3];
     float *pooled[3]; int *argmax[3]; float *g_pooled[3];
     float *part_w[3], *part_b[3];
-    int *tag[2], *ctag[2], *ntag[2], *lag[2], *tb_err;
+    int *tag[2], *ctag[2], *rlast[2], *tb_err;
     float *part, *grow[2], *mult, *aux;
     size_t bytes, persist;
 };
@@ -374,11 +380,8 @@ static TnWs tn_carve(void *ws, int64_t B, int T, int E, int L, int plus, int64_t
     w.tag[1] = reinterpret_cast<int *>(take((size_t)n_items * 4));
     w.ctag[0] = reinterpret_cast<int *>(take((size_t)cdiv(n_users * TN_ID, MF_CHUNK) * 4));
     w.ctag[1] = reinterpret_cast<int *>(take((size_t)cdiv(n_items * TN_ID, MF_CHUNK) * 4));
-    for (int t = 0; t < 2; ++t) {                           // the temporally blocked sweep's state (rows_device.h)
-        const size_t chunks = (size_t)cdiv((t ? n_items : n_users) * TN_ID, MF_CHUNK);
-        w.ntag[t] = reinterpret_cast<int *>(take(chunks * 4));
-        w.lag[t] = reinterpret_cast<int *>(take(chunks * 4));
-    }
+    w.rlast[0] = reinterpret_cast<int *>(take((size_t)n_users * 4));         // the scheduled sweep's state (rows_device.h)
+    w.rlast[1] = reinterpret_cast<int *>(take((size_t)n_items * 4));
     w.tb_err = reinterpret_cast<int *>(take(4));
     w.persist = o;
     for (int t = 0; t < 3; ++t)
@@ -460,12 +463,12 @@ extern "C" int r4r_transnet_step(const float *table, int64_t V,
                                  float dropout_p, int training, uint64_t seed, uint64_t offset, float inv_denom,
                                  int conv_algo, int token_buffer, int tokens_ready,
                                  const int64_t *next_user_idx, const int64_t *next_item_idx, const int64_t *next_this_idx,
-                                 const int64_t *next_uid, const int64_t *next_iid, int64_t next_B, int sweep_period,
+                                 int sweep_period, int64_t sweep_base, int sweep_all,
                                  float lr, double beta1, double beta2, float eps, float weight_decay, int64_t adam_step,
                                  void *stream) {
     R4R_REQUIRE(table && user_idx && item_idx && this_idx && flat_p && pred && ws, "transnet_step: null pointer");
     R4R_REQUIRE(sweep_period >= 1 && sweep_period <= MF_TB_MAX, "transnet_step: sweep_period %d outside 1..%d", sweep_period, MF_TB_MAX);
-    R4R_REQUIRE(!next_uid == !next_iid && (!next_uid || next_B > 0), "transnet_step: next_uid, next_iid and next_B > 0 go together");
+    R4R_REQUIRE(sweep_base >= 0 && (!flat_g || sweep_base < adam_step), "transnet_step: sweep_base outside 0..adam_step - 1");
     R4R_REQUIRE(!plus || (uid && iid && rows_p), "transnet_step: TransNet++ needs the ids and the ID-vector tables");
     R4R_REQUIRE(V > 0 && B >= 0 && T > 0 && n_users > 0 && n_items > 0, "transnet_step: bad sizes");
     R4R_REQUIRE(L > 0 && L <= NR_MAX_L, "transnet_step: latent_size %d outside 1..%d", L, NR_MAX_L);
@@ -540,7 +543,7 @@ extern "C" int r4r_transnet_step(const float *table, int64_t V,
         if (plus) {
             rp[t] = reinterpret_cast<float *>(rows_p[t]);
             R4R_REQUIRE(rp[t], "transnet_step: null ID-vector table");
-            if (train_step && apply) {
+            if (train_step && (apply || (rows_m && rows_v))) {   // (gradients only: the moments still serve the catch-up)
                 rm[t] = reinterpret_cast<float *>(rows_m[t]); rv[t] = reinterpret_cast<float *>(rows_v[t]);
                 R4R_REQUIRE(rm[t] && rv[t], "transnet_step: ID-vector table %d: null moment pointer", t);
             }
@@ -548,10 +551,21 @@ extern "C" int r4r_transnet_step(const float *table, int64_t V,
         h.emb[t] = rp[t]; h.tag[t] = w.tag[t]; h.ctag[t] = w.ctag[t]; h.grow[t] = w.grow[t];
     }
     h.id[0] = uid; h.id[1] = iid; h.flat_p = flat_p;
-    // the announced next batch (training steps that update in this call only: the sweep is what consumes the tags)
-    const bool announce = plus && train_step && apply && next_uid && sweep_period > 1;
-    h.next_id[0] = announce ? next_uid : nullptr; h.next_id[1] = announce ? next_iid : nullptr;
-    h.next_B = announce ? next_B : 0; h.ntag[0] = w.ntag[0]; h.ntag[1] = w.ntag[1];
+    // the scheduled sweep over the ID-vector tables (rows_device.h): the rows a rating reads catch up in registers
+    MfTimeBlock tb{};
+    h.tb = tb; h.sc0 = AdamScalars{};
+    const bool sched = plus && train_step && rm[0] && rm[1] &&
+                       ((reinterpret_cast<uintptr_t>(rp[0]) | reinterpret_cast<uintptr_t>(rp[1]) | reinterpret_cast<uintptr_t>(rm[0]) |
+                         reinterpret_cast<uintptr_t>(rm[1]) | reinterpret_cast<uintptr_t>(rv[0]) | reinterpret_cast<uintptr_t>(rv[1])) & 15) == 0;
+    if (sched) {
+        tb.rlast_u = w.rlast[0]; tb.rlast_i = w.rlast[1]; tb.err = w.tb_err; tb.base = (int)sweep_base;
+        tb.period = sweep_period; tb.flush = (sweep_all || sweep_period == 1) ? 1 : 0; tb.inc = 1;
+        mf_time_block_scalars(tb, lr, beta1, beta2, eps, weight_decay, adam_step);
+        if (sweep_period > 1) {
+            h.tb = tb; h.sc0 = adam_make_scalars(lr, beta1, beta2, eps, weight_decay, adam_step, nullptr);
+            for (int t = 0; t < 2; ++t) { h.embm[t] = rm[t]; h.embv[t] = rv[t]; }
+        }
+    }
     for (int i = 0; i < TN_COUNT; ++i) h.off[i] = (int)lay.off[i];
     h.lo = (int)lo;
     h.y = y; h.part = w.part; h.mult = w.mult; h.pred = pred; h.se = se; h.aux = w.aux;
@@ -606,14 +620,9 @@ extern "C" int r4r_transnet_step(const float *table, int64_t V,
     narre_reduce_kernel<<<dim3(red_blocks + comp_blocks + opt_blocks, 3), NRED_THREADS, 0, st>>>(
         wa, red_blocks, comp_blocks, nx, opt);
     if (!plus || !apply) return check_launch("transnet_step");
-    // the ID-vector tables: temporally blocked when the caller announced the next batch's ids, a flush of whatever
-    // earlier steps left pending otherwise (nothing pending: the plain sweep)
-    MfTimeBlock tb{};
-    tb.lag_u = w.lag[0]; tb.lag_i = w.lag[1]; tb.ntag_u = w.ntag[0]; tb.ntag_i = w.ntag[1]; tb.err = w.tb_err;
-    tb.period = announce ? sweep_period : 1; tb.flush = announce ? 0 : 1; tb.inc = 1;
-    mf_time_block_scalars(tb, lr, beta1, beta2, eps, weight_decay, adam_step);
+    // the ID-vector tables: the scheduled sweep (unaligned tables: the plain tagged sweep)
     return mf_table_rows_launch(rp[0], rm[0], rv[0], rp[1], rm[1], rv[1], n_users, n_items, TN_ID, uid, iid, w.grow[0], w.grow[1],
-                                w.tag[0], w.tag[1], w.ctag[0], w.ctag[1], B, (int)adam_step, opt.s, st, &tb);
+                                w.tag[0], w.tag[1], w.ctag[0], w.ctag[1], B, (int)adam_step, opt.s, st, sched ? &tb : nullptr);
 }
 
 // What the temporally blocked sweep left pending (r4r_transnet_step with next_uid and sweep_period > 1): every chunk
@@ -622,15 +631,18 @@ extern "C" int r4r_transnet_step(const float *table, int64_t V,
 extern "C" int r4r_transnet_rows_flush(const uint64_t *rows_p, const uint64_t *rows_m, const uint64_t *rows_v,
                                        int64_t n_users, int64_t n_items, void *ws, size_t ws_bytes,
                                        int64_t B, int T, int E, int L, int64_t V,
+                                       int sweep_period, int64_t sweep_base,
                                        float lr, double beta1, double beta2, float eps, float weight_decay, int64_t adam_step,
                                        void *stream) {
     R4R_REQUIRE(rows_p && rows_m && rows_v && ws, "transnet_rows_flush: null pointer");
     R4R_REQUIRE(adam_step >= 0 && adam_step < (1ll << 31), "transnet_rows_flush: bad adam_step");
+    R4R_REQUIRE(sweep_period >= 1 && sweep_period <= MF_TB_MAX && sweep_base >= 0 && sweep_base <= adam_step,
+                "transnet_rows_flush: sweep_period outside 1..%d or sweep_base outside 0..adam_step", MF_TB_MAX);
     if (ws_bytes < r4r_transnet_ws_bytes(B, T, E, L, 1, V, n_users, n_items)) {
         set_error("transnet_rows_flush: workspace %zu < %zu bytes", ws_bytes, r4r_transnet_ws_bytes(B, T, E, L, 1, V, n_users, n_items));
         return R4R_ERR_WORKSPACE;
     }
-    if (adam_step == 0) return R4R_OK;                      // no step yet: nothing can be pending
+    if (adam_step == 0 || sweep_base == adam_step) return R4R_OK;   // no step yet / nothing can be pending
     const TnWs w = tn_carve(ws, B, T, E, L, 1, V, n_users, n_items);
     float *rp[2], *rm[2], *rv[2];
     for (int t = 0; t < 2; ++t) {
@@ -638,9 +650,10 @@ extern "C" int r4r_transnet_rows_flush(const uint64_t *rows_p, const uint64_t *r
         rv[t] = reinterpret_cast<float *>(rows_v[t]);
         R4R_REQUIRE(rp[t] && rm[t] && rv[t], "transnet_rows_flush: ID-vector table %d: null pointer", t);
     }
+    if ((rows_p[0] | rows_p[1] | rows_m[0] | rows_m[1] | rows_v[0] | rows_v[1]) & 15) return R4R_OK;   // (unaligned tables never defer)
     MfTimeBlock tb{};
-    tb.lag_u = w.lag[0]; tb.lag_i = w.lag[1]; tb.ntag_u = w.ntag[0]; tb.ntag_i = w.ntag[1]; tb.err = w.tb_err;
-    tb.period = 1; tb.flush = 1; tb.inc = 0;
+    tb.rlast_u = w.rlast[0]; tb.rlast_i = w.rlast[1]; tb.err = w.tb_err; tb.base = (int)sweep_base;
+    tb.period = sweep_period; tb.flush = 1; tb.inc = 0;
     mf_time_block_scalars(tb, lr, beta1, beta2, eps, weight_decay, adam_step);
     const AdamScalars sc = adam_make_scalars(lr, beta1, beta2, eps, weight_decay, adam_step, nullptr);
     return mf_table_rows_launch(rp[0], rm[0], rv[0], rp[1], rm[1], rv[1], n_users, n_items, TN_ID, nullptr, nullptr, nullptr, nullptr,
@@ -652,15 +665,9 @@ extern "C" int r4r_transnet_rows_flush(const uint64_t *rows_p, const uint64_t *r
 // (flat_m == NULL).  `ws` and the shape arguments are the step's: the row / chunk tags live there.
 namespace r4r {
 __global__ void tn_tag_rows_kernel(const int64_t *uid, const int64_t *iid, int64_t n, int *tag_u, int *tag_i, int *ctag_u,
-                                   int *ctag_i, int now, const int64_t *next_uid, const int64_t *next_iid, int *ntag_u,
-                                   int *ntag_i) {
+                                   int *ctag_i, int now) {
     const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= n) return;
-    if (next_uid && next_uid[e] >= 0) {                     // what some rank announced for its next shard (temporally blocked sweep)
-        const int64_t nu = next_uid[e], ni = next_iid[e];
-        ntag_u[nu * TN_ID / MF_CHUNK] = now; ntag_u[(nu * TN_ID + TN_ID - 1) / MF_CHUNK] = now;
-        ntag_i[ni * TN_ID / MF_CHUNK] = now; ntag_i[(ni * TN_ID + TN_ID - 1) / MF_CHUNK] = now;
-    }
     const int64_t u = uid[e], i = iid[e];
     if (u < 0) return;
     tag_u[u] = now; tag_i[i] = now;
@@ -670,8 +677,7 @@ __global__ void tn_tag_rows_kernel(const int64_t *uid, const int64_t *iid, int64
 }  // namespace r4r
 
 extern "C" int r4r_transnet_rows_apply(const int64_t *uid_all, const int64_t *iid_all, const float *gu_all,
-                                       const float *gi_all, const int64_t *next_uid_all, const int64_t *next_iid_all,
-                                       int sweep_period, int announce, int64_t B_all,
+                                       const float *gi_all, int sweep_period, int64_t sweep_base, int sweep_all, int64_t B_all,
                                        const uint64_t *rows_p, const uint64_t *rows_m, const uint64_t *rows_v,
                                        int64_t n_users, int64_t n_items, void *ws, size_t ws_bytes,
                                        int64_t B, int T, int E, int L, int64_t V,
@@ -679,9 +685,9 @@ extern "C" int r4r_transnet_rows_apply(const int64_t *uid_all, const int64_t *ii
                                        void *stream) {
     R4R_REQUIRE(uid_all && iid_all && gu_all && gi_all && rows_p && rows_m && rows_v && ws, "transnet_rows_apply: null pointer");
     R4R_REQUIRE(B_all >= 0 && B_all <= 32768, "transnet_rows_apply: %lld gathered ratings outside 0..32768", (long long)B_all);
-    R4R_REQUIRE(sweep_period >= 1 && sweep_period <= MF_TB_MAX && !next_uid_all == !next_iid_all,
-                "transnet_rows_apply: sweep_period outside 1..%d, or only one of the next-id arrays", MF_TB_MAX);
-    R4R_REQUIRE(adam_step >= 1 && adam_step < (1ll << 31), "transnet_rows_apply: bad adam_step");
+    R4R_REQUIRE(sweep_period >= 1 && sweep_period <= MF_TB_MAX, "transnet_rows_apply: sweep_period outside 1..%d", MF_TB_MAX);
+    R4R_REQUIRE(adam_step >= 1 && adam_step < (1ll << 31) && sweep_base >= 0 && sweep_base < adam_step,
+                "transnet_rows_apply: bad adam_step, or sweep_base outside 0..adam_step - 1");
     if (ws_bytes < r4r_transnet_ws_bytes(B, T, E, L, 1, V, n_users, n_items)) {
         set_error("transnet_rows_apply: workspace %zu < %zu bytes", ws_bytes, r4r_transnet_ws_bytes(B, T, E, L, 1, V, n_users, n_items));
         return R4R_ERR_WORKSPACE;
@@ -695,16 +701,16 @@ extern "C" int r4r_transnet_rows_apply(const int64_t *uid_all, const int64_t *ii
         rv[t] = reinterpret_cast<float *>(rows_v[t]);
         R4R_REQUIRE(rp[t] && rm[t] && rv[t], "transnet_rows_apply: ID-vector table %d: null pointer", t);
     }
-    // the gathered entries' sweep, temporally blocked over what ALL ranks announced (the same period / announce on every rank)
-    const bool defer = announce && next_uid_all && sweep_period > 1;
+    // the gathered entries' sweep on the schedule (the same period / base / all on every rank)
     tn_tag_rows_kernel<<<(unsigned)cdiv(B_all, 256), 256, 0, st>>>(uid_all, iid_all, B_all, w.tag[0], w.tag[1], w.ctag[0],
-                                                                 w.ctag[1], (int)adam_step, defer ? next_uid_all : nullptr,
-                                                                 defer ? next_iid_all : nullptr, w.ntag[0], w.ntag[1]);
+                                                                 w.ctag[1], (int)adam_step);
     const AdamScalars sc = adam_make_scalars(lr, beta1, beta2, eps, weight_decay, adam_step, nullptr);
+    const bool aligned = ((rows_p[0] | rows_p[1] | rows_m[0] | rows_m[1] | rows_v[0] | rows_v[1]) & 15) == 0;
     MfTimeBlock tb{};
-    tb.lag_u = w.lag[0]; tb.lag_i = w.lag[1]; tb.ntag_u = w.ntag[0]; tb.ntag_i = w.ntag[1]; tb.err = w.tb_err;
-    tb.period = defer ? sweep_period : 1; tb.flush = defer ? 0 : 1; tb.inc = 1;
+    tb.rlast_u = w.rlast[0]; tb.rlast_i = w.rlast[1]; tb.err = w.tb_err; tb.base = (int)sweep_base;
+    tb.period = sweep_period; tb.flush = (sweep_all || sweep_period == 1) ? 1 : 0; tb.inc = 1;
     mf_time_block_scalars(tb, lr, beta1, beta2, eps, weight_decay, adam_step);
     return mf_table_rows_launch(rp[0], rm[0], rv[0], rp[1], rm[1], rv[1], n_users, n_items, TN_ID, uid_all, iid_all, gu_all,
-                                gi_all, w.tag[0], w.tag[1], w.ctag[0], w.ctag[1], B_all, (int)adam_step, sc, st, &tb);
+                                gi_all, w.tag[0], w.tag[1], w.ctag[0], w.ctag[1], B_all, (int)adam_step, sc, st,
+                                aligned ? &tb : nullptr);
 }

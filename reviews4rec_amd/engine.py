@@ -74,13 +74,29 @@ def padded_word_table(table):
     return out
 
 
-def promise_key(uid, iid, n):
-    """Identity of an announced batch for the temporally blocked sweeps: where its id tensors live AND their autograd
-    version counters -- a loader that refills the same device buffers in place (copy_, index assignment: every torch
-    write bumps ``_version``) is a different batch, not the promised one, and the engine flushes first.  (Writes
-    behind torch's back -- a raw pointer handed to another library -- are still caught by the device-side flag only:
-    check_announcements(), read at every epoch end.)"""
-    return (uid.data_ptr(), iid.data_ptr(), int(n), uid._version, iid._version)
+class _SweepSchedule:
+    """Host side of the temporally blocked ID-table sweeps (include/r4r.h, r4r_mf_step): every table element is
+    current through step `_tb_base`, and since then every training step has visited the chunks on the
+    period-`_tb_period` schedule (1: every chunk, every step).  A step that leaves the schedule in force -- another
+    period, or no deferral -- visits every chunk under the OLD one and starts the new one."""
+    _tb_base, _tb_period, _tb_used = 0, 1, False
+
+    def _schedule(self, defer):
+        """(period, base, all_chunks, period afterwards) of the next training step."""
+        want = self.sweep_period if (defer and self.has_tables) else 1
+        period = self._tb_period
+        return period, self._tb_base, int(want != period or period == 1), want
+
+    def _scheduled(self, sweep_all, want, step):
+        if sweep_all:
+            self._tb_base, self._tb_period = int(step), want
+        if want > 1:
+            self._tb_used = True
+
+    def _pending(self, last_step=None):
+        """the last completed step, if the tables may be behind it (else None)"""
+        step = int(self.step_count if last_step is None else last_step)
+        return step if (self.has_tables and self._ws is not None and self._tb_base < step) else None
 
 
 def flush_before_state_dict(engine, model):
@@ -547,7 +563,7 @@ class DeepCoNNEngine(_ConvRule):
                  zip(names, self.slots, self.offsets, self.sizes)})
 
 
-class MFEngine:
+class MFEngine(_SweepSchedule):
     """Native step for model_type 'MF_dot' / 'bias_only' (csrc/mf_engine.hip, r4r_mf_step): forward,
     loss, backward and the dense Adam update of MF.py / main.py:56-60,94-96 in two launches; the
     dense gradient of an ID table is never materialised.  Same calling surface as DeepCoNNEngine
@@ -582,7 +598,9 @@ class MFEngine:
         self._ws, self._ws_B, self._out = None, None, {}
         # visit period of the temporally blocked table sweep (include/r4r.h; 1 = the plain dense sweep)
         self.sweep_period = max(1, min(8, int(os.environ.get('R4R_SWEEP_PERIOD', hp.get('sweep_period', 8)))))
-        self._tb_promised, self._tb_next = None, None
+        # the schedule in force: every table element is current through step _tb_base, chunks have been visited on the
+        # period-_tb_period schedule since (1: every step)
+        self._tb_base, self._tb_period = 0, 1
         self._sd_hooks = flush_before_state_dict(self, model)
 
     TEMPORAL_SWEEP = True        # train_step(..., defer_sweep=True) + flush(): the table sweep, temporally blocked
@@ -592,25 +610,26 @@ class MFEngine:
 
     def flush(self, check=True, last_step=None):
         """Apply every pending table update of the temporally blocked sweep (no-op when nothing is pending).
-        last_step: the last COMPLETED step (default: step_count; a training step that finds a broken announcement
-        has already counted itself)."""
-        if self._tb_promised is None:
+        last_step: the last COMPLETED step (default: step_count)."""
+        step = self._pending(last_step)
+        if step is None:
             return
-        self._tb_promised = None
         _lib.check(_lib.lib().r4r_mf_rows_flush(
             self._ptrs(self.params), self._ptrs(self.m), self._ptrs(self.v), self.n_users, self.n_items, self.D,
-            ptr(self._ws), self._ws.numel(), self._ws_B, self.lr, self.betas[0], self.betas[1], self.eps, self.wd,
-            int(self.step_count if last_step is None else last_step), _lib.current_stream()), 'r4r_mf_rows_flush')
+            ptr(self._ws), self._ws.numel(), self._ws_B, self._tb_period, self._tb_base,
+            self.lr, self.betas[0], self.betas[1], self.eps, self.wd, step, _lib.current_stream()), 'r4r_mf_rows_flush')
+        self._tb_base = step
         if check:
             self.check_announcements()
 
     def check_announcements(self):
-        """Raise if a step trained on a batch other than the announced one while updates were pending."""
+        """Raise if the scheduled sweep ever found more than 8 updates pending (a step outside the schedule
+        without a flush: cannot happen through this class)."""
         if self._ws is None or not self.has_tables:
             return
         off = _lib.lib().r4r_mf_ws_flag_offset(self._ws_B, self.D, self.n_users, self.n_items)
         if int(self._ws[off:off + 4].view(torch.int32).item()):
-            raise RuntimeError('MFEngine: a deferred table sweep met a batch that was not the announced one')
+            raise RuntimeError('MFEngine: the temporally blocked table sweep found more pending updates than it can apply')
 
     def _workspace(self, B):
         """One workspace per batch size (the ragged last batch alternates with the full ones); the
@@ -627,19 +646,15 @@ class MFEngine:
             self._ws, self._ws_B = nxt, B
         return self._ws
 
-    def _launch(self, data, y, train_mode, inv_denom, adam_step, next_data=None):
+    def _launch(self, data, y, train_mode, inv_denom, adam_step, defer=False):
         uid, iid = data[5].reshape(-1), data[6].reshape(-1)
         if not (uid.is_cuda and uid.dtype == torch.int64):
             raise RuntimeError('MFEngine: batches must be int64 tensors on the ROCm device')
         uid, iid = uid.contiguous(), iid.contiguous()
         n = uid.numel()
-        if self._tb_promised is not None and (not adam_step or promise_key(uid, iid, n) != self._tb_promised[0]):
-            self.flush(last_step=adam_step - 1 if adam_step else None)   # not the announced training step: the tables catch up first
-        self._tb_promised, tbn = None, None
-        if next_data is not None and adam_step and self.has_tables and self.sweep_period > 1 and next_data[5].numel() > 0:
-            nu, ni = next_data[5].reshape(-1).contiguous(), next_data[6].reshape(-1).contiguous()
-            if nu.is_cuda and ni.is_cuda and nu.dtype == torch.int64 and ni.dtype == torch.int64 and nu.numel() == ni.numel():
-                tbn = (nu, ni, nu.numel())                   # (anything else: nothing is announced, this step flushes)
+        if not adam_step:
+            self.flush()                                     # a forward reads the tables: they catch up first
+        period, base, sweep_all, want = self._schedule(defer) if adam_step else (1, 0, 1, 1)
         if n not in self._out:
             self._out[n] = (torch.empty(n, dtype=torch.float32, device=self.dev),
                             torch.empty(n, dtype=torch.float32, device=self.dev))
@@ -650,36 +665,25 @@ class MFEngine:
             self._ptrs(self.m) if adam_step else None, self._ptrs(self.v) if adam_step else None,
             self.n_users, self.n_items, self.D, ptr(pred), ptr(se), ptr(self.sse) if adam_step else None,
             ptr(ws), ws.numel(), n, float(self.hp['dropout']), int(train_mode), self.seed, self.offset,
-            float(inv_denom), ptr(tbn[0]) if tbn else None, ptr(tbn[1]) if tbn else None, tbn[2] if tbn else 0,
-            self.sweep_period, self.lr, self.betas[0], self.betas[1], self.eps, self.wd, int(adam_step),
+            float(inv_denom), period, base, sweep_all,
+            self.lr, self.betas[0], self.betas[1], self.eps, self.wd, int(adam_step),
             _lib.current_stream())
         _lib.check(rc, 'r4r_mf_step')
-        if tbn is not None:                                  # (the id tensors stay referenced until the promise is kept)
-            self._tb_promised = (promise_key(tbn[0], tbn[1], tbn[2]), tbn)
-            self._tb_used = True
+        if adam_step:
+            self._scheduled(sweep_all, want, int(adam_step))
         if train_mode and float(self.hp['dropout']) > 0.0:
             self.offset += n * 2 * self.D
         return pred, se
 
     @torch.no_grad()
-    def _train_step_dp(self, data, y, n_global, next_data=None):
+    def _train_step_dp(self, data, y, n_global, defer=False):
         """Data parallel: this rank's compact gradient rows into a packed block, ONE
         all_gather of the blocks, then the same tagged sweep over all ranks' entries in rank order
-        on every rank (r4r_mf_grad / r4r_mf_apply): replicas stay bit-identical.  next_data (this rank's NEXT
-        shard; every rank passes one or none does): its ids ride in the block, and the sweep is temporally blocked
-        over what ALL ranks announced."""
+        on every rank (r4r_mf_grad / r4r_mf_apply): replicas stay bit-identical.  defer (the same on every rank): the
+        sweep runs on the schedule (include/r4r.h, r4r_mf_step)."""
         lib, dist = _lib.lib(), torch.distributed
         uid, iid = data[5].reshape(-1).contiguous(), data[6].reshape(-1).contiguous()
         n, world = uid.numel(), self.dp.world
-        if self._tb_promised is not None and promise_key(uid, iid, n) != self._tb_promised[0]:
-            self.flush(last_step=self.step_count - 1)        # (every rank takes the same branch: the loops run in lockstep)
-        self._tb_promised, tbn = None, None
-        # (only with the global count known: every shard, the next one included, then fits hyper_params['batch_size'],
-        # and every rank decides the same way)
-        announce = next_data is not None and self.has_tables and self.sweep_period > 1 and n_global is not None
-        if announce:
-            nu, ni = next_data[5].reshape(-1).contiguous(), next_data[6].reshape(-1).contiguous()
-            tbn = (nu, ni, nu.numel())                       # (an empty next shard announces nothing of its own)
         B_pad = int(self.hp.get('batch_size', 0))            # every rank's shard fits the configured batch: pad to it
         if n_global is not None and n > B_pad:
             # (taking the size-agreement branch on THIS rank only would leave the others in a different
@@ -700,21 +704,25 @@ class MFEngine:
                               torch.zeros(nb, dtype=torch.uint8, device=self.dev),
                               torch.zeros(world * nb, dtype=torch.uint8, device=self.dev))
         pred, se, block, blocks = self._out[key]
-        _lib.check(lib.r4r_mf_grad(ptr(uid), ptr(iid), ptr(y), self._ptrs(self.params), self.n_users, self.n_items, self.D,
+        step = int(self.step_count)
+        period, base, sweep_all, want = self._schedule(defer)
+        ws = self._workspace(world * B_pad)
+        pending = self.has_tables and period > 1             # (rows may carry pending updates: the forward catches them up)
+        _lib.check(lib.r4r_mf_grad(ptr(uid), ptr(iid), ptr(y), self._ptrs(self.params),
+                                   self._ptrs(self.m) if pending else None, self._ptrs(self.v) if pending else None,
+                                   self.n_users, self.n_items, self.D,
                                    ptr(pred), ptr(se), ptr(block), None, n, B_pad, float(self.hp['dropout']),
                                    int(self.model.training), self.seed, self.offset, 1.0 / float(n_global),
-                                   ptr(tbn[0]) if (tbn and tbn[2]) else None, ptr(tbn[1]) if (tbn and tbn[2]) else None,
-                                   tbn[2] if tbn else 0, _lib.current_stream()), 'r4r_mf_grad')
+                                   ptr(ws) if pending else None, period, base,
+                                   self.lr, self.betas[0], self.betas[1], self.eps, self.wd, step,
+                                   _lib.current_stream()), 'r4r_mf_grad')
         self.dp.all_gather(blocks, block)
-        ws = self._workspace(world * B_pad)
         _lib.check(lib.r4r_mf_apply(ptr(blocks), world, B_pad, self._ptrs(self.params), self._ptrs(self.m),
                                     self._ptrs(self.v), self.n_users, self.n_items, self.D, ptr(ws), ws.numel(),
-                                    self.sweep_period, int(announce),
-                                    self.lr, self.betas[0], self.betas[1], self.eps, self.wd, int(self.step_count),
+                                    period, base, sweep_all,
+                                    self.lr, self.betas[0], self.betas[1], self.eps, self.wd, step,
                                     _lib.current_stream()), 'r4r_mf_apply')
-        if tbn is not None:
-            self._tb_promised = (promise_key(tbn[0], tbn[1], tbn[2]), tbn)
-            self._tb_used = True
+        self._scheduled(sweep_all, want, step)
         if self.model.training and float(self.hp['dropout']) > 0.0:
             self.offset += n * 2 * self.D
         # this rank's share of the running metric (the host loop sums the ranks): one deterministic launch
@@ -724,20 +732,20 @@ class MFEngine:
     @torch.no_grad()
     def train_step(self, data, y, n_global=None, next_data=None, defer_sweep=False):
         """One optimisation step.  Returns the per-example SE tensor (device); the running sum is
-        in ``self.sse``.  defer_sweep (single process, with `next_data`): the Adam sweep over the two ID tables is
-        temporally blocked -- chunks neither batch names are visited every `sweep_period`-th step and take their
-        pending updates together: same bits, a fraction of the traffic.  The caller promises that the next call
-        trains on `next_data`; any other call (and `flush()`, `state_dict()`, `predict()`) brings the tables up to
-        date first; code that reads the embedding Parameters directly calls `flush()` before."""
+        in ``self.sse``.  defer_sweep: the Adam sweep over the two ID tables is temporally blocked -- a chunk no
+        rating names is visited every `sweep_period`-th step and takes its pending updates together, rows a rating
+        names catch up on the way: same bits, a fraction of the traffic.  `flush()`, `state_dict()`, `predict()` and a
+        step without defer_sweep bring the tables up to date; code that reads the embedding Parameters directly calls
+        `flush()` before.  (next_data: accepted for the engines' common calling surface; nothing is announced.)"""
         n = data[5].numel()
         y = y.reshape(-1).contiguous()
         if n == 0 and self.dp is None:                       # nothing to train on: no step, no state change
             return torch.empty(0, dtype=torch.float32, device=self.dev)
         self.step_count += 1
         if self.dp is not None:
-            return self._train_step_dp(data, y, n_global, next_data if defer_sweep else None)
+            return self._train_step_dp(data, y, n_global, defer_sweep)
         _, se = self._launch(data, y, self.model.training, 1.0 / float(n_global if n_global is not None else n),
-                             self.step_count, next_data if defer_sweep else None)
+                             self.step_count, defer_sweep)
         return se
 
     @torch.no_grad()
@@ -789,7 +797,7 @@ class MFEngine:
                 'betas': self.betas, 'eps': self.eps}
 
     def load_state_dict(self, sd):
-        self._tb_promised = None                             # (the workspaces are zeroed below: nothing pending any more)
+        self._tb_base = self.step_count                      # (what is pending is discarded with the state it belongs to)
         m, v = self.moments()
         for k in m:
             m[k].copy_(sd['exp_avg'][k].to(self.dev))
@@ -797,6 +805,7 @@ class MFEngine:
         self.step_count, self.offset = int(sd['step']), int(sd['dropout_offset'])
         self.lr, self.wd = float(sd['lr']), float(sd['weight_decay'])
         self.betas, self.eps = tuple(sd['betas']), float(sd['eps'])
+        self._tb_base, self._tb_period = self.step_count, 1  # the loaded tables are current through the loaded step
         # row tags written by earlier steps of THIS process must not collide with resumed step numbers
         for ws in self.__dict__.get('_ws_cache', {}).values():
             ws.zero_()
@@ -1023,9 +1032,6 @@ class NarreEngine(_ConvRule):
             vals[:n, base:base + L] = grow[:n]
             vals[:n, base + L:base + (1 + R) * L] = grow[n:].reshape(n, R * L)
 
-    def _dp_payload_next(self, ids):
-        """Families whose data-parallel sweep is temporally blocked put the ids of the rank's NEXT shard here."""
-
     def _dp_apply(self, all_ids, all_vals, B_all, ws, nb, R, T):
         L = self.L
         gids, grows = [], []
@@ -1095,7 +1101,6 @@ class NarreEngine(_ConvRule):
         if n > 0:
             f, _, R, T = self._fields(data)
             self._dp_payload(f, n, R, T, ids, vals)
-        self._dp_payload_next(ids)                           # (also from a rank whose CURRENT shard is empty)
         if solo:
             all_ids, all_vals = ids, vals
         else:
@@ -1275,7 +1280,7 @@ class DeepCoNNPPEngine(NarreEngine):
         return out
 
 
-class TransNetEngine(NarreEngine):
+class TransNetEngine(NarreEngine, _SweepSchedule):
     """Native step for TransNet / TransNet++ (csrc/transnet_engine.hip, r4r_transnet_step): three
     TextCNN towers, the source MLP, both factorisation machines, the three losses of main.py:35-53
     and their three disjoint parameter groups in ONE backward and one flat Adam (the three
@@ -1305,7 +1310,7 @@ class TransNetEngine(NarreEngine):
         self.plus = int(model.hyper_params['model_type'] == 'transnet++')
         # visit period of the temporally blocked ID-vector sweep (include/r4r.h; 1 = the plain dense sweep)
         self.sweep_period = max(1, min(8, int(os.environ.get('R4R_SWEEP_PERIOD', model.hyper_params.get('sweep_period', 8)))))
-        self._tb_promised, self._tb_next, self._defer_req = None, None, False
+        self._tb_base, self._tb_period, self._defer_req, self._tb_now = 0, 1, False, (1, 0, 1, 1)
         if not self.plus:
             self.DP_COLS = 0                                 # plain TransNet: no ID rows to exchange
         self.ROW_NAMES = ['user_embedding.weight', 'item_embedding.weight'] if self.plus else []
@@ -1344,90 +1349,80 @@ class TransNetEngine(NarreEngine):
     def _draws(self, R):
         return 5 * self.L + 10
 
-    # ---- the temporally blocked sweep (TransNet++, single process).  A step that was told `defer_sweep=True` and the
-    # next batch leaves gradient-zero updates of untouched table chunks pending; whatever is not the announced next
-    # training step flushes them first, so that nothing ever reads a table that is behind.
-    def _tb_key(self, f, n):
-        return promise_key(f[3], f[4], n)
+    # ---- the temporally blocked sweep (TransNet++): a step that was told `defer_sweep=True` visits the table chunks on
+    # the schedule; rows a rating names catch up inside the step, everything else that reads the tables flushes first.
+    @property
+    def has_tables(self):
+        return bool(self.plus)
 
     def _launch(self, data, y, train_mode, inv_denom, adam_step, next_data=None):
-        if self._tb_promised is not None:
-            f, n, _, _ = self._fields(data)
-            if not adam_step or self._tb_key(f, n) != self._tb_promised[0]:
-                self.flush(last_step=adam_step - 1 if adam_step else None)
-        self._tb_next = None
-        if (self._defer_req and adam_step and self.plus and self.dp is None and next_data is not None
-                and self.sweep_period > 1 and next_data[5].numel() > 0):
-            nf, nn, _, _ = self._fields(next_data)
-            self._tb_next = (nf[3], nf[4], nn)
-        self._tb_promised = None
-        out = super()._launch(data, y, train_mode, inv_denom, adam_step, next_data)
-        if self._tb_next is not None:                        # (the id tensors stay referenced until the promise is kept)
-            self._tb_promised = (self._tb_key([None] * 3 + list(self._tb_next[:2]), self._tb_next[2]), self._tb_next)
-            self._tb_used = True
-        return out
+        if not adam_step:
+            self.flush()                                     # a forward reads the tables: they catch up first
+        return super()._launch(data, y, train_mode, inv_denom, adam_step, next_data)
 
     @torch.no_grad()
     def train_step(self, data, y, n_global=None, next_data=None, defer_sweep=False):
-        """defer_sweep: with `next_data`, TransNet++'s ID-vector sweep is temporally blocked (chunks neither batch
-        names are visited every `sweep_period`-th step and take their pending updates together: same bits, a
-        fraction of the traffic).  The caller promises that the next call trains on `next_data`; any other call
-        (and `flush()`, `state_dict()`, `predict()`) brings the tables up to date first.  Code that reads the
-        embedding Parameters directly calls `flush()` before."""
-        self._defer_req = bool(defer_sweep)
-        try:
-            return super().train_step(data, y, n_global, next_data)
-        finally:
-            self._defer_req = False
+        """defer_sweep: TransNet++'s ID-vector sweep is temporally blocked (a chunk no rating names is visited every
+        `sweep_period`-th step and takes its pending updates together; rows a rating names catch up on the way: same
+        bits, a fraction of the traffic).  `flush()`, `state_dict()`, `predict()` and a step without defer_sweep bring
+        the tables up to date; code that reads the embedding Parameters directly calls `flush()` before."""
+        self._tb_now = self._schedule(bool(defer_sweep))
+        before = self.step_count
+        se = super().train_step(data, y, n_global, next_data)
+        if self.step_count > before:
+            self._scheduled(self._tb_now[2], self._tb_now[3], self.step_count)
+        return se
 
     def flush(self, check=True, last_step=None):
         """Apply every pending ID-vector update (no-op when nothing is pending).  last_step: the last COMPLETED step
-        (default: step_count; a training step that finds a broken announcement has already counted itself)."""
-        if self._tb_promised is None:
+        (default: step_count)."""
+        step = self._pending(last_step)
+        if step is None:
             return
-        self._tb_promised = None
         B, R, T = self._ws_key
         p2 = lambda ts: (ctypes.c_uint64 * 2)(*[t.data_ptr() for t in ts])   # noqa: E731
         _lib.check(_lib.lib().r4r_transnet_rows_flush(
             p2(self.rows), p2(self.rows_m), p2(self.rows_v), self.n_users, self.n_items, ptr(self._ws), self._ws.numel(),
-            B, T, self.E, self.L, self.V, self.lr, self.betas[0], self.betas[1], self.eps, self.wd,
-            int(self.step_count if last_step is None else last_step), _lib.current_stream()), 'r4r_transnet_rows_flush')
+            B, T, self.E, self.L, self.V, self._tb_period, self._tb_base,
+            self.lr, self.betas[0], self.betas[1], self.eps, self.wd, step, _lib.current_stream()), 'r4r_transnet_rows_flush')
+        self._tb_base = step
         if check:
             self.check_announcements()
 
     def check_announcements(self):
-        """Raise if a step trained on a batch other than the announced one while updates were pending (its rows
-        were read before they were brought up to date).  Reads one int from the device."""
+        """Raise if the scheduled sweep ever found more than 8 updates pending (a step outside the schedule without a
+        flush: cannot happen through this class).  Reads one int from the device."""
         if not self.plus or self._ws is None:
             return
         B, R, T = self._ws_key
         off = self._ws_offset(B, R, T, 5)
         if int(self._ws[off:off + 4].view(torch.int32).item()):
-            raise RuntimeError('TransNetEngine: a deferred ID-vector sweep met a batch that was not the announced one')
+            raise RuntimeError('TransNetEngine: the temporally blocked ID-vector sweep found more pending updates than it can apply')
 
     def moments(self):
         self.flush()
         return super().moments()
 
     def load_state_dict(self, sd):
-        self._tb_promised = None                             # (the workspaces are zeroed: nothing pending any more)
+        self._tb_base = self.step_count                      # (what is pending is discarded with the state it belongs to)
         super().load_state_dict(sd)
+        self._tb_base, self._tb_period = self.step_count, 1  # the loaded tables are current through the loaded step
 
     def _step(self, f, y, pred, se, ws, n, R, T, train_mode, inv_denom, adam_step, buf, ready, nxt):
         p2 = lambda ts: (ctypes.c_uint64 * 2)(*[t.data_ptr() for t in ts]) if ts else None   # noqa: E731
-        tbn = self._tb_next
+        period, base, sweep_all, _ = self._tb_now if adam_step else (1, 0, 1, 1)
         return _lib.lib().r4r_transnet_step(
             ptr(self.table), self.V, ptr(f[0]), ptr(f[1]), ptr(f[2]), ptr(f[3]), ptr(f[4]), ptr(y),
             ptr(self.flat_p), ptr(self.flat_g) if adam_step else None,
             ptr(self.flat_m) if (adam_step and self.dp is None) else None,     # data parallel: gradients only
             ptr(self.flat_v) if (adam_step and self.dp is None) else None, p2(self.rows),
-            p2(self.rows_m) if (adam_step and self.dp is None) else None,
-            p2(self.rows_v) if (adam_step and self.dp is None) else None,
+            p2(self.rows_m) if adam_step else None,          # (data parallel: still read, for the catch-up of named rows)
+            p2(self.rows_v) if adam_step else None,
             self.n_users, self.n_items, ptr(pred), ptr(se), ptr(self.sse) if adam_step else None,
             ptr(ws), ws.numel(), n, T, self.E, self.L, self.plus, float(self.hp['dropout']), int(train_mode), self.seed,
             self.offset, float(inv_denom), self._algo_req, buf, ready,
             ptr(nxt[0]) if nxt else None, ptr(nxt[1]) if nxt else None, ptr(nxt[2]) if nxt else None,
-            ptr(tbn[0]) if tbn else None, ptr(tbn[1]) if tbn else None, tbn[2] if tbn else 0, self.sweep_period,
+            period, base, sweep_all,
             self.lr, self.betas[0], self.betas[1], self.eps, self.wd, int(adam_step), _lib.current_stream())
 
     DP_COLS = 10
@@ -1443,44 +1438,16 @@ class TransNetEngine(NarreEngine):
         return 1, int(data[3].shape[-1])
 
     def _dp_cols(self, R):
-        return 4, 10                                         # ids: uid, iid, and the rank's announced NEXT uid, iid (-1: none)
-
-    def _dp_payload_next(self, ids):
-        nxt = self.__dict__.get('_dp_tb')
-        if nxt is not None and nxt[2] > 0:
-            ids[:nxt[2], 2], ids[:nxt[2], 3] = nxt[0], nxt[1]
-
-    @torch.no_grad()
-    def _train_step_dp(self, data, y, n_global, next_data):
-        # the temporally blocked sweep under data parallelism: every rank announces its next shard (or none does) and
-        # every rank flushes at the same steps -- the loops run in lockstep, and so do these decisions
-        n = data[5].numel()
-        key = promise_key(data[5].reshape(-1), data[6].reshape(-1), n)
-        if self._tb_promised is not None and key != self._tb_promised[0]:
-            self.flush(last_step=self.step_count)            # (this step has not counted itself yet)
-        self._tb_promised, self._dp_tb = None, None
-        if (self._defer_req and self.plus and next_data is not None and self.sweep_period > 1 and n_global is not None
-                and next_data[5].numel() <= int(self.hp.get('batch_size', 0))):
-            nu, ni = next_data[5].reshape(-1).contiguous(), next_data[6].reshape(-1).contiguous()
-            self._dp_tb = (nu, ni, nu.numel())
-        try:
-            se = super()._train_step_dp(data, y, n_global, next_data)
-            if self._dp_tb is not None:
-                nu, ni, nn = self._dp_tb
-                self._tb_promised = (promise_key(nu, ni, nn), self._dp_tb)
-                self._tb_used = True
-        finally:
-            self._dp_tb = None
-        return se
+        return 2, 10
 
     def _dp_apply(self, all_ids, all_vals, B_all, ws, nb, R, T):
         uid_all, iid_all = all_ids[:, 0].contiguous(), all_ids[:, 1].contiguous()
-        nu_all, ni_all = all_ids[:, 2].contiguous(), all_ids[:, 3].contiguous()
         gu_all, gi_all = all_vals[:, :5].contiguous(), all_vals[:, 5:].contiguous()
         p2 = lambda ts: (ctypes.c_uint64 * 2)(*[t.data_ptr() for t in ts])   # noqa: E731
+        period, base, sweep_all, _ = self._tb_now            # (the same on every rank: the loops run in lockstep)
         _lib.check(_lib.lib().r4r_transnet_rows_apply(
-            ptr(uid_all), ptr(iid_all), ptr(gu_all), ptr(gi_all), ptr(nu_all), ptr(ni_all), self.sweep_period,
-            int(self.__dict__.get('_dp_tb') is not None), B_all, p2(self.rows), p2(self.rows_m), p2(self.rows_v),
+            ptr(uid_all), ptr(iid_all), ptr(gu_all), ptr(gi_all), period, base, sweep_all,
+            B_all, p2(self.rows), p2(self.rows_m), p2(self.rows_v),
             self.n_users, self.n_items, ptr(ws), ws.numel(), nb, T, self.E, self.L, self.V, self.lr, self.betas[0],
             self.betas[1], self.eps, self.wd, int(self.step_count), _lib.current_stream()), 'r4r_transnet_rows_apply')
 
@@ -1508,7 +1475,7 @@ class TransNetEngine(NarreEngine):
         return out
 
 
-class IdNetEngine:
+class IdNetEngine(_SweepSchedule):
     """Native step for the ID-only recommenders with dense layers -- model_type 'MF' (MF.py:60-68) and the
     NeuMF family (NeuMF.py: GMF / MLP / NeuMF) -- csrc/idnet_engine.hip, r4r_idnet_step: forward, loss,
     backward and the dense Adam update of main.py:56-60,94-96 in 4 launches (5 for NeuMF); the dense
@@ -1593,7 +1560,7 @@ class IdNetEngine:
         self._ws, self._ws_B, self._out = None, None, {}
         # visit period of the temporally blocked table sweeps (include/r4r.h; 1 = the plain dense sweeps)
         self.sweep_period = max(1, min(8, int(os.environ.get('R4R_SWEEP_PERIOD', hp.get('sweep_period', 8)))))
-        self._tb_promised = None
+        self._tb_base, self._tb_period = 0, 1
         self._sd_hooks = flush_before_state_dict(self, model)
 
     TEMPORAL_SWEEP = True        # train_step(..., defer_sweep=True) + flush(): the table sweeps, temporally blocked
@@ -1606,23 +1573,24 @@ class IdNetEngine:
     def flush(self, check=True, last_step=None):
         """Apply every pending table update of the temporally blocked sweeps (no-op when nothing is pending).
         last_step: the last COMPLETED step (default: step_count)."""
-        if self._tb_promised is None:
+        step = self._pending(last_step)
+        if step is None:
             return
-        self._tb_promised = None
         _lib.check(_lib.lib().r4r_idnet_rows_flush(
             self.variant, self._p6(self.rows), self._p6(self.rows_m), self._p6(self.rows_v), self.n_users, self.n_items,
-            ptr(self._ws), self._ws.numel(), self._ws_B, self.L, self.lr, self.betas[0], self.betas[1], self.eps, self.wd,
-            int(self.step_count if last_step is None else last_step), _lib.current_stream()), 'r4r_idnet_rows_flush')
+            ptr(self._ws), self._ws.numel(), self._ws_B, self.L, self._tb_period, self._tb_base,
+            self.lr, self.betas[0], self.betas[1], self.eps, self.wd, step, _lib.current_stream()), 'r4r_idnet_rows_flush')
+        self._tb_base = step
         if check:
             self.check_announcements()
 
     def check_announcements(self):
-        """Raise if a step trained on a batch other than the announced one while updates were pending."""
+        """Raise if the scheduled sweeps ever found more than 8 updates pending (cannot happen through this class)."""
         if self._ws is None:
             return
         off = _lib.lib().r4r_idnet_ws_offset(self.variant, self._ws_B, self.L, self.n_users, self.n_items, 3)
         if int(self._ws[off:off + 4].view(torch.int32).item()):
-            raise RuntimeError('IdNetEngine: a deferred table sweep met a batch that was not the announced one')
+            raise RuntimeError('IdNetEngine: the temporally blocked table sweeps found more pending updates than they can apply')
 
     def draws(self):
         return 2 * self.L * (2 if self.variant == 3 else 1) + (0 if self.variant == 1 else 2 * self.L)
@@ -1638,18 +1606,14 @@ class IdNetEngine:
             self._ws, self._ws_B = nxt, B
         return self._ws
 
-    def _launch(self, data, y, train_mode, inv_denom, adam_step, next_data=None):
+    def _launch(self, data, y, train_mode, inv_denom, adam_step, sched=(1, 0, 1, 1)):
         uid, iid = data[5].reshape(-1).contiguous(), data[6].reshape(-1).contiguous()
         if not (uid.is_cuda and uid.dtype == torch.int64 and iid.is_cuda and iid.dtype == torch.int64):
             raise RuntimeError('IdNetEngine: batches must be int64 tensors on the ROCm device')
         n = uid.numel()
-        if self._tb_promised is not None and (not adam_step or promise_key(uid, iid, n) != self._tb_promised[0]):
-            self.flush(last_step=adam_step - 1 if adam_step else None)   # not the announced training step: the tables catch up first
-        self._tb_promised, tbn = None, None
-        if next_data is not None and adam_step and self.dp is None and self.sweep_period > 1 and next_data[5].numel() > 0:
-            nu, ni = next_data[5].reshape(-1).contiguous(), next_data[6].reshape(-1).contiguous()
-            if nu.is_cuda and ni.is_cuda and nu.dtype == torch.int64 and ni.dtype == torch.int64 and nu.numel() == ni.numel():
-                tbn = (nu, ni, nu.numel())                   # (anything else: nothing is announced, this step flushes)
+        if not adam_step:
+            self.flush()                                     # a forward reads the tables: they catch up first
+        period, base, sweep_all, _ = sched
         if adam_step and n > self.MAX_TRAIN_BATCH:
             raise RuntimeError('IdNetEngine: training batch %d > %d' % (n, self.MAX_TRAIN_BATCH))
         if n not in self._out:
@@ -1661,16 +1625,12 @@ class IdNetEngine:
         rc = _lib.lib().r4r_idnet_step(
             self.variant, ptr(uid), ptr(iid), ptr(y), ptr(self.flat_p), ptr(self.flat_g) if adam_step else None,
             ptr(self.flat_m) if apply else None, ptr(self.flat_v) if apply else None,
-            self._p6(self.rows), self._p6(self.rows_m) if apply else None,
-            self._p6(self.rows_v) if apply else None, self.n_users, self.n_items, ptr(pred), ptr(se),
+            self._p6(self.rows), self._p6(self.rows_m) if adam_step else None,   # (data parallel: still read, for the catch-up)
+            self._p6(self.rows_v) if adam_step else None, self.n_users, self.n_items, ptr(pred), ptr(se),
             ptr(self.sse) if adam_step else None, ptr(ws), ws.numel(), n, self.L, float(self.hp['dropout']),
-            int(train_mode), self.seed, self.offset, float(inv_denom),
-            ptr(tbn[0]) if tbn else None, ptr(tbn[1]) if tbn else None, tbn[2] if tbn else 0, self.sweep_period,
+            int(train_mode), self.seed, self.offset, float(inv_denom), period, base, sweep_all,
             self.lr, self.betas[0], self.betas[1], self.eps, self.wd, int(adam_step), _lib.current_stream())
         _lib.check(rc, 'r4r_idnet_step')
-        if tbn is not None:                                  # (the id tensors stay referenced until the promise is kept)
-            self._tb_promised = (promise_key(tbn[0], tbn[1], tbn[2]), tbn)
-            self._tb_used = True
         if train_mode and float(self.hp['dropout']) > 0.0:
             self.offset += n * self.draws()
         return pred, se
@@ -1678,33 +1638,28 @@ class IdNetEngine:
     @torch.no_grad()
     def train_step(self, data, y, n_global=None, next_data=None, defer_sweep=False):
         """One optimisation step.  Returns the per-example SE tensor (device, reused by the next call);
-        the running sum is in ``self.sse``.  defer_sweep (single process, with `next_data`): the Adam sweeps over
-        the ID tables are temporally blocked (MFEngine.train_step has the contract)."""
+        the running sum is in ``self.sse``.  defer_sweep: the Adam sweeps over the ID tables are temporally blocked
+        (MFEngine.train_step has the contract; next_data: accepted for the engines' common calling surface)."""
         if self.dp is not None:
-            return self._train_step_dp(data, y, n_global, next_data if defer_sweep else None)
+            return self._train_step_dp(data, y, n_global, bool(defer_sweep))
         n = data[5].numel()
         if n == 0:
             return torch.empty(0, dtype=torch.float32, device=self.dev)
         self.step_count += 1
+        sched = self._schedule(bool(defer_sweep))
         _, se = self._launch(data, y.reshape(-1).contiguous(), self.model.training,
-                             1.0 / float(n_global if n_global is not None else n), self.step_count,
-                             next_data if defer_sweep else None)
+                             1.0 / float(n_global if n_global is not None else n), self.step_count, sched)
+        self._scheduled(sched[2], sched[3], self.step_count)
         return se
 
     @torch.no_grad()
-    def _train_step_dp(self, data, y, n_global, next_data=None):
+    def _train_step_dp(self, data, y, n_global, defer=False):
         lib, dist = _lib.lib(), torch.distributed
         n, world, L = data[5].numel(), self.dp.world, self.L
         B_pad = int(self.hp.get('batch_size', 0))
-        # the temporally blocked sweeps under data parallelism: every rank announces its next shard (or none does) and
-        # every rank flushes at the same steps -- the loops run in lockstep, and so do these decisions
-        key = promise_key(data[5].reshape(-1), data[6].reshape(-1), n)
-        if self._tb_promised is not None and key != self._tb_promised[0]:
-            self.flush(last_step=self.step_count)            # (this step has not counted itself yet)
-        self._tb_promised, tbn = None, None
-        if (next_data is not None and self.sweep_period > 1 and n_global is not None and next_data[5].numel() <= B_pad):
-            nu, ni = next_data[5].reshape(-1).contiguous(), next_data[6].reshape(-1).contiguous()
-            tbn = (nu, ni, nu.numel())
+        # the scheduled sweeps under data parallelism: the same (period, base, all) on every rank -- the loops run in
+        # lockstep, and so do these decisions
+        sched = self._schedule(bool(defer))
         if n_global is not None and n > B_pad:
             # (taking the size-agreement branch on THIS rank only would leave the others in a different
             # collective: a hang, not an error)
@@ -1719,7 +1674,7 @@ class IdNetEngine:
         se = torch.empty(0, dtype=torch.float32, device=self.dev)
         if n > 0:
             _, se = self._launch(data, y.reshape(-1).contiguous(), self.model.training, 1.0 / float(n_global),
-                                 self.step_count)
+                                 self.step_count, sched)
         else:
             self.flat_g.zero_()                              # an empty shard contributes a zero gradient
         self.dp.allreduce_flat(self.flat_g)                  # C1: the dense gradient
@@ -1730,21 +1685,18 @@ class IdNetEngine:
                                       self.wd, int(self.step_count), None, _lib.current_stream()), 'r4r_adam_multi')
         # C2: per rating (uid, iid) and (d loss / d pred, the compact rows of every table); -1 ids pad ragged shards
         ntab = len(self.tables)
-        ids = torch.full((B_pad, 4), -1, dtype=torch.int64, device=self.dev)     # uid, iid, the announced NEXT uid, iid
-        if tbn is not None and tbn[2] > 0:
-            ids[:tbn[2], 2], ids[:tbn[2], 3] = tbn[0], tbn[1]
+        ids = torch.full((B_pad, 2), -1, dtype=torch.int64, device=self.dev)     # uid, iid
         vals = torch.zeros((B_pad, 1 + ntab * L), dtype=torch.float32, device=self.dev)
         if n > 0:
             ids[:n, 0], ids[:n, 1] = data[5].reshape(-1), data[6].reshape(-1)
             vals[:n, 0] = self._ws_view(n, 1, 1)[:, 0]
             for t in range(ntab):
                 vals[:n, 1 + t * L:1 + (t + 1) * L] = self._ws_view(n, 4 + t, L)
-        all_ids = torch.empty((world * B_pad, 4), dtype=torch.int64, device=self.dev)
+        all_ids = torch.empty((world * B_pad, 2), dtype=torch.int64, device=self.dev)
         all_vals = torch.empty((world * B_pad, 1 + ntab * L), dtype=torch.float32, device=self.dev)
         self.dp.all_gather(all_ids.view(-1), ids.view(-1))
         self.dp.all_gather(all_vals.view(-1), vals.view(-1))
         uid_all, iid_all = all_ids[:, 0].contiguous(), all_ids[:, 1].contiguous()
-        nu_all, ni_all = all_ids[:, 2].contiguous(), all_ids[:, 3].contiguous()
         g_all = all_vals[:, 0].contiguous()
         rows = [all_vals[:, 1 + t * L:1 + (t + 1) * L].contiguous() for t in range(ntab)]
         p2 = lambda ts: (ctypes.c_uint64 * 2)(*[t.data_ptr() for t in ts] + [0] * (2 - len(ts)))
@@ -1752,13 +1704,11 @@ class IdNetEngine:
         ws = self._workspace(nb)
         _lib.check(lib.r4r_idnet_rows_apply(
             self.variant, ptr(uid_all), ptr(iid_all), ptr(g_all), p2(rows[0::2]), p2(rows[1::2]),
-            ptr(nu_all), ptr(ni_all), self.sweep_period, int(tbn is not None), world * B_pad,
+            sched[0], sched[1], sched[2], world * B_pad,
             self._p6(self.rows), self._p6(self.rows_m), self._p6(self.rows_v), self.n_users, self.n_items, ptr(ws),
             ws.numel(), nb, L, self.lr, self.betas[0], self.betas[1], self.eps, self.wd, int(self.step_count),
             _lib.current_stream()), 'r4r_idnet_rows_apply')
-        if tbn is not None:
-            self._tb_promised = (promise_key(tbn[0], tbn[1], tbn[2]), tbn)
-            self._tb_used = True
+        self._scheduled(sched[2], sched[3], self.step_count)
         return se
 
     @torch.no_grad()
@@ -1819,7 +1769,7 @@ class IdNetEngine:
                 'betas': self.betas, 'eps': self.eps}
 
     def load_state_dict(self, sd):
-        self._tb_promised = None                             # (the workspace is zeroed below: nothing pending any more)
+        self._tb_base, self._tb_period = int(sd['step']), 1  # (what was pending is discarded with the state it belonged to)
         if sd['exp_avg'].numel() != self.total:
             raise ValueError('IdNetEngine.load_state_dict: %d moment elements for a %d-element layout'
                              % (sd['exp_avg'].numel(), self.total))

@@ -167,7 +167,7 @@ def _mf_worker(rank, world, port, case, out_dir):
         kw = dict(next_data=shards[step + 1][0] if step < 2 else None, defer_sweep=True) if defer else {}
         ses.append(eng.train_step(sd, sy, n_global=int(y.shape[0]) if step != 1 else None, **kw).cpu().clone())
         if defer and step == 0:
-            assert eng._tb_promised is not None              # (step 1 does not know the global count: it flushes)
+            assert eng._tb_period > 1                        # (the schedule is in force from the first step on)
     if defer:
         eng.flush()
     torch.save({'w': {k: v.detach().cpu() for k, v in model.state_dict().items()}, 'se': ses},
@@ -331,12 +331,8 @@ def _blocked_dp_worker(rank, world, port, family, defer, out_dir):
     for s, k in enumerate(order):
         (sd, sy), n_global = shards[k]
         nxt = shards[order[s + 1]][0][0] if s + 1 < len(order) else None
-        if s == 4:
-            nxt = shards[2][0][0]                            # an announcement that is not kept (step 5 trains on batch 5)
-        if s == 6:
-            nxt = None                                       # a step that announces nothing
-        if defer:
-            eng.train_step(sd, sy, n_global=n_global, next_data=nxt, defer_sweep=True)
+        if defer:                                            # (step 6 leaves the schedule: it visits every chunk)
+            eng.train_step(sd, sy, n_global=n_global, next_data=nxt, defer_sweep=(s != 6))
         else:
             eng.train_step(sd, sy, n_global=n_global)
     eng.flush()
@@ -349,10 +345,10 @@ def _blocked_dp_worker(rank, world, port, family, defer, out_dir):
 
 @pytest.mark.parametrize('family', ['MF_dot', 'transnet++', 'NeuMF'])
 def test_dp2_blocked_sweep_equals_the_plain_sweep(tmp_path, family):
-    """The temporally blocked sweep under data parallelism (every rank's next ids ride in the gathered payload;
-    r4r_mf_apply / r4r_transnet_rows_apply / r4r_idnet_rows_apply block over what ALL ranks announced): 2 ranks x 9 steps of ragged shards,
-    with an announcement that is not kept and a step that announces nothing -- parameters and both moments identical,
-    bit for bit, across the ranks and to the same run with the plain sweep."""
+    """The temporally blocked sweep under data parallelism (r4r_mf_apply / r4r_transnet_rows_apply /
+    r4r_idnet_rows_apply on the same schedule on every rank, the ranks' forwards catching up the rows they name): 2
+    ranks x 9 steps of ragged shards, one step off the schedule -- parameters and both moments identical, bit for bit,
+    across the ranks and to the same run with the plain sweep."""
     for defer in (0, 1):
         mp.spawn(_blocked_dp_worker, args=(2, _free_port(), family, defer, str(tmp_path)), nprocs=2, join=True)
     runs = {(d, r): torch.load(os.path.join(tmp_path, 'b%d_%d.pt' % (d, r))) for d in (0, 1) for r in (0, 1)}

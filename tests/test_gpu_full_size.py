@@ -277,9 +277,10 @@ def _same_bits(a, b, what):
 @pytest.mark.parametrize('period', [2, 4, 8])
 def test_temporally_blocked_sweep_is_the_dense_sweep_bit_for_bit(period, monkeypatch):
     """TransNet++'s ID-vector Adam with untouched chunks visited every `period`-th step (their pending gradient-zero
-    updates applied together, include/r4r.h) against the plain sweep that visits every element every step: 13
-    training steps over tables of 26 + 8 chunks, dropout on, a ragged batch, an announcement that is NOT kept (the
-    engine flushes), an evaluation in the middle -- every parameter and both Adam moments identical to the bit."""
+    updates applied together, rows a rating names catching up on the way: include/r4r.h) against the plain sweep that
+    visits every element every step: 13 training steps over tables of 26 + 8 chunks, dropout on, a ragged batch, a
+    row named four times, a step outside the schedule, an evaluation in the middle -- every parameter and both Adam
+    moments identical to the bit."""
     from reviews4rec_amd import synthetic
     monkeypatch.setenv('R4R_SWEEP_PERIOD', str(period))
     hp = dict(synthetic.hyper_params_for('cfg5_transnetpp_synthetic', dropout=0.5), total_users=21000, total_items=6000,
@@ -295,17 +296,16 @@ def test_temporally_blocked_sweep_is_the_dense_sweep_bit_for_bit(period, monkeyp
     order = [0, 1, 2, 3, 4, 5, 0, 2, 4, 1, 3, 5, 0]
     for s, k in enumerate(order):
         nxt = pool[order[s + 1]][0] if s + 1 < len(order) else None
-        announced = pool[5][0] if s == 6 else nxt            # step 6 announces batch 5, step 7 trains on batch 2
         plain[1].train_step(*pool[k], next_data=nxt)
-        blocked[1].train_step(*pool[k], next_data=announced, defer_sweep=True)
+        blocked[1].train_step(*pool[k], next_data=nxt, defer_sweep=(s != 6))   # step 6 leaves the schedule: every chunk
         if s == 3:                                           # an evaluation between two steps flushes first
             pa, pb = plain[1].predict(pool[1][0])[0], blocked[1].predict(pool[1][0])[0]
             assert torch.equal(pa, pb)
-        if s in (1, 8):                                      # an announcement is outstanding: updates may be pending
-            assert blocked[1]._tb_promised is not None
-    assert blocked[1]._tb_promised is None                   # the last step announced nothing: it flushed itself
+        if s in (1, 8):                                      # on the schedule: updates are pending
+            assert blocked[1]._tb_base < blocked[1].step_count
+    _same_bits(plain, blocked, 'period %d' % period)         # (state_dict() / moments() bring the pending updates in)
+    assert blocked[1]._tb_base == blocked[1].step_count
     blocked[1].check_announcements()
-    _same_bits(plain, blocked, 'period %d' % period)
 
 
 def test_temporally_blocked_sweep_at_cfg5_cardinalities():
@@ -319,33 +319,27 @@ def test_temporally_blocked_sweep_at_cfg5_cardinalities():
     for _ in range(4):
         data, y = gen.batch(128)
         pool.append(([torch.from_numpy(d).to(DEV) for d in data], torch.from_numpy(y).to(DEV)))
-    for s in range(6):
+    for s in range(11):
         plain[1].train_step(*pool[s % 4], next_data=pool[(s + 1) % 4][0])
-        # (step 2 announces the wrong batch: step 3 finds most chunks behind and the engine flushes first)
-        blocked[1].train_step(*pool[s % 4], next_data=pool[(s + (2 if s == 2 else 1)) % 4][0], defer_sweep=True)
-    assert blocked[1]._tb_promised is not None               # behind: most chunks are waiting for their turn
+        blocked[1].train_step(*pool[s % 4], next_data=pool[(s + 1) % 4][0], defer_sweep=True)
+    assert blocked[1]._tb_base < blocked[1].step_count       # behind: most chunks are waiting for their turn
     assert not torch.equal(plain[0].user_embedding.weight, blocked[0].user_embedding.weight)
     # nn.Module.state_dict() IS the model at any point of an epoch (main.py:125): the engine's pre-hook brings the
     # pending updates in first -- no explicit flush() here (a submodule's state_dict() does the same)
     sd = blocked[0].user_embedding.state_dict()
     assert torch.equal(sd['weight'], plain[0].user_embedding.weight)
-    assert blocked[1]._tb_promised is None
+    assert blocked[1]._tb_base == blocked[1].step_count
     _same_bits(plain, blocked, 'cfg5 tables')
-    # a promise broken behind the engine's back is detected by the sweep itself: batch 3 arrives where batch 1 was
-    # announced, and the chunks its users live in are a step behind
-    blocked[1].train_step(*pool[0], next_data=pool[1][0], defer_sweep=True)
-    blocked[1]._tb_promised = (blocked[1]._tb_key(blocked[1]._fields(pool[3][0])[0], 128), blocked[1]._tb_promised[1])
-    blocked[1].train_step(*pool[3], next_data=None, defer_sweep=True)
-    with pytest.raises(RuntimeError, match='not the announced one'):
-        blocked[1].check_announcements()
+    blocked[1].check_announcements()
 
 
-@pytest.mark.parametrize('period,B', [(2, 128), (4, 128), (8, 128), (4, 2500)])
+@pytest.mark.parametrize('period,B', [(2, 128), (4, 128), (8, 128), (4, 2500), (3, 128)])
 def test_temporally_blocked_mf_sweep_is_the_dense_sweep_bit_for_bit(period, B, monkeypatch):
-    """r4r_mf_step's table sweep with untouched chunks visited every `period`-th step against the sweep that visits
-    every element every step, on cfg2's own tables (192,403 x 64 + 63,001 x 64: 3,991 chunks): twelve training steps,
-    dropout on, a ragged batch, an evaluation in the middle, an announcement that is not kept -- every parameter and
-    both Adam moments identical to the bit (B = 2,500 runs the wide entry waves, mf_adam_kernel<8>)."""
+    """r4r_mf_step's table sweep with untouched chunks visited every `period`-th step (the scheduled form: nothing is
+    announced, rows a rating names catch up on the way) against the sweep that visits every element every step, on
+    cfg2's own tables (192,403 x 64 + 63,001 x 64: 3,991 chunks): twelve training steps, dropout on, a ragged batch,
+    a row named three times, an evaluation in the middle, a step outside the schedule -- every parameter and both Adam
+    moments identical to the bit (B = 2,500 runs the wide entry waves, mf_adam_kernel<8>)."""
     import reviews4rec_amd
     from reviews4rec_amd import synthetic
     from reviews4rec_amd.engine import MFEngine
@@ -366,59 +360,33 @@ def test_temporally_blocked_mf_sweep_is_the_dense_sweep_bit_for_bit(period, B, m
         data, y = gen.batch(B if k != 3 else B - 37)
         pool.append(([None] * 5 + [torch.from_numpy(data[5]).to(DEV), torch.from_numpy(data[6]).to(DEV)], torch.from_numpy(y).to(DEV)))
     pool[1][0][5][:3] = hp['total_users'] - 1                # the user table's last row, three times
-    order = [0, 1, 2, 3, 4, 0, 2, 4, 1, 3, 0, 1]
+    order = [0, 1, 2, 3, 4, 0, 2, 4, 1, 3, 0, 1, 1, 1, 2, 0, 3, 4, 4, 2]
     for s, k in enumerate(order):
-        nxt = pool[order[s + 1]][0] if s + 1 < len(order) else None
-        announced = pool[4][0] if s == 5 else nxt            # step 5 announces batch 4, step 6 trains on batch 2
         plain[1].train_step(*pool[k])
-        blocked[1].train_step(*pool[k], next_data=announced, defer_sweep=True)
+        blocked[1].train_step(*pool[k], defer_sweep=(s != 6))   # step 6 leaves the schedule: it visits every chunk
         if s == 3:
             assert torch.equal(plain[1].predict(pool[1][0])[0], blocked[1].predict(pool[1][0])[0])
-        if s == 8:
-            assert blocked[1]._tb_promised is not None
+        if s in (8, 17):
+            assert blocked[1]._tb_base < blocked[1].step_count
             if B == 128:                                     # behind: most chunks are waiting for their turn
                 assert not torch.equal(plain[0].user_embedding.weight, blocked[0].user_embedding.weight)
-    assert blocked[1]._tb_promised is None
-    blocked[1].check_announcements()
+    # nn.Module.state_dict() IS the model at any point of an epoch (main.py:125): the engine's pre-hook brings the
+    # pending updates in first -- no explicit flush() here
     sa, sb = plain[0].state_dict(), blocked[0].state_dict()
+    assert blocked[1]._tb_base == blocked[1].step_count
+    blocked[1].check_announcements()
     for k in sa:
         assert torch.equal(sa[k], sb[k]), k
     (ma, va), (mb, vb) = plain[1].moments(), blocked[1].moments()
     for k in ma:
         assert torch.equal(ma[k], mb[k]) and torch.equal(va[k], vb[k]), k
-    if period == 8 and B == 128:                             # a promise broken behind the engine's back is seen by the sweep
-        blocked[1].train_step(*pool[0], next_data=pool[1][0], defer_sweep=True)
-        t = blocked[1]._tb_promised[1]
-        u, i = pool[3][0][5].reshape(-1).contiguous(), pool[3][0][6].reshape(-1).contiguous()
-        from reviews4rec_amd.engine import promise_key
-        blocked[1]._tb_promised = (promise_key(u, i, u.numel()), t)
-        blocked[1].train_step(*pool[3])
-        with pytest.raises(RuntimeError, match='not the announced one'):
-            blocked[1].check_announcements()
-    if period == 4 and B == 128:
-        # a loader that REFILLS the announced buffers in place (same pointers, new ids): the promise key carries the
-        # tensors' version counters, the engine sees another batch and flushes first -- nothing stale is read, the
-        # tables still equal the plain sweep's to the bit
-        plain2, blocked2 = pair
-        buf_u, buf_i = pool[1][0][5].clone(), pool[1][0][6].clone()
-        plain2[1].train_step(*pool[0])
-        blocked2[1].train_step(*pool[0], next_data=[None] * 5 + [buf_u, buf_i], defer_sweep=True)
-        assert blocked2[1]._tb_promised is not None
-        buf_u.copy_(pool[2][0][5])                            # the refill: batch 2's ids where batch 1's were announced
-        buf_i.copy_(pool[2][0][6])
-        plain2[1].train_step(*pool[2])
-        blocked2[1].train_step([None] * 5 + [buf_u, buf_i], pool[2][1])
-        blocked2[1].check_announcements()                     # (no stale chunk was read)
-        sa, sb = plain2[0].state_dict(), blocked2[0].state_dict()
-        for k in sa:
-            assert torch.equal(sa[k], sb[k]), k
 
 
 @pytest.mark.parametrize('kind,L,period', [('MF', 32, 8), ('NeuMF', 32, 4), ('GMF', 10, 2), ('MLP', 24, 8)])
 def test_temporally_blocked_idnet_sweeps_are_the_dense_sweeps_bit_for_bit(kind, L, period, monkeypatch):
     """r4r_idnet_step's table sweeps (one pair + the bias vectors in one launch; NeuMF's second pair in another, with
-    its own pending counts) blocked against plain, on Electronics-sized tables: eleven steps, dropout on, a ragged
-    batch, an evaluation, an announcement that is not kept -- parameters and moments identical to the bit."""
+    its own per-row state) blocked against plain, on Electronics-sized tables: eleven steps, dropout on, a ragged
+    batch, an evaluation, a step outside the schedule -- parameters and moments identical to the bit."""
     import reviews4rec_amd
     from reviews4rec_amd import synthetic
     from reviews4rec_amd.engine import IdNetEngine
@@ -445,17 +413,15 @@ def test_temporally_blocked_idnet_sweeps_are_the_dense_sweeps_bit_for_bit(kind, 
     pool[0][0][5][:2] = U                                    # the user table's last row (MF.py:21: U + 1 rows)
     order = [0, 1, 2, 3, 4, 0, 3, 1, 4, 2, 0]
     for s, k in enumerate(order):
-        nxt = pool[order[s + 1]][0] if s + 1 < len(order) else None
-        announced = pool[4][0] if s == 5 else nxt            # step 5 announces batch 4, step 6 trains on batch 3
         plain[1].train_step(*pool[k])
-        blocked[1].train_step(*pool[k], next_data=announced, defer_sweep=True)
+        blocked[1].train_step(*pool[k], defer_sweep=(s != 5))   # step 5 leaves the schedule: it visits every chunk
         if s == 3:
             assert torch.equal(plain[1].predict(pool[1][0])[0], blocked[1].predict(pool[1][0])[0])
         if s == 8:
-            assert blocked[1]._tb_promised is not None
-    assert blocked[1]._tb_promised is None
-    blocked[1].check_announcements()
+            assert blocked[1]._tb_base < blocked[1].step_count
     sa, sb = plain[0].state_dict(), blocked[0].state_dict()
+    assert blocked[1]._tb_base == blocked[1].step_count
+    blocked[1].check_announcements()
     for k in sa:
         assert torch.equal(sa[k], sb[k]), k
     (ma, va), (mb, vb) = plain[1].moments(), blocked[1].moments()
@@ -465,9 +431,9 @@ def test_temporally_blocked_idnet_sweeps_are_the_dense_sweeps_bit_for_bit(kind, 
 
 @pytest.mark.parametrize('family', ['MF_dot', 'transnet++', 'NeuMF'])
 def test_temporally_blocked_sweeps_under_a_random_schedule(family, monkeypatch):
-    """150 steps of whatever a host loop might do -- announced batches, announcements that are not kept, steps that
-    announce nothing, ragged batches, evaluations, optimiser state_dict round trips, a changing visit period -- the
-    blocked engine against the plain one after every tenth step and at the end: identical bits."""
+    """150 steps of whatever a host loop might do -- steps on and off the schedule, ragged batches, evaluations,
+    optimiser state_dict round trips, a changing visit period -- the blocked engine against the plain one after every
+    tenth step and at the end: identical bits."""
     import random
     import reviews4rec_amd
     from reviews4rec_amd import synthetic
@@ -518,15 +484,10 @@ def test_temporally_blocked_sweeps_under_a_random_schedule(family, monkeypatch):
     for s in range(150):
         nxt = rnd.randrange(9)
         act = rnd.random()
-        if act < 0.70:
-            announced = pool[nxt][0]                         # the promise is kept
-        elif act < 0.85:
-            announced = pool[(nxt + 1) % 9][0]               # ... is not
-        else:
-            announced = None                                 # nothing announced: this step flushes
+        on = act < 0.85                                      # (else: a step off the schedule, which visits every chunk)
         plain[1].train_step(*pool[cur])
-        blocked[1].train_step(*pool[cur], next_data=announced, defer_sweep=True)
-        if announced is not None:
+        blocked[1].train_step(*pool[cur], next_data=pool[nxt][0], defer_sweep=on)
+        if on:
             behind += int(not torch.equal(getattr_path(plain[0], tables[0]), getattr_path(blocked[0], tables[0])))
         cur = nxt
         r = rnd.random()
