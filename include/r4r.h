@@ -446,9 +446,12 @@ int r4r_mf_grad(const int64_t *uid, const int64_t *iid, const float *y, const ui
 int r4r_mf_apply(const void *blocks, int world, int64_t B_pad, const uint64_t *p, const uint64_t *m,
                  const uint64_t *v, int64_t n_users, int64_t n_items, int D, void *ws, size_t ws_bytes,
                  int sweep_period, int64_t sweep_base, int sweep_all,
+                 const float *se, int64_t se_n, float *sse_accum,
                  float lr, double beta1, double beta2, float eps, float weight_decay, int64_t adam_step,
                  void *stream);
-/* The scheduled sweep under data parallelism: r4r_mf_apply(sweep_period, sweep_base, sweep_all) -- the SAME values on
+/* se [se_n] / sse_accum (nullable): sse_accum[0] += the sum of THIS rank's se in a fixed order (the running train metric
+ * of main.py:57), on the launch's global-bias workgroup instead of a launch of its own.
+ * The scheduled sweep under data parallelism: r4r_mf_apply(sweep_period, sweep_base, sweep_all) -- the SAME values on
  * every rank -- is r4r_mf_step's sweep over the gathered entries; r4r_mf_grad(m, v, ws = r4r_mf_apply's workspace,
  * the same schedule and optimiser scalars; all NULL / ignored when nothing can be pending) reads the rows its ratings
  * name as of step adam_step - 1.  r4r_mf_rows_flush on every rank before anything else reads the tables. */

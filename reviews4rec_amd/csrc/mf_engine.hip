@@ -193,13 +193,14 @@ struct MfSweep {
     const int *uid32, *iid32;                      // the batch's ids, compact (with first_*)
     const int64_t *uid, *iid;
     const float *gu, *gi, *g, *se;
+    int64_t se_n = -1;                 // entries of `se` (-1: B; data parallel: this rank's own ratings, not the gathered ones)
     float *sse_accum;
     const int *tag_u, *tag_i;
     const int *ctag_u = nullptr, *ctag_i = nullptr;   // per sweep chunk of the tables: the last step that touched a row in it (optional)
     int64_t B;
     int D, now;
     int nt = 0;                        // untouched chunks: nontemporal loads / stores (tables far larger than the Infinity Cache)
-    MfTimeBlock tb = MfTimeBlock{};    // temporally blocked sweep (rows_device.h); tb.lag_u == NULL: off
+    MfTimeBlock tb = MfTimeBlock{};    // temporally blocked sweep (rows_device.h); tb.rlast_u == NULL: off
     AdamScalars s;
 };
 
@@ -248,113 +249,6 @@ __device__ __forceinline__ void mf_stream_chunk(float *p, float *m, float *v, in
     if (k < cnt) {
         float P = p[k], M = m[k], V = v[k];
         adam_elem_fast(P, 0.f, M, V, sc);
-        p[k] = P; m[k] = M; v[k] = V;
-    }
-}
-
-#ifndef R4R_TB_PIPE
-#define R4R_TB_PIPE 1                  // (0: load, update, store in turn -- cfg2 4.33-4.40 M ratings/s against 4.85 M pipelined; cfg5 within 1 %)
-#endif
-#ifndef R4R_TB_BATCH
-#define R4R_TB_BATCH 2                 // float4 per array a thread has in flight (4: 160 VGPRs, 3 waves per SIMD -- cfg5's sweep 53 -> 74 us)
-#endif
-// The same stream for a chunk that carries `pend` (1 .. MF_TB_MAX) pending gradient-zero updates: one read and one
-// write of the element, the updates applied in step order with each step's own bias corrections (slot j of the
-// scalar arrays = step now - (MF_TB_MAX - 1 - j); compile-time indices: a run-time index into kernel arguments
-// would send them through scratch).
-template <bool NT>
-__device__ __forceinline__ void mf_stream_chunk_tb(float *p, float *m, float *v, int64_t cnt, int tid, const AdamScalars &sc0,
-                                                   const MfTimeBlock &tb, int pend) {
-    auto ld = [](const float *a, int64_t i) {
-        const mf_f32x4 *q = reinterpret_cast<const mf_f32x4 *>(a) + i;
-        return NT ? __builtin_nontemporal_load(q) : *q;
-    };
-    auto st = [](float *a, int64_t i, mf_f32x4 x) {
-        mf_f32x4 *q = reinterpret_cast<mf_f32x4 *>(a) + i;
-        if (NT) __builtin_nontemporal_store(x, q);
-        else *q = x;
-    };
-    auto upd = [&](mf_f32x4 &P, mf_f32x4 &M, mf_f32x4 &V) {
-#pragma unroll
-        for (int j = 0; j < MF_TB_MAX; ++j) {
-            if (j >= MF_TB_MAX - pend) {                     // uniform
-                AdamScalars sc = sc0;
-                sc.lr_over_bc1 = tb.lr_bc1[j];
-                sc.inv_sqrt_bc2 = tb.isb2[j];
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    float pc = P[c], mc = M[c], vc = V[c];
-                    adam_elem_fast(pc, 0.f, mc, vc, sc);
-                    P[c] = pc; M[c] = mc; V[c] = vc;
-                }
-            }
-        }
-    };
-    const int64_t nvec = cnt >> 2;
-    constexpr int NV = MF_CHUNK / 4 / MF_THREADS, NB = R4R_TB_BATCH < NV ? R4R_TB_BATCH : NV;   // float4 per thread and array; in flight together
-    static_assert(NV % NB == 0, "batches of the thread's float4");
-    // (nvec == 0 -- a table's last chunk with fewer than four elements: the clamped loads below would read 16 bytes
-    // at index 0 of a chunk that does not hold them, i.e. past the table's end; uniform)
-    if (nvec > 0) {
-#if R4R_TB_PIPE
-    // software pipeline: group g + 1's loads are requested before group g's updates (a wave's memory time and its
-    // arithmetic otherwise add up: every wave of the launch starts together and few of them carry work)
-    constexpr int NG = NV / NB;
-    mf_f32x4 P[2][NB], M[2][NB], V[2][NB];
-    auto load = [&](int g, mf_f32x4 (&Pg)[NB], mf_f32x4 (&Mg)[NB], mf_f32x4 (&Vg)[NB]) {
-#pragma unroll
-        for (int u = 0; u < NB; ++u) {
-            const int64_t i = tid + (int64_t)(g * NB + u) * MF_THREADS;
-            const int64_t ii = i < nvec ? i : 0;            // (the last chunk of a table: clamped, not stored)
-            Pg[u] = ld(p, ii); Mg[u] = ld(m, ii); Vg[u] = ld(v, ii);
-        }
-    };
-    load(0, P[0], M[0], V[0]);
-#pragma unroll
-    for (int g = 0; g < NG; ++g) {
-        if (g + 1 < NG) load(g + 1, P[(g + 1) & 1], M[(g + 1) & 1], V[(g + 1) & 1]);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int u = 0; u < NB; ++u) upd(P[g & 1][u], M[g & 1][u], V[g & 1][u]);
-#pragma unroll
-        for (int u = 0; u < NB; ++u) {
-            const int64_t i = tid + (int64_t)(g * NB + u) * MF_THREADS;
-            if (i < nvec) { st(p, i, P[g & 1][u]); st(m, i, M[g & 1][u]); st(v, i, V[g & 1][u]); }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-    }
-#else
-#pragma unroll 1
-    for (int u0 = 0; u0 < NV; u0 += NB) {
-        mf_f32x4 P[NB], M[NB], V[NB];
-#pragma unroll
-        for (int u = 0; u < NB; ++u) {
-            const int64_t i = tid + (int64_t)(u0 + u) * MF_THREADS;
-            const int64_t ii = i < nvec ? i : 0;            // (the last chunk of a table: clamped, not stored)
-            P[u] = ld(p, ii); M[u] = ld(m, ii); V[u] = ld(v, ii);
-        }
-#pragma unroll
-        for (int u = 0; u < NB; ++u) upd(P[u], M[u], V[u]);
-#pragma unroll
-        for (int u = 0; u < NB; ++u) {
-            const int64_t i = tid + (int64_t)(u0 + u) * MF_THREADS;
-            if (i < nvec) { st(p, i, P[u]); st(m, i, M[u]); st(v, i, V[u]); }
-        }
-    }
-#endif
-    }
-    const int64_t k = (nvec << 2) + tid;                    // cnt % 4 elements at the end of a table
-    if (k < cnt) {
-        float P = p[k], M = m[k], V = v[k];
-#pragma unroll
-        for (int j = 0; j < MF_TB_MAX; ++j) {
-            if (j >= MF_TB_MAX - pend) {
-                AdamScalars sc = sc0;
-                sc.lr_over_bc1 = tb.lr_bc1[j];
-                sc.inv_sqrt_bc2 = tb.isb2[j];
-                adam_elem_fast(P, 0.f, M, V, sc);
-            }
-        }
         p[k] = P; m[k] = M; v[k] = V;
     }
 }
@@ -620,7 +514,10 @@ __device__ __forceinline__ void mf_adam_body(const MfSweep &w) {
     // Entry workgroups are dispatched FIRST (the owner of a popular row is the launch's longest
     // workgroup; interleaving them with the sweep workgroups measured slower), but keep the highest
     // slot numbers.
-    const int bx = (int)blockIdx.x < w.n_entry_wgs ? w.cb_entries + (int)blockIdx.x : (int)blockIdx.x - w.n_entry_wgs;
+    // (then the bias-vector chunks and the global-bias workgroup -- short, and a tail when they come last -- then
+    // the table chunks)
+    const int nshort = w.cb_entries - w.cb2, rest = (int)blockIdx.x - w.n_entry_wgs;
+    const int bx = rest < 0 ? w.cb_entries + (int)blockIdx.x : (rest < nshort ? w.cb2 + rest : rest - nshort);
 #ifdef R4R_MF_ABL                                           // timing-only ablations (wrong results): 1 entries, 2 tables, 4 bias vectors, 8 global
     if ((R4R_MF_ABL & 1) && bx >= w.cb_entries) return;
     if ((R4R_MF_ABL & 8) && bx >= w.cb_global && bx < w.cb_entries) return;
@@ -701,7 +598,9 @@ __device__ __forceinline__ void mf_adam_body(const MfSweep &w) {
         // ---- global bias (gradient = sum of d loss / d pred over the batch) + the running SE:
         // strided per-thread sums, then a fixed tree -- deterministic
         float a = 0.f, e = 0.f;
-        for (int64_t b = tid; b < w.B; b += MF_THREADS) { a += w.g[b]; e += w.se ? w.se[b] : 0.f; }
+        const int64_t se_n = w.se ? (w.se_n >= 0 ? w.se_n : w.B) : 0;
+        for (int64_t b = tid; b < w.B; b += MF_THREADS) a += w.g[b];
+        for (int64_t b = tid; b < se_n; b += MF_THREADS) e += w.se[b];
         red[tid] = a;
         __syncthreads();
         for (int off = MF_THREADS / 2; off > 0; off >>= 1) { if (tid < off) red[tid] += red[tid + off]; __syncthreads(); }
@@ -731,7 +630,7 @@ __device__ __forceinline__ void mf_adam_body(const MfSweep &w) {
     const int W = t < 2 ? w.D : 1;
     int64_t ci64 = bx - cb;
     const bool sched = w.tb.rlast_u && t < 2;               // the scheduled form of the blocked sweep (rows_device.h)
-    if (sched && !w.tb.flush) ci64 = tb_due_chunk(ci64, w.now, w.tb.period);   // one due chunk per block of `period`
+    if (sched && !w.tb.flush) ci64 = tb_due_chunk(ci64, w.now, w.tb.period);   // the due chunks only
     const int64_t start = ci64 * mf_chunk(t);
     if (start >= numel) return;                             // (the last block's due chunk may lie past the table)
     int64_t cnt = numel - start;
@@ -848,35 +747,7 @@ __device__ __forceinline__ void mf_adam_body(const MfSweep &w) {
         }
         return;
     }
-    if (w.tb.lag_u && t < 2) {
-        // temporally blocked (rows_device.h): is this chunk visited now, and with how many updates?
-        int *lag = t == 0 ? w.tb.lag_u : w.tb.lag_i;
-        const int *ntag = t == 0 ? w.tb.ntag_u : w.tb.ntag_i;
-        const int ci = bx - cb;
-        const int pend = lag[ci] + w.tb.inc;
-        const bool touched = w.tb.inc && ctag[ci] == w.now;
-        // (the phase of a chunk is a hash of its number: "every period-th chunk" is a power-of-two address stride at
-        // periods 4 and 8, which lands on a subset of the HBM channels -- measured: period 4 slower than period 3)
-        const unsigned phase = ((unsigned)ci * 2654435761u) >> 16;
-        const bool due = w.tb.flush || touched || ntag[ci] == w.now || (phase + (unsigned)w.now) % (unsigned)w.tb.period == 0 ||
-                         pend >= MF_TB_MAX;
-        __syncthreads();                                    // every thread has read the lag before thread 0 rewrites it
-        if (!due) {
-            if (tid == 0) lag[ci] = pend;
-            return;
-        }
-        if (tid == 0) {
-            lag[ci] = 0;
-            if (touched && pend != 1) *w.tb.err = 1;        // the batch was not the announced one: its rows were read stale
-        }
-        if (pend == 0) return;
-        if (!touched) {
-            if (w.nt) mf_stream_chunk_tb<true>(p, m, v, cnt, tid, w.s, w.tb, pend);
-            else mf_stream_chunk_tb<false>(p, m, v, cnt, tid, w.s, w.tb, pend);
-            return;
-        }
-        // a chunk this batch names: one pending update (this step's), row by row below
-    } else if (ctag && aligned && ctag[bx - cb] != w.now) {
+    if (ctag && aligned && ctag[bx - cb] != w.now) {
         // no rating touched a row of this chunk (all but a handful of chunks of a 10^7-row table):
         // stream it -- no row tags, no row / column bookkeeping
         if (w.nt) mf_stream_chunk<true>(p, m, v, cnt, tid, w.s);
@@ -1013,12 +884,16 @@ __device__ __forceinline__ void mf_adam_body(const MfSweep &w) {
 }
 
 BWD_TRACE_DEFINE(r4r_debug_mf_adam_trace)
+#ifndef R4R_MF_WAVES
+#define R4R_MF_WAVES 0
+#endif
 template <int NACC>
-__global__ __launch_bounds__(MF_THREADS) void mf_adam_kernel(MfSweep w) {
+__global__ __launch_bounds__(MF_THREADS, R4R_MF_WAVES > 0 ? R4R_MF_WAVES : 1) void mf_adam_kernel(MfSweep w) {
     BWD_STAMP(0, wall_clock64());                           // (instrumented builds only: tools/sweep_trace.py)
     mf_adam_body<NACC>(w);
 #ifdef R4R_TRACE
-    const int bx = (int)blockIdx.x < w.n_entry_wgs ? w.cb_entries + (int)blockIdx.x : (int)blockIdx.x - w.n_entry_wgs;
+    const int nshort = w.cb_entries - w.cb2, rest = (int)blockIdx.x - w.n_entry_wgs;
+    const int bx = rest < 0 ? w.cb_entries + (int)blockIdx.x : (rest < nshort ? w.cb2 + rest : rest - nshort);
     BWD_STAMP(1, wall_clock64());
     BWD_STAMP(2, bx >= w.cb_entries ? 5 : bx >= w.cb_global ? 4 : bx >= w.cb2 ? 3 : 2);   // role + 1: tables, bias vectors, global, entries
 #endif
@@ -1118,12 +993,11 @@ void mf_time_block_scalars(MfTimeBlock &tb, float lr, double beta1, double beta2
 // sweep workgroups of one table: every chunk, or -- scheduled form outside an all-chunks launch -- one per block of `period`
 static int64_t mf_sweep_wgs(int64_t numel, int chunk, const MfTimeBlock &tb) {
     const int64_t nch = cdiv(numel, chunk);
-    return (tb.rlast_u && !tb.flush) ? cdiv(nch, tb.period) : nch;
+    return (tb.rlast_u && !tb.flush) ? tb_due_wgs(nch, tb.period) : nch;
 }
 static bool mf_tb_args_ok(const MfTimeBlock *tb, const int *ctag_u, const int *ctag_i, uintptr_t all) {
-    const bool announced = tb->lag_u && tb->lag_i && tb->ntag_u && tb->ntag_i, scheduled = tb->rlast_u && tb->rlast_i;
-    return ctag_u && ctag_i && (announced || scheduled) && tb->err && !(all & 15) && tb->period >= 1 && tb->period <= MF_TB_MAX &&
-           (!scheduled || tb->base >= 0);
+    return ctag_u && ctag_i && tb->rlast_u && tb->rlast_i && tb->err && !(all & 15) && tb->period >= 1 && tb->period <= MF_TB_MAX &&
+           tb->base >= 0;
 }
 
 // Adam on two ID tables of width D whose gradient rows are compact ([B, D] per table, one row per
@@ -1508,9 +1382,11 @@ extern "C" int r4r_mf_grad(const int64_t *uid, const int64_t *iid, const float *
 extern "C" int r4r_mf_apply(const void *blocks, int world, int64_t B_pad, const uint64_t *p, const uint64_t *m,
                             const uint64_t *v, int64_t n_users, int64_t n_items, int D, void *ws, size_t ws_bytes,
                             int sweep_period, int64_t sweep_base, int sweep_all,
+                            const float *se, int64_t se_n, float *sse_accum,
                             float lr, double beta1, double beta2, float eps, float weight_decay, int64_t adam_step,
                             void *stream) {
     R4R_REQUIRE(blocks && p && m && v && ws, "mf_apply: null pointer");
+    R4R_REQUIRE(!sse_accum || (se && se_n >= 0), "mf_apply: sse_accum needs se [se_n]");
     R4R_REQUIRE(sweep_period >= 1 && sweep_period <= MF_TB_MAX, "mf_apply: sweep_period %d outside 1..%d", sweep_period, MF_TB_MAX);
     R4R_REQUIRE(world >= 1 && B_pad >= 0 && n_users > 0 && n_items > 0, "mf_apply: bad sizes");
     const int64_t B = (int64_t)world * B_pad;
@@ -1569,7 +1445,8 @@ extern "C" int r4r_mf_apply(const void *blocks, int world, int64_t B_pad, const 
     R4R_REQUIRE(chunks < (1ll << 31), "mf_apply: too many workgroups");
     sw.first_u = w.first_u; sw.first_i = w.first_i; sw.last_u = w.last_u; sw.last_i = w.last_i;
     sw.uid32 = w.uid32; sw.iid32 = w.iid32;
-    sw.uid = nullptr; sw.iid = nullptr; sw.gu = w.gu; sw.gi = w.gi; sw.g = w.g; sw.se = nullptr; sw.sse_accum = nullptr;
+    sw.uid = nullptr; sw.iid = nullptr; sw.gu = w.gu; sw.gi = w.gi; sw.g = w.g;
+    sw.se = sse_accum ? se : nullptr; sw.se_n = se_n; sw.sse_accum = sse_accum;   // this rank's share of the running metric rides on the global-bias workgroup
     sw.tag_u = w.tag_u; sw.tag_i = w.tag_i; sw.B = B; sw.D = D; sw.now = (int)adam_step;
     sw.s = adam_make_scalars(lr, beta1, beta2, eps, weight_decay, adam_step, nullptr);
     if (tb_on) {

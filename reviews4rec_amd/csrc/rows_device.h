@@ -5,7 +5,7 @@
 namespace r4r {
 
 #ifndef R4R_MF_CHUNK
-#define R4R_MF_CHUNK 4096                  // (8192 until late round 3; A/B in profiles/r03f_chunk_ab.txt: cfg2 +12 % at B = 128, +6 % at 8,192; cfg5 within 1 %; 2048: cfg5 -10 %)
+#define R4R_MF_CHUNK 1024                  // (4096 until the sweep went on a schedule, round 4: only due chunks are launched now, and four times the waves share the 8 updates a visit applies -- profiles/r04d_chunk_ab.txt)
 #endif
 constexpr int MF_CHUNK = R4R_MF_CHUNK;         // elements of a table per sweep workgroup (and per chunk tag)
 
@@ -13,47 +13,57 @@ int mf_bias_rows_launch(float *ub, float *ub_m, float *ub_v, float *ib, float *i
                         int64_t n_users, int64_t n_items, const int64_t *uid, const int64_t *iid, const float *g,
                         const int *tag_u, const int *tag_i, int64_t B, int now, const AdamScalars &sc, hipStream_t st);
 
-// The sweep, temporally blocked.  Dense Adam moves every element every step (weight decay, decaying moments), but
-// an element no rating names goes through the SAME gradient-zero update whether it is applied now or together with
-// the next ones: per element the update reads nothing but the element's own (p, m, v) and the step's two bias
-// corrections.  So a chunk of MF_CHUNK elements that neither this batch nor the ANNOUNCED next batch names is
-// visited every `period`-th step only and then takes all its pending updates at once -- in order, each with its own
-// step's scalars: the fp32 operations per element are those of the plain sweep, the traffic a period-th.  Chunks this
-// batch names are visited now (they were brought up to date a step ago, when this batch was the announced one);
-// chunks the next batch names are brought up to date now.  `lag` = pending updates per chunk (0 = current; zeroed
-// workspace = nothing pending).  A caller that announces nothing flushes (period 1 semantics for this step).
-constexpr int MF_TB_MAX = 8;           // pending updates a chunk may carry (period <= this)
+// The sweep, temporally blocked on a schedule.  Dense Adam moves every element every step (weight decay, decaying
+// moments), but an element no rating names goes through the SAME gradient-zero update whether it is applied now or
+// together with the next ones: per element the update reads nothing but the element's own (p, m, v) and the step's two
+// bias corrections.  So chunk c of MF_CHUNK table elements (run r = c / MF_TB_RUN) is visited only at the steps s with
+// (r % period + r / period + s) % period == 0 -- one run of every block of `period` consecutive runs per step, on a
+// diagonal, so a launch covers exactly the due chunks and their addresses are not a power-of-two stride apart -- and
+// then takes all its pending updates at once, in order, each with its own step's scalars: the fp32 operations per
+// element are those of the plain sweep, the traffic a period-th.  Nothing is announced and no per-chunk state is
+// kept: the step of a chunk's LAST visit is a function of (c, now) (tb_prev_visit), an element is current through
+// max(base, last visit of its chunk, rlast[its row]), and whoever needs it newer applies the missing gradient-zero
+// updates on the way: the forward kernels in registers (nothing written), the entry waves before their gradient
+// update (they then set rlast[row] = now), the sweep at its visit.  `base`: a step through which EVERYTHING is current
+// (the last flush or all-chunks step); the caller keeps (base, period) and changes the period only at an all-chunks
+// launch (`flush` = 1), which uses the OLD period.  (Until round 4 the sweep kept a pending count per chunk and the
+// caller ANNOUNCED the next batch so that its rows could be brought up to date a step ahead: half of the traffic
+// at cfg2 was chunks some rating named, and a kept promise was part of the contract.)
+constexpr int MF_TB_MAX = 8;           // pending updates an element may carry (period <= this)
 struct MfTimeBlock {
-    int *lag_u, *lag_i;                // [chunks of the table]                                   (announced form)
-    const int *ntag_u, *ntag_i;        // [chunks]: == now where the announced next batch names a row (ignored when flushing)
-    int *err;                          // *err = 1: a chunk this batch names was NOT current (a broken announcement); 2: more than
-                                       // MF_TB_MAX updates pending somewhere (the caller left the schedule without a flush)
-    int period, flush;
+    int *err;                          // *err = 2 if more than MF_TB_MAX updates were ever pending somewhere
+    int period, flush;                 // flush: visit every chunk (applying what is pending under `period`)
     int inc;                           // 1: this launch is step `now` itself; 0: flush only, `now` = the last completed step
     float lr_bc1[MF_TB_MAX], isb2[MF_TB_MAX];   // AdamScalars::lr_over_bc1 / inv_sqrt_bc2 of steps now - 7 .. now
-    // The SCHEDULED form (round 4; rlast_u != NULL selects it): nothing is announced and no per-chunk state is kept.
-    // Chunk c is visited at the steps s with (c % period + c / period + s) % period == 0 -- one chunk of every block of
-    // `period` consecutive chunks per step, on a diagonal, so a launch covers exactly the due chunks and their
-    // addresses are not a power-of-two stride apart -- which makes the step of a chunk's LAST visit a function of
-    // (c, now): tb_prev_visit.  An element is current through max(base, last visit of its chunk, rlast[its row]);
-    // whoever needs it newer applies the missing gradient-zero updates on the way: the forward kernels in registers
-    // (nothing written), the entry waves before their gradient update (they then set rlast[row] = now), the sweep at
-    // its visit.  `base`: a step through which EVERYTHING is current (the last flush or all-chunks step); the caller
-    // keeps (base, period) and changes the period only at an all-chunks launch (`flush` = 1), which uses the OLD period.
-    int *rlast_u = nullptr, *rlast_i = nullptr;   // [rows]: the last step an entry wave updated the row (0: never)
+    int *rlast_u = nullptr, *rlast_i = nullptr;   // [rows]: the last step an entry wave updated the row (0: never); NULL: off
     int base = 0;
 };
 
+// The schedule works on RUNS of MF_TB_RUN consecutive chunks (one phase per run): what a launch visits is then runs
+// of MF_TB_RUN * MF_CHUNK contiguous elements per array -- whole DRAM pages instead of 4 KB pieces
+// (measured, profiles/r04d_run_ab.txt: runs of 1, 4, 16, 64 chunks within 1 % of each other at cfg2 and cfg5 -- the sweep is not bound by DRAM page locality; the default stays 1).
+#ifndef R4R_TB_RUN
+#define R4R_TB_RUN 1
+#endif
+constexpr int MF_TB_RUN = R4R_TB_RUN;
 // the last step <= t at which the schedule visits chunk c (may lie before `base`: the caller takes the max)
 __host__ __device__ inline int tb_prev_visit(int64_t c, int t, int period) {
-    const unsigned cu = (unsigned)c, pu = (unsigned)period;   // (chunk numbers fit 31 bits: the launch is one workgroup per chunk)
+    const unsigned cu = (unsigned)(c / MF_TB_RUN), pu = (unsigned)period;   // (chunk numbers fit 31 bits: the launch is one workgroup per chunk)
     const unsigned ph = (cu % pu + cu / pu) % pu;
     return t - (int)((ph + (unsigned)t) % pu);
 }
-// the one chunk of block q (chunks q * period ...) the schedule visits at step `now`
+// the chunk that workgroup q of a table's sweep visits at step `now`: chunk q % MF_TB_RUN of the one due run of the
+// block of `period` runs number q / MF_TB_RUN
 __host__ __device__ inline int64_t tb_due_chunk(int64_t q, int now, int period) {
     const unsigned pu = (unsigned)period;
-    return q * period + (int)((pu - ((unsigned)q + (unsigned)now) % pu) % pu);
+    const int64_t blk = q / MF_TB_RUN;
+    const int64_t run = blk * period + (int)((pu - ((unsigned)blk + (unsigned)now) % pu) % pu);
+    return run * MF_TB_RUN + q % MF_TB_RUN;
+}
+// workgroups of a table's sweep when only the due chunks are visited
+__host__ __device__ inline int64_t tb_due_wgs(int64_t nchunks, int period) {
+    const int64_t runs = (nchunks + MF_TB_RUN - 1) / MF_TB_RUN;
+    return ((runs + period - 1) / period) * MF_TB_RUN;
 }
 // the gradient-zero updates of steps cur + 1 .. upto on one element (upto <= now, upto - cur <= MF_TB_MAX; per lane)
 __device__ __forceinline__ void tb_catch_up(float &P, float &M, float &V, int cur, int upto, int now, const AdamScalars &sc0,

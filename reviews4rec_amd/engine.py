@@ -719,14 +719,13 @@ class MFEngine(_SweepSchedule):
         self.dp.all_gather(blocks, block)
         _lib.check(lib.r4r_mf_apply(ptr(blocks), world, B_pad, self._ptrs(self.params), self._ptrs(self.m),
                                     self._ptrs(self.v), self.n_users, self.n_items, self.D, ptr(ws), ws.numel(),
-                                    period, base, sweep_all,
+                                    period, base, sweep_all, ptr(se), n, ptr(self.sse),
                                     self.lr, self.betas[0], self.betas[1], self.eps, self.wd, step,
                                     _lib.current_stream()), 'r4r_mf_apply')
         self._scheduled(sweep_all, want, step)
         if self.model.training and float(self.hp['dropout']) > 0.0:
             self.offset += n * 2 * self.D
-        # this rank's share of the running metric (the host loop sums the ranks): one deterministic launch
-        _lib.check(lib.r4r_sse_accumulate(ptr(se), n, ptr(self.sse), _lib.current_stream()), 'r4r_sse_accumulate')
+        # (this rank's share of the running metric -- the host loop sums the ranks -- rode on r4r_mf_apply)
         return se[:n]
 
     @torch.no_grad()
