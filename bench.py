@@ -51,12 +51,12 @@ PEAK_HBM_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E spec peak (6.3 TB
 WORKLOAD = 'cfg3_deepconn_electronics_e300'
 
 
-PMC_SUMMARIES = {WORKLOAD: 'r04c_bench_pmc_summary.json',
-                 'cfg2_mfdot_electronics': 'r04c_bench_cfg2_pmc_summary.json',
-                 'cfg4_narre_kindle': 'r04c_bench_cfg4_pmc_summary.json',
-                 'cfg5_transnetpp_synthetic': 'r04c_bench_cfg5_pmc_summary.json',
+PMC_SUMMARIES = {WORKLOAD: 'r04e_bench_pmc_summary.json',
+                 'cfg2_mfdot_electronics': 'r04e_bench_cfg2_pmc_summary.json',
+                 'cfg4_narre_kindle': 'r04e_bench_cfg4_pmc_summary.json',
+                 'cfg5_transnetpp_synthetic': 'r04e_bench_cfg5_pmc_summary.json',
                  # the one true HBM gather: full-length documents of uniformly drawn words at a 1 M-word vocabulary
-                 ('cfg5_transnetpp_synthetic', 'full', 'uniform'): 'r04c_cfg5_fullunif_pmc_summary.json'}
+                 ('cfg5_transnetpp_synthetic', 'full', 'uniform'): 'r04e_cfg5_fullunif_pmc_summary.json'}
 
 
 def measured_traffic(kernel, args, live_launch_s=None):
@@ -580,8 +580,8 @@ def main():
                        'engine': 'native' if engine is not None else ('graph' if graphed is not None else 'module'),
                        'conv_algo': args.conv_algo, 'gemm_math': args.gemm_math, 'doc_fill': args.doc_fill,
                        'token_dist': args.token_dist,
-                       **({'table_sweep': 'temporally blocked: chunks neither this batch nor the announced next one names are '
-                                              'visited every %d-th step and take their pending Adam updates together (same bits as the '
+                       **({'table_sweep': 'temporally blocked on a schedule: a table chunk is visited every %d-th step and takes its pending Adam '
+                                              'updates together, rows a rating names catch up on the way (same bits as the '
                                               'dense sweep, tests/test_gpu_full_size.py); flushed inside the timed region' % engine.sweep_period}
                           if getattr(engine, 'TEMPORAL_SWEEP', False) and not dp_job
                           and (getattr(engine, 'plus', 0) or getattr(engine, 'has_tables', False))

@@ -138,8 +138,8 @@ def train(model, criterion, optimizer, reader, hyper_params, engine=None, dp=Non
         total_batches += 1
 
     if engine is not None:
-        # once per epoch, one int each: the blocked sweeps' device-side flag (a touched chunk that was not announced:
-        # stale rows were read -- engine.check_announcements) and the peer exchange's timed_out word
+        # once per epoch, one int each: the blocked sweeps' device-side flag (more updates pending than a visit can
+        # apply: a broken schedule -- engine.check_announcements) and the peer exchange's timed_out word
         for probe in ('check_announcements', 'check_exchange'):
             if hasattr(engine, probe):
                 getattr(engine, probe)()

@@ -24,4 +24,7 @@ bash tools/dp1_bench.sh > $O/rccl1_cfg3.log 2>&1
 for t in r04_bench r04_bench_cfg2 r04_bench_cfg4 r04_bench_cfg5 r04_cfg5_fullunif; do
   cp gpurun_out/prof_$t/kernel_stats.csv $O/${t}_kernel_stats.csv; cp gpurun_out/prof_$t/pmc_summary.json $O/${t}_pmc_summary.json
 done
+bash tools/r04_sweep_suite.sh 2 > $O/sweep_suite.txt 2>&1
+./scratch/dispatch_rate > $O/dispatch_rate.txt 2>&1
+for w in cfg2_mfdot_electronics cfg5_transnetpp_synthetic; do python tools/sweep_trace.py $w 2>/dev/null | tail -12 > $O/sweep_trace_${w%%_*}.txt; done
 ls -la $O
