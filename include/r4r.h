@@ -399,7 +399,7 @@ int r4r_mf_step(const int64_t *uid, const int64_t *iid, const float *y,
 
 /* sweep_period P in 2..8: the Adam sweep over the two ID tables, temporally blocked on a SCHEDULE (round 4).  A table
  * element no rating names goes through the same gradient-zero update whether it is applied now or together with the
- * next ones (it reads nothing but its own p, m, v and the step's two bias corrections), so chunk c of 4,096 table
+ * next ones (it reads nothing but its own p, m, v and the step's two bias corrections), so chunk c of 1,024 table
  * elements is visited only at the steps s with (c % P + c / P + s) % P == 0 -- one chunk of every P consecutive
  * ones per step, a launch of exactly the due chunks -- and then takes all its pending updates in order, each with its
  * own step's scalars: the fp32 operations per element are those of the dense sweep (bit-identical tables and
@@ -619,7 +619,7 @@ int r4r_transnet_step(const float *table, int64_t V,
  * there).  torch.optim.Adam moves EVERY row of user_embedding / item_embedding every step (main.py:94-96: weight
  * decay, decaying moments), 24 bytes of traffic per element -- but an element no rating of the batch names goes
  * through the same gradient-zero update whether it is applied now or together with the next few.  With
- * sweep_period P in 2..8 a chunk of 4,096 table elements is visited every P-th step only (chunk c at the steps s with
+ * sweep_period P in 2..8 a chunk of 1,024 table elements is visited every P-th step only (chunk c at the steps s with
  * (c % P + c / P + s) % P == 0) and then takes its pending updates at once, in step order, each with its own step's
  * scalars: the same fp32 operations per element as P = 1, a P-th of the bytes.  The ID vectors a rating reads catch
  * up in the head kernel's registers (rows_m / rows_v are read for that, also on a gradients-only step: pass them
