@@ -1394,12 +1394,21 @@ __global__ __launch_bounds__(WR_THREADS) void proj_gemm_wres_kernel(ProjArgs a) 
 // position p = t (its tap-2 row), feeds tap 1 of p = t+1 and tap 0 of p = t+2.  The four
 // slices of a segment are merged through LDS in position order (strict >, so the first
 // maximum wins like PyTorch's max-pool).
-constexpr int SLICE = 32;                 // positions per worker
+#ifndef R4R_GSLICE
+#define R4R_GSLICE 32
+#endif
+constexpr int SLICE = R4R_GSLICE;         // positions per worker (32: two segments per workgroup; 16: one -- three dependent rounds per worker instead of five, twice the workgroups)
+constexpr int GWPS = SEG / SLICE;         // workers per segment (4 | 8)
+constexpr int GSPW = 8 / GWPS;            // segments per workgroup (2 | 1)
+static_assert(SLICE == 32 || SLICE == 16, "a worker is 32 lanes; eight workers per workgroup");
 #ifndef R4R_GATHER_ROT
 #define R4R_GATHER_ROT 1
 #endif
 #ifndef R4R_GATHER_ROTDIV
 #define R4R_GATHER_ROTDIV 16            // documents per rotation step (A/B at cfg5: 1 .. 64 all help, 16 most: 34.2 -> 30.8 us; cfg3: neutral)
+#endif
+#ifndef R4R_GATHER_SPLIT
+#define R4R_GATHER_SPLIT 0              // (1: a workgroup's two segments half a document apart -- measured neutral, round 4)
 #endif
 #ifndef R4R_GDEPTH
 #define R4R_GDEPTH 7
@@ -1422,18 +1431,34 @@ __global__ __launch_bounds__(256) void proj_gather_max_kernel(ProjArgs a) {
     // or all zero-padded tails (R4R_GATHER_ROT=0: that order).  The pair index is rotated by document / R4R_GATHER_ROTDIV,
     // so that a CU's workgroups, and an XCD's, mix heads and tails.  Same work per workgroup, same outputs.
     int64_t bx = blockIdx.x;
+    bool split = false;                                     // the workgroup's two segments are half a document apart (below)
 #if R4R_GATHER_ROT
-    if ((a.tiles & 1) == 0 && a.tiles >= 4) {
+    if (GSPW == 2 && (a.tiles & 1) == 0 && a.tiles >= 4) {
         const int t2 = a.tiles >> 1;
         const int64_t d = bx / t2;
         const int pr = (int)(bx - d * t2);
         bx = d * t2 + (pr + (int)(d / R4R_GATHER_ROTDIV)) % t2;
+        split = R4R_GATHER_SPLIT != 0;
     }
 #endif
     // segment `unit` of the launch's N * tiles segments (document-major): workers 0-3 take the
     // workgroup's first segment, 4-7 its second -- of the same document, or (odd tile counts, e.g.
-    // NARRE's one-tile reviews) the first of the next one
-    const int64_t unit = bx * 2 + (worker >> 2), units = a.N * a.tiles;
+    // NARRE's one-tile reviews) the first of the next one.  With an even tile count the two segments are HALF A
+    // DOCUMENT apart (pair j = segments j and j + tiles / 2): documents are zero-padded at the end (data.py:198-199),
+    // so consecutive segments are both real words -- eight workers on five dependent rounds each, a CU of four such
+    // workgroups bound by its L1 -- or both padding (eight workers that shortcut); the split gives every workgroup
+    // one of each.  Same work, same outputs -- and the same time (cfg3 20.9 against 20.6 us, cfg5 32.3 / 32.4: a
+    // worker's five dependent rounds take ~3 us each whatever its neighbours do; R4R_GATHER_SPLIT=1 builds it).
+    // Likewise 16-position slices (R4R_GSLICE=16: three rounds per worker, twice the workgroups): cfg3 22.0-23.5 us,
+    // cfg5 38-39.5 against 32.
+    const int64_t units = a.N * a.tiles;
+    auto unit_of = [&](int h) -> int64_t {
+        if (!split) return bx * GSPW + h;
+        const int t2 = a.tiles >> 1;
+        const int64_t d = bx / t2;
+        return d * a.tiles + (bx - d * t2) + (int64_t)h * t2;
+    };
+    const int64_t unit = unit_of(worker / GWPS);
     const int64_t doc = unit < units ? unit / a.tiles : 0;
     const int seg = unit < units ? (int)(unit - doc * a.tiles) : a.tiles;     // a.tiles: no such segment
     const int T = a.T, P = T + 2;
@@ -1444,7 +1469,7 @@ __global__ __launch_bounds__(256) void proj_gather_max_kernel(ProjArgs a) {
         tw.count[0] = 0;
     }
 
-    const int p_lo = seg * SEG + (worker & 3) * SLICE;
+    const int p_lo = seg * SEG + (worker % GWPS) * SLICE;
     const int p_hi = min(P, p_lo + SLICE);
     const int t_lo = p_lo - 2;
     const int ntok = (seg < a.tiles && p_hi > p_lo) ? p_hi - t_lo : 0;     // tokens t_lo .. p_hi-1
@@ -1455,8 +1480,7 @@ __global__ __launch_bounds__(256) void proj_gather_max_kernel(ProjArgs a) {
     {
         // a slice is at most SLICE + 2 = 34 tokens: lane wl takes token wl and (wl < 2) token 32 + wl, both
         // requested together -- as a loop the second pass (two lanes) was two more dependent round trips
-        static_assert(SLICE == 32, "two tokens per lane cover a slice");
-        const int ta = t_lo + wl, tb = t_lo + 32 + wl;
+        const int ta = t_lo + wl, tb = t_lo + 32 + wl;        // (SLICE 16: 18 tokens, the second request is idle)
         const bool va = wl < ntok && ta >= 0 && ta < T, vb = 32 + wl < ntok && tb >= 0 && tb < T;
         const int64_t ia = tw.idx[doc * T + (va ? ta : 0)], ib = tw.idx[doc * T + (vb ? tb : 0)];
         const int sa = tw.slot[ia], sb = tw.slot[ib];
@@ -1526,14 +1550,14 @@ __global__ __launch_bounds__(256) void proj_gather_max_kernel(ProjArgs a) {
     HEAD_STAMP(2)
     // merge the 4 slices of each segment in position order; thread f (< 100) of each half
     const int half = threadIdx.x >> 7, f = threadIdx.x & 127;
-    const int64_t ounit = bx * 2 + half;
-    if (f < PF && ounit < units) {
-        float mb = sbest[half * 4][f];
-        int mp = sbp[half * 4][f];
+    const int64_t ounit = unit_of(half);
+    if (f < PF && ounit < units && half < GSPW) {
+        float mb = sbest[half * GWPS][f];
+        int mp = sbp[half * GWPS][f];
 #pragma unroll
-        for (int w = 1; w < 4; ++w) {
-            const float v = sbest[half * 4 + w][f];
-            if (v > mb) { mb = v; mp = sbp[half * 4 + w][f]; }
+        for (int w = 1; w < GWPS; ++w) {
+            const float v = sbest[half * GWPS + w][f];
+            if (v > mb) { mb = v; mp = sbp[half * GWPS + w][f]; }
         }
         const size_t o = (size_t)ounit * NP + f;           // [doc][tile][NP]
         tw.pmax[o] = mb;
@@ -1665,7 +1689,7 @@ int textcnn_proj_compute_launch(const float *table, int64_t V, const ProjTower *
     }
     {
         ScopedTiming tm(R4R_TIMING_PROJ_GATHER, st, /*chain=*/true);     // (starts where the GEMM's span ended)
-        proj_gather_max_kernel<<<dim3((unsigned)cdiv(N * a.tiles, 2), ntower), 256, 0, st>>>(a);
+        proj_gather_max_kernel<<<dim3((unsigned)cdiv(N * a.tiles, GSPW), ntower), 256, 0, st>>>(a);
     }
     return check_launch("textcnn_proj_fwd");
 }
