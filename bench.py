@@ -516,9 +516,18 @@ def main():
                 continue
             _, pool_s = make_pool(bs, n=max(2, min(args.pool, 8192 // bs)))      # (large shards: two resident batches)
             step_s = make_step(pool_s, bs, G)
-            for i in range(10):
-                step_s(i)
-            el_s = timed_region(step_s, args.steps, 10, 0)
+            # (the ID-table engines pad every rank's shard to hyper_params['batch_size']: the leg's own)
+            ehp = getattr(engine, 'hp', None)
+            saved_bs = ehp.get('batch_size') if isinstance(ehp, dict) else None
+            if isinstance(ehp, dict):
+                ehp['batch_size'] = bs
+            try:
+                for i in range(10):
+                    step_s(i)
+                el_s = timed_region(step_s, args.steps, 10, 0)
+            finally:
+                if isinstance(ehp, dict):
+                    ehp['batch_size'] = saved_bs
             strong_legs.append({'global_batch': G, 'batch_per_gpu': bs,
                                 'ratings_per_s': round(args.steps * G / el_s, 1),
                                 'ms_per_step': round(1000.0 * el_s / args.steps, 4), 'steps': args.steps})
