@@ -54,6 +54,27 @@ __device__ __forceinline__ void adam_elem_fast(float &p, float g, float &m, floa
     adam_elem_form<true>(p, g, m, v, s);
 }
 
+// adam_elem_fast on TWO elements at once: the same IEEE operations per element (fma, mul, v_sqrt_f32, v_rcp_f32 -- the
+// results are bit-identical to two adam_elem_fast calls), written on 2-vectors so that hipcc emits the packed fp32
+// instructions (v_pk_fma_f32 / v_pk_mul_f32: nine of them + four transcendentals for two elements instead of 2 x (8 + 2)).
+// The blocked sweeps apply several updates per byte moved and are bound by this arithmetic.
+typedef float adam_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void adam_pair_fast(adam_f32x2 &p, adam_f32x2 g, adam_f32x2 &m, adam_f32x2 &v, const AdamScalars &s) {
+#if R4R_ADAM_IEEE
+    float p0 = p.x, p1 = p.y, m0 = m.x, m1 = m.y, v0 = v.x, v1 = v.y;
+    adam_elem(p0, g.x, m0, v0, s); adam_elem(p1, g.y, m1, v1, s);
+    p = (adam_f32x2){p0, p1}; m = (adam_f32x2){m0, m1}; v = (adam_f32x2){v0, v1};
+#else
+    g = __builtin_elementwise_fma((adam_f32x2){s.wd, s.wd}, p, g);
+    m = __builtin_elementwise_fma((adam_f32x2){s.beta1, s.beta1}, m, s.omb1 * g);
+    v = __builtin_elementwise_fma((adam_f32x2){s.beta2, s.beta2}, v, (s.omb2 * g) * g);
+    const adam_f32x2 sq = {__builtin_amdgcn_sqrtf(v.x), __builtin_amdgcn_sqrtf(v.y)};
+    const adam_f32x2 den = sq * s.inv_sqrt_bc2 + s.eps;
+    const adam_f32x2 rc = {__builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y)};
+    p -= s.lr_over_bc1 * (m * rc);
+#endif
+}
+
 // step >= 1: the 1-based count of this update
 static inline AdamScalars adam_make_scalars(float lr, double beta1, double beta2, float eps, float weight_decay,
                                             int64_t step, const int64_t *step_dev) {

@@ -222,13 +222,12 @@ __device__ __forceinline__ void mf_stream_chunk(float *p, float *m, float *v, in
         if (NT) __builtin_nontemporal_store(x, q);
         else *q = x;
     };
-    auto upd = [&](mf_f32x4 &P, mf_f32x4 &M, mf_f32x4 &V) {  // (adam_elem takes references: vector lanes go through scalars)
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            float pc = P[c], mc = M[c], vc = V[c];
-            adam_elem_fast(pc, 0.f, mc, vc, sc);
-            P[c] = pc; M[c] = mc; V[c] = vc;
-        }
+    auto upd = [&](mf_f32x4 &P, mf_f32x4 &M, mf_f32x4 &V) {  // (two elements per packed instruction: adam_pair_fast)
+        const adam_f32x2 z = {0.f, 0.f};
+        adam_f32x2 pa = {P[0], P[1]}, ma = {M[0], M[1]}, va = {V[0], V[1]}, pb = {P[2], P[3]}, mb = {M[2], M[3]}, vb = {V[2], V[3]};
+        adam_pair_fast(pa, z, ma, va, sc);
+        adam_pair_fast(pb, z, mb, vb, sc);
+        P = (mf_f32x4){pa.x, pa.y, pb.x, pb.y}; M = (mf_f32x4){ma.x, ma.y, mb.x, mb.y}; V = (mf_f32x4){va.x, va.y, vb.x, vb.y};
     };
     const int64_t nvec = cnt >> 2;
     int64_t i = tid;
@@ -299,7 +298,7 @@ __device__ __forceinline__ void tb_catch_up4(float4 &P, float4 &M, float4 &V, in
 //     the wave reads epl = 256 / D entries per load instruction, eight instructions in flight (a
 //     popular item in a batch of thousands has > 1000 entries: not one dependent load each);
 //   generic form: lanes are columns (lane, lane + 64, ...), four entries in flight.
-template <int NACC>
+template <int NACC, int DL, bool WIDE>
 __device__ __forceinline__ void mf_entry(const MfSweep &w, const int *sid, int *pl, int t, int64_t k, int lane) {
     const unsigned long long *first = t ? w.first_i : w.first_u;
     const int *gid = t ? w.iid32 : w.uid32;
@@ -375,7 +374,7 @@ __device__ __forceinline__ void mf_entry(const MfSweep &w, const int *sid, int *
 
     float gb;                                               // the bias element's gradient
     const int lpr = D >> 2;                                 // lanes per gradient row, a float4 each
-    if (mf_wide(D, t ? w.p1 : w.p0, t ? w.m1 : w.m0, t ? w.v1 : w.v0)) {
+    if (WIDE && mf_wide(D, t ? w.p1 : w.p0, t ? w.m1 : w.m0, t ? w.v1 : w.v0)) {
         const int sh = __ffs(lpr) - 1, epl = 64 >> sh;
         const int grp = lane >> sh, sub = lane & (lpr - 1);
         const int nacc = epl * NACC > 64 ? (64 / epl) : NACC, cap = nacc * epl;   // cap <= 64
@@ -431,35 +430,35 @@ __device__ __forceinline__ void mf_entry(const MfSweep &w, const int *sid, int *
             reinterpret_cast<float4 *>(bv)[o] = V;
         }
     } else {
-        float acc[4][MF_MAX_D / 64], gsum[4] = {0.f, 0.f, 0.f, 0.f};
+        float acc[4][DL], gsum[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int q = 0; q < 4; ++q)
 #pragma unroll
-            for (int x = 0; x < MF_MAX_D / 64; ++x) acc[q][x] = 0.f;
+            for (int x = 0; x < DL; ++x) acc[q][x] = 0.f;
         scan([&](int base, int n) {
-            float tmp[4][MF_MAX_D / 64], tg[4];
+            float tmp[4][DL], tg[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int e = pl[base + (q < n ? q : 0)];
 #pragma unroll
-                for (int x = 0; x < MF_MAX_D / 64; ++x)
+                for (int x = 0; x < DL; ++x)
                     tmp[q][x] = (lane + 64 * x < D) ? rows[(int64_t)e * D + lane + 64 * x] : 0.f;
                 tg[q] = w.g ? w.g[e] : 0.f;
             }
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
 #pragma unroll
-                for (int x = 0; x < MF_MAX_D / 64; ++x) acc[q][x] += q < n ? tmp[q][x] : 0.f;
+                for (int x = 0; x < DL; ++x) acc[q][x] += q < n ? tmp[q][x] : 0.f;
                 gsum[q] += q < n ? tg[q] : 0.f;
             }
         }, 4);
         gb = (gsum[0] + gsum[1]) + (gsum[2] + gsum[3]);
         if (D > 0) {
             float *bp = t ? w.p1 : w.p0, *bm = t ? w.m1 : w.m0, *bv = t ? w.v1 : w.v0;
-            float Px[MF_MAX_D / 64], Mx[MF_MAX_D / 64], Vx[MF_MAX_D / 64];
-            int cx[MF_MAX_D / 64];
+            float Px[DL], Mx[DL], Vx[DL];
+            int cx[DL];
 #pragma unroll
-            for (int x = 0; x < MF_MAX_D / 64; ++x) {
+            for (int x = 0; x < DL; ++x) {
                 const int col = lane + 64 * x;
                 cx[x] = w.now;
                 Px[x] = Mx[x] = Vx[x] = 0.f;
@@ -477,12 +476,12 @@ __device__ __forceinline__ void mf_entry(const MfSweep &w, const int *sid, int *
                     sc.lr_over_bc1 = w.tb.lr_bc1[j];
                     sc.inv_sqrt_bc2 = w.tb.isb2[j];
 #pragma unroll
-                    for (int x = 0; x < MF_MAX_D / 64; ++x)
+                    for (int x = 0; x < DL; ++x)
                         if (sj > cx[x]) adam_elem_fast(Px[x], 0.f, Mx[x], Vx[x], sc);
                 }
             }
 #pragma unroll
-            for (int x = 0; x < MF_MAX_D / 64; ++x) {
+            for (int x = 0; x < DL; ++x) {
                 const int col = lane + 64 * x;
                 if (col < D) {
                     const int64_t o = (int64_t)row * D + col;
@@ -505,7 +504,7 @@ __device__ __forceinline__ void mf_entry(const MfSweep &w, const int *sid, int *
     }
 }
 
-template <int NACC>
+template <int NACC, int DL, bool WIDE>
 __device__ __forceinline__ void mf_adam_body(const MfSweep &w) {
     extern __shared__ int sid[];                            // entry waves: the side's ids
     __shared__ float red[MF_THREADS];
@@ -541,7 +540,7 @@ __device__ __forceinline__ void mf_adam_body(const MfSweep &w) {
             const int64_t base = (int64_t)gi * 4 + (tid >> 6), nw = (int64_t)(w.n_entry_wgs >> 1) * 4;
             if (base >= w.B) return;
             unsigned long long multi = 0;
-            if (w.epw > 1) {
+            if (WIDE && w.epw > 1) {
                 const int D = w.D, lpr = D >> 2, sh = __ffs(lpr) - 1;
                 const int grp = lane >> sh, sub = lane & (lpr - 1);
                 const int64_t k = base + grp * nw;
@@ -577,10 +576,10 @@ __device__ __forceinline__ void mf_adam_body(const MfSweep &w) {
                 while (multi) {
                     const int q = (__ffsll((long long)multi) - 1) >> sh;
                     multi &= multi - 1;
-                    mf_entry<NACC>(w, sid, pend[tid >> 6], t, base + q * nw, lane);
+                    mf_entry<NACC, DL, WIDE>(w, sid, pend[tid >> 6], t, base + q * nw, lane);
                 }
             } else {
-                mf_entry<NACC>(w, sid, pend[tid >> 6], t, base, lane);
+                mf_entry<NACC, DL, WIDE>(w, sid, pend[tid >> 6], t, base, lane);
             }
             return;
         }
@@ -590,7 +589,7 @@ __device__ __forceinline__ void mf_adam_body(const MfSweep &w) {
         for (int it = 0; it < w.epw; ++it) {                // entries of this wave: interleaved with its neighbours
             const int64_t k = ((int64_t)gi * w.epw + it) * 4 + (tid >> 6);
             if (k >= w.B) break;
-            mf_entry<NACC>(w, sid, pend[tid >> 6], t, k, lane);
+            mf_entry<NACC, DL, WIDE>(w, sid, pend[tid >> 6], t, k, lane);
         }
         return;
     }
@@ -887,10 +886,14 @@ BWD_TRACE_DEFINE(r4r_debug_mf_adam_trace)
 #ifndef R4R_MF_WAVES
 #define R4R_MF_WAVES 0
 #endif
-template <int NACC>
+// DL: elements per lane of a row in the generic entry form (1: rows of <= 64 elements); WIDE: the float4 entry forms are
+// compiled in.  <.., 1, false> is the LIGHT variant -- 52 VGPRs instead of 94, seven waves per SIMD instead of five:
+// every wave of the launch, the table chunks' included, is allocated what the entry waves' multi-row accumulation
+// needs -- taken for rows of <= 64 elements at <= MF_LIGHT_MAX_B ratings (one rating per entry wave).
+template <int NACC, int DL = 4, bool WIDE = true>
 __global__ __launch_bounds__(MF_THREADS, R4R_MF_WAVES > 0 ? R4R_MF_WAVES : 1) void mf_adam_kernel(MfSweep w) {
     BWD_STAMP(0, wall_clock64());                           // (instrumented builds only: tools/sweep_trace.py)
-    mf_adam_body<NACC>(w);
+    mf_adam_body<NACC, DL, WIDE>(w);
 #ifdef R4R_TRACE
     const int nshort = w.cb_entries - w.cb2, rest = (int)blockIdx.x - w.n_entry_wgs;
     const int bx = rest < 0 ? w.cb_entries + (int)blockIdx.x : (rest < nshort ? w.cb2 + rest : rest - nshort);
@@ -941,10 +944,20 @@ static MfWs mf_carve(void *ws, int64_t B, int D, int64_t n_users, int64_t n_item
 // untouched elements take the gradient-zero update, a touched element the fixed-order sum of its
 // ratings.  `tag_*`: per-element step tags the caller's forward kernel set to `now`.
 // (more than the default 64 KB of dynamic LDS once a side has more than 16,384 ids)
+#ifndef R4R_MF_LIGHT
+#define R4R_MF_LIGHT 1
+#endif
+constexpr int MF_LIGHT_MAX_B = 1024;   // beyond it popular rows have hundreds of entries: the wide forms' four entries per load instruction pay
+static bool mf_light(int D, int64_t B) {
+    static const char *e = getenv("R4R_MF_LIGHT");
+    return (e ? e[0] != '0' : R4R_MF_LIGHT != 0) && D <= 64 && B <= MF_LIGHT_MAX_B;
+}
 static void mf_ids_lds_attr() {
     static bool done = false;
     if (!done) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(mf_adam_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  MF_MAX_B * (int)sizeof(int));
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(mf_adam_kernel<4, 1, false>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   MF_MAX_B * (int)sizeof(int));
         done = true;
     }
@@ -974,7 +987,11 @@ int mf_bias_rows_launch(float *ub, float *ub_m, float *ub_v, float *ib, float *i
     sw.uid32 = sw.iid32 = nullptr;
     sw.uid = uid; sw.iid = iid; sw.g = g; sw.se = nullptr; sw.sse_accum = nullptr;
     sw.tag_u = tag_u; sw.tag_i = tag_i; sw.B = B; sw.D = 0; sw.now = now; sw.s = sc;
-    { mf_ids_lds_attr(); mf_adam_kernel<4><<<(unsigned)chunks, MF_THREADS, (size_t)B * sizeof(int), st>>>(sw); }
+    {
+            mf_ids_lds_attr();
+            if (mf_light(sw.D, B)) mf_adam_kernel<4, 1, false><<<(unsigned)chunks, MF_THREADS, (size_t)B * sizeof(int), st>>>(sw);
+            else mf_adam_kernel<4><<<(unsigned)chunks, MF_THREADS, (size_t)B * sizeof(int), st>>>(sw);
+        }
     return check_launch("bias rows");
 }
 
@@ -1042,7 +1059,11 @@ int mf_table_rows_launch(float *ut, float *ut_m, float *ut_v, float *it, float *
     sw.nt = mf_sweep_nt(sw.n0 + sw.n1);
     {
         ScopedTiming tm(R4R_TIMING_ADAM, st);
-        { mf_ids_lds_attr(); mf_adam_kernel<4><<<(unsigned)chunks, MF_THREADS, (size_t)B * sizeof(int), st>>>(sw); }
+        {
+            mf_ids_lds_attr();
+            if (mf_light(sw.D, B)) mf_adam_kernel<4, 1, false><<<(unsigned)chunks, MF_THREADS, (size_t)B * sizeof(int), st>>>(sw);
+            else mf_adam_kernel<4><<<(unsigned)chunks, MF_THREADS, (size_t)B * sizeof(int), st>>>(sw);
+        }
     }
     return check_launch("table rows");
 }
@@ -1095,7 +1116,11 @@ int mf_table_bias_rows_launch(float *ut, float *ut_m, float *ut_v, float *it, fl
     sw.tag_u = tag_u; sw.tag_i = tag_i; sw.B = B; sw.D = D; sw.now = now; sw.s = sc;
     {
         ScopedTiming tm(R4R_TIMING_ADAM, st);
-        { mf_ids_lds_attr(); mf_adam_kernel<4><<<(unsigned)chunks, MF_THREADS, (size_t)B * sizeof(int), st>>>(sw); }
+        {
+            mf_ids_lds_attr();
+            if (mf_light(sw.D, B)) mf_adam_kernel<4, 1, false><<<(unsigned)chunks, MF_THREADS, (size_t)B * sizeof(int), st>>>(sw);
+            else mf_adam_kernel<4><<<(unsigned)chunks, MF_THREADS, (size_t)B * sizeof(int), st>>>(sw);
+        }
     }
     return check_launch("table + bias rows");
 }
@@ -1204,7 +1229,8 @@ extern "C" int r4r_mf_step(const int64_t *uid, const int64_t *iid, const float *
     chunks += 1;
     sw.cb_entries = (int)chunks;                            // entry waves: 4 per workgroup, per side
     // election slots (no LDS staging to amortise): a wave takes 256 / D ratings in the wide form, else one
-    sw.epw = (D > 0 && mf_wide(D, sw.p0, sw.m0, sw.v0) && mf_wide(D, sw.p1, sw.m1, sw.v1)) ? 256 / D : 1;
+    const bool light = mf_light(D, B);                      // (one rating per entry wave, the generic form)
+    sw.epw = (!light && D > 0 && mf_wide(D, sw.p0, sw.m0, sw.v0) && mf_wide(D, sw.p1, sw.m1, sw.v1)) ? 256 / D : 1;
     sw.n_entry_wgs = (int)(2 * cdiv(B, 4 * sw.epw));
     chunks += sw.n_entry_wgs;
     sw.first_u = w.first_u; sw.first_i = w.first_i; sw.last_u = w.last_u; sw.last_i = w.last_i;
@@ -1223,6 +1249,7 @@ extern "C" int r4r_mf_step(const int64_t *uid, const int64_t *iid, const float *
         // more loads in flight per entry wave (and fewer waves per SIMD: 156 vs 116 VGPRs) once rows can
         // have hundreds of ratings
         if (B > 2048) mf_adam_kernel<8><<<(unsigned)chunks, MF_THREADS, 0, st>>>(sw);
+        else if (light) mf_adam_kernel<4, 1, false><<<(unsigned)chunks, MF_THREADS, 0, st>>>(sw);
         else mf_adam_kernel<4><<<(unsigned)chunks, MF_THREADS, 0, st>>>(sw);
     }
     return check_launch("mf_step");
@@ -1439,7 +1466,8 @@ extern "C" int r4r_mf_apply(const void *blocks, int world, int64_t B_pad, const 
     sw.cb_global = (int)chunks;
     chunks += 1;
     sw.cb_entries = (int)chunks;
-    sw.epw = (D > 0 && mf_wide(D, sw.p0, sw.m0, sw.v0) && mf_wide(D, sw.p1, sw.m1, sw.v1)) ? 256 / D : 1;
+    const bool light = mf_light(D, B);                      // (one rating per entry wave, the generic form)
+    sw.epw = (!light && D > 0 && mf_wide(D, sw.p0, sw.m0, sw.v0) && mf_wide(D, sw.p1, sw.m1, sw.v1)) ? 256 / D : 1;
     sw.n_entry_wgs = (int)(2 * cdiv(B, 4 * sw.epw));
     chunks += sw.n_entry_wgs;
     R4R_REQUIRE(chunks < (1ll << 31), "mf_apply: too many workgroups");
@@ -1455,6 +1483,7 @@ extern "C" int r4r_mf_apply(const void *blocks, int world, int64_t B_pad, const 
         sw.nt = mf_sweep_nt(sw.n0 + sw.n1);
     }
     if (B > 2048) mf_adam_kernel<8><<<(unsigned)chunks, MF_THREADS, 0, st>>>(sw);
+    else if (light) mf_adam_kernel<4, 1, false><<<(unsigned)chunks, MF_THREADS, 0, st>>>(sw);
     else mf_adam_kernel<4><<<(unsigned)chunks, MF_THREADS, 0, st>>>(sw);
     return check_launch("mf_apply");
 }

@@ -29,7 +29,10 @@ int mf_bias_rows_launch(float *ub, float *ub_m, float *ub_v, float *ib, float *i
 // launch (`flush` = 1), which uses the OLD period.  (Until round 4 the sweep kept a pending count per chunk and the
 // caller ANNOUNCED the next batch so that its rows could be brought up to date a step ahead: half of the traffic
 // at cfg2 was chunks some rating named, and a kept promise was part of the contract.)
-constexpr int MF_TB_MAX = 8;           // pending updates an element may carry (period <= this)
+#ifndef R4R_TB_MAX
+#define R4R_TB_MAX 8
+#endif
+constexpr int MF_TB_MAX = R4R_TB_MAX;  // pending updates an element may carry (period <= this)
 struct MfTimeBlock {
     int *err;                          // *err = 2 if more than MF_TB_MAX updates were ever pending somewhere
     int period, flush;                 // flush: visit every chunk (applying what is pending under `period`)
@@ -95,13 +98,14 @@ __device__ __forceinline__ void tb_catch_up_v(tb_f32x4 (&P)[N], tb_f32x4 (&M)[N]
         sc.inv_sqrt_bc2 = tb.isb2[j];
 #pragma unroll
         for (int u = 0; u < N; ++u)
-            if (s > cur[u]) {
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    float pc = P[u][c], mc = M[u][c], vc = V[u][c];
-                    adam_elem_fast(pc, 0.f, mc, vc, sc);
-                    P[u][c] = pc; M[u][c] = mc; V[u][c] = vc;
-                }
+            if (s > cur[u]) {                               // (two elements per packed instruction: adam_pair_fast)
+                const adam_f32x2 z = {0.f, 0.f};
+                adam_f32x2 pa = {P[u][0], P[u][1]}, ma = {M[u][0], M[u][1]}, va = {V[u][0], V[u][1]};
+                adam_f32x2 pb = {P[u][2], P[u][3]}, mb = {M[u][2], M[u][3]}, vb = {V[u][2], V[u][3]};
+                adam_pair_fast(pa, z, ma, va, sc);
+                adam_pair_fast(pb, z, mb, vb, sc);
+                P[u] = (tb_f32x4){pa.x, pa.y, pb.x, pb.y}; M[u] = (tb_f32x4){ma.x, ma.y, mb.x, mb.y};
+                V[u] = (tb_f32x4){va.x, va.y, vb.x, vb.y};
             }
     }
 }

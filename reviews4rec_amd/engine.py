@@ -597,7 +597,7 @@ class MFEngine(_SweepSchedule):
         self.offset = 0
         self._ws, self._ws_B, self._out = None, None, {}
         # visit period of the temporally blocked table sweep (include/r4r.h; 1 = the plain dense sweep)
-        self.sweep_period = max(1, min(8, int(os.environ.get('R4R_SWEEP_PERIOD', hp.get('sweep_period', 8)))))
+        self.sweep_period = max(1, min(int(os.environ.get('R4R_SWEEP_PERIOD_MAX', 8)), int(os.environ.get('R4R_SWEEP_PERIOD', hp.get('sweep_period', 8)))))
         # the schedule in force: every table element is current through step _tb_base, chunks have been visited on the
         # period-_tb_period schedule since (1: every step)
         self._tb_base, self._tb_period = 0, 1
@@ -1308,7 +1308,7 @@ class TransNetEngine(NarreEngine, _SweepSchedule):
             self.dp = dp
         self.plus = int(model.hyper_params['model_type'] == 'transnet++')
         # visit period of the temporally blocked ID-vector sweep (include/r4r.h; 1 = the plain dense sweep)
-        self.sweep_period = max(1, min(8, int(os.environ.get('R4R_SWEEP_PERIOD', model.hyper_params.get('sweep_period', 8)))))
+        self.sweep_period = max(1, min(int(os.environ.get('R4R_SWEEP_PERIOD_MAX', 8)), int(os.environ.get('R4R_SWEEP_PERIOD', model.hyper_params.get('sweep_period', 8)))))
         self._tb_base, self._tb_period, self._defer_req, self._tb_now = 0, 1, False, (1, 0, 1, 1)
         if not self.plus:
             self.DP_COLS = 0                                 # plain TransNet: no ID rows to exchange
@@ -1558,7 +1558,7 @@ class IdNetEngine(_SweepSchedule):
         self.offset = 0
         self._ws, self._ws_B, self._out = None, None, {}
         # visit period of the temporally blocked table sweeps (include/r4r.h; 1 = the plain dense sweeps)
-        self.sweep_period = max(1, min(8, int(os.environ.get('R4R_SWEEP_PERIOD', hp.get('sweep_period', 8)))))
+        self.sweep_period = max(1, min(int(os.environ.get('R4R_SWEEP_PERIOD_MAX', 8)), int(os.environ.get('R4R_SWEEP_PERIOD', hp.get('sweep_period', 8)))))
         self._tb_base, self._tb_period = 0, 1
         self._sd_hooks = flush_before_state_dict(self, model)
 
