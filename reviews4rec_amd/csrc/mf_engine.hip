@@ -176,7 +176,10 @@ __global__ __launch_bounds__(256) void mf_fwd_bwd_kernel(MfStep a) {
 
 constexpr int MF_THREADS = 256;        // (MF_CHUNK, the elements per sweep workgroup of a table: rows_device.h)
 
-constexpr int MF_CHUNK_BIAS = 1024;    // bias vectors: short workgroups, so they are not the tail
+#ifndef R4R_MF_CHUNK_BIAS
+#define R4R_MF_CHUNK_BIAS 1024
+#endif
+constexpr int MF_CHUNK_BIAS = R4R_MF_CHUNK_BIAS;    // bias vectors: short workgroups, so they are not the tail
 
 // Scalar fields only: an array member indexed by the workgroup's slot number (even through a
 // chain of constant-index selects, which LLVM turns back into an indexed access) is copied to
