@@ -659,3 +659,22 @@ def test_rccl_one_rank_bench_line(tmp_path):
     assert cfg['dist_backend'] == 'nccl' and cfg['rccl_ranks'] == 1 and cfg['replicas_identical'] is True
     assert cfg['dp_exchange'] in ('allreduce', 'gather') and set(cfg['dp_exchange_ms']) == {'allreduce', 'gather'}
     assert line['value'] > 0 and line['strong']['global_batch'] == 1024
+
+
+@pytest.mark.parametrize('workload', ['cfg2_mfdot_electronics', 'cfg5_transnetpp_synthetic'])
+def test_two_rank_bench_line_of_the_id_table_families(workload):
+    """bench.py --gpus 2 (two ranks sharing the one GPU over gloo) for the families whose data-parallel step pads
+    every rank's shard to hyper_params['batch_size']: the weak line AND a strong leg whose per-rank batch (512) exceeds
+    the weak one (128) -- the leg has to carry its own shard padding into the engine (it raised until round 4)."""
+    import json
+    import subprocess
+    env = dict(os.environ, R4R_DIST_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr',
+           '127.0.0.1', '--master-port', str(_free_port()), os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '6',
+           '--warmup', '2', '--no-cpu-baseline', '--workload', workload, '--strong-leg', '1024']
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    assert line['n_gpus'] == 2 and line['value'] > 0 and line['config']['replicas_identical'] is True
+    legs = line.get('strong_legs') or [line.get('strong')]
+    assert legs and legs[0]['global_batch'] == 1024 and legs[0].get('ratings_per_s', 0) > 0, legs
