@@ -124,8 +124,11 @@ __device__ __forceinline__ void narre_sweep_block(const RowSweep &w, int bx) {
     }
 }
 
+#ifndef R4R_NROW_HR
+#define R4R_NROW_HR 2                   // further hits of a lane requested per round (A/B: 4)
+#endif
 #ifndef R4R_NROW_EPW
-#define R4R_NROW_EPW 4
+#define R4R_NROW_EPW 2
 #endif
 constexpr int NROW_EPW = R4R_NROW_EPW;              // entries per wave of an entry workgroup (16 entries share one load of the ids)
 // MW: 64-bit words of a lane's hit mask (entries <= 4096 MW: 1 in the fused single-process launch,
@@ -224,7 +227,7 @@ __device__ __forceinline__ void narre_rows_block(const RowSweep &w, int bx, int 
                 for (int col = 0; col < ML; ++col) rv[col] = 0.f + ((c0[q] >= 0 && col < L) ? h0[q][col] : 0.f);
                 float gv = 0.f + ((c0[q] >= 0 && j0 < w.B) ? g0[q] : 0.f);     // only the self entries carry a bias gradient
                 while (__ballot(any(q))) {                  // a lane's further hits, two per round, their loads together
-                    constexpr int HR = 2;                   // (registers: the pair's first hits are still live)
+                    constexpr int HR = R4R_NROW_HR;         // (registers: the pair's first hits are still live)
                     int cs[HR];
 #pragma unroll
                     for (int u = 0; u < HR; ++u) cs[u] = pop(q);

@@ -88,9 +88,14 @@ __device__ __forceinline__ void wgrad_block(const WgradArgs &a, int f, int s, in
 // one WAVE per filter, four filters per workgroup -- `wgrad_block` would leave three waves of
 // four idle in its streaming phase.  Same per-(filter, split) summation order, so the same bits.
 // grid.x = ceil(F / 4) for this form.
+#ifndef R4R_WG_SUPER
+#define R4R_WG_SUPER 96                 // (16 = the round-by-round form: resolve 16 documents, stream them, resolve the next 16 ...)
+#endif
+constexpr int WG_SUPER = R4R_WG_SUPER;  // documents whose (argmax -> token -> row offset) chains are resolved TOGETHER
+static_assert(WG_SUPER % WG_CHUNK == 0, "whole streaming rounds per resolved super-chunk");
 __device__ __forceinline__ void wgrad_block_packed(const WgradArgs &a, int fgroup, int s, int tower) {
-    __shared__ long p_off[4][WG_CHUNK][3];
-    __shared__ float p_g[4][WG_CHUNK];
+    __shared__ long p_off[4][WG_SUPER][3];
+    __shared__ float p_g[4][WG_SUPER];
     const WgradTower &tw = a.t[tower];
     const float *__restrict__ table = a.table;
     const int64_t *__restrict__ idx = tw.idx;
@@ -106,35 +111,64 @@ __device__ __forceinline__ void wgrad_block_packed(const WgradArgs &a, int fgrou
     wg_f32x4 acc = (wg_f32x4){0.f, 0.f, 0.f, 0.f};
     const int vj = (lane * 4) / E, ve = lane * 4 - vj * E;
     float sb = 0.f;
-    for (int64_t c0 = n0; c0 < n1; c0 += WG_CHUNK) {
-        const int nd = (int)min((int64_t)WG_CHUNK, n1 - c0);
+    // A split is 80 documents at NARRE's 1,280 reviews per tower: resolved 16 at a time (argmax -> token id -> rows:
+    // three dependent round trips per round, five rounds) the launch was latency, not bandwidth -- 18 us where the
+    // rows themselves are 197 MB out of L2.  Now the chains of up to WG_SUPER documents are resolved together (every
+    // argmax / gradient read of the super-chunk in one round trip, every token id in the next), then the rows stream
+    // 16 per round trip as before: seven round trips per split instead of fifteen.  Same per-(filter, split) order
+    // of additions: the same bits.
+    constexpr int NRES = (WG_SUPER * 3 + 63) / 64;          // (document, tap) items per lane
+    for (int64_t c0 = n0; c0 < n1; c0 += WG_SUPER) {
+        const int nd = (int)min((int64_t)WG_SUPER, n1 - c0);
         __syncthreads();
-        if (live && lane < WG_CHUNK * 3) {
-            const int d = lane / 3, j = lane - d * 3;
-            const int64_t n = c0 + d;
-            const int p = d < nd ? argmax[n * F + f] : -1;
-            const int t = p - 2 + j;
-            long off = -1;
-            if (p >= 0 && t >= 0 && t < T) off = (long)idx[n * T + t] * E;
-            p_off[wave][d][j] = off;
-            if (j == 0) p_g[wave][d] = (p >= 0) ? gp[n * F + f] : 0.f;
+        if (live) {
+            int pv[NRES];
+            float gv[NRES];
+#pragma unroll
+            for (int k = 0; k < NRES; ++k) {                // every argmax and gradient of the super-chunk: one round trip
+                const int i = lane + 64 * k, d = i / 3;
+                const int64_t n = c0 + (d < nd ? d : 0);
+                pv[k] = argmax[n * F + f];
+                gv[k] = gp[n * F + f];
+                if (d >= nd) pv[k] = -1;
+            }
+            long off[NRES];
+#pragma unroll
+            for (int k = 0; k < NRES; ++k) {                // every token id: the next
+                const int i = lane + 64 * k, d = i / 3, j = i - d * 3;
+                const int64_t n = c0 + (d < nd ? d : 0);
+                const int t = pv[k] - 2 + j;
+                const bool on = pv[k] >= 0 && t >= 0 && t < T;
+                const long tok = idx[n * T + (on ? t : 0)];
+                off[k] = on ? tok * E : -1;
+            }
+#pragma unroll
+            for (int k = 0; k < NRES; ++k) {
+                const int i = lane + 64 * k, d = i / 3, j = i - d * 3;
+                if (d < WG_SUPER) {
+                    p_off[wave][d][j] = off[k];
+                    if (j == 0) p_g[wave][d] = pv[k] >= 0 ? gv[k] : 0.f;
+                }
+            }
         }
         __syncthreads();
-        // all WG_CHUNK rows of the round are requested before the first is used (unconditional loads -- a
+        // all WG_CHUNK rows of a round are requested before the first is used (unconditional loads -- a
         // slot without a contribution re-reads row 0 -- and selects instead of branches, in document
         // order: one memory round trip per round instead of four, same bits): NARRE's backward launch
         // 46.9 -> 34.6 us
         if (live && lane < nvec) {
-            wg_f32x4 v[WG_CHUNK];
+            for (int r0 = 0; r0 < nd; r0 += WG_CHUNK) {
+                wg_f32x4 v[WG_CHUNK];
 #pragma unroll
-            for (int d = 0; d < WG_CHUNK; ++d) {
-                const long off = p_off[wave][d][vj];
-                v[d] = *reinterpret_cast<const wg_f32x4 *>(table + (off < 0 ? 0 : off) + ve);
-            }
+                for (int d = 0; d < WG_CHUNK; ++d) {
+                    const long off = p_off[wave][r0 + d][vj];
+                    v[d] = *reinterpret_cast<const wg_f32x4 *>(table + (off < 0 ? 0 : off) + ve);
+                }
 #pragma unroll
-            for (int d = 0; d < WG_CHUNK; ++d) {
-                const wg_f32x4 sum = acc + p_g[wave][d] * v[d];
-                acc = p_off[wave][d][vj] >= 0 ? sum : acc;
+                for (int d = 0; d < WG_CHUNK; ++d) {
+                    const wg_f32x4 sum = acc + p_g[wave][r0 + d] * v[d];
+                    acc = p_off[wave][r0 + d][vj] >= 0 ? sum : acc;
+                }
             }
         }
         if (live && lane == 0)
