@@ -16,7 +16,10 @@ struct WgradArgs {
     int T, E, F, per_split, nsplit;
 };
 
-constexpr int WG_CHUNK = 16;       // documents resolved per phase-1 round
+#ifndef R4R_WG_CHUNK
+#define R4R_WG_CHUNK 16
+#endif
+constexpr int WG_CHUNK = R4R_WG_CHUNK;       // documents resolved per phase-1 round
 
 __device__ __forceinline__ void wgrad_block(const WgradArgs &a, int f, int s, int tower) {
     // Phase 1 resolves, for a chunk of documents at once, the dependent chain
