@@ -53,7 +53,7 @@ WORKLOAD = 'cfg3_deepconn_electronics_e300'
 
 PMC_SUMMARIES = {WORKLOAD: 'r04f_bench_pmc_summary.json',
                  'cfg2_mfdot_electronics': 'r04f_bench_cfg2_pmc_summary.json',
-                 'cfg4_narre_kindle': 'r04f_bench_cfg4_pmc_summary.json',
+                 'cfg4_narre_kindle': 'r04g_bench_cfg4_pmc_summary.json',
                  'cfg5_transnetpp_synthetic': 'r04f_bench_cfg5_pmc_summary.json',
                  # the one true HBM gather: full-length documents of uniformly drawn words at a 1 M-word vocabulary
                  ('cfg5_transnetpp_synthetic', 'full', 'uniform'): 'r04f_cfg5_fullunif_pmc_summary.json'}
