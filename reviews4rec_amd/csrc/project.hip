@@ -1410,6 +1410,9 @@ static_assert(SLICE == 32 || SLICE == 16, "a worker is 32 lanes; eight workers p
 #ifndef R4R_GATHER_SPLIT
 #define R4R_GATHER_SPLIT 0              // (1: a workgroup's two segments half a document apart -- measured neutral, round 4)
 #endif
+#ifndef R4R_GPIPE
+#define R4R_GPIPE 0
+#endif
 #ifndef R4R_GDEPTH
 #define R4R_GDEPTH 7
 #endif
@@ -1450,13 +1453,18 @@ __global__ __launch_bounds__(256) void proj_gather_max_kernel(ProjArgs a) {
     // one of each.  Same work, same outputs -- and the same time (cfg3 20.9 against 20.6 us, cfg5 32.3 / 32.4: a
     // worker's five dependent rounds take ~3 us each whatever its neighbours do; R4R_GATHER_SPLIT=1 builds it).
     // Likewise 16-position slices (R4R_GSLICE=16: three rounds per worker, twice the workgroups): cfg3 22.0-23.5 us,
-    // cfg5 38-39.5 against 32.
+    // cfg5 38-39.5 against 32.  R4R_GATHER_SPLIT=2 (the heavy half alternating between the workgroups that share a CU)
+    // and a software-pipelined group loop (R4R_GPIPE=1, groups of 2 .. 5 tokens) measured the same or slower as well
+    // (profiles/r04d_sweep_ab.txt 9, 14): the launch has stayed at 20.5 us under every restructuring of its schedule.
     const int64_t units = a.N * a.tiles;
     auto unit_of = [&](int h) -> int64_t {
         if (!split) return bx * GSPW + h;
         const int t2 = a.tiles >> 1;
         const int64_t d = bx / t2;
-        return d * a.tiles + (bx - d * t2) + (int64_t)h * t2;
+        // (which half of the workgroup's waves takes the document's first half alternates between the workgroups that
+        // share a CU -- blocks 256 apart: waves 0-1 of every workgroup land on SIMDs 0-1)
+        const int hh = R4R_GATHER_SPLIT == 2 ? (h ^ (int)((blockIdx.x >> 8) & 1)) : h;
+        return d * a.tiles + (bx - d * t2) + (int64_t)hh * t2;
     };
     const int64_t unit = unit_of(worker / GWPS);
     const int64_t doc = unit < units ? unit / a.tiles : 0;
@@ -1518,8 +1526,8 @@ __global__ __launch_bounds__(256) void proj_gather_max_kernel(ProjArgs a) {
         const f32x4 h00 = load_row(s0, 0), h11 = load_row(s1, 1), h10 = load_row(s1, 0);
         const int npos = npos_eff;                           // positions p_lo .. <-> tokens 2 ..; 1 if the slice is uniform
         bool seeded = false;
-        for (int k = 0; k < npos; k += GDEPTH) {
-            f32x4 r0[GDEPTH], r1[GDEPTH], r2[GDEPTH];
+        // a group of GDEPTH tokens: its three tap rows each, requested together (clamped: no branch)
+        auto loadg = [&](int k, f32x4 (&r0)[GDEPTH], f32x4 (&r1)[GDEPTH], f32x4 (&r2)[GDEPTH]) {
 #pragma unroll
             for (int u = 0; u < GDEPTH; ++u) {
                 const int s = (k + u < npos) ? sl[worker][2 + k + u] : -1;
@@ -1527,6 +1535,8 @@ __global__ __launch_bounds__(256) void proj_gather_max_kernel(ProjArgs a) {
                 r1[u] = load_row(s, 1);
                 r2[u] = load_row(s, 2);
             }
+        };
+        auto compg = [&](int k, const f32x4 (&r0)[GDEPTH], const f32x4 (&r1)[GDEPTH], const f32x4 (&r2)[GDEPTH]) {
             if (!seeded) { s_a = h00 + h11; s_b = h10; seeded = true; }
 #pragma unroll
             for (int u = 0; u < GDEPTH; ++u) {
@@ -1540,7 +1550,29 @@ __global__ __launch_bounds__(256) void proj_gather_max_kernel(ProjArgs a) {
                     s_b = r0[u];
                 }
             }
+        };
+#if R4R_GPIPE
+        // software pipeline: the NEXT group's rows are requested before this group's positions are evaluated.  The waves
+        // of a launch start together and walk their slices in step: unpipelined, every SIMD waited out each round's
+        // memory latency and then had all its waves' arithmetic at once (tools/head_trace.py --gather: a full slice
+        // five rounds of ~3 us).  Two register buffers, named (a run-time buffer index would go through scratch).
+        f32x4 a0[GDEPTH], a1[GDEPTH], a2[GDEPTH], b0[GDEPTH], b1[GDEPTH], b2[GDEPTH];
+        if (npos > 0) loadg(0, a0, a1, a2);
+        for (int k = 0; k < npos; k += 2 * GDEPTH) {
+            if (k + GDEPTH < npos) loadg(k + GDEPTH, b0, b1, b2);
+            compg(k, a0, a1, a2);
+            if (k + GDEPTH < npos) {
+                if (k + 2 * GDEPTH < npos) loadg(k + 2 * GDEPTH, a0, a1, a2);
+                compg(k + GDEPTH, b0, b1, b2);
+            }
         }
+#else
+        for (int k = 0; k < npos; k += GDEPTH) {
+            f32x4 r0[GDEPTH], r1[GDEPTH], r2[GDEPTH];
+            loadg(k, r0, r1, r2);
+            compg(k, r0, r1, r2);
+        }
+#endif
     }
     if (act) {
 #pragma unroll
