@@ -167,7 +167,7 @@ def _mf_worker(rank, world, port, case, out_dir):
         kw = dict(next_data=shards[step + 1][0] if step < 2 else None, defer_sweep=True) if defer else {}
         ses.append(eng.train_step(sd, sy, n_global=int(y.shape[0]) if step != 1 else None, **kw).cpu().clone())
         if defer and step == 0:
-            assert eng._tb_period > 1                        # (the schedule is in force from the first step on)
+            assert eng._tb_period == eng.sweep_period        # (the schedule is in force from the first step on)
     if defer:
         eng.flush()
     torch.save({'w': {k: v.detach().cpu() for k, v in model.state_dict().items()}, 'se': ses},
