@@ -1518,6 +1518,9 @@ __global__ __launch_bounds__(256) void proj_gather_max_kernel(ProjArgs a) {
         // halo: tokens t_lo and t_lo+1 only seed the sliding sums (tap 0 of t_lo, taps 1 and 0 of
         // t_lo+1): three loads issued together with the first group, not a round of their own
         auto load_row = [&](int s, int tap) {
+#ifdef R4R_GATHER_ABL                                       // timing only (wrong results): every XCD reads a window of R4R_GATHER_ABL rows of its own
+            if (s >= 0) s = s % R4R_GATHER_ABL + (int)((blockIdx.y * gridDim.x + blockIdx.x) & 7) * R4R_GATHER_ABL;
+#endif
             const float *row = base + (size_t)(s < 0 ? 0 : s) * PSTR + tap * PF;   // clamped: no branch
             const f32x4 v = *reinterpret_cast<const f32x4 *>(row);
             return s < 0 ? zero : v;
