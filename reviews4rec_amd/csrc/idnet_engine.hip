@@ -361,7 +361,7 @@ extern "C" size_t r4r_idnet_ws_bytes(int variant, int64_t B, int L, int64_t n_us
 }
 
 // which: 0 dropout multipliers [B, draws]; 1 d loss / d pred [B]; 2 the persistent head's size; 3 the int the
-// temporally blocked sweeps set when a batch was not the announced one;
+// temporally blocked sweeps set if more updates were ever pending than a visit applies (a broken schedule);
 // 4 + 2 * pair + side: compact gradient rows [B, L] of that ID table
 extern "C" size_t r4r_idnet_ws_offset(int variant, int64_t B, int L, int64_t n_users, int64_t n_items, int which) {
     const IdnWs w = idn_carve(reinterpret_cast<void *>(256), variant, B, L, n_users, n_items);

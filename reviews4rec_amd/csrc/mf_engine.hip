@@ -1289,7 +1289,7 @@ extern "C" int r4r_mf_rows_flush(const uint64_t *p, const uint64_t *m, const uin
                                 nullptr, nullptr, w.tag_u, w.tag_i, w.ctag_u, w.ctag_i, 0, (int)adam_step, sc, as_stream(stream), &tb);
 }
 
-// offset of the int the temporally blocked sweep sets when a batch was not the announced one
+// offset of the int the temporally blocked sweep sets if more updates were ever pending than a visit applies
 extern "C" size_t r4r_mf_ws_flag_offset(int64_t B, int D, int64_t n_users, int64_t n_items) {
     const MfWs w = mf_carve(reinterpret_cast<void *>(256), B, D, n_users, n_items);
     return (size_t)(reinterpret_cast<char *>(w.tb_err) - reinterpret_cast<char *>(256));

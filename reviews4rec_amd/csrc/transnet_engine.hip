@@ -438,7 +438,7 @@ extern "C" size_t r4r_transnet_ws_bytes(int64_t B, int T, int E, int L, int plus
 // which: 0 dropout multipliers [B, 5L + 10]; 1 / 2 compact gradient rows of the user / item ID vectors
 // [B, 5]; 3 the per-rating auxiliary outputs [B, 3]; 4 the SIZE of the persistent head of the workspace
 // (row and chunk tags, the temporally blocked sweep's pending counts: zero once, carry over when switching
-// buffers); 5 the int the sweep sets when a batch was not the announced one; 6 + 2 * tower + buffer: a token
+// buffers); 5 the int the sweep sets if more updates were ever pending than a visit applies; 6 + 2 * tower + buffer: a token
 // buffer's counter (towers 0 user, 1 item, 2 this review)
 extern "C" size_t r4r_transnet_ws_offset(int64_t B, int T, int E, int L, int plus, int64_t V, int64_t n_users,
                                          int64_t n_items, int which) {

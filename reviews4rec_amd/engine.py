@@ -93,6 +93,11 @@ class _SweepSchedule:
         if want > 1:
             self._tb_used = True
 
+    def check_schedule(self):
+        """Read the sweeps' device-side flag (one int): raises if more updates were ever pending than a visit applies.
+        (`check_announcements` is the same call under its round-3 name.)"""
+        return self.check_announcements()
+
     def _pending(self, last_step=None):
         """the last completed step, if the tables may be behind it (else None)"""
         step = int(self.step_count if last_step is None else last_step)
