@@ -286,8 +286,11 @@ __host__ __device__ inline int backward_cs_slices(int cs_blocks, int wgs_per_sli
 // WIDE: the generic wgrad (3E/4 > 64 float4: wgrad_block) instead of the packed one-wave-per-filter form.  Without
 // an ID-table role that variant fits 64 VGPRs -- 8 waves per SIMD, every workgroup of a DeepCoNN++ launch resident
 // (13.7 -> 11.0 us); the packed form spills at that cap (its workgroups went 4.6 -> 7.2 us) and keeps 4.
+#ifndef R4R_BWD_WAVES
+#define R4R_BWD_WAVES 4                 // waves per SIMD the backward launch is allocated for (A/B: 5, 6)
+#endif
 template <int ML, bool WIDE = false>
-__global__ __launch_bounds__(WG_THREADS, ML > 16 ? 2 : (ML == 0 && WIDE ? 8 : 4)) void narre_backward_kernel(WgradArgs w, ColSum c, int cs_blocks, TokenArgs nx,
+__global__ __launch_bounds__(WG_THREADS, ML > 16 ? 2 : (ML == 0 && WIDE ? 8 : R4R_BWD_WAVES)) void narre_backward_kernel(WgradArgs w, ColSum c, int cs_blocks, TokenArgs nx,
                                                                     int packed, RowSweep rows, int row_blocks, int ntower) {
     const int blk0 = blockIdx.y * gridDim.x + blockIdx.x, nblk = gridDim.x * gridDim.y;
     BWD_STAMP(0, wall_clock64())
