@@ -46,6 +46,41 @@ def test_mf_step_at_cfg2_cardinalities(B):
         torch.testing.assert_close(sd[k].cpu(), v, rtol=1e-5, atol=5e-6, msg=lambda m: k + ': ' + m)
 
 
+def test_scheduled_sweep_at_cfg2_cardinalities_against_the_oracle():
+    """The scheduled temporally blocked sweep DIRECTLY against the oracle's dense Adam (not through the plain engine):
+    cfg2's tables, B = 128, eleven steps with defer_sweep=True at period 4 -- chunks are visited on the schedule, the rows
+    later batches name catch up in the forward and in their entry waves (a row is named again three and seven steps
+    after its first touch) -- per-step SSE with the device's dropout masks injected, then all 16.6 M parameters."""
+    import reviews4rec_amd
+    from reviews4rec_amd import synthetic
+    from reviews4rec_amd.engine import MFEngine
+    hp = dict(synthetic.hyper_params_for('cfg2_mfdot_electronics', dropout=0.5), sweep_period=4)
+    D, B = hp['latent_size'], 128
+    P = oracle.init_params(hp, seed=29)
+    model = reviews4rec_amd.get_model_class('MF_dot')(hp)
+    model.load_state_dict(P)
+    model = model.to(DEV).train()
+    eng = MFEngine(model, lr=hp['lr'], weight_decay=hp['weight_decay'])
+    if eng.sweep_period != 4:
+        pytest.skip('R4R_SWEEP_PERIOD overrides the period this test is written for')
+    gen = synthetic.Generator(hp, seed=7)
+    state = oracle.AdamState()
+    for step in range(11):
+        data, y = gen.batch(B)
+        uid, iid, y = torch.from_numpy(data[5]), torch.from_numpy(data[6]), torch.from_numpy(y)
+        if step in (0, 3, 7):
+            uid[5], iid[9] = 12345, hp['total_items'] - 1              # the same rows again, several steps apart
+        se = eng.train_step([None] * 5 + [uid.to(DEV), iid.to(DEV)], y.to(DEV), defer_sweep=True).cpu().clone()
+        assert step == 0 or eng._tb_base < eng.step_count               # on the schedule: updates are pending
+        mult = eng.dropout_multipliers(B).cpu()
+        masks = {'dropout.user': mult[:, :D], 'dropout.item': mult[:, D:]}
+        sse, _ = oracle.train_step(P, [None] * 5 + [uid, iid], y, hp, state, masks=masks)
+        torch.testing.assert_close(se.sum(), torch.tensor(sse), rtol=1e-4, atol=1e-3)
+    sd = model.state_dict()                                             # (flushes through the hook)
+    for k, v in P.items():
+        torch.testing.assert_close(sd[k].cpu(), v, rtol=1e-5, atol=5e-6, msg=lambda m: k + ': ' + m)
+
+
 def test_transnet_step_at_cfg5_cardinalities():
     """cfg5 (TransNet++, 10 M users / 1 M items / 1 M words, E = 64, T = 1000, B = 128): one training step of the
     native engine against the oracle's literal three-optimiser step.  Per-rating source SE, the two auxiliary
