@@ -48,6 +48,7 @@ import torch
 PEAK_FP32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, dense
 PEAK_F16_MFMA_TFLOPS = 2500.0     # MI355X_MICROARCH.md: dense fp16 / bf16 MFMA (no sparsity)
 PEAK_HBM_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E spec peak (6.3 TB/s measured achievable)
+PEAK_L2_GBS = 34500.0             # MI355X_MICROARCH.md: L2, 4 MiB per XCD, aggregate over the 8 XCDs
 WORKLOAD = 'cfg3_deepconn_electronics_e300'
 
 
@@ -104,6 +105,11 @@ def parse():
     ap.add_argument('--cpu-seconds', type=float, default=12.0,
                     help='budget of each half (thread calibration, measurement) of the cpu_baseline leg')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-config-legs', action='store_true',
+                    help='N = 1 default line: skip the separately timed legs of the other BASELINE.json configurations '
+                         '(--no-cpu-baseline, the A/B scripts\' quick mode, skips them too unless --config-legs is given)')
+    ap.add_argument('--config-legs', action='store_true', help='time the configuration legs even with --no-cpu-baseline')
+    ap.add_argument('--leg-steps', type=int, default=200, help='timed steps of each configuration leg')
     ap.add_argument('--no-steady-leg', action='store_true',
                     help='short regions (--steps < 50): skip the appended 200-step steady leg')
     ap.add_argument('--no-kernel-timing', action='store_true',
@@ -161,6 +167,86 @@ def tower_flops_per_doc(hp):
     P positions x F filters x 3E window x 2."""
     P = hp['input_length'] + 2
     return P * 100 * 3 * hp['word_embed_size'] * 2
+
+
+def walked_positions(tokens):
+    """(positions the gather-add-max launch walks, positions in all) for the documents `tokens` [..., T]: the launch
+    cuts the T + 2 conv positions of a document into slices of 32; a slice whose tokens p_lo - 2 .. p_hi - 1 all name
+    the same row (out-of-range tokens count as a row of their own) is decided by its first position
+    (csrc/project.hip, proj_gather_max_kernel: `same`, `npos_eff`)."""
+    tok = np.asarray(tokens).reshape(-1, np.asarray(tokens).shape[-1])
+    n, T = tok.shape
+    P = T + 2
+    ext = np.full((n, T + 4), -1, dtype=np.int64)           # ext[:, t + 2] = token t; t = -2, -1, T, T + 1 are out of range
+    ext[:, 2:T + 2] = tok
+    walked = 0
+    for p_lo in range(0, P, 32):
+        p_hi = min(P, p_lo + 32)
+        sl = ext[:, p_lo:p_hi + 2]                           # tokens p_lo - 2 .. p_hi - 1
+        same = (sl == sl[:, :1]).all(axis=1)
+        walked += int(np.where(same, 1, p_hi - p_lo).sum())
+    return walked, n * P
+
+
+# The other BASELINE.json configurations and the data the projection conv does not like, as separately timed legs of
+# the default N = 1 line (never `value`): (label, bench arguments that differ from the headline's)
+CONFIG_LEGS = [
+    ('cfg1_bias_only_musical', dict(workload='cfg1_bias_only_musical')),
+    ('cfg2_mfdot_electronics', dict(workload='cfg2_mfdot_electronics')),
+    ('cfg2_mfdot_electronics_b8192', dict(workload='cfg2_mfdot_electronics', batch_per_gpu=8192)),
+    ('cfg4_narre_kindle', dict(workload='cfg4_narre_kindle')),
+    ('cfg5_transnetpp_synthetic', dict(workload='cfg5_transnetpp_synthetic')),
+    ('cfg3_full_uniform', dict(workload=WORKLOAD, doc_fill='full', token_dist='uniform')),
+    # (the one true HBM gather: 1 M-word vocabulary, full-length documents of uniformly drawn words -- the projected rows
+    # outgrow the Infinity Cache; the engines' measured rule would pick the direct conv here, so the leg pins the projection)
+    ('cfg5_full_uniform_hbm_gather', dict(workload='cfg5_transnetpp_synthetic', doc_fill='full', token_dist='uniform',
+                                          conv_algo='project')),
+]
+
+
+def config_legs_wanted(args, dp_job):
+    """The legs ride on the default single-GPU line only: the headline workload at its default shape and engine."""
+    return (not dp_job and not args.no_config_legs and (args.config_legs or not args.no_cpu_baseline)
+            and args.workload == WORKLOAD and args.engine == 'native'
+            and args.batch_per_gpu == 128 and args.scaling == 'weak' and not args.model_type and not args.embed
+            and not args.latent and not args.from_host and args.doc_fill == 'lognormal' and args.token_dist == 'zipf'
+            and args.gemm_math == 'f32' and args.conv_algo == 'auto')
+
+
+def config_legs(args, env):
+    """Each leg: its own model, engine and resident batch pool, --leg-steps timed steps between the same fences as the
+    headline region, kernel timing sampled the same way.  A leg that fails reports its error and the line survives."""
+    import copy
+    import gc
+    legs = []
+    for label, over in CONFIG_LEGS:
+        a = copy.copy(args)
+        for k, v in over.items():
+            setattr(a, k, v)
+        a.steps, a.warmup = args.leg_steps, 20
+        t0 = time.perf_counter()
+        try:
+            r = run(a, env, is_leg=True)
+        except (Exception, SystemExit) as e:                 # noqa: BLE001  (reported, not raised: the headline line stands)
+            legs.append({'leg': label, 'error': '%s: %s' % (type(e).__name__, str(e)[:300])})
+            continue
+        finally:
+            gc.collect()
+            torch.cuda.empty_cache()
+        out = {'leg': label, 'workload': a.workload, 'batch': r['config']['batch_per_gpu'], 'doc_fill': a.doc_fill,
+               'token_dist': a.token_dist, 'recommender': r['config']['shape']['recommender'],
+               'engine': r['config']['engine'], 'ratings_per_s': r['value'], 'ms_per_step': r['ms_per_step'],
+               'gpu_ms_per_step': r['gpu_ms_per_step'], 'steps': r['steps'], 'warmup': r['warmup'],
+               'kernel_ms': r.get('kernel_ms'), 'leg_wall_s': round(time.perf_counter() - t0, 1)}
+        if 'table_sweep' in r['config']:
+            out['table_sweep'] = r['config']['table_sweep']
+        for k in ('roofline', 'roofline_gather', 'roofline_gemm'):
+            if k in r:
+                out[k] = r[k]
+        if 'roofline' in r:
+            out['dominant_kernel'] = r['roofline']['kernel']
+        legs.append(out)
+    return legs
 
 
 def cpu_baseline(hp, table, batches_np, budget_s):
@@ -245,9 +331,69 @@ def make_engine(args, hp, model, dp, rank, world, B):
     return E.DeepCoNNEngine(model, conv_algo=algo, **kw)
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` with no launcher around it (no RANK / WORLD_SIZE in the environment): replace this
+    process by the N-rank job the driver would have started -- torch.distributed.run, one rank per GPU, static
+    rendezvous on 127.0.0.1 -- so that the bare command is a complete N-GPU run (rank 0 prints the one JSON line).
+    The reference side of this is the single-process loop main.py:401-431; data parallelism is new work."""
+    if args.gpus <= 1 or 'WORLD_SIZE' in os.environ or 'RANK' in os.environ:
+        return
+    check_device_count(args.gpus)
+    import socket
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')      # dmabuf IPC: what the host driver supports
+    os.environ.setdefault('OMP_NUM_THREADS', '4')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stdout.flush()
+    sys.stderr.flush()
+    os.execv(sys.executable, cmd)
+
+
+def check_device_count(n):
+    """One rank per GPU over RCCL needs N visible devices; say so in one line BEFORE any process group exists (ranks that
+    wrap around onto one device hang in ncclCommInitRank instead).  R4R_DIST_BACKEND=gloo is the test rig's several
+    ranks on one GPU and is exempt."""
+    if os.environ.get('R4R_DIST_BACKEND', 'nccl') != 'nccl':
+        return
+    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if n > have:
+        raise SystemExit('bench.py: --gpus %d but %d GPU(s) visible: one rank per GPU over RCCL needs %d devices '
+                         '(R4R_DIST_BACKEND=gloo lets test rigs share one)' % (n, have, n))
+
+
 def main():
     args = parse()
-    from reviews4rec_amd import _lib, dist as r4dist, synthetic
+    self_launch(args)
+    from reviews4rec_amd import _lib, dist as r4dist
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs a GPU: the HIP path has no CPU fallback')
+    world_env = int(os.environ.get('WORLD_SIZE', '1'))
+    if world_env != args.gpus:
+        raise SystemExit('launched with WORLD_SIZE=%d but --gpus %d' % (world_env, args.gpus))
+    if world_env > 1:
+        check_device_count(world_env)
+    rank, world, local = r4dist.init_from_env()
+    # a data-parallel job: N > 1 -- or ONE rank with R4R_DP_SINGLE=1 (tests: the whole N > 1 path over RCCL on one GPU)
+    dp_job = world > 1 or os.environ.get('R4R_DP_SINGLE') == '1'
+    env = dict(rank=rank, world=world, local=local, dp_job=dp_job, dev=torch.device('cuda', local), lib=_lib.lib())
+    result = run(args, env)
+    if rank == 0:
+        if config_legs_wanted(args, dp_job):
+            result['configs'] = config_legs(args, env)
+        if not dp_job and not args.no_cpu_baseline:
+            result['cpu_baseline'] = result.pop('_cpu_baseline_thunk')()
+        result.pop('_cpu_baseline_thunk', None)
+        print(json.dumps(result))
+    if dp_job:
+        torch.distributed.destroy_process_group()
+
+
+def run(args, env, is_leg=False):
+    """One workload, timed: the headline line (is_leg=False) or one of the `configs` legs.  -> rank 0's result dict."""
+    from reviews4rec_amd import synthetic
     import reviews4rec_amd
     from reviews4rec_amd.main import native_step_limits
     from reviews4rec_amd.loss import MSELoss
@@ -256,15 +402,8 @@ def main():
     from reviews4rec_amd.utils import xavier_init
 
     os.environ['R4R_GEMM_MATH'] = args.gemm_math             # read by the engines when they are built
-    rank, world, local = r4dist.init_from_env()
-    # a data-parallel job: N > 1 -- or ONE rank with R4R_DP_SINGLE=1 (tests: the whole N > 1 path over RCCL on one GPU)
-    dp_job = world > 1 or os.environ.get('R4R_DP_SINGLE') == '1'
-    if not torch.cuda.is_available():
-        raise SystemExit('bench.py needs a GPU: the HIP path has no CPU fallback')
-    if world != args.gpus:
-        raise SystemExit('launched with WORLD_SIZE=%d but --gpus %d' % (world, args.gpus))
-    dev = torch.device('cuda', local)
-    lib = _lib.lib()
+    rank, world, dp_job, dev, lib = env['rank'], env['world'], env['dp_job'], env['dev'], env['lib']
+    from reviews4rec_amd import dist as r4dist
 
     strong = args.scaling == 'strong'
     if strong:
@@ -481,10 +620,10 @@ def main():
     # be a visible share of the window (an instrumented step costs ~30 us) -- so its roofline would rest on one
     # launch, and the region itself on a clock that has not settled.  Such a run appends a separately timed STEADY
     # leg: the same step function for 200 more steps between the same fences, every 20th step instrumented.  `value`
-    # stays the requested region's; the roofline legs average the sampled launches of both (counts stated).
+    # and the roofline legs stay the requested region's; the steady leg's launches are reported beside them.
     steady = None
     if (args.steps < 50 and mask and not args.from_host and graphed is None and engine is not None
-            and not args.no_steady_leg):                     # (every rank takes the same branch: the legs' steps are collective)
+            and not args.no_steady_leg and not is_leg):                     # (every rank takes the same branch: the legs' steps are collective)
         STEADY = 200
         el_s = timed_region(step, STEADY, steps_run, mask)
         if hasattr(engine, 'check_announcements'):
@@ -492,20 +631,33 @@ def main():
         steady = {'steps': STEADY, 'ratings_per_s': round(STEADY * B_global / el_s, 1),
                   'ms_per_step': round(1000.0 * el_s / STEADY, 4), 'gpu_ms_per_step': round(gpu_span_ms[0] / STEADY, 4),
                   'note': 'the same step function, %d more steps between the same fences right after the timed region '
-                          '(never `value`); its sampled launches are averaged into the roofline legs' % STEADY}
+                          '(never `value`); its sampled launches are reported beside the roofline legs (steady_*), not pooled in' % STEADY}
         steps_run += STEADY
         leg_slots = read_slots()
         steady['kernel_ms'] = {k: round(v[0] / v[1], 4) for k, v in leg_slots.items()}
-        for k, (tot, cnt) in leg_slots.items():
-            t0, c0 = region_slots.get(k, (0.0, 0))
-            region_slots[k] = (t0 + tot, c0 + cnt)
-    timed = {k: (tot / cnt, cnt) for k, (tot, cnt) in region_slots.items()}   # (avg ms per launch, launches)
+        steady['kernel_launches_sampled'] = {k: v[1] for k, v in leg_slots.items()}
+        steady_slots = leg_slots
+    else:
+        steady_slots = {}
+    # The roofline legs rest on the launches sampled INSIDE the requested region (the region `value` comes from); the
+    # steady leg's launches are reported beside them (`steady_avg_launch_ms`, `steady_frac`), never pooled in.  A kernel
+    # the region did not sample at all (it cannot happen with the sampling above) falls back to the steady leg's.
+    timed = {k: (tot / cnt, cnt) for k, (tot, cnt) in {**steady_slots, **region_slots}.items()}   # (avg ms per launch, launches)
+
+    def steady_of(kernel, leg_dict, scale_key='frac'):
+        """Attach the steady leg's reading of the same kernel to a roofline leg."""
+        if kernel in steady_slots and kernel in region_slots:
+            tot, cnt = steady_slots[kernel]
+            leg_dict['steady_avg_launch_ms'] = round(tot / cnt, 4)
+            leg_dict['steady_launches'] = cnt
+            if leg_dict.get(scale_key) is not None and leg_dict.get('avg_launch_ms'):
+                leg_dict['steady_' + scale_key] = round(leg_dict[scale_key] * leg_dict['avg_launch_ms'] / (tot / cnt), 4)
     run_sse = float(engine.sse[0].item()) if engine is not None else (
         float(graphed.sse.item()) if graphed is not None else float(metric_sum.item()))
 
     # N > 1, weak: separately timed strong-scaling legs, each at a fixed global batch sharded over the ranks
     strong_legs = []
-    if dp_job and not strong and not args.from_host and graphed is None:
+    if dp_job and not strong and not args.from_host and graphed is None and not is_leg:
         for G in [int(x) for x in str(args.strong_leg).split(',') if x.strip()]:
             if G % world:
                 continue
@@ -575,8 +727,8 @@ def main():
         value = args.steps * B_global / elapsed
         result = {
             'metric': 'train ratings/sec', 'value': round(value, 1), 'unit': 'ratings/s',
-            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'warmup_requested': args.warmup,
-            'warmup_effective': ramp + args.warmup,       # --ramp untimed steps at least (clock ramp, see above)
+            # `warmup` is what RAN untimed before the region: the requested warm-up, raised to --ramp steps (clock ramp, above)
+            'n_gpus': world, 'steps': args.steps, 'warmup': ramp + args.warmup, 'warmup_requested': args.warmup,
             'ms_per_step': round(1000.0 * elapsed / args.steps, 4),
             'gpu_ms_per_step': round(gpu_ms_per_step, 4),     # HIP events around the same steps (rank 0's device)
             'higher_is_better': True, 'scaling': 'strong' if strong else 'weak', 'vs_baseline': None,
@@ -654,21 +806,44 @@ def main():
             # the PMC passes counted, with NO fraction of an HBM peak.  Only a vocabulary whose projected
             # rows outgrow the 256 MB Infinity Cache (cfg5: 1 M words) makes this a true HBM gather.
             avg_s = timed['proj_gather_max_kernel'][0] / 1000.0
-            nbytes = towers * B * hp['input_length'] * (8 + 1200)
+            # What the launch WALKS (csrc/project.hip, gather-add-max): a 32-position slice whose 34 tokens are all the same
+            # row -- the zero-padded tail of a document, data.py:198-199 -- is decided by its first position alone, so only
+            # the walked positions load their three 400-byte tap rows; every position's token id (8 B) and row slot (4 B)
+            # are read regardless.  Counted on the host from the very batches that were run.
+            walked, total = [], []
+            for d, _ in batches_np:
+                w_t = [walked_positions(d[k]) for k in ((3, 4, 0) if is_tn else (3, 4))]
+                walked.append(sum(w[0] for w in w_t) * (towers / len(w_t)))
+                total.append(sum(w[1] for w in w_t) * (towers / len(w_t)))
+            walked, total = float(np.mean(walked)), float(np.mean(total))
+            tokens = towers * B * (hp['narre_num_reviews'] * hp['narre_num_words'] if hp['model_type'] == 'NARRE'
+                                   else hp['input_length'])
+            nbytes = int(walked * 1200 + tokens * 12)
             ach_b = nbytes / avg_s / 1e9
             g_traffic, g_src = measured_traffic('proj_gather_max_kernel', args, avg_s)
-            ptab_bytes = rows * 1200
+            ptab_bytes = rows * 1216                          # (rows are stored at a 1,216-byte stride)
             leg = {'kernel': 'proj_gather_max_kernel', 'achieved': round(ach_b, 1), 'unit': 'GB/s',
-                   'avg_launch_ms': round(1000 * avg_s, 4), 'bytes_per_launch': nbytes,
+                   'avg_launch_ms': round(1000 * avg_s, 4), 'launches': timed['proj_gather_max_kernel'][1],
+                   'bytes_per_launch': nbytes, 'positions_per_launch': int(total),
+                   'walked_positions_per_launch': int(walked),
+                   'bytes_note': 'walked positions x 1,200 B (three tap rows) + every token x 12 B (id + row slot); positions '
+                                 'of uniform slices are not walked and not counted',
                    'traffic': g_traffic, 'traffic_source': g_src, 'projected_rows_bytes': int(ptab_bytes)}
             if ptab_bytes > 256e6:
-                leg.update({'bound': 'hbm', 'peak': PEAK_HBM_GBS, 'frac': round(ach_b / PEAK_HBM_GBS, 4)})
-            else:
-                leg.update({'bound': 'l2/mall', 'peak': None, 'frac': None,
+                # the projected rows outgrow the 256 MB Infinity Cache: a true HBM gather.  frac = walked bytes against
+                # the HBM peak; hbm_side_frac = what the PMC passes counted crossing HBM against the same peak
+                leg.update({'bound': 'hbm', 'peak': PEAK_HBM_GBS, 'frac': round(ach_b / PEAK_HBM_GBS, 4),
                             'hbm_side_GBs': None if g_traffic is None else round(g_traffic / avg_s / 1e9, 1),
-                            'note': 'algorithmic load bandwidth out of L2 / Infinity Cache (projected rows are '
-                                    'cache resident); hbm_side_GBs = PMC-counted HBM bytes / launch time'})
+                            'hbm_side_frac': None if g_traffic is None else round(g_traffic / avg_s / 1e9 / PEAK_HBM_GBS, 4)})
+            else:
+                leg.update({'bound': 'l2/mall', 'peak': PEAK_L2_GBS, 'frac': round(ach_b / PEAK_L2_GBS, 4),
+                            'hbm_side_GBs': None if g_traffic is None else round(g_traffic / avg_s / 1e9, 1),
+                            'note': 'load bandwidth of the walked positions out of L2 / Infinity Cache (the projected rows '
+                                    'are cache resident) against the guide\'s aggregate L2 figure; hbm_side_GBs = '
+                                    'PMC-counted HBM bytes / launch time'})
+            steady_of('proj_gather_max_kernel', leg)
             result['roofline_gather'] = leg
+            steady_of('proj_gemm_kernel', result['roofline'])
             result['conv_equivalent'] = {
                 'note': 'SURVEY 8d algorithmic conv flops (2 towers x P x 100 x 3E x 2 per rating) / (gemm + gather '
                         'time): what a direct conv would have to sustain to match',
@@ -689,6 +864,7 @@ def main():
                                       'avg_launch_ms': round(1000 * avg_s, 4), 'bytes_per_launch': int(nparam * 24),
                                       'parameters': int(nparam)}
                 blocked_sweep_leg(result['roofline'], engine, traffic, avg_s)
+                steady_of('adam_multi_kernel', result['roofline'], 'achieved')
         elif 'textcnn_fwd_kernel' in timed and hp.get('vocab'):
             flops = towers * B * tower_flops_per_doc(hp)
             avg_s = timed['textcnn_fwd_kernel'][0] / 1000.0
@@ -712,13 +888,14 @@ def main():
                                   'launches': timed['adam_multi_kernel'][1], 'avg_launch_ms': round(1000 * avg_s, 4),
                                   'bytes_per_launch': int(nparam * per), 'parameters': int(nparam)}
             blocked_sweep_leg(result['roofline'], engine, traffic, avg_s)
-        if not dp_job and not args.no_cpu_baseline:
+        if not is_leg:                                       # (runs after the config legs: main())
             cpu_hp = {k: v for k, v in hp.items() if k != 'word_vectors'}
-            result['cpu_baseline'] = cpu_baseline(cpu_hp, table, batches_np[:4], args.cpu_seconds)
+            result['_cpu_baseline_thunk'] = lambda: cpu_baseline(cpu_hp, table, batches_np[:4], args.cpu_seconds)
         result['train_mse_running'] = round(run_sse / (steps_run * B), 4)
-        print(json.dumps(result))
-    if dp_job:
-        torch.distributed.destroy_process_group()
+        gc.unfreeze()
+        return result
+    gc.unfreeze()
+    return None
 
 
 if __name__ == '__main__':

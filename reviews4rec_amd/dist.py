@@ -50,6 +50,11 @@ def init_from_env(backend=None):
     return rank, world, local
 
 
+class AgreedFailure(RuntimeError):
+    """A set-up failure EVERY rank of the group raises together (the ranks agreed on it over the process group): the
+    caller may return without another collective.  Any other exception out of StreamRccl() is one rank's own."""
+
+
 class StreamRccl:
     """A RCCL communicator of this package's own, called through ctypes ON THE CALLER'S STREAM.
 
@@ -104,7 +109,7 @@ class StreamRccl:
             box = [bytes(bytearray(uid.internal)) if rc == 0 else None]
         dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
         if box[0] is None:                                   # (every rank sees the same box: a collective decision)
-            raise RuntimeError('RCCL ncclGetUniqueId failed on rank 0')
+            raise AgreedFailure('RCCL ncclGetUniqueId failed on rank 0')
         ctypes.memmove(ctypes.byref(uid), box[0], 128)
         comm, done = ctypes.c_void_p(), {}
         dev = torch.cuda.current_device()
@@ -129,7 +134,7 @@ class StreamRccl:
             self.comm = comm
         try:
             self._agree(group, err)
-        except RuntimeError:
+        except AgreedFailure:
             self.close()
             raise
 
@@ -139,9 +144,9 @@ class StreamRccl:
         flag = torch.tensor([0 if err else 1], dtype=torch.int32, device=dev)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
         if err:
-            raise RuntimeError('StreamRccl: ' + err)
+            raise AgreedFailure('StreamRccl: ' + err)
         if int(flag.item()) == 0:
-            raise RuntimeError('StreamRccl: another rank failed to set the communicator up')
+            raise AgreedFailure('StreamRccl: another rank failed to set the communicator up')
 
     def _check(self, rc, what):
         if rc != 0:
@@ -323,12 +328,12 @@ class DataParallel:
             want = torch.arange(comm.world, device=dev, dtype=torch.float32).repeat_interleave(256)
             if not (bool((t == comm.world * (comm.world + 1) / 2).all()) and torch.equal(g, want)):
                 ok, why = 0, 'a collective returned wrong values'
-        except Exception as e:                               # noqa: BLE001 -- whatever went wrong, every rank must hear of it
+        except AgreedFailure as e:                           # every rank raised this together: no further agreement needed
+            warnings.warn('reviews4rec_amd.dist: the on-stream RCCL communicator is not usable here (%s); using '
+                          "torch.distributed's collectives" % e, RuntimeWarning)
+            return None
+        except Exception as e:                               # noqa: BLE001 -- this rank's own failure: every rank must hear of it
             ok, why = 0, '%s: %s' % (type(e).__name__, e)
-            if comm is None:                                 # StreamRccl() raised: its own agreements already made
-                warnings.warn('reviews4rec_amd.dist: the on-stream RCCL communicator is not usable here (%s); using '
-                              "torch.distributed's collectives" % why, RuntimeWarning)   # every rank raise together there
-                return None
         flag = torch.tensor([ok], device='cuda', dtype=torch.int32)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
         if int(flag.item()) == 1:

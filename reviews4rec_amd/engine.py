@@ -42,6 +42,41 @@ def apply_gemm_math(table, conv_weights=()):
     return mode
 
 
+def step_or_nothing(fn):
+    """train_step decorator: a step that RAISES (a shard larger than batch_size, a batch-cap check of the C entry point,
+    no memory for the workspace -- all raised before anything is launched) must not consume its step number.  The
+    temporally blocked sweeps count pending gradient-zero Adam updates from step_count, so a number consumed by a step
+    that never ran became one weight-decay / moment-decay update of the ID tables that dense Adam never made."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapped(self, *args, **kw):
+        before = self.step_count
+        try:
+            return fn(self, *args, **kw)
+        except BaseException:
+            self.step_count = before
+            raise
+    return wrapped
+
+
+def load_named_moments(who, m, v, sd):
+    """Copy a checkpoint's per-parameter Adam moments into the engine's views -- after checking every one of them (a
+    missing name or a size mismatch raises before anything was written: a rejected checkpoint leaves the engine as it
+    was).  -> the checkpoint's scalar state (step, dropout_offset, lr, weight_decay, betas, eps)."""
+    scalars = (int(sd['step']), int(sd['dropout_offset']), float(sd['lr']), float(sd['weight_decay']),
+               tuple(sd['betas']), float(sd['eps']))
+    for k in m:
+        for mine, theirs in ((m[k], sd['exp_avg'][k]), (v[k], sd['exp_avg_sq'][k])):
+            if theirs.numel() != mine.numel():
+                raise ValueError('%s.load_state_dict: %s has %d moment elements, the model %d'
+                                 % (who, k, theirs.numel(), mine.numel()))
+    for k in m:
+        m[k].copy_(sd['exp_avg'][k].to(m[k].device).view_as(m[k]))
+        v[k].copy_(sd['exp_avg_sq'][k].to(v[k].device).view_as(v[k]))
+    return scalars
+
+
 def pad4(E):
     return (int(E) + 3) // 4 * 4
 
@@ -418,6 +453,7 @@ class DeepCoNNEngine(_ConvRule):
             self._rule_decide([ws[a:a + 8] for a in at], 2 * n, T)
         return pred, se
 
+    @step_or_nothing
     @torch.no_grad()
     def train_step(self, data, y, n_global=None, next_data=None):
         """One optimisation step on this rank's shard.  Returns the per-example SE tensor
@@ -487,11 +523,30 @@ class DeepCoNNEngine(_ConvRule):
             return {}
         scratch = [torch.zeros_like(self.flat_p) for _ in range(4)]
         keep, res = self.exchange, {}
-        for how in ('allreduce', 'gather'):
+
+        def agreed_ok(ok):
+            f = torch.tensor([1 if ok else 0], dtype=torch.int32, device=self.dev)
+            torch.distributed.all_reduce(f, op=torch.distributed.ReduceOp.MIN, group=self.dp.group)
+            return int(f.item()) == 1
+
+        def wait(limit_s):
+            """Drain the stream with a deadline: a candidate whose collective never ends must not park this thread."""
+            import time
+            ev = torch.cuda.Event()
+            ev.record()
+            deadline = time.monotonic() + limit_s
+            while not ev.query():
+                if time.monotonic() > deadline:
+                    raise RuntimeError('autotune_exchange: the %r exchange did not finish within %.0f s on this fabric; pin '
+                                       'the other one with R4R_DP_EXCHANGE, or R4R_DP_RCCL=0 for torch.distributed\'s '
+                                       'collectives' % (self.exchange, limit_s))
+                time.sleep(0.0005)
+
+        def time_one(how):
             self.exchange = how
             for _ in range(3):
                 self._exchange_and_update(*scratch, 1)
-            torch.cuda.synchronize(self.dev)
+            wait(float(os.environ.get('R4R_RCCL_CHECK_TIMEOUT', 30.0)))
             torch.distributed.barrier(group=self.dp.group)
             t0 = torch.cuda.Event(enable_timing=True)
             t1 = torch.cuda.Event(enable_timing=True)
@@ -499,11 +554,41 @@ class DeepCoNNEngine(_ConvRule):
             for _ in range(trials):
                 self._exchange_and_update(*scratch, 1)
             t1.record()
-            torch.cuda.synchronize(self.dev)
-            t = torch.tensor([t0.elapsed_time(t1) / trials], dtype=torch.float64, device=self.dev)
-            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX, group=self.dp.group)
-            res[how] = float(t.item())
-        self.exchange = keep if os.environ.get('R4R_DP_EXCHANGE') else min(res, key=res.get)
+            wait(float(os.environ.get('R4R_RCCL_CHECK_TIMEOUT', 30.0)))
+            return t0.elapsed_time(t1) / trials
+
+        def candidates():
+            out = {}
+            for how in ('allreduce', 'gather'):
+                # a candidate that RAISES on any rank is dropped on every rank (the agreement below is the only
+                # collective a failed rank still joins for it)
+                try:
+                    ms, err = time_one(how), None
+                except Exception as e:                       # noqa: BLE001
+                    ms, err = float('inf'), '%s: %s' % (type(e).__name__, e)
+                if not agreed_ok(err is None):
+                    import warnings
+                    warnings.warn('autotune_exchange: the %r exchange failed here (%s); dropped on every rank'
+                                  % (how, err or 'another rank reported it'), RuntimeWarning)
+                    continue
+                t = torch.tensor([ms], dtype=torch.float64, device=self.dev)
+                torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX, group=self.dp.group)
+                out[how] = float(t.item())
+            return out
+
+        res = candidates()
+        if not res and getattr(self.dp, 'stream_rccl', None) is not None:
+            # neither form works through the package's own communicator: every rank drops it together and the
+            # exchange goes through torch.distributed's collectives (the same sums on the group's own stream)
+            import warnings
+            warnings.warn("autotune_exchange: both exchange forms failed on the on-stream communicator; using "
+                          "torch.distributed's collectives", RuntimeWarning)
+            self.dp.stream_rccl = None
+            res = candidates()
+        if not res:
+            self.exchange = keep
+            raise RuntimeError('autotune_exchange: no gradient exchange form works on this job (see the warnings above)')
+        self.exchange = keep if (os.environ.get('R4R_DP_EXCHANGE') and keep in res) else min(res, key=res.get)
         return res
 
     def check_exchange(self):
@@ -733,6 +818,7 @@ class MFEngine(_SweepSchedule):
         # (this rank's share of the running metric -- the host loop sums the ranks -- rode on r4r_mf_apply)
         return se[:n]
 
+    @step_or_nothing
     @torch.no_grad()
     def train_step(self, data, y, n_global=None, next_data=None, defer_sweep=False):
         """One optimisation step.  Returns the per-example SE tensor (device); the running sum is
@@ -801,14 +887,11 @@ class MFEngine(_SweepSchedule):
                 'betas': self.betas, 'eps': self.eps}
 
     def load_state_dict(self, sd):
-        self._tb_base = self.step_count                      # (what is pending is discarded with the state it belongs to)
+        # validate FIRST: a rejected checkpoint must leave the engine as it was -- its sweep schedule included (what is
+        # pending under the schedule is discarded only together with the state it belongs to)
         m, v = self.moments()
-        for k in m:
-            m[k].copy_(sd['exp_avg'][k].to(self.dev))
-            v[k].copy_(sd['exp_avg_sq'][k].to(self.dev))
-        self.step_count, self.offset = int(sd['step']), int(sd['dropout_offset'])
-        self.lr, self.wd = float(sd['lr']), float(sd['weight_decay'])
-        self.betas, self.eps = tuple(sd['betas']), float(sd['eps'])
+        scalars = load_named_moments('MFEngine', m, v, sd)
+        self.step_count, self.offset, self.lr, self.wd, self.betas, self.eps = scalars
         self._tb_base, self._tb_period = self.step_count, 1  # the loaded tables are current through the loaded step
         # row tags written by earlier steps of THIS process must not collide with resumed step numbers
         for ws in self.__dict__.get('_ws_cache', {}).values():
@@ -1117,6 +1200,7 @@ class NarreEngine(_ConvRule):
                        self._workspace(nb, R, T), nb, R, T)
         return se
 
+    @step_or_nothing
     @torch.no_grad()
     def train_step(self, data, y, n_global=None, next_data=None):
         if self.dp is not None:
@@ -1191,12 +1275,8 @@ class NarreEngine(_ConvRule):
 
     def load_state_dict(self, sd):
         m, v = self.moments()
-        for k in m:
-            m[k].copy_(sd['exp_avg'][k].to(self.dev))
-            v[k].copy_(sd['exp_avg_sq'][k].to(self.dev))
-        self.step_count, self.offset = int(sd['step']), int(sd['dropout_offset'])
-        self.lr, self.wd = float(sd['lr']), float(sd['weight_decay'])
-        self.betas, self.eps = tuple(sd['betas']), float(sd['eps'])
+        self.step_count, self.offset, self.lr, self.wd, self.betas, self.eps = \
+            load_named_moments(type(self).__name__, m, v, sd)
         self._rule_load(sd.get('conv_rule'))
         for ws in self.__dict__.get('_ws_cache', {}).values():
             ws.zero_()
@@ -1364,6 +1444,7 @@ class TransNetEngine(NarreEngine, _SweepSchedule):
             self.flush()                                     # a forward reads the tables: they catch up first
         return super()._launch(data, y, train_mode, inv_denom, adam_step, next_data)
 
+    @step_or_nothing
     @torch.no_grad()
     def train_step(self, data, y, n_global=None, next_data=None, defer_sweep=False):
         """defer_sweep: TransNet++'s ID-vector sweep is temporally blocked (a chunk no rating names is visited every
@@ -1408,8 +1489,15 @@ class TransNetEngine(NarreEngine, _SweepSchedule):
         return super().moments()
 
     def load_state_dict(self, sd):
-        self._tb_base = self.step_count                      # (what is pending is discarded with the state it belongs to)
-        super().load_state_dict(sd)
+        # (NarreEngine.load_state_dict validates before it copies; the schedule changes only once it has succeeded, so a
+        # rejected checkpoint leaves the pending sweep updates in force)
+        keep = (self._tb_base, self._tb_period)
+        self._tb_base = self.step_count                      # moments() below must not flush into state about to be replaced
+        try:
+            super().load_state_dict(sd)
+        except BaseException:
+            self._tb_base, self._tb_period = keep
+            raise
         self._tb_base, self._tb_period = self.step_count, 1  # the loaded tables are current through the loaded step
 
     def _step(self, f, y, pred, se, ws, n, R, T, train_mode, inv_denom, adam_step, buf, ready, nxt):
@@ -1639,6 +1727,7 @@ class IdNetEngine(_SweepSchedule):
             self.offset += n * self.draws()
         return pred, se
 
+    @step_or_nothing
     @torch.no_grad()
     def train_step(self, data, y, n_global=None, next_data=None, defer_sweep=False):
         """One optimisation step.  Returns the per-example SE tensor (device, reused by the next call);
@@ -1765,27 +1854,36 @@ class IdNetEngine(_SweepSchedule):
         return m, v
 
     def state_dict(self):
-        self.flush()
-        return {'exp_avg': self.flat_m.clone(), 'exp_avg_sq': self.flat_v.clone(),
-                'rows_exp_avg': [None if t is None else t.clone() for t in self.rows_m],
-                'rows_exp_avg_sq': [None if t is None else t.clone() for t in self.rows_v],
+        """Adam moments BY PARAMETER NAME (like the other engines): the flat buffer's slot alignment and padding are
+        layout details of a build, not of a checkpoint."""
+        m, v = self.moments()                                # (flushes the blocked sweeps)
+        return {'exp_avg': {k: t.clone() for k, t in m.items()}, 'exp_avg_sq': {k: t.clone() for k, t in v.items()},
                 'step': self.step_count, 'dropout_offset': self.offset, 'lr': self.lr, 'weight_decay': self.wd,
                 'betas': self.betas, 'eps': self.eps}
 
     def load_state_dict(self, sd):
-        self._tb_base, self._tb_period = int(sd['step']), 1  # (what was pending is discarded with the state it belonged to)
-        if sd['exp_avg'].numel() != self.total:
-            raise ValueError('IdNetEngine.load_state_dict: %d moment elements for a %d-element layout'
-                             % (sd['exp_avg'].numel(), self.total))
-        self.flat_m.copy_(sd['exp_avg'].to(self.dev))
-        self.flat_v.copy_(sd['exp_avg_sq'].to(self.dev))
-        for mine, theirs in zip(self.rows_m + self.rows_v, list(sd['rows_exp_avg']) + list(sd['rows_exp_avg_sq'])):
-            if mine is not None:
-                mine.copy_(theirs.to(self.dev))
-        self.step_count = int(sd['step'])
-        self.offset = int(sd['dropout_offset'])
-        self.lr, self.wd = float(sd['lr']), float(sd['weight_decay'])
-        self.betas, self.eps = tuple(sd['betas']), float(sd['eps'])
+        if torch.is_tensor(sd.get('exp_avg')):               # a checkpoint of the flat form (written before round 5)
+            if sd['exp_avg'].numel() != self.total:
+                raise ValueError('IdNetEngine.load_state_dict: a flat-form checkpoint of %d moment elements for a %d-element '
+                                 'layout (flat checkpoints do not survive layout changes; re-save by name)'
+                                 % (sd['exp_avg'].numel(), self.total))
+            rows = list(sd['rows_exp_avg']) + list(sd['rows_exp_avg_sq'])
+            for mine, theirs in zip(self.rows_m + self.rows_v, rows):
+                if mine is not None and (theirs is None or theirs.numel() != mine.numel()):
+                    raise ValueError('IdNetEngine.load_state_dict: an ID-table moment of the checkpoint does not fit the model')
+            scalars = (int(sd['step']), int(sd['dropout_offset']), float(sd['lr']), float(sd['weight_decay']),
+                       tuple(sd['betas']), float(sd['eps']))
+            self.flush()
+            self.flat_m.copy_(sd['exp_avg'].to(self.dev))
+            self.flat_v.copy_(sd['exp_avg_sq'].to(self.dev))
+            for mine, theirs in zip(self.rows_m + self.rows_v, rows):
+                if mine is not None:
+                    mine.copy_(theirs.to(self.dev))
+        else:
+            m, v = self.moments()                            # (flushes: whatever was pending belongs to the state replaced now)
+            scalars = load_named_moments('IdNetEngine', m, v, sd)
+        self.step_count, self.offset, self.lr, self.wd, self.betas, self.eps = scalars
+        self._tb_base, self._tb_period = self.step_count, 1  # the loaded tables are current through the loaded step
         # row tags written by earlier steps of THIS process must not collide with resumed step numbers
         if self._ws is not None:
             self._ws.zero_()

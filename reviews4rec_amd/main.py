@@ -195,9 +195,9 @@ def native_step_limits(hyper_params, world=1):
     maxL = 64 if mt in ('deepconn', 'NARRE') else 32     # (csrc/engine.hip: two FM inputs per lane beyond 32; csrc/narre_engine.hip:
     if L > maxL:                                          # the head's 64 x 64 instantiation + the split step)
         return 'latent_size %d > %d' % (L, maxL)
-    E = engine_pad_width(E)         # the engines zero-pad rows to whole float4 / whole K chunks (engine.pad_width: exact)
-    if 3 * E // 4 > 512:
-        return 'word_embed_size %d > 680' % E
+    Ep = engine_pad_width(E)        # the engines zero-pad rows to whole float4 / whole K chunks (engine.pad_width: exact)
+    if 3 * Ep // 4 > 512:           # (the weight-gradient window: 512 float4 per tap row, csrc/wgrad_device.h)
+        return 'word_embed_size %d > 672 (rows are padded to %d floats; the native step takes at most 672)' % (E, Ep)
     if mt == 'NARRE':
         if R > 64:
             return 'narre_num_reviews %d > 64' % R

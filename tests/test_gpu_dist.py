@@ -678,3 +678,39 @@ def test_two_rank_bench_line_of_the_id_table_families(workload):
     assert line['n_gpus'] == 2 and line['value'] > 0 and line['config']['replicas_identical'] is True
     legs = line.get('strong_legs') or [line.get('strong')]
     assert legs and legs[0]['global_batch'] == 1024 and legs[0].get('ratings_per_s', 0) > 0, legs
+
+
+def test_bare_two_gpu_bench_command_launches_its_own_ranks():
+    """Exactly `python bench.py --gpus 2 --steps 20 --warmup 5` -- no torchrun around it, no RANK / WORLD_SIZE in the
+    environment: bench.py re-launches itself as a two-rank job (here both ranks share the one GPU over
+    gloo), rank 0 prints the one JSON line with the weak value, the strong legs and the replica check."""
+    import json
+    import subprocess
+    env = dict(os.environ, R4R_DIST_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT', 'R4R_DP_SINGLE'):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '20', '--warmup', '5'],
+                         env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.strip().splitlines() if l.startswith('{')]
+    assert len(lines) == 1, out.stdout[-2000:]               # ONE JSON line, from rank 0
+    line = json.loads(lines[0])
+    cfg = line['config']
+    assert line['n_gpus'] == 2 and line['steps'] == 20 and line['warmup_requested'] == 5 and line['value'] > 0
+    assert line['scaling'] == 'weak' and cfg['ratings_per_step'] == 256 and cfg['parallelism'] == 'dp2'
+    assert cfg['rccl_ranks'] == 2 and cfg['dist_backend'] == 'gloo' and cfg['replicas_identical'] is True
+    assert cfg['dp_exchange'] in ('allreduce', 'gather')
+    legs = [l for l in line['strong_legs'] if 'skipped' not in l]
+    assert [l['global_batch'] for l in legs] == [1024, 8192, 32768] and all(l['ratings_per_s'] > 0 for l in legs)
+    assert 'configs' not in line and 'cpu_baseline' not in line     # (N = 1 only)
+
+
+def test_more_ranks_than_gpus_over_rccl_fails_with_one_line():
+    import subprocess
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT', 'R4R_DIST_BACKEND', 'R4R_DP_SINGLE'):
+        env.pop(k, None)
+    n = torch.cuda.device_count() + 1
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', str(n), '--steps', '2', '--warmup', '1'],
+                         env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode != 0 and ('--gpus %d but %d GPU' % (n, n - 1)) in out.stderr, out.stderr[-1000:]
