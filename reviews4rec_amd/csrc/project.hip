@@ -87,6 +87,7 @@ struct ProjArgs {
     int64_t N, V;
     int T, E, F, nchunk, tiles, cap;
     int ntower, balanced;          // 1: the GEMM may use its 7-row-tile form; 0: tile form (R4R_GEMM=tile); 2: tile form, whole tiles only (R4R_GEMM=whole)
+    const int *order;              // gather: the launch's segments dealt to workgroups by cost (tower << 28 | unit, -1: none), or null
 };
 
 #ifdef R4R_TRACE
@@ -1419,14 +1420,69 @@ static_assert(SLICE == 32 || SLICE == 16, "a worker is 32 lanes; eight workers p
 constexpr int GDEPTH = R4R_GDEPTH;        // tokens in flight per lane (7: 124 VGPRs, four waves per SIMD -- every workgroup of the
                                           // cfg3 launch resident at once; 8: 136 VGPRs, three, 1 us slower; 4..6 within 0.5 us of 7)
 
+// ---- 3a. the deal.  A segment whose slices are all uniform (the zero-padded tail of a document) costs its workers
+// one position each; any other slice costs five dependent rounds.  Document-major order leaves whole workgroups --
+// and, four workgroups to a CU, whole CUs -- with nothing but tails while others hold eight walking workers: the launch
+// ended when the unluckiest CU did.  cost[unit] = the segment's slices that must be walked (0 .. 4); the deal sorts
+// the launch's segments by cost (counting sort, stable) and hands workgroup w the w-th most expensive one together
+// with the w-th cheapest.  Any assignment gives the same outputs: every segment is computed by exactly one half
+// of one workgroup, exactly as before.
+__global__ __launch_bounds__(256) void proj_cost_kernel(ProjArgs a, int *cost) {
+    const int64_t per_tower = a.N * a.tiles * GWPS;        // (unit, slice) pairs
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= per_tower * a.ntower) return;
+    const int t = (int)(i / per_tower);
+    const int64_t r = i - t * per_tower;
+    const int64_t unit = r / GWPS;
+    const int w = (int)(r - unit * GWPS);
+    const int64_t doc = unit / a.tiles;
+    const int seg = (int)(unit - doc * a.tiles);
+    const int T = a.T, P = T + 2;
+    const int p_lo = seg * SEG + w * SLICE, p_hi = min(P, p_lo + SLICE);
+    if (p_hi <= p_lo) return;
+    const int64_t *idx = a.t[t].idx + doc * T;
+    auto tok = [&](int tt) -> int64_t { return (tt >= 0 && tt < T) ? idx[tt] : -1; };
+    const int64_t first = tok(p_lo - 2);
+    bool same = true;
+    for (int tt = p_lo - 1; tt < p_hi; ++tt) same &= tok(tt) == first;
+    if (!same) atomicAdd(cost + t * (a.N * a.tiles) + unit, 1);
+}
+__global__ __launch_bounds__(1024) void proj_deal_kernel(ProjArgs a, int *cost, int *order) {
+    __shared__ int hist[8], base[8];
+    const int64_t per_tower = a.N * a.tiles, n = per_tower * a.ntower;
+    const int64_t nwg = (n + GSPW - 1) / GSPW;
+    if (threadIdx.x < 8) hist[threadIdx.x] = 0;
+    __syncthreads();
+    for (int64_t i = threadIdx.x; i < n; i += 1024) atomicAdd(&hist[GWPS - cost[i]], 1);      // bucket 0 = the most expensive
+    __syncthreads();
+    if (threadIdx.x == 0) { int run = 0; for (int b = 0; b <= GWPS; ++b) { base[b] = run; run += hist[b]; } }
+    __syncthreads();
+    // (the order inside a bucket is whatever the atomics give: any order is a valid deal)
+    for (int64_t i = threadIdx.x; i < n; i += 1024) {
+        const int c = cost[i];
+        cost[i] = 0;                                        // left all-zero for the next use
+        const int64_t r = atomicAdd(&base[GWPS - c], 1);   // rank in descending-cost order
+        const int t = (int)(i / per_tower);
+        const int code = (t << 28) | (int)(i - t * per_tower);
+        // rank r < nwg: the heavy segment of workgroup r; otherwise the light one of workgroup 2 nwg - 1 - r
+        if (GSPW == 1) order[r] = code;
+        else if (r < nwg) order[2 * r] = code;
+        else order[2 * (2 * nwg - 1 - r) + 1] = code;
+    }
+    if (GSPW == 2 && (n & 1) && threadIdx.x == 0) order[1] = -1;        // odd count: ranks nwg .. n - 1 fill the light slots of workgroups nwg - 1 .. 1; workgroup 0's stays empty
+}
+
 HEAD_TRACE_DEFINE(r4r_debug_gather_trace)
 __global__ __launch_bounds__(256) void proj_gather_max_kernel(ProjArgs a) {
     HEAD_STAMP(0)
     __shared__ int sl[8][SLICE + 2];
     __shared__ float sbest[8][PF];
     __shared__ int sbp[8][PF];
-    const ProjTower &tw = a.t[blockIdx.y];
     const int worker = threadIdx.x >> 5, wl = threadIdx.x & 31;
+    // dealt launches (a.order): the workgroup's two segments come from the cost-sorted deal, each with its own tower
+    const int dcode = a.order ? __builtin_amdgcn_readfirstlane(a.order[(int64_t)blockIdx.x * GSPW + worker / GWPS]) : 0;
+    const int mcode = a.order ? __builtin_amdgcn_readfirstlane(a.order[(int64_t)blockIdx.x * GSPW + (threadIdx.x >> 7)]) : 0;
+    const ProjTower &tw = a.t[a.order ? (dcode < 0 ? 0 : dcode >> 28) : blockIdx.y];
     // Which pair of segments this workgroup takes.  Document-major order puts segment pair k of every document on
     // workgroups k mod tiles/2 -- and the dispatcher places workgroups 8 apart on one XCD and (one generation of 1,024
     // resident workgroups on 256 CUs) 256 apart on one CU: with 4 pairs per 1000-word document every CU, and every
@@ -1466,15 +1522,16 @@ __global__ __launch_bounds__(256) void proj_gather_max_kernel(ProjArgs a) {
         const int hh = R4R_GATHER_SPLIT == 2 ? (h ^ (int)((blockIdx.x >> 8) & 1)) : h;
         return d * a.tiles + (bx - d * t2) + (int64_t)hh * t2;
     };
-    const int64_t unit = unit_of(worker / GWPS);
+    const int64_t unit = a.order ? (dcode < 0 ? units : (int64_t)(dcode & 0xfffffff)) : unit_of(worker / GWPS);
     const int64_t doc = unit < units ? unit / a.tiles : 0;
     const int seg = unit < units ? (int)(unit - doc * a.tiles) : a.tiles;     // a.tiles: no such segment
     const int T = a.T, P = T + 2;
     const bool act = wl < PF / 4;
     const f32x4 zero = (f32x4){0.f, 0.f, 0.f, 0.f};
-    if (blockIdx.x == 0 && threadIdx.x == 0) {              // consumed by the GEMM launch before this one
-        tw.count[1] = tw.count[0];                          // ... but remembered: the host's measured conv rule reads it
-        tw.count[0] = 0;
+    if (blockIdx.x == 0 && (a.order ? (int)threadIdx.x < a.ntower : threadIdx.x == 0)) {   // consumed by the GEMM launch before this one
+        const ProjTower &tc = a.t[a.order ? threadIdx.x : blockIdx.y];
+        tc.count[1] = tc.count[0];                          // ... but remembered: the host's measured conv rule reads it
+        tc.count[0] = 0;
     }
 
     const int p_lo = seg * SEG + (worker % GWPS) * SLICE;
@@ -1585,7 +1642,8 @@ __global__ __launch_bounds__(256) void proj_gather_max_kernel(ProjArgs a) {
     HEAD_STAMP(2)
     // merge the 4 slices of each segment in position order; thread f (< 100) of each half
     const int half = threadIdx.x >> 7, f = threadIdx.x & 127;
-    const int64_t ounit = unit_of(half);
+    const int64_t ounit = a.order ? (mcode < 0 ? units : (int64_t)(mcode & 0xfffffff)) : unit_of(half);
+    const ProjTower &two = a.t[a.order ? (mcode < 0 ? 0 : mcode >> 28) : blockIdx.y];
     if (f < PF && ounit < units && half < GSPW) {
         float mb = sbest[half * GWPS][f];
         int mp = sbp[half * GWPS][f];
@@ -1595,8 +1653,8 @@ __global__ __launch_bounds__(256) void proj_gather_max_kernel(ProjArgs a) {
             if (v > mb) { mb = v; mp = sbp[half * GWPS + w][f]; }
         }
         const size_t o = (size_t)ounit * NP + f;           // [doc][tile][NP]
-        tw.pmax[o] = mb;
-        tw.parg[o] = mp;
+        two.pmax[o] = mb;
+        two.parg[o] = mp;
     }
     HEAD_STAMP(3)
 }
@@ -1631,6 +1689,7 @@ static ProjArgs make_args(const float *table, int64_t V, const ProjTower *tw, in
     a.tiles = proj_tiles(T);
     a.cap = (int)proj_row_capacity(N, T, V);
     a.ntower = ntower;
+    a.order = nullptr;
     if (g_gemm_balanced < 0) {
         const char *e = getenv("R4R_GEMM");
         g_gemm_balanced = (e && e[0] == 't') ? 0 : ((e && e[0] == 'w') ? 2 : ((e && e[0] == 'a') ? 3 : ((e && e[0] == 'b') ? 1 : ((e && e[0] == 'r') ? 4 : GEMM_DEFAULT_FORM))));
@@ -1722,7 +1781,24 @@ int textcnn_proj_compute_launch(const float *table, int64_t V, const ProjTower *
         const int lds_bytes = (a.balanced == 3 && ares_bytes > GEMM_LDS_BYTES) ? ares_bytes : GEMM_LDS_BYTES;
         proj_gemm_kernel<<<dim3((unsigned)wgs), GEMM_THREADS, lds_bytes, st>>>(a);
     }
-    {
+    static const bool deal = getenv("R4R_GATHER_DEAL") && atoi(getenv("R4R_GATHER_DEAL")) != 0;
+    if (deal) {                                             // EXPERIMENT: cost + deal as launches of their own
+        static int *scratch = nullptr;
+        static int64_t scratch_n = 0;
+        const int64_t n = N * a.tiles * ntower;
+        if (scratch_n < n) {
+            if (scratch) (void)hipFree(scratch);
+            (void)hipMalloc(&scratch, (size_t)(2 * n + 4) * 2 * sizeof(int));
+            (void)hipMemset(scratch, 0, (size_t)(2 * n + 4) * 2 * sizeof(int));
+            scratch_n = n;
+        }
+        ProjArgs b = a;
+        b.order = scratch + n;
+        proj_cost_kernel<<<(unsigned)cdiv(n * GWPS, 256), 256, 0, st>>>(a, scratch);
+        proj_deal_kernel<<<1, 1024, 0, st>>>(a, scratch, scratch + n);
+        ScopedTiming tm(R4R_TIMING_PROJ_GATHER, st);
+        proj_gather_max_kernel<<<dim3((unsigned)cdiv(n, GSPW)), 256, 0, st>>>(b);
+    } else {
         ScopedTiming tm(R4R_TIMING_PROJ_GATHER, st, /*chain=*/true);     // (starts where the GEMM's span ended)
         proj_gather_max_kernel<<<dim3((unsigned)cdiv(N * a.tiles, GSPW), ntower), 256, 0, st>>>(a);
     }

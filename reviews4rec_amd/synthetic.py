@@ -4,6 +4,7 @@ token ids, log-normal document fill zero-padded to T (the reference pads with id
 0, data.py:198-199), 5-star-skewed ratings, and a word table with the
 distribution utils.xavier_init leaves behind (fact 2)."""
 import math
+import os
 
 import numpy as np
 
@@ -35,12 +36,14 @@ def hyper_params_for(name, **over):
     return hp
 
 
-def _zipf_sampler(n, alpha, rng):
+def _zipf_sampler(n, alpha, rng, ranked=False):
     """Sampler of ids in [0, n) with P(rank k) ~ 1/(k+1)^alpha, ranks randomly permuted."""
     w = 1.0 / np.power(np.arange(1, n + 1, dtype=np.float64), alpha)
     cdf = np.cumsum(w)
     cdf /= cdf[-1]
     perm = rng.permutation(n)
+    if ranked:                                               # ids in frequency order (id 0 the most frequent)
+        perm = np.arange(n)
     return lambda size: perm[np.searchsorted(cdf, rng.random(size), side='right').clip(max=n - 1)]
 
 
@@ -70,7 +73,7 @@ class Generator:
             if token_dist == 'uniform':
                 self.tokens = lambda size: self.rng.integers(1, V, size=size)
             else:
-                tok = _zipf_sampler(V - 1, 1.0, self.rng)
+                tok = _zipf_sampler(V - 1, 1.0, self.rng, ranked=os.environ.get('R4R_SYNTH_TOKEN_ORDER') == 'rank')
                 self.tokens = lambda size: tok(size) + 1      # id 0 is the pad / UNK row
 
     def _docs(self, lead, T):
