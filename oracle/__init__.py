@@ -5,7 +5,7 @@ rating-prediction models, loss and optimiser step.  It exists so that the HIP
 path in ``reviews4rec_amd`` can be checked on a box where ``/root/reference``
 does not exist.  Only ``tests/``, ``__graft_entry__.smoke()`` and the
 ``cpu_baseline`` leg of ``bench.py`` may import it; the product package never
-does (``tests/test_no_oracle_in_product.py`` enforces that).
+does (``tests/test_cabi.py::test_product_package_never_imports_the_oracle`` enforces that).
 
 Parity pin: every function here is checked against outputs of the reference
 itself (imported from ``/root/reference`` in the build container) through the

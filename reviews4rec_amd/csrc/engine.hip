@@ -75,221 +75,15 @@ struct HeadArgs {
 };
 
 
-// One wave per rating, 4 ratings per 256-thread workgroup.  Everything a rating needs
-// besides its own partials -- both FC matrices, FM V / lin -- is staged in LDS once per
-// workgroup with independent coalesced loads, and the tile loop of the pool-finish is
-// unrolled, so the kernel is a handful of memory round trips instead of a chain of ~40.
 constexpr int HEAD_MAX_TILES = 8;
 
-// ML: compile-time cap of the latent size (LDS arrays, register arrays and unrolled staging loops
-// are sized by it; instantiated for <= 16 and <= 32)
+// ---- the head, ONE WORKGROUP PER RATING.  Wave w finishes the pool of (tower w >> 1, filters 64 (w & 1) ..): 16
+// partial loads per lane, every load of the prologue requested before anything waits; the FC layers' 2 L x 100
+// products are spread over all 256 threads (PARTS threads per output, summed in a fixed order through LDS:
+// deterministic); wave 0 alone runs the FM's cross-lane sums; the backward to g_pooled is one output per thread.
+// (A four-ratings-per-workgroup form put a batch of 128 on 32 CUs of 256: 11 us against 8; removed in round 5.)
+// ML: compile-time cap of the latent size (LDS arrays, register arrays and unrolled staging loops are sized by it).
 HEAD_TRACE_DEFINE(r4r_debug_dc_head_trace)
-template <int ML>
-__global__ __launch_bounds__(256) void deepconn_head_kernel(HeadArgs a) {
-    HEAD_STAMP(0)
-    __shared__ float sw[2][ML][F_CONV + 1];   // FC weights, +1 pad: lane i reads row i
-    __shared__ float sfb[2][ML];
-    __shared__ float sV[2 * ML][FM_K];
-    __shared__ float slw[2 * ML];
-    __shared__ float sp[4][2][F_CONV + 4];       // pooled, per wave
-    __shared__ float sz[4][2 * ML];           // gz, per wave
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int64_t b_raw = (int64_t)blockIdx.x * 4 + w;
-    const bool live = b_raw < a.B;             // a dead wave shadows the last rating and stores nothing
-    const int64_t b = live ? b_raw : a.B - 1;
-    const int L = a.L, n = 2 * L;
-    // scalars the tail needs: issued now, so they ride along with the first memory round trip
-    const float lin_b0 = a.lin_b[0], gbias0 = a.gbias[0], yb = a.y ? a.y[b] : 0.f;
-
-    // Stage the head's weights in LDS.  All the loads of this prologue -- these and the pooling
-    // partials below -- are issued before anything waits (a load -> LDS-store loop over the FC
-    // matrix alone was 8 dependent L2 round trips: 6 us of a 12 us kernel).
-    constexpr int WREGS = (2 * ML * F_CONV + 255) / 256;
-    float wreg[WREGS];
-    const int wtot = 2 * L * F_CONV;
-#pragma unroll
-    for (int k = 0; k < WREGS; ++k) {
-        wreg[k] = 0.f;
-        if (256 * k < wtot) {                               // uniform: rounds past the end cost nothing
-            const int i = min(tid + 256 * k, wtot - 1);
-            const int t = i >= L * F_CONV;
-            wreg[k] = a.fc_w[t][i - t * L * F_CONV];
-        }
-    }
-    const float fbreg = (tid < n) ? a.fc_b[tid / L][tid % L] : 0.f;
-    const float lwreg = (tid < n) ? a.lin_w[tid] : 0.f;
-    constexpr int VREGS = (2 * ML * FM_K + 255) / 256;
-    float vreg[VREGS];
-#pragma unroll
-    for (int k = 0; k < VREGS; ++k) vreg[k] = a.V[min(tid + 256 * k, n * FM_K - 1)];
-    auto stage_weights = [&]() {
-#pragma unroll
-        for (int k = 0; k < WREGS; ++k) {
-            const int i = tid + 256 * k;
-            if (i < wtot) {
-                const int t = i >= L * F_CONV, r = i - t * L * F_CONV, l = r / F_CONV;
-                sw[t][l][r - l * F_CONV] = wreg[k];
-            }
-        }
-        if (tid < n) { sfb[tid / L][tid % L] = fbreg; slw[tid] = lwreg; }
-#pragma unroll
-        for (int k = 0; k < VREGS; ++k) {
-            const int i = tid + 256 * k;
-            if (i < n * FM_K) sV[i / FM_K][i % FM_K] = vreg[k];
-        }
-    };
-
-    // ---- pool finish: max over tiles, relu, first argmax.  The common case (<= 8 tiles, i.e.
-    // T <= 1022) loads everything a lane needs -- 2 towers x 2 filters x 8 tiles of (max, arg) --
-    // before the first compare: one memory round trip instead of four dependent ones (the
-    // partials were just written by another XCD, so a round trip is a MALL/HBM access).
-    if (a.tiles <= HEAD_MAX_TILES) {
-        float v[2][2][HEAD_MAX_TILES];
-        int pp[2][2][HEAD_MAX_TILES];
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int f = min(lane + 64 * h, F_CONV - 1);
-#pragma unroll
-                for (int k = 0; k < HEAD_MAX_TILES; ++k) {
-                    const size_t o = ((size_t)b * a.tiles + min(k, a.tiles - 1)) * NP + f;
-                    v[t][h][k] = a.pmax[t][o];
-                    pp[t][h][k] = a.parg[t][o];
-                }
-            }
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int f = lane + 64 * h;
-                float best = -INFINITY;
-                int bp = -1;
-#pragma unroll
-                for (int k = 0; k < HEAD_MAX_TILES; ++k)       // a clamped duplicate never wins (strict >)
-                    if (v[t][h][k] > best) { best = v[t][h][k]; bp = pp[t][h][k]; }
-                if (!(best > 0.f)) { best = 0.f; bp = -1; }
-                if (f < F_CONV) {
-                    sp[w][t][f] = best;
-                    if (live) {
-                        a.pooled[t][b * F_CONV + f] = best;
-                        a.argmax[t][b * F_CONV + f] = bp;
-                    }
-                }
-            }
-    } else {
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-        for (int f = lane; f < F_CONV; f += 64) {
-            float best = -INFINITY;
-            int bp = -1;
-            for (int k0 = 0; k0 < a.tiles; k0 += HEAD_MAX_TILES) {
-                float v[HEAD_MAX_TILES];
-                int pp[HEAD_MAX_TILES];
-#pragma unroll
-                for (int k = 0; k < HEAD_MAX_TILES; ++k) {
-                    const bool in = k0 + k < a.tiles;
-                    const size_t o = ((size_t)b * a.tiles + (in ? k0 + k : 0)) * NP + f;
-                    v[k] = in ? a.pmax[t][o] : -INFINITY;
-                    pp[k] = a.parg[t][o];
-                }
-#pragma unroll
-                for (int k = 0; k < HEAD_MAX_TILES; ++k)
-                    if (v[k] > best) { best = v[k]; bp = pp[k]; }
-            }
-            if (!(best > 0.f)) { best = 0.f; bp = -1; }
-            sp[w][t][f] = best;
-            if (live) {
-                a.pooled[t][b * F_CONV + f] = best;
-                a.argmax[t][b * F_CONV + f] = bp;
-            }
-        }
-    }
-    HEAD_STAMP(1)
-    stage_weights();
-    __syncthreads();
-    HEAD_STAMP(2)
-
-    // ---- FC: lane i < 2L computes z[t][l] = b[l] + sum_f pooled[t][f] W[t][l][f]
-    float xi = 0.f;
-    if (lane < n) {
-        const int t = lane / L, l = lane - t * L;
-        float acc = 0.f;
-#pragma unroll 4
-        for (int f = 0; f < F_CONV; ++f) acc = fmaf(sp[w][t][f], sw[t][l][f], acc);
-        xi = acc + sfb[t][l];
-    }
-    // ---- dropout on the FC output (common_pytorch_models.py:37)
-    float mult = 1.f;
-    if (a.training && a.p_drop > 0.f && lane < n) {
-        const uint32_t r = philox_first_word(a.offset + (uint64_t)(b * n + lane), a.seed);
-        const float u = (float)(r >> 8) * (1.0f / 16777216.0f);
-        mult = (u >= a.p_drop) ? 1.f / (1.f - a.p_drop) : 0.f;
-    }
-    xi *= mult;
-
-    // ---- FM (common_pytorch_models.py:49-57) + global bias
-    float inter = 0.f, gacc = 0.f;
-    float sk_keep[FM_K];
-#pragma unroll
-    for (int k = 0; k < FM_K; ++k) {
-        const float v = (lane < n) ? sV[lane][k] : 0.f;
-        const float s = wave_sum(xi * v);
-        const float s2 = wave_sum(xi * xi * v * v);
-        inter += s * s - s2;
-        gacc += s * v - xi * v * v;
-        sk_keep[k] = s;
-    }
-    const float lw = (lane < n) ? slw[lane] : 0.f;
-    const float lin = wave_sum(xi * lw);
-    const float pred = (0.5f * inter + lin + lin_b0) + gbias0;
-    if (lane == 0 && live) a.pred[b] = pred;
-    if (!a.y) return;                                      // uniform across the grid
-    const float d = pred - yb;
-    if (lane == 0 && live) a.se[b] = d * d;
-    if (!a.want_grad) return;                              // uniform across the grid
-
-    // ---- backward of the head down to g_pooled
-    const float g = 2.f * d * a.inv_denom;                 // d mean(SE) / d pred
-    const float gx = g * (gacc + lw);                      // d / d x_i
-    const float gz = gx * mult;                            // through dropout
-    if (lane < n) {
-        sz[w][lane] = gz;
-        if (live) {
-            a.x[b * n + lane] = xi;
-            a.gz[b * n + lane] = gz;
-            a.mult[b * n + lane] = mult;
-        }
-    }
-    if (lane < FM_K && live) {
-        float sv = 0.f;
-#pragma unroll
-        for (int k = 0; k < FM_K; ++k) if (lane == k) sv = sk_keep[k];
-        a.s[b * FM_K + lane] = sv;
-    }
-    if (lane == 0 && live) a.g[b] = g;
-    __syncthreads();
-    HEAD_STAMP(3)
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-        for (int f = lane; f < F_CONV; f += 64) {
-            float acc = 0.f;
-            for (int l = 0; l < L; ++l) acc = fmaf(sz[w][t * L + l], sw[t][l][f], acc);
-            if (live) a.g_pooled[t][b * F_CONV + f] = acc;
-        }
-    HEAD_STAMP(4)
-}
-
-// ---- the same head, ONE WORKGROUP PER RATING (the default since round 4; R4R_HEAD_WG=0 builds the launch above).
-// The four-ratings-per-workgroup form puts a batch of 128 on 32 CUs, and each of its lanes waits for 64 partial
-// loads + 13 weight loads in its first round trip: 4.7 us of an 11 us launch (tools/head_trace.py) on a chip whose
-// other 224 CUs idle.  Here wave w finishes the pool of (tower w >> 1, filters 64 (w & 1) ..): 16 partial loads per
-// lane; the FC layers' 2 L x 100 products are spread over all 256 threads (PARTS threads per output, summed in a
-// fixed order through LDS: deterministic); wave 0 alone runs the FM's cross-lane sums; the backward to g_pooled is
-// one output per thread.  Same Philox draws per (rating, output) as the form above: identical dropout masks.
-#ifndef R4R_HEAD_WG
-#define R4R_HEAD_WG 1
-#endif
 template <int ML>
 __global__ __launch_bounds__(256) void deepconn_head_wg_kernel(HeadArgs a) {
     HEAD_STAMP(0)
@@ -850,15 +644,9 @@ extern "C" int r4r_deepconn_step(const float *table, int64_t V, const int64_t *u
     h.pred = pred; h.se = se;
     h.B = B; h.L = L; h.tiles = tiles; h.training = training; h.want_grad = flat_g != nullptr;
     h.p_drop = dropout_p; h.inv_denom = inv_denom; h.seed = seed; h.offset = offset;
-#if R4R_HEAD_WG
     if (L <= 16) deepconn_head_wg_kernel<16><<<(unsigned)B, 256, 0, st>>>(h);
     else if (L <= 32) deepconn_head_wg_kernel<32><<<(unsigned)B, 256, 0, st>>>(h);
     else deepconn_head_wg_kernel<64><<<(unsigned)B, 256, 0, st>>>(h);     // latent_size 33 .. 64 (hyper_params.py:63 has no bound)
-#else
-    R4R_REQUIRE(L <= 32, "deepconn_step: the four-ratings-per-workgroup head is built for latent_size <= 32");
-    if (L <= 16) deepconn_head_kernel<16><<<(unsigned)cdiv(B, 4), 256, 0, st>>>(h);
-    else deepconn_head_kernel<32><<<(unsigned)cdiv(B, 4), 256, 0, st>>>(h);
-#endif
 
     if (!flat_g) {
         if (y && sse_accum) sse_only_kernel<<<1, 256, 0, st>>>(se, sse_accum, B);

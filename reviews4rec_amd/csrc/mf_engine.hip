@@ -176,10 +176,7 @@ __global__ __launch_bounds__(256) void mf_fwd_bwd_kernel(MfStep a) {
 
 constexpr int MF_THREADS = 256;        // (MF_CHUNK, the elements per sweep workgroup of a table: rows_device.h)
 
-#ifndef R4R_MF_CHUNK_BIAS
-#define R4R_MF_CHUNK_BIAS 1024
-#endif
-constexpr int MF_CHUNK_BIAS = R4R_MF_CHUNK_BIAS;    // bias vectors: short workgroups, so they are not the tail
+constexpr int MF_CHUNK_BIAS = 1024;    // bias vectors: short workgroups, so they are not the tail
 
 // Scalar fields only: an array member indexed by the workgroup's slot number (even through a
 // chain of constant-index selects, which LLVM turns back into an indexed access) is copied to
@@ -520,12 +517,6 @@ __device__ __forceinline__ void mf_adam_body(const MfSweep &w) {
     // the table chunks)
     const int nshort = w.cb_entries - w.cb2, rest = (int)blockIdx.x - w.n_entry_wgs;
     const int bx = rest < 0 ? w.cb_entries + (int)blockIdx.x : (rest < nshort ? w.cb2 + rest : rest - nshort);
-#ifdef R4R_MF_ABL                                           // timing-only ablations (wrong results): 1 entries, 2 tables, 4 bias vectors, 8 global
-    if ((R4R_MF_ABL & 1) && bx >= w.cb_entries) return;
-    if ((R4R_MF_ABL & 8) && bx >= w.cb_global && bx < w.cb_entries) return;
-    if ((R4R_MF_ABL & 2) && bx < w.cb2) return;
-    if ((R4R_MF_ABL & 4) && bx >= w.cb2 && bx < w.cb_global) return;
-#endif
     if (bx >= w.cb_entries) {
         // ---- entry waves: 4 per workgroup, all of one side (user side's groups first)
         const int lane = tid & 63;
@@ -886,15 +877,12 @@ __device__ __forceinline__ void mf_adam_body(const MfSweep &w) {
 }
 
 BWD_TRACE_DEFINE(r4r_debug_mf_adam_trace)
-#ifndef R4R_MF_WAVES
-#define R4R_MF_WAVES 0
-#endif
 // DL: elements per lane of a row in the generic entry form (1: rows of <= 64 elements); WIDE: the float4 entry forms are
 // compiled in.  <.., 1, false> is the LIGHT variant -- 52 VGPRs instead of 94, seven waves per SIMD instead of five:
 // every wave of the launch, the table chunks' included, is allocated what the entry waves' multi-row accumulation
 // needs -- taken for rows of <= 64 elements at <= MF_LIGHT_MAX_B ratings (one rating per entry wave).
 template <int NACC, int DL = 4, bool WIDE = true>
-__global__ __launch_bounds__(MF_THREADS, R4R_MF_WAVES > 0 ? R4R_MF_WAVES : 1) void mf_adam_kernel(MfSweep w) {
+__global__ __launch_bounds__(MF_THREADS) void mf_adam_kernel(MfSweep w) {
     BWD_STAMP(0, wall_clock64());                           // (instrumented builds only: tools/sweep_trace.py)
     mf_adam_body<NACC, DL, WIDE>(w);
 #ifdef R4R_TRACE
@@ -947,13 +935,9 @@ static MfWs mf_carve(void *ws, int64_t B, int D, int64_t n_users, int64_t n_item
 // untouched elements take the gradient-zero update, a touched element the fixed-order sum of its
 // ratings.  `tag_*`: per-element step tags the caller's forward kernel set to `now`.
 // (more than the default 64 KB of dynamic LDS once a side has more than 16,384 ids)
-#ifndef R4R_MF_LIGHT
-#define R4R_MF_LIGHT 1
-#endif
 constexpr int MF_LIGHT_MAX_B = 1024;   // beyond it popular rows have hundreds of entries: the wide forms' four entries per load instruction pay
 static bool mf_light(int D, int64_t B) {
-    static const char *e = getenv("R4R_MF_LIGHT");
-    return (e ? e[0] != '0' : R4R_MF_LIGHT != 0) && D <= 64 && B <= MF_LIGHT_MAX_B;
+    return D <= 64 && B <= MF_LIGHT_MAX_B;
 }
 static void mf_ids_lds_attr() {
     static bool done = false;

@@ -26,10 +26,7 @@
 
 namespace r4r {
 
-#ifndef R4R_NHEAD_THREADS
-#define R4R_NHEAD_THREADS 512
-#endif
-constexpr int NHEAD_THREADS = R4R_NHEAD_THREADS;   // threads of the per-rating head workgroup
+constexpr int NHEAD_THREADS = 512;   // threads of the per-rating head workgroup
 constexpr int NARRE_MAX_L = 64, NARRE_MAX_R = 64;  // the head's widest instantiation (the fused ID-table role: NR_MAX_L / NR_MAX_R = 32)
 
 // flat dense-parameter layout (21 slots); slots 0,1 / 4,5 are the conv weight + bias of the towers

@@ -32,10 +32,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int PF = 100;            // filters (rows of 100 floats = 400 B per tap)
 constexpr int PROW = 3 * PF;       // projected row: 3 taps x 100 filters
-#ifndef R4R_PSTR
-#define R4R_PSTR 304
-#endif
-constexpr int PSTR = R4R_PSTR;     // its stride in the projected-row table: 1,216 B = 19 whole 64-byte pieces (at 1,200 B three
+constexpr int PSTR = 304;          // its stride in the projected-row table: 1,216 B = 19 whole 64-byte pieces (at 1,200 B three
                                    // of four 64-byte store pieces straddled two requests, and a gathered row touched 10.4 lines instead of 10)
 static_assert(PSTR >= PROW && PSTR % 4 == 0, "projected-row stride");
 constexpr int PN = 304;            // GEMM N: 300 padded to 19 tiles of 16
@@ -49,36 +46,16 @@ constexpr int PNH_COLS = PNH * 16;                     // 160
 constexpr int SEG = 128;           // positions per partial (matches the direct kernel's NW=4 tile)
 
 // Experiment switches of the projection GEMM (make variant EXTRA="-D..."; defaults = the shipped form)
-#ifndef R4R_STG_PERM
-#define R4R_STG_PERM 1             // staging threads take rows in the order 0,2,1,3: conflict-free ds_write_b128
-#endif
-#ifndef R4R_EPI
-#define R4R_EPI 0                  // tile / balanced forms -- 0: LDS-transposed epilogue (measured 1 us faster there); 1: direct float4 stores (operand roles swapped); 2: no stores (timing only, every form)
-#endif
-#ifndef R4R_EPI_NT
-#define R4R_EPI_NT 0               // 1: nontemporal epilogue stores
-#endif
-#ifndef R4R_PRIO
-#define R4R_PRIO 0                 // 1: waves 4..7 at s_setprio 1 for the K loop
-#endif
 
 // Staging row of thread-quad s (= tid >> 2).  A ds_write_b128 is served in groups of 8 consecutive lanes = two
 // quads over 32 banks; rows s and s + 1 at the 24-float stride overlap in 8 banks (a 2-way conflict: 27 % of the
 // kernel's LDS cycles, profiles/r02k_bench_pmc_summary.json), rows s and s + 2 are 48 floats apart = 16 banks: none.
 __device__ __forceinline__ int stage_row(int s) {
-#if R4R_STG_PERM
     return (s & ~3) | ((s & 1) << 1) | ((s >> 1) & 1);
-#else
-    return s;
-#endif
 }
 
 __device__ __forceinline__ void store_row4(float *dst, const f32x4 v) {
-#if R4R_EPI_NT
-    __builtin_nontemporal_store(v, reinterpret_cast<f32x4 *>(dst));
-#else
     *reinterpret_cast<f32x4 *>(dst) = v;
-#endif
 }
 
 struct ProjArgs {
@@ -87,7 +64,6 @@ struct ProjArgs {
     int64_t N, V;
     int T, E, F, nchunk, tiles, cap;
     int ntower, balanced;          // 1: the GEMM may use its 7-row-tile form; 0: tile form (R4R_GEMM=tile); 2: tile form, whole tiles only (R4R_GEMM=whole)
-    const int *order;              // gather: the launch's segments dealt to workgroups by cost (tower << 28 | unit, -1: none), or null
 };
 
 #ifdef R4R_TRACE
@@ -104,9 +80,26 @@ extern "C" int r4r_debug_trace(void *buf) {
 #define TRACE_STAMP_LAST(k)                                                                             \
     if (g_trace && (threadIdx.x & 63) == 0)                                                             \
         atomicMax(g_trace + ((size_t)blockIdx.x) * 8 + (k), (unsigned long long)wall_clock64());
+// where the workgroup runs (HW_ID, XCC_ID) + its active flag; shader-cycle spans (vs the 100 MHz stamps: the clock)
+#define TRACE_WHERE(xcc_mask)                                                                           \
+    if (g_trace && threadIdx.x == 0) {                                                                  \
+        unsigned long long *tr = g_trace + ((size_t)blockIdx.x) * 8;                                    \
+        tr[4] = __builtin_amdgcn_s_getreg((31 << 11) | 4);                                              \
+        tr[5] = __builtin_amdgcn_s_getreg((31 << 11) | 20) & (xcc_mask);                                \
+        tr[6] = 1;                                                                                      \
+    }
+#define TRACE_CLK(name) const unsigned long long name = __builtin_readcyclecounter();
+#define TRACE_CLK_SPAN(word, expr)                                                                      \
+    if (g_trace && threadIdx.x == 0) g_trace[((size_t)blockIdx.x) * 8 + (word)] = (expr);
+// (word 5 of the trace record: XCC id in the low byte, the end of the staging pass's prologue above it)
+#define PRO_STAMP if (g_trace && threadIdx.x == 0) g_trace[((size_t)blockIdx.x) * 8 + 5] |= (wall_clock64() << 8);
 #else
 #define TRACE_STAMP(k)
 #define TRACE_STAMP_LAST(k)
+#define TRACE_WHERE(xcc_mask)
+#define TRACE_CLK(name)
+#define TRACE_CLK_SPAN(word, expr)
+#define PRO_STAMP
 #endif
 
 // ---- 0. zero the token-state (callers whose workspace is not persistently zeroed).  A kernel
@@ -161,14 +154,7 @@ __device__ __forceinline__ void proj_gemm_body(const ProjArgs &a, float *lds, in
     const ProjTower &tw = a.t[tower];
     const int count = tw.count[0];
     TRACE_STAMP(0)
-#ifdef R4R_TRACE
-    if (g_trace && threadIdx.x == 0) {
-        unsigned long long *tr = g_trace + ((size_t)blockIdx.x) * 8;
-        tr[4] = __builtin_amdgcn_s_getreg((31 << 11) | 4);
-        tr[5] = __builtin_amdgcn_s_getreg((31 << 11) | 20);
-        tr[6] = 1;
-    }
-#endif
+    TRACE_WHERE(~0u)
     const float *__restrict__ table = a.table;
     const int E = a.E, nchunk = a.nchunk;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -225,11 +211,7 @@ __device__ __forceinline__ void proj_gemm_body(const ProjArgs &a, float *lds, in
         for (int mi = 0; mi < GMT; ++mi)
 #pragma unroll
             for (int ni = 0; ni < NTILE; ++ni)
-#if R4R_EPI == 0
                 acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mi][kk], b[ni][kk], acc[mi][ni], 0, 0, 0);
-#else           // roles swapped: the lane ends up with 4 consecutive COLUMNS of one table row (same fma chain, same bits)
-                acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[ni][kk], av[mi][kk], acc[mi][ni], 0, 0, 0);
-#endif
     };
     // Operand registers are double-buffered too: the staging of chunk c+2 (registers -> LDS),
     // the global loads of chunk c+3 and the ds_reads of chunk c+1 are all issued among the
@@ -282,33 +264,22 @@ __device__ __forceinline__ void proj_gemm_body(const ProjArgs &a, float *lds, in
     write_lds(lds + GEMM_BUF, 1);
     issue_loads(2);
     TRACE_STAMP(1)
-#ifdef R4R_TRACE
-    const unsigned long long clk0 = __builtin_readcyclecounter();
-#endif
+    TRACE_CLK(clk0)
     // (the odd last chunk is peeled: with an exit in the middle of the loop body hipcc's counter
     // analysis falls back to vmcnt(0) at the loop head)
-#if R4R_PRIO
-    if (wave >= 4) __builtin_amdgcn_s_setprio(1);
-#endif
     int c = 0;
     for (; c + 1 < nchunk; c += 2) {
         step(c, av0, b0, av1, b1);
         step(c + 1, av1, b1, av0, b0);
     }
     if (c < nchunk) step(c, av0, b0, av1, b1);
-#ifdef R4R_TRACE
-    if (g_trace && threadIdx.x == 0)                        // shader cycles of the loop (vs the 100 MHz stamps: the clock)
-        g_trace[((size_t)blockIdx.x) * 8 + 7] = __builtin_readcyclecounter() - clk0;
-#endif
-#if R4R_EPI == 0
+    TRACE_CLK_SPAN(7, __builtin_readcyclecounter() - clk0)      // shader cycles of the loop
     __syncthreads();                                        // all operand reads done: LDS is free
-#endif
     TRACE_STAMP(2)
     // Epilogue.  C layout of the MFMA: col = lane & 15, row = (lane >> 4) * 4 + reg -- storing
     // that directly is 80 scattered 4-byte stores per lane.  Instead each wave transposes one
     // 16-row tile at a time through its own LDS slab and writes whole row segments as float4
     // (an LDS queue is in-order per wave, so no barrier is needed inside a wave).
-#if R4R_EPI == 0
     constexpr int TS = NTILE * 16 + 4;
     float *slab = lds + wave * (16 * (PNH_COLS + 4));
     constexpr int NV = NTILE * 4;
@@ -327,23 +298,6 @@ __device__ __forceinline__ void proj_gemm_body(const ProjArgs &a, float *lds, in
                     *reinterpret_cast<const f32x4 *>(slab + rr * TS + cv * 4);
         }
     }
-#elif R4R_EPI == 1
-    // With the operand roles swapped the MFMA leaves lane (lrow, q) with columns 4q .. 4q+3 of table row lrow of
-    // each 16 x 16 tile: one float4 store per tile and lane, 16 rows x 64 B per instruction, no LDS round trip.
-#pragma unroll
-    for (int mi = 0; mi < GMT; ++mi) {
-        const int row = row0 + rowgrp * 16 * GMT + mi * 16 + lrow;
-        float *dst = tw.ptab + (size_t)row * PSTR + colbase + col0 + q * 4;
-#pragma unroll
-        for (int ni = 0; ni < NTILE; ++ni)
-            if (row < count && colbase + col0 + ni * 16 + q * 4 < PROW) store_row4(dst + ni * 16, acc[mi][ni]);
-    }
-#else
-#pragma unroll
-    for (int mi = 0; mi < GMT; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < NTILE; ++ni) asm volatile("" ::"v"(acc[mi][ni]));
-#endif
     TRACE_STAMP(3)
 }
 
@@ -403,11 +357,7 @@ __device__ __forceinline__ bool gemm7_plan(const ProjArgs &a, int wg, int nwg, G
 }
 
 // table operand x weight operand -> accumulator (R4R_EPI >= 1: roles swapped, see the tile form)
-#if R4R_EPI == 0
 #define MFMA4(tab, wgt, c) __builtin_amdgcn_mfma_f32_16x16x4f32(tab, wgt, c, 0, 0, 0)
-#else
-#define MFMA4(tab, wgt, c) __builtin_amdgcn_mfma_f32_16x16x4f32(wgt, tab, c, 0, 0, 0)
-#endif
 
 // One wave of the balanced form.  SIMD = wave & 3 owns NC column tiles (5, 5, 5, 4) of the 7 private row
 // tiles; its two waves split that 7 x NC block CHECKERBOARD-wise so that both carry the same load (18 / 17
@@ -423,14 +373,7 @@ __device__ __forceinline__ void proj_gemm7_body(const ProjArgs &a, float *lds, c
     const ProjTower &tw = a.t[p.tower];
     const int count = tw.count[0];
     TRACE_STAMP(0)
-#ifdef R4R_TRACE
-    if (g_trace && threadIdx.x == 0) {
-        unsigned long long *tr = g_trace + ((size_t)blockIdx.x) * 8;
-        tr[4] = __builtin_amdgcn_s_getreg((31 << 11) | 4);
-        tr[5] = __builtin_amdgcn_s_getreg((31 << 11) | 20);
-        tr[6] = 1;
-    }
-#endif
+    TRACE_WHERE(~0u)
     const float *__restrict__ table = a.table;
     const int E = a.E, nchunk = a.nchunk;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -563,27 +506,16 @@ __device__ __forceinline__ void proj_gemm7_body(const ProjArgs &a, float *lds, c
     write_lds(lds + GEMM_BUF, 1);
     issue_loads(2);
     TRACE_STAMP(1)
-#ifdef R4R_TRACE
-    const unsigned long long clk0 = __builtin_readcyclecounter();
-#endif
-#if R4R_PRIO
-    if (wave >= 4) __builtin_amdgcn_s_setprio(1);
-#endif
+    TRACE_CLK(clk0)
     int c = 0;
     for (; c + 1 < nchunk; c += 2) {
         step(c, o0, o1);
         step(c + 1, o1, o0);
     }
     if (c < nchunk) step(c, o0, o1);
-#ifdef R4R_TRACE
-    if (g_trace && threadIdx.x == 0)
-        g_trace[((size_t)blockIdx.x) * 8 + 7] = __builtin_readcyclecounter() - clk0;
-#endif
-#if R4R_EPI == 0
+    TRACE_CLK_SPAN(7, __builtin_readcyclecounter() - clk0)
     __syncthreads();                                        // all operand reads done: LDS is free
-#endif
     TRACE_STAMP(2)
-#if R4R_EPI == 0
     // epilogue: per wave, one 16-row tile at a time through its own LDS slab, whole row segments as float4
     constexpr int CMAX = CT > CB ? CT : CB;
     constexpr int TS = CMAX * 16 + 4;
@@ -601,22 +533,6 @@ __device__ __forceinline__ void proj_gemm7_body(const ProjArgs &a, float *lds, c
                     *reinterpret_cast<const f32x4 *>(slab + rr * TS + cv * 4);
         }
     };
-#elif R4R_EPI == 1
-    // epilogue: operand roles are swapped (MFMA4), so lane (lrow, q) holds columns 4q .. 4q+3 of table row lrow of
-    // every tile: one float4 store per tile, straight from the accumulator
-    auto store_tile = [&](const f32x4 *row_acc, int ntile, int row_first, int col_tile0) {
-        const int row = row_first + lrow;
-        float *dst = tw.ptab + (size_t)row * PSTR + col_tile0 * 16 + q * 4;
-#pragma unroll
-        for (int ni = 0; ni < ntile; ++ni)
-            if (row < count && (col_tile0 + ni) * 16 + q * 4 < PROW) store_row4(dst + ni * 16, row_acc[ni]);
-    };
-#else
-    auto store_tile = [&](const f32x4 *row_acc, int ntile, int, int) {
-#pragma unroll
-        for (int ni = 0; ni < ntile; ++ni) asm volatile("" ::"v"(row_acc[ni]));
-    };
-#endif
 #pragma unroll
     for (int mi = 0; mi < RT; ++mi) store_tile(acct[mi], CT, p.row0 + mi * 16, cbase + CT0);
 #pragma unroll
@@ -665,25 +581,7 @@ __device__ __forceinline__ void proj_gemm7_body(const ProjArgs &a, float *lds, c
 constexpr int AR_ROWS = 128;                       // LDS rows per K chunk
 constexpr int AR_CHUNK = AR_ROWS * PEC;            // floats per chunk region
 constexpr int AR_MAX_CHUNKS = 20;                  // 20 x 8 KB = 160 KB: E <= 320
-#ifndef R4R_AR_PMIN
-#define R4R_AR_PMIN 4
-#endif
-constexpr int AR_PMIN = R4R_AR_PMIN, AR_PMAX = 7;  // private row tiles per workgroup
-#ifndef R4R_AR_S
-#define R4R_AR_S 1                                 // chunks staged per barrier in pass 1 (1, 2 or 4: no measurable difference)
-#endif
-#ifndef R4R_AR_HALF
-#define R4R_AR_HALF 1                              // row tiles shared by two workgroups past 7 1/3 row tiles per workgroup (0: those launches take form 1)
-#endif
-#ifndef R4R_AR_PRE2
-#define R4R_AR_PRE2 1                              // pass 2's first weight fragments are requested before pass 1 starts
-#endif
-#ifndef R4R_AR_DB1
-#define R4R_AR_DB1 1                               // pass 1: the same (1 or 3)
-#endif
-#ifndef R4R_AR_DB
-#define R4R_AR_DB 1                                // pass 2: chunks the weight fragments are requested ahead of their MFMAs (1 or 3; 3 measured no faster)
-#endif
+constexpr int AR_PMIN = 4, AR_PMAX = 7;  // private row tiles per workgroup
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
@@ -741,7 +639,7 @@ __device__ __forceinline__ bool ares_plan_fit(const ProjArgs &a, int nwg, AresFi
     if (tiles128 * 2 <= grid) return false;
     for (int P = AR_PMIN; P <= AR_PMAX; ++P)
         if (ares_fit(a, f, P, grid, 3)) return true;
-    return R4R_AR_HALF && ares_fit(a, f, AR_PMAX, grid, 2);
+    return ares_fit(a, f, AR_PMAX, grid, 2);
 }
 
 // workgroup wg's share of the plan (p.tower < 0: nothing)
@@ -776,12 +674,6 @@ __device__ __forceinline__ void ares_assign(const ProjArgs &a, const AresFit &f,
 // consecutive rows x 4 columns, 32 banks) is conflict-free by construction.
 __device__ __forceinline__ int ar_col(int row, int q) { return q ^ ((4 - ((row >> 2) & 3)) & 3); }
 
-#ifdef R4R_TRACE
-// (word 5 of the trace record: XCC id in the low byte, the end of the staging pass's prologue above it)
-#define PRO_STAMP if (g_trace && threadIdx.x == 0) g_trace[((size_t)blockIdx.x) * 8 + 5] |= (wall_clock64() << 8);
-#else
-#define PRO_STAMP
-#endif
 
 struct AresCtx {
     const float *aptr;             // this thread's table row (staging)
@@ -814,7 +706,7 @@ __device__ __forceinline__ void ares_pass(const AresCtx &x, int rt0, const float
     // requested DB chunks ahead into a ring of DB + 1 sets.  (A timing ablation with the free pass's weight loads
     // aimed at one hot line took pass 2 from 11.7 to 8.8 us; requesting them 3 chunks ahead instead of 1 did NOT
     // -- 12.3 us: what those loads cost is their 16 lines per instruction in the address path, not their latency.)
-    constexpr int DB = S > 0 ? R4R_AR_DB1 : R4R_AR_DB, RB = DB + 1;
+    constexpr int DB = 1, RB = DB + 1;                     // (3 chunks ahead measured no faster in either pass)
     const int E = x.E, nchunk = x.nchunk;
     f32x4 ar[SS];
     auto ld_a = [&](int s, f32x4 (&r)[SS]) {                 // super-chunk s = chunks s S .. s S + S - 1 (past the end: the last chunk again)
@@ -973,14 +865,7 @@ __device__ __forceinline__ void proj_gemm_ares_body(const ProjArgs &a, float *ld
     const ProjTower &tw = a.t[p.tower];
     const int count = tw.count[0];
     TRACE_STAMP(0)
-#ifdef R4R_TRACE
-    if (g_trace && threadIdx.x == 0) {
-        unsigned long long *tr = g_trace + ((size_t)blockIdx.x) * 8;
-        tr[4] = __builtin_amdgcn_s_getreg((31 << 11) | 4);
-        tr[5] = __builtin_amdgcn_s_getreg((31 << 11) | 20) & 0xf;
-        tr[6] = 1;
-    }
-#endif
+    TRACE_WHERE(0xf)
     const int tid = threadIdx.x, lane = tid & 63, lrow = lane & 15;
     AresCtx x;
     x.lds = lds; x.E = a.E; x.nchunk = a.nchunk;
@@ -1010,19 +895,14 @@ __device__ __forceinline__ void proj_gemm_ares_body(const ProjArgs &a, float *ld
     float *pt = reinterpret_cast<float *>(((unsigned long long)phi << 32) | plo);
     [[maybe_unused]] const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(pt, 0, __builtin_amdgcn_readfirstlane(count) * (PSTR * 4), 0x00020000);
     auto store_tile = [&](const f32x4 &v, int row_first, int ct, bool ok = true) {
-#if R4R_EPI == 2
-        asm volatile("" ::"v"(v));
-#else
         const int row = row_first + lrow, col = ct * 16 + x.q * 4;
         const int off = (ok && row < count && col < PROW) ? (row * PSTR + col) * 4 : 0x7ffffff0;
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsrc, off, 0, 0);
-#endif
     };
-    // pass 2's first weight fragments: requested before pass 1 (R4R_AR_PRE2)
+    // pass 2's first weight fragments: requested before pass 1
     [[maybe_unused]] auto first_frag = [&](const float *wr) {
         return *reinterpret_cast<const f32x4 *>(wr + min(x.q * 4, a.E - 4));
     };
-#if R4R_AR_PRE2
     [[maybe_unused]] AresB<1> pre3;
     [[maybe_unused]] AresB<NE> prex;
     if constexpr (NCW == 3) pre3.b[0] = first_frag(wrow(ct0 + 2));
@@ -1030,19 +910,14 @@ __device__ __forceinline__ void proj_gemm_ares_body(const ProjArgs &a, float *ld
 #pragma unroll
         for (int j = 0; j < NE; ++j) prex.b[j] = first_frag(wrow(min(p.sh_c0 + eoff + j, PNT - 1)));
     }
-#endif
     // ---- pass 1: all P row tiles x the wave's first two column tiles; stages the A rows
     const float *b1[2] = {wrow(ct0), wrow(ct0 + 1)};
     f32x4 a1[P][2];
-#ifdef R4R_TRACE
-    const unsigned long long clk0 = __builtin_readcyclecounter();
-#endif
-    ares_pass<P, 2, R4R_AR_S, 0>(x, 0, b1, a1, [](auto) {});
+    TRACE_CLK(clk0)
+    ares_pass<P, 2, 1, 0>(x, 0, b1, a1, [](auto) {});      // (one chunk staged per barrier: 2 or 4 measured the same)
     TRACE_STAMP(1)
-#ifdef R4R_TRACE
-    const unsigned long long clk1 = __builtin_readcyclecounter();
-    if (g_trace && threadIdx.x == 0) g_trace[((size_t)blockIdx.x) * 8 + 7] = clk1 - clk0;    // shader cycles of pass 1
-#endif
+    TRACE_CLK(clk1)
+    TRACE_CLK_SPAN(7, clk1 - clk0)                           // shader cycles of pass 1
     __syncthreads();                                         // every chunk of every row is in LDS: the waves run free from here
     auto store1 = [&](auto kc) {                             // store k of pass 1's results: tile (k / 2, k % 2)
         constexpr int k = decltype(kc)::value;
@@ -1052,11 +927,7 @@ __device__ __forceinline__ void proj_gemm_ares_body(const ProjArgs &a, float *ld
     if constexpr (NCW == 3) {                                // the third column tile
         const float *b2[1] = {wrow(ct0 + 2)};
         f32x4 a2[P][1];
-#if R4R_AR_PRE2
         ares_pass<P, 1, 0, P * 2>(x, 0, b2, a2, store1, &pre3);
-#else
-        ares_pass<P, 1, 0, P * 2>(x, 0, b2, a2, store1);
-#endif
         TRACE_STAMP_LAST(2)
 #pragma unroll
         for (int i = 0; i < P; ++i) store_tile(a2[i][0], p.row0 + i * 16, ct0 + 2);
@@ -1069,11 +940,7 @@ __device__ __forceinline__ void proj_gemm_ares_body(const ProjArgs &a, float *ld
             be[j] = wrow(ecol[j]);
         }
         f32x4 ax[1][NE];
-#if R4R_AR_PRE2
         ares_pass<1, NE, 0, P * 2>(x, P, be, ax, store1, &prex);
-#else
-        ares_pass<1, NE, 0, P * 2>(x, P, be, ax, store1);
-#endif
         TRACE_STAMP_LAST(2)
 #pragma unroll
         for (int j = 0; j < NE; ++j) store_tile(ax[0][j], p.sh_row0, ecol[j], eoff + j < p.sh_n && p.sh_row0 >= 0);
@@ -1081,10 +948,7 @@ __device__ __forceinline__ void proj_gemm_ares_body(const ProjArgs &a, float *ld
         static_for<0, P * 2>([&](auto kc) { store1(kc); });  // nothing left to compute: store and leave
         TRACE_STAMP_LAST(2)
     }
-#ifdef R4R_TRACE
-    if (g_trace && threadIdx.x == 0)                         // shader cycles of wave 0's pass 2 (word 6: bit 0 = active)
-        g_trace[((size_t)blockIdx.x) * 8 + 6] = ((__builtin_readcyclecounter() - clk1) << 1) | 1;
-#endif
+    TRACE_CLK_SPAN(6, ((__builtin_readcyclecounter() - clk1) << 1) | 1)     // shader cycles of wave 0's pass 2 (bit 0 = active)
     TRACE_STAMP_LAST(3)
 }
 
@@ -1116,15 +980,9 @@ __global__ __launch_bounds__(GEMM_THREADS) void proj_gemm_kernel(ProjArgs a) {
             ares_assign(a, f, (int)blockIdx.x, p);
             if (p.tower < 0) return;                         // uniform: this workgroup has no rows
             switch (p.P) {
-#if R4R_AR_PMIN <= 4
                 case 4: proj_gemm_ares_wg<4>(a, lds, p); break;
-#endif
-#if R4R_AR_PMIN <= 5
                 case 5: proj_gemm_ares_wg<5>(a, lds, p); break;
-#endif
-#if R4R_AR_PMIN <= 6
                 case 6: proj_gemm_ares_wg<6>(a, lds, p); break;
-#endif
                 default: proj_gemm_ares_wg<7>(a, lds, p); break;
             }
             return;
@@ -1197,16 +1055,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void proj_gemm_kernel(ProjArgs a) {
 // stores.  Units go round-robin over the waves of the tower's workgroups (split over the towers in proportion to
 // their row tiles), so the tail is one unit, and a launch stores steadily from its first microsecond.  Same operand
 // arrangement and K order per output element as the other forms: identical bits.
-#ifndef R4R_WR_THREADS
-#define R4R_WR_THREADS 512
-#endif
-#ifndef R4R_WR_ABL
-#define R4R_WR_ABL 0
-#endif
-#ifndef R4R_WR_NB
-#define R4R_WR_NB 1                                 // units the table-fragment loads run ahead
-#endif
-constexpr int WR_THREADS = R4R_WR_THREADS, WR_WAVES = WR_THREADS / 64;
+constexpr int WR_THREADS = 512, WR_WAVES = WR_THREADS / 64;
 constexpr int WR_MAX_CHUNKS = 8;                       // 304 rows x (128 + 4) floats = 160,512 B
 constexpr int WR_NQ = (PNT + 3) / 4;                   // 5 column quads (the last one: 3 tiles)
 __host__ __device__ constexpr int wr_stride(int nch) { return nch * PEC + 4; }
@@ -1254,7 +1103,7 @@ __global__ __launch_bounds__(WR_THREADS) void proj_gemm_wres_kernel(ProjArgs a) 
     // no difference at cfg5, where the rows come from HBM -- the launch is bound by its stores --, and a longer
     // prologue at cfg4; NB = 1).  Rows past the end read row count - 1 and are never stored; units past the end
     // re-read the last unit's rows and are not computed.
-    constexpr int NB = R4R_WR_NB;
+    constexpr int NB = 1;
     auto load_tok = [&](int u) { return tw.list[min((min(u, units - 1) / WR_NQ) * 16 + lrow, count - 1)]; };
     auto load_a = [&](int tok, f32x4 (&o)[NCH]) {
         const float *ap = a.table + (long)tok * E;
@@ -1315,9 +1164,6 @@ __global__ __launch_bounds__(WR_THREADS) void proj_gemm_wres_kernel(ProjArgs a) 
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, z), rsrc, 0x7ffffff0 - 64 * i, 0, 0);
     }
     __syncthreads();                                         // the weights are in LDS: the waves run free from here
-#if R4R_WR_ABL == 4                                          // timing ablation: the prologue alone
-    if (count >= 0) return;
-#endif
     const float *bl = lds + lrow * STR + q * 4;
     auto unit = [&](int uu, f32x4 (&slot)[NCH], int &tok) {
         f32x4 cur[NCH];
@@ -1342,11 +1188,7 @@ __global__ __launch_bounds__(WR_THREADS) void proj_gemm_wres_kernel(ProjArgs a) 
                 for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
                     for (int i = 0; i < 4; ++i)
-#if R4R_WR_ABL == 2                                          // timing ablation: no MFMAs (operands still consumed)
-                        acc[i][kk] += cur[c][kk] + b[i][kk];
-#else
                         acc[i] = MFMA4S(cur[c][kk], b[i][kk], acc[i]);
-#endif
             }
         } else {                                             // the last quad: three column tiles
 #pragma unroll
@@ -1365,13 +1207,7 @@ __global__ __launch_bounds__(WR_THREADS) void proj_gemm_wres_kernel(ProjArgs a) 
         for (int i = 0; i < 4; ++i) {
             const int col = (ct0 + i) * 16 + q * 4;
             const int off = (row < count && col < PROW) ? (row * PSTR + col) * 4 : 0x7ffffff0;   // out of range: dropped by the hardware
-#if R4R_WR_ABL == 1                                          // timing ablation: no stores
-            asm volatile("" ::"v"(acc[i]), "v"(off));
-#elif R4R_WR_ABL == 3                                        // timing ablation: same bytes, every store 1 KB contiguous (wrong layout)
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[i]), rsrc, (uu * 4 + i) * 1024 + lane * 16 + (off & 0), 0, 0);
-#else
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[i]), rsrc, off, 0, 0);
-#endif
         }
     };
     // whole turns of the ring without a branch between the units (a skipped unit would leave a different queue
@@ -1395,82 +1231,13 @@ __global__ __launch_bounds__(WR_THREADS) void proj_gemm_wres_kernel(ProjArgs a) 
 // position p = t (its tap-2 row), feeds tap 1 of p = t+1 and tap 0 of p = t+2.  The four
 // slices of a segment are merged through LDS in position order (strict >, so the first
 // maximum wins like PyTorch's max-pool).
-#ifndef R4R_GSLICE
-#define R4R_GSLICE 32
-#endif
-constexpr int SLICE = R4R_GSLICE;         // positions per worker (32: two segments per workgroup; 16: one -- three dependent rounds per worker instead of five, twice the workgroups)
+constexpr int SLICE = 32;                 // positions per worker (16 -- three dependent rounds per worker instead of five, twice the workgroups -- measured slower)
 constexpr int GWPS = SEG / SLICE;         // workers per segment (4 | 8)
 constexpr int GSPW = 8 / GWPS;            // segments per workgroup (2 | 1)
 static_assert(SLICE == 32 || SLICE == 16, "a worker is 32 lanes; eight workers per workgroup");
-#ifndef R4R_GATHER_ROT
-#define R4R_GATHER_ROT 1
-#endif
-#ifndef R4R_GATHER_ROTDIV
-#define R4R_GATHER_ROTDIV 16            // documents per rotation step (A/B at cfg5: 1 .. 64 all help, 16 most: 34.2 -> 30.8 us; cfg3: neutral)
-#endif
-#ifndef R4R_GATHER_SPLIT
-#define R4R_GATHER_SPLIT 0              // (1: a workgroup's two segments half a document apart -- measured neutral, round 4)
-#endif
-#ifndef R4R_GPIPE
-#define R4R_GPIPE 0
-#endif
-#ifndef R4R_GDEPTH
-#define R4R_GDEPTH 7
-#endif
-constexpr int GDEPTH = R4R_GDEPTH;        // tokens in flight per lane (7: 124 VGPRs, four waves per SIMD -- every workgroup of the
+constexpr int GATHER_ROTDIV = 16;         // documents per rotation step (A/B at cfg5: 1 .. 64 all help, 16 most: 34.2 -> 30.8 us; cfg3: neutral)
+constexpr int GDEPTH = 7;                 // tokens in flight per lane (7: 124 VGPRs, four waves per SIMD -- every workgroup of the
                                           // cfg3 launch resident at once; 8: 136 VGPRs, three, 1 us slower; 4..6 within 0.5 us of 7)
-
-// ---- 3a. the deal.  A segment whose slices are all uniform (the zero-padded tail of a document) costs its workers
-// one position each; any other slice costs five dependent rounds.  Document-major order leaves whole workgroups --
-// and, four workgroups to a CU, whole CUs -- with nothing but tails while others hold eight walking workers: the launch
-// ended when the unluckiest CU did.  cost[unit] = the segment's slices that must be walked (0 .. 4); the deal sorts
-// the launch's segments by cost (counting sort, stable) and hands workgroup w the w-th most expensive one together
-// with the w-th cheapest.  Any assignment gives the same outputs: every segment is computed by exactly one half
-// of one workgroup, exactly as before.
-__global__ __launch_bounds__(256) void proj_cost_kernel(ProjArgs a, int *cost) {
-    const int64_t per_tower = a.N * a.tiles * GWPS;        // (unit, slice) pairs
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= per_tower * a.ntower) return;
-    const int t = (int)(i / per_tower);
-    const int64_t r = i - t * per_tower;
-    const int64_t unit = r / GWPS;
-    const int w = (int)(r - unit * GWPS);
-    const int64_t doc = unit / a.tiles;
-    const int seg = (int)(unit - doc * a.tiles);
-    const int T = a.T, P = T + 2;
-    const int p_lo = seg * SEG + w * SLICE, p_hi = min(P, p_lo + SLICE);
-    if (p_hi <= p_lo) return;
-    const int64_t *idx = a.t[t].idx + doc * T;
-    auto tok = [&](int tt) -> int64_t { return (tt >= 0 && tt < T) ? idx[tt] : -1; };
-    const int64_t first = tok(p_lo - 2);
-    bool same = true;
-    for (int tt = p_lo - 1; tt < p_hi; ++tt) same &= tok(tt) == first;
-    if (!same) atomicAdd(cost + t * (a.N * a.tiles) + unit, 1);
-}
-__global__ __launch_bounds__(1024) void proj_deal_kernel(ProjArgs a, int *cost, int *order) {
-    __shared__ int hist[8], base[8];
-    const int64_t per_tower = a.N * a.tiles, n = per_tower * a.ntower;
-    const int64_t nwg = (n + GSPW - 1) / GSPW;
-    if (threadIdx.x < 8) hist[threadIdx.x] = 0;
-    __syncthreads();
-    for (int64_t i = threadIdx.x; i < n; i += 1024) atomicAdd(&hist[GWPS - cost[i]], 1);      // bucket 0 = the most expensive
-    __syncthreads();
-    if (threadIdx.x == 0) { int run = 0; for (int b = 0; b <= GWPS; ++b) { base[b] = run; run += hist[b]; } }
-    __syncthreads();
-    // (the order inside a bucket is whatever the atomics give: any order is a valid deal)
-    for (int64_t i = threadIdx.x; i < n; i += 1024) {
-        const int c = cost[i];
-        cost[i] = 0;                                        // left all-zero for the next use
-        const int64_t r = atomicAdd(&base[GWPS - c], 1);   // rank in descending-cost order
-        const int t = (int)(i / per_tower);
-        const int code = (t << 28) | (int)(i - t * per_tower);
-        // rank r < nwg: the heavy segment of workgroup r; otherwise the light one of workgroup 2 nwg - 1 - r
-        if (GSPW == 1) order[r] = code;
-        else if (r < nwg) order[2 * r] = code;
-        else order[2 * (2 * nwg - 1 - r) + 1] = code;
-    }
-    if (GSPW == 2 && (n & 1) && threadIdx.x == 0) order[1] = -1;        // odd count: ranks nwg .. n - 1 fill the light slots of workgroups nwg - 1 .. 1; workgroup 0's stays empty
-}
 
 HEAD_TRACE_DEFINE(r4r_debug_gather_trace)
 __global__ __launch_bounds__(256) void proj_gather_max_kernel(ProjArgs a) {
@@ -1478,60 +1245,37 @@ __global__ __launch_bounds__(256) void proj_gather_max_kernel(ProjArgs a) {
     __shared__ int sl[8][SLICE + 2];
     __shared__ float sbest[8][PF];
     __shared__ int sbp[8][PF];
+    const ProjTower &tw = a.t[blockIdx.y];
     const int worker = threadIdx.x >> 5, wl = threadIdx.x & 31;
-    // dealt launches (a.order): the workgroup's two segments come from the cost-sorted deal, each with its own tower
-    const int dcode = a.order ? __builtin_amdgcn_readfirstlane(a.order[(int64_t)blockIdx.x * GSPW + worker / GWPS]) : 0;
-    const int mcode = a.order ? __builtin_amdgcn_readfirstlane(a.order[(int64_t)blockIdx.x * GSPW + (threadIdx.x >> 7)]) : 0;
-    const ProjTower &tw = a.t[a.order ? (dcode < 0 ? 0 : dcode >> 28) : blockIdx.y];
     // Which pair of segments this workgroup takes.  Document-major order puts segment pair k of every document on
     // workgroups k mod tiles/2 -- and the dispatcher places workgroups 8 apart on one XCD and (one generation of 1,024
     // resident workgroups on 256 CUs) 256 apart on one CU: with 4 pairs per 1000-word document every CU, and every
     // XCD, got four workgroups of the SAME pair index -- all heads of documents (real words, five dependent rounds)
-    // or all zero-padded tails (R4R_GATHER_ROT=0: that order).  The pair index is rotated by document / R4R_GATHER_ROTDIV,
-    // so that a CU's workgroups, and an XCD's, mix heads and tails.  Same work per workgroup, same outputs.
+    // or all zero-padded tails.  The pair index is rotated by document / GATHER_ROTDIV, so that a CU's workgroups, and
+    // an XCD's, mix heads and tails.  Same work per workgroup, same outputs.  (What else was tried on this launch's
+    // schedule and measured no faster -- segment pairs half a document apart, 16-position slices, a software-pipelined
+    // group loop, hot rows staged in LDS, segments dealt to workgroups by cost: DESIGN.md 4.1b, profiles/r05_negatives.txt.)
     int64_t bx = blockIdx.x;
-    bool split = false;                                     // the workgroup's two segments are half a document apart (below)
-#if R4R_GATHER_ROT
     if (GSPW == 2 && (a.tiles & 1) == 0 && a.tiles >= 4) {
         const int t2 = a.tiles >> 1;
         const int64_t d = bx / t2;
         const int pr = (int)(bx - d * t2);
-        bx = d * t2 + (pr + (int)(d / R4R_GATHER_ROTDIV)) % t2;
-        split = R4R_GATHER_SPLIT != 0;
+        bx = d * t2 + (pr + (int)(d / GATHER_ROTDIV)) % t2;
     }
-#endif
-    // segment `unit` of the launch's N * tiles segments (document-major): workers 0-3 take the
-    // workgroup's first segment, 4-7 its second -- of the same document, or (odd tile counts, e.g.
-    // NARRE's one-tile reviews) the first of the next one.  With an even tile count the two segments are HALF A
-    // DOCUMENT apart (pair j = segments j and j + tiles / 2): documents are zero-padded at the end (data.py:198-199),
-    // so consecutive segments are both real words -- eight workers on five dependent rounds each, a CU of four such
-    // workgroups bound by its L1 -- or both padding (eight workers that shortcut); the split gives every workgroup
-    // one of each.  Same work, same outputs -- and the same time (cfg3 20.9 against 20.6 us, cfg5 32.3 / 32.4: a
-    // worker's five dependent rounds take ~3 us each whatever its neighbours do; R4R_GATHER_SPLIT=1 builds it).
-    // Likewise 16-position slices (R4R_GSLICE=16: three rounds per worker, twice the workgroups): cfg3 22.0-23.5 us,
-    // cfg5 38-39.5 against 32.  R4R_GATHER_SPLIT=2 (the heavy half alternating between the workgroups that share a CU)
-    // and a software-pipelined group loop (R4R_GPIPE=1, groups of 2 .. 5 tokens) measured the same or slower as well
-    // (profiles/r04d_sweep_ab.txt 9, 14): the launch has stayed at 20.5 us under every restructuring of its schedule.
+    // segment `unit` of the launch's N * tiles segments (document-major): workers 0-3 take the workgroup's first
+    // segment, 4-7 its second -- of the same document, or (odd tile counts, e.g. NARRE's one-tile reviews) the first of
+    // the next one
     const int64_t units = a.N * a.tiles;
-    auto unit_of = [&](int h) -> int64_t {
-        if (!split) return bx * GSPW + h;
-        const int t2 = a.tiles >> 1;
-        const int64_t d = bx / t2;
-        // (which half of the workgroup's waves takes the document's first half alternates between the workgroups that
-        // share a CU -- blocks 256 apart: waves 0-1 of every workgroup land on SIMDs 0-1)
-        const int hh = R4R_GATHER_SPLIT == 2 ? (h ^ (int)((blockIdx.x >> 8) & 1)) : h;
-        return d * a.tiles + (bx - d * t2) + (int64_t)hh * t2;
-    };
-    const int64_t unit = a.order ? (dcode < 0 ? units : (int64_t)(dcode & 0xfffffff)) : unit_of(worker / GWPS);
+    auto unit_of = [&](int h) -> int64_t { return bx * GSPW + h; };
+    const int64_t unit = unit_of(worker / GWPS);
     const int64_t doc = unit < units ? unit / a.tiles : 0;
     const int seg = unit < units ? (int)(unit - doc * a.tiles) : a.tiles;     // a.tiles: no such segment
     const int T = a.T, P = T + 2;
     const bool act = wl < PF / 4;
     const f32x4 zero = (f32x4){0.f, 0.f, 0.f, 0.f};
-    if (blockIdx.x == 0 && (a.order ? (int)threadIdx.x < a.ntower : threadIdx.x == 0)) {   // consumed by the GEMM launch before this one
-        const ProjTower &tc = a.t[a.order ? threadIdx.x : blockIdx.y];
-        tc.count[1] = tc.count[0];                          // ... but remembered: the host's measured conv rule reads it
-        tc.count[0] = 0;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {              // consumed by the GEMM launch before this one
+        tw.count[1] = tw.count[0];                          // ... but remembered: the host's measured conv rule reads it
+        tw.count[0] = 0;
     }
 
     const int p_lo = seg * SEG + (worker % GWPS) * SLICE;
@@ -1575,9 +1319,6 @@ __global__ __launch_bounds__(256) void proj_gather_max_kernel(ProjArgs a) {
         // halo: tokens t_lo and t_lo+1 only seed the sliding sums (tap 0 of t_lo, taps 1 and 0 of
         // t_lo+1): three loads issued together with the first group, not a round of their own
         auto load_row = [&](int s, int tap) {
-#ifdef R4R_GATHER_ABL                                       // timing only (wrong results): every XCD reads a window of R4R_GATHER_ABL rows of its own
-            if (s >= 0) s = s % R4R_GATHER_ABL + (int)((blockIdx.y * gridDim.x + blockIdx.x) & 7) * R4R_GATHER_ABL;
-#endif
             const float *row = base + (size_t)(s < 0 ? 0 : s) * PSTR + tap * PF;   // clamped: no branch
             const f32x4 v = *reinterpret_cast<const f32x4 *>(row);
             return s < 0 ? zero : v;
@@ -1611,28 +1352,11 @@ __global__ __launch_bounds__(256) void proj_gather_max_kernel(ProjArgs a) {
                 }
             }
         };
-#if R4R_GPIPE
-        // software pipeline: the NEXT group's rows are requested before this group's positions are evaluated.  The waves
-        // of a launch start together and walk their slices in step: unpipelined, every SIMD waited out each round's
-        // memory latency and then had all its waves' arithmetic at once (tools/head_trace.py --gather: a full slice
-        // five rounds of ~3 us).  Two register buffers, named (a run-time buffer index would go through scratch).
-        f32x4 a0[GDEPTH], a1[GDEPTH], a2[GDEPTH], b0[GDEPTH], b1[GDEPTH], b2[GDEPTH];
-        if (npos > 0) loadg(0, a0, a1, a2);
-        for (int k = 0; k < npos; k += 2 * GDEPTH) {
-            if (k + GDEPTH < npos) loadg(k + GDEPTH, b0, b1, b2);
-            compg(k, a0, a1, a2);
-            if (k + GDEPTH < npos) {
-                if (k + 2 * GDEPTH < npos) loadg(k + 2 * GDEPTH, a0, a1, a2);
-                compg(k + GDEPTH, b0, b1, b2);
-            }
-        }
-#else
         for (int k = 0; k < npos; k += GDEPTH) {
             f32x4 r0[GDEPTH], r1[GDEPTH], r2[GDEPTH];
             loadg(k, r0, r1, r2);
             compg(k, r0, r1, r2);
         }
-#endif
     }
     if (act) {
 #pragma unroll
@@ -1642,8 +1366,7 @@ __global__ __launch_bounds__(256) void proj_gather_max_kernel(ProjArgs a) {
     HEAD_STAMP(2)
     // merge the 4 slices of each segment in position order; thread f (< 100) of each half
     const int half = threadIdx.x >> 7, f = threadIdx.x & 127;
-    const int64_t ounit = a.order ? (mcode < 0 ? units : (int64_t)(mcode & 0xfffffff)) : unit_of(half);
-    const ProjTower &two = a.t[a.order ? (mcode < 0 ? 0 : mcode >> 28) : blockIdx.y];
+    const int64_t ounit = unit_of(half);
     if (f < PF && ounit < units && half < GSPW) {
         float mb = sbest[half * GWPS][f];
         int mp = sbp[half * GWPS][f];
@@ -1653,8 +1376,8 @@ __global__ __launch_bounds__(256) void proj_gather_max_kernel(ProjArgs a) {
             if (v > mb) { mb = v; mp = sbp[half * GWPS + w][f]; }
         }
         const size_t o = (size_t)ounit * NP + f;           // [doc][tile][NP]
-        two.pmax[o] = mb;
-        two.parg[o] = mp;
+        tw.pmax[o] = mb;
+        tw.parg[o] = mp;
     }
     HEAD_STAMP(3)
 }
@@ -1664,14 +1387,8 @@ int proj_tiles(int T) { return (T + 2 + SEG - 1) / SEG; }
 int64_t proj_row_capacity(int64_t N, int T, int64_t V) { return (N * T < V) ? N * T : V; }
 size_t proj_ptab_floats(int64_t N, int T, int64_t V) { return (size_t)proj_row_capacity(N, T, V) * PSTR; }
 
-#ifndef R4R_GEMM_DEFAULT
-#define R4R_GEMM_DEFAULT 5
-#endif
-constexpr int GEMM_DEFAULT_FORM = R4R_GEMM_DEFAULT;
-#ifndef R4R_WR_DEFAULT_CHUNKS
-#define R4R_WR_DEFAULT_CHUNKS 4
-#endif
-constexpr int WR_DEFAULT_CHUNKS = R4R_WR_DEFAULT_CHUNKS;   // form 3 hands launches with at most this many K chunks to form 4
+constexpr int GEMM_DEFAULT_FORM = 5;
+constexpr int WR_DEFAULT_CHUNKS = 4;   // form 3 hands launches with at most this many K chunks to form 4
 static int g_gemm_balanced = -1;       // -1: from the environment (R4R_GEMM=tile | whole pin the tile form) on first use
 static int g_gemm_math = 0;            // 0: fp32 MFMA (the default and the headline); 1: fp16-split operands (project_f16.hip)
 static float g_table_maxabs = 0.f;     // max |table|, given with mode 1 (the table is frozen: the host computes it once)
@@ -1689,7 +1406,6 @@ static ProjArgs make_args(const float *table, int64_t V, const ProjTower *tw, in
     a.tiles = proj_tiles(T);
     a.cap = (int)proj_row_capacity(N, T, V);
     a.ntower = ntower;
-    a.order = nullptr;
     if (g_gemm_balanced < 0) {
         const char *e = getenv("R4R_GEMM");
         g_gemm_balanced = (e && e[0] == 't') ? 0 : ((e && e[0] == 'w') ? 2 : ((e && e[0] == 'a') ? 3 : ((e && e[0] == 'b') ? 1 : ((e && e[0] == 'r') ? 4 : GEMM_DEFAULT_FORM))));
@@ -1781,24 +1497,7 @@ int textcnn_proj_compute_launch(const float *table, int64_t V, const ProjTower *
         const int lds_bytes = (a.balanced == 3 && ares_bytes > GEMM_LDS_BYTES) ? ares_bytes : GEMM_LDS_BYTES;
         proj_gemm_kernel<<<dim3((unsigned)wgs), GEMM_THREADS, lds_bytes, st>>>(a);
     }
-    static const bool deal = getenv("R4R_GATHER_DEAL") && atoi(getenv("R4R_GATHER_DEAL")) != 0;
-    if (deal) {                                             // EXPERIMENT: cost + deal as launches of their own
-        static int *scratch = nullptr;
-        static int64_t scratch_n = 0;
-        const int64_t n = N * a.tiles * ntower;
-        if (scratch_n < n) {
-            if (scratch) (void)hipFree(scratch);
-            (void)hipMalloc(&scratch, (size_t)(2 * n + 4) * 2 * sizeof(int));
-            (void)hipMemset(scratch, 0, (size_t)(2 * n + 4) * 2 * sizeof(int));
-            scratch_n = n;
-        }
-        ProjArgs b = a;
-        b.order = scratch + n;
-        proj_cost_kernel<<<(unsigned)cdiv(n * GWPS, 256), 256, 0, st>>>(a, scratch);
-        proj_deal_kernel<<<1, 1024, 0, st>>>(a, scratch, scratch + n);
-        ScopedTiming tm(R4R_TIMING_PROJ_GATHER, st);
-        proj_gather_max_kernel<<<dim3((unsigned)cdiv(n, GSPW)), 256, 0, st>>>(b);
-    } else {
+    {
         ScopedTiming tm(R4R_TIMING_PROJ_GATHER, st, /*chain=*/true);     // (starts where the GEMM's span ended)
         proj_gather_max_kernel<<<dim3((unsigned)cdiv(N * a.tiles, GSPW), ntower), 256, 0, st>>>(a);
     }

@@ -4,10 +4,9 @@
 
 namespace r4r {
 
-#ifndef R4R_MF_CHUNK
-#define R4R_MF_CHUNK 1024                  // (4096 until the sweep went on a schedule, round 4: only due chunks are launched now, and four times the waves share the 8 updates a visit applies -- profiles/r04d_chunk_ab.txt)
-#endif
-constexpr int MF_CHUNK = R4R_MF_CHUNK;         // elements of a table per sweep workgroup (and per chunk tag)
+// elements of a table per sweep workgroup (and per chunk tag).  (4096 until the sweep went on a schedule: only due chunks
+// are launched now, and four times the waves share the 8 updates a visit applies -- profiles/r04d_chunk_ab.txt)
+constexpr int MF_CHUNK = 1024;
 
 int mf_bias_rows_launch(float *ub, float *ub_m, float *ub_v, float *ib, float *ib_m, float *ib_v,
                         int64_t n_users, int64_t n_items, const int64_t *uid, const int64_t *iid, const float *g,
@@ -29,10 +28,7 @@ int mf_bias_rows_launch(float *ub, float *ub_m, float *ub_v, float *ib, float *i
 // launch (`flush` = 1), which uses the OLD period.  (Until round 4 the sweep kept a pending count per chunk and the
 // caller ANNOUNCED the next batch so that its rows could be brought up to date a step ahead: half of the traffic
 // at cfg2 was chunks some rating named, and a kept promise was part of the contract.)
-#ifndef R4R_TB_MAX
-#define R4R_TB_MAX 8
-#endif
-constexpr int MF_TB_MAX = R4R_TB_MAX;  // pending updates an element may carry (period <= this)
+constexpr int MF_TB_MAX = 8;  // pending updates an element may carry (period <= this)
 struct MfTimeBlock {
     int *err;                          // *err = 2 if more than MF_TB_MAX updates were ever pending somewhere
     int period, flush;                 // flush: visit every chunk (applying what is pending under `period`)
@@ -45,10 +41,7 @@ struct MfTimeBlock {
 // The schedule works on RUNS of MF_TB_RUN consecutive chunks (one phase per run): what a launch visits is then runs
 // of MF_TB_RUN * MF_CHUNK contiguous elements per array -- whole DRAM pages instead of 4 KB pieces
 // (measured, profiles/r04d_run_ab.txt: runs of 1, 4, 16, 64 chunks within 1 % of each other at cfg2 and cfg5 -- the sweep is not bound by DRAM page locality; the default stays 1).
-#ifndef R4R_TB_RUN
-#define R4R_TB_RUN 1
-#endif
-constexpr int MF_TB_RUN = R4R_TB_RUN;
+constexpr int MF_TB_RUN = 1;
 // the last step <= t at which the schedule visits chunk c (may lie before `base`: the caller takes the max)
 __host__ __device__ inline int tb_prev_visit(int64_t c, int t, int period) {
     const unsigned cu = (unsigned)(c / MF_TB_RUN), pu = (unsigned)period;   // (chunk numbers fit 31 bits: the launch is one workgroup per chunk)

@@ -124,13 +124,7 @@ __device__ __forceinline__ void narre_sweep_block(const RowSweep &w, int bx) {
     }
 }
 
-#ifndef R4R_NROW_HR
-#define R4R_NROW_HR 2                   // further hits of a lane requested per round (A/B: 4)
-#endif
-#ifndef R4R_NROW_EPW
-#define R4R_NROW_EPW 2
-#endif
-constexpr int NROW_EPW = R4R_NROW_EPW;              // entries per wave of an entry workgroup (16 entries share one load of the ids)
+constexpr int NROW_EPW = 2;              // entries per wave of an entry workgroup (16 entries share one load of the ids)
 // MW: 64-bit words of a lane's hit mask (entries <= 4096 MW: 1 in the fused single-process launch,
 // 4 in the stand-alone data-parallel launch); `sid`: LDS for the entry ids (entries ints).
 template <int ML, int MW>
@@ -227,7 +221,7 @@ __device__ __forceinline__ void narre_rows_block(const RowSweep &w, int bx, int 
                 for (int col = 0; col < ML; ++col) rv[col] = 0.f + ((c0[q] >= 0 && col < L) ? h0[q][col] : 0.f);
                 float gv = 0.f + ((c0[q] >= 0 && j0 < w.B) ? g0[q] : 0.f);     // only the self entries carry a bias gradient
                 while (__ballot(any(q))) {                  // a lane's further hits, two per round, their loads together
-                    constexpr int HR = R4R_NROW_HR;         // (registers: the pair's first hits are still live)
+                    constexpr int HR = 2;         // (registers: the pair's first hits are still live)
                     int cs[HR];
 #pragma unroll
                     for (int u = 0; u < HR; ++u) cs[u] = pop(q);
@@ -286,11 +280,8 @@ __host__ __device__ inline int backward_cs_slices(int cs_blocks, int wgs_per_sli
 // WIDE: the generic wgrad (3E/4 > 64 float4: wgrad_block) instead of the packed one-wave-per-filter form.  Without
 // an ID-table role that variant fits 64 VGPRs -- 8 waves per SIMD, every workgroup of a DeepCoNN++ launch resident
 // (13.7 -> 11.0 us); the packed form spills at that cap (its workgroups went 4.6 -> 7.2 us) and keeps 4.
-#ifndef R4R_BWD_WAVES
-#define R4R_BWD_WAVES 4                 // waves per SIMD the backward launch is allocated for (A/B: 5, 6)
-#endif
 template <int ML, bool WIDE = false>
-__global__ __launch_bounds__(WG_THREADS, ML > 16 ? 2 : (ML == 0 && WIDE ? 8 : R4R_BWD_WAVES)) void narre_backward_kernel(WgradArgs w, ColSum c, int cs_blocks, TokenArgs nx,
+__global__ __launch_bounds__(WG_THREADS, ML > 16 ? 2 : (ML == 0 && WIDE ? 8 : 4)) void narre_backward_kernel(WgradArgs w, ColSum c, int cs_blocks, TokenArgs nx,
                                                                     int packed, RowSweep rows, int row_blocks, int ntower) {
     const int blk0 = blockIdx.y * gridDim.x + blockIdx.x, nblk = gridDim.x * gridDim.y;
     BWD_STAMP(0, wall_clock64())

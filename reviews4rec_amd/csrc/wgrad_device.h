@@ -16,10 +16,7 @@ struct WgradArgs {
     int T, E, F, per_split, nsplit;
 };
 
-#ifndef R4R_WG_CHUNK
-#define R4R_WG_CHUNK 16
-#endif
-constexpr int WG_CHUNK = R4R_WG_CHUNK;       // documents resolved per phase-1 round
+constexpr int WG_CHUNK = 16;       // documents resolved per phase-1 round
 
 __device__ __forceinline__ void wgrad_block(const WgradArgs &a, int f, int s, int tower) {
     // Phase 1 resolves, for a chunk of documents at once, the dependent chain
@@ -91,10 +88,7 @@ __device__ __forceinline__ void wgrad_block(const WgradArgs &a, int f, int s, in
 // one WAVE per filter, four filters per workgroup -- `wgrad_block` would leave three waves of
 // four idle in its streaming phase.  Same per-(filter, split) summation order, so the same bits.
 // grid.x = ceil(F / 4) for this form.
-#ifndef R4R_WG_SUPER
-#define R4R_WG_SUPER 96                 // (16 = the round-by-round form: resolve 16 documents, stream them, resolve the next 16 ...)
-#endif
-constexpr int WG_SUPER = R4R_WG_SUPER;  // documents whose (argmax -> token -> row offset) chains are resolved TOGETHER
+constexpr int WG_SUPER = 96;  // documents whose (argmax -> token -> row offset) chains are resolved TOGETHER
 static_assert(WG_SUPER % WG_CHUNK == 0, "whole streaming rounds per resolved super-chunk");
 __device__ __forceinline__ void wgrad_block_packed(const WgradArgs &a, int fgroup, int s, int tower) {
     __shared__ long p_off[4][WG_SUPER][3];

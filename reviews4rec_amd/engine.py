@@ -116,6 +116,13 @@ class _SweepSchedule:
     period, or no deferral -- visits every chunk under the OLD one and starts the new one."""
     _tb_base, _tb_period, _tb_used = 0, 1, False
 
+    @staticmethod
+    def configured_period(hp):
+        """Visit period of the blocked sweeps: hyper_params['sweep_period'] (default 8), overridden by R4R_SWEEP_PERIOD,
+        capped by R4R_SWEEP_PERIOD_MAX (the C side applies at most 8 pending updates per visit); 1 = the plain dense sweep."""
+        cap = int(os.environ.get('R4R_SWEEP_PERIOD_MAX', 8))
+        return max(1, min(cap, int(os.environ.get('R4R_SWEEP_PERIOD', hp.get('sweep_period', 8)))))
+
     def _schedule(self, defer):
         """(period, base, all_chunks, period afterwards) of the next training step."""
         want = self.sweep_period if (defer and self.has_tables) else 1
@@ -687,7 +694,7 @@ class MFEngine(_SweepSchedule):
         self.offset = 0
         self._ws, self._ws_B, self._out = None, None, {}
         # visit period of the temporally blocked table sweep (include/r4r.h; 1 = the plain dense sweep)
-        self.sweep_period = max(1, min(int(os.environ.get('R4R_SWEEP_PERIOD_MAX', 8)), int(os.environ.get('R4R_SWEEP_PERIOD', hp.get('sweep_period', 8)))))
+        self.sweep_period = self.configured_period(hp)
         # the schedule in force: every table element is current through step _tb_base, chunks have been visited on the
         # period-_tb_period schedule since (1: every step)
         self._tb_base, self._tb_period = 0, 1
@@ -1393,7 +1400,7 @@ class TransNetEngine(NarreEngine, _SweepSchedule):
             self.dp = dp
         self.plus = int(model.hyper_params['model_type'] == 'transnet++')
         # visit period of the temporally blocked ID-vector sweep (include/r4r.h; 1 = the plain dense sweep)
-        self.sweep_period = max(1, min(int(os.environ.get('R4R_SWEEP_PERIOD_MAX', 8)), int(os.environ.get('R4R_SWEEP_PERIOD', model.hyper_params.get('sweep_period', 8)))))
+        self.sweep_period = self.configured_period(model.hyper_params)
         self._tb_base, self._tb_period, self._defer_req, self._tb_now = 0, 1, False, (1, 0, 1, 1)
         if not self.plus:
             self.DP_COLS = 0                                 # plain TransNet: no ID rows to exchange
@@ -1651,7 +1658,7 @@ class IdNetEngine(_SweepSchedule):
         self.offset = 0
         self._ws, self._ws_B, self._out = None, None, {}
         # visit period of the temporally blocked table sweeps (include/r4r.h; 1 = the plain dense sweeps)
-        self.sweep_period = max(1, min(int(os.environ.get('R4R_SWEEP_PERIOD_MAX', 8)), int(os.environ.get('R4R_SWEEP_PERIOD', hp.get('sweep_period', 8)))))
+        self.sweep_period = self.configured_period(hp)
         self._tb_base, self._tb_period = 0, 1
         self._sd_hooks = flush_before_state_dict(self, model)
 
