@@ -8,6 +8,24 @@ import json
 import sys
 
 
+# MI355X_MICROARCH.md: on gfx950 FETCH_SIZE reports HALF of the bytes of a wide coalesced read (16 B per lane; 128-byte
+# requests tallied at 64 B) -- "double it"; other access patterns are to be calibrated on a known byte count.
+#   * proj_gather_max_kernel reads 400 contiguous bytes per half-wave with 16 B per lane.  Calibrated at the one point
+#     where nearly everything misses L2 (cfg5, full-length documents of uniformly drawn words: L2 hit rate 0.042): its
+#     4.51 M requests x 0.958 misses x 128 B = 553 MB, and at least 0.958 x 493 MB of row lines MUST cross the L2, while
+#     FETCH_SIZE reads 278 MB -- exactly the guide's half.  Doubled.
+#   * the projection GEMMs' table-row pieces (64 B per row and K chunk) matched their known byte count 1:1 (round 2
+#     calibration): not doubled.  WRITE_SIZE is taken as reported.
+FETCH_X2 = ('r4r::proj_gather_max_kernel',)
+
+
+def hbm_bytes(kernel, k):
+    """rocprofv3 reports KB."""
+    x2 = kernel.startswith(FETCH_X2)
+    k['fetch_size_correction'] = 2 if x2 else 1
+    k['hbm_bytes_per_launch'] = int(((2 if x2 else 1) * k['FETCH_SIZE'] + k['WRITE_SIZE']) * 1024)
+
+
 def main(root, out, note=''):
     agg = collections.defaultdict(lambda: collections.defaultdict(lambda: [0.0, 0, 0.0]))
     for f in sorted(glob.glob(root + '/p*/**/*counter_collection.csv', recursive=True)):
@@ -25,9 +43,7 @@ def main(root, out, note=''):
         durs = [us / n for _, (v, n, us) in d.items()]
         k['avg_duration_us_under_pmc'] = round(sum(durs) / len(durs), 2)
         if 'FETCH_SIZE' in k and 'WRITE_SIZE' in k:
-            # rocprofv3 reports KB.  Calibration on this access pattern (64-byte gathered segments):
-            # FETCH_SIZE matched the known byte count 1:1, so no x2 correction is applied here.
-            k['hbm_bytes_per_launch'] = int((k['FETCH_SIZE'] + k['WRITE_SIZE']) * 1024)
+            hbm_bytes(kn, k)
         if 'SQ_VALU_MFMA_BUSY_CYCLES' in k and 'GRBM_GUI_ACTIVE' in k and k['GRBM_GUI_ACTIVE']:
             k['mfma_pipe_busy_frac'] = round(k['SQ_VALU_MFMA_BUSY_CYCLES'] / (k['GRBM_GUI_ACTIVE'] / 8 * 1024), 4)
         if 'TCC_HIT_sum' in k and 'TCC_MISS_sum' in k:
