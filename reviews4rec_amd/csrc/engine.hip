@@ -33,7 +33,7 @@ namespace r4r {
 
 constexpr int F_CONV = 100;     // common_pytorch_models.py:11
 constexpr int FM_K = 8;         // DeepCoNN.py:32
-constexpr int MAX_L = 64;          // (the FM takes 2 L inputs: two per lane of its wave beyond 32)
+constexpr int MAX_L = 128;         // (the FM takes 2 L inputs: ceil(2 L / 64) per lane of its wave)
 
 enum { P_UCW = 0, P_UCB, P_UFW, P_UFB, P_ICW, P_ICB, P_IFW, P_IFB, P_FMV, P_FMLW, P_FMLB, P_GB, P_COUNT };
 
@@ -189,8 +189,8 @@ __global__ __launch_bounds__(256) void deepconn_head_wg_kernel(HeadArgs a) {
     __syncthreads();
     const bool has_y = a.y != nullptr, want = has_y && a.want_grad;     // uniform across the grid
     if (w == 0) {
-        // FM input i = lane + 64 u (NI = 2 inputs per lane once 2 L > 64: latent_size 33 .. 64)
-        constexpr int NI = N2 > 64 ? 2 : 1;
+        // FM input i = lane + 64 u (NI inputs per lane: 2 at latent_size 33 .. 64, 4 at 65 .. 128)
+        constexpr int NI = (N2 + 63) / 64;
         float xi[NI], mult[NI], lw[NI], gacc[NI];
 #pragma unroll
         for (int u = 0; u < NI; ++u) {
@@ -646,7 +646,8 @@ extern "C" int r4r_deepconn_step(const float *table, int64_t V, const int64_t *u
     h.p_drop = dropout_p; h.inv_denom = inv_denom; h.seed = seed; h.offset = offset;
     if (L <= 16) deepconn_head_wg_kernel<16><<<(unsigned)B, 256, 0, st>>>(h);
     else if (L <= 32) deepconn_head_wg_kernel<32><<<(unsigned)B, 256, 0, st>>>(h);
-    else deepconn_head_wg_kernel<64><<<(unsigned)B, 256, 0, st>>>(h);     // latent_size 33 .. 64 (hyper_params.py:63 has no bound)
+    else if (L <= 64) deepconn_head_wg_kernel<64><<<(unsigned)B, 256, 0, st>>>(h);     // (hyper_params.py:63 has no bound)
+    else deepconn_head_wg_kernel<128><<<(unsigned)B, 256, 0, st>>>(h);    // latent_size 65 .. 128: 115 KB of the CU's 160 KB of LDS
 
     if (!flat_g) {
         if (y && sse_accum) sse_only_kernel<<<1, 256, 0, st>>>(se, sse_accum, B);

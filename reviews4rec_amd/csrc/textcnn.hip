@@ -418,7 +418,6 @@ static int check_tower_args(const void *table, int64_t V, const void *idx, int64
     R4R_REQUIRE(E > 0 && E % 4 == 0, "textcnn: word_embed_size %d must be a positive multiple of 4 "
                                      "(pad the frozen table on the host otherwise)", E);
     R4R_REQUIRE(F > 0 && F <= NP, "textcnn: %d filters > %d supported", F, NP);
-    R4R_REQUIRE(3 * E / 4 <= 512, "textcnn: word_embed_size %d > 680 not supported by the wgrad kernel", E);
     R4R_REQUIRE(N * (int64_t)((T + 2 + 127) / 128) < (1ll << 31), "textcnn: grid too large");
     return R4R_OK;
 }

@@ -192,12 +192,13 @@ def native_step_limits(hyper_params, world=1):
         return None
     if mt not in ('deepconn', 'deepconn++', 'NARRE', 'transnet', 'transnet++'):
         return 'no fused native step for model_type %r' % (mt,)
-    maxL = 64 if mt in ('deepconn', 'NARRE') else 32     # (csrc/engine.hip: two FM inputs per lane beyond 32; csrc/narre_engine.hip:
-    if L > maxL:                                          # the head's 64 x 64 instantiation + the split step)
+    # csrc/engine.hip: DeepCoNN's head up to 128 (four FM inputs per lane, 115 KB of LDS); csrc/narre_engine.hip: the
+    # head's 64 x 64 instantiation + the split step (its scorer matrices no longer fit LDS beyond); the others 32
+    maxL = {'deepconn': 128, 'NARRE': 64}.get(mt, 32)
+    if L > maxL:
         return 'latent_size %d > %d' % (L, maxL)
-    Ep = engine_pad_width(E)        # the engines zero-pad rows to whole float4 / whole K chunks (engine.pad_width: exact)
-    if 3 * Ep // 4 > 512:           # (the weight-gradient window: 512 float4 per tap row, csrc/wgrad_device.h)
-        return 'word_embed_size %d > 672 (rows are padded to %d floats; the native step takes at most 672)' % (E, Ep)
+    # (any word_embed_size: the engines zero-pad rows to whole float4 / whole K chunks -- engine.pad_width, exact -- and
+    # the weight-gradient window takes another pass per 512 float4 columns beyond 680, csrc/wgrad_device.h)
     if mt == 'NARRE':
         if R > 64:
             return 'narre_num_reviews %d > 64' % R
@@ -216,9 +217,7 @@ def module_path_limits(hyper_params):
     L = int(hyper_params.get('latent_size', 10))
     E = int(hyper_params.get('word_embed_size', 64))
     if mt in ('deepconn', 'deepconn++', 'NARRE', 'transnet', 'transnet++'):
-        E = (E + 3) // 4 * 4        # ops._padded_table: zero-padded rows, exact
-        if 3 * E // 4 > 512:
-            return 'word_embed_size %d > 680' % E
+        pass                        # (any word_embed_size: ops._padded_table zero-pads rows to whole float4, exact)
     fm_in = {'MF': 2 * L, 'deepconn': 2 * L, 'transnet': L, 'transnet++': L + 10}.get(mt)
     if fm_in is not None and fm_in > 512:
         return 'factorization machine over %d inputs > 512 (latent_size %d)' % (fm_in, L)

@@ -130,17 +130,19 @@ def test_transnet_step_at_cfg5_cardinalities():
             assert float((diff > 2e-5 + 1e-4 * v.abs()).float().mean()) < 2e-3 and float(diff.max()) < 5e-4, k
 
 
-@pytest.mark.parametrize('mt', ['deepconn', 'deepconn++', 'NARRE', 'transnet', 'transnet++'])
-def test_word_embed_size_not_a_multiple_of_four(mt):
+@pytest.mark.parametrize('mt,E', [('deepconn', 50), ('deepconn++', 50), ('NARRE', 50), ('transnet', 50), ('transnet++', 50),
+                                  ('deepconn++', 702), ('NARRE', 702), ('transnet++', 702)])
+def test_word_embed_size_not_a_multiple_of_four(mt, E):
     """The reference takes any word_embed_size (hyper_params.py:64; the conv window is [3, E],
     common_pytorch_models.py:15): E = 50 (GloVe-50) on the native engines -- zero-padded table rows and conv
     weights inside the engine, the Parameters stay [100, 1, 3, 50] views -- two training steps and an eval forward
-    against the CPU oracle at E = 50; the state_dict keeps the reference's shapes and the pad columns stay 0."""
+    against the CPU oracle at E = 50; the state_dict keeps the reference's shapes and the pad columns stay 0.
+    E = 702 (padded to 704): beyond the 680 the weight-gradient window used to take in one pass (VERDICT r4 next #8)."""
     import reviews4rec_amd
     from reviews4rec_amd import main as M
     from helpers import synthetic_review_batch
     from test_oracle_golden import ill_conditioned
-    B, T, E, V, U, I, L = 12, 60, 50, 300, 40, 30, 8
+    B, T, V, U, I, L = 12, 60, 300, 40, 30, 8
     R, W = (10, 20) if mt == 'NARRE' else (None, None)
     hp = dict(model_type=mt, latent_size=L, word_embed_size=E, input_length=T, dropout=0.0, total_users=U,
               total_items=I, lr=0.002, weight_decay=1e-6, narre_num_reviews=10, narre_num_words=20, batch_size=B)
@@ -151,7 +153,7 @@ def test_word_embed_size_not_a_multiple_of_four(mt):
     model = model.to(DEV).train()
     assert M.native_step_limits(hp) is None
     eng = M.make_engine(dict(hp, engine='native'), model)
-    assert eng is not None and eng.E == 52 and eng.E_model == 50
+    assert eng is not None and eng.E == (52 if E == 50 else 704) and eng.E_model == E
     is_tn = mt.startswith('transnet')
     states = dict(source=oracle.AdamState(), source_fm=oracle.AdamState(), target=oracle.AdamState()) if is_tn \
         else oracle.AdamState()
@@ -172,9 +174,9 @@ def test_word_embed_size_not_a_multiple_of_four(mt):
             assert float((diff > 2e-5 + 1e-4 * v.abs()).float().mean()) < 2e-3 and float(diff.max()) < 5e-4, k
     for k, p in model.named_parameters():
         if k.endswith('convs.0.weight'):
-            assert tuple(p.shape) == (100, 1, 3, 50) and p.stride()[-2] == 52      # a view of the padded slot
-            full = p.data.as_strided((100, 1, 3, 52), p.stride(), p.storage_offset())
-            assert float(full[..., 50:].abs().max()) == 0.0                          # pad columns: exactly 0
+            assert tuple(p.shape) == (100, 1, 3, E) and p.stride()[-2] == eng.E     # a view of the padded slot
+            full = p.data.as_strided((100, 1, 3, eng.E), p.stride(), p.storage_offset())
+            assert float(full[..., E:].abs().max()) == 0.0                           # pad columns: exactly 0
     model.eval()
     data, y = synthetic_review_batch(B, T, V, U, I, seed=60, R=R, W=W)
     out = eng.predict([d.to(DEV) for d in data], None)[0].cpu()
@@ -211,12 +213,12 @@ def test_word_embed_size_not_a_multiple_of_four_module_path(mt):
             torch.testing.assert_close(got[k], v, rtol=2e-4, atol=1e-6, msg=lambda m: k + ': ' + m)
 
 
-@pytest.mark.parametrize('mt,L', [('deepconn', 80), ('MF', 48), ('transnet++', 80)])
+@pytest.mark.parametrize('mt,L', [('deepconn', 160), ('MF', 48), ('transnet++', 80)])
 def test_latent_size_beyond_the_native_steps(mt, L):
     """latent_size has no bound in the reference (hyper_params.py:63).  The fused native steps are built for
-    latent_size <= 32 (DeepCoNN's: <= 64, test_deepconn_native_step_at_latent_sizes_up_to_64); beyond that ``engine='auto'`` falls back -- with the reason -- to the op-by-op HIP path,
+    latent_size <= 32 (DeepCoNN's: <= 64, test_deepconn_native_step_at_latent_sizes_up_to_128); beyond that ``engine='auto'`` falls back -- with the reason -- to the op-by-op HIP path,
     whose factorization machine now takes up to 512 inputs (DeepCoNN's FM reads 2 x latent_size): one training
-    step's loss and gradients and an eval forward against the CPU oracle at latent_size 48 / 80."""
+    step's loss and gradients and an eval forward against the CPU oracle at latent_size 48 / 80 / 160."""
     import reviews4rec_amd
     from reviews4rec_amd import main as M
     from reviews4rec_amd.loss import MSELoss
@@ -546,10 +548,10 @@ def getattr_path(obj, path):
     return obj
 
 
-@pytest.mark.parametrize('L,dropout', [(48, 0.0), (64, 0.5), (33, 0.0)])
-def test_deepconn_native_step_at_latent_sizes_up_to_64(L, dropout):
-    """latent_size 33 .. 64 (hyper_params.py:63 has no bound) on DeepCoNN's fused native step -- the
-    head's FM wave takes two of the 2 L inputs per lane -- instead of the 3x slower op-by-op path: two training steps
+@pytest.mark.parametrize('L,dropout', [(48, 0.0), (64, 0.5), (33, 0.0), (96, 0.0), (128, 0.5)])
+def test_deepconn_native_step_at_latent_sizes_up_to_128(L, dropout):
+    """latent_size 33 .. 128 (hyper_params.py:63 has no bound) on DeepCoNN's fused native
+    step -- the head's FM wave takes two (65 .. 128: four) of the 2 L inputs per lane -- instead of the 3x slower op-by-op path: two training steps
     (dropout multipliers drawn on the device, injected into the oracle) and an eval forward against the CPU oracle."""
     import copy
     import reviews4rec_amd
@@ -633,3 +635,60 @@ def test_narre_native_step_at_latent_sizes_and_review_counts_up_to_64(L, R):
     pred = eng.predict([d.to(DEV) for d in data], None)[0].cpu()
     ref = oracle.model_forward(P, data, hp, train=False)
     torch.testing.assert_close(pred, ref, rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize('path', ['native', 'module'])
+def test_word_embed_size_768(path):
+    """word_embed_size beyond 680 (hyper_params.py:64 has no bound; 768 = a BERT-width table).  The
+    weight-gradient window is 3 E / 4 = 576 float4 columns wide: two passes of the split's documents (csrc/wgrad_device.h),
+    the projection GEMM runs its K loop over 48 chunks.  DeepCoNN, one training step's loss and gradients, the weights
+    after two steps and an eval forward against the CPU oracle, on the fused native step and on the op-by-op path."""
+    import reviews4rec_amd
+    from reviews4rec_amd import main as M
+    from reviews4rec_amd.loss import MSELoss
+    from reviews4rec_amd.optim import Adam
+    from helpers import synthetic_review_batch
+    from test_oracle_golden import ill_conditioned
+    B, T, E, V, U, I, L = 12, 40, 768, 300, 40, 30, 8
+    hp = dict(model_type='deepconn', latent_size=L, word_embed_size=E, input_length=T, dropout=0.0, total_users=U,
+              total_items=I, lr=0.002, weight_decay=1e-6, batch_size=B)
+    assert M.native_step_limits(hp) is None and M.module_path_limits(hp) is None
+    P = oracle.init_params(hp, vocab_size=V, seed=71)
+    model = reviews4rec_amd.get_model_class('deepconn')(dict(hp, word_vectors=P['word2vec.weight'].numpy()))
+    model.load_state_dict(P)
+    model = model.to(DEV).train()
+    state = oracle.AdamState()
+    if path == 'native':
+        eng = M.make_engine(dict(hp, engine='native', log_file=None), model)
+        assert type(eng).__name__ == 'DeepCoNNEngine'
+    else:
+        opt = Adam(model.parameters(), lr=hp['lr'], weight_decay=hp['weight_decay'])
+    for step in range(2):
+        data, y = synthetic_review_batch(B, T, V, U, I, seed=120 + step)
+        dev = [d.to(DEV) for d in data]
+        if path == 'native':
+            se = eng.train_step(dev, y.to(DEV)).cpu().clone()
+            got = {k: v.cpu() for k, v in eng.grads().items()} if step == 0 else None
+        else:
+            opt.zero_grad()
+            se = MSELoss(hp)(model(dev), y.to(DEV), return_mean=False)
+            torch.mean(se).backward()
+            got = {k: p.grad.cpu().clone() for k, p in model.named_parameters() if p.grad is not None} if step == 0 else None
+            opt.step()
+            se = se.detach().cpu()
+        sse, grads = oracle.train_step(P, data, y, hp, state)
+        torch.testing.assert_close(se.sum(), torch.tensor(sse), rtol=1e-4, atol=1e-3)
+        if step == 0:
+            for k, v in grads.items():
+                if v is not None and not ill_conditioned(k):
+                    torch.testing.assert_close(got[k], v, rtol=2e-4, atol=1e-6, msg=lambda m: k + ': ' + m)
+    sd = model.state_dict()
+    for k, v in P.items():
+        if not ill_conditioned(k):
+            diff = (sd[k].cpu() - v).abs()
+            assert float((diff > 2e-5 + 1e-4 * v.abs()).float().mean()) < 2e-3 and float(diff.max()) < 2.5e-3, k
+    model.eval()
+    data, y = synthetic_review_batch(B, T, V, U, I, seed=130)
+    dev = [d.to(DEV) for d in data]
+    pred = (eng.predict(dev, None)[0] if path == 'native' else model(dev).detach()).cpu()
+    torch.testing.assert_close(pred, oracle.model_forward(P, data, hp, train=False), rtol=1e-4, atol=1e-4)
