@@ -1432,3 +1432,65 @@ def test_narre_engine_beyond_the_fused_entry_caps_against_the_oracle(B):
         diff = (sd[k].cpu() - v).abs()
         assert float((diff > 2e-5 + 1e-4 * v.abs()).float().mean()) < 2e-3, k
         assert float(diff.max()) < 2.5e-3, k
+
+
+def _engine_of(kind):
+    from reviews4rec_amd import engine as E
+    case, cls = {'mf': ('mf_dot', E.MFEngine), 'idnet': ('neumf_full', E.IdNetEngine),
+                 'narre': ('narre_e16', E.NarreEngine), 'transnetpp': ('transnetpp_e16', E.TransNetEngine)}[kind]
+    g = Golden(case)
+    model, hp = build_model(g)
+    return g, model.train(), cls(model, lr=hp['lr'], weight_decay=hp['weight_decay'])
+
+
+@pytest.mark.parametrize('kind', ['mf', 'idnet', 'narre', 'transnetpp'])
+def test_rejected_checkpoint_and_failed_step_leave_the_engine_as_it_was(kind):
+    """(1) a training step that RAISES before anything is launched must not consume its step number -- the
+    blocked sweeps count pending gradient-zero updates from it; (2) a checkpoint that does not fit is rejected BEFORE
+    anything is written -- weights, moments, step count and the sweep schedule stay, and training goes on as if nothing
+    had happened; (3) a checkpoint written by name survives a round trip bit for bit."""
+    import copy
+    g, model, eng = _engine_of(kind)
+    defer = dict(defer_sweep=True) if getattr(eng, 'TEMPORAL_SWEEP', False) else {}
+    for step in range(3):
+        data, y = g.batch(step % 2, DEV)
+        eng.train_step(data, y, **defer)
+    good = copy.deepcopy(eng.state_dict())
+    assert isinstance(good['exp_avg'], dict) and good['step'] == 3            # moments BY NAME, every engine
+    before = (eng.step_count, getattr(eng, '_tb_base', None), getattr(eng, '_tb_period', None))
+    # (1) a step that raises on the host: a rating tensor of the wrong length
+    data, y = g.batch(0, DEV)
+    with pytest.raises(Exception):
+        eng.train_step(data, None, **defer)                                    # y = None: fails before any launch
+    assert (eng.step_count, getattr(eng, '_tb_base', None), getattr(eng, '_tb_period', None)) == before
+    # (2) a checkpoint with one moment of the wrong size, and one with a missing name
+    bad = copy.deepcopy(good)
+    k0 = sorted(bad['exp_avg'])[0]
+    bad['exp_avg'][k0] = torch.zeros(bad['exp_avg'][k0].numel() + 1)
+    with pytest.raises(ValueError):
+        eng.load_state_dict(bad)
+    bad = copy.deepcopy(good)
+    del bad['exp_avg_sq'][sorted(bad['exp_avg_sq'])[-1]]
+    with pytest.raises(KeyError):
+        eng.load_state_dict(bad)
+    assert (eng.step_count, getattr(eng, '_tb_base', None), getattr(eng, '_tb_period', None)) == before
+    now = eng.state_dict()
+    for k, v in good['exp_avg'].items():
+        assert torch.equal(now['exp_avg'][k], v) and torch.equal(now['exp_avg_sq'][k], good['exp_avg_sq'][k]), k
+    # training goes on: a reference engine that never saw the bad checkpoints takes the same next step
+    g2, model2, ref = _engine_of(kind)
+    for step in range(3):
+        data, y = g2.batch(step % 2, DEV)
+        ref.train_step(data, y, **defer)
+    data, y = g.batch(1, DEV)
+    se, se_ref = eng.train_step(data, y, **defer).clone(), ref.train_step(data, y, **defer).clone()
+    assert torch.equal(se, se_ref)
+    sd, sd_ref = model.state_dict(), model2.state_dict()
+    for k in sd:
+        assert torch.equal(sd[k], sd_ref[k]), k
+    # (3) the round trip
+    eng.load_state_dict(copy.deepcopy(good))
+    again = eng.state_dict()
+    assert again['step'] == 3
+    for k, v in good['exp_avg'].items():
+        assert torch.equal(again['exp_avg'][k], v), k
