@@ -394,8 +394,10 @@ def main():
         if not dp_job and not args.no_cpu_baseline:
             result['cpu_baseline'] = result.pop('_cpu_baseline_thunk')()
         result.pop('_cpu_baseline_thunk', None)
-        print(json.dumps(result))
+        print(json.dumps(result), flush=True)
     if dp_job:
+        if env.get('dp') is not None:
+            env['dp'].close()                                # the on-stream communicator, before the process group it was built over
         torch.distributed.destroy_process_group()
 
 
@@ -439,6 +441,7 @@ def run(args, env, is_leg=False):
     model = model.to(dev)
     model.train()
     dp = r4dist.DataParallel(model)
+    env['dp'] = dp
     dp.broadcast_parameters()
     DropoutState.manual_seed(4321, rank)
     criterion = MSELoss(hp)

@@ -344,6 +344,16 @@ class DataParallel:
                       "torch.distributed's collectives" % (why or 'another rank reported a failure'), RuntimeWarning)
         return None
 
+    def close(self):
+        """Destroy the package's own RCCL communicator (collective in effect: every rank calls it, with its device idle --
+        a communicator left alive at interpreter exit is torn down in whatever order the process dies in)."""
+        comm, self.stream_rccl = self.stream_rccl, None
+        if comm is not None:
+            torch.cuda.synchronize()
+            if dist.is_initialized():
+                dist.barrier(group=self.group)
+            comm.close()
+
     def rebind(self, model):
         """Point the exchange at `model` (a new training stage, a freshly built model): its parameters
         become the exchanged set, every cached decision about the previous model -- which parameters
