@@ -18,13 +18,11 @@ struct WgradArgs {
 
 constexpr int WG_CHUNK = 16;       // documents resolved per phase-1 round
 
-__device__ __forceinline__ void wgrad_block(const WgradArgs &a, int f, int s, int tower) {
-    // Phase 1 resolves, for a chunk of documents at once, the dependent chain
-    // argmax -> position -> token id -> table row offset (one lane per (document, tap), so
-    // the chain's latency is paid once per chunk, not once per document); phase 2 streams
-    // the resolved rows with independent float4 loads.
-    __shared__ long s_off[WG_CHUNK][3];     // table row offset in floats, -1 = no contribution
-    __shared__ float s_g[WG_CHUNK];
+// One pass over the split's documents for the 2 x 256 float4 columns from v0 on of the [3][E] window (each thread owns
+// up to 2 of them).  FIRST: this pass also sums the bias gradient.
+template <bool FIRST>
+__device__ __forceinline__ void wgrad_block_pass(const WgradArgs &a, int f, int s, int tower, int v0,
+                                                 long (&s_off)[WG_CHUNK][3], float (&s_g)[WG_CHUNK]) {
     const WgradTower &tw = a.t[tower];
     const float *__restrict__ table = a.table;
     const int64_t *__restrict__ idx = tw.idx;
@@ -35,57 +33,67 @@ __device__ __forceinline__ void wgrad_block(const WgradArgs &a, int f, int s, in
     const int64_t n1 = min(a.N, n0 + (int64_t)a.per_split);
     const int nvec = 3 * E / 4;
     const int tid = threadIdx.x;
-    // each thread owns up to 2 float4 columns of the [3][E] window per PASS over the split's documents: one pass up to
-    // 3 E / 4 = 512 (word_embed_size <= 680), another for every further 512 columns (the reference puts no bound on
-    // word_embed_size, hyper_params.py:64; wider windows repeat the resolve phase instead of costing every launch
-    // registers).  Per column the additions are the same, in the same document order, whatever the pass.
+    wg_f32x4 acc[2] = {(wg_f32x4){0.f, 0.f, 0.f, 0.f}, (wg_f32x4){0.f, 0.f, 0.f, 0.f}};
+    int vj[2], ve[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int v = v0 + tid + k * WG_THREADS;
+        vj[k] = (v * 4) / E;
+        ve[k] = v * 4 - vj[k] * E;
+    }
     float sb = 0.f;
-    for (int v0 = 0; v0 < nvec; v0 += 2 * WG_THREADS) {
-        wg_f32x4 acc[2] = {(wg_f32x4){0.f, 0.f, 0.f, 0.f}, (wg_f32x4){0.f, 0.f, 0.f, 0.f}};
-        int vj[2], ve[2];
+    for (int64_t c0 = n0; c0 < n1; c0 += WG_CHUNK) {
+        const int nd = (int)min((int64_t)WG_CHUNK, n1 - c0);
+        __syncthreads();
+        if (tid < nd * 3) {
+            const int d = tid / 3, j = tid - d * 3;
+            const int64_t n = c0 + d;
+            const int p = argmax[n * F + f];
+            const int t = p - 2 + j;
+            long off = -1;
+            if (p >= 0 && t >= 0 && t < T) off = (long)idx[n * T + t] * E;
+            s_off[d][j] = off;
+            if (j == 0) s_g[d] = (p >= 0) ? gp[n * F + f] : 0.f;
+        }
+        __syncthreads();
+        // (wide windows: 1.2 KB rows at E = 300.  Requesting all 16 rows of the round unconditionally, as
+        // wgrad_block_packed does, was measured SLOWER here -- +4 us on the cfg3 step: the skipped
+        // rows are real traffic at this width)
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
-            const int v = v0 + tid + k * WG_THREADS;
-            vj[k] = (v * 4) / E;
-            ve[k] = v * 4 - vj[k] * E;
-        }
-        for (int64_t c0 = n0; c0 < n1; c0 += WG_CHUNK) {
-            const int nd = (int)min((int64_t)WG_CHUNK, n1 - c0);
-            __syncthreads();
-            if (tid < nd * 3) {
-                const int d = tid / 3, j = tid - d * 3;
-                const int64_t n = c0 + d;
-                const int p = argmax[n * F + f];
-                const int t = p - 2 + j;
-                long off = -1;
-                if (p >= 0 && t >= 0 && t < T) off = (long)idx[n * T + t] * E;
-                s_off[d][j] = off;
-                if (j == 0) s_g[d] = (p >= 0) ? gp[n * F + f] : 0.f;
-            }
-            __syncthreads();
-            // (wide windows: 1.2 KB rows at E = 300.  Requesting all 16 rows of the round unconditionally, as
-            // wgrad_block_packed does, was measured SLOWER here -- +4 us on the cfg3 step: the skipped
-            // rows are real traffic at this width)
-#pragma unroll
-            for (int k = 0; k < 2; ++k) {
-                if (v0 + tid + k * WG_THREADS < nvec) {
+            if (v0 + tid + k * WG_THREADS < nvec) {
 #pragma unroll 4
-                    for (int d = 0; d < nd; ++d) {
-                        const long off = s_off[d][vj[k]];
-                        if (off >= 0) acc[k] += s_g[d] * *reinterpret_cast<const wg_f32x4 *>(table + off + ve[k]);
-                    }
+                for (int d = 0; d < nd; ++d) {
+                    const long off = s_off[d][vj[k]];
+                    if (off >= 0) acc[k] += s_g[d] * *reinterpret_cast<const wg_f32x4 *>(table + off + ve[k]);
                 }
             }
-            if (tid == 0 && v0 == 0)
-                for (int d = 0; d < nd; ++d) sb += s_g[d];
         }
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            const int v = v0 + tid + k * WG_THREADS;
-            if (v < nvec) *reinterpret_cast<wg_f32x4 *>(tw.part_w + ((size_t)s * F + f) * 3 * E + v * 4) = acc[k];
-        }
+        if (FIRST && tid == 0)
+            for (int d = 0; d < nd; ++d) sb += s_g[d];
     }
-    if (tid == 0) tw.part_b[(size_t)s * F + f] = sb;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int v = v0 + tid + k * WG_THREADS;
+        if (v < nvec) *reinterpret_cast<wg_f32x4 *>(tw.part_w + ((size_t)s * F + f) * 3 * E + v * 4) = acc[k];
+    }
+    if (FIRST && tid == 0) tw.part_b[(size_t)s * F + f] = sb;
+}
+
+__device__ __forceinline__ void wgrad_block(const WgradArgs &a, int f, int s, int tower) {
+    // Phase 1 resolves, for a chunk of documents at once, the dependent chain
+    // argmax -> position -> token id -> table row offset (one lane per (document, tap), so
+    // the chain's latency is paid once per chunk, not once per document); phase 2 streams
+    // the resolved rows with independent float4 loads.
+    // One pass takes up to 3 E / 4 = 512 float4 columns (word_embed_size <= 680: every configuration of BASELINE.json, the
+    // code path and the code of rounds 1-4); wider windows (the reference puts no bound on word_embed_size,
+    // hyper_params.py:64) take another pass per 512 columns, repeating the resolve phase instead of costing every launch
+    // registers.  Per column the additions are the same, in the same document order, whatever the pass.
+    __shared__ long s_off[WG_CHUNK][3];     // table row offset in floats, -1 = no contribution
+    __shared__ float s_g[WG_CHUNK];
+    wgrad_block_pass<true>(a, f, s, tower, 0, s_off, s_g);
+    const int nvec = 3 * a.E / 4;
+    for (int v0 = 2 * WG_THREADS; v0 < nvec; v0 += 2 * WG_THREADS) wgrad_block_pass<false>(a, f, s, tower, v0, s_off, s_g);
 }
 
 
