@@ -488,6 +488,11 @@ class DeepCoNNEngine(_ConvRule):
         self._exchange_and_update(self.flat_p, self.flat_g, self.flat_m, self.flat_v, self.step_count)
         return se
 
+    def _exchange_prepare(self, how):
+        """What this rank needs, by itself, before exchange form `how` can run (no collective in here)."""
+        if how == 'gather' and self._gathered is None:
+            self._gathered = torch.empty(self.dp.world * self.total, dtype=torch.float32, device=self.dev)
+
     def _exchange_and_update(self, p, g, m, v, step):
         """Sum the ranks' gradients and apply Adam update number `step` to (p, m, v)."""
         if self.exchange == 'peer':
@@ -507,8 +512,7 @@ class DeepCoNNEngine(_ConvRule):
             _lib.check(rc, 'r4r_adam_gathered_guarded')
             return
         if self.exchange == 'gather':
-            if self._gathered is None:
-                self._gathered = torch.empty(self.dp.world * self.total, dtype=torch.float32, device=self.dev)
+            self._exchange_prepare('gather')
             self.dp.gather_flat(g, self._gathered)
             rc = _lib.lib().r4r_adam_gathered(ptr(p), ptr(self._gathered), self.dp.world, ptr(g), ptr(m), ptr(v),
                                               self.total, self.lr, self.betas[0], self.betas[1], self.eps, self.wd,
@@ -567,18 +571,21 @@ class DeepCoNNEngine(_ConvRule):
         def candidates():
             out = {}
             for how in ('allreduce', 'gather'):
-                # a candidate that RAISES on any rank is dropped on every rank (the agreement below is the only
-                # collective a failed rank still joins for it)
+                # Everything a rank does ALONE for a form -- its buffers, its checks -- happens in _exchange_prepare, and
+                # the ranks agree on the outcome BEFORE the form's first collective: a form one rank cannot set up is
+                # dropped on every rank.  (A failure inside a collective cannot be agreed on any more -- the other ranks
+                # are in it; there the deadline of wait() turns a hang into an error.)
                 try:
-                    ms, err = time_one(how), None
+                    self._exchange_prepare(how)
+                    err = None
                 except Exception as e:                       # noqa: BLE001
-                    ms, err = float('inf'), '%s: %s' % (type(e).__name__, e)
+                    err = '%s: %s' % (type(e).__name__, e)
                 if not agreed_ok(err is None):
                     import warnings
-                    warnings.warn('autotune_exchange: the %r exchange failed here (%s); dropped on every rank'
+                    warnings.warn('autotune_exchange: the %r exchange cannot be set up here (%s); dropped on every rank'
                                   % (how, err or 'another rank reported it'), RuntimeWarning)
                     continue
-                t = torch.tensor([ms], dtype=torch.float64, device=self.dev)
+                t = torch.tensor([time_one(how)], dtype=torch.float64, device=self.dev)
                 torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX, group=self.dp.group)
                 out[how] = float(t.item())
             return out
