@@ -130,16 +130,8 @@ __global__ __launch_bounds__(1024) void proj_compact_kernel(TokenArgs a) {
 // waves per SIMD cover each other's stalls.  K runs in chunks of 16 floats through two LDS
 // buffers, two operand register sets and two staging register sets.
 //
-// What bounds it (tools/gemm_trace.py, tools/microbench/): under this load the
-// shader clock sits at ~2.1-2.2 GHz, not the 2.4 GHz behind the 157 TFLOP/s figure; every memory
-// instruction a wave issues costs its MFMA stream ~20 cycles (12 ds_read_b128 per 80 MFMAs take
-// 9-11 % off the pure MFMA rate in isolation); prologue + epilogue are ~5 us of a ~54 us launch
-// and all workgroups run them in phase.  Two other decompositions were built and measured
-// slower: two 4-wave workgroups per row tile (one per column half: the A tile staged twice,
-// 61.9 us vs 57.5), and a B-stationary form (an 80-column slice of W resident in LDS, A straight
-// from global memory into registers in the MFMA layout, no barrier in the loop: 9 instead of 20
-// memory instructions per 80 MFMAs, but four times the A traffic and waves that finish out of
-// step -- a wave storing its tile while its SIMD neighbour streams MFMAs crawls: 64.3 us).
+// (What bounds it -- the clock under load, what a memory instruction costs the MFMA stream, prologue + epilogue --
+// and the decompositions that were built and measured slower: DESIGN.md 4.2 and Appendix A.)
 constexpr int GEMM_THREADS = 512;
 constexpr int WB_ROWS = 320;                              // B rows staged: 304 padded to 5 x 64
 constexpr int GEMM_BUF = (PM + WB_ROWS) * PS;               // floats per LDS buffer
@@ -546,12 +538,9 @@ __device__ __forceinline__ void proj_gemm7_body(const ProjArgs &a, float *lds, c
 }
 
 // ---- 2c. the A-resident form of the balanced decomposition (form 3).
-// What the two forms above leave on the table (profiles/r03a_gemm_variants.txt): a timing-only build that stores
-// nothing runs 51-52 us where the real kernel takes 58 -- every workgroup finishes its K loop at the same moment,
-// 35.5 MB of projected rows are written in one burst, sit dirty in the L2s and are written back when the kernel
-// ends (~6 TB/s), with no MFMA issued meanwhile.  Output can only leave earlier if it is COMPLETE earlier, i.e. if
-// a workgroup runs all of K over part of its tile, then all of K again over the rest -- which the forms above
-// cannot do without staging their operands twice.
+// In the forms above every workgroup finishes its K loop at the same moment and 35.5 MB of projected rows leave in one
+// burst, with no MFMA issued meanwhile.  Output can only leave earlier if it is COMPLETE earlier, i.e. if a workgroup
+// runs all of K over part of its tile, then all of K again over the rest -- without staging its operands twice.
 // Here the workgroup's A rows (P private row tiles + the shared one, <= 128 rows x all of K, swizzled 64-byte chunk
 // rows: 155,648 B of the CU's 160 KB at E = 300) stay RESIDENT in LDS once staged, and the B operand never passes
 // through LDS: every wave owns whole COLUMN tiles (3 or 2 of the 19: waves w and w + 4 of a SIMD share its 5, SIMD
@@ -571,9 +560,7 @@ __device__ __forceinline__ void proj_gemm7_body(const ProjArgs &a, float *lds, c
 // Only pass 2's share of the output (a fifth at P = 7) is still written in the final burst.  Same K order per output
 // element as the other forms: identical bits.  P = 4 .. 7 (the balanced form's plan generalised: the smallest P whose
 // plan applies puts the most CUs to work -- cfg4's 1,234 row tiles run as 246 workgroups of 5 instead of 176 of 7).
-// Measured alternatives (row-group passes, column groups 2 | 1, chunks per barrier, write-through / nontemporal
-// stores, mid-kernel write-back requests, deeper weight prefetch, several rounds of tiles per workgroup): DESIGN.md
-// 4.1b, profiles/r03a_gemm_variants.txt.
+// (Measured alternatives: DESIGN.md Appendix A, docs/DESIGN_rounds1-4.md 4.1b.)
 //
 // weight operand x table operand: the lane ends up with 4 consecutive COLUMNS of one table row (same fma chain as
 // the other forms' table x weight order: identical bits), which it stores as one float4
