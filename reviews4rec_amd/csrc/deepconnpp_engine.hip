@@ -262,7 +262,7 @@ extern "C" int r4r_deepconnpp_nparam(void) { return DP_COUNT; }
 
 extern "C" int r4r_deepconnpp_layout(int E, int L, int64_t *offsets, int64_t *sizes, int64_t *total) {
     R4R_REQUIRE(offsets && sizes && total, "deepconnpp_layout: null pointer");
-    R4R_REQUIRE(E > 0 && L > 0 && L <= NR_MAX_L, "deepconnpp_layout: bad sizes");
+    R4R_REQUIRE(E > 0 && L > 0 && L <= HEAD_MAX_L, "deepconnpp_layout: bad sizes");
     const DLayout lay = dcpp_layout(E, L);
     for (int i = 0; i < DP_COUNT; ++i) { offsets[i] = lay.off[i]; sizes[i] = lay.size[i]; }
     *total = lay.total;
@@ -298,7 +298,7 @@ extern "C" int r4r_deepconnpp_step(const float *table, int64_t V, const int64_t 
                                    void *stream) {
     R4R_REQUIRE(table && user_idx && item_idx && uid && iid && flat_p && rows_p && pred && ws, "deepconnpp_step: null pointer");
     R4R_REQUIRE(V > 0 && B >= 0 && T > 0 && n_users > 0 && n_items > 0, "deepconnpp_step: bad sizes");
-    R4R_REQUIRE(L > 0 && L <= NR_MAX_L, "deepconnpp_step: latent_size %d outside 1..%d", L, NR_MAX_L);
+    R4R_REQUIRE(L > 0 && L <= HEAD_MAX_L, "deepconnpp_step: latent_size %d outside 1..%d", L, HEAD_MAX_L);
     R4R_REQUIRE(E > 0 && E % 4 == 0, "deepconnpp_step: word_embed_size %d must be a positive multiple of 4", E);
     const bool train_step = flat_g != nullptr;
     // flat_m == NULL on a training step: gradients only (flat_g, d loss / d pred in the workspace) -- the
@@ -372,7 +372,8 @@ extern "C" int r4r_deepconnpp_step(const float *table, int64_t V, const int64_t 
     h.B = B; h.L = L; h.tiles = tiles; h.nhp = nhp; h.training = training; h.want_grad = train_step;
     h.now = (int)adam_step; h.p_drop = dropout_p; h.inv_denom = inv_denom; h.seed = seed; h.offset = offset;
     if (L <= 16) dcpp_head_kernel<16><<<(unsigned)B, 256, 0, st>>>(h);
-    else dcpp_head_kernel<32><<<(unsigned)B, 256, 0, st>>>(h);
+    else if (L <= 32) dcpp_head_kernel<32><<<(unsigned)B, 256, 0, st>>>(h);
+    else dcpp_head_kernel<64><<<(unsigned)B, 256, 0, st>>>(h);          // latent_size 33 .. 64 (hyper_params.py:63 has no bound)
     if (!train_step) return check_launch("deepconnpp_step(forward)");
 
     WgradTower wt[2];

@@ -30,7 +30,7 @@ namespace r4r {
 enum { IDN_MF = 0, IDN_GMF, IDN_MLP, IDN_NEUMF };
 // flat dense layout: projection / project .1 and .3, final (FM: V + lin, else Linear), global bias
 enum { IP_P1W = 0, IP_P1B, IP_P3W, IP_P3B, IP_FV, IP_FW, IP_FB, IP_GB, IP_COUNT };
-constexpr int IDN_MAX_L = 32;        // LDS arrays of the head kernel are sized by it (and MF's FM reads 2L <= 64 inputs)
+constexpr int IDN_MAX_L = 64;        // LDS arrays of the head kernel are sized by it (85 KB at 64: W1 [64][129], W3 [64][65], FV [128][65])
 
 struct ILayout { int64_t off[IP_COUNT], size[IP_COUNT], total; };
 
@@ -448,7 +448,8 @@ extern "C" int r4r_idnet_step(int variant, const int64_t *uid, const int64_t *ii
     h.B = B; h.L = L; h.np = (int)lay.total; h.variant = variant; h.training = training; h.want_grad = train_step;
     h.now = (int)adam_step; h.p_drop = dropout_p; h.inv_denom = inv_denom; h.seed = seed; h.offset = offset;
     if (L <= 16) idnet_head_kernel<16><<<(unsigned)B, 256, 0, st>>>(h);
-    else idnet_head_kernel<IDN_MAX_L><<<(unsigned)B, 256, 0, st>>>(h);
+    else if (L <= 32) idnet_head_kernel<32><<<(unsigned)B, 256, 0, st>>>(h);
+    else idnet_head_kernel<IDN_MAX_L><<<(unsigned)B, 256, 0, st>>>(h);       // latent_size 33 .. 64 (hyper_params.py:63 has no bound)
     if (!train_step) {
         if (int rc = check_launch("idnet_step(forward)")) return rc;
         return R4R_OK;

@@ -17,7 +17,8 @@
 namespace r4r {
 
 constexpr int NF = 100;                // conv filters (common_pytorch_models.py:11)
-constexpr int NR_MAX_L = 32, NR_MAX_R = 32;        // hard limits; the kernels are instantiated for <= 16 and <= 32
+constexpr int NR_MAX_L = 32, NR_MAX_R = 32;        // hard limits of the fused ID-table ROW role (a row in registers); instantiated for <= 16 and <= 32
+constexpr int HEAD_MAX_L = 64;                       // DeepCoNN++'s and TransNet's heads (LDS arrays by the template's ML; their ID parts go through the MF sweeps)
 
 // ---- 4: column sums of the [B, NHP] matrix (fixed order) -> flat gradient; + running SE
 struct ColSum {

@@ -246,22 +246,38 @@ __global__ __launch_bounds__(256) void tn_head_kernel(TnHead a) {
     HEAD_STAMP(4)
     // ---- S4: the two factorisation machines (common_pytorch_models.py:49-57): wave 0 source, wave 1 target
     if (wv < 2) {
+        // input i = lane + 64 u (two per lane: TransNet++'s source FM reads latent_size + 10 inputs, up to 74)
         const int n = wv ? L : ns;
-        const float xi = lane < n ? (wv ? tir[lane] : fin[lane]) : 0.f;
-        float inter = 0.f, gacc = 0.f;
+        float xi[2], lw[2], gacc[2] = {0.f, 0.f};
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int i = lane + 64 * u;
+            xi[u] = i < n ? (wv ? tir[i] : fin[i]) : 0.f;
+            lw[u] = i < n ? (wv ? lwt[i] : lws[i]) : 0.f;
+        }
+        float inter = 0.f;
 #pragma unroll
         for (int k = 0; k < TN_FM_K; ++k) {
-            const float v = lane < n ? (wv ? Vt[lane][k] : Vs[lane][k]) : 0.f;
-            const float s = wave_sum(xi * v);
-            const float s2 = wave_sum(xi * xi * v * v);
+            float v[2], pv = 0.f, pv2 = 0.f;
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int i = lane + 64 * u;
+                v[u] = i < n ? (wv ? Vt[i][k] : Vs[i][k]) : 0.f;
+                pv += xi[u] * v[u];
+                pv2 += xi[u] * xi[u] * v[u] * v[u];
+            }
+            const float s = wave_sum(pv);
+            const float s2 = wave_sum(pv2);
             inter += s * s - s2;
-            gacc += s * v - xi * v * v;
+#pragma unroll
+            for (int u = 0; u < 2; ++u) gacc[u] += s * v[u] - xi[u] * v[u] * v[u];
             if (lane == 0) (wv ? skt : sks)[k] = s;
         }
-        const float lw = lane < n ? (wv ? lwt[lane] : lws[lane]) : 0.f;
-        const float lin = wave_sum(xi * lw);
+        const float lin = wave_sum(xi[0] * lw[0] + xi[1] * lw[1]);
         const float out = 0.5f * inter + (lin + misc[wv]);
-        if (lane < n) (wv ? dft : dfs)[lane] = gacc + lw;      // d FM / d x_i
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+            if (lane + 64 * u < n) (wv ? dft : dfs)[lane + 64 * u] = gacc[u] + lw[u];      // d FM / d x_i
         if (lane == 0) misc[2 + wv] = out;
     } else if (wv == 2) {
         const float d = lane < L ? sir[lane] - tir[lane] : 0.f;
@@ -423,7 +439,7 @@ extern "C" int r4r_transnet_nparam(void) { return TN_COUNT; }
 
 extern "C" int r4r_transnet_layout(int E, int L, int plus, int64_t *offsets, int64_t *sizes, int64_t *total) {
     R4R_REQUIRE(offsets && sizes && total, "transnet_layout: null pointer");
-    R4R_REQUIRE(E > 0 && L > 0 && L <= NR_MAX_L, "transnet_layout: bad sizes");
+    R4R_REQUIRE(E > 0 && L > 0 && L <= HEAD_MAX_L, "transnet_layout: bad sizes");
     const TLayout lay = tn_layout(E, L, plus);
     for (int i = 0; i < TN_COUNT; ++i) { offsets[i] = lay.off[i]; sizes[i] = lay.size[i]; }
     *total = lay.total;
@@ -471,7 +487,7 @@ extern "C" int r4r_transnet_step(const float *table, int64_t V,
     R4R_REQUIRE(sweep_base >= 0 && (!flat_g || sweep_base < adam_step), "transnet_step: sweep_base outside 0..adam_step - 1");
     R4R_REQUIRE(!plus || (uid && iid && rows_p), "transnet_step: TransNet++ needs the ids and the ID-vector tables");
     R4R_REQUIRE(V > 0 && B >= 0 && T > 0 && n_users > 0 && n_items > 0, "transnet_step: bad sizes");
-    R4R_REQUIRE(L > 0 && L <= NR_MAX_L, "transnet_step: latent_size %d outside 1..%d", L, NR_MAX_L);
+    R4R_REQUIRE(L > 0 && L <= HEAD_MAX_L, "transnet_step: latent_size %d outside 1..%d", L, HEAD_MAX_L);
     R4R_REQUIRE(E > 0 && E % 4 == 0, "transnet_step: word_embed_size %d must be a positive multiple of 4", E);
     const bool train_step = flat_g != nullptr;
     // flat_m == NULL on a training step: gradients only (flat_g, the compact ID-vector rows) -- the data-parallel
@@ -572,7 +588,8 @@ extern "C" int r4r_transnet_step(const float *table, int64_t V,
     h.B = B; h.L = L; h.tiles = tiles; h.nhp = nhp; h.training = training; h.want_grad = train_step;
     h.now = (int)adam_step; h.plus = plus; h.p_drop = dropout_p; h.inv_denom = inv_denom; h.seed = seed; h.offset = offset;
     if (L <= 16) tn_head_kernel<16><<<(unsigned)B, 256, 0, st>>>(h);
-    else tn_head_kernel<32><<<(unsigned)B, 256, 0, st>>>(h);
+    else if (L <= 32) tn_head_kernel<32><<<(unsigned)B, 256, 0, st>>>(h);
+    else tn_head_kernel<64><<<(unsigned)B, 256, 0, st>>>(h);          // latent_size 33 .. 64 (hyper_params.py:63 has no bound)
     if (!train_step) return check_launch("transnet_step(forward)");
 
     WgradTower wt[3];

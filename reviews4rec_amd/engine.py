@@ -1607,7 +1607,7 @@ class IdNetEngine(_SweepSchedule):
         'NeuMF': ['gmf_user_embedding.weight', 'gmf_item_embedding.weight', 'mlp_user_embedding.weight',
                   'mlp_item_embedding.weight'],
     }
-    MAX_L, MAX_TRAIN_BATCH = 32, 32768
+    MAX_L, MAX_TRAIN_BATCH = 64, 32768
 
     @staticmethod
     def kind_of(model):

@@ -185,16 +185,17 @@ def native_step_limits(hyper_params, world=1):
             return 'global batch %d > %d' % (B * world, 1 << 20)
         return None
     if mt in ('MF', 'NeuMF'):
-        if L > 32:
-            return 'latent_size %d > 32' % L
+        if L > 64:                                          # (csrc/idnet_engine.hip: the head's LDS arrays, 85 KB at 64)
+            return 'latent_size %d > 64' % L
         if B * world > 32768:
             return 'global batch %d > 32768' % (B * world)
         return None
     if mt not in ('deepconn', 'deepconn++', 'NARRE', 'transnet', 'transnet++'):
         return 'no fused native step for model_type %r' % (mt,)
-    # csrc/engine.hip: DeepCoNN's head up to 128 (four FM inputs per lane, 115 KB of LDS); csrc/narre_engine.hip: the
-    # head's 64 x 64 instantiation + the split step (its scorer matrices no longer fit LDS beyond); the others 32
-    maxL = {'deepconn': 128, 'NARRE': 64}.get(mt, 32)
+    # csrc/engine.hip: DeepCoNN's head up to 128 (four FM inputs per lane, 115 KB of LDS); the others 64 (NARRE: the head's
+    # 64 x 64 instantiation + the split step -- its scorer matrices no longer fit LDS beyond; DeepCoNN++, TransNet: 64
+    # instantiations of their heads)
+    maxL = {'deepconn': 128}.get(mt, 64)
     if L > maxL:
         return 'latent_size %d > %d' % (L, maxL)
     # (any word_embed_size: the engines zero-pad rows to whole float4 / whole K chunks -- engine.pad_width, exact -- and

@@ -1242,7 +1242,7 @@ def test_idnet_engine_dropout_masks_injected_into_oracle(case):
 
 
 @pytest.mark.parametrize('kind,L,B', [('MF', 32, 3000), ('NeuMF', 10, 2500), ('MLP', 24, 700), ('GMF', 5, 16384), ('GMF', 5, 32768),
-                                      ('MF', 16, 20000)])
+                                      ('MF', 16, 20000), ('MF', 64, 1200), ('NeuMF', 48, 900), ('MLP', 64, 500)])
 def test_idnet_engine_large_batches_with_popular_rows(kind, L, B):
     """Wide / odd latent sizes and batches where one item collects 14 % of the ratings and one user 5 %: the
     step against the oracle (dropout masks injected), run-to-run bit equality."""

@@ -213,7 +213,7 @@ def test_word_embed_size_not_a_multiple_of_four_module_path(mt):
             torch.testing.assert_close(got[k], v, rtol=2e-4, atol=1e-6, msg=lambda m: k + ': ' + m)
 
 
-@pytest.mark.parametrize('mt,L', [('deepconn', 160), ('MF', 48), ('transnet++', 80)])
+@pytest.mark.parametrize('mt,L', [('deepconn', 160), ('MF', 80), ('transnet++', 80), ('deepconn++', 80)])
 def test_latent_size_beyond_the_native_steps(mt, L):
     """latent_size has no bound in the reference (hyper_params.py:63).  The fused native steps are built for
     latent_size <= 32 (DeepCoNN's: <= 64, test_deepconn_native_step_at_latent_sizes_up_to_128); beyond that ``engine='auto'`` falls back -- with the reason -- to the op-by-op HIP path,
@@ -692,3 +692,50 @@ def test_word_embed_size_768(path):
     dev = [d.to(DEV) for d in data]
     pred = (eng.predict(dev, None)[0] if path == 'native' else model(dev).detach()).cpu()
     torch.testing.assert_close(pred, oracle.model_forward(P, data, hp, train=False), rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize('mt,L', [('deepconn++', 64), ('transnet', 48), ('transnet++', 64), ('deepconn++', 33)])
+def test_native_steps_of_the_other_text_families_at_latent_sizes_up_to_64(mt, L):
+    """latent_size 33 .. 64 (hyper_params.py:63 has no bound) on the fused native steps of
+    DeepCoNN++ and TransNet(++) -- 64-wide instantiations of their head kernels -- instead of the op-by-op path: two
+    training steps (TransNet: the three-optimiser step) and an eval forward against the CPU oracle."""
+    import reviews4rec_amd
+    from reviews4rec_amd import main as M
+    from helpers import synthetic_review_batch
+    from test_oracle_golden import ill_conditioned
+    B, T, E, V, U, I = 12, 60, 32, 300, 40, 30
+    hp = dict(model_type=mt, latent_size=L, word_embed_size=E, input_length=T, dropout=0.0, total_users=U,
+              total_items=I, lr=0.002, weight_decay=1e-6, batch_size=B)
+    assert M.native_step_limits(hp) is None
+    P = oracle.init_params(hp, vocab_size=V, seed=83)
+    tkey = 'target.word2vec.weight' if mt.startswith('transnet') else 'word2vec.weight'
+    model = reviews4rec_amd.get_model_class(mt)(dict(hp, word_vectors=P[tkey].numpy()))
+    model.load_state_dict(P)
+    model = model.to(DEV).train()
+    eng = M.make_engine(dict(hp, engine='native', log_file=None), model)
+    assert eng is not None and eng.L == L
+    is_tn = mt.startswith('transnet')
+    states = dict(source=oracle.AdamState(), source_fm=oracle.AdamState(), target=oracle.AdamState()) if is_tn \
+        else oracle.AdamState()
+    for step in range(2):
+        data, y = synthetic_review_batch(B, T, V, U, I, seed=140 + step)
+        se = eng.train_step([d.to(DEV) for d in data], y.to(DEV)).cpu().clone()
+        if is_tn:
+            ref_se, _, _ = oracle.transnet_train_step(P, data, y, hp, states)
+            torch.testing.assert_close(se, ref_se, rtol=1e-4, atol=1e-4)
+        else:
+            sse, _ = oracle.train_step(P, data, y, hp, states)
+            torch.testing.assert_close(se.sum(), torch.tensor(sse), rtol=1e-4, atol=1e-3)
+    if hasattr(eng, 'flush'):
+        eng.flush()
+    sd = model.state_dict()
+    for k, v in P.items():
+        if not ill_conditioned(k):
+            diff = (sd[k].cpu() - v).abs()
+            assert float((diff > 2e-5 + 1e-4 * v.abs()).float().mean()) < 2e-3 and float(diff.max()) < 2.5e-3, k
+    model.eval()
+    data, y = synthetic_review_batch(B, T, V, U, I, seed=150)
+    out = eng.predict([d.to(DEV) for d in data], None)[0].cpu()
+    ref = oracle.model_forward(P, data, hp, train=False)
+    ref = ref[0] if isinstance(ref, (list, tuple)) else ref
+    torch.testing.assert_close(out, ref, rtol=1e-4, atol=1e-4)
