@@ -142,29 +142,35 @@ __global__ __launch_bounds__(NT) void narre_head_kernel(NarreHead a) {
     // ---- S0: weights -> LDS, pool finish, ID vectors.  The three big reads -- the pooling
     // partials, the FC matrices, the scorer matrices -- are issued into registers before anything
     // waits (a load -> LDS-store loop is one memory round trip per iteration: 8 + 8 + 2 of them)
-    constexpr int PREG = (2 * MR * NF + NT - 1) / NT, WREG = (2 * ML * NF + NT - 1) / NT,
+    // (the kernel is bound by vector-ALU issue: the 2,000-element partial and FC-weight blocks move as 16-byte units
+    // -- NF / 4 = 25 filter quads per row -- a quarter of the loads, index computations and stores)
+    constexpr int NQ4 = NF / 4;
+    typedef float hq4 __attribute__((ext_vector_type(4)));
+    typedef int hi4 __attribute__((ext_vector_type(4)));
+    constexpr int PREG = (2 * MR * NQ4 + NT - 1) / NT, WREG = (2 * ML * NQ4 + NT - 1) / NT,
                   AREG = (2 * ML * 2 * ML + NT - 1) / NT;
-    float pv[PREG], wv[WREG], av[AREG];
-    int pa[PREG];
+    hq4 pv[PREG], wv[WREG];
+    float av[AREG];
+    hi4 pa[PREG];
     const bool one_tile = a.tiles == 1;
 #pragma unroll
     for (int u = 0; u < PREG; ++u) {
-        pv[u] = 0.f; pa[u] = 0;
-        if (one_tile && NT * u < 2 * R * NF) {             // uniform: rounds past the end cost nothing
-            const int i = min(tid + NT * u, 2 * R * NF - 1);
-            const int s = i >= R * NF, rem = i - s * R * NF, rr = rem / NF, f = rem - rr * NF;
-            const size_t q = ((size_t)(b * R + rr) * a.tiles) * NP + f;
-            pv[u] = a.pmax[s][q];
-            pa[u] = a.parg[s][q];
+        pv[u] = (hq4){0.f, 0.f, 0.f, 0.f}; pa[u] = (hi4){0, 0, 0, 0};
+        if (one_tile && NT * u < 2 * R * NQ4) {            // uniform: rounds past the end cost nothing
+            const int i = min(tid + NT * u, 2 * R * NQ4 - 1);
+            const int s = i >= R * NQ4, rem = i - s * R * NQ4, rr = rem / NQ4, q4 = rem - rr * NQ4;
+            const size_t q = ((size_t)(b * R + rr) * a.tiles) * NP + 4 * q4;
+            pv[u] = *reinterpret_cast<const hq4 *>(a.pmax[s] + q);
+            pa[u] = *reinterpret_cast<const hi4 *>(a.parg[s] + q);
         }
     }
 #pragma unroll
     for (int u = 0; u < WREG; ++u) {
-        wv[u] = 0.f;
-        if (NT * u < 2 * L * NF) {
-            const int i = min(tid + NT * u, 2 * L * NF - 1);
-            const int s = i >= L * NF;
-            wv[u] = fp[a.off[s ? NP_IFW : NP_UFW] + i - s * L * NF];
+        wv[u] = (hq4){0.f, 0.f, 0.f, 0.f};
+        if (NT * u < 2 * L * NQ4) {
+            const int i = min(tid + NT * u, 2 * L * NQ4 - 1);
+            const int s = i >= L * NQ4;
+            wv[u] = *reinterpret_cast<const hq4 *>(fp + a.off[s ? NP_IFW : NP_UFW] + 4 * (i - s * L * NQ4));
         }
     }
 #pragma unroll
@@ -213,9 +219,11 @@ __global__ __launch_bounds__(NT) void narre_head_kernel(NarreHead a) {
 #pragma unroll
     for (int u = 0; u < WREG; ++u) {
         const int i = tid + NT * u;
-        if (i < 2 * L * NF) {
-            const int s = i >= L * NF, r = i - s * L * NF, l = r / NF;
-            fcw[(s * L + l) * (NF + 1) + r - l * NF] = wv[u];
+        if (i < 2 * L * NQ4) {
+            const int s = i >= L * NQ4, r = i - s * L * NQ4, l = r / NQ4;
+            float *dst = fcw + (s * L + l) * (NF + 1) + 4 * (r - l * NQ4);      // (rows of NF + 1 floats: four 4-byte writes)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) dst[c] = wv[u][c];
         }
     }
 #pragma unroll
@@ -241,15 +249,17 @@ __global__ __launch_bounds__(NT) void narre_head_kernel(NarreHead a) {
 #pragma unroll
         for (int u = 0; u < PREG; ++u) {
             const int i = tid + NT * u;
-            if (i < 2 * R * NF) {
-                const int s = i >= R * NF, rem = i - s * R * NF, rr = rem / NF, f = rem - rr * NF;
+            if (i < 2 * R * NQ4) {
+                const int s = i >= R * NQ4, rem = i - s * R * NQ4, rr = rem / NQ4, q4 = rem - rr * NQ4;
                 const int64_t n = b * R + rr;
-                float best = pv[u];
-                int bp = pa[u];
-                if (!(best > 0.f)) { best = 0.f; bp = -1; }
-                P[i] = best;
-                a.pooled[s][n * NF + f] = best;
-                a.argmax[s][n * NF + f] = bp;
+                hq4 best = pv[u];
+                hi4 bp = pa[u];
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+                    if (!(best[c] > 0.f)) { best[c] = 0.f; bp[c] = -1; }
+                *reinterpret_cast<hq4 *>(P + (s * R + rr) * NF + 4 * q4) = best;
+                *reinterpret_cast<hq4 *>(a.pooled[s] + n * NF + 4 * q4) = best;
+                *reinterpret_cast<hi4 *>(a.argmax[s] + n * NF + 4 * q4) = bp;
             }
         }
     } else {
