@@ -74,7 +74,7 @@ template <int ML>
 __global__ __launch_bounds__(256) void tn_head_kernel(TnHead a) {
     HEAD_STAMP(0)
     constexpr int MS = ML + 2 * TN_ID;                      // widest source_fm input
-    __shared__ float P[3][NF];
+    __shared__ __attribute__((aligned(16))) float P[3][NF];
     __shared__ float fcw[3][ML][NF + 1];
     __shared__ float W0[ML][2 * ML + 1], W2[ML][ML + 1];
     __shared__ float Vs[MS][TN_FM_K], Vt[ML][TN_FM_K], lws[MS], lwt[ML];
@@ -103,15 +103,21 @@ __global__ __launch_bounds__(256) void tn_head_kernel(TnHead a) {
     // this prologue is issued into registers before anything waits (a load -> LDS-store loop is one
     // memory round trip per iteration, and the tile loop of the pool finish one per tile: 14.5 us
     // of a 26 us kernel at cfg5 -- tools/head_trace.py)
-    constexpr int WREG = (ML * NF + 255) / 256, AREG = (ML * 2 * ML + 255) / 256, FREG = (ML * ML + 255) / 256,
+    // (the kernel is bound by vector-ALU issue: the towers' FC weights move as 16-byte units -- NF / 4 = 25 filter quads
+    // per row -- a quarter of the loads and index computations)
+    constexpr int NQ4 = NF / 4;
+    typedef float hq4 __attribute__((ext_vector_type(4)));
+    constexpr int WREG = (ML * NQ4 + 255) / 256, AREG = (ML * 2 * ML + 255) / 256, FREG = (ML * ML + 255) / 256,
                   SREG = (MS * TN_FM_K + 255) / 256, TREG = (ML * TN_FM_K + 255) / 256, PT = 8;
-    float wreg[3][WREG], av[AREG], f2v[FREG], vsv[SREG], vtv[TREG];
-    const int wtot = L * NF;
+    hq4 wreg[3][WREG];
+    float av[AREG], f2v[FREG], vsv[SREG], vtv[TREG];
+    const int wtot = L * NQ4;
 #pragma unroll
     for (int s = 0; s < 3; ++s) {
         const float *src = fp + a.off[s == 0 ? TN_UFW : (s == 1 ? TN_IFW : TN_TFW)];
 #pragma unroll
-        for (int u = 0; u < WREG; ++u) wreg[s][u] = 256 * u < wtot ? src[min(tid + 256 * u, wtot - 1)] : 0.f;
+        for (int u = 0; u < WREG; ++u)
+            wreg[s][u] = 256 * u < wtot ? *reinterpret_cast<const hq4 *>(src + 4 * min(tid + 256 * u, wtot - 1)) : (hq4){0.f, 0.f, 0.f, 0.f};
     }
 #pragma unroll
     for (int u = 0; u < AREG; ++u) av[u] = 256 * u < L * L2 ? fp[a.off[TN_P0W] + min(tid + 256 * u, L * L2 - 1)] : 0.f;
@@ -173,7 +179,11 @@ __global__ __launch_bounds__(256) void tn_head_kernel(TnHead a) {
 #pragma unroll
         for (int u = 0; u < WREG; ++u) {
             const int r = tid + 256 * u;
-            if (r < wtot) { const int l = r / NF; fcw[s][l][r - l * NF] = wreg[s][u]; }
+            if (r < wtot) {
+                const int l = r / NQ4, f0 = 4 * (r - l * NQ4);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) fcw[s][l][f0 + c] = wreg[s][u][c];   // (rows of NF + 1 floats: four 4-byte writes)
+            }
         }
 #pragma unroll
     for (int u = 0; u < AREG; ++u) {
@@ -246,21 +256,24 @@ __global__ __launch_bounds__(256) void tn_head_kernel(TnHead a) {
     HEAD_STAMP(4)
     // ---- S4: the two factorisation machines (common_pytorch_models.py:49-57): wave 0 source, wave 1 target
     if (wv < 2) {
-        // input i = lane + 64 u (two per lane: TransNet++'s source FM reads latent_size + 10 inputs, up to 74)
+        // input i = lane + 64 u: one per lane, two in the 64-wide instantiation (TransNet++'s source FM reads
+        // latent_size + 10 inputs, up to 74)
+        constexpr int NI = (MS + 63) / 64;
         const int n = wv ? L : ns;
-        float xi[2], lw[2], gacc[2] = {0.f, 0.f};
+        float xi[NI], lw[NI], gacc[NI];
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
+        for (int u = 0; u < NI; ++u) {
             const int i = lane + 64 * u;
             xi[u] = i < n ? (wv ? tir[i] : fin[i]) : 0.f;
             lw[u] = i < n ? (wv ? lwt[i] : lws[i]) : 0.f;
+            gacc[u] = 0.f;
         }
         float inter = 0.f;
 #pragma unroll
         for (int k = 0; k < TN_FM_K; ++k) {
-            float v[2], pv = 0.f, pv2 = 0.f;
+            float v[NI], pv = 0.f, pv2 = 0.f;
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
+            for (int u = 0; u < NI; ++u) {
                 const int i = lane + 64 * u;
                 v[u] = i < n ? (wv ? Vt[i][k] : Vs[i][k]) : 0.f;
                 pv += xi[u] * v[u];
@@ -270,13 +283,16 @@ __global__ __launch_bounds__(256) void tn_head_kernel(TnHead a) {
             const float s2 = wave_sum(pv2);
             inter += s * s - s2;
 #pragma unroll
-            for (int u = 0; u < 2; ++u) gacc[u] += s * v[u] - xi[u] * v[u] * v[u];
+            for (int u = 0; u < NI; ++u) gacc[u] += s * v[u] - xi[u] * v[u] * v[u];
             if (lane == 0) (wv ? skt : sks)[k] = s;
         }
-        const float lin = wave_sum(xi[0] * lw[0] + xi[1] * lw[1]);
+        float pl = 0.f;
+#pragma unroll
+        for (int u = 0; u < NI; ++u) pl += xi[u] * lw[u];
+        const float lin = wave_sum(pl);
         const float out = 0.5f * inter + (lin + misc[wv]);
 #pragma unroll
-        for (int u = 0; u < 2; ++u)
+        for (int u = 0; u < NI; ++u)
             if (lane + 64 * u < n) (wv ? dft : dfs)[lane + 64 * u] = gacc[u] + lw[u];      // d FM / d x_i
         if (lane == 0) misc[2 + wv] = out;
     } else if (wv == 2) {
@@ -363,9 +379,13 @@ __global__ __launch_bounds__(256) void tn_head_kernel(TnHead a) {
         const int s = tid / L;
         prow[col(a.off[s == 0 ? TN_UFB : (s == 1 ? TN_IFB : TN_TFB)] + (tid - s * L))] = dz[tid];
     }
-    for (int s = 0; s < 3; ++s) {
+    for (int s = 0; s < 3; ++s) {                           // (filter quads: 16-byte reads of the pooled features, 16-byte stores)
         float *dst = prow + col(a.off[s == 0 ? TN_UFW : (s == 1 ? TN_IFW : TN_TFW)]);
-        for (int r = tid; r < L * NF; r += 256) { const int l = r / NF; dst[r] = dz[s * L + l] * P[s][r - l * NF]; }
+        for (int r = tid; r < L * NQ4; r += 256) {
+            const int l = r / NQ4, q = r - l * NQ4;
+            const hq4 p4 = *reinterpret_cast<const hq4 *>(&P[s][4 * q]);
+            *reinterpret_cast<hq4 *>(dst + l * NF + 4 * q) = dz[s * L + l] * p4;
+        }
     }
     for (int i = tid; i < 3 * NF; i += 256) {
         const int s = i / NF, f = i - s * NF;
