@@ -99,16 +99,19 @@ __global__ __launch_bounds__(256) void deepconn_head_wg_kernel(HeadArgs a) {
     const float lin_b0 = a.lin_b[0], gbias0 = a.gbias[0], yb = a.y ? a.y[b] : 0.f;
 
     // every load of the prologue is issued before anything waits: the FC matrices, FM V / lin, and this lane's partials
-    constexpr int WREGS = (2 * ML * F_CONV + 255) / 256;
-    float wreg[WREGS];
-    const int wtot = 2 * L * F_CONV;
+    // (the FC matrices as 16-byte units, F_CONV / 4 = 25 filter quads per row: a quarter of the loads and index computations)
+    constexpr int FQ = F_CONV / 4;
+    typedef float hq4 __attribute__((ext_vector_type(4)));
+    constexpr int WREGS = (2 * ML * FQ + 255) / 256;
+    hq4 wreg[WREGS];
+    const int wtot = 2 * L * FQ;
 #pragma unroll
     for (int k = 0; k < WREGS; ++k) {
-        wreg[k] = 0.f;
+        wreg[k] = (hq4){0.f, 0.f, 0.f, 0.f};
         if (256 * k < wtot) {                               // uniform
             const int i = min(tid + 256 * k, wtot - 1);
-            const int t = i >= L * F_CONV;
-            wreg[k] = a.fc_w[t][i - t * L * F_CONV];
+            const int t = i >= L * FQ;
+            wreg[k] = *reinterpret_cast<const hq4 *>(a.fc_w[t] + 4 * (i - t * L * FQ));
         }
     }
     const float fbreg = (tid < n) ? a.fc_b[tid / L][tid % L] : 0.f;
@@ -163,8 +166,9 @@ __global__ __launch_bounds__(256) void deepconn_head_wg_kernel(HeadArgs a) {
     for (int k = 0; k < WREGS; ++k) {
         const int i = tid + 256 * k;
         if (i < wtot) {
-            const int t = i >= L * F_CONV, r = i - t * L * F_CONV, l = r / F_CONV;
-            sw[t][l][r - l * F_CONV] = wreg[k];
+            const int t = i >= L * FQ, r = i - t * L * FQ, l = r / FQ, f0 = 4 * (r - l * FQ);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) sw[t][l][f0 + c] = wreg[k][c];          // (rows of F_CONV + 1 floats: four 4-byte writes)
         }
     }
     if (tid < n) { sfb[tid] = fbreg; slw[tid] = lwreg; }
