@@ -52,7 +52,7 @@ BWD_TRACE_DEFINE(r4r_debug_dcpp_bwd_trace)
 // One workgroup of 256 threads per rating (the work is ~2000-element loops: FC gradients, d pooled).
 template <int ML>
 __global__ __launch_bounds__(256) void dcpp_head_kernel(DcppHead a) {
-    __shared__ float P[2][NF];
+    __shared__ __attribute__((aligned(16))) float P[2][NF];
     __shared__ float fcw[2][ML][NF + 1];
     __shared__ float W1[ML][2 * ML + 1];
     __shared__ float x[2 * ML], xm[2 * ML], dzs[2 * ML], hs[ML], hms[ML], dhs[ML], fcbs[2 * ML], b1s[ML], w3s[ML], misc[8];
@@ -76,15 +76,20 @@ __global__ __launch_bounds__(256) void dcpp_head_kernel(DcppHead a) {
     // ---- S0: weights, pool finish (max over tiles, relu, first argmax), biases.  All global reads are
     // issued into registers before anything waits (a load -> LDS-store loop is one memory round
     // trip per iteration, the tile loop of the pool finish one per tile)
-    constexpr int WREG = (2 * ML * NF + 255) / 256, AREG = (ML * 2 * ML + 255) / 256, PT = 8;
-    float wv[WREG], av[AREG];
-    const int wtot = 2 * L * NF;
+    // (the FC matrices as 16-byte units, NF / 4 = 25 filter quads per row: a quarter of the loads and index computations --
+    // the head kernels are bound by vector-ALU issue)
+    constexpr int NQ4 = NF / 4;
+    typedef float hq4 __attribute__((ext_vector_type(4)));
+    constexpr int WREG = (2 * ML * NQ4 + 255) / 256, AREG = (ML * 2 * ML + 255) / 256, PT = 8;
+    hq4 wv[WREG];
+    float av[AREG];
+    const int wtot = 2 * L * NQ4;
 #pragma unroll
     for (int u = 0; u < WREG; ++u) {
-        wv[u] = 0.f;
+        wv[u] = (hq4){0.f, 0.f, 0.f, 0.f};
         if (256 * u < wtot) {
-            const int i = min(tid + 256 * u, wtot - 1), s = i >= L * NF;
-            wv[u] = fp[a.off[s ? DP_IFW : DP_UFW] + i - s * L * NF];
+            const int i = min(tid + 256 * u, wtot - 1), s = i >= L * NQ4;
+            wv[u] = *reinterpret_cast<const hq4 *>(fp + a.off[s ? DP_IFW : DP_UFW] + 4 * (i - s * L * NQ4));
         }
     }
 #pragma unroll
@@ -120,7 +125,11 @@ __global__ __launch_bounds__(256) void dcpp_head_kernel(DcppHead a) {
 #pragma unroll
     for (int u = 0; u < WREG; ++u) {
         const int i = tid + 256 * u;
-        if (i < wtot) { const int s = i >= L * NF, r = i - s * L * NF, l = r / NF; fcw[s][l][r - l * NF] = wv[u]; }
+        if (i < wtot) {
+            const int s = i >= L * NQ4, r = i - s * L * NQ4, l = r / NQ4, f0 = 4 * (r - l * NQ4);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) fcw[s][l][f0 + c] = wv[u][c];           // (rows of NF + 1 floats: four 4-byte writes)
+        }
     }
 #pragma unroll
     for (int u = 0; u < AREG; ++u) {
@@ -194,9 +203,10 @@ __global__ __launch_bounds__(256) void dcpp_head_kernel(DcppHead a) {
     __syncthreads();
     // ---- B3: TextCNN FC gradients, d pooled
     if (tid < L2) prow[col(a.off[tid >= L ? DP_IFB : DP_UFB] + (tid >= L ? tid - L : tid))] = dzs[tid];
-    for (int i = tid; i < 2 * L * NF; i += 256) {
-        const int s = i >= L * NF, r = i - s * L * NF, l = r / NF, f = r - l * NF;
-        prow[col(a.off[s ? DP_IFW : DP_UFW] + r)] = dzs[s * L + l] * P[s][f];
+    for (int i = tid; i < 2 * L * NQ4; i += 256) {          // (filter quads: 16-byte reads of the pooled features, 16-byte stores)
+        const int s = i >= L * NQ4, r = i - s * L * NQ4, l = r / NQ4, q = r - l * NQ4;
+        const hq4 p4 = *reinterpret_cast<const hq4 *>(&P[s][4 * q]);
+        *reinterpret_cast<hq4 *>(prow + col(a.off[s ? DP_IFW : DP_UFW] + l * NF + 4 * q)) = dzs[s * L + l] * p4;
     }
     if (tid < 2 * NF) {
         const int s = tid >= NF, f = tid - s * NF;
