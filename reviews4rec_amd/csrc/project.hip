@@ -580,26 +580,28 @@ struct AresFit { int rt[MAX_TOWERS], g[MAX_TOWERS], U, P; };
 // the left-over row tiles of a tower each shared column-wise by >= SH of its workgroups (SH = 3: at most 7 column
 // units per sharer, all on SIMD 3; SH = 2: up to 10, the three units past the seventh on the two-column waves of
 // SIMDs 0 - 2).  A pure function of the towers' distinct-token counts, evaluated by every workgroup.
+// (loops over the towers are unrolled to MAX_TOWERS with a guard: a run-time trip count made hipcc index rt[] / g[] dynamically,
+// i.e. keep them in scratch memory -- the plan is evaluated by every workgroup before its first load)
 __device__ __forceinline__ bool ares_fit(const ProjArgs &a, AresFit &f, int P, int cap, int SH) {
     int G = f.U / P;
     if (G > cap) G = cap;
     if (G < a.ntower) return false;
     int used = 0;
-    for (int t = 0; t < a.ntower; ++t) {
+    _Pragma("unroll") for (int t = 0; t < MAX_TOWERS; ++t) if (t < a.ntower) {
         f.g[t] = f.rt[t] * G / f.U;                         // (products < 2^24: 32-bit arithmetic)
         if (f.g[t] < 1) return false;
         used += f.g[t];
     }
     for (; used < G; ++used) {                              // (fewer than ntower of them)
         int best = -1, most = 0;
-        for (int t = 0; t < a.ntower; ++t) {
+        _Pragma("unroll") for (int t = 0; t < MAX_TOWERS; ++t) if (t < a.ntower) {
             const int left = f.rt[t] - P * (f.g[t] + 1);
             if (left >= 0 && f.rt[t] - P * f.g[t] > most) { most = f.rt[t] - P * f.g[t]; best = t; }
         }
         if (best < 0) break;
-        for (int t = 0; t < a.ntower; ++t) f.g[t] += (t == best);
+        _Pragma("unroll") for (int t = 0; t < MAX_TOWERS; ++t) f.g[t] += (t == best && t < a.ntower);
     }
-    for (int t = 0; t < a.ntower; ++t) {
+    _Pragma("unroll") for (int t = 0; t < MAX_TOWERS; ++t) if (t < a.ntower) {
         const int left = f.rt[t] - P * f.g[t];              // row tiles nobody owns: shared, >= SH workgroups each
         if (left < 0 || SH * left > f.g[t]) return false;
     }
@@ -613,7 +615,7 @@ __device__ __forceinline__ bool ares_plan_fit(const ProjArgs &a, int nwg, AresFi
     f.U = 0;
     for (int t = 0; t < MAX_TOWERS; ++t) f.rt[t] = 0;
     int tiles128 = 0;
-    for (int t = 0; t < a.ntower; ++t) {
+    _Pragma("unroll") for (int t = 0; t < MAX_TOWERS; ++t) if (t < a.ntower) {
         const int cnt = a.t[t].count[0];
         f.rt[t] = (cnt + 15) >> 4;
         f.U += f.rt[t];
@@ -635,7 +637,7 @@ __device__ __forceinline__ void ares_assign(const ProjArgs &a, const AresFit &f,
     p.tower = -1;
     p.P = P;
     int base = 0;
-    for (int t = 0; t < a.ntower; ++t) {
+    _Pragma("unroll") for (int t = 0; t < MAX_TOWERS; ++t) if (t < a.ntower) {
         if (wg >= base && wg < base + f.g[t]) {
             const int wl = wg - base, left = f.rt[t] - P * f.g[t];
             p.tower = t;
