@@ -315,19 +315,19 @@ struct Gemm7Plan { int tower, row0, sh_row0, sh_c0, sh_n; };
 __device__ __forceinline__ bool gemm7_plan(const ProjArgs &a, int wg, int nwg, Gemm7Plan &p) {
     int rt[MAX_TOWERS], g[MAX_TOWERS];
     int U = 0;
-    for (int t = 0; t < a.ntower; ++t) { rt[t] = (a.t[t].count[0] + 15) >> 4; U += rt[t]; }
+    _Pragma("unroll") for (int t = 0; t < MAX_TOWERS; ++t) { rt[t] = t < a.ntower ? (a.t[t].count[0] + 15) >> 4 : 0; U += rt[t]; g[t] = 0; }
     const int cap = nwg < G7_WGS ? nwg : G7_WGS;
     int G = U / G7_ROWS;
     if (G > cap) G = cap;
     if (G < a.ntower) return false;
-    for (int t = 0; t < a.ntower; ++t) {
+    _Pragma("unroll") for (int t = 0; t < MAX_TOWERS; ++t) if (t < a.ntower) {
         g[t] = rt[t] * G / U;                               // (products < 2^24: 32-bit arithmetic)
         const int left = rt[t] - G7_ROWS * g[t];           // row tiles nobody owns: shared, >= 3 workgroups each
         if (g[t] < 1 || left < 0 || 3 * left > g[t]) return false;
     }
     p.tower = -1;
     int base = 0;
-    for (int t = 0; t < a.ntower; ++t) {
+    _Pragma("unroll") for (int t = 0; t < MAX_TOWERS; ++t) if (t < a.ntower) {
         if (wg >= base && wg < base + g[t]) {
             const int wl = wg - base, left = rt[t] - G7_ROWS * g[t];
             p.tower = t;
@@ -977,12 +977,22 @@ __global__ __launch_bounds__(GEMM_THREADS) void proj_gemm_kernel(ProjArgs a) {
             return;
         }
     }
+    // (towers unrolled to MAX_TOWERS and first[] searched by selects: run-time indices would put the array in scratch memory)
     int first[MAX_TOWERS + 1];
     first[0] = 0;
-    for (int t = 0; t < a.ntower; ++t) first[t + 1] = first[t] + (a.t[t].count[0] + PM - 1) / PM;
+#pragma unroll
+    for (int t = 0; t < MAX_TOWERS; ++t) first[t + 1] = first[t] + (t < a.ntower ? (a.t[t].count[0] + PM - 1) / PM : 0);
+    auto tower_of = [&](int tile, int &row0) {
+        int t = 0, f0 = 0;
+#pragma unroll
+        for (int k = 1; k < MAX_TOWERS; ++k)
+            if (k < a.ntower && tile >= first[k]) { t = k; f0 = first[k]; }
+        row0 = (tile - f0) * PM;
+        return t;
+    };
     // (a launch whose tiles fill at most half of the grid is faster in column parts -- below -- than in the
     // balanced form, which keeps 112 rows per workgroup whatever the count)
-    if (a.balanced == 1 && first[a.ntower] * 2 > (int)gridDim.x) {
+    if (a.balanced == 1 && first[MAX_TOWERS] * 2 > (int)gridDim.x) {
         Gemm7Plan p;
         if (gemm7_plan(a, (int)blockIdx.x, (int)gridDim.x, p)) {
             if (p.tower < 0) return;                         // uniform: this workgroup has no rows
@@ -1004,22 +1014,20 @@ __global__ __launch_bounds__(GEMM_THREADS) void proj_gemm_kernel(ProjArgs a) {
     // the grid, each of its tiles is cut into 2 (4) COLUMN PARTS (10 + 9, or 5 + 5 + 5 + 4 column tiles) that as
     // many workgroups compute side by side, every wave on its own 16 rows: same per-element summation order,
     // same bits, and the round costs 0.55 (0.3) of a tile time.
-    const int total = first[a.ntower], G = (int)gridDim.x;
+    const int total = first[MAX_TOWERS], G = (int)gridDim.x;
     const int full = total / G * G, tail = total - full;
     const int parts = a.balanced == 2 ? 1 : (tail * 4 <= G ? 4 : (tail * 2 <= G ? 2 : 1));   // (2: whole tiles only -- A/B runs, tests)
     for (int tile = blockIdx.x; tile < (parts == 1 ? total : full); tile += gridDim.x) {
-        int t = 0;
-        while (tile >= first[t + 1]) ++t;
-        const int row0 = (tile - first[t]) * PM;
+        int row0;
+        const int t = tower_of(tile, row0);
         if (threadIdx.x >> 8) proj_gemm_body<PNT - PNH, 2>(a, lds, t, row0);   // waves 4..7: columns 160..303
         else proj_gemm_body<PNH, 3>(a, lds, t, row0);                          // waves 0..3: columns 0..159
         __syncthreads();                                    // every wave is done with the LDS buffers (operand reads, epilogue slabs)
     }
     if (parts > 1 && (int)blockIdx.x < tail * parts) {
         const int tile = full + (int)blockIdx.x / parts, part = (int)blockIdx.x % parts;
-        int t = 0;
-        while (tile >= first[t + 1]) ++t;
-        const int row0 = (tile - first[t]) * PM;
+        int row0;
+        const int t = tower_of(tile, row0);
         if (parts == 2) {
             if (part == 0) proj_gemm_body<PNH, 2, 1>(a, lds, t, row0, 0);
             else proj_gemm_body<PNT - PNH, 2, 1>(a, lds, t, row0, PNH_COLS);
