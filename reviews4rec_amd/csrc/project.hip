@@ -1252,21 +1252,23 @@ __global__ __launch_bounds__(256) void proj_gather_max_kernel(ProjArgs a) {
     // an XCD's, mix heads and tails.  Same work per workgroup, same outputs.  (What else was tried on this launch's
     // schedule and measured no faster -- segment pairs half a document apart, 16-position slices, a software-pipelined
     // group loop, hot rows staged in LDS, segments dealt to workgroups by cost: DESIGN.md 4.1b, profiles/r05_negatives.txt.)
-    int64_t bx = blockIdx.x;
+    // (32-bit arithmetic throughout: the launcher keeps N * tiles under 2^31, and a 64-bit division by a run-time value is a
+    // hundred instructions at the head of every workgroup's dependent chain)
+    unsigned bx = blockIdx.x;
     if (GSPW == 2 && (a.tiles & 1) == 0 && a.tiles >= 4) {
-        const int t2 = a.tiles >> 1;
-        const int64_t d = bx / t2;
-        const int pr = (int)(bx - d * t2);
-        bx = d * t2 + (pr + (int)(d / GATHER_ROTDIV)) % t2;
+        const unsigned t2 = (unsigned)a.tiles >> 1;
+        const unsigned d = bx / t2, pr = bx - d * t2;
+        bx = d * t2 + (pr + d / GATHER_ROTDIV) % t2;
     }
     // segment `unit` of the launch's N * tiles segments (document-major): workers 0-3 take the workgroup's first
     // segment, 4-7 its second -- of the same document, or (odd tile counts, e.g. NARRE's one-tile reviews) the first of
     // the next one
-    const int64_t units = a.N * a.tiles;
-    auto unit_of = [&](int h) -> int64_t { return bx * GSPW + h; };
-    const int64_t unit = unit_of(worker / GWPS);
-    const int64_t doc = unit < units ? unit / a.tiles : 0;
-    const int seg = unit < units ? (int)(unit - doc * a.tiles) : a.tiles;     // a.tiles: no such segment
+    const unsigned units = (unsigned)(a.N * a.tiles);
+    auto unit_of = [&](int h) -> unsigned { return bx * GSPW + h; };
+    const unsigned unit = unit_of(worker / GWPS);
+    const unsigned udoc = unit < units ? unit / (unsigned)a.tiles : 0u;
+    const int64_t doc = udoc;
+    const int seg = unit < units ? (int)(unit - udoc * (unsigned)a.tiles) : a.tiles;     // a.tiles: no such segment
     const int T = a.T, P = T + 2;
     const bool act = wl < PF / 4;
     const f32x4 zero = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -1363,7 +1365,7 @@ __global__ __launch_bounds__(256) void proj_gather_max_kernel(ProjArgs a) {
     HEAD_STAMP(2)
     // merge the 4 slices of each segment in position order; thread f (< 100) of each half
     const int half = threadIdx.x >> 7, f = threadIdx.x & 127;
-    const int64_t ounit = unit_of(half);
+    const unsigned ounit = unit_of(half);
     if (f < PF && ounit < units && half < GSPW) {
         float mb = sbest[half * GWPS][f];
         int mp = sbp[half * GWPS][f];
