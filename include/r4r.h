@@ -454,7 +454,33 @@ int r4r_mf_apply(const void *blocks, int world, int64_t B_pad, const uint64_t *p
  * The scheduled sweep under data parallelism: r4r_mf_apply(sweep_period, sweep_base, sweep_all) -- the SAME values on
  * every rank -- is r4r_mf_step's sweep over the gathered entries; r4r_mf_grad(m, v, ws = r4r_mf_apply's workspace,
  * the same schedule and optimiser scalars; all NULL / ignored when nothing can be pending) reads the rows its ratings
- * name as of step adam_step - 1.  r4r_mf_rows_flush on every rank before anything else reads the tables. */
+ * name as of step adam_step - 1.  r4r_mf_rows_flush on every rank before anything else reads the tables.
+ * Up to 2,048 gathered entries r4r_mf_apply is ONE launch: its workgroups read the ids out of the blocks and find the
+ * rows the step names themselves (beyond, a registering launch runs first).
+ *
+ * The same step with NO collective call -- the exchange rides on the two launches, over peer-mapped memory (the
+ * segments, flags and epochs of r4r_peer_* below; one process per GPU on an xGMI mesh):
+ * r4r_mf_grad_push: r4r_mf_grad whose block goes straight into slot `rank` of EVERY rank's gathered buffer
+ *   (peer_dst[r] = rank r's buffer of this epoch's parity, world slots of r4r_mf_dp_block_bytes each); the launch's last
+ *   workgroup raises flags[r][rank] = epoch on every rank (system-scope release).  arrive: one zeroed uint32 of this rank.
+ * r4r_mf_apply_peer: r4r_mf_apply on this rank's gathered buffer, every workgroup first waiting (bounded by
+ *   timeout_s; *timed_out = 1 + the missing rank otherwise) until all `world` flags of wait_flags (THIS rank's flag
+ *   array) have reached `epoch`.  world * B_pad <= 2,048. */
+int r4r_mf_grad_push(const int64_t *uid, const int64_t *iid, const float *y, const uint64_t *p,
+                     const uint64_t *m, const uint64_t *v,
+                     int64_t n_users, int64_t n_items, int D, float *pred, float *se, float *mult,
+                     int64_t B, int64_t B_pad, float dropout_p, int training, uint64_t seed, uint64_t offset,
+                     float inv_denom, void *ws, int sweep_period, int64_t sweep_base,
+                     float lr, double beta1, double beta2, float eps, float weight_decay, int64_t adam_step,
+                     const uint64_t *peer_dst, const uint64_t *peer_flags, uint32_t *arrive, int rank, int world,
+                     uint32_t epoch, void *stream);
+int r4r_mf_apply_peer(const void *blocks, int world, int64_t B_pad, const uint64_t *p, const uint64_t *m,
+                      const uint64_t *v, int64_t n_users, int64_t n_items, int D, void *ws, size_t ws_bytes,
+                      int sweep_period, int64_t sweep_base, int sweep_all,
+                      const float *se, int64_t se_n, float *sse_accum,
+                      float lr, double beta1, double beta2, float eps, float weight_decay, int64_t adam_step,
+                      const uint32_t *wait_flags, uint32_t epoch, uint32_t *timed_out, double timeout_s,
+                      void *stream);
 
 /* ---- fused native step for NARRE (pytorch_models/NARRE.py:10-124)
  * Replaces, per training step: the word gathers + TextCNN over the B*R review documents of each

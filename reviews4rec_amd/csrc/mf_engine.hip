@@ -27,6 +27,7 @@
 #include "adam_device.h"
 #include "common.h"
 #include "rows_device.h"
+#include "peer_device.h"
 #include "trace_device.h"
 
 namespace r4r {
@@ -68,13 +69,41 @@ struct MfStep {
     MfTimeBlock tb = MfTimeBlock{};
     AdamScalars sc0 = AdamScalars{};
     int now = 0;
+    // PUSH form (data parallel over peer-mapped memory, r4r_mf_grad_push): the entry arrays are written into this rank's
+    // slot of EVERY rank's gathered buffer (uid32 / iid32 / g / gu / gi above are then offsets from push[r], in 4-byte units)
+    char *push[PEER_MAX_WORLD];
+    unsigned *flags[PEER_MAX_WORLD];   // rank r's flag array
+    unsigned *arrive = nullptr;        // this rank's arrival counter (zero between launches)
+    int rank = 0, world = 0;
+    unsigned epoch = 0;
 };
 
-__global__ __launch_bounds__(256) void mf_fwd_bwd_kernel(MfStep a) {
+// One rating per wave.  PUSH: every store of an entry goes to all ranks' buffers.
+template <bool PUSH>
+__device__ __forceinline__ void mf_fwd_bwd_wave(const MfStep &a) {
     const int lane = threadIdx.x & 63;
     const int64_t b = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    // entry stores: element `i` of the entry array `arr` (a pointer, or -- PUSH -- its offset inside a rank's slot)
+    auto put_f = [&](float *arr, int64_t i, float x) {
+        if constexpr (PUSH) {
+#pragma unroll
+            for (int r = 0; r < PEER_MAX_WORLD; ++r)
+                if (r < a.world) reinterpret_cast<float *>(a.push[r])[reinterpret_cast<uintptr_t>(arr) + i] = x;
+        } else {
+            arr[i] = x;
+        }
+    };
+    auto put_i = [&](int *arr, int64_t i, int x) {
+        if constexpr (PUSH) {
+#pragma unroll
+            for (int r = 0; r < PEER_MAX_WORLD; ++r)
+                if (r < a.world) reinterpret_cast<int *>(a.push[r])[reinterpret_cast<uintptr_t>(arr) + i] = x;
+        } else {
+            arr[i] = x;
+        }
+    };
     if (b >= a.B) {                                         // whole wave
-        if (b < a.B_pad && lane == 0) { a.uid32[b] = -1; a.iid32[b] = -1; a.g[b] = 0.f; }
+        if (b < a.B_pad && lane == 0) { put_i(a.uid32, b, -1); put_i(a.iid32, b, -1); put_f(a.g, b, 0.f); }
         return;
     }
     const int D = a.D;
@@ -147,7 +176,7 @@ __global__ __launch_bounds__(256) void mf_fwd_bwd_kernel(MfStep a) {
     if (!a.want_grad) return;
     const float g = 2.f * d * a.inv_denom;
     if (lane == 0) {
-        a.g[b] = g;
+        put_f(a.g, b, g);
         if (a.register_rows) {
             a.tag_u[u] = a.tag;
             a.tag_i[i] = a.tag;
@@ -161,16 +190,45 @@ __global__ __launch_bounds__(256) void mf_fwd_bwd_kernel(MfStep a) {
                 a.ctag_i[i * D / MF_CHUNK] = a.tag; a.ctag_i[(i * D + D - 1) / MF_CHUNK] = a.tag;
             }
         }
-        a.uid32[b] = (int)u;
-        a.iid32[b] = (int)i;
+        put_i(a.uid32, b, (int)u);
+        put_i(a.iid32, b, (int)i);
     }
 #pragma unroll
     for (int k = 0; k < MF_MAX_D / 64; ++k) {
         const int dd = lane + 64 * k;
         if (dd < D) {
-            a.gu[b * D + dd] = g * mu[k] * xi[k];          // d pred / d U[u, d] = mult_u * (dropped item value)
-            a.gi[b * D + dd] = g * mi[k] * xu[k];
+            put_f(a.gu, b * D + dd, g * mu[k] * xi[k]);    // d pred / d U[u, d] = mult_u * (dropped item value)
+            put_f(a.gi, b * D + dd, g * mi[k] * xu[k]);
         }
+    }
+}
+
+__global__ __launch_bounds__(256) void mf_fwd_bwd_kernel(MfStep a) { mf_fwd_bwd_wave<false>(a); }
+
+// The PUSH form: when the launch's last workgroup is done, this rank's flag goes up in every rank's flag array (the
+// protocol of peer.hip: system-scope release after the stores, acquire on the waiting side -- r4r_mf_apply_peer).
+__global__ __launch_bounds__(256) void mf_fwd_bwd_push_kernel(MfStep a) {
+    mf_fwd_bwd_wave<true>(a);
+    // every thread's stores reach the peers' memories before this workgroup counts as arrived; the arrival itself is a
+    // relaxed add (an agent-scope acq_rel one writes back and invalidates the L2 once per workgroup), and the workgroup
+    // that arrives last fences again before it raises the flags: fence - relaxed RMW - relaxed RMW - fence orders every
+    // workgroup's stores before the flag stores
+    __threadfence_system();
+    __syncthreads();
+    __shared__ unsigned last;
+    if (threadIdx.x == 0) {
+        const unsigned k = __hip_atomic_fetch_add(a.arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        last = (k == gridDim.x - 1);
+    }
+    __syncthreads();
+    if (last && threadIdx.x < (unsigned)a.world) {
+        __threadfence_system();
+        if (threadIdx.x == 0) __hip_atomic_store(a.arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // for the next launch
+        unsigned *f = a.flags[0];
+#pragma unroll
+        for (int r = 1; r < PEER_MAX_WORLD; ++r)
+            if ((int)threadIdx.x == r) f = a.flags[r];
+        __hip_atomic_store(f + a.rank, a.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 
@@ -200,11 +258,36 @@ struct MfSweep {
     int64_t B;
     int D, now;
     int nt = 0;                        // untouched chunks: nontemporal loads / stores (tables far larger than the Infinity Cache)
+    // SCAN form (data parallel, r4r_mf_apply): the entries live in the ranks' gathered blocks -- entry e is entry
+    // e % B_pad of block e / B_pad, `blk_units` 4-byte units apart; uid32 / iid32 / g / gu / gi point into block 0.
+    // Nothing was registered: every workgroup finds the rows the step names by scanning the ids.
+    int64_t B_pad = 0, blk_units = 0;
+    int *ctag_wu = nullptr, *ctag_wi = nullptr;      // the chunk tags, for the owners to stamp (scheduled sweep)
+    // ... and, when the blocks arrive over peer-mapped memory (r4r_mf_apply_peer), every workgroup first waits (bounded)
+    // until all `world` ranks' flags in THIS rank's flag array have reached `wait_epoch`
+    const unsigned *wait_flags = nullptr;
+    unsigned *timed_out = nullptr;
+    unsigned long long max_ticks = 0;
+    unsigned wait_epoch = 0;
+    int world = 0;
     MfTimeBlock tb = MfTimeBlock{};    // temporally blocked sweep (rows_device.h); tb.rlast_u == NULL: off
     AdamScalars s;
 };
 
 typedef float mf_f32x4 __attribute__((ext_vector_type(4)));
+
+// offset (4-byte units) of entry e's field of `width` units per entry: compact arrays, or the gathered blocks
+template <bool SCAN>
+__device__ __forceinline__ int64_t mf_eoff(const MfSweep &w, int64_t e, int width) {
+    if constexpr (SCAN) {
+        const int r = (int)((unsigned)e / (unsigned)w.B_pad);
+        return (int64_t)r * w.blk_units + (e - (int64_t)r * w.B_pad) * width;
+    } else {
+        return e * width;
+    }
+}
+constexpr int MF_SCAN_MAX_B = 2048;    // gathered entries up to which r4r_mf_apply's workgroups scan the ids themselves
+constexpr int MF_SCAN_WORDS = MF_CHUNK / 32 + 8;   // named-row bitmap of a sweep workgroup: <= MF_CHUNK + 2 rows
 
 // The untouched-chunk stream of the sweep: `cnt` elements of p / m / v get the gradient-zero update, two float4
 // per array and thread in flight.  NT: nontemporal accesses -- a 55 M-parameter table (1.3 GB per sweep) passes
@@ -298,7 +381,7 @@ __device__ __forceinline__ void tb_catch_up4(float4 &P, float4 &M, float4 &V, in
 //     the wave reads epl = 256 / D entries per load instruction, eight instructions in flight (a
 //     popular item in a batch of thousands has > 1000 entries: not one dependent load each);
 //   generic form: lanes are columns (lane, lane + 64, ...), four entries in flight.
-template <int NACC, int DL, bool WIDE>
+template <int NACC, int DL, bool WIDE, bool SCAN = false>
 __device__ __forceinline__ void mf_entry(const MfSweep &w, const int *sid, int *pl, int t, int64_t k, int lane) {
     const unsigned long long *first = t ? w.first_i : w.first_u;
     const int *gid = t ? w.iid32 : w.uid32;
@@ -324,6 +407,15 @@ __device__ __forceinline__ void mf_entry(const MfSweep &w, const int *sid, int *
     const int D = w.D;
     const float *rows = t ? w.gi : w.gu;
     const int last_j = (int)w.B - 1;
+    if constexpr (SCAN) {
+        // nobody registered the step's rows: the owner stamps its row's chunk tags for the scheduled sweep's later visits
+        // (a due chunk's own workgroup, in this launch, sees the row in its scan of the ids either way)
+        int *ct = t ? w.ctag_wi : w.ctag_wu;
+        if (ct && D > 0 && lane == 0) {
+            const int64_t e0 = (int64_t)row * D;
+            ct[e0 / MF_CHUNK] = w.now; ct[(e0 + D - 1) / MF_CHUNK] = w.now;
+        }
+    }
 
     // scan chunks [kc, c_end), appending matches to pl and handing `cap` of them at a time to flush(base, n)
     auto scan = [&](auto &&flush, int cap) {
@@ -389,8 +481,8 @@ __device__ __forceinline__ void mf_entry(const MfSweep &w, const int *sid, int *
             for (int q = 0; q < NACC; ++q) {
                 const int idx = q * epl + grp;
                 const int e = pl[base + ((q < nacc && idx < n) ? idx : 0)];
-                tmp[q] = reinterpret_cast<const float4 *>(rows + (int64_t)e * D)[sub];
-                tg[q] = w.g ? w.g[e] : 0.f;
+                tmp[q] = reinterpret_cast<const float4 *>(rows + mf_eoff<SCAN>(w, e, D))[sub];
+                tg[q] = w.g ? w.g[mf_eoff<SCAN>(w, e, 1)] : 0.f;
             }
 #pragma unroll
             for (int q = 0; q < NACC; ++q) {
@@ -440,10 +532,11 @@ __device__ __forceinline__ void mf_entry(const MfSweep &w, const int *sid, int *
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int e = pl[base + (q < n ? q : 0)];
+                const int64_t eo = mf_eoff<SCAN>(w, e, D);
 #pragma unroll
                 for (int x = 0; x < DL; ++x)
-                    tmp[q][x] = (lane + 64 * x < D) ? rows[(int64_t)e * D + lane + 64 * x] : 0.f;
-                tg[q] = w.g ? w.g[e] : 0.f;
+                    tmp[q][x] = (lane + 64 * x < D) ? rows[eo + lane + 64 * x] : 0.f;
+                tg[q] = w.g ? w.g[mf_eoff<SCAN>(w, e, 1)] : 0.f;
             }
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
@@ -504,10 +597,22 @@ __device__ __forceinline__ void mf_entry(const MfSweep &w, const int *sid, int *
     }
 }
 
-template <int NACC, int DL, bool WIDE>
+template <int NACC, int DL, bool WIDE, bool SCAN>
 __device__ __forceinline__ void mf_adam_body(const MfSweep &w) {
     extern __shared__ int sid[];                            // entry waves: the side's ids
     __shared__ float red[MF_THREADS];
+    __shared__ unsigned nm[SCAN ? MF_SCAN_WORDS : 1];       // SCAN, sweep workgroups: the rows of the chunk the step names
+    // r4r_mf_apply_peer: lane r of the first wave polls rank r's flag -- relaxed system-scope loads and no invalidation
+    // behind them (peer_device.h): the blocks are read from the fine-grained segment itself, which no cache holds
+    auto wait_peers = [&]() {                               // (uniform over the workgroup)
+        if constexpr (SCAN) {
+            if (w.wait_flags) {
+                if (threadIdx.x < (unsigned)w.world)
+                    peer_wait_lane<false>(w.wait_flags, threadIdx.x, w.wait_epoch, w.timed_out, w.max_ticks);
+                __syncthreads();
+            }
+        }
+    };
     __shared__ int pend[MF_THREADS / 64][128];              // entry waves, wide form: the row's pending entries
     const int tid = threadIdx.x;
     // Entry workgroups are dispatched FIRST (the owner of a popular row is the launch's longest
@@ -577,22 +682,29 @@ __device__ __forceinline__ void mf_adam_body(const MfSweep &w) {
             }
             return;
         }
-        const int64_t *ids = t ? w.iid : w.uid;             // no election slots: stage the side's ids
-        for (int64_t j = tid; j < w.B; j += MF_THREADS) sid[j] = (int)ids[j];
+        wait_peers();
+        if constexpr (SCAN) {                               // no election slots: stage the side's ids (out of the gathered blocks)
+            const int *ids32 = t ? w.iid32 : w.uid32;
+            for (int64_t j = tid; j < w.B; j += MF_THREADS) sid[j] = ids32[mf_eoff<true>(w, j, 1)];
+        } else {
+            const int64_t *ids = t ? w.iid : w.uid;
+            for (int64_t j = tid; j < w.B; j += MF_THREADS) sid[j] = (int)ids[j];
+        }
         __syncthreads();
         for (int it = 0; it < w.epw; ++it) {                // entries of this wave: interleaved with its neighbours
             const int64_t k = ((int64_t)gi * w.epw + it) * 4 + (tid >> 6);
             if (k >= w.B) break;
-            mf_entry<NACC, DL, WIDE>(w, sid, pend[tid >> 6], t, k, lane);
+            mf_entry<NACC, DL, WIDE, SCAN>(w, sid, pend[tid >> 6], t, k, lane);
         }
         return;
     }
     if (bx >= w.cb_global) {
         // ---- global bias (gradient = sum of d loss / d pred over the batch) + the running SE:
         // strided per-thread sums, then a fixed tree -- deterministic
+        wait_peers();
         float a = 0.f, e = 0.f;
         const int64_t se_n = w.se ? (w.se_n >= 0 ? w.se_n : w.B) : 0;
-        for (int64_t b = tid; b < w.B; b += MF_THREADS) a += w.g[b];
+        for (int64_t b = tid; b < w.B; b += MF_THREADS) a += w.g[mf_eoff<SCAN>(w, b, 1)];
         for (int64_t b = tid; b < se_n; b += MF_THREADS) e += w.se[b];
         red[tid] = a;
         __syncthreads();
@@ -632,6 +744,50 @@ __device__ __forceinline__ void mf_adam_body(const MfSweep &w) {
     const int *tag = (t == 0 || t == 2) ? w.tag_u : w.tag_i;
     const bool aligned = (((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(m) | reinterpret_cast<uintptr_t>(v)) & 15) == 0);
     const int *ctag = t == 0 ? w.ctag_u : (t == 1 ? w.ctag_i : nullptr);
+    // Which rows of the chunk does the step name?  The row tags the forward kernel stamped -- or, SCAN, a bitmap this
+    // workgroup builds from the step's ids (every id requested at once, next to nothing: B <= MF_SCAN_MAX_B).
+    const int64_t nm_row0 = start / W;
+    bool any_named = false;
+    auto build_named = [&]() {                              // (called once the chunk's own elements have been requested)
+      if constexpr (SCAN) {
+        constexpr int NID = MF_SCAN_MAX_B / MF_THREADS;
+        wait_peers();
+        const int *ids32 = (t == 0 || t == 2) ? w.uid32 : w.iid32;
+        int idv[NID];
+#pragma unroll
+        for (int u = 0; u < NID; ++u) {
+            const int j = tid + u * MF_THREADS;
+            idv[u] = j < w.B ? ids32[mf_eoff<true>(w, j, 1)] : -1;
+        }
+        if (tid < MF_SCAN_WORDS) nm[tid] = 0u;
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < NID; ++u) {
+            const int64_t d = (int64_t)idv[u] - nm_row0;
+            if (idv[u] >= 0 && d >= 0 && d < MF_SCAN_WORDS * 32) atomicOr(&nm[d >> 5], 1u << (d & 31));
+        }
+        __syncthreads();
+        const int64_t row_end = (start + cnt - 1) / W;      // the chunk's last row
+        unsigned anyw = 0;
+        for (int q = 0; q < MF_SCAN_WORDS; ++q) {           // (uniform: every thread reads the same words)
+            const int64_t lo = (int64_t)q * 32;
+            if (lo > row_end - nm_row0) break;
+            unsigned word = nm[q];
+            const int64_t over = lo + 31 - (row_end - nm_row0);
+            if (over > 0) word &= 0xffffffffu >> over;      // rows past the chunk's last do not count as the chunk's
+            anyw |= word;
+        }
+        any_named = anyw != 0;
+      }
+    };
+    auto named = [&](int64_t row) -> bool {
+        if constexpr (SCAN) {
+            const unsigned d = (unsigned)(row - nm_row0);
+            return (nm[d >> 5] >> (d & 31)) & 1u;
+        } else {
+            return tag[row] == w.now;
+        }
+    };
     if (sched) {
         // through which step is the chunk current?  its last scheduled visit, or the base
         int vis = tb_prev_visit(ci64, w.now - w.tb.inc, w.tb.period);
@@ -661,7 +817,8 @@ __device__ __forceinline__ void mf_adam_body(const MfSweep &w) {
             cur[u] = vis;
             if (nvec > 0) { P[u] = ld(p, ii); M[u] = ld(m, ii); V[u] = ld(v, ii); }
         }
-        const bool recent = ctag[ci64] > vis;               // a row of the chunk was touched after the visit (or is, now)
+        build_named();
+        const bool recent = ctag[ci64] > vis || any_named;  // a row of the chunk was touched after the visit (or is, now)
         const int *rlast = t == 0 ? w.tb.rlast_u : w.tb.rlast_i;
         const bool skip_now = w.tb.inc != 0;
         const int64_t row_start = start / W;
@@ -674,9 +831,10 @@ __device__ __forceinline__ void mf_adam_body(const MfSweep &w) {
                 for (int u = 0; u < NV; ++u) {
                     const int64_t ii = on[u] ? tid + (int64_t)u * MF_THREADS : 0;
                     const int64_t row = row_start + (col_start + (unsigned)ii * 4u) / (unsigned)W;
-                    const int tg = tag[row], rl = rlast[row];
+                    const bool tg = named(row);
+                    const int rl = rlast[row];
                     if (rl > cur[u]) cur[u] = rl;
-                    if (skip_now && tg == w.now) on[u] = false;
+                    if (skip_now && tg) on[u] = false;
                 }
             }
             if (nvec > 0) {
@@ -702,7 +860,7 @@ __device__ __forceinline__ void mf_adam_body(const MfSweep &w) {
                     const int64_t row = row_start + (col_start + (unsigned)i * 4u + c) / (unsigned)W;
                     const int r = rlast[row];
                     ce[c] = r > vis ? r : vis;
-                    oe[c] = !(skip_now && tag[row] == w.now) && ce[c] < w.now;
+                    oe[c] = !(skip_now && named(row)) && ce[c] < w.now;
                     all = all && oe[c];
                     if (!oe[c]) ce[c] = w.now;
                     Pn[c] = Pq[c]; Mn[c] = Mq[c]; Vn[c] = Vq[c];
@@ -732,7 +890,7 @@ __device__ __forceinline__ void mf_adam_body(const MfSweep &w) {
         if (k < cnt) {
             const int64_t row = (start + k) / W;
             const int r = recent ? rlast[row] : 0, c1 = r > vis ? r : vis;
-            if (!(recent && skip_now && tag[row] == w.now) && c1 < w.now) {
+            if (!(recent && skip_now && named(row)) && c1 < w.now) {
                 float Pk = p[k], Mk = m[k], Vk = v[k];
                 tb_catch_up(Pk, Mk, Vk, c1, w.now, w.now, w.s, w.tb);
                 p[k] = Pk; m[k] = Mk; v[k] = Vk;
@@ -740,7 +898,8 @@ __device__ __forceinline__ void mf_adam_body(const MfSweep &w) {
         }
         return;
     }
-    if (ctag && aligned && ctag[bx - cb] != w.now) {
+    build_named();
+    if ((SCAN ? t < 2 && !any_named : (ctag && ctag[bx - cb] != w.now)) && aligned) {
         // no rating touched a row of this chunk (all but a handful of chunks of a 10^7-row table):
         // stream it -- no row tags, no row / column bookkeeping
         if (w.nt) mf_stream_chunk<true>(p, m, v, cnt, tid, w.s);
@@ -768,14 +927,14 @@ __device__ __forceinline__ void mf_adam_body(const MfSweep &w) {
             float4 P0 = reinterpret_cast<float4 *>(p)[i], P1 = reinterpret_cast<float4 *>(p)[j];
             float4 M0 = reinterpret_cast<float4 *>(m)[i], M1 = reinterpret_cast<float4 *>(m)[j];
             float4 V0 = reinterpret_cast<float4 *>(v)[i], V1 = reinterpret_cast<float4 *>(v)[j];
-            const int t0 = tag[row], t1 = tag[row1];
-            if (t0 != w.now) {                              // touched rows belong to their entry wave
+            const bool n0 = named(row), n1 = named(row1);
+            if (!n0) {                                      // touched rows belong to their entry wave
                 adam_elem_fast(P0.x, 0.f, M0.x, V0.x, w.s); adam_elem_fast(P0.y, 0.f, M0.y, V0.y, w.s);
                 adam_elem_fast(P0.z, 0.f, M0.z, V0.z, w.s); adam_elem_fast(P0.w, 0.f, M0.w, V0.w, w.s);
                 reinterpret_cast<float4 *>(p)[i] = P0; reinterpret_cast<float4 *>(m)[i] = M0;
                 reinterpret_cast<float4 *>(v)[i] = V0;
             }
-            if (t1 != w.now) {
+            if (!n1) {
                 adam_elem_fast(P1.x, 0.f, M1.x, V1.x, w.s); adam_elem_fast(P1.y, 0.f, M1.y, V1.y, w.s);
                 adam_elem_fast(P1.z, 0.f, M1.z, V1.z, w.s); adam_elem_fast(P1.w, 0.f, M1.w, V1.w, w.s);
                 reinterpret_cast<float4 *>(p)[j] = P1; reinterpret_cast<float4 *>(m)[j] = M1;
@@ -789,7 +948,7 @@ __device__ __forceinline__ void mf_adam_body(const MfSweep &w) {
             float4 P = reinterpret_cast<float4 *>(p)[i];
             float4 M = reinterpret_cast<float4 *>(m)[i];
             float4 V = reinterpret_cast<float4 *>(v)[i];
-            if (tag[row] != w.now) {
+            if (!named(row)) {
                 adam_elem_fast(P.x, 0.f, M.x, V.x, w.s); adam_elem_fast(P.y, 0.f, M.y, V.y, w.s);
                 adam_elem_fast(P.z, 0.f, M.z, V.z, w.s); adam_elem_fast(P.w, 0.f, M.w, V.w, w.s);
                 reinterpret_cast<float4 *>(p)[i] = P; reinterpret_cast<float4 *>(m)[i] = M;
@@ -808,9 +967,9 @@ __device__ __forceinline__ void mf_adam_body(const MfSweep &w) {
         int64_t row = row_start + first / (unsigned)W;
         int col = (int)(first % (unsigned)W);
         const int step_row = (MF_THREADS * 4) / W, step_col = (MF_THREADS * 4) % W;
-        auto finish = [&](int64_t i, float4 P, float4 M, float4 V, int col_i, int t_lo, int t_hi) {
-            const bool f0 = t_lo != w.now, f1 = (col_i + 1 >= W ? t_hi : t_lo) != w.now,
-                       f2 = (col_i + 2 >= W ? t_hi : t_lo) != w.now, f3 = (col_i + 3 >= W ? t_hi : t_lo) != w.now;
+        auto finish = [&](int64_t i, float4 P, float4 M, float4 V, int col_i, bool n_lo, bool n_hi) {
+            const bool f0 = !n_lo, f1 = !(col_i + 1 >= W ? n_hi : n_lo),
+                       f2 = !(col_i + 2 >= W ? n_hi : n_lo), f3 = !(col_i + 3 >= W ? n_hi : n_lo);
             if (f0) adam_elem_fast(P.x, 0.f, M.x, V.x, w.s);
             if (f1) adam_elem_fast(P.y, 0.f, M.y, V.y, w.s);
             if (f2) adam_elem_fast(P.z, 0.f, M.z, V.z, w.s);
@@ -834,7 +993,7 @@ __device__ __forceinline__ void mf_adam_body(const MfSweep &w) {
             const float4 P0 = reinterpret_cast<float4 *>(p)[i], P1 = reinterpret_cast<float4 *>(p)[j];
             const float4 M0 = reinterpret_cast<float4 *>(m)[i], M1 = reinterpret_cast<float4 *>(m)[j];
             const float4 V0 = reinterpret_cast<float4 *>(v)[i], V1 = reinterpret_cast<float4 *>(v)[j];
-            const int a0 = tag[row], a1 = tag[row + (col + 3 >= W)], b0 = tag[row1], b1 = tag[row1 + (col1 + 3 >= W)];
+            const bool a0 = named(row), a1 = named(row + (col + 3 >= W)), b0 = named(row1), b1 = named(row1 + (col1 + 3 >= W));
             finish(i, P0, M0, V0, col, a0, a1);
             finish(j, P1, M1, V1, col1, b0, b1);
             row = row1 + step_row;
@@ -844,7 +1003,7 @@ __device__ __forceinline__ void mf_adam_body(const MfSweep &w) {
         for (; i < nvec; i += MF_THREADS) {
             const float4 P = reinterpret_cast<float4 *>(p)[i], M = reinterpret_cast<float4 *>(m)[i];
             const float4 V = reinterpret_cast<float4 *>(v)[i];
-            finish(i, P, M, V, col, tag[row], tag[row + (col + 3 >= W)]);
+            finish(i, P, M, V, col, named(row), named(row + (col + 3 >= W)));
             row += step_row;
             col += step_col;
             if (col >= W) { col -= W; ++row; }
@@ -853,7 +1012,7 @@ __device__ __forceinline__ void mf_adam_body(const MfSweep &w) {
         if (k < cnt) {
             const int64_t r = (start + k) / W;
             float P = p[k], M = m[k], V = v[k];
-            if (tag[r] != w.now) {
+            if (!named(r)) {
                 adam_elem_fast(P, 0.f, M, V, w.s);
                 p[k] = P; m[k] = M; v[k] = V;
             }
@@ -865,7 +1024,7 @@ __device__ __forceinline__ void mf_adam_body(const MfSweep &w) {
         const int step_row = MF_THREADS / W, step_col = MF_THREADS % W;
         for (int64_t i = tid; i < cnt; i += MF_THREADS) {
             float P = p[i], M = m[i], V = v[i];
-            if (tag[row] != w.now) {
+            if (!named(row)) {
                 adam_elem_fast(P, 0.f, M, V, w.s);
                 p[i] = P; m[i] = M; v[i] = V;
             }
@@ -881,10 +1040,10 @@ BWD_TRACE_DEFINE(r4r_debug_mf_adam_trace)
 // compiled in.  <.., 1, false> is the LIGHT variant -- 52 VGPRs instead of 94, seven waves per SIMD instead of five:
 // every wave of the launch, the table chunks' included, is allocated what the entry waves' multi-row accumulation
 // needs -- taken for rows of <= 64 elements at <= MF_LIGHT_MAX_B ratings (one rating per entry wave).
-template <int NACC, int DL = 4, bool WIDE = true>
+template <int NACC, int DL = 4, bool WIDE = true, bool SCAN = false>
 __global__ __launch_bounds__(MF_THREADS) void mf_adam_kernel(MfSweep w) {
     BWD_STAMP(0, wall_clock64());                           // (instrumented builds only: tools/sweep_trace.py)
-    mf_adam_body<NACC, DL, WIDE>(w);
+    mf_adam_body<NACC, DL, WIDE, SCAN>(w);
 #ifdef R4R_TRACE
     const int nshort = w.cb_entries - w.cb2, rest = (int)blockIdx.x - w.n_entry_wgs;
     const int bx = rest < 0 ? w.cb_entries + (int)blockIdx.x : (rest < nshort ? w.cb2 + rest : rest - nshort);
@@ -1350,14 +1509,23 @@ extern "C" size_t r4r_mf_dp_block_bytes(int64_t B_pad, int D) {
     return mf_block(B_pad, D).bytes;
 }
 
-extern "C" int r4r_mf_grad(const int64_t *uid, const int64_t *iid, const float *y, const uint64_t *p,
-                           const uint64_t *m, const uint64_t *v,
-                           int64_t n_users, int64_t n_items, int D, float *pred, float *se, void *block, float *mult,
-                           int64_t B, int64_t B_pad, float dropout_p, int training, uint64_t seed, uint64_t offset,
-                           float inv_denom, void *ws, int sweep_period, int64_t sweep_base,
-                           float lr, double beta1, double beta2, float eps, float weight_decay, int64_t adam_step,
-                           void *stream) {
-    R4R_REQUIRE(p && pred && se && block, "mf_grad: null pointer");
+namespace r4r {
+struct MfPush {                        // r4r_mf_grad_push: where the block goes (null peer_dst: into `block`)
+    const uint64_t *peer_dst = nullptr, *peer_flags = nullptr;
+    uint32_t *arrive = nullptr;
+    int rank = 0, world = 0;
+    uint32_t epoch = 0;
+};
+}  // namespace r4r
+
+static int mf_grad_impl(const int64_t *uid, const int64_t *iid, const float *y, const uint64_t *p,
+                        const uint64_t *m, const uint64_t *v,
+                        int64_t n_users, int64_t n_items, int D, float *pred, float *se, void *block, float *mult,
+                        int64_t B, int64_t B_pad, float dropout_p, int training, uint64_t seed, uint64_t offset,
+                        float inv_denom, void *ws, int sweep_period, int64_t sweep_base,
+                        float lr, double beta1, double beta2, float eps, float weight_decay, int64_t adam_step,
+                        void *stream, const MfPush &push) {
+    R4R_REQUIRE(p && pred && se && (block || push.peer_dst), "mf_grad: null pointer");
     R4R_REQUIRE(!m == !v && !m == !ws, "mf_grad: m, v and the workspace of r4r_mf_apply go together");
     R4R_REQUIRE(!m || (sweep_period >= 1 && sweep_period <= MF_TB_MAX && sweep_base >= 0 && sweep_base < adam_step &&
                        adam_step < (1ll << 31)),
@@ -1373,9 +1541,24 @@ extern "C" int r4r_mf_grad(const int64_t *uid, const int64_t *iid, const float *
     a.uid = uid; a.iid = iid; a.y = y;
     for (int s = 0; s < MF_SLOTS; ++s) a.p[s] = reinterpret_cast<float *>(p[s]);
     for (int s = (D > 0 ? 0 : 2); s < MF_SLOTS; ++s) R4R_REQUIRE(a.p[s], "mf_grad: slot %d: null parameter pointer", s);
-    a.uid32 = reinterpret_cast<int *>(blk + k.uid); a.iid32 = reinterpret_cast<int *>(blk + k.iid);
-    a.g = reinterpret_cast<float *>(blk + k.g); a.gu = reinterpret_cast<float *>(blk + k.gu);
-    a.gi = reinterpret_cast<float *>(blk + k.gi); a.mult = mult;
+    if (push.peer_dst) {
+        // the entry arrays as offsets (4-byte units) inside a rank's slot; push[r] = this rank's slot in rank r's buffer
+        R4R_REQUIRE(push.peer_flags && push.arrive && push.world >= 1 && push.world <= PEER_MAX_WORLD && push.rank >= 0 &&
+                    push.rank < push.world, "mf_grad_push: rank %d of %d (<= %d ranks), flags and an arrival counter", push.rank,
+                    push.world, PEER_MAX_WORLD);
+        for (int r = 0; r < PEER_MAX_WORLD; ++r) {
+            const int rr = r < push.world ? r : 0;
+            R4R_REQUIRE(push.peer_dst[rr] && push.peer_flags[rr] && (push.peer_dst[rr] & 15) == 0, "mf_grad_push: bad peer buffer %d", rr);
+            a.push[r] = reinterpret_cast<char *>(push.peer_dst[rr]) + (size_t)push.rank * k.bytes;
+            a.flags[r] = reinterpret_cast<unsigned *>(push.peer_flags[rr]);
+        }
+        a.arrive = push.arrive; a.rank = push.rank; a.world = push.world; a.epoch = push.epoch;
+    }
+    // (PUSH: not pointers but the arrays' offsets inside a slot, in 4-byte units -- mf_fwd_bwd_wave's put_*)
+    auto field = [&](size_t off) { return push.peer_dst ? static_cast<uintptr_t>(off / 4) : reinterpret_cast<uintptr_t>(blk + off); };
+    a.uid32 = reinterpret_cast<int *>(field(k.uid)); a.iid32 = reinterpret_cast<int *>(field(k.iid));
+    a.g = reinterpret_cast<float *>(field(k.g)); a.gu = reinterpret_cast<float *>(field(k.gu));
+    a.gi = reinterpret_cast<float *>(field(k.gi)); a.mult = mult;
     // the tables may carry pending gradient-zero updates (r4r_mf_apply's scheduled sweep): the rows a rating reads
     // are brought to step adam_step - 1 in registers
     if (m && D > 0 && sweep_period > 1 && (((p[0] | p[1] | m[0] | m[1] | v[0] | v[1]) & 15) == 0)) {
@@ -1389,16 +1572,55 @@ extern "C" int r4r_mf_grad(const int64_t *uid, const int64_t *iid, const float *
     }
     a.pred = pred; a.se = se; a.B = B; a.B_pad = B_pad; a.register_rows = 0; a.D = D; a.training = training;
     a.want_grad = 1; a.tag = 0; a.p_drop = dropout_p; a.inv_denom = inv_denom; a.seed = seed; a.offset = offset;
-    mf_fwd_bwd_kernel<<<(unsigned)cdiv(B_pad, 4), 256, 0, as_stream(stream)>>>(a);
+    if (push.peer_dst) mf_fwd_bwd_push_kernel<<<(unsigned)cdiv(B_pad, 4), 256, 0, as_stream(stream)>>>(a);
+    else mf_fwd_bwd_kernel<<<(unsigned)cdiv(B_pad, 4), 256, 0, as_stream(stream)>>>(a);
     return check_launch("mf_grad");
 }
 
-extern "C" int r4r_mf_apply(const void *blocks, int world, int64_t B_pad, const uint64_t *p, const uint64_t *m,
-                            const uint64_t *v, int64_t n_users, int64_t n_items, int D, void *ws, size_t ws_bytes,
-                            int sweep_period, int64_t sweep_base, int sweep_all,
-                            const float *se, int64_t se_n, float *sse_accum,
-                            float lr, double beta1, double beta2, float eps, float weight_decay, int64_t adam_step,
-                            void *stream) {
+extern "C" int r4r_mf_grad(const int64_t *uid, const int64_t *iid, const float *y, const uint64_t *p,
+                           const uint64_t *m, const uint64_t *v,
+                           int64_t n_users, int64_t n_items, int D, float *pred, float *se, void *block, float *mult,
+                           int64_t B, int64_t B_pad, float dropout_p, int training, uint64_t seed, uint64_t offset,
+                           float inv_denom, void *ws, int sweep_period, int64_t sweep_base,
+                           float lr, double beta1, double beta2, float eps, float weight_decay, int64_t adam_step,
+                           void *stream) {
+    return mf_grad_impl(uid, iid, y, p, m, v, n_users, n_items, D, pred, se, block, mult, B, B_pad, dropout_p, training, seed,
+                        offset, inv_denom, ws, sweep_period, sweep_base, lr, beta1, beta2, eps, weight_decay, adam_step, stream,
+                        MfPush{});
+}
+
+extern "C" int r4r_mf_grad_push(const int64_t *uid, const int64_t *iid, const float *y, const uint64_t *p,
+                                const uint64_t *m, const uint64_t *v,
+                                int64_t n_users, int64_t n_items, int D, float *pred, float *se, float *mult,
+                                int64_t B, int64_t B_pad, float dropout_p, int training, uint64_t seed, uint64_t offset,
+                                float inv_denom, void *ws, int sweep_period, int64_t sweep_base,
+                                float lr, double beta1, double beta2, float eps, float weight_decay, int64_t adam_step,
+                                const uint64_t *peer_dst, const uint64_t *peer_flags, uint32_t *arrive, int rank, int world,
+                                uint32_t epoch, void *stream) {
+    R4R_REQUIRE(peer_dst && peer_flags && arrive, "mf_grad_push: null pointer");
+    MfPush push;
+    push.peer_dst = peer_dst; push.peer_flags = peer_flags; push.arrive = arrive; push.rank = rank; push.world = world;
+    push.epoch = epoch;
+    return mf_grad_impl(uid, iid, y, p, m, v, n_users, n_items, D, pred, se, nullptr, mult, B, B_pad, dropout_p, training, seed,
+                        offset, inv_denom, ws, sweep_period, sweep_base, lr, beta1, beta2, eps, weight_decay, adam_step, stream,
+                        push);
+}
+
+namespace r4r {
+struct MfWait {                        // r4r_mf_apply_peer: the flags every workgroup waits for before it reads the blocks
+    const uint32_t *flags = nullptr;
+    uint32_t *timed_out = nullptr;
+    uint32_t epoch = 0;
+    double timeout_s = 0.0;
+};
+}  // namespace r4r
+
+static int mf_apply_impl(const void *blocks, int world, int64_t B_pad, const uint64_t *p, const uint64_t *m,
+                         const uint64_t *v, int64_t n_users, int64_t n_items, int D, void *ws, size_t ws_bytes,
+                         int sweep_period, int64_t sweep_base, int sweep_all,
+                         const float *se, int64_t se_n, float *sse_accum,
+                         float lr, double beta1, double beta2, float eps, float weight_decay, int64_t adam_step,
+                         void *stream, const MfWait &wait) {
     R4R_REQUIRE(blocks && p && m && v && ws, "mf_apply: null pointer");
     R4R_REQUIRE(!sse_accum || (se && se_n >= 0), "mf_apply: sse_accum needs se [se_n]");
     R4R_REQUIRE(sweep_period >= 1 && sweep_period <= MF_TB_MAX, "mf_apply: sweep_period %d outside 1..%d", sweep_period, MF_TB_MAX);
@@ -1424,7 +1646,13 @@ extern "C" int r4r_mf_apply(const void *blocks, int world, int64_t B_pad, const 
     // the temporally blocked sweep (rows_device.h) over the gathered entries: 16-byte aligned tables
     const bool tb_on = D > 0 && (((p[0] | p[1] | m[0] | m[1] | v[0] | v[1]) & 15) == 0);
     if (tb_on) { rg.ctag_u = w.ctag_u; rg.ctag_i = w.ctag_i; }
-    mf_register_kernel<<<(unsigned)cdiv(B, 4), 256, 0, st>>>(rg);
+    // Up to MF_SCAN_MAX_B gathered entries nothing is registered: the update launch's workgroups read the ids out of
+    // the blocks and find their rows themselves (one dependent launch less per step; R4R_MF_DP_REGISTER=1 pins the
+    // registered form for A/B runs and tests).  Same entries, same order, same sums: the same bits.
+    static const bool pin_register = [] { const char *e = getenv("R4R_MF_DP_REGISTER"); return e && e[0] == '1'; }();
+    const bool scan = B <= MF_SCAN_MAX_B && rg.k.bytes % 4 == 0 && (!pin_register || wait.flags);
+    R4R_REQUIRE(scan || !wait.flags, "mf_apply_peer: %lld gathered entries > %d", (long long)B, MF_SCAN_MAX_B);
+    if (!scan) mf_register_kernel<<<(unsigned)cdiv(B, 4), 256, 0, st>>>(rg);
     float *P[MF_SLOTS], *M[MF_SLOTS], *V[MF_SLOTS];
     for (int k = 0; k < MF_SLOTS; ++k) {
         P[k] = reinterpret_cast<float *>(p[k]); M[k] = reinterpret_cast<float *>(m[k]); V[k] = reinterpret_cast<float *>(v[k]);
@@ -1454,13 +1682,28 @@ extern "C" int r4r_mf_apply(const void *blocks, int world, int64_t B_pad, const 
     chunks += 1;
     sw.cb_entries = (int)chunks;
     const bool light = mf_light(D, B);                      // (one rating per entry wave, the generic form)
-    sw.epw = (!light && D > 0 && mf_wide(D, sw.p0, sw.m0, sw.v0) && mf_wide(D, sw.p1, sw.m1, sw.v1)) ? 256 / D : 1;
+    if (scan) sw.epw = mf_epw(B);
+    else sw.epw = (!light && D > 0 && mf_wide(D, sw.p0, sw.m0, sw.v0) && mf_wide(D, sw.p1, sw.m1, sw.v1)) ? 256 / D : 1;
     sw.n_entry_wgs = (int)(2 * cdiv(B, 4 * sw.epw));
     chunks += sw.n_entry_wgs;
     R4R_REQUIRE(chunks < (1ll << 31), "mf_apply: too many workgroups");
-    sw.first_u = w.first_u; sw.first_i = w.first_i; sw.last_u = w.last_u; sw.last_i = w.last_i;
-    sw.uid32 = w.uid32; sw.iid32 = w.iid32;
-    sw.uid = nullptr; sw.iid = nullptr; sw.gu = w.gu; sw.gi = w.gi; sw.g = w.g;
+    sw.uid = nullptr; sw.iid = nullptr;
+    if (scan) {                                             // entries straight out of the gathered blocks
+        const char *b0 = rg.blocks;
+        sw.uid32 = reinterpret_cast<const int *>(b0 + rg.k.uid); sw.iid32 = reinterpret_cast<const int *>(b0 + rg.k.iid);
+        sw.g = reinterpret_cast<const float *>(b0 + rg.k.g);
+        sw.gu = reinterpret_cast<const float *>(b0 + rg.k.gu); sw.gi = reinterpret_cast<const float *>(b0 + rg.k.gi);
+        sw.B_pad = B_pad; sw.blk_units = (int64_t)(rg.k.bytes / 4);
+        if (tb_on) { sw.ctag_wu = w.ctag_u; sw.ctag_wi = w.ctag_i; }
+        if (wait.flags) {
+            sw.wait_flags = wait.flags; sw.timed_out = wait.timed_out; sw.wait_epoch = wait.epoch; sw.world = world;
+            sw.max_ticks = (unsigned long long)(wait.timeout_s * 1e8);
+        }
+    } else {
+        sw.first_u = w.first_u; sw.first_i = w.first_i; sw.last_u = w.last_u; sw.last_i = w.last_i;
+        sw.uid32 = w.uid32; sw.iid32 = w.iid32;
+        sw.gu = w.gu; sw.gi = w.gi; sw.g = w.g;
+    }
     sw.se = sse_accum ? se : nullptr; sw.se_n = se_n; sw.sse_accum = sse_accum;   // this rank's share of the running metric rides on the global-bias workgroup
     sw.tag_u = w.tag_u; sw.tag_i = w.tag_i; sw.B = B; sw.D = D; sw.now = (int)adam_step;
     sw.s = adam_make_scalars(lr, beta1, beta2, eps, weight_decay, adam_step, nullptr);
@@ -1469,8 +1712,39 @@ extern "C" int r4r_mf_apply(const void *blocks, int world, int64_t B_pad, const 
         sw.tb = tb;
         sw.nt = mf_sweep_nt(sw.n0 + sw.n1);
     }
-    if (B > 2048) mf_adam_kernel<8><<<(unsigned)chunks, MF_THREADS, 0, st>>>(sw);
+    if (scan) {
+        const size_t lds = (size_t)B * sizeof(int);         // the entry waves' ids (<= 8 KB)
+        if (light) mf_adam_kernel<4, 1, false, true><<<(unsigned)chunks, MF_THREADS, lds, st>>>(sw);
+        else mf_adam_kernel<4, 4, true, true><<<(unsigned)chunks, MF_THREADS, lds, st>>>(sw);
+    }
+    else if (B > 2048) mf_adam_kernel<8><<<(unsigned)chunks, MF_THREADS, 0, st>>>(sw);
     else if (light) mf_adam_kernel<4, 1, false><<<(unsigned)chunks, MF_THREADS, 0, st>>>(sw);
     else mf_adam_kernel<4><<<(unsigned)chunks, MF_THREADS, 0, st>>>(sw);
     return check_launch("mf_apply");
+}
+
+extern "C" int r4r_mf_apply(const void *blocks, int world, int64_t B_pad, const uint64_t *p, const uint64_t *m,
+                            const uint64_t *v, int64_t n_users, int64_t n_items, int D, void *ws, size_t ws_bytes,
+                            int sweep_period, int64_t sweep_base, int sweep_all,
+                            const float *se, int64_t se_n, float *sse_accum,
+                            float lr, double beta1, double beta2, float eps, float weight_decay, int64_t adam_step,
+                            void *stream) {
+    return mf_apply_impl(blocks, world, B_pad, p, m, v, n_users, n_items, D, ws, ws_bytes, sweep_period, sweep_base, sweep_all,
+                         se, se_n, sse_accum, lr, beta1, beta2, eps, weight_decay, adam_step, stream, MfWait{});
+}
+
+extern "C" int r4r_mf_apply_peer(const void *blocks, int world, int64_t B_pad, const uint64_t *p, const uint64_t *m,
+                                 const uint64_t *v, int64_t n_users, int64_t n_items, int D, void *ws, size_t ws_bytes,
+                                 int sweep_period, int64_t sweep_base, int sweep_all,
+                                 const float *se, int64_t se_n, float *sse_accum,
+                                 float lr, double beta1, double beta2, float eps, float weight_decay, int64_t adam_step,
+                                 const uint32_t *wait_flags, uint32_t epoch, uint32_t *timed_out, double timeout_s,
+                                 void *stream) {
+    R4R_REQUIRE(wait_flags && timed_out, "mf_apply_peer: null pointer");
+    R4R_REQUIRE(world >= 1 && world <= PEER_MAX_WORLD, "mf_apply_peer: %d ranks (<= %d)", world, PEER_MAX_WORLD);
+    R4R_REQUIRE(timeout_s > 0 && timeout_s <= 60, "mf_apply_peer: timeout %.3f s outside (0, 60]", timeout_s);
+    MfWait wait;
+    wait.flags = wait_flags; wait.timed_out = timed_out; wait.epoch = epoch; wait.timeout_s = timeout_s;
+    return mf_apply_impl(blocks, world, B_pad, p, m, v, n_users, n_items, D, ws, ws_bytes, sweep_period, sweep_base, sweep_all,
+                         se, se_n, sse_accum, lr, beta1, beta2, eps, weight_decay, adam_step, stream, wait);
 }

@@ -19,6 +19,7 @@
 // push, so the buffer a fast rank writes for step k+1 is never the one a slow rank still reads for step k.
 // Nothing here assumes a placement: correctness comes from the system-scope release (push) / acquire (wait).
 #include "common.h"
+#include "peer_device.h"
 #include <string.h>
 
 #define R4R_HIP(expr)                                                        \
@@ -32,7 +33,6 @@
 
 namespace r4r {
 
-constexpr int PEER_MAX_WORLD = 16;
 constexpr int PEER_THREADS = 256;
 
 struct PeerPush {
@@ -47,18 +47,6 @@ struct PeerPush {
     int rank, world;
     unsigned epoch;
 };
-
-// lane r of the calling wave waits for rank r.  Bounded: a peer that never arrives sets *timed_out instead of hanging the GPU.
-__device__ __forceinline__ void peer_wait_lane(const unsigned *flags, int r, unsigned epoch, unsigned *timed_out,
-                                               unsigned long long max_ticks) {
-    const unsigned long long t0 = wall_clock64();           // 100 MHz
-    for (;;) {
-        const unsigned f = __hip_atomic_load(flags + r, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
-        if ((int)(f - epoch) >= 0) break;
-        if (wall_clock64() - t0 > max_ticks) { __hip_atomic_store(timed_out, 1u + (unsigned)r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
-        __builtin_amdgcn_s_sleep(8);
-    }
-}
 
 typedef float peer_f32x4 __attribute__((ext_vector_type(4)));
 

@@ -672,8 +672,11 @@ class MFEngine(_SweepSchedule):
     loss, backward and the dense Adam update of MF.py / main.py:56-60,94-96 in two launches; the
     dense gradient of an ID table is never materialised.  Same calling surface as DeepCoNNEngine
     (train_step / predict / sse / state_dict).  Under data parallelism (``dp``) the step splits into
-    r4r_mf_grad -> one all_gather of the ranks' compact rows -> r4r_mf_apply."""
+    r4r_mf_grad -> one all_gather of the ranks' compact rows -> r4r_mf_apply; with ``R4R_DP_EXCHANGE=peer`` (and at most
+    PEER_MAX_ENTRIES gathered ratings) into r4r_mf_grad_push -> r4r_mf_apply_peer, the exchange riding on the two launches
+    over peer-mapped memory (dist.PeerExchange's segments) with no collective call in the step."""
     MAX_TRAIN_BATCH = 1 << 20    # r4r_mf_step's limit (csrc/mf_engine.hip: MF_MAX_B_STEP)
+    PEER_MAX_ENTRIES = 2048      # r4r_mf_apply_peer's limit on world * B_pad (csrc/mf_engine.hip: MF_SCAN_MAX_B)
 
     def __init__(self, model, lr=0.002, weight_decay=1e-6, betas=(0.9, 0.999), eps=1e-8, seed=0x5EED5EED, rank=0,
                  dp=None):
@@ -706,11 +709,25 @@ class MFEngine(_SweepSchedule):
         # period-_tb_period schedule since (1: every step)
         self._tb_base, self._tb_period = 0, 1
         self._sd_hooks = flush_before_state_dict(self, model)
+        self.exchange = os.environ.get('R4R_DP_EXCHANGE', '') if self.dp is not None else ''
+        self._peer, self._peer_epoch, self._peer_B = None, 0, None   # dist.PeerExchange of the blocks ('peer'), built on first use
 
     TEMPORAL_SWEEP = True        # train_step(..., defer_sweep=True) + flush(): the table sweep, temporally blocked
 
     def _ptrs(self, tensors):
         return (ctypes.c_uint64 * 5)(*[0 if t is None else t.data_ptr() for t in tensors])
+
+    def check_exchange(self):
+        """Raise if a peer-mapped exchange of this engine timed out (one int read back from the device)."""
+        if self._peer is not None:
+            self._peer.check()
+
+    def close(self):
+        """Release the peer exchange's IPC mappings and segment (collective: every rank calls it)."""
+        if self._peer is not None:
+            peer, self._peer = self._peer, None
+            peer.check()
+            peer.close()
 
     def flush(self, check=True, last_step=None):
         """Apply every pending table update of the temporally blocked sweep (no-op when nothing is pending).
@@ -794,6 +811,7 @@ class MFEngine(_SweepSchedule):
             # collective: a hang, not an error)
             raise RuntimeError("data parallel: this rank's shard has %d ratings but hyper_params['batch_size'] is %d; "
                                "pass n_global=None to let the ranks agree on the sizes first" % (n, B_pad))
+        sizes_known = n_global is not None                   # (the peer exchange's buffers are sized once, for the configured batch)
         if n_global is None:                                 # (otherwise agree on the sizes first: one more collective + a sync)
             sizes = torch.tensor([n], dtype=torch.int64, device=self.dev)
             all_sizes = torch.empty(world, dtype=torch.int64, device=self.dev)
@@ -812,6 +830,33 @@ class MFEngine(_SweepSchedule):
         period, base, sweep_all, want = self._schedule(defer)
         ws = self._workspace(world * B_pad)
         pending = self.has_tables and period > 1             # (rows may carry pending updates: the forward catches them up)
+        if self.exchange == 'peer' and sizes_known and 0 < world * B_pad <= self.PEER_MAX_ENTRIES:
+            # no collective call: the block goes into every rank's gathered buffer from the gradient launch, the update
+            # launch waits for the ranks' flags (csrc/peer.hip's protocol; two buffers alternate by step parity)
+            from . import dist as _dist
+            if self._peer is None or self._peer_B != B_pad:
+                if self._peer is not None:
+                    self.close()
+                self._peer = _dist.PeerExchange(lib.r4r_mf_dp_block_bytes(B_pad, self.D) // 4, self.dev, self.dp.group)
+                self._peer_B = B_pad
+            peer = self._peer
+            self._peer_epoch += 1
+            epoch, par = self._peer_epoch & 0x7fffffff, self._peer_epoch & 1
+            _lib.check(lib.r4r_mf_grad_push(
+                ptr(uid), ptr(iid), ptr(y), self._ptrs(self.params),
+                self._ptrs(self.m) if pending else None, self._ptrs(self.v) if pending else None,
+                self.n_users, self.n_items, self.D, ptr(pred), ptr(se), None, n, B_pad, float(self.hp['dropout']),
+                int(self.model.training), self.seed, self.offset, 1.0 / float(n_global),
+                ptr(ws) if pending else None, period, base,
+                self.lr, self.betas[0], self.betas[1], self.eps, self.wd, step,
+                peer._dst[par].data_ptr(), peer._flg.data_ptr(), peer.local.data_ptr(), peer.rank, world, epoch,
+                _lib.current_stream()), 'r4r_mf_grad_push')
+            _lib.check(lib.r4r_mf_apply_peer(
+                peer.gathered[par], world, B_pad, self._ptrs(self.params), self._ptrs(self.m), self._ptrs(self.v),
+                self.n_users, self.n_items, self.D, ptr(ws), ws.numel(), period, base, sweep_all, ptr(se), n, ptr(self.sse),
+                self.lr, self.betas[0], self.betas[1], self.eps, self.wd, step,
+                peer._mine, epoch, peer.local.data_ptr() + 4, peer.TIMEOUT_S, _lib.current_stream()), 'r4r_mf_apply_peer')
+            return self._dp_step_done(sweep_all, want, step, n, se)
         _lib.check(lib.r4r_mf_grad(ptr(uid), ptr(iid), ptr(y), self._ptrs(self.params),
                                    self._ptrs(self.m) if pending else None, self._ptrs(self.v) if pending else None,
                                    self.n_users, self.n_items, self.D,
@@ -826,6 +871,9 @@ class MFEngine(_SweepSchedule):
                                     period, base, sweep_all, ptr(se), n, ptr(self.sse),
                                     self.lr, self.betas[0], self.betas[1], self.eps, self.wd, step,
                                     _lib.current_stream()), 'r4r_mf_apply')
+        return self._dp_step_done(sweep_all, want, step, n, se)
+
+    def _dp_step_done(self, sweep_all, want, step, n, se):
         self._scheduled(sweep_all, want, step)
         if self.model.training and float(self.hp['dropout']) > 0.0:
             self.offset += n * 2 * self.D

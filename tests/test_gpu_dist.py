@@ -175,33 +175,47 @@ def _mf_worker(rank, world, port, case, out_dir):
     assert isinstance(eng, MFEngine) and eng.dp is not None
     ses = []
     defer = os.environ.get('R4R_TEST_DEFER') == '1'          # the temporally blocked sweep over all ranks' announced next shards
-    shards = [r4dist.shard_batch(*g.batch(step % 2, 'cuda'), rank, world) for step in range(4)]
-    for step in range(3):
+    steps = int(os.environ.get('R4R_TEST_STEPS', '3'))
+    shards = [r4dist.shard_batch(*g.batch(step % 2, 'cuda'), rank, world) for step in range(steps + 1)]
+    for step in range(steps):
         data, y = g.batch(step % 2, 'cuda')
         sd, sy = shards[step]                                        # ragged: the ranks' shards differ in length
         # (with the global count known the shards are padded to hyper_params['batch_size'] and no sizes are
         # exchanged; without it the ranks agree on the sizes first: both forms)
-        kw = dict(next_data=shards[step + 1][0] if step < 2 else None, defer_sweep=True) if defer else {}
+        kw = dict(next_data=shards[step + 1][0] if step < steps - 1 else None, defer_sweep=True) if defer else {}
         ses.append(eng.train_step(sd, sy, n_global=int(y.shape[0]) if step != 1 else None, **kw).cpu().clone())
         if defer and step == 0:
             assert eng._tb_period == eng.sweep_period        # (the schedule is in force from the first step on)
     if defer:
         eng.flush()
+    if os.environ.get('R4R_DP_EXCHANGE') == 'peer':          # the steps with a known global count went over peer-mapped memory
+        assert eng._peer is not None and eng._peer_epoch == steps - 1
+        eng.check_exchange()
+    eng.close()
     torch.save({'w': {k: v.detach().cpu() for k, v in model.state_dict().items()}, 'se': ses},
                os.path.join(out_dir, 'm%d.pt' % rank))
     torch.distributed.destroy_process_group()
 
 
-@pytest.mark.parametrize('case', ['mf_dot', 'mf_bias_only', 'mf_dot+blocked'])
+@pytest.mark.parametrize('case', ['mf_dot', 'mf_bias_only', 'mf_dot+blocked', 'mf_dot+registered', 'mf_dot+blocked+registered',
+                                  'mf_dot+peer', 'mf_bias_only+peer', 'mf_dot+blocked+peer'])
 def test_dp2_native_mf_step_equals_the_single_process_step(tmp_path, case, monkeypatch):
     """MF under data parallelism on the native step (r4r_mf_grad -> all_gather of the packed compact
     rows -> r4r_mf_apply): 2 ranks x ragged shards reproduce the reference's 3 single-process steps,
     replicas bit-identical -- and identical, bit for bit, to the single-process native step on the
-    whole batch (same entries in the same order)."""
+    whole batch (same entries in the same order).  +registered: the update launch behind a registering launch (the form
+    of more than 2,048 gathered ratings) instead of finding its rows by scanning the ids; +peer: no collective call,
+    the blocks pushed into every rank's buffer over peer-mapped memory (r4r_mf_grad_push -> r4r_mf_apply_peer)."""
     sys.path.insert(0, TESTS)
     from helpers import Golden
     from test_gpu_models import build_model
     from reviews4rec_amd.engine import MFEngine
+    if case.endswith('+peer'):
+        case = case[:-len('+peer')]
+        monkeypatch.setenv('R4R_DP_EXCHANGE', 'peer')
+    if case.endswith('+registered'):
+        case = case[:-len('+registered')]
+        monkeypatch.setenv('R4R_MF_DP_REGISTER', '1')
     if case.endswith('+blocked'):                            # ... with every rank announcing its next shard (r4r.h)
         case = case[:-len('+blocked')]
         monkeypatch.setenv('R4R_TEST_DEFER', '1')
@@ -223,6 +237,28 @@ def test_dp2_native_mf_step_equals_the_single_process_step(tmp_path, case, monke
         assert torch.equal(r0['w'][k], r1['w'][k]), k               # replicas stay bit-identical
         assert torch.equal(r0['w'][k], single[k]), k                # == the single-process native step
         torch.testing.assert_close(r0['w'][k], v, rtol=1e-5, atol=5e-6, msg=lambda m: k + ': ' + m)
+
+
+@pytest.mark.parametrize('blocked', [False, True])
+def test_dp2_mf_peer_exchange_equals_the_collective_over_many_steps(tmp_path, monkeypatch, blocked):
+    """Twenty steps of two ranks with the blocks pushed over peer-mapped memory (both parity buffers reused nine times,
+    the scheduled sweep's chunks visited twice and more) end on the bits of the same steps over the collective."""
+    monkeypatch.setenv('R4R_TEST_STEPS', '20')
+    if blocked:
+        monkeypatch.setenv('R4R_TEST_DEFER', '1')
+    got = {}
+    for how in ('collective', 'peer'):
+        out = tmp_path / how
+        out.mkdir()
+        if how == 'peer':
+            monkeypatch.setenv('R4R_DP_EXCHANGE', 'peer')
+        mp.spawn(_mf_worker, args=(2, _free_port(), 'mf_dot', str(out)), nprocs=2, join=True)
+        got[how] = [torch.load(os.path.join(out, 'm%d.pt' % r)) for r in range(2)]
+    for r in range(2):
+        for k, v in got['collective'][0]['w'].items():
+            assert torch.equal(got['peer'][r]['w'][k], v), (r, k)
+        for a, b in zip(got['peer'][r]['se'], got['collective'][r]['se']):
+            assert torch.equal(a, b)
 
 
 def _empty_shard_worker(rank, world, port, out_dir):
