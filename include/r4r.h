@@ -677,6 +677,21 @@ int r4r_transnet_rows_apply(const int64_t *uid_all, const int64_t *iid_all, cons
                             int64_t B, int T, int E, int L, int64_t V,
                             float lr, double beta1, double beta2, float eps, float weight_decay, int64_t adam_step,
                             void *stream);
+/* The same update with one exchange and no glue launches (world * B_pad <= 2,048 gathered ratings):
+ * r4r_transnet_dp_block packs this rank's entries of the LAST gradients-only r4r_transnet_step on (uid, iid, ws)
+ *   into `block` (r4r_transnet_dp_block_bytes(B_pad) bytes: ids as int32 + the two gradient rows; entries past B carry
+ *   id -1), the caller all_gathers the blocks (rank order) and every rank calls
+ * r4r_transnet_rows_apply_blocks(blocks [world], ...): the scheduled sweep straight over the blocks, ONE launch. */
+size_t r4r_transnet_dp_block_bytes(int64_t B_pad);
+int r4r_transnet_dp_block(const int64_t *uid, const int64_t *iid, void *ws, size_t ws_bytes, int64_t B, int T,
+                          int E, int L, int64_t V, int64_t n_users, int64_t n_items, void *block, int64_t B_pad,
+                          void *stream);
+int r4r_transnet_rows_apply_blocks(const void *blocks, int world, int64_t B_pad, int sweep_period, int64_t sweep_base,
+                                   int sweep_all, const uint64_t *rows_p, const uint64_t *rows_m,
+                                   const uint64_t *rows_v, int64_t n_users, int64_t n_items, void *ws, size_t ws_bytes,
+                                   int64_t B, int T, int E, int L, int64_t V,
+                                   float lr, double beta1, double beta2, float eps, float weight_decay,
+                                   int64_t adam_step, void *stream);
 
 /* ------------------------------------------------------------------------
  * Fused native step for the ID-only recommenders with dense layers: model_type 'MF' (MF.py:60-68) and

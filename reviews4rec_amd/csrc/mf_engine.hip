@@ -1214,6 +1214,61 @@ int mf_table_rows_launch(float *ut, float *ut_m, float *ut_v, float *it, float *
     return check_launch("table rows");
 }
 
+// mf_table_rows_launch over the ranks' gathered blocks (data parallel; rows_device.h: mf_block's layout, `world` blocks
+// of B_pad entries each, ids -1 = padding): ONE launch -- nobody tags the rows first, the workgroups find the rows the
+// step names by scanning the ids (the SCAN form of the sweep), the owners stamp the chunk tags.  world * B_pad <=
+// MF_SCAN_MAX_B.
+int mf_table_rows_blocks_launch(float *ut, float *ut_m, float *ut_v, float *it, float *it_m, float *it_v,
+                                int64_t n_users, int64_t n_items, int D, const void *blocks, int world, int64_t B_pad,
+                                int *ctag_u, int *ctag_i, int now, const AdamScalars &sc, hipStream_t st, const MfTimeBlock *tb) {
+    const int64_t B = (int64_t)world * B_pad;
+    if (B > MF_SCAN_MAX_B || B < 1 || D < 1 || D > MF_MAX_D) {
+        set_error("table rows (blocks): %lld gathered entries outside 1..%d or width %d outside 1..%d", (long long)B,
+                  MF_SCAN_MAX_B, D, MF_MAX_D);
+        return R4R_ERR_ARG;
+    }
+    MfSweep sw{};
+    if (tb) {
+        const uintptr_t all = reinterpret_cast<uintptr_t>(ut) | reinterpret_cast<uintptr_t>(ut_m) | reinterpret_cast<uintptr_t>(ut_v) |
+                              reinterpret_cast<uintptr_t>(it) | reinterpret_cast<uintptr_t>(it_m) | reinterpret_cast<uintptr_t>(it_v);
+        if (!mf_tb_args_ok(tb, ctag_u, ctag_i, all)) {
+            set_error("table rows (blocks): the temporally blocked sweep needs chunk tags, its state arrays, 16-byte aligned "
+                      "tables and a period in 1..%d", MF_TB_MAX);
+            return R4R_ERR_ARG;
+        }
+        sw.tb = *tb;
+        sw.ctag_u = ctag_u; sw.ctag_i = ctag_i; sw.ctag_wu = ctag_u; sw.ctag_wi = ctag_i;
+    }
+    sw.p0 = ut; sw.m0 = ut_m; sw.v0 = ut_v; sw.p1 = it; sw.m1 = it_m; sw.v1 = it_v;
+    sw.n0 = n_users * D; sw.n1 = n_items * D; sw.n2 = sw.n3 = 0;
+    int64_t chunks = mf_sweep_wgs(sw.n0, mf_chunk(0), sw.tb);
+    sw.cb1 = (int)chunks;
+    chunks += mf_sweep_wgs(sw.n1, mf_chunk(1), sw.tb);
+    sw.cb2 = sw.cb3 = sw.cb_global = sw.cb_entries = (int)chunks;   // no bias vectors, no global-bias workgroup
+    sw.epw = mf_epw(B);
+    sw.n_entry_wgs = (int)(2 * cdiv(B, 4 * sw.epw));
+    chunks += sw.n_entry_wgs;
+    if (chunks >= (1ll << 31)) {
+        set_error("table rows (blocks): too many workgroups");
+        return R4R_ERR_ARG;
+    }
+    const MfBlock k = mf_block(B_pad, D);
+    const char *b0 = static_cast<const char *>(blocks);
+    sw.uid32 = reinterpret_cast<const int *>(b0 + k.uid); sw.iid32 = reinterpret_cast<const int *>(b0 + k.iid);
+    sw.gu = reinterpret_cast<const float *>(b0 + k.gu); sw.gi = reinterpret_cast<const float *>(b0 + k.gi);
+    sw.g = nullptr; sw.se = nullptr; sw.sse_accum = nullptr;
+    sw.B_pad = B_pad; sw.blk_units = (int64_t)(k.bytes / 4);
+    sw.B = B; sw.D = D; sw.now = now; sw.s = sc;
+    sw.nt = mf_sweep_nt(sw.n0 + sw.n1);
+    {
+        ScopedTiming tm(R4R_TIMING_ADAM, st);
+        const size_t lds = (size_t)B * sizeof(int);
+        if (mf_light(sw.D, B)) mf_adam_kernel<4, 1, false, true><<<(unsigned)chunks, MF_THREADS, lds, st>>>(sw);
+        else mf_adam_kernel<4, 4, true, true><<<(unsigned)chunks, MF_THREADS, lds, st>>>(sw);
+    }
+    return check_launch("table rows (blocks)");
+}
+
 // Both of the above in ONE launch: two ID tables of width D with compact gradient rows AND the two ID bias
 // vectors whose gradient is d loss / d pred of the ratings that name the id (r4r_idnet_step: MF, GMF, MLP, NeuMF's
 // first table pair).  An entry wave that owns a row updates the table row and the row's bias element together.
@@ -1446,17 +1501,6 @@ extern "C" size_t r4r_mf_ws_flag_offset(int64_t B, int D, int64_t n_users, int64
 // order).  Block layout (bytes): uid32 [B_pad] | iid32 [B_pad] | g [B_pad] | gu [B_pad, D] | gi [B_pad, D];
 // entries past a rank's own count carry id -1 (ragged shards).
 namespace r4r {
-
-struct MfBlock { size_t uid, iid, g, gu, gi, bytes; };
-static MfBlock mf_block(int64_t B_pad, int D) {
-    MfBlock k;
-    size_t o = 0;
-    auto take = [&](size_t n) { size_t r = o; o += a256(n); return r; };
-    k.uid = take((size_t)B_pad * 4); k.iid = take((size_t)B_pad * 4); k.g = take((size_t)B_pad * 4);
-    k.gu = take((size_t)B_pad * D * 4); k.gi = take((size_t)B_pad * D * 4);
-    k.bytes = o;
-    return k;
-}
 
 struct MfRegister {
     const char *blocks;                // [world] packed blocks

@@ -118,6 +118,23 @@ int mf_table_rows_launch(float *ut, float *ut_m, float *ut_v, float *it, float *
                          int64_t B, int now, const AdamScalars &sc, hipStream_t st,
                          const MfTimeBlock *tb = nullptr);       // (needs the chunk tags and 16-byte aligned tables)
 
+// Data parallel: a rank's compact entries as one packed block (bytes): uid32 [B_pad] | iid32 [B_pad] | g [B_pad] |
+// gu [B_pad, D] | gi [B_pad, D], every field 256-byte aligned; entries past the rank's own count carry id -1.
+struct MfBlock { size_t uid, iid, g, gu, gi, bytes; };
+inline MfBlock mf_block(int64_t B_pad, int D) {
+    MfBlock k;
+    size_t o = 0;
+    auto take = [&](size_t n) { size_t r = o; o += (n + 255) & ~(size_t)255; return r; };
+    k.uid = take((size_t)B_pad * 4); k.iid = take((size_t)B_pad * 4); k.g = take((size_t)B_pad * 4);
+    k.gu = take((size_t)B_pad * D * 4); k.gi = take((size_t)B_pad * D * 4);
+    k.bytes = o;
+    return k;
+}
+int mf_table_rows_blocks_launch(float *ut, float *ut_m, float *ut_v, float *it, float *it_m, float *it_v,
+                                int64_t n_users, int64_t n_items, int D, const void *blocks, int world, int64_t B_pad,
+                                int *ctag_u, int *ctag_i, int now, const AdamScalars &sc, hipStream_t st,
+                                const MfTimeBlock *tb = nullptr);
+
 int mf_table_bias_rows_launch(float *ut, float *ut_m, float *ut_v, float *it, float *it_m, float *it_v,
                               float *ub, float *ub_m, float *ub_v, float *ib, float *ib_m, float *ib_v,
                               int64_t n_users, int64_t n_items, int D, const int64_t *uid, const int64_t *iid,

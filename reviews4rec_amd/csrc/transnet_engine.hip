@@ -751,3 +751,85 @@ extern "C" int r4r_transnet_rows_apply(const int64_t *uid_all, const int64_t *ii
                                 gi_all, w.tag[0], w.tag[1], w.ctag[0], w.ctag[1], B_all, (int)adam_step, sc, st,
                                 aligned ? &tb : nullptr);
 }
+
+// ---- the same update with ONE exchange and no glue launches: every rank packs its compact entries into one block
+// (r4r_transnet_dp_block: ids as int32 + the two gradient rows, rows_device.h mf_block's layout at D = 5), ONE
+// all_gather moves the blocks, and r4r_transnet_rows_apply_blocks runs the scheduled sweep straight over them -- its
+// workgroups find the rows the step names by scanning the ids (mf_engine.hip's SCAN form), nobody tags them first.
+namespace r4r {
+__global__ __launch_bounds__(256) void tn_dp_block_kernel(const int64_t *uid, const int64_t *iid, const float *grow_u,
+                                                          const float *grow_i, int *uid32, int *iid32, float *g, float *gu,
+                                                          float *gi, int64_t B, int64_t B_pad) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;      // element of the [B_pad, TN_ID] row arrays
+    if (i < B_pad) {
+        const bool real = i < B;
+        uid32[i] = real ? (int)uid[i] : -1;
+        iid32[i] = real ? (int)iid[i] : -1;
+        g[i] = 0.f;
+    }
+    if (i < B_pad * TN_ID) {
+        const bool real = i < B * TN_ID;
+        gu[i] = real ? grow_u[i] : 0.f;
+        gi[i] = real ? grow_i[i] : 0.f;
+    }
+}
+}  // namespace r4r
+
+extern "C" size_t r4r_transnet_dp_block_bytes(int64_t B_pad) { return B_pad < 0 ? 0 : mf_block(B_pad, TN_ID).bytes; }
+
+extern "C" int r4r_transnet_dp_block(const int64_t *uid, const int64_t *iid, void *ws, size_t ws_bytes, int64_t B, int T,
+                                     int E, int L, int64_t V, int64_t n_users, int64_t n_items, void *block, int64_t B_pad,
+                                     void *stream) {
+    R4R_REQUIRE(block && B >= 0 && B_pad >= B, "transnet_dp_block: null block, or B_pad < B");
+    R4R_REQUIRE(B == 0 || (uid && iid && ws), "transnet_dp_block: null ids / workspace");
+    if (B_pad == 0) return R4R_OK;
+    const float *gu = nullptr, *gi = nullptr;
+    if (B > 0) {
+        if (ws_bytes < r4r_transnet_ws_bytes(B, T, E, L, 1, V, n_users, n_items)) {
+            set_error("transnet_dp_block: workspace %zu < %zu bytes", ws_bytes, r4r_transnet_ws_bytes(B, T, E, L, 1, V, n_users, n_items));
+            return R4R_ERR_WORKSPACE;
+        }
+        const TnWs w = tn_carve(ws, B, T, E, L, 1, V, n_users, n_items);
+        gu = w.grow[0]; gi = w.grow[1];
+    }
+    const MfBlock k = mf_block(B_pad, TN_ID);
+    char *b = static_cast<char *>(block);
+    tn_dp_block_kernel<<<(unsigned)cdiv(B_pad * TN_ID, 256), 256, 0, as_stream(stream)>>>(
+        uid, iid, gu, gi, reinterpret_cast<int *>(b + k.uid), reinterpret_cast<int *>(b + k.iid), reinterpret_cast<float *>(b + k.g),
+        reinterpret_cast<float *>(b + k.gu), reinterpret_cast<float *>(b + k.gi), B, B_pad);
+    return check_launch("transnet_dp_block");
+}
+
+extern "C" int r4r_transnet_rows_apply_blocks(const void *blocks, int world, int64_t B_pad, int sweep_period, int64_t sweep_base,
+                                              int sweep_all, const uint64_t *rows_p, const uint64_t *rows_m,
+                                              const uint64_t *rows_v, int64_t n_users, int64_t n_items, void *ws, size_t ws_bytes,
+                                              int64_t B, int T, int E, int L, int64_t V,
+                                              float lr, double beta1, double beta2, float eps, float weight_decay,
+                                              int64_t adam_step, void *stream) {
+    R4R_REQUIRE(blocks && rows_p && rows_m && rows_v && ws, "transnet_rows_apply_blocks: null pointer");
+    R4R_REQUIRE(world >= 1 && B_pad >= 0 && (int64_t)world * B_pad <= 2048,
+                "transnet_rows_apply_blocks: %lld gathered ratings outside 0..2048", (long long)world * B_pad);
+    R4R_REQUIRE(sweep_period >= 1 && sweep_period <= MF_TB_MAX, "transnet_rows_apply_blocks: sweep_period outside 1..%d", MF_TB_MAX);
+    R4R_REQUIRE(adam_step >= 1 && adam_step < (1ll << 31) && sweep_base >= 0 && sweep_base < adam_step,
+                "transnet_rows_apply_blocks: bad adam_step, or sweep_base outside 0..adam_step - 1");
+    if (ws_bytes < r4r_transnet_ws_bytes(B, T, E, L, 1, V, n_users, n_items)) {
+        set_error("transnet_rows_apply_blocks: workspace %zu < %zu bytes", ws_bytes, r4r_transnet_ws_bytes(B, T, E, L, 1, V, n_users, n_items));
+        return R4R_ERR_WORKSPACE;
+    }
+    if ((int64_t)world * B_pad == 0) return R4R_OK;
+    const TnWs w = tn_carve(ws, B, T, E, L, 1, V, n_users, n_items);
+    float *rp[2], *rm[2], *rv[2];
+    for (int t = 0; t < 2; ++t) {
+        rp[t] = reinterpret_cast<float *>(rows_p[t]); rm[t] = reinterpret_cast<float *>(rows_m[t]);
+        rv[t] = reinterpret_cast<float *>(rows_v[t]);
+        R4R_REQUIRE(rp[t] && rm[t] && rv[t], "transnet_rows_apply_blocks: ID-vector table %d: null pointer", t);
+    }
+    const AdamScalars sc = adam_make_scalars(lr, beta1, beta2, eps, weight_decay, adam_step, nullptr);
+    const bool aligned = ((rows_p[0] | rows_p[1] | rows_m[0] | rows_m[1] | rows_v[0] | rows_v[1]) & 15) == 0;
+    MfTimeBlock tb{};
+    tb.rlast_u = w.rlast[0]; tb.rlast_i = w.rlast[1]; tb.err = w.tb_err; tb.base = (int)sweep_base;
+    tb.period = sweep_period; tb.flush = (sweep_all || sweep_period == 1) ? 1 : 0; tb.inc = 1;
+    mf_time_block_scalars(tb, lr, beta1, beta2, eps, weight_decay, adam_step);
+    return mf_table_rows_blocks_launch(rp[0], rm[0], rv[0], rp[1], rm[1], rv[1], n_users, n_items, TN_ID, blocks, world, B_pad,
+                                       w.ctag[0], w.ctag[1], (int)adam_step, sc, as_stream(stream), aligned ? &tb : nullptr);
+}

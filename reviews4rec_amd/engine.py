@@ -1241,8 +1241,13 @@ class NarreEngine(_ConvRule):
                                       one(self.flat_m.data_ptr()), one(self.flat_v.data_ptr()),
                                       (ctypes.c_int64 * 1)(self.total), self.lr, self.betas[0], self.betas[1], self.eps,
                                       self.wd, int(self.step_count), None, _lib.current_stream()), 'r4r_adam_multi')
-        if not self.DP_COLS:
-            return se
+        if self.DP_COLS:
+            self._dp_rows(data, n, B_pad, world, solo)
+        return se
+
+    def _dp_rows(self, data, n, B_pad, world, solo):
+        """The ID tables' half of the data-parallel step: the ranks' compact entries, gathered, into the same update on
+        every rank."""
         R, T = self._dp_doc_shape(data)
         id_cols, val_cols = self._dp_cols(R)
         ids = torch.full((B_pad, id_cols), -1, dtype=torch.int64, device=self.dev)
@@ -1260,7 +1265,6 @@ class NarreEngine(_ConvRule):
         nb = max(n, 1)                                       # (the workspace of this rank's own shape holds the row tags)
         self._dp_apply(all_ids.view(world * B_pad, id_cols), all_vals.view(world * B_pad, val_cols), world * B_pad,
                        self._workspace(nb, R, T), nb, R, T)
-        return se
 
     @step_or_nothing
     @torch.no_grad()
@@ -1580,6 +1584,38 @@ class TransNetEngine(NarreEngine, _SweepSchedule):
             self.lr, self.betas[0], self.betas[1], self.eps, self.wd, int(adam_step), _lib.current_stream())
 
     DP_COLS = 10
+    BLOCKS_MAX_ENTRIES = 2048    # r4r_transnet_rows_apply_blocks' limit on world * B_pad
+
+    def _dp_rows(self, data, n, B_pad, world, solo):
+        """Up to BLOCKS_MAX_ENTRIES gathered ratings: one packing launch, ONE all_gather, one update launch that reads the
+        ranks' blocks directly (no tagging launch, no host-side slicing); beyond, the generic form."""
+        if not (0 < world * B_pad <= self.BLOCKS_MAX_ENTRIES):
+            return super()._dp_rows(data, n, B_pad, world, solo)
+        lib = _lib.lib()
+        R, T = self._dp_doc_shape(data)
+        key = ('dp_blocks', B_pad, world)
+        if key not in self._out:
+            nb_bytes = lib.r4r_transnet_dp_block_bytes(B_pad)
+            block = torch.zeros(nb_bytes, dtype=torch.uint8, device=self.dev)
+            self._out[key] = (block, block if solo else torch.zeros(world * nb_bytes, dtype=torch.uint8, device=self.dev))
+        block, blocks = self._out[key]
+        nb = max(n, 1)                                       # (the workspace of this rank's own shape holds the sweep's state)
+        ws = self._workspace(nb, R, T)
+        uid = iid = None
+        if n > 0:
+            f = self._fields(data)[0]
+            uid, iid = f[3], f[4]
+        _lib.check(lib.r4r_transnet_dp_block(ptr(uid) if n else None, ptr(iid) if n else None, ptr(ws), ws.numel(), n, T,
+                                             self.E, self.L, self.V, self.n_users, self.n_items, ptr(block), B_pad,
+                                             _lib.current_stream()), 'r4r_transnet_dp_block')
+        if not solo:
+            self.dp.all_gather(blocks, block)
+        p2 = lambda ts: (ctypes.c_uint64 * 2)(*[t.data_ptr() for t in ts])   # noqa: E731
+        period, base, sweep_all, _ = self._tb_now            # (the same on every rank: the loops run in lockstep)
+        _lib.check(lib.r4r_transnet_rows_apply_blocks(
+            ptr(blocks), world, B_pad, period, base, sweep_all, p2(self.rows), p2(self.rows_m), p2(self.rows_v),
+            self.n_users, self.n_items, ptr(ws), ws.numel(), nb, T, self.E, self.L, self.V, self.lr, self.betas[0],
+            self.betas[1], self.eps, self.wd, int(self.step_count), _lib.current_stream()), 'r4r_transnet_rows_apply_blocks')
 
     def _dp_payload(self, f, n, R, T, ids, vals):
         ws = self._workspace(n, R, T)
