@@ -537,6 +537,22 @@ int r4r_narre_rows_apply(const int64_t *gid0, const int64_t *gid1, const float *
                          int64_t B, int R, int T, int E, int L, int64_t V,
                          float lr, double beta1, double beta2, float eps, float weight_decay, int64_t adam_step,
                          void *stream);
+/* The same update with one exchange and no glue launches (world * B_pad * (1 + R) <= 16,384 entries, latent_size <= 32):
+ * r4r_narre_dp_block packs this rank's entries of the LAST gradients-only r4r_narre_step on `ws` into `block`
+ *   (r4r_narre_dp_block_bytes(B_pad, R, L) bytes: ids as int32, an entry's bias gradient, the gradient rows; the B_pad
+ *   self entries first, then the neighbour entries; entries past the rank's own carry id -1), the caller all_gathers
+ *   the blocks (rank order) and every rank calls
+ * r4r_narre_rows_apply_blocks(blocks [world], ...): r4r_narre_rows_apply straight over the blocks, entries in (rank,
+ *   in-block) order on every rank. */
+size_t r4r_narre_dp_block_bytes(int64_t B_pad, int R, int L);
+int r4r_narre_dp_block(void *ws, size_t ws_bytes, int64_t B, int R, int T, int E, int L, int64_t V,
+                       int64_t n_users, int64_t n_items, void *block, int64_t B_pad, void *stream);
+int r4r_narre_rows_apply_blocks(const void *blocks, int world, int64_t B_pad,
+                                const uint64_t *rows_p, const uint64_t *rows_m, const uint64_t *rows_v,
+                                int64_t n_users, int64_t n_items, void *ws, size_t ws_bytes,
+                                int64_t B, int R, int T, int E, int L, int64_t V,
+                                float lr, double beta1, double beta2, float eps, float weight_decay, int64_t adam_step,
+                                void *stream);
 
 /* The same for ANY number of entries (a data-parallel step at a global batch of 8,192 gathers 90,112 entries per
  * table; a single-process step beyond the fused launch's 4,096): the named rows go through r4r_rows_apply_large

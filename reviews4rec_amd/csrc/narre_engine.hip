@@ -897,6 +897,129 @@ extern "C" int r4r_narre_rows_apply(const int64_t *gid0, const int64_t *gid1, co
     return check_launch("narre_rows_apply");
 }
 
+// ---- the same update with ONE exchange and no glue launches: every rank packs its compact entries into one block
+// (r4r_narre_dp_block: rows_device.h mf_block's layout over E_pad = B_pad (1 + R) entries of width L -- ids as int32,
+// an entry's bias gradient, the two tables' gradient rows; the B_pad self entries first, then a rating's R neighbour
+// entries, ids -1 = padding), ONE all_gather moves the blocks, r4r_narre_rows_apply_blocks tags the rows and runs the
+// entry waves + the sweep straight over the gathered blocks, entries in (rank, in-block) order on every rank.
+namespace r4r {
+__global__ __launch_bounds__(256) void narre_dp_block_kernel(const int64_t *gid0, const int64_t *gid1, const float *grow0,
+                                                             const float *grow1, const float *g, int *o_gid0, int *o_gid1,
+                                                             float *o_g, float *o_grow0, float *o_grow1, int64_t B,
+                                                             int64_t B_pad, int R, int L) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;      // element of the [E_pad, L] row arrays
+    const int64_t E_pad = B_pad * (1 + R);
+    if (i >= E_pad * L) return;
+    const int64_t e = i / L;
+    const int col = (int)(i - e * L);
+    // block entry e -> this rank's entry: the self entries [0, B) stay, rating b's neighbour j sits at B + b R + j
+    int64_t src = -1;
+    if (e < B_pad) { if (e < B) src = e; }
+    else { const int64_t b = (e - B_pad) / R; if (b < B) src = B + (e - B_pad); }
+    o_grow0[i] = src >= 0 ? grow0[src * L + col] : 0.f;
+    o_grow1[i] = src >= 0 ? grow1[src * L + col] : 0.f;
+    if (col == 0) {
+        o_gid0[e] = src >= 0 ? (int)gid0[src] : -1;
+        o_gid1[e] = src >= 0 ? (int)gid1[src] : -1;
+        o_g[e] = (src >= 0 && e < B) ? g[e] : 0.f;          // only a rating's own user / item entry carries a bias gradient
+    }
+}
+__global__ void narre_tag_rows_blocks_kernel(RowSweep w, int *tag0, int *tag1) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= w.entries) return;
+    const int64_t o = nrow_eoff<true>(w, e, 1);
+    const int a = w.gid32_0[o], b = w.gid32_1[o];
+    if (a >= 0) tag0[a] = w.now;
+    if (b >= 0) tag1[b] = w.now;
+}
+}  // namespace r4r
+
+extern "C" size_t r4r_narre_dp_block_bytes(int64_t B_pad, int R, int L) {
+    return (B_pad < 0 || R < 0 || L < 1) ? 0 : mf_block(B_pad * (1 + R), L).bytes;
+}
+
+extern "C" int r4r_narre_dp_block(void *ws, size_t ws_bytes, int64_t B, int R, int T, int E, int L, int64_t V,
+                                  int64_t n_users, int64_t n_items, void *block, int64_t B_pad, void *stream) {
+    R4R_REQUIRE(block && B >= 0 && B_pad >= B && R >= 1 && L >= 1, "narre_dp_block: null block, B_pad < B, or bad R / L");
+    R4R_REQUIRE(B == 0 || ws, "narre_dp_block: null workspace");
+    if (B_pad == 0) return R4R_OK;
+    NarreWs w{};
+    if (B > 0) {
+        if (ws_bytes < r4r_narre_ws_bytes(B, R, T, E, L, V, n_users, n_items)) {
+            set_error("narre_dp_block: workspace %zu < %zu bytes", ws_bytes, r4r_narre_ws_bytes(B, R, T, E, L, V, n_users, n_items));
+            return R4R_ERR_WORKSPACE;
+        }
+        w = narre_carve(ws, B, R, T, E, L, V, n_users, n_items);
+    }
+    const int64_t E_pad = B_pad * (1 + R);
+    const MfBlock k = mf_block(E_pad, L);
+    char *b = static_cast<char *>(block);
+    narre_dp_block_kernel<<<(unsigned)cdiv(E_pad * L, 256), 256, 0, as_stream(stream)>>>(
+        w.gid[0], w.gid[1], w.grow[0], w.grow[1], w.g, reinterpret_cast<int *>(b + k.uid), reinterpret_cast<int *>(b + k.iid),
+        reinterpret_cast<float *>(b + k.g), reinterpret_cast<float *>(b + k.gu), reinterpret_cast<float *>(b + k.gi), B, B_pad, R, L);
+    return check_launch("narre_dp_block");
+}
+
+extern "C" int r4r_narre_rows_apply_blocks(const void *blocks, int world, int64_t B_pad,
+                                           const uint64_t *rows_p, const uint64_t *rows_m, const uint64_t *rows_v,
+                                           int64_t n_users, int64_t n_items, void *ws, size_t ws_bytes,
+                                           int64_t B, int R, int T, int E, int L, int64_t V,
+                                           float lr, double beta1, double beta2, float eps, float weight_decay, int64_t adam_step,
+                                           void *stream) {
+    R4R_REQUIRE(blocks && rows_p && rows_m && rows_v && ws, "narre_rows_apply_blocks: null pointer");
+    R4R_REQUIRE(world >= 1 && B_pad >= 0 && R >= 1, "narre_rows_apply_blocks: bad sizes");
+    const int64_t E_pad = B_pad * (1 + R), entries = (int64_t)world * E_pad;
+    R4R_REQUIRE(entries <= NROW_DP_MAX_ENTRIES, "narre_rows_apply_blocks: %lld entries outside 0..%d", (long long)entries,
+                NROW_DP_MAX_ENTRIES);
+    R4R_REQUIRE(L > 0 && L <= NR_MAX_L, "narre_rows_apply_blocks: latent_size %d outside 1..%d", L, NR_MAX_L);
+    R4R_REQUIRE(adam_step >= 1 && adam_step < (1ll << 31), "narre_rows_apply_blocks: bad adam_step");
+    if (ws_bytes < r4r_narre_ws_bytes(B, R, T, E, L, V, n_users, n_items)) {
+        set_error("narre_rows_apply_blocks: workspace %zu < %zu bytes", ws_bytes, r4r_narre_ws_bytes(B, R, T, E, L, V, n_users, n_items));
+        return R4R_ERR_WORKSPACE;
+    }
+    if (entries == 0) return R4R_OK;
+    hipStream_t st = as_stream(stream);
+    const NarreWs w = narre_carve(ws, B, R, T, E, L, V, n_users, n_items);
+    RowSweep rs;
+    float *rp[4], *rm[4], *rv[4];
+    for (int k = 0; k < 4; ++k) {
+        rp[k] = reinterpret_cast<float *>(rows_p[k]); rm[k] = reinterpret_cast<float *>(rows_m[k]);
+        rv[k] = reinterpret_cast<float *>(rows_v[k]);
+        R4R_REQUIRE(rp[k] && rm[k] && rv[k], "narre_rows_apply_blocks: row tensor %d: null parameter / moment pointer", k);
+    }
+    rs.p0 = rp[0]; rs.p1 = rp[1]; rs.p2 = rp[2]; rs.p3 = rp[3];
+    rs.m0 = rm[0]; rs.m1 = rm[1]; rs.m2 = rm[2]; rs.m3 = rm[3];
+    rs.v0 = rv[0]; rs.v1 = rv[1]; rs.v2 = rv[2]; rs.v3 = rv[3];
+    const int64_t numel[4] = {n_users * L, n_items * L, n_users, n_items};
+    int64_t begin[5], chunks = 0;
+    for (int k = 0; k < 4; ++k) { begin[k] = chunks; chunks += cdiv(numel[k], NROW_CHUNK); }
+    rs.n0 = numel[0]; rs.n1 = numel[1]; rs.n2 = numel[2]; rs.n3 = numel[3];
+    rs.cb1 = (int)begin[1]; rs.cb2 = (int)begin[2]; rs.cb3 = (int)begin[3]; rs.cb_entries = (int)chunks;
+    chunks += 2 * cdiv(entries, 4 * NROW_EPW);
+    R4R_REQUIRE(chunks < (1ll << 31), "narre_rows_apply_blocks: too many chunks");
+    rs.sweep_elsewhere = 0;
+    const MfBlock k = mf_block(E_pad, L);
+    const char *b0 = static_cast<const char *>(blocks);
+    rs.gid0 = nullptr; rs.gid1 = nullptr;
+    rs.gid32_0 = reinterpret_cast<const int *>(b0 + k.uid); rs.gid32_1 = reinterpret_cast<const int *>(b0 + k.iid);
+    rs.g = reinterpret_cast<const float *>(b0 + k.g);
+    rs.grow0 = reinterpret_cast<const float *>(b0 + k.gu); rs.grow1 = reinterpret_cast<const float *>(b0 + k.gi);
+    rs.E_pad = E_pad; rs.blk_units = (int64_t)(k.bytes / 4);
+    rs.tag0 = w.tag[0]; rs.tag1 = w.tag[1]; rs.entries = entries; rs.B = entries; rs.L = L; rs.now = (int)adam_step;
+    rs.s = adam_make_scalars(lr, beta1, beta2, eps, weight_decay, adam_step, nullptr);
+    narre_tag_rows_blocks_kernel<<<(unsigned)cdiv(entries, 256), 256, 0, st>>>(rs, w.tag[0], w.tag[1]);
+    const size_t lds = (size_t)entries * sizeof(int);
+    static size_t attr16 = 0, attr32 = 0;
+    if (L <= 16) {
+        if (attr16 < lds) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(narre_rows_kernel<16, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr16 = lds; }
+        narre_rows_kernel<16, true><<<(unsigned)chunks, NROW_THREADS, lds, st>>>(rs);
+    } else {
+        if (attr32 < lds) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(narre_rows_kernel<32, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr32 = lds; }
+        narre_rows_kernel<32, true><<<(unsigned)chunks, NROW_THREADS, lds, st>>>(rs);
+    }
+    return check_launch("narre_rows_apply_blocks");
+}
+
 // Any number of entries: the named rows by the bucketed entry waves of rows_large.hip, the others by the tagged sweep.
 extern "C" int r4r_narre_rows_apply_large(const int64_t *gid0, const int64_t *gid1, const float *grow0, const float *grow1,
                                           const float *g_entry, int64_t entries,

@@ -87,7 +87,22 @@ struct RowSweep {
     int L, now;
     AdamScalars s;
     int sweep_elsewhere;               // the sweep workgroups ride in the reduce launch: the backward launch runs the entry waves only
+    // BLK form (data parallel, r4r_narre_rows_apply_blocks): the entries live in the ranks' gathered blocks (rows_device.h:
+    // mf_block(E_pad, L)) -- entry e is entry e % E_pad of block e / E_pad, `blk_units` 4-byte units apart; gid32_* / grow* / g
+    // point into block 0
+    const int *gid32_0 = nullptr, *gid32_1 = nullptr;
+    int64_t E_pad = 0, blk_units = 0;
 };
+// offset (4-byte units) of entry e's field of `width` units per entry
+template <bool BLK>
+__device__ __forceinline__ int64_t nrow_eoff(const RowSweep &w, int64_t e, int width) {
+    if constexpr (BLK) {
+        const int r = (int)((unsigned)e / (unsigned)w.E_pad);
+        return (int64_t)r * w.blk_units + (e - (int64_t)r * w.E_pad) * width;
+    } else {
+        return e * width;
+    }
+}
 // ---- sweep workgroup `bx` (< cb_entries) of the ID tables / bias vectors: rows no rating touched
 __device__ __forceinline__ void narre_sweep_block(const RowSweep &w, int bx) {
     const int t = (bx >= w.cb1) + (bx >= w.cb2) + (bx >= w.cb3);
@@ -128,7 +143,7 @@ __device__ __forceinline__ void narre_sweep_block(const RowSweep &w, int bx) {
 constexpr int NROW_EPW = 2;              // entries per wave of an entry workgroup (16 entries share one load of the ids)
 // MW: 64-bit words of a lane's hit mask (entries <= 4096 MW: 1 in the fused single-process launch,
 // 4 in the stand-alone data-parallel launch); `sid`: LDS for the entry ids (entries ints).
-template <int ML, int MW>
+template <int ML, int MW, bool BLK = false>
 __device__ __forceinline__ void narre_rows_block(const RowSweep &w, int bx, int *sid) {
     if (bx >= w.cb_entries) {
         // ---- entry waves: 4 per workgroup, NROW_EPW entries each (interleaved: the owners of popular rows
@@ -140,7 +155,12 @@ __device__ __forceinline__ void narre_rows_block(const RowSweep &w, int bx, int 
         if (t) gi -= groups;
         const int64_t *ids = t ? w.gid1 : w.gid0;
         const float *rows = t ? w.grow1 : w.grow0;
-        for (int64_t j = threadIdx.x; j < w.entries; j += NROW_THREADS) sid[j] = (int)ids[j];   // one round trip
+        if constexpr (BLK) {
+            const int *ids32 = t ? w.gid32_1 : w.gid32_0;
+            for (int64_t j = threadIdx.x; j < w.entries; j += NROW_THREADS) sid[j] = ids32[nrow_eoff<true>(w, j, 1)];
+        } else {
+            for (int64_t j = threadIdx.x; j < w.entries; j += NROW_THREADS) sid[j] = (int)ids[j];   // one round trip
+        }
         __syncthreads();
         const int L = w.L;
         const int nch = (int)((w.entries + 63) / 64);
@@ -206,9 +226,10 @@ __device__ __forceinline__ void narre_rows_block(const RowSweep &w, int bx, int 
                 c0[q] = pop(q);
                 int64_t jj = (int64_t)(c0[q] < 0 ? 0 : c0[q]) * 64 + lane;
                 if (jj >= w.entries) jj = w.entries - 1;
+                const int64_t ro = nrow_eoff<BLK>(w, jj, L);
 #pragma unroll
-                for (int col = 0; col < ML; ++col) h0[q][col] = rows[jj * L + (col < L ? col : L - 1)];
-                g0[q] = w.g[jj < w.B ? jj : 0];
+                for (int col = 0; col < ML; ++col) h0[q][col] = rows[ro + (col < L ? col : L - 1)];
+                g0[q] = w.g[nrow_eoff<BLK>(w, jj < w.B ? jj : 0, 1)];
             }
 #pragma unroll
             for (int q = 0; q < PAIR; ++q) if (own[q]) {    // uniform
@@ -230,10 +251,11 @@ __device__ __forceinline__ void narre_rows_block(const RowSweep &w, int bx, int 
 #pragma unroll
                     for (int u = 0; u < HR; ++u) {
                         const int64_t jj = (int64_t)(cs[u] < 0 ? 0 : cs[u]) * 64 + lane;
+                        const int64_t ro = cs[u] >= 0 ? nrow_eoff<BLK>(w, jj, L) : 0;
 #pragma unroll
                         for (int col = 0; col < ML; ++col)
-                            tmp[u][col] = (cs[u] >= 0 && col < L) ? rows[jj * L + col] : 0.f;
-                        tg[u] = (cs[u] >= 0 && jj < w.B) ? w.g[jj] : 0.f;
+                            tmp[u][col] = (cs[u] >= 0 && col < L) ? rows[ro + col] : 0.f;
+                        tg[u] = (cs[u] >= 0 && jj < w.B) ? w.g[nrow_eoff<BLK>(w, jj, 1)] : 0.f;
                     }
 #pragma unroll
                     for (int u = 0; u < HR; ++u) {          // ascending entry order within the lane
@@ -329,10 +351,10 @@ __global__ __launch_bounds__(WG_THREADS, ML > 16 ? 2 : (ML == 0 && WIDE ? 8 : 4)
 // The ID-table role as a launch of its own (data parallel: the entries of ALL ranks, gathered): up to
 // 16,384 entries per table, their ids in dynamic LDS.
 constexpr int NROW_DP_WORDS = 4, NROW_DP_MAX_ENTRIES = 64 * 64 * NROW_DP_WORDS;
-template <int ML>
+template <int ML, bool BLK = false>
 static __global__ __launch_bounds__(NROW_THREADS) void narre_rows_kernel(RowSweep w) {
     extern __shared__ int rows_sid_dyn[];
-    narre_rows_block<ML, NROW_DP_WORDS>(w, (int)blockIdx.x, rows_sid_dyn);
+    narre_rows_block<ML, NROW_DP_WORDS, BLK>(w, (int)blockIdx.x, rows_sid_dyn);
 }
 
 // ---- 5: wgrad partial reduce + Adam on the dense parameters + next batch's compaction

@@ -1245,10 +1245,32 @@ class NarreEngine(_ConvRule):
             self._dp_rows(data, n, B_pad, world, solo)
         return se
 
+    BLOCKS_DP = True             # the entries travel as one packed block per rank (r4r_narre_dp_block; subclasses: their own forms)
+
     def _dp_rows(self, data, n, B_pad, world, solo):
         """The ID tables' half of the data-parallel step: the ranks' compact entries, gathered, into the same update on
-        every rank."""
+        every rank.  Up to ROWS_APPLY_MAX entries (and latent_size 32): one packing launch, ONE all_gather, and the update
+        reads the ranks' blocks directly; beyond, the generic form (per-rating payload rows, sliced on the host side)."""
         R, T = self._dp_doc_shape(data)
+        if self.BLOCKS_DP and 0 < world * B_pad * (1 + R) <= self.ROWS_APPLY_MAX and self.L <= 32:
+            lib = _lib.lib()
+            key = ('dp_blocks', B_pad, world, R)
+            if key not in self._out:
+                nb_bytes = lib.r4r_narre_dp_block_bytes(B_pad, R, self.L)
+                block = torch.zeros(nb_bytes, dtype=torch.uint8, device=self.dev)
+                self._out[key] = (block, block if solo else torch.zeros(world * nb_bytes, dtype=torch.uint8, device=self.dev))
+            block, blocks = self._out[key]
+            nb = max(n, 1)                                   # (the workspace of this rank's own shape holds the row tags)
+            ws = self._workspace(nb, R, T)
+            _lib.check(lib.r4r_narre_dp_block(ptr(ws), ws.numel(), n, R, T, self.E, self.L, self.V, self.n_users, self.n_items,
+                                              ptr(block), B_pad, _lib.current_stream()), 'r4r_narre_dp_block')
+            if not solo:
+                self.dp.all_gather(blocks, block)
+            _lib.check(lib.r4r_narre_rows_apply_blocks(
+                ptr(blocks), world, B_pad, self._p4(self.rows), self._p4(self.rows_m), self._p4(self.rows_v), self.n_users,
+                self.n_items, ptr(ws), ws.numel(), nb, R, T, self.E, self.L, self.V, self.lr, self.betas[0], self.betas[1],
+                self.eps, self.wd, int(self.step_count), _lib.current_stream()), 'r4r_narre_rows_apply_blocks')
+            return
         id_cols, val_cols = self._dp_cols(R)
         ids = torch.full((B_pad, id_cols), -1, dtype=torch.int64, device=self.dev)
         vals = torch.zeros((B_pad, val_cols), dtype=torch.float32, device=self.dev)
@@ -1362,6 +1384,7 @@ class DeepCoNNPPEngine(NarreEngine):
     MODEL_TYPE = 'deepconn++'
     C = 'deepconnpp'
     DP_COLS = 1
+    BLOCKS_DP = False            # (two bias vectors: the generic per-rating payload)
 
     def __init__(self, model, dp=None, **kw):
         super().__init__(model, dp=dp, **kw)

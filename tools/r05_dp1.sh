@@ -18,6 +18,9 @@ for rep in 1 2; do
   ARGS="--workload cfg5_transnetpp_synthetic"
   python $R/bench.py --no-cpu-baseline --no-config-legs $ARGS 2>/dev/null | line "cfg5 single process (6 launches)"
   dp1 env | line "cfg5 dp1: one block, one all_gather, update over the blocks"
+  ARGS="--workload cfg4_narre_kindle"
+  python $R/bench.py --no-cpu-baseline --no-config-legs $ARGS 2>/dev/null | line "cfg4 single process (5 launches)"
+  dp1 env | line "cfg4 dp1: one block, one all_gather, entry waves + sweep over the blocks"
   ARGS=""
   python $R/bench.py --no-cpu-baseline --no-config-legs $ARGS 2>/dev/null | line "cfg3 single process (5 launches)"
   dp1 env | line "cfg3 dp1 (exchange autotuned)"
