@@ -314,9 +314,6 @@ __global__ __launch_bounds__(WG_THREADS, ML > 16 ? 2 : (ML == 0 && WIDE ? 8 : 4)
     const int z = (int)blockIdx.z - (ML > 0 ? 1 : 0);
     if (z < 0) {
         if constexpr (ML > 0) {
-#ifdef R4R_ABL_NOROWS
-            return;
-#endif
             __shared__ int rows_sid[NROW_MAX_ENTRIES];
             // entry workgroups first (the owner of a popular row is the longest), then the sweep
             const int ne = row_blocks - rows.cb_entries;
@@ -326,11 +323,6 @@ __global__ __launch_bounds__(WG_THREADS, ML > 16 ? 2 : (ML == 0 && WIDE ? 8 : 4)
             }
         }
     } else if (z < ntower) {
-#ifdef R4R_ABL_NOWGRAD
-        if (ML > 0) return;
-#endif
-#ifdef R4R_ABL_NOROWS
-#endif
         if constexpr (WIDE) wgrad_block(w, blockIdx.x, blockIdx.y, z);
         else if (packed) wgrad_block_packed(w, blockIdx.x, blockIdx.y, z);   // grid.x = ceil(F / 4)
         else wgrad_block(w, blockIdx.x, blockIdx.y, z);
