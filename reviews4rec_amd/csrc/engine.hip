@@ -83,6 +83,9 @@ constexpr int HEAD_MAX_TILES = 8;
 // deterministic); wave 0 alone runs the FM's cross-lane sums; the backward to g_pooled is one output per thread.
 // (A four-ratings-per-workgroup form put a batch of 128 on 32 CUs of 256: 11 us against 8; removed in round 5.)
 // ML: compile-time cap of the latent size (LDS arrays, register arrays and unrolled staging loops are sized by it).
+// (a pointer array of the kernel arguments indexed by a run-time tower makes every lane FETCH the pointer from the
+// argument segment, a round trip in front of the access it serves: select between the constant-index elements instead)
+#define SEL2(arr, s) ((s) ? (arr)[1] : (arr)[0])
 HEAD_TRACE_DEFINE(r4r_debug_dc_head_trace)
 template <int ML>
 __global__ __launch_bounds__(256) void deepconn_head_wg_kernel(HeadArgs a) {
@@ -111,10 +114,10 @@ __global__ __launch_bounds__(256) void deepconn_head_wg_kernel(HeadArgs a) {
         if (256 * k < wtot) {                               // uniform
             const int i = min(tid + 256 * k, wtot - 1);
             const int t = i >= L * FQ;
-            wreg[k] = *reinterpret_cast<const hq4 *>(a.fc_w[t] + 4 * (i - t * L * FQ));
+            wreg[k] = *reinterpret_cast<const hq4 *>(SEL2(a.fc_w, t) + 4 * (i - t * L * FQ));
         }
     }
-    const float fbreg = (tid < n) ? a.fc_b[tid / L][tid % L] : 0.f;
+    const float fbreg = (tid < n) ? SEL2(a.fc_b, tid / L)[tid % L] : 0.f;
     const float lwreg = (tid < n) ? a.lin_w[tid] : 0.f;
     constexpr int VREGS = (N2 * FM_K + 255) / 256;
     float vreg[VREGS];
@@ -132,8 +135,8 @@ __global__ __launch_bounds__(256) void deepconn_head_wg_kernel(HeadArgs a) {
 #pragma unroll
             for (int k = 0; k < HEAD_MAX_TILES; ++k) {
                 const size_t o = ((size_t)b * a.tiles + min(k, a.tiles - 1)) * NP + fc;
-                v[k] = a.pmax[t][o];
-                pp[k] = a.parg[t][o];
+                v[k] = SEL2(a.pmax, t)[o];
+                pp[k] = SEL2(a.parg, t)[o];
             }
 #pragma unroll
             for (int k = 0; k < HEAD_MAX_TILES; ++k)           // a clamped duplicate never wins (strict >)
@@ -146,8 +149,8 @@ __global__ __launch_bounds__(256) void deepconn_head_wg_kernel(HeadArgs a) {
                 for (int k = 0; k < HEAD_MAX_TILES; ++k) {
                     const bool in = k0 + k < a.tiles;
                     const size_t o = ((size_t)b * a.tiles + (in ? k0 + k : 0)) * NP + fc;
-                    v[k] = in ? a.pmax[t][o] : -INFINITY;
-                    pp[k] = a.parg[t][o];
+                    v[k] = in ? SEL2(a.pmax, t)[o] : -INFINITY;
+                    pp[k] = SEL2(a.parg, t)[o];
                 }
 #pragma unroll
                 for (int k = 0; k < HEAD_MAX_TILES; ++k)
@@ -157,8 +160,8 @@ __global__ __launch_bounds__(256) void deepconn_head_wg_kernel(HeadArgs a) {
         if (!(best > 0.f)) { best = 0.f; bp = -1; }
         if (f < F_CONV) {
             sp[t][f] = best;
-            a.pooled[t][b * F_CONV + f] = best;
-            a.argmax[t][b * F_CONV + f] = bp;
+            SEL2(a.pooled, t)[b * F_CONV + f] = best;
+            SEL2(a.argmax, t)[b * F_CONV + f] = bp;
         }
     }
     HEAD_STAMP(1)
@@ -276,7 +279,7 @@ __global__ __launch_bounds__(256) void deepconn_head_wg_kernel(HeadArgs a) {
         const int t = tid >= F_CONV, f = tid - t * F_CONV;
         float acc = 0.f;
         for (int l = 0; l < L; ++l) acc = fmaf(sz[t * L + l], sw[t][l][f], acc);
-        a.g_pooled[t][b * F_CONV + f] = acc;
+        SEL2(a.g_pooled, t)[b * F_CONV + f] = acc;
     }
     HEAD_STAMP(4)
 }

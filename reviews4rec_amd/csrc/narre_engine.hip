@@ -95,6 +95,11 @@ __device__ __forceinline__ int head_col(const NarreHead &a, int flat_off) {
 // The kernel is bound by vector-ALU issue (index arithmetic around ~2000-element loops), with one
 // workgroup per CU on half the CUs -- so more waves per rating, not fewer instructions per
 // memory access, is what shortens it.
+// A pointer array of the kernel arguments indexed by a run-time side makes every lane FETCH the pointer from the
+// argument segment -- a memory round trip in front of the access it serves (and, the loads returning in order, behind
+// everything requested before it).  Selecting between the two constant-index elements is two scalar registers and a
+// v_cndmask.
+#define SEL2(arr, s) ((s) ? (arr)[1] : (arr)[0])
 HEAD_TRACE_DEFINE(r4r_debug_narre_head_trace)
 BWD_TRACE_DEFINE(r4r_debug_narre_bwd_trace)
 template <int MR, int ML, int NT>
@@ -153,6 +158,24 @@ __global__ __launch_bounds__(NT) void narre_head_kernel(NarreHead a) {
     float av[AREG];
     hi4 pa[PREG];
     const bool one_tile = a.tiles == 1;
+    // The ids go out FIRST: the ID vectors need them (a second, dependent round trip), and loads return in order -- with
+    // the ids the oldest requests, waiting for them does not wait for the big reads behind them, and the second round
+    // trip runs under the first.
+    constexpr int FREG = (ML * ML + NT - 1) / NT, OREG = (2 * MR * ML + NT - 1) / NT;
+    float f1v[FREG], ov[OREG];
+    int64_t oid[OREG];
+#pragma unroll
+    for (int u = 0; u < OREG; ++u) {
+        oid[u] = 0;
+        if (NT * u < 2 * RL) {
+            const int i = min(tid + NT * u, 2 * RL - 1);
+            const int s = i >= RL, rem = i - s * RL, r = qd(rem, invL);
+            oid[u] = SEL2(a.other_id, s)[b * R + r];
+        }
+    }
+    const int ti = min(tid, L2 - 1), ts = ti >= L, tl = ti - ts * L;          // this thread's (side, l) for the [2][L] vectors
+    const int64_t sid_r = SEL2(a.self_id, ts)[b];
+    const int64_t sid0 = a.self_id[0][b], sid1 = a.self_id[1][b];
 #pragma unroll
     for (int u = 0; u < PREG; ++u) {
         pv[u] = (hq4){0.f, 0.f, 0.f, 0.f}; pa[u] = (hi4){0, 0, 0, 0};
@@ -160,8 +183,8 @@ __global__ __launch_bounds__(NT) void narre_head_kernel(NarreHead a) {
             const int i = min(tid + NT * u, 2 * R * NQ4 - 1);
             const int s = i >= R * NQ4, rem = i - s * R * NQ4, rr = rem / NQ4, q4 = rem - rr * NQ4;
             const size_t q = ((size_t)(b * R + rr) * a.tiles) * NP + 4 * q4;
-            pv[u] = *reinterpret_cast<const hq4 *>(a.pmax[s] + q);
-            pa[u] = *reinterpret_cast<const hi4 *>(a.parg[s] + q);
+            pv[u] = *reinterpret_cast<const hq4 *>(SEL2(a.pmax, s) + q);
+            pa[u] = *reinterpret_cast<const hi4 *>(SEL2(a.parg, s) + q);
         }
     }
 #pragma unroll
@@ -170,7 +193,7 @@ __global__ __launch_bounds__(NT) void narre_head_kernel(NarreHead a) {
         if (NT * u < 2 * L * NQ4) {
             const int i = min(tid + NT * u, 2 * L * NQ4 - 1);
             const int s = i >= L * NQ4;
-            wv[u] = *reinterpret_cast<const hq4 *>(fp + a.off[s ? NP_IFW : NP_UFW] + 4 * (i - s * L * NQ4));
+            wv[u] = *reinterpret_cast<const hq4 *>(fp + (s ? a.off[NP_IFW] : a.off[NP_UFW]) + 4 * (i - s * L * NQ4));
         }
     }
 #pragma unroll
@@ -179,31 +202,16 @@ __global__ __launch_bounds__(NT) void narre_head_kernel(NarreHead a) {
         if (NT * u < 2 * L * L2) {
             const int i = min(tid + NT * u, 2 * L * L2 - 1);
             const int s = i >= L * L2;
-            av[u] = fp[a.off[s ? NP_AIW0 : NP_AUW0] + i - s * L * L2];
+            av[u] = fp[(s ? a.off[NP_AIW0] : a.off[NP_AUW0]) + i - s * L * L2];
         }
     }
-    // the small reads ride in the same round trip; the ID vectors need their ids first (round 2)
-    constexpr int FREG = (ML * ML + NT - 1) / NT, OREG = (2 * MR * ML + NT - 1) / NT;
-    float f1v[FREG], ov[OREG];
-    int64_t oid[OREG];
+    // the small reads ride in the same round trip
 #pragma unroll
     for (int u = 0; u < FREG; ++u) f1v[u] = (NT * u < L * L) ? fp[a.off[NP_F1W] + min(tid + NT * u, L * L - 1)] : 0.f;
-#pragma unroll
-    for (int u = 0; u < OREG; ++u) {
-        oid[u] = 0;
-        if (NT * u < 2 * RL) {
-            const int i = min(tid + NT * u, 2 * RL - 1);
-            const int s = i >= RL, rem = i - s * RL, r = qd(rem, invL);
-            oid[u] = a.other_id[s][b * R + r];
-        }
-    }
-    const int ti = min(tid, L2 - 1), ts = ti >= L, tl = ti - ts * L;          // this thread's (side, l) for the [2][L] vectors
-    const float fcb_r = fp[a.off[ts ? NP_IFB : NP_UFB] + tl], b0_r = fp[a.off[ts ? NP_AIB0 : NP_AUB0] + tl],
-                w3_r = fp[a.off[ts ? NP_AIW3 : NP_AUW3] + tl];
-    const int64_t sid_r = a.self_id[ts][b];
+    const float fcb_r = fp[(ts ? a.off[NP_IFB] : a.off[NP_UFB]) + tl], b0_r = fp[(ts ? a.off[NP_AIB0] : a.off[NP_AUB0]) + tl],
+                w3_r = fp[(ts ? a.off[NP_AIW3] : a.off[NP_AUW3]) + tl];
     const float f1b_r = fp[a.off[NP_F1B] + min(tid, L - 1)], f3w_r = fp[a.off[NP_F3W] + min(tid, L - 1)];
     const float m0 = fp[a.off[NP_AUB3]], m1 = fp[a.off[NP_AIB3]], m2 = fp[a.off[NP_F3B]], m3 = fp[a.off[NP_GB]];
-    const int64_t sid0 = a.self_id[0][b], sid1 = a.self_id[1][b];
     // round 2: the reads that depend on ids
 #pragma unroll
     for (int u = 0; u < OREG; ++u) {
@@ -211,10 +219,10 @@ __global__ __launch_bounds__(NT) void narre_head_kernel(NarreHead a) {
         if (NT * u < 2 * RL) {
             const int i = min(tid + NT * u, 2 * RL - 1);
             const int s = i >= RL, rem = i - s * RL, r = qd(rem, invL), l = rem - r * L;
-            ov[u] = a.emb[1 - s][oid[u] * L + l];
+            ov[u] = SEL2(a.emb, 1 - s)[oid[u] * L + l];
         }
     }
-    const float ev_r = a.emb[ts][sid_r * L + tl];
+    const float ev_r = SEL2(a.emb, ts)[sid_r * L + tl];
     const float ub_r = a.bias[0][sid0], ib_r = a.bias[1][sid1];
 #pragma unroll
     for (int u = 0; u < WREG; ++u) {
@@ -258,8 +266,8 @@ __global__ __launch_bounds__(NT) void narre_head_kernel(NarreHead a) {
                 for (int c = 0; c < 4; ++c)
                     if (!(best[c] > 0.f)) { best[c] = 0.f; bp[c] = -1; }
                 *reinterpret_cast<hq4 *>(P + (s * R + rr) * NF + 4 * q4) = best;
-                *reinterpret_cast<hq4 *>(a.pooled[s] + n * NF + 4 * q4) = best;
-                *reinterpret_cast<hi4 *>(a.argmax[s] + n * NF + 4 * q4) = bp;
+                *reinterpret_cast<hq4 *>(SEL2(a.pooled, s) + n * NF + 4 * q4) = best;
+                *reinterpret_cast<hi4 *>(SEL2(a.argmax, s) + n * NF + 4 * q4) = bp;
             }
         }
     } else {
@@ -270,13 +278,13 @@ __global__ __launch_bounds__(NT) void narre_head_kernel(NarreHead a) {
             int bp = -1;
             for (int k = 0; k < a.tiles; ++k) {
                 const size_t q = ((size_t)n * a.tiles + k) * NP + f;
-                const float val = a.pmax[s][q];
-                if (val > best) { best = val; bp = a.parg[s][q]; }
+                const float val = SEL2(a.pmax, s)[q];
+                if (val > best) { best = val; bp = SEL2(a.parg, s)[q]; }
             }
             if (!(best > 0.f)) { best = 0.f; bp = -1; }
             P[i] = best;
-            a.pooled[s][n * NF + f] = best;
-            a.argmax[s][n * NF + f] = bp;
+            SEL2(a.pooled, s)[n * NF + f] = best;
+            SEL2(a.argmax, s)[n * NF + f] = bp;
         }
     }
     __syncthreads();
@@ -394,16 +402,16 @@ __global__ __launch_bounds__(NT) void narre_head_kernel(NarreHead a) {
         prow[head_col(a, a.off[NP_GB])] = g;
         // ids + tags of the self rows: user table entry b <- uid, item table entry b <- iid
         for (int s = 0; s < 2; ++s) {
-            const int64_t id = a.self_id[s][b];
-            a.gid[s][b] = id;
-            a.tag[s][id] = a.now;
+            const int64_t id = SEL2(a.self_id, s)[b];
+            SEL2(a.gid, s)[b] = id;
+            SEL2(a.tag, s)[id] = a.now;
         }
     }
     for (int i = tid; i < 2 * R; i += NT) {                // others: side s's ids index table 1-s
         const int s = i >= R, r = i - s * R;
-        const int64_t id = a.other_id[s][b * R + r];
-        a.gid[1 - s][nself + b * R + r] = id;
-        a.tag[1 - s][id] = a.now;
+        const int64_t id = SEL2(a.other_id, s)[b * R + r];
+        SEL2(a.gid, 1 - s)[nself + b * R + r] = id;
+        SEL2(a.tag, 1 - s)[id] = a.now;
     }
     __syncthreads();
     HEAD_STAMP(10)
@@ -421,7 +429,7 @@ __global__ __launch_bounds__(NT) void narre_head_kernel(NarreHead a) {
     // ---- B3: self ID rows (compact), d attention weights
     for (int i = tid; i < L2; i += NT) {
         const int s = i >= L, l = i - s * L;
-        a.grow[s][(size_t)b * L + l] = dv[i] * evm[i];
+        SEL2(a.grow, s)[(size_t)b * L + l] = dv[i] * evm[i];
     }
     for (int i = tid; i < 2 * R; i += NT) {
         const int s = i >= R;
@@ -444,13 +452,13 @@ __global__ __launch_bounds__(NT) void narre_head_kernel(NarreHead a) {
     if (tid < 2) {
         float acc = 0.f;
         for (int r = 0; r < R; ++r) acc += da[tid * R + r];
-        prow[head_col(a, a.off[tid ? NP_AIB3 : NP_AUB3])] = acc;
+        prow[head_col(a, (tid ? a.off[NP_AIB3] : a.off[NP_AUB3]))] = acc;
     }
     for (int i = tid; i < L2; i += NT) {
         const int s = i >= L, k = i - s * L;
         float acc = 0.f;
         for (int r = 0; r < R; ++r) acc = fmaf(da[s * R + r], h[(s * R + r) * L + k] * hm[(s * R + r) * L + k], acc);
-        prow[head_col(a, a.off[s ? NP_AIW3 : NP_AUW3] + k)] = acc;
+        prow[head_col(a, (s ? a.off[NP_AIW3] : a.off[NP_AUW3]) + k)] = acc;
     }
     for (int i = tid; i < 2 * RL; i += NT) {
         const int s = i >= RL, rem = i - s * RL, r = qd(rem, invL), k = rem - r * L;
@@ -463,7 +471,7 @@ __global__ __launch_bounds__(NT) void narre_head_kernel(NarreHead a) {
         const int s = i >= L, k = i - s * L;
         float acc = 0.f;
         for (int r = 0; r < R; ++r) acc += dz[(s * R + r) * L + k];
-        prow[head_col(a, a.off[s ? NP_AIB0 : NP_AUB0] + k)] = acc;
+        prow[head_col(a, (s ? a.off[NP_AIB0] : a.off[NP_AUB0]) + k)] = acc;
     }
     for (int i = tid; i < 2 * L * L2; i += NT) {
         const int s = i >= L * L2, rem = i - s * L * L2, k = qd(rem, invL2), j = rem - k * L2;
@@ -472,7 +480,7 @@ __global__ __launch_bounds__(NT) void narre_head_kernel(NarreHead a) {
             const float c = j < L ? x[(s * R + r) * L + j] : o[(s * R + r) * L + j - L];
             acc = fmaf(dz[(s * R + r) * L + k], c, acc);
         }
-        prow[head_col(a, a.off[s ? NP_AIW0 : NP_AUW0] + k * L2 + j)] = acc;
+        prow[head_col(a, (s ? a.off[NP_AIW0] : a.off[NP_AUW0]) + k * L2 + j)] = acc;
     }
     float dzv[(2 * MR * ML + NT - 1) / NT];        // d z of this thread's elements (kept over the barrier)
 #pragma unroll
@@ -488,7 +496,7 @@ __global__ __launch_bounds__(NT) void narre_head_kernel(NarreHead a) {
                 ao = fmaf(d, W0[(s * L + k) * (L2 + 1) + L + j], ao);
             }
             dzv[it] = ax * xm[i];
-            a.grow[1 - s][(size_t)(nself + b * R + r) * L + j] = ao;
+            SEL2(a.grow, 1 - s)[(size_t)(nself + b * R + r) * L + j] = ao;
         }
     }
     __syncthreads();
@@ -505,7 +513,7 @@ __global__ __launch_bounds__(NT) void narre_head_kernel(NarreHead a) {
         const int s = i >= L, l = i - s * L;
         float acc = 0.f;
         for (int r = 0; r < R; ++r) acc += dz[(s * R + r) * L + l];
-        prow[head_col(a, a.off[s ? NP_IFB : NP_UFB] + l)] = acc;
+        prow[head_col(a, (s ? a.off[NP_IFB] : a.off[NP_UFB]) + l)] = acc;
     }
     // Four consecutive filters per thread (NF / 4 = 25 quads): one dz read serves four products, the pooled features come
     // as one 16-byte LDS read, the results leave as one 16-byte store -- 2 (L + R) x 25 items, one pass of the 512 threads
@@ -523,7 +531,7 @@ __global__ __launch_bounds__(NT) void narre_head_kernel(NarreHead a) {
 #pragma unroll
             for (int c = 0; c < 4; ++c) acc[c] = fmaf(d, p4[c], acc[c]);
         }
-        *reinterpret_cast<hf4 *>(prow + head_col(a, a.off[s ? NP_IFW : NP_UFW] + l * NF + 4 * q)) = acc;
+        *reinterpret_cast<hf4 *>(prow + head_col(a, (s ? a.off[NP_IFW] : a.off[NP_UFW]) + l * NF + 4 * q)) = acc;
     }
     for (int i = tid; i < 2 * R * NQ; i += NT) {
         const int s = i >= R * NQ, rem = i - s * R * NQ, r = rem / NQ, q = rem - r * NQ;
@@ -535,7 +543,7 @@ __global__ __launch_bounds__(NT) void narre_head_kernel(NarreHead a) {
 #pragma unroll
             for (int c = 0; c < 4; ++c) acc[c] = fmaf(d, wr[c], acc[c]);
         }
-        *reinterpret_cast<hf4 *>(a.g_pooled[s] + (b * R + r) * NF + 4 * q) = acc;
+        *reinterpret_cast<hf4 *>(SEL2(a.g_pooled, s) + (b * R + r) * NF + 4 * q) = acc;
     }
     HEAD_STAMP(17)
 }

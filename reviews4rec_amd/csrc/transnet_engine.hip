@@ -70,6 +70,10 @@ struct TnHead {
 HEAD_TRACE_DEFINE(r4r_debug_tn_head_trace)
 BWD_TRACE_DEFINE(r4r_debug_tn_bwd_trace)
 // One workgroup of 256 threads per rating.
+// (a pointer array of the kernel arguments indexed by a run-time tower / side makes every lane FETCH the pointer from
+// the argument segment, a round trip in front of the access it serves: select between the constant-index elements)
+#define SEL2(arr, s) ((s) ? (arr)[1] : (arr)[0])
+#define SEL3(arr, s) ((s) == 0 ? (arr)[0] : ((s) == 1 ? (arr)[1] : (arr)[2]))
 template <int ML>
 __global__ __launch_bounds__(256) void tn_head_kernel(TnHead a) {
     HEAD_STAMP(0)
@@ -114,7 +118,7 @@ __global__ __launch_bounds__(256) void tn_head_kernel(TnHead a) {
     const int wtot = L * NQ4;
 #pragma unroll
     for (int s = 0; s < 3; ++s) {
-        const float *src = fp + a.off[s == 0 ? TN_UFW : (s == 1 ? TN_IFW : TN_TFW)];
+        const float *src = fp + (s == 0 ? a.off[TN_UFW] : (s == 1 ? a.off[TN_IFW] : a.off[TN_TFW]));
 #pragma unroll
         for (int u = 0; u < WREG; ++u)
             wreg[s][u] = 256 * u < wtot ? *reinterpret_cast<const hq4 *>(src + 4 * min(tid + 256 * u, wtot - 1)) : (hq4){0.f, 0.f, 0.f, 0.f};
@@ -130,16 +134,16 @@ __global__ __launch_bounds__(256) void tn_head_kernel(TnHead a) {
     const float lws_r = fp[a.off[TN_SLW] + min(tid, ns - 1)];
     const int tl = min(tid, L - 1), t3 = min(tid, L3 - 1), s3 = t3 / L;
     const float lwt_r = fp[a.off[TN_TLW] + tl], b0_r = fp[a.off[TN_P0B] + tl], b2_r = fp[a.off[TN_P2B] + tl];
-    const float fcb_r = fp[a.off[s3 == 0 ? TN_UFB : (s3 == 1 ? TN_IFB : TN_TFB)] + (t3 - s3 * L)];
+    const float fcb_r = fp[(s3 == 0 ? a.off[TN_UFB] : (s3 == 1 ? a.off[TN_IFB] : a.off[TN_TFB])) + (t3 - s3 * L)];
     const float m0 = fp[a.off[TN_SLB]], m1 = fp[a.off[TN_TLB]];
     const bool idt = a.plus && tid >= 64 && tid < 64 + 2 * TN_ID;
     float idv = 0.f;
     if (idt) {
         const int k = tid - 64, s = k >= TN_ID, c = k - s * TN_ID;
-        const int64_t r = a.id[s][b], e = r * TN_ID + c;
-        idv = a.emb[s][e];
+        const int64_t r = SEL2(a.id, s)[b], e = r * TN_ID + c;
+        idv = SEL2(a.emb, s)[e];
         if (a.tb.rlast_u) {                                 // the element's pending gradient-zero updates (not written back)
-            float mq = a.embm[s][e], vq = a.embv[s][e];
+            float mq = SEL2(a.embm, s)[e], vq = SEL2(a.embv, s)[e];
             const int cur = tb_current(a.tb, s ? a.tb.rlast_i : a.tb.rlast_u, e, r, a.now);
 #pragma unroll
             for (int j = 0; j < MF_TB_MAX - 1; ++j) {       // steps now - 7 .. now - 1
@@ -162,8 +166,8 @@ __global__ __launch_bounds__(256) void tn_head_kernel(TnHead a) {
             for (int k = 0; k < PT; ++k) {
                 const bool in = k0 + k < a.tiles;
                 const size_t q = ((size_t)b * a.tiles + (in ? k0 + k : 0)) * NP + f;
-                v[k] = in ? a.pmax[s][q] : -INFINITY;
-                pp[k] = a.parg[s][q];
+                v[k] = in ? SEL3(a.pmax, s)[q] : -INFINITY;
+                pp[k] = SEL3(a.parg, s)[q];
             }
 #pragma unroll
             for (int k = 0; k < PT; ++k)
@@ -171,8 +175,8 @@ __global__ __launch_bounds__(256) void tn_head_kernel(TnHead a) {
         }
         if (!(best > 0.f)) { best = 0.f; bp = -1; }
         P[s][f] = best;
-        a.pooled[s][b * NF + f] = best;
-        a.argmax[s][b * NF + f] = bp;
+        SEL3(a.pooled, s)[b * NF + f] = best;
+        SEL3(a.argmax, s)[b * NF + f] = bp;
     }
 #pragma unroll
     for (int s = 0; s < 3; ++s)
@@ -319,10 +323,10 @@ __global__ __launch_bounds__(256) void tn_head_kernel(TnHead a) {
         a.pred[b] = out_s;
         if (a.want_grad && a.plus) {
             for (int s = 0; s < 2; ++s) {
-                const int64_t r = a.id[s][b];
-                a.tag[s][r] = a.now;
-                a.ctag[s][r * TN_ID / MF_CHUNK] = a.now;              // (a row can straddle two chunks)
-                a.ctag[s][(r * TN_ID + TN_ID - 1) / MF_CHUNK] = a.now;
+                const int64_t r = SEL2(a.id, s)[b];
+                SEL2(a.tag, s)[r] = a.now;
+                SEL2(a.ctag, s)[r * TN_ID / MF_CHUNK] = a.now;              // (a row can straddle two chunks)
+                SEL2(a.ctag, s)[(r * TN_ID + TN_ID - 1) / MF_CHUNK] = a.now;
             }
         }
     }
@@ -344,7 +348,7 @@ __global__ __launch_bounds__(256) void tn_head_kernel(TnHead a) {
     if (tid == 0) { prow[col(a.off[TN_SLB])] = g_s; prow[col(a.off[TN_TLB])] = g_t; }
     if (a.plus && tid >= 64 && tid < 64 + 2 * TN_ID) {
         const int k = tid - 64, s = k >= TN_ID, c = k - s * TN_ID;
-        a.grow[s][b * TN_ID + c] = g_s * dfs[k] * finm[k];
+        SEL2(a.grow, s)[b * TN_ID + c] = g_s * dfs[k] * finm[k];
     }
     if (tid >= 128 && tid < 128 + L) {
         const int l = tid - 128;
@@ -377,10 +381,10 @@ __global__ __launch_bounds__(256) void tn_head_kernel(TnHead a) {
     // ---- B4: the towers' FC gradients, d pooled
     if (tid < L3) {
         const int s = tid / L;
-        prow[col(a.off[s == 0 ? TN_UFB : (s == 1 ? TN_IFB : TN_TFB)] + (tid - s * L))] = dz[tid];
+        prow[col((s == 0 ? a.off[TN_UFB] : (s == 1 ? a.off[TN_IFB] : a.off[TN_TFB])) + (tid - s * L))] = dz[tid];
     }
     for (int s = 0; s < 3; ++s) {                           // (filter quads: 16-byte reads of the pooled features, 16-byte stores)
-        float *dst = prow + col(a.off[s == 0 ? TN_UFW : (s == 1 ? TN_IFW : TN_TFW)]);
+        float *dst = prow + col((s == 0 ? a.off[TN_UFW] : (s == 1 ? a.off[TN_IFW] : a.off[TN_TFW])));
         for (int r = tid; r < L * NQ4; r += 256) {
             const int l = r / NQ4, q = r - l * NQ4;
             const hq4 p4 = *reinterpret_cast<const hq4 *>(&P[s][4 * q]);
@@ -391,7 +395,7 @@ __global__ __launch_bounds__(256) void tn_head_kernel(TnHead a) {
         const int s = i / NF, f = i - s * NF;
         float acc = 0.f;
         for (int l = 0; l < L; ++l) acc = fmaf(dz[s * L + l], fcw[s][l][f], acc);
-        a.g_pooled[s][b * NF + f] = acc;
+        SEL3(a.g_pooled, s)[b * NF + f] = acc;
     }
     HEAD_STAMP(9)
 }
