@@ -110,15 +110,15 @@ __global__ __launch_bounds__(256) void deepconn_head_wg_kernel(HeadArgs a) {
     const int wtot = 2 * L * FQ;
 #pragma unroll
     for (int k = 0; k < WREGS; ++k) {
-        wreg[k] = (hq4){0.f, 0.f, 0.f, 0.f};
-        if (256 * k < wtot) {                               // uniform
-            const int i = min(tid + 256 * k, wtot - 1);
-            const int t = i >= L * FQ;
-            wreg[k] = *reinterpret_cast<const hq4 *>(SEL2(a.fc_w, t) + 4 * (i - t * L * FQ));
-        }
+        // (unconditional, clamped: behind a uniform `if (256 k < wtot)` hipcc put a branch and a full vmcnt(0) around every
+        // one of these loads -- four dependent round trips in front of the launch's first barrier)
+        const int i = min(tid + 256 * k, wtot - 1);
+        const int t = i >= L * FQ;
+        wreg[k] = *reinterpret_cast<const hq4 *>(SEL2(a.fc_w, t) + 4 * (i - t * L * FQ));
     }
-    const float fbreg = (tid < n) ? SEL2(a.fc_b, tid / L)[tid % L] : 0.f;
-    const float lwreg = (tid < n) ? a.lin_w[tid] : 0.f;
+    const int tn = min(tid, n - 1);
+    const float fbreg = SEL2(a.fc_b, tn >= L)[tn - (tn >= L ? L : 0)];
+    const float lwreg = a.lin_w[tn];
     constexpr int VREGS = (N2 * FM_K + 255) / 256;
     float vreg[VREGS];
 #pragma unroll

@@ -1290,7 +1290,8 @@ __global__ __launch_bounds__(256) void proj_gather_max_kernel(ProjArgs a) {
         // requested together -- as a loop the second pass (two lanes) was two more dependent round trips
         const int ta = t_lo + wl, tb = t_lo + 32 + wl;        // (SLICE 16: 18 tokens, the second request is idle)
         const bool va = wl < ntok && ta >= 0 && ta < T, vb = 32 + wl < ntok && tb >= 0 && tb < T;
-        const int64_t ia = tw.idx[doc * T + (va ? ta : 0)], ib = tw.idx[doc * T + (vb ? tb : 0)];
+        int64_t ia = tw.idx[doc * T + (va ? ta : 0)], ib = tw.idx[doc * T + (vb ? tb : 0)];
+        asm volatile("" : "+v"(ia), "+v"(ib));                // (both ids requested before either slot: hipcc had ordered id a, slot a, id b, slot b -- three round trips)
         const int sa = tw.slot[ia], sb = tw.slot[ib];
         if (wl < ntok) sl[worker][wl] = va ? sa : -1;
         if (32 + wl < ntok) sl[worker][32 + wl] = vb ? sb : -1;

@@ -116,12 +116,32 @@ __global__ __launch_bounds__(256) void tn_head_kernel(TnHead a) {
     hq4 wreg[3][WREG];
     float av[AREG], f2v[FREG], vsv[SREG], vtv[TREG];
     const int wtot = L * NQ4;
+    // What later reads depend on goes out FIRST (loads return in order: waiting for the oldest requests does not wait for
+    // the weights behind them): the rating's ids -- the ID vectors need them, a second round trip that now runs under
+    // the first -- and the pool partials of this thread's (tower, filter) items, first PT tiles each (as a loop behind
+    // the weights' LDS writes they were a third round trip).
+    const bool idt = a.plus && tid >= 64 && tid < 64 + 2 * TN_ID;
+    int64_t id_r = 0;
+    if (idt) id_r = SEL2(a.id, (tid - 64) >= TN_ID)[b];
+    constexpr int PITEMS = (3 * NF + 255) / 256;            // (tower, filter) items per thread: 2
+    float pv0[PITEMS][PT];
+    int pp0[PITEMS][PT];
+#pragma unroll
+    for (int it = 0; it < PITEMS; ++it) {
+        const int i = min(tid + 256 * it, 3 * NF - 1), s = i / NF, f = i - s * NF;
+#pragma unroll
+        for (int k = 0; k < PT; ++k) {
+            const size_t q = ((size_t)b * a.tiles + min(k, a.tiles - 1)) * NP + f;   // (a clamped duplicate never wins: strict >)
+            pv0[it][k] = SEL3(a.pmax, s)[q];
+            pp0[it][k] = SEL3(a.parg, s)[q];
+        }
+    }
 #pragma unroll
     for (int s = 0; s < 3; ++s) {
         const float *src = fp + (s == 0 ? a.off[TN_UFW] : (s == 1 ? a.off[TN_IFW] : a.off[TN_TFW]));
 #pragma unroll
         for (int u = 0; u < WREG; ++u)
-            wreg[s][u] = 256 * u < wtot ? *reinterpret_cast<const hq4 *>(src + 4 * min(tid + 256 * u, wtot - 1)) : (hq4){0.f, 0.f, 0.f, 0.f};
+            wreg[s][u] = *reinterpret_cast<const hq4 *>(src + 4 * min(tid + 256 * u, wtot - 1));   // (clamped: rounds past the end re-read the last quad, unused)
     }
 #pragma unroll
     for (int u = 0; u < AREG; ++u) av[u] = 256 * u < L * L2 ? fp[a.off[TN_P0W] + min(tid + 256 * u, L * L2 - 1)] : 0.f;
@@ -136,11 +156,10 @@ __global__ __launch_bounds__(256) void tn_head_kernel(TnHead a) {
     const float lwt_r = fp[a.off[TN_TLW] + tl], b0_r = fp[a.off[TN_P0B] + tl], b2_r = fp[a.off[TN_P2B] + tl];
     const float fcb_r = fp[(s3 == 0 ? a.off[TN_UFB] : (s3 == 1 ? a.off[TN_IFB] : a.off[TN_TFB])) + (t3 - s3 * L)];
     const float m0 = fp[a.off[TN_SLB]], m1 = fp[a.off[TN_TLB]];
-    const bool idt = a.plus && tid >= 64 && tid < 64 + 2 * TN_ID;
     float idv = 0.f;
     if (idt) {
         const int k = tid - 64, s = k >= TN_ID, c = k - s * TN_ID;
-        const int64_t r = SEL2(a.id, s)[b], e = r * TN_ID + c;
+        const int64_t r = id_r, e = r * TN_ID + c;
         idv = SEL2(a.emb, s)[e];
         if (a.tb.rlast_u) {                                 // the element's pending gradient-zero updates (not written back)
             float mq = SEL2(a.embm, s)[e], vq = SEL2(a.embv, s)[e];
@@ -155,11 +174,17 @@ __global__ __launch_bounds__(256) void tn_head_kernel(TnHead a) {
         }
     }
     // pool finish: thread i < 3 NF owns (tower, filter) i; threads 0 .. 3 NF - 257 a second one
-    for (int i = tid; i < 3 * NF; i += 256) {
+#pragma unroll
+    for (int it = 0; it < PITEMS; ++it) {
+        const int i = tid + 256 * it;
+        if (i >= 3 * NF) break;
         const int s = i / NF, f = i - s * NF;
         float best = -INFINITY;
         int bp = -1;
-        for (int k0 = 0; k0 < a.tiles; k0 += PT) {
+#pragma unroll
+        for (int k = 0; k < PT; ++k)
+            if (pv0[it][k] > best) { best = pv0[it][k]; bp = pp0[it][k]; }
+        for (int k0 = PT; k0 < a.tiles; k0 += PT) {          // documents of more than PT tiles: the rest, PT at a time
             float v[PT];
             int pp[PT];
 #pragma unroll
