@@ -395,6 +395,7 @@ extern "C" int r4r_deepconnpp_step(const float *table, int64_t V, const int64_t 
     }
     for (int k = 0; k < MAX_TOWERS; ++k) wa.t[k] = wt[k < 2 ? k : 0];
     wa.table = table; wa.N = B; wa.T = T; wa.E = E; wa.F = NF;
+    wa.table_bytes = (int64_t)V * E * 4;                   // (the wide wgrad reads the rows through a buffer resource)
     wa.nsplit = textcnn_wgrad_splits(B);
     wa.per_split = (int)cdiv(B, wa.nsplit);
     ColSum cs;

@@ -683,6 +683,7 @@ extern "C" int r4r_deepconn_step(const float *table, int64_t V, const int64_t *u
     }
     for (int k = 0; k < MAX_TOWERS; ++k) wa.t[k] = wt[k < 2 ? k : 0];
     wa.table = table; wa.N = B; wa.T = T; wa.E = E; wa.F = F_CONV;
+    wa.table_bytes = (int64_t)V * E * 4;                   // (the wide wgrad reads the rows through a buffer resource)
     wa.nsplit = textcnn_wgrad_splits(B);
     wa.per_split = (int)cdiv(B, wa.nsplit);
     // token state of the next batch (same B, T) into the OTHER token buffer, if asked for and

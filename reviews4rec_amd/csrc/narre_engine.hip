@@ -765,6 +765,7 @@ extern "C" int r4r_narre_step(const float *table, int64_t V,
     }
     for (int k = 0; k < MAX_TOWERS; ++k) wa.t[k] = wt[k < 2 ? k : 0];
     wa.table = table; wa.N = N; wa.T = T; wa.E = E; wa.F = NF;
+    wa.table_bytes = (int64_t)V * E * 4;                   // (the wide wgrad reads the rows through a buffer resource)
     wa.nsplit = textcnn_wgrad_splits(N);
     wa.per_split = (int)cdiv(N, wa.nsplit);
     ColSum cs;

@@ -14,9 +14,11 @@ struct WgradArgs {
     const float *table;
     int64_t N;
     int T, E, F, per_split, nsplit;
+    int64_t table_bytes = 0;           // bytes of `table` (0: unknown -- wgrad_block keeps its per-row loads)
 };
 
 constexpr int WG_CHUNK = 16;       // documents resolved per phase-1 round
+constexpr int WG_FLIGHT = 8;       // rows in flight per column slot (4 / 8 / 16, at 8 / 6 / 4 waves per SIMD: all within 1 % at cfg3)
 
 // One pass over the split's documents for the 2 x 256 float4 columns from v0 on of the [3][E] window (each thread owns
 // up to 2 of them).  FIRST: this pass also sums the bias gradient.
@@ -42,6 +44,15 @@ __device__ __forceinline__ void wgrad_block_pass(const WgradArgs &a, int f, int 
         ve[k] = v * 4 - vj[k] * E;
     }
     float sb = 0.f;
+    // The rows come through a buffer resource over the table: a slot without a contribution asks for an offset past the
+    // end, which the hardware answers with zeros WITHOUT a memory access -- so all 16 rows of a round are requested
+    // back to back with no branch between them (as `if (off >= 0) acc += g * row` hipcc had put a branch and a full
+    // vmcnt(0) around every single row: sixteen dependent round trips per round, the whole launch), and the skipped
+    // rows stay free (requesting them for real, as wgrad_block_packed does, cost +4 us at this width).
+    // (tables of 4 GB and more keep the per-row form: 32-bit buffer offsets)
+    const bool buf_ok = a.table_bytes > 0 && a.table_bytes < (1ll << 32);
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(table), 0, buf_ok ? (int)(unsigned)a.table_bytes : 0, 0x00020000);
+    typedef unsigned wg_u32x4 __attribute__((ext_vector_type(4)));
     for (int64_t c0 = n0; c0 < n1; c0 += WG_CHUNK) {
         const int nd = (int)min((int64_t)WG_CHUNK, n1 - c0);
         __syncthreads();
@@ -49,23 +60,47 @@ __device__ __forceinline__ void wgrad_block_pass(const WgradArgs &a, int f, int 
             const int d = tid / 3, j = tid - d * 3;
             const int64_t n = c0 + d;
             const int p = argmax[n * F + f];
+            const float gv = gp[n * F + f];                 // (with the argmax, not behind it)
             const int t = p - 2 + j;
             long off = -1;
             if (p >= 0 && t >= 0 && t < T) off = (long)idx[n * T + t] * E;
             s_off[d][j] = off;
-            if (j == 0) s_g[d] = (p >= 0) ? gp[n * F + f] : 0.f;
+            if (j == 0) s_g[d] = (p >= 0) ? gv : 0.f;
         }
         __syncthreads();
-        // (wide windows: 1.2 KB rows at E = 300.  Requesting all 16 rows of the round unconditionally, as
-        // wgrad_block_packed does, was measured SLOWER here -- +4 us on the cfg3 step: the skipped
-        // rows are real traffic at this width)
+        if (buf_ok) {
 #pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            if (v0 + tid + k * WG_THREADS < nvec) {
+            for (int k = 0; k < 2; ++k) {
+                if (v0 + tid + k * WG_THREADS < nvec) {
+#pragma unroll
+                    for (int d0 = 0; d0 < WG_CHUNK; d0 += WG_FLIGHT) {
+                        wg_f32x4 row[WG_FLIGHT];
+                        bool on[WG_FLIGHT];
+#pragma unroll
+                        for (int u = 0; u < WG_FLIGHT; ++u) {
+                            const int d = d0 + u;
+                            const long off = d < nd ? s_off[d][vj[k]] : -1;
+                            on[u] = off >= 0;
+                            const unsigned bo = on[u] ? (unsigned)((off + ve[k]) * 4) : 0xfffffff0u;
+                            row[u] = __builtin_bit_cast(wg_f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)bo, 0, 0));
+                        }
+#pragma unroll
+                        for (int u = 0; u < WG_FLIGHT; ++u) {  // document order, the same additions as the per-row form
+                            const wg_f32x4 sum = acc[k] + s_g[d0 + u < nd ? d0 + u : 0] * row[u];
+                            acc[k] = on[u] ? sum : acc[k];
+                        }
+                    }
+                }
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                if (v0 + tid + k * WG_THREADS < nvec) {
 #pragma unroll 4
-                for (int d = 0; d < nd; ++d) {
-                    const long off = s_off[d][vj[k]];
-                    if (off >= 0) acc[k] += s_g[d] * *reinterpret_cast<const wg_f32x4 *>(table + off + ve[k]);
+                    for (int d = 0; d < nd; ++d) {
+                        const long off = s_off[d][vj[k]];
+                        if (off >= 0) acc[k] += s_g[d] * *reinterpret_cast<const wg_f32x4 *>(table + off + ve[k]);
+                    }
                 }
             }
         }
