@@ -177,16 +177,22 @@ __device__ __forceinline__ void wgrad_block_packed(const WgradArgs &a, int fgrou
                 gv[k] = gp[n * F + f];
                 if (d >= nd) pv[k] = -1;
             }
-            long off[NRES];
+            long off[NRES], tokv[NRES];
+            bool onv[NRES];
 #pragma unroll
             for (int k = 0; k < NRES; ++k) {                // every token id: the next
                 const int i = lane + 64 * k, d = i / 3, j = i - d * 3;
                 const int64_t n = c0 + (d < nd ? d : 0);
                 const int t = pv[k] - 2 + j;
-                const bool on = pv[k] >= 0 && t >= 0 && t < T;
-                const long tok = idx[n * T + (on ? t : 0)];
-                off[k] = on ? tok * E : -1;
+                onv[k] = pv[k] >= 0 && t >= 0 && t < T;
+                tokv[k] = idx[n * T + (onv[k] ? t : 0)];
             }
+            // (all of them requested before the first is used: hipcc had sunk each load into the branch of its `on`, with a
+            // full vmcnt(0) behind it -- five dependent round trips per super-chunk instead of one)
+#pragma unroll
+            for (int k = 0; k < NRES; ++k) asm volatile("" : "+v"(tokv[k]));
+#pragma unroll
+            for (int k = 0; k < NRES; ++k) off[k] = onv[k] ? tokv[k] * E : -1;
 #pragma unroll
             for (int k = 0; k < NRES; ++k) {
                 const int i = lane + 64 * k, d = i / 3, j = i - d * 3;
