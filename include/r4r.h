@@ -482,6 +482,18 @@ int r4r_mf_apply_peer(const void *blocks, int world, int64_t B_pad, const uint64
                       const uint32_t *wait_flags, uint32_t epoch, uint32_t *timed_out, double timeout_s,
                       void *stream);
 
+/* ---- data parallel: the glue around the step's ONE all_gather of the ranks' compact entries (csrc/dp_pack.hip).
+ * A family's entries are `nfields` arrays of `widths[f]` 4-byte units per rating (int64 ids: 2; d loss / d pred: 1; a
+ * gradient row of an ID table: its width).  r4r_dp_pack copies this rank's n entries of every field into one block
+ * (r4r_dp_block_bytes; entries n .. B_pad - 1 are padding: all ones where pad_ones[f] -- an int64 id of -1 --, zero
+ * elsewhere); the caller all_gathers the blocks (rank order); r4r_dp_unpack writes field f of all ranks, rank-major,
+ * to dst[f] [world * B_pad, widths[f]]: the arrays the r4r_*_rows_apply launches take.  At most 8 fields. */
+size_t r4r_dp_block_bytes(int nfields, const int *widths, int64_t B_pad);
+int r4r_dp_pack(int nfields, const uint64_t *src, const int *widths, const int *pad_ones, int64_t n,
+                int64_t B_pad, void *block, void *stream);
+int r4r_dp_unpack(int nfields, const uint64_t *dst, const int *widths, const void *blocks, int world,
+                  int64_t B_pad, void *stream);
+
 /* ---- fused native step for NARRE (pytorch_models/NARRE.py:10-124)
  * Replaces, per training step: the word gathers + TextCNN over the B*R review documents of each
  * side, TextCNN's FC + dropout, both attention scorers + softmax (NARRE.py:53-64), the four

@@ -52,7 +52,6 @@ __device__ __forceinline__ void wgrad_block_pass(const WgradArgs &a, int f, int 
     // (tables of 4 GB and more keep the per-row form: 32-bit buffer offsets)
     const bool buf_ok = a.table_bytes > 0 && a.table_bytes < (1ll << 32);
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(table), 0, buf_ok ? (int)(unsigned)a.table_bytes : 0, 0x00020000);
-    typedef unsigned wg_u32x4 __attribute__((ext_vector_type(4)));
     for (int64_t c0 = n0; c0 < n1; c0 += WG_CHUNK) {
         const int nd = (int)min((int64_t)WG_CHUNK, n1 - c0);
         __syncthreads();

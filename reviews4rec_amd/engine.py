@@ -77,6 +77,39 @@ def load_named_moments(who, m, v, sd):
     return scalars
 
 
+def gather_entry_fields(owner, fields, n, B_pad, world, all_gather):
+    """Data parallel: a rank's compact entries -> the gathered arrays the `r4r_*_rows_apply` launches read, with ONE
+    packing launch, ONE all_gather and one unpacking launch (csrc/dp_pack.hip).  fields: [(tensor of this rank's n
+    entries -- contiguous, int64 or float32, [n] or [n, w]; ignored when n == 0 --, w, torch dtype)]; ids (int64) are
+    padded with -1, values with 0.  all_gather(out, block) (None: one rank, nothing to gather).  -> the gathered tensors
+    [world * B_pad] / [world * B_pad, w], buffers owned by `owner` and reused from step to step."""
+    lib = _lib.lib()
+    nf = len(fields)
+    units = [w * (2 if dt == torch.int64 else 1) for _, w, dt in fields]
+    key = ('entry_fields', B_pad, world) + tuple((w, dt) for _, w, dt in fields)
+    cache = owner.__dict__.setdefault('_entry_field_bufs', {})
+    if key not in cache:
+        widths = (ctypes.c_int * nf)(*units)
+        nbytes = lib.r4r_dp_block_bytes(nf, widths, B_pad)
+        dev = owner.dev
+        block = torch.zeros(max(nbytes, 4), dtype=torch.uint8, device=dev)
+        blocks = block if all_gather is None else torch.zeros(world * max(nbytes, 4), dtype=torch.uint8, device=dev)
+        outs = [torch.empty((world * B_pad,) + ((w,) if w > 1 else ()), dtype=dt, device=dev) for _, w, dt in fields]
+        cache[key] = (widths, (ctypes.c_int * nf)(*[1 if dt == torch.int64 else 0 for _, _, dt in fields]), block, blocks, outs,
+                      (ctypes.c_uint64 * nf)(*[o.data_ptr() for o in outs]))
+    widths, ones, block, blocks, outs, dst = cache[key]
+    src = (ctypes.c_uint64 * nf)(*[(t.data_ptr() if n > 0 else 0) for t, _, _ in fields])
+    if n > 0:
+        for t, w, dt in fields:
+            if not (t.is_contiguous() and t.dtype == dt and t.numel() == n * w):
+                raise RuntimeError('gather_entry_fields: a field is not a contiguous [n, %d] %s tensor' % (w, dt))
+    _lib.check(lib.r4r_dp_pack(nf, src, widths, ones, n, B_pad, ptr(block), _lib.current_stream()), 'r4r_dp_pack')
+    if all_gather is not None:
+        all_gather(blocks, block)
+    _lib.check(lib.r4r_dp_unpack(nf, dst, widths, ptr(blocks), world, B_pad, _lib.current_stream()), 'r4r_dp_unpack')
+    return outs
+
+
 def pad4(E):
     return (int(E) + 3) // 4 * 4
 
@@ -1395,6 +1428,24 @@ class DeepCoNNPPEngine(NarreEngine):
     def _dp_cols(self, R):
         return 2, 1
 
+    def _dp_rows(self, data, n, B_pad, world, solo):
+        """(uid, iid, d loss / d pred) per rating: one packing launch, ONE all_gather, one unpacking launch, the update."""
+        R, T = self._dp_doc_shape(data)
+        fields = [(None, 1, torch.int64), (None, 1, torch.int64), (None, 1, torch.float32)]
+        if n > 0:
+            f = self._fields(data)[0]
+            off = self._ws_offset(n, R, T, 5)
+            fields = [(f[2], 1, torch.int64), (f[3], 1, torch.int64),
+                      (self._workspace(n, R, T)[off:off + n * 4].view(torch.float32), 1, torch.float32)]
+        uid_all, iid_all, g_all = gather_entry_fields(self, fields, n, B_pad, world, None if solo else self.dp.all_gather)
+        nb = max(n, 1)                                       # (the workspace of this rank's own shape holds the row tags)
+        ws = self._workspace(nb, R, T)
+        p2 = lambda ts: (ctypes.c_uint64 * 2)(*[t.data_ptr() for t in ts])   # noqa: E731
+        _lib.check(_lib.lib().r4r_deepconnpp_rows_apply(
+            ptr(uid_all), ptr(iid_all), ptr(g_all), world * B_pad, p2(self.rows), p2(self.rows_m), p2(self.rows_v),
+            self.n_users, self.n_items, ptr(ws), ws.numel(), nb, T, self.E, self.L, self.V, self.lr, self.betas[0],
+            self.betas[1], self.eps, self.wd, int(self.step_count), _lib.current_stream()), 'r4r_deepconnpp_rows_apply')
+
     def _dp_payload(self, f, n, R, T, ids, vals):
         off = self._ws_offset(n, R, T, 5)
         ids[:n, 0], ids[:n, 1] = f[2], f[3]
@@ -1897,22 +1948,15 @@ class IdNetEngine(_SweepSchedule):
                                       one(self.flat_m.data_ptr()), one(self.flat_v.data_ptr()),
                                       (ctypes.c_int64 * 1)(self.total), self.lr, self.betas[0], self.betas[1], self.eps,
                                       self.wd, int(self.step_count), None, _lib.current_stream()), 'r4r_adam_multi')
-        # C2: per rating (uid, iid) and (d loss / d pred, the compact rows of every table); -1 ids pad ragged shards
+        # C2: per rating (uid, iid) and (d loss / d pred, the compact rows of every table); -1 ids pad ragged shards --
+        # one packing launch, ONE all_gather, one unpacking launch (gather_entry_fields)
         ntab = len(self.tables)
-        ids = torch.full((B_pad, 2), -1, dtype=torch.int64, device=self.dev)     # uid, iid
-        vals = torch.zeros((B_pad, 1 + ntab * L), dtype=torch.float32, device=self.dev)
-        if n > 0:
-            ids[:n, 0], ids[:n, 1] = data[5].reshape(-1), data[6].reshape(-1)
-            vals[:n, 0] = self._ws_view(n, 1, 1)[:, 0]
-            for t in range(ntab):
-                vals[:n, 1 + t * L:1 + (t + 1) * L] = self._ws_view(n, 4 + t, L)
-        all_ids = torch.empty((world * B_pad, 2), dtype=torch.int64, device=self.dev)
-        all_vals = torch.empty((world * B_pad, 1 + ntab * L), dtype=torch.float32, device=self.dev)
-        self.dp.all_gather(all_ids.view(-1), ids.view(-1))
-        self.dp.all_gather(all_vals.view(-1), vals.view(-1))
-        uid_all, iid_all = all_ids[:, 0].contiguous(), all_ids[:, 1].contiguous()
-        g_all = all_vals[:, 0].contiguous()
-        rows = [all_vals[:, 1 + t * L:1 + (t + 1) * L].contiguous() for t in range(ntab)]
+        fields = [(data[5].reshape(-1).contiguous() if n else None, 1, torch.int64),
+                  (data[6].reshape(-1).contiguous() if n else None, 1, torch.int64),
+                  (self._ws_view(n, 1, 1) if n else None, 1, torch.float32)]
+        fields += [(self._ws_view(n, 4 + t, L) if n else None, L, torch.float32) for t in range(ntab)]
+        got = gather_entry_fields(self, fields, n, B_pad, world, self.dp.all_gather)
+        uid_all, iid_all, g_all, rows = got[0], got[1], got[2], got[3:]
         p2 = lambda ts: (ctypes.c_uint64 * 2)(*[t.data_ptr() for t in ts] + [0] * (2 - len(ts)))
         nb = max(n, 1)                                       # (the workspace of this rank's own shape holds the row tags)
         ws = self._workspace(nb)
