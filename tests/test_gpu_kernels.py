@@ -519,3 +519,40 @@ def test_fp16_split_gemm_is_as_accurate_as_the_fp32_gemm(N, T, E, V, tscale):
     assert not torch.equal(p16, p32)                         # (it really ran the other arithmetic)
     assert float((a16 == a32).float().mean()) > 0.9999
     torch.testing.assert_close(p16.float(), ref.float(), rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize('world,n,B_pad', [(1, 5, 5), (2, 3, 7), (3, 0, 4), (2, 128, 128)])
+def test_dp_pack_and_unpack_move_every_field_of_every_rank(world, n, B_pad):
+    """csrc/dp_pack.hip: a rank's entry fields -> one padded block; the ranks' blocks -> rank-major field arrays
+    (ids padded with -1, values with 0): bit-exact against plain indexing."""
+    import ctypes
+    from reviews4rec_amd import _lib
+    from reviews4rec_amd._lib import ptr
+    lib = _lib.lib()
+    g = torch.Generator().manual_seed(world * 1000 + n)
+    spec = [(1, torch.int64), (1, torch.int64), (1, torch.float32), (5, torch.float32), (16, torch.float32)]
+    units = (ctypes.c_int * len(spec))(*[w * (2 if dt == torch.int64 else 1) for w, dt in spec])
+    ones = (ctypes.c_int * len(spec))(*[1 if dt == torch.int64 else 0 for _, dt in spec])
+    nbytes = lib.r4r_dp_block_bytes(len(spec), units, B_pad)
+    assert nbytes % 256 == 0 and nbytes >= sum(B_pad * w * (8 if dt == torch.int64 else 4) for w, dt in spec)
+    blocks = torch.zeros(world * nbytes, dtype=torch.uint8, device=DEV)
+    fields = []
+    for r in range(world):
+        nr = max(n - r, 0)                                   # ragged shards
+        mine = [(torch.randint(0, 1 << 40, (nr,), generator=g) if dt == torch.int64 else torch.randn(nr, w, generator=g)).to(DEV)
+                for w, dt in spec]
+        fields.append((nr, mine))
+        src = (ctypes.c_uint64 * len(spec))(*[(t.data_ptr() if nr else 0) for t in mine])
+        block = torch.full((nbytes,), 0x5a, dtype=torch.uint8, device=DEV)      # (every byte the layout names is written)
+        _lib.check(lib.r4r_dp_pack(len(spec), src, units, ones, nr, B_pad, ptr(block), _lib.current_stream()), 'r4r_dp_pack')
+        blocks[r * nbytes:(r + 1) * nbytes] = block
+    outs = [torch.empty((world * B_pad,) + ((w,) if w > 1 else ()), dtype=dt, device=DEV) for w, dt in spec]
+    dst = (ctypes.c_uint64 * len(spec))(*[o.data_ptr() for o in outs])
+    _lib.check(lib.r4r_dp_unpack(len(spec), dst, units, ptr(blocks), world, B_pad, _lib.current_stream()), 'r4r_dp_unpack')
+    torch.cuda.synchronize()
+    for f, (w, dt) in enumerate(spec):
+        want = torch.full_like(outs[f], -1) if dt == torch.int64 else torch.zeros_like(outs[f])
+        for r, (nr, mine) in enumerate(fields):
+            if nr:
+                want[r * B_pad:r * B_pad + nr] = mine[f].reshape(want[r * B_pad:r * B_pad + nr].shape)
+        assert torch.equal(outs[f], want), f
