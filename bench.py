@@ -543,19 +543,21 @@ def run(args, env, is_leg=False):
             resident_step(0)                                 # trains pool[0], prepares the tokens of pool[1]
             pool[0], pool[1] = pool[1], next(feed)
 
-    def fence():
+    def fence(ev=None):
         # barrier + torch.cuda.synchronize() on both sides of the timed region, as the contract says.  The host
-        # first SPINS on an event behind the queued work: synchronize() on an already idle device returns at once,
-        # while a blocked synchronize() is woken some tens of microseconds after the GPU went idle -- 3-5 % of a
-        # 20-step (2 ms) region that are the host's wake-up latency, not the steps'.
-        ev = torch.cuda.Event()
-        ev.record()
+        # first SPINS on an event behind the queued work (`ev`: one already recorded there, else a new one):
+        # synchronize() on an already idle device returns at once, while a blocked synchronize() is woken some tens of
+        # microseconds after the GPU went idle -- 3-5 % of a 20-step (2 ms) region that are the host's wake-up
+        # latency, not the steps'.
+        if ev is None:
+            ev = torch.cuda.Event()
+            ev.record()
         while not ev.query():
             pass
         torch.cuda.synchronize()
-        if dp_job:
+        if dp_job:                                           # (one process: nobody to meet, and the device is already idle)
             torch.distributed.barrier()
-        torch.cuda.synchronize()
+            torch.cuda.synchronize()
 
     gpu_span_ms = [0.0]
 
@@ -570,13 +572,16 @@ def run(args, env, is_leg=False):
         # durations -- measured: 56.0 vs 59.4 us for the GEMM), or -- short regions, where two
         # instrumented steps are already 1.5 % of the window -- one step in the middle
         sample = (lambda i: i % 20 == 10) if steps >= 50 else (lambda i: i == steps // 2)
+        # (a short region's one instrumented step times the DOMINANT kernel only -- the `roofline` leg; every further
+        # pair of events is another ~10 us of a 2 ms window, and the other legs have the steady leg's samples)
+        m = mask if steps >= 50 else (mask & short_mask)
         for i in range(steps):
-            lib.r4r_timing_enable(mask if sample(i) else 0)
+            lib.r4r_timing_enable(m if sample(i) else 0)
             step_fn(first + i)
         if hasattr(engine, 'flush'):                         # every optimizer update of the K steps lands inside the region
             engine.flush(check=False)
         ev1.record()
-        fence()
+        fence(ev1)
         elapsed = time.perf_counter() - t0
         # first launch's start -> last launch's end on the device: what the steps cost the GPU, without the two
         # host fences and the launch-queue fill the host clock also sees (value stays host-clock)
@@ -607,6 +612,8 @@ def run(args, env, is_leg=False):
     # every launch of every step cost 20 % of a 0.13 ms step, sampling costs ~1 %.
     mask = 0 if args.no_kernel_timing else (1 << 0) | (1 << 3) | (1 << 4) | \
         ((1 << 2) if hp['model_type'] in ('MF_dot', 'bias_only', 'transnet++') else 0)   # the Adam sweep is the leg
+    # the dominant kernel's slot: the Adam sweep of the ID-table families, the projection GEMM (or the direct conv) otherwise
+    short_mask = (1 << 2) if hp['model_type'] in ('MF_dot', 'bias_only', 'transnet++') else ((1 << 0) | (1 << 3))
     elapsed = timed_region(step, args.steps, ramp + args.warmup, mask)
     if hasattr(engine, 'check_announcements'):               # (outside the region: one int read back from the device)
         engine.check_announcements()
