@@ -714,7 +714,7 @@ def test_rccl_one_rank_bench_line(tmp_path):
     assert line['value'] > 0 and line['strong']['global_batch'] == 1024
 
 
-@pytest.mark.parametrize('workload', ['cfg2_mfdot_electronics', 'cfg5_transnetpp_synthetic'])
+@pytest.mark.parametrize('workload', ['cfg2_mfdot_electronics', 'cfg4_narre_kindle', 'cfg5_transnetpp_synthetic'])
 def test_two_rank_bench_line_of_the_id_table_families(workload):
     """bench.py --gpus 2 (two ranks sharing the one GPU over gloo) for the families whose data-parallel step pads
     every rank's shard to hyper_params['batch_size']: the weak line AND a strong leg whose per-rank batch (512) exceeds
