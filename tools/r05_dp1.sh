@@ -27,7 +27,7 @@ for rep in 1 2; do
   for spec in "cfg2_mfdot_electronics MF" "cfg2_mfdot_electronics NeuMF" "cfg3_deepconn_electronics_e300 deepconn++"; do
     set -- $spec
     ARGS="--workload $1 --model-type $2"
-    python $R/bench.py --no-cpu-baseline --no-config-legs $ARGS 2>/dev/null | line "$2 (on $1's shapes) single process"
+    python $R/bench.py --no-cpu-baseline --no-config-legs $ARGS 2>/dev/null | line "$2 (shapes of $1) single process"
     dp1 env | line "$2 dp1: pack, one all_gather, unpack, update"
   done
 done
