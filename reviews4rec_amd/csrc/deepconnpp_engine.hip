@@ -50,6 +50,7 @@ struct DcppHead {
 
 BWD_TRACE_DEFINE(r4r_debug_dcpp_bwd_trace)
 // One workgroup of 256 threads per rating (the work is ~2000-element loops: FC gradients, d pooled).
+#define SEL2(arr, s) ((s) ? (arr)[1] : (arr)[0])
 template <int ML>
 __global__ __launch_bounds__(256) void dcpp_head_kernel(DcppHead a) {
     __shared__ __attribute__((aligned(16))) float P[2][NF];
@@ -84,34 +85,49 @@ __global__ __launch_bounds__(256) void dcpp_head_kernel(DcppHead a) {
     hq4 wv[WREG];
     float av[AREG];
     const int wtot = 2 * L * NQ4;
+    // What later reads depend on goes out FIRST (loads return in order: waiting for the oldest requests does not wait
+    // for the weights behind them): the rating's ids -- their bias elements are a second round trip, now under the
+    // first -- and this thread's pool partials, first PT tiles (as a loop behind the weights they were a third one).
+    // Every load unconditional at a clamped address (behind a uniform `if` each got a branch and a full wait), the
+    // towers' pointer arrays selected, not indexed (transnet_engine.hip).
+    const int64_t uid_r = a.id[0][b], iid_r = a.id[1][b];
+    const int ps = tid >= NF, pf = min(tid - ps * NF, NF - 1);
+    float pv0[PT];
+    int pp0[PT];
 #pragma unroll
-    for (int u = 0; u < WREG; ++u) {
-        wv[u] = (hq4){0.f, 0.f, 0.f, 0.f};
-        if (256 * u < wtot) {
-            const int i = min(tid + 256 * u, wtot - 1), s = i >= L * NQ4;
-            wv[u] = *reinterpret_cast<const hq4 *>(fp + a.off[s ? DP_IFW : DP_UFW] + 4 * (i - s * L * NQ4));
-        }
+    for (int k = 0; k < PT; ++k) {
+        const size_t q = ((size_t)b * a.tiles + min(k, a.tiles - 1)) * NP + pf;   // (a clamped duplicate never wins: strict >)
+        pv0[k] = SEL2(a.pmax, ps)[q];
+        pp0[k] = SEL2(a.parg, ps)[q];
     }
 #pragma unroll
-    for (int u = 0; u < AREG; ++u) av[u] = 256 * u < L * L2 ? fp[a.off[DP_F0W] + min(tid + 256 * u, L * L2 - 1)] : 0.f;
+    for (int u = 0; u < WREG; ++u) {
+        const int i = min(tid + 256 * u, wtot - 1), s = i >= L * NQ4;
+        wv[u] = *reinterpret_cast<const hq4 *>(fp + (s ? a.off[DP_IFW] : a.off[DP_UFW]) + 4 * (i - s * L * NQ4));
+    }
+#pragma unroll
+    for (int u = 0; u < AREG; ++u) av[u] = fp[a.off[DP_F0W] + min(tid + 256 * u, L * L2 - 1)];
     const int t2 = min(tid, L2 - 1), tl = min(tid, L - 1);
-    const float fcb_r = fp[a.off[t2 >= L ? DP_IFB : DP_UFB] + (t2 >= L ? t2 - L : t2)];
+    const float fcb_r = fp[(t2 >= L ? a.off[DP_IFB] : a.off[DP_UFB]) + (t2 >= L ? t2 - L : t2)];
     const float b1_r = fp[a.off[DP_F0B] + tl], w3_r = fp[a.off[DP_F3W] + tl];
     const float m0 = fp[a.off[DP_F3B]], m1 = fp[a.off[DP_GB]];
-    const float m2 = a.bias[0][a.id[0][b]], m3 = a.bias[1][a.id[1][b]];
+    const float m2 = a.bias[0][uid_r], m3 = a.bias[1][iid_r];
     if (tid < 2 * NF) {
-        const int s = tid >= NF, f = tid - s * NF;
+        const int s = ps, f = pf;
         float best = -INFINITY;
         int bp = -1;
-        for (int k0 = 0; k0 < a.tiles; k0 += PT) {
+#pragma unroll
+        for (int k = 0; k < PT; ++k)
+            if (pv0[k] > best) { best = pv0[k]; bp = pp0[k]; }
+        for (int k0 = PT; k0 < a.tiles; k0 += PT) {          // documents of more than PT tiles: the rest, PT at a time
             float v[PT];
             int pp[PT];
 #pragma unroll
             for (int k = 0; k < PT; ++k) {
                 const bool in = k0 + k < a.tiles;
                 const size_t q = ((size_t)b * a.tiles + (in ? k0 + k : 0)) * NP + f;
-                v[k] = in ? a.pmax[s][q] : -INFINITY;
-                pp[k] = a.parg[s][q];
+                v[k] = in ? SEL2(a.pmax, s)[q] : -INFINITY;
+                pp[k] = SEL2(a.parg, s)[q];
             }
 #pragma unroll
             for (int k = 0; k < PT; ++k)
@@ -119,8 +135,8 @@ __global__ __launch_bounds__(256) void dcpp_head_kernel(DcppHead a) {
         }
         if (!(best > 0.f)) { best = 0.f; bp = -1; }
         P[s][f] = best;
-        a.pooled[s][b * NF + f] = best;
-        a.argmax[s][b * NF + f] = bp;
+        SEL2(a.pooled, s)[b * NF + f] = best;
+        SEL2(a.argmax, s)[b * NF + f] = bp;
     }
 #pragma unroll
     for (int u = 0; u < WREG; ++u) {
@@ -212,7 +228,7 @@ __global__ __launch_bounds__(256) void dcpp_head_kernel(DcppHead a) {
         const int s = tid >= NF, f = tid - s * NF;
         float acc = 0.f;
         for (int l = 0; l < L; ++l) acc = fmaf(dzs[s * L + l], fcw[s][l][f], acc);
-        a.g_pooled[s][b * NF + f] = acc;
+        SEL2(a.g_pooled, s)[b * NF + f] = acc;
     }
 }
 
