@@ -113,6 +113,7 @@ def parse():
     ap.add_argument('--cpu-seconds', type=float, default=12.0,
                     help='budget of each half (thread calibration, measurement) of the cpu_baseline leg')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--step-events', action='store_true', help='diagnosis: a HIP event after every timed step, spans on stderr')
     ap.add_argument('--no-config-legs', action='store_true',
                     help='N = 1 default line: skip the separately timed legs of the other BASELINE.json configurations '
                          '(--no-cpu-baseline, the A/B scripts\' quick mode, skips them too unless --config-legs is given)')
@@ -563,8 +564,10 @@ def run(args, env, is_leg=False):
 
     def timed_region(step_fn, steps, first, mask):
         """EXACTLY `steps` steps between two fences; -> max-over-ranks wall seconds."""
-        fence()
+        # (everything the region needs is made BEFORE the fence: between the fence and the first launch the device is idle,
+        # and that idle time is inside the region -- 35-75 us of a 2 ms one, tools: bench.py --step-events)
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        fence()
         t0 = time.perf_counter()
         ev0.record()                                         # (torch's current stream = the one every launch goes to)
         # sampled kernel timing: every 20th step (an instrumented step costs ~30 us more: its HIP events
@@ -575,9 +578,14 @@ def run(args, env, is_leg=False):
         # (a short region's one instrumented step times the DOMINANT kernel only -- the `roofline` leg; every further
         # pair of events is another ~10 us of a 2 ms window, and the other legs have the steady leg's samples)
         m = mask if steps >= 50 else (mask & short_mask)
+        marks = []
         for i in range(steps):
             lib.r4r_timing_enable(m if sample(i) else 0)
             step_fn(first + i)
+            if args.step_events:                             # (diagnosis only: an event per step costs the region ~3 us each)
+                e = torch.cuda.Event(enable_timing=True)
+                e.record()
+                marks.append(e)
         if hasattr(engine, 'flush'):                         # every optimizer update of the K steps lands inside the region
             engine.flush(check=False)
         ev1.record()
@@ -586,6 +594,10 @@ def run(args, env, is_leg=False):
         # first launch's start -> last launch's end on the device: what the steps cost the GPU, without the two
         # host fences and the launch-queue fill the host clock also sees (value stays host-clock)
         gpu_span_ms[0] = ev0.elapsed_time(ev1)
+        if marks:
+            ts = [ev0.elapsed_time(e) for e in marks]
+            print('step ends (us since the region\'s first event): ' + ' '.join('%.0f' % (1000 * t) for t in ts), file=sys.stderr)
+            print('step spans (us): ' + ' '.join('%.0f' % (1000 * (b - a)) for a, b in zip([0.0] + ts[:-1], ts)), file=sys.stderr)
         lib.r4r_timing_enable(0)
         el = torch.tensor([elapsed], device=dev)
         if dp_job:
