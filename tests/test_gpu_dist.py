@@ -767,3 +767,56 @@ def test_more_ranks_than_gpus_over_rccl_fails_with_one_line():
     out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', str(n), '--steps', '2', '--warmup', '1'],
                          env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode != 0 and ('--gpus %d but %d GPU' % (n, n - 1)) in out.stderr, out.stderr[-1000:]
+
+
+def test_peer_waits_are_bounded_when_a_rank_never_arrives():
+    """The peer-mapped exchanges wait for the ranks' flags INSIDE kernels: a rank that never raises its flag must cost
+    the timeout, not the GPU.  One process plays rank 0 of two (both 'ranks' map the same segment): r4r_peer_wait and
+    r4r_mf_grad_push -> r4r_mf_apply_peer (every workgroup of the update launch polls) return after ~the timeout and
+    name the missing rank in the timed_out word."""
+    import ctypes
+    import time
+    from reviews4rec_amd import _lib
+    from reviews4rec_amd._lib import ptr
+    lib = _lib.lib()
+    dev = torch.device('cuda')
+    n_users, n_items, D, B = 300, 200, 16, 8
+    nbytes = lib.r4r_mf_dp_block_bytes(B, D)
+    FLAGS = 4096
+    seg, handle = ctypes.c_void_p(), (ctypes.c_uint8 * 64)()
+    _lib.check(lib.r4r_peer_segment_create(FLAGS + 2 * nbytes, ctypes.byref(seg), handle), 'r4r_peer_segment_create')
+    try:
+        local = torch.zeros(16, dtype=torch.int32, device=dev)              # [0] arrival counter, [1] timed_out
+        # the bare wait: flag 1 of 2 never reaches epoch 1
+        t0 = time.perf_counter()
+        _lib.check(lib.r4r_peer_wait(seg.value, 2, 1, local.data_ptr() + 4, 0.2, _lib.current_stream()), 'r4r_peer_wait')
+        torch.cuda.synchronize()
+        assert 0.15 < time.perf_counter() - t0 < 5.0
+        assert int(local[1].item()) in (1, 2)                               # 1 + the rank that was missing (0 and 1 both are)
+        local.zero_()
+        # the MF step: rank 0 pushes, "rank 1" never does
+        torch.manual_seed(0)
+        p = [torch.randn(n_users, D, device=dev) * 0.1, torch.randn(n_items, D, device=dev) * 0.1,
+             torch.zeros(n_users, device=dev), torch.zeros(n_items, device=dev), torch.zeros(1, device=dev)]
+        m, v = [torch.zeros_like(t) for t in p], [torch.zeros_like(t) for t in p]
+        P5 = lambda ts: (ctypes.c_uint64 * 5)(*[t.data_ptr() for t in ts])   # noqa: E731
+        uid = torch.randint(0, n_users, (B,), device=dev)
+        iid = torch.randint(0, n_items, (B,), device=dev)
+        y = torch.rand(B, device=dev) * 4 + 1
+        pred, se, sse = torch.empty(B, device=dev), torch.empty(B, device=dev), torch.zeros(1, device=dev)
+        ws = torch.zeros(lib.r4r_mf_ws_bytes(2 * B, D, n_users, n_items), dtype=torch.uint8, device=dev)
+        u64 = lambda vals: (ctypes.c_uint64 * 16)(*(vals + [0] * (16 - len(vals))))   # noqa: E731
+        dst, flg = u64([seg.value + FLAGS, seg.value + FLAGS]), u64([seg.value, seg.value])
+        _lib.check(lib.r4r_mf_grad_push(ptr(uid), ptr(iid), ptr(y), P5(p), None, None, n_users, n_items, D, ptr(pred), ptr(se),
+                                        None, B, B, 0.0, 1, 1, 0, 1.0 / (2 * B), None, 1, 0, 0.002, 0.9, 0.999, 1e-8, 1e-6, 1,
+                                        dst, flg, local.data_ptr(), 0, 2, 1, _lib.current_stream()), 'r4r_mf_grad_push')
+        t0 = time.perf_counter()
+        _lib.check(lib.r4r_mf_apply_peer(seg.value + FLAGS, 2, B, P5(p), P5(m), P5(v), n_users, n_items, D, ptr(ws), ws.numel(),
+                                         1, 0, 1, ptr(se), B, ptr(sse), 0.002, 0.9, 0.999, 1e-8, 1e-6, 1,
+                                         seg.value, 1, local.data_ptr() + 4, 0.2, _lib.current_stream()), 'r4r_mf_apply_peer')
+        torch.cuda.synchronize()
+        assert 0.15 < time.perf_counter() - t0 < 10.0
+        assert int(local[1].item()) == 2                                    # rank 1 never raised its flag
+    finally:
+        torch.cuda.synchronize()
+        _lib.check(lib.r4r_peer_segment_destroy(seg), 'r4r_peer_segment_destroy')
