@@ -1065,8 +1065,14 @@ __global__ __launch_bounds__(WR_THREADS) void proj_gemm_wres_kernel(ProjArgs a) 
     constexpr int STR = wr_stride(NCH), SLOTS = NCH * 4;
     // the towers' workgroups: in proportion to their row tiles, every tower with rows at least one
     int rt[MAX_TOWERS], g[MAX_TOWERS], U = 0, live = 0;
+    // the towers' row counts in ONE round trip: lane t reads tower t's (as scalar loads, one per tower and each behind a
+    // branch, they were a chain of dependent round trips in front of everything else)
+    static_assert(MAX_TOWERS == 4, "the lane -> tower select below");
+    const int ln = threadIdx.x & 63;
+    const int *cp = ln == 0 ? a.t[0].count : (ln == 1 ? a.t[1].count : (ln == 2 ? a.t[2].count : a.t[3].count));
+    const int cl = ln < a.ntower ? cp[0] : 0;
     for (int t = 0; t < MAX_TOWERS; ++t) {
-        rt[t] = t < a.ntower ? (a.t[t].count[0] + 15) >> 4 : 0;
+        rt[t] = (__builtin_amdgcn_readlane(cl, t) + 15) >> 4;
         U += rt[t];
         live += rt[t] > 0;
     }
@@ -1074,7 +1080,7 @@ __global__ __launch_bounds__(WR_THREADS) void proj_gemm_wres_kernel(ProjArgs a) 
     const int G = (int)gridDim.x;                            // (the launcher gives every tower a workgroup: G >= ntower)
     int used = 0, big = 0;
     for (int t = 0; t < MAX_TOWERS; ++t) {
-        g[t] = rt[t] > 0 ? max(1, (int)((long)rt[t] * (G - live) / U)) : 0;
+        g[t] = rt[t] > 0 ? max(1, (int)((unsigned)rt[t] * (unsigned)(G - live) / (unsigned)U)) : 0;   // (row tiles < 2^20, workgroups < 2^10: 32 bits)
         used += g[t];
         if (rt[t] > rt[big]) big = t;
     }
