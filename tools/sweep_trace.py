@@ -45,6 +45,10 @@ for i in range(3):
     tr = tr[tr[:, 0] > 0]
     t0 = tr[:, 0].min()
     print('%s step %d: %d workgroups, first start -> last end %.2f us' % (workload, i, len(tr), (tr[:, 1].max() - t0) / 100.0))
+    # how many workgroups are resident at once (every 2 us of the launch)
+    st_all, en_all = (tr[:, 0] - t0) / 100.0, (tr[:, 1] - t0) / 100.0
+    print('  resident workgroups at t = 1, 3, 5, ... us: ' + ' '.join(
+        '%d' % int(((st_all <= t) & (en_all > t)).sum()) for t in np.arange(1.0, en_all.max(), 2.0)))
     for z in sorted(set(tr[:, 2].tolist())):
         r = tr[tr[:, 2] == z]
         d = (r[:, 1] - r[:, 0]) / 100.0
