@@ -82,13 +82,23 @@ typedef float tb_f32x4 __attribute__((ext_vector_type(4)));
 template <int N>
 __device__ __forceinline__ void tb_catch_up_v(tb_f32x4 (&P)[N], tb_f32x4 (&M)[N], tb_f32x4 (&V)[N], const int (&cur)[N], int upto,
                                               int now, const AdamScalars &sc0, const MfTimeBlock &tb) {
+    // The sixteen per-step scalars live in VECTOR registers here (the same value in every lane): as kernel arguments they
+    // are scalar registers, the sweep kernels have none to spare (128 scalar spills), and hipcc kept them spilled in the
+    // lanes of a vector register -- 136 v_readlane restores among the 208 arithmetic instructions of this loop, in a
+    // launch its arithmetic bounds.
+    float lrv[MF_TB_MAX], isv[MF_TB_MAX];
+#pragma unroll
+    for (int j = 0; j < MF_TB_MAX; ++j) {
+        lrv[j] = tb.lr_bc1[j]; isv[j] = tb.isb2[j];
+        asm volatile("" : "+v"(lrv[j]), "+v"(isv[j]));
+    }
 #pragma unroll
     for (int j = 0; j < MF_TB_MAX; ++j) {
         const int s = now - (MF_TB_MAX - 1 - j);
         if (s > upto) continue;                             // uniform
         AdamScalars sc = sc0;
-        sc.lr_over_bc1 = tb.lr_bc1[j];
-        sc.inv_sqrt_bc2 = tb.isb2[j];
+        sc.lr_over_bc1 = lrv[j];
+        sc.inv_sqrt_bc2 = isv[j];
 #pragma unroll
         for (int u = 0; u < N; ++u)
             if (s > cur[u]) {                               // (two elements per packed instruction: adam_pair_fast)
