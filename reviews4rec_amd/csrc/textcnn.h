@@ -70,7 +70,7 @@ int textcnn_fwd_launch(const float *table, const FwdTower *tw, int ntower,
 int textcnn_pool_finish_launch(const float *pmax, const int *parg, float *pooled, int *argmax,
                                int64_t N, int tiles, int F, hipStream_t st);
 int textcnn_wgrad_launch(const float *table, const WgradTower *tw, int ntower,
-                         int64_t N, int T, int E, int F, hipStream_t st);
+                         int64_t N, int T, int E, int F, hipStream_t st, int64_t table_bytes = 0);
 
 // second stage of the wgrad: add the nsplit partials of every tower in a fixed order
 int textcnn_wgrad_reduce_launch(const WgradTower *tw, int ntower, int64_t N, int E, int F, hipStream_t st);

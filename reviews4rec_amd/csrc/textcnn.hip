@@ -369,10 +369,11 @@ int textcnn_pool_finish_launch(const float *pmax, const int *parg, float *pooled
 }
 
 int textcnn_wgrad_launch(const float *table, const WgradTower *tw, int ntower,
-                         int64_t N, int T, int E, int F, hipStream_t st) {
+                         int64_t N, int T, int E, int F, hipStream_t st, int64_t table_bytes) {
     WgradArgs a;
     for (int k = 0; k < MAX_TOWERS; ++k) a.t[k] = tw[k < ntower ? k : 0];
     a.table = table; a.N = N; a.T = T; a.E = E; a.F = F;
+    a.table_bytes = table_bytes;                            // (0: the wide form keeps its per-row loads)
     a.nsplit = textcnn_wgrad_splits(N);
     a.per_split = (int)cdiv(N > 0 ? N : 1, a.nsplit);
     {
@@ -525,5 +526,9 @@ extern "C" int r4r_textcnn_wgrad(const float *table, int64_t V, const int64_t *i
     tw.part_w = reinterpret_cast<float *>(base);
     base += align256((size_t)ns * F * 3 * E * 4);
     tw.part_b = reinterpret_cast<float *>(base);
-    return textcnn_wgrad_launch(table, &tw, 1, N, T, E, F, as_stream(stream));
+    // R4R_WGRAD_ROWS=loop: the wide form's per-row loads (what tables of 4 GB and more get) instead of the buffer-resource
+    // batches -- for the test that holds the two to the same bits
+    const char *rows = getenv("R4R_WGRAD_ROWS");
+    const bool loop = rows && rows[0] == 'l';
+    return textcnn_wgrad_launch(table, &tw, 1, N, T, E, F, as_stream(stream), loop ? 0 : (int64_t)V * E * 4);
 }

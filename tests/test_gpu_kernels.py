@@ -556,3 +556,25 @@ def test_dp_pack_and_unpack_move_every_field_of_every_rank(world, n, B_pad):
             if nr:
                 want[r * B_pad:r * B_pad + nr] = mine[f].reshape(want[r * B_pad:r * B_pad + nr].shape)
         assert torch.equal(outs[f], want), f
+
+
+@pytest.mark.parametrize('N,T,E,V', [(32, 200, 300, 500), (40, 120, 128, 300), (17, 60, 702, 90)])
+def test_wide_wgrad_buffer_batches_equal_the_per_row_loads(N, T, E, V, monkeypatch):
+    """The wide weight gradient reads a round's rows through a buffer resource, eight requested together, skipped slots
+    answered with zeros by the range check; tables of 4 GB and more keep one load per contributing row.  Same
+    additions in the same order: the same bits (R4R_WGRAD_ROWS=loop selects the per-row form of the stand-alone op)."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(N * 7 + E)
+    table = ((torch.rand((V, E), generator=g) - 0.5) * 0.2).to(DEV)
+    w = ((torch.rand((100, 1, 3, E), generator=g) - 0.5) * 0.2).to(DEV)
+    b = (torch.rand(100, generator=g) - 0.5) * 0.1
+    b[::5] = -10.0                                                       # every fifth filter dead: argmax -1, skipped slots
+    b = b.to(DEV)
+    idx = torch.randint(0, V, (N, T), generator=g).to(DEV)
+    gp = torch.randn((N, 100), generator=g).to(DEV)
+    pooled, arg = ops.textcnn_fwd_raw(idx, table, w, b)
+    assert (arg < 0).any() and (arg >= 0).any()
+    d_w, d_b = ops.textcnn_wgrad_raw(idx, table, gp, arg, w.shape)
+    monkeypatch.setenv('R4R_WGRAD_ROWS', 'loop')
+    l_w, l_b = ops.textcnn_wgrad_raw(idx, table, gp, arg, w.shape)
+    assert torch.equal(d_w, l_w) and torch.equal(d_b, l_b)
