@@ -1417,16 +1417,12 @@ class DeepCoNNPPEngine(NarreEngine):
     MODEL_TYPE = 'deepconn++'
     C = 'deepconnpp'
     DP_COLS = 1
-    BLOCKS_DP = False            # (two bias vectors: the generic per-rating payload)
 
     def __init__(self, model, dp=None, **kw):
         super().__init__(model, dp=dp, **kw)
 
     def _dp_doc_shape(self, data):
         return 1, int(data[3].shape[-1])
-
-    def _dp_cols(self, R):
-        return 2, 1
 
     def _dp_rows(self, data, n, B_pad, world, solo):
         """(uid, iid, d loss / d pred) per rating: one packing launch, ONE all_gather, one unpacking launch, the update."""
@@ -1443,20 +1439,6 @@ class DeepCoNNPPEngine(NarreEngine):
         p2 = lambda ts: (ctypes.c_uint64 * 2)(*[t.data_ptr() for t in ts])   # noqa: E731
         _lib.check(_lib.lib().r4r_deepconnpp_rows_apply(
             ptr(uid_all), ptr(iid_all), ptr(g_all), world * B_pad, p2(self.rows), p2(self.rows_m), p2(self.rows_v),
-            self.n_users, self.n_items, ptr(ws), ws.numel(), nb, T, self.E, self.L, self.V, self.lr, self.betas[0],
-            self.betas[1], self.eps, self.wd, int(self.step_count), _lib.current_stream()), 'r4r_deepconnpp_rows_apply')
-
-    def _dp_payload(self, f, n, R, T, ids, vals):
-        off = self._ws_offset(n, R, T, 5)
-        ids[:n, 0], ids[:n, 1] = f[2], f[3]
-        vals[:n, 0] = self._workspace(n, R, T)[off:off + n * 4].view(torch.float32)
-
-    def _dp_apply(self, all_ids, all_vals, B_all, ws, nb, R, T):
-        uid_all, iid_all = all_ids[:, 0].contiguous(), all_ids[:, 1].contiguous()
-        g_all = all_vals[:, 0].contiguous()
-        p2 = lambda ts: (ctypes.c_uint64 * 2)(*[t.data_ptr() for t in ts])   # noqa: E731
-        _lib.check(_lib.lib().r4r_deepconnpp_rows_apply(
-            ptr(uid_all), ptr(iid_all), ptr(g_all), B_all, p2(self.rows), p2(self.rows_m), p2(self.rows_v),
             self.n_users, self.n_items, ptr(ws), ws.numel(), nb, T, self.E, self.L, self.V, self.lr, self.betas[0],
             self.betas[1], self.eps, self.wd, int(self.step_count), _lib.current_stream()), 'r4r_deepconnpp_rows_apply')
 
@@ -1658,6 +1640,7 @@ class TransNetEngine(NarreEngine, _SweepSchedule):
             self.lr, self.betas[0], self.betas[1], self.eps, self.wd, int(adam_step), _lib.current_stream())
 
     DP_COLS = 10
+    BLOCKS_DP = False            # (NarreEngine's own block form is not this family's: beyond BLOCKS_MAX_ENTRIES the generic payload)
     BLOCKS_MAX_ENTRIES = 2048    # r4r_transnet_rows_apply_blocks' limit on world * B_pad
 
     def _dp_rows(self, data, n, B_pad, world, solo):

@@ -714,8 +714,11 @@ def test_rccl_one_rank_bench_line(tmp_path):
     assert line['value'] > 0 and line['strong']['global_batch'] == 1024
 
 
-@pytest.mark.parametrize('workload', ['cfg2_mfdot_electronics', 'cfg4_narre_kindle', 'cfg5_transnetpp_synthetic'])
-def test_two_rank_bench_line_of_the_id_table_families(workload):
+@pytest.mark.parametrize('workload,strong', [('cfg2_mfdot_electronics', 1024), ('cfg4_narre_kindle', 1024),
+                                             ('cfg5_transnetpp_synthetic', 1024),
+                                             # beyond the block forms' entry limits: the generic exchange of gathered entries
+                                             ('cfg5_transnetpp_synthetic', 4096), ('cfg2_mfdot_electronics', 4096)])
+def test_two_rank_bench_line_of_the_id_table_families(workload, strong):
     """bench.py --gpus 2 (two ranks sharing the one GPU over gloo) for the families whose data-parallel step pads
     every rank's shard to hyper_params['batch_size']: the weak line AND a strong leg whose per-rank batch (512) exceeds
     the weak one (128) -- the leg has to carry its own shard padding into the engine (it raised until round 4)."""
@@ -724,13 +727,13 @@ def test_two_rank_bench_line_of_the_id_table_families(workload):
     env = dict(os.environ, R4R_DIST_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0')
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr',
            '127.0.0.1', '--master-port', str(_free_port()), os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '6',
-           '--warmup', '2', '--no-cpu-baseline', '--workload', workload, '--strong-leg', '1024']
+           '--warmup', '2', '--ramp', '4', '--no-cpu-baseline', '--workload', workload, '--strong-leg', str(strong)]
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-2000:]
     line = json.loads(out.stdout.strip().splitlines()[-1])
     assert line['n_gpus'] == 2 and line['value'] > 0 and line['config']['replicas_identical'] is True
     legs = line.get('strong_legs') or [line.get('strong')]
-    assert legs and legs[0]['global_batch'] == 1024 and legs[0].get('ratings_per_s', 0) > 0, legs
+    assert legs and legs[0]['global_batch'] == strong and legs[0].get('ratings_per_s', 0) > 0, legs
 
 
 def test_bare_two_gpu_bench_command_launches_its_own_ranks():
