@@ -2,7 +2,9 @@
   - VGPRs, scratch bytes (small arrays indexed by a run-time trip count land in scratch: DESIGN 4.2),
   - vector loads that are WAITED FOR AT ONCE (`s_waitcnt vmcnt(0)` within four instructions and no other load in
     between): a load inside a branch with its use, a load behind a uniform `if`, a pointer fetched from the argument
-    segment -- in a prologue or a loop each one is a dependent memory round trip.
+    segment -- in a prologue or a loop each one is a dependent memory round trip,
+  - scalar registers spilled into vector lanes and the v_readlane / v_writelane instructions that serve them (in an
+    arithmetic-bound loop they are issue slots: DESIGN 4.7).
 `python tools/isa_scan.py [unit ...]` (default: every translation unit); prints the kernels with three or more."""
 import glob, os, re, subprocess, sys, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -27,6 +29,9 @@ for unit in units:
         vg = re.search(r'\.amdhsa_next_free_vgpr (\d+)', meta).group(1)
         sc = re.search(r'\.amdhsa_private_segment_fixed_size (\d+)', meta).group(1)
         spills = sum('scratch_' in l for l in ins)
-        if len(hits) >= 3 or spills:
-            print('%-22s %-62s %5d instr  %3s VGPRs  scratch %3s B (%d ops)  loads waited for at once: %2d  %s'
-                  % (unit, name[8:70], len(ins), vg, sc, spills, len(hits), hits[:8]))
+        md = re.search(r'\.name:\s+' + re.escape(name) + r'\n(?:.*\n)*?\s+\.sgpr_spill_count:\s+(\d+)', s)
+        sspill = int(md.group(1)) if md else 0             # scalar registers spilled into vector lanes: v_readlane / v_writelane traffic
+        lane = sum(l.startswith(('v_readlane', 'v_writelane')) for l in ins)
+        if len(hits) >= 3 or spills or sspill >= 64:
+            print('%-22s %-62s %5d instr  %3s VGPRs  scratch %3s B (%d ops)  scalar spills %3d (%d lane ops)  loads waited for at once: %2d  %s'
+                  % (unit, name[8:70], len(ins), vg, sc, spills, sspill, lane, len(hits), hits[:8]))
