@@ -800,6 +800,85 @@ int r4r_batch_build(const int32_t *user_tok, const int64_t *user_rev_off, const 
                     const int64_t *ku, const int64_t *ki, const int64_t *held, int train, int64_t *out,
                     int64_t n, int T, int R, int W, int64_t pad_user, int64_t pad_item, void *stream);
 
+/* ------------------------------------------------------------------------
+ * Spans: K training steps per host call (csrc/span.hip).
+ * Replaces  the body of the epoch loop, K iterations at a time        main.py:23-60
+ *             for data, y in reader.iter(): zero_grad -> model(data) -> loss -> backward -> optimizer.step()
+ *           with the batcher's slices                                  data_fast.py:99-109, data.py:250-372
+ * for K consecutive FULL batches of an epoch: r4r_batch_build for a GROUP of batches per launch into a ring
+ * of two groups, then the family's native step per batch, everything enqueued on `stream` from C.  The kernels are
+ * those of the per-step entry points with the same arguments -- a span and K single steps give the same bits --; what
+ * changes between two steps (batch pointers, adam_step, the dropout stream position, the token buffer, the sweep
+ * schedule) advances here exactly as the per-step caller advances it.
+ *
+ * `loader`: HOST array of R4R_LOADER_WORDS uint64 describing the epoch (reviews4rec_amd/data.py builds it):
+ *    0..3  user pool tok, rev_off, first, nb     4..7  item pool     8, 9  held_tok, held_off   (r4r_batch_build's)
+ *   10..15 u, i, ku, ki, held (int64 [N]), y (float [N]): the epoch's ratings in loader order
+ *   16 train  17 T  18 R  19 W  20 pad_user  21 pad_item                                          (r4r_batch_build's)
+ *   22 ring: int64 device buffer of 2 groups, 0 = an ids-only loader (iter_simple: words 0..9, 12..14, 16..23 unused)
+ *   23 ring stride per group (int64 elements, >= G * B * (3 doc + 20))   24 N   25 G batches per group   26 B
+ * Batch b = ratings [b B, (b + 1) B); only the N / B full batches are reachable (a ragged tail goes through the
+ * per-step entry).  built_group (host, in / out): the highest group whose block is in the ring, -1 before the
+ * epoch's first span; groups are built in order as the steps reach them (the next one before the current one's last
+ * step).  announce: a full batch follows the span and the last step announces it (its token marks ride on that
+ * step's backward launch: pass tokens_ready = 1, token_buffer = the other buffer to whatever trains on it next).
+ * steps_done (host, out, nullable): steps enqueued before an error.  token_buffer / tokens_ready / offset /
+ * adam_step / sweep_*: the FIRST step's; step k runs with token_buffer ^ (k & 1), tokens_ready = 1 (k > 0),
+ * offset + k * draws_per_step, adam_step + k.  sweep_period / sweep_want: the schedule in force and the one wanted
+ * (engine.py _SweepSchedule: a step visits every chunk iff they differ or the period is 1, and the wanted one is in
+ * force afterwards); *sweep_base / *sweep_period_out carry the schedule across calls.  Training steps only
+ * (flat_g, moments and adam_step >= 1 required); all other arguments as in the family's r4r_*_step.
+ * r4r_span_build: make sure the group of `batch` is in the ring.  r4r_span_batch: the eight device pointers of a
+ * built batch -- this, who, what, user doc, item doc, uid, iid, y (data_fast.py:101-109 order) -- into HOST slots[8]. */
+#define R4R_LOADER_WORDS 28
+int r4r_span_build(const uint64_t *loader, int64_t batch, int64_t *built_group, void *stream);
+int r4r_span_batch(const uint64_t *loader, int64_t batch, uint64_t *slots);
+int r4r_deepconn_span(const uint64_t *loader, int64_t first_batch, int64_t steps, int announce,
+                      int64_t *built_group, int64_t *steps_done, const float *table, int64_t V, float *flat_p,
+                      float *flat_g, float *pred, float *se, float *sse_accum, void *ws, size_t ws_bytes, int T,
+                      int E, int L, float dropout_p, int training, uint64_t seed, uint64_t offset,
+                      uint64_t draws_per_step, float inv_denom, int conv_algo, int token_buffer, int tokens_ready,
+                      float *flat_m, float *flat_v, float lr, double beta1, double beta2, float eps,
+                      float weight_decay, int64_t adam_step, void *stream);
+int r4r_deepconnpp_span(const uint64_t *loader, int64_t first_batch, int64_t steps, int announce,
+                        int64_t *built_group, int64_t *steps_done, const float *table, int64_t V, float *flat_p,
+                        float *flat_g, float *flat_m, float *flat_v, const uint64_t *rows_p,
+                        const uint64_t *rows_m, const uint64_t *rows_v, int64_t n_users, int64_t n_items,
+                        float *pred, float *se, float *sse_accum, void *ws, size_t ws_bytes, int T, int E, int L,
+                        float dropout_p, int training, uint64_t seed, uint64_t offset, uint64_t draws_per_step,
+                        float inv_denom, int conv_algo, int token_buffer, int tokens_ready, float lr, double beta1,
+                        double beta2, float eps, float weight_decay, int64_t adam_step, void *stream);
+int r4r_narre_span(const uint64_t *loader, int64_t first_batch, int64_t steps, int announce, int64_t *built_group,
+                   int64_t *steps_done, const float *table, int64_t V, float *flat_p, float *flat_g, float *flat_m,
+                   float *flat_v, const uint64_t *rows_p, const uint64_t *rows_m, const uint64_t *rows_v,
+                   int64_t n_users, int64_t n_items, float *pred, float *se, float *sse_accum, void *ws,
+                   size_t ws_bytes, int R, int T, int E, int L, float dropout_p, int training, uint64_t seed,
+                   uint64_t offset, uint64_t draws_per_step, float inv_denom, int conv_algo, int token_buffer,
+                   int tokens_ready, float lr, double beta1, double beta2, float eps, float weight_decay,
+                   int64_t adam_step, void *stream);
+int r4r_transnet_span(const uint64_t *loader, int64_t first_batch, int64_t steps, int announce,
+                      int64_t *built_group, int64_t *steps_done, const float *table, int64_t V, float *flat_p,
+                      float *flat_g, float *flat_m, float *flat_v, const uint64_t *rows_p, const uint64_t *rows_m,
+                      const uint64_t *rows_v, int64_t n_users, int64_t n_items, float *pred, float *se,
+                      float *sse_accum, void *ws, size_t ws_bytes, int T, int E, int L, int plus, float dropout_p,
+                      int training, uint64_t seed, uint64_t offset, uint64_t draws_per_step, float inv_denom,
+                      int conv_algo, int token_buffer, int tokens_ready, int sweep_period, int sweep_want,
+                      int64_t *sweep_base, int *sweep_period_out, float lr, double beta1, double beta2, float eps,
+                      float weight_decay, int64_t adam_step, void *stream);
+int r4r_mf_span(const uint64_t *loader, int64_t first_batch, int64_t steps, int64_t *steps_done, const uint64_t *p,
+                const uint64_t *m, const uint64_t *v, int64_t n_users, int64_t n_items, int D, float *pred,
+                float *se, float *sse_accum, void *ws, size_t ws_bytes, float dropout_p, int training,
+                uint64_t seed, uint64_t offset, uint64_t draws_per_step, float inv_denom, int sweep_period,
+                int sweep_want, int64_t *sweep_base, int *sweep_period_out, float lr, double beta1, double beta2,
+                float eps, float weight_decay, int64_t adam_step, void *stream);
+int r4r_idnet_span(const uint64_t *loader, int64_t first_batch, int64_t steps, int64_t *steps_done, int variant,
+                   float *flat_p, float *flat_g, float *flat_m, float *flat_v, const uint64_t *rows_p,
+                   const uint64_t *rows_m, const uint64_t *rows_v, int64_t n_users, int64_t n_items, float *pred,
+                   float *se, float *sse_accum, void *ws, size_t ws_bytes, int L, float dropout_p, int training,
+                   uint64_t seed, uint64_t offset, uint64_t draws_per_step, float inv_denom, int sweep_period,
+                   int sweep_want, int64_t *sweep_base, int *sweep_period_out, float lr, double beta1,
+                   double beta2, float eps, float weight_decay, int64_t adam_step, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

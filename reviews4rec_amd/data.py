@@ -153,6 +153,47 @@ def _np_neighbours(nb, rb, re, skip, pad):
     return np.where(ok, padded[np.where(ok, at, len(nb))], pad).astype(np.int64)
 
 
+class SpanDescriptor:
+    """Host-side view of one loader for r4r_*_span: `words` (ctypes uint64 [R4R_LOADER_WORDS], layout in
+    include/r4r.h), `built` (the ring's state, a c_int64 the C side advances), `full_batches`, `batch_size`, and the
+    tensors the words point at (kept alive here)."""
+
+    WORDS = 28
+
+    def __init__(self, loader):
+        import ctypes
+        hp, st, dev = loader.hyper_params, loader.store, loader.device
+        B, N = int(hp['batch_size']), len(loader.data)
+        self.batch_size, self.n_ratings, self.full_batches = B, N, N // B
+        self.review = loader.iter != loader.iter_simple
+        w = [0] * self.WORDS
+        if self.review:
+            narre = hp['model_type'] in ['NARRE']
+            T = int(hp['input_length'])
+            R, W = (int(hp['narre_num_reviews']), int(hp['narre_num_words'])) if narre else (0, 0)
+            doc = R * W if narre else T
+            d = loader._device_split()
+            self.group = G = max(1, loader.SPAN_RATINGS // B)
+            stride = G * B * (3 * doc + 2 * NEIGHBOURS)
+            self.ring = torch.empty(2 * stride, dtype=torch.int64, device=dev)
+            pools = list(st.users.device(dev)) + list(st.items.device(dev)) + list(st.held.device(dev))
+            self._keep = (pools, d, self.ring)
+            w[0:10] = [t.data_ptr() for t in pools]
+            w[10:16] = [d[k].data_ptr() for k in ('u', 'i', 'ku', 'ki', 'held', 'y')]
+            w[16:22] = [int(loader.this_index_user_item is not None), T, R, W, int(hp['total_users']) + 1,
+                        int(hp['total_items']) + 1]
+            w[22:24] = [self.ring.data_ptr(), stride]
+            self.doc_shape = (R, W) if narre else (T,)
+        else:
+            d = loader._device_split_simple()
+            self.group, self.ring, self._keep = 1, None, (d,)
+            w[10], w[11], w[15] = d['u'].data_ptr(), d['i'].data_ptr(), d['y'].data_ptr()
+            self.doc_shape = None
+        w[24:27] = [N, self.group, B]
+        self.words = (ctypes.c_uint64 * self.WORDS)(*w)
+        self.built = ctypes.c_int64(-1)
+
+
 class DataLoader():
     """data.DataLoader (data.py:11-447).  ``data`` is the rating list ``[[user, item, rating], ...]``;
     the dict arguments are the unpickled files of a dataset directory.  A loader built with
@@ -193,6 +234,7 @@ class DataLoader():
         self._dev_split = None
         self._dev_simple = None
         self._dev_negs = {}
+        self._span = None
 
     # ------------------------------------------------------------------ the reference's small methods
     @property
@@ -339,6 +381,38 @@ class DataLoader():
     def _on_device(self):
         return self.device.type == 'cuda'
 
+    def _device_batch(self, s, e):
+        """Ratings [s, e) of the split as one batch built on the device."""
+        d = self._device_split()
+        u, i = d['u'][s:e], d['i'][s:e]
+        f = self._review_fields_device(u, i, d['ku'][s:e], d['ki'][s:e], d['held'][s:e], (e - s,))
+        return f + [u, i], d['y'][s:e]
+
+    def batch(self, b):
+        """Batch number b of iter() by itself (device loaders): what a caller that runs most of an epoch through
+        span_descriptor() uses for the steps it keeps to itself (a ragged tail, a step it wants to look at)."""
+        bsz, n = int(self.hyper_params['batch_size']), len(self.data)
+        s, e = b * bsz, min(n, (b + 1) * bsz)
+        if self.iter == self.iter_simple:
+            d = self._device_split_simple()
+            return [None, None, None, None, None, d['u'][s:e], d['i'][s:e]], d['y'][s:e]
+        return self._device_batch(s, e)
+
+    # ------------------------------------------------------------------ spans (include/r4r.h: r4r_*_span)
+    SPAN_RATINGS = 1024          # ratings per r4r_batch_build launch of a span (a group of batches)
+
+    def span_descriptor(self):
+        """The epoch as the native K-steps-per-call entry points read it (include/r4r.h, "Spans"): the host array of
+        R4R_LOADER_WORDS words over this loader's HBM-resident pools and split arrays, plus the ring the batch groups
+        are built into.  None on the host (no device, nothing to enqueue).  The ring's state (`built`) restarts with
+        every call: one descriptor per epoch, like one `iter()` per epoch."""
+        if not self._on_device():
+            return None
+        if self._span is None:
+            self._span = SpanDescriptor(self)
+        self._span.built.value = -1
+        return self._span
+
     # ------------------------------------------------------------------ iterators
     def iter_review(self, eval=False, simple=False, batch=None):
         """data.py:250-333: contiguous slices of batch_size ratings (ragged tail), the 7-slot list.
@@ -347,12 +421,8 @@ class DataLoader():
         bsz = int(batch or self.hyper_params['batch_size'])
         n = len(self.data)
         if self._on_device() and not simple:
-            d = self._device_split()
             for s in range(0, n, bsz):
-                e = min(n, s + bsz)
-                u, i = d['u'][s:e], d['i'][s:e]
-                f = self._review_fields_device(u, i, d['ku'][s:e], d['ki'][s:e], d['held'][s:e], (e - s,))
-                yield f + [u, i], d['y'][s:e]
+                yield self._device_batch(s, min(n, s + bsz))
             return
         ku, ki, held = self._split_arrays()
         for s in range(0, n, bsz):

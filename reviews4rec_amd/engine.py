@@ -60,6 +60,66 @@ def step_or_nothing(fn):
     return wrapped
 
 
+class _RawPtr:
+    """A device address standing in for a tensor where only ``ptr(t)`` is taken: a batch inside a span loader's ring."""
+    __slots__ = ('p', 'keep')
+
+    def __init__(self, p, keep=None):
+        self.p, self.keep = int(p), keep
+
+    def data_ptr(self):
+        return self.p
+
+
+def _span_slots(desc, batch):
+    """The eight device addresses of batch `batch` of a span loader (this, who, what, user doc, item doc, uid, iid, y)."""
+    slots = (ctypes.c_uint64 * 8)()
+    _lib.check(_lib.lib().r4r_span_batch(desc.words, int(batch), slots), 'r4r_span_batch')
+    return slots
+
+
+class _Spans:
+    """K training steps per host call (include/r4r.h, "Spans"; csrc/span.hip): main.py:23-60's loop body enqueued from C
+    for the FULL batches of a device-side loader's epoch -- the batch construction for a group of batches per launch,
+    the family's native step per batch.  The kernels and their arguments are the per-step path's, so an epoch run
+    through spans leaves the same bits as the same epoch run through train_step (tests/test_gpu_span.py); what the
+    per-step path pays per batch on the host (the iterator, six tensor slices, two ctypes calls of 25 and 35
+    arguments: 70-100 us, more than NARRE's or MF_dot's whole step takes on the device) is paid once per SPAN_STEPS
+    batches.  Steps a span cannot carry -- a ragged last batch, a step whose conv-rule probe reads a counter back --
+    go through train_step in their place."""
+    SPAN_STEPS = 64              # steps per host call (a call cannot be interrupted; 64 steps are 1.5-7 ms)
+
+    def _span_ok(self, desc):
+        return False
+
+    def _span_limit(self, desc, ahead=0):
+        """How many consecutive steps, starting `ahead` steps from now, one call may carry (0: that step is its own)."""
+        return self.SPAN_STEPS
+
+    def train_epoch(self, reader):
+        """One epoch over ``reader`` (data.DataLoader on the device): every batch of ``reader.iter()``, in order, as
+        main.train's loop would train on it.  -> (ratings, batches), or None when this reader / engine pair has no
+        span form (the caller iterates)."""
+        if os.environ.get('R4R_SPANS', '1') == '0' or getattr(self, 'dp', None) is not None and self.dp.on:
+            return None
+        desc = reader.span_descriptor() if hasattr(reader, 'span_descriptor') else None
+        if desc is None or desc.full_batches == 0 or not self._span_ok(desc):
+            return None
+        kw = {'defer_sweep': True} if getattr(self, 'TEMPORAL_SWEEP', False) else {}
+        nb, total, b = desc.full_batches, len(reader), 0
+        while b < total:
+            k = min(self._span_limit(desc), self.SPAN_STEPS, nb - b) if b < nb else 0
+            if k <= 0:                                       # the ragged tail, a probing step
+                data, y = reader.batch(b)
+                self.train_step(data, y, n_global=int(y.shape[0]), **kw)
+                b += 1
+                continue
+            announce = b + k < nb and self._span_limit(desc, ahead=k) > 0
+            self._span(desc, b, k, announce)
+            b += k
+        return float(desc.n_ratings), float(total)
+
+
 def load_named_moments(who, m, v, sd):
     """Copy a checkpoint's per-parameter Adam moments into the engine's views -- after checking every one of them (a
     missing name or a size mismatch raises before anything was written: a rejected checkpoint leaves the engine as it
@@ -282,6 +342,28 @@ class _ConvRule:
                 self._rule_n += 1
         return req, lib.r4r_conv_algo(req, docs_per_tower, T, self.E, 100), probe
 
+    def _rule_peek(self, docs_per_tower, T, ahead=0):
+        """For spans of TRAINING steps.  -> (how many consecutive steps, starting `ahead` steps from now, run on one
+        request without a probe -- 0: that step probes --, the request, the algorithm that runs, whether the rule
+        counts these steps).  Changes nothing; `_rule_advance` after the steps ran."""
+        lib = _lib.lib()
+        if getattr(self, 'gemm_math', 'f32') == 'f16x2':
+            return 0, None, None, False                      # (the fp16-split GEMM refreshes its scales between steps)
+        req = self.conv_algo
+        static = lib.r4r_conv_algo(0, docs_per_tower, T, self.E, 100) if req == 0 else req
+        small = (req == 0 and static != 2 and self.V <= self.SMALL_LAUNCH_MAX_V
+                 and lib.r4r_conv_algo(2, docs_per_tower, T, self.E, 100) == 2)
+        if not (req == 0 and (static == 2 or small)):
+            return 1 << 30, req, lib.r4r_conv_algo(req, docs_per_tower, T, self.E, 100), False
+        n = self._rule_n + int(ahead)
+        to_probe = self.PROBE_AT - n if n <= self.PROBE_AT else (self.PROBE_AT - n) % self.PROBE_EVERY
+        req = 2 if self._rule_choice is None else self._rule_choice
+        return to_probe, req, lib.r4r_conv_algo(req, docs_per_tower, T, self.E, 100), True
+
+    def _rule_advance(self, steps, counted):
+        if counted:
+            self._rule_n += int(steps)
+
     def _rule_decide(self, counters, docs_total, T):
         """`counters`: per tower the int32 [live, last] pair of the token buffer the probe step used."""
         torch.cuda.current_stream(self.dev).synchronize()
@@ -299,7 +381,7 @@ class _ConvRule:
         return {None: None, 1: 'direct', 2: 'project'}[self._rule_choice]
 
 
-class DeepCoNNEngine(_ConvRule):
+class DeepCoNNEngine(_ConvRule, _Spans):
     def __init__(self, model, lr=0.002, weight_decay=1e-6, betas=(0.9, 0.999), eps=1e-8, dp=None,
                  seed=0x5EED5EED, rank=0, conv_algo=0):
         hp = model.hyper_params
@@ -521,6 +603,60 @@ class DeepCoNNEngine(_ConvRule):
         self._exchange_and_update(self.flat_p, self.flat_g, self.flat_m, self.flat_v, self.step_count)
         return se
 
+    # ------------------------------------------------------------------ spans (K steps per host call)
+    def _span_ok(self, desc):
+        return desc.review and len(desc.doc_shape) == 1
+
+    def _span_limit(self, desc, ahead=0):
+        return self._rule_peek(desc.batch_size, desc.doc_shape[0], ahead)[0]
+
+    @torch.no_grad()
+    def _span(self, desc, first, steps, announce):
+        """Steps on batches first .. first + steps - 1 of the loader behind `desc` in ONE C call (r4r_deepconn_span); the
+        engine's per-step state moves as `steps` train_step calls with next_data would have moved it."""
+        lib = _lib.lib()
+        B, T = desc.batch_size, desc.doc_shape[0]
+        pred, se = self._outputs(B)
+        ws = self._workspace(B, T)
+        main = torch.cuda.current_stream(self.dev)
+        _, req, algo, counted = self._rule_peek(B, T)
+        projecting = algo == 2
+        slots = _span_slots(desc, first)
+        ready = 0
+        if projecting and self._prepared is not None and self._prepared[0] == (slots[3], slots[4], B, T):
+            buf, ev = self._prepared[1], self._prepared[2]
+            if ev is not None:
+                main.wait_event(ev)
+            self._prepared = None
+            ready = 1
+        else:
+            if self._prepared is not None:
+                self._discard_prepared(main)
+            buf = self._last_buf ^ 1
+        training, p_drop = self.model.training, float(self.hp['dropout'])
+        draws = B * 2 * self.L if (training and p_drop > 0.0) else 0
+        done = ctypes.c_int64(0)
+        rc = lib.r4r_deepconn_span(
+            desc.words, int(first), int(steps), int(bool(announce)), ctypes.byref(desc.built), ctypes.byref(done),
+            ptr(self.table), self.V, ptr(self.flat_p), ptr(self.flat_g), ptr(pred), ptr(se), ptr(self.sse), ptr(ws),
+            ws.numel(), T, self.E, self.L, p_drop, int(training), self.seed, self.offset, draws, 1.0 / float(B), req, buf,
+            ready, ptr(self.flat_m), ptr(self.flat_v), self.lr, self.betas[0], self.betas[1], self.eps, self.wd,
+            self.step_count + 1, main.cuda_stream)
+        k = int(done.value)                                  # (an error names the step it stopped at: the state follows)
+        self.step_count += k
+        self.offset += k * draws
+        self._rule_advance(k, counted)
+        if k:
+            self._last_buf = (buf + k - 1) & 1
+            if self._side is not None:
+                ev = torch.cuda.Event()
+                ev.record(main)
+                self._step_done = [ev, ev]
+        if rc == 0 and announce and projecting:
+            nx = _span_slots(desc, first + steps)
+            self._prepared = ((nx[3], nx[4], B, T), self._last_buf ^ 1, None, (_RawPtr(nx[3], desc), _RawPtr(nx[4], desc)))
+        _lib.check(rc, 'r4r_deepconn_span')
+
     def _exchange_prepare(self, how):
         """What this rank needs, by itself, before exchange form `how` can run (no collective in here)."""
         if how == 'gather' and self._gathered is None:
@@ -700,7 +836,7 @@ class DeepCoNNEngine(_ConvRule):
                  zip(names, self.slots, self.offsets, self.sizes)})
 
 
-class MFEngine(_SweepSchedule):
+class MFEngine(_SweepSchedule, _Spans):
     """Native step for model_type 'MF_dot' / 'bias_only' (csrc/mf_engine.hip, r4r_mf_step): forward,
     loss, backward and the dense Adam update of MF.py / main.py:56-60,94-96 in two launches; the
     dense gradient of an ID table is never materialised.  Same calling surface as DeepCoNNEngine
@@ -828,6 +964,37 @@ class MFEngine(_SweepSchedule):
         if train_mode and float(self.hp['dropout']) > 0.0:
             self.offset += n * 2 * self.D
         return pred, se
+
+    # ------------------------------------------------------------------ spans (K steps per host call)
+    def _span_ok(self, desc):
+        return not desc.review and desc.batch_size <= self.MAX_TRAIN_BATCH
+
+    @torch.no_grad()
+    def _span(self, desc, first, steps, announce):
+        """`steps` consecutive train_step(defer_sweep=True) calls as ONE C call (r4r_mf_span)."""
+        lib, B = _lib.lib(), desc.batch_size
+        if B not in self._out:
+            self._out[B] = (torch.empty(B, dtype=torch.float32, device=self.dev),
+                            torch.empty(B, dtype=torch.float32, device=self.dev))
+        pred, se = self._out[B]
+        ws = self._workspace(B)
+        training, p_drop = self.model.training, float(self.hp['dropout'])
+        draws = B * 2 * self.D if (training and p_drop > 0.0) else 0
+        want = self.sweep_period if self.has_tables else 1
+        base, period, done = ctypes.c_int64(self._tb_base), ctypes.c_int(self._tb_period), ctypes.c_int64(0)
+        rc = lib.r4r_mf_span(
+            desc.words, int(first), int(steps), ctypes.byref(done), self._ptrs(self.params), self._ptrs(self.m),
+            self._ptrs(self.v), self.n_users, self.n_items, self.D, ptr(pred), ptr(se), ptr(self.sse), ptr(ws), ws.numel(),
+            p_drop, int(training), self.seed, self.offset, draws, 1.0 / float(B), self._tb_period, want,
+            ctypes.byref(base), ctypes.byref(period), self.lr, self.betas[0], self.betas[1], self.eps, self.wd,
+            self.step_count + 1, _lib.current_stream())
+        k = int(done.value)
+        self.step_count += k
+        self.offset += k * draws
+        self._tb_base, self._tb_period = int(base.value), int(period.value)
+        if k and want > 1:
+            self._tb_used = True
+        _lib.check(rc, 'r4r_mf_span')
 
     @torch.no_grad()
     def _train_step_dp(self, data, y, n_global, defer=False):
@@ -993,7 +1160,7 @@ class MFEngine(_SweepSchedule):
             ws.zero_()
 
 
-class NarreEngine(_ConvRule):
+class NarreEngine(_ConvRule, _Spans):
     """Native step for NARRE (csrc/narre_engine.hip, r4r_narre_step): TextCNN over the B*R review
     documents of each side, both attention scorers, the ID vectors, `final`, the bias head, SE,
     the backward and the dense Adam update in five launches (the op-by-op path needs ~130).
@@ -1174,6 +1341,76 @@ class NarreEngine(_ConvRule):
             at = [self._ws_offset(n, R, T, 6 + 2 * t + buf) for t in range(self.NTOWER)]
             self._rule_decide([ws[a:a + 8] for a in at], self.NTOWER * n * R, T)
         return pred, se
+
+    # ------------------------------------------------------------------ spans (K steps per host call)
+    def _span_doc(self, desc):
+        """(R, T) of the loader's documents if this family trains on them, else None."""
+        if not desc.review or len(desc.doc_shape) != 2:
+            return None
+        R, W = desc.doc_shape
+        if desc.batch_size * (1 + R) > self.FUSED_MAX_ENTRIES or self.L > 32 or R > 32:
+            return None                                      # (train_step's split form: per step)
+        return R, W
+
+    def _span_towers(self, slots):
+        return (slots[3], slots[4])                          # the documents the TextCNN towers read: user, item
+
+    def _span_ok(self, desc):
+        return self._span_doc(desc) is not None
+
+    def _span_limit(self, desc, ahead=0):
+        R, T = self._span_doc(desc)
+        return self._rule_peek(desc.batch_size * R, T, ahead)[0]
+
+    def _span_call(self, lib, desc, first, steps, announce, done, pred, se, ws, R, T, draws, buf, ready, stream):
+        return lib.r4r_narre_span(
+            desc.words, int(first), int(steps), int(bool(announce)), ctypes.byref(desc.built), ctypes.byref(done),
+            ptr(self.table), self.V, ptr(self.flat_p), ptr(self.flat_g), ptr(self.flat_m), ptr(self.flat_v),
+            self._p4(self.rows), self._p4(self.rows_m), self._p4(self.rows_v), self.n_users, self.n_items, ptr(pred),
+            ptr(se), ptr(self.sse), ptr(ws), ws.numel(), R, T, self.E, self.L, float(self.hp['dropout']),
+            int(self.model.training), self.seed, self.offset, draws, 1.0 / float(desc.batch_size), self._algo_req, buf,
+            ready, self.lr, self.betas[0], self.betas[1], self.eps, self.wd, self.step_count + 1, stream)
+
+    @torch.no_grad()
+    def _span(self, desc, first, steps, announce):
+        """`steps` consecutive train_step calls (each announcing its successor) as ONE C call (r4r_<family>_span)."""
+        lib, B = _lib.lib(), desc.batch_size
+        R, T = self._span_doc(desc)
+        if B not in self._out:
+            self._out[B] = (torch.empty(B, dtype=torch.float32, device=self.dev),
+                            torch.empty(B, dtype=torch.float32, device=self.dev))
+        pred, se = self._out[B]
+        ws = self._workspace(B, R, T)
+        _, self._algo_req, algo, counted = self._rule_peek(B * R, T)
+        projecting = algo == 2
+        key = self._span_towers(_span_slots(desc, first)) + (B, R, T)
+        ready = 0
+        if projecting and self._prepared is not None and self._prepared[0] == key:
+            buf, ready = self._prepared[1], 1
+            self._prepared = None
+        else:
+            if self._prepared is not None:                   # a state nobody will consume: drop it (as _launch does)
+                pb = self._prepared[1]
+                for t in range(self.NTOWER):
+                    at = self._ws_offset(B, R, T, 6 + 2 * t + pb)
+                    ws[at:at + 4].zero_()
+                self._prepared = None
+                self._last_buf = pb ^ 1
+            buf = self._last_buf ^ 1
+        draws = B * self._draws(R) if (self.model.training and float(self.hp['dropout']) > 0.0) else 0
+        done = ctypes.c_int64(0)
+        rc = self._span_call(lib, desc, first, steps, announce, done, pred, se, ws, R, T, draws, buf, ready,
+                             _lib.current_stream())
+        k = int(done.value)
+        self.step_count += k
+        self.offset += k * draws
+        self._rule_advance(k, counted)
+        if k:
+            self._last_buf = (buf + k - 1) & 1
+        if rc == 0 and announce and projecting:
+            nx = self._span_towers(_span_slots(desc, first + steps))
+            self._prepared = (nx + (B, R, T), self._last_buf ^ 1, [_RawPtr(a, desc) for a in nx])
+        _lib.check(rc, 'r4r_%s_span' % self.C)
 
     # ---- data parallel (SURVEY 8e): gradients only on this rank (the C step with flat_m = NULL), C1 -- one
     # all-reduce of the flat dense gradient + the flat Adam -- and C2: the ranks' compact ID rows gathered
@@ -1451,6 +1688,21 @@ class DeepCoNNPPEngine(NarreEngine):
             raise RuntimeError('DeepCoNNPPEngine: batches must be int64 tensors on the ROCm device')
         return [t.contiguous() for t in f], n, 1, f[0].shape[1]
 
+    def _span_doc(self, desc):
+        if not desc.review or len(desc.doc_shape) != 1 or desc.batch_size > 32768:
+            return None
+        return 1, desc.doc_shape[0]
+
+    def _span_call(self, lib, desc, first, steps, announce, done, pred, se, ws, R, T, draws, buf, ready, stream):
+        p2 = lambda ts: (ctypes.c_uint64 * 2)(*[t.data_ptr() for t in ts])   # noqa: E731
+        return lib.r4r_deepconnpp_span(
+            desc.words, int(first), int(steps), int(bool(announce)), ctypes.byref(desc.built), ctypes.byref(done),
+            ptr(self.table), self.V, ptr(self.flat_p), ptr(self.flat_g), ptr(self.flat_m), ptr(self.flat_v),
+            p2(self.rows), p2(self.rows_m), p2(self.rows_v), self.n_users, self.n_items, ptr(pred), ptr(se),
+            ptr(self.sse), ptr(ws), ws.numel(), T, self.E, self.L, float(self.hp['dropout']), int(self.model.training),
+            self.seed, self.offset, draws, 1.0 / float(desc.batch_size), self._algo_req, buf, ready, self.lr,
+            self.betas[0], self.betas[1], self.eps, self.wd, self.step_count + 1, stream)
+
     def _ws_bytes(self, B, R, T):
         return _lib.lib().r4r_deepconnpp_ws_bytes(B, T, self.E, self.L, self.V, self.n_users, self.n_items)
 
@@ -1542,6 +1794,31 @@ class TransNetEngine(NarreEngine, _SweepSchedule):
         if not all(t.is_cuda and t.dtype == torch.int64 for t in f):
             raise RuntimeError('TransNetEngine: batches must be int64 tensors on the ROCm device')
         return [t.contiguous() for t in f], n, 1, f[0].shape[1]
+
+    def _span_doc(self, desc):
+        if not desc.review or len(desc.doc_shape) != 1 or desc.batch_size > 32768:
+            return None
+        return 1, desc.doc_shape[0]
+
+    def _span_towers(self, slots):
+        return (slots[3], slots[4], slots[0])                # user documents, item documents, the review being rated
+
+    def _span_call(self, lib, desc, first, steps, announce, done, pred, se, ws, R, T, draws, buf, ready, stream):
+        p2 = lambda ts: (ctypes.c_uint64 * 2)(*[t.data_ptr() for t in ts]) if ts else None   # noqa: E731
+        want = self.sweep_period if self.has_tables else 1   # (main.train: defer_sweep=True for this family)
+        base, period = ctypes.c_int64(self._tb_base), ctypes.c_int(self._tb_period)
+        rc = lib.r4r_transnet_span(
+            desc.words, int(first), int(steps), int(bool(announce)), ctypes.byref(desc.built), ctypes.byref(done),
+            ptr(self.table), self.V, ptr(self.flat_p), ptr(self.flat_g), ptr(self.flat_m), ptr(self.flat_v),
+            p2(self.rows), p2(self.rows_m), p2(self.rows_v), self.n_users, self.n_items, ptr(pred), ptr(se),
+            ptr(self.sse), ptr(ws), ws.numel(), T, self.E, self.L, self.plus, float(self.hp['dropout']),
+            int(self.model.training), self.seed, self.offset, draws, 1.0 / float(desc.batch_size), self._algo_req, buf,
+            ready, self._tb_period, want, ctypes.byref(base), ctypes.byref(period), self.lr, self.betas[0],
+            self.betas[1], self.eps, self.wd, self.step_count + 1, stream)
+        self._tb_base, self._tb_period = int(base.value), int(period.value)
+        if int(done.value) and want > 1:
+            self._tb_used = True
+        return rc
 
     def _ws_bytes(self, B, R, T):
         return _lib.lib().r4r_transnet_ws_bytes(B, T, self.E, self.L, self.plus, self.V, self.n_users, self.n_items)
@@ -1722,7 +1999,7 @@ class TransNetEngine(NarreEngine, _SweepSchedule):
         return out
 
 
-class IdNetEngine(_SweepSchedule):
+class IdNetEngine(_SweepSchedule, _Spans):
     """Native step for the ID-only recommenders with dense layers -- model_type 'MF' (MF.py:60-68) and the
     NeuMF family (NeuMF.py: GMF / MLP / NeuMF) -- csrc/idnet_engine.hip, r4r_idnet_step: forward, loss,
     backward and the dense Adam update of main.py:56-60,94-96 in 4 launches (5 for NeuMF); the dense
@@ -1881,6 +2158,38 @@ class IdNetEngine(_SweepSchedule):
         if train_mode and float(self.hp['dropout']) > 0.0:
             self.offset += n * self.draws()
         return pred, se
+
+    # ------------------------------------------------------------------ spans (K steps per host call)
+    def _span_ok(self, desc):
+        return not desc.review and desc.batch_size <= self.MAX_TRAIN_BATCH
+
+    @torch.no_grad()
+    def _span(self, desc, first, steps, announce):
+        """`steps` consecutive train_step(defer_sweep=True) calls as ONE C call (r4r_idnet_span)."""
+        lib, B = _lib.lib(), desc.batch_size
+        if B not in self._out:
+            self._out[B] = (torch.empty(B, dtype=torch.float32, device=self.dev),
+                            torch.empty(B, dtype=torch.float32, device=self.dev))
+        pred, se = self._out[B]
+        ws = self._workspace(B)
+        training, p_drop = self.model.training, float(self.hp['dropout'])
+        draws = B * self.draws() if (training and p_drop > 0.0) else 0
+        want = self.sweep_period
+        base, period, done = ctypes.c_int64(self._tb_base), ctypes.c_int(self._tb_period), ctypes.c_int64(0)
+        rc = lib.r4r_idnet_span(
+            desc.words, int(first), int(steps), ctypes.byref(done), self.variant, ptr(self.flat_p), ptr(self.flat_g),
+            ptr(self.flat_m), ptr(self.flat_v), self._p6(self.rows), self._p6(self.rows_m), self._p6(self.rows_v),
+            self.n_users, self.n_items, ptr(pred), ptr(se), ptr(self.sse), ptr(ws), ws.numel(), self.L, p_drop,
+            int(training), self.seed, self.offset, draws, 1.0 / float(B), self._tb_period, want, ctypes.byref(base),
+            ctypes.byref(period), self.lr, self.betas[0], self.betas[1], self.eps, self.wd, self.step_count + 1,
+            _lib.current_stream())
+        k = int(done.value)
+        self.step_count += k
+        self.offset += k * draws
+        self._tb_base, self._tb_period = int(base.value), int(period.value)
+        if k and want > 1:
+            self._tb_used = True
+        _lib.check(rc, 'r4r_idnet_span')
 
     @step_or_nothing
     @torch.no_grad()

@@ -76,7 +76,16 @@ def train(model, criterion, optimizer, reader, hyper_params, engine=None, dp=Non
     # global batch sizes for the loss scale 1/B_global: ONE collective per epoch from the readers' batch
     # sizes (a per-step all-reduce + .item() would serialise the launch queue behind every batch)
     counts = dp.epoch_counts(reader) if dp_on else None
-    batches = _with_next(reader.iter()) if engine is not None else ((b, None) for b in reader.iter())
+    # a device-side loader + a native engine: the epoch's full batches go to the device K steps per host call
+    # (engine._Spans: the batch construction and the steps enqueued from C; the same kernels, arguments and bits)
+    spanned = None
+    if engine is not None and not dp_on and hyper_params.get('spans', True) and hasattr(engine, 'train_epoch'):
+        spanned = engine.train_epoch(reader)
+    if spanned is not None:
+        total_x, total_batches = spanned
+        batches = ()
+    else:
+        batches = _with_next(reader.iter()) if engine is not None else ((b, None) for b in reader.iter())
     for step_no, ((data, y), upcoming) in enumerate(batches):
         n_local = int(y.shape[0])
         if not dp_on:

@@ -29,6 +29,8 @@ def main():
     ap.add_argument('--embed', type=int, default=300)
     ap.add_argument('--batch', type=int, default=128)
     ap.add_argument('--model-type', default='deepconn')
+    ap.add_argument('--spans', type=int, default=1, help='0: main.train iterates the loader and steps per batch')
+    ap.add_argument('--epochs', type=int, default=3)
     args = ap.parse_args()
     import reviews4rec_amd
     from reviews4rec_amd import main as M, synthetic
@@ -41,7 +43,7 @@ def main():
     hp = dict(model_type=args.model_type, batch_size=args.batch, input_length=1000, narre_num_reviews=10,
               narre_num_words=100, total_users=args.users, total_items=args.items, latent_size=10,
               word_embed_size=args.embed, dropout=0.6, lr=0.002, weight_decay=1e-6, vocab=args.vocab,
-              total_words=args.vocab, engine='native')
+              total_words=args.vocab, engine='native', spans=bool(args.spans))
     hp['word_vectors'] = synthetic.word_table(args.vocab, args.embed)
     train = DataLoader(hp, d['train'], d['user_reviews'], d['item_reviews'], None,
                        this_index_user_item=d['this_index_user_item'], device='cuda')
@@ -58,8 +60,8 @@ def main():
     gc.collect()
     gc.freeze()                                              # as main.train_complete does before its loop
     out = {'model_type': args.model_type, 'train_ratings': len(d['train']), 'val_ratings': len(d['test']),
-           'batch': args.batch, 'embed': args.embed}
-    for epoch in range(2):
+           'batch': args.batch, 'embed': args.embed, 'spans': bool(args.spans)}
+    for epoch in range(args.epochs):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         metrics = M.train(model, criterion, None, train, hp, engine=engine)
@@ -73,6 +75,22 @@ def main():
                                   'us_per_step': round((t1 - t0) * 1e6 / len(train), 1), 'train_MSE': metrics['MSE'],
                                   'val_s': round(t2 - t1, 3), 'val_ratings_per_s': round(len(d['test']) / (t2 - t1)),
                                   'val_MSE': vm['MSE']}
+    # the same engine on the same loader's batches held RESIDENT (what bench.py times): the loop's ceiling on this data
+    keep = [b for _, b in zip(range(64), train.iter())]
+    keep = [b for b in keep if b[1].shape[0] == args.batch]
+    kw = {'defer_sweep': True} if getattr(engine, 'TEMPORAL_SWEEP', False) else {}
+    model.train()
+    for timed in (False, True):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        nsteps = 4 * len(keep)
+        for k in range(nsteps):
+            data, y = keep[k % len(keep)]
+            engine.train_step(data, y, n_global=args.batch, next_data=keep[(k + 1) % len(keep)][0], **kw)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+    out['resident'] = {'us_per_step': round((t1 - t0) * 1e6 / nsteps, 1),
+                       'train_ratings_per_s': round(nsteps * args.batch / (t1 - t0))}
     print(json.dumps(out))
 
 

@@ -4,7 +4,7 @@ import argparse, os, sys, time
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tools'))
-ap = argparse.ArgumentParser(); ap.add_argument('--model-type', default='deepconn'); ap.add_argument('--ratings', type=int, default=100000)
+ap = argparse.ArgumentParser(); ap.add_argument('--model-type', default='deepconn'); ap.add_argument('--ratings', type=int, default=100000); ap.add_argument('--embed', type=int, default=300)
 args = ap.parse_args()
 import reviews4rec_amd
 from reviews4rec_amd import main as M, synthetic
@@ -13,9 +13,9 @@ from reviews4rec_amd.utils import xavier_init
 from synth_reviews import synthesize
 d = synthesize(args.ratings, 40000, 15000, 50002, test=1000)
 hp = dict(model_type=args.model_type, batch_size=128, input_length=1000, narre_num_reviews=10, narre_num_words=100,
-          total_users=40000, total_items=15000, latent_size=10, word_embed_size=300, dropout=0.6, lr=0.002,
+          total_users=40000, total_items=15000, latent_size=10, word_embed_size=args.embed, dropout=0.6, lr=0.002,
           weight_decay=1e-6, vocab=50002, total_words=50002, engine='native')
-hp['word_vectors'] = synthetic.word_table(50002, 300)
+hp['word_vectors'] = synthetic.word_table(50002, args.embed)
 train = DataLoader(hp, d['train'], d['user_reviews'], d['item_reviews'], None,
                    this_index_user_item=d['this_index_user_item'], device='cuda')
 model = reviews4rec_amd.get_model_class(args.model_type)(hp); xavier_init(model); model = model.cuda().train()
