@@ -144,13 +144,16 @@ def parse():
                     help='untimed steps before the requested warm-up when --warmup is shorter than this: clocks '
                          'and launch queue reach steady state whatever --warmup says (reported as warmup_effective)')
     ap.add_argument('--opt-in-leg', action='store_true',
-                    help='also time the opt-in fp16-split-GEMM leg at N = 1 (off by default: it is not fp32 arithmetic '
-                         'and earns the line nothing)')
-    ap.add_argument('--no-opt-in-leg', action='store_true', help='(accepted for older scripts: the leg is off by default)')
+                    help='time the opt-in fp16-split-GEMM leg also where the configuration legs are off (it rides on the '
+                         'default N = 1 line; never `value`)')
+    ap.add_argument('--no-opt-in-leg', action='store_true', help='skip the opt-in arithmetic leg of the default N = 1 line')
     ap.add_argument('--gemm-math', choices=['f32', 'f16x2'], default='f32',
                     help='arithmetic of the projection GEMM: f32 (default, the headline: fp32 operands on the fp32 MFMA) or '
                          'the opt-in fp16-split form (every operand = hi + lo fp16, three f16-MFMA products per fp32 '
                          'product, fp32 accumulation; csrc/project_f16.hip) -- reported under its own dtype')
+    ap.add_argument('--per-step', action='store_true',
+                    help='native engine: one train_step call per step from Python (default: the steps are enqueued K per host '
+                         'call through the span entry points, r4r_*_span, as main.train enqueues them)')
     ap.add_argument('--engine', choices=['native', 'module', 'graph'], default='native',
                     help="native: fused r4r_deepconn_step where the model has one (else module); module: op-by-op "
                          "autograd path; graph: the module path captured into one hipGraph per step")
@@ -166,9 +169,7 @@ def blocked_sweep_leg(leg, engine, traffic, avg_s):
     leg['algorithmic_frac'] = leg['frac']
     leg['hbm_side_GBs'] = None if traffic is None else round(traffic / avg_s / 1e9, 1)
     leg['frac'] = None if traffic is None else round(traffic / avg_s / 1e9 / PEAK_HBM_GBS, 4)
-    leg['note'] = ('temporally blocked sweep (visit period %d): untouched chunks take several steps\' gradient-zero Adam '
-                   'updates per visit, so the algorithmic 24 B per parameter and step are not what crosses HBM; frac = '
-                   'PMC-counted HBM bytes per launch / launch time against the HBM peak' % engine.sweep_period)
+    leg['blocked_sweep_period'] = engine.sweep_period        # (frac = counter bytes per launch / launch time / HBM peak: DESIGN 5)
 
 
 def tower_flops_per_doc(hp):
@@ -256,6 +257,125 @@ def config_legs(args, env):
             out['dominant_kernel'] = r['roofline']['kernel']
         legs.append(out)
     return legs
+
+
+LEG_FIELDS = ['ratings_per_s', 'ms_per_step', 'dominant_kernel', 'kernel_ms', 'bound', 'frac', 'hbm_bytes_per_launch(pmc)']
+
+
+def compact_leg(leg):
+    """One `configs` leg as a short array in LEG_FIELDS order (+ the gather kernel's [ms, bound, frac, hbm_side_frac]
+    where the leg has one)."""
+    if 'error' in leg:
+        return {'error': leg['error'][:120]}
+    r = leg.get('roofline') or {}
+    out = [leg['ratings_per_s'], leg['ms_per_step'], r.get('kernel'), r.get('avg_launch_ms'), r.get('bound'), r.get('frac'),
+           r.get('traffic')]
+    g = leg.get('roofline_gather')
+    if g:
+        out.append([g.get('avg_launch_ms'), g.get('bound'), g.get('frac'), g.get('hbm_side_frac')])
+    return out
+
+
+def emit(result):
+    """The ONE JSON line, short enough to survive in the last 8 KB of stdout whole: the contract's fields, the roofline
+    legs, the CPU baseline, and -- last -- every configuration leg as a short array (`legs`, LEG_FIELDS order), the
+    opt-in arithmetic leg and the host-loop legs.  The full record (every leg's own roofline dictionaries) goes to
+    stderr and to gpurun_out/bench_line_full.json."""
+    full = json.dumps(result)
+    try:
+        os.makedirs(os.path.join(ROOT, 'gpurun_out'), exist_ok=True)
+        with open(os.path.join(ROOT, 'gpurun_out', 'bench_line_full.json'), 'w') as f:
+            f.write(full + '\n')
+    except OSError:
+        pass
+    print('bench.py full record: ' + full, file=sys.stderr, flush=True)
+    line = dict(result)
+    legs = line.pop('configs', None)
+    opt_in = line.pop('opt_in_f16_split', None)
+    host = line.pop('host_loop', None)
+    for key in ('roofline', 'roofline_gather', 'roofline_gemm'):
+        if key in line:
+            line[key] = {k: v for k, v in line[key].items() if k not in ('traffic_source', 'launches_in_timed_region',
+                         'positions_per_launch', 'walked_positions_per_launch', 'projected_rows_bytes',
+                         'distinct_token_rows_per_launch', 'algorithmic_GBs', 'steady_launches')}
+    if 'steady' in line:
+        line['steady'] = {k: line['steady'][k] for k in ('steps', 'ratings_per_s', 'ms_per_step') if k in line['steady']}
+    line.pop('conv_equivalent', None)
+    if legs is not None:
+        line['leg_fields'] = LEG_FIELDS
+        line['legs'] = {leg['leg']: compact_leg(leg) for leg in legs}
+    if opt_in is not None:
+        line['legs_opt_in_f16_split'] = [opt_in['ratings_per_s'], opt_in['ms_per_step']]
+    if host is not None:
+        line['host_loop_fields'] = ['main.train ratings_per_s', 'same engine, batches resident', 'train MSE']
+        line['host_loop'] = host
+    print(json.dumps(line), flush=True)
+
+
+def host_loop_legs(env, ratings=20000):
+    """The PRODUCT loop beside the bench's resident-pool loop: reviews4rec_amd.main.train over data.DataLoader (every
+    batch built on the device from HBM-resident token pools, data.py:250-372's slices) driving the native engine through
+    the span entry points, one epoch of `ratings` Amazon-shaped synthetic ratings in the reference's pickled schema
+    (tools/synth_reviews.py), second and third epoch timed (the first warms workspaces); and the same engine on the
+    loader's own batches held resident.  -> {family: [loop ratings/s, resident ratings/s, train MSE]}"""
+    sys.path.insert(0, os.path.join(ROOT, 'tools'))
+    import reviews4rec_amd
+    from reviews4rec_amd import main as M, synthetic
+    from reviews4rec_amd.data import DataLoader
+    from reviews4rec_amd.loss import MSELoss
+    from reviews4rec_amd.utils import xavier_init
+    from synth_reviews import synthesize
+    users, items, vocab, B = 8000, 3000, 50002, 128
+    d = synthesize(ratings, users, items, vocab)
+    out = {}
+    for label, mt, E in (('deepconn_e300', 'deepconn', 300), ('narre_e64', 'NARRE', 64), ('mf_dot', 'MF_dot', 64)):
+        hp = dict(model_type=mt, batch_size=B, input_length=1000, narre_num_reviews=10, narre_num_words=100,
+                  total_users=users, total_items=items, latent_size=10 if mt != 'MF_dot' else 64, word_embed_size=E,
+                  dropout=0.6, lr=0.002, weight_decay=1e-6, vocab=vocab, total_words=vocab, engine='native')
+        hp['word_vectors'] = synthetic.word_table(vocab, E)
+        train = DataLoader(hp, d['train'], d['user_reviews'], d['item_reviews'], None,
+                           this_index_user_item=d['this_index_user_item'], device=env['dev'])
+        torch.manual_seed(0)
+        model = reviews4rec_amd.get_model_class(mt)(hp)
+        xavier_init(model)
+        model = model.to(env['dev'])
+        engine = M.make_engine(hp, model)
+        best, mse = None, None
+        for epoch in range(3):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            mse = M.train(model, MSELoss(hp), None, train, hp, engine=engine)['MSE']
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            if epoch:
+                best = dt if best is None else min(best, dt)
+        keep = [b for _, b in zip(range(32), train.iter())]
+        keep = [b for b in keep if b[1].shape[0] == B]
+        kw = {'defer_sweep': True} if getattr(engine, 'TEMPORAL_SWEEP', False) else {}
+        from reviews4rec_amd.data import SpanDescriptor
+        desc = SpanDescriptor.resident(keep, review=mt != 'MF_dot')
+        model.train()
+        res = None
+        for rep in range(3):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            n = 0
+            while n < 4 * len(keep):
+                k = min(engine._span_limit(desc), engine.SPAN_STEPS)
+                if k <= 0:
+                    engine.train_step(*keep[n % len(keep)], n_global=B, **kw)
+                    k = 1
+                else:
+                    engine._span(desc, n, k, True)
+                n += k
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            if rep:
+                res = n * B / dt if res is None else max(res, n * B / dt)
+        out[label] = [round(len(d['train']) / best), round(res), mse]
+        del engine, model, train
+        torch.cuda.empty_cache()
+    return out
 
 
 def cpu_baseline(hp, table, batches_np, budget_s):
@@ -392,10 +512,14 @@ def main():
     if rank == 0:
         if config_legs_wanted(args, dp_job):
             result['configs'] = config_legs(args, env)
+            try:
+                result['host_loop'] = host_loop_legs(env)
+            except (Exception, SystemExit) as e:             # noqa: BLE001  (reported, not raised: the headline line stands)
+                result['host_loop'] = {'error': '%s: %s' % (type(e).__name__, str(e)[:200])}
         if not dp_job and not args.no_cpu_baseline:
             result['cpu_baseline'] = result.pop('_cpu_baseline_thunk')()
         result.pop('_cpu_baseline_thunk', None)
-        print(json.dumps(result), flush=True)
+        emit(result)
     if dp_job:
         if env.get('dp') is not None:
             env['dp'].close()                                # the on-stream communicator, before the process group it was built over
@@ -525,6 +649,41 @@ def run(args, env, is_leg=False):
 
     step = make_step(pool, B, B_global)
 
+    # The product loop (main.train over a device-side loader) enqueues the steps K per host call (engine._Spans ->
+    # r4r_*_span: the same kernels and arguments as train_step, bit for bit); so does the bench, over its resident pool.
+    span_desc = None
+    if (engine is not None and not dp_job and not args.from_host and graphed is None and not args.per_step
+            and args.token_prefetch == 'fused' and hasattr(engine, '_span')):
+        from reviews4rec_amd.data import SpanDescriptor
+        d = SpanDescriptor.resident(pool, review=bool(hp.get('vocab')))
+        if engine._span_ok(d):
+            span_desc = d
+
+    def run_steps(step_fn, first, count, mask=0, sample=None):
+        """Steps first .. first + count - 1; the sampled ones (kernel timing on) by themselves."""
+        if span_desc is None or step_fn is not step:
+            for i in range(first, first + count):
+                lib.r4r_timing_enable(mask if (sample and sample(i - first)) else 0)
+                step_fn(i)
+            return
+        i, end = first, first + count
+        while i < end:
+            if sample and sample(i - first):
+                lib.r4r_timing_enable(mask)
+                k = 1
+            else:
+                lib.r4r_timing_enable(0)
+                k = 1
+                while i + k < end and k < engine.SPAN_STEPS and not (sample and sample(i + k - first)):
+                    k += 1
+            k = min(k, engine._span_limit(span_desc))
+            if k <= 0:                                       # (the conv rule's probe step reads a counter back: by itself)
+                step_fn(i)
+                i += 1
+                continue
+            engine._span(span_desc, i, k, True)
+            i += k
+
     if args.from_host:
         from reviews4rec_amd import data_fast
         cat = [np.concatenate([b[0][k] for b in batches_np]) for k in range(7)]
@@ -579,13 +738,15 @@ def run(args, env, is_leg=False):
         # pair of events is another ~10 us of a 2 ms window, and the other legs have the steady leg's samples)
         m = mask if steps >= 50 else (mask & short_mask)
         marks = []
-        for i in range(steps):
-            lib.r4r_timing_enable(m if sample(i) else 0)
-            step_fn(first + i)
-            if args.step_events:                             # (diagnosis only: an event per step costs the region ~3 us each)
+        if args.step_events:                                 # (diagnosis only: an event per step costs the region ~3 us each)
+            for i in range(steps):
+                lib.r4r_timing_enable(m if sample(i) else 0)
+                step_fn(first + i)
                 e = torch.cuda.Event(enable_timing=True)
                 e.record()
                 marks.append(e)
+        else:
+            run_steps(step_fn, first, steps, m, sample)
         if hasattr(engine, 'flush'):                         # every optimizer update of the K steps lands inside the region
             engine.flush(check=False)
         ev1.record()
@@ -616,8 +777,7 @@ def run(args, env, is_leg=False):
     # profiles/r03e_ramp_ab.txt -- the driver's 20-step command after 30 / 100 / 300 untimed steps reads 1.13 / 1.15 /
     # 1.18 M ratings/s (its sampled GEMM launch 59-61 / 57 / 55 us): the clocks settle over the first ~30 ms of work.
     ramp = max(0, args.ramp - args.warmup)
-    for i in range(ramp + args.warmup):
-        step(i)
+    run_steps(step, 0, ramp + args.warmup)
     # Kernel timing for the roofline legs happens INSIDE the timed region but is sampled: only every
     # 20th step is instrumented, and only the kernels the legs need (direct conv: slot 0; projection
     # GEMM + gather: slots 3, 4).  A HIP event record serialises the queue for ~3 us; instrumenting
@@ -660,8 +820,7 @@ def run(args, env, is_leg=False):
             engine.check_announcements()
         steady = {'steps': STEADY, 'ratings_per_s': round(STEADY * B_global / el_s, 1),
                   'ms_per_step': round(1000.0 * el_s / STEADY, 4), 'gpu_ms_per_step': round(gpu_span_ms[0] / STEADY, 4),
-                  'note': 'the same step function, %d more steps between the same fences right after the timed region '
-                          '(never `value`); its sampled launches are reported beside the roofline legs (steady_*), not pooled in' % STEADY}
+                  }   # (the same step function, 200 more steps between the same fences; never `value`: DESIGN 5)
         steps_run += STEADY
         leg_slots = read_slots()
         steady['kernel_ms'] = {k: round(v[0] / v[1], 4) for k, v in leg_slots.items()}
@@ -719,7 +878,8 @@ def run(args, env, is_leg=False):
     # fp32 accumulation: DESIGN.md 4.1d).  Reported beside the fp32 line, never as `value`.
     opt_in = None
     if (not dp_job and args.gemm_math == 'f32' and getattr(engine, 'gemm_math', None) == 'f32'
-            and 'proj_gemm_kernel' in timed and not args.from_host and args.opt_in_leg and not args.no_opt_in_leg):
+            and 'proj_gemm_kernel' in timed and not args.from_host and not args.no_opt_in_leg
+            and (args.opt_in_leg or (not is_leg and config_legs_wanted(args, dp_job)))):
         from reviews4rec_amd import engine as E
         os.environ['R4R_GEMM_MATH'] = 'f16x2'
         engine.gemm_math = 'f16x2'
@@ -757,8 +917,9 @@ def run(args, env, is_leg=False):
         value = args.steps * B_global / elapsed
         result = {
             'metric': 'train ratings/sec', 'value': round(value, 1), 'unit': 'ratings/s',
-            # `warmup` is what RAN untimed before the region: the requested warm-up, raised to --ramp steps (clock ramp, above)
-            'n_gpus': world, 'steps': args.steps, 'warmup': ramp + args.warmup, 'warmup_requested': args.warmup,
+            # `warmup` is what was asked; `warmup_effective` what RAN untimed before the region (raised to --ramp steps: clock ramp)
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'warmup_effective': ramp + args.warmup,
+            'warmup_requested': args.warmup,
             'ms_per_step': round(1000.0 * elapsed / args.steps, 4),
             'gpu_ms_per_step': round(gpu_ms_per_step, 4),     # HIP events around the same steps (rank 0's device)
             'higher_is_better': True, 'scaling': 'strong' if strong else 'weak', 'vs_baseline': None,
@@ -769,11 +930,10 @@ def run(args, env, is_leg=False):
             'config': {'workload': args.workload, 'ratings_per_step': B_global, 'batch_per_gpu': B,
                        'parallelism': 'dp%d' % world,
                        'engine': 'native' if engine is not None else ('graph' if graphed is not None else 'module'),
+                       'enqueue': 'spans (K steps per host call)' if span_desc is not None else 'per step',
                        'conv_algo': args.conv_algo, 'gemm_math': args.gemm_math, 'doc_fill': args.doc_fill,
                        'token_dist': args.token_dist,
-                       **({'table_sweep': 'temporally blocked on a schedule: a table chunk is visited every %d-th step and takes its pending Adam '
-                                              'updates together, rows a rating names catch up on the way (same bits as the '
-                                              'dense sweep, tests/test_gpu_full_size.py); flushed inside the timed region' % engine.sweep_period}
+                       **({'table_sweep': 'blocked, period %d, flushed inside the timed region' % engine.sweep_period}
                           if getattr(engine, 'TEMPORAL_SWEEP', False) and not dp_job
                           and (getattr(engine, 'plus', 0) or getattr(engine, 'has_tables', False))
                           and engine.sweep_period > 1 and args.token_prefetch == 'fused' else {}),
@@ -856,8 +1016,6 @@ def run(args, env, is_leg=False):
                    'avg_launch_ms': round(1000 * avg_s, 4), 'launches': timed['proj_gather_max_kernel'][1],
                    'bytes_per_launch': nbytes, 'positions_per_launch': int(total),
                    'walked_positions_per_launch': int(walked),
-                   'bytes_note': 'walked positions x 1,200 B (three tap rows) + every token x 12 B (id + row slot); positions '
-                                 'of uniform slices are not walked and not counted',
                    'traffic': g_traffic, 'traffic_source': g_src, 'projected_rows_bytes': int(ptab_bytes)}
             if ptab_bytes > 256e6:
                 # the projected rows outgrow the 256 MB Infinity Cache: a true HBM gather.  frac = walked bytes against
@@ -868,15 +1026,11 @@ def run(args, env, is_leg=False):
             else:
                 leg.update({'bound': 'l2/mall', 'peak': PEAK_L2_GBS, 'frac': round(ach_b / PEAK_L2_GBS, 4),
                             'hbm_side_GBs': None if g_traffic is None else round(g_traffic / avg_s / 1e9, 1),
-                            'note': 'load bandwidth of the walked positions out of L2 / Infinity Cache (the projected rows '
-                                    'are cache resident) against the guide\'s aggregate L2 figure; hbm_side_GBs = '
-                                    'PMC-counted HBM bytes / launch time'})
+                            })
             steady_of('proj_gather_max_kernel', leg)
             result['roofline_gather'] = leg
             steady_of('proj_gemm_kernel', result['roofline'])
             result['conv_equivalent'] = {
-                'note': 'SURVEY 8d algorithmic conv flops (2 towers x P x 100 x 3E x 2 per rating) / (gemm + gather '
-                        'time): what a direct conv would have to sustain to match',
                 'TFLOPs': round(towers * B * tower_flops_per_doc(hp) / (avg_s + g_s) / 1e12, 1),
                 'peak_fp32_mfma': PEAK_FP32_MFMA_TFLOPS}
             if hp['model_type'] == 'transnet++' and engine is not None and 'adam_multi_kernel' in timed:

@@ -817,6 +817,9 @@ int r4r_batch_build(const int32_t *user_tok, const int64_t *user_rev_off, const 
  *   16 train  17 T  18 R  19 W  20 pad_user  21 pad_item                                          (r4r_batch_build's)
  *   22 ring: int64 device buffer of 2 groups, 0 = an ids-only loader (iter_simple: words 0..9, 12..14, 16..23 unused)
  *   23 ring stride per group (int64 elements, >= G * B * (3 doc + 20))   24 N   25 G batches per group   26 B
+ *   27 0, or a HOST table [G][8] of the device pointers (r4r_span_batch's order) of G batches of B ratings that are
+ *      already built and resident: batch b is entry b % G, nothing is constructed (a pool of batches cycled through;
+ *      words 0..23 unused)
  * Batch b = ratings [b B, (b + 1) B); only the N / B full batches are reachable (a ragged tail goes through the
  * per-step entry).  built_group (host, in / out): the highest group whose block is in the ring, -1 before the
  * epoch's first span; groups are built in order as the steps reach them (the next one before the current one's last

@@ -27,6 +27,7 @@ struct SpanLoader {
     int64_t pad_user, pad_item;
     int64_t *ring;
     int64_t stride, N, G, B;
+    const uint64_t *resident;                               // HOST table [G][8] of built batches, cycled (word 27)
     bool review;                                            // false: ids only (iter_simple, data.py:336-372)
     int64_t doc() const { return R > 0 ? (int64_t)R * W : T; }
     int64_t full_batches() const { return B > 0 ? N / B : 0; }
@@ -54,7 +55,12 @@ static int decode_loader(const uint64_t *w, SpanLoader &L) {
     L.pad_user = (int64_t)w[20]; L.pad_item = (int64_t)w[21];
     L.ring = reinterpret_cast<int64_t *>(w[22]);
     L.stride = (int64_t)w[23]; L.N = (int64_t)w[24]; L.G = (int64_t)w[25]; L.B = (int64_t)w[26];
+    L.resident = reinterpret_cast<const uint64_t *>(w[27]);
     L.review = L.ring != nullptr;
+    if (L.resident) {
+        R4R_REQUIRE(!L.ring && L.G > 0 && L.B > 0 && L.N >= 0, "span: a resident descriptor has a table of G > 0 batches and no ring");
+        return R4R_OK;
+    }
     R4R_REQUIRE(L.u && L.i && L.y && L.N >= 0 && L.B > 0, "span: the descriptor needs u, i, y and a batch size");
     if (L.review) {
         R4R_REQUIRE(L.G > 0 && L.stride >= L.G * L.B * (3 * L.doc() + 2 * NB),
@@ -75,6 +81,13 @@ static int build_group(const SpanLoader &L, int64_t g, hipStream_t st) {
 
 static SpanBatch batch_at(const SpanLoader &L, int64_t b) {
     SpanBatch s{};
+    if (L.resident) {
+        const uint64_t *t = L.resident + (b % L.G) * 8;
+        auto p64 = [&](int k) { return reinterpret_cast<const int64_t *>(t[k]); };
+        s.this_doc = p64(0); s.who = p64(1); s.what = p64(2); s.user_doc = p64(3); s.item_doc = p64(4);
+        s.uid = p64(5); s.iid = p64(6); s.y = reinterpret_cast<const float *>(t[7]);
+        return s;
+    }
     s.uid = L.u + b * L.B; s.iid = L.i + b * L.B; s.y = L.y + b * L.B;
     if (!L.review) return s;
     const int64_t g = b / L.G, j = b - g * L.G, n = L.group_ratings(g), doc = L.doc();

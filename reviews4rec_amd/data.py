@@ -193,6 +193,44 @@ class SpanDescriptor:
         self.words = (ctypes.c_uint64 * self.WORDS)(*w)
         self.built = ctypes.c_int64(-1)
 
+    @classmethod
+    def resident(cls, batches, review=None):
+        """A descriptor over batches that already exist on the device -- ``[(data, y), ...]`` in the 7-slot layout, all
+        of one size -- cycled through: batch b of a span is ``batches[b % len(batches)]``, nothing is built.  (What a
+        caller holding its epoch in HBM -- bench.py's pool -- gives the span entry points.)"""
+        import ctypes
+        self = cls.__new__(cls)
+        data0, y0 = batches[0]
+        B = int(y0.numel())
+        table, keep = [], []
+        for data, y in batches:
+            if int(y.numel()) != B:
+                raise ValueError('SpanDescriptor.resident: batches of %d and %d ratings' % (B, int(y.numel())))
+            row = []
+            for t in list(data) + [y]:
+                if t is None:
+                    row.append(0)
+                    continue
+                t = t.contiguous()
+                keep.append(t)
+                row.append(t.data_ptr())
+            table += row
+        self.batch_size, self.group, self.ring = B, len(batches), None
+        self.n_ratings = (1 << 40) * B
+        self.full_batches = 1 << 40
+        self.review = (data0[3] is not None) if review is None else bool(review)   # (ids-only batches may carry dummy documents)
+        self.doc_shape = None
+        if self.review:
+            self.doc_shape = tuple(data0[3].shape[-2:]) if data0[3].dim() - data0[5].dim() == 2 else tuple(data0[3].shape[-1:])
+        self._table = (ctypes.c_uint64 * len(table))(*table)
+        self._keep = keep
+        w = [0] * cls.WORDS
+        w[24:27] = [self.n_ratings, self.group, B]
+        w[27] = ctypes.addressof(self._table)
+        self.words = (ctypes.c_uint64 * cls.WORDS)(*w)
+        self.built = ctypes.c_int64(-1)
+        return self
+
 
 class DataLoader():
     """data.DataLoader (data.py:11-447).  ``data`` is the rating list ``[[user, item, rating], ...]``;

@@ -1150,9 +1150,18 @@ class MFEngine(_SweepSchedule, _Spans):
 
     def load_state_dict(self, sd):
         # validate FIRST: a rejected checkpoint must leave the engine as it was -- its sweep schedule included (what is
-        # pending under the schedule is discarded only together with the state it belongs to)
-        m, v = self.moments()
-        scalars = load_named_moments('MFEngine', m, v, sd)
+        # pending under the schedule is discarded only together with the state it belongs to).  The moment views are taken
+        # WITHOUT a flush: main.py:306-308's order is model.load_state_dict, then this -- the tables already hold the
+        # checkpoint's rows, and the pending gradient-zero updates of the state being replaced (old moments, old step
+        # numbers) must not be applied to them.
+        keep = (self._tb_base, self._tb_period)
+        self._tb_base = self.step_count                      # nothing pending while moments() builds its views
+        try:
+            m, v = self.moments()
+            scalars = load_named_moments('MFEngine', m, v, sd)
+        except BaseException:
+            self._tb_base, self._tb_period = keep
+            raise
         self.step_count, self.offset, self.lr, self.wd, self.betas, self.eps = scalars
         self._tb_base, self._tb_period = self.step_count, 1  # the loaded tables are current through the loaded step
         # row tags written by earlier steps of THIS process must not collide with resumed step numbers
@@ -2330,15 +2339,23 @@ class IdNetEngine(_SweepSchedule, _Spans):
                     raise ValueError('IdNetEngine.load_state_dict: an ID-table moment of the checkpoint does not fit the model')
             scalars = (int(sd['step']), int(sd['dropout_offset']), float(sd['lr']), float(sd['weight_decay']),
                        tuple(sd['betas']), float(sd['eps']))
-            self.flush()
+            self._tb_base = self.step_count                  # (validated: what was pending belongs to the state replaced now)
             self.flat_m.copy_(sd['exp_avg'].to(self.dev))
             self.flat_v.copy_(sd['exp_avg_sq'].to(self.dev))
             for mine, theirs in zip(self.rows_m + self.rows_v, rows):
                 if mine is not None:
                     mine.copy_(theirs.to(self.dev))
         else:
-            m, v = self.moments()                            # (flushes: whatever was pending belongs to the state replaced now)
-            scalars = load_named_moments('IdNetEngine', m, v, sd)
+            # moment views WITHOUT a flush (MFEngine.load_state_dict has the argument): the tables may already hold the
+            # checkpoint's rows, and the old state's pending updates must not be applied to them
+            keep = (self._tb_base, self._tb_period)
+            self._tb_base = self.step_count
+            try:
+                m, v = self.moments()
+                scalars = load_named_moments('IdNetEngine', m, v, sd)
+            except BaseException:
+                self._tb_base, self._tb_period = keep
+                raise
         self.step_count, self.offset, self.lr, self.wd, self.betas, self.eps = scalars
         self._tb_base, self._tb_period = self.step_count, 1  # the loaded tables are current through the loaded step
         # row tags written by earlier steps of THIS process must not collide with resumed step numbers

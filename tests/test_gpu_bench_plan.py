@@ -190,3 +190,109 @@ def test_narre_engine_one_training_step_at_kindle_cardinalities_against_the_orac
             assert float((mine - v).abs().max()) < 2.5e-3, k
         elif grads.get(k) is None:
             assert torch.equal(mine, v), k
+
+
+def test_deepconn_engine_at_the_full_uniform_plan_against_the_oracle():
+    """bench.py's `cfg3_full_uniform` leg: cfg3 on full-length documents of uniformly drawn words -- 92 k distinct rows
+    per step, the projection GEMM's TILE form and a gather that walks every position -- eval forward against the oracle
+    on sampled ratings, then one training step (dropout 0.6, the device's multipliers injected): per-rating SE and every
+    gradient (DeepCoNN.py:37-66, common_pytorch_models.py:22-39)."""
+    import reviews4rec_amd
+    from reviews4rec_amd import synthetic
+    from reviews4rec_amd.engine import DeepCoNNEngine
+    hp = synthetic.hyper_params_for('cfg3_deepconn_electronics_e300')
+    table = torch.from_numpy(synthetic.word_table(hp['vocab'], hp['word_embed_size']))
+    P = oracle.init_params(hp, vocab_size=hp['vocab'], seed=41)
+    P['word2vec.weight'] = table
+    model = reviews4rec_amd.get_model_class('deepconn')(dict(hp, word_vectors=table.numpy()))
+    model.load_state_dict(P)
+    model = model.to(DEV).train()
+    eng = DeepCoNNEngine(model, lr=hp['lr'], weight_decay=hp['weight_decay'])
+    gen = synthetic.Generator(hp, seed=synthetic.SEED, doc_fill='full', token_dist='uniform')   # the leg's generator
+    data, y = gen.batch(hp['batch_size'])
+    data, y = [torch.from_numpy(d) for d in data], torch.from_numpy(y)
+    assert int((data[3] == 0).sum()) == 0                    # no padding anywhere: nothing for the gather to skip
+    rows_used = sum(_distinct_rows(data))
+    assert 85000 < rows_used < 100004, rows_used             # beyond the A-resident plan (30,720 rows): the tile form
+    B, T, L = hp['batch_size'], hp['input_length'], hp['latent_size']
+    dev_data = [d.to(DEV) for d in data]
+    pred = eng.predict(dev_data, None)[0].cpu().clone()
+    rows = [0, 31, 64, 127]
+    ref = oracle.model_forward(P, [d[rows] for d in data], hp, train=False)
+    torch.testing.assert_close(pred[rows], ref, rtol=1e-5, atol=1e-5)
+    se = eng.train_step(dev_data, y.to(DEV)).cpu().clone()
+    mult = eng.dropout_multipliers(B, T).cpu()
+    masks = {'user_conv.dropout': mult[:, :L], 'item_conv.dropout': mult[:, L:]}
+    ref_P = copy.deepcopy(P)
+    sse, grads = oracle.train_step(ref_P, data, y, hp, oracle.AdamState(), masks=masks)
+    torch.testing.assert_close(se.sum(), torch.tensor(sse), rtol=1e-4, atol=1e-3)
+    got = eng.grads()
+    for k, v in grads.items():
+        if v is not None:
+            torch.testing.assert_close(got[k].cpu(), v, rtol=2e-4, atol=1e-7, msg=lambda m: k + ': ' + m)
+
+
+def test_transnet_engine_at_the_full_uniform_hbm_gather_plan_against_the_oracle():
+    """bench.py's `cfg5_full_uniform_hbm_gather` leg: TransNet++ at 10 M users / 1 M items / 1 M words on full-length
+    documents of uniformly drawn words with the projection PINNED (the engines' measured rule would run the direct conv
+    here) -- 360 k projected rows = 390 MB, the weight-resident GEMM and the one gather that misses every cache.  One
+    training step against the oracle's literal three-optimiser step (TransNet.py:9-122, main.py:35-53): per-rating
+    source SE and both auxiliary losses; then an eval forward on sampled ratings."""
+    import reviews4rec_amd
+    from reviews4rec_amd import synthetic
+    from reviews4rec_amd.engine import TransNetEngine
+    B = 128
+    hp = synthetic.hyper_params_for('cfg5_transnetpp_synthetic', dropout=0.0)
+    V = hp['vocab']
+    P = oracle.init_params(hp, vocab_size=V, seed=31)
+    model = reviews4rec_amd.get_model_class('transnet++')(dict(hp, word_vectors=P['target.word2vec.weight'].numpy()))
+    model.load_state_dict(P)
+    model = model.to(DEV).train()
+    eng = TransNetEngine(model, lr=hp['lr'], weight_decay=hp['weight_decay'], conv_algo=2)   # bench: --conv-algo project
+    gen = synthetic.Generator(hp, seed=synthetic.SEED, doc_fill='full', token_dist='uniform')
+    data, y = gen.batch(B)
+    data, y = [torch.from_numpy(d) for d in data], torch.from_numpy(y)
+    rows_used = sum(d.unique().numel() for d in (data[0], data[3], data[4]))
+    assert rows_used > 340000, rows_used                     # x 1,216 B > the 256 MB Infinity Cache
+    dev_data = [d.to(DEV) for d in data]
+    se = eng.train_step(dev_data, y.to(DEV)).cpu().clone()
+    aux = eng.aux(dev_data).cpu()
+    states = dict(source=oracle.AdamState(), source_fm=oracle.AdamState(), target=oracle.AdamState())
+    ref_P = copy.deepcopy(P)
+    ref_se, lt, ltr = oracle.transnet_train_step(ref_P, data, y, hp, states)
+    torch.testing.assert_close(se, ref_se, rtol=1e-4, atol=1e-4)
+    assert float(((se - ref_se) ** 2).mean()) < 1e-4
+    torch.testing.assert_close(aux[:, 1].mean(), torch.tensor(lt), rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(aux[:, 2].mean(), torch.tensor(ltr), rtol=1e-4, atol=1e-4)
+    model.eval()
+    pred = eng.predict(dev_data, None)[0].cpu().clone()
+    rows = [0, 50, 127]
+    ref = oracle.model_forward(ref_P, [d[rows] for d in data], hp, train=False)
+    torch.testing.assert_close(pred[rows], ref[0], rtol=1e-4, atol=1e-4)
+
+
+def test_bias_only_engine_through_the_cfg1_plan_against_the_oracle():
+    """bench.py's `cfg1_bias_only_musical` leg by its own name: synthetic.hyper_params_for('cfg1_bias_only_musical')
+    (1,429 users / 900 items, B = 128, dropout 0.6 -- which bias_only has no site for), the leg's generator, five
+    training steps against the oracle: SE per step and every parameter (MF.py:45-50, main.py:94-96)."""
+    import reviews4rec_amd
+    from reviews4rec_amd import synthetic
+    from reviews4rec_amd.engine import MFEngine
+    hp = synthetic.hyper_params_for('cfg1_bias_only_musical')
+    assert (hp['model_type'], hp['total_users'], hp['total_items'], hp['batch_size']) == ('bias_only', 1429, 900, 128)
+    P = oracle.init_params(hp, seed=17)
+    model = reviews4rec_amd.get_model_class('bias_only')(hp)
+    model.load_state_dict(P)
+    model = model.to(DEV).train()
+    eng = MFEngine(model, lr=hp['lr'], weight_decay=hp['weight_decay'])
+    gen = synthetic.Generator(hp, seed=synthetic.SEED)
+    state = oracle.AdamState()
+    for step in range(5):
+        data, y = gen.batch(hp['batch_size'])
+        uid, iid, y = torch.from_numpy(data[5]), torch.from_numpy(data[6]), torch.from_numpy(y)
+        se = eng.train_step([None] * 5 + [uid.to(DEV), iid.to(DEV)], y.to(DEV), defer_sweep=True).cpu().clone()
+        sse, _ = oracle.train_step(P, [None] * 5 + [uid, iid], y, hp, state)
+        torch.testing.assert_close(se.sum(), torch.tensor(sse), rtol=1e-4, atol=1e-3)
+    sd = model.state_dict()
+    for k, v in P.items():
+        torch.testing.assert_close(sd[k].cpu(), v, rtol=1e-5, atol=5e-6, msg=lambda m: k + ': ' + m)

@@ -1494,3 +1494,40 @@ def test_rejected_checkpoint_and_failed_step_leave_the_engine_as_it_was(kind):
     assert again['step'] == 3
     for k, v in good['exp_avg'].items():
         assert torch.equal(again['exp_avg'][k], v), k
+
+
+@pytest.mark.parametrize('kind', ['mf', 'idnet', 'transnetpp'])
+def test_loading_a_checkpoint_over_pending_sweep_updates_leaves_the_checkpoint_s_tables(kind):
+    """main.py:306-308's order -- model.load_state_dict, then engine.load_state_dict -- with updates of the
+    temporally blocked sweep still pending in the engine being overwritten: they belong to the state that is replaced
+    (old moments, old step numbers) and must be dropped with it, not applied to the freshly loaded rows."""
+    import copy
+    g, model, eng = _engine_of(kind)
+    defer = dict(defer_sweep=True)
+    for step in range(3):
+        eng.train_step(*g.batch(step % 2, DEV), **defer)
+    ck_model = {k: v.detach().clone() for k, v in model.state_dict().items()}     # (flushes through the hook)
+    ck_opt = copy.deepcopy(eng.state_dict())
+    for step in range(5):
+        eng.train_step(*g.batch(step % 2, DEV), **defer)
+    assert eng._tb_period > 1 and eng._tb_base < eng.step_count                   # updates are pending right now
+    model.load_state_dict(ck_model)
+    eng.load_state_dict(ck_opt)
+    assert eng.step_count == 3 and eng._tb_base == 3
+    torch.cuda.synchronize()
+    now = model.state_dict()
+    for k, v in ck_model.items():
+        assert torch.equal(now[k], v), k
+    again = eng.state_dict()
+    for k, v in ck_opt['exp_avg'].items():
+        assert torch.equal(again['exp_avg'][k], v) and torch.equal(again['exp_avg_sq'][k], ck_opt['exp_avg_sq'][k]), k
+    # ... and the resumed engine continues like one that stopped there
+    g2, model2, ref = _engine_of(kind)
+    for step in range(3):
+        ref.train_step(*g2.batch(step % 2, DEV), **defer)
+    a = eng.train_step(*g.batch(1, DEV), **defer).clone()
+    b = ref.train_step(*g2.batch(1, DEV), **defer).clone()
+    assert torch.equal(a, b)
+    sd, sd_ref = model.state_dict(), model2.state_dict()
+    for k in sd:
+        assert torch.equal(sd[k], sd_ref[k]), k
