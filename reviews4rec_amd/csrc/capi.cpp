@@ -70,6 +70,24 @@ void timing_begin(int id, hipStream_t st, void **token, bool chain) {
 }
 void timing_begin(int id, hipStream_t st, void **token) { timing_begin(id, st, token, false); }
 
+// A span measured by the kernel's OWN dispatch packet (hipExtLaunchKernel's start / stop events): no event records --
+// no barrier packets, no release fences -- around the kernel, so an instrumented step costs what a plain one does
+// (two hipEventRecords around the projection GEMM made the sampled step ~30 us longer: 1.5 % of the driver's 20-step
+// region).  -> false when the slot is not instrumented (launch the plain way).
+bool timing_kernel_events(int id, hipEvent_t *start, hipEvent_t *stop) {
+    if (!(g_timing_mask & (1u << id))) return false;
+    TimedSpan s;
+    s.id = id;
+    s.a_shared = false;
+    s.a = take_event();
+    s.b = take_event();
+    g_spans.push_back(s);
+    g_last_ended = g_spans.size();                          // (a chained span may start at this kernel's stop event)
+    *start = s.a;
+    *stop = s.b;
+    return true;
+}
+
 void timing_end(void *token, hipStream_t st) {
     const size_t i = reinterpret_cast<size_t>(token) - 1;
     (void)hipEventRecord(g_spans[i].b, st);

@@ -1,6 +1,7 @@
 // Internal helpers shared by the gfx950 kernels of libr4r_hip.so.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 #include <stdio.h>
 
@@ -16,6 +17,8 @@ void timing_begin(int id, hipStream_t st, void **token);
 void timing_begin(int id, hipStream_t st, void **token, bool chain);
 void timing_end(void *token, hipStream_t st);
 
+bool timing_kernel_events(int id, hipEvent_t *start, hipEvent_t *stop);
+
 struct ScopedTiming {
     void *tok = nullptr;
     hipStream_t st;
@@ -23,6 +26,16 @@ struct ScopedTiming {
     ScopedTiming(int id, hipStream_t s, bool chain = false) : st(s) { if (timing_on()) timing_begin(id, s, &tok, chain); }
     ~ScopedTiming() { if (tok) timing_end(tok, st); }
 };
+
+// Launch `kernel`; when timing slot `id` is on, with the dispatch packet's own start / stop timestamps (capi.cpp).
+template <class K, class... A>
+inline void launch_timed(int id, K kernel, dim3 grid, dim3 block, size_t lds, hipStream_t st, A... args) {
+    hipEvent_t e0, e1;
+    if (timing_on() && timing_kernel_events(id, &e0, &e1))
+        hipExtLaunchKernelGGL(kernel, grid, block, (uint32_t)lds, st, e0, e1, 0, args...);
+    else
+        hipLaunchKernelGGL(kernel, grid, block, lds, st, args...);
+}
 
 inline int check_launch(const char *what) {
     hipError_t e = hipGetLastError();
@@ -94,5 +107,21 @@ __device__ __forceinline__ uint32_t philox_first_word(uint64_t ctr, uint64_t see
 }
 
 inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// Kernel arguments read WHERE THEY ARE USED.  hipcc loads every by-value kernel argument in the kernel's first block
+// (the kernarg segment is known dereferenceable and invariant, so every s_load is hoisted there), keeps all of them
+// live in scalar registers for the whole kernel and spills what does not fit into the lanes of vector registers -- a
+// v_writelane / v_readlane pair around every use (tools/isa_scan.py: 128-330 spilled scalars and up to 1,400 lane
+// operations in the role kernels, whose ~70 arguments are mostly ANOTHER role's).  kernel_args<T>() is the kernel's one
+// argument struct (it must be the kernel's FIRST parameter) seen through a pointer the optimiser knows nothing about:
+// each field becomes an s_load next to its use, inside the role's own branch.
+template <class T>
+__device__ __forceinline__ const T &kernel_args() {
+    typedef const T __attribute__((address_space(4))) *kernarg_ptr;
+    kernarg_ptr p = (kernarg_ptr)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(p));
+    return *(const T *)p;
+}
+
 
 }  // namespace r4r

@@ -383,8 +383,18 @@ __device__ __forceinline__ void head_grad_block(const HeadGradArgs &a, int blk) 
 // only on the next batch's indices, the slice's workgroups fill CUs the latency-bound wgrad
 // leaves idle, and the next step then starts at its GEMM.
 BWD_TRACE_DEFINE(r4r_debug_dc_bwd_trace)
-__global__ __launch_bounds__(WG_THREADS, 8) void deepconn_backward_kernel(WgradArgs w, HeadGradArgs h, int hg_blocks,
-                                                                       TokenArgs nx) {
+struct DcBackwardArgs {
+    WgradArgs w;
+    HeadGradArgs h;
+    int hg_blocks;
+    TokenArgs nx;
+};
+__global__ __launch_bounds__(WG_THREADS, 8) void deepconn_backward_kernel(DcBackwardArgs) {
+    const DcBackwardArgs &A = kernel_args<DcBackwardArgs>();   // (each role's fields loaded in its own branch: common.h)
+    const WgradArgs &w = A.w;
+    const HeadGradArgs &h = A.h;
+    const TokenArgs &nx = A.nx;
+    const int hg_blocks = A.hg_blocks;
     BWD_STAMP(0, wall_clock64())
     BWD_STAMP(2, (unsigned long long)blockIdx.z + 1)
     // (slice 0 = the head gradients: its ~140 working workgroups are the longest chains of the launch and
@@ -704,7 +714,7 @@ extern "C" int r4r_deepconn_step(const float *table, int64_t V, const int64_t *u
     }
     {
         ScopedTiming tm(R4R_TIMING_TEXTCNN_WGRAD, st);
-        deepconn_backward_kernel<<<dim3(F_CONV, wa.nsplit, prefetch ? 4 : 3), WG_THREADS, 0, st>>>(wa, hg, hg_blocks, nx);
+        deepconn_backward_kernel<<<dim3(F_CONV, wa.nsplit, prefetch ? 4 : 3), WG_THREADS, 0, st>>>(DcBackwardArgs{wa, hg, hg_blocks, nx});
     }
     // 6: wgrad partial reduce -> flat gradient buffer (+ compaction of the next batch's tokens)
     const int red_blocks = (F_CONV * 3 * E + F_CONV + RED_THREADS - 1) / RED_THREADS;

@@ -1041,7 +1041,8 @@ BWD_TRACE_DEFINE(r4r_debug_mf_adam_trace)
 // every wave of the launch, the table chunks' included, is allocated what the entry waves' multi-row accumulation
 // needs -- taken for rows of <= 64 elements at <= MF_LIGHT_MAX_B ratings (one rating per entry wave).
 template <int NACC, int DL = 4, bool WIDE = true, bool SCAN = false>
-__global__ __launch_bounds__(MF_THREADS) void mf_adam_kernel(MfSweep w) {
+__global__ __launch_bounds__(MF_THREADS) void mf_adam_kernel(MfSweep) {
+    const MfSweep &w = kernel_args<MfSweep>();              // (fields loaded at their uses, not all up front: common.h)
     BWD_STAMP(0, wall_clock64());                           // (instrumented builds only: tools/sweep_trace.py)
     mf_adam_body<NACC, DL, WIDE, SCAN>(w);
 #ifdef R4R_TRACE
@@ -1204,12 +1205,9 @@ int mf_table_rows_launch(float *ut, float *ut_m, float *ut_v, float *it, float *
     sw.B = B; sw.D = D; sw.now = now; sw.s = sc;
     sw.nt = mf_sweep_nt(sw.n0 + sw.n1);
     {
-        ScopedTiming tm(R4R_TIMING_ADAM, st);
-        {
-            mf_ids_lds_attr();
-            if (mf_light(sw.D, B)) mf_adam_kernel<4, 1, false><<<(unsigned)chunks, MF_THREADS, (size_t)B * sizeof(int), st>>>(sw);
-            else mf_adam_kernel<4><<<(unsigned)chunks, MF_THREADS, (size_t)B * sizeof(int), st>>>(sw);
-        }
+        mf_ids_lds_attr();
+        if (mf_light(sw.D, B)) launch_timed(R4R_TIMING_ADAM, mf_adam_kernel<4, 1, false>, dim3((unsigned)chunks), dim3(MF_THREADS), (size_t)B * sizeof(int), st, sw);
+        else launch_timed(R4R_TIMING_ADAM, mf_adam_kernel<4>, dim3((unsigned)chunks), dim3(MF_THREADS), (size_t)B * sizeof(int), st, sw);
     }
     return check_launch("table rows");
 }
@@ -1261,10 +1259,9 @@ int mf_table_rows_blocks_launch(float *ut, float *ut_m, float *ut_v, float *it, 
     sw.B = B; sw.D = D; sw.now = now; sw.s = sc;
     sw.nt = mf_sweep_nt(sw.n0 + sw.n1);
     {
-        ScopedTiming tm(R4R_TIMING_ADAM, st);
         const size_t lds = (size_t)B * sizeof(int);
-        if (mf_light(sw.D, B)) mf_adam_kernel<4, 1, false, true><<<(unsigned)chunks, MF_THREADS, lds, st>>>(sw);
-        else mf_adam_kernel<4, 4, true, true><<<(unsigned)chunks, MF_THREADS, lds, st>>>(sw);
+        if (mf_light(sw.D, B)) launch_timed(R4R_TIMING_ADAM, mf_adam_kernel<4, 1, false, true>, dim3((unsigned)chunks), dim3(MF_THREADS), lds, st, sw);
+        else launch_timed(R4R_TIMING_ADAM, mf_adam_kernel<4, 4, true, true>, dim3((unsigned)chunks), dim3(MF_THREADS), lds, st, sw);
     }
     return check_launch("table rows (blocks)");
 }
@@ -1316,12 +1313,9 @@ int mf_table_bias_rows_launch(float *ut, float *ut_m, float *ut_v, float *it, fl
     sw.uid = uid; sw.iid = iid; sw.gu = gu; sw.gi = gi; sw.g = g; sw.se = nullptr; sw.sse_accum = nullptr;
     sw.tag_u = tag_u; sw.tag_i = tag_i; sw.B = B; sw.D = D; sw.now = now; sw.s = sc;
     {
-        ScopedTiming tm(R4R_TIMING_ADAM, st);
-        {
-            mf_ids_lds_attr();
-            if (mf_light(sw.D, B)) mf_adam_kernel<4, 1, false><<<(unsigned)chunks, MF_THREADS, (size_t)B * sizeof(int), st>>>(sw);
-            else mf_adam_kernel<4><<<(unsigned)chunks, MF_THREADS, (size_t)B * sizeof(int), st>>>(sw);
-        }
+        mf_ids_lds_attr();
+        if (mf_light(sw.D, B)) launch_timed(R4R_TIMING_ADAM, mf_adam_kernel<4, 1, false>, dim3((unsigned)chunks), dim3(MF_THREADS), (size_t)B * sizeof(int), st, sw);
+        else launch_timed(R4R_TIMING_ADAM, mf_adam_kernel<4>, dim3((unsigned)chunks), dim3(MF_THREADS), (size_t)B * sizeof(int), st, sw);
     }
     return check_launch("table + bias rows");
 }
@@ -1446,12 +1440,11 @@ extern "C" int r4r_mf_step(const int64_t *uid, const int64_t *iid, const float *
         sw.nt = mf_sweep_nt(sw.n0 + sw.n1);
     }
     {
-        ScopedTiming tm(R4R_TIMING_ADAM, st);
         // more loads in flight per entry wave (and fewer waves per SIMD: 156 vs 116 VGPRs) once rows can
         // have hundreds of ratings
-        if (B > 2048) mf_adam_kernel<8><<<(unsigned)chunks, MF_THREADS, 0, st>>>(sw);
-        else if (light) mf_adam_kernel<4, 1, false><<<(unsigned)chunks, MF_THREADS, 0, st>>>(sw);
-        else mf_adam_kernel<4><<<(unsigned)chunks, MF_THREADS, 0, st>>>(sw);
+        if (B > 2048) launch_timed(R4R_TIMING_ADAM, mf_adam_kernel<8>, dim3((unsigned)chunks), dim3(MF_THREADS), 0, st, sw);
+        else if (light) launch_timed(R4R_TIMING_ADAM, mf_adam_kernel<4, 1, false>, dim3((unsigned)chunks), dim3(MF_THREADS), 0, st, sw);
+        else launch_timed(R4R_TIMING_ADAM, mf_adam_kernel<4>, dim3((unsigned)chunks), dim3(MF_THREADS), 0, st, sw);
     }
     return check_launch("mf_step");
 }

@@ -103,7 +103,8 @@ __device__ __forceinline__ int head_col(const NarreHead &a, int flat_off) {
 HEAD_TRACE_DEFINE(r4r_debug_narre_head_trace)
 BWD_TRACE_DEFINE(r4r_debug_narre_bwd_trace)
 template <int MR, int ML, int NT>
-__global__ __launch_bounds__(NT) void narre_head_kernel(NarreHead a) {
+__global__ __launch_bounds__(NT) void narre_head_kernel(NarreHead) {
+    const NarreHead &a = kernel_args<NarreHead>();          // (fields loaded at their uses: common.h -- 88 spilled scalars before)
     HEAD_STAMP(0)
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int R = a.R, L = a.L, RL = R * L, L2 = 2 * L;
@@ -814,10 +815,9 @@ extern "C" int r4r_narre_step(const float *table, int64_t V,
     const int gx = packed ? (NF + 3) / 4 : NF;              // slices: ID tables, two towers, the column sums, the marks
     const dim3 bgrid(gx, wa.nsplit, 3 + backward_cs_slices(cs_blocks, gx * wa.nsplit) + (prefetch ? 1 : 0));
     if (!apply)                                             // gradients only: no ID-table role in this launch
-        narre_backward_kernel<0><<<dim3(bgrid.x, bgrid.y, bgrid.z - 1), WG_THREADS, 0, st>>>(wa, cs, cs_blocks, nx, packed,
-                                                                                             RowSweep{}, 0, 2);
-    else if (L <= 16) narre_backward_kernel<16><<<bgrid, WG_THREADS, 0, st>>>(wa, cs, cs_blocks, nx, packed, rs, (int)chunks, 2);
-    else narre_backward_kernel<32><<<bgrid, WG_THREADS, 0, st>>>(wa, cs, cs_blocks, nx, packed, rs, (int)chunks, 2);
+        narre_backward_kernel<0><<<dim3(bgrid.x, bgrid.y, bgrid.z - 1), WG_THREADS, 0, st>>>(BackwardArgs{wa, cs, cs_blocks, nx, packed, RowSweep{}, 0, 2});
+    else if (L <= 16) narre_backward_kernel<16><<<bgrid, WG_THREADS, 0, st>>>(BackwardArgs{wa, cs, cs_blocks, nx, packed, rs, (int)chunks, 2});
+    else narre_backward_kernel<32><<<bgrid, WG_THREADS, 0, st>>>(BackwardArgs{wa, cs, cs_blocks, nx, packed, rs, (int)chunks, 2});
 
     // 5: wgrad reduce + Adam on the dense parameters (+ next batch's compaction)
     const int red_blocks = (NF * 3 * E + NF + NRED_THREADS - 1) / NRED_THREADS;

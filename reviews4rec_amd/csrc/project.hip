@@ -32,7 +32,10 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int PF = 100;            // filters (rows of 100 floats = 400 B per tap)
 constexpr int PROW = 3 * PF;       // projected row: 3 taps x 100 filters
-constexpr int PSTR = 304;          // its stride in the projected-row table: 1,216 B = 19 whole 64-byte pieces (at 1,200 B three
+#ifndef R4R_PSTR
+#define R4R_PSTR 304
+#endif
+constexpr int PSTR = R4R_PSTR;     // its stride in the projected-row table: 1,216 B = 19 whole 64-byte pieces (at 1,200 B three
                                    // of four 64-byte store pieces straddled two requests, and a gathered row touched 10.4 lines instead of 10)
 static_assert(PSTR >= PROW && PSTR % 4 == 0, "projected-row stride");
 constexpr int PN = 304;            // GEMM N: 300 padded to 19 tiles of 16
@@ -1452,7 +1455,7 @@ static void wres_launch_n(const ProjArgs &a, unsigned wgs, hipStream_t st) {
                                   hipFuncAttributeMaxDynamicSharedMemorySize, wr_lds_bytes(NCH));
         attr_set = true;
     }
-    proj_gemm_wres_kernel<NCH><<<dim3(wgs), WR_THREADS, wr_lds_bytes(NCH), st>>>(a);
+    launch_timed(R4R_TIMING_PROJ_GEMM, proj_gemm_wres_kernel<NCH>, dim3(wgs), dim3(WR_THREADS), wr_lds_bytes(NCH), st, a);
 }
 static void wres_launch(const ProjArgs &a, unsigned wgs, hipStream_t st) {
     switch (a.nchunk) {
@@ -1487,21 +1490,19 @@ int textcnn_proj_compute_launch(const float *table, int64_t V, const ProjTower *
         ScopedTiming tm(R4R_TIMING_PROJ_GEMM, st);           // (the opt-in arithmetic: its weight-scale launch included)
         if (int rc = proj_gemm_f16_launch(table, tw, ntower, a.cap, E, g_table_maxabs, g_weight_maxabs, st)) return rc;
     } else if (a.balanced == 4) {
-        ScopedTiming tm(R4R_TIMING_PROJ_GEMM, st);
         // one workgroup per CU at most; fewer when the row capacity is small (a workgroup's 8 waves take 8 units per round)
         int64_t wgs = ((int64_t)a.cap + 15) / 16 * WR_NQ / WR_WAVES + ntower;
         if (wgs > G7_WGS) wgs = G7_WGS;
         if (wgs < ntower) wgs = ntower;
         wres_launch(a, (unsigned)wgs, st);
     } else {
-        ScopedTiming tm(R4R_TIMING_PROJ_GEMM, st);
         // persistent: one workgroup per CU at most (86 KB of LDS each), fewer when the row capacity is small
         const int rows_wg = (a.balanced == 3 ? AR_PMIN : G7_ROWS) * 16;     // fewest rows a workgroup may own
         int64_t wgs = ((int64_t)a.cap + rows_wg - 1) / rows_wg * ntower;
         if (wgs > G7_WGS) wgs = G7_WGS;
         const int ares_bytes = a.nchunk * AR_CHUNK * 4;     // form 3 keeps every K chunk of its 128 rows resident
         const int lds_bytes = (a.balanced == 3 && ares_bytes > GEMM_LDS_BYTES) ? ares_bytes : GEMM_LDS_BYTES;
-        proj_gemm_kernel<<<dim3((unsigned)wgs), GEMM_THREADS, lds_bytes, st>>>(a);
+        launch_timed(R4R_TIMING_PROJ_GEMM, proj_gemm_kernel, dim3((unsigned)wgs), dim3(GEMM_THREADS), lds_bytes, st, a);
     }
     {
         ScopedTiming tm(R4R_TIMING_PROJ_GATHER, st, /*chain=*/true);     // (starts where the GEMM's span ended)

@@ -40,7 +40,10 @@ constexpr int HCT = 20;                // column tiles of 16 in the packed B ima
 constexpr int HABUF = HM * HROW;       // bytes per A buffer (18,432)
 constexpr int H_THREADS = 512;
 constexpr int HPF = 100, HPROW = 300, HNH_COLS = 160;
-constexpr int HPSTR = 304;    // row stride of the projected-row table (project.hip: PSTR)
+#ifndef R4R_PSTR
+#define R4R_PSTR 304
+#endif
+constexpr int HPSTR = R4R_PSTR;   // row stride of the projected-row table (project.hip: PSTR)
 constexpr int H_LDS_BYTES = 8 * 16 * (HNH_COLS + 4) * 4;   // the epilogue's slabs (83,968) > the loop's two A buffers
 static_assert(2 * HABUF <= H_LDS_BYTES, "the A buffers live in the epilogue's region");
 constexpr int HIMG_CHUNK = HCT * 2 * 64 * 16;              // bytes of packed B per chunk (40,960)

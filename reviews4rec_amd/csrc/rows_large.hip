@@ -119,7 +119,8 @@ __global__ __launch_bounds__(256) void rl_scatter_kernel(RlArgs a) {
     }
 }
 
-__global__ __launch_bounds__(256) void rl_apply_kernel(RlArgs a) {
+__global__ __launch_bounds__(256) void rl_apply_kernel(RlArgs) {
+    const RlArgs &a = kernel_args<RlArgs>();                // (fields loaded at their uses: common.h)
     __shared__ int s_bucket;
     const int g = blockIdx.x;
     if (g >= a.group_begin[RL_NB]) return;                  // (the grid is the host's upper bound)

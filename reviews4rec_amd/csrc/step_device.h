@@ -316,9 +316,28 @@ __host__ __device__ inline int backward_cs_slices(int cs_blocks, int wgs_per_sli
 // WIDE: the generic wgrad (3E/4 > 64 float4: wgrad_block) instead of the packed one-wave-per-filter form.  Without
 // an ID-table role that variant fits 64 VGPRs -- 8 waves per SIMD, every workgroup of a DeepCoNN++ launch resident
 // (13.7 -> 11.0 us); the packed form spills at that cap (its workgroups went 4.6 -> 7.2 us) and keeps 4.
+// ONE argument struct, read through kernel_args (common.h): each role loads its own fields inside its own branch --
+// as eight by-value arguments all ~90 scalars were loaded up front and 160 of NARRE's lived spilled in vector lanes
+// (775 v_readlane / v_writelane; tools/isa_scan.py).
+struct BackwardArgs {
+    WgradArgs w;
+    ColSum c;
+    int cs_blocks;
+    TokenArgs nx;
+    int packed;
+    RowSweep rows;
+    int row_blocks, ntower;
+};
 template <int ML, bool WIDE = false>
-__global__ __launch_bounds__(WG_THREADS, ML > 16 ? 2 : (ML == 0 && WIDE ? 8 : 4)) void narre_backward_kernel(WgradArgs w, ColSum c, int cs_blocks, TokenArgs nx,
-                                                                    int packed, RowSweep rows, int row_blocks, int ntower) {
+__global__ __launch_bounds__(WG_THREADS, ML > 16 ? 2 : (ML == 0 && WIDE ? 8 : 4)) void narre_backward_kernel(BackwardArgs by_value) {
+    // (without the ID-table role the arguments fit the scalar registers -- 15-20 spills -- and loading them up front is
+    // 0.3 us faster than at their uses: same-box A/B, profiles/r06_ab_kernargs.txt)
+    const BackwardArgs &A = ML > 0 ? kernel_args<BackwardArgs>() : by_value;
+    const WgradArgs &w = A.w;
+    const ColSum &c = A.c;
+    const TokenArgs &nx = A.nx;
+    const RowSweep &rows = A.rows;
+    const int cs_blocks = A.cs_blocks, packed = A.packed, row_blocks = A.row_blocks, ntower = A.ntower;
     const int blk0 = blockIdx.y * gridDim.x + blockIdx.x, nblk = gridDim.x * gridDim.y;
     BWD_STAMP(0, wall_clock64())
     BWD_STAMP(2, (unsigned long long)blockIdx.z + 1)
@@ -357,7 +376,8 @@ __global__ __launch_bounds__(WG_THREADS, ML > 16 ? 2 : (ML == 0 && WIDE ? 8 : 4)
 // 16,384 entries per table, their ids in dynamic LDS.
 constexpr int NROW_DP_WORDS = 4, NROW_DP_MAX_ENTRIES = 64 * 64 * NROW_DP_WORDS;
 template <int ML, bool BLK = false>
-static __global__ __launch_bounds__(NROW_THREADS) void narre_rows_kernel(RowSweep w) {
+static __global__ __launch_bounds__(NROW_THREADS) void narre_rows_kernel(RowSweep) {
+    const RowSweep &w = kernel_args<RowSweep>();
     extern __shared__ int rows_sid_dyn[];
     narre_rows_block<ML, NROW_DP_WORDS, BLK>(w, (int)blockIdx.x, rows_sid_dyn);
 }

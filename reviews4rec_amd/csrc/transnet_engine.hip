@@ -674,8 +674,8 @@ extern "C" int r4r_transnet_step(const float *table, int64_t V,
     const int packed = 3 * E / 4 <= 64;
     const int gx = packed ? (NF + 3) / 4 : NF;
     const dim3 bgrid(gx, wa.nsplit, 3 + backward_cs_slices(cs_blocks, gx * wa.nsplit) + (prefetch ? 1 : 0));
-    if (packed) narre_backward_kernel<0, false><<<bgrid, WG_THREADS, 0, st>>>(wa, cs, cs_blocks, nx, 1, RowSweep{}, 0, 3);
-    else narre_backward_kernel<0, true><<<bgrid, WG_THREADS, 0, st>>>(wa, cs, cs_blocks, nx, 0, RowSweep{}, 0, 3);
+    if (packed) narre_backward_kernel<0, false><<<bgrid, WG_THREADS, 0, st>>>(BackwardArgs{wa, cs, cs_blocks, nx, 1, RowSweep{}, 0, 3});
+    else narre_backward_kernel<0, true><<<bgrid, WG_THREADS, 0, st>>>(BackwardArgs{wa, cs, cs_blocks, nx, 0, RowSweep{}, 0, 3});
 
     const int red_blocks = (NF * 3 * E + NF + NRED_THREADS - 1) / NRED_THREADS;
     const int comp_blocks = prefetch ? (int)cdiv((V + 3) / 4, NRED_THREADS * compact_groups(V)) : 0;
