@@ -87,6 +87,15 @@ __device__ __forceinline__ float wave_max(float v) {
     return fmaxf(fmaxf(r0, r1), fmaxf(r2, r3));
 }
 
+// Lanes of ONE wave handing values to one another through LDS without a workgroup barrier: a wave's LDS operations
+// execute in order, so what is needed is only that hipcc keeps the writes before the reads (a wavefront-scope fence
+// costs no instruction).
+__device__ __forceinline__ void wave_lds_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 // Philox4x32-10, first word of the draw for counter `ctr` (the fused steps draw one word per
 // element; smallops.hip keeps the four-word form for the stand-alone dropout op)
 __device__ __forceinline__ uint32_t philox_first_word(uint64_t ctr, uint64_t seed) {

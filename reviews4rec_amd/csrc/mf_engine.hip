@@ -841,7 +841,10 @@ __device__ __forceinline__ void mf_adam_body(const MfSweep &w) {
                 int lim[NV];
 #pragma unroll
                 for (int u = 0; u < NV; ++u) lim[u] = on[u] ? cur[u] : w.now;
-                tb_catch_up_v<NV>(P, M, V, lim, w.now, w.now, w.s, w.tb);
+                // (the step-invariant scalars as VALUES, read once here: through the argument pointer they were re-loaded --
+                // an s_load and a full scalar wait -- inside each of the loop's eight predicated blocks)
+                const AdamScalars sc = w.s;
+                tb_catch_up_v<NV>(P, M, V, lim, w.now, w.now, sc, w.tb);
 #pragma unroll
                 for (int u = 0; u < NV; ++u) {
                     const int64_t i = tid + (int64_t)u * MF_THREADS;

@@ -213,6 +213,7 @@ __global__ __launch_bounds__(NT) void narre_head_kernel(NarreHead) {
                 w3_r = fp[(ts ? a.off[NP_AIW3] : a.off[NP_AUW3]) + tl];
     const float f1b_r = fp[a.off[NP_F1B] + min(tid, L - 1)], f3w_r = fp[a.off[NP_F3W] + min(tid, L - 1)];
     const float m0 = fp[a.off[NP_AUB3]], m1 = fp[a.off[NP_AIB3]], m2 = fp[a.off[NP_F3B]], m3 = fp[a.off[NP_GB]];
+    const float y_r = a.y ? a.y[b] : 0.f;                   // (the rating rides in the first round trip: wave 0's S8 does not wait for it)
     // round 2: the reads that depend on ids
 #pragma unroll
     for (int u = 0; u < OREG; ++u) {
@@ -323,111 +324,115 @@ __global__ __launch_bounds__(NT) void narre_head_kernel(NarreHead) {
     }
     __syncthreads();
     HEAD_STAMP(3)
-    // ---- S3: scores
-    for (int i = tid; i < 2 * R; i += NT) {
-        const int s = i >= R;
-        float acc = 0.f;
-        for (int k = 0; k < L; ++k) acc = fmaf(h[i * L + k] * hm[i * L + k], w3[s * L + k], acc);
-        sc[i] = acc + misc[s];
-    }
-    __syncthreads();
-    HEAD_STAMP(4)
-    // ---- S4: softmax over the R reviews of a side (pads are not masked, like the reference)
-    if (tid < 128) {                                        // wave s = side s, one review per lane (R <= MR <= 32)
+    // ---- S3 + S4 + S5 by ONE WAVE per side (wave s = side s), with no workgroup barrier between them.  A side's
+    // scores, their softmax and the attended vector are 2 R + L values; as three barrier-separated stages of all 512
+    // threads they cost 1.5 us of barrier round trips around a few hundred nanoseconds of work, and the nine stages
+    // from here to the scorer's backward 6.6 us of the launch's 18 (tools/head_trace.py).  A wave's LDS operations
+    // execute in order, so its lanes see one another's writes behind a wave-level fence; per output the operations
+    // and their order are what they were.
+    if (tid < 128) {
         const int s = tid >> 6, ln = tid & 63;
-        const float val = ln < R ? sc[s * R + ln] : -INFINITY;
-        const float mx = wave_max(val);                     // all 64 lanes take part: never reduce under a lane-divergent branch
+        float val = -INFINITY;
+        if (ln < R) {
+            const int i = s * R + ln;
+            float acc = 0.f;
+            for (int k = 0; k < L; ++k) acc = fmaf(h[i * L + k] * hm[i * L + k], w3[s * L + k], acc);
+            val = acc + misc[s];
+        }
+        // softmax over the R reviews of the side (pads are not masked, like the reference); all 64 lanes take part in
+        // the reductions: never reduce under a lane-divergent branch
+        const float mx = wave_max(val);
         const float e = ln < R ? expf(val - mx) : 0.f;
         const float den = wave_sum(e);
         if (ln < R) sc[s * R + ln] = e / den;
-    }
-    __syncthreads();
-    HEAD_STAMP(5)
-    // ---- S5: attended review vector + the ID vector (NARRE.py:110-111)
-    for (int i = tid; i < L2; i += NT) {
-        const int s = i >= L, l = i - s * L;
-        float acc = 0.f;
-        for (int r = 0; r < R; ++r) acc = fmaf(sc[s * R + r], x[(s * R + r) * L + l], acc);
-        v[i] = acc + ev[i] * evm[i];
-    }
-    __syncthreads();
-    HEAD_STAMP(6)
-    // ---- S6: interaction + dropout (final.0)
-    for (int i = tid; i < L; i += NT) {
-        const float m = draw(4 * RL + 2 * L + i);
-        cdv[L + i] = m;
-        cdv[i] = v[i] * v[L + i] * m;
-    }
-    __syncthreads();
-    HEAD_STAMP(7)
-    // ---- S7: final.1 + relu
-    for (int k = tid; k < L; k += NT) {
-        float acc = 0.f;
-        for (int l = 0; l < L; ++l) acc = fmaf(cdv[l], F1[k * (L + 1) + l], acc);
-        acc += fv[k];
-        fh[k] = acc > 0.f ? acc : 0.f;
-    }
-    __syncthreads();
-    HEAD_STAMP(8)
-    // ---- S8: final.3, bias head, SE
-    if (tid == 0) {
-        float acc = 0.f;
-        for (int k = 0; k < L; ++k) acc = fmaf(fh[k], fv[L + k], acc);
-        const float rating = acc + misc[2];
-        const float pred = ((rating + misc[4]) + misc[5]) + misc[3];
-        a.pred[b] = pred;
-        float g = 0.f;
-        if (a.y) {
-            const float d = pred - a.y[b];
-            a.se[b] = d * d;
-            g = 2.f * d * a.inv_denom;
+        wave_lds_fence();
+        if (ln < L) {                                       // attended review vector + the ID vector (NARRE.py:110-111)
+            const int i = s * L + ln;
+            float acc = 0.f;
+            for (int r = 0; r < R; ++r) acc = fmaf(sc[s * R + r], x[(s * R + r) * L + ln], acc);
+            v[i] = acc + ev[i] * evm[i];
         }
-        misc[6] = g;
-        if (a.want_grad) a.g[b] = g;
+    }
+    __syncthreads();
+    HEAD_STAMP(4)
+    // ---- S6 + S7 + S8 and the vector parts of B1 / B2 by wave 0: L-element vectors, each step reading what the one
+    // before wrote.  The other waves meanwhile write the step's ID entries and row tags (nothing computed here feeds them).
+    const int64_t nself = a.B;                              // entries [0, B): self rows, then B*R others
+    float *prow = a.part + (size_t)b * a.nhp;
+    if (tid < 64) {
+        const int ln = tid;
+        if (ln < L) {                                       // interaction + dropout (final.0)
+            const float m = draw(4 * RL + 2 * L + ln);
+            cdv[L + ln] = m;
+            cdv[ln] = v[ln] * v[L + ln] * m;
+        }
+        wave_lds_fence();
+        if (ln < L) {                                       // final.1 + relu
+            float acc = 0.f;
+            for (int l = 0; l < L; ++l) acc = fmaf(cdv[l], F1[ln * (L + 1) + l], acc);
+            acc += fv[ln];
+            fh[ln] = acc > 0.f ? acc : 0.f;
+        }
+        wave_lds_fence();
+        if (ln == 0) {                                      // final.3, bias head, SE
+            float acc = 0.f;
+            for (int k = 0; k < L; ++k) acc = fmaf(fh[k], fv[L + k], acc);
+            const float rating = acc + misc[2];
+            const float pred = ((rating + misc[4]) + misc[5]) + misc[3];
+            a.pred[b] = pred;
+            float g0 = 0.f;
+            if (a.y) {
+                const float d = pred - y_r;
+                a.se[b] = d * d;
+                g0 = 2.f * d * a.inv_denom;
+            }
+            misc[6] = g0;
+            if (a.want_grad) a.g[b] = g0;
+        }
+        if (a.want_grad) {                                  // uniform
+            wave_lds_fence();
+            const float g = misc[6];
+            if (ln < L) {                                   // B1: final.3 / final.1 bias, d fpre
+                prow[head_col(a, a.off[NP_F3W] + ln)] = g * fh[ln];
+                const float d = fh[ln] > 0.f ? g * fv[L + ln] : 0.f;
+                fh[L + ln] = d;
+                prow[head_col(a, a.off[NP_F1B] + ln)] = d;
+            }
+            if (ln == 0) {
+                prow[head_col(a, a.off[NP_F3B])] = g;
+                prow[head_col(a, a.off[NP_GB])] = g;
+            }
+            wave_lds_fence();
+            if (ln < L) {                                   // B2: d interaction -> d v
+                float acc = 0.f;
+                for (int k = 0; k < L; ++k) acc = fmaf(fh[L + k], F1[k * (L + 1) + ln], acc);
+                const float dcat = acc * cdv[L + ln];
+                dv[ln] = dcat * v[L + ln];
+                dv[L + ln] = dcat * v[ln];
+            }
+        }
+    } else if (a.want_grad) {
+        const int t2 = tid - 64;
+        if (t2 == 0) {
+            // ids + tags of the self rows: user table entry b <- uid, item table entry b <- iid
+            for (int s = 0; s < 2; ++s) {
+                const int64_t id = SEL2(a.self_id, s)[b];
+                SEL2(a.gid, s)[b] = id;
+                SEL2(a.tag, s)[id] = a.now;
+            }
+        }
+        for (int i = t2; i < 2 * R; i += NT - 64) {         // others: side s's ids index table 1-s
+            const int s = i >= R, r = i - s * R;
+            const int64_t id = SEL2(a.other_id, s)[b * R + r];
+            SEL2(a.gid, 1 - s)[nself + b * R + r] = id;
+            SEL2(a.tag, 1 - s)[id] = a.now;
+        }
     }
     if (!a.want_grad) return;                               // uniform
     __syncthreads();
-    HEAD_STAMP(9)
-    const float g = misc[6];
-    float *prow = a.part + (size_t)b * a.nhp;
-    const int64_t nself = a.B;                              // entries [0, B): self rows, then B*R others
-    // ---- B1: final.3 / final.1 bias, d fpre
-    for (int k = tid; k < L; k += NT) {
-        prow[head_col(a, a.off[NP_F3W] + k)] = g * fh[k];
-        const float d = fh[k] > 0.f ? g * fv[L + k] : 0.f;
-        fh[L + k] = d;
-        prow[head_col(a, a.off[NP_F1B] + k)] = d;
-    }
-    if (tid == 0) {
-        prow[head_col(a, a.off[NP_F3B])] = g;
-        prow[head_col(a, a.off[NP_GB])] = g;
-        // ids + tags of the self rows: user table entry b <- uid, item table entry b <- iid
-        for (int s = 0; s < 2; ++s) {
-            const int64_t id = SEL2(a.self_id, s)[b];
-            SEL2(a.gid, s)[b] = id;
-            SEL2(a.tag, s)[id] = a.now;
-        }
-    }
-    for (int i = tid; i < 2 * R; i += NT) {                // others: side s's ids index table 1-s
-        const int s = i >= R, r = i - s * R;
-        const int64_t id = SEL2(a.other_id, s)[b * R + r];
-        SEL2(a.gid, 1 - s)[nself + b * R + r] = id;
-        SEL2(a.tag, 1 - s)[id] = a.now;
-    }
-    __syncthreads();
-    HEAD_STAMP(10)
-    // ---- B2: final.1 weight, d interaction -> d v
+    HEAD_STAMP(5)
+    // ---- B2 (final.1 weight) + B3: self ID rows (compact), d attention weights
     for (int i = tid; i < L * L; i += NT) { const int k = qd(i, invL); prow[head_col(a, a.off[NP_F1W] + i)] = fh[L + k] * cdv[i - k * L]; }
-    for (int l = tid; l < L; l += NT) {
-        float acc = 0.f;
-        for (int k = 0; k < L; ++k) acc = fmaf(fh[L + k], F1[k * (L + 1) + l], acc);
-        const float dcat = acc * cdv[L + l];
-        dv[l] = dcat * v[L + l];
-        dv[L + l] = dcat * v[l];
-    }
-    __syncthreads();
-    HEAD_STAMP(11)
-    // ---- B3: self ID rows (compact), d attention weights
     for (int i = tid; i < L2; i += NT) {
         const int s = i >= L, l = i - s * L;
         SEL2(a.grow, s)[(size_t)b * L + l] = dv[i] * evm[i];
@@ -439,34 +444,31 @@ __global__ __launch_bounds__(NT) void narre_head_kernel(NarreHead) {
         da[i] = acc;
     }
     __syncthreads();
-    HEAD_STAMP(12)
-    // ---- B4: softmax backward
-    if (tid < 128) {                                        // wave s = side s: d score = a (d a - <a, d a>)
+    HEAD_STAMP(6)
+    // ---- B4 + B5 by one wave per side: softmax backward, the scorer's output layer, d hidden
+    if (tid < 128) {
         const int s = tid >> 6, ln = tid & 63;
         const float av = ln < R ? sc[s * R + ln] : 0.f, dav = ln < R ? da[s * R + ln] : 0.f;
-        const float dot = wave_sum(av * dav);
+        const float dot = wave_sum(av * dav);               // d score = a (d a - <a, d a>)
         if (ln < R) da[s * R + ln] = av * (dav - dot);
+        wave_lds_fence();
+        if (ln == 0) {
+            float acc = 0.f;
+            for (int r = 0; r < R; ++r) acc += da[s * R + r];
+            prow[head_col(a, (s ? a.off[NP_AIB3] : a.off[NP_AUB3]))] = acc;
+        }
+        if (ln < L) {
+            float acc = 0.f;
+            for (int r = 0; r < R; ++r) acc = fmaf(da[s * R + r], h[(s * R + r) * L + ln] * hm[(s * R + r) * L + ln], acc);
+            prow[head_col(a, (s ? a.off[NP_AIW3] : a.off[NP_AUW3]) + ln)] = acc;
+        }
+        for (int rem = ln; rem < RL; rem += 64) {           // d hpre of the side's R x L hidden units
+            const int i = s * RL + rem, r = qd(rem, invL), k = rem - r * L;
+            dz[i] = h[i] > 0.f ? da[s * R + r] * w3[s * L + k] * hm[i] : 0.f;
+        }
     }
     __syncthreads();
-    HEAD_STAMP(13)
-    // ---- B5: scorer output layer, d hidden
-    if (tid < 2) {
-        float acc = 0.f;
-        for (int r = 0; r < R; ++r) acc += da[tid * R + r];
-        prow[head_col(a, (tid ? a.off[NP_AIB3] : a.off[NP_AUB3]))] = acc;
-    }
-    for (int i = tid; i < L2; i += NT) {
-        const int s = i >= L, k = i - s * L;
-        float acc = 0.f;
-        for (int r = 0; r < R; ++r) acc = fmaf(da[s * R + r], h[(s * R + r) * L + k] * hm[(s * R + r) * L + k], acc);
-        prow[head_col(a, (s ? a.off[NP_AIW3] : a.off[NP_AUW3]) + k)] = acc;
-    }
-    for (int i = tid; i < 2 * RL; i += NT) {
-        const int s = i >= RL, rem = i - s * RL, r = qd(rem, invL), k = rem - r * L;
-        dz[i] = h[i] > 0.f ? da[s * R + r] * w3[s * L + k] * hm[i] : 0.f;     // d hpre
-    }
-    __syncthreads();
-    HEAD_STAMP(14)
+    HEAD_STAMP(7)
     // ---- B6: scorer hidden layer gradients, d x (-> d z), d other (compact rows)
     for (int i = tid; i < L2; i += NT) {
         const int s = i >= L, k = i - s * L;
@@ -501,14 +503,14 @@ __global__ __launch_bounds__(NT) void narre_head_kernel(NarreHead) {
         }
     }
     __syncthreads();
-    HEAD_STAMP(15)
+    HEAD_STAMP(8)
 #pragma unroll
     for (int it = 0; it < (2 * MR * ML + NT - 1) / NT; ++it) {
         const int i = tid + NT * it;
         if (i < 2 * RL) dz[i] = dzv[it];
     }
     __syncthreads();
-    HEAD_STAMP(16)
+    HEAD_STAMP(9)
     // ---- B7: TextCNN FC gradients, d pooled
     for (int i = tid; i < L2; i += NT) {
         const int s = i >= L, l = i - s * L;
@@ -546,7 +548,7 @@ __global__ __launch_bounds__(NT) void narre_head_kernel(NarreHead) {
         }
         *reinterpret_cast<hf4 *>(SEL2(a.g_pooled, s) + (b * R + r) * NF + 4 * q) = acc;
     }
-    HEAD_STAMP(17)
+    HEAD_STAMP(10)
 }
 
 static size_t narre_head_lds_bytes(int R, int L) {

@@ -92,11 +92,16 @@ __device__ __forceinline__ void tb_catch_up_v(tb_f32x4 (&P)[N], tb_f32x4 (&M)[N]
         lrv[j] = tb.lr_bc1[j]; isv[j] = tb.isb2[j];
         asm volatile("" : "+v"(lrv[j]), "+v"(isv[j]));
     }
+    // ... and the six step-invariant ones are pinned in scalar registers: read through the argument pointer (common.h:
+    // kernel_args) they are loads hipcc is free to SINK into the blocks that use them -- an s_load_dwordx4 and a full
+    // scalar wait in front of each of the eight predicated updates.
+    AdamScalars scp = sc0;
+    asm volatile("" : "+s"(scp.beta1), "+s"(scp.beta2), "+s"(scp.eps), "+s"(scp.wd), "+s"(scp.omb1), "+s"(scp.omb2));
 #pragma unroll
     for (int j = 0; j < MF_TB_MAX; ++j) {
         const int s = now - (MF_TB_MAX - 1 - j);
         if (s > upto) continue;                             // uniform
-        AdamScalars sc = sc0;
+        AdamScalars sc = scp;
         sc.lr_over_bc1 = lrv[j];
         sc.inv_sqrt_bc2 = isv[j];
 #pragma unroll

@@ -237,6 +237,10 @@ class PeerExchange:
         """Raise if a wait timed out (a host sync: call it at epoch ends, not per step)."""
         word = int(self.local[1].item())
         if word:
+            # (the device side skips every later wait while the word is set -- csrc/peer_device.h -- so it is cleared
+            # with the report: a caller that catches this and goes on gets its waits back, not a whole epoch of
+            # exchanges over incomplete buffers)
+            self.local[1].zero_()
             raise RuntimeError('PeerExchange: rank %d never raised its flag (waited %.0f s)' % (word - 1, self.TIMEOUT_S))
 
     def close(self):

@@ -766,7 +766,8 @@ class DeepCoNNEngine(_ConvRule, _Spans):
             import warnings
             warnings.warn("autotune_exchange: both exchange forms failed on the on-stream communicator; using "
                           "torch.distributed's collectives", RuntimeWarning)
-            self.dp.stream_rccl = None
+            comm, self.dp.stream_rccl = self.dp.stream_rccl, None
+            comm.close(abort=True)                           # (every rank is here: the decision was agreed; a hung collective dies with it)
             res = candidates()
         if not res:
             self.exchange = keep
