@@ -52,18 +52,18 @@ PEAK_L2_GBS = 34500.0             # MI355X_MICROARCH.md: L2, 4 MiB per XCD, aggr
 WORKLOAD = 'cfg3_deepconn_electronics_e300'
 
 
-# rocprofv3 --pmc summaries (profiles/, made by tools/r05_profiles.sh: separate counter passes of the same bench command)
+# rocprofv3 --pmc summaries (profiles/, made by tools/r06_profiles.sh: separate counter passes of the same bench command)
 # by (workload, ratings per rank, doc_fill, token_dist)
 PMC_SUMMARIES = {
-    (WORKLOAD, 128, 'lognormal', 'zipf'): 'r05_bench_pmc_summary.json',
-    ('cfg1_bias_only_musical', 128, 'lognormal', 'zipf'): 'r05_bench_cfg1_pmc_summary.json',
-    ('cfg2_mfdot_electronics', 128, 'lognormal', 'zipf'): 'r05_bench_cfg2_pmc_summary.json',
-    ('cfg2_mfdot_electronics', 8192, 'lognormal', 'zipf'): 'r05_bench_cfg2_b8192_pmc_summary.json',
-    ('cfg4_narre_kindle', 128, 'lognormal', 'zipf'): 'r05_bench_cfg4_pmc_summary.json',
-    ('cfg5_transnetpp_synthetic', 128, 'lognormal', 'zipf'): 'r05_bench_cfg5_pmc_summary.json',
-    (WORKLOAD, 128, 'full', 'uniform'): 'r05_bench_cfg3_fullunif_pmc_summary.json',
+    (WORKLOAD, 128, 'lognormal', 'zipf'): 'r06_bench_pmc_summary.json',
+    ('cfg1_bias_only_musical', 128, 'lognormal', 'zipf'): 'r06_bench_cfg1_pmc_summary.json',
+    ('cfg2_mfdot_electronics', 128, 'lognormal', 'zipf'): 'r06_bench_cfg2_pmc_summary.json',
+    ('cfg2_mfdot_electronics', 8192, 'lognormal', 'zipf'): 'r06_bench_cfg2_b8192_pmc_summary.json',
+    ('cfg4_narre_kindle', 128, 'lognormal', 'zipf'): 'r06_bench_cfg4_pmc_summary.json',
+    ('cfg5_transnetpp_synthetic', 128, 'lognormal', 'zipf'): 'r06_bench_cfg5_pmc_summary.json',
+    (WORKLOAD, 128, 'full', 'uniform'): 'r06_bench_cfg3_fullunif_pmc_summary.json',
     # the one true HBM gather: full-length documents of uniformly drawn words at a 1 M-word vocabulary, projection pinned
-    ('cfg5_transnetpp_synthetic', 128, 'full', 'uniform'): 'r05_cfg5_fullunif_pmc_summary.json',
+    ('cfg5_transnetpp_synthetic', 128, 'full', 'uniform'): 'r06_cfg5_fullunif_pmc_summary.json',
 }
 
 
@@ -72,7 +72,7 @@ def measured_traffic(kernel, args, live_launch_s=None):
     --pmc summary (profiles/: separate counter passes of this same command, corrected as
     MI355X_MICROARCH.md prescribes) -- only for the configuration those passes ran, and only while the
     summary still describes this build: if the kernel duration recorded with the counters is more than
-    25 % away from the one measured live in this run, the summary is stale and no traffic is reported."""
+    35 % away from the one measured live in this run, the summary is stale and no traffic is reported."""
     name = PMC_SUMMARIES.get((args.workload, args.batch_per_gpu, args.doc_fill, args.token_dist))
     path = os.path.join(ROOT, 'profiles', name) if name else None
     pinned_ok = args.conv_algo == 'auto' or (args.conv_algo == 'project' and args.doc_fill == 'full'
@@ -88,7 +88,8 @@ def measured_traffic(kernel, args, live_launch_s=None):
         return None, None
     v = min(same, key=lambda v: abs(v['avg_duration_us_under_pmc'] * 1e-6 - (live_launch_s or 0.0)))
     then = v['avg_duration_us_under_pmc']
-    if live_launch_s and abs(then * 1e-6 - live_launch_s) > 0.25 * live_launch_s:
+    # (a kernel runs 5-20 % longer under the counter passes than in the timed region: the band is wide enough for that)
+    if live_launch_s and abs(then * 1e-6 - live_launch_s) > 0.35 * live_launch_s:
         return None, 'profiles/%s is stale for %s (%.1f us then, %.1f us now)' % (name, kernel, then, live_launch_s * 1e6)
     return v.get('hbm_bytes_per_launch'), 'profiles/' + name
 

@@ -103,8 +103,10 @@ __device__ __forceinline__ int head_col(const NarreHead &a, int flat_off) {
 HEAD_TRACE_DEFINE(r4r_debug_narre_head_trace)
 BWD_TRACE_DEFINE(r4r_debug_narre_bwd_trace)
 template <int MR, int ML, int NT>
-__global__ __launch_bounds__(NT) void narre_head_kernel(NarreHead) {
-    const NarreHead &a = kernel_args<NarreHead>();          // (fields loaded at their uses: common.h -- 88 spilled scalars before)
+__global__ __launch_bounds__(NT) void narre_head_kernel(NarreHead by_value) {
+    // (fields loaded at their uses: common.h -- 88 spilled scalars before, 0 now; the 64 x 64 instantiation is at its
+    // 256-VGPR cap and puts the address arithmetic of lazy loads into scratch memory: it keeps the up-front form)
+    const NarreHead &a = ML <= 32 ? kernel_args<NarreHead>() : by_value;
     HEAD_STAMP(0)
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int R = a.R, L = a.L, RL = R * L, L2 = 2 * L;

@@ -346,19 +346,25 @@ class _ConvRule:
         """For spans of TRAINING steps.  -> (how many consecutive steps, starting `ahead` steps from now, run on one
         request without a probe -- 0: that step probes --, the request, the algorithm that runs, whether the rule
         counts these steps).  Changes nothing; `_rule_advance` after the steps ran."""
-        lib = _lib.lib()
         if getattr(self, 'gemm_math', 'f32') == 'f16x2':
             return 0, None, None, False                      # (the fp16-split GEMM refreshes its scales between steps)
+        # (r4r_conv_algo is a pure function of its arguments and the process environment: asked once per shape -- a span
+        # call is on the critical path of a short timed region, and three C calls per look were 5 us of it)
+        memo = self.__dict__.setdefault('_rule_memo', {})
+        key = (docs_per_tower, T)
+        if key not in memo:
+            lib = _lib.lib()
+            memo[key] = tuple(lib.r4r_conv_algo(r, docs_per_tower, T, self.E, 100) for r in (0, 1, 2))
+        resolved = memo[key]
         req = self.conv_algo
-        static = lib.r4r_conv_algo(0, docs_per_tower, T, self.E, 100) if req == 0 else req
-        small = (req == 0 and static != 2 and self.V <= self.SMALL_LAUNCH_MAX_V
-                 and lib.r4r_conv_algo(2, docs_per_tower, T, self.E, 100) == 2)
+        static = resolved[0] if req == 0 else req
+        small = req == 0 and static != 2 and self.V <= self.SMALL_LAUNCH_MAX_V and resolved[2] == 2
         if not (req == 0 and (static == 2 or small)):
-            return 1 << 30, req, lib.r4r_conv_algo(req, docs_per_tower, T, self.E, 100), False
+            return 1 << 30, req, resolved[req], False
         n = self._rule_n + int(ahead)
         to_probe = self.PROBE_AT - n if n <= self.PROBE_AT else (self.PROBE_AT - n) % self.PROBE_EVERY
         req = 2 if self._rule_choice is None else self._rule_choice
-        return to_probe, req, lib.r4r_conv_algo(req, docs_per_tower, T, self.E, 100), True
+        return to_probe, req, resolved[req], True
 
     def _rule_advance(self, steps, counted):
         if counted:
