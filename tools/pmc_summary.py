@@ -16,7 +16,11 @@ import sys
 #     FETCH_SIZE reads 278 MB -- exactly the guide's half.  Doubled.
 #   * the projection GEMMs' table-row pieces (64 B per row and K chunk) matched their known byte count 1:1 (round 2
 #     calibration): not doubled.  WRITE_SIZE is taken as reported.
-FETCH_X2 = ('r4r::proj_gather_max_kernel',)
+#   * mf_adam_kernel (the ID-table sweeps) streams p, m, v as one float4 per lane -- the guide's case word for word -- and
+#     WRITES exactly the elements it reads: its true read bytes are at least its write bytes, and FETCH_SIZE reads half
+#     of WRITE_SIZE on every workload (round 6: cfg5 42.5 vs 83.5 MB, cfg2 14.8 vs 27.9, the B = 8,192 flush form 85.1
+#     vs 164.1).  Doubled.
+FETCH_X2 = ('r4r::proj_gather_max_kernel', 'r4r::mf_adam_kernel')
 
 
 def hbm_bytes(kernel, k):
