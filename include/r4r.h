@@ -843,6 +843,22 @@ int r4r_deepconn_span(const uint64_t *loader, int64_t first_batch, int64_t steps
                       uint64_t draws_per_step, float inv_denom, int conv_algo, int token_buffer, int tokens_ready,
                       float *flat_m, float *flat_v, float lr, double beta1, double beta2, float eps,
                       float weight_decay, int64_t adam_step, void *stream);
+/* Data parallel: r4r_deepconn_span with the gradient exchange between every step's gradients and its
+ * Adam update -- step k = r4r_deepconn_step (gradients only, inv_denom = 1 / B_global) -> the collective -> the update,
+ * everything enqueued from C.  exchange 0: `collective` = the address of RCCL's ncclAllReduce (in place on flat_g,
+ * float32 sum), then r4r_adam_multi; exchange 1: ncclAllGather of flat_g into `gathered` [world][total], then
+ * r4r_adam_gathered (rank order).  `collective` / `comm`: resolved and built by the caller in the RCCL library it
+ * already holds (reviews4rec_amd/dist.py: StreamRccl); total = the flat layout's element count.  Replaces, per step,
+ * the reference loop body of main.py:26-60 on every rank + the gradient sum the reference (single-process,
+ * main.py:407) does not have. */
+int r4r_deepconn_span_dp(const uint64_t *loader, int64_t first_batch, int64_t steps, int announce,
+                         int64_t *built_group, int64_t *steps_done, const float *table, int64_t V, float *flat_p,
+                         float *flat_g, float *pred, float *se, float *sse_accum, void *ws, size_t ws_bytes, int T,
+                         int E, int L, float dropout_p, int training, uint64_t seed, uint64_t offset,
+                         uint64_t draws_per_step, float inv_denom, int conv_algo, int token_buffer, int tokens_ready,
+                         float *flat_m, float *flat_v, int64_t total, float lr, double beta1, double beta2, float eps,
+                         float weight_decay, int64_t adam_step, int exchange, void *collective, void *comm, int world,
+                         float *gathered, void *stream);
 int r4r_deepconnpp_span(const uint64_t *loader, int64_t first_batch, int64_t steps, int announce,
                         int64_t *built_group, int64_t *steps_done, const float *table, int64_t V, float *flat_p,
                         float *flat_g, float *flat_m, float *flat_v, const uint64_t *rows_p,

@@ -187,6 +187,56 @@ extern "C" int r4r_deepconn_span(const uint64_t *loader, int64_t first_batch, in
                     });
 }
 
+// ---- data parallel: the headline family's span with the gradient exchange between every step's
+// gradients and its update, all of it enqueued from C.  The collective is RCCL's own entry point, called through the
+// address the caller resolved in the library it already holds (reviews4rec_amd/dist.py: StreamRccl) on the
+// communicator it built -- no second copy of RCCL in the process, nothing linked here.
+typedef int (*rccl_allreduce_fn)(const void *, void *, size_t, int, int, void *, void *);
+typedef int (*rccl_allgather_fn)(const void *, void *, size_t, int, void *, void *);
+constexpr int RCCL_FLOAT32 = 7, RCCL_SUM = 0;              // ncclDataType_t / ncclRedOp_t (rccl.h)
+
+extern "C" int r4r_deepconn_span_dp(const uint64_t *loader, int64_t first_batch, int64_t steps, int announce,
+                                    int64_t *built_group, int64_t *steps_done, const float *table, int64_t V,
+                                    float *flat_p, float *flat_g, float *pred, float *se, float *sse_accum, void *ws,
+                                    size_t ws_bytes, int T, int E, int L, float dropout_p, int training, uint64_t seed,
+                                    uint64_t offset, uint64_t draws_per_step, float inv_denom, int conv_algo,
+                                    int token_buffer, int tokens_ready, float *flat_m, float *flat_v, int64_t total,
+                                    float lr, double beta1, double beta2, float eps, float weight_decay,
+                                    int64_t adam_step, int exchange, void *collective, void *comm, int world,
+                                    float *gathered, void *stream) {
+    R4R_REQUIRE(flat_g && flat_m && flat_v && adam_step >= 1 && total > 0, "deepconn_span_dp: training steps only");
+    R4R_REQUIRE(collective && comm && world >= 1 && (exchange == 0 || (exchange == 1 && gathered)),
+                "deepconn_span_dp: exchange 0 (all-reduce) or 1 (all-gather into `gathered` [world][total]) with RCCL's "
+                "entry point and a communicator");
+    const int64_t B = loader ? (int64_t)loader[26] : 0;
+    return run_span(
+        loader, first_batch, steps, announce, built_group, steps_done, as_stream(stream),
+        [&](int64_t k, const SpanBatch &c, const SpanBatch *n) {
+            if (int rc = r4r_deepconn_step(table, V, c.user_doc, c.item_doc, c.y, flat_p, flat_g, pred, se, sse_accum, ws,
+                                           ws_bytes, B, T, E, L, dropout_p, training, seed,
+                                           offset + (uint64_t)k * draws_per_step, inv_denom, conv_algo,
+                                           (token_buffer + (int)k) & 1, k ? 1 : tokens_ready, n ? n->user_doc : nullptr,
+                                           n ? n->item_doc : nullptr, nullptr, nullptr, lr, beta1, beta2, eps,
+                                           weight_decay, 0, stream))
+                return rc;
+            if (exchange == 0) {
+                const int rc = reinterpret_cast<rccl_allreduce_fn>(collective)(flat_g, flat_g, (size_t)total, RCCL_FLOAT32,
+                                                                              RCCL_SUM, comm, stream);
+                if (rc) { set_error("deepconn_span_dp: ncclAllReduce returned %d", rc); return R4R_ERR_LAUNCH; }
+                const uint64_t p1[1] = {(uint64_t)flat_p}, g1[1] = {(uint64_t)flat_g}, m1[1] = {(uint64_t)flat_m},
+                               v1[1] = {(uint64_t)flat_v};
+                const int64_t n1[1] = {total};
+                return r4r_adam_multi(1, p1, g1, m1, v1, n1, lr, beta1, beta2, eps, weight_decay, adam_step + k, nullptr,
+                                      stream);
+            }
+            const int rc = reinterpret_cast<rccl_allgather_fn>(collective)(flat_g, gathered, (size_t)total, RCCL_FLOAT32,
+                                                                          comm, stream);
+            if (rc) { set_error("deepconn_span_dp: ncclAllGather returned %d", rc); return R4R_ERR_LAUNCH; }
+            return r4r_adam_gathered(flat_p, gathered, world, flat_g, flat_m, flat_v, total, lr, beta1, beta2, eps,
+                                     weight_decay, adam_step + k, stream);
+        });
+}
+
 extern "C" int r4r_deepconnpp_span(const uint64_t *loader, int64_t first_batch, int64_t steps, int announce,
                                    int64_t *built_group, int64_t *steps_done, const float *table, int64_t V, float *flat_p, float *flat_g,
                                    float *flat_m, float *flat_v, const uint64_t *rows_p, const uint64_t *rows_m,

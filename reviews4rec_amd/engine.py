@@ -96,22 +96,36 @@ class _Spans:
         """How many consecutive steps, starting `ahead` steps from now, one call may carry (0: that step is its own)."""
         return self.SPAN_STEPS
 
-    def train_epoch(self, reader):
+    def _span_dp_ok(self):
+        """Can this engine's DATA-PARALLEL step be enqueued from C (the exchange included)?"""
+        return False
+
+    def train_epoch(self, reader, counts=None):
         """One epoch over ``reader`` (data.DataLoader on the device): every batch of ``reader.iter()``, in order, as
         main.train's loop would train on it.  -> (ratings, batches), or None when this reader / engine pair has no
-        span form (the caller iterates)."""
-        if os.environ.get('R4R_SPANS', '1') == '0' or getattr(self, 'dp', None) is not None and self.dp.on:
+        span form (the caller iterates).  Data parallel: ``counts`` = the global size of every step's batch
+        (DataParallel.epoch_counts); steps in which every rank holds a full batch go through the span entry, the
+        others -- and engines whose exchange is a Python-side call -- through train_step."""
+        dp = getattr(self, 'dp', None)
+        dp_on = dp is not None and dp.on
+        if os.environ.get('R4R_SPANS', '1') == '0' or (dp_on and (counts is None or not self._span_dp_ok())):
             return None
         desc = reader.span_descriptor() if hasattr(reader, 'span_descriptor') else None
-        if desc is None or desc.full_batches == 0 or not self._span_ok(desc):
+        if desc is None or not self._span_ok(desc) or (desc.full_batches == 0 and not dp_on):
             return None
         kw = {'defer_sweep': True} if getattr(self, 'TEMPORAL_SWEEP', False) else {}
         nb, total, b = desc.full_batches, len(reader), 0
+        if dp_on:
+            # (every rank walks the SAME list of steps -- len(counts) of them -- and issues one exchange per step,
+            # whether from a span or from train_step: a shard that has run out contributes an empty batch)
+            total = len(counts)
+            full = desc.batch_size * dp.world
+            nb = min(nb, next((k for k, c in enumerate(counts) if c != full), len(counts)))
         while b < total:
             k = min(self._span_limit(desc), self.SPAN_STEPS, nb - b) if b < nb else 0
-            if k <= 0:                                       # the ragged tail, a probing step
+            if k <= 0:                                       # the ragged tail, a probing step, a step some rank has less for
                 data, y = reader.batch(b)
-                self.train_step(data, y, n_global=int(y.shape[0]), **kw)
+                self.train_step(data, y, n_global=int(counts[b]) if dp_on else int(y.shape[0]), **kw)
                 b += 1
                 continue
             announce = b + k < nb and self._span_limit(desc, ahead=k) > 0
@@ -616,10 +630,16 @@ class DeepCoNNEngine(_ConvRule, _Spans):
     def _span_limit(self, desc, ahead=0):
         return self._rule_peek(desc.batch_size, desc.doc_shape[0], ahead)[0]
 
+    def _span_dp_ok(self):
+        # the exchange must be one the C side can issue itself: RCCL through the package's own communicator
+        return (self.exchange in ('allreduce', 'gather') and getattr(self.dp, 'stream_rccl', None) is not None
+                and self.dp.stream_rccl.comm)
+
     @torch.no_grad()
     def _span(self, desc, first, steps, announce):
         """Steps on batches first .. first + steps - 1 of the loader behind `desc` in ONE C call (r4r_deepconn_span); the
-        engine's per-step state moves as `steps` train_step calls with next_data would have moved it."""
+        engine's per-step state moves as `steps` train_step calls with next_data would have moved it.  Data parallel
+        (every rank a full batch): r4r_deepconn_span_dp -- gradients, RCCL's collective, the update, per step, from C."""
         lib = _lib.lib()
         B, T = desc.batch_size, desc.doc_shape[0]
         pred, se = self._outputs(B)
@@ -642,12 +662,29 @@ class DeepCoNNEngine(_ConvRule, _Spans):
         training, p_drop = self.model.training, float(self.hp['dropout'])
         draws = B * 2 * self.L if (training and p_drop > 0.0) else 0
         done = ctypes.c_int64(0)
-        rc = lib.r4r_deepconn_span(
-            desc.words, int(first), int(steps), int(bool(announce)), ctypes.byref(desc.built), ctypes.byref(done),
-            ptr(self.table), self.V, ptr(self.flat_p), ptr(self.flat_g), ptr(pred), ptr(se), ptr(self.sse), ptr(ws),
-            ws.numel(), T, self.E, self.L, p_drop, int(training), self.seed, self.offset, draws, 1.0 / float(B), req, buf,
-            ready, ptr(self.flat_m), ptr(self.flat_v), self.lr, self.betas[0], self.betas[1], self.eps, self.wd,
-            self.step_count + 1, main.cuda_stream)
+        if self.dp is not None and self.dp.on:
+            if not self._span_dp_ok():
+                raise RuntimeError('DeepCoNNEngine: the data-parallel span needs the on-stream RCCL communicator and the '
+                                   "'allreduce' or 'gather' exchange (got %r)" % (self.exchange,))
+            comm = self.dp.stream_rccl
+            gather = self.exchange == 'gather'
+            if gather:
+                self._exchange_prepare('gather')
+            fn = ctypes.cast(comm.lib.ncclAllGather if gather else comm.lib.ncclAllReduce, ctypes.c_void_p).value
+            rc = lib.r4r_deepconn_span_dp(
+                desc.words, int(first), int(steps), int(bool(announce)), ctypes.byref(desc.built), ctypes.byref(done),
+                ptr(self.table), self.V, ptr(self.flat_p), ptr(self.flat_g), ptr(pred), ptr(se), ptr(self.sse), ptr(ws),
+                ws.numel(), T, self.E, self.L, p_drop, int(training), self.seed, self.offset, draws,
+                1.0 / float(B * self.dp.world), req, buf, ready, ptr(self.flat_m), ptr(self.flat_v), self.total, self.lr,
+                self.betas[0], self.betas[1], self.eps, self.wd, self.step_count + 1, int(gather), fn, comm.comm,
+                self.dp.world, ptr(self._gathered) if gather else None, main.cuda_stream)
+        else:
+            rc = lib.r4r_deepconn_span(
+                desc.words, int(first), int(steps), int(bool(announce)), ctypes.byref(desc.built), ctypes.byref(done),
+                ptr(self.table), self.V, ptr(self.flat_p), ptr(self.flat_g), ptr(pred), ptr(se), ptr(self.sse), ptr(ws),
+                ws.numel(), T, self.E, self.L, p_drop, int(training), self.seed, self.offset, draws, 1.0 / float(B), req,
+                buf, ready, ptr(self.flat_m), ptr(self.flat_v), self.lr, self.betas[0], self.betas[1], self.eps, self.wd,
+                self.step_count + 1, main.cuda_stream)
         k = int(done.value)                                  # (an error names the step it stopped at: the state follows)
         self.step_count += k
         self.offset += k * draws
@@ -661,7 +698,7 @@ class DeepCoNNEngine(_ConvRule, _Spans):
         if rc == 0 and announce and projecting:
             nx = _span_slots(desc, first + steps)
             self._prepared = ((nx[3], nx[4], B, T), self._last_buf ^ 1, None, (_RawPtr(nx[3], desc), _RawPtr(nx[4], desc)))
-        _lib.check(rc, 'r4r_deepconn_span')
+        _lib.check(rc, 'r4r_deepconn_span_dp' if (self.dp is not None and self.dp.on) else 'r4r_deepconn_span')
 
     def _exchange_prepare(self, how):
         """What this rank needs, by itself, before exchange form `how` can run (no collective in here)."""

@@ -79,8 +79,8 @@ def train(model, criterion, optimizer, reader, hyper_params, engine=None, dp=Non
     # a device-side loader + a native engine: the epoch's full batches go to the device K steps per host call
     # (engine._Spans: the batch construction and the steps enqueued from C; the same kernels, arguments and bits)
     spanned = None
-    if engine is not None and not dp_on and hyper_params.get('spans', True) and hasattr(engine, 'train_epoch'):
-        spanned = engine.train_epoch(reader)
+    if engine is not None and hyper_params.get('spans', True) and hasattr(engine, 'train_epoch') and (not dp_on or counts is not None):
+        spanned = engine.train_epoch(reader, counts=counts)
     if spanned is not None:
         total_x, total_batches = spanned
         batches = ()

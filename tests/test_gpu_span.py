@@ -7,6 +7,7 @@ probe step in the middle of the first epoch (auto), span lengths that do and do 
 
 The loop the spans replace: /root/reference/main.py:23-60 over data.py:250-372 / data_fast.py:99-109."""
 import copy
+import os
 import ctypes
 
 import numpy as np
@@ -162,3 +163,75 @@ def test_span_arguments_are_checked_before_anything_runs():
     lib = _lib.lib()
     assert lib.r4r_span_batch(None, 0, (ctypes.c_uint64 * 8)()) != 0
     assert b'span' in lib.r4r_last_error()
+
+
+# ---- data parallel: the headline family's span with the exchange issued from C (r4r_deepconn_span_dp), as a ONE-rank
+# RCCL job (the test box has one GPU; RCCL wants one per rank): every call of the N > 1 path is made, with the real
+# communicator, and an epoch through DP spans must leave the bits of the per-step DP loop.
+def _dp_span_worker(rank, world, port, out_dir):
+    import os
+    import sys
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank), R4R_DIST_BACKEND='nccl', R4R_DP_SINGLE='1', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    import reviews4rec_amd
+    from reviews4rec_amd import dist as r4dist, main as M
+    from reviews4rec_amd.data import DataLoader
+    from reviews4rec_amd.loss import MSELoss
+    from reviews4rec_amd.utils import xavier_init
+    from test_gpu_span import hyper, tiny_corpus
+    r4dist.init_from_env()
+    corpus = tiny_corpus(seed=15)
+    res = {}
+    for exchange in ('allreduce', 'gather'):
+        os.environ['R4R_DP_EXCHANGE'] = exchange
+        got = {}
+        for spans in (False, True):
+            hp = hyper('deepconn', spans=spans)
+            reader = DataLoader(hp, corpus['train'], corpus['user_reviews'], corpus['item_reviews'], None,
+                                this_index_user_item=corpus['this_index_user_item'], device='cuda')
+            torch.manual_seed(5)
+            model = reviews4rec_amd.get_model_class('deepconn')(hp)
+            xavier_init(model)
+            model = model.cuda()
+            dp = r4dist.DataParallel(model)
+            dp.broadcast_parameters()
+            engine = M.make_engine(hp, model, dp=dp, rank=rank)
+            engine.SPAN_STEPS = 9
+            calls = [0]
+            inner = engine._span
+
+            def counting(*a, _inner=inner, **k):
+                calls[0] += 1
+                return _inner(*a, **k)
+            engine._span = counting
+            metrics = [M.train(model, MSELoss(hp), None, reader, hp, engine=engine, dp=dp) for _ in range(2)]
+            torch.cuda.synchronize()
+            got[spans] = (metrics, {k: v.detach().cpu().clone() for k, v in model.state_dict().items()},
+                          engine.flat_m.cpu().clone(), engine.flat_v.cpu().clone(), engine.step_count, engine.offset, calls[0])
+            dp.close()
+        a, b = got[False], got[True]
+        res[exchange] = dict(same_metrics=a[0] == b[0], same_weights=all(torch.equal(a[1][k], b[1][k]) for k in a[1]),
+                             same_moments=bool(torch.equal(a[2], b[2]) and torch.equal(a[3], b[3])),
+                             same_counts=(a[4], a[5]) == (b[4], b[5]), span_calls=b[6], per_step_span_calls=a[6])
+    torch.save(res, os.path.join(out_dir, 'dp_span.pt'))
+    torch.distributed.destroy_process_group()
+
+
+def test_data_parallel_span_leaves_the_bits_of_the_per_step_exchange(tmp_path):
+    import socket
+    import torch.multiprocessing as mp
+    from test_gpu_dist import _need_rccl
+    _need_rccl()
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_dp_span_worker, args=(1, port, str(tmp_path)), nprocs=1, join=True)
+    res = torch.load(os.path.join(tmp_path, 'dp_span.pt'))
+    for exchange in ('allreduce', 'gather'):
+        r = res[exchange]
+        assert r['span_calls'] >= 2 * (46 // 9) and r['per_step_span_calls'] == 0, r
+        assert r['same_metrics'] and r['same_weights'] and r['same_moments'] and r['same_counts'], (exchange, r)
