@@ -731,8 +731,8 @@ def run(args, env, is_leg=False):
         # and that idle time is inside the region -- 35-75 us of a 2 ms one, tools: bench.py --step-events)
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         fence()
-        t0 = time.perf_counter()
-        ev0.record()                                         # (torch's current stream = the one every launch goes to)
+        ev0.record()                                         # (torch's current stream = the one every launch goes to; the device
+        t0 = time.perf_counter()                             # is idle behind the fence: recorded before the clock starts, 4 us of host time)
         # sampled kernel timing: every 20th step (an instrumented step costs ~30 us more: its HIP events
         # carry release fences, and without them the spans stop agreeing with rocprofv3's kernel
         # durations -- measured: 56.0 vs 59.4 us for the GEMM), or -- short regions, where two
