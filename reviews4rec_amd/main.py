@@ -10,6 +10,9 @@ batch, main.py:57), and ``optimizer`` is this package's fused Adam (same surface
 ``hyper_params['engine']`` (default 'auto'): models with a fused native step (DeepCoNN 'deepconn' and
 'deepconn++', NARRE, TransNet(++), MF_dot, bias_only) run the whole sequence as one native call per batch; the others run the
 op-by-op step captured once into a hipGraph and replayed ('module' forces plain eager).
+``hyper_params['spans']`` (default True): with a native engine and this package's device-side loader the epoch's full
+batches are enqueued K = 64 steps per host call from C (engine._Spans, include/r4r.h "Spans": the batch construction and
+the native step; the same kernels, arguments and bits as the per-batch loop below, which False restores).
 
 TransNet's three-optimiser step (main.py:35-53) raises on torch >= 1.5 in the
 reference; ``train`` restates its torch-0.4 behaviour: the three
