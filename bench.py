@@ -182,20 +182,24 @@ def tower_flops_per_doc(hp):
 
 def walked_positions(tokens):
     """(positions the gather-add-max launch walks, positions in all) for the documents `tokens` [..., T]: the launch
-    cuts the T + 2 conv positions of a document into slices of 32; a slice whose tokens p_lo - 2 .. p_hi - 1 all name
-    the same row (out-of-range tokens count as a row of their own) is decided by its first position
-    (csrc/project.hip, proj_gather_max_kernel: `same`, `npos_eff`)."""
+    cuts the T + 2 conv positions of a document into segments of 128 and every segment into four EQUAL slices (32
+    positions; ceil(len / 4) in a shorter segment: NARRE's 102-position review, a 1000-word document's last 106); a slice
+    whose tokens p_lo - 2 .. p_hi - 1 all name the same row (out-of-range tokens count as a row of their own) is decided
+    by its first position (csrc/project.hip, proj_gather_max_kernel: `slen`, `same`, `npos_eff`)."""
     tok = np.asarray(tokens).reshape(-1, np.asarray(tokens).shape[-1])
     n, T = tok.shape
     P = T + 2
     ext = np.full((n, T + 4), -1, dtype=np.int64)           # ext[:, t + 2] = token t; t = -2, -1, T, T + 1 are out of range
     ext[:, 2:T + 2] = tok
     walked = 0
-    for p_lo in range(0, P, 32):
-        p_hi = min(P, p_lo + 32)
-        sl = ext[:, p_lo:p_hi + 2]                           # tokens p_lo - 2 .. p_hi - 1
-        same = (sl == sl[:, :1]).all(axis=1)
-        walked += int(np.where(same, 1, p_hi - p_lo).sum())
+    for seg_lo in range(0, P, 128):
+        seg_hi = min(P, seg_lo + 128)
+        slen = 32 if seg_hi - seg_lo == 128 else -(-(seg_hi - seg_lo) // 4)
+        for p_lo in range(seg_lo, seg_hi, slen):
+            p_hi = min(seg_hi, p_lo + slen)
+            sl = ext[:, p_lo:p_hi + 2]                       # tokens p_lo - 2 .. p_hi - 1
+            same = (sl == sl[:, :1]).all(axis=1)
+            walked += int(np.where(same, 1, p_hi - p_lo).sum())
     return walked, n * P
 
 

@@ -1286,8 +1286,18 @@ __global__ __launch_bounds__(256) void proj_gather_max_kernel(ProjArgs a) {
         tw.count[0] = 0;
     }
 
-    const int p_lo = seg * SEG + (worker % GWPS) * SLICE;
-    const int p_hi = min(P, p_lo + SLICE);
+    // A segment's positions are dealt to its GWPS workers in EQUAL slices: a full 128-position segment in slices of 32, a
+    // shorter one -- NARRE's whole 102-position review, the 106-position last segment of a 1000-word document -- in slices of
+    // ceil(len / GWPS) (26, 27), so that its last worker does not sit on 6 positions while the others walk 32 in five
+    // dependent rounds (four now).  Which positions a slice holds changes nothing downstream: the slices are merged in
+    // position order.
+#ifndef R4R_GATHER_EVEN_SLICES
+#define R4R_GATHER_EVEN_SLICES 1
+#endif
+    const int seg_len = min(SEG, P - seg * SEG);
+    const int slen = (R4R_GATHER_EVEN_SLICES && seg_len > 0 && seg_len < SEG) ? (seg_len + GWPS - 1) / GWPS : SLICE;
+    const int p_lo = seg * SEG + (worker % GWPS) * slen;
+    const int p_hi = min(min(P, (seg + 1) * SEG), p_lo + slen);
     const int t_lo = p_lo - 2;
     const int ntok = (seg < a.tiles && p_hi > p_lo) ? p_hi - t_lo : 0;     // tokens t_lo .. p_hi-1
     // stage the slice's slots; at the same time find out whether all its tokens are the SAME row

@@ -55,19 +55,26 @@ def test_more_ranks_than_gpus_is_one_clear_line(monkeypatch):
 
 
 def _walked_by_the_kernels_rule(doc):
-    """proj_gather_max_kernel, one document: slices of 32 positions over P = T + 2; tokens p_lo - 2 .. p_hi - 1; a token
-    outside [0, T) has slot -1; all slots equal -> one position walked."""
+    """proj_gather_max_kernel, one document: P = T + 2 positions in segments of 128, a segment dealt to four workers in
+    equal slices (32 positions of a full segment, ceil(len / 4) of a shorter one); a worker's tokens are p_lo - 2 ..
+    p_hi - 1; a token outside [0, T) has slot -1; all slots equal -> one position walked."""
     T = len(doc)
     P = T + 2
     walked = 0
-    for p_lo in range(0, P, 32):
-        p_hi = min(P, p_lo + 32)
-        slots = [int(doc[t]) if 0 <= t < T else -1 for t in range(p_lo - 2, p_hi)]
-        walked += 1 if len(set(slots)) == 1 else p_hi - p_lo
+    for seg in range((P + 127) // 128):
+        seg_len = min(128, P - seg * 128)
+        slen = 32 if seg_len == 128 else (seg_len + 3) // 4
+        for worker in range(4):
+            p_lo = seg * 128 + worker * slen
+            p_hi = min(min(P, (seg + 1) * 128), p_lo + slen)
+            if p_hi <= p_lo:
+                continue
+            slots = [int(doc[t]) if 0 <= t < T else -1 for t in range(p_lo - 2, p_hi)]
+            walked += 1 if len(set(slots)) == 1 else p_hi - p_lo
     return walked
 
 
-@pytest.mark.parametrize('T', [100, 126, 1000])
+@pytest.mark.parametrize('T', [100, 126, 127, 250, 1000])
 def test_walked_positions_follow_the_kernels_slice_rule(T):
     rng = np.random.default_rng(T)
     docs = rng.integers(1, 50, size=(6, T))
