@@ -52,10 +52,15 @@ def step_or_nothing(fn):
     @functools.wraps(fn)
     def wrapped(self, *args, **kw):
         before = self.step_count
+        self._step_launched = False                          # set by the engine once the step's first launch is enqueued
         try:
             return fn(self, *args, **kw)
         except BaseException:
-            self.step_count = before
+            # (a step that raises AFTER it enqueued work -- a later buffer of the data-parallel exchange that does not
+            # fit, a C argument check of a later call -- has consumed its number: the dense parameters may already
+            # carry update N, and a retry under the same number would apply it twice)
+            if not self._step_launched:
+                self.step_count = before
             raise
     return wrapped
 
@@ -580,6 +585,7 @@ class DeepCoNNEngine(_ConvRule, _Spans):
             ptr(self.flat_m) if adam_step else None, ptr(self.flat_v) if adam_step else None,
             self.lr, self.betas[0], self.betas[1], self.eps, self.wd, int(adam_step), main.cuda_stream)
         _lib.check(rc, 'r4r_deepconn_step')
+        self._step_launched = True
         if nxt is not None:
             self._prepared = (self._key(nxt[0], nxt[1], n), buf ^ 1, None, nxt)
         self._last_buf = buf
@@ -1003,6 +1009,7 @@ class MFEngine(_SweepSchedule, _Spans):
             self.lr, self.betas[0], self.betas[1], self.eps, self.wd, int(adam_step),
             _lib.current_stream())
         _lib.check(rc, 'r4r_mf_step')
+        self._step_launched = True
         if adam_step:
             self._scheduled(sweep_all, want, int(adam_step))
         if train_mode and float(self.hp['dropout']) > 0.0:
@@ -1095,6 +1102,7 @@ class MFEngine(_SweepSchedule, _Spans):
                 self.lr, self.betas[0], self.betas[1], self.eps, self.wd, step,
                 peer._dst[par].data_ptr(), peer._flg.data_ptr(), peer.local.data_ptr(), peer.rank, world, epoch,
                 _lib.current_stream()), 'r4r_mf_grad_push')
+            self._step_launched = True
             _lib.check(lib.r4r_mf_apply_peer(
                 peer.gathered[par], world, B_pad, self._ptrs(self.params), self._ptrs(self.m), self._ptrs(self.v),
                 self.n_users, self.n_items, self.D, ptr(ws), ws.numel(), period, base, sweep_all, ptr(se), n, ptr(self.sse),
@@ -1109,6 +1117,7 @@ class MFEngine(_SweepSchedule, _Spans):
                                    ptr(ws) if pending else None, period, base,
                                    self.lr, self.betas[0], self.betas[1], self.eps, self.wd, step,
                                    _lib.current_stream()), 'r4r_mf_grad')
+        self._step_launched = True
         self.dp.all_gather(blocks, block)
         _lib.check(lib.r4r_mf_apply(ptr(blocks), world, B_pad, self._ptrs(self.params), self._ptrs(self.m),
                                     self._ptrs(self.v), self.n_users, self.n_items, self.D, ptr(ws), ws.numel(),
@@ -1385,6 +1394,7 @@ class NarreEngine(_ConvRule, _Spans):
             buf = self._last_buf ^ 1
         rc = self._step(f, y, pred, se, ws, n, R, T, train_mode, inv_denom, adam_step, buf, ready, nxt)
         _lib.check(rc, 'r4r_%s_step' % self.C)
+        self._step_launched = True
         self._last_buf = buf
         if nxt is not None:
             self._prepared = (tuple(t.data_ptr() for t in nxt[:self.NTOWER]) + (n, R, T), buf ^ 1, nxt)
@@ -2208,6 +2218,7 @@ class IdNetEngine(_SweepSchedule, _Spans):
             int(train_mode), self.seed, self.offset, float(inv_denom), period, base, sweep_all,
             self.lr, self.betas[0], self.betas[1], self.eps, self.wd, int(adam_step), _lib.current_stream())
         _lib.check(rc, 'r4r_idnet_step')
+        self._step_launched = True
         if train_mode and float(self.hp['dropout']) > 0.0:
             self.offset += n * self.draws()
         return pred, se

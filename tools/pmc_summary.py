@@ -46,6 +46,7 @@ def main(root, out, note=''):
         k = {c: round(v / n, 3) for c, (v, n, _) in d.items()}
         durs = [us / n for _, (v, n, us) in d.items()]
         k['avg_duration_us_under_pmc'] = round(sum(durs) / len(durs), 2)
+        k['launches_under_pmc'] = max(n for _, (v, n, us) in d.items())      # per counter pass (a one-off flush launch: 1)
         if 'FETCH_SIZE' in k and 'WRITE_SIZE' in k:
             hbm_bytes(kn, k)
         if 'SQ_VALU_MFMA_BUSY_CYCLES' in k and 'GRBM_GUI_ACTIVE' in k and k['GRBM_GUI_ACTIVE']:
