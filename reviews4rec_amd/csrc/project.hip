@@ -1059,7 +1059,15 @@ constexpr int WR_THREADS = 512, WR_WAVES = WR_THREADS / 64;
 constexpr int WR_MAX_CHUNKS = 8;                       // 304 rows x (128 + 4) floats = 160,512 B
 constexpr int WR_NQ = (PNT + 3) / 4;                   // 5 column quads (the last one: 3 tiles)
 __host__ __device__ constexpr int wr_stride(int nch) { return nch * PEC + 4; }
-__host__ __device__ constexpr int wr_lds_bytes(int nch) { return PN * wr_stride(nch) * 4; }
+// LDS rows of the weight image: the 300 real ones only.  Rows 300 .. 303 (N padded to 19 tiles of 16) are read by lanes
+// whose outputs are never stored -- they read row 299 instead -- and without them the image of a table of E <= 64 is
+// 81,600 B: TWO workgroups per CU (2 x 81,920 allocated = the CU's 160 KB), four waves per SIMD instead of two.
+#ifndef R4R_WRES_ROWS
+#define R4R_WRES_ROWS PROW
+#endif
+constexpr int WR_ROWS = R4R_WRES_ROWS;
+__host__ __device__ constexpr int wr_lds_bytes(int nch) { return WR_ROWS * wr_stride(nch) * 4; }
+__host__ __device__ constexpr int wr_wgs_per_cu(int nch) { return 2 * wr_lds_bytes(nch) <= 160 * 1024 - 2 * 256 ? 2 : 1; }
 
 template <int NCH>
 __global__ __launch_bounds__(WR_THREADS) void proj_gemm_wres_kernel(ProjArgs a) {
@@ -1161,7 +1169,7 @@ __global__ __launch_bounds__(WR_THREADS) void proj_gemm_wres_kernel(ProjArgs a) 
         f32x4 v;
 #pragma unroll
         for (int c = 0; c < 4; ++c) v[c] = wreal[k] ? wv[k][c] : 0.f;
-        if (i < PN * SLOTS) *reinterpret_cast<f32x4 *>(lds + n * STR + sl * 4) = v;
+        if (i < PN * SLOTS && n < WR_ROWS) *reinterpret_cast<f32x4 *>(lds + n * STR + sl * 4) = v;
     }
     if (has_units) {
         const f32x4 z = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -1171,6 +1179,7 @@ __global__ __launch_bounds__(WR_THREADS) void proj_gemm_wres_kernel(ProjArgs a) 
     }
     __syncthreads();                                         // the weights are in LDS: the waves run free from here
     const float *bl = lds + lrow * STR + q * 4;
+    const float *blast = lds + min((PNT - 1) * 16 + lrow, WR_ROWS - 1) * STR + q * 4;   // the last column tile's rows
     auto unit = [&](int uu, f32x4 (&slot)[NCH], int &tok) {
         f32x4 cur[NCH];
 #pragma unroll
@@ -1201,7 +1210,8 @@ __global__ __launch_bounds__(WR_THREADS) void proj_gemm_wres_kernel(ProjArgs a) 
             for (int c = 0; c < NCH; ++c) {
                 f32x4 b[3];
 #pragma unroll
-                for (int i = 0; i < 3; ++i) b[i] = *reinterpret_cast<const f32x4 *>(bu + i * 16 * STR + c * PEC);
+                for (int i = 0; i < 2; ++i) b[i] = *reinterpret_cast<const f32x4 *>(bu + i * 16 * STR + c * PEC);
+                b[2] = *reinterpret_cast<const f32x4 *>(blast + c * PEC);       // (rows 300 .. 303: row 299's, never stored)
 #pragma unroll
                 for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
@@ -1502,7 +1512,12 @@ int textcnn_proj_compute_launch(const float *table, int64_t V, const ProjTower *
     } else if (a.balanced == 4) {
         // one workgroup per CU at most; fewer when the row capacity is small (a workgroup's 8 waves take 8 units per round)
         int64_t wgs = ((int64_t)a.cap + 15) / 16 * WR_NQ / WR_WAVES + ntower;
-        if (wgs > G7_WGS) wgs = G7_WGS;
+        // two workgroups per CU where the weight image leaves room AND the launch is long enough to pay for a second
+        // 78 KB fill per CU (by row capacity: a million-word vocabulary -- cfg5 46.3 -> 43.9 us, its full / uniform point
+        // 174 -> 158; at a 50 k-word vocabulary, three units per wave, the second fill costs more than the occupancy buys:
+        // cfg4 16.4 -> 18.6 us; profiles/r06_ab_wres2.txt)
+        const int64_t resident = (int64_t)G7_WGS * (wgs >= 8 * G7_WGS ? wr_wgs_per_cu(a.nchunk) : 1);
+        if (wgs > resident) wgs = resident;
         if (wgs < ntower) wgs = ntower;
         wres_launch(a, (unsigned)wgs, st);
     } else {
