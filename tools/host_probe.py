@@ -1,5 +1,6 @@
 """Host-side cost per step of the training loop's pieces (enqueue time, no device sync inside the loops): the loader's
-batch iterator, the native engine's train_step, both.  python tools/host_probe.py [--model-type deepconn]"""
+batch iterator, the native engine's train_step, both through main.train -- per batch (hyper_params['spans'] = False) and
+through the span entry points (the default).  python tools/host_probe.py [--model-type deepconn] [--embed 300]"""
 import argparse, os, sys, time
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -34,10 +35,13 @@ for _ in range(2):
         engine.train_step(data, y, n_global=128, next_data=keep[(i + 1) % 64][0])
     t1 = time.perf_counter(); torch.cuda.synchronize(); t2 = time.perf_counter()
     print('engine only: host %.1f us per step, with drain %.1f' % ((t1 - t0) * 1e6 / nb, (t2 - t0) * 1e6 / nb))
-    torch.cuda.synchronize(); t0 = time.perf_counter()
-    M.train(model, None, None, train, hp, engine=engine)
-    torch.cuda.synchronize(); t2 = time.perf_counter()
-    print('main.train : %.1f us per step' % ((t2 - t0) * 1e6 / nb))
+    for spans in (False, True):
+        hp['spans'] = spans
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        M.train(model, None, None, train, hp, engine=engine)
+        t1 = time.perf_counter(); torch.cuda.synchronize(); t2 = time.perf_counter()
+        print('main.train, %s: host %.1f us per step, with drain %.1f' % ('spans (K steps per host call)' if spans else 'per-batch loop',
+                                                                           (t1 - t0) * 1e6 / nb, (t2 - t0) * 1e6 / nb))
 import cProfile, pstats
 pr = cProfile.Profile(); pr.enable()
 M.train(model, None, None, train, hp, engine=engine)
