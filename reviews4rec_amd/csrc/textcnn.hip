@@ -319,8 +319,14 @@ int textcnn_wgrad_splits(int64_t N) {
         docs = e ? atoi(e) : 16;
         if (docs < 1) docs = 16;
     }
+    static int cap = -1;
+    if (cap < 0) {
+        const char *e = getenv("R4R_WGRAD_MAX_SPLITS");
+        cap = e ? atoi(e) : 16;
+        if (cap < 1) cap = 16;
+    }
     int s = (int)cdiv(N, docs);
-    if (s > 16) s = 16;
+    if (s > cap) s = cap;
     if (s < 1) s = 1;
     return s;
 }
