@@ -102,11 +102,14 @@ def same(a, b, what):
 FAMILIES = ['deepconn', 'deepconn++', 'NARRE', 'transnet', 'transnet++', 'MF_dot', 'bias_only', 'MF']
 
 
-@pytest.mark.parametrize('mt', FAMILIES)
+@pytest.mark.parametrize('mt', FAMILIES + ['NeuMF/GMF', 'NeuMF/MLP', 'NeuMF/NeuMF'])
 def test_span_epochs_leave_the_bits_of_the_per_step_loop(mt):
     corpus = tiny_corpus()
-    want_m, want_w, want_o, _, _ = run_epochs(mt, corpus, spans=False)
-    got_m, got_w, got_o, calls, engine = run_epochs(mt, corpus, spans=True, span_steps=7)
+    kw = {}
+    if '/' in mt:                                            # the three stage models of main_NeuMF (NeuMF.py), one engine variant each
+        mt, kw['neumf_stage'] = mt.split('/')
+    want_m, want_w, want_o, _, _ = run_epochs(mt, corpus, spans=False, **kw)
+    got_m, got_w, got_o, calls, engine = run_epochs(mt, corpus, spans=True, span_steps=7, **kw)
     assert calls['span'] >= 2 * (46 // 7), calls               # the epoch really went through the span entry
     assert calls['step'] <= 2 * 3, calls                       # ... but for the ragged tail and the rule's probes
     assert got_m == want_m
